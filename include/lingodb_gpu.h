@@ -1,0 +1,325 @@
+/*
+ * lingodb_gpu.h — C-ABI of liblingodb_gpu.so, the MI355X (gfx950) relational-operator
+ * runtime that replaces LingoDB's CPU sub-operator hot path.
+ *
+ * Granularity: one call per `subop.execution_step` building block (the unit handled by
+ * handleExecutionStepCPU, reference src/compiler/Conversion/SubOpToControlFlow/
+ * SubOpToControlFlow.cpp:4363).  The reference exposes its runtime to JIT'd code as
+ * Itanium-mangled C++ methods taking host function pointers (eq/combine/cmp callbacks,
+ * include/lingodb/runtime/ headers); host callbacks cannot cross to the device, so every
+ * callback is replaced by a declarative descriptor (ldb_filter_desc, ldb_expr,
+ * ldb_agg_spec, ldb_sort_spec) that the device kernels evaluate.
+ *
+ * Conventions
+ *   - every function returns LDB_OK (0) or a negative ldb_status; the message is
+ *     available per-thread from ldb_gpu_last_error().  No C++ exception crosses the ABI.
+ *     (Reference behaviour being replaced: std::runtime_error / assert / exit(1),
+ *     src/execution/Execution.cpp:252-271.)
+ *   - handles are opaque; the library owns all device memory until the matching
+ *     *_release / ldb_gpu_ctx_destroy (reference: ExecutionContext::registerState,
+ *     include/lingodb/runtime/ExecutionContext.h:111).
+ *   - all work of one ctx is issued on ONE HIP stream (own, or caller supplied);
+ *     calls are asynchronous unless they return host-visible counts.
+ *   - row ids are uint32 (≤ 4 294 967 294 rows per GPU-resident table fragment).
+ *   - plain pointers and sizes only; no torch / Arrow C++ types in any signature.
+ */
+#ifndef LINGODB_GPU_H
+#define LINGODB_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Arrow C Data Interface (public, stable ABI; https://arrow.apache.org/docs/format/CDataInterface.html) */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+#define ARROW_FLAG_DICTIONARY_ORDERED 1
+#define ARROW_FLAG_NULLABLE 2
+#define ARROW_FLAG_MAP_KEYS_SORTED 4
+struct ArrowSchema {
+   const char* format;
+   const char* name;
+   const char* metadata;
+   int64_t flags;
+   int64_t n_children;
+   struct ArrowSchema** children;
+   struct ArrowSchema* dictionary;
+   void (*release)(struct ArrowSchema*);
+   void* private_data;
+};
+struct ArrowArray {
+   int64_t length;
+   int64_t null_count;
+   int64_t offset;
+   int64_t n_buffers;
+   int64_t n_children;
+   const void** buffers;
+   struct ArrowArray** children;
+   struct ArrowArray* dictionary;
+   void (*release)(struct ArrowArray*);
+   void* private_data;
+};
+#endif
+
+typedef struct ldb_ctx ldb_ctx;
+typedef struct ldb_table ldb_table; /* device-resident columnar table (one buffer per column) */
+typedef struct ldb_rel ldb_rel; /* late-materialised relation: n rows over 1..LDB_MAX_SIDES tables */
+typedef struct ldb_hashtable ldb_hashtable; /* join hash table (replaces HashIndexedView) */
+
+typedef enum {
+   LDB_OK = 0,
+   LDB_ERR_INVALID = -1, /* bad argument / descriptor */
+   LDB_ERR_UNSUPPORTED = -2, /* legal in the reference but not implemented on the device yet */
+   LDB_ERR_OOM = -3,
+   LDB_ERR_HIP = -4, /* HIP runtime error; text in ldb_gpu_last_error() */
+   LDB_ERR_NO_DEVICE = -5
+} ldb_status;
+
+/* Physical column types = the Arrow physical types LingoDB stores
+ * (toPhysicalType, reference src/runtime/storage/LingoDBTable.cpp:122-195). */
+typedef enum {
+   LDB_T_INT8 = 0,
+   LDB_T_INT16 = 1,
+   LDB_T_INT32 = 2,
+   LDB_T_INT64 = 3,
+   LDB_T_DATE32 = 4, /* days since epoch; hashed/compared as ns where the reference does */
+   LDB_T_DECIMAL128 = 5, /* 16 B little-endian two's complement, (precision, scale) */
+   LDB_T_CHAR4 = 6, /* fixed_size_binary(4) = char(1) */
+   LDB_T_UTF8 = 7, /* int64 offsets on device + bytes */
+   LDB_T_FLOAT64 = 8,
+   LDB_T_FLOAT32 = 9,
+   LDB_T_BOOL8 = 10 /* one byte per value (device-side results only) */
+} ldb_type;
+
+typedef struct {
+   int32_t type; /* ldb_type */
+   int32_t precision; /* decimals */
+   int32_t scale;
+   int32_t nullable;
+} ldb_coltype;
+
+/* Column reference inside a relation: table `side` of the relation, column index in it. */
+typedef struct {
+   int32_t side;
+   int32_t col;
+} ldb_colref;
+
+#define LDB_MAX_SIDES 6
+#define LDB_NULL_ROW 0xFFFFFFFFu /* build-side row id of an unmatched outer-join row */
+
+/* ------------------------------------------------------------------ context */
+/* Replaces ExecutionContext + scheduler worker set (reference ExecutionContext.h:62-127,
+ * scheduler/Scheduler.h:29-42).  `stream` = an existing hipStream_t to issue on, or NULL
+ * for a private stream. */
+int32_t ldb_gpu_ctx_create(int32_t device_id, void* stream, ldb_ctx** out);
+int32_t ldb_gpu_ctx_destroy(ldb_ctx* ctx);
+int32_t ldb_gpu_ctx_sync(ldb_ctx* ctx);
+const char* ldb_gpu_last_error(void);
+/* device properties: name (gfx950 expected), CUs, HBM bytes free/total */
+int32_t ldb_gpu_device_info(ldb_ctx* ctx, char* name, int32_t name_cap, int32_t* cus, int64_t* hbm_free, int64_t* hbm_total);
+
+/* HIP-event timing on the ctx stream (bench.py must time on the stream the kernels run on). */
+int32_t ldb_gpu_timer_create(ldb_ctx* ctx, int32_t* timer_id);
+int32_t ldb_gpu_timer_start(ldb_ctx* ctx, int32_t timer_id);
+int32_t ldb_gpu_timer_stop(ldb_ctx* ctx, int32_t timer_id);
+int32_t ldb_gpu_timer_elapsed_ms(ldb_ctx* ctx, int32_t timer_id, float* ms); /* syncs on the stop event */
+
+/* ------------------------------------------------------------------ tables (a1) */
+/* Replaces LingoDBTable::ensureLoaded + TableChunk flattening (LingoDBTable.cpp:27-54,
+ * 200-225).  `schema` is a struct schema (format "+s"); each batch a struct array whose
+ * children's buffers are exactly ArrayView.buffers[0..2].  Batches are concatenated per
+ * column into one device buffer.  narrow_decimals != 0 stores decimal128(p<19) as int64
+ * on the device (the width the generated code truncates to anyway, LowerToStd.cpp:128-132). */
+int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct ArrowSchema* schema,
+                               struct ArrowArray** batches, int64_t n_batches, int32_t narrow_decimals,
+                               ldb_table** out);
+/* Allocate an uninitialised device table (generator / shuffle receive side).
+ * utf8 columns: data_bytes[i] = byte capacity of column i (ignored for fixed width). */
+int32_t ldb_gpu_table_alloc(ldb_ctx* ctx, const char* name, int32_t n_cols, const ldb_coltype* types,
+                            const char* const* col_names, int64_t n_rows, const int64_t* data_bytes,
+                            int32_t narrow_decimals, ldb_table** out);
+int32_t ldb_gpu_table_release(ldb_ctx* ctx, ldb_table* t); /* == evict */
+int64_t ldb_gpu_table_rows(const ldb_table* t);
+int32_t ldb_gpu_table_cols(const ldb_table* t);
+int32_t ldb_gpu_table_coltype(const ldb_table* t, int32_t col, ldb_coltype* out);
+int32_t ldb_gpu_table_col_index(const ldb_table* t, const char* name); /* -1 if absent */
+const char* ldb_gpu_table_col_name(const ldb_table* t, int32_t col);
+/* width in bytes of one value as resident on the device (8 for narrowed decimals) */
+int32_t ldb_gpu_table_col_width(const ldb_table* t, int32_t col);
+/* raw device pointers (for RCCL exchange / zero-copy wrap); offsets/validity may be NULL */
+int32_t ldb_gpu_table_col_ptrs(const ldb_table* t, int32_t col, void** values, void** offsets, void** validity,
+                               int64_t* value_bytes);
+/* shrink the logical row count (receive buffers allocated at capacity) */
+int32_t ldb_gpu_table_set_rows(ldb_table* t, int64_t n_rows);
+/* blocking D2H copy of a fixed-width column's values (n_rows * width bytes) */
+int32_t ldb_gpu_table_read_fixed(ldb_ctx* ctx, const ldb_table* t, int32_t col, void* host_out, int64_t out_bytes);
+/* blocking H2D copy into a fixed-width column */
+int32_t ldb_gpu_table_write_fixed(ldb_ctx* ctx, ldb_table* t, int32_t col, const void* host_in, int64_t in_bytes);
+
+/* Replaces result materialisation into Arrow builders (a15: MaterializeTableLowering,
+ * SubOpToControlFlow.cpp:984-1004; ArrowColumnBuilder, ArrowColumn.h:15-37).  Fills a struct
+ * ArrowArray + ArrowSchema with host copies in the reference's physical types (narrowed
+ * decimals are sign-extended back to 128 bit, LowerToStd.cpp:211-298).  Caller releases. */
+int32_t ldb_gpu_export(ldb_ctx* ctx, const ldb_table* t, struct ArrowSchema* out_schema, struct ArrowArray* out_array);
+
+/* ------------------------------------------------------------------ relations */
+int32_t ldb_gpu_rel_from_table(ldb_ctx* ctx, const ldb_table* t, ldb_rel** out); /* identity rows */
+int32_t ldb_gpu_rel_release(ldb_ctx* ctx, ldb_rel* r);
+int64_t ldb_gpu_rel_rows(ldb_ctx* ctx, ldb_rel* r); /* syncs if the count is still on the device */
+int32_t ldb_gpu_rel_sides(const ldb_rel* r);
+/* blocking D2H of the row-id vector of one side (NULL row ids = identity → fills 0..n-1) */
+int32_t ldb_gpu_rel_read_rowids(ldb_ctx* ctx, ldb_rel* r, int32_t side, uint32_t* host_out, int64_t cap);
+/* gather the listed columns into a dense device table (late materialisation) */
+int32_t ldb_gpu_materialize(ldb_ctx* ctx, ldb_rel* r, const ldb_colref* cols, int32_t n_cols, ldb_table** out);
+
+/* ------------------------------------------------------------------ scan + filter (a2, a3, a4) */
+/* FilterOp mirrors lingodb::runtime::FilterOp (include/lingodb/runtime/storage/TableStorage.h:14-24). */
+typedef enum { LDB_F_EQ = 0, LDB_F_NEQ = 1, LDB_F_LT = 2, LDB_F_LTE = 3, LDB_F_GT = 4, LDB_F_GTE = 5, LDB_F_NOTNULL = 6, LDB_F_IN = 7 } ldb_filter_op;
+typedef enum { LDB_RHS_INT = 0, LDB_RHS_STRING = 1, LDB_RHS_COLUMN = 2, LDB_RHS_FLOAT = 3 } ldb_rhs_kind;
+
+/* One conjunct.  Constants are already typed against the column (the host mirror of
+ * Restrictions::create, Restrictions.cpp:392-521, does date parsing / decimal rescaling):
+ *   ints, dates (days), char(1) (4 raw bytes as int32), decimals (unscaled at column scale)
+ *   travel as a 128-bit integer (value_lo, value_hi); strings as (str, str_len).
+ * rhs_kind = COLUMN compares two columns (residual predicates such as l_commitdate <
+ * l_receiptdate that the reference evaluates in generated code). */
+typedef struct {
+   ldb_colref col;
+   int32_t op; /* ldb_filter_op */
+   int32_t rhs_kind; /* ldb_rhs_kind */
+   uint64_t value_lo;
+   int64_t value_hi;
+   double value_f64;
+   const char* str;
+   int32_t str_len;
+   ldb_colref rhs_col;
+   /* IN lists: n_in constants; ints as lo/hi pairs (2*n_in words), strings as pointers+lengths */
+   int32_t n_in;
+   const int64_t* in_values;
+   const char* const* in_strs;
+   const int32_t* in_str_lens;
+} ldb_filter_desc;
+
+/* Replaces ScanBatchesTask::unitRun + Restrictions::applyFilters (LingoDBTable.cpp:382-407,
+ * Restrictions.cpp:365-390): conjunction evaluated in descriptor order; the result relation
+ * holds the passing rows in ascending row order (the order of the reference's selection
+ * vectors inside a morsel, morsels in table order). */
+int32_t ldb_gpu_scan_filter(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds, int32_t n_preds, ldb_rel** out);
+/* count only (no selection written) */
+int32_t ldb_gpu_scan_count(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds, int32_t n_preds, int64_t* count);
+
+/* ------------------------------------------------------------------ hash (a5) */
+/* db.hash over the key columns, bit-identical to HashLowering (LowerToStd.cpp:1065-1152) +
+ * Hash64/HashCombine/VarLenTryCheapHash (LowerToLLVM.cpp:372-391,493-524).
+ * Output: a 1-column LDB_T_INT64 device table (`hash`). */
+int32_t ldb_gpu_hash_keys(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* keys, int32_t n_keys, ldb_table** out);
+
+/* ------------------------------------------------------------------ expressions (a16) */
+/* Integer/decimal expression in sum-of-products normal form:
+ *     value = Σ_t sign_t * ( Π_f (a_f + b_f * col_f) ) / 10^div_pow10_t      (128-bit, wrapping)
+ * which is what the reference's decimal lowerings reduce to once the frontend has fixed the
+ * scales: DecimalMulOpLowering = integer multiply (+ truncating divide when the result scale
+ * was clamped, LowerToStd.cpp:653-677), add/sub = integer add after common-scale casts
+ * (:680-699), int→decimal(19,0) casts = multiply by 10^k (folded into a/b). */
+#define LDB_MAX_FACTORS 3
+#define LDB_MAX_TERMS 2
+typedef struct {
+   int32_t has_col;
+   ldb_colref col;
+   int64_t a;
+   int64_t b;
+} ldb_factor;
+typedef struct {
+   int32_t n_factors;
+   int32_t negate;
+   int32_t div_pow10;
+   int32_t reserved;
+   ldb_factor f[LDB_MAX_FACTORS];
+} ldb_term;
+typedef struct {
+   int32_t n_terms;
+   int32_t is_float; /* 1: evaluate the same form in f64 (float/double columns) */
+   ldb_term t[LDB_MAX_TERMS];
+} ldb_expr;
+
+/* ------------------------------------------------------------------ group-by (a9, a10, a11, a14) */
+typedef enum { LDB_AGG_SUM = 0, LDB_AGG_MIN = 1, LDB_AGG_MAX = 2, LDB_AGG_COUNT = 3, LDB_AGG_COUNT_STAR = 4, LDB_AGG_ANY = 5, LDB_AGG_AVG = 6 } ldb_agg_fn;
+#define LDB_MAX_AGG_PREDS 3
+typedef struct {
+   int32_t fn; /* ldb_agg_fn */
+   int32_t wide; /* 1: accumulate/emit as 128-bit (decimal p>=19), 0: int64 (SUM type = arg type, sql_analyzer.cpp:2631) */
+   ldb_expr arg;
+   /* conditional aggregate: sum(case when <preds> then arg else 0 end) */
+   int32_t n_preds;
+   ldb_filter_desc preds[LDB_MAX_AGG_PREDS];
+   /* AVG = (SUM * 10^avg_pow10) sdiv COUNT in 128 bit (DecimalOpScaledLowering, LowerToStd.cpp:631-651) */
+   int32_t avg_pow10;
+   /* result column type written to the output table: LDB_T_INT64 (COUNT, integer SUM),
+    * LDB_T_DECIMAL128 (out_precision, out_scale), LDB_T_DATE32 / LDB_T_INT32 / LDB_T_CHAR4
+    * (MIN/MAX/ANY of such columns), LDB_T_FLOAT64 */
+   int32_t out_type;
+   int32_t out_precision;
+   int32_t out_scale;
+   int32_t reserved;
+} ldb_agg_spec;
+
+/* Replaces PreAggregationHashtableFragment::insert + generated lookup/update
+ * (PreAggregationHashtable.cpp:46-60, SubOpToControlFlow.cpp:3065-3157, 3719-3768),
+ * PreAggregationHashtable::merge (:76-158), Hashtable (Hashtable.cpp) and, for n_keys == 0,
+ * SimpleState (SimpleState.cpp:8-30).  `preds` are fused into the same pass (the scan is not
+ * materialised).  Output table: key columns (input types) then one column per aggregate.
+ * Group order is unspecified (as in the reference).  est_groups: optimiser estimate, 0 = unknown. */
+int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds, int32_t n_preds,
+                        const ldb_colref* keys, int32_t n_keys, const ldb_agg_spec* aggs, int32_t n_aggs,
+                        int64_t est_groups, ldb_table** out);
+
+/* ------------------------------------------------------------------ hash join (a6, a7, a8) */
+typedef enum { LDB_JOIN_INNER = 0, LDB_JOIN_SEMI = 1, LDB_JOIN_ANTI = 2, LDB_JOIN_LEFT_OUTER = 3, LDB_JOIN_MARK = 4, LDB_JOIN_SINGLE = 5 } ldb_join_kind;
+
+/* Replaces GrowingBuffer::insert materialisation + HashIndexedView::build
+ * (GrowingBuffer.cpp:44, LazyJoinHashtable.cpp:12-34): builds an index over the rows of
+ * `build` keyed by `keys`.  No payload is copied (late materialisation: the table stores
+ * build row numbers).  build_unique != 0: keys are known unique (primary key). */
+int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_colref* keys, int32_t n_keys, int32_t build_unique,
+                           ldb_hashtable** out);
+int32_t ldb_gpu_hashtable_release(ldb_ctx* ctx, ldb_hashtable* ht);
+int64_t ldb_gpu_hashtable_slots(const ldb_hashtable* ht);
+/* Replaces LookupHashIndexedViewLowering + ScanListLowering (SubOpToControlFlow.cpp:2558-2586,
+ * 2254-2313).  Output relation: INNER / LEFT_OUTER / SINGLE → sides = probe sides then build sides,
+ * one row per match (LEFT_OUTER/SINGLE: unmatched probe rows carry LDB_NULL_ROW on build sides);
+ * SEMI / ANTI → probe sides only, ascending; MARK → probe sides, all rows, plus *mark_out =
+ * 1-column BOOL8 table.  NULL keys never match. */
+int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys,
+                           int32_t kind, ldb_rel** out, ldb_table** mark_out);
+/* count matches only — the probe micro-benchmark kernel (Grows/s) */
+int32_t ldb_gpu_join_probe_count(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys,
+                                 int64_t* matches);
+
+/* ------------------------------------------------------------------ sort / top-k (a12, a13) */
+typedef struct {
+   ldb_colref col;
+   int32_t descending;
+   int32_t reserved;
+} ldb_sort_spec;
+/* Replaces GrowingBuffer::sort / parallelSort (GrowingBuffer.cpp:54-78, Sorting.cpp:343-393)
+ * with comparator semantics of db.sort_compare (LowerToStd.cpp:1046-1064).  Stable w.r.t. input
+ * order among equal keys (the reference's std::sort leaves that order unspecified). */
+int32_t ldb_gpu_sort(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int32_t n_specs, ldb_rel** out);
+/* Replaces Heap (Heap.cpp:8-72): first k rows of the sorted order. */
+int32_t ldb_gpu_topk(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int32_t n_specs, int64_t k, ldb_rel** out);
+
+/* ------------------------------------------------------------------ multi-GPU shuffle (§8(e), new) */
+/* Hash-radix partition the listed columns of `in` into `nparts` destinations:
+ * dest = (db.hash(keys) >> 16) % nparts  (reference hash, so every GPU agrees).
+ * Output: a dense table whose rows are grouped by destination; counts[nparts] on the host.
+ * The exchange itself is an RCCL all-to-all on the column buffers (ldb_gpu_table_col_ptrs). */
+int32_t ldb_gpu_partition(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* keys, int32_t n_keys, int32_t nparts,
+                          const ldb_colref* cols, int32_t n_cols, ldb_table** out, int64_t* counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINGODB_GPU_H */

@@ -1,0 +1,843 @@
+// ldb_core.hip — context, device tables (Arrow C Data Interface in/out), relations, gather.
+// Replaces (reference): ExecutionContext (include/lingodb/runtime/ExecutionContext.h:62-127),
+// LingoDBTable::ensureLoaded + TableChunk flattening (src/runtime/storage/LingoDBTable.cpp:27-54,
+// 200-225) and result materialisation (ArrowColumnBuilder, include/lingodb/runtime/ArrowColumn.h:15-37).
+#include "ldb_device.h"
+#include <cstdlib>
+#include <memory>
+
+// ---------------------------------------------------------------- errors
+static thread_local char g_err[1024] = "";
+void ldb_set_error(const char* fmt, ...) {
+   va_list ap;
+   va_start(ap, fmt);
+   vsnprintf(g_err, sizeof(g_err), fmt, ap);
+   va_end(ap);
+}
+extern "C" const char* ldb_gpu_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------- memory
+int32_t ldb_dev_alloc(ldb_ctx* ctx, void** out, size_t bytes) {
+   if (bytes == 0) bytes = 16;
+   LDB_HIP(hipMallocAsync(out, bytes, ctx->stream));
+   return LDB_OK;
+}
+void ldb_dev_free(ldb_ctx* ctx, void* p) {
+   if (p) (void) hipFreeAsync(p, ctx->stream);
+}
+int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_out) {
+   LDB_TRY(ldb_dev_alloc(ctx, dev_out, bytes));
+   // pageable source: the runtime stages the bytes before returning, so `host` may be a local
+   LDB_HIP(hipMemcpyAsync(*dev_out, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+   return LDB_OK;
+}
+int32_t ldb_read_u64(ldb_ctx* ctx, const void* d_word, uint64_t* out) {
+   LDB_HIP(hipMemcpyAsync(ctx->h_scratch, d_word, 8, hipMemcpyDeviceToHost, ctx->stream));
+   LDB_HIP(hipStreamSynchronize(ctx->stream));
+   *out = (uint64_t) ctx->h_scratch[0];
+   return LDB_OK;
+}
+
+// ---------------------------------------------------------------- context
+extern "C" int32_t ldb_gpu_ctx_create(int32_t device_id, void* stream, ldb_ctx** out) {
+   if (!out) LDB_FAIL(LDB_ERR_INVALID, "ctx_create: out is NULL");
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess || n == 0) LDB_FAIL(LDB_ERR_NO_DEVICE, "no HIP device visible (liblingodb_gpu has no CPU fallback)");
+   if (device_id < 0 || device_id >= n) LDB_FAIL(LDB_ERR_INVALID, "device %d out of range (have %d)", device_id, n);
+   LDB_HIP(hipSetDevice(device_id));
+   auto ctx = std::make_unique<ldb_ctx>();
+   ctx->device = device_id;
+   if (stream) {
+      ctx->stream = (hipStream_t) stream;
+   } else {
+      LDB_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      ctx->own_stream = true;
+   }
+   hipDeviceProp_t prop;
+   LDB_HIP(hipGetDeviceProperties(&prop, device_id));
+   ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+   // keep freed blocks cached in the stream-ordered pool (operators allocate per call)
+   hipMemPool_t pool;
+   if (hipDeviceGetDefaultMemPool(&pool, device_id) == hipSuccess) {
+      uint64_t thr = UINT64_MAX;
+      (void) hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+   }
+   LDB_HIP(hipHostMalloc((void**) &ctx->h_scratch, 64 * sizeof(int64_t), hipHostMallocDefault));
+   LDB_HIP(hipMalloc((void**) &ctx->d_scratch, 64 * sizeof(int64_t)));
+   *out = ctx.release();
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_ctx_destroy(ldb_ctx* ctx) {
+   if (!ctx) return LDB_OK;
+   (void) hipSetDevice(ctx->device);
+   (void) hipStreamSynchronize(ctx->stream);
+   for (auto e : ctx->timers) (void) hipEventDestroy(e);
+   if (ctx->h_scratch) (void) hipHostFree(ctx->h_scratch);
+   if (ctx->d_scratch) (void) hipFree(ctx->d_scratch);
+   if (ctx->own_stream) (void) hipStreamDestroy(ctx->stream);
+   delete ctx;
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_ctx_sync(ldb_ctx* ctx) {
+   LDB_HIP(hipStreamSynchronize(ctx->stream));
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_device_info(ldb_ctx* ctx, char* name, int32_t name_cap, int32_t* cus, int64_t* hbm_free, int64_t* hbm_total) {
+   hipDeviceProp_t prop;
+   LDB_HIP(hipGetDeviceProperties(&prop, ctx->device));
+   if (name && name_cap > 0) snprintf(name, (size_t) name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+   if (cus) *cus = prop.multiProcessorCount;
+   size_t f = 0, t = 0;
+   LDB_HIP(hipMemGetInfo(&f, &t));
+   if (hbm_free) *hbm_free = (int64_t) f;
+   if (hbm_total) *hbm_total = (int64_t) t;
+   return LDB_OK;
+}
+
+extern "C" int32_t ldb_gpu_timer_create(ldb_ctx* ctx, int32_t* timer_id) {
+   hipEvent_t a, b;
+   LDB_HIP(hipEventCreate(&a));
+   LDB_HIP(hipEventCreate(&b));
+   *timer_id = (int32_t) (ctx->timers.size() / 2);
+   ctx->timers.push_back(a);
+   ctx->timers.push_back(b);
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_timer_start(ldb_ctx* ctx, int32_t id) {
+   if (id < 0 || (size_t) id * 2 + 1 >= ctx->timers.size() + 0) LDB_FAIL(LDB_ERR_INVALID, "bad timer id %d", id);
+   LDB_HIP(hipEventRecord(ctx->timers[(size_t) id * 2], ctx->stream));
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_timer_stop(ldb_ctx* ctx, int32_t id) {
+   if (id < 0 || (size_t) id * 2 + 1 >= ctx->timers.size() + 0) LDB_FAIL(LDB_ERR_INVALID, "bad timer id %d", id);
+   LDB_HIP(hipEventRecord(ctx->timers[(size_t) id * 2 + 1], ctx->stream));
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_timer_elapsed_ms(ldb_ctx* ctx, int32_t id, float* ms) {
+   if (id < 0 || (size_t) id * 2 + 1 >= ctx->timers.size() + 0) LDB_FAIL(LDB_ERR_INVALID, "bad timer id %d", id);
+   LDB_HIP(hipEventSynchronize(ctx->timers[(size_t) id * 2 + 1]));
+   LDB_HIP(hipEventElapsedTime(ms, ctx->timers[(size_t) id * 2], ctx->timers[(size_t) id * 2 + 1]));
+   return LDB_OK;
+}
+
+// ---------------------------------------------------------------- tables
+int32_t ldb_width_of(const ldb_coltype& t, int narrow) {
+   switch (t.type) {
+      case LDB_T_INT8:
+      case LDB_T_BOOL8: return 1;
+      case LDB_T_INT16: return 2;
+      case LDB_T_INT32:
+      case LDB_T_DATE32:
+      case LDB_T_CHAR4:
+      case LDB_T_FLOAT32: return 4;
+      case LDB_T_INT64:
+      case LDB_T_FLOAT64: return 8;
+      case LDB_T_DECIMAL128: return (narrow && t.precision < 19) ? 8 : 16;
+      default: return 0;
+   }
+}
+
+static int parse_format(const char* f, ldb_coltype* t, bool* large) {
+   *large = false;
+   t->precision = t->scale = 0;
+   if (!strcmp(f, "c")) t->type = LDB_T_INT8;
+   else if (!strcmp(f, "s")) t->type = LDB_T_INT16;
+   else if (!strcmp(f, "i")) t->type = LDB_T_INT32;
+   else if (!strcmp(f, "l")) t->type = LDB_T_INT64;
+   else if (!strcmp(f, "tdD")) t->type = LDB_T_DATE32;
+   else if (!strcmp(f, "g")) t->type = LDB_T_FLOAT64;
+   else if (!strcmp(f, "f")) t->type = LDB_T_FLOAT32;
+   else if (!strcmp(f, "u")) t->type = LDB_T_UTF8;
+   else if (!strcmp(f, "U")) {
+      t->type = LDB_T_UTF8;
+      *large = true;
+   } else if (!strcmp(f, "w:4")) t->type = LDB_T_CHAR4;
+   else if (!strncmp(f, "d:", 2)) {
+      int p = 0, s = 0, bits = 128;
+      int n = sscanf(f + 2, "%d,%d,%d", &p, &s, &bits);
+      if (n < 2 || bits != 128) return -1;
+      t->type = LDB_T_DECIMAL128;
+      t->precision = p;
+      t->scale = s;
+   } else
+      return -1;
+   return 0;
+}
+
+extern "C" int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct ArrowSchema* schema, struct ArrowArray** batches,
+                                          int64_t n_batches, int32_t narrow, ldb_table** out) {
+   if (!ctx || !schema || !out) LDB_FAIL(LDB_ERR_INVALID, "table_register: NULL argument");
+   if (strcmp(schema->format, "+s")) LDB_FAIL(LDB_ERR_INVALID, "table_register: schema must be a struct (+s), got %s", schema->format);
+   auto t = std::make_unique<ldb_table>();
+   t->ctx = ctx;
+   t->name = name ? name : "";
+   int64_t rows = 0;
+   for (int64_t b = 0; b < n_batches; b++) {
+      if (batches[b]->n_children != schema->n_children) LDB_FAIL(LDB_ERR_INVALID, "batch %ld has %ld children, schema %ld", (long) b, (long) batches[b]->n_children, (long) schema->n_children);
+      rows += batches[b]->length;
+   }
+   if (rows >= (int64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "table_register: %ld rows exceed uint32 row ids", (long) rows);
+   t->n_rows = rows;
+   t->cols.resize((size_t) schema->n_children);
+   for (int64_t c = 0; c < schema->n_children; c++) {
+      ldb_column& col = t->cols[(size_t) c];
+      struct ArrowSchema* cs = schema->children[c];
+      col.name = cs->name ? cs->name : "";
+      bool large = false;
+      if (parse_format(cs->format, &col.type, &large)) LDB_FAIL(LDB_ERR_UNSUPPORTED, "column %s: Arrow format '%s' not supported", col.name.c_str(), cs->format);
+      col.type.nullable = (cs->flags & ARROW_FLAG_NULLABLE) ? 1 : 0;
+      col.width = ldb_width_of(col.type, narrow);
+      // validity: only materialised when some batch really has nulls
+      bool any_null = false;
+      for (int64_t b = 0; b < n_batches; b++) {
+         struct ArrowArray* a = batches[b]->children[c];
+         if (a->null_count != 0 && a->buffers[0]) {
+            const uint8_t* v = (const uint8_t*) a->buffers[0];
+            for (int64_t i = 0; i < a->length && !any_null; i++) {
+               int64_t k = i + a->offset;
+               if (!((v[k >> 3] >> (k & 7)) & 1)) any_null = true;
+            }
+         }
+      }
+      if (any_null) {
+         std::vector<uint8_t> bm((size_t) ((rows + 7) / 8), 0);
+         int64_t pos = 0;
+         for (int64_t b = 0; b < n_batches; b++) {
+            struct ArrowArray* a = batches[b]->children[c];
+            const uint8_t* v = (const uint8_t*) a->buffers[0];
+            for (int64_t i = 0; i < a->length; i++, pos++) {
+               int64_t k = i + a->offset;
+               bool ok = !v || ((v[k >> 3] >> (k & 7)) & 1);
+               if (ok) bm[(size_t) (pos >> 3)] |= (uint8_t) (1u << (pos & 7));
+               else col.null_count++;
+            }
+         }
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &col.validity, bm.size()));
+         LDB_HIP(hipMemcpyAsync(col.validity, bm.data(), bm.size(), hipMemcpyHostToDevice, ctx->stream));
+         LDB_HIP(hipStreamSynchronize(ctx->stream));
+      }
+      if (col.type.type == LDB_T_UTF8) {
+         std::vector<int64_t> offs((size_t) rows + 1);
+         int64_t pos = 0, bytes = 0;
+         offs[0] = 0;
+         for (int64_t b = 0; b < n_batches; b++) {
+            struct ArrowArray* a = batches[b]->children[c];
+            for (int64_t i = 0; i < a->length; i++) {
+               int64_t lo, hi;
+               if (large) {
+                  const int64_t* o = (const int64_t*) a->buffers[1] + a->offset;
+                  lo = o[i];
+                  hi = o[i + 1];
+               } else {
+                  const int32_t* o = (const int32_t*) a->buffers[1] + a->offset;
+                  lo = o[i];
+                  hi = o[i + 1];
+               }
+               bytes += hi - lo;
+               offs[(size_t) ++pos] = bytes;
+            }
+         }
+         col.value_bytes = bytes;
+         LDB_TRY(ldb_dev_alloc(ctx, &col.values, (size_t) bytes));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &col.offsets, sizeof(int64_t) * ((size_t) rows + 1)));
+         LDB_HIP(hipMemcpyAsync(col.offsets, offs.data(), sizeof(int64_t) * ((size_t) rows + 1), hipMemcpyHostToDevice, ctx->stream));
+         int64_t dpos = 0;
+         for (int64_t b = 0; b < n_batches; b++) {
+            struct ArrowArray* a = batches[b]->children[c];
+            if (a->length == 0) continue;
+            int64_t lo, hi;
+            if (large) {
+               const int64_t* o = (const int64_t*) a->buffers[1] + a->offset;
+               lo = o[0];
+               hi = o[a->length];
+            } else {
+               const int32_t* o = (const int32_t*) a->buffers[1] + a->offset;
+               lo = o[0];
+               hi = o[a->length];
+            }
+            if (hi > lo) LDB_HIP(hipMemcpyAsync((uint8_t*) col.values + dpos, (const uint8_t*) a->buffers[2] + lo, (size_t) (hi - lo), hipMemcpyHostToDevice, ctx->stream));
+            dpos += hi - lo;
+         }
+         LDB_HIP(hipStreamSynchronize(ctx->stream));
+      } else {
+         int src_w = ldb_width_of(col.type, 0);
+         col.value_bytes = rows * col.width;
+         LDB_TRY(ldb_dev_alloc(ctx, &col.values, (size_t) col.value_bytes));
+         int64_t pos = 0;
+         std::vector<int64_t> tmp;
+         for (int64_t b = 0; b < n_batches; b++) {
+            struct ArrowArray* a = batches[b]->children[c];
+            if (a->length == 0) continue;
+            const uint8_t* src = (const uint8_t*) a->buffers[1] + a->offset * src_w;
+            if (src_w == col.width) {
+               LDB_HIP(hipMemcpyAsync((uint8_t*) col.values + pos * col.width, src, (size_t) (a->length * src_w), hipMemcpyHostToDevice, ctx->stream));
+            } else { // narrowed decimal: keep the low 64 bits (the value fits, p < 19)
+               tmp.resize((size_t) a->length);
+               for (int64_t i = 0; i < a->length; i++) memcpy(&tmp[(size_t) i], src + i * 16, 8);
+               LDB_HIP(hipMemcpyAsync((uint8_t*) col.values + pos * 8, tmp.data(), (size_t) (a->length * 8), hipMemcpyHostToDevice, ctx->stream));
+               LDB_HIP(hipStreamSynchronize(ctx->stream));
+            }
+            pos += a->length;
+         }
+         LDB_HIP(hipStreamSynchronize(ctx->stream));
+      }
+   }
+   *out = t.release();
+   return LDB_OK;
+}
+
+extern "C" int32_t ldb_gpu_table_alloc(ldb_ctx* ctx, const char* name, int32_t n_cols, const ldb_coltype* types, const char* const* col_names,
+                                       int64_t n_rows, const int64_t* data_bytes, int32_t narrow, ldb_table** out) {
+   if (!ctx || !out || n_cols < 0) LDB_FAIL(LDB_ERR_INVALID, "table_alloc: bad argument");
+   if (n_rows >= (int64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "table_alloc: %ld rows exceed uint32 row ids", (long) n_rows);
+   auto t = std::make_unique<ldb_table>();
+   t->ctx = ctx;
+   t->name = name ? name : "";
+   t->n_rows = n_rows;
+   t->cols.resize((size_t) n_cols);
+   for (int32_t c = 0; c < n_cols; c++) {
+      ldb_column& col = t->cols[(size_t) c];
+      col.name = col_names && col_names[c] ? col_names[c] : "";
+      col.type = types[c];
+      col.width = ldb_width_of(col.type, narrow);
+      if (col.type.type == LDB_T_UTF8) {
+         col.value_bytes = data_bytes ? data_bytes[c] : 0;
+         LDB_TRY(ldb_dev_alloc(ctx, &col.values, (size_t) col.value_bytes));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &col.offsets, sizeof(int64_t) * ((size_t) n_rows + 1)));
+      } else {
+         col.value_bytes = n_rows * col.width;
+         LDB_TRY(ldb_dev_alloc(ctx, &col.values, (size_t) col.value_bytes));
+      }
+   }
+   *out = t.release();
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_table_release(ldb_ctx* ctx, ldb_table* t) {
+   if (!t) return LDB_OK;
+   for (auto& c : t->cols) {
+      if (!c.owned) continue;
+      ldb_dev_free(ctx, c.values);
+      ldb_dev_free(ctx, c.offsets);
+      ldb_dev_free(ctx, c.validity);
+   }
+   delete t;
+   return LDB_OK;
+}
+extern "C" int64_t ldb_gpu_table_rows(const ldb_table* t) { return t ? t->n_rows : -1; }
+extern "C" int32_t ldb_gpu_table_cols(const ldb_table* t) { return t ? (int32_t) t->cols.size() : -1; }
+extern "C" int32_t ldb_gpu_table_coltype(const ldb_table* t, int32_t col, ldb_coltype* out) {
+   if (!t || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "coltype: bad column %d", col);
+   *out = t->cols[(size_t) col].type;
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_table_col_index(const ldb_table* t, const char* name) {
+   for (size_t i = 0; i < t->cols.size(); i++)
+      if (t->cols[i].name == name) return (int32_t) i;
+   return -1;
+}
+extern "C" const char* ldb_gpu_table_col_name(const ldb_table* t, int32_t col) {
+   if (!t || col < 0 || (size_t) col >= t->cols.size()) return nullptr;
+   return t->cols[(size_t) col].name.c_str();
+}
+extern "C" int32_t ldb_gpu_table_col_width(const ldb_table* t, int32_t col) {
+   if (!t || col < 0 || (size_t) col >= t->cols.size()) return -1;
+   return t->cols[(size_t) col].width;
+}
+extern "C" int32_t ldb_gpu_table_col_ptrs(const ldb_table* t, int32_t col, void** values, void** offsets, void** validity, int64_t* value_bytes) {
+   if (!t || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "col_ptrs: bad column %d", col);
+   const ldb_column& c = t->cols[(size_t) col];
+   if (values) *values = c.values;
+   if (offsets) *offsets = c.offsets;
+   if (validity) *validity = c.validity;
+   if (value_bytes) *value_bytes = c.value_bytes;
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_table_set_rows(ldb_table* t, int64_t n_rows) {
+   if (!t || n_rows < 0) LDB_FAIL(LDB_ERR_INVALID, "set_rows: bad argument");
+   for (auto& c : t->cols)
+      if (c.type.type != LDB_T_UTF8 && n_rows * c.width > c.value_bytes) LDB_FAIL(LDB_ERR_INVALID, "set_rows: %ld rows exceed capacity of column %s", (long) n_rows, c.name.c_str());
+   t->n_rows = n_rows;
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_table_read_fixed(ldb_ctx* ctx, const ldb_table* t, int32_t col, void* host_out, int64_t out_bytes) {
+   if (!t || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "read_fixed: bad column %d", col);
+   const ldb_column& c = t->cols[(size_t) col];
+   if (c.type.type == LDB_T_UTF8) LDB_FAIL(LDB_ERR_INVALID, "read_fixed: column %s is utf8 (use export)", c.name.c_str());
+   int64_t need = t->n_rows * c.width;
+   if (out_bytes < need) LDB_FAIL(LDB_ERR_INVALID, "read_fixed: buffer %ld < %ld bytes", (long) out_bytes, (long) need);
+   if (need) LDB_HIP(hipMemcpyAsync(host_out, c.values, (size_t) need, hipMemcpyDeviceToHost, ctx->stream));
+   LDB_HIP(hipStreamSynchronize(ctx->stream));
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_table_write_fixed(ldb_ctx* ctx, ldb_table* t, int32_t col, const void* host_in, int64_t in_bytes) {
+   if (!t || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "write_fixed: bad column %d", col);
+   ldb_column& c = t->cols[(size_t) col];
+   if (c.type.type == LDB_T_UTF8) LDB_FAIL(LDB_ERR_INVALID, "write_fixed: column %s is utf8", c.name.c_str());
+   if (in_bytes > c.value_bytes) LDB_FAIL(LDB_ERR_INVALID, "write_fixed: %ld bytes exceed column capacity %ld", (long) in_bytes, (long) c.value_bytes);
+   if (in_bytes) LDB_HIP(hipMemcpyAsync(c.values, host_in, (size_t) in_bytes, hipMemcpyHostToDevice, ctx->stream));
+   LDB_HIP(hipStreamSynchronize(ctx->stream));
+   return LDB_OK;
+}
+
+// ---------------------------------------------------------------- export (Arrow C Data Interface out)
+struct ExportPriv {
+   std::vector<void*> bufs;
+   std::vector<struct ArrowArray*> child_arrays;
+   std::vector<struct ArrowSchema*> child_schemas;
+   std::vector<char*> strings;
+   const void** buffers = nullptr;
+};
+static void release_array(struct ArrowArray* a) {
+   if (!a || !a->release) return;
+   ExportPriv* p = (ExportPriv*) a->private_data;
+   for (int64_t i = 0; i < a->n_children; i++) {
+      if (a->children[i]->release) a->children[i]->release(a->children[i]);
+      free(a->children[i]);
+   }
+   free(a->children);
+   for (void* b : p->bufs) free(b);
+   free(p->buffers);
+   delete p;
+   a->release = nullptr;
+}
+static void release_schema(struct ArrowSchema* s) {
+   if (!s || !s->release) return;
+   ExportPriv* p = (ExportPriv*) s->private_data;
+   for (int64_t i = 0; i < s->n_children; i++) {
+      if (s->children[i]->release) s->children[i]->release(s->children[i]);
+      free(s->children[i]);
+   }
+   free(s->children);
+   for (char* c : p->strings) free(c);
+   delete p;
+   s->release = nullptr;
+}
+static char* dup_str(ExportPriv* p, const std::string& s) {
+   char* c = strdup(s.c_str());
+   p->strings.push_back(c);
+   return c;
+}
+
+extern "C" int32_t ldb_gpu_export(ldb_ctx* ctx, const ldb_table* t, struct ArrowSchema* out_schema, struct ArrowArray* out_array) {
+   if (!ctx || !t || !out_schema || !out_array) LDB_FAIL(LDB_ERR_INVALID, "export: NULL argument");
+   LDB_HIP(hipStreamSynchronize(ctx->stream));
+   const int64_t n = t->n_rows;
+   const int64_t nc = (int64_t) t->cols.size();
+   memset(out_schema, 0, sizeof(*out_schema));
+   memset(out_array, 0, sizeof(*out_array));
+   auto* sp = new ExportPriv();
+   out_schema->format = dup_str(sp, "+s");
+   out_schema->name = dup_str(sp, t->name);
+   out_schema->n_children = nc;
+   out_schema->children = (struct ArrowSchema**) calloc((size_t) (nc ? nc : 1), sizeof(void*));
+   out_schema->release = release_schema;
+   out_schema->private_data = sp;
+   auto* ap = new ExportPriv();
+   ap->buffers = (const void**) calloc(1, sizeof(void*));
+   out_array->length = n;
+   out_array->n_buffers = 1;
+   out_array->buffers = ap->buffers;
+   out_array->n_children = nc;
+   out_array->children = (struct ArrowArray**) calloc((size_t) (nc ? nc : 1), sizeof(void*));
+   out_array->release = release_array;
+   out_array->private_data = ap;
+   for (int64_t c = 0; c < nc; c++) {
+      const ldb_column& col = t->cols[(size_t) c];
+      auto* cs = (struct ArrowSchema*) calloc(1, sizeof(struct ArrowSchema));
+      auto* ca = (struct ArrowArray*) calloc(1, sizeof(struct ArrowArray));
+      out_schema->children[c] = cs;
+      out_array->children[c] = ca;
+      auto* csp = new ExportPriv();
+      auto* cap = new ExportPriv();
+      cs->release = release_schema;
+      cs->private_data = csp;
+      cs->children = nullptr;
+      ca->release = release_array;
+      ca->private_data = cap;
+      cs->name = dup_str(csp, col.name);
+      cs->flags = ARROW_FLAG_NULLABLE;
+      ca->length = n;
+      ca->null_count = col.validity ? col.null_count : 0;
+      char fmt[64];
+      bool utf8 = col.type.type == LDB_T_UTF8;
+      bool large = false;
+      switch (col.type.type) {
+         case LDB_T_INT8: strcpy(fmt, "c"); break;
+         case LDB_T_BOOL8: strcpy(fmt, "C"); break; // uint8 0/1
+         case LDB_T_INT16: strcpy(fmt, "s"); break;
+         case LDB_T_INT32: strcpy(fmt, "i"); break;
+         case LDB_T_INT64: strcpy(fmt, "l"); break;
+         case LDB_T_DATE32: strcpy(fmt, "tdD"); break;
+         case LDB_T_FLOAT64: strcpy(fmt, "g"); break;
+         case LDB_T_FLOAT32: strcpy(fmt, "f"); break;
+         case LDB_T_CHAR4: strcpy(fmt, "w:4"); break;
+         case LDB_T_DECIMAL128: snprintf(fmt, sizeof(fmt), "d:%d,%d", col.type.precision, col.type.scale); break;
+         case LDB_T_UTF8:
+            large = col.value_bytes > 0x7fffffffLL;
+            strcpy(fmt, large ? "U" : "u");
+            break;
+         default: LDB_FAIL(LDB_ERR_UNSUPPORTED, "export: column type %d", col.type.type);
+      }
+      cs->format = dup_str(csp, fmt);
+      ca->n_buffers = utf8 ? 3 : 2;
+      cap->buffers = (const void**) calloc(3, sizeof(void*));
+      ca->buffers = cap->buffers;
+      if (col.validity) {
+         size_t vb = (size_t) ((n + 7) / 8);
+         void* hv = malloc(vb ? vb : 1);
+         cap->bufs.push_back(hv);
+         if (vb) LDB_HIP(hipMemcpy(hv, col.validity, vb, hipMemcpyDeviceToHost));
+         cap->buffers[0] = hv;
+      }
+      if (utf8) {
+         std::vector<int64_t> offs((size_t) n + 1, 0);
+         LDB_HIP(hipMemcpy(offs.data(), col.offsets, sizeof(int64_t) * ((size_t) n + 1), hipMemcpyDeviceToHost));
+         int64_t bytes = offs[(size_t) n];
+         void* data = malloc((size_t) (bytes ? bytes : 1));
+         cap->bufs.push_back(data);
+         if (bytes) LDB_HIP(hipMemcpy(data, col.values, (size_t) bytes, hipMemcpyDeviceToHost));
+         if (large) {
+            void* ho = malloc(sizeof(int64_t) * ((size_t) n + 1));
+            memcpy(ho, offs.data(), sizeof(int64_t) * ((size_t) n + 1));
+            cap->bufs.push_back(ho);
+            cap->buffers[1] = ho;
+         } else {
+            int32_t* ho = (int32_t*) malloc(sizeof(int32_t) * ((size_t) n + 1));
+            for (int64_t i = 0; i <= n; i++) ho[i] = (int32_t) offs[(size_t) i];
+            cap->bufs.push_back(ho);
+            cap->buffers[1] = ho;
+         }
+         cap->buffers[2] = data;
+      } else {
+         int out_w = ldb_width_of(col.type, 0);
+         size_t bytes = (size_t) (n * out_w);
+         uint8_t* hv = (uint8_t*) malloc(bytes ? bytes : 1);
+         cap->bufs.push_back(hv);
+         if (out_w == col.width) {
+            if (bytes) LDB_HIP(hipMemcpy(hv, col.values, bytes, hipMemcpyDeviceToHost));
+         } else { // narrowed decimal → sign-extend back to 128 bit (reference LowerToStd.cpp:211-298)
+            std::vector<int64_t> tmp((size_t) n);
+            if (n) LDB_HIP(hipMemcpy(tmp.data(), col.values, (size_t) n * 8, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n; i++) {
+               int64_t lo = tmp[(size_t) i], hi = lo >> 63;
+               memcpy(hv + i * 16, &lo, 8);
+               memcpy(hv + i * 16 + 8, &hi, 8);
+            }
+         }
+         cap->buffers[1] = hv;
+      }
+   }
+   return LDB_OK;
+}
+
+// ---------------------------------------------------------------- relations
+ldb_rel* ldb_rel_new(ldb_ctx* ctx) {
+   auto* r = new ldb_rel();
+   r->ctx = ctx;
+   return r;
+}
+extern "C" int32_t ldb_gpu_rel_from_table(ldb_ctx* ctx, const ldb_table* t, ldb_rel** out) {
+   if (!ctx || !t || !out) LDB_FAIL(LDB_ERR_INVALID, "rel_from_table: NULL argument");
+   ldb_rel* r = ldb_rel_new(ctx);
+   r->n_rows = t->n_rows;
+   r->sides.push_back({t, nullptr, false});
+   *out = r;
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_rel_release(ldb_ctx* ctx, ldb_rel* r) {
+   if (!r) return LDB_OK;
+   for (auto& s : r->sides)
+      if (s.owned) ldb_dev_free(ctx, s.rowids);
+   delete r;
+   return LDB_OK;
+}
+extern "C" int64_t ldb_gpu_rel_rows(ldb_ctx* ctx, ldb_rel* r) {
+   (void) ctx;
+   return r ? r->n_rows : -1;
+}
+extern "C" int32_t ldb_gpu_rel_sides(const ldb_rel* r) { return r ? (int32_t) r->sides.size() : -1; }
+
+__global__ void k_iota_u32(uint32_t* out, uint64_t n) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = (uint32_t) i;
+}
+extern "C" int32_t ldb_gpu_rel_read_rowids(ldb_ctx* ctx, ldb_rel* r, int32_t side, uint32_t* host_out, int64_t cap) {
+   if (!r || side < 0 || (size_t) side >= r->sides.size()) LDB_FAIL(LDB_ERR_INVALID, "read_rowids: bad side %d", side);
+   if (cap < r->n_rows) LDB_FAIL(LDB_ERR_INVALID, "read_rowids: buffer too small");
+   if (r->sides[(size_t) side].rowids) {
+      if (r->n_rows) LDB_HIP(hipMemcpyAsync(host_out, r->sides[(size_t) side].rowids, (size_t) r->n_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+      LDB_HIP(hipStreamSynchronize(ctx->stream));
+   } else {
+      for (int64_t i = 0; i < r->n_rows; i++) host_out[i] = (uint32_t) i;
+   }
+   return LDB_OK;
+}
+
+int32_t ldb_make_dcol(const ldb_rel* r, ldb_colref ref, DCol* out) {
+   if (ref.side < 0 || (size_t) ref.side >= r->sides.size()) LDB_FAIL(LDB_ERR_INVALID, "column ref: side %d out of range", ref.side);
+   const ldb_rel_side& s = r->sides[(size_t) ref.side];
+   if (ref.col < 0 || (size_t) ref.col >= s.table->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "column ref: col %d out of range on side %d", ref.col, ref.side);
+   const ldb_column& c = s.table->cols[(size_t) ref.col];
+   out->values = c.values;
+   out->offsets = c.offsets;
+   out->validity = c.validity;
+   out->rowids = s.rowids;
+   out->type = c.type.type;
+   out->width = c.width;
+   out->precision = c.type.precision;
+   out->scale = c.type.scale;
+   return LDB_OK;
+}
+
+int32_t ldb_make_dpred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out) {
+   memset(out, 0, sizeof(*out));
+   LDB_TRY(ldb_make_dcol(r, p->col, &out->col));
+   out->op = p->op;
+   out->rhs_kind = p->rhs_kind;
+   out->lo = p->value_lo;
+   out->hi = p->value_hi;
+   out->f = p->value_f64;
+   if (p->op < LDB_F_EQ || p->op > LDB_F_IN) LDB_FAIL(LDB_ERR_INVALID, "filter: bad op %d", p->op);
+   if (p->op == LDB_F_NOTNULL) return LDB_OK;
+   bool is_str = out->col.type == LDB_T_UTF8;
+   if (p->rhs_kind == LDB_RHS_COLUMN) {
+      if (p->op == LDB_F_IN) LDB_FAIL(LDB_ERR_INVALID, "filter: IN needs constants");
+      LDB_TRY(ldb_make_dcol(r, p->rhs_col, &out->rhs));
+      if ((out->rhs.type == LDB_T_UTF8) != is_str) LDB_FAIL(LDB_ERR_INVALID, "filter: string compared with non-string column");
+      return LDB_OK;
+   }
+   if (is_str != (p->rhs_kind == LDB_RHS_STRING)) LDB_FAIL(LDB_ERR_INVALID, "filter: constant kind %d does not match column type %d", p->rhs_kind, out->col.type);
+   if (p->op == LDB_F_IN) {
+      if (p->n_in < 0 || p->n_in > LDB_MAX_IN) LDB_FAIL(LDB_ERR_UNSUPPORTED, "filter: IN list of %d values (max %d)", p->n_in, LDB_MAX_IN);
+      out->n_in = p->n_in;
+      if (is_str) {
+         int32_t pos = 0;
+         for (int k = 0; k < p->n_in; k++) {
+            if (pos + p->in_str_lens[k] > (int32_t) sizeof(out->in_blob)) LDB_FAIL(LDB_ERR_UNSUPPORTED, "filter: IN string constants exceed %zu bytes", sizeof(out->in_blob));
+            out->in_off[k] = pos;
+            memcpy(out->in_blob + pos, p->in_strs[k], (size_t) p->in_str_lens[k]);
+            pos += p->in_str_lens[k];
+         }
+         out->in_off[p->n_in] = pos;
+      } else {
+         for (int k = 0; k < p->n_in; k++) {
+            out->in_lo[k] = (uint64_t) p->in_values[2 * k];
+            out->in_hi[k] = p->in_values[2 * k + 1];
+         }
+      }
+      return LDB_OK;
+   }
+   if (is_str) {
+      if (p->str_len < 0 || p->str_len > LDB_STR_INLINE) LDB_FAIL(LDB_ERR_UNSUPPORTED, "filter: string constant of %d bytes (max %d)", p->str_len, LDB_STR_INLINE);
+      out->str_len = p->str_len;
+      memcpy(out->str, p->str, (size_t) p->str_len);
+   }
+   return LDB_OK;
+}
+
+// ---------------------------------------------------------------- gather / materialize
+template <typename T>
+__global__ void k_gather_fixed(const T* __restrict__ src, const uint32_t* __restrict__ rowids, T* __restrict__ dst, uint64_t n) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      uint32_t r = rowids ? rowids[i] : (uint32_t) i;
+      T v{};
+      if (r != LDB_NULL_ROW) v = src[r];
+      dst[i] = v;
+   }
+}
+__global__ void k_gather_valid(const uint8_t* __restrict__ validity, const uint32_t* __restrict__ rowids, uint8_t* __restrict__ out_bytes, uint64_t n) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      uint32_t r = rowids ? rowids[i] : (uint32_t) i;
+      bool ok = r != LDB_NULL_ROW && (!validity || ((validity[r >> 3] >> (r & 7)) & 1));
+      out_bytes[i] = ok ? 1 : 0;
+   }
+}
+__global__ void k_pack_valid(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bitmap, uint64_t n, unsigned long long* null_count) {
+   uint64_t nb = (n + 7) / 8;
+   for (uint64_t b = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; b < nb; b += (uint64_t) gridDim.x * blockDim.x) {
+      uint8_t m = 0;
+      int nulls = 0;
+      for (int k = 0; k < 8; k++) {
+         uint64_t i = b * 8 + k;
+         if (i < n) {
+            if (bytes[i]) m |= (uint8_t) (1u << k);
+            else nulls++;
+         }
+      }
+      bitmap[b] = m;
+      if (nulls) atomicAdd(null_count, (unsigned long long) nulls);
+   }
+}
+__global__ void k_str_lens(const int64_t* __restrict__ offsets, const uint32_t* __restrict__ rowids, int64_t* __restrict__ lens, uint64_t n) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      uint32_t r = rowids ? rowids[i] : (uint32_t) i;
+      lens[i] = r == LDB_NULL_ROW ? 0 : offsets[r + 1] - offsets[r];
+   }
+}
+__global__ void k_str_copy(const uint8_t* __restrict__ src, const int64_t* __restrict__ src_off, const uint32_t* __restrict__ rowids,
+                           const int64_t* __restrict__ dst_off, uint8_t* __restrict__ dst, uint64_t n) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      uint32_t r = rowids ? rowids[i] : (uint32_t) i;
+      if (r == LDB_NULL_ROW) continue;
+      int64_t b = src_off[r], len = src_off[r + 1] - b, d = dst_off[i];
+      for (int64_t k = 0; k < len; k++) dst[d + k] = src[b + k];
+   }
+}
+
+struct u128x {
+   uint64_t a, b;
+};
+
+// gather one column of `r` into a new owned column
+int32_t ldb_gather_column(ldb_ctx* ctx, const ldb_rel* r, ldb_colref ref, ldb_column* out) {
+   DCol dc;
+   LDB_TRY(ldb_make_dcol(r, ref, &dc));
+   const ldb_column& src = r->sides[(size_t) ref.side].table->cols[(size_t) ref.col];
+   const uint64_t n = (uint64_t) r->n_rows;
+   out->name = src.name;
+   out->type = src.type;
+   out->width = src.width;
+   out->owned = true;
+   int grid = ldb_grid_for(ctx, (int64_t) n, 256, 8);
+   bool outer = false; // rows may carry LDB_NULL_ROW only through rowids
+   if (dc.rowids) outer = true;
+   if (src.validity || outer) {
+      uint8_t* bytes;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &bytes, (size_t) n));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &out->validity, (size_t) ((n + 7) / 8)));
+      LDB_HIP(hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
+      hipLaunchKernelGGL(k_gather_valid, dim3(grid), dim3(256), 0, ctx->stream, src.validity, dc.rowids, bytes, n);
+      hipLaunchKernelGGL(k_pack_valid, dim3(grid), dim3(256), 0, ctx->stream, bytes, out->validity, n, (unsigned long long*) ctx->d_scratch);
+      uint64_t nulls = 0;
+      LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &nulls));
+      ldb_dev_free(ctx, bytes);
+      out->null_count = (int64_t) nulls;
+      if (nulls == 0) {
+         ldb_dev_free(ctx, out->validity);
+         out->validity = nullptr;
+      }
+   }
+   if (src.type.type == LDB_T_UTF8) {
+      int64_t* lens;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &lens, sizeof(int64_t) * (size_t) (n + 1)));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &out->offsets, sizeof(int64_t) * (size_t) (n + 1)));
+      hipLaunchKernelGGL(k_str_lens, dim3(grid), dim3(256), 0, ctx->stream, src.offsets, dc.rowids, lens, n);
+      LDB_TRY(ldb_exclusive_scan_i64(ctx, lens, out->offsets, (int64_t) n, out->offsets + n));
+      uint64_t total = 0;
+      LDB_TRY(ldb_read_u64(ctx, out->offsets + n, &total));
+      ldb_dev_free(ctx, lens);
+      out->value_bytes = (int64_t) total;
+      LDB_TRY(ldb_dev_alloc(ctx, &out->values, (size_t) total));
+      hipLaunchKernelGGL(k_str_copy, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*) src.values, src.offsets, dc.rowids, out->offsets,
+                         (uint8_t*) out->values, n);
+   } else {
+      out->value_bytes = (int64_t) n * src.width;
+      LDB_TRY(ldb_dev_alloc(ctx, &out->values, (size_t) out->value_bytes));
+      switch (src.width) {
+         case 1: hipLaunchKernelGGL(k_gather_fixed<uint8_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*) src.values, dc.rowids, (uint8_t*) out->values, n); break;
+         case 2: hipLaunchKernelGGL(k_gather_fixed<uint16_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint16_t*) src.values, dc.rowids, (uint16_t*) out->values, n); break;
+         case 4: hipLaunchKernelGGL(k_gather_fixed<uint32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*) src.values, dc.rowids, (uint32_t*) out->values, n); break;
+         case 8: hipLaunchKernelGGL(k_gather_fixed<uint64_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint64_t*) src.values, dc.rowids, (uint64_t*) out->values, n); break;
+         default: hipLaunchKernelGGL(k_gather_fixed<u128x>, dim3(grid), dim3(256), 0, ctx->stream, (const u128x*) src.values, dc.rowids, (u128x*) out->values, n); break;
+      }
+   }
+   LDB_HIP(hipGetLastError());
+   return LDB_OK;
+}
+
+extern "C" int32_t ldb_gpu_materialize(ldb_ctx* ctx, ldb_rel* r, const ldb_colref* cols, int32_t n_cols, ldb_table** out) {
+   if (!ctx || !r || !out || n_cols < 0) LDB_FAIL(LDB_ERR_INVALID, "materialize: bad argument");
+   auto t = std::make_unique<ldb_table>();
+   t->ctx = ctx;
+   t->name = "materialized";
+   t->n_rows = r->n_rows;
+   t->cols.resize((size_t) n_cols);
+   for (int32_t c = 0; c < n_cols; c++) {
+      int32_t s = ldb_gather_column(ctx, r, cols[c], &t->cols[(size_t) c]);
+      if (s != LDB_OK) {
+         ldb_gpu_table_release(ctx, t.release());
+         return s;
+      }
+   }
+   *out = t.release();
+   return LDB_OK;
+}
+
+// ---------------------------------------------------------------- exclusive scans
+// Single-pass-per-level scan: per-block sums → recursive scan of the sums → add back.
+template <typename T, typename TO>
+__global__ void k_scan_block(const T* __restrict__ in, TO* __restrict__ out, TO* __restrict__ block_sums, uint64_t n) {
+   __shared__ TO sh[256];
+   const int ITEMS = 8;
+   uint64_t base = (uint64_t) blockIdx.x * 256 * ITEMS + (uint64_t) threadIdx.x * ITEMS;
+   TO v[ITEMS];
+   TO sum = 0;
+#pragma unroll
+   for (int k = 0; k < ITEMS; k++) {
+      v[k] = base + k < n ? (TO) in[base + k] : (TO) 0;
+      sum += v[k];
+   }
+   sh[threadIdx.x] = sum;
+   __syncthreads();
+   for (int off = 1; off < 256; off <<= 1) {
+      TO t = threadIdx.x >= (unsigned) off ? sh[threadIdx.x - off] : (TO) 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+   }
+   TO excl = sh[threadIdx.x] - sum;
+   if (threadIdx.x == 255 && block_sums) block_sums[blockIdx.x] = sh[255];
+#pragma unroll
+   for (int k = 0; k < ITEMS; k++) {
+      if (base + k < n) out[base + k] = excl;
+      excl += v[k];
+   }
+}
+template <typename TO>
+__global__ void k_scan_add(TO* __restrict__ out, const TO* __restrict__ block_offsets, uint64_t n) {
+   const int ITEMS = 8;
+   uint64_t base = (uint64_t) blockIdx.x * 256 * ITEMS + (uint64_t) threadIdx.x * ITEMS;
+   TO add = block_offsets[blockIdx.x];
+#pragma unroll
+   for (int k = 0; k < ITEMS; k++)
+      if (base + k < n) out[base + k] += add;
+}
+template <typename TO>
+__global__ void k_store_total(const TO* last_excl, const TO* last_sum_src, TO* total) { *total = *last_excl + *last_sum_src; }
+
+template <typename T, typename TO>
+static int32_t scan_impl(ldb_ctx* ctx, const T* d_in, TO* d_out, int64_t n, TO* d_total) {
+   if (n <= 0) {
+      if (d_total) LDB_HIP(hipMemsetAsync(d_total, 0, sizeof(TO), ctx->stream));
+      return LDB_OK;
+   }
+   const int64_t per_block = 256 * 8;
+   int64_t nb = (n + per_block - 1) / per_block;
+   TO* sums;
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &sums, sizeof(TO) * (size_t) (nb + 1)));
+   hipLaunchKernelGGL((k_scan_block<T, TO>), dim3((unsigned) nb), dim3(256), 0, ctx->stream, d_in, d_out, sums, (uint64_t) n);
+   if (nb > 1) {
+      TO* sums_scanned;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &sums_scanned, sizeof(TO) * (size_t) (nb + 1)));
+      LDB_TRY((scan_impl<TO, TO>(ctx, sums, sums_scanned, nb, d_total)));
+      hipLaunchKernelGGL((k_scan_add<TO>), dim3((unsigned) nb), dim3(256), 0, ctx->stream, d_out, sums_scanned, (uint64_t) n);
+      ldb_dev_free(ctx, sums_scanned);
+   } else if (d_total) {
+      LDB_HIP(hipMemcpyAsync(d_total, sums, sizeof(TO), hipMemcpyDeviceToDevice, ctx->stream));
+   }
+   ldb_dev_free(ctx, sums);
+   LDB_HIP(hipGetLastError());
+   return LDB_OK;
+}
+int32_t ldb_exclusive_scan_u32(ldb_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, uint64_t* d_total) {
+   // totals are reported as 64-bit: scan in 64-bit when a total is requested through a temp
+   if (!d_total) return scan_impl<uint32_t, uint32_t>(ctx, d_in, d_out, n, nullptr);
+   uint32_t* t32 = (uint32_t*) (ctx->d_scratch + 8);
+   LDB_TRY((scan_impl<uint32_t, uint32_t>(ctx, d_in, d_out, n, t32)));
+   // widen
+   LDB_HIP(hipMemsetAsync(d_total, 0, 8, ctx->stream));
+   LDB_HIP(hipMemcpyAsync(d_total, t32, 4, hipMemcpyDeviceToDevice, ctx->stream));
+   return LDB_OK;
+}
+int32_t ldb_exclusive_scan_i64(ldb_ctx* ctx, const int64_t* d_in, int64_t* d_out, int64_t n, int64_t* d_total) {
+   return scan_impl<int64_t, int64_t>(ctx, d_in, d_out, n, d_total);
+}

@@ -1,0 +1,319 @@
+// ldb_device.h — device-side scalar semantics shared by all kernels (gfx950 / wave64).
+// Each helper cites the reference lowering whose result it must reproduce bit-exactly.
+#pragma once
+#include "ldb_internal.h"
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+#define LDB_WAVE 64
+
+__device__ __forceinline__ uint64_t d_bswap64(uint64_t x) { return __builtin_bswap64(x); }
+
+// util.hash64 (Hash64Lowering, reference src/compiler/Conversion/UtilToLLVM/LowerToLLVM.cpp:493-503):
+// m = x * 0x9E3779B97F4A7C55; m ^ bswap64(m)
+__device__ __forceinline__ uint64_t d_hash64(uint64_t x) {
+   uint64_t m = x * 11400714819323198549ull;
+   return m ^ d_bswap64(m);
+}
+// util.hash_combine(new, total) = new ^ bswap64(total) (HashCombineLowering, LowerToLLVM.cpp:505-512)
+__device__ __forceinline__ uint64_t d_hash_combine(uint64_t h_new, uint64_t total) { return h_new ^ d_bswap64(total); }
+
+// ---- XXH64, seed 0 (hashVarLenData → llvm::xxHash64, reference src/runtime/Hash.cpp:13-16)
+#define DXP1 11400714785074694791ULL
+#define DXP2 14029467366897019727ULL
+#define DXP3 1609587929392839161ULL
+#define DXP4 9650029242287828579ULL
+#define DXP5 2870177450012600261ULL
+__device__ __forceinline__ uint64_t d_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t d_rd64(const uint8_t* p) {
+   uint64_t v = 0;
+#pragma unroll
+   for (int i = 0; i < 8; i++) v |= (uint64_t) p[i] << (8 * i);
+   return v;
+}
+__device__ __forceinline__ uint32_t d_rd32(const uint8_t* p) {
+   return (uint32_t) p[0] | ((uint32_t) p[1] << 8) | ((uint32_t) p[2] << 16) | ((uint32_t) p[3] << 24);
+}
+__device__ __forceinline__ uint64_t d_xround(uint64_t acc, uint64_t in) {
+   acc += in * DXP2;
+   acc = d_rotl64(acc, 31);
+   return acc * DXP1;
+}
+__device__ __forceinline__ uint64_t d_xmerge(uint64_t acc, uint64_t val) {
+   val = d_xround(0, val);
+   acc ^= val;
+   return acc * DXP1 + DXP4;
+}
+__device__ inline uint64_t d_xxh64(const uint8_t* p, uint64_t len) {
+   const uint8_t* end = p + len;
+   uint64_t h;
+   if (len >= 32) {
+      const uint8_t* limit = end - 32;
+      uint64_t v1 = DXP1 + DXP2, v2 = DXP2, v3 = 0, v4 = 0 - DXP1;
+      do {
+         v1 = d_xround(v1, d_rd64(p));
+         v2 = d_xround(v2, d_rd64(p + 8));
+         v3 = d_xround(v3, d_rd64(p + 16));
+         v4 = d_xround(v4, d_rd64(p + 24));
+         p += 32;
+      } while (p <= limit);
+      h = d_rotl64(v1, 1) + d_rotl64(v2, 7) + d_rotl64(v3, 12) + d_rotl64(v4, 18);
+      h = d_xmerge(h, v1);
+      h = d_xmerge(h, v2);
+      h = d_xmerge(h, v3);
+      h = d_xmerge(h, v4);
+   } else {
+      h = DXP5;
+   }
+   h += len;
+   while (p + 8 <= end) {
+      h ^= d_xround(0, d_rd64(p));
+      h = d_rotl64(h, 27) * DXP1 + DXP4;
+      p += 8;
+   }
+   if (p + 4 <= end) {
+      h ^= (uint64_t) d_rd32(p) * DXP1;
+      h = d_rotl64(h, 23) * DXP2 + DXP3;
+      p += 4;
+   }
+   while (p < end) {
+      h ^= (*p) * DXP5;
+      h = d_rotl64(h, 11) * DXP1;
+      p++;
+   }
+   h ^= h >> 33;
+   h *= DXP2;
+   h ^= h >> 29;
+   h *= DXP3;
+   h ^= h >> 32;
+   return h;
+}
+// VarLenTryCheapHash (LowerToLLVM.cpp:372-391): len <= 12 → hash64(first64) ^ bswap(hash64(last64))
+// over the 16-byte VarLen32 image {len:u32, bytes[12] zero padded} (helpers.h:194-209); else XXH64.
+__device__ inline uint64_t d_hash_varlen(const uint8_t* p, uint32_t len) {
+   if (len > 12) return d_xxh64(p, len);
+   uint64_t first64 = len, last64 = 0;
+#pragma unroll
+   for (int i = 0; i < 4; i++)
+      if ((uint32_t) i < len) first64 |= (uint64_t) p[i] << (32 + 8 * i);
+#pragma unroll
+   for (int i = 0; i < 8; i++)
+      if ((uint32_t) (i + 4) < len) last64 |= (uint64_t) p[i + 4] << (8 * i);
+   return d_hash64(first64) ^ d_bswap64(d_hash64(last64));
+}
+
+// ---- column access (LoadArrowOpLowering, reference src/compiler/Conversion/DBToStd/LowerToStd.cpp:111-209)
+__device__ __forceinline__ uint32_t d_phys_row(const DCol& c, uint64_t i) { return c.rowids ? c.rowids[i] : (uint32_t) i; }
+__device__ __forceinline__ bool d_valid(const DCol& c, uint32_t row) {
+   if (row == LDB_NULL_ROW) return false;
+   if (!c.validity) return true;
+   return (c.validity[row >> 3] >> (row & 7)) & 1;
+}
+// 64-bit view of a fixed-width value (sign-extended); decimal128 with p<19 is truncated to
+// i64 exactly as the generated code does (LowerToStd.cpp:128-132)
+__device__ __forceinline__ int64_t d_load_i64(const DCol& c, uint32_t row) {
+   switch (c.width) {
+      case 4: return ((const int32_t*) c.values)[row];
+      case 8: return ((const int64_t*) c.values)[row];
+      case 16: return ((const int64_t*) c.values)[2 * (uint64_t) row];
+      case 2: return ((const int16_t*) c.values)[row];
+      default: return c.type == LDB_T_BOOL8 ? (((const uint8_t*) c.values)[row] ? 1 : 0) : ((const int8_t*) c.values)[row];
+   }
+}
+__device__ __forceinline__ bool d_is_wide(const DCol& c) { return c.type == LDB_T_DECIMAL128 && c.precision >= 19; }
+__device__ __forceinline__ i128 d_load_i128(const DCol& c, uint32_t row) {
+   if (c.width == 16) {
+      const uint64_t* p = (const uint64_t*) c.values + 2 * (uint64_t) row;
+      uint64_t lo = p[0], hi = p[1];
+      if (c.precision < 19) return (i128) (int64_t) lo;
+      return (i128) (((u128) hi << 64) | lo);
+   }
+   return (i128) d_load_i64(c, row);
+}
+__device__ __forceinline__ double d_load_f64(const DCol& c, uint32_t row) {
+   if (c.type == LDB_T_FLOAT64) return ((const double*) c.values)[row];
+   if (c.type == LDB_T_FLOAT32) return ((const float*) c.values)[row];
+   return (double) d_load_i64(c, row);
+}
+__device__ __forceinline__ const uint8_t* d_load_str(const DCol& c, uint32_t row, uint32_t* len) {
+   int64_t b = c.offsets[row], e = c.offsets[row + 1];
+   *len = (uint32_t) (e - b);
+   return (const uint8_t*) c.values + b;
+}
+// std::string_view compare: unsigned bytewise then length (reference StringRuntime.cpp:242-256)
+__device__ inline int d_str_cmp(const uint8_t* a, uint32_t la, const uint8_t* b, uint32_t lb) {
+   uint32_t m = la < lb ? la : lb;
+   for (uint32_t i = 0; i < m; i++) {
+      if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+   }
+   return la < lb ? -1 : (la > lb ? 1 : 0);
+}
+__device__ __forceinline__ bool d_cmp_apply(int op, int c3) {
+   switch (op) {
+      case LDB_F_EQ: return c3 == 0;
+      case LDB_F_NEQ: return c3 != 0;
+      case LDB_F_LT: return c3 < 0;
+      case LDB_F_LTE: return c3 <= 0;
+      case LDB_F_GT: return c3 > 0;
+      default: return c3 >= 0;
+   }
+}
+
+// One conjunct on logical row i.  Semantics: Filter impls of reference
+// src/runtime/storage/Restrictions.cpp:67-321 (native-type compare, decimals as __int128,
+// strings as string_view, IN = membership); NULL operands fail.  All branches on p.* are
+// wave-uniform (p lives in scalar registers / constant memory).
+__device__ inline bool d_eval_pred(const DPred& p, uint64_t i) {
+   uint32_t row = d_phys_row(p.col, i);
+   bool valid = d_valid(p.col, row);
+   if (p.op == LDB_F_NOTNULL) return valid;
+   if (!valid) return false;
+   const int type = p.col.type;
+   if (p.rhs_kind == LDB_RHS_COLUMN) {
+      uint32_t row2 = d_phys_row(p.rhs, i);
+      if (!d_valid(p.rhs, row2)) return false;
+      if (type == LDB_T_UTF8) {
+         uint32_t la, lb;
+         const uint8_t* a = d_load_str(p.col, row, &la);
+         const uint8_t* b = d_load_str(p.rhs, row2, &lb);
+         return d_cmp_apply(p.op, d_str_cmp(a, la, b, lb));
+      }
+      if (type == LDB_T_FLOAT64 || type == LDB_T_FLOAT32 || p.rhs.type == LDB_T_FLOAT64 || p.rhs.type == LDB_T_FLOAT32) {
+         double a = d_load_f64(p.col, row), b = d_load_f64(p.rhs, row2);
+         return d_cmp_apply(p.op, a < b ? -1 : (a > b ? 1 : 0));
+      }
+      if (d_is_wide(p.col) || d_is_wide(p.rhs)) {
+         i128 a = d_load_i128(p.col, row), b = d_load_i128(p.rhs, row2);
+         return d_cmp_apply(p.op, a < b ? -1 : (a > b ? 1 : 0));
+      }
+      int64_t a = d_load_i64(p.col, row), b = d_load_i64(p.rhs, row2);
+      return d_cmp_apply(p.op, a < b ? -1 : (a > b ? 1 : 0));
+   }
+   if (type == LDB_T_UTF8) {
+      uint32_t la;
+      const uint8_t* a = d_load_str(p.col, row, &la);
+      if (p.op == LDB_F_IN) {
+         for (int k = 0; k < p.n_in; k++) {
+            uint32_t lb = (uint32_t) (p.in_off[k + 1] - p.in_off[k]);
+            if (d_str_cmp(a, la, (const uint8_t*) p.in_blob + p.in_off[k], lb) == 0) return true;
+         }
+         return false;
+      }
+      return d_cmp_apply(p.op, d_str_cmp(a, la, (const uint8_t*) p.str, (uint32_t) p.str_len));
+   }
+   if (type == LDB_T_FLOAT64 || type == LDB_T_FLOAT32) {
+      double a = d_load_f64(p.col, row);
+      if (p.op == LDB_F_IN) {
+         for (int k = 0; k < p.n_in; k++)
+            if (a == __longlong_as_double((long long) p.in_lo[k])) return true;
+         return false;
+      }
+      return d_cmp_apply(p.op, a < p.f ? -1 : (a > p.f ? 1 : 0));
+   }
+   if (d_is_wide(p.col)) {
+      i128 a = d_load_i128(p.col, row);
+      if (p.op == LDB_F_IN) {
+         for (int k = 0; k < p.n_in; k++)
+            if (a == (i128) (((u128) (uint64_t) p.in_hi[k] << 64) | p.in_lo[k])) return true;
+         return false;
+      }
+      i128 b = (i128) (((u128) (uint64_t) p.hi << 64) | p.lo);
+      return d_cmp_apply(p.op, a < b ? -1 : (a > b ? 1 : 0));
+   }
+   // narrow integer path: the constant is a 128-bit value; a column value (fits i64) compares
+   // against it exactly after clamping the constant's position relative to the i64 range
+   int64_t a = d_load_i64(p.col, row);
+   if (p.op == LDB_F_IN) {
+      for (int k = 0; k < p.n_in; k++) {
+         bool fits = (p.in_hi[k] == ((int64_t) p.in_lo[k] >> 63));
+         if (fits && a == (int64_t) p.in_lo[k]) return true;
+      }
+      return false;
+   }
+   int c3;
+   if (p.hi == ((int64_t) p.lo >> 63)) {
+      int64_t b = (int64_t) p.lo;
+      c3 = a < b ? -1 : (a > b ? 1 : 0);
+   } else {
+      c3 = p.hi < 0 ? 1 : -1; // constant below / above every int64
+   }
+   return d_cmp_apply(p.op, c3);
+}
+
+// db.hash of one key part folded into `total` (HashLowering::hashImpl, LowerToStd.cpp:1073-1132).
+// Caller has checked validity (NULL parts are skipped).
+__device__ inline uint64_t d_hash_part(const DCol& c, uint32_t row, uint64_t total) {
+   switch (c.type) {
+      case LDB_T_UTF8: {
+         uint32_t len;
+         const uint8_t* p = d_load_str(c, row, &len);
+         return d_hash_combine(d_hash_varlen(p, len), total);
+      }
+      case LDB_T_FLOAT64: return d_hash_combine(d_hash64(((const uint64_t*) c.values)[row]), total);
+      case LDB_T_FLOAT32: return d_hash_combine(d_hash64((uint64_t) (int64_t) ((const int32_t*) c.values)[row]), total);
+      case LDB_T_DATE32: // hashed in ns (LowerToStd.cpp:133-139)
+         return d_hash_combine(d_hash64((uint64_t) ((int64_t) ((const int32_t*) c.values)[row] * 86400000000000LL)), total);
+      case LDB_T_BOOL8: return d_hash_combine(d_hash64(((const uint8_t*) c.values)[row] ? ~0ull : 0ull), total);
+      case LDB_T_DECIMAL128:
+         if (c.precision >= 19) { // two pieces: high then low (LowerToStd.cpp:1079-1090)
+            i128 v = d_load_i128(c, row);
+            uint64_t h1 = d_hash_combine(d_hash64((uint64_t) (v >> 64)), total);
+            return d_hash_combine(d_hash64((uint64_t) v), h1);
+         }
+         [[fallthrough]];
+      default: return d_hash_combine(d_hash64((uint64_t) d_load_i64(c, row)), total);
+   }
+}
+
+// equality of one key part between two physical rows of (possibly different) columns
+__device__ inline bool d_key_part_equal(const DCol& ca, uint32_t ra, const DCol& cb, uint32_t rb) {
+   if (ca.type == LDB_T_UTF8) {
+      uint32_t la, lb;
+      const uint8_t* a = d_load_str(ca, ra, &la);
+      const uint8_t* b = d_load_str(cb, rb, &lb);
+      if (la != lb) return false;
+      for (uint32_t i = 0; i < la; i++)
+         if (a[i] != b[i]) return false;
+      return true;
+   }
+   if (ca.type == LDB_T_FLOAT64 || ca.type == LDB_T_FLOAT32) return d_load_f64(ca, ra) == d_load_f64(cb, rb);
+   if (d_is_wide(ca) || d_is_wide(cb)) return d_load_i128(ca, ra) == d_load_i128(cb, rb);
+   return d_load_i64(ca, ra) == d_load_i64(cb, rb);
+}
+
+// ---- 128-bit helpers (no libcalls on the device: no __divti3)
+__device__ inline u128 d_udiv128(u128 n, u128 d) {
+   if (d == 0) return 0;
+   if (n < d) return 0;
+   // shift-subtract long division; used only in per-group finalisation / clamped-scale terms
+   u128 q = 0, r = 0;
+   for (int i = 127; i >= 0; i--) {
+      r = (r << 1) | ((n >> i) & 1);
+      if (r >= d) {
+         r -= d;
+         q |= ((u128) 1 << i);
+      }
+   }
+   return q;
+}
+// arith.divsi: truncating signed division
+__device__ inline i128 d_sdiv128(i128 a, i128 b) {
+   bool neg = (a < 0) != (b < 0);
+   u128 ua = a < 0 ? (u128) 0 - (u128) a : (u128) a;
+   u128 ub = b < 0 ? (u128) 0 - (u128) b : (u128) b;
+   u128 q = d_udiv128(ua, ub);
+   return neg ? (i128) ((u128) 0 - q) : (i128) q;
+}
+__device__ inline i128 d_pow10(int k) {
+   i128 r = 1;
+   for (int i = 0; i < k; i++) r *= 10;
+   return r;
+}
+
+// wave-level helpers
+__device__ __forceinline__ uint32_t d_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t d_rank_in(uint64_t mask) {
+   return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+}

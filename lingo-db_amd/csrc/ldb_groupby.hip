@@ -1,0 +1,828 @@
+// ldb_groupby.hip — fused scan + predicate + hash group-by aggregation.
+// Replaces (reference): the generated pipeline body around PreAggregationHashtableFragment
+// (LookupPreAggrHtFragment, src/compiler/Conversion/SubOpToControlFlow/SubOpToControlFlow.cpp:3065-3157;
+// ReduceOpLowering :3719-3768; PreAggregationHashtableFragment::insert,
+// src/runtime/PreAggregationHashtable.cpp:46-60), PreAggregationHashtable::merge (:76-158),
+// Hashtable (src/runtime/Hashtable.cpp) and SimpleState for key-less aggregates
+// (src/runtime/SimpleState.cpp:8-30).
+//
+// MI355X design (not a port of the pointer-chained CPU tables):
+//   * the reference's per-worker 1024-slot pre-aggregation cache becomes a per-workgroup table in
+//     LDS (160 KB/CU): open addressing, slot word = {hash tag : 32 | representative row+1 : 32}
+//     claimed by one 64-bit LDS CAS; accumulators are 64-bit words updated with LDS atomics.
+//   * low-cardinality group-bys (TPC-H Q1: 4 groups) would serialise 64 lanes on a handful of
+//     LDS addresses, so the table is REPLICATED R times and lane l works on replica l % R.
+//   * 128-bit decimal SUMs are two 64-bit words: atomic add on the low word returns the old value,
+//     the carry (old + v < old) is added to the high word — exact because additions commute and
+//     every wrap of the low word is observed by exactly one lane.
+//   * at the end each workgroup flushes its LDS groups into one global open-addressing table
+//     (global 64-bit CAS + atomics); rows whose group does not fit LDS go to the global table
+//     directly.  A final kernel compacts occupied slots into dense result columns.
+//   * keys are never copied into the table: a slot names a representative input row; equality
+//     is checked against that row's key columns (any key type, incl. strings), and the output key
+//     columns are a gather of the representative rows (late materialisation).
+#include "ldb_keys.h"
+#include <algorithm>
+#include <memory>
+
+#define GB_BLOCK 256
+#define GB_MAX_COLS 12
+#define GB_MAX_ACCS 20
+#define GB_MAX_CPREDS 6
+#define GB_MAX_OUT 16
+#define GB_MAX_WORDS 24
+
+enum { ACC_SUM64 = 0,
+       ACC_SUM128 = 1,
+       ACC_COUNT = 2,
+       ACC_MIN64 = 3,
+       ACC_MAX64 = 4,
+       ACC_SUMF64 = 5,
+       ACC_MINF64 = 6,
+       ACC_MAXF64 = 7 };
+
+struct DFactorG {
+   int32_t has_col;
+   int32_t col_idx; // into DGroupBy::cols
+   int64_t a, b;
+};
+struct DTermG {
+   int32_t n_factors, negate, div_pow10, pad;
+   DFactorG f[LDB_MAX_FACTORS];
+};
+struct DExprG {
+   int32_t n_terms, is_float;
+   DTermG t[LDB_MAX_TERMS];
+};
+struct DAcc {
+   int32_t kind;
+   int32_t word; // first accumulator word
+   int32_t n_cpreds;
+   int32_t cpred[LDB_MAX_AGG_PREDS]; // indexes into DGroupBy::cpreds
+   int32_t count_rows; // ACC_COUNT: 1 = count rows (COUNT(*)), 0 = count non-NULL expr
+   DExprG e;
+};
+struct DOut { // one output aggregate column
+   int32_t fn; // ldb_agg_fn
+   int32_t acc; // value accumulator
+   int32_t cnt_acc; // AVG divisor / validity counter (-1: always valid)
+   int32_t wide;
+   int32_t avg_pow10;
+   int32_t out_width; // bytes per output value
+   int32_t is_float;
+   int32_t pad;
+   void* out_values;
+   uint8_t* out_valid; // one byte per group (packed later) or NULL
+   DExprG e; // ANY: evaluated on the representative row
+};
+struct DGroupBy {
+   uint64_t n_rows;
+   int32_t n_preds, n_cols, n_accs, n_words, n_cpreds, n_outs;
+   int32_t keyless, use_lds;
+   uint32_t lds_slots, lds_reps; // S (pow2), R (pow2)
+   uint64_t g_cap; // global capacity (pow2)
+   uint64_t* g_keys;
+   uint64_t* g_acc; // word w of slot p at g_acc[w * g_cap + p]
+   uint32_t* g_flags; // [0] = overflow
+   DKeys keys;
+   DPred preds[LDB_MAX_PREDS];
+   DPred cpreds[GB_MAX_CPREDS];
+   DCol cols[GB_MAX_COLS];
+   DAcc accs[GB_MAX_ACCS];
+   uint64_t word_init[GB_MAX_WORDS];
+   DOut outs[GB_MAX_OUT];
+};
+
+// ---------------------------------------------------------------- expression evaluation
+// value cache: the low 64 bits of every referenced narrow column, loaded once per row into a
+// register array (indexed with s_set_gpr_idx by the wave-uniform col_idx).
+// (a bare array, not a struct member: only array allocas are promoted to registers)
+typedef long long RowVals[GB_MAX_COLS];
+
+__device__ __forceinline__ void d_load_vals(const DGroupBy* __restrict__ d, uint64_t i, RowVals& rv, uint32_t& rvalid) {
+   rvalid = 0; // bit c = column c non-NULL
+   const int nc = d->n_cols;
+#pragma unroll
+   for (int c = 0; c < GB_MAX_COLS; c++) {
+      long long x = 0;
+      if (c < nc) {
+         const DCol& col = d->cols[c];
+         uint32_t row = d_phys_row(col, i);
+         if (d_valid(col, row)) {
+            rvalid |= 1u << c;
+            if (col.type != LDB_T_FLOAT64 && col.type != LDB_T_FLOAT32) x = d_load_i64(col, row);
+            else x = __double_as_longlong(d_load_f64(col, row));
+         }
+      }
+      rv[c] = x;
+   }
+}
+
+// Σ_t ± Π_f (a + b*col) / 10^k in wrapping 128-bit arithmetic (DecimalMulOpLowering /
+// DecimalBinOpLowering, reference LowerToStd.cpp:653-699).  Returns false when a referenced
+// column is NULL.
+__device__ __forceinline__ bool d_eval_int(const DGroupBy* __restrict__ d, const DExprG& e, const RowVals& rv, uint32_t rvalid, uint64_t i, i128* out) {
+   u128 total = 0;
+   const int nt = e.n_terms;
+   for (int t = 0; t < nt; t++) {
+      const DTermG& tm = e.t[t];
+      u128 prod = 1;
+      const int nf = tm.n_factors;
+      for (int f = 0; f < nf; f++) {
+         const DFactorG& fa = tm.f[f];
+         i128 v = (i128) fa.a;
+         if (fa.has_col) {
+            const int ci = fa.col_idx;
+            if (!((rvalid >> ci) & 1)) return false;
+            const DCol& col = d->cols[ci];
+            if (d_is_wide(col)) v = (i128) ((u128) v + (u128) (i128) fa.b * (u128) d_load_i128(col, d_phys_row(col, i)));
+            else v += (i128) fa.b * (i128) rv[ci]; // 64x64 → 128, exact
+         }
+         prod = f == 0 ? (u128) v : prod * (u128) v;
+      }
+      if (tm.div_pow10 > 0) prod = (u128) d_sdiv128((i128) prod, d_pow10(tm.div_pow10));
+      total = tm.negate ? total - prod : total + prod;
+   }
+   *out = (i128) total;
+   return true;
+}
+__device__ __forceinline__ bool d_eval_flt(const DGroupBy* __restrict__ d, const DExprG& e, const RowVals& rv, uint32_t rvalid, double* out) {
+   double total = 0;
+   const int nt = e.n_terms;
+   for (int t = 0; t < nt; t++) {
+      const DTermG& tm = e.t[t];
+      double prod = 1;
+      const int nf = tm.n_factors;
+      for (int f = 0; f < nf; f++) {
+         const DFactorG& fa = tm.f[f];
+         double v = (double) fa.a;
+         if (fa.has_col) {
+            const int ci = fa.col_idx;
+            if (!((rvalid >> ci) & 1)) return false;
+            const DCol& col = d->cols[ci];
+            double x = (col.type == LDB_T_FLOAT64 || col.type == LDB_T_FLOAT32) ? __longlong_as_double(rv[ci]) : (double) rv[ci];
+            v += (double) fa.b * x;
+         }
+         prod *= v;
+      }
+      total = tm.negate ? total - prod : total + prod;
+   }
+   *out = total;
+   return true;
+}
+
+// ---------------------------------------------------------------- accumulator sinks
+// double min/max via CAS on the bit pattern
+__device__ __forceinline__ void d_atomic_minmax_f64(unsigned long long* p, double v, bool is_min) {
+   unsigned long long old = *p;
+   for (;;) {
+      double cur = __longlong_as_double((long long) old);
+      bool better = is_min ? v < cur : v > cur;
+      if (!better) return;
+      unsigned long long prev = atomicCAS(p, old, (unsigned long long) __double_as_longlong(v));
+      if (prev == old) return;
+      old = prev;
+   }
+}
+
+struct Sink {
+   unsigned long long* base; // word 0 of this slot
+   uint64_t stride; // distance between consecutive words of one slot
+   __device__ __forceinline__ unsigned long long* w(int k) const { return base + (uint64_t) k * stride; }
+};
+
+__device__ __forceinline__ void d_sink_add128(const Sink& s, int word, u128 v) {
+   unsigned long long lo = (unsigned long long) v, hi = (unsigned long long) (v >> 64);
+   unsigned long long old = atomicAdd(s.w(word), lo);
+   hi += (unsigned long long) (old + lo < old); // carry out of the low word
+   if (hi) atomicAdd(s.w(word + 1), hi);
+}
+
+// fold one input row into the accumulators of its group
+__device__ __forceinline__ void d_accumulate(const DGroupBy* __restrict__ d, const RowVals& rv, uint32_t rvalid, uint64_t i, const Sink& s) {
+   const int na = d->n_accs;
+   for (int a = 0; a < na; a++) {
+      const DAcc& acc = d->accs[a];
+      bool pass = true;
+      for (int p = 0; p < acc.n_cpreds; p++)
+         if (pass) pass = d_eval_pred(d->cpreds[acc.cpred[p]], i);
+      if (!pass) continue; // sum(case when p then x else 0 end) adds 0
+      if (acc.kind == ACC_COUNT && acc.count_rows) {
+         atomicAdd(s.w(acc.word), 1ull);
+         continue;
+      }
+      if (acc.e.is_float) {
+         double fv;
+         if (!d_eval_flt(d, acc.e, rv, rvalid, &fv)) continue;
+         switch (acc.kind) {
+            case ACC_COUNT: atomicAdd(s.w(acc.word), 1ull); break;
+            case ACC_SUMF64: atomicAdd((double*) s.w(acc.word), fv); break;
+            case ACC_MINF64: d_atomic_minmax_f64(s.w(acc.word), fv, true); break;
+            default: d_atomic_minmax_f64(s.w(acc.word), fv, false); break;
+         }
+         continue;
+      }
+      i128 v;
+      if (!d_eval_int(d, acc.e, rv, rvalid, i, &v)) continue;
+      switch (acc.kind) {
+         case ACC_COUNT: atomicAdd(s.w(acc.word), 1ull); break;
+         case ACC_SUM64: atomicAdd(s.w(acc.word), (unsigned long long) v); break; // i64 wrap = SUM in the argument type
+         case ACC_SUM128: d_sink_add128(s, acc.word, (u128) v); break;
+         case ACC_MIN64: atomicMin((long long*) s.w(acc.word), (long long) v); break;
+         default: atomicMax((long long*) s.w(acc.word), (long long) v); break;
+      }
+   }
+}
+
+// merge accumulator words of an LDS slot into the global slot (combine step of
+// MergePreAggrHashMap, reference SubOpToControlFlow.cpp:1861-1938)
+__device__ __forceinline__ void d_combine(const DGroupBy* __restrict__ d, const Sink& src, const Sink& dst) {
+   const int na = d->n_accs;
+   for (int a = 0; a < na; a++) {
+      const DAcc& acc = d->accs[a];
+      unsigned long long x = *src.w(acc.word);
+      switch (acc.kind) {
+         case ACC_COUNT:
+         case ACC_SUM64:
+            if (x) atomicAdd(dst.w(acc.word), x);
+            break;
+         case ACC_SUM128: {
+            unsigned long long hi = *src.w(acc.word + 1);
+            d_sink_add128(dst, acc.word, ((u128) hi << 64) | x);
+            break;
+         }
+         case ACC_MIN64: atomicMin((long long*) dst.w(acc.word), (long long) x); break;
+         case ACC_MAX64: atomicMax((long long*) dst.w(acc.word), (long long) x); break;
+         case ACC_SUMF64:
+            if (__longlong_as_double((long long) x) != 0.0) atomicAdd((double*) dst.w(acc.word), __longlong_as_double((long long) x));
+            break;
+         case ACC_MINF64: d_atomic_minmax_f64(dst.w(acc.word), __longlong_as_double((long long) x), true); break;
+         default: d_atomic_minmax_f64(dst.w(acc.word), __longlong_as_double((long long) x), false); break;
+      }
+   }
+}
+
+// ---------------------------------------------------------------- tables
+// global find-or-insert; returns slot or ~0 on overflow
+__device__ __forceinline__ uint64_t d_global_slot(const DGroupBy* __restrict__ d, uint64_t h, uint64_t i) {
+   if (d->keyless) return 0;
+   const uint64_t mask = d->g_cap - 1;
+   const uint64_t mine = (h & 0xFFFFFFFF00000000ull) | (uint64_t) ((uint32_t) i + 1u);
+   uint64_t pos = (h ^ (h >> 29)) & mask;
+   for (uint64_t step = 0; step <= mask; step++) {
+      unsigned long long w = __hip_atomic_load((unsigned long long*) &d->g_keys[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (w == 0) {
+         unsigned long long old = atomicCAS((unsigned long long*) &d->g_keys[pos], 0ull, (unsigned long long) mine);
+         if (old == 0) return pos;
+         w = old;
+      }
+      if ((w >> 32) == (h >> 32) && d_keys_equal(d->keys, (uint64_t) ((uint32_t) w - 1u), d->keys, i, true)) return pos;
+      pos = (pos + 1) & mask;
+   }
+   atomicOr(&d->g_flags[0], 1u);
+   return ~0ull;
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned long long gb_lds[];
+
+__global__ __launch_bounds__(GB_BLOCK) void k_groupby(const DGroupBy* __restrict__ d) {
+   const uint32_t S = d->lds_slots, R = d->lds_reps;
+   const uint32_t SR = S * R;
+   const int nw = d->n_words;
+   const bool use_lds = d->use_lds != 0;
+   unsigned long long* l_keys = gb_lds;
+   unsigned long long* l_acc = gb_lds + SR; // word w of index idx at l_acc[w*SR + idx], idx = slot*R + replica
+   if (use_lds) {
+      for (uint32_t k = threadIdx.x; k < SR; k += GB_BLOCK) l_keys[k] = d->keyless ? 1ull : 0ull;
+      for (int w = 0; w < nw; w++) {
+         unsigned long long init = d->word_init[w];
+         for (uint32_t k = threadIdx.x; k < SR; k += GB_BLOCK) l_acc[(uint32_t) w * SR + k] = init;
+      }
+      __syncthreads();
+   }
+   const uint64_t n = d->n_rows;
+   const uint32_t rep = threadIdx.x & (R - 1);
+   const int np = d->n_preds;
+   for (uint64_t i = blockIdx.x * (uint64_t) GB_BLOCK + threadIdx.x; i < n; i += (uint64_t) gridDim.x * GB_BLOCK) {
+      bool pass = true;
+      for (int p = 0; p < np; p++)
+         if (pass) pass = d_eval_pred(d->preds[p], i);
+      if (!pass) continue;
+      uint64_t h = 0;
+      if (!d->keyless) h = d_hash_keys(d->keys, i);
+      RowVals rv;
+      uint32_t rvalid;
+      d_load_vals(d, i, rv, rvalid);
+      int32_t lslot = -1;
+      if (use_lds) {
+         if (d->keyless) {
+            lslot = 0;
+         } else {
+            const unsigned long long mine = (h & 0xFFFFFFFF00000000ull) | (unsigned long long) ((uint32_t) i + 1u);
+            uint32_t pos = (uint32_t) (h >> 6) & (S - 1);
+            for (uint32_t step = 0; step < S; step++) {
+               unsigned long long w = l_keys[pos * R + rep];
+               if (w == 0) {
+                  unsigned long long old = atomicCAS(&l_keys[pos * R + rep], 0ull, mine);
+                  if (old == 0) {
+                     lslot = (int32_t) pos;
+                     break;
+                  }
+                  w = old;
+               }
+               if ((w >> 32) == (h >> 32) && d_keys_equal(d->keys, (uint64_t) ((uint32_t) w - 1u), d->keys, i, true)) {
+                  lslot = (int32_t) pos;
+                  break;
+               }
+               pos = (pos + 1) & (S - 1);
+               if (step >= 15) break; // long probe sequences: send the row to the global table instead
+            }
+         }
+      }
+      if (lslot >= 0) {
+         Sink s{l_acc + (uint32_t) lslot * R + rep, SR};
+         d_accumulate(d, rv, rvalid, i, s);
+      } else {
+         uint64_t g = d_global_slot(d, h, i);
+         if (g != ~0ull) {
+            Sink s{(unsigned long long*) d->g_acc + g, d->g_cap};
+            d_accumulate(d, rv, rvalid, i, s);
+         }
+      }
+   }
+   if (!use_lds) return;
+   __syncthreads();
+   // flush: every occupied (slot, replica) → global table
+   for (uint32_t k = threadIdx.x; k < SR; k += GB_BLOCK) {
+      unsigned long long w = l_keys[k];
+      if (w == 0) continue;
+      Sink src{l_acc + k, SR};
+      uint64_t g;
+      if (d->keyless) {
+         // skip untouched replicas cheaply: all-initial words contribute nothing
+         g = 0;
+      } else {
+         uint64_t i = (uint64_t) ((uint32_t) w - 1u);
+         uint64_t h = d_hash_keys(d->keys, i);
+         g = d_global_slot(d, h, i);
+         if (g == ~0ull) continue;
+      }
+      Sink dst{(unsigned long long*) d->g_acc + g, d->g_cap};
+      d_combine(d, src, dst);
+   }
+}
+
+__global__ void k_gb_init(uint64_t* keys, uint64_t* acc, const DGroupBy* __restrict__ d) {
+   const uint64_t cap = d->g_cap;
+   const int nw = d->n_words;
+   for (uint64_t p = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; p < cap; p += (uint64_t) gridDim.x * blockDim.x) {
+      keys[p] = (d->keyless && p == 0) ? 1ull : 0ull;
+      for (int w = 0; w < nw; w++) acc[(uint64_t) w * cap + p] = d->word_init[w];
+   }
+}
+
+// compact occupied slots → dense outputs
+__global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restrict__ rep_rows, unsigned long long* __restrict__ counter) {
+   const uint64_t cap = d->g_cap;
+   for (uint64_t p = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; p < cap; p += (uint64_t) gridDim.x * blockDim.x) {
+      uint64_t w = d->g_keys[p];
+      if (w == 0) continue;
+      uint64_t g = atomicAdd(counter, 1ull);
+      uint32_t rep = (uint32_t) w - 1u;
+      rep_rows[g] = rep;
+      const uint64_t* acc = d->g_acc + p;
+      for (int o = 0; o < d->n_outs; o++) {
+         const DOut& out = d->outs[o];
+         bool ok = true;
+         unsigned long long cnt = 0;
+         if (out.cnt_acc >= 0) {
+            cnt = acc[(uint64_t) d->accs[out.cnt_acc].word * cap];
+            ok = cnt != 0;
+         }
+         if (out.is_float) {
+            double v = 0;
+            if (out.fn == LDB_AGG_COUNT || out.fn == LDB_AGG_COUNT_STAR) {
+               // counts are integers; handled below
+            } else if (out.fn == LDB_AGG_ANY) {
+               RowVals rv;
+               uint32_t rvalid;
+               d_load_vals(d, rep, rv, rvalid);
+               ok = d_eval_flt(d, out.e, rv, rvalid, &v);
+            } else {
+               v = __longlong_as_double((long long) acc[(uint64_t) d->accs[out.acc].word * cap]);
+               if (out.fn == LDB_AGG_AVG && ok) v = v / (double) cnt;
+            }
+            if (out.fn != LDB_AGG_COUNT && out.fn != LDB_AGG_COUNT_STAR) {
+               ((double*) out.out_values)[g] = ok ? v : 0.0;
+               if (out.out_valid) out.out_valid[g] = ok ? 1 : 0;
+               continue;
+            }
+         }
+         i128 v = 0;
+         switch (out.fn) {
+            case LDB_AGG_COUNT:
+            case LDB_AGG_COUNT_STAR:
+               v = (i128) acc[(uint64_t) d->accs[out.acc].word * cap];
+               ok = true;
+               break;
+            case LDB_AGG_ANY: {
+               RowVals rv;
+               uint32_t rvalid;
+               d_load_vals(d, rep, rv, rvalid);
+               ok = d_eval_int(d, out.e, rv, rvalid, rep, &v);
+               break;
+            }
+            default: {
+               const DAcc& a = d->accs[out.acc];
+               uint64_t lo = acc[(uint64_t) a.word * cap];
+               if (a.kind == ACC_SUM128) v = (i128) (((u128) acc[(uint64_t) (a.word + 1) * cap] << 64) | lo);
+               else v = (i128) (int64_t) lo;
+               if (out.fn == LDB_AGG_AVG && ok) {
+                  // (sum * 10^k) sdiv count in i128 (DecimalOpScaledLowering, LowerToStd.cpp:631-651)
+                  v = d_sdiv128((i128) ((u128) v * (u128) d_pow10(out.avg_pow10)), (i128) cnt);
+               }
+               break;
+            }
+         }
+         if (!ok) v = 0;
+         switch (out.out_width) {
+            case 4: ((int32_t*) out.out_values)[g] = (int32_t) v; break;
+            case 8: ((int64_t*) out.out_values)[g] = (int64_t) v; break;
+            default: {
+               if (!out.wide && out.fn != LDB_AGG_AVG) v = (i128) (int64_t) v;
+               ((uint64_t*) out.out_values)[2 * g] = (uint64_t) v;
+               ((uint64_t*) out.out_values)[2 * g + 1] = (uint64_t) (v >> 64);
+            }
+         }
+         if (out.out_valid) out.out_valid[g] = ok ? 1 : 0;
+      }
+   }
+}
+
+__global__ void k_pack_valid_bytes(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bitmap, uint64_t n) {
+   uint64_t nb = (n + 7) / 8;
+   for (uint64_t b = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; b < nb; b += (uint64_t) gridDim.x * blockDim.x) {
+      uint8_t m = 0;
+      for (int k = 0; k < 8; k++)
+         if (b * 8 + k < n && bytes[b * 8 + k]) m |= (uint8_t) (1u << k);
+      bitmap[b] = m;
+   }
+}
+
+// ---------------------------------------------------------------- host side
+int32_t ldb_rel_select(ldb_ctx* ctx, ldb_rel* in, uint32_t* sel, int64_t n_sel, ldb_rel** out);
+int32_t ldb_gather_column(ldb_ctx* ctx, const ldb_rel* r, ldb_colref ref, ldb_column* out);
+
+static uint64_t next_pow2_u64(uint64_t v) {
+   uint64_t p = 1;
+   while (p < v) p <<= 1;
+   return p;
+}
+
+struct GbBuilder {
+   ldb_rel* in;
+   DGroupBy* h;
+   std::vector<ldb_colref> col_refs;
+   int32_t add_col(ldb_colref ref, int32_t* idx) {
+      for (size_t k = 0; k < col_refs.size(); k++)
+         if (col_refs[k].side == ref.side && col_refs[k].col == ref.col) {
+            *idx = (int32_t) k;
+            return LDB_OK;
+         }
+      if (col_refs.size() >= GB_MAX_COLS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: more than %d distinct aggregate input columns", GB_MAX_COLS);
+      DCol dc;
+      LDB_TRY(ldb_make_dcol(in, ref, &dc));
+      if (dc.type == LDB_T_UTF8) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: string column in an aggregate expression");
+      h->cols[col_refs.size()] = dc;
+      *idx = (int32_t) col_refs.size();
+      col_refs.push_back(ref);
+      h->n_cols = (int32_t) col_refs.size();
+      return LDB_OK;
+   }
+   int32_t conv_expr(const ldb_expr* e, DExprG* out, bool* nullable) {
+      memset(out, 0, sizeof(*out));
+      if (e->n_terms < 0 || e->n_terms > LDB_MAX_TERMS) LDB_FAIL(LDB_ERR_INVALID, "expression: %d terms (max %d)", e->n_terms, LDB_MAX_TERMS);
+      out->n_terms = e->n_terms;
+      out->is_float = e->is_float;
+      for (int t = 0; t < e->n_terms; t++) {
+         const ldb_term& tm = e->t[t];
+         if (tm.n_factors < 0 || tm.n_factors > LDB_MAX_FACTORS) LDB_FAIL(LDB_ERR_INVALID, "expression: %d factors (max %d)", tm.n_factors, LDB_MAX_FACTORS);
+         if (tm.div_pow10 < 0 || tm.div_pow10 > 38) LDB_FAIL(LDB_ERR_INVALID, "expression: div_pow10 %d", tm.div_pow10);
+         out->t[t].n_factors = tm.n_factors;
+         out->t[t].negate = tm.negate;
+         out->t[t].div_pow10 = tm.div_pow10;
+         for (int f = 0; f < tm.n_factors; f++) {
+            out->t[t].f[f].has_col = tm.f[f].has_col;
+            out->t[t].f[f].a = tm.f[f].a;
+            out->t[t].f[f].b = tm.f[f].b;
+            if (tm.f[f].has_col) {
+               int32_t idx;
+               LDB_TRY(add_col(tm.f[f].col, &idx));
+               out->t[t].f[f].col_idx = idx;
+               const ldb_column& c = in->sides[(size_t) tm.f[f].col.side].table->cols[(size_t) tm.f[f].col.col];
+               if (c.validity || in->sides[(size_t) tm.f[f].col.side].rowids) *nullable = *nullable || c.validity != nullptr;
+               bool colf = c.type.type == LDB_T_FLOAT64 || c.type.type == LDB_T_FLOAT32;
+               if (colf && !e->is_float) LDB_FAIL(LDB_ERR_INVALID, "expression: float column in an integer expression (set is_float)");
+            }
+         }
+      }
+      return LDB_OK;
+   }
+};
+
+static bool same_acc(const DAcc& a, const DAcc& b) {
+   if (a.kind != b.kind || a.n_cpreds != b.n_cpreds || a.count_rows != b.count_rows) return false;
+   for (int p = 0; p < a.n_cpreds; p++)
+      if (a.cpred[p] != b.cpred[p]) return false;
+   if (a.kind == ACC_COUNT && a.count_rows) return true;
+   return memcmp(&a.e, &b.e, sizeof(DExprG)) == 0;
+}
+
+extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds, int32_t n_preds, const ldb_colref* keys, int32_t n_keys,
+                                   const ldb_agg_spec* aggs, int32_t n_aggs, int64_t est_groups, ldb_table** out) {
+   if (!ctx || !in || !out) LDB_FAIL(LDB_ERR_INVALID, "groupby: NULL argument");
+   if (n_preds < 0 || n_preds > LDB_MAX_PREDS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: %d predicates (max %d)", n_preds, LDB_MAX_PREDS);
+   if (n_aggs < 0 || n_aggs > GB_MAX_OUT) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: %d aggregates (max %d)", n_aggs, GB_MAX_OUT);
+   if (in->n_rows >= (int64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: too many rows");
+   auto hp = std::make_unique<DGroupBy>();
+   DGroupBy* h = hp.get();
+   memset(h, 0, sizeof(*h));
+   h->n_rows = (uint64_t) in->n_rows;
+   h->n_preds = n_preds;
+   for (int32_t p = 0; p < n_preds; p++) LDB_TRY(ldb_make_dpred(in, &preds[p], &h->preds[p]));
+   LDB_TRY(ldb_make_dkeys(in, keys, n_keys, &h->keys));
+   h->keyless = n_keys == 0;
+   GbBuilder b{in, h, {}};
+
+   auto add_acc = [&](DAcc& a, int words, uint64_t init, int32_t* idx) -> int32_t {
+      for (int k = 0; k < h->n_accs; k++)
+         if (same_acc(h->accs[k], a)) {
+            *idx = k;
+            return LDB_OK;
+         }
+      if (h->n_accs >= GB_MAX_ACCS || h->n_words + words > GB_MAX_WORDS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: too many distinct accumulators");
+      a.word = h->n_words;
+      h->word_init[h->n_words] = init;
+      if (words == 2) h->word_init[h->n_words + 1] = 0;
+      h->n_words += words;
+      h->accs[h->n_accs] = a;
+      *idx = h->n_accs++;
+      return LDB_OK;
+   };
+
+   // output table layout: keys then aggregates
+   auto res = std::make_unique<ldb_table>();
+   res->ctx = ctx;
+   res->name = "groupby";
+   h->n_outs = n_aggs;
+   struct OutInfo {
+      ldb_coltype type;
+      int width;
+   };
+   std::vector<OutInfo> oinfo((size_t) n_aggs);
+   for (int32_t a = 0; a < n_aggs; a++) {
+      const ldb_agg_spec& sp = aggs[a];
+      DOut& o = h->outs[a];
+      memset(&o, 0, sizeof(o));
+      o.fn = sp.fn;
+      o.wide = sp.wide;
+      o.avg_pow10 = sp.avg_pow10;
+      o.acc = -1;
+      o.cnt_acc = -1;
+      o.is_float = sp.arg.is_float && sp.fn != LDB_AGG_COUNT && sp.fn != LDB_AGG_COUNT_STAR;
+      if (sp.n_preds < 0 || sp.n_preds > LDB_MAX_AGG_PREDS) LDB_FAIL(LDB_ERR_INVALID, "groupby: aggregate %d has %d predicates", a, sp.n_preds);
+      if (sp.avg_pow10 < 0 || sp.avg_pow10 > 38) LDB_FAIL(LDB_ERR_INVALID, "groupby: avg_pow10 %d", sp.avg_pow10);
+      DAcc acc;
+      memset(&acc, 0, sizeof(acc));
+      acc.n_cpreds = sp.n_preds;
+      for (int p = 0; p < sp.n_preds; p++) {
+         DPred dp;
+         LDB_TRY(ldb_make_dpred(in, &sp.preds[p], &dp));
+         int found = -1;
+         for (int k = 0; k < h->n_cpreds; k++)
+            if (!memcmp(&h->cpreds[k], &dp, sizeof(DPred))) found = k;
+         if (found < 0) {
+            if (h->n_cpreds >= GB_MAX_CPREDS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: too many conditional-aggregate predicates");
+            h->cpreds[h->n_cpreds] = dp;
+            found = h->n_cpreds++;
+         }
+         acc.cpred[p] = found;
+      }
+      bool nullable = false;
+      if (sp.fn != LDB_AGG_COUNT_STAR) LDB_TRY(b.conv_expr(&sp.arg, &acc.e, &nullable));
+      o.e = acc.e;
+      // counter of contributing rows: AVG divisor, and NULL-ness of SUM/MIN/MAX results
+      auto need_counter = [&](int32_t* idx) -> int32_t {
+         DAcc c = acc;
+         c.kind = ACC_COUNT;
+         c.count_rows = (!nullable && sp.fn != LDB_AGG_COUNT) ? 1 : 0;
+         if (c.count_rows) memset(&c.e, 0, sizeof(c.e));
+         return add_acc(c, 1, 0, idx);
+      };
+      switch (sp.fn) {
+         case LDB_AGG_COUNT_STAR: {
+            acc.kind = ACC_COUNT;
+            acc.count_rows = 1;
+            LDB_TRY(add_acc(acc, 1, 0, &o.acc));
+            break;
+         }
+         case LDB_AGG_COUNT: {
+            acc.kind = ACC_COUNT;
+            acc.count_rows = nullable ? 0 : 1;
+            if (acc.count_rows) memset(&acc.e, 0, sizeof(acc.e));
+            LDB_TRY(add_acc(acc, 1, 0, &o.acc));
+            break;
+         }
+         case LDB_AGG_SUM:
+         case LDB_AGG_AVG: {
+            if (sp.arg.is_float) {
+               acc.kind = ACC_SUMF64;
+               LDB_TRY(add_acc(acc, 1, 0, &o.acc));
+            } else if (sp.wide) {
+               acc.kind = ACC_SUM128;
+               LDB_TRY(add_acc(acc, 2, 0, &o.acc));
+            } else {
+               acc.kind = ACC_SUM64;
+               LDB_TRY(add_acc(acc, 1, 0, &o.acc));
+            }
+            // a conditional SUM (case … else 0) is never NULL; a plain SUM over no non-NULL input is
+            if (sp.fn == LDB_AGG_AVG || nullable || (h->keyless && sp.n_preds == 0)) LDB_TRY(need_counter(&o.cnt_acc));
+            break;
+         }
+         case LDB_AGG_MIN:
+         case LDB_AGG_MAX: {
+            if (sp.wide && !sp.arg.is_float) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: MIN/MAX over 128-bit decimals");
+            if (sp.arg.is_float) {
+               double init = sp.fn == LDB_AGG_MIN ? __builtin_inf() : -__builtin_inf();
+               uint64_t bits;
+               memcpy(&bits, &init, 8);
+               acc.kind = sp.fn == LDB_AGG_MIN ? ACC_MINF64 : ACC_MAXF64;
+               LDB_TRY(add_acc(acc, 1, bits, &o.acc));
+            } else {
+               acc.kind = sp.fn == LDB_AGG_MIN ? ACC_MIN64 : ACC_MAX64;
+               LDB_TRY(add_acc(acc, 1, sp.fn == LDB_AGG_MIN ? (uint64_t) INT64_MAX : (uint64_t) INT64_MIN, &o.acc));
+            }
+            if (nullable || h->keyless || sp.n_preds) LDB_TRY(need_counter(&o.cnt_acc));
+            break;
+         }
+         case LDB_AGG_ANY: break; // evaluated on the representative row
+         default: LDB_FAIL(LDB_ERR_INVALID, "groupby: unknown aggregate function %d", sp.fn);
+      }
+      ldb_coltype ot{};
+      ot.type = sp.out_type;
+      ot.precision = sp.out_precision;
+      ot.scale = sp.out_scale;
+      ot.nullable = 1;
+      if (o.is_float) ot.type = LDB_T_FLOAT64;
+      if (sp.fn == LDB_AGG_COUNT || sp.fn == LDB_AGG_COUNT_STAR) ot.type = LDB_T_INT64;
+      int w = ldb_width_of(ot, 0);
+      if (w != 4 && w != 8 && w != 16) LDB_FAIL(LDB_ERR_INVALID, "groupby: aggregate %d output type %d unsupported", a, ot.type);
+      o.out_width = w;
+      oinfo[(size_t) a] = {ot, w};
+   }
+   // at least one word so that every slot has something to initialise
+   if (h->n_words == 0) {
+      DAcc c;
+      memset(&c, 0, sizeof(c));
+      c.kind = ACC_COUNT;
+      c.count_rows = 1;
+      int32_t idx;
+      LDB_TRY(add_acc(c, 1, 0, &idx));
+   }
+
+   // ---- geometry
+   const int nw = h->n_words;
+   const size_t slot_bytes = 8 * (size_t) (1 + nw);
+   const size_t lds_budget = 60 * 1024;
+   uint64_t est = est_groups > 0 ? (uint64_t) est_groups : 0;
+   if (h->keyless) est = 1;
+   uint32_t S, R;
+   h->use_lds = 1;
+   if (h->keyless) {
+      S = 1;
+      R = 64;
+   } else if (est == 0) {
+      S = 1;
+      while ((size_t) S * 2 * slot_bytes <= lds_budget && S < 4096) S <<= 1;
+      R = 1;
+   } else {
+      S = (uint32_t) std::max<uint64_t>(8, next_pow2_u64(est * 2));
+      if ((size_t) S * slot_bytes > lds_budget) {
+         // more groups than LDS can pre-aggregate: the hit rate of a small cache is poor when
+         // the input is not clustered, so go straight to the global table
+         uint32_t smax = 1;
+         while ((size_t) smax * 2 * slot_bytes <= lds_budget) smax <<= 1;
+         S = smax;
+         if (est > (uint64_t) smax * 4) h->use_lds = 0;
+         R = 1;
+      } else {
+         R = 1;
+         while (R < 64 && (size_t) S * (R * 2) * slot_bytes <= lds_budget) R <<= 1;
+      }
+   }
+   h->lds_slots = S;
+   h->lds_reps = R;
+   size_t lds_bytes = h->use_lds ? (size_t) S * R * slot_bytes : 0;
+
+   uint64_t cap_guess = est ? est * 2 : std::min<uint64_t>((uint64_t) in->n_rows * 2, 1ull << 22);
+   uint64_t cap = std::max<uint64_t>(1024, next_pow2_u64(cap_guess));
+   const uint64_t cap_max = next_pow2_u64(std::max<uint64_t>(1024, (uint64_t) in->n_rows * 2));
+   if (cap > cap_max) cap = cap_max;
+
+   uint32_t* d_flags;
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_flags, 64));
+   DGroupBy* d = nullptr;
+   uint64_t n_groups = 0;
+   uint32_t* rep_rows = nullptr;
+   std::vector<void*> out_vals((size_t) n_aggs, nullptr);
+   std::vector<uint8_t*> out_valid((size_t) n_aggs, nullptr);
+   for (int attempt = 0;; attempt++) {
+      h->g_cap = cap;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &h->g_keys, 8 * (size_t) cap));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &h->g_acc, 8 * (size_t) cap * (size_t) nw));
+      h->g_flags = d_flags;
+      LDB_HIP(hipMemsetAsync(d_flags, 0, 64, ctx->stream));
+      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+      hipLaunchKernelGGL(k_gb_init, dim3(ldb_grid_for(ctx, (int64_t) cap, 256, 8)), dim3(256), 0, ctx->stream, h->g_keys, h->g_acc, d);
+      if (in->n_rows) {
+         int per_cu = lds_bytes > 40 * 1024 ? 2 : 4;
+         int grid = ldb_grid_for(ctx, in->n_rows, GB_BLOCK, per_cu);
+         hipLaunchKernelGGL(k_groupby, dim3(grid), dim3(GB_BLOCK), lds_bytes, ctx->stream, d);
+      }
+      LDB_HIP(hipGetLastError());
+      uint64_t flags = 0;
+      LDB_TRY(ldb_read_u64(ctx, d_flags, &flags));
+      if ((flags & 1) == 0) break;
+      // global table overflowed: retry larger (the estimate was too low)
+      ldb_dev_free(ctx, h->g_keys);
+      ldb_dev_free(ctx, h->g_acc);
+      ldb_dev_free(ctx, d);
+      if (cap >= cap_max) LDB_FAIL(LDB_ERR_HIP, "groupby: global table overflow at maximum capacity");
+      cap = std::min(cap * 8, cap_max);
+   }
+   // ---- finalize
+   // upper bound of groups = min(cap, rows) (+1 for keyless)
+   uint64_t max_groups = h->keyless ? 1 : std::min<uint64_t>(cap, (uint64_t) in->n_rows);
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &rep_rows, 4 * (size_t) (max_groups ? max_groups : 1)));
+   for (int32_t a = 0; a < n_aggs; a++) {
+      LDB_TRY(ldb_dev_alloc(ctx, &out_vals[(size_t) a], (size_t) oinfo[(size_t) a].width * (size_t) (max_groups ? max_groups : 1)));
+      h->outs[a].out_values = out_vals[(size_t) a];
+      if (h->outs[a].cnt_acc >= 0 || h->outs[a].fn == LDB_AGG_ANY) {
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &out_valid[(size_t) a], (size_t) (max_groups ? max_groups : 1)));
+         h->outs[a].out_valid = out_valid[(size_t) a];
+      }
+   }
+   ldb_dev_free(ctx, d);
+   LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+   LDB_HIP(hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
+   hipLaunchKernelGGL(k_gb_finalize, dim3(ldb_grid_for(ctx, (int64_t) cap, 256, 8)), dim3(256), 0, ctx->stream, d, rep_rows, (unsigned long long*) ctx->d_scratch);
+   LDB_HIP(hipGetLastError());
+   LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &n_groups));
+   ldb_dev_free(ctx, h->g_keys);
+   ldb_dev_free(ctx, h->g_acc);
+   ldb_dev_free(ctx, d);
+   ldb_dev_free(ctx, d_flags);
+
+   // ---- result table: key columns = gather of representative rows, then aggregates
+   res->n_rows = (int64_t) n_groups;
+   res->cols.resize((size_t) (n_keys + n_aggs));
+   ldb_rel* reps = nullptr;
+   LDB_TRY(ldb_rel_select(ctx, in, rep_rows, (int64_t) n_groups, &reps));
+   for (int32_t k = 0; k < n_keys; k++) {
+      int32_t s = ldb_gather_column(ctx, reps, keys[k], &res->cols[(size_t) k]);
+      if (s != LDB_OK) return s;
+   }
+   ldb_gpu_rel_release(ctx, reps);
+   for (int32_t a = 0; a < n_aggs; a++) {
+      ldb_column& c = res->cols[(size_t) (n_keys + a)];
+      char nm[32];
+      snprintf(nm, sizeof(nm), "agg%d", a);
+      c.name = nm;
+      c.type = oinfo[(size_t) a].type;
+      c.width = oinfo[(size_t) a].width;
+      c.values = out_vals[(size_t) a];
+      c.value_bytes = (int64_t) n_groups * c.width;
+      c.owned = true;
+      if (out_valid[(size_t) a]) {
+         // pack the per-group validity bytes; drop the bitmap when nothing is NULL
+         uint8_t* bm;
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &bm, (size_t) ((n_groups + 7) / 8 + 1)));
+         if (n_groups) hipLaunchKernelGGL(k_pack_valid_bytes, dim3(ldb_grid_for(ctx, (int64_t) n_groups, 256, 4)), dim3(256), 0, ctx->stream, out_valid[(size_t) a], bm, n_groups);
+         std::vector<uint8_t> hb((size_t) (n_groups ? n_groups : 1));
+         if (n_groups) LDB_HIP(hipMemcpyAsync(hb.data(), out_valid[(size_t) a], (size_t) n_groups, hipMemcpyDeviceToHost, ctx->stream));
+         LDB_HIP(hipStreamSynchronize(ctx->stream));
+         int64_t nulls = 0;
+         for (uint64_t g = 0; g < n_groups; g++) nulls += hb[(size_t) g] ? 0 : 1;
+         ldb_dev_free(ctx, out_valid[(size_t) a]);
+         if (nulls) {
+            c.validity = bm;
+            c.null_count = nulls;
+         } else {
+            ldb_dev_free(ctx, bm);
+         }
+      }
+   }
+   LDB_HIP(hipGetLastError());
+   *out = res.release();
+   return LDB_OK;
+}

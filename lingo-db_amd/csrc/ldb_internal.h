@@ -1,0 +1,133 @@
+// ldb_internal.h — host-side structures of liblingodb_gpu.so (not part of the ABI).
+#pragma once
+#include "../../include/lingodb_gpu.h"
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------- errors
+void ldb_set_error(const char* fmt, ...);
+#define LDB_FAIL(code, ...)        \
+   do {                            \
+      ldb_set_error(__VA_ARGS__);  \
+      return (code);               \
+   } while (0)
+#define LDB_HIP(expr)                                                                       \
+   do {                                                                                     \
+      hipError_t e_ = (expr);                                                               \
+      if (e_ != hipSuccess) {                                                               \
+         ldb_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+         return e_ == hipErrorOutOfMemory ? LDB_ERR_OOM : LDB_ERR_HIP;                      \
+      }                                                                                     \
+   } while (0)
+#define LDB_TRY(expr)            \
+   do {                          \
+      int32_t s_ = (expr);       \
+      if (s_ != LDB_OK) return s_; \
+   } while (0)
+
+// ---------------------------------------------------------------- device-visible descriptors
+// One column as the kernels see it.  `rowids` belongs to the relation side the column is read
+// through (NULL = identity), so a kernel reads logical row i at values[rowids ? rowids[i] : i].
+struct DCol {
+   const void* values;
+   const int64_t* offsets; // utf8
+   const uint8_t* validity; // Arrow bitmap or NULL
+   const uint32_t* rowids;
+   int32_t type; // ldb_type
+   int32_t width; // bytes per value on the device
+   int32_t precision;
+   int32_t scale;
+};
+
+#define LDB_MAX_PREDS 8
+#define LDB_MAX_IN 8
+#define LDB_STR_INLINE 48
+struct DPred {
+   DCol col;
+   DCol rhs;
+   int32_t op;
+   int32_t rhs_kind;
+   uint64_t lo;
+   int64_t hi;
+   double f;
+   int32_t str_len;
+   int32_t n_in;
+   char str[LDB_STR_INLINE];
+   // IN lists: ints as lo/hi; strings packed into in_blob with in_off[k]..in_off[k+1]
+   uint64_t in_lo[LDB_MAX_IN];
+   int64_t in_hi[LDB_MAX_IN];
+   int32_t in_off[LDB_MAX_IN + 1];
+   char in_blob[LDB_MAX_IN * 16];
+};
+
+// ---------------------------------------------------------------- host objects
+struct ldb_column {
+   std::string name;
+   ldb_coltype type{};
+   int32_t width = 0; // device bytes per value (0 for utf8)
+   void* values = nullptr; // device
+   int64_t* offsets = nullptr; // device, utf8: int64[n+1]
+   uint8_t* validity = nullptr; // device bitmap or NULL
+   int64_t value_bytes = 0; // bytes in `values`
+   int64_t null_count = 0;
+   bool owned = true;
+};
+
+struct ldb_ctx {
+   int device = 0;
+   hipStream_t stream = nullptr;
+   bool own_stream = false;
+   int cus = 256;
+   std::vector<hipEvent_t> timers; // pairs (start, stop)
+   // small pinned staging area for counts read back from the device
+   int64_t* h_scratch = nullptr; // pinned, 64 words
+   int64_t* d_scratch = nullptr; // device, 64 words
+};
+
+struct ldb_table {
+   ldb_ctx* ctx = nullptr;
+   std::string name;
+   int64_t n_rows = 0;
+   std::vector<ldb_column> cols;
+};
+
+struct ldb_rel_side {
+   const ldb_table* table = nullptr;
+   uint32_t* rowids = nullptr; // device, NULL = identity
+   bool owned = false;
+};
+struct ldb_rel {
+   ldb_ctx* ctx = nullptr;
+   int64_t n_rows = 0;
+   std::vector<ldb_rel_side> sides;
+};
+
+// device allocation helpers (stream-ordered pool)
+int32_t ldb_dev_alloc(ldb_ctx* ctx, void** out, size_t bytes);
+void ldb_dev_free(ldb_ctx* ctx, void* p);
+// upload a host descriptor struct into device memory (stream-ordered)
+int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_out);
+
+int32_t ldb_make_dcol(const ldb_rel* r, ldb_colref ref, DCol* out);
+int32_t ldb_make_dpred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out);
+int32_t ldb_width_of(const ldb_coltype& t, int narrow);
+
+// launch geometry: blocks for a grid-stride kernel over n items
+static inline int ldb_grid_for(const ldb_ctx* ctx, int64_t n, int block, int per_cu) {
+   int64_t want = (n + block - 1) / block;
+   int64_t cap = (int64_t) ctx->cus * per_cu;
+   if (want < 1) want = 1;
+   return (int) (want < cap ? want : cap);
+}
+
+// exclusive scan of n uint32 values on the device (in place allowed); total written to *d_total (uint64)
+int32_t ldb_exclusive_scan_u32(ldb_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, uint64_t* d_total);
+int32_t ldb_exclusive_scan_i64(ldb_ctx* ctx, const int64_t* d_in, int64_t* d_out, int64_t n, int64_t* d_total);
+// blocking read of one 64-bit device word
+int32_t ldb_read_u64(ldb_ctx* ctx, const void* d_word, uint64_t* out);
+// new relation helpers
+ldb_rel* ldb_rel_new(ldb_ctx* ctx);

@@ -1,0 +1,394 @@
+// ldb_join.hip — hash-join build and probe.
+// Replaces (reference): build-side materialisation + HashIndexedView::build
+// (src/runtime/GrowingBuffer.cpp:44, src/runtime/LazyJoinHashtable.cpp:12-34) and the generated
+// probe (LookupHashIndexedViewLowering / ScanListLowering,
+// src/compiler/Conversion/SubOpToControlFlow/SubOpToControlFlow.cpp:2558-2586, 2254-2313).
+//
+// MI355X design: no row store, no pointer chains, no bloom-tagged pointers.  The table is a flat
+// open-addressing array of 64-bit words claimed with ONE global CAS each:
+//   KEY32 mode (one integer key of <= 32 bit — every TPC-H join):  word = key32 << 32 | (row + 1)
+//            → a probe needs exactly one random 8-byte access per visited slot, no key re-check
+//            (the CPU path drops the hash compare in the same case, SpecializeSubOpPass.cpp:110-118);
+//   TAG mode (anything else, incl. strings / composite keys):      word = hash[63:32] << 32 | (row + 1)
+//            → tag match is verified on the build row's key columns (late materialised).
+// Capacity nextPow2(2n) (load factor <= 0.5) instead of the CPU's chained nextPow2(1.25n).
+// Duplicate build keys occupy separate slots; a probe walks until the first empty slot.
+// Output pairs are appended with wave-aggregated atomics (order unspecified, as in the reference
+// where morsels finish in any order); SEMI/ANTI results are produced in ascending probe order
+// through a ballot bitmap.
+#include "ldb_keys.h"
+#include <algorithm>
+#include <memory>
+
+struct ldb_hashtable {
+   ldb_ctx* ctx = nullptr;
+   ldb_rel* build = nullptr; // referenced (kept alive by the caller until release)
+   std::vector<ldb_colref> keys;
+   uint64_t* slots = nullptr;
+   uint64_t cap = 0;
+   int32_t key32 = 0;
+   int32_t unique = 0;
+   int64_t n_inserted = 0;
+};
+
+struct DJoin {
+   uint64_t n_rows; // rows of the relation the kernel iterates (build or probe)
+   uint64_t cap;
+   uint64_t* slots;
+   int32_t key32;
+   int32_t kind;
+   DKeys bkeys;
+   DKeys pkeys;
+   // outputs
+   uint32_t* out_probe;
+   uint32_t* out_build;
+   uint64_t out_cap;
+   unsigned long long* counter; // [0] = rows produced (may exceed out_cap), [1] = matches
+   uint64_t* bitmap; // SEMI / ANTI
+   uint8_t* mark; // MARK
+};
+
+__device__ __forceinline__ bool d_is_int32ish(const DCol& c) {
+   return c.type == LDB_T_INT32 || c.type == LDB_T_DATE32 || c.type == LDB_T_CHAR4 || c.type == LDB_T_INT16 || c.type == LDB_T_INT8;
+}
+
+__global__ void k_join_build(const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows, mask = d->cap - 1;
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      bool nul;
+      uint64_t h = d_hash_keys(d->bkeys, i, &nul);
+      if (nul) continue; // a NULL key can never be matched (eq on NULL is false)
+      uint64_t word;
+      if (d->key32) {
+         const DCol& c = d->bkeys.cols[0];
+         word = ((uint64_t) (uint32_t) d_load_i64(c, d_phys_row(c, i)) << 32) | (uint64_t) ((uint32_t) i + 1u);
+      } else {
+         word = (h & 0xFFFFFFFF00000000ull) | (uint64_t) ((uint32_t) i + 1u);
+      }
+      uint64_t pos = h & mask;
+      for (;;) {
+         unsigned long long old = atomicCAS((unsigned long long*) &d->slots[pos], 0ull, (unsigned long long) word);
+         if (old == 0) break;
+         pos = (pos + 1) & mask;
+      }
+   }
+}
+
+// One probe row → visits its slot run.  EMIT is called for every match with the build row.
+template <typename EMIT>
+__device__ __forceinline__ uint32_t d_probe_row(const DJoin* __restrict__ d, uint64_t i, EMIT emit) {
+   bool nul;
+   uint64_t h = d_hash_keys(d->pkeys, i, &nul);
+   if (nul) return 0;
+   const uint64_t mask = d->cap - 1;
+   uint64_t pos = h & mask;
+   uint32_t matches = 0;
+   if (d->key32) {
+      const DCol& c = d->pkeys.cols[0];
+      int64_t kv = d_load_i64(c, d_phys_row(c, i));
+      if (kv != (int64_t) (int32_t) kv) return 0; // wider probe value can equal no 32-bit build key
+      const uint32_t key = (uint32_t) kv;
+      for (;;) {
+         uint64_t w = d->slots[pos];
+         if (w == 0) break;
+         if ((uint32_t) (w >> 32) == key) {
+            matches++;
+            if (!emit((uint32_t) w - 1u)) break;
+         }
+         pos = (pos + 1) & mask;
+      }
+   } else {
+      for (;;) {
+         uint64_t w = d->slots[pos];
+         if (w == 0) break;
+         if ((w >> 32) == (h >> 32) && d_keys_equal(d->bkeys, (uint64_t) ((uint32_t) w - 1u), d->pkeys, i, false)) {
+            matches++;
+            if (!emit((uint32_t) w - 1u)) break;
+         }
+         pos = (pos + 1) & mask;
+      }
+   }
+   return matches;
+}
+
+// INNER / LEFT_OUTER / SINGLE: append (probe, build) pairs
+__global__ void k_join_probe_pairs(const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows;
+   const int kind = d->kind;
+   unsigned long long local_matches = 0;
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      uint32_t m = d_probe_row(d, i, [&](uint32_t brow) {
+         unsigned long long idx = atomicAdd(&d->counter[0], 1ull);
+         if (idx < d->out_cap) {
+            d->out_probe[idx] = (uint32_t) i;
+            d->out_build[idx] = brow;
+         }
+         return kind != LDB_JOIN_SINGLE; // SINGLE: at most one match
+      });
+      local_matches += m;
+      if (m == 0 && kind != LDB_JOIN_INNER) {
+         unsigned long long idx = atomicAdd(&d->counter[0], 1ull);
+         if (idx < d->out_cap) {
+            d->out_probe[idx] = (uint32_t) i;
+            d->out_build[idx] = LDB_NULL_ROW;
+         }
+      }
+   }
+   if (local_matches) atomicAdd(&d->counter[1], local_matches);
+}
+
+// count matches only (probe micro-benchmark: Grows/s)
+__global__ void k_join_probe_count(const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows;
+   unsigned long long local = 0;
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+      local += d_probe_row(d, i, [](uint32_t) { return true; });
+   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+   if ((threadIdx.x & 63) == 0 && local) atomicAdd(&d->counter[1], local);
+}
+
+// SEMI / ANTI / MARK: existence per probe row → bitmap word per wave (rows in ascending order)
+__global__ void k_join_probe_exists(const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows;
+   const uint64_t n_words = (n + 63) / 64;
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+   unsigned long long local = 0;
+   for (uint64_t w = wave; w < n_words; w += n_waves) {
+      uint64_t i = w * 64 + lane;
+      bool hit = false;
+      if (i < n) hit = d_probe_row(d, i, [](uint32_t) { return false; }) != 0;
+      bool keep = i < n && (d->kind == LDB_JOIN_ANTI ? !hit : hit);
+      if (d->mark && i < n) d->mark[i] = hit ? 1 : 0;
+      uint64_t m = __ballot(keep);
+      if (lane == 0) {
+         d->bitmap[w] = m;
+         local += (unsigned long long) __popcll(m);
+      }
+   }
+   if (lane == 0 && local) atomicAdd(&d->counter[0], local);
+}
+
+// bitmap → ascending row ids (single wave per 64-bit word, block prefix via global scan of word popcounts)
+__global__ void k_word_pop(const uint64_t* __restrict__ bitmap, uint32_t* __restrict__ pop, uint64_t n_words) {
+   for (uint64_t w = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; w < n_words; w += (uint64_t) gridDim.x * blockDim.x) pop[w] = (uint32_t) __popcll(bitmap[w]);
+}
+__global__ void k_bitmap_expand(const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ word_off, uint32_t* __restrict__ out, uint64_t n_words) {
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+   for (uint64_t w = wave; w < n_words; w += n_waves) {
+      uint64_t m = bitmap[w];
+      if ((m >> lane) & 1) out[word_off[w] + d_rank_in(m)] = (uint32_t) (w * 64 + lane);
+   }
+}
+
+// out[j] = ids[sel[j]] with LDB_NULL_ROW passthrough
+__global__ void k_compose_null(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ sel, uint32_t* __restrict__ out, uint64_t n) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      uint32_t s = sel[i];
+      out[i] = s == LDB_NULL_ROW ? LDB_NULL_ROW : (ids ? ids[s] : s);
+   }
+}
+
+static uint64_t next_pow2_u64(uint64_t v) {
+   uint64_t p = 1;
+   while (p < v) p <<= 1;
+   return p;
+}
+
+int32_t ldb_rel_select(ldb_ctx* ctx, ldb_rel* in, uint32_t* sel, int64_t n_sel, ldb_rel** out);
+
+extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_colref* keys, int32_t n_keys, int32_t build_unique, ldb_hashtable** out) {
+   if (!ctx || !build || !out || n_keys < 1) LDB_FAIL(LDB_ERR_INVALID, "join_build: bad argument");
+   auto ht = std::make_unique<ldb_hashtable>();
+   ht->ctx = ctx;
+   ht->build = build;
+   ht->keys.assign(keys, keys + n_keys);
+   ht->unique = build_unique;
+   auto hp = std::make_unique<DJoin>();
+   DJoin* h = hp.get();
+   memset(h, 0, sizeof(*h));
+   LDB_TRY(ldb_make_dkeys(build, keys, n_keys, &h->bkeys));
+   const DCol& k0 = h->bkeys.cols[0];
+   ht->key32 = (n_keys == 1 && (k0.type == LDB_T_INT32 || k0.type == LDB_T_DATE32 || k0.type == LDB_T_CHAR4 || k0.type == LDB_T_INT16 || k0.type == LDB_T_INT8)) ? 1 : 0;
+   ht->cap = std::max<uint64_t>(64, next_pow2_u64((uint64_t) build->n_rows * 2));
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->slots, 8 * (size_t) ht->cap));
+   LDB_HIP(hipMemsetAsync(ht->slots, 0, 8 * (size_t) ht->cap, ctx->stream));
+   h->n_rows = (uint64_t) build->n_rows;
+   h->cap = ht->cap;
+   h->slots = ht->slots;
+   h->key32 = ht->key32;
+   DJoin* d;
+   LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+   if (build->n_rows) hipLaunchKernelGGL(k_join_build, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d);
+   LDB_HIP(hipGetLastError());
+   ldb_dev_free(ctx, d);
+   *out = ht.release();
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_hashtable_release(ldb_ctx* ctx, ldb_hashtable* ht) {
+   if (!ht) return LDB_OK;
+   ldb_dev_free(ctx, ht->slots);
+   delete ht;
+   return LDB_OK;
+}
+extern "C" int64_t ldb_gpu_hashtable_slots(const ldb_hashtable* ht) { return ht ? (int64_t) ht->cap : -1; }
+
+static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, DJoin* h) {
+   if ((size_t) n_keys != ht->keys.size()) LDB_FAIL(LDB_ERR_INVALID, "join_probe: %d probe keys vs %zu build keys", n_keys, ht->keys.size());
+   memset(h, 0, sizeof(*h));
+   LDB_TRY(ldb_make_dkeys(ht->build, ht->keys.data(), n_keys, &h->bkeys));
+   LDB_TRY(ldb_make_dkeys(probe, keys, n_keys, &h->pkeys));
+   for (int k = 0; k < n_keys; k++) {
+      bool sa = h->bkeys.cols[k].type == LDB_T_UTF8, sb = h->pkeys.cols[k].type == LDB_T_UTF8;
+      bool fa = h->bkeys.cols[k].type == LDB_T_FLOAT64 || h->bkeys.cols[k].type == LDB_T_FLOAT32;
+      bool fb = h->pkeys.cols[k].type == LDB_T_FLOAT64 || h->pkeys.cols[k].type == LDB_T_FLOAT32;
+      if (sa != sb || fa != fb) LDB_FAIL(LDB_ERR_INVALID, "join_probe: key %d type class differs between build and probe", k);
+      // the hash must agree on both sides: date32 hashes in ns, plain ints as is
+      if ((h->bkeys.cols[k].type == LDB_T_DATE32) != (h->pkeys.cols[k].type == LDB_T_DATE32)) LDB_FAIL(LDB_ERR_INVALID, "join_probe: key %d date vs non-date", k);
+      bool wa = h->bkeys.cols[k].type == LDB_T_DECIMAL128 && h->bkeys.cols[k].precision >= 19;
+      bool wb = h->pkeys.cols[k].type == LDB_T_DECIMAL128 && h->pkeys.cols[k].precision >= 19;
+      if (wa != wb) LDB_FAIL(LDB_ERR_INVALID, "join_probe: key %d decimal width class differs (cast to a common type first)", k);
+   }
+   h->n_rows = (uint64_t) probe->n_rows;
+   h->cap = ht->cap;
+   h->slots = ht->slots;
+   h->key32 = ht->key32;
+   return LDB_OK;
+}
+
+extern "C" int32_t ldb_gpu_join_probe_count(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int64_t* matches) {
+   if (!ctx || !ht || !probe || !matches) LDB_FAIL(LDB_ERR_INVALID, "join_probe_count: NULL argument");
+   auto hp = std::make_unique<DJoin>();
+   LDB_TRY(make_probe_desc(ht, probe, keys, n_keys, hp.get()));
+   hp->kind = LDB_JOIN_INNER;
+   unsigned long long* counter = (unsigned long long*) (ctx->d_scratch + 16);
+   LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
+   hp->counter = counter;
+   DJoin* d;
+   LDB_TRY(ldb_dev_upload(ctx, hp.get(), sizeof(DJoin), (void**) &d));
+   if (probe->n_rows) hipLaunchKernelGGL(k_join_probe_count, dim3(ldb_grid_for(ctx, probe->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d);
+   LDB_HIP(hipGetLastError());
+   uint64_t m = 0;
+   LDB_TRY(ldb_read_u64(ctx, counter + 1, &m));
+   ldb_dev_free(ctx, d);
+   *matches = (int64_t) m;
+   return LDB_OK;
+}
+
+extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind, ldb_rel** out,
+                                      ldb_table** mark_out) {
+   if (!ctx || !ht || !probe || !out) LDB_FAIL(LDB_ERR_INVALID, "join_probe: NULL argument");
+   if (kind < LDB_JOIN_INNER || kind > LDB_JOIN_SINGLE) LDB_FAIL(LDB_ERR_INVALID, "join_probe: bad kind %d", kind);
+   if (probe->sides.size() + ht->build->sides.size() > LDB_MAX_SIDES && (kind == LDB_JOIN_INNER || kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE))
+      LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: result would have more than %d sides (materialize first)", LDB_MAX_SIDES);
+   auto hp = std::make_unique<DJoin>();
+   DJoin* h = hp.get();
+   LDB_TRY(make_probe_desc(ht, probe, keys, n_keys, h));
+   h->kind = kind;
+   unsigned long long* counter = (unsigned long long*) (ctx->d_scratch + 16);
+   h->counter = counter;
+   const int64_t n = probe->n_rows;
+   const int grid = ldb_grid_for(ctx, n, 256, 8);
+
+   if (kind == LDB_JOIN_SEMI || kind == LDB_JOIN_ANTI || kind == LDB_JOIN_MARK) {
+      const int64_t n_words = (n + 63) / 64;
+      uint64_t* bitmap;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmap, 8 * (size_t) (n_words ? n_words : 1)));
+      h->bitmap = bitmap;
+      ldb_table* mark = nullptr;
+      if (kind == LDB_JOIN_MARK) {
+         if (!mark_out) LDB_FAIL(LDB_ERR_INVALID, "join_probe: MARK needs mark_out");
+         ldb_coltype t = {LDB_T_BOOL8, 0, 0, 0};
+         const char* nm = "mark";
+         LDB_TRY(ldb_gpu_table_alloc(ctx, "mark", 1, &t, &nm, n, nullptr, 0, &mark));
+         h->mark = (uint8_t*) mark->cols[0].values;
+      }
+      LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
+      DJoin* d;
+      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+      if (n) hipLaunchKernelGGL(k_join_probe_exists, dim3(grid), dim3(256), 0, ctx->stream, d);
+      LDB_HIP(hipGetLastError());
+      ldb_dev_free(ctx, d);
+      if (kind == LDB_JOIN_MARK) {
+         ldb_dev_free(ctx, bitmap);
+         *mark_out = mark;
+         // all probe rows, identity order: share the probe's sides by selecting everything
+         ldb_rel* r = ldb_rel_new(ctx);
+         r->n_rows = n;
+         for (auto& s : probe->sides) {
+            ldb_rel_side ns{s.table, nullptr, false};
+            if (s.rowids) {
+               LDB_TRY(ldb_dev_alloc(ctx, (void**) &ns.rowids, 4 * (size_t) (n ? n : 1)));
+               if (n) LDB_HIP(hipMemcpyAsync(ns.rowids, s.rowids, 4 * (size_t) n, hipMemcpyDeviceToDevice, ctx->stream));
+               ns.owned = true;
+            }
+            r->sides.push_back(ns);
+         }
+         *out = r;
+         return LDB_OK;
+      }
+      uint64_t total = 0;
+      LDB_TRY(ldb_read_u64(ctx, counter, &total));
+      uint32_t *pop, *off, *sel;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) (n_words ? n_words : 1)));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) (n_words ? n_words : 1)));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &sel, 4 * (size_t) (total ? total : 1)));
+      if (n_words) {
+         hipLaunchKernelGGL(k_word_pop, dim3(ldb_grid_for(ctx, n_words, 256, 8)), dim3(256), 0, ctx->stream, bitmap, pop, (uint64_t) n_words);
+         LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, n_words, nullptr));
+         if (total) hipLaunchKernelGGL(k_bitmap_expand, dim3(ldb_grid_for(ctx, n_words * 64, 256, 8)), dim3(256), 0, ctx->stream, bitmap, off, sel, (uint64_t) n_words);
+      }
+      LDB_HIP(hipGetLastError());
+      ldb_dev_free(ctx, bitmap);
+      ldb_dev_free(ctx, pop);
+      ldb_dev_free(ctx, off);
+      return ldb_rel_select(ctx, probe, sel, (int64_t) total, out);
+   }
+
+   // pair-producing kinds: optimistic capacity, exact retry on overflow
+   uint64_t out_cap = std::max<uint64_t>(1024, (uint64_t) n);
+   uint32_t *op = nullptr, *ob = nullptr;
+   uint64_t produced = 0;
+   for (int attempt = 0; attempt < 2; attempt++) {
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &op, 4 * (size_t) out_cap));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &ob, 4 * (size_t) out_cap));
+      h->out_probe = op;
+      h->out_build = ob;
+      h->out_cap = out_cap;
+      LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
+      DJoin* d;
+      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+      if (n) hipLaunchKernelGGL(k_join_probe_pairs, dim3(grid), dim3(256), 0, ctx->stream, d);
+      LDB_HIP(hipGetLastError());
+      LDB_TRY(ldb_read_u64(ctx, counter, &produced));
+      ldb_dev_free(ctx, d);
+      if (produced <= out_cap) break;
+      ldb_dev_free(ctx, op);
+      ldb_dev_free(ctx, ob);
+      if (produced >= (uint64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: %llu result rows exceed uint32 row ids", (unsigned long long) produced);
+      out_cap = produced;
+   }
+   // result relation: probe sides composed with op, build sides composed with ob
+   ldb_rel* r = ldb_rel_new(ctx);
+   r->n_rows = (int64_t) produced;
+   const int cg = ldb_grid_for(ctx, (int64_t) produced, 256, 8);
+   auto add_sides = [&](ldb_rel* src, uint32_t* sel) -> int32_t {
+      for (auto& s : src->sides) {
+         ldb_rel_side ns{s.table, nullptr, true};
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &ns.rowids, 4 * (size_t) (produced ? produced : 1)));
+         if (produced) hipLaunchKernelGGL(k_compose_null, dim3(cg), dim3(256), 0, ctx->stream, (const uint32_t*) s.rowids, (const uint32_t*) sel, ns.rowids, produced);
+         r->sides.push_back(ns);
+      }
+      return LDB_OK;
+   };
+   LDB_TRY(add_sides(probe, op));
+   LDB_TRY(add_sides(ht->build, ob));
+   LDB_HIP(hipGetLastError());
+   ldb_dev_free(ctx, op);
+   ldb_dev_free(ctx, ob);
+   *out = r;
+   return LDB_OK;
+}

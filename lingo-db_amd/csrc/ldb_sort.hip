@@ -1,0 +1,273 @@
+// ldb_sort.hip — sort, top-k and hash-radix partitioning (all built on one stable counting sort).
+// Replaces (reference): GrowingBuffer::sort / parallelSort (src/runtime/GrowingBuffer.cpp:54-78,
+// src/runtime/Sorting.cpp:343-393) with the comparator of db.sort_compare
+// (src/compiler/Conversion/DBToStd/LowerToStd.cpp:1046-1064) and Heap (src/runtime/Heap.cpp:8-72).
+//
+// MI355X design: the CPU sorts row POINTERS through an indirect comparator call.  Here every row
+// gets an order-preserving fixed-width byte key (sign-flipped big-endian integers, zero-padded
+// strings + length, bytes inverted for DESC) and a row permutation is LSD-radix-sorted on it,
+// 4 bits per pass with a stable counting sort (per-thread register histograms → one device scan
+// of the [digit][thread] matrix → ordered scatter).  Equal keys keep input order.
+// TPC-H sorts are post-aggregation (≤ ~1 M rows); the pass structure favours simplicity.
+#include "ldb_keys.h"
+#include <algorithm>
+#include <memory>
+
+#define CS_CHUNK 16 // rows per thread
+#define CS_BLOCK 256
+
+// ---------------------------------------------------------------- stable counting sort on 4-bit digits
+// digit of perm_in[j] = (keys[perm_in[j] * words + word] >> shift) & 15
+__global__ void k_cs_count(const uint64_t* __restrict__ keys, int words, int word, int shift, const uint32_t* __restrict__ perm_in, uint64_t n,
+                           uint32_t* __restrict__ counts, uint64_t n_threads) {
+   uint64_t t = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x;
+   if (t >= n_threads) return;
+   uint32_t c[16];
+#pragma unroll
+   for (int k = 0; k < 16; k++) c[k] = 0;
+   uint64_t b = t * CS_CHUNK, e = b + CS_CHUNK < n ? b + CS_CHUNK : n;
+   for (uint64_t j = b; j < e; j++) {
+      uint32_t dg = (uint32_t) (keys[(uint64_t) perm_in[j] * words + word] >> shift) & 15u;
+#pragma unroll
+      for (int k = 0; k < 16; k++) c[k] += (dg == (uint32_t) k);
+   }
+#pragma unroll
+   for (int k = 0; k < 16; k++) counts[(uint64_t) k * n_threads + t] = c[k];
+}
+__global__ void k_cs_scatter(const uint64_t* __restrict__ keys, int words, int word, int shift, const uint32_t* __restrict__ perm_in,
+                             uint32_t* __restrict__ perm_out, uint64_t n, const uint32_t* __restrict__ offsets, uint64_t n_threads) {
+   uint64_t t = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x;
+   if (t >= n_threads) return;
+   uint32_t o[16];
+#pragma unroll
+   for (int k = 0; k < 16; k++) o[k] = offsets[(uint64_t) k * n_threads + t];
+   uint64_t b = t * CS_CHUNK, e = b + CS_CHUNK < n ? b + CS_CHUNK : n;
+   for (uint64_t j = b; j < e; j++) {
+      uint32_t p = perm_in[j];
+      uint32_t dg = (uint32_t) (keys[(uint64_t) p * words + word] >> shift) & 15u;
+      uint32_t dst = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+         if (dg == (uint32_t) k) {
+            dst = o[k];
+            o[k]++;
+         }
+      }
+      perm_out[dst] = p;
+   }
+}
+
+// ---------------------------------------------------------------- key normalisation
+#define SORT_MAX_SPECS 8
+struct DSortSpec {
+   DCol col;
+   int32_t descending;
+   int32_t byte_off; // offset of this key inside the record
+   int32_t nbytes; // bytes this key occupies
+   int32_t str_pad; // utf8: padded string bytes (nbytes = str_pad + 4)
+};
+struct DSort {
+   uint64_t n_rows;
+   int32_t n_specs;
+   int32_t words; // 64-bit words per record
+   DSortSpec specs[SORT_MAX_SPECS];
+};
+
+// record bytes are big-endian inside big-endian words: byte b of the record is bits
+// [63-8*(b%8) ..] of word b/8, so word-wise unsigned compare == bytewise compare.
+__device__ __forceinline__ void d_put_byte(uint64_t* rec, int b, uint8_t v) { rec[b >> 3] |= (uint64_t) v << (56 - 8 * (b & 7)); }
+
+__global__ void k_sort_keys(const DSort* __restrict__ d, uint64_t* __restrict__ keys) {
+   const uint64_t n = d->n_rows;
+   const int words = d->words;
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      uint64_t* rec = keys + i * words;
+      for (int w = 0; w < words; w++) rec[w] = 0;
+      for (int s = 0; s < d->n_specs; s++) {
+         const DSortSpec& sp = d->specs[s];
+         const uint8_t inv = sp.descending ? 0xFF : 0x00;
+         uint32_t row = d_phys_row(sp.col, i);
+         int b = sp.byte_off;
+         if (sp.col.type == LDB_T_UTF8) {
+            uint32_t len;
+            const uint8_t* p = d_load_str(sp.col, row, &len);
+            for (int k = 0; k < sp.str_pad; k++) d_put_byte(rec, b + k, (uint8_t) (((uint32_t) k < len ? p[k] : 0) ^ inv));
+            for (int k = 0; k < 4; k++) d_put_byte(rec, b + sp.str_pad + k, (uint8_t) ((len >> (24 - 8 * k)) ^ inv));
+         } else if (sp.col.type == LDB_T_FLOAT64 || sp.col.type == LDB_T_FLOAT32) {
+            uint64_t bits = (uint64_t) __double_as_longlong(d_load_f64(sp.col, row));
+            bits = (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
+            for (int k = 0; k < 8; k++) d_put_byte(rec, b + k, (uint8_t) ((bits >> (56 - 8 * k)) ^ inv));
+         } else if (sp.nbytes == 16) {
+            u128 v = (u128) d_load_i128(sp.col, row) ^ ((u128) 1 << 127);
+            for (int k = 0; k < 16; k++) d_put_byte(rec, b + k, (uint8_t) ((uint8_t) (v >> (120 - 8 * k)) ^ inv));
+         } else {
+            uint64_t v = (uint64_t) d_load_i64(sp.col, row) ^ 0x8000000000000000ull;
+            for (int k = 0; k < 8; k++) d_put_byte(rec, b + k, (uint8_t) ((v >> (56 - 8 * k)) ^ inv));
+         }
+      }
+   }
+}
+
+__global__ void k_str_maxlen(DCol col, uint64_t n, unsigned long long* out) {
+   unsigned long long m = 0;
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      uint32_t len;
+      d_load_str(col, d_phys_row(col, i), &len);
+      if (len > m) m = len;
+   }
+   if (m) atomicMax(out, m);
+}
+__global__ void k_iota(uint32_t* out, uint64_t n) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = (uint32_t) i;
+}
+__global__ void k_all_valid(DCol col, uint64_t n, unsigned int* flag) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+      if (!d_valid(col, d_phys_row(col, i))) atomicOr(flag, 1u);
+}
+
+int32_t ldb_rel_select(ldb_ctx* ctx, ldb_rel* in, uint32_t* sel, int64_t n_sel, ldb_rel** out);
+int32_t ldb_gather_column(ldb_ctx* ctx, const ldb_rel* r, ldb_colref ref, ldb_column* out);
+
+// stable LSD sort of `perm` (n entries) by `words`-word records, digits [bit_lo, bit_hi) of each word
+static int32_t radix_sort_perm(ldb_ctx* ctx, const uint64_t* keys, int words, uint32_t** perm_io, uint64_t n, int first_word, int last_word, int bits_lo, int bits_hi) {
+   if (n < 2) return LDB_OK;
+   const uint64_t n_threads = (n + CS_CHUNK - 1) / CS_CHUNK;
+   const int grid = (int) ((n_threads + CS_BLOCK - 1) / CS_BLOCK);
+   uint32_t *counts, *offsets, *perm_b;
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &counts, 4 * 16 * (size_t) n_threads));
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &offsets, 4 * 16 * (size_t) n_threads));
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &perm_b, 4 * (size_t) n));
+   uint32_t* a = *perm_io;
+   uint32_t* b = perm_b;
+   for (int w = last_word; w >= first_word; w--) {
+      for (int shift = bits_lo; shift < bits_hi; shift += 4) {
+         hipLaunchKernelGGL(k_cs_count, dim3(grid), dim3(CS_BLOCK), 0, ctx->stream, keys, words, w, shift, (const uint32_t*) a, n, counts, n_threads);
+         LDB_TRY(ldb_exclusive_scan_u32(ctx, counts, offsets, (int64_t) (16 * n_threads), nullptr));
+         hipLaunchKernelGGL(k_cs_scatter, dim3(grid), dim3(CS_BLOCK), 0, ctx->stream, keys, words, w, shift, (const uint32_t*) a, b, n, (const uint32_t*) offsets, n_threads);
+         std::swap(a, b);
+      }
+   }
+   LDB_HIP(hipGetLastError());
+   *perm_io = a;
+   ldb_dev_free(ctx, b);
+   ldb_dev_free(ctx, counts);
+   ldb_dev_free(ctx, offsets);
+   return LDB_OK;
+}
+
+static int32_t sort_perm(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int32_t n_specs, uint32_t** perm_out) {
+   if (n_specs < 1 || n_specs > SORT_MAX_SPECS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "sort: %d keys (1..%d supported)", n_specs, SORT_MAX_SPECS);
+   const uint64_t n = (uint64_t) in->n_rows;
+   auto hp = std::make_unique<DSort>();
+   DSort* h = hp.get();
+   memset(h, 0, sizeof(*h));
+   h->n_rows = n;
+   h->n_specs = n_specs;
+   const int grid = ldb_grid_for(ctx, (int64_t) n, 256, 8);
+   int off = 0;
+   for (int s = 0; s < n_specs; s++) {
+      DSortSpec& sp = h->specs[s];
+      LDB_TRY(ldb_make_dcol(in, specs[s].col, &sp.col));
+      sp.descending = specs[s].descending ? 1 : 0;
+      sp.byte_off = off;
+      // db.sort_compare is only defined for non-nullable operands (LowerToStd.cpp:1050-1052)
+      if ((sp.col.validity || sp.col.rowids) && n) {
+         LDB_HIP(hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
+         hipLaunchKernelGGL(k_all_valid, dim3(grid), dim3(256), 0, ctx->stream, sp.col, n, (unsigned int*) ctx->d_scratch);
+         uint64_t f = 0;
+         LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &f));
+         if (f & 1) LDB_FAIL(LDB_ERR_UNSUPPORTED, "sort: key %d contains NULLs (nullable sort keys are not lowered to db.sort_compare)", s);
+      }
+      if (sp.col.type == LDB_T_UTF8) {
+         LDB_HIP(hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
+         if (n) hipLaunchKernelGGL(k_str_maxlen, dim3(grid), dim3(256), 0, ctx->stream, sp.col, n, (unsigned long long*) ctx->d_scratch);
+         uint64_t m = 0;
+         LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &m));
+         if (m > 256) LDB_FAIL(LDB_ERR_UNSUPPORTED, "sort: string key longer than 256 bytes");
+         sp.str_pad = (int32_t) m;
+         sp.nbytes = sp.str_pad + 4;
+      } else if (sp.col.type == LDB_T_DECIMAL128 && sp.col.precision >= 19) {
+         sp.nbytes = 16;
+      } else {
+         sp.nbytes = 8;
+      }
+      off += sp.nbytes;
+   }
+   h->words = (off + 7) / 8;
+   uint64_t* keys;
+   uint32_t* perm;
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &keys, 8 * (size_t) h->words * (size_t) (n ? n : 1)));
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &perm, 4 * (size_t) (n ? n : 1)));
+   DSort* d;
+   LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+   if (n) {
+      hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d, keys);
+      hipLaunchKernelGGL(k_iota, dim3(grid), dim3(256), 0, ctx->stream, perm, n);
+   }
+   LDB_HIP(hipGetLastError());
+   LDB_TRY(radix_sort_perm(ctx, keys, h->words, &perm, n, 0, h->words - 1, 0, 64));
+   ldb_dev_free(ctx, d);
+   ldb_dev_free(ctx, keys);
+   *perm_out = perm;
+   return LDB_OK;
+}
+
+extern "C" int32_t ldb_gpu_sort(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int32_t n_specs, ldb_rel** out) {
+   if (!ctx || !in || !out) LDB_FAIL(LDB_ERR_INVALID, "sort: NULL argument");
+   uint32_t* perm;
+   LDB_TRY(sort_perm(ctx, in, specs, n_specs, &perm));
+   return ldb_rel_select(ctx, in, perm, in->n_rows, out);
+}
+extern "C" int32_t ldb_gpu_topk(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int32_t n_specs, int64_t k, ldb_rel** out) {
+   if (!ctx || !in || !out || k < 0) LDB_FAIL(LDB_ERR_INVALID, "topk: bad argument");
+   uint32_t* perm;
+   LDB_TRY(sort_perm(ctx, in, specs, n_specs, &perm));
+   return ldb_rel_select(ctx, in, perm, std::min<int64_t>(k, in->n_rows), out);
+}
+
+// ---------------------------------------------------------------- hash-radix partition (multi-GPU shuffle)
+__global__ void k_part_ids(const DKeys* __restrict__ d, uint64_t n, uint32_t nparts, uint64_t* __restrict__ ids) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+      ids[i] = (d_hash_keys(*d, i) >> 16) % nparts;
+}
+__global__ void k_part_hist(const uint64_t* __restrict__ ids, uint64_t n, unsigned long long* __restrict__ hist) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) atomicAdd(&hist[ids[i]], 1ull);
+}
+
+extern "C" int32_t ldb_gpu_partition(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* keys, int32_t n_keys, int32_t nparts, const ldb_colref* cols, int32_t n_cols,
+                                     ldb_table** out, int64_t* counts) {
+   if (!ctx || !in || !out || !counts || nparts < 1 || nparts > 256) LDB_FAIL(LDB_ERR_INVALID, "partition: bad argument (1..256 partitions)");
+   const uint64_t n = (uint64_t) in->n_rows;
+   DKeys hk;
+   LDB_TRY(ldb_make_dkeys(in, keys, n_keys, &hk));
+   DKeys* dk;
+   LDB_TRY(ldb_dev_upload(ctx, &hk, sizeof(hk), (void**) &dk));
+   uint64_t* ids;
+   uint32_t* perm;
+   unsigned long long* hist;
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &ids, 8 * (size_t) (n ? n : 1)));
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &perm, 4 * (size_t) (n ? n : 1)));
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &hist, 8 * 256));
+   LDB_HIP(hipMemsetAsync(hist, 0, 8 * 256, ctx->stream));
+   const int grid = ldb_grid_for(ctx, (int64_t) n, 256, 8);
+   if (n) {
+      hipLaunchKernelGGL(k_part_ids, dim3(grid), dim3(256), 0, ctx->stream, dk, n, (uint32_t) nparts, ids);
+      hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(256), 0, ctx->stream, ids, n, hist);
+      hipLaunchKernelGGL(k_iota, dim3(grid), dim3(256), 0, ctx->stream, perm, n);
+   }
+   LDB_HIP(hipGetLastError());
+   // stable counting sort on the partition id (<= 8 bits → two 4-bit passes)
+   LDB_TRY(radix_sort_perm(ctx, ids, 1, &perm, n, 0, 0, 0, nparts > 16 ? 8 : 4));
+   std::vector<unsigned long long> hh(256);
+   LDB_HIP(hipMemcpyAsync(hh.data(), hist, 8 * 256, hipMemcpyDeviceToHost, ctx->stream));
+   LDB_HIP(hipStreamSynchronize(ctx->stream));
+   for (int p = 0; p < nparts; p++) counts[p] = (int64_t) hh[(size_t) p];
+   ldb_dev_free(ctx, dk);
+   ldb_dev_free(ctx, ids);
+   ldb_dev_free(ctx, hist);
+   ldb_rel* permuted;
+   LDB_TRY(ldb_rel_select(ctx, in, perm, (int64_t) n, &permuted));
+   int32_t s = ldb_gpu_materialize(ctx, permuted, cols, n_cols, out);
+   ldb_gpu_rel_release(ctx, permuted);
+   return s;
+}

@@ -1,0 +1,424 @@
+// ldb_host.cpp — host mirror of the reference's filter interface + TPC-H plan layer (see ldb_host.hpp).
+#include "ldb_host.hpp"
+#include <cstring>
+#include <regex>
+
+namespace lingodb::runtime::gpu {
+
+static thread_local std::string g_plan_err;
+
+void check(int32_t status, const char* what) {
+   if (status != LDB_OK) throw CtxError(std::string(what) + ": " + ldb_gpu_last_error());
+}
+
+// days from civil (proleptic Gregorian), Howard Hinnant's algorithm
+static int32_t daysFromCivil(int y, unsigned m, unsigned d) {
+   y -= m <= 2;
+   const int era = (y >= 0 ? y : y - 399) / 400;
+   const unsigned yoe = (unsigned) (y - era * 400);
+   const unsigned doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+   const unsigned doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+   return era * 146097 + (int) doe - 719468;
+}
+// Restrictions.cpp:17-25: normalise "YYYY-M-DD" then parse as date32
+int32_t parseDate32(std::string str) {
+   static std::regex r("(\\d\\d\\d\\d)-(\\d)-(\\d\\d)");
+   str = std::regex_replace(str, r, "$1-0$2-$3");
+   int y, m, d;
+   if (str.size() != 10 || sscanf(str.c_str(), "%4d-%2d-%2d", &y, &m, &d) != 3 || m < 1 || m > 12 || d < 1 || d > 31) throw std::runtime_error("could not parse date");
+   return daysFromCivil(y, (unsigned) m, (unsigned) d);
+}
+
+// arrow::Decimal128::FromString + Rescale(scale_in, scale_out) (Restrictions.cpp:455-468):
+// rescaling up multiplies by 10^k; rescaling down must be exact (Arrow returns an error
+// otherwise, which the reference turns into ValueOrDie()).
+__int128 parseDecimal(const std::string& s, int32_t scale) {
+   size_t i = 0;
+   bool neg = false;
+   if (i < s.size() && (s[i] == '-' || s[i] == '+')) neg = s[i++] == '-';
+   __int128 v = 0;
+   int32_t frac = 0;
+   bool dot = false, any = false;
+   for (; i < s.size(); i++) {
+      if (s[i] == '.' && !dot) {
+         dot = true;
+         continue;
+      }
+      if (s[i] < '0' || s[i] > '9') throw std::runtime_error("could not parse decimal const");
+      v = v * 10 + (s[i] - '0');
+      if (dot) frac++;
+      any = true;
+   }
+   if (!any) throw std::runtime_error("could not parse decimal const");
+   for (; frac < scale; frac++) v *= 10;
+   for (; frac > scale; frac--) {
+      if (v % 10 != 0) throw std::runtime_error("decimal const loses precision when rescaled");
+      v /= 10;
+   }
+   return neg ? -v : v;
+}
+
+static void setInt(ldb_filter_desc& d, __int128 v) {
+   d.rhs_kind = LDB_RHS_INT;
+   d.value_lo = (uint64_t) v;
+   d.value_hi = (int64_t) (v >> 64);
+}
+
+std::unique_ptr<Restrictions> Restrictions::create(const std::vector<FilterDescription>& filterDescs, const ldb_table* table, int32_t side) {
+   auto res = std::make_unique<Restrictions>();
+   for (const auto& fd : filterDescs) {
+      int32_t colId = ldb_gpu_table_col_index(table, fd.columnName.c_str());
+      if (colId < 0) throw std::runtime_error("unknown column in filter");
+      ldb_filter_desc d;
+      memset(&d, 0, sizeof(d));
+      d.col = {side, colId};
+      d.op = (int32_t) fd.op;
+      if (fd.op == FilterOp::NOTNULL) {
+         res->descs.push_back(d);
+         continue;
+      }
+      ldb_coltype type;
+      ldb_gpu_table_coltype(table, colId, &type);
+      auto intOf = [&](const std::variant<std::string, int64_t, double>& v) -> int64_t {
+         if (!std::holds_alternative<int64_t>(v)) throw std::runtime_error("integer constant expected in filter");
+         return std::get<int64_t>(v);
+      };
+      switch (type.type) {
+         case LDB_T_CHAR4: { // char(1): memcpy(<=4 bytes) into an int32 (:409-417)
+            const std::string& strVal = std::get<std::string>(fd.value);
+            if (strVal.size() > 4) throw std::runtime_error("char(1) filter constant longer than 4 bytes");
+            int32_t intVal = 0;
+            std::memcpy(&intVal, strVal.data(), strVal.size());
+            setInt(d, intVal);
+            break;
+         }
+         case LDB_T_INT8:
+         case LDB_T_INT16:
+         case LDB_T_INT32:
+         case LDB_T_INT64: {
+            auto cast = [&](int64_t v) -> int64_t { // static_cast<T>(int64) of createSimpleTypeFilter (:342-347)
+               switch (type.type) {
+                  case LDB_T_INT8: return (int8_t) v;
+                  case LDB_T_INT16: return (int16_t) v;
+                  case LDB_T_INT32: return (int32_t) v;
+                  default: return v;
+               }
+            };
+            if (fd.op == FilterOp::IN) {
+               auto vals = std::make_unique<std::vector<int64_t>>();
+               for (auto v : std::get<std::vector<int64_t>>(fd.values)) {
+                  int64_t c = cast(v);
+                  vals->push_back(c);
+                  vals->push_back(c >> 63);
+               }
+               d.rhs_kind = LDB_RHS_INT;
+               d.n_in = (int32_t) (vals->size() / 2);
+               d.in_values = vals->data();
+               res->inInts.push_back(std::move(vals));
+            } else {
+               setInt(d, cast(intOf(fd.value)));
+            }
+            break;
+         }
+         case LDB_T_DATE32: {
+            if (fd.op == FilterOp::IN) {
+               auto vals = std::make_unique<std::vector<int64_t>>();
+               for (const auto& s : std::get<std::vector<std::string>>(fd.values)) {
+                  vals->push_back(parseDate32(s));
+                  vals->push_back(0);
+               }
+               d.rhs_kind = LDB_RHS_INT;
+               d.n_in = (int32_t) (vals->size() / 2);
+               d.in_values = vals->data();
+               res->inInts.push_back(std::move(vals));
+            } else {
+               setInt(d, parseDate32(std::get<std::string>(fd.value)));
+            }
+            break;
+         }
+         case LDB_T_DECIMAL128: {
+            __int128 v;
+            if (std::holds_alternative<std::string>(fd.value)) {
+               v = parseDecimal(std::get<std::string>(fd.value), type.scale);
+            } else if (std::holds_alternative<int64_t>(fd.value)) {
+               v = std::get<int64_t>(fd.value);
+               for (int32_t s = type.scale; s > 0; s--) v *= 10; // :470-475
+            } else {
+               throw std::runtime_error("unsupported decimal constant type");
+            }
+            if (fd.op == FilterOp::IN) throw std::runtime_error("unsupported filter op");
+            setInt(d, v);
+            break;
+         }
+         case LDB_T_UTF8: {
+            d.rhs_kind = LDB_RHS_STRING;
+            if (fd.op == FilterOp::IN) {
+               auto ptrs = std::make_unique<std::vector<const char*>>();
+               auto lens = std::make_unique<std::vector<int32_t>>();
+               for (const auto& s : std::get<std::vector<std::string>>(fd.values)) {
+                  res->strings.push_back(std::make_unique<std::string>(s));
+                  ptrs->push_back(res->strings.back()->data());
+                  lens->push_back((int32_t) s.size());
+               }
+               d.n_in = (int32_t) ptrs->size();
+               d.in_strs = ptrs->data();
+               d.in_str_lens = lens->data();
+               res->inStrPtrs.push_back(std::move(ptrs));
+               res->inStrLens.push_back(std::move(lens));
+            } else {
+               res->strings.push_back(std::make_unique<std::string>(std::get<std::string>(fd.value)));
+               d.str = res->strings.back()->data();
+               d.str_len = (int32_t) res->strings.back()->size();
+            }
+            break;
+         }
+         case LDB_T_FLOAT64:
+         case LDB_T_FLOAT32: {
+            d.rhs_kind = LDB_RHS_FLOAT;
+            d.value_f64 = std::holds_alternative<double>(fd.value) ? std::get<double>(fd.value) : (double) intOf(fd.value);
+            break;
+         }
+         default: throw std::runtime_error("unsupported type in filter");
+      }
+      res->descs.push_back(d);
+   }
+   return res;
+}
+
+// ---------------------------------------------------------------- decimal typing
+DecimalType adaptedAfterMulDiv(int64_t p, int64_t s) {
+   int64_t beforeComma = p - s;
+   if (beforeComma > 32 && s > 6) {
+      p = 38;
+      s = 6;
+   } else if (beforeComma > 32 && s <= 6) {
+      p = 38;
+   } else {
+      p = std::min<int64_t>(p, 38);
+      s = std::min<int64_t>(s, 38 - beforeComma);
+   }
+   return {(int32_t) p, (int32_t) s};
+}
+DecimalType typeAfterMul(DecimalType a, DecimalType b) { return adaptedAfterMulDiv(a.p + b.p, a.s + b.s); }
+DecimalType typeAfterDiv(DecimalType a, DecimalType b) {
+   int64_t s = std::max<int64_t>(6, a.s + b.p);
+   return adaptedAfterMulDiv(a.p - a.s + b.s + s, s);
+}
+DecimalType higherDecimalType(DecimalType a, DecimalType b) {
+   int32_t hidig = std::max(a.p - a.s, b.p - b.s);
+   int32_t maxs = std::max(a.s, b.s);
+   return {hidig + maxs, maxs};
+}
+DecimalType avgType(DecimalType arg) { return typeAfterDiv(arg, {19, 0}); }
+int64_t pow10i(int k) {
+   int64_t r = 1;
+   while (k-- > 0) r *= 10;
+   return r;
+}
+
+} // namespace lingodb::runtime::gpu
+
+// ================================================================== plans
+using namespace lingodb::runtime::gpu;
+
+namespace {
+
+struct Rel {
+   ldb_ctx* ctx;
+   ldb_rel* r = nullptr;
+   Rel(ldb_ctx* c) : ctx(c) {}
+   ~Rel() {
+      if (r) ldb_gpu_rel_release(ctx, r);
+   }
+   Rel(const Rel&) = delete;
+};
+struct Table {
+   ldb_ctx* ctx;
+   ldb_table* t = nullptr;
+   Table(ldb_ctx* c) : ctx(c) {}
+   ~Table() {
+      if (t) ldb_gpu_table_release(ctx, t);
+   }
+   ldb_table* release() {
+      ldb_table* x = t;
+      t = nullptr;
+      return x;
+   }
+};
+struct Ht {
+   ldb_ctx* ctx;
+   ldb_hashtable* h = nullptr;
+   Ht(ldb_ctx* c) : ctx(c) {}
+   ~Ht() {
+      if (h) ldb_gpu_hashtable_release(ctx, h);
+   }
+};
+
+int32_t colOf(const ldb_table* t, const char* name) {
+   int32_t c = ldb_gpu_table_col_index(t, name);
+   if (c < 0) throw std::runtime_error(std::string("column not found: ") + name);
+   return c;
+}
+DecimalType decOf(const ldb_table* t, int32_t col) {
+   ldb_coltype ct;
+   ldb_gpu_table_coltype(t, col, &ct);
+   if (ct.type != LDB_T_DECIMAL128) throw std::runtime_error("decimal column expected");
+   return {ct.precision, ct.scale};
+}
+
+ldb_factor colFactor(ldb_colref c) { return {1, c, 0, 1}; }
+// (k - col) or (k + col) with k an integer literal: int → decimal(19,0) → common scale of the
+// column (sql_analyzer.cpp:3125-3141, getHigherDecimalType): a = k * 10^scale
+ldb_factor constPlusCol(int64_t k, int sign, ldb_colref c, DecimalType colType, DecimalType* outType) {
+   *outType = higherDecimalType({19, 0}, colType);
+   return {1, c, k * pow10i(colType.s), sign};
+}
+ldb_expr product(std::initializer_list<ldb_factor> fs) {
+   ldb_expr e;
+   memset(&e, 0, sizeof(e));
+   e.n_terms = 1;
+   e.t[0].n_factors = (int32_t) fs.size();
+   int i = 0;
+   for (auto& f : fs) e.t[0].f[i++] = f;
+   return e;
+}
+ldb_agg_spec sumDec(ldb_expr e, DecimalType t) {
+   ldb_agg_spec a;
+   memset(&a, 0, sizeof(a));
+   a.fn = LDB_AGG_SUM;
+   a.arg = e;
+   a.wide = t.wide();
+   a.out_type = LDB_T_DECIMAL128;
+   a.out_precision = t.p;
+   a.out_scale = t.s;
+   return a;
+}
+ldb_agg_spec avgDec(ldb_expr e, DecimalType t) {
+   ldb_agg_spec a = sumDec(e, t);
+   a.fn = LDB_AGG_AVG;
+   DecimalType r = avgType(t);
+   // (sum * 10^(sRes + s2 - s1)) sdiv count with the divisor typed decimal(19,0) (LowerToStd.cpp:631-651)
+   a.avg_pow10 = r.s + 0 - t.s;
+   a.out_precision = r.p;
+   a.out_scale = r.s;
+   return a;
+}
+ldb_agg_spec countStar() {
+   ldb_agg_spec a;
+   memset(&a, 0, sizeof(a));
+   a.fn = LDB_AGG_COUNT_STAR;
+   a.out_type = LDB_T_INT64;
+   return a;
+}
+
+template <typename F>
+int32_t guarded(F&& f) {
+   try {
+      f();
+      return LDB_OK;
+   } catch (const std::exception& e) {
+      g_plan_err = e.what();
+      return LDB_ERR_INVALID;
+   }
+}
+
+} // namespace
+
+extern "C" const char* ldb_plan_last_error(void) { return g_plan_err.c_str(); }
+
+// TPC-H Q1 (resources/sql/tpch/1.sql): scan lineitem with the pushed-down l_shipdate filter,
+// group by (l_returnflag, l_linestatus), 4 SUM + 3 AVG + COUNT(*), order by the keys.
+extern "C" int32_t ldb_plan_tpch_q1(ldb_ctx* ctx, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel scan(ctx), sorted(ctx);
+      check(ldb_gpu_rel_from_table(ctx, li, &scan.r), "q1 scan");
+      // date '1998-12-01' - interval '90' day is constant-folded by the frontend
+      auto restr = Restrictions::create({{"l_shipdate", FilterOp::LTE, std::string("1998-09-02"), {}}}, li);
+      ldb_colref qty{0, colOf(li, "l_quantity")}, ext{0, colOf(li, "l_extendedprice")}, disc{0, colOf(li, "l_discount")}, tax{0, colOf(li, "l_tax")};
+      ldb_colref keys[2] = {{0, colOf(li, "l_returnflag")}, {0, colOf(li, "l_linestatus")}};
+      DecimalType tq = decOf(li, qty.col), te = decOf(li, ext.col), td = decOf(li, disc.col), tt = decOf(li, tax.col);
+      DecimalType t1md, t1pt;
+      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, td, &t1md);
+      ldb_factor onePlusTax = constPlusCol(1, +1, tax, tt, &t1pt);
+      DecimalType tDiscPrice = typeAfterMul(te, t1md); // decimal(33,4)
+      DecimalType tCharge = typeAfterMul(tDiscPrice, t1pt); // decimal(38,6)
+      if (tDiscPrice.s != te.s + t1md.s || tCharge.s != tDiscPrice.s + t1pt.s) throw std::runtime_error("q1: unexpected scale clamp");
+      ldb_agg_spec aggs[8] = {
+         sumDec(product({colFactor(qty)}), tq),
+         sumDec(product({colFactor(ext)}), te),
+         sumDec(product({colFactor(ext), oneMinusDisc}), tDiscPrice),
+         sumDec(product({colFactor(ext), oneMinusDisc, onePlusTax}), tCharge),
+         avgDec(product({colFactor(qty)}), tq),
+         avgDec(product({colFactor(ext)}), te),
+         avgDec(product({colFactor(disc)}), td),
+         countStar()};
+      Table grouped(ctx);
+      check(ldb_gpu_groupby(ctx, scan.r, restr->data(), restr->size(), keys, 2, aggs, 8, /*est_groups*/ 6, &grouped.t), "q1 groupby");
+      Rel g(ctx);
+      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q1 rel");
+      ldb_sort_spec specs[2] = {{{0, 0}, 0, 0}, {{0, 1}, 0, 0}};
+      check(ldb_gpu_sort(ctx, g.r, specs, 2, &sorted.r), "q1 sort");
+      ldb_colref outc[10];
+      for (int c = 0; c < 10; c++) outc[c] = {0, c};
+      check(ldb_gpu_materialize(ctx, sorted.r, outc, 10, result), "q1 materialize");
+   });
+}
+
+// TPC-H Q6 (resources/sql/tpch/6.sql): pure scan + key-less SUM (SimpleState).
+extern "C" int32_t ldb_plan_tpch_q6(ldb_ctx* ctx, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel scan(ctx);
+      check(ldb_gpu_rel_from_table(ctx, li, &scan.r), "q6 scan");
+      // 0.06 - 0.01 / 0.06 + 0.01 are folded to decimal constants; BETWEEN → two inclusive filters
+      auto restr = Restrictions::create({{"l_shipdate", FilterOp::GTE, std::string("1994-01-01"), {}},
+                                         {"l_shipdate", FilterOp::LT, std::string("1995-01-01"), {}},
+                                         {"l_discount", FilterOp::GTE, std::string("0.05"), {}},
+                                         {"l_discount", FilterOp::LTE, std::string("0.07"), {}},
+                                         {"l_quantity", FilterOp::LT, (int64_t) 24, {}}},
+                                        li);
+      ldb_colref ext{0, colOf(li, "l_extendedprice")}, disc{0, colOf(li, "l_discount")};
+      DecimalType tr = typeAfterMul(decOf(li, ext.col), decOf(li, disc.col)); // decimal(24,4)
+      ldb_agg_spec agg = sumDec(product({colFactor(ext), colFactor(disc)}), tr);
+      check(ldb_gpu_groupby(ctx, scan.r, restr->data(), restr->size(), nullptr, 0, &agg, 1, 1, result), "q6 aggregate");
+   });
+}
+
+// TPC-H Q3 (resources/sql/tpch/3.sql): customer ⋈ orders ⋈ lineitem, group by 3 keys, top-10.
+extern "C" int32_t ldb_plan_tpch_q3(ldb_ctx* ctx, const ldb_table* cust, const ldb_table* ord, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel c0(ctx), c1(ctx), o0(ctx), o1(ctx), l0(ctx), l1(ctx), co(ctx), lco(ctx), top(ctx);
+      check(ldb_gpu_rel_from_table(ctx, cust, &c0.r), "q3 customer");
+      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q3 orders");
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q3 lineitem");
+      auto rc = Restrictions::create({{"c_mktsegment", FilterOp::EQ, std::string("BUILDING"), {}}}, cust);
+      auto ro = Restrictions::create({{"o_orderdate", FilterOp::LT, std::string("1995-03-15"), {}}}, ord);
+      auto rl = Restrictions::create({{"l_shipdate", FilterOp::GT, std::string("1995-03-15"), {}}}, li);
+      check(ldb_gpu_scan_filter(ctx, c0.r, rc->data(), rc->size(), &c1.r), "q3 filter customer");
+      check(ldb_gpu_scan_filter(ctx, o0.r, ro->data(), ro->size(), &o1.r), "q3 filter orders");
+      check(ldb_gpu_scan_filter(ctx, l0.r, rl->data(), rl->size(), &l1.r), "q3 filter lineitem");
+      // build on the filtered customers (primary key), probe with the filtered orders
+      Ht hc(ctx), ho(ctx);
+      ldb_colref ck{0, colOf(cust, "c_custkey")}, ock{0, colOf(ord, "o_custkey")};
+      check(ldb_gpu_join_build(ctx, c1.r, &ck, 1, 1, &hc.h), "q3 build customer");
+      check(ldb_gpu_join_probe(ctx, hc.h, o1.r, &ock, 1, LDB_JOIN_INNER, &co.r, nullptr), "q3 probe orders"); // sides: orders, customer
+      ldb_colref ook{0, colOf(ord, "o_orderkey")}, lok{0, colOf(li, "l_orderkey")};
+      check(ldb_gpu_join_build(ctx, co.r, &ook, 1, 1, &ho.h), "q3 build orders");
+      check(ldb_gpu_join_probe(ctx, ho.h, l1.r, &lok, 1, LDB_JOIN_INNER, &lco.r, nullptr), "q3 probe lineitem"); // sides: lineitem, orders, customer
+      ldb_colref ext{0, colOf(li, "l_extendedprice")}, disc{0, colOf(li, "l_discount")};
+      DecimalType t1md;
+      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, decOf(li, disc.col), &t1md);
+      DecimalType tRev = typeAfterMul(decOf(li, ext.col), t1md);
+      ldb_agg_spec agg = sumDec(product({colFactor(ext), oneMinusDisc}), tRev);
+      ldb_colref keys[3] = {lok, {1, colOf(ord, "o_orderdate")}, {1, colOf(ord, "o_shippriority")}};
+      Table grouped(ctx);
+      int64_t est = ldb_gpu_rel_rows(ctx, lco.r);
+      check(ldb_gpu_groupby(ctx, lco.r, nullptr, 0, keys, 3, &agg, 1, est > 0 ? est : 1, &grouped.t), "q3 groupby");
+      Rel g(ctx);
+      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q3 rel");
+      // order by revenue desc, o_orderdate limit 10; output l_orderkey, revenue, o_orderdate, o_shippriority
+      ldb_sort_spec specs[2] = {{{0, 3}, 1, 0}, {{0, 1}, 0, 0}};
+      check(ldb_gpu_topk(ctx, g.r, specs, 2, 10, &top.r), "q3 topk");
+      ldb_colref outc[4] = {{0, 0}, {0, 3}, {0, 1}, {0, 2}};
+      check(ldb_gpu_materialize(ctx, top.r, outc, 4, result), "q3 materialize");
+   });
+}

@@ -1,0 +1,75 @@
+// ldb_host.hpp — C++ host-side mirror of the reference's scan/filter interface and the plan layer
+// that drives liblingodb_gpu.so through its C-ABI only (no HIP, no torch here).
+//
+// Mirrors (same names, argument meaning, error behaviour = std::runtime_error):
+//   lingodb::runtime::FilterOp / FilterDescription   include/lingodb/runtime/storage/TableStorage.h:14-36
+//   Restrictions::create type dispatch                src/runtime/storage/Restrictions.cpp:392-521
+//   parseDate32                                       src/runtime/storage/Restrictions.cpp:17-25
+//   decimal result-type rules                         src/compiler/frontend/sql_analyzer.cpp:3058-3159, 2617-2642
+#pragma once
+#include "../../include/lingodb_gpu.h"
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <variant>
+#include <vector>
+
+namespace lingodb::runtime::gpu {
+
+enum class FilterOp : uint8_t { EQ, NEQ, LT, LTE, GT, GTE, NOTNULL, IN };
+
+struct FilterDescription {
+   std::string columnName;
+   FilterOp op;
+   std::variant<std::string, int64_t, double> value;
+   std::variant<std::vector<std::string>, std::vector<int64_t>, std::vector<double>> values;
+};
+
+int32_t parseDate32(std::string str); // "YYYY-MM-DD" (also "YYYY-M-DD") → days since epoch
+// decimal literal → unscaled 128-bit integer at `scale` (arrow::Decimal128::FromString + Rescale)
+__int128 parseDecimal(const std::string& s, int32_t scale);
+
+// Typed predicate list for one table: owns the string / IN-list storage the C descriptors point to.
+class Restrictions {
+   public:
+   static std::unique_ptr<Restrictions> create(const std::vector<FilterDescription>& filterDescs, const ldb_table* table, int32_t side = 0);
+   const ldb_filter_desc* data() const { return descs.data(); }
+   int32_t size() const { return (int32_t) descs.size(); }
+
+   private:
+   std::vector<ldb_filter_desc> descs;
+   std::vector<std::unique_ptr<std::string>> strings;
+   std::vector<std::unique_ptr<std::vector<int64_t>>> inInts;
+   std::vector<std::unique_ptr<std::vector<const char*>>> inStrPtrs;
+   std::vector<std::unique_ptr<std::vector<int32_t>>> inStrLens;
+};
+
+// decimal(p, s) typing (SQLTypeUtils)
+struct DecimalType {
+   int32_t p, s;
+   bool wide() const { return p >= 19; } // storage width rule, LowerToStd.cpp:1479-1486
+};
+DecimalType adaptedAfterMulDiv(int64_t p, int64_t s); // getAdaptedDecimalPAndSAfterMulDiv :3145-3159
+DecimalType typeAfterMul(DecimalType a, DecimalType b); // :3099-3106
+DecimalType typeAfterDiv(DecimalType a, DecimalType b); // :3088-3097
+DecimalType higherDecimalType(DecimalType a, DecimalType b); // getHigherDecimalType :3058-3065 (add/sub/compare)
+DecimalType avgType(DecimalType arg); // :2636-2642 (division by decimal(19,0))
+int64_t pow10i(int k);
+
+// RAII wrappers used by the plans
+struct CtxError : std::runtime_error {
+   using std::runtime_error::runtime_error;
+};
+void check(int32_t status, const char* what);
+
+} // namespace lingodb::runtime::gpu
+
+extern "C" {
+// TPC-H plans (hand-built pipeline DAGs in place of the MLIR-produced execution steps).
+// Inputs: device tables with the TPC-H column names; result: device table (caller releases).
+int32_t ldb_plan_tpch_q1(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q6(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q3(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
+const char* ldb_plan_last_error(void);
+}

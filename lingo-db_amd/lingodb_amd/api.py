@@ -1,0 +1,441 @@
+"""Thin object layer over the C-ABI (tests / bench harness).  Every call goes through
+liblingodb_gpu.so; nothing here computes query results on the CPU."""
+import ctypes as C
+
+import numpy as np
+import pyarrow as pa
+
+from . import capi
+from .capi import (AggSpec, ColRef, ColType, Expr, Factor, FilterDesc, SortSpec, Term, check, check_plan)
+
+
+# ------------------------------------------------------------------ descriptor builders
+def colref(side, col):
+    return ColRef(int(side), int(col))
+
+
+def _split128(v):
+    v = int(v)
+    lo = v & 0xFFFFFFFFFFFFFFFF
+    hi = (v >> 64) & 0xFFFFFFFFFFFFFFFF
+    if hi >= 1 << 63:
+        hi -= 1 << 64
+    return lo, hi
+
+
+class _Keep:
+    """holds python objects referenced by raw pointers inside descriptor structs"""
+
+    def __init__(self):
+        self.objs = []
+
+    def add(self, o):
+        self.objs.append(o)
+        return o
+
+
+def pred(col, op, value=None, *, rhs_col=None, values=None, keep=None):
+    """One conjunct.  col=(side, col); value int | bytes/str | float; rhs_col=(side,col); values=list for IN."""
+    keep = keep if keep is not None else _Keep()
+    d = FilterDesc()
+    d.col = colref(*col)
+    d.op = op
+    if op == capi.F_NOTNULL:
+        return d, keep
+    if rhs_col is not None:
+        d.rhs_kind = capi.RHS_COLUMN
+        d.rhs_col = colref(*rhs_col)
+        return d, keep
+    if op == capi.F_IN:
+        vals = list(values)
+        d.n_in = len(vals)
+        if vals and isinstance(vals[0], (bytes, str)):
+            bs = [v.encode() if isinstance(v, str) else v for v in vals]
+            arr = (C.c_char_p * len(bs))(*bs)
+            lens = (C.c_int32 * len(bs))(*[len(b) for b in bs])
+            keep.add(bs), keep.add(arr), keep.add(lens)
+            d.rhs_kind = capi.RHS_STRING
+            d.in_strs = arr
+            d.in_str_lens = lens
+        else:
+            flat = []
+            for v in vals:
+                if isinstance(v, float):
+                    flat += [int(np.float64(v).view(np.int64)), 0]
+                else:
+                    lo, hi = _split128(v)
+                    flat += [lo if lo < 1 << 63 else lo - (1 << 64), hi]
+            arr = (C.c_int64 * len(flat))(*flat)
+            keep.add(arr)
+            d.rhs_kind = capi.RHS_FLOAT if vals and isinstance(vals[0], float) else capi.RHS_INT
+            d.in_values = arr
+        return d, keep
+    if isinstance(value, (bytes, str)):
+        b = value.encode() if isinstance(value, str) else value
+        keep.add(b)
+        d.rhs_kind = capi.RHS_STRING
+        d.str = b
+        d.str_len = len(b)
+    elif isinstance(value, float):
+        d.rhs_kind = capi.RHS_FLOAT
+        d.value_f64 = value
+    else:
+        d.rhs_kind = capi.RHS_INT
+        d.value_lo, d.value_hi = _split128(value)
+    return d, keep
+
+
+def preds_array(plist):
+    """plist: list of (FilterDesc, keep) → (ctypes array, n, keepalive)"""
+    n = len(plist)
+    arr = (FilterDesc * max(n, 1))()
+    keeps = []
+    for i, (d, k) in enumerate(plist):
+        arr[i] = d
+        keeps.append(k)
+    return arr, n, keeps
+
+
+def factor(a=0, b=0, col=None):
+    f = Factor()
+    f.has_col = 0 if col is None else 1
+    if col is not None:
+        f.col = colref(*col)
+    f.a = int(a)
+    f.b = int(b)
+    return f
+
+
+def expr(terms, is_float=False):
+    """terms: list of dicts {factors:[Factor], negate:bool, div_pow10:int}"""
+    e = Expr()
+    e.n_terms = len(terms)
+    e.is_float = 1 if is_float else 0
+    for t, tm in enumerate(terms):
+        e.t[t].n_factors = len(tm["factors"])
+        e.t[t].negate = 1 if tm.get("negate") else 0
+        e.t[t].div_pow10 = int(tm.get("div_pow10", 0))
+        for f, fa in enumerate(tm["factors"]):
+            e.t[t].f[f] = fa
+    return e
+
+
+def col_expr(col, is_float=False):
+    return expr([{"factors": [factor(0, 1, col)]}], is_float)
+
+
+def agg(fn, e=None, *, wide=False, out_type=capi.T_INT64, p=0, s=0, preds=(), avg_pow10=0):
+    a = AggSpec()
+    a.fn = fn
+    a.wide = 1 if wide else 0
+    if e is not None:
+        a.arg = e
+    a.n_preds = len(preds)
+    keeps = []
+    for i, (d, k) in enumerate(preds):
+        a.preds[i] = d
+        keeps.append(k)
+    a.avg_pow10 = avg_pow10
+    a.out_type = out_type
+    a.out_precision = p
+    a.out_scale = s
+    a._keep = keeps
+    return a
+
+
+def sort_spec(col, descending=False):
+    s = SortSpec()
+    s.col = colref(*col)
+    s.descending = 1 if descending else 0
+    return s
+
+
+def _refs(cols):
+    n = len(cols)
+    arr = (ColRef * max(n, 1))()
+    for i, c in enumerate(cols):
+        arr[i] = colref(*c)
+    return arr, n
+
+
+# ------------------------------------------------------------------ handles
+class Table:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def release(self):
+        if self.h:
+            check(self.ctx.lib.ldb_gpu_table_release(self.ctx.h, self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    @property
+    def rows(self):
+        return self.ctx.lib.ldb_gpu_table_rows(self.h)
+
+    @property
+    def n_cols(self):
+        return self.ctx.lib.ldb_gpu_table_cols(self.h)
+
+    def col(self, name):
+        i = self.ctx.lib.ldb_gpu_table_col_index(self.h, name.encode())
+        if i < 0:
+            raise KeyError(name)
+        return i
+
+    def col_name(self, i):
+        return self.ctx.lib.ldb_gpu_table_col_name(self.h, i).decode()
+
+    def coltype(self, i):
+        t = ColType()
+        check(self.ctx.lib.ldb_gpu_table_coltype(self.h, i, C.byref(t)))
+        return t
+
+    def col_width(self, i):
+        return self.ctx.lib.ldb_gpu_table_col_width(self.h, i)
+
+    def col_ptrs(self, i):
+        v, o, b = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nb = C.c_int64()
+        check(self.ctx.lib.ldb_gpu_table_col_ptrs(self.h, i, C.byref(v), C.byref(o), C.byref(b), C.byref(nb)))
+        return v.value, o.value, b.value, nb.value
+
+    def read_fixed(self, i):
+        """raw bytes of a fixed-width column as a numpy uint8 array"""
+        w = self.col_width(i)
+        out = np.empty(self.rows * w, dtype=np.uint8)
+        check(self.ctx.lib.ldb_gpu_table_read_fixed(self.ctx.h, self.h, i, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def rel(self):
+        r = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_rel_from_table(self.ctx.h, self.h, C.byref(r)))
+        return Rel(self.ctx, r, [self])
+
+    def to_arrow(self):
+        """D2H export through the Arrow C Data Interface (ldb_gpu_export)."""
+        schema, array = capi.ArrowSchema(), capi.ArrowArray()
+        check(self.ctx.lib.ldb_gpu_export(self.ctx.h, self.h, C.byref(schema), C.byref(array)))
+        batch = pa.RecordBatch._import_from_c(C.addressof(array), C.addressof(schema))
+        return pa.Table.from_batches([batch])
+
+
+class Rel:
+    def __init__(self, ctx, handle, deps=()):
+        self.ctx, self.h = ctx, handle
+        self.deps = list(deps)  # keep tables / build relations alive
+
+    def release(self):
+        if self.h:
+            check(self.ctx.lib.ldb_gpu_rel_release(self.ctx.h, self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    @property
+    def rows(self):
+        return self.ctx.lib.ldb_gpu_rel_rows(self.ctx.h, self.h)
+
+    @property
+    def sides(self):
+        return self.ctx.lib.ldb_gpu_rel_sides(self.h)
+
+    def rowids(self, side=0):
+        out = np.empty(max(self.rows, 1), dtype=np.uint32)
+        check(self.ctx.lib.ldb_gpu_rel_read_rowids(self.ctx.h, self.h, side, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size))
+        return out[: self.rows]
+
+    # ---- operators
+    def scan_filter(self, plist):
+        arr, n, keep = preds_array(plist)
+        r = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_scan_filter(self.ctx.h, self.h, arr, n, C.byref(r)))
+        return Rel(self.ctx, r, self.deps)
+
+    def scan_count(self, plist):
+        arr, n, keep = preds_array(plist)
+        c = C.c_int64()
+        check(self.ctx.lib.ldb_gpu_scan_count(self.ctx.h, self.h, arr, n, C.byref(c)))
+        return c.value
+
+    def hash_keys(self, keys):
+        arr, n = _refs(keys)
+        t = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_hash_keys(self.ctx.h, self.h, arr, n, C.byref(t)))
+        tab = Table(self.ctx, t)
+        return tab.read_fixed(0).view(np.uint64)
+
+    def groupby(self, keys, aggs, plist=(), est_groups=0):
+        parr, np_, keep = preds_array(list(plist))
+        karr, nk = _refs(keys)
+        aarr = (AggSpec * max(len(aggs), 1))()
+        for i, a in enumerate(aggs):
+            aarr[i] = a
+        t = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_groupby(self.ctx.h, self.h, parr, np_, karr, nk, aarr, len(aggs), est_groups, C.byref(t)))
+        return Table(self.ctx, t)
+
+    def materialize(self, cols):
+        arr, n = _refs(cols)
+        t = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_materialize(self.ctx.h, self.h, arr, n, C.byref(t)))
+        return Table(self.ctx, t)
+
+    def join_build(self, keys, unique=False):
+        arr, n = _refs(keys)
+        h = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_join_build(self.ctx.h, self.h, arr, n, 1 if unique else 0, C.byref(h)))
+        return HashTable(self.ctx, h, self)
+
+    def sort(self, specs):
+        arr = (SortSpec * len(specs))(*specs)
+        r = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_sort(self.ctx.h, self.h, arr, len(specs), C.byref(r)))
+        return Rel(self.ctx, r, self.deps)
+
+    def topk(self, specs, k):
+        arr = (SortSpec * len(specs))(*specs)
+        r = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_topk(self.ctx.h, self.h, arr, len(specs), k, C.byref(r)))
+        return Rel(self.ctx, r, self.deps)
+
+    def partition(self, keys, nparts, cols):
+        karr, nk = _refs(keys)
+        carr, nc = _refs(cols)
+        counts = (C.c_int64 * nparts)()
+        t = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_partition(self.ctx.h, self.h, karr, nk, nparts, carr, nc, C.byref(t), counts))
+        return Table(self.ctx, t), list(counts)
+
+
+class HashTable:
+    def __init__(self, ctx, handle, build_rel):
+        self.ctx, self.h, self.build = ctx, handle, build_rel
+
+    def release(self):
+        if self.h:
+            check(self.ctx.lib.ldb_gpu_hashtable_release(self.ctx.h, self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    @property
+    def slots(self):
+        return self.ctx.lib.ldb_gpu_hashtable_slots(self.h)
+
+    def probe(self, probe_rel, keys, kind=capi.JOIN_INNER):
+        arr, n = _refs(keys)
+        r, m = C.c_void_p(), C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_join_probe(self.ctx.h, self.h, probe_rel.h, arr, n, kind, C.byref(r), C.byref(m)))
+        out = Rel(self.ctx, r, probe_rel.deps + self.build.deps + [self.build])
+        if kind == capi.JOIN_MARK:
+            return out, Table(self.ctx, m)
+        return out
+
+    def probe_count(self, probe_rel, keys):
+        arr, n = _refs(keys)
+        c = C.c_int64()
+        check(self.ctx.lib.ldb_gpu_join_probe_count(self.ctx.h, self.h, probe_rel.h, arr, n, C.byref(c)))
+        return c.value
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self.lib = capi.gpu_lib()
+        h = C.c_void_p()
+        check(self.lib.ldb_gpu_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.ldb_gpu_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        check(self.lib.ldb_gpu_ctx_sync(self.h))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, free, total = C.c_int32(), C.c_int64(), C.c_int64()
+        check(self.lib.ldb_gpu_device_info(self.h, name, 256, C.byref(cus), C.byref(free), C.byref(total)))
+        return {"name": name.value.decode(), "cus": cus.value, "hbm_free": free.value, "hbm_total": total.value}
+
+    # ---- timers (HIP events on the ctx stream)
+    def timer(self):
+        t = C.c_int32()
+        check(self.lib.ldb_gpu_timer_create(self.h, C.byref(t)))
+        return t.value
+
+    def timer_start(self, t):
+        check(self.lib.ldb_gpu_timer_start(self.h, t))
+
+    def timer_stop(self, t):
+        check(self.lib.ldb_gpu_timer_stop(self.h, t))
+
+    def timer_ms(self, t):
+        ms = C.c_float()
+        check(self.lib.ldb_gpu_timer_elapsed_ms(self.h, t, C.byref(ms)))
+        return ms.value
+
+    # ---- tables
+    def register(self, name, table: pa.Table, narrow_decimals=False):
+        """Arrow C Data Interface hand-over of host record batches (zero-copy on the host side)."""
+        batches = table.to_batches()
+        if not batches:
+            batches = [pa.RecordBatch.from_arrays([pa.array([], type=f.type) for f in table.schema], schema=table.schema)]
+        schema = capi.ArrowSchema()
+        table.schema._export_to_c(C.addressof(schema))
+        arrays = [capi.ArrowArray() for _ in batches]
+        for a, b in zip(arrays, batches):
+            b._export_to_c(C.addressof(a))
+        ptrs = (C.POINTER(capi.ArrowArray) * len(arrays))(*[C.pointer(a) for a in arrays])
+        h = C.c_void_p()
+        try:
+            check(self.lib.ldb_gpu_table_register(self.h, name.encode(), C.byref(schema), ptrs, len(arrays), 1 if narrow_decimals else 0, C.byref(h)))
+        finally:
+            # the library copied everything to the device: release the exported structs
+            rel_t = C.CFUNCTYPE(None, C.c_void_p)
+            for a in arrays:
+                if a.release:
+                    rel_t(a.release)(C.addressof(a))
+            if schema.release:
+                rel_t(schema.release)(C.addressof(schema))
+        return Table(self, h)
+
+    def tpch_generate(self, table_id, n_orders, part=0, n_parts=1, cols=None, narrow_decimals=False, all_cols=None):
+        mask = 0
+        if cols is not None:
+            for c in cols:
+                mask |= 1 << c
+        h = C.c_void_p()
+        check(self.lib.ldb_gpu_tpch_generate(self.h, table_id, n_orders, part, n_parts, mask, 1 if narrow_decimals else 0, C.byref(h)))
+        return Table(self, h)
+
+    # ---- plans (C++ host mirror)
+    def plan_q1(self, lineitem):
+        t = C.c_void_p()
+        check_plan(capi.host_lib().ldb_plan_tpch_q1(self.h, lineitem.h, C.byref(t)))
+        return Table(self, t)
+
+    def plan_q6(self, lineitem):
+        t = C.c_void_p()
+        check_plan(capi.host_lib().ldb_plan_tpch_q6(self.h, lineitem.h, C.byref(t)))
+        return Table(self, t)
+
+    def plan_q3(self, customer, orders, lineitem):
+        t = C.c_void_p()
+        check_plan(capi.host_lib().ldb_plan_tpch_q3(self.h, customer.h, orders.h, lineitem.h, C.byref(t)))
+        return Table(self, t)

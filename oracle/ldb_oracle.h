@@ -1,0 +1,83 @@
+/*
+ * ldb_oracle.h — CPU restatement of LingoDB's sub-operator hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is linked into, imported by, or executed
+ * from the product (liblingodb_gpu.so, lingo-db_amd/).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may use it, and only as the checker / reported baseline.
+ *
+ * Each function cites the reference file:line it restates (paths relative to the
+ * lingo-db/lingo-db checkout).  Parity pinning: the hash functions are checked against the
+ * reference's known-answer vectors (test/lit/DB/hash.mlir:27-34,
+ * test/unittests/storage/TestStorage.cpp:289) in tests/test_oracle_golden.py; the operator
+ * restatements are cross-checked against the reference's own runtime objects compiled from
+ * /root/reference (oracle/_ref, see oracle/ref_build/) where those compile offline.
+ * Long-string hashing (XXH64, seed 0 = llvm::xxHash64 of LLVM 20.1) has no absolute
+ * known-answer in the reference ("parity unpinned" for that one function; it is checked
+ * against the xxhash package's published test vectors instead).
+ *
+ * Descriptors (ldb_filter_desc, ldb_expr, ldb_agg_spec, ldb_sort_spec) are shared with the
+ * C-ABI so the same test input drives both sides.
+ */
+#ifndef LDB_ORACLE_H
+#define LDB_ORACLE_H
+#include "../include/lingodb_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+   int32_t type; /* ldb_type */
+   int32_t precision, scale;
+   int32_t width; /* bytes per value as stored: 16 (or 8 when narrowed) for decimals */
+   const void* values;
+   const int64_t* offsets; /* utf8: int64[n+1] */
+   const uint8_t* validity; /* Arrow validity bitmap or NULL = all valid */
+} ora_col;
+
+typedef struct {
+   int64_t n_rows;
+   int32_t n_cols;
+   const ora_col* cols;
+} ora_table;
+
+typedef struct {
+   int64_t n_rows;
+   int32_t n_sides;
+   const ora_table* tables[LDB_MAX_SIDES];
+   const uint32_t* rowids[LDB_MAX_SIDES]; /* NULL = identity */
+} ora_rel;
+
+/* ---- scalar spec (a5) */
+uint64_t ora_hash64(int64_t v);
+uint64_t ora_hash_combine(uint64_t h_new, uint64_t total);
+uint64_t ora_xxh64(const void* data, uint64_t len, uint64_t seed);
+void ora_varlen32_image(const uint8_t* p, uint32_t len, uint8_t out16[16]);
+uint64_t ora_hash_varlen(const uint8_t* p, uint32_t len);
+uint64_t ora_hash_i128(uint64_t lo, int64_t hi, int first, uint64_t total);
+uint16_t ora_bloom_mask(uint32_t idx);
+
+/* ---- operators.  `threads` = worker count (morsel size 20 000 rows as the reference). */
+int64_t ora_scan_filter(const ora_rel* in, const ldb_filter_desc* preds, int32_t n_preds, uint32_t* out_rows, int32_t threads);
+void ora_hash_keys(const ora_rel* in, const ldb_colref* keys, int32_t n_keys, uint64_t* out);
+/* returns #groups; rep_rows[g] = logical row of `in` holding the group's key values;
+ * vals[g*n_aggs + a] = aggregate as 128-bit integer (lo,hi) or, for is_float args, the f64 bits in lo;
+ * valid[g*n_aggs+a] = 0 when the aggregate is NULL (MIN/MAX/SUM over no non-null input). */
+int64_t ora_groupby(const ora_rel* in, const ldb_filter_desc* preds, int32_t n_preds, const ldb_colref* keys, int32_t n_keys,
+                    const ldb_agg_spec* aggs, int32_t n_aggs, int32_t threads, uint32_t* rep_rows, int64_t* vals_lohi,
+                    uint8_t* valid, int64_t cap_groups);
+/* returns #output rows (may exceed cap: then only cap rows were written) */
+int64_t ora_join(const ora_rel* build, const ldb_colref* bkeys, const ora_rel* probe, const ldb_colref* pkeys, int32_t n_keys,
+                 int32_t kind, int32_t threads, uint32_t* out_probe, uint32_t* out_build, uint8_t* out_mark, int64_t cap);
+void ora_sort(const ora_rel* in, const ldb_sort_spec* specs, int32_t n_specs, uint32_t* out_perm);
+int64_t ora_topk(const ora_rel* in, const ldb_sort_spec* specs, int32_t n_specs, int64_t k, uint32_t* out_perm);
+/* evaluate an expression for every row (tests of a16): out = lo/hi pairs */
+void ora_eval_expr(const ora_rel* in, const ldb_expr* e, int64_t* out_lohi);
+/* partition id per row: (hash >> 16) % nparts */
+void ora_partition_ids(const ora_rel* in, const ldb_colref* keys, int32_t n_keys, int32_t nparts, int32_t* out);
+int32_t ora_num_cores(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,230 @@
+"""Pins the CPU oracle against the reference's own known-answer vectors and
+against independent restatements (numpy / python ints).  Runs without a GPU."""
+import datetime
+import decimal
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from lingodb_amd import api, capi
+from oracle_bind import HostTable
+
+M64 = (1 << 64) - 1
+
+
+# ---------------------------------------------------------------- reference golden vectors
+# test/lit/DB/hash.mlir:27-34 (FileCheck'd stdout of the reference's compiled db.hash)
+def test_hash_mlir_scalars(oracle):
+    assert oracle.hash64(10) == 9003023063795233148  # i32 10 and i64 10 (sign-extended)
+    assert oracle.hash64(-1) == 14576801547736533962  # i1 true sign-extends to -1
+    assert oracle.hash64(10001) == 5768746606534069840  # decimal(15,2) 100.01 → i64 10001
+    days = (datetime.date(2020, 6, 11) - datetime.date(1970, 1, 1)).days
+    assert oracle.hash64(days * 86400000000000) == 5158205948029867335  # date hashed in ns
+    secs = int(datetime.datetime(2020, 6, 11, 12, 30, 0, tzinfo=datetime.timezone.utc).timestamp())
+    # a db.constant of timestamp<second> keeps its own unit (only Arrow LOADS are rescaled to ns,
+    # LowerToStd.cpp:149-160), so the golden value is the hash of the seconds count
+    assert oracle.hash64(secs) == 12374225058675341995
+    assert oracle.hash_varlen(b"hello world!") == 15716802195356392922  # 12-byte inline path
+
+
+def test_hash_mlir_tuple_fold(oracle):
+    # 7-tuple (i32 10, i64 10, true, decimal 100.01, date, timestamp, "hello world!"): fold new ^ bswap(total)
+    days = (datetime.date(2020, 6, 11) - datetime.date(1970, 1, 1)).days
+    secs = int(datetime.datetime(2020, 6, 11, 12, 30, 0, tzinfo=datetime.timezone.utc).timestamp())
+    parts = [oracle.hash64(10), oracle.hash64(10), oracle.hash64(-1), oracle.hash64(10001), oracle.hash64(days * 86400000000000),
+             oracle.hash64(secs), oracle.hash_varlen(b"hello world!")]
+    total = parts[0]
+    for h in parts[1:]:
+        total = oracle.hash_combine(h, total)
+    assert total == 12427541571883202476
+
+
+# test/unittests/storage/TestStorage.cpp:289 — lookup(-3797884931935089717) finds int8 key 1
+def test_hash_teststorage_int8(oracle):
+    assert oracle.hash64(1) == (-3797884931935089717) % (1 << 64)
+
+
+def test_hash_keys_matches_golden_through_columns(oracle):
+    """the same vectors through ora_hash_keys on Arrow-typed columns (type widening rules)"""
+    t = pa.table({
+        "i32": pa.array([10], pa.int32()),
+        "i64": pa.array([10], pa.int64()),
+        "dec": pa.array([decimal.Decimal("100.01")], pa.decimal128(15, 2)),
+        "date": pa.array([datetime.date(2020, 6, 11)], pa.date32()),
+        "str": pa.array(["hello world!"], pa.string()),
+        "i8": pa.array([1], pa.int8()),
+    })
+    rel = HostTable(t).rel()
+    assert oracle.hash_keys(rel, [(0, 0)])[0] == 9003023063795233148
+    assert oracle.hash_keys(rel, [(0, 1)])[0] == 9003023063795233148
+    assert oracle.hash_keys(rel, [(0, 2)])[0] == 5768746606534069840
+    assert oracle.hash_keys(rel, [(0, 3)])[0] == 5158205948029867335
+    assert oracle.hash_keys(rel, [(0, 4)])[0] == 15716802195356392922
+    assert oracle.hash_keys(rel, [(0, 5)])[0] == 14648859141774461899
+
+
+# ---------------------------------------------------------------- third-party algorithm (LLVM xxHash64 = XXH64 seed 0)
+def test_xxh64_published_vectors(oracle):
+    xxhash = pytest.importorskip("xxhash")
+    rng = np.random.default_rng(7)
+    samples = [b"", b"a", b"abc", b"betaggamaetanetalambda", bytes(range(64)), bytes(rng.integers(0, 256, 1000, dtype=np.uint8))]
+    samples += [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in range(13, 80)]
+    for s in samples:
+        assert oracle.xxh64(s) == xxhash.xxh64(s, seed=0).intdigest()
+    # known XXH64 test vector from the xxHash repository (empty input, seed 0)
+    assert oracle.xxh64(b"") == 0xEF46DB3751D8E999
+
+
+def test_long_string_uses_xxh64(oracle):
+    s = b"betaggamaetanetalambda"  # the >12-byte string of TestStorage.cpp:306-372
+    assert oracle.hash_varlen(s) == oracle.xxh64(s)
+
+
+# ---------------------------------------------------------------- independent restatements
+def _py_hash64(v):
+    m = (v * 11400714819323198549) & M64
+    return m ^ int.from_bytes(m.to_bytes(8, "little"), "big")
+
+
+def test_hash64_python_model(oracle):
+    rng = np.random.default_rng(1)
+    for v in rng.integers(-(2 ** 63), 2 ** 63 - 1, 200):
+        assert oracle.hash64(int(v)) == _py_hash64(int(v) & M64)
+
+
+def test_short_string_image(oracle):
+    for s in [b"", b"a", b"abcd", b"abcdefgh", b"abcdefghi", b"abcdefghijkl"]:
+        img = len(s).to_bytes(4, "little") + s.ljust(12, b"\0")
+        first, last = int.from_bytes(img[:8], "little"), int.from_bytes(img[8:], "little")
+        lh = _py_hash64(last)
+        want = _py_hash64(first) ^ int.from_bytes(lh.to_bytes(8, "little"), "big")
+        assert oracle.hash_varlen(s) == want
+
+
+def test_bloom_masks_shape(oracle):
+    masks = [oracle.lib.ora_bloom_mask(i) for i in range(2048)]
+    assert all(bin(m).count("1") == 4 for m in masks)
+    assert masks[:6] == [15, 23, 27, 29, 30, 39]  # head of the reference table (src/runtime/helpers.cpp)
+    assert len(set(masks[:1820])) == 1820
+
+
+def _lineitem_like(n, seed=3, nulls=False):
+    rng = np.random.default_rng(seed)
+    qty = rng.integers(1, 51, n) * 100
+    price = rng.integers(90000, 10500000, n)
+    disc = rng.integers(0, 11, n)
+    tax = rng.integers(0, 9, n)
+    flag = [[b"A\0\0\0", b"N\0\0\0", b"R\0\0\0"][i] for i in rng.integers(0, 3, n)]
+    status = [[b"F\0\0\0", b"O\0\0\0"][i] for i in rng.integers(0, 2, n)]
+    ship = rng.integers(8035, 10600, n).astype(np.int32)
+    dec = lambda a: pa.array([decimal.Decimal(int(x)).scaleb(-2) for x in a], pa.decimal128(12, 2))
+    cols = {
+        "qty": dec(qty), "price": dec(price), "disc": dec(disc), "tax": dec(tax),
+        "flag": pa.array(flag, pa.binary(4)), "status": pa.array(status, pa.binary(4)),
+        "ship": pa.array(ship, pa.int32()).cast(pa.date32()),
+    }
+    raw = dict(qty=qty, price=price, disc=disc, tax=tax, flag=flag, status=status, ship=ship)
+    return pa.table(cols), raw
+
+
+def test_scan_filter_vs_numpy(oracle):
+    t, raw = _lineitem_like(50021)
+    rel = HostTable(t).rel()
+    plist = [api.pred((0, 6), capi.F_LTE, 10471), api.pred((0, 2), capi.F_GTE, 5), api.pred((0, 0), capi.F_LT, 2400)]
+    want = np.nonzero((raw["ship"] <= 10471) & (raw["disc"] >= 5) & (raw["qty"] < 2400))[0]
+    for threads in (1, 4):
+        got = oracle.scan_filter(rel, plist, threads)
+        assert np.array_equal(got, want.astype(np.uint32))
+
+
+def test_groupby_q1_shape_vs_python(oracle):
+    t, raw = _lineitem_like(40003)
+    rel = HostTable(t).rel()
+    f = api.factor
+    e_qty = api.col_expr((0, 0))
+    e_dp = api.expr([{"factors": [f(0, 1, (0, 1)), f(100, -1, (0, 2))]}])
+    e_ch = api.expr([{"factors": [f(0, 1, (0, 1)), f(100, -1, (0, 2)), f(100, 1, (0, 3))]}])
+    aggs = [api.agg(capi.AGG_SUM, e_qty, out_type=capi.T_DECIMAL128, p=12, s=2),
+            api.agg(capi.AGG_SUM, e_dp, wide=True, out_type=capi.T_DECIMAL128, p=33, s=4),
+            api.agg(capi.AGG_SUM, e_ch, wide=True, out_type=capi.T_DECIMAL128, p=38, s=6),
+            api.agg(capi.AGG_AVG, e_qty, out_type=capi.T_DECIMAL128, p=31, s=21, avg_pow10=19),
+            api.agg(capi.AGG_COUNT_STAR)]
+    plist = [api.pred((0, 6), capi.F_LTE, 10471)]
+    want = {}
+    for i in range(len(raw["qty"])):
+        if raw["ship"][i] > 10471:
+            continue
+        k = (bytes(raw["flag"][i]), bytes(raw["status"][i]))
+        a = want.setdefault(k, [0, 0, 0, 0])
+        q, p, d, x = int(raw["qty"][i]), int(raw["price"][i]), int(raw["disc"][i]), int(raw["tax"][i])
+        a[0] += q
+        a[1] += p * (100 - d)
+        a[2] += p * (100 - d) * (100 + x)
+        a[3] += 1
+    for threads in (1, 3):
+        rep, vals, valid = oracle.groupby(rel, [(0, 4), (0, 5)], aggs, plist, threads)
+        assert len(rep) == len(want)
+        for g, r in enumerate(rep):
+            k = (bytes(raw["flag"][r]), bytes(raw["status"][r]))
+            sq, sdp, sch, cnt = want[k]
+            # AVG = (sum * 10^19) sdiv count, truncating (positive here)
+            assert vals[g] == [sq, sdp, sch, (sq * 10 ** 19) // cnt, cnt]
+            assert valid[g].all()
+
+
+def test_join_vs_numpy(oracle):
+    rng = np.random.default_rng(5)
+    bk = rng.integers(0, 500, 700).astype(np.int32)
+    pk = rng.integers(0, 800, 3000).astype(np.int32)
+    b = HostTable(pa.table({"k": pa.array(bk)})).rel()
+    p = HostTable(pa.table({"k": pa.array(pk)})).rel()
+    for threads in (1, 4):
+        op, ob, _ = oracle.join(b, [(0, 0)], p, [(0, 0)], capi.JOIN_INNER, threads)
+        got = sorted(zip(op.tolist(), ob.tolist()))
+        want = sorted((i, j) for i in range(len(pk)) for j in np.nonzero(bk == pk[i])[0].tolist())
+        assert got == want
+        semi, _, _ = oracle.join(b, [(0, 0)], p, [(0, 0)], capi.JOIN_SEMI, threads)
+        assert np.array_equal(semi, np.nonzero(np.isin(pk, bk))[0].astype(np.uint32))
+        anti, _, _ = oracle.join(b, [(0, 0)], p, [(0, 0)], capi.JOIN_ANTI, threads)
+        assert np.array_equal(anti, np.nonzero(~np.isin(pk, bk))[0].astype(np.uint32))
+
+
+def test_join_null_keys_never_match(oracle):
+    b = HostTable(pa.table({"k": pa.array([1, None, 3], pa.int32())})).rel()
+    p = HostTable(pa.table({"k": pa.array([None, 1, 3, 4], pa.int32())})).rel()
+    op, ob, _ = oracle.join(b, [(0, 0)], p, [(0, 0)], capi.JOIN_INNER)
+    assert sorted(zip(op.tolist(), ob.tolist())) == [(1, 0), (2, 2)]
+    lo_p, lo_b, _ = oracle.join(b, [(0, 0)], p, [(0, 0)], capi.JOIN_LEFT_OUTER)
+    assert sorted(zip(lo_p.tolist(), lo_b.tolist())) == [(0, capi.LDB_NULL_ROW), (1, 0), (2, 2), (3, capi.LDB_NULL_ROW)]
+
+
+def test_sort_and_topk(oracle):
+    rng = np.random.default_rng(9)
+    a = rng.integers(-5, 5, 300).astype(np.int64)
+    s = [["x", "yy", "", "abc", "ab"][i] for i in rng.integers(0, 5, 300)]
+    rel = HostTable(pa.table({"a": pa.array(a), "s": pa.array(s)})).rel()
+    perm = oracle.sort(rel, [api.sort_spec((0, 0), True), api.sort_spec((0, 1))])
+    want = sorted(range(300), key=lambda i: (-a[i], s[i].encode(), i))
+    assert perm.tolist() == want
+    assert oracle.topk(rel, [api.sort_spec((0, 0), True), api.sort_spec((0, 1))], 7).tolist() == want[:7]
+
+
+def test_groupby_null_key_and_nullable_agg(oracle):
+    # test/sqlite-small/groupby.test semantics: NULL is its own group; SUM skips NULLs; SUM of none = NULL
+    t = pa.table({"k": pa.array([1, None, 1, None, 2], pa.int32()), "v": pa.array([10, 20, None, 5, None], pa.int64())})
+    rel = HostTable(t).rel()
+    aggs = [api.agg(capi.AGG_SUM, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT_STAR)]
+    rep, vals, valid = oracle.groupby(rel, [(0, 0)], aggs)
+    keys = [t.column(0)[int(r)].as_py() for r in rep]
+    got = {k: (v, list(ok)) for k, v, ok in zip(keys, vals, valid)}
+    assert got[1] == ([10, 1, 2], [1, 1, 1])
+    assert got[None] == ([25, 2, 2], [1, 1, 1])
+    assert got[2][0][1:] == [0, 1] and list(got[2][1]) == [0, 1, 1]
+
+
+def test_keyless_empty_input(oracle):
+    t = pa.table({"v": pa.array([], pa.int64())})
+    rel = HostTable(t).rel()
+    rep, vals, valid = oracle.groupby(rel, [], [api.agg(capi.AGG_SUM, api.col_expr((0, 0))), api.agg(capi.AGG_COUNT_STAR)])
+    assert len(rep) == 1 and vals[0][1] == 0 and list(valid[0]) == [0, 1]
