@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py — TPC-H (synthetic, dbgen-shaped) on the MI355X-native LingoDB operator runtime.
+
+  python bench.py --gpus N --steps K --warmup W [--sf 100] [--queries 1,6,3]
+
+One "step" = one pass of the implemented TPC-H queries over the HBM-resident database.
+N > 1: launched by torch.distributed.run, one rank per GPU; the database is sharded by order
+ranges (strong scaling: the total is SF `--sf`), partial results are merged over RCCL.
+Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "lingo-db_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ≈6.3 TB/s achievable
+ORDERS_PER_SF = 1_500_000
+
+# algorithmic bytes per input row at the resident (Arrow-native) widths, SURVEY §8(d)
+Q1_BYTES_PER_ROW = 4 + 4 + 4 + 16 + 16 + 16 + 16  # shipdate, returnflag, linestatus, qty, extprice, discount, tax
+Q1_BYTES_PER_ROW_NARROW = 4 + 4 + 4 + 8 + 8 + 8 + 8
+
+
+def geomean(xs):
+    xs = [max(x, 1e-9) for x in xs]
+    return math.exp(sum(math.log(x) for x in xs) / len(xs))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--sf", type=float, default=100.0)
+    ap.add_argument("--queries", default="1,6,3")
+    ap.add_argument("--narrow-decimals", type=int, default=0)
+    ap.add_argument("--cpu-sample-sf", type=float, default=1.0, help="scale of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback: the product path is the HIP library)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import lingodb_amd as ldb
+    import tpch_plans
+
+    queries = [int(q) for q in args.queries.split(",") if q]
+    n_orders = int(round(args.sf * ORDERS_PER_SF))
+    ctx = ldb.Context(local_rank)
+    info = ctx.device_info()
+    db = tpch_plans.Database(ctx, n_orders, rank, world, queries, bool(args.narrow_decimals))
+    runner = tpch_plans.Runner(ctx, db, world, dist if world > 1 else None, torch)
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.prof_enable(True)
+    for _ in range(args.warmup):
+        for q in queries:
+            runner.run(q)
+    timers = {q: ctx.timer() for q in queries}
+    q_ms = {q: 0.0 for q in queries}
+    kernel_ms = {}  # (query, kernel) -> [launches, ms]
+    ctx.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for q in queries:
+            ctx.timer_start(timers[q])
+            runner.run(q)
+            ctx.timer_stop(timers[q])
+            q_ms[q] += ctx.timer_ms(timers[q])
+            for k, (n, ms) in ctx.prof_all().items():
+                e = kernel_ms.setdefault((q, k), [0, 0.0])
+                e[0] += n
+                e[1] += ms
+            ctx.prof_reset()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1000.0
+    per_query = {q: q_ms[q] / args.steps for q in queries}
+    if world > 1:
+        t = torch.tensor([per_query[q] for q in queries], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_query = {q: float(v) for q, v in zip(queries, t.tolist())}
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the fused scan+filter+aggregate kernel of Q1
+        roof_q = 1 if 1 in queries else queries[0]
+        n_l, ms_l = kernel_ms.get((roof_q, "k_groupby"), [0, 0.0])
+        rows_local = db.lineitem.rows
+        bpr = Q1_BYTES_PER_ROW_NARROW if args.narrow_decimals else Q1_BYTES_PER_ROW
+        roofline = None
+        if n_l:
+            avg_ms = ms_l / n_l
+            achieved = rows_local * bpr / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "k_groupby (TPC-H Q%d: scan+filter+hash aggregate)" % roof_q, "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_kernel_ms": round(avg_ms, 4), "launches": n_l, "algorithmic_bytes_per_launch": rows_local * bpr,
+                        "bytes_per_row": bpr}
+        extras = {}
+        if 3 in queries:
+            n_p, ms_p = kernel_ms.get((3, "k_join_probe_pairs"), [0, 0.0])
+            if n_p:
+                extras["q3_probe_launches_per_step"] = n_p / args.steps
+                extras["q3_probe_ms_per_step"] = round(ms_p / args.steps, 4)
+        probe = runner.probe_microbench() if 3 in queries else None
+        cpu = None
+        if world == 1 and args.cpu_sample_sf > 0:
+            cpu = tpch_plans.cpu_baseline(queries, args.cpu_sample_sf)
+        out = {
+            "metric": "tpch_sf%g_geomean_ms" % args.sf,
+            "value": round(geomean([per_query[q] for q in queries]), 4),
+            "unit": "ms",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": False,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "int64/int128 decimal",
+            "data": "synthetic",
+            "config": {"workload": "TPC-H SF%g %s on %d x MI355X, Arrow columns resident in HBM (synthetic dbgen-shaped data, seed 20260925)" % (
+                args.sf, "+".join("Q%d" % q for q in queries), world), "queries": queries, "rows_lineitem_total": int(db.n_lineitem_total),
+                "narrow_decimals": bool(args.narrow_decimals), "device": info["name"]},
+            "per_query_ms": {"Q%d" % q: round(v, 4) for q, v in per_query.items()},
+            "kernel_ms_per_step": {"Q%d:%s" % (q, k): round(v[1] / args.steps, 4) for (q, k), v in sorted(kernel_ms.items())},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if probe:
+            out["join_probe"] = probe
+        out.update(extras)
+    barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,16 @@ int32_t ldb_gpu_timer_start(ldb_ctx* ctx, int32_t timer_id);
 int32_t ldb_gpu_timer_stop(ldb_ctx* ctx, int32_t timer_id);
 int32_t ldb_gpu_timer_elapsed_ms(ldb_ctx* ctx, int32_t timer_id, float* ms); /* syncs on the stop event */
 
+/* Per-kernel timing (Tracer-event equivalent, reference include/lingodb/utility/Tracer.h:13-166):
+ * when enabled, the dominant kernels of each operator (k_groupby, k_scan_bitmap, k_join_build,
+ * k_join_probe_*, …) are bracketed by HIP events on the ctx stream.  prof_get syncs, folds the
+ * finished launches into per-name totals and returns launches and total milliseconds. */
+int32_t ldb_gpu_prof_enable(ldb_ctx* ctx, int32_t on);
+int32_t ldb_gpu_prof_reset(ldb_ctx* ctx);
+int32_t ldb_gpu_prof_get(ldb_ctx* ctx, const char* kernel_name, int64_t* launches, double* total_ms);
+/* names of all kernels seen so far, '\n'-separated, into buf */
+int32_t ldb_gpu_prof_names(ldb_ctx* ctx, char* buf, int32_t cap);
+
 /* ------------------------------------------------------------------ tables (a1) */
 /* Replaces LingoDBTable::ensureLoaded + TableChunk flattening (LingoDBTable.cpp:27-54,
  * 200-225).  `schema` is a struct schema (format "+s"); each batch a struct array whose

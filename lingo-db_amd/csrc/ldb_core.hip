@@ -72,6 +72,11 @@ extern "C" int32_t ldb_gpu_ctx_destroy(ldb_ctx* ctx) {
    (void) hipSetDevice(ctx->device);
    (void) hipStreamSynchronize(ctx->stream);
    for (auto e : ctx->timers) (void) hipEventDestroy(e);
+   for (auto& p : ctx->prof_pending) {
+      (void) hipEventDestroy(p.start);
+      (void) hipEventDestroy(p.stop);
+   }
+   for (auto e : ctx->prof_free) (void) hipEventDestroy(e);
    if (ctx->h_scratch) (void) hipHostFree(ctx->h_scratch);
    if (ctx->d_scratch) (void) hipFree(ctx->d_scratch);
    if (ctx->own_stream) (void) hipStreamDestroy(ctx->stream);
@@ -117,6 +122,83 @@ extern "C" int32_t ldb_gpu_timer_elapsed_ms(ldb_ctx* ctx, int32_t id, float* ms)
    if (id < 0 || (size_t) id * 2 + 1 >= ctx->timers.size() + 0) LDB_FAIL(LDB_ERR_INVALID, "bad timer id %d", id);
    LDB_HIP(hipEventSynchronize(ctx->timers[(size_t) id * 2 + 1]));
    LDB_HIP(hipEventElapsedTime(ms, ctx->timers[(size_t) id * 2], ctx->timers[(size_t) id * 2 + 1]));
+   return LDB_OK;
+}
+
+// ---------------------------------------------------------------- per-kernel profiling
+static hipEvent_t prof_event(ldb_ctx* ctx) {
+   if (!ctx->prof_free.empty()) {
+      hipEvent_t e = ctx->prof_free.back();
+      ctx->prof_free.pop_back();
+      return e;
+   }
+   hipEvent_t e = nullptr;
+   (void) hipEventCreate(&e);
+   return e;
+}
+LdbProf::LdbProf(ldb_ctx* c, const char* name) : ctx(c) {
+   if (!c->prof_on) return;
+   ldb_prof_pending p{name, prof_event(c), prof_event(c)};
+   if (!p.start || !p.stop) return;
+   (void) hipEventRecord(p.start, c->stream);
+   idx = c->prof_pending.size();
+   c->prof_pending.push_back(p);
+   active = true;
+}
+LdbProf::~LdbProf() {
+   if (active) (void) hipEventRecord(ctx->prof_pending[idx].stop, ctx->stream);
+}
+static void prof_fold(ldb_ctx* ctx) {
+   if (ctx->prof_pending.empty()) return;
+   (void) hipStreamSynchronize(ctx->stream);
+   for (auto& p : ctx->prof_pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+         ldb_prof_total* t = nullptr;
+         for (auto& x : ctx->prof_totals)
+            if (x.name == p.name) t = &x;
+         if (!t) {
+            ctx->prof_totals.push_back({p.name, 0, 0});
+            t = &ctx->prof_totals.back();
+         }
+         t->launches++;
+         t->ms += ms;
+      }
+      ctx->prof_free.push_back(p.start);
+      ctx->prof_free.push_back(p.stop);
+   }
+   ctx->prof_pending.clear();
+}
+extern "C" int32_t ldb_gpu_prof_enable(ldb_ctx* ctx, int32_t on) {
+   if (!ctx) LDB_FAIL(LDB_ERR_INVALID, "prof_enable: NULL ctx");
+   prof_fold(ctx);
+   ctx->prof_on = on != 0;
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_prof_reset(ldb_ctx* ctx) {
+   if (!ctx) LDB_FAIL(LDB_ERR_INVALID, "prof_reset: NULL ctx");
+   prof_fold(ctx);
+   ctx->prof_totals.clear();
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_prof_get(ldb_ctx* ctx, const char* kernel_name, int64_t* launches, double* total_ms) {
+   if (!ctx || !kernel_name) LDB_FAIL(LDB_ERR_INVALID, "prof_get: NULL argument");
+   prof_fold(ctx);
+   if (launches) *launches = 0;
+   if (total_ms) *total_ms = 0;
+   for (auto& x : ctx->prof_totals)
+      if (x.name == kernel_name) {
+         if (launches) *launches = x.launches;
+         if (total_ms) *total_ms = x.ms;
+      }
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_prof_names(ldb_ctx* ctx, char* buf, int32_t cap) {
+   if (!ctx || !buf || cap < 1) LDB_FAIL(LDB_ERR_INVALID, "prof_names: bad argument");
+   prof_fold(ctx);
+   std::string s;
+   for (auto& x : ctx->prof_totals) s += x.name + "\n";
+   snprintf(buf, (size_t) cap, "%s", s.c_str());
    return LDB_OK;
 }
 

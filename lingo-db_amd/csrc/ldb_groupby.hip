@@ -747,7 +747,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       if (in->n_rows) {
          int per_cu = lds_bytes > 40 * 1024 ? 2 : 4;
          int grid = ldb_grid_for(ctx, in->n_rows, GB_BLOCK, per_cu);
-         hipLaunchKernelGGL(k_groupby, dim3(grid), dim3(GB_BLOCK), lds_bytes, ctx->stream, d);
+         { LdbProf prof_(ctx, "k_groupby"); hipLaunchKernelGGL(k_groupby, dim3(grid), dim3(GB_BLOCK), lds_bytes, ctx->stream, d); }
       }
       LDB_HIP(hipGetLastError());
       uint64_t flags = 0;

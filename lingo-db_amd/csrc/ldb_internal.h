@@ -77,7 +77,20 @@ struct ldb_column {
    bool owned = true;
 };
 
+struct ldb_prof_pending {
+   const char* name;
+   hipEvent_t start, stop;
+};
+struct ldb_prof_total {
+   std::string name;
+   int64_t launches = 0;
+   double ms = 0;
+};
 struct ldb_ctx {
+   bool prof_on = false;
+   std::vector<ldb_prof_pending> prof_pending;
+   std::vector<ldb_prof_total> prof_totals;
+   std::vector<hipEvent_t> prof_free;
    int device = 0;
    hipStream_t stream = nullptr;
    bool own_stream = false;
@@ -104,6 +117,15 @@ struct ldb_rel {
    ldb_ctx* ctx = nullptr;
    int64_t n_rows = 0;
    std::vector<ldb_rel_side> sides;
+};
+
+// kernel timing scope: LdbProf p(ctx, "k_name"); <launch>; (destructor records the stop event)
+struct LdbProf {
+   ldb_ctx* ctx;
+   size_t idx = 0;
+   bool active = false;
+   LdbProf(ldb_ctx* c, const char* name);
+   ~LdbProf();
 };
 
 // device allocation helpers (stream-ordered pool)

@@ -222,7 +222,7 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
    h->key32 = ht->key32;
    DJoin* d;
    LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-   if (build->n_rows) hipLaunchKernelGGL(k_join_build, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d);
+   if (build->n_rows) { LdbProf prof_(ctx, "k_join_build"); hipLaunchKernelGGL(k_join_build, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d); }
    LDB_HIP(hipGetLastError());
    ldb_dev_free(ctx, d);
    *out = ht.release();
@@ -269,7 +269,7 @@ extern "C" int32_t ldb_gpu_join_probe_count(ldb_ctx* ctx, ldb_hashtable* ht, ldb
    hp->counter = counter;
    DJoin* d;
    LDB_TRY(ldb_dev_upload(ctx, hp.get(), sizeof(DJoin), (void**) &d));
-   if (probe->n_rows) hipLaunchKernelGGL(k_join_probe_count, dim3(ldb_grid_for(ctx, probe->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d);
+   if (probe->n_rows) { LdbProf prof_(ctx, "k_join_probe_count"); hipLaunchKernelGGL(k_join_probe_count, dim3(ldb_grid_for(ctx, probe->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d); }
    LDB_HIP(hipGetLastError());
    uint64_t m = 0;
    LDB_TRY(ldb_read_u64(ctx, counter + 1, &m));
@@ -309,7 +309,7 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
       LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-      if (n) hipLaunchKernelGGL(k_join_probe_exists, dim3(grid), dim3(256), 0, ctx->stream, d);
+      if (n) { LdbProf prof_(ctx, "k_join_probe_exists"); hipLaunchKernelGGL(k_join_probe_exists, dim3(grid), dim3(256), 0, ctx->stream, d); }
       LDB_HIP(hipGetLastError());
       ldb_dev_free(ctx, d);
       if (kind == LDB_JOIN_MARK) {
@@ -361,7 +361,7 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
       LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-      if (n) hipLaunchKernelGGL(k_join_probe_pairs, dim3(grid), dim3(256), 0, ctx->stream, d);
+      if (n) { LdbProf prof_(ctx, "k_join_probe_pairs"); hipLaunchKernelGGL(k_join_probe_pairs, dim3(grid), dim3(256), 0, ctx->stream, d); }
       LDB_HIP(hipGetLastError());
       LDB_TRY(ldb_read_u64(ctx, counter, &produced));
       ldb_dev_free(ctx, d);

@@ -159,7 +159,7 @@ extern "C" int32_t ldb_gpu_scan_filter(ldb_ctx* ctx, ldb_rel* in, const ldb_filt
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmap, sizeof(uint64_t) * (size_t) n_words));
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &counts, sizeof(uint32_t) * (size_t) n_blocks));
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &offsets, sizeof(uint32_t) * (size_t) n_blocks));
-   hipLaunchKernelGGL(k_scan_bitmap, dim3((unsigned) n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, d, bitmap, counts);
+   { LdbProf prof_(ctx, "k_scan_bitmap"); hipLaunchKernelGGL(k_scan_bitmap, dim3((unsigned) n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, d, bitmap, counts); }
    LDB_HIP(hipGetLastError());
    LDB_TRY(ldb_exclusive_scan_u32(ctx, counts, offsets, n_blocks, (uint64_t*) ctx->d_scratch));
    uint64_t total = 0;
@@ -182,7 +182,7 @@ extern "C" int32_t ldb_gpu_scan_count(ldb_ctx* ctx, ldb_rel* in, const ldb_filte
    DScan* d;
    LDB_TRY(ldb_dev_upload(ctx, &h, sizeof(h), (void**) &d));
    LDB_HIP(hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
-   if (in->n_rows) hipLaunchKernelGGL(k_scan_count, dim3(ldb_grid_for(ctx, in->n_rows, SCAN_BLOCK, 8)), dim3(SCAN_BLOCK), 0, ctx->stream, d, (unsigned long long*) ctx->d_scratch);
+   if (in->n_rows) { LdbProf prof_(ctx, "k_scan_count"); hipLaunchKernelGGL(k_scan_count, dim3(ldb_grid_for(ctx, in->n_rows, SCAN_BLOCK, 8)), dim3(SCAN_BLOCK), 0, ctx->stream, d, (unsigned long long*) ctx->d_scratch); }
    LDB_HIP(hipGetLastError());
    uint64_t total = 0;
    LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &total));

@@ -422,3 +422,21 @@ extern "C" int32_t ldb_plan_tpch_q3(ldb_ctx* ctx, const ldb_table* cust, const l
       check(ldb_gpu_materialize(ctx, top.r, outc, 4, result), "q3 materialize");
    });
 }
+
+// ---------------------------------------------------------------- C hooks for the host-logic tests
+extern "C" int32_t ldb_host_parse_date32(const char* s, int32_t* out) {
+   return guarded([&] { *out = parseDate32(s); });
+}
+extern "C" int32_t ldb_host_parse_decimal(const char* s, int32_t scale, int64_t* lo, int64_t* hi) {
+   return guarded([&] {
+      __int128 v = parseDecimal(s, scale);
+      *lo = (int64_t) (uint64_t) v;
+      *hi = (int64_t) (v >> 64);
+   });
+}
+// op: 0 = mul, 1 = div, 2 = add/sub/compare common type, 3 = avg
+extern "C" void ldb_host_decimal_type(int32_t op, int32_t p1, int32_t s1, int32_t p2, int32_t s2, int32_t* p, int32_t* s) {
+   DecimalType r = op == 0 ? typeAfterMul({p1, s1}, {p2, s2}) : op == 1 ? typeAfterDiv({p1, s1}, {p2, s2}) : op == 2 ? higherDecimalType({p1, s1}, {p2, s2}) : avgType({p1, s1});
+   *p = r.p;
+   *s = r.s;
+}

@@ -72,4 +72,8 @@ int32_t ldb_plan_tpch_q1(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** re
 int32_t ldb_plan_tpch_q6(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q3(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
 const char* ldb_plan_last_error(void);
+// test hooks for the host logic (date / decimal parsing, decimal typing rules)
+int32_t ldb_host_parse_date32(const char* s, int32_t* out);
+int32_t ldb_host_parse_decimal(const char* s, int32_t scale, int64_t* lo, int64_t* hi);
+void ldb_host_decimal_type(int32_t op, int32_t p1, int32_t s1, int32_t p2, int32_t s2, int32_t* p, int32_t* s);
 }

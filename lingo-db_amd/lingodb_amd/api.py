@@ -390,6 +390,23 @@ class Context:
         check(self.lib.ldb_gpu_timer_elapsed_ms(self.h, t, C.byref(ms)))
         return ms.value
 
+    # ---- per-kernel profiling (HIP events around the dominant kernels)
+    def prof_enable(self, on=True):
+        check(self.lib.ldb_gpu_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        check(self.lib.ldb_gpu_prof_reset(self.h))
+
+    def prof_get(self, name):
+        n, ms = C.c_int64(), C.c_double()
+        check(self.lib.ldb_gpu_prof_get(self.h, name.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def prof_all(self):
+        buf = C.create_string_buffer(4096)
+        check(self.lib.ldb_gpu_prof_names(self.h, buf, 4096))
+        return {k: self.prof_get(k) for k in buf.value.decode().split("\n") if k}
+
     # ---- tables
     def register(self, name, table: pa.Table, narrow_decimals=False):
         """Arrow C Data Interface hand-over of host record batches (zero-copy on the host side)."""

@@ -138,6 +138,10 @@ GPU_API = {
     "ldb_gpu_timer_start": (i32, [P, i32]),
     "ldb_gpu_timer_stop": (i32, [P, i32]),
     "ldb_gpu_timer_elapsed_ms": (i32, [P, i32, C.POINTER(C.c_float)]),
+    "ldb_gpu_prof_enable": (i32, [P, i32]),
+    "ldb_gpu_prof_reset": (i32, [P]),
+    "ldb_gpu_prof_get": (i32, [P, C.c_char_p, C.POINTER(i64), C.POINTER(C.c_double)]),
+    "ldb_gpu_prof_names": (i32, [P, C.c_char_p, i32]),
     "ldb_gpu_table_register": (i32, [P, C.c_char_p, C.POINTER(ArrowSchema), C.POINTER(C.POINTER(ArrowArray)), i64, i32, PP]),
     "ldb_gpu_table_alloc": (i32, [P, C.c_char_p, i32, C.POINTER(ColType), C.POINTER(C.c_char_p), i64, C.POINTER(i64), i32, PP]),
     "ldb_gpu_table_release": (i32, [P, P]),
@@ -181,6 +185,9 @@ HOST_API = {
     "ldb_plan_tpch_q6": (i32, [P, P, PP]),
     "ldb_plan_tpch_q3": (i32, [P, P, P, P, PP]),
     "ldb_plan_last_error": (C.c_char_p, []),
+    "ldb_host_parse_date32": (i32, [C.c_char_p, C.POINTER(i32)]),
+    "ldb_host_parse_decimal": (i32, [C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64)]),
+    "ldb_host_decimal_type": (None, [i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
 }
 
 

@@ -1,0 +1,139 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/*.h declares, fails
+loudly without a GPU, and the C++ host mirror's parsing / decimal-typing rules match the
+reference's rules.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from lingodb_amd import capi
+import tpch_data
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ldb_gpu_\w+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = capi.gpu_lib()
+    names = declared("lingodb_gpu.h") + [n for n in declared("ldb_tpchgen.h") if n.startswith("ldb_gpu_")]
+    assert len(names) >= 45
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported by liblingodb_gpu.so"
+        assert n in capi.GPU_API, f"{n} not bound in lingodb_amd.capi"
+    assert set(capi.GPU_API) <= set(names)
+
+
+def test_host_library_exports():
+    lib = capi.host_lib()
+    for n in capi.HOST_API:
+        assert hasattr(lib, n)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    st = capi.gpu_lib().ldb_gpu_ctx_create(0, None, C.byref(h))
+    assert st == capi.LDB_ERR_NO_DEVICE
+    assert b"no HIP device" in capi.gpu_lib().ldb_gpu_last_error()
+
+
+def test_struct_sizes_match_header():
+    # compile-time layout of the descriptor structs as the C compiler sees them
+    import subprocess
+    import tempfile
+
+    prog = r'''
+#include "lingodb_gpu.h"
+#include <stdio.h>
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ldb_coltype), sizeof(ldb_colref), sizeof(ldb_filter_desc), sizeof(ldb_factor),
+  sizeof(ldb_term), sizeof(ldb_expr), sizeof(ldb_agg_spec), sizeof(ldb_sort_spec)); return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "s.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    want = [C.sizeof(t) for t in (capi.ColType, capi.ColRef, capi.FilterDesc, capi.Factor, capi.Term, capi.Expr, capi.AggSpec, capi.SortSpec)]
+    assert sizes == want
+
+
+# ---------------------------------------------------------------- host mirror (Restrictions::create helpers, SQLTypeUtils)
+def parse_date(s):
+    out = C.c_int32()
+    st = capi.host_lib().ldb_host_parse_date32(s.encode(), C.byref(out))
+    return st, out.value
+
+
+def test_parse_date32():
+    assert parse_date("1970-01-01") == (0, 0)
+    assert parse_date("1998-09-02") == (0, 10471)
+    assert parse_date("1995-03-15") == (0, 9204)
+    assert parse_date("2020-06-11") == (0, 18424)
+    assert parse_date("1994-1-01") == (0, 8766)  # the regex of Restrictions.cpp:18-19 pads a 1-digit month
+    assert parse_date("1969-12-31") == (0, -1)
+    assert parse_date("not a date")[0] != 0  # reference: throws "could not parse date"
+
+
+def parse_dec(s, scale):
+    lo, hi = C.c_int64(), C.c_int64()
+    st = capi.host_lib().ldb_host_parse_decimal(s.encode(), scale, C.byref(lo), C.byref(hi))
+    return st, (hi.value << 64) | (lo.value & 0xFFFFFFFFFFFFFFFF)
+
+
+def test_parse_decimal_rescale():
+    assert parse_dec("0.05", 2) == (0, 5)
+    assert parse_dec("24", 2) == (0, 2400)
+    assert parse_dec("-1.5", 3) == (0, -1500)
+    assert parse_dec("100.01", 2) == (0, 10001)
+    assert parse_dec("12345678901234567890.12", 2) == (0, 1234567890123456789012)
+    assert parse_dec("0.055", 2)[0] != 0  # rescale would lose precision (Arrow Rescale error → ValueOrDie)
+
+
+def dec_type(op, a, b=(19, 0)):
+    p, s = C.c_int32(), C.c_int32()
+    capi.host_lib().ldb_host_decimal_type(op, a[0], a[1], b[0], b[1], C.byref(p), C.byref(s))
+    return p.value, s.value
+
+
+def test_decimal_typing_rules_q1_worked_example():
+    # SURVEY §9.1 worked example, from sql_analyzer.cpp:3058-3159
+    one_minus_disc = dec_type(2, (19, 0), (12, 2))
+    assert one_minus_disc == (21, 2)
+    disc_price = dec_type(0, (12, 2), one_minus_disc)
+    assert disc_price == (33, 4)
+    charge = dec_type(0, disc_price, (21, 2))
+    assert charge == (38, 6)  # raw (54,6) clamped, scale kept
+    assert dec_type(3, (12, 2)) == (31, 21)  # avg(decimal(12,2))
+    assert dec_type(0, (12, 2), (12, 2)) == (24, 4)  # Q6 revenue
+    assert dec_type(0, (38, 6), (38, 6)) == (38, 6)  # scale clamp: s > 6 and p - s > 32
+    assert dec_type(1, (12, 2), (12, 2)) == (26, 14)
+
+
+# ---------------------------------------------------------------- host generator invariants (include/ldb_tpchgen.h)
+def test_host_generator_shape_invariants():
+    n_orders = 7000
+    li = tpch_data.host_table(tpch_data.LINEITEM, n_orders)
+    od = tpch_data.host_table(tpch_data.ORDERS, n_orders)
+    assert li.num_rows == 4 * n_orders  # period-7 pattern, mean 4 lines per order
+    ok = np.asarray(li.column("l_orderkey"))
+    assert set(np.unique(ok)) == set(np.asarray(od.column("o_orderkey")).tolist())
+    ship = np.asarray(li.column("l_shipdate").cast("int32"))
+    rec = np.asarray(li.column("l_receiptdate").cast("int32"))
+    assert (rec > ship).all() and ship.min() >= 8036
+    flags = set(li.column("l_returnflag").to_pylist())
+    assert flags == {b"A\0\0\0", b"N\0\0\0", b"R\0\0\0"}
+    # slices tile the table exactly
+    parts = [tpch_data.host_table(tpch_data.LINEITEM, n_orders, p, 3, cols=[0, 3]) for p in range(3)]
+    assert sum(p.num_rows for p in parts) == li.num_rows
+    assert np.array_equal(np.concatenate([np.asarray(p.column("l_orderkey")) for p in parts]), ok)

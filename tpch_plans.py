@@ -1,0 +1,161 @@
+"""bench.py support: device-resident synthetic TPC-H database, query runner over the C++ plan
+layer (libldb_host.so → C-ABI), the join-probe micro-benchmark, and the CPU-baseline leg.
+
+Only cpu_baseline() touches the oracle (allowed: reported baseline, never the measured path)."""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+LINEITEM, ORDERS, CUSTOMER = 0, 1, 2
+# column ids of include/ldb_tpchgen.h
+L_ORDERKEY, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, L_TAX, L_RETURNFLAG, L_LINESTATUS, L_SHIPDATE = 0, 4, 5, 6, 7, 8, 9, 10
+O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY = 0, 1, 4, 6
+C_CUSTKEY, C_MKTSEGMENT = 0, 3
+
+
+class Database:
+    """Slice rank/world of the SF database, generated straight into HBM (only the columns the
+    selected queries touch — the reference likewise scans only referenced columns)."""
+
+    def __init__(self, ctx, n_orders, rank, world, queries, narrow):
+        self.ctx, self.n_orders, self.rank, self.world = ctx, n_orders, rank, world
+        lcols = set()
+        if 1 in queries:
+            lcols |= {L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, L_TAX, L_RETURNFLAG, L_LINESTATUS, L_SHIPDATE}
+        if 6 in queries:
+            lcols |= {L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, L_SHIPDATE}
+        if 3 in queries:
+            lcols |= {L_ORDERKEY, L_EXTENDEDPRICE, L_DISCOUNT, L_SHIPDATE}
+        self.lineitem = ctx.tpch_generate(LINEITEM, n_orders, rank, world, sorted(lcols), narrow)
+        self.orders = self.customer = None
+        if 3 in queries:
+            self.orders = ctx.tpch_generate(ORDERS, n_orders, rank, world, [O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY], narrow)
+            self.customer = ctx.tpch_generate(CUSTOMER, n_orders, rank, world, [C_CUSTKEY, C_MKTSEGMENT], narrow)
+        self.n_lineitem_total = (n_orders // 7) * 28 + [0, 4, 5, 12, 15, 21, 23, 28][n_orders % 7]
+
+
+class Runner:
+    def __init__(self, ctx, db, world, dist, torch):
+        self.ctx, self.db, self.world, self.dist, self.torch = ctx, db, world, dist, torch
+        self.last = {}
+
+    def run(self, q):
+        if self.world > 1:
+            import tpch_dist
+
+            res = tpch_dist.run_query(self, q)
+        elif q == 1:
+            res = self.ctx.plan_q1(self.db.lineitem)
+        elif q == 6:
+            res = self.ctx.plan_q6(self.db.lineitem)
+        elif q == 3:
+            res = self.ctx.plan_q3(self.db.customer, self.db.orders, self.db.lineitem)
+        else:
+            raise ValueError(f"TPC-H Q{q} has no plan yet")
+        self.last[q] = res
+        return res
+
+    def probe_microbench(self, reps=3):
+        """FK probe of l_orderkey into a table built on o_orderkey (100 % match), SURVEY §8(d)."""
+        ctx, db = self.ctx, self.db
+        orel, lrel = db.orders.rel(), db.lineitem.rel()
+        ok, lk = db.orders.col("o_orderkey"), db.lineitem.col("l_orderkey")
+        ctx.prof_reset()
+        ht = orel.join_build([(0, ok)], unique=True)
+        matches = 0
+        for _ in range(reps):
+            matches = ht.probe_count(lrel, [(0, lk)])
+        prof = ctx.prof_all()
+        n_b, ms_b = prof.get("k_join_build", (0, 0.0))
+        n_p, ms_p = prof.get("k_join_probe_count", (0, 0.0))
+        rows = db.lineitem.rows
+        out = {"probe_rows": rows, "build_rows": db.orders.rows, "matches": matches, "table_slots": ht.slots, "slot_bytes": 8}
+        if n_p:
+            avg = ms_p / n_p
+            out["probe_ms"] = round(avg, 4)
+            out["probe_grows_per_s"] = round(rows / (avg * 1e-3) / 1e9, 3)
+            # byte models of SURVEY §8(d): key 4 B + slot 8 B algorithmic; 4 B + one 64 B sector per random access
+            out["algorithmic_gbs"] = round(rows * 12 / (avg * 1e-3) / 1e9, 1)
+            out["sector_model_gbs"] = round(rows * 68 / (avg * 1e-3) / 1e9, 1)
+        if n_b:
+            out["build_ms"] = round(ms_b / n_b, 4)
+            out["build_grows_per_s"] = round(db.orders.rows / (ms_b / n_b * 1e-3) / 1e9, 3)
+        ht.release()
+        ctx.prof_reset()
+        return out
+
+
+# ---------------------------------------------------------------- CPU baseline (oracle = reported, non-target)
+def cpu_baseline(queries, sample_sf):
+    """The oracle restatement of the reference CPU path (oracle/ldb_oracle.c, kind "port") timed on
+    this host's cores over a bounded sample: the same generator at `sample_sf`, all cores,
+    morsel size 20 000.  Median of 3 runs per query; value = geomean over the queries."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import statistics
+
+    import oracle_bind
+    import tpch_data
+    from lingodb_amd import api, capi
+
+    oracle = oracle_bind.load()
+    cores = oracle.num_cores()
+    n_orders = int(round(sample_sf * 1_500_000))
+    li = oracle_bind.HostTable(tpch_data.host_table(tpch_data.LINEITEM, n_orders, cols=[0, 4, 5, 6, 7, 8, 9, 10]))
+    # column positions inside the trimmed lineitem table
+    LK, QTY, EXT, DISC, TAX, RF, LS, SHIP = range(8)
+    f = api.factor
+    D = capi.T_DECIMAL128
+
+    def q1():
+        dp = api.expr([{"factors": [f(0, 1, (0, EXT)), f(100, -1, (0, DISC))]}])
+        ch = api.expr([{"factors": [f(0, 1, (0, EXT)), f(100, -1, (0, DISC)), f(100, 1, (0, TAX))]}])
+        aggs = [api.agg(capi.AGG_SUM, api.col_expr((0, QTY)), out_type=D, p=12, s=2), api.agg(capi.AGG_SUM, api.col_expr((0, EXT)), out_type=D, p=12, s=2),
+                api.agg(capi.AGG_SUM, dp, wide=True, out_type=D, p=33, s=4), api.agg(capi.AGG_SUM, ch, wide=True, out_type=D, p=38, s=6),
+                api.agg(capi.AGG_AVG, api.col_expr((0, QTY)), out_type=D, p=31, s=21, avg_pow10=19), api.agg(capi.AGG_AVG, api.col_expr((0, EXT)), out_type=D, p=31, s=21, avg_pow10=19),
+                api.agg(capi.AGG_AVG, api.col_expr((0, DISC)), out_type=D, p=31, s=21, avg_pow10=19), api.agg(capi.AGG_COUNT_STAR)]
+        return oracle.groupby(li.rel(), [(0, RF), (0, LS)], aggs, [api.pred((0, SHIP), capi.F_LTE, 10471)], threads=cores)
+
+    def q6():
+        aggs = [api.agg(capi.AGG_SUM, api.expr([{"factors": [f(0, 1, (0, EXT)), f(0, 1, (0, DISC))]}]), wide=True, out_type=D, p=24, s=4)]
+        plist = [api.pred((0, SHIP), capi.F_GTE, 8766), api.pred((0, SHIP), capi.F_LT, 9131), api.pred((0, DISC), capi.F_GTE, 5), api.pred((0, DISC), capi.F_LTE, 7),
+                 api.pred((0, QTY), capi.F_LT, 2400)]
+        return oracle.groupby(li.rel(), [], aggs, plist, threads=cores)
+
+    od = cu = None
+    if 3 in queries:
+        od = oracle_bind.HostTable(tpch_data.host_table(tpch_data.ORDERS, n_orders, cols=[0, 1, 4, 6]))
+        cu = oracle_bind.HostTable(tpch_data.host_table(tpch_data.CUSTOMER, n_orders, cols=[0, 3]))
+
+    def q3():
+        hc, ho, hl = cu.rel(), od.rel(), li.rel()
+        c1 = hc.select(oracle.scan_filter(hc, [api.pred((0, 1), capi.F_EQ, "BUILDING")], cores))
+        o1 = ho.select(oracle.scan_filter(ho, [api.pred((0, 2), capi.F_LT, 9204)], cores))
+        l1 = hl.select(oracle.scan_filter(hl, [api.pred((0, SHIP), capi.F_GT, 9204)], cores))
+        op, ob, _ = oracle.join(c1, [(0, 0)], o1, [(0, 1)], capi.JOIN_INNER, cores)
+        co = oracle_bind.HostRel([(od, o1.phys(0)[op]), (cu, c1.phys(0)[ob])], len(op))
+        lp, lb, _ = oracle.join(co, [(0, 0)], l1, [(0, LK)], capi.JOIN_INNER, cores)
+        lco = oracle_bind.HostRel([(li, l1.phys(0)[lp]), (od, co.phys(0)[lb]), (cu, co.phys(1)[lb])], len(lp))
+        agg = api.agg(capi.AGG_SUM, api.expr([{"factors": [f(0, 1, (0, EXT)), f(100, -1, (0, DISC))]}]), wide=True, out_type=D, p=33, s=4)
+        rep, vals, valid = oracle.groupby(lco, [(0, LK), (1, 2), (1, 3)], [agg], threads=cores)
+        return len(rep)
+
+    fns = {1: q1, 6: q6, 3: q3}
+    per = {}
+    for q in queries:
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fns[q]()
+            ts.append((time.perf_counter() - t0) * 1000.0)
+        per[q] = statistics.median(ts)
+    import math
+
+    gm = math.exp(sum(math.log(max(v, 1e-9)) for v in per.values()) / len(per))
+    return {"value": round(gm, 3), "unit": "ms", "cores": cores, "kind": "port",
+            "sample": "SF%g (%d lineitem rows): oracle restatement of the reference CPU path, %d threads, morsel 20000, median of 3; "
+                      "geomean over %s — NOT the SF of `value` (scale linearly for a rough comparison)" % (
+                          sample_sf, li.struct.n_rows, cores, "+".join("Q%d" % q for q in queries)),
+            "per_query_ms": {"Q%d" % q: round(v, 3) for q, v in per.items()}, "sample_sf": sample_sf}
