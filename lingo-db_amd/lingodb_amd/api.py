@@ -164,9 +164,9 @@ class Table:
         self.ctx, self.h = ctx, handle
 
     def release(self):
-        if self.h:
+        if self.h and self.ctx.h:
             check(self.ctx.lib.ldb_gpu_table_release(self.ctx.h, self.h))
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -231,9 +231,9 @@ class Rel:
         self.deps = list(deps)  # keep tables / build relations alive
 
     def release(self):
-        if self.h:
+        if self.h and self.ctx.h:
             check(self.ctx.lib.ldb_gpu_rel_release(self.ctx.h, self.h))
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -322,9 +322,9 @@ class HashTable:
         self.ctx, self.h, self.build = ctx, handle, build_rel
 
     def release(self):
-        if self.h:
+        if self.h and self.ctx.h:
             check(self.ctx.lib.ldb_gpu_hashtable_release(self.ctx.h, self.h))
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
