@@ -26,8 +26,10 @@
 #ifndef LINGODB_GPU_H
 #define LINGODB_GPU_H
 
+#ifndef LDB_NO_STD_HEADERS /* the run-time kernel specialiser (hiprtc) supplies its own typedefs */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -136,6 +138,12 @@ int32_t ldb_gpu_prof_reset(ldb_ctx* ctx);
 int32_t ldb_gpu_prof_get(ldb_ctx* ctx, const char* kernel_name, int64_t* launches, double* total_ms);
 /* names of all kernels seen so far, '\n'-separated, into buf */
 int32_t ldb_gpu_prof_names(ldb_ctx* ctx, char* buf, int32_t cap);
+
+/* Run-time kernel specialisation (the role LLVM JIT plays in the reference,
+ * src/execution/LLVMBackends.cpp:219-406): kernels compiled / cache hits / compile time so far,
+ * and a device-less compile check of the specialiser (hiprtc log into `log`). */
+int32_t ldb_gpu_jit_stats(int64_t* compiled, int64_t* cache_hits, double* compile_ms);
+int32_t ldb_gpu_jit_compile_check(char* log, int32_t cap);
 
 /* ------------------------------------------------------------------ tables (a1) */
 /* Replaces LingoDBTable::ensureLoaded + TableChunk flattening (LingoDBTable.cpp:27-54,

@@ -2,6 +2,7 @@
 // Replaces (reference): ExecutionContext (include/lingodb/runtime/ExecutionContext.h:62-127),
 // LingoDBTable::ensureLoaded + TableChunk flattening (src/runtime/storage/LingoDBTable.cpp:27-54,
 // 200-225) and result materialisation (ArrowColumnBuilder, include/lingodb/runtime/ArrowColumn.h:15-37).
+#include "ldb_internal.h"
 #include "ldb_device.h"
 #include <cstdlib>
 #include <memory>
@@ -659,10 +660,10 @@ int32_t ldb_make_dcol(const ldb_rel* r, ldb_colref ref, DCol* out) {
    const ldb_rel_side& s = r->sides[(size_t) ref.side];
    if (ref.col < 0 || (size_t) ref.col >= s.table->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "column ref: col %d out of range on side %d", ref.col, ref.side);
    const ldb_column& c = s.table->cols[(size_t) ref.col];
-   out->values = c.values;
-   out->offsets = c.offsets;
-   out->validity = c.validity;
-   out->rowids = s.rowids;
+   out->values = (uint64_t) c.values;
+   out->offsets = (uint64_t) c.offsets;
+   out->validity = (uint64_t) c.validity;
+   out->rowids = (uint64_t) s.rowids;
    out->type = c.type.type;
    out->width = c.width;
    out->precision = c.type.precision;
@@ -771,8 +772,11 @@ struct u128x {
 
 // gather one column of `r` into a new owned column
 int32_t ldb_gather_column(ldb_ctx* ctx, const ldb_rel* r, ldb_colref ref, ldb_column* out) {
-   DCol dc;
-   LDB_TRY(ldb_make_dcol(r, ref, &dc));
+   DCol dcol;
+   LDB_TRY(ldb_make_dcol(r, ref, &dcol));
+   struct {
+      const uint32_t* rowids;
+   } dc{(const uint32_t*) dcol.rowids};
    const ldb_column& src = r->sides[(size_t) ref.side].table->cols[(size_t) ref.col];
    const uint64_t n = (uint64_t) r->n_rows;
    out->name = src.name;

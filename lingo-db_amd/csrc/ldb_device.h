@@ -1,12 +1,53 @@
 // ldb_device.h — device-side scalar semantics shared by all kernels (gfx950 / wave64).
 // Each helper cites the reference lowering whose result it must reproduce bit-exactly.
+//
+// Column / predicate / key-set VIEWS (CV, PV, KV) pair a metadata source `m` with an address
+// source `p`.  In ahead-of-time kernels both are the same descriptor in memory; in a run-time
+// specialised kernel (ldb_jit.hip) `m` is a constexpr copy, so every `c.m.type` / `p.m.op`
+// test folds at compile time while the addresses still come from the launch's descriptor.
 #pragma once
-#include "ldb_internal.h"
+#include "ldb_devtypes.h"
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#endif
 
 typedef __int128 i128;
 typedef unsigned __int128 u128;
 
 #define LDB_WAVE 64
+// loops over descriptor counts: fully unrolled when the descriptor is a compile-time constant
+#ifdef LDB_JIT_SPECIALIZED
+#define LDB_UNROLL _Pragma("unroll")
+#else
+#define LDB_UNROLL
+#endif
+
+// Addresses travel as uint64_t; casting through address space 1 tells the compiler the memory is
+// global, so it emits global_load / global_atomic instead of flat instructions.
+#define LDB_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const T* gptr(uint64_t a) {
+   return (const T*) (const LDB_GLOBAL T*) a;
+}
+template <typename T>
+__device__ __forceinline__ T* gptr_mut(uint64_t a) {
+   return (T*) (LDB_GLOBAL T*) a;
+}
+
+struct CV {
+   const DCol& m;
+   const DCol& p;
+   __device__ __forceinline__ CV(const DCol& c) : m(c), p(c) {}
+   __device__ __forceinline__ CV(const DCol& m_, const DCol& p_) : m(m_), p(p_) {}
+};
+struct PV {
+   const DPred& m;
+   const DPred& p;
+   __device__ __forceinline__ PV(const DPred& c) : m(c), p(c) {}
+   __device__ __forceinline__ PV(const DPred& m_, const DPred& p_) : m(m_), p(p_) {}
+   __device__ __forceinline__ CV col() const { return CV(m.col, p.col); }
+   __device__ __forceinline__ CV rhs() const { return CV(m.rhs, p.rhs); }
+};
 
 __device__ __forceinline__ uint64_t d_bswap64(uint64_t x) { return __builtin_bswap64(x); }
 
@@ -104,42 +145,46 @@ __device__ inline uint64_t d_hash_varlen(const uint8_t* p, uint32_t len) {
 }
 
 // ---- column access (LoadArrowOpLowering, reference src/compiler/Conversion/DBToStd/LowerToStd.cpp:111-209)
-__device__ __forceinline__ uint32_t d_phys_row(const DCol& c, uint64_t i) { return c.rowids ? c.rowids[i] : (uint32_t) i; }
-__device__ __forceinline__ bool d_valid(const DCol& c, uint32_t row) {
-   if (row == LDB_NULL_ROW) return false;
-   if (!c.validity) return true;
-   return (c.validity[row >> 3] >> (row & 7)) & 1;
+// (presence of row ids / a validity bitmap is metadata: the specialised kernel's constexpr copy
+// keeps non-zero flags in those fields, the addresses themselves come from c.p)
+__device__ __forceinline__ uint32_t d_phys_row(CV c, uint64_t i) { return c.m.rowids ? gptr<uint32_t>(c.p.rowids)[i] : (uint32_t) i; }
+__device__ __forceinline__ bool d_valid(CV c, uint32_t row) {
+   if (c.m.rowids && row == LDB_NULL_ROW) return false; // only row-id vectors can carry outer-join padding
+   if (!c.m.validity) return true;
+   return (gptr<uint8_t>(c.p.validity)[row >> 3] >> (row & 7)) & 1;
 }
 // 64-bit view of a fixed-width value (sign-extended); decimal128 with p<19 is truncated to
 // i64 exactly as the generated code does (LowerToStd.cpp:128-132)
-__device__ __forceinline__ int64_t d_load_i64(const DCol& c, uint32_t row) {
-   switch (c.width) {
-      case 4: return ((const int32_t*) c.values)[row];
-      case 8: return ((const int64_t*) c.values)[row];
-      case 16: return ((const int64_t*) c.values)[2 * (uint64_t) row];
-      case 2: return ((const int16_t*) c.values)[row];
-      default: return c.type == LDB_T_BOOL8 ? (((const uint8_t*) c.values)[row] ? 1 : 0) : ((const int8_t*) c.values)[row];
+__device__ __forceinline__ int64_t d_load_i64(CV c, uint32_t row) {
+   switch (c.m.width) {
+      case 4: return gptr<int32_t>(c.p.values)[row];
+      case 8: return gptr<int64_t>(c.p.values)[row];
+      case 16: return gptr<int64_t>(c.p.values)[2 * (uint64_t) row];
+      case 2: return gptr<int16_t>(c.p.values)[row];
+      default: return c.m.type == LDB_T_BOOL8 ? (gptr<uint8_t>(c.p.values)[row] ? 1 : 0) : gptr<int8_t>(c.p.values)[row];
    }
 }
-__device__ __forceinline__ bool d_is_wide(const DCol& c) { return c.type == LDB_T_DECIMAL128 && c.precision >= 19; }
-__device__ __forceinline__ i128 d_load_i128(const DCol& c, uint32_t row) {
-   if (c.width == 16) {
-      const uint64_t* p = (const uint64_t*) c.values + 2 * (uint64_t) row;
+__device__ __forceinline__ bool d_is_wide(CV c) { return c.m.type == LDB_T_DECIMAL128 && c.m.precision >= 19; }
+__device__ __forceinline__ bool d_is_flt(CV c) { return c.m.type == LDB_T_FLOAT64 || c.m.type == LDB_T_FLOAT32; }
+__device__ __forceinline__ i128 d_load_i128(CV c, uint32_t row) {
+   if (c.m.width == 16) {
+      const uint64_t* p = gptr<uint64_t>(c.p.values) + 2 * (uint64_t) row;
       uint64_t lo = p[0], hi = p[1];
-      if (c.precision < 19) return (i128) (int64_t) lo;
+      if (c.m.precision < 19) return (i128) (int64_t) lo;
       return (i128) (((u128) hi << 64) | lo);
    }
    return (i128) d_load_i64(c, row);
 }
-__device__ __forceinline__ double d_load_f64(const DCol& c, uint32_t row) {
-   if (c.type == LDB_T_FLOAT64) return ((const double*) c.values)[row];
-   if (c.type == LDB_T_FLOAT32) return ((const float*) c.values)[row];
+__device__ __forceinline__ double d_load_f64(CV c, uint32_t row) {
+   if (c.m.type == LDB_T_FLOAT64) return gptr<double>(c.p.values)[row];
+   if (c.m.type == LDB_T_FLOAT32) return gptr<float>(c.p.values)[row];
    return (double) d_load_i64(c, row);
 }
-__device__ __forceinline__ const uint8_t* d_load_str(const DCol& c, uint32_t row, uint32_t* len) {
-   int64_t b = c.offsets[row], e = c.offsets[row + 1];
+__device__ __forceinline__ const uint8_t* d_load_str(CV c, uint32_t row, uint32_t* len) {
+   const int64_t* o = gptr<int64_t>(c.p.offsets);
+   int64_t b = o[row], e = o[row + 1];
    *len = (uint32_t) (e - b);
-   return (const uint8_t*) c.values + b;
+   return gptr<uint8_t>(c.p.values) + b;
 }
 // std::string_view compare: unsigned bytewise then length (reference StringRuntime.cpp:242-256)
 __device__ inline int d_str_cmp(const uint8_t* a, uint32_t la, const uint8_t* b, uint32_t lb) {
@@ -159,104 +204,103 @@ __device__ __forceinline__ bool d_cmp_apply(int op, int c3) {
       default: return c3 >= 0;
    }
 }
+template <typename T>
+__device__ __forceinline__ bool d_cmp_vals(int op, T a, T b) {
+   switch (op) {
+      case LDB_F_EQ: return a == b;
+      case LDB_F_NEQ: return a != b;
+      case LDB_F_LT: return a < b;
+      case LDB_F_LTE: return a <= b;
+      case LDB_F_GT: return a > b;
+      default: return a >= b;
+   }
+}
 
 // One conjunct on logical row i.  Semantics: Filter impls of reference
 // src/runtime/storage/Restrictions.cpp:67-321 (native-type compare, decimals as __int128,
-// strings as string_view, IN = membership); NULL operands fail.  All branches on p.* are
-// wave-uniform (p lives in scalar registers / constant memory).
-__device__ inline bool d_eval_pred(const DPred& p, uint64_t i) {
-   uint32_t row = d_phys_row(p.col, i);
-   bool valid = d_valid(p.col, row);
-   if (p.op == LDB_F_NOTNULL) return valid;
+// strings as string_view, IN = membership); NULL operands fail.  All branches on p.m.* are
+// wave-uniform (descriptor in scalar registers / constant memory, or folded when specialised).
+__device__ __forceinline__ bool d_eval_pred(PV p, uint64_t i) {
+   const CV col = p.col();
+   uint32_t row = d_phys_row(col, i);
+   bool valid = d_valid(col, row);
+   if (p.m.op == LDB_F_NOTNULL) return valid;
    if (!valid) return false;
-   const int type = p.col.type;
-   if (p.rhs_kind == LDB_RHS_COLUMN) {
-      uint32_t row2 = d_phys_row(p.rhs, i);
-      if (!d_valid(p.rhs, row2)) return false;
+   const int type = p.m.col.type;
+   if (p.m.rhs_kind == LDB_RHS_COLUMN) {
+      const CV rhs = p.rhs();
+      uint32_t row2 = d_phys_row(rhs, i);
+      if (!d_valid(rhs, row2)) return false;
       if (type == LDB_T_UTF8) {
          uint32_t la, lb;
-         const uint8_t* a = d_load_str(p.col, row, &la);
-         const uint8_t* b = d_load_str(p.rhs, row2, &lb);
-         return d_cmp_apply(p.op, d_str_cmp(a, la, b, lb));
+         const uint8_t* a = d_load_str(col, row, &la);
+         const uint8_t* b = d_load_str(rhs, row2, &lb);
+         return d_cmp_apply(p.m.op, d_str_cmp(a, la, b, lb));
       }
-      if (type == LDB_T_FLOAT64 || type == LDB_T_FLOAT32 || p.rhs.type == LDB_T_FLOAT64 || p.rhs.type == LDB_T_FLOAT32) {
-         double a = d_load_f64(p.col, row), b = d_load_f64(p.rhs, row2);
-         return d_cmp_apply(p.op, a < b ? -1 : (a > b ? 1 : 0));
-      }
-      if (d_is_wide(p.col) || d_is_wide(p.rhs)) {
-         i128 a = d_load_i128(p.col, row), b = d_load_i128(p.rhs, row2);
-         return d_cmp_apply(p.op, a < b ? -1 : (a > b ? 1 : 0));
-      }
-      int64_t a = d_load_i64(p.col, row), b = d_load_i64(p.rhs, row2);
-      return d_cmp_apply(p.op, a < b ? -1 : (a > b ? 1 : 0));
+      if (d_is_flt(col) || d_is_flt(rhs)) return d_cmp_vals<double>(p.m.op, d_load_f64(col, row), d_load_f64(rhs, row2));
+      if (d_is_wide(col) || d_is_wide(rhs)) return d_cmp_vals<i128>(p.m.op, d_load_i128(col, row), d_load_i128(rhs, row2));
+      return d_cmp_vals<int64_t>(p.m.op, d_load_i64(col, row), d_load_i64(rhs, row2));
    }
    if (type == LDB_T_UTF8) {
       uint32_t la;
-      const uint8_t* a = d_load_str(p.col, row, &la);
-      if (p.op == LDB_F_IN) {
-         for (int k = 0; k < p.n_in; k++) {
-            uint32_t lb = (uint32_t) (p.in_off[k + 1] - p.in_off[k]);
-            if (d_str_cmp(a, la, (const uint8_t*) p.in_blob + p.in_off[k], lb) == 0) return true;
+      const uint8_t* a = d_load_str(col, row, &la);
+      if (p.m.op == LDB_F_IN) {
+         for (int k = 0; k < p.m.n_in; k++) {
+            uint32_t lb = (uint32_t) (p.m.in_off[k + 1] - p.m.in_off[k]);
+            if (d_str_cmp(a, la, (const uint8_t*) p.m.in_blob + p.m.in_off[k], lb) == 0) return true;
          }
          return false;
       }
-      return d_cmp_apply(p.op, d_str_cmp(a, la, (const uint8_t*) p.str, (uint32_t) p.str_len));
+      return d_cmp_apply(p.m.op, d_str_cmp(a, la, (const uint8_t*) p.m.str, (uint32_t) p.m.str_len));
    }
-   if (type == LDB_T_FLOAT64 || type == LDB_T_FLOAT32) {
-      double a = d_load_f64(p.col, row);
-      if (p.op == LDB_F_IN) {
-         for (int k = 0; k < p.n_in; k++)
-            if (a == __longlong_as_double((long long) p.in_lo[k])) return true;
+   if (d_is_flt(col)) {
+      double a = d_load_f64(col, row);
+      if (p.m.op == LDB_F_IN) {
+         for (int k = 0; k < p.m.n_in; k++)
+            if (a == __longlong_as_double((long long) p.m.in_lo[k])) return true;
          return false;
       }
-      return d_cmp_apply(p.op, a < p.f ? -1 : (a > p.f ? 1 : 0));
+      return d_cmp_vals<double>(p.m.op, a, p.m.f);
    }
-   if (d_is_wide(p.col)) {
-      i128 a = d_load_i128(p.col, row);
-      if (p.op == LDB_F_IN) {
-         for (int k = 0; k < p.n_in; k++)
-            if (a == (i128) (((u128) (uint64_t) p.in_hi[k] << 64) | p.in_lo[k])) return true;
+   if (d_is_wide(col)) {
+      i128 a = d_load_i128(col, row);
+      if (p.m.op == LDB_F_IN) {
+         for (int k = 0; k < p.m.n_in; k++)
+            if (a == (i128) (((u128) (uint64_t) p.m.in_hi[k] << 64) | p.m.in_lo[k])) return true;
          return false;
       }
-      i128 b = (i128) (((u128) (uint64_t) p.hi << 64) | p.lo);
-      return d_cmp_apply(p.op, a < b ? -1 : (a > b ? 1 : 0));
+      return d_cmp_vals<i128>(p.m.op, a, (i128) (((u128) (uint64_t) p.m.hi << 64) | p.m.lo));
    }
    // narrow integer path: the constant is a 128-bit value; a column value (fits i64) compares
-   // against it exactly after clamping the constant's position relative to the i64 range
-   int64_t a = d_load_i64(p.col, row);
-   if (p.op == LDB_F_IN) {
-      for (int k = 0; k < p.n_in; k++) {
-         bool fits = (p.in_hi[k] == ((int64_t) p.in_lo[k] >> 63));
-         if (fits && a == (int64_t) p.in_lo[k]) return true;
+   // against it exactly after placing the constant relative to the i64 range
+   int64_t a = d_load_i64(col, row);
+   if (p.m.op == LDB_F_IN) {
+      for (int k = 0; k < p.m.n_in; k++) {
+         bool fits = (p.m.in_hi[k] == ((int64_t) p.m.in_lo[k] >> 63));
+         if (fits && a == (int64_t) p.m.in_lo[k]) return true;
       }
       return false;
    }
-   int c3;
-   if (p.hi == ((int64_t) p.lo >> 63)) {
-      int64_t b = (int64_t) p.lo;
-      c3 = a < b ? -1 : (a > b ? 1 : 0);
-   } else {
-      c3 = p.hi < 0 ? 1 : -1; // constant below / above every int64
-   }
-   return d_cmp_apply(p.op, c3);
+   if (p.m.hi == ((int64_t) p.m.lo >> 63)) return d_cmp_vals<int64_t>(p.m.op, a, (int64_t) p.m.lo);
+   return d_cmp_apply(p.m.op, p.m.hi < 0 ? 1 : -1); // constant below / above every int64
 }
 
 // db.hash of one key part folded into `total` (HashLowering::hashImpl, LowerToStd.cpp:1073-1132).
 // Caller has checked validity (NULL parts are skipped).
-__device__ inline uint64_t d_hash_part(const DCol& c, uint32_t row, uint64_t total) {
-   switch (c.type) {
+__device__ __forceinline__ uint64_t d_hash_part(CV c, uint32_t row, uint64_t total) {
+   switch (c.m.type) {
       case LDB_T_UTF8: {
          uint32_t len;
          const uint8_t* p = d_load_str(c, row, &len);
          return d_hash_combine(d_hash_varlen(p, len), total);
       }
-      case LDB_T_FLOAT64: return d_hash_combine(d_hash64(((const uint64_t*) c.values)[row]), total);
-      case LDB_T_FLOAT32: return d_hash_combine(d_hash64((uint64_t) (int64_t) ((const int32_t*) c.values)[row]), total);
+      case LDB_T_FLOAT64: return d_hash_combine(d_hash64(gptr<uint64_t>(c.p.values)[row]), total);
+      case LDB_T_FLOAT32: return d_hash_combine(d_hash64((uint64_t) (int64_t) gptr<int32_t>(c.p.values)[row]), total);
       case LDB_T_DATE32: // hashed in ns (LowerToStd.cpp:133-139)
-         return d_hash_combine(d_hash64((uint64_t) ((int64_t) ((const int32_t*) c.values)[row] * 86400000000000LL)), total);
-      case LDB_T_BOOL8: return d_hash_combine(d_hash64(((const uint8_t*) c.values)[row] ? ~0ull : 0ull), total);
+         return d_hash_combine(d_hash64((uint64_t) ((int64_t) gptr<int32_t>(c.p.values)[row] * 86400000000000LL)), total);
+      case LDB_T_BOOL8: return d_hash_combine(d_hash64(gptr<uint8_t>(c.p.values)[row] ? ~0ull : 0ull), total);
       case LDB_T_DECIMAL128:
-         if (c.precision >= 19) { // two pieces: high then low (LowerToStd.cpp:1079-1090)
+         if (c.m.precision >= 19) { // two pieces: high then low (LowerToStd.cpp:1079-1090)
             i128 v = d_load_i128(c, row);
             uint64_t h1 = d_hash_combine(d_hash64((uint64_t) (v >> 64)), total);
             return d_hash_combine(d_hash64((uint64_t) v), h1);
@@ -267,8 +311,8 @@ __device__ inline uint64_t d_hash_part(const DCol& c, uint32_t row, uint64_t tot
 }
 
 // equality of one key part between two physical rows of (possibly different) columns
-__device__ inline bool d_key_part_equal(const DCol& ca, uint32_t ra, const DCol& cb, uint32_t rb) {
-   if (ca.type == LDB_T_UTF8) {
+__device__ __forceinline__ bool d_key_part_equal(CV ca, uint32_t ra, CV cb, uint32_t rb) {
+   if (ca.m.type == LDB_T_UTF8) {
       uint32_t la, lb;
       const uint8_t* a = d_load_str(ca, ra, &la);
       const uint8_t* b = d_load_str(cb, rb, &lb);
@@ -277,7 +321,7 @@ __device__ inline bool d_key_part_equal(const DCol& ca, uint32_t ra, const DCol&
          if (a[i] != b[i]) return false;
       return true;
    }
-   if (ca.type == LDB_T_FLOAT64 || ca.type == LDB_T_FLOAT32) return d_load_f64(ca, ra) == d_load_f64(cb, rb);
+   if (d_is_flt(ca)) return d_load_f64(ca, ra) == d_load_f64(cb, rb);
    if (d_is_wide(ca) || d_is_wide(cb)) return d_load_i128(ca, ra) == d_load_i128(cb, rb);
    return d_load_i64(ca, ra) == d_load_i64(cb, rb);
 }

@@ -1,0 +1,378 @@
+// ldb_gb_kernel.h — device code of the fused scan + predicate + hash group-by kernel.
+// Compiled twice: ahead of time by hipcc (generic: the descriptor is read from memory) and, for
+// large inputs, at run time by hiprtc with the descriptor's metadata baked in as a constexpr
+// (ldb_jit.hip) — the same hand-written source, the compiler folds every type/op switch and
+// unrolls every descriptor loop.  This mirrors what the reference does with LLVM: its per-tuple
+// pipeline code is generated per query (SubOpToControlFlow.cpp) and JIT-compiled
+// (src/execution/LLVMBackends.cpp:219-406).
+//
+// Replaces (reference): LookupPreAggrHtFragment + ReduceOpLowering
+// (src/compiler/Conversion/SubOpToControlFlow/SubOpToControlFlow.cpp:3065-3157, 3719-3768),
+// PreAggregationHashtableFragment::insert / PreAggregationHashtable::merge
+// (src/runtime/PreAggregationHashtable.cpp:46-60, 76-158), SimpleState (src/runtime/SimpleState.cpp:8-30).
+#pragma once
+#include "ldb_keys.h"
+
+#define GB_BLOCK 256
+#define GB_MAX_COLS 12
+#define GB_MAX_ACCS 20
+#define GB_MAX_CPREDS 6
+#define GB_MAX_OUT 16
+#define GB_MAX_WORDS 24
+
+enum { ACC_SUM64 = 0,
+       ACC_SUM128 = 1,
+       ACC_COUNT = 2,
+       ACC_MIN64 = 3,
+       ACC_MAX64 = 4,
+       ACC_SUMF64 = 5,
+       ACC_MINF64 = 6,
+       ACC_MAXF64 = 7 };
+
+struct DFactorG {
+   int32_t has_col;
+   int32_t col_idx; // into DGroupBy::cols
+   int64_t a, b;
+};
+struct DTermG {
+   int32_t n_factors, negate, div_pow10, pad;
+   DFactorG f[LDB_MAX_FACTORS];
+};
+struct DExprG {
+   int32_t n_terms, is_float;
+   DTermG t[LDB_MAX_TERMS];
+};
+struct DAcc {
+   int32_t kind;
+   int32_t word; // first accumulator word
+   int32_t n_cpreds;
+   int32_t cpred[LDB_MAX_AGG_PREDS]; // indexes into DGroupBy::cpreds
+   int32_t count_rows; // ACC_COUNT: 1 = count rows (COUNT(*)), 0 = count non-NULL expr
+   int32_t pad;
+   DExprG e;
+};
+struct DOut { // one output aggregate column
+   int32_t fn; // ldb_agg_fn
+   int32_t acc; // value accumulator
+   int32_t cnt_acc; // AVG divisor / validity counter (-1: always valid)
+   int32_t wide;
+   int32_t avg_pow10;
+   int32_t out_width; // bytes per output value
+   int32_t is_float;
+   int32_t pad;
+   uint64_t out_values; // device address
+   uint64_t out_valid; // one byte per group (packed later) or 0
+   DExprG e; // ANY: evaluated on the representative row
+};
+struct DGroupBy {
+   // ---- run-time part (never specialised on)
+   uint64_t n_rows;
+   uint64_t g_cap; // global capacity (pow2)
+   uint64_t g_keys; // uint64_t*
+   uint64_t g_acc; // uint64_t*: word w of slot p at g_acc[w * g_cap + p]
+   uint64_t g_flags; // uint32_t*: [0] = overflow
+   uint32_t lds_slots, lds_reps; // S (pow2), R (pow2)
+   // ---- metadata (+ the addresses inside the DCols, which are run-time too)
+   int32_t n_preds, n_cols, n_accs, n_words, n_cpreds, n_outs;
+   int32_t keyless, use_lds;
+   DKeys keys;
+   DPred preds[LDB_MAX_PREDS];
+   DPred cpreds[GB_MAX_CPREDS];
+   DCol cols[GB_MAX_COLS];
+   DAcc accs[GB_MAX_ACCS];
+   uint64_t word_init[GB_MAX_WORDS];
+   DOut outs[GB_MAX_OUT];
+};
+
+// ---------------------------------------------------------------- expression evaluation
+// value cache: the low 64 bits of every referenced narrow column, loaded once per row into a
+// register array (a bare array: only array allocas are promoted to registers; generic kernels
+// index it with s_set_gpr_idx by the wave-uniform col_idx, specialised ones statically).
+typedef long long RowVals[GB_MAX_COLS];
+
+__device__ __forceinline__ void d_load_vals(const DGroupBy& m, const DGroupBy* __restrict__ d, uint64_t i, RowVals& rv, uint32_t& rvalid) {
+   rvalid = 0; // bit c = column c non-NULL
+   const int nc = m.n_cols;
+#pragma unroll
+   for (int c = 0; c < GB_MAX_COLS; c++) {
+      long long x = 0;
+      if (c < nc) {
+         const CV col(m.cols[c], d->cols[c]);
+         uint32_t row = d_phys_row(col, i);
+         if (d_valid(col, row)) {
+            rvalid |= 1u << c;
+            if (!d_is_flt(col)) x = d_load_i64(col, row);
+            else x = __double_as_longlong(d_load_f64(col, row));
+         }
+      }
+      rv[c] = x;
+   }
+}
+
+// Σ_t ± Π_f (a + b*col) / 10^k in wrapping 128-bit arithmetic (DecimalMulOpLowering /
+// DecimalBinOpLowering, reference LowerToStd.cpp:653-699).  Returns false when a referenced
+// column is NULL.
+__device__ __forceinline__ bool d_eval_int(const DGroupBy& m, const DGroupBy* __restrict__ d, const DExprG& e, const RowVals& rv, uint32_t rvalid,
+                                           uint64_t i, i128* out) {
+   u128 total = 0;
+   const int nt = e.n_terms;
+   LDB_UNROLL
+   for (int t = 0; t < nt; t++) {
+      const DTermG& tm = e.t[t];
+      u128 prod = 1;
+      const int nf = tm.n_factors;
+      LDB_UNROLL
+      for (int f = 0; f < nf; f++) {
+         const DFactorG& fa = tm.f[f];
+         i128 v = (i128) fa.a;
+         if (fa.has_col) {
+            const int ci = fa.col_idx;
+            if (!((rvalid >> ci) & 1)) return false;
+            const CV col(m.cols[ci], d->cols[ci]);
+            if (d_is_wide(col)) v = (i128) ((u128) v + (u128) (i128) fa.b * (u128) d_load_i128(col, d_phys_row(col, i)));
+            else v += (i128) fa.b * (i128) rv[ci]; // 64x64 → 128, exact
+         }
+         prod = f == 0 ? (u128) v : prod * (u128) v;
+      }
+      if (tm.div_pow10 > 0) prod = (u128) d_sdiv128((i128) prod, d_pow10(tm.div_pow10));
+      total = tm.negate ? total - prod : total + prod;
+   }
+   *out = (i128) total;
+   return true;
+}
+__device__ __forceinline__ bool d_eval_flt(const DGroupBy& m, const DExprG& e, const RowVals& rv, uint32_t rvalid, double* out) {
+   double total = 0;
+   const int nt = e.n_terms;
+   LDB_UNROLL
+   for (int t = 0; t < nt; t++) {
+      const DTermG& tm = e.t[t];
+      double prod = 1;
+      const int nf = tm.n_factors;
+      LDB_UNROLL
+      for (int f = 0; f < nf; f++) {
+         const DFactorG& fa = tm.f[f];
+         double v = (double) fa.a;
+         if (fa.has_col) {
+            const int ci = fa.col_idx;
+            if (!((rvalid >> ci) & 1)) return false;
+            const bool colf = m.cols[ci].type == LDB_T_FLOAT64 || m.cols[ci].type == LDB_T_FLOAT32;
+            double x = colf ? __longlong_as_double(rv[ci]) : (double) rv[ci];
+            v += (double) fa.b * x;
+         }
+         prod *= v;
+      }
+      total = tm.negate ? total - prod : total + prod;
+   }
+   *out = total;
+   return true;
+}
+
+// ---------------------------------------------------------------- accumulator sinks
+// double min/max via CAS on the bit pattern
+__device__ __forceinline__ void d_atomic_minmax_f64(unsigned long long* p, double v, bool is_min) {
+   unsigned long long old = *p;
+   for (;;) {
+      double cur = __longlong_as_double((long long) old);
+      bool better = is_min ? v < cur : v > cur;
+      if (!better) return;
+      unsigned long long prev = atomicCAS(p, old, (unsigned long long) __double_as_longlong(v));
+      if (prev == old) return;
+      old = prev;
+   }
+}
+
+struct Sink {
+   unsigned long long* base; // word 0 of this slot
+   uint64_t stride; // distance between consecutive words of one slot
+   __device__ __forceinline__ unsigned long long* w(int k) const { return base + (uint64_t) k * stride; }
+};
+
+// 128-bit SUM as two 64-bit words: the carry out of the low word is the only cross-word traffic
+__device__ __forceinline__ void d_sink_add128(const Sink& s, int word, u128 v) {
+   unsigned long long lo = (unsigned long long) v, hi = (unsigned long long) (v >> 64);
+   unsigned long long old = atomicAdd(s.w(word), lo);
+   hi += (unsigned long long) (old + lo < old);
+   if (hi) atomicAdd(s.w(word + 1), hi);
+}
+
+// fold one input row into the accumulators of its group
+__device__ __forceinline__ void d_accumulate(const DGroupBy& m, const DGroupBy* __restrict__ d, const RowVals& rv, uint32_t rvalid, uint64_t i,
+                                             const Sink& s) {
+   const int na = m.n_accs;
+   LDB_UNROLL
+   for (int a = 0; a < na; a++) {
+      const DAcc& acc = m.accs[a];
+      bool pass = true;
+      LDB_UNROLL
+      for (int p = 0; p < acc.n_cpreds; p++)
+         if (pass) pass = d_eval_pred(PV(m.cpreds[acc.cpred[p]], d->cpreds[acc.cpred[p]]), i);
+      if (!pass) continue; // sum(case when p then x else 0 end) adds 0
+      if (acc.kind == ACC_COUNT && acc.count_rows) {
+         atomicAdd(s.w(acc.word), 1ull);
+         continue;
+      }
+      if (acc.e.is_float) {
+         double fv;
+         if (!d_eval_flt(m, acc.e, rv, rvalid, &fv)) continue;
+         switch (acc.kind) {
+            case ACC_COUNT: atomicAdd(s.w(acc.word), 1ull); break;
+            case ACC_SUMF64: atomicAdd((double*) s.w(acc.word), fv); break;
+            case ACC_MINF64: d_atomic_minmax_f64(s.w(acc.word), fv, true); break;
+            default: d_atomic_minmax_f64(s.w(acc.word), fv, false); break;
+         }
+         continue;
+      }
+      i128 v;
+      if (!d_eval_int(m, d, acc.e, rv, rvalid, i, &v)) continue;
+      switch (acc.kind) {
+         case ACC_COUNT: atomicAdd(s.w(acc.word), 1ull); break;
+         case ACC_SUM64: atomicAdd(s.w(acc.word), (unsigned long long) v); break; // i64 wrap = SUM in the argument type
+         case ACC_SUM128: d_sink_add128(s, acc.word, (u128) v); break;
+         case ACC_MIN64: atomicMin((long long*) s.w(acc.word), (long long) v); break;
+         default: atomicMax((long long*) s.w(acc.word), (long long) v); break;
+      }
+   }
+}
+
+// merge accumulator words of an LDS slot into the global slot (combine step of
+// MergePreAggrHashMap, reference SubOpToControlFlow.cpp:1861-1938)
+__device__ __forceinline__ void d_combine(const DGroupBy& m, const Sink& src, const Sink& dst) {
+   const int na = m.n_accs;
+   LDB_UNROLL
+   for (int a = 0; a < na; a++) {
+      const DAcc& acc = m.accs[a];
+      unsigned long long x = *src.w(acc.word);
+      switch (acc.kind) {
+         case ACC_COUNT:
+         case ACC_SUM64:
+            if (x) atomicAdd(dst.w(acc.word), x);
+            break;
+         case ACC_SUM128: {
+            unsigned long long hi = *src.w(acc.word + 1);
+            d_sink_add128(dst, acc.word, ((u128) hi << 64) | x);
+            break;
+         }
+         case ACC_MIN64: atomicMin((long long*) dst.w(acc.word), (long long) x); break;
+         case ACC_MAX64: atomicMax((long long*) dst.w(acc.word), (long long) x); break;
+         case ACC_SUMF64:
+            if (__longlong_as_double((long long) x) != 0.0) atomicAdd((double*) dst.w(acc.word), __longlong_as_double((long long) x));
+            break;
+         case ACC_MINF64: d_atomic_minmax_f64(dst.w(acc.word), __longlong_as_double((long long) x), true); break;
+         default: d_atomic_minmax_f64(dst.w(acc.word), __longlong_as_double((long long) x), false); break;
+      }
+   }
+}
+
+// ---------------------------------------------------------------- tables
+// global find-or-insert; returns slot or ~0 on overflow
+__device__ __forceinline__ uint64_t d_global_slot(const DGroupBy& m, const DGroupBy* __restrict__ d, uint64_t h, uint64_t i) {
+   if (m.keyless) return 0;
+   const uint64_t mask = d->g_cap - 1;
+   unsigned long long* gk = gptr_mut<unsigned long long>(d->g_keys);
+   const uint64_t mine = (h & 0xFFFFFFFF00000000ull) | (uint64_t) ((uint32_t) i + 1u);
+   uint64_t pos = (h ^ (h >> 29)) & mask;
+   const KV keys(m.keys, d->keys);
+   for (uint64_t step = 0; step <= mask; step++) {
+      unsigned long long w = __hip_atomic_load(&gk[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (w == 0) {
+         unsigned long long old = atomicCAS(&gk[pos], 0ull, (unsigned long long) mine);
+         if (old == 0) return pos;
+         w = old;
+      }
+      if ((w >> 32) == (h >> 32) && d_keys_equal(keys, (uint64_t) ((uint32_t) w - 1u), keys, i, true)) return pos;
+      pos = (pos + 1) & mask;
+   }
+   atomicOr(gptr_mut<uint32_t>(d->g_flags), 1u);
+   return ~0ull;
+}
+
+// the kernel body: `m` = metadata source (== *d in the generic kernel, a constexpr in a
+// specialised one), `d` = this launch's descriptor in device memory (addresses, sizes)
+__device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __restrict__ d, unsigned long long* gb_lds) {
+   const uint32_t S = d->lds_slots, R = d->lds_reps;
+   const uint32_t SR = S * R;
+   const int nw = m.n_words;
+   const bool use_lds = m.use_lds != 0;
+   unsigned long long* l_keys = gb_lds;
+   unsigned long long* l_acc = gb_lds + SR; // word w of index idx at l_acc[w*SR + idx], idx = slot*R + replica
+   if (use_lds) {
+      for (uint32_t k = threadIdx.x; k < SR; k += GB_BLOCK) l_keys[k] = m.keyless ? 1ull : 0ull;
+      LDB_UNROLL
+      for (int w = 0; w < nw; w++) {
+         unsigned long long init = m.word_init[w];
+         for (uint32_t k = threadIdx.x; k < SR; k += GB_BLOCK) l_acc[(uint32_t) w * SR + k] = init;
+      }
+      __syncthreads();
+   }
+   const uint64_t n = d->n_rows;
+   const uint32_t rep = threadIdx.x & (R - 1);
+   const int np = m.n_preds;
+   const KV keys(m.keys, d->keys);
+   unsigned long long* g_acc = gptr_mut<unsigned long long>(d->g_acc);
+   const uint64_t g_cap = d->g_cap;
+   for (uint64_t i = blockIdx.x * (uint64_t) GB_BLOCK + threadIdx.x; i < n; i += (uint64_t) gridDim.x * GB_BLOCK) {
+      bool pass = true;
+      LDB_UNROLL
+      for (int p = 0; p < np; p++)
+         if (pass) pass = d_eval_pred(PV(m.preds[p], d->preds[p]), i);
+      if (!pass) continue;
+      uint64_t h = 0;
+      if (!m.keyless) h = d_hash_keys(keys, i);
+      RowVals rv;
+      uint32_t rvalid;
+      d_load_vals(m, d, i, rv, rvalid);
+      int32_t lslot = -1;
+      if (use_lds) {
+         if (m.keyless) {
+            lslot = 0;
+         } else {
+            const unsigned long long mine = (h & 0xFFFFFFFF00000000ull) | (unsigned long long) ((uint32_t) i + 1u);
+            uint32_t pos = (uint32_t) (h >> 6) & (S - 1);
+            for (uint32_t step = 0; step < S; step++) {
+               unsigned long long w = l_keys[pos * R + rep];
+               if (w == 0) {
+                  unsigned long long old = atomicCAS(&l_keys[pos * R + rep], 0ull, mine);
+                  if (old == 0) {
+                     lslot = (int32_t) pos;
+                     break;
+                  }
+                  w = old;
+               }
+               if ((w >> 32) == (h >> 32) && d_keys_equal(keys, (uint64_t) ((uint32_t) w - 1u), keys, i, true)) {
+                  lslot = (int32_t) pos;
+                  break;
+               }
+               pos = (pos + 1) & (S - 1);
+               if (step >= 15) break; // long probe sequences: send the row to the global table instead
+            }
+         }
+      }
+      if (lslot >= 0) {
+         Sink s{l_acc + (uint32_t) lslot * R + rep, SR};
+         d_accumulate(m, d, rv, rvalid, i, s);
+      } else {
+         uint64_t g = d_global_slot(m, d, h, i);
+         if (g != ~0ull) {
+            Sink s{g_acc + g, g_cap};
+            d_accumulate(m, d, rv, rvalid, i, s);
+         }
+      }
+   }
+   if (!use_lds) return;
+   __syncthreads();
+   // flush: every occupied (slot, replica) → global table
+   for (uint32_t k = threadIdx.x; k < SR; k += GB_BLOCK) {
+      unsigned long long w = l_keys[k];
+      if (w == 0) continue;
+      Sink src{l_acc + k, SR};
+      uint64_t g = 0;
+      if (!m.keyless) {
+         uint64_t i = (uint64_t) ((uint32_t) w - 1u);
+         uint64_t h = d_hash_keys(keys, i);
+         g = d_global_slot(m, d, h, i);
+         if (g == ~0ull) continue;
+      }
+      Sink dst{g_acc + g, g_cap};
+      d_combine(m, src, dst);
+   }
+}

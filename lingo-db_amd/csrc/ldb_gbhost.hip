@@ -1,4 +1,5 @@
-// ldb_groupby.hip — fused scan + predicate + hash group-by aggregation.
+// ldb_gbhost.hip — fused scan + predicate + hash group-by aggregation: host side, AOT kernels,
+// and the hook into the run-time specialiser.  Device code: ldb_gb_kernel.h.
 // Replaces (reference): the generated pipeline body around PreAggregationHashtableFragment
 // (LookupPreAggrHtFragment, src/compiler/Conversion/SubOpToControlFlow/SubOpToControlFlow.cpp:3065-3157;
 // ReduceOpLowering :3719-3768; PreAggregationHashtableFragment::insert,
@@ -21,356 +22,19 @@
 //   * keys are never copied into the table: a slot names a representative input row; equality
 //     is checked against that row's key columns (any key type, incl. strings), and the output key
 //     columns are a gather of the representative rows (late materialisation).
-#include "ldb_keys.h"
+//   * like the reference (which JIT-compiles each pipeline with LLVM), large inputs run a kernel
+//     specialised at run time on the descriptor (hiprtc, ldb_jit.hip); small inputs and any
+//     specialisation failure use the generic ahead-of-time kernel below — both are this source.
+#include "ldb_internal.h"
+#include "ldb_gb_kernel.h"
+#include "ldb_jit.h"
 #include <algorithm>
 #include <memory>
 
-#define GB_BLOCK 256
-#define GB_MAX_COLS 12
-#define GB_MAX_ACCS 20
-#define GB_MAX_CPREDS 6
-#define GB_MAX_OUT 16
-#define GB_MAX_WORDS 24
+extern __shared__ __attribute__((aligned(16))) unsigned long long gb_lds_dyn[];
 
-enum { ACC_SUM64 = 0,
-       ACC_SUM128 = 1,
-       ACC_COUNT = 2,
-       ACC_MIN64 = 3,
-       ACC_MAX64 = 4,
-       ACC_SUMF64 = 5,
-       ACC_MINF64 = 6,
-       ACC_MAXF64 = 7 };
-
-struct DFactorG {
-   int32_t has_col;
-   int32_t col_idx; // into DGroupBy::cols
-   int64_t a, b;
-};
-struct DTermG {
-   int32_t n_factors, negate, div_pow10, pad;
-   DFactorG f[LDB_MAX_FACTORS];
-};
-struct DExprG {
-   int32_t n_terms, is_float;
-   DTermG t[LDB_MAX_TERMS];
-};
-struct DAcc {
-   int32_t kind;
-   int32_t word; // first accumulator word
-   int32_t n_cpreds;
-   int32_t cpred[LDB_MAX_AGG_PREDS]; // indexes into DGroupBy::cpreds
-   int32_t count_rows; // ACC_COUNT: 1 = count rows (COUNT(*)), 0 = count non-NULL expr
-   DExprG e;
-};
-struct DOut { // one output aggregate column
-   int32_t fn; // ldb_agg_fn
-   int32_t acc; // value accumulator
-   int32_t cnt_acc; // AVG divisor / validity counter (-1: always valid)
-   int32_t wide;
-   int32_t avg_pow10;
-   int32_t out_width; // bytes per output value
-   int32_t is_float;
-   int32_t pad;
-   void* out_values;
-   uint8_t* out_valid; // one byte per group (packed later) or NULL
-   DExprG e; // ANY: evaluated on the representative row
-};
-struct DGroupBy {
-   uint64_t n_rows;
-   int32_t n_preds, n_cols, n_accs, n_words, n_cpreds, n_outs;
-   int32_t keyless, use_lds;
-   uint32_t lds_slots, lds_reps; // S (pow2), R (pow2)
-   uint64_t g_cap; // global capacity (pow2)
-   uint64_t* g_keys;
-   uint64_t* g_acc; // word w of slot p at g_acc[w * g_cap + p]
-   uint32_t* g_flags; // [0] = overflow
-   DKeys keys;
-   DPred preds[LDB_MAX_PREDS];
-   DPred cpreds[GB_MAX_CPREDS];
-   DCol cols[GB_MAX_COLS];
-   DAcc accs[GB_MAX_ACCS];
-   uint64_t word_init[GB_MAX_WORDS];
-   DOut outs[GB_MAX_OUT];
-};
-
-// ---------------------------------------------------------------- expression evaluation
-// value cache: the low 64 bits of every referenced narrow column, loaded once per row into a
-// register array (indexed with s_set_gpr_idx by the wave-uniform col_idx).
-// (a bare array, not a struct member: only array allocas are promoted to registers)
-typedef long long RowVals[GB_MAX_COLS];
-
-__device__ __forceinline__ void d_load_vals(const DGroupBy* __restrict__ d, uint64_t i, RowVals& rv, uint32_t& rvalid) {
-   rvalid = 0; // bit c = column c non-NULL
-   const int nc = d->n_cols;
-#pragma unroll
-   for (int c = 0; c < GB_MAX_COLS; c++) {
-      long long x = 0;
-      if (c < nc) {
-         const DCol& col = d->cols[c];
-         uint32_t row = d_phys_row(col, i);
-         if (d_valid(col, row)) {
-            rvalid |= 1u << c;
-            if (col.type != LDB_T_FLOAT64 && col.type != LDB_T_FLOAT32) x = d_load_i64(col, row);
-            else x = __double_as_longlong(d_load_f64(col, row));
-         }
-      }
-      rv[c] = x;
-   }
-}
-
-// Σ_t ± Π_f (a + b*col) / 10^k in wrapping 128-bit arithmetic (DecimalMulOpLowering /
-// DecimalBinOpLowering, reference LowerToStd.cpp:653-699).  Returns false when a referenced
-// column is NULL.
-__device__ __forceinline__ bool d_eval_int(const DGroupBy* __restrict__ d, const DExprG& e, const RowVals& rv, uint32_t rvalid, uint64_t i, i128* out) {
-   u128 total = 0;
-   const int nt = e.n_terms;
-   for (int t = 0; t < nt; t++) {
-      const DTermG& tm = e.t[t];
-      u128 prod = 1;
-      const int nf = tm.n_factors;
-      for (int f = 0; f < nf; f++) {
-         const DFactorG& fa = tm.f[f];
-         i128 v = (i128) fa.a;
-         if (fa.has_col) {
-            const int ci = fa.col_idx;
-            if (!((rvalid >> ci) & 1)) return false;
-            const DCol& col = d->cols[ci];
-            if (d_is_wide(col)) v = (i128) ((u128) v + (u128) (i128) fa.b * (u128) d_load_i128(col, d_phys_row(col, i)));
-            else v += (i128) fa.b * (i128) rv[ci]; // 64x64 → 128, exact
-         }
-         prod = f == 0 ? (u128) v : prod * (u128) v;
-      }
-      if (tm.div_pow10 > 0) prod = (u128) d_sdiv128((i128) prod, d_pow10(tm.div_pow10));
-      total = tm.negate ? total - prod : total + prod;
-   }
-   *out = (i128) total;
-   return true;
-}
-__device__ __forceinline__ bool d_eval_flt(const DGroupBy* __restrict__ d, const DExprG& e, const RowVals& rv, uint32_t rvalid, double* out) {
-   double total = 0;
-   const int nt = e.n_terms;
-   for (int t = 0; t < nt; t++) {
-      const DTermG& tm = e.t[t];
-      double prod = 1;
-      const int nf = tm.n_factors;
-      for (int f = 0; f < nf; f++) {
-         const DFactorG& fa = tm.f[f];
-         double v = (double) fa.a;
-         if (fa.has_col) {
-            const int ci = fa.col_idx;
-            if (!((rvalid >> ci) & 1)) return false;
-            const DCol& col = d->cols[ci];
-            double x = (col.type == LDB_T_FLOAT64 || col.type == LDB_T_FLOAT32) ? __longlong_as_double(rv[ci]) : (double) rv[ci];
-            v += (double) fa.b * x;
-         }
-         prod *= v;
-      }
-      total = tm.negate ? total - prod : total + prod;
-   }
-   *out = total;
-   return true;
-}
-
-// ---------------------------------------------------------------- accumulator sinks
-// double min/max via CAS on the bit pattern
-__device__ __forceinline__ void d_atomic_minmax_f64(unsigned long long* p, double v, bool is_min) {
-   unsigned long long old = *p;
-   for (;;) {
-      double cur = __longlong_as_double((long long) old);
-      bool better = is_min ? v < cur : v > cur;
-      if (!better) return;
-      unsigned long long prev = atomicCAS(p, old, (unsigned long long) __double_as_longlong(v));
-      if (prev == old) return;
-      old = prev;
-   }
-}
-
-struct Sink {
-   unsigned long long* base; // word 0 of this slot
-   uint64_t stride; // distance between consecutive words of one slot
-   __device__ __forceinline__ unsigned long long* w(int k) const { return base + (uint64_t) k * stride; }
-};
-
-__device__ __forceinline__ void d_sink_add128(const Sink& s, int word, u128 v) {
-   unsigned long long lo = (unsigned long long) v, hi = (unsigned long long) (v >> 64);
-   unsigned long long old = atomicAdd(s.w(word), lo);
-   hi += (unsigned long long) (old + lo < old); // carry out of the low word
-   if (hi) atomicAdd(s.w(word + 1), hi);
-}
-
-// fold one input row into the accumulators of its group
-__device__ __forceinline__ void d_accumulate(const DGroupBy* __restrict__ d, const RowVals& rv, uint32_t rvalid, uint64_t i, const Sink& s) {
-   const int na = d->n_accs;
-   for (int a = 0; a < na; a++) {
-      const DAcc& acc = d->accs[a];
-      bool pass = true;
-      for (int p = 0; p < acc.n_cpreds; p++)
-         if (pass) pass = d_eval_pred(d->cpreds[acc.cpred[p]], i);
-      if (!pass) continue; // sum(case when p then x else 0 end) adds 0
-      if (acc.kind == ACC_COUNT && acc.count_rows) {
-         atomicAdd(s.w(acc.word), 1ull);
-         continue;
-      }
-      if (acc.e.is_float) {
-         double fv;
-         if (!d_eval_flt(d, acc.e, rv, rvalid, &fv)) continue;
-         switch (acc.kind) {
-            case ACC_COUNT: atomicAdd(s.w(acc.word), 1ull); break;
-            case ACC_SUMF64: atomicAdd((double*) s.w(acc.word), fv); break;
-            case ACC_MINF64: d_atomic_minmax_f64(s.w(acc.word), fv, true); break;
-            default: d_atomic_minmax_f64(s.w(acc.word), fv, false); break;
-         }
-         continue;
-      }
-      i128 v;
-      if (!d_eval_int(d, acc.e, rv, rvalid, i, &v)) continue;
-      switch (acc.kind) {
-         case ACC_COUNT: atomicAdd(s.w(acc.word), 1ull); break;
-         case ACC_SUM64: atomicAdd(s.w(acc.word), (unsigned long long) v); break; // i64 wrap = SUM in the argument type
-         case ACC_SUM128: d_sink_add128(s, acc.word, (u128) v); break;
-         case ACC_MIN64: atomicMin((long long*) s.w(acc.word), (long long) v); break;
-         default: atomicMax((long long*) s.w(acc.word), (long long) v); break;
-      }
-   }
-}
-
-// merge accumulator words of an LDS slot into the global slot (combine step of
-// MergePreAggrHashMap, reference SubOpToControlFlow.cpp:1861-1938)
-__device__ __forceinline__ void d_combine(const DGroupBy* __restrict__ d, const Sink& src, const Sink& dst) {
-   const int na = d->n_accs;
-   for (int a = 0; a < na; a++) {
-      const DAcc& acc = d->accs[a];
-      unsigned long long x = *src.w(acc.word);
-      switch (acc.kind) {
-         case ACC_COUNT:
-         case ACC_SUM64:
-            if (x) atomicAdd(dst.w(acc.word), x);
-            break;
-         case ACC_SUM128: {
-            unsigned long long hi = *src.w(acc.word + 1);
-            d_sink_add128(dst, acc.word, ((u128) hi << 64) | x);
-            break;
-         }
-         case ACC_MIN64: atomicMin((long long*) dst.w(acc.word), (long long) x); break;
-         case ACC_MAX64: atomicMax((long long*) dst.w(acc.word), (long long) x); break;
-         case ACC_SUMF64:
-            if (__longlong_as_double((long long) x) != 0.0) atomicAdd((double*) dst.w(acc.word), __longlong_as_double((long long) x));
-            break;
-         case ACC_MINF64: d_atomic_minmax_f64(dst.w(acc.word), __longlong_as_double((long long) x), true); break;
-         default: d_atomic_minmax_f64(dst.w(acc.word), __longlong_as_double((long long) x), false); break;
-      }
-   }
-}
-
-// ---------------------------------------------------------------- tables
-// global find-or-insert; returns slot or ~0 on overflow
-__device__ __forceinline__ uint64_t d_global_slot(const DGroupBy* __restrict__ d, uint64_t h, uint64_t i) {
-   if (d->keyless) return 0;
-   const uint64_t mask = d->g_cap - 1;
-   const uint64_t mine = (h & 0xFFFFFFFF00000000ull) | (uint64_t) ((uint32_t) i + 1u);
-   uint64_t pos = (h ^ (h >> 29)) & mask;
-   for (uint64_t step = 0; step <= mask; step++) {
-      unsigned long long w = __hip_atomic_load((unsigned long long*) &d->g_keys[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (w == 0) {
-         unsigned long long old = atomicCAS((unsigned long long*) &d->g_keys[pos], 0ull, (unsigned long long) mine);
-         if (old == 0) return pos;
-         w = old;
-      }
-      if ((w >> 32) == (h >> 32) && d_keys_equal(d->keys, (uint64_t) ((uint32_t) w - 1u), d->keys, i, true)) return pos;
-      pos = (pos + 1) & mask;
-   }
-   atomicOr(&d->g_flags[0], 1u);
-   return ~0ull;
-}
-
-extern __shared__ __attribute__((aligned(16))) unsigned long long gb_lds[];
-
-__global__ __launch_bounds__(GB_BLOCK) void k_groupby(const DGroupBy* __restrict__ d) {
-   const uint32_t S = d->lds_slots, R = d->lds_reps;
-   const uint32_t SR = S * R;
-   const int nw = d->n_words;
-   const bool use_lds = d->use_lds != 0;
-   unsigned long long* l_keys = gb_lds;
-   unsigned long long* l_acc = gb_lds + SR; // word w of index idx at l_acc[w*SR + idx], idx = slot*R + replica
-   if (use_lds) {
-      for (uint32_t k = threadIdx.x; k < SR; k += GB_BLOCK) l_keys[k] = d->keyless ? 1ull : 0ull;
-      for (int w = 0; w < nw; w++) {
-         unsigned long long init = d->word_init[w];
-         for (uint32_t k = threadIdx.x; k < SR; k += GB_BLOCK) l_acc[(uint32_t) w * SR + k] = init;
-      }
-      __syncthreads();
-   }
-   const uint64_t n = d->n_rows;
-   const uint32_t rep = threadIdx.x & (R - 1);
-   const int np = d->n_preds;
-   for (uint64_t i = blockIdx.x * (uint64_t) GB_BLOCK + threadIdx.x; i < n; i += (uint64_t) gridDim.x * GB_BLOCK) {
-      bool pass = true;
-      for (int p = 0; p < np; p++)
-         if (pass) pass = d_eval_pred(d->preds[p], i);
-      if (!pass) continue;
-      uint64_t h = 0;
-      if (!d->keyless) h = d_hash_keys(d->keys, i);
-      RowVals rv;
-      uint32_t rvalid;
-      d_load_vals(d, i, rv, rvalid);
-      int32_t lslot = -1;
-      if (use_lds) {
-         if (d->keyless) {
-            lslot = 0;
-         } else {
-            const unsigned long long mine = (h & 0xFFFFFFFF00000000ull) | (unsigned long long) ((uint32_t) i + 1u);
-            uint32_t pos = (uint32_t) (h >> 6) & (S - 1);
-            for (uint32_t step = 0; step < S; step++) {
-               unsigned long long w = l_keys[pos * R + rep];
-               if (w == 0) {
-                  unsigned long long old = atomicCAS(&l_keys[pos * R + rep], 0ull, mine);
-                  if (old == 0) {
-                     lslot = (int32_t) pos;
-                     break;
-                  }
-                  w = old;
-               }
-               if ((w >> 32) == (h >> 32) && d_keys_equal(d->keys, (uint64_t) ((uint32_t) w - 1u), d->keys, i, true)) {
-                  lslot = (int32_t) pos;
-                  break;
-               }
-               pos = (pos + 1) & (S - 1);
-               if (step >= 15) break; // long probe sequences: send the row to the global table instead
-            }
-         }
-      }
-      if (lslot >= 0) {
-         Sink s{l_acc + (uint32_t) lslot * R + rep, SR};
-         d_accumulate(d, rv, rvalid, i, s);
-      } else {
-         uint64_t g = d_global_slot(d, h, i);
-         if (g != ~0ull) {
-            Sink s{(unsigned long long*) d->g_acc + g, d->g_cap};
-            d_accumulate(d, rv, rvalid, i, s);
-         }
-      }
-   }
-   if (!use_lds) return;
-   __syncthreads();
-   // flush: every occupied (slot, replica) → global table
-   for (uint32_t k = threadIdx.x; k < SR; k += GB_BLOCK) {
-      unsigned long long w = l_keys[k];
-      if (w == 0) continue;
-      Sink src{l_acc + k, SR};
-      uint64_t g;
-      if (d->keyless) {
-         // skip untouched replicas cheaply: all-initial words contribute nothing
-         g = 0;
-      } else {
-         uint64_t i = (uint64_t) ((uint32_t) w - 1u);
-         uint64_t h = d_hash_keys(d->keys, i);
-         g = d_global_slot(d, h, i);
-         if (g == ~0ull) continue;
-      }
-      Sink dst{(unsigned long long*) d->g_acc + g, d->g_cap};
-      d_combine(d, src, dst);
-   }
-}
+// generic ahead-of-time kernel: metadata and addresses both come from the descriptor in memory
+__global__ __launch_bounds__(GB_BLOCK) void k_groupby(const DGroupBy* __restrict__ d) { gb_body(*d, d, gb_lds_dyn); }
 
 __global__ void k_gb_init(uint64_t* keys, uint64_t* acc, const DGroupBy* __restrict__ d) {
    const uint64_t cap = d->g_cap;
@@ -385,12 +49,12 @@ __global__ void k_gb_init(uint64_t* keys, uint64_t* acc, const DGroupBy* __restr
 __global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restrict__ rep_rows, unsigned long long* __restrict__ counter) {
    const uint64_t cap = d->g_cap;
    for (uint64_t p = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; p < cap; p += (uint64_t) gridDim.x * blockDim.x) {
-      uint64_t w = d->g_keys[p];
+      uint64_t w = ((const uint64_t*) d->g_keys)[p];
       if (w == 0) continue;
       uint64_t g = atomicAdd(counter, 1ull);
       uint32_t rep = (uint32_t) w - 1u;
       rep_rows[g] = rep;
-      const uint64_t* acc = d->g_acc + p;
+      const uint64_t* acc = (const uint64_t*) d->g_acc + p;
       for (int o = 0; o < d->n_outs; o++) {
          const DOut& out = d->outs[o];
          bool ok = true;
@@ -406,15 +70,15 @@ __global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restri
             } else if (out.fn == LDB_AGG_ANY) {
                RowVals rv;
                uint32_t rvalid;
-               d_load_vals(d, rep, rv, rvalid);
-               ok = d_eval_flt(d, out.e, rv, rvalid, &v);
+               d_load_vals(*d, d, rep, rv, rvalid);
+               ok = d_eval_flt(*d, out.e, rv, rvalid, &v);
             } else {
                v = __longlong_as_double((long long) acc[(uint64_t) d->accs[out.acc].word * cap]);
                if (out.fn == LDB_AGG_AVG && ok) v = v / (double) cnt;
             }
             if (out.fn != LDB_AGG_COUNT && out.fn != LDB_AGG_COUNT_STAR) {
                ((double*) out.out_values)[g] = ok ? v : 0.0;
-               if (out.out_valid) out.out_valid[g] = ok ? 1 : 0;
+               if (out.out_valid) ((uint8_t*) out.out_valid)[g] = ok ? 1 : 0;
                continue;
             }
          }
@@ -428,8 +92,8 @@ __global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restri
             case LDB_AGG_ANY: {
                RowVals rv;
                uint32_t rvalid;
-               d_load_vals(d, rep, rv, rvalid);
-               ok = d_eval_int(d, out.e, rv, rvalid, rep, &v);
+               d_load_vals(*d, d, rep, rv, rvalid);
+               ok = d_eval_int(*d, d, out.e, rv, rvalid, rep, &v);
                break;
             }
             default: {
@@ -454,7 +118,7 @@ __global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restri
                ((uint64_t*) out.out_values)[2 * g + 1] = (uint64_t) (v >> 64);
             }
          }
-         if (out.out_valid) out.out_valid[g] = ok ? 1 : 0;
+         if (out.out_valid) ((uint8_t*) out.out_valid)[g] = ok ? 1 : 0;
       }
    }
 }
@@ -738,24 +402,40 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    std::vector<uint8_t*> out_valid((size_t) n_aggs, nullptr);
    for (int attempt = 0;; attempt++) {
       h->g_cap = cap;
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &h->g_keys, 8 * (size_t) cap));
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &h->g_acc, 8 * (size_t) cap * (size_t) nw));
-      h->g_flags = d_flags;
+      uint64_t *gk, *ga;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &gk, 8 * (size_t) cap));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &ga, 8 * (size_t) cap * (size_t) nw));
+      h->g_keys = (uint64_t) gk;
+      h->g_acc = (uint64_t) ga;
+      h->g_flags = (uint64_t) d_flags;
       LDB_HIP(hipMemsetAsync(d_flags, 0, 64, ctx->stream));
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-      hipLaunchKernelGGL(k_gb_init, dim3(ldb_grid_for(ctx, (int64_t) cap, 256, 8)), dim3(256), 0, ctx->stream, h->g_keys, h->g_acc, d);
+      hipLaunchKernelGGL(k_gb_init, dim3(ldb_grid_for(ctx, (int64_t) cap, 256, 8)), dim3(256), 0, ctx->stream, gk, ga, d);
       if (in->n_rows) {
          int per_cu = lds_bytes > 40 * 1024 ? 2 : 4;
          int grid = ldb_grid_for(ctx, in->n_rows, GB_BLOCK, per_cu);
-         { LdbProf prof_(ctx, "k_groupby"); hipLaunchKernelGGL(k_groupby, dim3(grid), dim3(GB_BLOCK), lds_bytes, ctx->stream, d); }
+         hipFunction_t spec = nullptr;
+         if (ldb_jit_wanted(in->n_rows)) {
+            std::string why;
+            spec = ldb_jit_groupby(h, &why);
+            if (!spec) ldb_set_error("groupby: specialised kernel unavailable (%s); using the generic kernel", why.c_str());
+         }
+         if (spec) {
+            LdbProf prof_(ctx, "k_groupby");
+            void* params[] = {(void*) &d};
+            LDB_HIP(hipModuleLaunchKernel(spec, (unsigned) grid, 1, 1, GB_BLOCK, 1, 1, (unsigned) lds_bytes, ctx->stream, params, nullptr));
+         } else {
+            LdbProf prof_(ctx, "k_groupby");
+            hipLaunchKernelGGL(k_groupby, dim3(grid), dim3(GB_BLOCK), lds_bytes, ctx->stream, d);
+         }
       }
       LDB_HIP(hipGetLastError());
       uint64_t flags = 0;
       LDB_TRY(ldb_read_u64(ctx, d_flags, &flags));
       if ((flags & 1) == 0) break;
       // global table overflowed: retry larger (the estimate was too low)
-      ldb_dev_free(ctx, h->g_keys);
-      ldb_dev_free(ctx, h->g_acc);
+      ldb_dev_free(ctx, gk);
+      ldb_dev_free(ctx, ga);
       ldb_dev_free(ctx, d);
       if (cap >= cap_max) LDB_FAIL(LDB_ERR_HIP, "groupby: global table overflow at maximum capacity");
       cap = std::min(cap * 8, cap_max);
@@ -766,10 +446,10 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &rep_rows, 4 * (size_t) (max_groups ? max_groups : 1)));
    for (int32_t a = 0; a < n_aggs; a++) {
       LDB_TRY(ldb_dev_alloc(ctx, &out_vals[(size_t) a], (size_t) oinfo[(size_t) a].width * (size_t) (max_groups ? max_groups : 1)));
-      h->outs[a].out_values = out_vals[(size_t) a];
+      h->outs[a].out_values = (uint64_t) out_vals[(size_t) a];
       if (h->outs[a].cnt_acc >= 0 || h->outs[a].fn == LDB_AGG_ANY) {
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &out_valid[(size_t) a], (size_t) (max_groups ? max_groups : 1)));
-         h->outs[a].out_valid = out_valid[(size_t) a];
+         h->outs[a].out_valid = (uint64_t) out_valid[(size_t) a];
       }
    }
    ldb_dev_free(ctx, d);
@@ -778,8 +458,8 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    hipLaunchKernelGGL(k_gb_finalize, dim3(ldb_grid_for(ctx, (int64_t) cap, 256, 8)), dim3(256), 0, ctx->stream, d, rep_rows, (unsigned long long*) ctx->d_scratch);
    LDB_HIP(hipGetLastError());
    LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &n_groups));
-   ldb_dev_free(ctx, h->g_keys);
-   ldb_dev_free(ctx, h->g_acc);
+   ldb_dev_free(ctx, (void*) h->g_keys);
+   ldb_dev_free(ctx, (void*) h->g_acc);
    ldb_dev_free(ctx, d);
    ldb_dev_free(ctx, d_flags);
 

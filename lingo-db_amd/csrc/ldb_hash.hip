@@ -2,6 +2,7 @@
 // Replaces (reference): HashLowering (src/compiler/Conversion/DBToStd/LowerToStd.cpp:1065-1152),
 // Hash64Lowering / HashCombineLowering / VarLenTryCheapHashLowering / HashVarLenLowering
 // (src/compiler/Conversion/UtilToLLVM/LowerToLLVM.cpp:372-391,493-524).
+#include "ldb_internal.h"
 #include "ldb_keys.h"
 #include <memory>
 

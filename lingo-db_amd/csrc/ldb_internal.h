@@ -29,40 +29,8 @@ void ldb_set_error(const char* fmt, ...);
       if (s_ != LDB_OK) return s_; \
    } while (0)
 
-// ---------------------------------------------------------------- device-visible descriptors
-// One column as the kernels see it.  `rowids` belongs to the relation side the column is read
-// through (NULL = identity), so a kernel reads logical row i at values[rowids ? rowids[i] : i].
-struct DCol {
-   const void* values;
-   const int64_t* offsets; // utf8
-   const uint8_t* validity; // Arrow bitmap or NULL
-   const uint32_t* rowids;
-   int32_t type; // ldb_type
-   int32_t width; // bytes per value on the device
-   int32_t precision;
-   int32_t scale;
-};
-
-#define LDB_MAX_PREDS 8
-#define LDB_MAX_IN 8
-#define LDB_STR_INLINE 48
-struct DPred {
-   DCol col;
-   DCol rhs;
-   int32_t op;
-   int32_t rhs_kind;
-   uint64_t lo;
-   int64_t hi;
-   double f;
-   int32_t str_len;
-   int32_t n_in;
-   char str[LDB_STR_INLINE];
-   // IN lists: ints as lo/hi; strings packed into in_blob with in_off[k]..in_off[k+1]
-   uint64_t in_lo[LDB_MAX_IN];
-   int64_t in_hi[LDB_MAX_IN];
-   int32_t in_off[LDB_MAX_IN + 1];
-   char in_blob[LDB_MAX_IN * 16];
-};
+// device-visible descriptors (DCol, DPred, DKeys) live in ldb_devtypes.h
+#include "ldb_devtypes.h"
 
 // ---------------------------------------------------------------- host objects
 struct ldb_column {
@@ -136,6 +104,7 @@ int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_
 
 int32_t ldb_make_dcol(const ldb_rel* r, ldb_colref ref, DCol* out);
 int32_t ldb_make_dpred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out);
+int32_t ldb_make_dkeys(const ldb_rel* r, const ldb_colref* keys, int32_t n_keys, DKeys* out);
 int32_t ldb_width_of(const ldb_coltype& t, int narrow);
 
 // launch geometry: blocks for a grid-stride kernel over n items

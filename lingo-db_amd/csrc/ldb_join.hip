@@ -16,6 +16,7 @@
 // Output pairs are appended with wave-aggregated atomics (order unspecified, as in the reference
 // where morsels finish in any order); SEMI/ANTI results are produced in ascending probe order
 // through a ballot bitmap.
+#include "ldb_internal.h"
 #include "ldb_keys.h"
 #include <algorithm>
 #include <memory>

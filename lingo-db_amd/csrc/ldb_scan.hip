@@ -7,6 +7,7 @@
 // their column for lanes still alive), a wave turns its 64 verdicts into one 64-bit ballot word,
 // and the selection is produced from that bitmap (1 bit/row of extra traffic) in ascending row
 // order: k_scan_bitmap → block-count scan → k_scan_expand (mbcnt rank → coalesced id writes).
+#include "ldb_internal.h"
 #include "ldb_device.h"
 #include <memory>
 

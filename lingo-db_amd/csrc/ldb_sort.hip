@@ -9,6 +9,7 @@
 // 4 bits per pass with a stable counting sort (per-thread register histograms → one device scan
 // of the [digit][thread] matrix → ordered scatter).  Equal keys keep input order.
 // TPC-H sorts are post-aggregation (≤ ~1 M rows); the pass structure favours simplicity.
+#include "ldb_internal.h"
 #include "ldb_keys.h"
 #include <algorithm>
 #include <memory>

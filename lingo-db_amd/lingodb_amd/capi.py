@@ -142,6 +142,8 @@ GPU_API = {
     "ldb_gpu_prof_reset": (i32, [P]),
     "ldb_gpu_prof_get": (i32, [P, C.c_char_p, C.POINTER(i64), C.POINTER(C.c_double)]),
     "ldb_gpu_prof_names": (i32, [P, C.c_char_p, i32]),
+    "ldb_gpu_jit_stats": (i32, [C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),
+    "ldb_gpu_jit_compile_check": (i32, [C.c_char_p, i32]),
     "ldb_gpu_table_register": (i32, [P, C.c_char_p, C.POINTER(ArrowSchema), C.POINTER(C.POINTER(ArrowArray)), i64, i32, PP]),
     "ldb_gpu_table_alloc": (i32, [P, C.c_char_p, i32, C.POINTER(ColType), C.POINTER(C.c_char_p), i64, C.POINTER(i64), i32, PP]),
     "ldb_gpu_table_release": (i32, [P, P]),

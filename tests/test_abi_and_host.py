@@ -137,3 +137,10 @@ def test_host_generator_shape_invariants():
     parts = [tpch_data.host_table(tpch_data.LINEITEM, n_orders, p, 3, cols=[0, 3]) for p in range(3)]
     assert sum(p.num_rows for p in parts) == li.num_rows
     assert np.array_equal(np.concatenate([np.asarray(p.column("l_orderkey")) for p in parts]), ok)
+
+
+def test_runtime_specialiser_compiles_without_a_device():
+    """the hiprtc specialisation of the group-by kernel (same source as the AOT kernel) compiles for gfx950"""
+    buf = C.create_string_buffer(16000)
+    st = capi.gpu_lib().ldb_gpu_jit_compile_check(buf, 16000)
+    assert st == 0, buf.value.decode(errors="replace")

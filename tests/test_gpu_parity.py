@@ -415,3 +415,23 @@ def test_plan_q1_q6_q3(ctx, oracle, tpch):
     assert len(got3) == min(10, len(want3))
     assert [(r[1], r[2]) for r in got3] == [(r[1], r[2]) for r in want3[: len(got3)]]
     assert set(got3) <= set(want3)
+
+
+def test_specialised_kernel_matches_generic(ctx, oracle, tpch):
+    """run-time specialised group-by kernels (hiprtc) give the same bits as the generic kernel;
+    LDB_JIT_MIN_ROWS=0 (set by the GPU test command) forces specialisation at these small sizes"""
+    import ctypes as C
+
+    n0, h0, ms0 = C.c_int64(), C.c_int64(), C.c_double()
+    capi.gpu_lib().ldb_gpu_jit_stats(C.byref(n0), C.byref(h0), C.byref(ms0))
+    keys, plist = [(0, 8), (0, 9)], [api.pred((0, 10), capi.F_LTE, 10471)]
+    rep, vals, valid = oracle.groupby(tpch["hli"].rel(), keys, q1_aggs(), plist)
+    for _ in range(2):
+        got = tpch["gli"].rel().groupby(keys, q1_aggs(), plist, est_groups=6)
+        assert_groupby_equal(got, tpch["hli"].rel(), keys, rep, vals, valid)
+    n1, h1, ms1 = C.c_int64(), C.c_int64(), C.c_double()
+    capi.gpu_lib().ldb_gpu_jit_stats(C.byref(n1), C.byref(h1), C.byref(ms1))
+    import os
+
+    if os.environ.get("LDB_JIT_MIN_ROWS") == "0":
+        assert n1.value + h1.value > n0.value + h0.value, "specialised kernel was not used"
