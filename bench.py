@@ -54,10 +54,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback: the product path is the HIP library)")
+    # LDB_DIST_BACKEND=gloo lets the N>1 path be exercised functionally on a 1-GPU box (all ranks
+    # share device 0, collectives staged through host memory); the real runs use nccl (= RCCL)
+    backend = os.environ.get("LDB_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    local_rank = local_rank % n_dev if backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
+    red_dev = "cpu" if backend == "gloo" else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import lingodb_amd as ldb
     import tpch_plans
@@ -101,13 +110,13 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1000.0
     per_query = {q: q_ms[q] / args.steps for q in queries}
     if world > 1:
-        t = torch.tensor([per_query[q] for q in queries], device="cuda", dtype=torch.float64)
+        t = torch.tensor([per_query[q] for q in queries], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         per_query = {q: float(v) for q, v in zip(queries, t.tolist())}
 

@@ -176,6 +176,8 @@ int32_t ldb_gpu_table_set_rows(ldb_table* t, int64_t n_rows);
 int32_t ldb_gpu_table_read_fixed(ldb_ctx* ctx, const ldb_table* t, int32_t col, void* host_out, int64_t out_bytes);
 /* blocking H2D copy into a fixed-width column */
 int32_t ldb_gpu_table_write_fixed(ldb_ctx* ctx, ldb_table* t, int32_t col, const void* host_in, int64_t in_bytes);
+/* device-to-device copy on the ctx stream (moving column buffers to / from RCCL exchange buffers) */
+int32_t ldb_gpu_memcpy_d2d(ldb_ctx* ctx, void* dst, const void* src, int64_t bytes);
 
 /* Replaces result materialisation into Arrow builders (a15: MaterializeTableLowering,
  * SubOpToControlFlow.cpp:984-1004; ArrowColumnBuilder, ArrowColumn.h:15-37).  Fills a struct
@@ -281,7 +283,12 @@ typedef struct {
    int32_t out_type;
    int32_t out_precision;
    int32_t out_scale;
-   int32_t reserved;
+   /* AVG only, has_count_expr != 0: the divisor is SUM(count_expr) instead of the number of
+    * contributing rows — the combine step for partial (sum, count) states (the reference merges
+    * thread-local aggregate states the same way, MergeThreadLocal*, SubOpToControlFlow.cpp:1733,
+    * 1861-1938); used to merge per-GPU partial aggregates. */
+   int32_t has_count_expr;
+   ldb_expr count_expr;
 } ldb_agg_spec;
 
 /* Replaces PreAggregationHashtableFragment::insert + generated lookup/update

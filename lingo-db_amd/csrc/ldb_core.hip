@@ -462,6 +462,12 @@ extern "C" int32_t ldb_gpu_table_write_fixed(ldb_ctx* ctx, ldb_table* t, int32_t
    return LDB_OK;
 }
 
+extern "C" int32_t ldb_gpu_memcpy_d2d(ldb_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+   if (!ctx || bytes < 0 || (bytes && (!dst || !src))) LDB_FAIL(LDB_ERR_INVALID, "memcpy_d2d: bad argument");
+   if (bytes) LDB_HIP(hipMemcpyAsync(dst, src, (size_t) bytes, hipMemcpyDeviceToDevice, ctx->stream));
+   return LDB_OK;
+}
+
 // ---------------------------------------------------------------- export (Arrow C Data Interface out)
 struct ExportPriv {
    std::vector<void*> bufs;

@@ -278,6 +278,15 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       // counter of contributing rows: AVG divisor, and NULL-ness of SUM/MIN/MAX results
       auto need_counter = [&](int32_t* idx) -> int32_t {
          DAcc c = acc;
+         if (sp.fn == LDB_AGG_AVG && sp.has_count_expr) {
+            // merging partial (sum, count) states: the divisor is SUM(count_expr)
+            bool cn = false;
+            c.kind = ACC_SUM64;
+            c.count_rows = 0;
+            LDB_TRY(b.conv_expr(&sp.count_expr, &c.e, &cn));
+            if (c.e.is_float) LDB_FAIL(LDB_ERR_INVALID, "groupby: AVG count_expr must be an integer expression");
+            return add_acc(c, 1, 0, idx);
+         }
          c.kind = ACC_COUNT;
          c.count_rows = (!nullable && sp.fn != LDB_AGG_COUNT) ? 1 : 0;
          if (c.count_rows) memset(&c.e, 0, sizeof(c.e));

@@ -423,6 +423,139 @@ extern "C" int32_t ldb_plan_tpch_q3(ldb_ctx* ctx, const ldb_table* cust, const l
    });
 }
 
+// ---------------------------------------------------------------- multi-GPU plan pieces
+// Row-range sharded fact tables: every rank runs the *_partial plan on its shard, the tiny partial
+// tables are exchanged over RCCL, and *_final merges them exactly as the reference merges
+// thread-local aggregate states (combine = add sums, add counts; AVG = SUM / COUNT afterwards).
+namespace {
+ldb_agg_spec avgMerge(ldb_colref sumCol, ldb_colref cntCol, DecimalType argType) {
+   ldb_agg_spec a = avgDec(product({colFactor(sumCol)}), argType);
+   a.has_count_expr = 1;
+   a.count_expr = product({colFactor(cntCol)});
+   return a;
+}
+ldb_agg_spec sumInt64(ldb_colref c) {
+   ldb_agg_spec a;
+   memset(&a, 0, sizeof(a));
+   a.fn = LDB_AGG_SUM;
+   a.arg = product({colFactor(c)});
+   a.out_type = LDB_T_INT64;
+   return a;
+}
+} // namespace
+
+// keys, sum_qty, sum_base_price, sum_disc_price, sum_charge, sum_disc, count — no AVG division yet
+extern "C" int32_t ldb_plan_tpch_q1_partial(ldb_ctx* ctx, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel scan(ctx);
+      check(ldb_gpu_rel_from_table(ctx, li, &scan.r), "q1 scan");
+      auto restr = Restrictions::create({{"l_shipdate", FilterOp::LTE, std::string("1998-09-02"), {}}}, li);
+      ldb_colref qty{0, colOf(li, "l_quantity")}, ext{0, colOf(li, "l_extendedprice")}, disc{0, colOf(li, "l_discount")}, tax{0, colOf(li, "l_tax")};
+      ldb_colref keys[2] = {{0, colOf(li, "l_returnflag")}, {0, colOf(li, "l_linestatus")}};
+      DecimalType tq = decOf(li, qty.col), te = decOf(li, ext.col), td = decOf(li, disc.col), tt = decOf(li, tax.col);
+      DecimalType t1md, t1pt;
+      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, td, &t1md);
+      ldb_factor onePlusTax = constPlusCol(1, +1, tax, tt, &t1pt);
+      DecimalType tDiscPrice = typeAfterMul(te, t1md), tCharge = typeAfterMul(tDiscPrice, t1pt);
+      ldb_agg_spec aggs[6] = {sumDec(product({colFactor(qty)}), tq),
+                              sumDec(product({colFactor(ext)}), te),
+                              sumDec(product({colFactor(ext), oneMinusDisc}), tDiscPrice),
+                              sumDec(product({colFactor(ext), oneMinusDisc, onePlusTax}), tCharge),
+                              sumDec(product({colFactor(disc)}), td),
+                              countStar()};
+      check(ldb_gpu_groupby(ctx, scan.r, restr->data(), restr->size(), keys, 2, aggs, 6, 6, result), "q1 partial groupby");
+   });
+}
+// partials: the concatenation of every rank's q1_partial table (same column order)
+extern "C" int32_t ldb_plan_tpch_q1_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result) {
+   return guarded([&] {
+      Rel in(ctx), sorted(ctx);
+      check(ldb_gpu_rel_from_table(ctx, partials, &in.r), "q1 final");
+      ldb_colref keys[2] = {{0, 0}, {0, 1}};
+      DecimalType tq = decOf(partials, 2), te = decOf(partials, 3), tdp = decOf(partials, 4), tch = decOf(partials, 5), td = decOf(partials, 6);
+      ldb_colref cnt{0, 7};
+      ldb_agg_spec aggs[8] = {sumDec(product({colFactor({0, 2})}), tq), sumDec(product({colFactor({0, 3})}), te), sumDec(product({colFactor({0, 4})}), tdp),
+                              sumDec(product({colFactor({0, 5})}), tch), avgMerge({0, 2}, cnt, tq), avgMerge({0, 3}, cnt, te), avgMerge({0, 6}, cnt, td), sumInt64(cnt)};
+      Table grouped(ctx);
+      check(ldb_gpu_groupby(ctx, in.r, nullptr, 0, keys, 2, aggs, 8, 6, &grouped.t), "q1 final groupby");
+      Rel g(ctx);
+      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q1 final rel");
+      ldb_sort_spec specs[2] = {{{0, 0}, 0, 0}, {{0, 1}, 0, 0}};
+      check(ldb_gpu_sort(ctx, g.r, specs, 2, &sorted.r), "q1 final sort");
+      ldb_colref outc[10];
+      for (int c = 0; c < 10; c++) outc[c] = {0, c};
+      check(ldb_gpu_materialize(ctx, sorted.r, outc, 10, result), "q1 final materialize");
+   });
+}
+// partials: one row per rank (column 0 = that rank's Q6 revenue, NULL if nothing passed there)
+extern "C" int32_t ldb_plan_tpch_q6_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result) {
+   return guarded([&] {
+      Rel in(ctx);
+      check(ldb_gpu_rel_from_table(ctx, partials, &in.r), "q6 final");
+      ldb_agg_spec agg = sumDec(product({colFactor({0, 0})}), decOf(partials, 0));
+      check(ldb_gpu_groupby(ctx, in.r, nullptr, 0, nullptr, 0, &agg, 1, 1, result), "q6 final aggregate");
+   });
+}
+// Q3 step 1: c_custkey of the customers of this shard with c_mktsegment = 'BUILDING' (to be replicated)
+extern "C" int32_t ldb_plan_tpch_q3_customers(ldb_ctx* ctx, const ldb_table* cust, ldb_table** result) {
+   return guarded([&] {
+      Rel c0(ctx), c1(ctx);
+      check(ldb_gpu_rel_from_table(ctx, cust, &c0.r), "q3 customer");
+      auto rc = Restrictions::create({{"c_mktsegment", FilterOp::EQ, std::string("BUILDING"), {}}}, cust);
+      check(ldb_gpu_scan_filter(ctx, c0.r, rc->data(), rc->size(), &c1.r), "q3 filter customer");
+      ldb_colref ck{0, colOf(cust, "c_custkey")};
+      check(ldb_gpu_materialize(ctx, c1.r, &ck, 1, result), "q3 customer keys");
+   });
+}
+// Q3 step 2 on one shard: `custkeys` = the replicated filtered customer keys (column 0); orders and
+// lineitem are co-partitioned by order range, so both joins and the group-by are shard-local.
+// Result: the shard's top-10 (l_orderkey, revenue, o_orderdate, o_shippriority).
+extern "C" int32_t ldb_plan_tpch_q3_local(ldb_ctx* ctx, const ldb_table* custkeys, const ldb_table* ord, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel c1(ctx), o0(ctx), o1(ctx), l0(ctx), l1(ctx), co(ctx), lco(ctx), top(ctx);
+      check(ldb_gpu_rel_from_table(ctx, custkeys, &c1.r), "q3 customer keys");
+      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q3 orders");
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q3 lineitem");
+      auto ro = Restrictions::create({{"o_orderdate", FilterOp::LT, std::string("1995-03-15"), {}}}, ord);
+      auto rl = Restrictions::create({{"l_shipdate", FilterOp::GT, std::string("1995-03-15"), {}}}, li);
+      check(ldb_gpu_scan_filter(ctx, o0.r, ro->data(), ro->size(), &o1.r), "q3 filter orders");
+      check(ldb_gpu_scan_filter(ctx, l0.r, rl->data(), rl->size(), &l1.r), "q3 filter lineitem");
+      Ht hc(ctx), ho(ctx);
+      ldb_colref ck{0, 0}, ock{0, colOf(ord, "o_custkey")};
+      check(ldb_gpu_join_build(ctx, c1.r, &ck, 1, 1, &hc.h), "q3 build customer");
+      check(ldb_gpu_join_probe(ctx, hc.h, o1.r, &ock, 1, LDB_JOIN_INNER, &co.r, nullptr), "q3 probe orders");
+      ldb_colref ook{0, colOf(ord, "o_orderkey")}, lok{0, colOf(li, "l_orderkey")};
+      check(ldb_gpu_join_build(ctx, co.r, &ook, 1, 1, &ho.h), "q3 build orders");
+      check(ldb_gpu_join_probe(ctx, ho.h, l1.r, &lok, 1, LDB_JOIN_INNER, &lco.r, nullptr), "q3 probe lineitem");
+      ldb_colref ext{0, colOf(li, "l_extendedprice")}, disc{0, colOf(li, "l_discount")};
+      DecimalType t1md;
+      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, decOf(li, disc.col), &t1md);
+      DecimalType tRev = typeAfterMul(decOf(li, ext.col), t1md);
+      ldb_agg_spec agg = sumDec(product({colFactor(ext), oneMinusDisc}), tRev);
+      ldb_colref keys[3] = {lok, {1, colOf(ord, "o_orderdate")}, {1, colOf(ord, "o_shippriority")}};
+      Table grouped(ctx);
+      int64_t est = ldb_gpu_rel_rows(ctx, lco.r);
+      check(ldb_gpu_groupby(ctx, lco.r, nullptr, 0, keys, 3, &agg, 1, est > 0 ? est : 1, &grouped.t), "q3 groupby");
+      Rel g(ctx);
+      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q3 rel");
+      ldb_sort_spec specs[2] = {{{0, 3}, 1, 0}, {{0, 1}, 0, 0}};
+      check(ldb_gpu_topk(ctx, g.r, specs, 2, 10, &top.r), "q3 topk");
+      ldb_colref outc[4] = {{0, 0}, {0, 3}, {0, 1}, {0, 2}};
+      check(ldb_gpu_materialize(ctx, top.r, outc, 4, result), "q3 materialize");
+   });
+}
+// Q3 step 3: global top-10 of the gathered shard top-10s (order keys are disjoint across shards)
+extern "C" int32_t ldb_plan_tpch_q3_final(ldb_ctx* ctx, const ldb_table* tops, ldb_table** result) {
+   return guarded([&] {
+      Rel in(ctx), top(ctx);
+      check(ldb_gpu_rel_from_table(ctx, tops, &in.r), "q3 final");
+      ldb_sort_spec specs[2] = {{{0, 1}, 1, 0}, {{0, 2}, 0, 0}};
+      check(ldb_gpu_topk(ctx, in.r, specs, 2, 10, &top.r), "q3 final topk");
+      ldb_colref outc[4] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}};
+      check(ldb_gpu_materialize(ctx, top.r, outc, 4, result), "q3 final materialize");
+   });
+}
+
 // ---------------------------------------------------------------- C hooks for the host-logic tests
 extern "C" int32_t ldb_host_parse_date32(const char* s, int32_t* out) {
    return guarded([&] { *out = parseDate32(s); });

@@ -72,6 +72,13 @@ int32_t ldb_plan_tpch_q1(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** re
 int32_t ldb_plan_tpch_q6(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q3(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
 const char* ldb_plan_last_error(void);
+// multi-GPU pieces: shard-local partial plans + merges of the exchanged partial tables
+int32_t ldb_plan_tpch_q1_partial(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q1_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
+int32_t ldb_plan_tpch_q6_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
+int32_t ldb_plan_tpch_q3_customers(ldb_ctx* ctx, const ldb_table* customer, ldb_table** result);
+int32_t ldb_plan_tpch_q3_local(ldb_ctx* ctx, const ldb_table* custkeys, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q3_final(ldb_ctx* ctx, const ldb_table* tops, ldb_table** result);
 // test hooks for the host logic (date / decimal parsing, decimal typing rules)
 int32_t ldb_host_parse_date32(const char* s, int32_t* out);
 int32_t ldb_host_parse_decimal(const char* s, int32_t scale, int64_t* lo, int64_t* hi);

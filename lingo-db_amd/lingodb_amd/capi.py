@@ -81,7 +81,8 @@ class AggSpec(C.Structure):
         ("out_type", C.c_int32),
         ("out_precision", C.c_int32),
         ("out_scale", C.c_int32),
-        ("reserved", C.c_int32),
+        ("has_count_expr", C.c_int32),
+        ("count_expr", Expr),
     ]
 
 
@@ -157,6 +158,7 @@ GPU_API = {
     "ldb_gpu_table_set_rows": (i32, [P, i64]),
     "ldb_gpu_table_read_fixed": (i32, [P, P, i32, P, i64]),
     "ldb_gpu_table_write_fixed": (i32, [P, P, i32, P, i64]),
+    "ldb_gpu_memcpy_d2d": (i32, [P, P, P, i64]),
     "ldb_gpu_export": (i32, [P, P, C.POINTER(ArrowSchema), C.POINTER(ArrowArray)]),
     "ldb_gpu_rel_from_table": (i32, [P, P, PP]),
     "ldb_gpu_rel_release": (i32, [P, P]),
@@ -187,6 +189,12 @@ HOST_API = {
     "ldb_plan_tpch_q6": (i32, [P, P, PP]),
     "ldb_plan_tpch_q3": (i32, [P, P, P, P, PP]),
     "ldb_plan_last_error": (C.c_char_p, []),
+    "ldb_plan_tpch_q1_partial": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q1_final": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q6_final": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q3_customers": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q3_local": (i32, [P, P, P, P, PP]),
+    "ldb_plan_tpch_q3_final": (i32, [P, P, PP]),
     "ldb_host_parse_date32": (i32, [C.c_char_p, C.POINTER(i32)]),
     "ldb_host_parse_decimal": (i32, [C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64)]),
     "ldb_host_decimal_type": (None, [i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),

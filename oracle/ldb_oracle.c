@@ -617,7 +617,12 @@ static void agg_update(const ora_rel* r, const ldb_agg_spec* aggs, int32_t n_agg
                s->v = wrap_add(s->v, v);
             else
                s->v = (int64_t) ((uint64_t) (int64_t) s->v + (uint64_t) (int64_t) v);
-            s->cnt++;
+            if (sp->fn == LDB_AGG_AVG && sp->has_count_expr) { /* combining partial (sum, count) states */
+               int cnul;
+               s->cnt += (int64_t) eval_expr_int(r, &sp->count_expr, i, &cnul);
+            } else {
+               s->cnt++;
+            }
             s->valid = 1;
             break;
          case LDB_AGG_MIN:

@@ -1,0 +1,55 @@
+"""Launched by torch.distributed.run (see test_gpu_dist.py): runs the sharded multi-rank TPC-H plans
+(tpch_dist.py) and checks on rank 0 that they return exactly what the single-GPU plans return on
+the unsharded database.  With LDB_DIST_BACKEND=gloo all ranks share GPU 0 (functional check of the
+N>1 path on a 1-GPU box); with nccl it needs one GPU per rank."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "lingo-db_amd"))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    backend = os.environ.get("LDB_DIST_BACKEND", "nccl")
+    dev = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend)
+    import lingodb_amd as ldb
+    import tpch_plans
+
+    n_orders = int(os.environ.get("LDB_CHECK_ORDERS", "30002"))
+    queries = [1, 6, 3]
+    ctx = ldb.Context(dev)
+    db = tpch_plans.Database(ctx, n_orders, rank, world, queries, False)
+    runner = tpch_plans.Runner(ctx, db, world, dist, torch)
+    got = {q: runner.run(q).to_arrow() for q in queries}
+    ok = True
+    if rank == 0:
+        full = tpch_plans.Database(ctx, n_orders, 0, 1, queries, False)
+        single = tpch_plans.Runner(ctx, full, 1, None, torch)
+        for q in queries:
+            want = single.run(q).to_arrow()
+            a, b = got[q].to_pylist(), want.to_pylist()
+            if q == 3:  # ORDER BY revenue desc, o_orderdate: ties beyond the keys are unspecified
+                same = [(r["agg0"], r["o_orderdate"]) for r in a] == [(r["agg0"], r["o_orderdate"]) for r in b]
+            else:
+                same = a == b
+            print(f"[dist-check] Q{q}: {'OK' if same else 'MISMATCH'} ({len(a)} rows, world={world}, backend={backend})", flush=True)
+            if not same:
+                print(a[:3], b[:3], flush=True)
+            ok = ok and same
+    flag = torch.tensor([1 if ok else 0])
+    dist.broadcast(flag, 0)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag.item()) else 1)
+
+
+if __name__ == "__main__":
+    main()
