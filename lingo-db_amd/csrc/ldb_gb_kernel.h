@@ -14,6 +14,14 @@
 #include "ldb_keys.h"
 
 #define GB_BLOCK 256
+// rows per thread per loop iteration: the specialised kernel keeps only the referenced columns in
+// registers, so it can afford 4 rows in flight; the generic kernel indexes its value cache
+// dynamically and stays at 1
+#ifdef LDB_JIT_SPECIALIZED
+#define GB_ROWS 4
+#else
+#define GB_ROWS 1
+#endif
 #define GB_MAX_COLS 12
 #define GB_MAX_ACCS 20
 #define GB_MAX_CPREDS 6
@@ -310,17 +318,38 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
    const KV keys(m.keys, d->keys);
    unsigned long long* g_acc = gptr_mut<unsigned long long>(d->g_acc);
    const uint64_t g_cap = d->g_cap;
-   for (uint64_t i = blockIdx.x * (uint64_t) GB_BLOCK + threadIdx.x; i < n; i += (uint64_t) gridDim.x * GB_BLOCK) {
-      bool pass = true;
-      LDB_UNROLL
-      for (int p = 0; p < np; p++)
-         if (pass) pass = d_eval_pred(PV(m.preds[p], d->preds[p]), i);
-      if (!pass) continue;
-      uint64_t h = 0;
-      if (!m.keyless) h = d_hash_keys(keys, i);
-      RowVals rv;
-      uint32_t rvalid;
-      d_load_vals(m, d, i, rv, rvalid);
+   // GB_ROWS rows per thread per iteration: phase A issues the predicate / key / value loads of all
+   // rows (independent → memory-level parallelism, the dependent predicate chain of a selective
+   // scan overlaps across rows), phase B folds each surviving row into its group.
+   const uint64_t tid = blockIdx.x * (uint64_t) GB_BLOCK + threadIdx.x;
+   const uint64_t nthreads = (uint64_t) gridDim.x * GB_BLOCK;
+   for (uint64_t i0 = tid; i0 < n; i0 += nthreads * GB_ROWS) {
+      bool passv[GB_ROWS];
+      uint64_t hv[GB_ROWS];
+      long long rvv[GB_ROWS][GB_MAX_COLS];
+      uint32_t rvalidv[GB_ROWS];
+#pragma unroll
+      for (int u = 0; u < GB_ROWS; u++) {
+         const uint64_t i = i0 + (uint64_t) u * nthreads;
+         bool pass = i < n;
+         LDB_UNROLL
+         for (int p = 0; p < np; p++)
+            if (pass) pass = d_eval_pred(PV(m.preds[p], d->preds[p]), i);
+         passv[u] = pass;
+         hv[u] = 0;
+         rvalidv[u] = 0;
+         if (pass) {
+            if (!m.keyless) hv[u] = d_hash_keys(keys, i);
+            d_load_vals(m, d, i, rvv[u], rvalidv[u]);
+         }
+      }
+#pragma unroll
+      for (int u = 0; u < GB_ROWS; u++) {
+      if (!passv[u]) continue;
+      const uint64_t i = i0 + (uint64_t) u * nthreads;
+      const uint64_t h = hv[u];
+      const RowVals& rv = rvv[u];
+      const uint32_t rvalid = rvalidv[u];
       int32_t lslot = -1;
       if (use_lds) {
          if (m.keyless) {
@@ -356,6 +385,7 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
             Sink s{g_acc + g, g_cap};
             d_accumulate(m, d, rv, rvalid, i, s);
          }
+      }
       }
    }
    if (!use_lds) return;

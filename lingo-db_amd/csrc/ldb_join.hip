@@ -45,8 +45,10 @@ struct DJoin {
    uint32_t* out_build;
    uint64_t out_cap;
    unsigned long long* counter; // [0] = rows produced (may exceed out_cap), [1] = matches
-   uint64_t* bitmap; // SEMI / ANTI
+   uint64_t* bitmap; // SEMI / ANTI / unique-build INNER
    uint8_t* mark; // MARK
+   uint32_t* match; // unique-build path: build row (or LDB_NULL_ROW) per probe row
+   uint32_t* flags; // build: [0] |= 1 when two build rows carry the same key (or tag)
 };
 
 __device__ __forceinline__ bool d_is_int32ish(const DCol& c) {
@@ -70,6 +72,7 @@ __global__ void k_join_build(const DJoin* __restrict__ d) {
       for (;;) {
          unsigned long long old = atomicCAS((unsigned long long*) &d->slots[pos], 0ull, (unsigned long long) word);
          if (old == 0) break;
+         if (d->flags && (old >> 32) == (word >> 32)) atomicOr(&d->flags[0], 1u); // same key (KEY32) / same tag: not provably unique
          pos = (pos + 1) & mask;
       }
    }
@@ -225,6 +228,35 @@ __global__ void k_join_probe_exists(const DJoin* __restrict__ d) {
    if (lane == 0 && local) atomicAdd(&d->counter[0], local);
 }
 
+// Unique build side (primary-key joins: every TPC-H join): a probe row has at most one match, so
+// the kernel writes match[i] densely (coalesced) plus a ballot bitmap, and the pairs are produced
+// by the ordered bitmap expansion — no atomics on an output cursor, deterministic ascending order.
+__global__ void k_join_probe_unique(const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows;
+   const uint64_t n_words = (n + 63) / 64;
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+   unsigned long long local = 0;
+   for (uint64_t w = wave; w < n_words; w += n_waves) {
+      uint64_t i = w * 64 + lane;
+      uint32_t brow = LDB_NULL_ROW;
+      if (i < n) {
+         d_probe_row(d, i, [&](uint32_t b) {
+            brow = b;
+            return false;
+         });
+         d->match[i] = brow;
+      }
+      uint64_t m = __ballot(brow != LDB_NULL_ROW);
+      if (lane == 0) {
+         if (d->bitmap) d->bitmap[w] = m;
+         local += (unsigned long long) __popcll(m);
+      }
+   }
+   if (lane == 0 && local) atomicAdd(&d->counter[0], local);
+}
+
 // bitmap → ascending row ids (single wave per 64-bit word, block prefix via global scan of word popcounts)
 __global__ void k_word_pop(const uint64_t* __restrict__ bitmap, uint32_t* __restrict__ pop, uint64_t n_words) {
    for (uint64_t w = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; w < n_words; w += (uint64_t) gridDim.x * blockDim.x) pop[w] = (uint32_t) __popcll(bitmap[w]);
@@ -239,6 +271,9 @@ __global__ void k_bitmap_expand(const uint64_t* __restrict__ bitmap, const uint3
    }
 }
 
+__global__ void k_iota_u32j(uint32_t* out, uint64_t n) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = (uint32_t) i;
+}
 // out[j] = ids[sel[j]] with LDB_NULL_ROW passthrough
 __global__ void k_compose_null(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ sel, uint32_t* __restrict__ out, uint64_t n) {
    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
@@ -275,11 +310,21 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
    h->cap = ht->cap;
    h->slots = ht->slots;
    h->key32 = ht->key32;
+   uint32_t* dflags = (uint32_t*) (ctx->d_scratch + 24);
+   if (build_unique) {
+      LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
+      h->flags = dflags;
+   }
    DJoin* d;
    LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
    if (build->n_rows) { LdbProf prof_(ctx, "k_join_build"); hipLaunchKernelGGL(k_join_build, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d); }
    LDB_HIP(hipGetLastError());
    ldb_dev_free(ctx, d);
+   if (build_unique) { // the caller's promise is verified: duplicates fall back to the general probe
+      uint64_t f = 0;
+      LDB_TRY(ldb_read_u64(ctx, dflags, &f));
+      if (f & 1) ht->unique = 0;
+   }
    *out = ht.release();
    return LDB_OK;
 }
@@ -403,10 +448,50 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
       return ldb_rel_select(ctx, probe, sel, (int64_t) total, out);
    }
 
-   // pair-producing kinds: optimistic capacity, exact retry on overflow
-   uint64_t out_cap = std::max<uint64_t>(1024, (uint64_t) n);
    uint32_t *op = nullptr, *ob = nullptr;
    uint64_t produced = 0;
+   if (ht->unique) {
+      // at most one match per probe row: dense match vector + ordered bitmap compaction
+      const int64_t n_words = (n + 63) / 64;
+      uint32_t* match;
+      uint64_t* bitmap = nullptr;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &match, 4 * (size_t) (n ? n : 1)));
+      if (kind == LDB_JOIN_INNER) LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmap, 8 * (size_t) (n_words ? n_words : 1)));
+      h->match = match;
+      h->bitmap = bitmap;
+      LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
+      DJoin* d;
+      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+      if (n) { LdbProf prof_(ctx, "k_join_probe_unique"); hipLaunchKernelGGL(k_join_probe_unique, dim3(grid), dim3(256), 0, ctx->stream, d); }
+      LDB_HIP(hipGetLastError());
+      ldb_dev_free(ctx, d);
+      if (kind == LDB_JOIN_INNER) {
+         LDB_TRY(ldb_read_u64(ctx, counter, &produced));
+         uint32_t *pop, *off;
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) (n_words ? n_words : 1)));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) (n_words ? n_words : 1)));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &op, 4 * (size_t) (produced ? produced : 1)));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &ob, 4 * (size_t) (produced ? produced : 1)));
+         if (n_words && produced) {
+            hipLaunchKernelGGL(k_word_pop, dim3(ldb_grid_for(ctx, n_words, 256, 8)), dim3(256), 0, ctx->stream, bitmap, pop, (uint64_t) n_words);
+            LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, n_words, nullptr));
+            hipLaunchKernelGGL(k_bitmap_expand, dim3(ldb_grid_for(ctx, n_words * 64, 256, 8)), dim3(256), 0, ctx->stream, bitmap, off, op, (uint64_t) n_words);
+            hipLaunchKernelGGL(k_compose_null, dim3(ldb_grid_for(ctx, (int64_t) produced, 256, 8)), dim3(256), 0, ctx->stream, (const uint32_t*) match, (const uint32_t*) op, ob, produced);
+         }
+         LDB_HIP(hipGetLastError());
+         ldb_dev_free(ctx, pop);
+         ldb_dev_free(ctx, off);
+         ldb_dev_free(ctx, bitmap);
+         ldb_dev_free(ctx, match);
+      } else { // LEFT_OUTER / SINGLE: exactly one output row per probe row
+         produced = (uint64_t) n;
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &op, 4 * (size_t) (n ? n : 1)));
+         if (n) hipLaunchKernelGGL(k_iota_u32j, dim3(grid), dim3(256), 0, ctx->stream, op, (uint64_t) n);
+         ob = match;
+      }
+   } else {
+   // pair-producing kinds: optimistic capacity, exact retry on overflow
+   uint64_t out_cap = std::max<uint64_t>(1024, (uint64_t) n);
    for (int attempt = 0; attempt < 2; attempt++) {
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &op, 4 * (size_t) out_cap));
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &ob, 4 * (size_t) out_cap));
@@ -425,6 +510,7 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
       ldb_dev_free(ctx, ob);
       if (produced >= (uint64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: %llu result rows exceed uint32 row ids", (unsigned long long) produced);
       out_cap = produced;
+   }
    }
    // result relation: probe sides composed with op, build sides composed with ob
    ldb_rel* r = ldb_rel_new(ctx);

@@ -38,12 +38,22 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_bitmap(const DScan* __restr
    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
    const uint64_t word0 = (uint64_t) blockIdx.x * SCAN_WORDS_PER_BLOCK;
    uint32_t cnt = 0;
-   for (uint32_t w = wave; w < SCAN_WORDS_PER_BLOCK; w += SCAN_BLOCK / LDB_WAVE) {
-      uint64_t i = (word0 + w) * 64 + lane;
-      bool pass = i < n && d_eval_conj(d, i);
-      uint64_t m = __ballot(pass);
-      if (lane == 0 && (word0 + w) * 64 < n) bitmap[word0 + w] = m;
-      cnt += (uint32_t) __popcll(m);
+   // 4 bitmap words (256 rows) per wave iteration: the four rows' column loads are independent and
+   // issue back to back before the first ballot (memory-level parallelism for an HBM-bound scan)
+   constexpr uint32_t WPW = SCAN_BLOCK / LDB_WAVE; // waves per block
+   for (uint32_t w = wave; w < SCAN_WORDS_PER_BLOCK; w += 4 * WPW) {
+      bool pass[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         uint64_t i = (word0 + w + u * WPW) * 64 + lane;
+         pass[u] = i < n && d_eval_conj(d, i);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         uint64_t m = __ballot(pass[u]);
+         if (lane == 0 && (word0 + w + u * WPW) * 64 < n) bitmap[word0 + w + u * WPW] = m;
+         cnt += (uint32_t) __popcll(m);
+      }
    }
    if (lane == 0) s_cnt[wave] = cnt;
    __syncthreads();
