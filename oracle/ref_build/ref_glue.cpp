@@ -1,0 +1,292 @@
+// ref_glue.cpp — C entry points over the REFERENCE'S OWN runtime objects (compiled from
+// /root/reference by build_ref.sh into oracle/_ref/libldb_ref.so).  TEST INFRASTRUCTURE: used to
+// validate the C restatement in oracle/ldb_oracle.c against the real implementation where the
+// reference compiles offline:
+//   * dbHashApplyColumn            src/runtime/Hash.cpp           (runtime twin of the compiled db.hash)
+//   * Restrictions::create/applyFilters + Filter impls   src/runtime/storage/Restrictions.cpp
+//   * HashIndexedView::build + tag helpers + bloomMasks  src/runtime/LazyJoinHashtable.cpp, helpers.{h,cpp}
+//   * PreAggregationHashtableFragment::insert + PreAggregationHashtable::merge   src/runtime/PreAggregationHashtable.cpp
+//   * GrowingBuffer / FlexibleBuffer / ThreadLocal / ExecutionContext            src/runtime/*.cpp
+// The JIT-generated per-tuple loops (scan callback, probe loop, fragment lookup) have no C++ source
+// in the reference; they are restated HERE following the lowerings cited at each loop, around the
+// real data structures.  Nothing from this file is shipped or linked into the product.
+#include <mutex>
+
+#include "lingodb/runtime/ArrowView.h"
+#include "lingodb/runtime/ExecutionContext.h"
+#include "lingodb/runtime/GrowingBuffer.h"
+#include "lingodb/runtime/Hash.h"
+#include "lingodb/runtime/LazyJoinHashtable.h"
+#include "lingodb/runtime/PreAggregationHashtable.h"
+#include "lingodb/runtime/ThreadLocal.h"
+#include "lingodb/runtime/helpers.h"
+#include "lingodb/runtime/storage/Restrictions.h"
+#include "lingodb/scheduler/Scheduler.h"
+#include "lingodb/scheduler/Tasks.h"
+
+#include <arrow/api.h>
+#include <arrow/c/bridge.h>
+
+#include <atomic>
+#include <cstring>
+#include <functional>
+
+using namespace lingodb;
+
+namespace {
+// ExecutionContext only stores the Session reference; a session is never touched on this path.
+alignas(64) char g_fakeSession[4096];
+struct CtxScope {
+   std::unique_ptr<scheduler::SchedulerHandle> handle;
+   std::unique_ptr<runtime::ExecutionContext> ctx;
+   explicit CtxScope(int threads) {
+      handle = scheduler::startScheduler((size_t) threads);
+      ctx = std::make_unique<runtime::ExecutionContext>(*reinterpret_cast<runtime::Session*>(g_fakeSession));
+      runtime::setCurrentExecutionContext(ctx.get());
+   }
+   ~CtxScope() {
+      ctx.reset();
+      runtime::setCurrentExecutionContext(nullptr);
+   }
+};
+
+// morsel task: units of `unit` rows handed out by an atomic cursor
+class RangeTask : public scheduler::TaskWithImplicitContext {
+   std::atomic<size_t> next{0};
+   size_t n, unit;
+   std::function<void(size_t, size_t, size_t)> fn; // (begin, end, worker)
+   std::vector<size_t> resv;
+
+   public:
+   RangeTask(size_t n, size_t unit, std::function<void(size_t, size_t, size_t)> fn) : n(n), unit(unit), fn(std::move(fn)), resv(scheduler::getNumWorkers(), 0) {}
+   bool allocateWork() override {
+      size_t b = next.fetch_add(unit);
+      if (b >= n) {
+         workExhausted.store(true);
+         return false;
+      }
+      resv[scheduler::currentWorkerId()] = b;
+      return true;
+   }
+   void performWork() override {
+      size_t b = resv[scheduler::currentWorkerId()];
+      fn(b, std::min(n, b + unit), scheduler::currentWorkerId());
+   }
+};
+
+// TableChunk's flattening of one Arrow column into an ArrayView (LingoDBTable.cpp:200-225)
+struct ColumnView {
+   runtime::ArrayView view;
+   const void* bufs[3];
+};
+void makeView(const arrow::Array& arr, ColumnView& cv) {
+   auto data = arr.data();
+   cv.view.length = data->length;
+   cv.view.nullCount = data->null_count;
+   cv.view.offset = data->offset;
+   cv.view.nBuffers = (int64_t) data->buffers.size();
+   cv.view.nChildren = 0;
+   cv.view.children = nullptr;
+   for (size_t b = 0; b < 3; b++) cv.bufs[b] = b < data->buffers.size() && data->buffers[b] ? data->buffers[b]->data() : nullptr;
+   if (!cv.bufs[0]) cv.bufs[0] = runtime::ArrayView::validData.data(); // shared all-valid bitmap (:213-218)
+   cv.view.buffers = cv.bufs;
+}
+} // namespace
+
+extern "C" {
+
+// ---- db.hash twin: fold one Arrow column into running[] (Hash.cpp:58-239)
+int32_t ref_hash_column(struct ArrowSchema* schema, struct ArrowArray* array, uint64_t* running, int64_t n) {
+   auto res = arrow::ImportArray(array, schema);
+   if (!res.ok()) return -1;
+   std::vector<uint64_t> r(running, running + n);
+   runtime::dbHashApplyColumn(r, **res);
+   std::memcpy(running, r.data(), sizeof(uint64_t) * (size_t) n);
+   return 0;
+}
+
+uint16_t ref_bloom_mask(uint32_t idx) { return runtime::bloomMasks[idx & 2047]; }
+
+// ---- pushed-down filters on a record batch (Restrictions.cpp) driven by the scan unit loop of
+// ScanBatchesTask::unitRun (LingoDBTable.cpp:382-407).  Filter constants: kind 0 = string,
+// 1 = int64, 2 = double; IN lists as arrays.
+struct RefFilter {
+   const char* column;
+   int32_t op; // lingodb::runtime::FilterOp
+   int32_t kind;
+   const char* sval;
+   int64_t ival;
+   double dval;
+   int32_t n_in;
+   const char* const* in_s;
+   const int64_t* in_i;
+};
+int64_t ref_scan_filter(struct ArrowSchema* schema, struct ArrowArray* batch, const RefFilter* filters, int32_t n_filters, uint32_t* out_rows, int32_t threads) {
+   auto rb = arrow::ImportRecordBatch(batch, schema);
+   if (!rb.ok()) return -1;
+   auto& table = **rb;
+   std::vector<runtime::FilterDescription> descs;
+   for (int32_t f = 0; f < n_filters; f++) {
+      runtime::FilterDescription d{};
+      d.columnName = filters[f].column;
+      d.columnId = 0;
+      d.op = (runtime::FilterOp) filters[f].op;
+      if (d.op == runtime::FilterOp::IN) {
+         if (filters[f].kind == 0) {
+            std::vector<std::string> v;
+            for (int k = 0; k < filters[f].n_in; k++) v.emplace_back(filters[f].in_s[k]);
+            d.values = v;
+         } else {
+            std::vector<int64_t> v(filters[f].in_i, filters[f].in_i + filters[f].n_in);
+            d.values = v;
+         }
+      } else if (filters[f].kind == 0) {
+         d.value = std::string(filters[f].sval ? filters[f].sval : "");
+      } else if (filters[f].kind == 1) {
+         d.value = filters[f].ival;
+      } else {
+         d.value = filters[f].dval;
+      }
+      descs.push_back(d);
+   }
+   std::unique_ptr<runtime::Restrictions> restrictions;
+   try {
+      restrictions = runtime::Restrictions::create(descs, *table.schema());
+   } catch (std::exception&) { return -2; }
+   std::vector<ColumnView> views((size_t) table.num_columns());
+   for (int c = 0; c < table.num_columns(); c++) makeView(*table.column(c), views[(size_t) c]);
+   const size_t n = (size_t) table.num_rows();
+   const size_t unit = 20000; // splitSize, LingoDBTable.cpp:364
+   std::vector<uint32_t> staged(n ? n : 1);
+   std::vector<size_t> counts((n + unit - 1) / unit + 1, 0);
+   CtxScope scope(threads);
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>(n, unit, [&](size_t b, size_t e, size_t) {
+      uint16_t sv1[65536], sv2[65536];
+      auto [len, sel] = restrictions->applyFilters(b, e - b, sv1, sv2, [&](size_t colId) { return &views[colId].view; });
+      for (size_t i = 0; i < len; i++) staged[b + i] = (uint32_t) (b + sel[i]);
+      counts[b / unit] = len;
+   }));
+   int64_t total = 0;
+   for (size_t u = 0; u * unit < n; u++) {
+      if (out_rows) std::memcpy(out_rows + total, staged.data() + u * unit, sizeof(uint32_t) * counts[u]);
+      total += (int64_t) counts[u];
+   }
+   return total;
+}
+
+// ---- hash join: real GrowingBuffer + HashIndexedView::build, probe loop restated from
+// LookupHashIndexedViewLowering / ScanListLowering (SubOpToControlFlow.cpp:2558-2586, 2254-2313).
+// Build rows: {next, hash, key:int64, row:uint64} (MultiMapAsHashIndexedView layout,
+// SpecializeSubOpPass.cpp:70-84).  Single int64 key → no hash compare (:110-118).
+struct JoinEntry {
+   JoinEntry* next;
+   uint64_t hash;
+   int64_t key;
+   uint64_t row;
+};
+struct ViewLayout { // what generated code reads: {Entry** ht; size_t mask} (LazyJoinHashtable.h:13-14)
+   JoinEntry** ht;
+   size_t mask;
+};
+int64_t ref_join_int64(const int64_t* bkeys, const uint64_t* bhash, int64_t nb, const int64_t* pkeys, const uint64_t* phash, int64_t np, uint32_t* out_probe,
+                       uint32_t* out_build, int64_t cap, int32_t threads) {
+   CtxScope scope(threads);
+   // build pipeline: thread-local GrowingBuffers, merged, then indexed
+   auto* tl = runtime::GrowingBuffer::createThreadLocal(sizeof(JoinEntry));
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>((size_t) nb, 20000, [&](size_t b, size_t e, size_t) {
+      auto* buf = reinterpret_cast<runtime::GrowingBuffer*>(tl->getLocal());
+      for (size_t i = b; i < e; i++) {
+         auto* en = reinterpret_cast<JoinEntry*>(buf->insert());
+         en->next = nullptr;
+         en->hash = bhash[i];
+         en->key = bkeys[i];
+         en->row = i;
+      }
+   }));
+   auto* merged = runtime::GrowingBuffer::merge(tl);
+   auto* view = runtime::HashIndexedView::build(merged);
+   auto* lay = reinterpret_cast<ViewLayout*>(view);
+   std::atomic<int64_t> cursor{0};
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>((size_t) np, 20000, [&](size_t b, size_t e, size_t) {
+      for (size_t i = b; i < e; i++) {
+         uint64_t h = phash[i];
+         JoinEntry* slot = lay->ht[h & lay->mask];
+         JoinEntry* cur = runtime::matchesTag(slot, h) ? runtime::untag(slot) : nullptr; // = filterTagged (helpers.h:338-342)
+         for (; cur; cur = cur->next) {
+            if (cur->key == pkeys[i]) {
+               int64_t idx = cursor.fetch_add(1);
+               if (idx < cap) {
+                  out_probe[idx] = (uint32_t) i;
+                  out_build[idx] = (uint32_t) cur->row;
+               }
+            }
+         }
+      }
+   }));
+   return cursor.load();
+}
+
+// ---- group-by: real PreAggregationHashtableFragment (per worker via ThreadLocal) + merge.
+// Per-tuple code restated from LookupPreAggrHtFragment (SubOpToControlFlow.cpp:3065-3157):
+// slot = ht[(hash >> 6) & 1023]; hit = hash equal && keys equal → reduce; miss → insert + init.
+// Entry content: {key:int64, sum:int64, count:int64}.
+struct AggContent {
+   int64_t key, sum, count;
+};
+static bool aggEq(uint8_t* a, uint8_t* b) { return reinterpret_cast<AggContent*>(a)->key == reinterpret_cast<AggContent*>(b)->key; }
+static void aggCombine(uint8_t* dst, uint8_t* src) {
+   reinterpret_cast<AggContent*>(dst)->sum += reinterpret_cast<AggContent*>(src)->sum;
+   reinterpret_cast<AggContent*>(dst)->count += reinterpret_cast<AggContent*>(src)->count;
+}
+int64_t ref_groupby_int64(const int64_t* keys, const uint64_t* hashes, const int64_t* vals, int64_t n, int64_t* out_keys, int64_t* out_sums, int64_t* out_counts,
+                          int64_t cap, int32_t threads) {
+   using Fragment = runtime::PreAggregationHashtableFragment;
+   CtxScope scope(threads);
+   const size_t typeSize = sizeof(Fragment::Entry) + sizeof(AggContent);
+   auto* tl = runtime::ThreadLocal::create([](uint8_t* arg) -> uint8_t* { return reinterpret_cast<uint8_t*>(Fragment::create(*reinterpret_cast<size_t*>(arg), false)); },
+                                           reinterpret_cast<uint8_t*>(const_cast<size_t*>(&typeSize)));
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>((size_t) n, 20000, [&](size_t b, size_t e, size_t) {
+      auto* frag = reinterpret_cast<Fragment*>(tl->getLocal());
+      for (size_t i = b; i < e; i++) {
+         uint64_t h = hashes[i];
+         Fragment::Entry* en = frag->ht[(h >> 6) & (Fragment::hashtableSize - 1)];
+         if (!(en && en->hashValue == h && reinterpret_cast<AggContent*>(en->content)->key == keys[i])) {
+            en = frag->insert(h);
+            auto* c = reinterpret_cast<AggContent*>(en->content);
+            c->key = keys[i];
+            c->sum = 0;
+            c->count = 0;
+         }
+         auto* c = reinterpret_cast<AggContent*>(en->content);
+         c->sum += vals[i];
+         c->count += 1;
+      }
+   }));
+   auto* merged = runtime::PreAggregationHashtable::merge(tl, aggEq, aggCombine);
+   // scan of the merged table (ScanPreAggrHtLowering, :2110): the buffer holds entry pointers
+   struct Out {
+      int64_t *keys, *sums, *counts;
+      int64_t n, cap;
+   } o{out_keys, out_sums, out_counts, 0, cap};
+   auto* it = merged->createIterator();
+   runtime::BufferIterator::iterate(
+      it, false,
+      [](runtime::Buffer buf, void* arg) {
+         auto* st = reinterpret_cast<Out*>(arg);
+         auto** entries = reinterpret_cast<Fragment::Entry**>(buf.ptr);
+         size_t cnt = buf.numElements / sizeof(Fragment::Entry*); // iterator buffers carry a byte length
+         for (size_t k = 0; k < cnt; k++) {
+            auto* c = reinterpret_cast<AggContent*>(entries[k]->content);
+            if (st->n < st->cap) {
+               st->keys[st->n] = c->key;
+               st->sums[st->n] = c->sum;
+               st->counts[st->n] = c->count;
+            }
+            st->n++;
+         }
+      },
+      &o);
+   return o.n;
+}
+
+} // extern "C"
