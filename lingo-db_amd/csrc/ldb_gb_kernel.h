@@ -294,6 +294,25 @@ __device__ __forceinline__ uint64_t d_global_slot(const DGroupBy& m, const DGrou
    return ~0ull;
 }
 
+// find-or-insert the group of logical row i in replica `rep` of the workgroup's LDS table;
+// returns the slot or -1 (table region full / long probe run → caller uses the global table)
+__device__ __forceinline__ int32_t d_lds_slot(const DGroupBy& m, KV keys, unsigned long long* l_keys, uint32_t S, uint32_t R, uint32_t rep, uint64_t h, uint64_t i) {
+   if (m.keyless) return 0;
+   const unsigned long long mine = (h & 0xFFFFFFFF00000000ull) | (unsigned long long) ((uint32_t) i + 1u);
+   uint32_t pos = (uint32_t) (h >> 6) & (S - 1);
+   for (uint32_t step = 0; step < S && step < 16; step++) {
+      unsigned long long w = l_keys[pos * R + rep];
+      if (w == 0) {
+         unsigned long long old = atomicCAS(&l_keys[pos * R + rep], 0ull, mine);
+         if (old == 0) return (int32_t) pos;
+         w = old;
+      }
+      if ((w >> 32) == (h >> 32) && d_keys_equal(keys, (uint64_t) ((uint32_t) w - 1u), keys, i, true)) return (int32_t) pos;
+      pos = (pos + 1) & (S - 1);
+   }
+   return -1;
+}
+
 // the kernel body: `m` = metadata source (== *d in the generic kernel, a constexpr in a
 // specialised one), `d` = this launch's descriptor in device memory (addresses, sizes)
 __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __restrict__ d, unsigned long long* gb_lds) {
@@ -351,31 +370,7 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
       const RowVals& rv = rvv[u];
       const uint32_t rvalid = rvalidv[u];
       int32_t lslot = -1;
-      if (use_lds) {
-         if (m.keyless) {
-            lslot = 0;
-         } else {
-            const unsigned long long mine = (h & 0xFFFFFFFF00000000ull) | (unsigned long long) ((uint32_t) i + 1u);
-            uint32_t pos = (uint32_t) (h >> 6) & (S - 1);
-            for (uint32_t step = 0; step < S; step++) {
-               unsigned long long w = l_keys[pos * R + rep];
-               if (w == 0) {
-                  unsigned long long old = atomicCAS(&l_keys[pos * R + rep], 0ull, mine);
-                  if (old == 0) {
-                     lslot = (int32_t) pos;
-                     break;
-                  }
-                  w = old;
-               }
-               if ((w >> 32) == (h >> 32) && d_keys_equal(keys, (uint64_t) ((uint32_t) w - 1u), keys, i, true)) {
-                  lslot = (int32_t) pos;
-                  break;
-               }
-               pos = (pos + 1) & (S - 1);
-               if (step >= 15) break; // long probe sequences: send the row to the global table instead
-            }
-         }
-      }
+      if (use_lds) lslot = d_lds_slot(m, keys, l_keys, S, R, rep, h, i);
       if (lslot >= 0) {
          Sink s{l_acc + (uint32_t) lslot * R + rep, SR};
          d_accumulate(m, d, rv, rvalid, i, s);
@@ -390,7 +385,27 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
    }
    if (!use_lds) return;
    __syncthreads();
-   // flush: every occupied (slot, replica) → global table
+   // Fold the replicas into replica 0 inside the workgroup first (LDS atomics): a global flush of
+   // every replica would put R x #workgroups same-address atomics on each hot group's global
+   // slot — for a key-less SUM (Q6) that serialisation alone cost more than the scan.
+   if (R > 1) {
+      for (uint32_t k = threadIdx.x; k < SR; k += GB_BLOCK) {
+         const uint32_t r = k & (R - 1);
+         if (r == 0) continue;
+         unsigned long long w = l_keys[k];
+         if (w == 0) continue;
+         const uint64_t i = (uint64_t) ((uint32_t) w - 1u);
+         const uint64_t h = m.keyless ? 0 : d_hash_keys(keys, i);
+         int32_t t = d_lds_slot(m, keys, l_keys, S, R, 0, h, i);
+         if (t < 0) continue; // replica 0 full: this entry goes to the global table below
+         Sink src{l_acc + k, SR};
+         Sink dst{l_acc + (uint32_t) t * R, SR};
+         d_combine(m, src, dst);
+         l_keys[k] = 0;
+      }
+      __syncthreads();
+   }
+   // flush: every remaining occupied (slot, replica) → global table
    for (uint32_t k = threadIdx.x; k < SR; k += GB_BLOCK) {
       unsigned long long w = l_keys[k];
       if (w == 0) continue;

@@ -1,8 +1,8 @@
 // ldb_jit.h — run-time specialisation of pipeline kernels with hiprtc.
 // The reference compiles every query pipeline with LLVM (src/execution/LLVMBackends.cpp:219-406);
-// the MI355X runtime keeps ONE hand-written kernel source per operator and, for large inputs,
-// re-compiles it with the launch descriptor's metadata as a compile-time constant so the
-// compiler folds the type/op dispatch and unrolls the descriptor loops.
+// the MI355X runtime keeps ONE hand-written kernel source per operator (ldb_*_kernel.h) and, for
+// large inputs, re-compiles it with the launch descriptor's metadata as a compile-time constant so
+// the compiler folds the type/op dispatch and unrolls the descriptor loops.
 #pragma once
 #include "ldb_internal.h"
 #include "ldb_gb_kernel.h"
@@ -11,9 +11,24 @@
 // (env LDB_JIT=0 disables, LDB_JIT_MIN_ROWS overrides the default threshold of 4 M rows)
 bool ldb_jit_wanted(int64_t n_rows);
 
-// Specialised group-by kernel for the metadata of `h` (addresses / sizes are NOT baked in).
-// Returns nullptr (and records the reason in *why) when hiprtc is unavailable or compilation
-// fails — the caller then launches the generic ahead-of-time kernel.
+// Generic entry: compile (or fetch from the cache) a module made of
+//    #include "<header>";  constexpr <struct_name> LDB_META = <meta bytes>;  <kernels_src>
+// and return `kernel_name` from it.  `meta` must be pointer-free metadata (addresses stripped with
+// the helpers below).  Returns nullptr (reason in *why) when hiprtc is unavailable or the
+// compilation fails — callers then launch their generic ahead-of-time kernel.
+hipFunction_t ldb_jit_kernel(const char* header, const char* struct_name, const char* kernels_src, const char* kernel_name, const void* meta, size_t meta_bytes,
+                             std::string* why);
+// compile only (no device needed, nothing cached): used by the device-less build check
+bool ldb_jit_compile_only(const char* header, const char* struct_name, const char* kernels_src, const void* meta, size_t meta_bytes, std::string* log);
+// per-operator compile checks with a representative descriptor (ldb_scan.hip, ldb_join.hip)
+bool ldb_scan_jit_check(std::string* log);
+bool ldb_join_jit_check(std::string* log);
+// addresses → presence flags (0/1); what remains of a column / predicate / key set is metadata
+void ldb_jit_strip_col(DCol& c);
+void ldb_jit_strip_pred(DPred& p);
+void ldb_jit_strip_keys(DKeys& k);
+
+// specialised group-by kernel for the metadata of `h`
 hipFunction_t ldb_jit_groupby(const DGroupBy* h, std::string* why);
 
 // statistics for tests / bench: kernels compiled, cache hits, total compile milliseconds

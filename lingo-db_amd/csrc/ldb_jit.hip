@@ -17,14 +17,15 @@ static const EmbeddedHeader g_headers[] = {
 };
 static const int g_n_headers = (int) (sizeof(g_headers) / sizeof(g_headers[0]));
 
-struct JitEntry {
-   std::vector<unsigned char> key;
+struct JitModule {
+   std::string key; // header | struct | kernel source | metadata bytes
    hipModule_t module = nullptr;
-   hipFunction_t fn = nullptr;
+   std::unordered_map<std::string, hipFunction_t> fns;
+   std::vector<char> code;
    std::string error; // non-empty: compilation failed once, do not retry
 };
 static std::mutex g_mu;
-static std::unordered_map<uint64_t, std::vector<JitEntry>> g_cache;
+static std::unordered_map<uint64_t, std::vector<std::unique_ptr<JitModule>>> g_cache;
 static int64_t g_compiled = 0, g_hits = 0;
 static double g_compile_ms = 0;
 
@@ -39,8 +40,7 @@ bool ldb_jit_wanted(int64_t n_rows) {
    return enabled && n_rows >= min_rows;
 }
 
-static uint64_t fnv1a(const unsigned char* p, size_t n) {
-   uint64_t h = 1469598103934665603ull;
+static uint64_t fnv1a(const unsigned char* p, size_t n, uint64_t h = 1469598103934665603ull) {
    for (size_t i = 0; i < n; i++) {
       h ^= p[i];
       h *= 1099511628211ull;
@@ -49,34 +49,26 @@ static uint64_t fnv1a(const unsigned char* p, size_t n) {
 }
 
 // addresses become presence flags, per-launch sizes are cleared: what remains is the metadata
-static void strip_col(DCol& c) {
+void ldb_jit_strip_col(DCol& c) {
    c.values = 0;
    c.offsets = c.offsets ? 1 : 0;
    c.validity = c.validity ? 1 : 0;
    c.rowids = c.rowids ? 1 : 0;
 }
-static void strip_pred(DPred& p) {
-   strip_col(p.col);
-   strip_col(p.rhs);
+void ldb_jit_strip_pred(DPred& p) {
+   ldb_jit_strip_col(p.col);
+   ldb_jit_strip_col(p.rhs);
 }
-static void make_meta(const DGroupBy* h, DGroupBy* m) {
-   memcpy(m, h, sizeof(DGroupBy));
-   m->n_rows = 0;
-   m->g_cap = 0;
-   m->g_keys = m->g_acc = m->g_flags = 0;
-   m->lds_slots = m->lds_reps = 0;
-   for (int k = 0; k < LDB_MAX_KEYS; k++) strip_col(m->keys.cols[k]);
-   for (int p = 0; p < LDB_MAX_PREDS; p++) strip_pred(m->preds[p]);
-   for (int p = 0; p < GB_MAX_CPREDS; p++) strip_pred(m->cpreds[p]);
-   for (int c = 0; c < GB_MAX_COLS; c++) strip_col(m->cols[c]);
-   for (int o = 0; o < GB_MAX_OUT; o++) m->outs[o].out_values = m->outs[o].out_valid = 0;
+void ldb_jit_strip_keys(DKeys& k) {
+   for (int j = 0; j < LDB_MAX_KEYS; j++) ldb_jit_strip_col(k.cols[j]);
 }
 
-static std::string build_source(const unsigned char* meta, size_t n) {
+static std::string build_source(const char* header, const char* struct_name, const char* kernels, const unsigned char* meta, size_t n) {
    std::string s;
-   s.reserve(n * 5 + 2048);
-   s += "#define LDB_JIT_SPECIALIZED 1\n#include \"ldb_gb_kernel.h\"\n";
-   s += "struct LdbMetaBytes { unsigned char b[" + std::to_string(n) + "]; };\n";
+   s.reserve(n * 5 + 4096);
+   s += "#define LDB_JIT_SPECIALIZED 1\n#include \"";
+   s += header;
+   s += "\"\nstruct LdbMetaBytes { unsigned char b[" + std::to_string(n) + "]; };\n";
    s += "static constexpr LdbMetaBytes LDB_META_BYTES = {{";
    char buf[8];
    for (size_t i = 0; i < n; i++) {
@@ -84,22 +76,25 @@ static std::string build_source(const unsigned char* meta, size_t n) {
       s += buf;
       if ((i & 63) == 63) s += "\n";
    }
-   s += "}};\n";
-   s += "__device__ static constexpr DGroupBy LDB_META = __builtin_bit_cast(DGroupBy, LDB_META_BYTES);\n";
-   s += "extern __shared__ __attribute__((aligned(16))) unsigned long long gb_lds_dyn[];\n";
-   s += "extern \"C\" __global__ __launch_bounds__(GB_BLOCK) void k_groupby_spec(const DGroupBy* __restrict__ d) { gb_body(LDB_META, d, gb_lds_dyn); }\n";
+   s += "}};\n__device__ static constexpr ";
+   s += struct_name;
+   s += " LDB_META = __builtin_bit_cast(";
+   s += struct_name;
+   s += ", LDB_META_BYTES);\n";
+   s += kernels;
    return s;
 }
 
-static bool compile(const std::string& src, JitEntry* e) {
+// compile only (no device needed); code object into *code
+static bool compile(const std::string& src, std::vector<char>* code, std::string* err) {
    std::vector<const char*> names, texts;
    for (int i = 0; i < g_n_headers; i++) {
       names.push_back(g_headers[i].name);
       texts.push_back(g_headers[i].text);
    }
    hiprtcProgram prog;
-   if (hiprtcCreateProgram(&prog, src.c_str(), "ldb_groupby_spec.hip", g_n_headers, texts.data(), names.data()) != HIPRTC_SUCCESS) {
-      e->error = "hiprtcCreateProgram failed";
+   if (hiprtcCreateProgram(&prog, src.c_str(), "ldb_spec.hip", g_n_headers, texts.data(), names.data()) != HIPRTC_SUCCESS) {
+      *err = "hiprtcCreateProgram failed";
       return false;
    }
    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics"};
@@ -109,49 +104,96 @@ static bool compile(const std::string& src, JitEntry* e) {
       hiprtcGetProgramLogSize(prog, &ls);
       std::string log(ls, '\0');
       if (ls) hiprtcGetProgramLog(prog, log.data());
-      e->error = std::string("hiprtc: ") + hiprtcGetErrorString(r) + ": " + log.substr(0, 1500);
+      *err = std::string("hiprtc: ") + hiprtcGetErrorString(r) + ": " + log.substr(0, 3000);
       hiprtcDestroyProgram(&prog);
       return false;
    }
    size_t cs = 0;
    hiprtcGetCodeSize(prog, &cs);
-   std::vector<char> code(cs);
-   hiprtcGetCode(prog, code.data());
+   code->resize(cs);
+   hiprtcGetCode(prog, code->data());
    hiprtcDestroyProgram(&prog);
-   if (hipModuleLoadData(&e->module, code.data()) != hipSuccess) {
-      e->error = "hipModuleLoadData failed for the specialised kernel";
-      return false;
+   return cs > 0;
+}
+
+bool ldb_jit_compile_only(const char* header, const char* struct_name, const char* kernels_src, const void* meta, size_t meta_bytes, std::string* log) {
+   std::vector<char> code;
+   return compile(build_source(header, struct_name, kernels_src, (const unsigned char*) meta, meta_bytes), &code, log);
+}
+
+hipFunction_t ldb_jit_kernel(const char* header, const char* struct_name, const char* kernels_src, const char* kernel_name, const void* meta, size_t meta_bytes,
+                             std::string* why) {
+   std::string key;
+   key.reserve(meta_bytes + 256);
+   key += header;
+   key += '|';
+   key += struct_name;
+   key += '|';
+   key += kernels_src;
+   key += '|';
+   key.append((const char*) meta, meta_bytes);
+   const uint64_t h = fnv1a((const unsigned char*) key.data(), key.size());
+   std::lock_guard<std::mutex> lock(g_mu);
+   auto& bucket = g_cache[h];
+   JitModule* mod = nullptr;
+   for (auto& e : bucket)
+      if (e->key == key) mod = e.get();
+   if (!mod) {
+      auto e = std::make_unique<JitModule>();
+      e->key = key;
+      auto t0 = std::chrono::steady_clock::now();
+      bool ok = compile(build_source(header, struct_name, kernels_src, (const unsigned char*) meta, meta_bytes), &e->code, &e->error);
+      g_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (ok) {
+         if (hipModuleLoadData(&e->module, e->code.data()) != hipSuccess) {
+            e->error = "hipModuleLoadData failed for the specialised kernel";
+            e->module = nullptr;
+         } else {
+            g_compiled++;
+         }
+      }
+      bucket.push_back(std::move(e));
+      mod = bucket.back().get();
+   } else if (mod->module) {
+      g_hits++;
    }
-   if (hipModuleGetFunction(&e->fn, e->module, "k_groupby_spec") != hipSuccess) {
-      e->error = "k_groupby_spec not found in the specialised module";
-      return false;
+   if (!mod->module) {
+      if (why) *why = mod->error;
+      return nullptr;
    }
-   return true;
+   auto it = mod->fns.find(kernel_name);
+   if (it != mod->fns.end()) return it->second;
+   hipFunction_t fn = nullptr;
+   if (hipModuleGetFunction(&fn, mod->module, kernel_name) != hipSuccess) {
+      if (why) *why = std::string(kernel_name) + " not found in the specialised module";
+      return nullptr;
+   }
+   mod->fns[kernel_name] = fn;
+   return fn;
+}
+
+// ---------------------------------------------------------------- group-by
+static const char* GB_SPEC_SRC =
+   "extern __shared__ __attribute__((aligned(16))) unsigned long long gb_lds_dyn[];\n"
+   "extern \"C\" __global__ __launch_bounds__(GB_BLOCK) void k_groupby_spec(const DGroupBy* __restrict__ d) { gb_body(LDB_META, d, gb_lds_dyn); }\n";
+
+static void gb_meta(const DGroupBy* h, DGroupBy* m) {
+   memcpy(m, h, sizeof(DGroupBy));
+   m->n_rows = 0;
+   m->g_cap = 0;
+   m->g_keys = m->g_acc = m->g_flags = 0;
+   m->lds_slots = m->lds_reps = 0;
+   ldb_jit_strip_keys(m->keys);
+   for (int p = 0; p < LDB_MAX_PREDS; p++) ldb_jit_strip_pred(m->preds[p]);
+   for (int p = 0; p < GB_MAX_CPREDS; p++) ldb_jit_strip_pred(m->cpreds[p]);
+   for (int c = 0; c < GB_MAX_COLS; c++) ldb_jit_strip_col(m->cols[c]);
+   for (int o = 0; o < GB_MAX_OUT; o++) m->outs[o].out_values = m->outs[o].out_valid = 0;
 }
 
 hipFunction_t ldb_jit_groupby(const DGroupBy* h, std::string* why) {
    auto meta = std::make_unique<DGroupBy>();
-   make_meta(h, meta.get());
-   const unsigned char* bytes = (const unsigned char*) meta.get();
-   const uint64_t key = fnv1a(bytes, sizeof(DGroupBy));
-   std::lock_guard<std::mutex> lock(g_mu);
-   auto& bucket = g_cache[key];
-   for (auto& e : bucket) {
-      if (e.key.size() == sizeof(DGroupBy) && !memcmp(e.key.data(), bytes, sizeof(DGroupBy))) {
-         if (e.fn) g_hits++;
-         else if (why) *why = e.error;
-         return e.fn;
-      }
-   }
-   JitEntry e;
-   e.key.assign(bytes, bytes + sizeof(DGroupBy));
-   auto t0 = std::chrono::steady_clock::now();
-   bool ok = compile(build_source(bytes, sizeof(DGroupBy)), &e);
-   g_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-   if (ok) g_compiled++;
-   else if (why) *why = e.error;
-   bucket.push_back(std::move(e));
-   return bucket.back().fn;
+   gb_meta(h, meta.get());
+   return ldb_jit_kernel("ldb_gb_kernel.h", "DGroupBy", GB_SPEC_SRC, "k_groupby_spec", meta.get(), sizeof(DGroupBy), why);
 }
 
 // Compile-only check (no device needed): specialise the group-by kernel for a TPC-H-Q1-shaped
@@ -193,39 +235,22 @@ extern "C" int32_t ldb_gpu_jit_compile_check(char* log, int32_t cap) {
    h->n_words = 4;
    h->use_lds = 1;
    auto meta = std::make_unique<DGroupBy>();
-   make_meta(h.get(), meta.get());
-   std::string src = build_source((const unsigned char*) meta.get(), sizeof(DGroupBy));
-   std::vector<const char*> names, texts;
-   for (int i = 0; i < g_n_headers; i++) {
-      names.push_back(g_headers[i].name);
-      texts.push_back(g_headers[i].text);
-   }
-   hiprtcProgram prog;
-   if (hiprtcCreateProgram(&prog, src.c_str(), "ldb_groupby_spec.hip", g_n_headers, texts.data(), names.data()) != HIPRTC_SUCCESS) {
-      if (log && cap > 0) snprintf(log, (size_t) cap, "hiprtcCreateProgram failed");
-      return LDB_ERR_HIP;
-   }
-   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics"};
-   hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
-   size_t ls = 0;
-   hiprtcGetProgramLogSize(prog, &ls);
-   std::string l(ls, '\0');
-   if (ls) hiprtcGetProgramLog(prog, l.data());
-   if (log && cap > 0) snprintf(log, (size_t) cap, "%s%s", r == HIPRTC_SUCCESS ? "" : hiprtcGetErrorString(r), l.c_str());
-   size_t cs = 0;
-   if (r == HIPRTC_SUCCESS) hiprtcGetCodeSize(prog, &cs);
-   if (cs) {
+   gb_meta(h.get(), meta.get());
+   std::vector<char> code;
+   std::string err;
+   bool ok = compile(build_source("ldb_gb_kernel.h", "DGroupBy", GB_SPEC_SRC, (const unsigned char*) meta.get(), sizeof(DGroupBy)), &code, &err);
+   if (ok) ok = ldb_scan_jit_check(&err);
+   if (ok) ok = ldb_join_jit_check(&err);
+   if (log && cap > 0) snprintf(log, (size_t) cap, "%s", err.c_str());
+   if (ok) {
       if (const char* dump = getenv("LDB_JIT_DUMP")) { // code object for llvm-objdump inspection
-         std::vector<char> code(cs);
-         hiprtcGetCode(prog, code.data());
          if (FILE* f = fopen(dump, "wb")) {
-            fwrite(code.data(), 1, cs, f);
+            fwrite(code.data(), 1, code.size(), f);
             fclose(f);
          }
       }
    }
-   hiprtcDestroyProgram(&prog);
-   return (r == HIPRTC_SUCCESS && cs > 0) ? LDB_OK : LDB_ERR_HIP;
+   return ok ? LDB_OK : LDB_ERR_HIP;
 }
 
 extern "C" int32_t ldb_gpu_jit_stats(int64_t* compiled, int64_t* cache_hits, double* compile_ms) {

@@ -1,4 +1,5 @@
-// ldb_join.hip — hash-join build and probe.
+// ldb_join.hip — hash-join build and probe: host side, AOT kernels, run-time specialisation hook.
+// Device code: ldb_join_kernel.h.
 // Replaces (reference): build-side materialisation + HashIndexedView::build
 // (src/runtime/GrowingBuffer.cpp:44, src/runtime/LazyJoinHashtable.cpp:12-34) and the generated
 // probe (LookupHashIndexedViewLowering / ScanListLowering,
@@ -13,11 +14,12 @@
 //            → tag match is verified on the build row's key columns (late materialised).
 // Capacity nextPow2(2n) (load factor <= 0.5) instead of the CPU's chained nextPow2(1.25n).
 // Duplicate build keys occupy separate slots; a probe walks until the first empty slot.
-// Output pairs are appended with wave-aggregated atomics (order unspecified, as in the reference
-// where morsels finish in any order); SEMI/ANTI results are produced in ascending probe order
-// through a ballot bitmap.
+// Unique build sides (verified while building) produce pairs through a dense match vector +
+// ordered ballot-bitmap compaction (no output-cursor atomics); duplicated build keys use
+// wave-aggregated appends; SEMI/ANTI/MARK results come out in ascending probe order.
 #include "ldb_internal.h"
-#include "ldb_keys.h"
+#include "ldb_join_kernel.h"
+#include "ldb_jit.h"
 #include <algorithm>
 #include <memory>
 
@@ -29,238 +31,66 @@ struct ldb_hashtable {
    uint64_t cap = 0;
    int32_t key32 = 0;
    int32_t unique = 0;
-   int64_t n_inserted = 0;
 };
 
-struct DJoin {
-   uint64_t n_rows; // rows of the relation the kernel iterates (build or probe)
-   uint64_t cap;
-   uint64_t* slots;
-   int32_t key32;
-   int32_t kind;
-   DKeys bkeys;
-   DKeys pkeys;
-   // outputs
-   uint32_t* out_probe;
-   uint32_t* out_build;
-   uint64_t out_cap;
-   unsigned long long* counter; // [0] = rows produced (may exceed out_cap), [1] = matches
-   uint64_t* bitmap; // SEMI / ANTI / unique-build INNER
-   uint8_t* mark; // MARK
-   uint32_t* match; // unique-build path: build row (or LDB_NULL_ROW) per probe row
-   uint32_t* flags; // build: [0] |= 1 when two build rows carry the same key (or tag)
-};
+// ---------------------------------------------------------------- ahead-of-time (generic) kernels
+__global__ void k_join_build(const DJoin* __restrict__ d) { join_build_body(*d, d); }
+__global__ void k_join_probe_pairs(const DJoin* __restrict__ d) { join_probe_pairs_body(*d, d); }
+__global__ void k_join_probe_count(const DJoin* __restrict__ d) { join_probe_count_body(*d, d); }
+__global__ void k_join_probe_exists(const DJoin* __restrict__ d) { join_probe_exists_body(*d, d); }
+__global__ void k_join_probe_unique(const DJoin* __restrict__ d) { join_probe_unique_body(*d, d); }
 
-__device__ __forceinline__ bool d_is_int32ish(const DCol& c) {
-   return c.type == LDB_T_INT32 || c.type == LDB_T_DATE32 || c.type == LDB_T_CHAR4 || c.type == LDB_T_INT16 || c.type == LDB_T_INT8;
-}
+// run-time specialised variants (hiprtc; ldb_jit.hip)
+static const char* JOIN_SPEC_SRC =
+   "extern \"C\" __global__ void k_join_build_spec(const DJoin* __restrict__ d) { join_build_body(LDB_META, d); }\n"
+   "extern \"C\" __global__ void k_join_probe_pairs_spec(const DJoin* __restrict__ d) { join_probe_pairs_body(LDB_META, d); }\n"
+   "extern \"C\" __global__ void k_join_probe_count_spec(const DJoin* __restrict__ d) { join_probe_count_body(LDB_META, d); }\n"
+   "extern \"C\" __global__ void k_join_probe_exists_spec(const DJoin* __restrict__ d) { join_probe_exists_body(LDB_META, d); }\n"
+   "extern \"C\" __global__ void k_join_probe_unique_spec(const DJoin* __restrict__ d) { join_probe_unique_body(LDB_META, d); }\n";
 
-__global__ void k_join_build(const DJoin* __restrict__ d) {
-   const uint64_t n = d->n_rows, mask = d->cap - 1;
-   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-      bool nul;
-      uint64_t h = d_hash_keys(d->bkeys, i, &nul);
-      if (nul) continue; // a NULL key can never be matched (eq on NULL is false)
-      uint64_t word;
-      if (d->key32) {
-         const DCol& c = d->bkeys.cols[0];
-         word = ((uint64_t) (uint32_t) d_load_i64(c, d_phys_row(c, i)) << 32) | (uint64_t) ((uint32_t) i + 1u);
-      } else {
-         word = (h & 0xFFFFFFFF00000000ull) | (uint64_t) ((uint32_t) i + 1u);
-      }
-      uint64_t pos = h & mask;
-      for (;;) {
-         unsigned long long old = atomicCAS((unsigned long long*) &d->slots[pos], 0ull, (unsigned long long) word);
-         if (old == 0) break;
-         if (d->flags && (old >> 32) == (word >> 32)) atomicOr(&d->flags[0], 1u); // same key (KEY32) / same tag: not provably unique
-         pos = (pos + 1) & mask;
-      }
+typedef void (*join_kernel_t)(const DJoin*);
+// launch `generic` or its specialised twin `<name>_spec` on the ctx stream
+static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int grid, const char* prof_name, const char* spec_name, join_kernel_t generic) {
+   hipFunction_t spec = nullptr;
+   if (ldb_jit_wanted((int64_t) h->n_rows)) {
+      auto meta = std::make_unique<DJoin>();
+      memcpy(meta.get(), h, sizeof(DJoin));
+      meta->n_rows = meta->cap = meta->slots = meta->out_probe = meta->out_build = meta->out_cap = 0;
+      meta->counter = meta->bitmap = meta->mark = meta->match = meta->flags = 0;
+      ldb_jit_strip_keys(meta->bkeys);
+      ldb_jit_strip_keys(meta->pkeys);
+      std::string why;
+      spec = ldb_jit_kernel("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, spec_name, meta.get(), sizeof(DJoin), &why);
    }
-}
-
-// One probe row → visits its slot run.  EMIT is called for every match with the build row.
-template <typename EMIT>
-__device__ __forceinline__ uint32_t d_probe_row(const DJoin* __restrict__ d, uint64_t i, EMIT emit) {
-   bool nul;
-   uint64_t h = d_hash_keys(d->pkeys, i, &nul);
-   if (nul) return 0;
-   const uint64_t mask = d->cap - 1;
-   uint64_t pos = h & mask;
-   uint32_t matches = 0;
-   if (d->key32) {
-      const DCol& c = d->pkeys.cols[0];
-      int64_t kv = d_load_i64(c, d_phys_row(c, i));
-      if (kv != (int64_t) (int32_t) kv) return 0; // wider probe value can equal no 32-bit build key
-      const uint32_t key = (uint32_t) kv;
-      for (;;) {
-         uint64_t w = d->slots[pos];
-         if (w == 0) break;
-         if ((uint32_t) (w >> 32) == key) {
-            matches++;
-            if (!emit((uint32_t) w - 1u)) break;
-         }
-         pos = (pos + 1) & mask;
-      }
+   LdbProf prof_(ctx, prof_name);
+   if (spec) {
+      void* params[] = {(void*) &d};
+      LDB_HIP(hipModuleLaunchKernel(spec, (unsigned) grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
    } else {
-      for (;;) {
-         uint64_t w = d->slots[pos];
-         if (w == 0) break;
-         if ((w >> 32) == (h >> 32) && d_keys_equal(d->bkeys, (uint64_t) ((uint32_t) w - 1u), d->pkeys, i, false)) {
-            matches++;
-            if (!emit((uint32_t) w - 1u)) break;
-         }
-         pos = (pos + 1) & mask;
-      }
+      hipLaunchKernelGGL(generic, dim3(grid), dim3(256), 0, ctx->stream, d);
    }
-   return matches;
+   LDB_HIP(hipGetLastError());
+   return LDB_OK;
 }
 
-// INNER / LEFT_OUTER / SINGLE: append (probe, build) pairs
-// Each lane walks its slot run until its NEXT match, then the wave appends all pending matches
-// with ONE atomicAdd (ballot → popcount → mbcnt rank): 64x fewer atomics on the output cursor
-// than one per pair, and each wave's pairs land contiguously (coalesced stores).
-__global__ void k_join_probe_pairs(const DJoin* __restrict__ d) {
-   const uint64_t n = d->n_rows;
-   const int kind = d->kind;
-   const uint64_t mask = d->cap - 1;
-   const bool key32 = d->key32 != 0;
-   const uint32_t lane = threadIdx.x & 63;
-   unsigned long long local_matches = 0;
-   const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
-   // wave-uniform trip count so that every lane reaches the ballots
-   for (uint64_t base = blockIdx.x * (uint64_t) blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
-      const uint64_t i = base + lane;
-      bool done = i >= n;
-      uint64_t h = 0, pos = 0;
-      uint32_t key = 0, matches = 0;
-      if (!done) {
-         bool nul;
-         h = d_hash_keys(d->pkeys, i, &nul);
-         pos = h & mask;
-         if (key32) {
-            const DCol& c = d->pkeys.cols[0];
-            int64_t kv = d_load_i64(c, d_phys_row(c, i));
-            if (kv != (int64_t) (int32_t) kv) nul = true; // can equal no 32-bit build key
-            key = (uint32_t) kv;
-         }
-         if (nul) done = true;
-      }
-      bool emitted_null = false;
-      for (;;) {
-         bool found = false;
-         uint32_t brow = LDB_NULL_ROW;
-         bool scanning = !done && !(i >= n);
-         // NULL-key rows never scan; they may still owe an outer-join row
-         if (i < n && done && matches == 0 && !emitted_null && kind != LDB_JOIN_INNER) {
-            found = true;
-            emitted_null = true;
-         }
-         while (scanning) {
-            uint64_t w = d->slots[pos];
-            if (w == 0) {
-               done = true;
-               if (matches == 0 && kind != LDB_JOIN_INNER && !emitted_null) { // unmatched probe row of an outer join
-                  found = true;
-                  emitted_null = true;
-               }
-               break;
-            }
-            pos = (pos + 1) & mask;
-            bool hit = key32 ? ((uint32_t) (w >> 32) == key)
-                             : ((w >> 32) == (h >> 32) && d_keys_equal(d->bkeys, (uint64_t) ((uint32_t) w - 1u), d->pkeys, i, false));
-            if (hit) {
-               found = true;
-               brow = (uint32_t) w - 1u;
-               matches++;
-               if (kind == LDB_JOIN_SINGLE) done = true;
-               break;
-            }
-         }
-         const uint64_t m = __ballot(found);
-         if (m == 0) break; // no lane produced anything → every lane is done
-         unsigned long long first = 0;
-         if (lane == (uint32_t) __builtin_ctzll(m)) first = atomicAdd(&d->counter[0], (unsigned long long) __popcll(m));
-         first = __shfl(first, __builtin_ctzll(m));
-         if (found) {
-            unsigned long long idx = first + d_rank_in(m);
-            if (idx < d->out_cap) {
-               d->out_probe[idx] = (uint32_t) i;
-               d->out_build[idx] = brow;
-            }
-         }
-      }
-      local_matches += matches;
-   }
-   for (int off = 32; off > 0; off >>= 1) local_matches += __shfl_down(local_matches, off);
-   if (lane == 0 && local_matches) atomicAdd(&d->counter[1], local_matches);
+bool ldb_join_jit_check(std::string* log) {
+   auto m = std::make_unique<DJoin>();
+   memset(m.get(), 0, sizeof(DJoin));
+   m->key32 = 1;
+   m->kind = LDB_JOIN_INNER;
+   m->has_bitmap = 1;
+   m->bkeys.n_keys = m->pkeys.n_keys = 1;
+   m->bkeys.cols[0].type = m->pkeys.cols[0].type = LDB_T_INT32;
+   m->bkeys.cols[0].width = m->pkeys.cols[0].width = 4;
+   m->pkeys.cols[0].rowids = 1;
+   return ldb_jit_compile_only("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, m.get(), sizeof(DJoin), log);
 }
 
-// count matches only (probe micro-benchmark: Grows/s)
-__global__ void k_join_probe_count(const DJoin* __restrict__ d) {
-   const uint64_t n = d->n_rows;
-   unsigned long long local = 0;
-   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
-      local += d_probe_row(d, i, [](uint32_t) { return true; });
-   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
-   if ((threadIdx.x & 63) == 0 && local) atomicAdd(&d->counter[1], local);
-}
-
-// SEMI / ANTI / MARK: existence per probe row → bitmap word per wave (rows in ascending order)
-__global__ void k_join_probe_exists(const DJoin* __restrict__ d) {
-   const uint64_t n = d->n_rows;
-   const uint64_t n_words = (n + 63) / 64;
-   const uint32_t lane = threadIdx.x & 63;
-   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
-   const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
-   unsigned long long local = 0;
-   for (uint64_t w = wave; w < n_words; w += n_waves) {
-      uint64_t i = w * 64 + lane;
-      bool hit = false;
-      if (i < n) hit = d_probe_row(d, i, [](uint32_t) { return false; }) != 0;
-      bool keep = i < n && (d->kind == LDB_JOIN_ANTI ? !hit : hit);
-      if (d->mark && i < n) d->mark[i] = hit ? 1 : 0;
-      uint64_t m = __ballot(keep);
-      if (lane == 0) {
-         d->bitmap[w] = m;
-         local += (unsigned long long) __popcll(m);
-      }
-   }
-   if (lane == 0 && local) atomicAdd(&d->counter[0], local);
-}
-
-// Unique build side (primary-key joins: every TPC-H join): a probe row has at most one match, so
-// the kernel writes match[i] densely (coalesced) plus a ballot bitmap, and the pairs are produced
-// by the ordered bitmap expansion — no atomics on an output cursor, deterministic ascending order.
-__global__ void k_join_probe_unique(const DJoin* __restrict__ d) {
-   const uint64_t n = d->n_rows;
-   const uint64_t n_words = (n + 63) / 64;
-   const uint32_t lane = threadIdx.x & 63;
-   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
-   const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
-   unsigned long long local = 0;
-   for (uint64_t w = wave; w < n_words; w += n_waves) {
-      uint64_t i = w * 64 + lane;
-      uint32_t brow = LDB_NULL_ROW;
-      if (i < n) {
-         d_probe_row(d, i, [&](uint32_t b) {
-            brow = b;
-            return false;
-         });
-         d->match[i] = brow;
-      }
-      uint64_t m = __ballot(brow != LDB_NULL_ROW);
-      if (lane == 0) {
-         if (d->bitmap) d->bitmap[w] = m;
-         local += (unsigned long long) __popcll(m);
-      }
-   }
-   if (lane == 0 && local) atomicAdd(&d->counter[0], local);
-}
-
-// bitmap → ascending row ids (single wave per 64-bit word, block prefix via global scan of word popcounts)
+// ---------------------------------------------------------------- small helper kernels
 __global__ void k_word_pop(const uint64_t* __restrict__ bitmap, uint32_t* __restrict__ pop, uint64_t n_words) {
    for (uint64_t w = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; w < n_words; w += (uint64_t) gridDim.x * blockDim.x) pop[w] = (uint32_t) __popcll(bitmap[w]);
 }
+// bitmap → ascending row ids: one wave per 64-bit word, offsets from a device scan of the word popcounts
 __global__ void k_bitmap_expand(const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ word_off, uint32_t* __restrict__ out, uint64_t n_words) {
    const uint32_t lane = threadIdx.x & 63;
    const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
@@ -270,7 +100,6 @@ __global__ void k_bitmap_expand(const uint64_t* __restrict__ bitmap, const uint3
       if ((m >> lane) & 1) out[word_off[w] + d_rank_in(m)] = (uint32_t) (w * 64 + lane);
    }
 }
-
 __global__ void k_iota_u32j(uint32_t* out, uint64_t n) {
    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = (uint32_t) i;
 }
@@ -290,6 +119,7 @@ static uint64_t next_pow2_u64(uint64_t v) {
 
 int32_t ldb_rel_select(ldb_ctx* ctx, ldb_rel* in, uint32_t* sel, int64_t n_sel, ldb_rel** out);
 
+// ---------------------------------------------------------------- build
 extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_colref* keys, int32_t n_keys, int32_t build_unique, ldb_hashtable** out) {
    if (!ctx || !build || !out || n_keys < 1) LDB_FAIL(LDB_ERR_INVALID, "join_build: bad argument");
    auto ht = std::make_unique<ldb_hashtable>();
@@ -308,17 +138,17 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
    LDB_HIP(hipMemsetAsync(ht->slots, 0, 8 * (size_t) ht->cap, ctx->stream));
    h->n_rows = (uint64_t) build->n_rows;
    h->cap = ht->cap;
-   h->slots = ht->slots;
+   h->slots = (uint64_t) ht->slots;
    h->key32 = ht->key32;
    uint32_t* dflags = (uint32_t*) (ctx->d_scratch + 24);
    if (build_unique) {
       LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
-      h->flags = dflags;
+      h->flags = (uint64_t) dflags;
+      h->has_flags = 1;
    }
    DJoin* d;
    LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-   if (build->n_rows) { LdbProf prof_(ctx, "k_join_build"); hipLaunchKernelGGL(k_join_build, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d); }
-   LDB_HIP(hipGetLastError());
+   if (build->n_rows) LDB_TRY(launch_join(ctx, h, d, ldb_grid_for(ctx, build->n_rows, 256, 8), "k_join_build", "k_join_build_spec", k_join_build));
    ldb_dev_free(ctx, d);
    if (build_unique) { // the caller's promise is verified: duplicates fall back to the general probe
       uint64_t f = 0;
@@ -354,7 +184,7 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    }
    h->n_rows = (uint64_t) probe->n_rows;
    h->cap = ht->cap;
-   h->slots = ht->slots;
+   h->slots = (uint64_t) ht->slots;
    h->key32 = ht->key32;
    return LDB_OK;
 }
@@ -366,11 +196,10 @@ extern "C" int32_t ldb_gpu_join_probe_count(ldb_ctx* ctx, ldb_hashtable* ht, ldb
    hp->kind = LDB_JOIN_INNER;
    unsigned long long* counter = (unsigned long long*) (ctx->d_scratch + 16);
    LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
-   hp->counter = counter;
+   hp->counter = (uint64_t) counter;
    DJoin* d;
    LDB_TRY(ldb_dev_upload(ctx, hp.get(), sizeof(DJoin), (void**) &d));
-   if (probe->n_rows) { LdbProf prof_(ctx, "k_join_probe_count"); hipLaunchKernelGGL(k_join_probe_count, dim3(ldb_grid_for(ctx, probe->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d); }
-   LDB_HIP(hipGetLastError());
+   if (probe->n_rows) LDB_TRY(launch_join(ctx, hp.get(), d, ldb_grid_for(ctx, probe->n_rows, 256, 8), "k_join_probe_count", "k_join_probe_count_spec", k_join_probe_count));
    uint64_t m = 0;
    LDB_TRY(ldb_read_u64(ctx, counter + 1, &m));
    ldb_dev_free(ctx, d);
@@ -382,40 +211,42 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
                                       ldb_table** mark_out) {
    if (!ctx || !ht || !probe || !out) LDB_FAIL(LDB_ERR_INVALID, "join_probe: NULL argument");
    if (kind < LDB_JOIN_INNER || kind > LDB_JOIN_SINGLE) LDB_FAIL(LDB_ERR_INVALID, "join_probe: bad kind %d", kind);
-   if (probe->sides.size() + ht->build->sides.size() > LDB_MAX_SIDES && (kind == LDB_JOIN_INNER || kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE))
+   const bool pairs = kind == LDB_JOIN_INNER || kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE;
+   if (pairs && probe->sides.size() + ht->build->sides.size() > LDB_MAX_SIDES)
       LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: result would have more than %d sides (materialize first)", LDB_MAX_SIDES);
    auto hp = std::make_unique<DJoin>();
    DJoin* h = hp.get();
    LDB_TRY(make_probe_desc(ht, probe, keys, n_keys, h));
    h->kind = kind;
    unsigned long long* counter = (unsigned long long*) (ctx->d_scratch + 16);
-   h->counter = counter;
+   h->counter = (uint64_t) counter;
    const int64_t n = probe->n_rows;
+   const int64_t n_words = (n + 63) / 64;
    const int grid = ldb_grid_for(ctx, n, 256, 8);
 
-   if (kind == LDB_JOIN_SEMI || kind == LDB_JOIN_ANTI || kind == LDB_JOIN_MARK) {
-      const int64_t n_words = (n + 63) / 64;
+   if (!pairs) { // SEMI / ANTI / MARK
       uint64_t* bitmap;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmap, 8 * (size_t) (n_words ? n_words : 1)));
-      h->bitmap = bitmap;
+      h->bitmap = (uint64_t) bitmap;
+      h->has_bitmap = 1;
       ldb_table* mark = nullptr;
       if (kind == LDB_JOIN_MARK) {
          if (!mark_out) LDB_FAIL(LDB_ERR_INVALID, "join_probe: MARK needs mark_out");
          ldb_coltype t = {LDB_T_BOOL8, 0, 0, 0};
          const char* nm = "mark";
          LDB_TRY(ldb_gpu_table_alloc(ctx, "mark", 1, &t, &nm, n, nullptr, 0, &mark));
-         h->mark = (uint8_t*) mark->cols[0].values;
+         h->mark = (uint64_t) mark->cols[0].values;
+         h->has_mark = 1;
       }
       LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-      if (n) { LdbProf prof_(ctx, "k_join_probe_exists"); hipLaunchKernelGGL(k_join_probe_exists, dim3(grid), dim3(256), 0, ctx->stream, d); }
-      LDB_HIP(hipGetLastError());
+      if (n) LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_exists", "k_join_probe_exists_spec", k_join_probe_exists));
       ldb_dev_free(ctx, d);
       if (kind == LDB_JOIN_MARK) {
          ldb_dev_free(ctx, bitmap);
          *mark_out = mark;
-         // all probe rows, identity order: share the probe's sides by selecting everything
+         // all probe rows in input order
          ldb_rel* r = ldb_rel_new(ctx);
          r->n_rows = n;
          for (auto& s : probe->sides) {
@@ -452,18 +283,19 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
    uint64_t produced = 0;
    if (ht->unique) {
       // at most one match per probe row: dense match vector + ordered bitmap compaction
-      const int64_t n_words = (n + 63) / 64;
       uint32_t* match;
       uint64_t* bitmap = nullptr;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &match, 4 * (size_t) (n ? n : 1)));
-      if (kind == LDB_JOIN_INNER) LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmap, 8 * (size_t) (n_words ? n_words : 1)));
-      h->match = match;
-      h->bitmap = bitmap;
+      if (kind == LDB_JOIN_INNER) {
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmap, 8 * (size_t) (n_words ? n_words : 1)));
+         h->has_bitmap = 1;
+      }
+      h->match = (uint64_t) match;
+      h->bitmap = (uint64_t) bitmap;
       LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-      if (n) { LdbProf prof_(ctx, "k_join_probe_unique"); hipLaunchKernelGGL(k_join_probe_unique, dim3(grid), dim3(256), 0, ctx->stream, d); }
-      LDB_HIP(hipGetLastError());
+      if (n) LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_unique", "k_join_probe_unique_spec", k_join_probe_unique));
       ldb_dev_free(ctx, d);
       if (kind == LDB_JOIN_INNER) {
          LDB_TRY(ldb_read_u64(ctx, counter, &produced));
@@ -490,27 +322,26 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
          ob = match;
       }
    } else {
-   // pair-producing kinds: optimistic capacity, exact retry on overflow
-   uint64_t out_cap = std::max<uint64_t>(1024, (uint64_t) n);
-   for (int attempt = 0; attempt < 2; attempt++) {
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &op, 4 * (size_t) out_cap));
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &ob, 4 * (size_t) out_cap));
-      h->out_probe = op;
-      h->out_build = ob;
-      h->out_cap = out_cap;
-      LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
-      DJoin* d;
-      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-      if (n) { LdbProf prof_(ctx, "k_join_probe_pairs"); hipLaunchKernelGGL(k_join_probe_pairs, dim3(grid), dim3(256), 0, ctx->stream, d); }
-      LDB_HIP(hipGetLastError());
-      LDB_TRY(ldb_read_u64(ctx, counter, &produced));
-      ldb_dev_free(ctx, d);
-      if (produced <= out_cap) break;
-      ldb_dev_free(ctx, op);
-      ldb_dev_free(ctx, ob);
-      if (produced >= (uint64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: %llu result rows exceed uint32 row ids", (unsigned long long) produced);
-      out_cap = produced;
-   }
+      // duplicated build keys: optimistic capacity, exact retry on overflow
+      uint64_t out_cap = std::max<uint64_t>(1024, (uint64_t) n);
+      for (int attempt = 0; attempt < 2; attempt++) {
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &op, 4 * (size_t) out_cap));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &ob, 4 * (size_t) out_cap));
+         h->out_probe = (uint64_t) op;
+         h->out_build = (uint64_t) ob;
+         h->out_cap = out_cap;
+         LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
+         DJoin* d;
+         LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+         if (n) LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_pairs", "k_join_probe_pairs_spec", k_join_probe_pairs));
+         LDB_TRY(ldb_read_u64(ctx, counter, &produced));
+         ldb_dev_free(ctx, d);
+         if (produced <= out_cap) break;
+         ldb_dev_free(ctx, op);
+         ldb_dev_free(ctx, ob);
+         if (produced >= (uint64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: %llu result rows exceed uint32 row ids", (unsigned long long) produced);
+         out_cap = produced;
+      }
    }
    // result relation: probe sides composed with op, build sides composed with ob
    ldb_rel* r = ldb_rel_new(ctx);

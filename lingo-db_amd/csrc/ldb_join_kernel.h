@@ -1,0 +1,265 @@
+// ldb_join_kernel.h — device code of the hash-join build / probe kernels.
+// Compiled ahead of time (generic) and, for large inputs, at run time with the key metadata and
+// join kind as compile-time constants (ldb_jit.hip) — same source (see ldb_gb_kernel.h).
+// Replaces (reference): HashIndexedView::build (src/runtime/LazyJoinHashtable.cpp:12-34) and the
+// generated probe (LookupHashIndexedViewLowering / ScanListLowering,
+// src/compiler/Conversion/SubOpToControlFlow/SubOpToControlFlow.cpp:2558-2586, 2254-2313).
+#pragma once
+#include "ldb_keys.h"
+
+struct DJoin {
+   // ---- run-time part
+   uint64_t n_rows; // rows of the relation the kernel iterates (build or probe)
+   uint64_t cap; // table capacity (pow2)
+   uint64_t slots; // uint64_t*
+   uint64_t out_probe; // uint32_t*
+   uint64_t out_build; // uint32_t*
+   uint64_t out_cap;
+   uint64_t counter; // unsigned long long*: [0] = rows produced (may exceed out_cap), [1] = matches
+   uint64_t bitmap; // uint64_t*: SEMI / ANTI / unique-build INNER
+   uint64_t mark; // uint8_t*: MARK
+   uint64_t match; // uint32_t*: unique-build path: build row (or LDB_NULL_ROW) per probe row
+   uint64_t flags; // uint32_t*: build: [0] |= 1 when two build rows carry the same key (or tag)
+   // ---- metadata
+   int32_t key32;
+   int32_t kind;
+   int32_t has_bitmap, has_mark, has_flags, pad;
+   DKeys bkeys;
+   DKeys pkeys;
+};
+
+__device__ __forceinline__ void join_build_body(const DJoin& m, const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows, mask = d->cap - 1;
+   unsigned long long* slots = gptr_mut<unsigned long long>(d->slots);
+   const KV bkeys(m.bkeys, d->bkeys);
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      bool nul;
+      uint64_t h = d_hash_keys(bkeys, i, &nul);
+      if (nul) continue; // a NULL key can never be matched (eq on NULL is false)
+      uint64_t word;
+      if (m.key32) {
+         const CV c = bkeys.col(0);
+         word = ((uint64_t) (uint32_t) d_load_i64(c, d_phys_row(c, i)) << 32) | (uint64_t) ((uint32_t) i + 1u);
+      } else {
+         word = (h & 0xFFFFFFFF00000000ull) | (uint64_t) ((uint32_t) i + 1u);
+      }
+      uint64_t pos = h & mask;
+      for (;;) {
+         unsigned long long old = atomicCAS(&slots[pos], 0ull, (unsigned long long) word);
+         if (old == 0) break;
+         if (m.has_flags && (old >> 32) == (word >> 32)) atomicOr(gptr_mut<uint32_t>(d->flags), 1u); // same key (KEY32) / same tag: not provably unique
+         pos = (pos + 1) & mask;
+      }
+   }
+}
+
+// One probe row → visits its slot run.  EMIT is called for every match with the build row and
+// returns whether to keep scanning.
+template <typename EMIT>
+__device__ __forceinline__ uint32_t d_probe_row(const DJoin& m, const DJoin* __restrict__ d, uint64_t i, EMIT emit) {
+   const KV pkeys(m.pkeys, d->pkeys);
+   bool nul;
+   uint64_t h = d_hash_keys(pkeys, i, &nul);
+   if (nul) return 0;
+   const uint64_t mask = d->cap - 1;
+   const uint64_t* slots = gptr<uint64_t>(d->slots);
+   uint64_t pos = h & mask;
+   uint32_t matches = 0;
+   if (m.key32) {
+      const CV c = pkeys.col(0);
+      int64_t kv = d_load_i64(c, d_phys_row(c, i));
+      if (kv != (int64_t) (int32_t) kv) return 0; // wider probe value can equal no 32-bit build key
+      const uint32_t key = (uint32_t) kv;
+      for (;;) {
+         uint64_t w = slots[pos];
+         if (w == 0) break;
+         if ((uint32_t) (w >> 32) == key) {
+            matches++;
+            if (!emit((uint32_t) w - 1u)) break;
+         }
+         pos = (pos + 1) & mask;
+      }
+   } else {
+      const KV bkeys(m.bkeys, d->bkeys);
+      for (;;) {
+         uint64_t w = slots[pos];
+         if (w == 0) break;
+         if ((w >> 32) == (h >> 32) && d_keys_equal(bkeys, (uint64_t) ((uint32_t) w - 1u), pkeys, i, false)) {
+            matches++;
+            if (!emit((uint32_t) w - 1u)) break;
+         }
+         pos = (pos + 1) & mask;
+      }
+   }
+   return matches;
+}
+
+// INNER / LEFT_OUTER / SINGLE with possibly duplicated build keys: each lane walks its slot run
+// until its NEXT match, then the wave appends all pending matches with ONE atomicAdd (ballot →
+// popcount → mbcnt rank): 64x fewer atomics on the output cursor than one per pair, and each
+// wave's pairs land contiguously (coalesced stores).
+__device__ __forceinline__ void join_probe_pairs_body(const DJoin& m, const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows;
+   const int kind = m.kind;
+   const uint64_t mask = d->cap - 1;
+   const bool key32 = m.key32 != 0;
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t* slots = gptr<uint64_t>(d->slots);
+   unsigned long long* counter = gptr_mut<unsigned long long>(d->counter);
+   uint32_t* out_probe = gptr_mut<uint32_t>(d->out_probe);
+   uint32_t* out_build = gptr_mut<uint32_t>(d->out_build);
+   const uint64_t out_cap = d->out_cap;
+   const KV pkeys(m.pkeys, d->pkeys), bkeys(m.bkeys, d->bkeys);
+   unsigned long long local_matches = 0;
+   const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+   // wave-uniform trip count so that every lane reaches the ballots
+   for (uint64_t base = blockIdx.x * (uint64_t) blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
+      const uint64_t i = base + lane;
+      bool done = i >= n;
+      uint64_t h = 0, pos = 0;
+      uint32_t key = 0, matches = 0;
+      if (!done) {
+         bool nul;
+         h = d_hash_keys(pkeys, i, &nul);
+         pos = h & mask;
+         if (key32) {
+            const CV c = pkeys.col(0);
+            int64_t kv = d_load_i64(c, d_phys_row(c, i));
+            if (kv != (int64_t) (int32_t) kv) nul = true; // can equal no 32-bit build key
+            key = (uint32_t) kv;
+         }
+         if (nul) done = true;
+      }
+      bool emitted_null = false;
+      for (;;) {
+         bool found = false;
+         uint32_t brow = LDB_NULL_ROW;
+         bool scanning = !done && !(i >= n);
+         // NULL-key rows never scan; they may still owe an outer-join row
+         if (i < n && done && matches == 0 && !emitted_null && kind != LDB_JOIN_INNER) {
+            found = true;
+            emitted_null = true;
+         }
+         while (scanning) {
+            uint64_t w = slots[pos];
+            if (w == 0) {
+               done = true;
+               if (matches == 0 && kind != LDB_JOIN_INNER && !emitted_null) { // unmatched probe row of an outer join
+                  found = true;
+                  emitted_null = true;
+               }
+               break;
+            }
+            pos = (pos + 1) & mask;
+            bool hit = key32 ? ((uint32_t) (w >> 32) == key) : ((w >> 32) == (h >> 32) && d_keys_equal(bkeys, (uint64_t) ((uint32_t) w - 1u), pkeys, i, false));
+            if (hit) {
+               found = true;
+               brow = (uint32_t) w - 1u;
+               matches++;
+               if (kind == LDB_JOIN_SINGLE) done = true;
+               break;
+            }
+         }
+         const uint64_t mm = __ballot(found);
+         if (mm == 0) break; // no lane produced anything → every lane is done
+         unsigned long long first = 0;
+         if (lane == (uint32_t) __builtin_ctzll(mm)) first = atomicAdd(&counter[0], (unsigned long long) __popcll(mm));
+         first = __shfl(first, __builtin_ctzll(mm));
+         if (found) {
+            unsigned long long idx = first + d_rank_in(mm);
+            if (idx < out_cap) {
+               out_probe[idx] = (uint32_t) i;
+               out_build[idx] = brow;
+            }
+         }
+      }
+      local_matches += matches;
+   }
+   for (int off = 32; off > 0; off >>= 1) local_matches += __shfl_down(local_matches, off);
+   if (lane == 0 && local_matches) atomicAdd(&counter[1], local_matches);
+}
+
+// count matches only — the probe micro-benchmark kernel (Grows/s)
+__device__ __forceinline__ void join_probe_count_body(const DJoin& m, const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows;
+   unsigned long long local = 0;
+   const uint64_t tid = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x, nth = (uint64_t) gridDim.x * blockDim.x;
+   for (uint64_t i0 = tid; i0 < n; i0 += 4 * nth) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         const uint64_t i = i0 + (uint64_t) u * nth;
+         if (i < n) local += d_probe_row(m, d, i, [](uint32_t) { return true; });
+      }
+   }
+   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+   if ((threadIdx.x & 63) == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter) + 1, local);
+}
+
+// SEMI / ANTI / MARK: existence per probe row → bitmap word per wave (rows in ascending order)
+__device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows;
+   const uint64_t n_words = (n + 63) / 64;
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+   uint64_t* bitmap = gptr_mut<uint64_t>(d->bitmap);
+   uint8_t* mark = gptr_mut<uint8_t>(d->mark);
+   unsigned long long local = 0;
+   for (uint64_t w = wave; w < n_words; w += n_waves) {
+      uint64_t i = w * 64 + lane;
+      bool hit = false;
+      if (i < n) hit = d_probe_row(m, d, i, [](uint32_t) { return false; }) != 0;
+      bool keep = i < n && (m.kind == LDB_JOIN_ANTI ? !hit : hit);
+      if (m.has_mark && i < n) mark[i] = hit ? 1 : 0;
+      uint64_t mm = __ballot(keep);
+      if (lane == 0) {
+         bitmap[w] = mm;
+         local += (unsigned long long) __popcll(mm);
+      }
+   }
+   if (lane == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter), local);
+}
+
+// Unique build side (primary-key joins: every TPC-H join): a probe row has at most one match, so
+// the kernel writes match[i] densely (coalesced) plus a ballot bitmap, and the pairs are produced
+// by the ordered bitmap expansion — no atomics on an output cursor, deterministic ascending
+// order.  Two words (128 rows) per wave iteration keep two independent probes in flight.
+__device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows;
+   const uint64_t n_words = (n + 63) / 64;
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+   uint64_t* bitmap = gptr_mut<uint64_t>(d->bitmap);
+   uint32_t* match = gptr_mut<uint32_t>(d->match);
+   unsigned long long local = 0;
+   for (uint64_t w0 = wave; w0 < n_words; w0 += 2 * n_waves) {
+      uint32_t brow[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+         const uint64_t w = w0 + (uint64_t) u * n_waves;
+         const uint64_t i = w * 64 + lane;
+         brow[u] = LDB_NULL_ROW;
+         if (w < n_words && i < n) {
+            uint32_t b = LDB_NULL_ROW;
+            d_probe_row(m, d, i, [&](uint32_t x) {
+               b = x;
+               return false;
+            });
+            brow[u] = b;
+         }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+         const uint64_t w = w0 + (uint64_t) u * n_waves;
+         const uint64_t i = w * 64 + lane;
+         if (w < n_words && i < n) match[i] = brow[u];
+         uint64_t mm = __ballot(brow[u] != LDB_NULL_ROW);
+         if (lane == 0 && w < n_words) {
+            if (m.has_bitmap) bitmap[w] = mm;
+            local += (unsigned long long) __popcll(mm);
+         }
+      }
+   }
+   if (lane == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter), local);
+}

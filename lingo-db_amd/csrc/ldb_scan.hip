@@ -11,57 +11,43 @@
 #include "ldb_device.h"
 #include <memory>
 
-#define SCAN_BLOCK 256
-#define SCAN_WORDS_PER_BLOCK 256 // 64-bit words → 16384 rows per block
+#include "ldb_scan_kernel.h"
+#include "ldb_jit.h"
 
-struct DScan {
-   uint64_t n_rows;
-   int32_t n_preds;
-   int32_t pad;
-   DPred preds[LDB_MAX_PREDS];
-};
+// generic ahead-of-time kernels (descriptor read from memory)
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_bitmap(const DScan* __restrict__ d, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ block_counts) {
+   __shared__ uint32_t s_cnt[SCAN_BLOCK / LDB_WAVE];
+   scan_bitmap_body(*d, d, bitmap, block_counts, s_cnt);
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_count(const DScan* __restrict__ d, unsigned long long* __restrict__ total) { scan_count_body(*d, d, total); }
 
-__device__ __forceinline__ bool d_eval_conj(const DScan* __restrict__ d, uint64_t i) {
-   bool pass = true;
-   const int np = d->n_preds;
-   for (int p = 0; p < np; p++) {
-      if (pass) pass = d_eval_pred(d->preds[p], i);
-   }
-   return pass;
+// run-time specialised variants of the two kernels above (hiprtc; ldb_jit.hip)
+static const char* SCAN_SPEC_SRC =
+   "extern \"C\" __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_bitmap_spec(const DScan* __restrict__ d, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ counts) {\n"
+   "   __shared__ uint32_t s_cnt[SCAN_BLOCK / LDB_WAVE];\n"
+   "   scan_bitmap_body(LDB_META, d, bitmap, counts, s_cnt);\n"
+   "}\n"
+   "extern \"C\" __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_count_spec(const DScan* __restrict__ d, unsigned long long* __restrict__ total) { scan_count_body(LDB_META, d, total); }\n";
+static void scan_meta(const DScan* h, DScan* m) {
+   memcpy(m, h, sizeof(DScan));
+   m->n_rows = 0;
+   for (int p = 0; p < LDB_MAX_PREDS; p++) ldb_jit_strip_pred(m->preds[p]);
 }
 
-// One block = 16384 consecutive rows; each wave handles 64 of the block's 256 bitmap words.
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_bitmap(const DScan* __restrict__ d, uint64_t* __restrict__ bitmap,
-                                                            uint32_t* __restrict__ block_counts) {
-   __shared__ uint32_t s_cnt[SCAN_BLOCK / LDB_WAVE];
-   const uint64_t n = d->n_rows;
-   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-   const uint64_t word0 = (uint64_t) blockIdx.x * SCAN_WORDS_PER_BLOCK;
-   uint32_t cnt = 0;
-   // 4 bitmap words (256 rows) per wave iteration: the four rows' column loads are independent and
-   // issue back to back before the first ballot (memory-level parallelism for an HBM-bound scan)
-   constexpr uint32_t WPW = SCAN_BLOCK / LDB_WAVE; // waves per block
-   for (uint32_t w = wave; w < SCAN_WORDS_PER_BLOCK; w += 4 * WPW) {
-      bool pass[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-         uint64_t i = (word0 + w + u * WPW) * 64 + lane;
-         pass[u] = i < n && d_eval_conj(d, i);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-         uint64_t m = __ballot(pass[u]);
-         if (lane == 0 && (word0 + w + u * WPW) * 64 < n) bitmap[word0 + w + u * WPW] = m;
-         cnt += (uint32_t) __popcll(m);
-      }
-   }
-   if (lane == 0) s_cnt[wave] = cnt;
-   __syncthreads();
-   if (threadIdx.x == 0) {
-      uint32_t t = 0;
-      for (int k = 0; k < SCAN_BLOCK / LDB_WAVE; k++) t += s_cnt[k];
-      block_counts[blockIdx.x] = t;
-   }
+bool ldb_scan_jit_check(std::string* log) {
+   DScan m;
+   memset(&m, 0, sizeof(m));
+   m.n_preds = 2;
+   m.preds[0].col.type = LDB_T_DATE32;
+   m.preds[0].col.width = 4;
+   m.preds[0].op = LDB_F_GTE;
+   m.preds[1].col.type = LDB_T_UTF8;
+   m.preds[1].col.offsets = 1;
+   m.preds[1].op = LDB_F_EQ;
+   m.preds[1].rhs_kind = LDB_RHS_STRING;
+   m.preds[1].str_len = 8;
+   memcpy(m.preds[1].str, "BUILDING", 8);
+   return ldb_jit_compile_only("ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, &m, sizeof(m), log);
 }
 
 // Expand the bitmap into ascending row ids.  Each wave walks its words; the lane whose bit is
@@ -93,16 +79,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_expand(const uint64_t* __re
       uint64_t m = bitmap[word0 + w]; // wave-uniform
       if ((m >> lane) & 1) out_rows[base + s_pop[w] + d_rank_in(m)] = (uint32_t) ((word0 + w) * 64 + lane);
    }
-}
-
-// count-only variant: grid-stride, no bitmap
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_count(const DScan* __restrict__ d, unsigned long long* __restrict__ total) {
-   const uint64_t n = d->n_rows;
-   uint32_t cnt = 0;
-   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) cnt += d_eval_conj(d, i) ? 1u : 0u;
-   // wave reduce
-   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
-   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(total, (unsigned long long) cnt);
 }
 
 // compose: new_rowids[j] = old_rowids[sel[j]] (sides that already had row ids)
@@ -170,7 +146,22 @@ extern "C" int32_t ldb_gpu_scan_filter(ldb_ctx* ctx, ldb_rel* in, const ldb_filt
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmap, sizeof(uint64_t) * (size_t) n_words));
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &counts, sizeof(uint32_t) * (size_t) n_blocks));
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &offsets, sizeof(uint32_t) * (size_t) n_blocks));
-   { LdbProf prof_(ctx, "k_scan_bitmap"); hipLaunchKernelGGL(k_scan_bitmap, dim3((unsigned) n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, d, bitmap, counts); }
+   {
+      hipFunction_t spec = nullptr;
+      if (ldb_jit_wanted(n)) {
+         DScan meta;
+         scan_meta(&h, &meta);
+         std::string why;
+         spec = ldb_jit_kernel("ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, "k_scan_bitmap_spec", &meta, sizeof(meta), &why);
+      }
+      LdbProf prof_(ctx, "k_scan_bitmap");
+      if (spec) {
+         void* params[] = {(void*) &d, (void*) &bitmap, (void*) &counts};
+         LDB_HIP(hipModuleLaunchKernel(spec, (unsigned) n_blocks, 1, 1, SCAN_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
+      } else {
+         hipLaunchKernelGGL(k_scan_bitmap, dim3((unsigned) n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, d, bitmap, counts);
+      }
+   }
    LDB_HIP(hipGetLastError());
    LDB_TRY(ldb_exclusive_scan_u32(ctx, counts, offsets, n_blocks, (uint64_t*) ctx->d_scratch));
    uint64_t total = 0;
@@ -193,7 +184,24 @@ extern "C" int32_t ldb_gpu_scan_count(ldb_ctx* ctx, ldb_rel* in, const ldb_filte
    DScan* d;
    LDB_TRY(ldb_dev_upload(ctx, &h, sizeof(h), (void**) &d));
    LDB_HIP(hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
-   if (in->n_rows) { LdbProf prof_(ctx, "k_scan_count"); hipLaunchKernelGGL(k_scan_count, dim3(ldb_grid_for(ctx, in->n_rows, SCAN_BLOCK, 8)), dim3(SCAN_BLOCK), 0, ctx->stream, d, (unsigned long long*) ctx->d_scratch); }
+   if (in->n_rows) {
+      hipFunction_t spec = nullptr;
+      if (ldb_jit_wanted(in->n_rows)) {
+         DScan meta;
+         scan_meta(&h, &meta);
+         std::string why;
+         spec = ldb_jit_kernel("ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, "k_scan_count_spec", &meta, sizeof(meta), &why);
+      }
+      unsigned long long* total = (unsigned long long*) ctx->d_scratch;
+      const int grid = ldb_grid_for(ctx, in->n_rows, SCAN_BLOCK, 8);
+      LdbProf prof_(ctx, "k_scan_count");
+      if (spec) {
+         void* params[] = {(void*) &d, (void*) &total};
+         LDB_HIP(hipModuleLaunchKernel(spec, (unsigned) grid, 1, 1, SCAN_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
+      } else {
+         hipLaunchKernelGGL(k_scan_count, dim3(grid), dim3(SCAN_BLOCK), 0, ctx->stream, d, total);
+      }
+   }
    LDB_HIP(hipGetLastError());
    uint64_t total = 0;
    LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &total));

@@ -1,0 +1,76 @@
+// ldb_scan_kernel.h — device code of the columnar scan + pushed-down predicate kernels.
+// Compiled ahead of time (generic) and, for large inputs, at run time with the predicate list as
+// a compile-time constant (ldb_jit.hip) — same source, see ldb_gb_kernel.h for the rationale.
+// Replaces (reference): ScanBatchesTask::unitRun (src/runtime/storage/LingoDBTable.cpp:382-407) and
+// Restrictions::applyFilters + Filter impls (src/runtime/storage/Restrictions.cpp:67-390).
+#pragma once
+#include "ldb_device.h"
+
+#define SCAN_BLOCK 256
+#define SCAN_WORDS_PER_BLOCK 256 // 64-bit words → 16384 rows per block
+
+struct DScan {
+   uint64_t n_rows; // run-time
+   int32_t n_preds;
+   int32_t pad;
+   DPred preds[LDB_MAX_PREDS];
+};
+
+__device__ __forceinline__ bool d_eval_conj(const DScan& m, const DScan* __restrict__ d, uint64_t i) {
+   bool pass = true;
+   const int np = m.n_preds;
+   LDB_UNROLL
+   for (int p = 0; p < np; p++) {
+      if (pass) pass = d_eval_pred(PV(m.preds[p], d->preds[p]), i);
+   }
+   return pass;
+}
+
+// One block = 16384 consecutive rows; each wave handles 64 of the block's 256 bitmap words,
+// 4 words (256 rows) per iteration: the four rows' column loads are independent and issue back to
+// back before the first ballot (memory-level parallelism for an HBM-bound scan).
+__device__ __forceinline__ void scan_bitmap_body(const DScan& m, const DScan* __restrict__ d, uint64_t* __restrict__ bitmap,
+                                                 uint32_t* __restrict__ block_counts, uint32_t* s_cnt) {
+   const uint64_t n = d->n_rows;
+   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const uint64_t word0 = (uint64_t) blockIdx.x * SCAN_WORDS_PER_BLOCK;
+   uint32_t cnt = 0;
+   constexpr uint32_t WPW = SCAN_BLOCK / LDB_WAVE; // waves per block
+   for (uint32_t w = wave; w < SCAN_WORDS_PER_BLOCK; w += 4 * WPW) {
+      bool pass[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         uint64_t i = (word0 + w + u * WPW) * 64 + lane;
+         pass[u] = i < n && d_eval_conj(m, d, i);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         uint64_t mask = __ballot(pass[u]);
+         if (lane == 0 && (word0 + w + u * WPW) * 64 < n) bitmap[word0 + w + u * WPW] = mask;
+         cnt += (uint32_t) __popcll(mask);
+      }
+   }
+   if (lane == 0) s_cnt[wave] = cnt;
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int k = 0; k < SCAN_BLOCK / LDB_WAVE; k++) t += s_cnt[k];
+      block_counts[blockIdx.x] = t;
+   }
+}
+
+// count-only variant: grid-stride, 4 rows in flight per thread, no bitmap
+__device__ __forceinline__ void scan_count_body(const DScan& m, const DScan* __restrict__ d, unsigned long long* __restrict__ total) {
+   const uint64_t n = d->n_rows;
+   const uint64_t tid = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x, nth = (uint64_t) gridDim.x * blockDim.x;
+   uint32_t cnt = 0;
+   for (uint64_t i0 = tid; i0 < n; i0 += 4 * nth) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         uint64_t i = i0 + (uint64_t) u * nth;
+         cnt += (i < n && d_eval_conj(m, d, i)) ? 1u : 0u;
+      }
+   }
+   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(total, (unsigned long long) cnt);
+}
