@@ -285,6 +285,47 @@ __device__ __forceinline__ bool d_eval_pred(PV p, uint64_t i) {
    return d_cmp_apply(p.m.op, p.m.hi < 0 ? 1 : -1); // constant below / above every int64
 }
 
+// A "simple" conjunct: narrow integer-like column (ints, date32, char(1), decimal p<19) against a
+// constant with a comparison operator — the shape of almost every pushed-down TPC-H filter.
+__device__ __forceinline__ bool d_pred_is_simple(const DPred& pm) {
+   const int t = pm.col.type;
+   const bool narrow = t == LDB_T_INT8 || t == LDB_T_INT16 || t == LDB_T_INT32 || t == LDB_T_INT64 || t == LDB_T_DATE32 || t == LDB_T_CHAR4 || t == LDB_T_BOOL8 ||
+                       (t == LDB_T_DECIMAL128 && pm.col.precision < 19);
+   return narrow && pm.rhs_kind == LDB_RHS_INT && pm.op != LDB_F_IN && pm.op != LDB_F_NOTNULL;
+}
+
+// One conjunct over U rows of the same thread, load phase separated from the compare phase: the
+// U loads are independent and issue back to back (memory-level parallelism) instead of one
+// load → compare → branch chain per row.  Rows with pass[u] == false are neither loaded nor
+// changed.  Falls back to d_eval_pred for the non-simple shapes.
+template <int U>
+__device__ __forceinline__ void d_eval_pred_batch(PV p, const uint64_t (&rows)[U], bool (&pass)[U]) {
+   if (d_pred_is_simple(p.m)) {
+      const CV col = p.col();
+      int64_t val[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         val[u] = 0;
+         ok[u] = false;
+         if (pass[u]) {
+            uint32_t row = d_phys_row(col, rows[u]);
+            ok[u] = d_valid(col, row);
+            if (ok[u]) val[u] = d_load_i64(col, row);
+         }
+      }
+      const bool fits = p.m.hi == ((int64_t) p.m.lo >> 63);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         if (pass[u]) pass[u] = ok[u] && (fits ? d_cmp_vals<int64_t>(p.m.op, val[u], (int64_t) p.m.lo) : d_cmp_apply(p.m.op, p.m.hi < 0 ? 1 : -1));
+      }
+   } else {
+#pragma unroll
+      for (int u = 0; u < U; u++)
+         if (pass[u]) pass[u] = d_eval_pred(p, rows[u]);
+   }
+}
+
 // db.hash of one key part folded into `total` (HashLowering::hashImpl, LowerToStd.cpp:1073-1132).
 // Caller has checked validity (NULL parts are skipped).
 __device__ __forceinline__ uint64_t d_hash_part(CV c, uint32_t row, uint64_t total) {

@@ -347,19 +347,24 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
       uint64_t hv[GB_ROWS];
       long long rvv[GB_ROWS][GB_MAX_COLS];
       uint32_t rvalidv[GB_ROWS];
+      uint64_t rowsv[GB_ROWS];
 #pragma unroll
       for (int u = 0; u < GB_ROWS; u++) {
-         const uint64_t i = i0 + (uint64_t) u * nthreads;
-         bool pass = i < n;
-         LDB_UNROLL
-         for (int p = 0; p < np; p++)
-            if (pass) pass = d_eval_pred(PV(m.preds[p], d->preds[p]), i);
-         passv[u] = pass;
+         rowsv[u] = i0 + (uint64_t) u * nthreads;
+         passv[u] = rowsv[u] < n;
+      }
+      // predicate-major: each conjunct is evaluated for all rows of the batch (loads first, then
+      // compares), so the dependent filter chain costs one memory round trip per conjunct column
+      // for the whole batch rather than one per row
+      LDB_UNROLL
+      for (int p = 0; p < np; p++) d_eval_pred_batch<GB_ROWS>(PV(m.preds[p], d->preds[p]), rowsv, passv);
+#pragma unroll
+      for (int u = 0; u < GB_ROWS; u++) {
          hv[u] = 0;
          rvalidv[u] = 0;
-         if (pass) {
-            if (!m.keyless) hv[u] = d_hash_keys(keys, i);
-            d_load_vals(m, d, i, rvv[u], rvalidv[u]);
+         if (passv[u]) {
+            if (!m.keyless) hv[u] = d_hash_keys(keys, rowsv[u]);
+            d_load_vals(m, d, rowsv[u], rvv[u], rvalidv[u]);
          }
       }
 #pragma unroll

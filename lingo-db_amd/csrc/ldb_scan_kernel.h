@@ -26,6 +26,14 @@ __device__ __forceinline__ bool d_eval_conj(const DScan& m, const DScan* __restr
    return pass;
 }
 
+// the conjunction over U rows of one thread, predicate-major (see d_eval_pred_batch)
+template <int U>
+__device__ __forceinline__ void d_eval_conj_batch(const DScan& m, const DScan* __restrict__ d, const uint64_t (&rows)[U], bool (&pass)[U]) {
+   const int np = m.n_preds;
+   LDB_UNROLL
+   for (int p = 0; p < np; p++) d_eval_pred_batch<U>(PV(m.preds[p], d->preds[p]), rows, pass);
+}
+
 // One block = 16384 consecutive rows; each wave handles 64 of the block's 256 bitmap words,
 // 4 words (256 rows) per iteration: the four rows' column loads are independent and issue back to
 // back before the first ballot (memory-level parallelism for an HBM-bound scan).
@@ -38,11 +46,13 @@ __device__ __forceinline__ void scan_bitmap_body(const DScan& m, const DScan* __
    constexpr uint32_t WPW = SCAN_BLOCK / LDB_WAVE; // waves per block
    for (uint32_t w = wave; w < SCAN_WORDS_PER_BLOCK; w += 4 * WPW) {
       bool pass[4];
+      uint64_t rows[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-         uint64_t i = (word0 + w + u * WPW) * 64 + lane;
-         pass[u] = i < n && d_eval_conj(m, d, i);
+         rows[u] = (word0 + w + u * WPW) * 64 + lane;
+         pass[u] = rows[u] < n;
       }
+      d_eval_conj_batch<4>(m, d, rows, pass);
 #pragma unroll
       for (int u = 0; u < 4; u++) {
          uint64_t mask = __ballot(pass[u]);
@@ -65,11 +75,16 @@ __device__ __forceinline__ void scan_count_body(const DScan& m, const DScan* __r
    const uint64_t tid = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x, nth = (uint64_t) gridDim.x * blockDim.x;
    uint32_t cnt = 0;
    for (uint64_t i0 = tid; i0 < n; i0 += 4 * nth) {
+      bool pass[4];
+      uint64_t rows[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-         uint64_t i = i0 + (uint64_t) u * nth;
-         cnt += (i < n && d_eval_conj(m, d, i)) ? 1u : 0u;
+         rows[u] = i0 + (uint64_t) u * nth;
+         pass[u] = rows[u] < n;
       }
+      d_eval_conj_batch<4>(m, d, rows, pass);
+#pragma unroll
+      for (int u = 0; u < 4; u++) cnt += pass[u] ? 1u : 0u;
    }
    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(total, (unsigned long long) cnt);
