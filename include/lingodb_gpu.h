@@ -302,7 +302,19 @@ int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds,
                         int64_t est_groups, ldb_table** out);
 
 /* ------------------------------------------------------------------ hash join (a6, a7, a8) */
-typedef enum { LDB_JOIN_INNER = 0, LDB_JOIN_SEMI = 1, LDB_JOIN_ANTI = 2, LDB_JOIN_LEFT_OUTER = 3, LDB_JOIN_MARK = 4, LDB_JOIN_SINGLE = 5 } ldb_join_kind;
+typedef enum {
+   LDB_JOIN_INNER = 0,
+   LDB_JOIN_SEMI = 1,
+   LDB_JOIN_ANTI = 2,
+   LDB_JOIN_LEFT_OUTER = 3,
+   LDB_JOIN_MARK = 4,
+   LDB_JOIN_SINGLE = 5,
+   /* build-side semi / anti join: the result is the BUILD relation restricted to the rows with at
+    * least one (SEMI_BUILD) / no (ANTI_BUILD) matching probe row, in ascending build order — the
+    * reference's reverseSides scheme (translateHJWithMarker, RelAlgToSubOp.cpp:1248-1287) */
+   LDB_JOIN_SEMI_BUILD = 6,
+   LDB_JOIN_ANTI_BUILD = 7
+} ldb_join_kind;
 
 /* Replaces GrowingBuffer::insert materialisation + HashIndexedView::build
  * (GrowingBuffer.cpp:44, LazyJoinHashtable.cpp:12-34): builds an index over the rows of

@@ -17,10 +17,17 @@
 // rows per thread per loop iteration: the specialised kernel keeps only the referenced columns in
 // registers, so it can afford 4 rows in flight; the generic kernel indexes its value cache
 // dynamically and stays at 1
+#ifndef GB_ROWS
 #ifdef LDB_JIT_SPECIALIZED
 #define GB_ROWS 4
 #else
 #define GB_ROWS 1
+#endif
+#endif
+// 1: evaluate each conjunct for the whole row batch (loads first, then compares);
+// 0: evaluate the conjunction row by row (a dependent load → compare chain per row)
+#ifndef GB_PRED_BATCH
+#define GB_PRED_BATCH 0
 #endif
 #define GB_MAX_COLS 12
 #define GB_MAX_ACCS 20
@@ -356,8 +363,19 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
       // predicate-major: each conjunct is evaluated for all rows of the batch (loads first, then
       // compares), so the dependent filter chain costs one memory round trip per conjunct column
       // for the whole batch rather than one per row
+#if GB_PRED_BATCH
       LDB_UNROLL
       for (int p = 0; p < np; p++) d_eval_pred_batch<GB_ROWS>(PV(m.preds[p], d->preds[p]), rowsv, passv);
+#else
+#pragma unroll
+      for (int u = 0; u < GB_ROWS; u++) {
+         bool pass = passv[u];
+         LDB_UNROLL
+         for (int p = 0; p < np; p++)
+            if (pass) pass = d_eval_pred(PV(m.preds[p], d->preds[p]), rowsv[u]);
+         passv[u] = pass;
+      }
+#endif
 #pragma unroll
       for (int u = 0; u < GB_ROWS; u++) {
          hv[u] = 0;

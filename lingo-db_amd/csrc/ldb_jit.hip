@@ -97,8 +97,21 @@ static bool compile(const std::string& src, std::vector<char>* code, std::string
       *err = "hiprtcCreateProgram failed";
       return false;
    }
-   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics"};
-   hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+   std::vector<std::string> extra; // tuning experiments: LDB_JIT_DEFINES="-DGB_ROWS=8 -DGB_PRED_BATCH=0"
+   if (const char* defs = getenv("LDB_JIT_DEFINES")) {
+      std::string s(defs), tok;
+      for (size_t i = 0; i <= s.size(); i++) {
+         if (i == s.size() || s[i] == ' ') {
+            if (!tok.empty()) extra.push_back(tok);
+            tok.clear();
+         } else {
+            tok += s[i];
+         }
+      }
+   }
+   std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics"};
+   for (auto& e : extra) opts.push_back(e.c_str());
+   hiprtcResult r = hiprtcCompileProgram(prog, (int) opts.size(), opts.data());
    if (r != HIPRTC_SUCCESS) {
       size_t ls = 0;
       hiprtcGetProgramLogSize(prog, &ls);
@@ -145,6 +158,14 @@ hipFunction_t ldb_jit_kernel(const char* header, const char* struct_name, const 
       bool ok = compile(build_source(header, struct_name, kernels_src, (const unsigned char*) meta, meta_bytes), &e->code, &e->error);
       g_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (ok) {
+         if (const char* dir = getenv("LDB_JIT_DUMP_DIR")) { // code objects for llvm-objdump inspection
+            char path[512];
+            snprintf(path, sizeof(path), "%s/%s_%016llx.co", dir, kernel_name, (unsigned long long) h);
+            if (FILE* f = fopen(path, "wb")) {
+               fwrite(e->code.data(), 1, e->code.size(), f);
+               fclose(f);
+            }
+         }
          if (hipModuleLoadData(&e->module, e->code.data()) != hipSuccess) {
             e->error = "hipModuleLoadData failed for the specialised kernel";
             e->module = nullptr;

@@ -39,6 +39,10 @@ __global__ void k_join_probe_pairs(const DJoin* __restrict__ d) { join_probe_pai
 __global__ void k_join_probe_count(const DJoin* __restrict__ d) { join_probe_count_body(*d, d); }
 __global__ void k_join_probe_exists(const DJoin* __restrict__ d) { join_probe_exists_body(*d, d); }
 __global__ void k_join_probe_unique(const DJoin* __restrict__ d) { join_probe_unique_body(*d, d); }
+__global__ void k_join_probe_markbuild(const DJoin* __restrict__ d) { join_probe_markbuild_body(*d, d); }
+__global__ void k_join_flags_bitmap(const uint8_t* __restrict__ flags, uint64_t n, int anti, uint64_t* __restrict__ bitmap, unsigned long long* __restrict__ counter) {
+   join_flags_bitmap_body(flags, n, anti, bitmap, counter);
+}
 
 // run-time specialised variants (hiprtc; ldb_jit.hip)
 static const char* JOIN_SPEC_SRC =
@@ -46,7 +50,8 @@ static const char* JOIN_SPEC_SRC =
    "extern \"C\" __global__ void k_join_probe_pairs_spec(const DJoin* __restrict__ d) { join_probe_pairs_body(LDB_META, d); }\n"
    "extern \"C\" __global__ void k_join_probe_count_spec(const DJoin* __restrict__ d) { join_probe_count_body(LDB_META, d); }\n"
    "extern \"C\" __global__ void k_join_probe_exists_spec(const DJoin* __restrict__ d) { join_probe_exists_body(LDB_META, d); }\n"
-   "extern \"C\" __global__ void k_join_probe_unique_spec(const DJoin* __restrict__ d) { join_probe_unique_body(LDB_META, d); }\n";
+   "extern \"C\" __global__ void k_join_probe_unique_spec(const DJoin* __restrict__ d) { join_probe_unique_body(LDB_META, d); }\n"
+   "extern \"C\" __global__ void k_join_probe_markbuild_spec(const DJoin* __restrict__ d) { join_probe_markbuild_body(LDB_META, d); }\n";
 
 typedef void (*join_kernel_t)(const DJoin*);
 // launch `generic` or its specialised twin `<name>_spec` on the ctx stream
@@ -210,8 +215,47 @@ extern "C" int32_t ldb_gpu_join_probe_count(ldb_ctx* ctx, ldb_hashtable* ht, ldb
 extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind, ldb_rel** out,
                                       ldb_table** mark_out) {
    if (!ctx || !ht || !probe || !out) LDB_FAIL(LDB_ERR_INVALID, "join_probe: NULL argument");
-   if (kind < LDB_JOIN_INNER || kind > LDB_JOIN_SINGLE) LDB_FAIL(LDB_ERR_INVALID, "join_probe: bad kind %d", kind);
+   if (kind < LDB_JOIN_INNER || kind > LDB_JOIN_ANTI_BUILD) LDB_FAIL(LDB_ERR_INVALID, "join_probe: bad kind %d", kind);
    const bool pairs = kind == LDB_JOIN_INNER || kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE;
+   if (kind == LDB_JOIN_SEMI_BUILD || kind == LDB_JOIN_ANTI_BUILD) {
+      // flag the build rows that some probe row matches, then keep (SEMI) / drop (ANTI) them
+      auto hb = std::make_unique<DJoin>();
+      LDB_TRY(make_probe_desc(ht, probe, keys, n_keys, hb.get()));
+      hb->kind = kind;
+      const int64_t nb = ht->build->n_rows, nbw = (nb + 63) / 64;
+      uint8_t* flags;
+      uint64_t* bitmap;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &flags, (size_t) (nb ? nb : 1)));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmap, 8 * (size_t) (nbw ? nbw : 1)));
+      LDB_HIP(hipMemsetAsync(flags, 0, (size_t) (nb ? nb : 1), ctx->stream));
+      hb->mark = (uint64_t) flags;
+      hb->has_mark = 1;
+      unsigned long long* cnt = (unsigned long long*) (ctx->d_scratch + 16);
+      LDB_HIP(hipMemsetAsync(cnt, 0, 16, ctx->stream));
+      DJoin* d;
+      LDB_TRY(ldb_dev_upload(ctx, hb.get(), sizeof(DJoin), (void**) &d));
+      if (probe->n_rows) LDB_TRY(launch_join(ctx, hb.get(), d, ldb_grid_for(ctx, probe->n_rows, 256, 8), "k_join_probe_markbuild", "k_join_probe_markbuild_spec", k_join_probe_markbuild));
+      ldb_dev_free(ctx, d);
+      if (nb) hipLaunchKernelGGL(k_join_flags_bitmap, dim3(ldb_grid_for(ctx, nb, 256, 8)), dim3(256), 0, ctx->stream, (const uint8_t*) flags, (uint64_t) nb, kind == LDB_JOIN_ANTI_BUILD ? 1 : 0, bitmap, cnt);
+      LDB_HIP(hipGetLastError());
+      uint64_t total = 0;
+      LDB_TRY(ldb_read_u64(ctx, cnt, &total));
+      uint32_t *pop, *off, *sel;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) (nbw ? nbw : 1)));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) (nbw ? nbw : 1)));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &sel, 4 * (size_t) (total ? total : 1)));
+      if (nbw) {
+         hipLaunchKernelGGL(k_word_pop, dim3(ldb_grid_for(ctx, nbw, 256, 8)), dim3(256), 0, ctx->stream, bitmap, pop, (uint64_t) nbw);
+         LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, nbw, nullptr));
+         if (total) hipLaunchKernelGGL(k_bitmap_expand, dim3(ldb_grid_for(ctx, nbw * 64, 256, 8)), dim3(256), 0, ctx->stream, bitmap, off, sel, (uint64_t) nbw);
+      }
+      LDB_HIP(hipGetLastError());
+      ldb_dev_free(ctx, flags);
+      ldb_dev_free(ctx, bitmap);
+      ldb_dev_free(ctx, pop);
+      ldb_dev_free(ctx, off);
+      return ldb_rel_select(ctx, ht->build, sel, (int64_t) total, out);
+   }
    if (pairs && probe->sides.size() + ht->build->sides.size() > LDB_MAX_SIDES)
       LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: result would have more than %d sides (materialize first)", LDB_MAX_SIDES);
    auto hp = std::make_unique<DJoin>();

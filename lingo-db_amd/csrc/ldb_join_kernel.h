@@ -220,6 +220,46 @@ __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJo
    if (lane == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter), local);
 }
 
+// Build-side semi / anti join (the reference's `reverseSides` scheme: the build rows carry a
+// boolean flag that matching probe tuples set, then the build buffer is re-scanned on the flag —
+// translateHJWithMarker, src/compiler/Conversion/RelAlgToSubOp/RelAlgToSubOp.cpp:1248-1287).
+// The flag store is idempotent, so no atomic is needed (the CPU path uses an atomic OR).
+__device__ __forceinline__ void join_probe_markbuild_body(const DJoin& m, const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows;
+   uint8_t* flags = gptr_mut<uint8_t>(d->mark);
+   const uint64_t tid = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x, nth = (uint64_t) gridDim.x * blockDim.x;
+   for (uint64_t i0 = tid; i0 < n; i0 += 2 * nth) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+         const uint64_t i = i0 + (uint64_t) u * nth;
+         if (i < n)
+            d_probe_row(m, d, i, [&](uint32_t b) {
+               flags[b] = 1;
+               return true;
+            });
+      }
+   }
+}
+// flags (one byte per build row) → ballot bitmap of the rows to keep (+ their count)
+__device__ __forceinline__ void join_flags_bitmap_body(const uint8_t* __restrict__ flags, uint64_t n, int anti, uint64_t* __restrict__ bitmap,
+                                                       unsigned long long* __restrict__ counter) {
+   const uint64_t n_words = (n + 63) / 64;
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+   unsigned long long local = 0;
+   for (uint64_t w = wave; w < n_words; w += n_waves) {
+      const uint64_t i = w * 64 + lane;
+      bool keep = i < n && ((flags[i] != 0) != (anti != 0));
+      uint64_t mm = __ballot(keep);
+      if (lane == 0) {
+         bitmap[w] = mm;
+         local += (unsigned long long) __popcll(mm);
+      }
+   }
+   if (lane == 0 && local) atomicAdd(counter, local);
+}
+
 // Unique build side (primary-key joins: every TPC-H join): a probe row has at most one match, so
 // the kernel writes match[i] densely (coalesced) plus a ballot bitmap, and the pairs are produced
 // by the ordered bitmap expansion — no atomics on an output cursor, deterministic ascending

@@ -29,7 +29,7 @@ RHS_INT, RHS_STRING, RHS_COLUMN, RHS_FLOAT = range(4)
 # ldb_agg_fn
 AGG_SUM, AGG_MIN, AGG_MAX, AGG_COUNT, AGG_COUNT_STAR, AGG_ANY, AGG_AVG = range(7)
 # ldb_join_kind
-JOIN_INNER, JOIN_SEMI, JOIN_ANTI, JOIN_LEFT_OUTER, JOIN_MARK, JOIN_SINGLE = range(6)
+JOIN_INNER, JOIN_SEMI, JOIN_ANTI, JOIN_LEFT_OUTER, JOIN_MARK, JOIN_SINGLE, JOIN_SEMI_BUILD, JOIN_ANTI_BUILD = range(8)
 
 
 class ColType(C.Structure):

@@ -1048,9 +1048,70 @@ static void jprobe_unit(void* a, int worker, int64_t u) {
    if (!writing) j->unit_counts[u] = n;
 }
 
+/* reverseSides semi / anti join (translateHJWithMarker, RelAlgToSubOp.cpp:1248-1287): probe
+ * tuples set a boolean flag in the matching build rows (atomic OR when parallel,
+ * SubOpToControlFlow.cpp:3593), then the build buffer is scanned on the flag. */
+typedef struct {
+   jbuild_job* b;
+   const ora_rel* probe;
+   const ldb_colref* pkeys;
+   _Atomic uint8_t* flags;
+   int cmp_hash;
+} jmark_job;
+static void jmark_unit(void* a, int worker, int64_t u) {
+   (void) worker;
+   jmark_job* j = (jmark_job*) a;
+   jbuild_job* b = j->b;
+   int64_t base = u * MORSEL, end = base + MORSEL < j->probe->n_rows ? base + MORSEL : j->probe->n_rows;
+   for (int64_t i = base; i < end; i++) {
+      uint64_t h = hash_row(j->probe, j->pkeys, b->n_keys, i);
+      uint64_t slot = atomic_load(&b->ht[h & b->mask]);
+      if (!slot_matches(slot, h)) continue;
+      for (jentry* e = (jentry*) (uintptr_t) (slot >> 16); e; e = e->next) {
+         if (j->cmp_hash && e->hash != h) continue;
+         if (!keys_equal(b->build, b->bkeys, (int64_t) e->row, j->probe, j->pkeys, i, b->n_keys, 0)) continue;
+         atomic_store(&j->flags[e->row], 1);
+      }
+   }
+}
+
 int64_t ora_join(const ora_rel* build, const ldb_colref* bkeys, const ora_rel* probe, const ldb_colref* pkeys, int32_t n_keys,
                  int32_t kind, int32_t threads, uint32_t* out_probe, uint32_t* out_build, uint8_t* out_mark, int64_t cap) {
    if (threads < 1) threads = 1;
+   if (kind == LDB_JOIN_SEMI_BUILD || kind == LDB_JOIN_ANTI_BUILD) {
+      jbuild_job b;
+      b.build = build;
+      b.bkeys = bkeys;
+      b.n_keys = n_keys;
+      b.rows = (jentry*) malloc(sizeof(jentry) * (size_t) (build->n_rows ? build->n_rows : 1));
+      uint64_t hs = next_pow2((uint64_t) ((double) build->n_rows * 1.25));
+      if (hs < 1) hs = 1;
+      b.mask = hs - 1;
+      b.ht = (_Atomic uint64_t*) calloc((size_t) hs, sizeof(uint64_t));
+      int64_t bu = (build->n_rows + MORSEL - 1) / MORSEL;
+      run_units(threads, bu, jmat_unit, &b);
+      run_units(threads, bu, jbuild_unit, &b);
+      jmark_job mj;
+      mj.b = &b;
+      mj.probe = probe;
+      mj.pkeys = pkeys;
+      mj.flags = (_Atomic uint8_t*) calloc((size_t) (build->n_rows ? build->n_rows : 1), 1);
+      const ora_col* k0 = rel_col(build, bkeys[0]);
+      mj.cmp_hash = !(n_keys == 1 && !is_string(k0) && !is_float(k0));
+      run_units(threads, (probe->n_rows + MORSEL - 1) / MORSEL, jmark_unit, &mj);
+      int64_t n = 0;
+      for (int64_t r = 0; r < build->n_rows; r++) {
+         int keep = (mj.flags[r] != 0) == (kind == LDB_JOIN_SEMI_BUILD);
+         if (keep) {
+            if (out_probe && n < cap) out_probe[n] = (uint32_t) r; /* build row numbers, ascending */
+            n++;
+         }
+      }
+      free((void*) mj.flags);
+      free(b.rows);
+      free((void*) b.ht);
+      return n;
+   }
    jbuild_job b;
    b.build = build;
    b.bkeys = bkeys;
