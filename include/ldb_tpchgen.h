@@ -63,7 +63,21 @@ enum { C_CUSTKEY = 0,
        C_NATIONKEY,
        C_ACCTBAL,
        C_MKTSEGMENT,
+       C_NAME, /* "Customer#%09d" of the customer key: fixed 18 bytes (TPC-H spec 4.2.3) */
        C_NCOLS };
+#define LDB_TPCH_CNAME_LEN 18
+/* writes the 18 bytes of c_name for customer key `custkey` */
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline void ldb_tpch_c_name(int64_t custkey, char* out) {
+   const char pre[9] = {'C', 'u', 's', 't', 'o', 'm', 'e', 'r', '#'};
+   for (int i = 0; i < 9; i++) out[i] = pre[i];
+   for (int i = 8; i >= 0; i--) {
+      out[9 + i] = (char) ('0' + custkey % 10);
+      custkey /= 10;
+   }
+}
 enum { P_PARTKEY = 0,
        P_SIZE,
        P_RETAILPRICE,

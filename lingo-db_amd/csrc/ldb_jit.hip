@@ -155,7 +155,16 @@ hipFunction_t ldb_jit_kernel(const char* header, const char* struct_name, const 
       auto e = std::make_unique<JitModule>();
       e->key = key;
       auto t0 = std::chrono::steady_clock::now();
-      bool ok = compile(build_source(header, struct_name, kernels_src, (const unsigned char*) meta, meta_bytes), &e->code, &e->error);
+      const std::string src = build_source(header, struct_name, kernels_src, (const unsigned char*) meta, meta_bytes);
+      if (const char* dir = getenv("LDB_JIT_DUMP_DIR")) { // the specialised translation unit, for offline ISA inspection
+         char path[512];
+         snprintf(path, sizeof(path), "%s/%s_%016llx.hip", dir, kernel_name, (unsigned long long) h);
+         if (FILE* f = fopen(path, "wb")) {
+            fwrite(src.data(), 1, src.size(), f);
+            fclose(f);
+         }
+      }
+      bool ok = compile(src, &e->code, &e->error);
       g_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (ok) {
          if (const char* dir = getenv("LDB_JIT_DUMP_DIR")) { // code objects for llvm-objdump inspection

@@ -126,6 +126,14 @@ __global__ void k_gen_str_fill(StrDomain dom, int32_t table, int32_t col, int64_
    }
 }
 
+// c_name = "Customer#%09d": fixed width, so offsets are closed-form
+__global__ void k_gen_cname(int64_t row0, uint64_t n, int64_t* offs, char* out) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i <= n; i += (uint64_t) gridDim.x * blockDim.x) {
+      offs[i] = (int64_t) i * LDB_TPCH_CNAME_LEN;
+      if (i < n) ldb_tpch_c_name(row0 + (int64_t) i + 1, out + i * LDB_TPCH_CNAME_LEN);
+   }
+}
+
 static const char* const* domain_strings(int32_t table, int32_t col) {
    if (table == LDB_TPCH_LINEITEM && col == L_SHIPINSTRUCT) return ldb_tpch_instructs;
    if (table == LDB_TPCH_LINEITEM && col == L_SHIPMODE) return ldb_tpch_shipmodes;
@@ -147,7 +155,7 @@ struct ColDef {
 #define CT_STR {LDB_T_UTF8, 0, 0, 0}
 static const ColDef LINEITEM_COLS[L_NCOLS] = {{"l_orderkey", CT_I32}, {"l_partkey", CT_I32}, {"l_suppkey", CT_I32}, {"l_linenumber", CT_I32}, {"l_quantity", CT_DEC}, {"l_extendedprice", CT_DEC}, {"l_discount", CT_DEC}, {"l_tax", CT_DEC}, {"l_returnflag", CT_CH}, {"l_linestatus", CT_CH}, {"l_shipdate", CT_DATE}, {"l_commitdate", CT_DATE}, {"l_receiptdate", CT_DATE}, {"l_shipinstruct", CT_STR}, {"l_shipmode", CT_STR}};
 static const ColDef ORDERS_COLS[O_NCOLS] = {{"o_orderkey", CT_I32}, {"o_custkey", CT_I32}, {"o_orderstatus", CT_CH}, {"o_totalprice", CT_DEC}, {"o_orderdate", CT_DATE}, {"o_orderpriority", CT_STR}, {"o_shippriority", CT_I32}};
-static const ColDef CUSTOMER_COLS[C_NCOLS] = {{"c_custkey", CT_I32}, {"c_nationkey", CT_I32}, {"c_acctbal", CT_DEC}, {"c_mktsegment", CT_STR}};
+static const ColDef CUSTOMER_COLS[C_NCOLS] = {{"c_custkey", CT_I32}, {"c_nationkey", CT_I32}, {"c_acctbal", CT_DEC}, {"c_mktsegment", CT_STR}, {"c_name", CT_STR}};
 static const ColDef PART_COLS[P_NCOLS] = {{"p_partkey", CT_I32}, {"p_size", CT_I32}, {"p_retailprice", CT_DEC}};
 static const ColDef SUPPLIER_COLS[S_NCOLS] = {{"s_suppkey", CT_I32}, {"s_nationkey", CT_I32}, {"s_acctbal", CT_DEC}};
 static const ColDef PARTSUPP_COLS[PS_NCOLS] = {{"ps_partkey", CT_I32}, {"ps_suppkey", CT_I32}, {"ps_availqty", CT_I32}, {"ps_supplycost", CT_DEC}};
@@ -212,7 +220,12 @@ extern "C" int32_t ldb_gpu_tpch_generate(ldb_ctx* ctx, int32_t table_id, int64_t
       col.name = defs[c].name;
       col.type = defs[c].type;
       col.width = ldb_width_of(col.type, narrow);
-      if (col.type.type == LDB_T_UTF8) {
+      if (col.type.type == LDB_T_UTF8 && table_id == LDB_TPCH_CUSTOMER && c == C_NAME) {
+         col.value_bytes = n * LDB_TPCH_CNAME_LEN;
+         LDB_TRY(ldb_dev_alloc(ctx, &col.values, (size_t) col.value_bytes));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &col.offsets, 8 * (size_t) (n + 1)));
+         hipLaunchKernelGGL(k_gen_cname, dim3(grid), dim3(256), 0, ctx->stream, b, (uint64_t) n, col.offsets, (char*) col.values);
+      } else if (col.type.type == LDB_T_UTF8) {
          const char* const* strs = domain_strings(table_id, c);
          StrDomain dom;
          memset(&dom, 0, sizeof(dom));

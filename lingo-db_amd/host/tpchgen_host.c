@@ -55,6 +55,7 @@ static void put_dec(void* out, int64_t i, int64_t v) {
 /* kind of a column: 0 = int32-like (4 bytes), 1 = decimal128 (16 bytes), 2 = utf8 */
 static int col_kind(int32_t table, int32_t col) {
    if (ldb_tpch_str_domain(table, col)) return 2;
+   if (table == LDB_TPCH_CUSTOMER && col == C_NAME) return 2;
    switch (table) {
       case LDB_TPCH_LINEITEM: return (col >= L_QUANTITY && col <= L_TAX) ? 1 : 0;
       case LDB_TPCH_ORDERS: return col == O_TOTALPRICE ? 1 : 0;
@@ -72,6 +73,15 @@ int64_t ldb_tpch_host_column(int32_t table, int32_t col, int64_t n_orders, int32
    slice(table, n_orders, part, n_parts, &b, &e);
    const int64_t n = e - b;
    const int kind = col_kind(table, col);
+   if (kind == 2 && table == LDB_TPCH_CUSTOMER && col == C_NAME) {
+      for (int64_t i = 0; i < n; i++) {
+         if (offsets_out) offsets_out[i] = i * LDB_TPCH_CNAME_LEN;
+         if (out) ldb_tpch_c_name(b + i + 1, (char*) out + i * LDB_TPCH_CNAME_LEN);
+      }
+      if (offsets_out) offsets_out[n] = n * LDB_TPCH_CNAME_LEN;
+      if (bytes) *bytes = n * LDB_TPCH_CNAME_LEN;
+      return n;
+   }
    if (kind == 2) {
       const char* const* dom = domain(table, col);
       int64_t pos = 0;

@@ -274,6 +274,5 @@ class Oracle:
 
 
 def load():
-    if not os.path.exists(LIB):
-        build()
+    build()  # make: a no-op when the library is newer than its sources, so a stale checker is never loaded
     return Oracle(C.CDLL(LIB))

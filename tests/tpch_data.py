@@ -18,7 +18,7 @@ SCHEMAS = {
                ("l_receiptdate", pa.date32()), ("l_shipinstruct", pa.string()), ("l_shipmode", pa.string())],
     ORDERS: [("o_orderkey", pa.int32()), ("o_custkey", pa.int32()), ("o_orderstatus", CH), ("o_totalprice", DEC),
              ("o_orderdate", pa.date32()), ("o_orderpriority", pa.string()), ("o_shippriority", pa.int32())],
-    CUSTOMER: [("c_custkey", pa.int32()), ("c_nationkey", pa.int32()), ("c_acctbal", DEC), ("c_mktsegment", pa.string())],
+    CUSTOMER: [("c_custkey", pa.int32()), ("c_nationkey", pa.int32()), ("c_acctbal", DEC), ("c_mktsegment", pa.string()), ("c_name", pa.string())],
     PART: [("p_partkey", pa.int32()), ("p_size", pa.int32()), ("p_retailprice", DEC)],
     SUPPLIER: [("s_suppkey", pa.int32()), ("s_nationkey", pa.int32()), ("s_acctbal", DEC)],
     PARTSUPP: [("ps_partkey", pa.int32()), ("ps_suppkey", pa.int32()), ("ps_availqty", pa.int32()), ("ps_supplycost", DEC)],
