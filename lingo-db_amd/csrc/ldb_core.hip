@@ -723,6 +723,18 @@ int32_t ldb_make_dpred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out) {
    return LDB_OK;
 }
 
+// marks conjuncts whose lhs column is the previous conjunct's (range filters): the batched
+// evaluator loads the column once for both (ldb_device.h d_eval_conj_batch)
+void ldb_mark_same_col(DPred* preds, int32_t n) {
+   for (int32_t p = 1; p < n; p++) {
+      const DCol &a = preds[p - 1].col, &b = preds[p].col;
+      preds[p].same_col = a.values == b.values && a.offsets == b.offsets && a.validity == b.validity && a.rowids == b.rowids && a.type == b.type && a.width == b.width &&
+                                a.precision == b.precision
+                             ? 1
+                             : 0;
+   }
+}
+
 // ---------------------------------------------------------------- gather / materialize
 template <typename T>
 __global__ void k_gather_fixed(const T* __restrict__ src, const uint32_t* __restrict__ rowids, T* __restrict__ dst, uint64_t n) {

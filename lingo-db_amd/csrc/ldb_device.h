@@ -294,35 +294,63 @@ __device__ __forceinline__ bool d_pred_is_simple(const DPred& pm) {
    return narrow && pm.rhs_kind == LDB_RHS_INT && pm.op != LDB_F_IN && pm.op != LDB_F_NOTNULL;
 }
 
-// One conjunct over U rows of the same thread, load phase separated from the compare phase: the
-// U loads are independent and issue back to back (memory-level parallelism) instead of one
-// load → compare → branch chain per row.  Rows with pass[u] == false are neither loaded nor
-// changed.  Falls back to d_eval_pred for the non-simple shapes.
+// A conjunction over U rows of the same thread, predicate-major, load phase separated from the
+// compare phase: the U loads of one conjunct are independent and issue back to back under their
+// own exec masks (memory-level parallelism: one memory round trip per conjunct column for the
+// whole batch) instead of one load → wait → compare → branch chain per row and conjunct.
+// (Branching on pass[u] around the loads instead gets jump-threaded into one code path per
+// pass/fail combination: a 25k-line kernel that ran 2x slower than the row-major one.)
+// Consecutive simple conjuncts on the same column (`same_col`, set by the host: l_shipdate >= a
+// AND l_shipdate < b) share one load.  Rows with pass[u] == false are not loaded; a wave whose
+// rows all failed skips the loads (execz).  Non-simple shapes go through d_eval_pred.
 template <int U>
-__device__ __forceinline__ void d_eval_pred_batch(PV p, const uint64_t (&rows)[U], bool (&pass)[U]) {
-   if (d_pred_is_simple(p.m)) {
-      const CV col = p.col();
-      int64_t val[U];
-      bool ok[U];
+__device__ __forceinline__ void d_eval_conj_batch(const DPred* mp, const DPred* __restrict__ dp, int np, const uint64_t (&rows)[U], bool (&pass)[U]) {
+   int64_t val[U];
+   bool ok[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-         val[u] = 0;
-         ok[u] = false;
-         if (pass[u]) {
-            uint32_t row = d_phys_row(col, rows[u]);
-            ok[u] = d_valid(col, row);
-            if (ok[u]) val[u] = d_load_i64(col, row);
+   for (int u = 0; u < U; u++) {
+      val[u] = 0;
+      ok[u] = false;
+   }
+   LDB_UNROLL
+   for (int p = 0; p < np; p++) {
+      const PV pv(mp[p], dp[p]);
+      if (d_pred_is_simple(mp[p])) {
+         const bool reuse = p > 0 && mp[p].same_col && d_pred_is_simple(mp[p - 1]);
+         if (!reuse) {
+            const CV col = pv.col();
+            if (!col.m.rowids && !col.m.validity) {
+               // dense column: a failed row loads row 0 instead (one broadcast line, no branch), so
+               // the batch's loads carry no control dependence at all.  Callers guarantee n >= 1.
+#pragma unroll
+               for (int u = 0; u < U; u++) {
+                  ok[u] = true;
+                  val[u] = d_load_i64(col, pass[u] ? (uint32_t) rows[u] : 0u);
+               }
+            } else {
+#pragma unroll
+               for (int u = 0; u < U; u++) {
+                  ok[u] = false;
+                  val[u] = 0;
+                  if (pass[u]) {
+                     uint32_t row = d_phys_row(col, rows[u]);
+                     ok[u] = d_valid(col, row);
+                     if (ok[u]) val[u] = d_load_i64(col, row);
+                  }
+               }
+            }
          }
-      }
-      const bool fits = p.m.hi == ((int64_t) p.m.lo >> 63);
+         const bool fits = mp[p].hi == ((int64_t) mp[p].lo >> 63);
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-         if (pass[u]) pass[u] = ok[u] && (fits ? d_cmp_vals<int64_t>(p.m.op, val[u], (int64_t) p.m.lo) : d_cmp_apply(p.m.op, p.m.hi < 0 ? 1 : -1));
-      }
-   } else {
+         for (int u = 0; u < U; u++) {
+            const bool c = fits ? d_cmp_vals<int64_t>(mp[p].op, val[u], (int64_t) mp[p].lo) : d_cmp_apply(mp[p].op, mp[p].hi < 0 ? 1 : -1);
+            pass[u] = pass[u] & ok[u] & c; // unconditional: no branch to correlate with the load's
+         }
+      } else {
 #pragma unroll
-      for (int u = 0; u < U; u++)
-         if (pass[u]) pass[u] = d_eval_pred(p, rows[u]);
+         for (int u = 0; u < U; u++)
+            if (pass[u]) pass[u] = d_eval_pred(pv, rows[u]);
+      }
    }
 }
 

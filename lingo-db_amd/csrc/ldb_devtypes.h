@@ -51,7 +51,7 @@ struct DPred {
    uint64_t in_lo[LDB_MAX_IN];
    int64_t in_hi[LDB_MAX_IN];
    int32_t in_off[LDB_MAX_IN + 1];
-   int32_t pad;
+   int32_t same_col; // lhs column identical to the previous conjunct's (host: ldb_mark_same_col)
    char in_blob[LDB_MAX_IN * 16];
 };
 

@@ -27,7 +27,7 @@
 // 1: evaluate each conjunct for the whole row batch (loads first, then compares);
 // 0: evaluate the conjunction row by row (a dependent load → compare chain per row)
 #ifndef GB_PRED_BATCH
-#define GB_PRED_BATCH 0
+#define GB_PRED_BATCH 1
 #endif
 #define GB_MAX_COLS 12
 #define GB_MAX_ACCS 20
@@ -364,8 +364,7 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
       // compares), so the dependent filter chain costs one memory round trip per conjunct column
       // for the whole batch rather than one per row
 #if GB_PRED_BATCH
-      LDB_UNROLL
-      for (int p = 0; p < np; p++) d_eval_pred_batch<GB_ROWS>(PV(m.preds[p], d->preds[p]), rowsv, passv);
+      d_eval_conj_batch<GB_ROWS>(m.preds, d->preds, np, rowsv, passv);
 #else
 #pragma unroll
       for (int u = 0; u < GB_ROWS; u++) {

@@ -214,6 +214,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    h->n_rows = (uint64_t) in->n_rows;
    h->n_preds = n_preds;
    for (int32_t p = 0; p < n_preds; p++) LDB_TRY(ldb_make_dpred(in, &preds[p], &h->preds[p]));
+   ldb_mark_same_col(h->preds, n_preds);
    LDB_TRY(ldb_make_dkeys(in, keys, n_keys, &h->keys));
    h->keyless = n_keys == 0;
    GbBuilder b{in, h, {}};

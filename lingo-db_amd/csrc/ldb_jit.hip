@@ -109,7 +109,10 @@ static bool compile(const std::string& src, std::vector<char>* code, std::string
          }
       }
    }
-   std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics"};
+   // The descriptor loops (LDB_UNROLL) must unroll completely or nothing folds: before unrolling
+   // their bodies hold the whole generic interpreter, which exceeds the default pragma-unroll
+   // size limit and silently leaves a generic loop reading the constexpr descriptor from memory.
+   std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-mllvm", "-pragma-unroll-threshold=4000000"};
    for (auto& e : extra) opts.push_back(e.c_str());
    hiprtcResult r = hiprtcCompileProgram(prog, (int) opts.size(), opts.data());
    if (r != HIPRTC_SUCCESS) {

@@ -26,12 +26,10 @@ __device__ __forceinline__ bool d_eval_conj(const DScan& m, const DScan* __restr
    return pass;
 }
 
-// the conjunction over U rows of one thread, predicate-major (see d_eval_pred_batch)
+// the conjunction over U rows of one thread, predicate-major (ldb_device.h d_eval_conj_batch)
 template <int U>
 __device__ __forceinline__ void d_eval_conj_batch(const DScan& m, const DScan* __restrict__ d, const uint64_t (&rows)[U], bool (&pass)[U]) {
-   const int np = m.n_preds;
-   LDB_UNROLL
-   for (int p = 0; p < np; p++) d_eval_pred_batch<U>(PV(m.preds[p], d->preds[p]), rows, pass);
+   d_eval_conj_batch<U>(m.preds, d->preds, m.n_preds, rows, pass);
 }
 
 // One block = 16384 consecutive rows; each wave handles 64 of the block's 256 bitmap words,
