@@ -141,7 +141,21 @@ def main():
             if n_p:
                 extras["q3_probe_launches_per_step"] = n_p / args.steps
                 extras["q3_probe_ms_per_step"] = round(ms_p / args.steps, 4)
-        probe = runner.probe_microbench() if 3 in queries else None
+        if roofline:
+            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+            # runs of this same command; tools/pmc_summary.py calibrates the gfx950 FETCH_SIZE unit on a
+            # kernel of known byte count).  Counters cannot be read from inside the timed process, so the
+            # committed summary of the matching configuration is quoted; null when there is none.
+            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_q%d_sf%g%s.json" % (roof_q, args.sf, "_narrow" if args.narrow_decimals else ""))
+            if world == 1 and os.path.exists(pmc_path):
+                with open(pmc_path) as f:
+                    pmc = json.load(f)
+                k = pmc["kernels"].get("k_groupby_spec") or pmc["kernels"].get("k_groupby")
+                if k:
+                    roofline["traffic"] = round(k["fetch_bytes"] + k.get("write_raw_bytes", 0.0))
+                    roofline["traffic_source"] = os.path.relpath(pmc_path, ROOT)
+        probe = runner.probe_microbench() if any(q in queries for q in (3, 4, 18)) else None  # needs o_orderkey, o_orderdate, l_orderkey
+        ceiling = runner.hbm_ceiling()
         cpu = None
         if world == 1 and args.cpu_sample_sf > 0:
             cpu = tpch_plans.cpu_baseline(queries, args.cpu_sample_sf)
@@ -166,6 +180,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        out["hbm_ceiling"] = ceiling
         if probe:
             out["join_probe"] = probe
         out.update(extras)

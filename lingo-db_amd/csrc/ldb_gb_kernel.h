@@ -14,16 +14,11 @@
 #include "ldb_keys.h"
 
 #define GB_BLOCK 256
-// rows per thread per loop iteration: the specialised kernel keeps only the referenced columns in
-// registers, so it can afford 4 rows in flight; the generic kernel indexes its value cache
-// dynamically and stays at 1
-#ifndef GB_ROWS
-#ifdef LDB_JIT_SPECIALIZED
-#define GB_ROWS 4
-#else
-#define GB_ROWS 1
-#endif
-#endif
+// Rows per thread per loop iteration = gb_body's template argument.  The specialised kernel keeps
+// only the referenced columns in registers, so it can afford several rows in flight: the host
+// picks DGroupBy::batch_rows (8 for a multi-column filter chain — every conjunct column costs a
+// dependent memory round trip per batch, so deeper batches amortise it: Q6 2.1 → 1.8 ms — else 4);
+// the generic kernel indexes its value cache dynamically and stays at 1.
 // 1: evaluate each conjunct for the whole row batch (loads first, then compares);
 // 0: evaluate the conjunction row by row (a dependent load → compare chain per row)
 #ifndef GB_PRED_BATCH
@@ -90,6 +85,7 @@ struct DGroupBy {
    // ---- metadata (+ the addresses inside the DCols, which are run-time too)
    int32_t n_preds, n_cols, n_accs, n_words, n_cpreds, n_outs;
    int32_t keyless, use_lds;
+   int32_t batch_rows, pad0; // rows per thread per iteration of the specialised kernel (1, 2, 4 or 8)
    DKeys keys;
    DPred preds[LDB_MAX_PREDS];
    DPred cpreds[GB_MAX_CPREDS];
@@ -322,6 +318,7 @@ __device__ __forceinline__ int32_t d_lds_slot(const DGroupBy& m, KV keys, unsign
 
 // the kernel body: `m` = metadata source (== *d in the generic kernel, a constexpr in a
 // specialised one), `d` = this launch's descriptor in device memory (addresses, sizes)
+template <int ROWS>
 __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __restrict__ d, unsigned long long* gb_lds) {
    const uint32_t S = d->lds_slots, R = d->lds_reps;
    const uint32_t SR = S * R;
@@ -344,19 +341,19 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
    const KV keys(m.keys, d->keys);
    unsigned long long* g_acc = gptr_mut<unsigned long long>(d->g_acc);
    const uint64_t g_cap = d->g_cap;
-   // GB_ROWS rows per thread per iteration: phase A issues the predicate / key / value loads of all
+   // ROWS rows per thread per iteration: phase A issues the predicate / key / value loads of all
    // rows (independent → memory-level parallelism, the dependent predicate chain of a selective
    // scan overlaps across rows), phase B folds each surviving row into its group.
    const uint64_t tid = blockIdx.x * (uint64_t) GB_BLOCK + threadIdx.x;
    const uint64_t nthreads = (uint64_t) gridDim.x * GB_BLOCK;
-   for (uint64_t i0 = tid; i0 < n; i0 += nthreads * GB_ROWS) {
-      bool passv[GB_ROWS];
-      uint64_t hv[GB_ROWS];
-      long long rvv[GB_ROWS][GB_MAX_COLS];
-      uint32_t rvalidv[GB_ROWS];
-      uint64_t rowsv[GB_ROWS];
+   for (uint64_t i0 = tid; i0 < n; i0 += nthreads * ROWS) {
+      bool passv[ROWS];
+      uint64_t hv[ROWS];
+      long long rvv[ROWS][GB_MAX_COLS];
+      uint32_t rvalidv[ROWS];
+      uint64_t rowsv[ROWS];
 #pragma unroll
-      for (int u = 0; u < GB_ROWS; u++) {
+      for (int u = 0; u < ROWS; u++) {
          rowsv[u] = i0 + (uint64_t) u * nthreads;
          passv[u] = rowsv[u] < n;
       }
@@ -364,10 +361,10 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
       // compares), so the dependent filter chain costs one memory round trip per conjunct column
       // for the whole batch rather than one per row
 #if GB_PRED_BATCH
-      d_eval_conj_batch<GB_ROWS>(m.preds, d->preds, np, rowsv, passv);
+      d_eval_conj_batch<ROWS>(m.preds, d->preds, np, rowsv, passv);
 #else
 #pragma unroll
-      for (int u = 0; u < GB_ROWS; u++) {
+      for (int u = 0; u < ROWS; u++) {
          bool pass = passv[u];
          LDB_UNROLL
          for (int p = 0; p < np; p++)
@@ -376,7 +373,7 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
       }
 #endif
 #pragma unroll
-      for (int u = 0; u < GB_ROWS; u++) {
+      for (int u = 0; u < ROWS; u++) {
          hv[u] = 0;
          rvalidv[u] = 0;
          if (passv[u]) {
@@ -385,7 +382,7 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
          }
       }
 #pragma unroll
-      for (int u = 0; u < GB_ROWS; u++) {
+      for (int u = 0; u < ROWS; u++) {
       if (!passv[u]) continue;
       const uint64_t i = i0 + (uint64_t) u * nthreads;
       const uint64_t h = hv[u];

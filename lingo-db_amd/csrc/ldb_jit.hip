@@ -208,7 +208,8 @@ hipFunction_t ldb_jit_kernel(const char* header, const char* struct_name, const 
 // ---------------------------------------------------------------- group-by
 static const char* GB_SPEC_SRC =
    "extern __shared__ __attribute__((aligned(16))) unsigned long long gb_lds_dyn[];\n"
-   "extern \"C\" __global__ __launch_bounds__(GB_BLOCK) void k_groupby_spec(const DGroupBy* __restrict__ d) { gb_body(LDB_META, d, gb_lds_dyn); }\n";
+   "#ifndef GB_ROWS\n#define GB_ROWS (LDB_META.batch_rows > 0 ? LDB_META.batch_rows : 4)\n#endif\n"
+   "extern \"C\" __global__ __launch_bounds__(GB_BLOCK) void k_groupby_spec(const DGroupBy* __restrict__ d) { gb_body<GB_ROWS>(LDB_META, d, gb_lds_dyn); }\n";
 
 static void gb_meta(const DGroupBy* h, DGroupBy* m) {
    memcpy(m, h, sizeof(DGroupBy));

@@ -156,7 +156,152 @@ static int32_t radix_sort_perm(ldb_ctx* ctx, const uint64_t* keys, int words, ui
    return LDB_OK;
 }
 
-static int32_t sort_perm(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int32_t n_specs, uint32_t** perm_out) {
+// ---------------------------------------------------------------- small inputs: one workgroup, bitonic in LDS
+// TPC-H's ORDER BYs are post-aggregation (4 .. a few thousand rows): a radix sort there is ~100
+// launches of nothing.  One workgroup sorts up to SS_MAX row numbers by full record compare
+// (ties: lower row number first = stable for an ascending input permutation).
+#define SS_MAX 4096
+#define SS_BLOCK 1024
+__device__ __forceinline__ bool d_rec_greater(const uint64_t* __restrict__ keys, int words, uint32_t a, uint32_t b) {
+   if (a == 0xFFFFFFFFu || b == 0xFFFFFFFFu) return a == 0xFFFFFFFFu && b != 0xFFFFFFFFu; // padding sorts last
+   for (int w = 0; w < words; w++) {
+      uint64_t x = keys[(uint64_t) a * words + w], y = keys[(uint64_t) b * words + w];
+      if (x != y) return x > y;
+   }
+   return a > b;
+}
+__global__ __launch_bounds__(SS_BLOCK) void k_small_sort(const uint64_t* __restrict__ keys, int words, uint32_t* __restrict__ perm, uint32_t n) {
+   __shared__ uint32_t idx[SS_MAX];
+   uint32_t m = 1;
+   while (m < n) m <<= 1;
+   for (uint32_t i = threadIdx.x; i < m; i += SS_BLOCK) idx[i] = i < n ? perm[i] : 0xFFFFFFFFu;
+   __syncthreads();
+   for (uint32_t k = 2; k <= m; k <<= 1) {
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+         for (uint32_t i = threadIdx.x; i < m; i += SS_BLOCK) {
+            uint32_t l = i ^ j;
+            if (l > i) {
+               uint32_t a = idx[i], b = idx[l];
+               bool asc = (i & k) == 0;
+               if (d_rec_greater(keys, words, a, b) == asc) {
+                  idx[i] = b;
+                  idx[l] = a;
+               }
+            }
+         }
+         __syncthreads();
+      }
+   }
+   for (uint32_t i = threadIdx.x; i < n; i += SS_BLOCK) perm[i] = idx[i];
+}
+
+// ---------------------------------------------------------------- top-k: radix select on the leading key word
+// state[0] = prefix found so far (high bits), state[1] = rank still to find inside the prefix group
+__global__ void k_sel_hist(const uint64_t* __restrict__ keys, int words, uint64_t n, int shift, const unsigned long long* __restrict__ state, uint32_t* __restrict__ hist) {
+   __shared__ uint32_t lh[256];
+   for (int k = threadIdx.x; k < 256; k += blockDim.x) lh[k] = 0;
+   __syncthreads();
+   const uint64_t prefix = state[0];
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      uint64_t w = keys[i * words];
+      bool in = shift == 56 || (w >> (shift + 8)) == (prefix >> (shift + 8));
+      if (in) atomicAdd(&lh[(w >> shift) & 255u], 1u);
+   }
+   __syncthreads();
+   for (int k = threadIdx.x; k < 256; k += blockDim.x)
+      if (lh[k]) atomicAdd(&hist[k], lh[k]);
+}
+__global__ void k_sel_pick(unsigned long long* __restrict__ state, uint32_t* __restrict__ hist, int shift) {
+   if (threadIdx.x == 0) {
+      unsigned long long rank = state[1], cum = 0;
+      int dsel = 255;
+      for (int dg = 0; dg < 256; dg++) {
+         if (cum + hist[dg] > rank) {
+            dsel = dg;
+            break;
+         }
+         cum += hist[dg];
+      }
+      state[0] |= (unsigned long long) dsel << shift;
+      state[1] = rank - cum;
+   }
+   __syncthreads();
+   for (int k = threadIdx.x; k < 256; k += blockDim.x) hist[k] = 0;
+}
+// candidates = rows whose leading word is <= the k-th smallest one; one bitmap word + popcount per wave
+__global__ void k_sel_flags(const uint64_t* __restrict__ keys, int words, uint64_t n, const unsigned long long* __restrict__ state, uint64_t* __restrict__ bitmap,
+                            uint32_t* __restrict__ pop) {
+   const uint64_t t = state[0];
+   const uint64_t n_words = (n + 63) / 64;
+   const uint32_t lane = threadIdx.x & 63;
+   for (uint64_t w = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6; w < n_words; w += ((uint64_t) gridDim.x * blockDim.x) >> 6) {
+      uint64_t i = w * 64 + lane;
+      uint64_t mask = __ballot(i < n && keys[i * words] <= t);
+      if (lane == 0) {
+         bitmap[w] = mask;
+         pop[w] = (uint32_t) __popcll(mask);
+      }
+   }
+}
+__global__ void k_sel_expand(const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ off, uint32_t* __restrict__ out, uint64_t n_words) {
+   const uint32_t lane = threadIdx.x & 63;
+   for (uint64_t w = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6; w < n_words; w += ((uint64_t) gridDim.x * blockDim.x) >> 6) {
+      uint64_t mask = bitmap[w];
+      if ((mask >> lane) & 1) out[off[w] + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t) (w * 64 + lane);
+   }
+}
+
+static int32_t radix_sort_perm(ldb_ctx* ctx, const uint64_t* keys, int words, uint32_t** perm_io, uint64_t n, int first_word, int last_word, int bits_lo, int bits_hi);
+
+// the k smallest records (all of them when k >= n), sorted: *perm_out holds min(k, n) row numbers
+static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint64_t n, uint64_t k, uint32_t** perm_out) {
+   uint32_t* perm;
+   const int grid = ldb_grid_for(ctx, (int64_t) n, 256, 8);
+   uint64_t m = n; // rows to sort
+   if (k < n && n > SS_MAX) {
+      // radix select: 8 passes of 8 bits over the leading word, decisions stay on the device
+      unsigned long long* state;
+      uint32_t* hist;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &state, 16));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &hist, 4 * 256));
+      unsigned long long init[2] = {0ull, (unsigned long long) (k ? k - 1 : 0)};
+      LDB_HIP(hipMemcpyAsync(state, init, 16, hipMemcpyHostToDevice, ctx->stream));
+      LDB_HIP(hipStreamSynchronize(ctx->stream)); // init[] is a stack buffer
+      LDB_HIP(hipMemsetAsync(hist, 0, 4 * 256, ctx->stream));
+      for (int shift = 56; shift >= 0; shift -= 8) {
+         hipLaunchKernelGGL(k_sel_hist, dim3(grid), dim3(256), 0, ctx->stream, keys, words, n, shift, (const unsigned long long*) state, hist);
+         hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(256), 0, ctx->stream, state, hist, shift);
+      }
+      const uint64_t n_words = (n + 63) / 64;
+      uint64_t* bitmap;
+      uint32_t *pop, *off;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmap, 8 * (size_t) n_words));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) n_words));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) n_words));
+      hipLaunchKernelGGL(k_sel_flags, dim3(grid), dim3(256), 0, ctx->stream, keys, words, n, (const unsigned long long*) state, bitmap, pop);
+      uint64_t* d_total = (uint64_t*) ctx->d_scratch;
+      LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, (int64_t) n_words, d_total));
+      LDB_TRY(ldb_read_u64(ctx, d_total, &m));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &perm, 4 * (size_t) (m ? m : 1)));
+      hipLaunchKernelGGL(k_sel_expand, dim3(grid), dim3(256), 0, ctx->stream, (const uint64_t*) bitmap, (const uint32_t*) off, perm, n_words);
+      LDB_HIP(hipGetLastError());
+      ldb_dev_free(ctx, state);
+      ldb_dev_free(ctx, hist);
+      ldb_dev_free(ctx, bitmap);
+      ldb_dev_free(ctx, pop);
+      ldb_dev_free(ctx, off);
+   } else {
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &perm, 4 * (size_t) (n ? n : 1)));
+      if (n) hipLaunchKernelGGL(k_iota, dim3(grid), dim3(256), 0, ctx->stream, perm, n);
+   }
+   if (m > 1 && m <= SS_MAX) hipLaunchKernelGGL(k_small_sort, dim3(1), dim3(SS_BLOCK), 0, ctx->stream, keys, words, perm, (uint32_t) m);
+   else LDB_TRY(radix_sort_perm(ctx, keys, words, &perm, m, 0, words - 1, 0, 64));
+   LDB_HIP(hipGetLastError());
+   *perm_out = perm;
+   return LDB_OK;
+}
+
+static int32_t sort_perm(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int32_t n_specs, uint64_t k, uint32_t** perm_out) {
    if (n_specs < 1 || n_specs > SORT_MAX_SPECS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "sort: %d keys (1..%d supported)", n_specs, SORT_MAX_SPECS);
    const uint64_t n = (uint64_t) in->n_rows;
    auto hp = std::make_unique<DSort>();
@@ -196,33 +341,29 @@ static int32_t sort_perm(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, 
    }
    h->words = (off + 7) / 8;
    uint64_t* keys;
-   uint32_t* perm;
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &keys, 8 * (size_t) h->words * (size_t) (n ? n : 1)));
-   LDB_TRY(ldb_dev_alloc(ctx, (void**) &perm, 4 * (size_t) (n ? n : 1)));
    DSort* d;
    LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-   if (n) {
-      hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d, keys);
-      hipLaunchKernelGGL(k_iota, dim3(grid), dim3(256), 0, ctx->stream, perm, n);
-   }
+   if (n) hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d, keys);
    LDB_HIP(hipGetLastError());
-   LDB_TRY(radix_sort_perm(ctx, keys, h->words, &perm, n, 0, h->words - 1, 0, 64));
+   LDB_TRY(sort_records(ctx, keys, h->words, n, k, perm_out));
    ldb_dev_free(ctx, d);
    ldb_dev_free(ctx, keys);
-   *perm_out = perm;
    return LDB_OK;
 }
 
 extern "C" int32_t ldb_gpu_sort(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int32_t n_specs, ldb_rel** out) {
    if (!ctx || !in || !out) LDB_FAIL(LDB_ERR_INVALID, "sort: NULL argument");
    uint32_t* perm;
-   LDB_TRY(sort_perm(ctx, in, specs, n_specs, &perm));
+   LDB_TRY(sort_perm(ctx, in, specs, n_specs, (uint64_t) in->n_rows, &perm));
    return ldb_rel_select(ctx, in, perm, in->n_rows, out);
 }
+// Heap (reference src/runtime/Heap.cpp:8-72): the k smallest rows under the comparator, sorted.
+// Radix select on the leading key word → the few candidate rows → sorted (see sort_records).
 extern "C" int32_t ldb_gpu_topk(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int32_t n_specs, int64_t k, ldb_rel** out) {
    if (!ctx || !in || !out || k < 0) LDB_FAIL(LDB_ERR_INVALID, "topk: bad argument");
    uint32_t* perm;
-   LDB_TRY(sort_perm(ctx, in, specs, n_specs, &perm));
+   LDB_TRY(sort_perm(ctx, in, specs, n_specs, (uint64_t) k, &perm));
    return ldb_rel_select(ctx, in, perm, std::min<int64_t>(k, in->n_rows), out);
 }
 

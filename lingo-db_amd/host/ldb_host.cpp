@@ -423,6 +423,144 @@ extern "C" int32_t ldb_plan_tpch_q3(ldb_ctx* ctx, const ldb_table* cust, const l
    });
 }
 
+namespace {
+// residual column-vs-column conjunct (evaluated by generated db.compare in the reference, not by
+// Restrictions: only column-vs-constant filters are pushed into the scan)
+ldb_filter_desc colCompare(ldb_colref a, FilterOp op, ldb_colref b) {
+   ldb_filter_desc d;
+   memset(&d, 0, sizeof(d));
+   d.col = a;
+   d.op = (int32_t) op;
+   d.rhs_kind = LDB_RHS_COLUMN;
+   d.rhs_col = b;
+   return d;
+}
+std::vector<ldb_filter_desc> conj(const Restrictions& r, std::initializer_list<ldb_filter_desc> more) {
+   std::vector<ldb_filter_desc> v(r.data(), r.data() + r.size());
+   v.insert(v.end(), more.begin(), more.end());
+   return v;
+}
+// sum(case when <preds> then 1 else 0 end): integer literals are int32, SUM keeps the argument
+// type (sql_analyzer.cpp:2617-2631) → int32
+ldb_agg_spec sumCaseOne(const Restrictions& when) {
+   ldb_agg_spec a;
+   memset(&a, 0, sizeof(a));
+   a.fn = LDB_AGG_SUM;
+   a.arg.n_terms = 1;
+   a.arg.t[0].n_factors = 1;
+   a.arg.t[0].f[0] = {0, {0, 0}, 1, 0};
+   a.out_type = LDB_T_INT32;
+   if (when.size() > LDB_MAX_AGG_PREDS) throw std::runtime_error("conditional aggregate: too many conjuncts");
+   a.n_preds = when.size();
+   for (int32_t p = 0; p < when.size(); p++) a.preds[p] = when.data()[p];
+   return a;
+}
+} // namespace
+
+// TPC-H Q4 (resources/sql/tpch/4.sql): orders of one quarter that have a late lineitem (EXISTS →
+// semi join, orders kept = the hash-table side), count per o_orderpriority, ordered by it.
+extern "C" int32_t ldb_plan_tpch_q4(ldb_ctx* ctx, const ldb_table* ord, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel o0(ctx), o1(ctx), l0(ctx), l1(ctx), osel(ctx), sorted(ctx);
+      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q4 orders");
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q4 lineitem");
+      auto ro = Restrictions::create({{"o_orderdate", FilterOp::GTE, std::string("1993-07-01"), {}}, {"o_orderdate", FilterOp::LT, std::string("1993-10-01"), {}}}, ord);
+      check(ldb_gpu_scan_filter(ctx, o0.r, ro->data(), ro->size(), &o1.r), "q4 filter orders");
+      ldb_filter_desc late = colCompare({0, colOf(li, "l_commitdate")}, FilterOp::LT, {0, colOf(li, "l_receiptdate")});
+      check(ldb_gpu_scan_filter(ctx, l0.r, &late, 1, &l1.r), "q4 filter lineitem");
+      Ht ho(ctx);
+      ldb_colref ook{0, colOf(ord, "o_orderkey")}, lok{0, colOf(li, "l_orderkey")};
+      check(ldb_gpu_join_build(ctx, o1.r, &ook, 1, 1, &ho.h), "q4 build orders");
+      check(ldb_gpu_join_probe(ctx, ho.h, l1.r, &lok, 1, LDB_JOIN_SEMI_BUILD, &osel.r, nullptr), "q4 semi join");
+      ldb_colref key{0, colOf(ord, "o_orderpriority")};
+      ldb_agg_spec cnt = countStar();
+      Table grouped(ctx);
+      check(ldb_gpu_groupby(ctx, osel.r, nullptr, 0, &key, 1, &cnt, 1, 5, &grouped.t), "q4 groupby");
+      Rel g(ctx);
+      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q4 rel");
+      ldb_sort_spec spec{{0, 0}, 0, 0};
+      check(ldb_gpu_sort(ctx, g.r, &spec, 1, &sorted.r), "q4 sort");
+      ldb_colref outc[2] = {{0, 0}, {0, 1}};
+      check(ldb_gpu_materialize(ctx, sorted.r, outc, 2, result), "q4 materialize");
+   });
+}
+
+// TPC-H Q12 (resources/sql/tpch/12.sql): late lineitems of two ship modes in one year ⋈ orders,
+// per l_shipmode the number of high / low priority orders (conditional sums), ordered by mode.
+// The few filtered lineitems are the hash-table side; all orders probe it.
+extern "C" int32_t ldb_plan_tpch_q12(ldb_ctx* ctx, const ldb_table* ord, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel o0(ctx), l0(ctx), l1(ctx), ol(ctx), sorted(ctx);
+      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q12 orders");
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q12 lineitem");
+      auto rl = Restrictions::create({{"l_shipmode", FilterOp::IN, {}, std::vector<std::string>{"MAIL", "SHIP"}},
+                                      {"l_receiptdate", FilterOp::GTE, std::string("1994-01-01"), {}},
+                                      {"l_receiptdate", FilterOp::LT, std::string("1995-01-01"), {}}},
+                                     li);
+      ldb_colref commit{0, colOf(li, "l_commitdate")}, receipt{0, colOf(li, "l_receiptdate")}, ship{0, colOf(li, "l_shipdate")};
+      auto lp = conj(*rl, {colCompare(commit, FilterOp::LT, receipt), colCompare(ship, FilterOp::LT, commit)});
+      check(ldb_gpu_scan_filter(ctx, l0.r, lp.data(), (int32_t) lp.size(), &l1.r), "q12 filter lineitem");
+      Ht hl(ctx);
+      ldb_colref lok{0, colOf(li, "l_orderkey")}, ook{0, colOf(ord, "o_orderkey")};
+      check(ldb_gpu_join_build(ctx, l1.r, &lok, 1, 0, &hl.h), "q12 build lineitem");
+      check(ldb_gpu_join_probe(ctx, hl.h, o0.r, &ook, 1, LDB_JOIN_INNER, &ol.r, nullptr), "q12 probe orders"); // sides: orders, lineitem
+      auto high = Restrictions::create({{"o_orderpriority", FilterOp::IN, {}, std::vector<std::string>{"1-URGENT", "2-HIGH"}}}, ord, 0);
+      auto low = Restrictions::create({{"o_orderpriority", FilterOp::NEQ, std::string("1-URGENT"), {}}, {"o_orderpriority", FilterOp::NEQ, std::string("2-HIGH"), {}}}, ord, 0);
+      ldb_agg_spec aggs[2] = {sumCaseOne(*high), sumCaseOne(*low)};
+      ldb_colref key{1, colOf(li, "l_shipmode")};
+      Table grouped(ctx);
+      check(ldb_gpu_groupby(ctx, ol.r, nullptr, 0, &key, 1, aggs, 2, 2, &grouped.t), "q12 groupby");
+      Rel g(ctx);
+      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q12 rel");
+      ldb_sort_spec spec{{0, 0}, 0, 0};
+      check(ldb_gpu_sort(ctx, g.r, &spec, 1, &sorted.r), "q12 sort");
+      ldb_colref outc[3] = {{0, 0}, {0, 1}, {0, 2}};
+      check(ldb_gpu_materialize(ctx, sorted.r, outc, 3, result), "q12 materialize");
+   });
+}
+
+// TPC-H Q18 (resources/sql/tpch/18.sql): orders whose lineitems sum to more than 300 units — a
+// group-by with one group per order (1.5 M x SF groups) — joined back to customer, orders and
+// lineitem, grouped, top-100 by (o_totalprice desc, o_orderdate).
+extern "C" int32_t ldb_plan_tpch_q18(ldb_ctx* ctx, const ldb_table* cust, const ldb_table* ord, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel l0(ctx), o0(ctx), c0(ctx), g0(ctx), g1(ctx), o1(ctx), co(ctx), lco(ctx), top(ctx);
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q18 lineitem");
+      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q18 orders");
+      check(ldb_gpu_rel_from_table(ctx, cust, &c0.r), "q18 customer");
+      ldb_colref lok{0, colOf(li, "l_orderkey")}, qty{0, colOf(li, "l_quantity")};
+      DecimalType tq = decOf(li, qty.col);
+      ldb_agg_spec sumq = sumDec(product({colFactor(qty)}), tq);
+      Table perOrder(ctx);
+      check(ldb_gpu_groupby(ctx, l0.r, nullptr, 0, &lok, 1, &sumq, 1, std::max<int64_t>(1, ldb_gpu_table_rows(ord)), &perOrder.t), "q18 group by l_orderkey");
+      check(ldb_gpu_rel_from_table(ctx, perOrder.t, &g0.r), "q18 rel");
+      auto having = Restrictions::create({{"agg0", FilterOp::GT, (int64_t) 300, {}}}, perOrder.t);
+      check(ldb_gpu_scan_filter(ctx, g0.r, having->data(), having->size(), &g1.r), "q18 having");
+      // o_orderkey IN (subquery) → semi join, the small key set is the hash table
+      Ht hk(ctx), ho(ctx), hco(ctx);
+      ldb_colref gk{0, 0}, ook{0, colOf(ord, "o_orderkey")};
+      check(ldb_gpu_join_build(ctx, g1.r, &gk, 1, 1, &hk.h), "q18 build keys");
+      check(ldb_gpu_join_probe(ctx, hk.h, o0.r, &ook, 1, LDB_JOIN_SEMI, &o1.r, nullptr), "q18 semi join orders");
+      // customer ⋈ those orders (hash table on the few orders, customers probe)
+      ldb_colref ock{0, colOf(ord, "o_custkey")}, ck{0, colOf(cust, "c_custkey")};
+      check(ldb_gpu_join_build(ctx, o1.r, &ock, 1, 0, &ho.h), "q18 build orders");
+      check(ldb_gpu_join_probe(ctx, ho.h, c0.r, &ck, 1, LDB_JOIN_INNER, &co.r, nullptr), "q18 probe customer"); // sides: customer, orders
+      // lineitem ⋈ that on the order key
+      ldb_colref cok{1, ook.col};
+      check(ldb_gpu_join_build(ctx, co.r, &cok, 1, 1, &hco.h), "q18 build customer-orders");
+      check(ldb_gpu_join_probe(ctx, hco.h, l0.r, &lok, 1, LDB_JOIN_INNER, &lco.r, nullptr), "q18 probe lineitem"); // sides: lineitem, customer, orders
+      ldb_colref keys[5] = {{1, colOf(cust, "c_name")}, {1, ck.col}, {2, ook.col}, {2, colOf(ord, "o_orderdate")}, {2, colOf(ord, "o_totalprice")}};
+      Table grouped(ctx);
+      check(ldb_gpu_groupby(ctx, lco.r, nullptr, 0, keys, 5, &sumq, 1, std::max<int64_t>(1, ldb_gpu_rel_rows(ctx, co.r)), &grouped.t), "q18 groupby");
+      Rel g(ctx);
+      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q18 rel");
+      ldb_sort_spec specs[2] = {{{0, 4}, 1, 0}, {{0, 3}, 0, 0}};
+      check(ldb_gpu_topk(ctx, g.r, specs, 2, 100, &top.r), "q18 topk");
+      ldb_colref outc[6] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}};
+      check(ldb_gpu_materialize(ctx, top.r, outc, 6, result), "q18 materialize");
+   });
+}
+
 // ---------------------------------------------------------------- multi-GPU plan pieces
 // Row-range sharded fact tables: every rank runs the *_partial plan on its shard, the tiny partial
 // tables are exchanged over RCCL, and *_final merges them exactly as the reference merges

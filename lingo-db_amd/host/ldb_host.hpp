@@ -71,6 +71,9 @@ extern "C" {
 int32_t ldb_plan_tpch_q1(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q6(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q3(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q4(ldb_ctx* ctx, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q12(ldb_ctx* ctx, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q18(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
 const char* ldb_plan_last_error(void);
 // multi-GPU pieces: shard-local partial plans + merges of the exchanged partial tables
 int32_t ldb_plan_tpch_q1_partial(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);

@@ -456,3 +456,18 @@ class Context:
         t = C.c_void_p()
         check_plan(capi.host_lib().ldb_plan_tpch_q3(self.h, customer.h, orders.h, lineitem.h, C.byref(t)))
         return Table(self, t)
+
+    def plan_q4(self, orders, lineitem):
+        t = C.c_void_p()
+        check_plan(capi.host_lib().ldb_plan_tpch_q4(self.h, orders.h, lineitem.h, C.byref(t)))
+        return Table(self, t)
+
+    def plan_q12(self, orders, lineitem):
+        t = C.c_void_p()
+        check_plan(capi.host_lib().ldb_plan_tpch_q12(self.h, orders.h, lineitem.h, C.byref(t)))
+        return Table(self, t)
+
+    def plan_q18(self, customer, orders, lineitem):
+        t = C.c_void_p()
+        check_plan(capi.host_lib().ldb_plan_tpch_q18(self.h, customer.h, orders.h, lineitem.h, C.byref(t)))
+        return Table(self, t)

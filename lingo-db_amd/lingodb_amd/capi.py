@@ -188,6 +188,9 @@ HOST_API = {
     "ldb_plan_tpch_q1": (i32, [P, P, PP]),
     "ldb_plan_tpch_q6": (i32, [P, P, PP]),
     "ldb_plan_tpch_q3": (i32, [P, P, P, P, PP]),
+    "ldb_plan_tpch_q4": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q12": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q18": (i32, [P, P, P, P, PP]),
     "ldb_plan_last_error": (C.c_char_p, []),
     "ldb_plan_tpch_q1_partial": (i32, [P, P, PP]),
     "ldb_plan_tpch_q1_final": (i32, [P, P, PP]),

@@ -351,6 +351,28 @@ def test_sort_and_topk_parity(ctx, oracle, tpch):
     assert np.array_equal(perm, oracle.sort(HostTable(wt).rel(), [api.sort_spec((0, 1), True), api.sort_spec((0, 0))]))
 
 
+def test_topk_select_and_small_sort_paths(ctx, oracle, tpch):
+    """top-k = radix select on the leading key word + sort of the candidates; inputs <= 4096 rows
+    sort in one workgroup.  Ties on the leading word (few distinct values) and k around the
+    candidate-count thresholds must give exactly the stable-sort prefix."""
+    big = tpch["li"].slice(0, 30011)
+    g, h = ctx.register("topme", big).rel(), HostTable(big).rel()
+    cases = [[api.sort_spec((0, 5), True), api.sort_spec((0, 0))],  # extendedprice desc: nearly unique leading word
+             [api.sort_spec((0, 4)), api.sort_spec((0, 5), True)],  # quantity: 50 distinct values -> thousands of ties
+             [api.sort_spec((0, 8)), api.sort_spec((0, 10), True), api.sort_spec((0, 1))]]  # returnflag: 3 values
+    for specs in cases:
+        want = oracle.sort(h, specs)
+        for k in (0, 1, 10, 100, 4096, 5000, 30011, 40000):
+            assert np.array_equal(g.topk(specs, k).rowids(0), want[:k]), (k, specs)
+    for n in (1, 2, 63, 64, 65, 1000, 4096, 4097):
+        sub = tpch["li"].slice(100, n)
+        gs, hs = ctx.register("small%d" % n, sub).rel(), HostTable(sub).rel()
+        specs = [api.sort_spec((0, 14)), api.sort_spec((0, 6), True), api.sort_spec((0, 10))]
+        want = oracle.sort(hs, specs)
+        assert np.array_equal(gs.sort(specs).rowids(0), want)
+        assert np.array_equal(gs.topk(specs, 7).rowids(0), want[:7])
+
+
 # ---------------------------------------------------------------- materialize / partition
 def test_materialize_gathers_all_types(ctx, oracle, tpch):
     plist = [api.pred((0, 14), capi.F_EQ, "FOB"), api.pred((0, 6), capi.F_GTE, 9)]

@@ -12,8 +12,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 LINEITEM, ORDERS, CUSTOMER = 0, 1, 2
 # column ids of include/ldb_tpchgen.h
 L_ORDERKEY, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, L_TAX, L_RETURNFLAG, L_LINESTATUS, L_SHIPDATE = 0, 4, 5, 6, 7, 8, 9, 10
-O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY = 0, 1, 4, 6
-C_CUSTKEY, C_MKTSEGMENT = 0, 3
+L_COMMITDATE, L_RECEIPTDATE, L_SHIPMODE = 11, 12, 14
+O_ORDERKEY, O_CUSTKEY, O_TOTALPRICE, O_ORDERDATE, O_ORDERPRIORITY, O_SHIPPRIORITY = 0, 1, 3, 4, 5, 6
+C_CUSTKEY, C_MKTSEGMENT, C_NAME = 0, 3, 4
 
 
 class Database:
@@ -29,11 +30,30 @@ class Database:
             lcols |= {L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, L_SHIPDATE}
         if 3 in queries:
             lcols |= {L_ORDERKEY, L_EXTENDEDPRICE, L_DISCOUNT, L_SHIPDATE}
+        if 4 in queries:
+            lcols |= {L_ORDERKEY, L_COMMITDATE, L_RECEIPTDATE}
+        if 12 in queries:
+            lcols |= {L_ORDERKEY, L_SHIPDATE, L_COMMITDATE, L_RECEIPTDATE, L_SHIPMODE}
+        if 18 in queries:
+            lcols |= {L_ORDERKEY, L_QUANTITY}
+        lcols |= {L_EXTENDEDPRICE, L_SHIPDATE}  # hbm_ceiling() calibration scans
         self.lineitem = ctx.tpch_generate(LINEITEM, n_orders, rank, world, sorted(lcols), narrow)
         self.orders = self.customer = None
+        ocols, ccols = set(), set()
         if 3 in queries:
-            self.orders = ctx.tpch_generate(ORDERS, n_orders, rank, world, [O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY], narrow)
-            self.customer = ctx.tpch_generate(CUSTOMER, n_orders, rank, world, [C_CUSTKEY, C_MKTSEGMENT], narrow)
+            ocols |= {O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY}
+            ccols |= {C_CUSTKEY, C_MKTSEGMENT}
+        if 4 in queries:
+            ocols |= {O_ORDERKEY, O_ORDERDATE, O_ORDERPRIORITY}
+        if 12 in queries:
+            ocols |= {O_ORDERKEY, O_ORDERPRIORITY}
+        if 18 in queries:
+            ocols |= {O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_TOTALPRICE}
+            ccols |= {C_CUSTKEY, C_NAME}
+        if ocols:
+            self.orders = ctx.tpch_generate(ORDERS, n_orders, rank, world, sorted(ocols), narrow)
+        if ccols:
+            self.customer = ctx.tpch_generate(CUSTOMER, n_orders, rank, world, sorted(ccols), narrow)
         self.n_lineitem_total = (n_orders // 7) * 28 + [0, 4, 5, 12, 15, 21, 23, 28][n_orders % 7]
 
 
@@ -53,6 +73,12 @@ class Runner:
             res = self.ctx.plan_q6(self.db.lineitem)
         elif q == 3:
             res = self.ctx.plan_q3(self.db.customer, self.db.orders, self.db.lineitem)
+        elif q == 4:
+            res = self.ctx.plan_q4(self.db.orders, self.db.lineitem)
+        elif q == 12:
+            res = self.ctx.plan_q12(self.db.orders, self.db.lineitem)
+        elif q == 18:
+            res = self.ctx.plan_q18(self.db.customer, self.db.orders, self.db.lineitem)
         else:
             raise ValueError(f"TPC-H Q{q} has no plan yet")
         self.last[q] = res
@@ -84,6 +110,63 @@ class Runner:
             out["build_ms"] = round(ms_b / n_b, 4)
             out["build_grows_per_s"] = round(db.orders.rows / (ms_b / n_b * 1e-3) / 1e9, 3)
         ht.release()
+        # selective variant: build side filtered to ≈10 % of orders (o_orderdate < 1992-09-01)
+        ctx.prof_reset()
+        from lingodb_amd import api, capi
+
+        sel = orel.scan_filter([api.pred((0, db.orders.col("o_orderdate")), capi.F_LT, 8279)])
+        ht = sel.join_build([(0, ok)], unique=True)
+        for _ in range(reps):
+            matches = ht.probe_count(lrel, [(0, lk)])
+        n_p, ms_p = ctx.prof_all().get("k_join_probe_count", (0, 0.0))
+        if n_p:
+            avg = ms_p / n_p
+            out["selective"] = {"build_rows": sel.rows, "matches": matches, "table_slots": ht.slots, "probe_ms": round(avg, 4),
+                                "probe_grows_per_s": round(rows / (avg * 1e-3) / 1e9, 3)}
+        ht.release()
+        sel.release()
+        ctx.prof_reset()
+        return out
+
+    def hbm_ceiling(self, reps=5):
+        """What this GPU's HBM delivers to simple streaming kernels, measured in the same run
+        (SURVEY §8(d)): a device-to-device copy (read + write) and the library's own count-only
+        scan over one 16-byte column (read only)."""
+        torch, ctx, db = self.torch, self.ctx, self.db
+        out = {}
+        n = 1 << 30
+        a = torch.empty(n, dtype=torch.int32, device="cuda")
+        b = torch.empty_like(a)
+        a.fill_(1)
+        b.copy_(a)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        ev1.record()
+        torch.cuda.synchronize()
+        out["copy_gbs"] = round(2 * 4 * n * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
+        del a, b
+        from lingodb_amd import api, capi
+
+        col = db.lineitem.col("l_extendedprice")
+        lrel = db.lineitem.rel()
+        ctx.prof_reset()
+        for _ in range(reps):
+            lrel.scan_count([api.pred((0, col), capi.F_GTE, 0)])
+        n_s, ms_s = ctx.prof_all().get("k_scan_count", (0, 0.0))
+        if n_s:
+            width = db.lineitem.col_width(col)
+            out["scan_count_gbs"] = round(db.lineitem.rows * width / (ms_s / n_s * 1e-3) / 1e9, 1)
+            out["scan_count_ms"] = round(ms_s / n_s, 4)
+        # the same over a 4-byte column (second PMC calibration point: dword loads)
+        ctx.prof_reset()
+        col4 = db.lineitem.col("l_shipdate")
+        for _ in range(reps):
+            lrel.scan_count([api.pred((0, col4), capi.F_GTE, 0)])
+        n_s, ms_s = ctx.prof_all().get("k_scan_count", (0, 0.0))
+        if n_s:
+            out["scan_count_4B_gbs"] = round(db.lineitem.rows * 4 / (ms_s / n_s * 1e-3) / 1e9, 1)
         ctx.prof_reset()
         return out
 
@@ -144,6 +227,9 @@ def cpu_baseline(queries, sample_sf):
 
     fns = {1: q1, 6: q6, 3: q3}
     per = {}
+    queries = [q for q in queries if q in fns]  # the CPU leg covers the headline queries
+    if not queries:
+        return None
     for q in queries:
         ts = []
         for _ in range(3):
