@@ -69,6 +69,10 @@ struct DOut { // one output aggregate column
    int32_t avg_pow10;
    int32_t out_width; // bytes per output value
    int32_t is_float;
+   // conditional SUM (case when p then x else 0 end): a row failing p contributes a non-NULL 0, so
+   // the result is NULL only if every row passes p with a NULL x: valid ⇔ rows − pass + nonnull > 0
+   int32_t cnt_rows_acc; // all rows of the group (-1: not needed)
+   int32_t cnt_pass_acc; // rows passing the aggregate's predicates (-1: argument not nullable)
    int32_t pad;
    uint64_t out_values; // device address
    uint64_t out_valid; // one byte per group (packed later) or 0
@@ -245,6 +249,113 @@ __device__ __forceinline__ void d_accumulate(const DGroupBy& m, const DGroupBy* 
    }
 }
 
+// ---------------------------------------------------------------- run combining (high-cardinality path)
+// When the LDS table is off (more groups than it can hold) every row would pay a global atomic
+// per accumulator — ~15 G atomics/s on random addresses, 40 ms for Q18's 600 M rows.  Fact tables
+// are clustered on their key (lineitem by l_orderkey), so neighbouring lanes very often carry the
+// SAME group: lanes whose key equals the previous lane's form a run, the run is reduced inside the
+// wave with shuffles and only its head lane touches the global table (one lookup + one atomic per
+// accumulator per run).  Exact: integer adds commute; float sums are reassociated (as atomics
+// already do).  Every lane of the wave executes the shuffles; lanes without a row carry the
+// identity.
+__device__ __forceinline__ unsigned long long d_shfl_down(unsigned long long v, int off) { return __shfl_down(v, off); }
+__device__ __forceinline__ long long d_shfl_down(long long v, int off) { return __shfl_down(v, off); }
+__device__ __forceinline__ double d_shfl_down(double v, int off) { return __shfl_down(v, off); }
+__device__ __forceinline__ u128 d_shfl_down(u128 v, int off) {
+   unsigned long long lo = __shfl_down((unsigned long long) v, off), hi = __shfl_down((unsigned long long) (v >> 64), off);
+   return ((u128) hi << 64) | lo;
+}
+// reduction of v over lanes [lane, run_end] (run_end = last lane of this lane's run)
+template <typename T, typename OP>
+__device__ __forceinline__ T d_seg_reduce(T v, uint32_t lane, uint32_t run_end, OP op) {
+#pragma unroll
+   for (int off = 1; off < 64; off <<= 1) {
+      T o = d_shfl_down(v, off);
+      if (lane + (uint32_t) off <= run_end) v = op(v, o);
+   }
+   return v;
+}
+
+#define GB_I64_MAX 0x7FFFFFFFFFFFFFFFll
+#define GB_I64_MIN (-0x7FFFFFFFFFFFFFFFll - 1)
+// d_accumulate for a whole run: `pass` = this lane has a row of the run, `apply` = this lane is the
+// run's head and owns a valid slot `s`.  Must be called by all lanes of the wave.
+__device__ __forceinline__ void d_accumulate_runs(const DGroupBy& m, const DGroupBy* __restrict__ d, const RowVals& rv, uint32_t rvalid, uint64_t i, bool pass,
+                                                  bool apply, uint32_t lane, uint32_t run_end, const Sink& s) {
+   const int na = m.n_accs;
+   auto add_u64 = [](unsigned long long a, unsigned long long b) { return a + b; };
+   LDB_UNROLL
+   for (int a = 0; a < na; a++) {
+      const DAcc& acc = m.accs[a];
+      bool ok = pass;
+      LDB_UNROLL
+      for (int p = 0; p < acc.n_cpreds; p++)
+         if (ok) ok = d_eval_pred(PV(m.cpreds[acc.cpred[p]], d->cpreds[acc.cpred[p]]), i);
+      if (acc.kind == ACC_COUNT && acc.count_rows) {
+         unsigned long long c = d_seg_reduce<unsigned long long>(ok ? 1ull : 0ull, lane, run_end, add_u64);
+         if (apply && c) atomicAdd(s.w(acc.word), c);
+         continue;
+      }
+      if (acc.e.is_float) {
+         double fv = 0;
+         if (ok) ok = d_eval_flt(m, acc.e, rv, rvalid, &fv);
+         switch (acc.kind) {
+            case ACC_COUNT: {
+               unsigned long long c = d_seg_reduce<unsigned long long>(ok ? 1ull : 0ull, lane, run_end, add_u64);
+               if (apply && c) atomicAdd(s.w(acc.word), c);
+               break;
+            }
+            case ACC_SUMF64: {
+               unsigned long long c = d_seg_reduce<unsigned long long>(ok ? 1ull : 0ull, lane, run_end, add_u64);
+               double r = d_seg_reduce<double>(ok ? fv : 0.0, lane, run_end, [](double x, double y) { return x + y; });
+               if (apply && c) atomicAdd((double*) s.w(acc.word), r);
+               break;
+            }
+            case ACC_MINF64: {
+               double r = d_seg_reduce<double>(ok ? fv : __builtin_inf(), lane, run_end, [](double x, double y) { return y < x ? y : x; });
+               if (apply && r != __builtin_inf()) d_atomic_minmax_f64(s.w(acc.word), r, true);
+               break;
+            }
+            default: {
+               double r = d_seg_reduce<double>(ok ? fv : -__builtin_inf(), lane, run_end, [](double x, double y) { return y > x ? y : x; });
+               if (apply && r != -__builtin_inf()) d_atomic_minmax_f64(s.w(acc.word), r, false);
+               break;
+            }
+         }
+         continue;
+      }
+      i128 v = 0;
+      if (ok) ok = d_eval_int(m, d, acc.e, rv, rvalid, i, &v);
+      switch (acc.kind) {
+         case ACC_COUNT: {
+            unsigned long long c = d_seg_reduce<unsigned long long>(ok ? 1ull : 0ull, lane, run_end, add_u64);
+            if (apply && c) atomicAdd(s.w(acc.word), c);
+            break;
+         }
+         case ACC_SUM64: {
+            unsigned long long r = d_seg_reduce<unsigned long long>(ok ? (unsigned long long) v : 0ull, lane, run_end, add_u64);
+            if (apply && r) atomicAdd(s.w(acc.word), r);
+            break;
+         }
+         case ACC_SUM128: {
+            u128 r = d_seg_reduce<u128>(ok ? (u128) v : (u128) 0, lane, run_end, [](u128 x, u128 y) { return x + y; });
+            if (apply && r) d_sink_add128(s, acc.word, r);
+            break;
+         }
+         case ACC_MIN64: {
+            long long r = d_seg_reduce<long long>(ok ? (long long) v : GB_I64_MAX, lane, run_end, [](long long x, long long y) { return y < x ? y : x; });
+            if (apply && r != GB_I64_MAX) atomicMin((long long*) s.w(acc.word), r);
+            break;
+         }
+         default: {
+            long long r = d_seg_reduce<long long>(ok ? (long long) v : GB_I64_MIN, lane, run_end, [](long long x, long long y) { return y > x ? y : x; });
+            if (apply && r != GB_I64_MIN) atomicMax((long long*) s.w(acc.word), r);
+            break;
+         }
+      }
+   }
+}
+
 // merge accumulator words of an LDS slot into the global slot (combine step of
 // MergePreAggrHashMap, reference SubOpToControlFlow.cpp:1861-1938)
 __device__ __forceinline__ void d_combine(const DGroupBy& m, const Sink& src, const Sink& dst) {
@@ -346,7 +457,9 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
    // scan overlaps across rows), phase B folds each surviving row into its group.
    const uint64_t tid = blockIdx.x * (uint64_t) GB_BLOCK + threadIdx.x;
    const uint64_t nthreads = (uint64_t) gridDim.x * GB_BLOCK;
-   for (uint64_t i0 = tid; i0 < n; i0 += nthreads * ROWS) {
+   const uint32_t lane = threadIdx.x & 63;
+   // wave-uniform trip count (the wave's first row decides): the run-combining path shuffles
+   for (uint64_t i0 = tid; i0 - lane < n; i0 += nthreads * ROWS) {
       bool passv[ROWS];
       uint64_t hv[ROWS];
       long long rvv[ROWS][GB_MAX_COLS];
@@ -380,6 +493,32 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
             if (!m.keyless) hv[u] = d_hash_keys(keys, rowsv[u]);
             d_load_vals(m, d, rowsv[u], rvv[u], rvalidv[u]);
          }
+      }
+      if (!use_lds) {
+         // high-cardinality path: runs of neighbouring lanes with the same key are combined in the
+         // wave, the run's head lane does the one lookup and the atomics (see d_accumulate_runs)
+#pragma unroll
+         for (int u = 0; u < ROWS; u++) {
+            const uint64_t i = rowsv[u];
+            const bool pass = passv[u];
+            const uint64_t h = hv[u];
+            const uint64_t hprev = __shfl_up((unsigned long long) h, 1);
+            const bool pprev = __shfl_up(pass ? 1 : 0, 1) != 0;
+            bool same = lane > 0 && pass && pprev && hprev == h; // lane - 1 holds row i - 1
+            if (same && !m.keyless) same = d_keys_equal(keys, i - 1, keys, i, true);
+            const bool head = pass && !same;
+            const uint64_t headmask = __ballot(head), passmask = __ballot(pass);
+            if (passmask == 0) continue; // wave-uniform
+            uint64_t g = ~0ull;
+            if (head) g = d_global_slot(m, d, h, i);
+            const uint64_t above = lane >= 63 ? 0ull : (~0ull << (lane + 1));
+            const uint64_t brk = (headmask | ~passmask) & above; // first lane after this one that is not a member of its run
+            const uint32_t run_end = !pass ? lane : (brk ? (uint32_t) __builtin_ctzll(brk) - 1u : 63u);
+            const bool apply = head && g != ~0ull;
+            Sink s{g_acc + (apply ? g : 0), g_cap};
+            d_accumulate_runs(m, d, rvv[u], rvalidv[u], i, pass, apply, lane, run_end, s);
+         }
+         continue;
       }
 #pragma unroll
       for (int u = 0; u < ROWS; u++) {

@@ -46,21 +46,24 @@ __global__ void k_gb_init(uint64_t* keys, uint64_t* acc, const DGroupBy* __restr
 }
 
 // compact occupied slots → dense outputs
-__global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restrict__ rep_rows, unsigned long long* __restrict__ counter) {
+// occupied slots per 64-slot chunk (→ exclusive scan → output position of every group).  A cursor
+// atomic per wave instead is one contended address: ~10 ns each in the L2 — 84 ms for the 8.4 M
+// chunks of Q18's 150 M-group table.
+__global__ void k_gb_occupancy(const uint64_t* __restrict__ g_keys, uint64_t cap, uint32_t* __restrict__ pop) {
+   for (uint64_t p = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; p < ((cap + 63) & ~63ull); p += (uint64_t) gridDim.x * blockDim.x) {
+      const uint64_t occ = __ballot(p < cap && g_keys[p] != 0);
+      if ((threadIdx.x & 63) == 0) pop[p >> 6] = (uint32_t) __popcll(occ);
+   }
+}
+__global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restrict__ rep_rows, const uint32_t* __restrict__ chunk_off) {
    const uint64_t cap = d->g_cap;
-   for (uint64_t p = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; p < cap; p += (uint64_t) gridDim.x * blockDim.x) {
-      // cap and the grid are multiples of the wave size: a wave enters the loop body as a whole.
-      // One counter atomic per wave (ballot + prefix popcount), not one per group: a million
-      // groups on one address cost 1.5 ms on Q3.
-      uint64_t w = ((const uint64_t*) d->g_keys)[p];
+   for (uint64_t p = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; p < ((cap + 63) & ~63ull); p += (uint64_t) gridDim.x * blockDim.x) {
+      // the grid stride is a multiple of the wave size: a wave covers one aligned 64-slot chunk
+      uint64_t w = p < cap ? ((const uint64_t*) d->g_keys)[p] : 0;
       const uint64_t occ = __ballot(w != 0);
-      if (occ == 0) continue;
-      const uint32_t lane = threadIdx.x & 63;
-      unsigned long long base = 0;
-      if (lane == (uint32_t) __ffsll((long long) occ) - 1u) base = atomicAdd(counter, (unsigned long long) __popcll(occ));
-      base = __shfl(base, __ffsll((long long) occ) - 1);
       if (w == 0) continue;
-      uint64_t g = base + (uint64_t) __popcll(occ & ((1ull << lane) - 1ull));
+      const uint32_t lane = threadIdx.x & 63;
+      uint64_t g = (uint64_t) chunk_off[p >> 6] + (uint64_t) __popcll(occ & ((1ull << lane) - 1ull));
       uint32_t rep = (uint32_t) w - 1u;
       rep_rows[g] = rep;
       const uint64_t* acc = (const uint64_t*) d->g_acc + p;
@@ -71,6 +74,12 @@ __global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restri
          if (out.cnt_acc >= 0) {
             cnt = acc[(uint64_t) d->accs[out.cnt_acc].word * cap];
             ok = cnt != 0;
+         }
+         if (out.cnt_rows_acc >= 0) { // conditional SUM: rows failing the predicates contribute a non-NULL 0
+            unsigned long long rows = acc[(uint64_t) d->accs[out.cnt_rows_acc].word * cap];
+            unsigned long long passing = out.cnt_pass_acc >= 0 ? acc[(uint64_t) d->accs[out.cnt_pass_acc].word * cap] : 0;
+            unsigned long long nonnull = out.cnt_pass_acc >= 0 ? cnt : 0; // not nullable: no passing row is NULL
+            ok = rows - passing + nonnull != 0;
          }
          if (out.is_float) {
             double v = 0;
@@ -223,7 +232,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    h->n_rows = (uint64_t) in->n_rows;
    h->n_preds = n_preds;
    for (int32_t p = 0; p < n_preds; p++) LDB_TRY(ldb_make_dpred(in, &preds[p], &h->preds[p]));
-   ldb_mark_same_col(h->preds, n_preds);
+   ldb_order_preds(h->preds, n_preds); // cheap conjuncts first, same-column neighbours marked
    h->batch_rows = n_preds >= 2 ? 8 : 4;
    LDB_TRY(ldb_make_dkeys(in, keys, n_keys, &h->keys));
    h->keyless = n_keys == 0;
@@ -264,6 +273,8 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       o.avg_pow10 = sp.avg_pow10;
       o.acc = -1;
       o.cnt_acc = -1;
+      o.cnt_rows_acc = -1;
+      o.cnt_pass_acc = -1;
       o.is_float = sp.arg.is_float && sp.fn != LDB_AGG_COUNT && sp.fn != LDB_AGG_COUNT_STAR;
       if (sp.n_preds < 0 || sp.n_preds > LDB_MAX_AGG_PREDS) LDB_FAIL(LDB_ERR_INVALID, "groupby: aggregate %d has %d predicates", a, sp.n_preds);
       if (sp.avg_pow10 < 0 || sp.avg_pow10 > 38) LDB_FAIL(LDB_ERR_INVALID, "groupby: avg_pow10 %d", sp.avg_pow10);
@@ -329,8 +340,23 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
                acc.kind = ACC_SUM64;
                LDB_TRY(add_acc(acc, 1, 0, &o.acc));
             }
-            // a conditional SUM (case … else 0) is never NULL; a plain SUM over no non-NULL input is
+            // a plain SUM over no non-NULL input is NULL; a conditional SUM (case … else 0) gets a
+            // non-NULL 0 from every row failing its predicates (see DOut::cnt_rows_acc)
             if (sp.fn == LDB_AGG_AVG || nullable || (h->keyless && sp.n_preds == 0)) LDB_TRY(need_counter(&o.cnt_acc));
+            if (sp.fn == LDB_AGG_SUM && sp.n_preds > 0 && (nullable || h->keyless)) {
+               DAcc rows;
+               memset(&rows, 0, sizeof(rows));
+               rows.kind = ACC_COUNT;
+               rows.count_rows = 1;
+               LDB_TRY(add_acc(rows, 1, 0, &o.cnt_rows_acc));
+               if (nullable) {
+                  DAcc passing = acc; // same predicates, counts rows
+                  passing.kind = ACC_COUNT;
+                  passing.count_rows = 1;
+                  memset(&passing.e, 0, sizeof(passing.e));
+                  LDB_TRY(add_acc(passing, 1, 0, &o.cnt_pass_acc));
+               }
+            }
             break;
          }
          case LDB_AGG_MIN:
@@ -467,17 +493,27 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    for (int32_t a = 0; a < n_aggs; a++) {
       LDB_TRY(ldb_dev_alloc(ctx, &out_vals[(size_t) a], (size_t) oinfo[(size_t) a].width * (size_t) (max_groups ? max_groups : 1)));
       h->outs[a].out_values = (uint64_t) out_vals[(size_t) a];
-      if (h->outs[a].cnt_acc >= 0 || h->outs[a].fn == LDB_AGG_ANY) {
+      if (h->outs[a].cnt_acc >= 0 || h->outs[a].cnt_rows_acc >= 0 || h->outs[a].fn == LDB_AGG_ANY) {
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &out_valid[(size_t) a], (size_t) (max_groups ? max_groups : 1)));
          h->outs[a].out_valid = (uint64_t) out_valid[(size_t) a];
       }
    }
    ldb_dev_free(ctx, d);
    LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-   LDB_HIP(hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
-   hipLaunchKernelGGL(k_gb_finalize, dim3(ldb_grid_for(ctx, (int64_t) cap, 256, 8)), dim3(256), 0, ctx->stream, d, rep_rows, (unsigned long long*) ctx->d_scratch);
-   LDB_HIP(hipGetLastError());
-   LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &n_groups));
+   {
+      const int64_t n_chunks = (int64_t) ((cap + 63) / 64);
+      uint32_t *pop, *off;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) n_chunks));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) n_chunks));
+      const int fgrid = ldb_grid_for(ctx, (int64_t) cap, 256, 8);
+      hipLaunchKernelGGL(k_gb_occupancy, dim3(fgrid), dim3(256), 0, ctx->stream, (const uint64_t*) h->g_keys, cap, pop);
+      LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, n_chunks, (uint64_t*) ctx->d_scratch));
+      hipLaunchKernelGGL(k_gb_finalize, dim3(fgrid), dim3(256), 0, ctx->stream, d, rep_rows, (const uint32_t*) off);
+      LDB_HIP(hipGetLastError());
+      LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &n_groups));
+      ldb_dev_free(ctx, pop);
+      ldb_dev_free(ctx, off);
+   }
    ldb_dev_free(ctx, (void*) h->g_keys);
    ldb_dev_free(ctx, (void*) h->g_acc);
    ldb_dev_free(ctx, d);

@@ -36,6 +36,7 @@ struct ldb_hashtable {
 // ---------------------------------------------------------------- ahead-of-time (generic) kernels
 __global__ void k_join_build(const DJoin* __restrict__ d) { join_build_body(*d, d); }
 __global__ void k_join_probe_pairs(const DJoin* __restrict__ d) { join_probe_pairs_body(*d, d); }
+__global__ void k_join_probe_pairs_count(const DJoin* __restrict__ d) { join_probe_pairs_count_body(*d, d); }
 __global__ void k_join_probe_count(const DJoin* __restrict__ d) { join_probe_count_body(*d, d); }
 __global__ void k_join_probe_exists(const DJoin* __restrict__ d) { join_probe_exists_body(*d, d); }
 __global__ void k_join_probe_unique(const DJoin* __restrict__ d) { join_probe_unique_body(*d, d); }
@@ -48,6 +49,7 @@ __global__ void k_join_flags_bitmap(const uint8_t* __restrict__ flags, uint64_t 
 static const char* JOIN_SPEC_SRC =
    "extern \"C\" __global__ void k_join_build_spec(const DJoin* __restrict__ d) { join_build_body(LDB_META, d); }\n"
    "extern \"C\" __global__ void k_join_probe_pairs_spec(const DJoin* __restrict__ d) { join_probe_pairs_body(LDB_META, d); }\n"
+   "extern \"C\" __global__ void k_join_probe_pairs_count_spec(const DJoin* __restrict__ d) { join_probe_pairs_count_body(LDB_META, d); }\n"
    "extern \"C\" __global__ void k_join_probe_count_spec(const DJoin* __restrict__ d) { join_probe_count_body(LDB_META, d); }\n"
    "extern \"C\" __global__ void k_join_probe_exists_spec(const DJoin* __restrict__ d) { join_probe_exists_body(LDB_META, d); }\n"
    "extern \"C\" __global__ void k_join_probe_unique_spec(const DJoin* __restrict__ d) { join_probe_unique_body(LDB_META, d); }\n"
@@ -366,26 +368,35 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
          ob = match;
       }
    } else {
-      // duplicated build keys: optimistic capacity, exact retry on overflow
-      uint64_t out_cap = std::max<uint64_t>(1024, (uint64_t) n);
-      for (int attempt = 0; attempt < 2; attempt++) {
-         LDB_TRY(ldb_dev_alloc(ctx, (void**) &op, 4 * (size_t) out_cap));
-         LDB_TRY(ldb_dev_alloc(ctx, (void**) &ob, 4 * (size_t) out_cap));
+      // duplicated build keys: count per 64-row chunk → scan → emit (see join_probe_pairs_body)
+      const int64_t n_chunks = (n + 63) / 64;
+      uint32_t *chunk_cnt, *chunk_off;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &chunk_cnt, 4 * (size_t) (n_chunks ? n_chunks : 1)));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &chunk_off, 4 * (size_t) (n_chunks ? n_chunks : 1)));
+      h->match = (uint64_t) chunk_cnt;
+      LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
+      DJoin* d;
+      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+      if (n) {
+         LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_pairs_count", "k_join_probe_pairs_count_spec", k_join_probe_pairs_count));
+         LDB_TRY(ldb_exclusive_scan_u32(ctx, chunk_cnt, chunk_off, n_chunks, nullptr));
+         LDB_TRY(ldb_read_u64(ctx, counter, &produced));
+      }
+      ldb_dev_free(ctx, d);
+      if (produced >= (uint64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: %llu result rows exceed uint32 row ids", (unsigned long long) produced);
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &op, 4 * (size_t) (produced ? produced : 1)));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &ob, 4 * (size_t) (produced ? produced : 1)));
+      if (produced) {
+         h->match = (uint64_t) chunk_off;
          h->out_probe = (uint64_t) op;
          h->out_build = (uint64_t) ob;
-         h->out_cap = out_cap;
-         LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
-         DJoin* d;
+         h->out_cap = produced;
          LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-         if (n) LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_pairs", "k_join_probe_pairs_spec", k_join_probe_pairs));
-         LDB_TRY(ldb_read_u64(ctx, counter, &produced));
+         LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_pairs", "k_join_probe_pairs_spec", k_join_probe_pairs));
          ldb_dev_free(ctx, d);
-         if (produced <= out_cap) break;
-         ldb_dev_free(ctx, op);
-         ldb_dev_free(ctx, ob);
-         if (produced >= (uint64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: %llu result rows exceed uint32 row ids", (unsigned long long) produced);
-         out_cap = produced;
       }
+      ldb_dev_free(ctx, chunk_cnt);
+      ldb_dev_free(ctx, chunk_off);
    }
    // result relation: probe sides composed with op, build sides composed with ob
    ldb_rel* r = ldb_rel_new(ctx);

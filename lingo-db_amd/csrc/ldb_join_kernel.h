@@ -18,7 +18,7 @@ struct DJoin {
    uint64_t counter; // unsigned long long*: [0] = rows produced (may exceed out_cap), [1] = matches
    uint64_t bitmap; // uint64_t*: SEMI / ANTI / unique-build INNER
    uint64_t mark; // uint8_t*: MARK
-   uint64_t match; // uint32_t*: unique-build path: build row (or LDB_NULL_ROW) per probe row
+   uint64_t match; // uint32_t*: unique-build path: build row (or LDB_NULL_ROW) per probe row; pairs path: per-chunk counts / offsets
    uint64_t flags; // uint32_t*: build: [0] |= 1 when two build rows carry the same key (or tag)
    // ---- metadata
    int32_t key32;
@@ -94,89 +94,66 @@ __device__ __forceinline__ uint32_t d_probe_row(const DJoin& m, const DJoin* __r
    return matches;
 }
 
-// INNER / LEFT_OUTER / SINGLE with possibly duplicated build keys: each lane walks its slot run
-// until its NEXT match, then the wave appends all pending matches with ONE atomicAdd (ballot →
-// popcount → mbcnt rank): 64x fewer atomics on the output cursor than one per pair, and each
-// wave's pairs land contiguously (coalesced stores).
+// INNER / LEFT_OUTER / SINGLE with possibly duplicated build keys, two passes and no atomics on
+// an output cursor (one contended cursor address serialises at ~10 ns per wave-append in the
+// L2: Q12's 150 M-row probe spent 22 ms there).  Pass 1 counts the rows every 64-row chunk
+// produces, a device scan turns the counts into chunk offsets, pass 2 re-walks (the slot runs are
+// now cache-resident) and every lane writes its pairs at chunk offset + in-wave prefix: output in
+// probe order, sized exactly.
+// rows one probe row contributes: its matches, or one NULL-padded row when an outer join finds none
+__device__ __forceinline__ uint32_t d_pairs_of_row(const DJoin& m, const DJoin* __restrict__ d, uint64_t i) {
+   uint32_t c = d_probe_row(m, d, i, [&](uint32_t) { return m.kind != LDB_JOIN_SINGLE; });
+   return (m.kind != LDB_JOIN_INNER && c == 0) ? 1u : c;
+}
+__device__ __forceinline__ void join_probe_pairs_count_body(const DJoin& m, const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows;
+   const uint64_t n_chunks = (n + 63) / 64;
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+   uint32_t* chunk_cnt = gptr_mut<uint32_t>(d->match);
+   unsigned long long total = 0; // exact 64-bit row count (the 32-bit offsets cannot detect > 4 G rows)
+   for (uint64_t w = wave; w < n_chunks; w += n_waves) {
+      const uint64_t i = w * 64 + lane;
+      uint32_t c = i < n ? d_pairs_of_row(m, d, i) : 0u;
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+      if (lane == 0) chunk_cnt[w] = c;
+      total += c;
+   }
+   if (lane == 0 && total) atomicAdd(gptr_mut<unsigned long long>(d->counter), total);
+}
 __device__ __forceinline__ void join_probe_pairs_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows;
-   const int kind = m.kind;
-   const uint64_t mask = d->cap - 1;
-   const bool key32 = m.key32 != 0;
+   const uint64_t n_chunks = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;
-   const uint64_t* slots = gptr<uint64_t>(d->slots);
-   unsigned long long* counter = gptr_mut<unsigned long long>(d->counter);
+   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+   const uint32_t* chunk_off = gptr<uint32_t>(d->match);
    uint32_t* out_probe = gptr_mut<uint32_t>(d->out_probe);
    uint32_t* out_build = gptr_mut<uint32_t>(d->out_build);
-   const uint64_t out_cap = d->out_cap;
-   const KV pkeys(m.pkeys, d->pkeys), bkeys(m.bkeys, d->bkeys);
-   unsigned long long local_matches = 0;
-   const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
-   // wave-uniform trip count so that every lane reaches the ballots
-   for (uint64_t base = blockIdx.x * (uint64_t) blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
-      const uint64_t i = base + lane;
-      bool done = i >= n;
-      uint64_t h = 0, pos = 0;
-      uint32_t key = 0, matches = 0;
-      if (!done) {
-         bool nul;
-         h = d_hash_keys(pkeys, i, &nul);
-         pos = h & mask;
-         if (key32) {
-            const CV c = pkeys.col(0);
-            int64_t kv = d_load_i64(c, d_phys_row(c, i));
-            if (kv != (int64_t) (int32_t) kv) nul = true; // can equal no 32-bit build key
-            key = (uint32_t) kv;
-         }
-         if (nul) done = true;
+   for (uint64_t w = wave; w < n_chunks; w += n_waves) {
+      const uint64_t i = w * 64 + lane;
+      const uint32_t c = i < n ? d_pairs_of_row(m, d, i) : 0u;
+      uint32_t incl = c;
+      for (int off = 1; off < 64; off <<= 1) {
+         uint32_t up = __shfl_up(incl, off);
+         if (lane >= (uint32_t) off) incl += up;
       }
-      bool emitted_null = false;
-      for (;;) {
-         bool found = false;
-         uint32_t brow = LDB_NULL_ROW;
-         bool scanning = !done && !(i >= n);
-         // NULL-key rows never scan; they may still owe an outer-join row
-         if (i < n && done && matches == 0 && !emitted_null && kind != LDB_JOIN_INNER) {
-            found = true;
-            emitted_null = true;
-         }
-         while (scanning) {
-            uint64_t w = slots[pos];
-            if (w == 0) {
-               done = true;
-               if (matches == 0 && kind != LDB_JOIN_INNER && !emitted_null) { // unmatched probe row of an outer join
-                  found = true;
-                  emitted_null = true;
-               }
-               break;
-            }
-            pos = (pos + 1) & mask;
-            bool hit = key32 ? ((uint32_t) (w >> 32) == key) : ((w >> 32) == (h >> 32) && d_keys_equal(bkeys, (uint64_t) ((uint32_t) w - 1u), pkeys, i, false));
-            if (hit) {
-               found = true;
-               brow = (uint32_t) w - 1u;
-               matches++;
-               if (kind == LDB_JOIN_SINGLE) done = true;
-               break;
-            }
-         }
-         const uint64_t mm = __ballot(found);
-         if (mm == 0) break; // no lane produced anything → every lane is done
-         unsigned long long first = 0;
-         if (lane == (uint32_t) __builtin_ctzll(mm)) first = atomicAdd(&counter[0], (unsigned long long) __popcll(mm));
-         first = __shfl(first, __builtin_ctzll(mm));
-         if (found) {
-            unsigned long long idx = first + d_rank_in(mm);
-            if (idx < out_cap) {
-               out_probe[idx] = (uint32_t) i;
-               out_build[idx] = brow;
-            }
+      if (c != 0) {
+         const uint64_t at = (uint64_t) chunk_off[w] + (incl - c);
+         uint32_t emitted = 0;
+         d_probe_row(m, d, i, [&](uint32_t brow) {
+            out_probe[at + emitted] = (uint32_t) i;
+            out_build[at + emitted] = brow;
+            emitted++;
+            return m.kind != LDB_JOIN_SINGLE;
+         });
+         if (emitted == 0) { // unmatched (or NULL-key) probe row of an outer join
+            out_probe[at] = (uint32_t) i;
+            out_build[at] = LDB_NULL_ROW;
          }
       }
-      local_matches += matches;
    }
-   for (int off = 32; off > 0; off >>= 1) local_matches += __shfl_down(local_matches, off);
-   if (lane == 0 && local_matches) atomicAdd(&counter[1], local_matches);
 }
 
 // count matches only — the probe micro-benchmark kernel (Grows/s)

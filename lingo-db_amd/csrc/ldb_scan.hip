@@ -92,7 +92,7 @@ static int32_t build_scan_desc(ldb_rel* in, const ldb_filter_desc* preds, int32_
    h->n_rows = (uint64_t) in->n_rows;
    h->n_preds = n_preds;
    for (int32_t p = 0; p < n_preds; p++) LDB_TRY(ldb_make_dpred(in, &preds[p], &h->preds[p]));
-   ldb_mark_same_col(h->preds, n_preds);
+   ldb_order_preds(h->preds, n_preds); // cheap conjuncts first, same-column neighbours marked
    return LDB_OK;
 }
 

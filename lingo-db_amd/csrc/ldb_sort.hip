@@ -130,7 +130,10 @@ int32_t ldb_rel_select(ldb_ctx* ctx, ldb_rel* in, uint32_t* sel, int64_t n_sel, 
 int32_t ldb_gather_column(ldb_ctx* ctx, const ldb_rel* r, ldb_colref ref, ldb_column* out);
 
 // stable LSD sort of `perm` (n entries) by `words`-word records, digits [bit_lo, bit_hi) of each word
-static int32_t radix_sort_perm(ldb_ctx* ctx, const uint64_t* keys, int words, uint32_t** perm_io, uint64_t n, int first_word, int last_word, int bits_lo, int bits_hi) {
+// `varmask` (host, one word per record word, may be NULL): bits that differ between some two
+// records — a digit whose bits are all constant is skipped (an LSD pass over it is the identity).
+static int32_t radix_sort_perm(ldb_ctx* ctx, const uint64_t* keys, int words, uint32_t** perm_io, uint64_t n, int first_word, int last_word, int bits_lo, int bits_hi,
+                               const uint64_t* varmask) {
    if (n < 2) return LDB_OK;
    const uint64_t n_threads = (n + CS_CHUNK - 1) / CS_CHUNK;
    const int grid = (int) ((n_threads + CS_BLOCK - 1) / CS_BLOCK);
@@ -142,6 +145,7 @@ static int32_t radix_sort_perm(ldb_ctx* ctx, const uint64_t* keys, int words, ui
    uint32_t* b = perm_b;
    for (int w = last_word; w >= first_word; w--) {
       for (int shift = bits_lo; shift < bits_hi; shift += 4) {
+         if (varmask && ((varmask[w] >> shift) & 15ull) == 0) continue;
          hipLaunchKernelGGL(k_cs_count, dim3(grid), dim3(CS_BLOCK), 0, ctx->stream, keys, words, w, shift, (const uint32_t*) a, n, counts, n_threads);
          LDB_TRY(ldb_exclusive_scan_u32(ctx, counts, offsets, (int64_t) (16 * n_threads), nullptr));
          hipLaunchKernelGGL(k_cs_scatter, dim3(grid), dim3(CS_BLOCK), 0, ctx->stream, keys, words, w, shift, (const uint32_t*) a, b, n, (const uint32_t*) offsets, n_threads);
@@ -195,25 +199,58 @@ __global__ __launch_bounds__(SS_BLOCK) void k_small_sort(const uint64_t* __restr
    for (uint32_t i = threadIdx.x; i < n; i += SS_BLOCK) perm[i] = idx[i];
 }
 
-// ---------------------------------------------------------------- top-k: radix select on the leading key word
-// state[0] = prefix found so far (high bits), state[1] = rank still to find inside the prefix group
-__global__ void k_sel_hist(const uint64_t* __restrict__ keys, int words, uint64_t n, int shift, const unsigned long long* __restrict__ state, uint32_t* __restrict__ hist) {
+// ---------------------------------------------------------------- which key bits vary at all
+// OR and AND of every record word: bits where they agree are constant over the whole input and
+// carry no order information (a decimal(33,4) revenue occupies 16 key bytes of which ~5 vary).
+__global__ void k_key_bits(const uint64_t* __restrict__ keys, int words, uint64_t n, unsigned long long* __restrict__ or_and) {
+   const int w = blockIdx.y;
+   uint64_t o = 0, a = ~0ull;
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      uint64_t v = keys[i * words + w];
+      o |= v;
+      a &= v;
+   }
+   for (int off = 32; off > 0; off >>= 1) {
+      o |= (uint64_t) __shfl_xor((unsigned long long) o, off);
+      a &= (uint64_t) __shfl_xor((unsigned long long) a, off);
+   }
+   if ((threadIdx.x & 63) == 0) {
+      atomicOr(&or_and[w], (unsigned long long) o);
+      atomicAnd(&or_and[words + w], (unsigned long long) a);
+   }
+}
+
+// ---------------------------------------------------------------- top-k: radix select over the leading varying key bytes
+// Select state (device): prefix value / mask per record word for the first SEL_WORDS words, and the
+// rank still to find among the records that match the prefix so far.
+#define SEL_WORDS 4
+struct SelState {
+   unsigned long long pval[SEL_WORDS];
+   unsigned long long pmask[SEL_WORDS];
+   unsigned long long rank;
+};
+__device__ __forceinline__ bool d_sel_match(const uint64_t* __restrict__ rec, const SelState& st, int upto) {
+   bool m = true;
+   for (int w = 0; w <= upto; w++) m = m && ((rec[w] & st.pmask[w]) == st.pval[w]);
+   return m;
+}
+// histogram of byte (w, shift) over the records matching the prefix chosen so far
+__global__ void k_sel_hist(const uint64_t* __restrict__ keys, int words, uint64_t n, int w, int shift, const SelState* __restrict__ state, uint32_t* __restrict__ hist) {
    __shared__ uint32_t lh[256];
    for (int k = threadIdx.x; k < 256; k += blockDim.x) lh[k] = 0;
    __syncthreads();
-   const uint64_t prefix = state[0];
+   const SelState& st = *state; // wave-uniform: scalar loads
    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-      uint64_t w = keys[i * words];
-      bool in = shift == 56 || (w >> (shift + 8)) == (prefix >> (shift + 8));
-      if (in) atomicAdd(&lh[(w >> shift) & 255u], 1u);
+      const uint64_t* rec = keys + i * words;
+      if (d_sel_match(rec, st, w)) atomicAdd(&lh[(rec[w] >> shift) & 255u], 1u);
    }
    __syncthreads();
    for (int k = threadIdx.x; k < 256; k += blockDim.x)
       if (lh[k]) atomicAdd(&hist[k], lh[k]);
 }
-__global__ void k_sel_pick(unsigned long long* __restrict__ state, uint32_t* __restrict__ hist, int shift) {
+__global__ void k_sel_pick(SelState* __restrict__ state, uint32_t* __restrict__ hist, int w, int shift) {
    if (threadIdx.x == 0) {
-      unsigned long long rank = state[1], cum = 0;
+      unsigned long long rank = state->rank, cum = 0;
       int dsel = 255;
       for (int dg = 0; dg < 256; dg++) {
          if (cum + hist[dg] > rank) {
@@ -222,24 +259,37 @@ __global__ void k_sel_pick(unsigned long long* __restrict__ state, uint32_t* __r
          }
          cum += hist[dg];
       }
-      state[0] |= (unsigned long long) dsel << shift;
-      state[1] = rank - cum;
+      state->pval[w] |= (unsigned long long) dsel << shift;
+      state->pmask[w] |= 255ull << shift;
+      state->rank = rank - cum;
    }
    __syncthreads();
    for (int k = threadIdx.x; k < 256; k += blockDim.x) hist[k] = 0;
 }
-// candidates = rows whose leading word is <= the k-th smallest one; one bitmap word + popcount per wave
-__global__ void k_sel_flags(const uint64_t* __restrict__ keys, int words, uint64_t n, const unsigned long long* __restrict__ state, uint64_t* __restrict__ bitmap,
+// candidates = records whose selected bytes are lexicographically <= the k-th smallest's; one
+// bitmap word + popcount per wave
+__global__ void k_sel_flags(const uint64_t* __restrict__ keys, int words, uint64_t n, int sel_words, const SelState* __restrict__ state, uint64_t* __restrict__ bitmap,
                             uint32_t* __restrict__ pop) {
-   const uint64_t t = state[0];
+   const SelState& st = *state; // wave-uniform: scalar loads
    const uint64_t n_words = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;
-   for (uint64_t w = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6; w < n_words; w += ((uint64_t) gridDim.x * blockDim.x) >> 6) {
-      uint64_t i = w * 64 + lane;
-      uint64_t mask = __ballot(i < n && keys[i * words] <= t);
+   for (uint64_t bw = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6; bw < n_words; bw += ((uint64_t) gridDim.x * blockDim.x) >> 6) {
+      uint64_t i = bw * 64 + lane;
+      bool keep = false;
+      if (i < n) {
+         keep = true; // equal on every selected byte → candidate
+         for (int w = 0; w < sel_words; w++) {
+            uint64_t x = keys[i * words + w] & st.pmask[w];
+            if (x != st.pval[w]) {
+               keep = x < st.pval[w];
+               break;
+            }
+         }
+      }
+      uint64_t mask = __ballot(keep);
       if (lane == 0) {
-         bitmap[w] = mask;
-         pop[w] = (uint32_t) __popcll(mask);
+         bitmap[bw] = mask;
+         pop[bw] = (uint32_t) __popcll(mask);
       }
    }
 }
@@ -251,26 +301,48 @@ __global__ void k_sel_expand(const uint64_t* __restrict__ bitmap, const uint32_t
    }
 }
 
-static int32_t radix_sort_perm(ldb_ctx* ctx, const uint64_t* keys, int words, uint32_t** perm_io, uint64_t n, int first_word, int last_word, int bits_lo, int bits_hi);
-
-// the k smallest records (all of them when k >= n), sorted: *perm_out holds min(k, n) row numbers
+// the k smallest records (all of them when k >= n), sorted: *perm_out holds >= min(k, n) row numbers
 static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint64_t n, uint64_t k, uint32_t** perm_out) {
    uint32_t* perm;
    const int grid = ldb_grid_for(ctx, (int64_t) n, 256, 8);
    uint64_t m = n; // rows to sort
+   std::vector<uint64_t> varmask((size_t) words, ~0ull);
+   if (n > SS_MAX) {
+      unsigned long long* d_bits;
+      std::vector<unsigned long long> init((size_t) (2 * words), 0ull), bits((size_t) (2 * words));
+      for (int w = 0; w < words; w++) init[(size_t) (words + w)] = ~0ull;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_bits, 16 * (size_t) words));
+      LDB_HIP(hipMemcpyAsync(d_bits, init.data(), 16 * (size_t) words, hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_key_bits, dim3(std::min(grid, 1024), words), dim3(256), 0, ctx->stream, keys, words, n, d_bits);
+      LDB_HIP(hipMemcpyAsync(bits.data(), d_bits, 16 * (size_t) words, hipMemcpyDeviceToHost, ctx->stream));
+      LDB_HIP(hipStreamSynchronize(ctx->stream));
+      ldb_dev_free(ctx, d_bits);
+      for (int w = 0; w < words; w++) varmask[(size_t) w] = bits[(size_t) w] ^ bits[(size_t) (words + w)];
+   }
    if (k < n && n > SS_MAX) {
-      // radix select: 8 passes of 8 bits over the leading word, decisions stay on the device
-      unsigned long long* state;
+      // radix select over the first (up to 8) varying bytes of the first SEL_WORDS words, most
+      // significant first; decisions stay on the device (no host round trip per pass)
+      struct Pass {
+         int w, shift;
+      } passes[8];
+      int n_pass = 0, sel_words = 0;
+      for (int w = 0; w < words && w < SEL_WORDS && n_pass < 8; w++)
+         for (int shift = 56; shift >= 0 && n_pass < 8; shift -= 8)
+            if ((varmask[(size_t) w] >> shift) & 255ull) {
+               passes[n_pass++] = {w, shift};
+               sel_words = w + 1;
+            }
+      SelState h_state;
+      memset(&h_state, 0, sizeof(h_state));
+      h_state.rank = k ? k - 1 : 0;
+      SelState* state;
       uint32_t* hist;
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &state, 16));
+      LDB_TRY(ldb_dev_upload(ctx, &h_state, sizeof(h_state), (void**) &state));
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &hist, 4 * 256));
-      unsigned long long init[2] = {0ull, (unsigned long long) (k ? k - 1 : 0)};
-      LDB_HIP(hipMemcpyAsync(state, init, 16, hipMemcpyHostToDevice, ctx->stream));
-      LDB_HIP(hipStreamSynchronize(ctx->stream)); // init[] is a stack buffer
       LDB_HIP(hipMemsetAsync(hist, 0, 4 * 256, ctx->stream));
-      for (int shift = 56; shift >= 0; shift -= 8) {
-         hipLaunchKernelGGL(k_sel_hist, dim3(grid), dim3(256), 0, ctx->stream, keys, words, n, shift, (const unsigned long long*) state, hist);
-         hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(256), 0, ctx->stream, state, hist, shift);
+      for (int p = 0; p < n_pass; p++) {
+         hipLaunchKernelGGL(k_sel_hist, dim3(grid), dim3(256), 0, ctx->stream, keys, words, n, passes[p].w, passes[p].shift, (const SelState*) state, hist);
+         hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(256), 0, ctx->stream, state, hist, passes[p].w, passes[p].shift);
       }
       const uint64_t n_words = (n + 63) / 64;
       uint64_t* bitmap;
@@ -278,7 +350,7 @@ static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint6
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmap, 8 * (size_t) n_words));
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) n_words));
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) n_words));
-      hipLaunchKernelGGL(k_sel_flags, dim3(grid), dim3(256), 0, ctx->stream, keys, words, n, (const unsigned long long*) state, bitmap, pop);
+      hipLaunchKernelGGL(k_sel_flags, dim3(grid), dim3(256), 0, ctx->stream, keys, words, n, sel_words, (const SelState*) state, bitmap, pop);
       uint64_t* d_total = (uint64_t*) ctx->d_scratch;
       LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, (int64_t) n_words, d_total));
       LDB_TRY(ldb_read_u64(ctx, d_total, &m));
@@ -295,7 +367,7 @@ static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint6
       if (n) hipLaunchKernelGGL(k_iota, dim3(grid), dim3(256), 0, ctx->stream, perm, n);
    }
    if (m > 1 && m <= SS_MAX) hipLaunchKernelGGL(k_small_sort, dim3(1), dim3(SS_BLOCK), 0, ctx->stream, keys, words, perm, (uint32_t) m);
-   else LDB_TRY(radix_sort_perm(ctx, keys, words, &perm, m, 0, words - 1, 0, 64));
+   else LDB_TRY(radix_sort_perm(ctx, keys, words, &perm, m, 0, words - 1, 0, 64, varmask.data()));
    LDB_HIP(hipGetLastError());
    *perm_out = perm;
    return LDB_OK;
@@ -399,7 +471,7 @@ extern "C" int32_t ldb_gpu_partition(ldb_ctx* ctx, ldb_rel* in, const ldb_colref
    }
    LDB_HIP(hipGetLastError());
    // stable counting sort on the partition id (<= 8 bits → two 4-bit passes)
-   LDB_TRY(radix_sort_perm(ctx, ids, 1, &perm, n, 0, 0, 0, nparts > 16 ? 8 : 4));
+   LDB_TRY(radix_sort_perm(ctx, ids, 1, &perm, n, 0, 0, 0, nparts > 16 ? 8 : 4, nullptr));
    std::vector<unsigned long long> hh(256);
    LDB_HIP(hipMemcpyAsync(hh.data(), hist, 8 * 256, hipMemcpyDeviceToHost, ctx->stream));
    LDB_HIP(hipStreamSynchronize(ctx->stream));

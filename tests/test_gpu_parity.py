@@ -280,6 +280,39 @@ def test_groupby_float_sum_within_tolerance(ctx, oracle):
         assert mn == vals[gi][2] and mx == vals[gi][3]  # min/max are exact
 
 
+def test_groupby_run_combining_high_cardinality(ctx, oracle):
+    """more groups than the LDS table holds → global-table path, where runs of neighbouring rows
+    with the same key are reduced inside the wave before one atomic per run (Q18's shape: lineitem
+    clustered on l_orderkey).  Clustered keys with NULL keys / NULL values / runs crossing wave
+    boundaries, and the same rows shuffled (runs of length 1)."""
+    rng = np.random.default_rng(11)
+    runs = rng.integers(1, 10, 9000)
+    k = np.repeat(np.arange(len(runs)) * 3, runs)
+    n = len(k)
+    kk = [None if (x % 101) == 5 else int(x) for x in k]
+    v = [None if x % 5 == 0 else int(x) for x in rng.integers(-10**9, 10**9, n)]
+    x = rng.uniform(-50, 50, n)
+    f = api.factor
+    sq = api.expr([{"factors": [f(0, 1, (0, 1)), f(0, 1, (0, 1)), f(3, 1, (0, 1))]}])
+    cond = [api.pred((0, 1), capi.F_GTE, 0)]
+    iaggs = [api.agg(capi.AGG_SUM, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT, api.col_expr((0, 1))), api.agg(capi.AGG_MIN, api.col_expr((0, 1))),
+             api.agg(capi.AGG_MAX, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT_STAR), api.agg(capi.AGG_SUM, sq, wide=True, out_type=capi.T_DECIMAL128, p=38, s=0),
+             api.agg(capi.AGG_SUM, api.col_expr((0, 1)), preds=cond), api.agg(capi.AGG_COUNT_STAR, preds=cond)]
+    faggs = [api.agg(capi.AGG_SUM, api.col_expr((0, 2), True), out_type=capi.T_FLOAT64), api.agg(capi.AGG_MIN, api.col_expr((0, 2), True), out_type=capi.T_FLOAT64),
+             api.agg(capi.AGG_MAX, api.col_expr((0, 2), True), out_type=capi.T_FLOAT64)]
+    for order in (np.arange(n), rng.permutation(n)):
+        t = pa.table({"k": pa.array([kk[i] for i in order], pa.int64()), "v": pa.array([v[i] for i in order], pa.int64()), "x": pa.array(x[order], pa.float64())})
+        g, h = ctx.register("runs", t).rel(), HostTable(t).rel()
+        rep, vals, valid = oracle.groupby(h, [(0, 0)], iaggs)
+        assert_groupby_equal(g.groupby([(0, 0)], iaggs, est_groups=n), h, [(0, 0)], rep, vals, valid)
+        rep, vals, valid = oracle.groupby(h, [(0, 0)], faggs)
+        got = {r[0]: r[1:] for r in rows_of(g.groupby([(0, 0)], faggs, est_groups=n).to_arrow())}
+        kv = key_values(h, rep, [(0, 0)])
+        for gi in range(len(rep)):
+            s, mn, mx = got[kv[gi][0]]
+            assert s == pytest.approx(vals[gi][0], rel=1e-9, abs=1e-9) and mn == vals[gi][1] and mx == vals[gi][2]
+
+
 # ---------------------------------------------------------------- joins (a6, a7, a8)
 def pairs(rel):
     return sorted(zip(rel.rowids(0).tolist(), rel.rowids(rel.sides - 1).tolist()))
