@@ -642,8 +642,9 @@ extern "C" int32_t ldb_gpu_rel_release(ldb_ctx* ctx, ldb_rel* r) {
    return LDB_OK;
 }
 extern "C" int64_t ldb_gpu_rel_rows(ldb_ctx* ctx, ldb_rel* r) {
-   (void) ctx;
-   return r ? r->n_rows : -1;
+   if (!r) return -1;
+   if (!r->pending.empty() && ldb_rel_force(ctx ? ctx : r->ctx, r) != LDB_OK) return -1; // a lazy filter is evaluated now
+   return r->n_rows;
 }
 extern "C" int32_t ldb_gpu_rel_sides(const ldb_rel* r) { return r ? (int32_t) r->sides.size() : -1; }
 
@@ -652,6 +653,7 @@ __global__ void k_iota_u32(uint32_t* out, uint64_t n) {
 }
 extern "C" int32_t ldb_gpu_rel_read_rowids(ldb_ctx* ctx, ldb_rel* r, int32_t side, uint32_t* host_out, int64_t cap) {
    if (!r || side < 0 || (size_t) side >= r->sides.size()) LDB_FAIL(LDB_ERR_INVALID, "read_rowids: bad side %d", side);
+   LDB_TRY(ldb_rel_force(ctx, r));
    if (cap < r->n_rows) LDB_FAIL(LDB_ERR_INVALID, "read_rowids: buffer too small");
    if (r->sides[(size_t) side].rowids) {
       if (r->n_rows) LDB_HIP(hipMemcpyAsync(host_out, r->sides[(size_t) side].rowids, (size_t) r->n_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -869,6 +871,7 @@ int32_t ldb_gather_column(ldb_ctx* ctx, const ldb_rel* r, ldb_colref ref, ldb_co
 
 extern "C" int32_t ldb_gpu_materialize(ldb_ctx* ctx, ldb_rel* r, const ldb_colref* cols, int32_t n_cols, ldb_table** out) {
    if (!ctx || !r || !out || n_cols < 0) LDB_FAIL(LDB_ERR_INVALID, "materialize: bad argument");
+   LDB_TRY(ldb_rel_force(ctx, r));
    auto t = std::make_unique<ldb_table>();
    t->ctx = ctx;
    t->name = "materialized";

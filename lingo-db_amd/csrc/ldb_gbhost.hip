@@ -224,6 +224,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
                                    const ldb_agg_spec* aggs, int32_t n_aggs, int64_t est_groups, ldb_table** out) {
    if (!ctx || !in || !out) LDB_FAIL(LDB_ERR_INVALID, "groupby: NULL argument");
    if (n_preds < 0 || n_preds > LDB_MAX_PREDS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: %d predicates (max %d)", n_preds, LDB_MAX_PREDS);
+   if (in->pending.size() + (size_t) n_preds > LDB_MAX_PREDS) LDB_TRY(ldb_rel_force(ctx, in)); // else: a lazy input's conjuncts are fused below
    if (n_aggs < 0 || n_aggs > GB_MAX_OUT) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: %d aggregates (max %d)", n_aggs, GB_MAX_OUT);
    if (in->n_rows >= (int64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: too many rows");
    auto hp = std::make_unique<DGroupBy>();
@@ -232,6 +233,8 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    h->n_rows = (uint64_t) in->n_rows;
    h->n_preds = n_preds;
    for (int32_t p = 0; p < n_preds; p++) LDB_TRY(ldb_make_dpred(in, &preds[p], &h->preds[p]));
+   for (auto& dp : in->pending) h->preds[h->n_preds++] = dp;
+   n_preds = h->n_preds;
    ldb_order_preds(h->preds, n_preds); // cheap conjuncts first, same-column neighbours marked
    h->batch_rows = n_preds >= 2 ? 8 : 4;
    LDB_TRY(ldb_make_dkeys(in, keys, n_keys, &h->keys));

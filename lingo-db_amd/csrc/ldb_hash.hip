@@ -20,6 +20,7 @@ int32_t ldb_make_dkeys(const ldb_rel* r, const ldb_colref* keys, int32_t n_keys,
 
 extern "C" int32_t ldb_gpu_hash_keys(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* keys, int32_t n_keys, ldb_table** out) {
    if (!ctx || !in || !out) LDB_FAIL(LDB_ERR_INVALID, "hash_keys: NULL argument");
+   LDB_TRY(ldb_rel_force(ctx, in));
    DKeys h;
    LDB_TRY(ldb_make_dkeys(in, keys, n_keys, &h));
    ldb_coltype t = {LDB_T_INT64, 0, 0, 0};

@@ -85,7 +85,16 @@ struct ldb_rel {
    ldb_ctx* ctx = nullptr;
    int64_t n_rows = 0;
    std::vector<ldb_rel_side> sides;
+   // A LAZY filtered relation: the rows of `sides` (all dense, no row ids) that satisfy the
+   // conjunction `pending` — not evaluated yet.  ldb_gpu_scan_filter over a large base table
+   // returns this; the consumers that fuse the filter into their own kernel (join probe,
+   // group-by, count) evaluate the conjuncts per row and never materialise a row-id vector, which
+   // is what the reference's fused pipelines do (scan → filter → probe in one generated loop).
+   // Everything else calls ldb_rel_force first.  n_rows is the UNFILTERED row count while lazy.
+   std::vector<DPred> pending;
 };
+// materialise a lazy relation in place (no-op otherwise)
+int32_t ldb_rel_force(ldb_ctx* ctx, ldb_rel* r);
 
 // kernel timing scope: LdbProf p(ctx, "k_name"); <launch>; (destructor records the stop event)
 struct LdbProf {

@@ -66,6 +66,7 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
       meta->counter = meta->bitmap = meta->mark = meta->match = meta->flags = 0;
       ldb_jit_strip_keys(meta->bkeys);
       ldb_jit_strip_keys(meta->pkeys);
+      for (int p = 0; p < LDB_MAX_PREDS; p++) ldb_jit_strip_pred(meta->ppreds[p]);
       std::string why;
       spec = ldb_jit_kernel("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, spec_name, meta.get(), sizeof(DJoin), &why);
    }
@@ -129,6 +130,7 @@ int32_t ldb_rel_select(ldb_ctx* ctx, ldb_rel* in, uint32_t* sel, int64_t n_sel, 
 // ---------------------------------------------------------------- build
 extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_colref* keys, int32_t n_keys, int32_t build_unique, ldb_hashtable** out) {
    if (!ctx || !build || !out || n_keys < 1) LDB_FAIL(LDB_ERR_INVALID, "join_build: bad argument");
+   LDB_TRY(ldb_rel_force(ctx, build)); // the table is sized from the exact row count
    auto ht = std::make_unique<ldb_hashtable>();
    ht->ctx = ctx;
    ht->build = build;
@@ -193,6 +195,10 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    h->cap = ht->cap;
    h->slots = (uint64_t) ht->slots;
    h->key32 = ht->key32;
+   // a lazy probe relation brings its filter along: evaluated inside the probe kernel
+   h->n_ppreds = (int32_t) probe->pending.size();
+   for (size_t p = 0; p < probe->pending.size(); p++) h->ppreds[p] = probe->pending[p];
+   ldb_order_preds(h->ppreds, h->n_ppreds);
    return LDB_OK;
 }
 
@@ -218,6 +224,8 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
                                       ldb_table** mark_out) {
    if (!ctx || !ht || !probe || !out) LDB_FAIL(LDB_ERR_INVALID, "join_probe: NULL argument");
    if (kind < LDB_JOIN_INNER || kind > LDB_JOIN_ANTI_BUILD) LDB_FAIL(LDB_ERR_INVALID, "join_probe: bad kind %d", kind);
+   // kinds that emit a row for EVERY probe row (outer / single / mark) need the filtered row set itself
+   if (kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE || kind == LDB_JOIN_MARK) LDB_TRY(ldb_rel_force(ctx, probe));
    const bool pairs = kind == LDB_JOIN_INNER || kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE;
    if (kind == LDB_JOIN_SEMI_BUILD || kind == LDB_JOIN_ANTI_BUILD) {
       // flag the build rows that some probe row matches, then keep (SEMI) / drop (ANTI) them

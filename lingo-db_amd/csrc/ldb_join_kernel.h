@@ -26,7 +26,20 @@ struct DJoin {
    int32_t has_bitmap, has_mark, has_flags, pad;
    DKeys bkeys;
    DKeys pkeys;
+   // conjuncts of a lazy (not materialised) probe relation, evaluated per probe row before the
+   // lookup: scan → filter → probe in one kernel, like the reference's fused pipelines
+   int32_t n_ppreds, pad2;
+   DPred ppreds[LDB_MAX_PREDS];
 };
+
+__device__ __forceinline__ bool d_probe_pass(const DJoin& m, const DJoin* __restrict__ d, uint64_t i) {
+   bool pass = true;
+   const int np = m.n_ppreds;
+   LDB_UNROLL
+   for (int p = 0; p < np; p++)
+      if (pass) pass = d_eval_pred(PV(m.ppreds[p], d->ppreds[p]), i);
+   return pass;
+}
 
 __device__ __forceinline__ void join_build_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows, mask = d->cap - 1;
@@ -102,6 +115,7 @@ __device__ __forceinline__ uint32_t d_probe_row(const DJoin& m, const DJoin* __r
 // probe order, sized exactly.
 // rows one probe row contributes: its matches, or one NULL-padded row when an outer join finds none
 __device__ __forceinline__ uint32_t d_pairs_of_row(const DJoin& m, const DJoin* __restrict__ d, uint64_t i) {
+   if (!d_probe_pass(m, d, i)) return 0; // (the host only fuses filters for INNER here)
    uint32_t c = d_probe_row(m, d, i, [&](uint32_t) { return m.kind != LDB_JOIN_SINGLE; });
    return (m.kind != LDB_JOIN_INNER && c == 0) ? 1u : c;
 }
@@ -165,7 +179,7 @@ __device__ __forceinline__ void join_probe_count_body(const DJoin& m, const DJoi
 #pragma unroll
       for (int u = 0; u < 4; u++) {
          const uint64_t i = i0 + (uint64_t) u * nth;
-         if (i < n) local += d_probe_row(m, d, i, [](uint32_t) { return true; });
+         if (i < n && d_probe_pass(m, d, i)) local += d_probe_row(m, d, i, [](uint32_t) { return true; });
       }
    }
    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
@@ -185,8 +199,9 @@ __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJo
    for (uint64_t w = wave; w < n_words; w += n_waves) {
       uint64_t i = w * 64 + lane;
       bool hit = false;
-      if (i < n) hit = d_probe_row(m, d, i, [](uint32_t) { return false; }) != 0;
-      bool keep = i < n && (m.kind == LDB_JOIN_ANTI ? !hit : hit);
+      const bool pass = i < n && d_probe_pass(m, d, i); // rows a fused filter rejects do not exist
+      if (pass) hit = d_probe_row(m, d, i, [](uint32_t) { return false; }) != 0;
+      bool keep = pass && (m.kind == LDB_JOIN_ANTI ? !hit : hit);
       if (m.has_mark && i < n) mark[i] = hit ? 1 : 0;
       uint64_t mm = __ballot(keep);
       if (lane == 0) {
@@ -209,7 +224,7 @@ __device__ __forceinline__ void join_probe_markbuild_body(const DJoin& m, const 
 #pragma unroll
       for (int u = 0; u < 2; u++) {
          const uint64_t i = i0 + (uint64_t) u * nth;
-         if (i < n)
+         if (i < n && d_probe_pass(m, d, i))
             d_probe_row(m, d, i, [&](uint32_t b) {
                flags[b] = 1;
                return true;
@@ -252,12 +267,21 @@ __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJo
    unsigned long long local = 0;
    for (uint64_t w0 = wave; w0 < n_words; w0 += 2 * n_waves) {
       uint32_t brow[2];
+      uint64_t rows[2];
+      bool pass[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+         const uint64_t w = w0 + (uint64_t) u * n_waves;
+         rows[u] = w * 64 + lane;
+         pass[u] = w < n_words && rows[u] < n;
+      }
+      d_eval_conj_batch<2>(m.ppreds, d->ppreds, m.n_ppreds, rows, pass); // fused filter of a lazy probe side
 #pragma unroll
       for (int u = 0; u < 2; u++) {
          const uint64_t w = w0 + (uint64_t) u * n_waves;
          const uint64_t i = w * 64 + lane;
          brow[u] = LDB_NULL_ROW;
-         if (w < n_words && i < n) {
+         if (pass[u]) {
             uint32_t b = LDB_NULL_ROW;
             d_probe_row(m, d, i, [&](uint32_t x) {
                b = x;
@@ -270,7 +294,9 @@ __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJo
       for (int u = 0; u < 2; u++) {
          const uint64_t w = w0 + (uint64_t) u * n_waves;
          const uint64_t i = w * 64 + lane;
-         if (w < n_words && i < n) match[i] = brow[u];
+         // INNER reads match[] only at the bitmap's set bits: unmatched rows are not written (a
+         // selective join would otherwise stream 4 B per probe row for nothing)
+         if (w < n_words && i < n && (brow[u] != LDB_NULL_ROW || !m.has_bitmap)) match[i] = brow[u];
          uint64_t mm = __ballot(brow[u] != LDB_NULL_ROW);
          if (lane == 0 && w < n_words) {
             if (m.has_bitmap) bitmap[w] = mm;

@@ -128,17 +128,17 @@ int32_t ldb_rel_select(ldb_ctx* ctx, ldb_rel* in, uint32_t* sel, int64_t n_sel, 
    return LDB_OK;
 }
 
-extern "C" int32_t ldb_gpu_scan_filter(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds, int32_t n_preds, ldb_rel** out) {
-   if (!ctx || !in || !out) LDB_FAIL(LDB_ERR_INVALID, "scan_filter: NULL argument");
-   DScan h;
-   LDB_TRY(build_scan_desc(in, preds, n_preds, &h));
+// run the conjunction over the dense base rows of `in` → ascending row numbers (device, owned by caller)
+static int32_t scan_run(ldb_ctx* ctx, ldb_rel* in, const DScan& h, uint32_t** sel_out, uint64_t* total_out) {
    const int64_t n = in->n_rows;
    const int64_t n_words = (n + 63) / 64;
    const int64_t n_blocks = (n_words + SCAN_WORDS_PER_BLOCK - 1) / SCAN_WORDS_PER_BLOCK;
+   uint32_t* sel;
    if (n == 0) {
-      uint32_t* sel;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &sel, 16));
-      return ldb_rel_select(ctx, in, sel, 0, out);
+      *sel_out = sel;
+      *total_out = 0;
+      return LDB_OK;
    }
    DScan* d;
    uint64_t* bitmap;
@@ -167,7 +167,6 @@ extern "C" int32_t ldb_gpu_scan_filter(ldb_ctx* ctx, ldb_rel* in, const ldb_filt
    LDB_TRY(ldb_exclusive_scan_u32(ctx, counts, offsets, n_blocks, (uint64_t*) ctx->d_scratch));
    uint64_t total = 0;
    LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &total));
-   uint32_t* sel;
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &sel, sizeof(uint32_t) * (size_t) (total ? total : 1)));
    if (total) hipLaunchKernelGGL(k_scan_expand, dim3((unsigned) n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, bitmap, offsets, sel, (uint64_t) n);
    LDB_HIP(hipGetLastError());
@@ -175,13 +174,81 @@ extern "C" int32_t ldb_gpu_scan_filter(ldb_ctx* ctx, ldb_rel* in, const ldb_filt
    ldb_dev_free(ctx, bitmap);
    ldb_dev_free(ctx, counts);
    ldb_dev_free(ctx, offsets);
+   *sel_out = sel;
+   *total_out = total;
+   return LDB_OK;
+}
+
+// lazy filters: on by default for dense relations of >= LDB_LAZY_MIN_ROWS rows (default 1 M);
+// LDB_LAZY_FILTER=0 materialises every filter immediately
+static bool lazy_wanted(const ldb_rel* in) {
+   static int enabled = -1;
+   static int64_t min_rows = 1 << 20;
+   if (enabled < 0) {
+      const char* e = getenv("LDB_LAZY_FILTER");
+      enabled = (e && e[0] == '0') ? 0 : 1;
+      if (const char* m = getenv("LDB_LAZY_MIN_ROWS")) min_rows = atoll(m);
+   }
+   if (!enabled || in->n_rows < min_rows) return false;
+   for (auto& s : in->sides)
+      if (s.rowids) return false;
+   return true;
+}
+
+int32_t ldb_rel_force(ldb_ctx* ctx, ldb_rel* r) {
+   if (!r || r->pending.empty()) return LDB_OK;
+   DScan h;
+   memset(&h, 0, sizeof(h));
+   h.n_rows = (uint64_t) r->n_rows;
+   h.n_preds = (int32_t) r->pending.size();
+   for (size_t p = 0; p < r->pending.size(); p++) h.preds[p] = r->pending[p];
+   ldb_order_preds(h.preds, h.n_preds);
+   uint32_t* sel;
+   uint64_t total;
+   LDB_TRY(scan_run(ctx, r, h, &sel, &total));
+   r->pending.clear();
+   ldb_rel* m = nullptr;
+   LDB_TRY(ldb_rel_select(ctx, r, sel, (int64_t) total, &m));
+   r->n_rows = m->n_rows;
+   r->sides.swap(m->sides); // r was dense: m's old sides (after the swap) own nothing
+   ldb_gpu_rel_release(ctx, m);
+   return LDB_OK;
+}
+
+extern "C" int32_t ldb_gpu_scan_filter(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds, int32_t n_preds, ldb_rel** out) {
+   if (!ctx || !in || !out) LDB_FAIL(LDB_ERR_INVALID, "scan_filter: NULL argument");
+   if (n_preds < 0 || n_preds > LDB_MAX_PREDS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "scan: %d predicates (max %d)", n_preds, LDB_MAX_PREDS);
+   if (!in->pending.empty() && in->pending.size() + (size_t) n_preds > LDB_MAX_PREDS) LDB_TRY(ldb_rel_force(ctx, in));
+   if (!in->pending.empty() || lazy_wanted(in)) {
+      // stay lazy: the conjuncts (compiled against the dense sides) travel with the relation
+      std::vector<DPred> all = in->pending;
+      for (int32_t p = 0; p < n_preds; p++) {
+         DPred dp;
+         LDB_TRY(ldb_make_dpred(in, &preds[p], &dp));
+         all.push_back(dp);
+      }
+      ldb_rel* r = ldb_rel_new(ctx);
+      r->n_rows = in->n_rows;
+      for (auto& s : in->sides) r->sides.push_back(ldb_rel_side{s.table, nullptr, false});
+      r->pending.swap(all);
+      *out = r;
+      return LDB_OK;
+   }
+   DScan h;
+   LDB_TRY(build_scan_desc(in, preds, n_preds, &h));
+   uint32_t* sel;
+   uint64_t total;
+   LDB_TRY(scan_run(ctx, in, h, &sel, &total));
    return ldb_rel_select(ctx, in, sel, (int64_t) total, out);
 }
 
 extern "C" int32_t ldb_gpu_scan_count(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds, int32_t n_preds, int64_t* count) {
    if (!ctx || !in || !count) LDB_FAIL(LDB_ERR_INVALID, "scan_count: NULL argument");
+   if (in->pending.size() + (size_t) (n_preds > 0 ? n_preds : 0) > LDB_MAX_PREDS) LDB_TRY(ldb_rel_force(ctx, in));
    DScan h;
    LDB_TRY(build_scan_desc(in, preds, n_preds, &h));
+   for (auto& dp : in->pending) h.preds[h.n_preds++] = dp; // a lazy input's own conjuncts, fused
+   ldb_order_preds(h.preds, h.n_preds);
    DScan* d;
    LDB_TRY(ldb_dev_upload(ctx, &h, sizeof(h), (void**) &d));
    LDB_HIP(hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));

@@ -313,7 +313,8 @@ static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint6
       for (int w = 0; w < words; w++) init[(size_t) (words + w)] = ~0ull;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_bits, 16 * (size_t) words));
       LDB_HIP(hipMemcpyAsync(d_bits, init.data(), 16 * (size_t) words, hipMemcpyHostToDevice, ctx->stream));
-      hipLaunchKernelGGL(k_key_bits, dim3(std::min(grid, 1024), words), dim3(256), 0, ctx->stream, keys, words, n, d_bits);
+      // few blocks: every wave ends in two same-address atomics (≈10 ns each when contended)
+      hipLaunchKernelGGL(k_key_bits, dim3(std::min(grid, 64), words), dim3(256), 0, ctx->stream, keys, words, n, d_bits);
       LDB_HIP(hipMemcpyAsync(bits.data(), d_bits, 16 * (size_t) words, hipMemcpyDeviceToHost, ctx->stream));
       LDB_HIP(hipStreamSynchronize(ctx->stream));
       ldb_dev_free(ctx, d_bits);
@@ -426,6 +427,7 @@ static int32_t sort_perm(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, 
 
 extern "C" int32_t ldb_gpu_sort(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int32_t n_specs, ldb_rel** out) {
    if (!ctx || !in || !out) LDB_FAIL(LDB_ERR_INVALID, "sort: NULL argument");
+   LDB_TRY(ldb_rel_force(ctx, in));
    uint32_t* perm;
    LDB_TRY(sort_perm(ctx, in, specs, n_specs, (uint64_t) in->n_rows, &perm));
    return ldb_rel_select(ctx, in, perm, in->n_rows, out);
@@ -434,6 +436,7 @@ extern "C" int32_t ldb_gpu_sort(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* 
 // Radix select on the leading key word → the few candidate rows → sorted (see sort_records).
 extern "C" int32_t ldb_gpu_topk(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int32_t n_specs, int64_t k, ldb_rel** out) {
    if (!ctx || !in || !out || k < 0) LDB_FAIL(LDB_ERR_INVALID, "topk: bad argument");
+   LDB_TRY(ldb_rel_force(ctx, in));
    uint32_t* perm;
    LDB_TRY(sort_perm(ctx, in, specs, n_specs, (uint64_t) k, &perm));
    return ldb_rel_select(ctx, in, perm, std::min<int64_t>(k, in->n_rows), out);
@@ -451,6 +454,7 @@ __global__ void k_part_hist(const uint64_t* __restrict__ ids, uint64_t n, unsign
 extern "C" int32_t ldb_gpu_partition(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* keys, int32_t n_keys, int32_t nparts, const ldb_colref* cols, int32_t n_cols,
                                      ldb_table** out, int64_t* counts) {
    if (!ctx || !in || !out || !counts || nparts < 1 || nparts > 256) LDB_FAIL(LDB_ERR_INVALID, "partition: bad argument (1..256 partitions)");
+   LDB_TRY(ldb_rel_force(ctx, in));
    const uint64_t n = (uint64_t) in->n_rows;
    DKeys hk;
    LDB_TRY(ldb_make_dkeys(in, keys, n_keys, &hk));

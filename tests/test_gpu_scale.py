@@ -95,3 +95,36 @@ def test_partition_conserves_rows(ctx, big):
     keys_before = np.frombuffer(od.read_fixed(od.col("o_orderkey")).tobytes(), dtype=np.int32).astype(np.int64).sum()
     keys_after = np.frombuffer(packed.read_fixed(0).tobytes(), dtype=np.int32).astype(np.int64).sum()
     assert keys_before == keys_after
+
+
+def test_lazy_filter_fused_into_probe_and_groupby_equals_materialised(ctx, big):
+    """A filter over a large base table stays lazy and is fused into the consuming probe / group-by
+    kernel; forcing it first (reading the row count materialises the row-id vector) must give the
+    same rows, pairs and sums — every join kind that fuses, plus the kinds that force."""
+    li, od = big["li"], big["od"]
+    lk, lship, ext = li.col("l_orderkey"), li.col("l_shipdate"), li.col("l_extendedprice")
+    ok, odate = od.col("o_orderkey"), od.col("o_orderdate")
+    lpred = [api.pred((0, lship), capi.F_GT, 9204), api.pred((0, lship), capi.F_LTE, 9300)]
+    opred = [api.pred((0, odate), capi.F_LT, 9204), api.pred((0, odate), capi.F_GTE, 9100)]
+    ht = od.rel().scan_filter(opred).join_build([(0, ok)], unique=True)
+    agg = [api.agg(capi.AGG_SUM, api.col_expr((0, ext)), out_type=capi.T_DECIMAL128, p=12, s=2), api.agg(capi.AGG_COUNT_STAR)]
+
+    def variants():
+        lazy = li.rel().scan_filter(lpred)
+        forced = li.rel().scan_filter(lpred)
+        assert forced.rows > 0  # materialises
+        return lazy, forced
+
+    for kind in (capi.JOIN_INNER, capi.JOIN_SEMI, capi.JOIN_ANTI, capi.JOIN_SEMI_BUILD, capi.JOIN_ANTI_BUILD, capi.JOIN_LEFT_OUTER):
+        lazy, forced = variants()
+        a, b = ht.probe(lazy, [(0, lk)], kind), ht.probe(forced, [(0, lk)], kind)
+        assert a.rows == b.rows and a.sides == b.sides, kind
+        for s in range(a.sides):
+            assert np.array_equal(a.rowids(s), b.rowids(s)), (kind, s)
+    lazy, forced = variants()
+    assert ht.probe_count(lazy, [(0, lk)]) == ht.probe_count(forced, [(0, lk)])
+    lazy, forced = variants()
+    extra = [api.pred((0, li.col("l_quantity")), capi.F_LT, 2500)]
+    assert rows_of(lazy.groupby([], agg, extra).to_arrow()) == rows_of(forced.groupby([], agg, extra).to_arrow())
+    lazy, forced = variants()
+    assert lazy.scan_filter(extra).scan_count([]) == forced.scan_filter(extra).rows

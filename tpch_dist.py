@@ -58,19 +58,72 @@ def tensors_to_table(ctx, like, cols, n_rows, name):
     return out
 
 
+def _d2d(ctx, dst_ptr, src_ptr, nbytes):
+    if nbytes:
+        check(ctx.lib.ldb_gpu_memcpy_d2d(ctx.h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes))
+
+
 def replicate(runner, table, name):
-    """all-gather a small fixed-width table: every rank gets the concatenation in rank order.
-    NULLs: the exchanged partial tables carry validity only for empty-input SUMs; those rows are
-    dropped by exchanging a validity-free table (callers pass NOT NULL tables)."""
-    cols, widths = table_to_tensors(runner.ctx, table)
+    """all-gather a small table: every rank gets the concatenation in rank order.  Fixed-width
+    columns travel as they are; a utf8 column travels as its lengths (int64 per row) plus one
+    separate gather of its bytes, and the offsets are rebuilt on arrival.
+    NULLs: the exchanged partial tables carry validity only for empty-input SUMs; callers pass
+    NOT NULL tables."""
+    ctx, n, nc = runner.ctx, table.rows, table.n_cols
     staged = runner.dist.get_backend() == "gloo"  # functional testing of the N>1 path on one GPU
-    if staged:
-        cols = [c.cpu() for c in cols]
-    out, counts = ldist.allgather_columns(runner.dist, cols, widths, table.rows)
-    if staged:
-        out = [c.cuda() for c in out]
+    cols, widths, blobs = [], [], {}
+    for c in range(nc):
+        values, offsets, _, _ = table.col_ptrs(c)
+        if table.coltype(c).type == capi.T_UTF8:
+            off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+            _d2d(ctx, off.data_ptr(), offsets, 8 * (n + 1) if n else 0)
+            ctx.sync()
+            first, total = (int(off[0].item()), int((off[n] - off[0]).item())) if n else (0, 0)
+            blob = torch.empty(max(total, 1), dtype=torch.uint8, device="cuda")
+            _d2d(ctx, blob.data_ptr(), values + first, total)
+            cols.append((off[1:] - off[:-1]).contiguous().view(torch.uint8) if n else torch.empty(1, dtype=torch.uint8, device="cuda"))
+            widths.append(8)
+            blobs[c] = (blob, total)
+        else:
+            w = table.col_width(c)
+            t = torch.empty(max(n * w, 1), dtype=torch.uint8, device="cuda")
+            _d2d(ctx, t.data_ptr(), values, n * w)
+            cols.append(t)
+            widths.append(w)
+    ctx.sync()
+
+    def gather(tensors, ws, rows):
+        if staged:
+            tensors = [t.cpu() for t in tensors]
+        out, counts = ldist.allgather_columns(runner.dist, tensors, ws, rows)
+        return ([t.cuda() for t in out] if staged else out), counts
+
+    out, counts = gather(cols, widths, n)
+    n_all = sum(counts)
+    data = {c: gather([blob], [1], total) for c, (blob, total) in blobs.items()}
     torch.cuda.synchronize()
-    return tensors_to_table(runner.ctx, table, out, sum(counts), name)
+    types = (ColType * nc)(*[table.coltype(c) for c in range(nc)])
+    names = (C.c_char_p * nc)(*[table.col_name(c).encode() for c in range(nc)])
+    data_bytes = (C.c_int64 * nc)(*[(sum(data[c][1]) if c in data else 0) for c in range(nc)])
+    narrow = 1 if any(table.col_width(c) == 8 and table.coltype(c).type == capi.T_DECIMAL128 for c in range(nc)) else 0
+    h = C.c_void_p()
+    check(ctx.lib.ldb_gpu_table_alloc(ctx.h, name.encode(), nc, types, names, n_all, data_bytes, narrow, C.byref(h)))
+    res = Table(ctx, h)
+    keep = []
+    for c in range(nc):
+        values, offsets, _, _ = res.col_ptrs(c)
+        if c in data:
+            lens = out[c].view(torch.int64) if n_all else torch.zeros(0, dtype=torch.int64, device="cuda")
+            off = torch.zeros(n_all + 1, dtype=torch.int64, device="cuda")
+            off[1:] = torch.cumsum(lens, 0)
+            keep.append(off)
+            torch.cuda.synchronize()
+            _d2d(ctx, offsets, off.data_ptr(), 8 * (n_all + 1))
+            _d2d(ctx, values, data[c][0][0].data_ptr(), sum(data[c][1]))
+        else:
+            _d2d(ctx, values, out[c].data_ptr(), n_all * res.col_width(c))
+    ctx.sync()
+    return res
 
 
 def run_query(runner, q):
