@@ -186,9 +186,119 @@ __device__ __forceinline__ void join_probe_count_body(const DJoin& m, const DJoi
    if ((threadIdx.x & 63) == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter) + 1, local);
 }
 
+// ---------------------------------------------------------------- fused filter: LDS-staged compaction
+// With a fused filter a lane whose row fails would idle while its neighbours walk the table, and a
+// probe is latency-bound: throughput is proportional to the lanes actually probing (54 % for
+// Q3's lineitem side).  So a workgroup first filters a TILE of JT_ROWS consecutive rows
+// (predicate-major, JT_U rows per thread, coalesced), compacts the survivors' tile-relative row
+// numbers into an LDS queue (ballot + popcount rank, one LDS atomic per wave and batch row), and
+// then probes from the queue with every lane busy.  Results that must stay in row order go through
+// a per-tile bitmap in LDS (JT_ROWS / 64 words) that is written out once per tile.
+#define JT_BLOCK 256
+#define JT_U 8
+#define JT_ROWS (JT_BLOCK * JT_U)
+struct JoinTile {
+   unsigned short q[JT_ROWS];
+   unsigned long long bm[JT_ROWS / 64];
+   uint32_t qn;
+};
+// filter rows [base, base + JT_ROWS) → st.q[0 .. st.qn); ends with a barrier
+__device__ __forceinline__ void d_tile_filter(const DJoin& m, const DJoin* __restrict__ d, uint64_t base, uint64_t n, JoinTile& st) {
+   const uint32_t t = threadIdx.x, lane = t & 63;
+   if (t < JT_ROWS / 64) st.bm[t] = 0;
+   if (t == 0) st.qn = 0;
+   __syncthreads();
+   uint64_t rows[JT_U];
+   bool pass[JT_U];
+#pragma unroll
+   for (int u = 0; u < JT_U; u++) {
+      rows[u] = base + (uint64_t) u * JT_BLOCK + t;
+      pass[u] = rows[u] < n;
+   }
+   d_eval_conj_batch<JT_U>(m.ppreds, d->ppreds, m.n_ppreds, rows, pass);
+#pragma unroll
+   for (int u = 0; u < JT_U; u++) {
+      const uint64_t mask = __ballot(pass[u]);
+      uint32_t b = 0;
+      if (mask != 0 && lane == (uint32_t) __builtin_ctzll(mask)) b = atomicAdd(&st.qn, (uint32_t) __popcll(mask));
+      b = __shfl(b, mask ? __builtin_ctzll(mask) : 0);
+      if (pass[u]) st.q[b + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short) (u * JT_BLOCK + t);
+   }
+   __syncthreads();
+}
+
+__device__ __forceinline__ void join_probe_unique_filtered_body(const DJoin& m, const DJoin* __restrict__ d) {
+   __shared__ JoinTile st;
+   const uint64_t n = d->n_rows;
+   const uint64_t n_words = (n + 63) / 64, n_tiles = (n + JT_ROWS - 1) / JT_ROWS;
+   uint64_t* bitmap = gptr_mut<uint64_t>(d->bitmap);
+   uint32_t* match = gptr_mut<uint32_t>(d->match);
+   unsigned long long local = 0;
+   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      const uint64_t base = tile * JT_ROWS;
+      d_tile_filter(m, d, base, n, st);
+      const uint32_t qn = st.qn;
+      for (uint32_t j = threadIdx.x; j < qn; j += JT_BLOCK) {
+         const uint32_t r = st.q[j];
+         uint32_t b = LDB_NULL_ROW;
+         d_probe_row(m, d, base + r, [&](uint32_t x) {
+            b = x;
+            return false;
+         });
+         if (b != LDB_NULL_ROW) {
+            match[base + r] = b;
+            atomicOr(&st.bm[r >> 6], 1ull << (r & 63));
+         }
+      }
+      __syncthreads();
+      if (threadIdx.x < JT_ROWS / 64) {
+         const uint64_t w = tile * (JT_ROWS / 64) + threadIdx.x;
+         if (w < n_words) {
+            bitmap[w] = st.bm[threadIdx.x];
+            local += (unsigned long long) __popcll(st.bm[threadIdx.x]);
+         }
+      }
+      __syncthreads();
+   }
+   if (threadIdx.x < 64) {
+      for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+      if (threadIdx.x == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter), local);
+   }
+}
+
 // SEMI / ANTI / MARK: existence per probe row → bitmap word per wave (rows in ascending order)
 __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows;
+   if (m.n_ppreds > 0) { // fused filter: tile compaction (never MARK: the host forces those)
+      __shared__ JoinTile st;
+      const uint64_t n_words = (n + 63) / 64, n_tiles = (n + JT_ROWS - 1) / JT_ROWS;
+      uint64_t* bitmap = gptr_mut<uint64_t>(d->bitmap);
+      unsigned long long local = 0;
+      for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+         const uint64_t base = tile * JT_ROWS;
+         d_tile_filter(m, d, base, n, st);
+         const uint32_t qn = st.qn;
+         for (uint32_t j = threadIdx.x; j < qn; j += JT_BLOCK) {
+            const uint32_t r = st.q[j];
+            const bool hit = d_probe_row(m, d, base + r, [](uint32_t) { return false; }) != 0;
+            if (m.kind == LDB_JOIN_ANTI ? !hit : hit) atomicOr(&st.bm[r >> 6], 1ull << (r & 63));
+         }
+         __syncthreads();
+         if (threadIdx.x < JT_ROWS / 64) {
+            const uint64_t w = tile * (JT_ROWS / 64) + threadIdx.x;
+            if (w < n_words) {
+               bitmap[w] = st.bm[threadIdx.x];
+               local += (unsigned long long) __popcll(st.bm[threadIdx.x]);
+            }
+         }
+         __syncthreads();
+      }
+      if (threadIdx.x < 64) {
+         for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+         if (threadIdx.x == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter), local);
+      }
+      return;
+   }
    const uint64_t n_words = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;
    const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
@@ -219,6 +329,22 @@ __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJo
 __device__ __forceinline__ void join_probe_markbuild_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows;
    uint8_t* flags = gptr_mut<uint8_t>(d->mark);
+   if (m.n_ppreds > 0) { // fused filter: tile compaction, then every lane probes
+      __shared__ JoinTile st;
+      const uint64_t n_tiles = (n + JT_ROWS - 1) / JT_ROWS;
+      for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+         const uint64_t base = tile * JT_ROWS;
+         d_tile_filter(m, d, base, n, st);
+         const uint32_t qn = st.qn;
+         for (uint32_t j = threadIdx.x; j < qn; j += JT_BLOCK)
+            d_probe_row(m, d, base + st.q[j], [&](uint32_t b) {
+               flags[b] = 1;
+               return true;
+            });
+         __syncthreads();
+      }
+      return;
+   }
    const uint64_t tid = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x, nth = (uint64_t) gridDim.x * blockDim.x;
    for (uint64_t i0 = tid; i0 < n; i0 += 2 * nth) {
 #pragma unroll
@@ -257,6 +383,10 @@ __device__ __forceinline__ void join_flags_bitmap_body(const uint8_t* __restrict
 // by the ordered bitmap expansion — no atomics on an output cursor, deterministic ascending
 // order.  Two words (128 rows) per wave iteration keep two independent probes in flight.
 __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJoin* __restrict__ d) {
+   if (m.n_ppreds > 0 && m.has_bitmap) { // INNER with a fused filter
+      join_probe_unique_filtered_body(m, d);
+      return;
+   }
    const uint64_t n = d->n_rows;
    const uint64_t n_words = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;

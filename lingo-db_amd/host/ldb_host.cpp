@@ -694,6 +694,105 @@ extern "C" int32_t ldb_plan_tpch_q3_final(ldb_ctx* ctx, const ldb_table* tops, l
    });
 }
 
+// Q4 / Q12 multi-GPU: orders and their lineitems live on the same rank, so every rank runs the
+// single-GPU plan on its shard; the gathered per-rank rows are merged by summing the counts
+// (the reference's combine step) and re-sorted.
+namespace {
+ldb_agg_spec sumIntCol(ldb_colref c, int32_t out_type) {
+   ldb_agg_spec a = sumInt64(c);
+   a.out_type = out_type;
+   return a;
+}
+void mergeCounts(ldb_ctx* ctx, const ldb_table* partials, int n_counts, int32_t out_type, ldb_table** result, const char* what) {
+   Rel in(ctx), sorted(ctx), g(ctx);
+   check(ldb_gpu_rel_from_table(ctx, partials, &in.r), what);
+   ldb_colref key{0, 0};
+   ldb_agg_spec aggs[4];
+   for (int a = 0; a < n_counts; a++) aggs[a] = sumIntCol({0, 1 + a}, out_type);
+   Table grouped(ctx);
+   check(ldb_gpu_groupby(ctx, in.r, nullptr, 0, &key, 1, aggs, n_counts, 8, &grouped.t), what);
+   check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), what);
+   ldb_sort_spec spec{{0, 0}, 0, 0};
+   check(ldb_gpu_sort(ctx, g.r, &spec, 1, &sorted.r), what);
+   ldb_colref outc[5];
+   for (int c = 0; c < 1 + n_counts; c++) outc[c] = {0, c};
+   check(ldb_gpu_materialize(ctx, sorted.r, outc, 1 + n_counts, result), what);
+}
+} // namespace
+extern "C" int32_t ldb_plan_tpch_q4_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result) {
+   return guarded([&] { mergeCounts(ctx, partials, 1, LDB_T_INT64, result, "q4 final"); });
+}
+extern "C" int32_t ldb_plan_tpch_q12_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result) {
+   return guarded([&] { mergeCounts(ctx, partials, 2, LDB_T_INT32, result, "q12 final"); });
+}
+
+// Q18 multi-GPU.  Step 1 (per shard; orders and lineitem are co-partitioned): the big group-by,
+// HAVING, the join back to orders and lineitem, and the shard's top-100 — customer columns are
+// not needed yet: (o_custkey, o_orderkey, o_orderdate, o_totalprice, sum_qty).
+extern "C" int32_t ldb_plan_tpch_q18_local(ldb_ctx* ctx, const ldb_table* ord, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel l0(ctx), o0(ctx), g0(ctx), g1(ctx), o1(ctx), lo(ctx), top(ctx), g(ctx);
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q18 lineitem");
+      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q18 orders");
+      ldb_colref lok{0, colOf(li, "l_orderkey")}, qty{0, colOf(li, "l_quantity")};
+      ldb_agg_spec sumq = sumDec(product({colFactor(qty)}), decOf(li, qty.col));
+      Table perOrder(ctx), grouped(ctx);
+      check(ldb_gpu_groupby(ctx, l0.r, nullptr, 0, &lok, 1, &sumq, 1, std::max<int64_t>(1, ldb_gpu_table_rows(ord)), &perOrder.t), "q18 group by l_orderkey");
+      check(ldb_gpu_rel_from_table(ctx, perOrder.t, &g0.r), "q18 rel");
+      auto having = Restrictions::create({{"agg0", FilterOp::GT, (int64_t) 300, {}}}, perOrder.t);
+      check(ldb_gpu_scan_filter(ctx, g0.r, having->data(), having->size(), &g1.r), "q18 having");
+      Ht hk(ctx), ho(ctx);
+      ldb_colref gk{0, 0}, ook{0, colOf(ord, "o_orderkey")};
+      check(ldb_gpu_join_build(ctx, g1.r, &gk, 1, 1, &hk.h), "q18 build keys");
+      check(ldb_gpu_join_probe(ctx, hk.h, o0.r, &ook, 1, LDB_JOIN_SEMI, &o1.r, nullptr), "q18 semi join orders");
+      check(ldb_gpu_join_build(ctx, o1.r, &ook, 1, 1, &ho.h), "q18 build orders");
+      check(ldb_gpu_join_probe(ctx, ho.h, l0.r, &lok, 1, LDB_JOIN_INNER, &lo.r, nullptr), "q18 probe lineitem"); // sides: lineitem, orders
+      ldb_colref keys[4] = {{1, colOf(ord, "o_custkey")}, {1, ook.col}, {1, colOf(ord, "o_orderdate")}, {1, colOf(ord, "o_totalprice")}};
+      check(ldb_gpu_groupby(ctx, lo.r, nullptr, 0, keys, 4, &sumq, 1, std::max<int64_t>(1, ldb_gpu_rel_rows(ctx, o1.r)), &grouped.t), "q18 groupby");
+      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q18 rel");
+      ldb_sort_spec specs[2] = {{{0, 3}, 1, 0}, {{0, 2}, 0, 0}};
+      check(ldb_gpu_topk(ctx, g.r, specs, 2, 100, &top.r), "q18 local topk");
+      ldb_colref outc[5] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}};
+      check(ldb_gpu_materialize(ctx, top.r, outc, 5, result), "q18 local materialize");
+   });
+}
+// Step 2 (replicated): the global top-100 of the gathered shard top-100s.
+extern "C" int32_t ldb_plan_tpch_q18_mid(ldb_ctx* ctx, const ldb_table* tops, ldb_table** result) {
+   return guarded([&] {
+      Rel in(ctx), top(ctx);
+      check(ldb_gpu_rel_from_table(ctx, tops, &in.r), "q18 mid");
+      ldb_sort_spec specs[2] = {{{0, 3}, 1, 0}, {{0, 2}, 0, 0}};
+      check(ldb_gpu_topk(ctx, in.r, specs, 2, 100, &top.r), "q18 mid topk");
+      ldb_colref outc[5] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}};
+      check(ldb_gpu_materialize(ctx, top.r, outc, 5, result), "q18 mid materialize");
+   });
+}
+// Step 3 (per shard): c_name for the winners whose customer lives in this rank's customer shard.
+extern "C" int32_t ldb_plan_tpch_q18_names(ldb_ctx* ctx, const ldb_table* top100, const ldb_table* cust, ldb_table** result) {
+   return guarded([&] {
+      Rel t0(ctx), c0(ctx), ct(ctx);
+      check(ldb_gpu_rel_from_table(ctx, top100, &t0.r), "q18 names");
+      check(ldb_gpu_rel_from_table(ctx, cust, &c0.r), "q18 names customer");
+      Ht ht(ctx);
+      ldb_colref tk{0, 0}, ck{0, colOf(cust, "c_custkey")};
+      check(ldb_gpu_join_build(ctx, t0.r, &tk, 1, 0, &ht.h), "q18 names build");
+      check(ldb_gpu_join_probe(ctx, ht.h, c0.r, &ck, 1, LDB_JOIN_INNER, &ct.r, nullptr), "q18 names probe"); // sides: customer, top100
+      ldb_colref outc[6] = {{0, colOf(cust, "c_name")}, {0, ck.col}, {1, 1}, {1, 2}, {1, 3}, {1, 4}};
+      check(ldb_gpu_materialize(ctx, ct.r, outc, 6, result), "q18 names materialize");
+   });
+}
+// Step 4 (replicated): order the gathered rows.
+extern "C" int32_t ldb_plan_tpch_q18_final(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result) {
+   return guarded([&] {
+      Rel in(ctx), top(ctx);
+      check(ldb_gpu_rel_from_table(ctx, rows, &in.r), "q18 final");
+      ldb_sort_spec specs[2] = {{{0, 4}, 1, 0}, {{0, 3}, 0, 0}};
+      check(ldb_gpu_topk(ctx, in.r, specs, 2, 100, &top.r), "q18 final topk");
+      ldb_colref outc[6] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}};
+      check(ldb_gpu_materialize(ctx, top.r, outc, 6, result), "q18 final materialize");
+   });
+}
+
 // ---------------------------------------------------------------- C hooks for the host-logic tests
 extern "C" int32_t ldb_host_parse_date32(const char* s, int32_t* out) {
    return guarded([&] { *out = parseDate32(s); });

@@ -82,6 +82,12 @@ int32_t ldb_plan_tpch_q6_final(ldb_ctx* ctx, const ldb_table* partials, ldb_tabl
 int32_t ldb_plan_tpch_q3_customers(ldb_ctx* ctx, const ldb_table* customer, ldb_table** result);
 int32_t ldb_plan_tpch_q3_local(ldb_ctx* ctx, const ldb_table* custkeys, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q3_final(ldb_ctx* ctx, const ldb_table* tops, ldb_table** result);
+int32_t ldb_plan_tpch_q4_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
+int32_t ldb_plan_tpch_q12_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
+int32_t ldb_plan_tpch_q18_local(ldb_ctx* ctx, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q18_mid(ldb_ctx* ctx, const ldb_table* tops, ldb_table** result);
+int32_t ldb_plan_tpch_q18_names(ldb_ctx* ctx, const ldb_table* top100, const ldb_table* customer, ldb_table** result);
+int32_t ldb_plan_tpch_q18_final(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
 // test hooks for the host logic (date / decimal parsing, decimal typing rules)
 int32_t ldb_host_parse_date32(const char* s, int32_t* out);
 int32_t ldb_host_parse_decimal(const char* s, int32_t scale, int64_t* lo, int64_t* hi);

@@ -198,6 +198,12 @@ HOST_API = {
     "ldb_plan_tpch_q3_customers": (i32, [P, P, PP]),
     "ldb_plan_tpch_q3_local": (i32, [P, P, P, P, PP]),
     "ldb_plan_tpch_q3_final": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q4_final": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q12_final": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q18_local": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q18_mid": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q18_names": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q18_final": (i32, [P, P, PP]),
     "ldb_host_parse_date32": (i32, [C.c_char_p, C.POINTER(i32)]),
     "ldb_host_parse_decimal": (i32, [C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64)]),
     "ldb_host_decimal_type": (None, [i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),

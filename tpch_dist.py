@@ -143,4 +143,15 @@ def run_query(runner, q):
         top = _plan(ctx, "ldb_plan_tpch_q3_local", allkeys, db.orders, db.lineitem)
         tops = replicate(runner, top, "q3_tops")
         return _plan(ctx, "ldb_plan_tpch_q3_final", tops)
+    if q == 4:  # orders and their lineitems are co-located: local plan, merge the per-rank counts
+        part = ctx.plan_q4(db.orders, db.lineitem)
+        return _plan(ctx, "ldb_plan_tpch_q4_final", replicate(runner, part, "q4_partials"))
+    if q == 12:
+        part = ctx.plan_q12(db.orders, db.lineitem)
+        return _plan(ctx, "ldb_plan_tpch_q12_final", replicate(runner, part, "q12_partials"))
+    if q == 18:
+        top = _plan(ctx, "ldb_plan_tpch_q18_local", db.orders, db.lineitem)
+        top100 = _plan(ctx, "ldb_plan_tpch_q18_mid", replicate(runner, top, "q18_tops"))
+        named = _plan(ctx, "ldb_plan_tpch_q18_names", top100, db.customer)  # customers are sharded by rows
+        return _plan(ctx, "ldb_plan_tpch_q18_final", replicate(runner, named, "q18_named"))
     raise ValueError(f"TPC-H Q{q} has no multi-GPU plan yet")

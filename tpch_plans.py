@@ -186,9 +186,9 @@ def cpu_baseline(queries, sample_sf):
     oracle = oracle_bind.load()
     cores = oracle.num_cores()
     n_orders = int(round(sample_sf * 1_500_000))
-    li = oracle_bind.HostTable(tpch_data.host_table(tpch_data.LINEITEM, n_orders, cols=[0, 4, 5, 6, 7, 8, 9, 10]))
+    li = oracle_bind.HostTable(tpch_data.host_table(tpch_data.LINEITEM, n_orders, cols=[0, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14]))
     # column positions inside the trimmed lineitem table
-    LK, QTY, EXT, DISC, TAX, RF, LS, SHIP = range(8)
+    LK, QTY, EXT, DISC, TAX, RF, LS, SHIP, COMMIT, RECEIPT, MODE = range(11)
     f = api.factor
     D = capi.T_DECIMAL128
 
@@ -225,7 +225,32 @@ def cpu_baseline(queries, sample_sf):
         rep, vals, valid = oracle.groupby(lco, [(0, LK), (1, 2), (1, 3)], [agg], threads=cores)
         return len(rep)
 
-    fns = {1: q1, 6: q6, 3: q3}
+    od2 = None
+    if 4 in queries or 12 in queries:
+        od2 = oracle_bind.HostTable(tpch_data.host_table(tpch_data.ORDERS, n_orders, cols=[0, 4, 5]))  # o_orderkey, o_orderdate, o_orderpriority
+
+    def q4():
+        ho, hl = od2.rel(), li.rel()
+        o1 = ho.select(oracle.scan_filter(ho, [api.pred((0, 1), capi.F_GTE, 8582), api.pred((0, 1), capi.F_LT, 8674)], cores))
+        l1 = hl.select(oracle.scan_filter(hl, [api.pred((0, COMMIT), capi.F_LT, rhs_col=(0, RECEIPT))], cores))
+        keep, _, _ = oracle.join(o1, [(0, 0)], l1, [(0, LK)], capi.JOIN_SEMI_BUILD, cores)
+        osel = oracle_bind.HostRel([(od2, o1.phys(0)[keep])], len(keep))
+        return oracle.groupby(osel, [(0, 2)], [api.agg(capi.AGG_COUNT_STAR)], threads=cores)
+
+    def q12():
+        ho, hl = od2.rel(), li.rel()
+        lp = [api.pred((0, RECEIPT), capi.F_GTE, 8766), api.pred((0, RECEIPT), capi.F_LT, 9131), api.pred((0, COMMIT), capi.F_LT, rhs_col=(0, RECEIPT)),
+              api.pred((0, SHIP), capi.F_LT, rhs_col=(0, COMMIT)), api.pred((0, MODE), capi.F_IN, values=["MAIL", "SHIP"])]
+        l1 = hl.select(oracle.scan_filter(hl, lp, cores))
+        op, ob, _ = oracle.join(l1, [(0, LK)], ho, [(0, 0)], capi.JOIN_INNER, cores)
+        ol = oracle_bind.HostRel([(od2, op), (li, l1.phys(0)[ob])], len(op))
+        one = api.expr([{"factors": [f(1, 0)]}])
+        high = [api.pred((0, 2), capi.F_IN, values=["1-URGENT", "2-HIGH"])]
+        low = [api.pred((0, 2), capi.F_NEQ, "1-URGENT"), api.pred((0, 2), capi.F_NEQ, "2-HIGH")]
+        aggs = [api.agg(capi.AGG_SUM, one, out_type=capi.T_INT32, preds=high), api.agg(capi.AGG_SUM, one, out_type=capi.T_INT32, preds=low)]
+        return oracle.groupby(ol, [(1, MODE)], aggs, threads=cores)
+
+    fns = {1: q1, 6: q6, 3: q3, 4: q4, 12: q12}
     per = {}
     queries = [q for q in queries if q in fns]  # the CPU leg covers the headline queries
     if not queries:
