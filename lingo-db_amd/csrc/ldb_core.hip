@@ -430,6 +430,7 @@ extern "C" int32_t ldb_gpu_table_col_width(const ldb_table* t, int32_t col) {
 extern "C" int32_t ldb_gpu_table_col_ptrs(const ldb_table* t, int32_t col, void** values, void** offsets, void** validity, int64_t* value_bytes) {
    if (!t || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "col_ptrs: bad column %d", col);
    const ldb_column& c = t->cols[(size_t) col];
+   c.has_range = false; // the caller may write through the raw pointers
    if (values) *values = c.values;
    if (offsets) *offsets = c.offsets;
    if (validity) *validity = c.validity;
@@ -441,6 +442,7 @@ extern "C" int32_t ldb_gpu_table_set_rows(ldb_table* t, int64_t n_rows) {
    for (auto& c : t->cols)
       if (c.type.type != LDB_T_UTF8 && n_rows * c.width > c.value_bytes) LDB_FAIL(LDB_ERR_INVALID, "set_rows: %ld rows exceed capacity of column %s", (long) n_rows, c.name.c_str());
    t->n_rows = n_rows;
+   for (auto& c : t->cols) c.has_range = false;
    return LDB_OK;
 }
 extern "C" int32_t ldb_gpu_table_read_fixed(ldb_ctx* ctx, const ldb_table* t, int32_t col, void* host_out, int64_t out_bytes) {
@@ -460,6 +462,7 @@ extern "C" int32_t ldb_gpu_table_write_fixed(ldb_ctx* ctx, ldb_table* t, int32_t
    if (in_bytes > c.value_bytes) LDB_FAIL(LDB_ERR_INVALID, "write_fixed: %ld bytes exceed column capacity %ld", (long) in_bytes, (long) c.value_bytes);
    if (in_bytes) LDB_HIP(hipMemcpyAsync(c.values, host_in, (size_t) in_bytes, hipMemcpyHostToDevice, ctx->stream));
    LDB_HIP(hipStreamSynchronize(ctx->stream));
+   c.has_range = false;
    return LDB_OK;
 }
 
@@ -741,6 +744,57 @@ static int pred_cost(const DPred& p) {
    if (p.rhs_kind == LDB_RHS_COLUMN || p.op == LDB_F_IN) return 2;
    return 1;
 }
+// ---------------------------------------------------------------- column statistics
+__global__ void k_column_range(DCol col, uint64_t n, long long* __restrict__ out) {
+   long long lo = 0x7FFFFFFFFFFFFFFFll, hi = -0x7FFFFFFFFFFFFFFFll - 1;
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      long long k = d_load_i64(col, (uint32_t) i);
+      lo = k < lo ? k : lo;
+      hi = k > hi ? k : hi;
+   }
+   for (int off = 32; off > 0; off >>= 1) {
+      long long l2 = __shfl_down(lo, off), h2 = __shfl_down(hi, off);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+   }
+   if ((threadIdx.x & 63) == 0) {
+      atomicMin(&out[0], lo);
+      atomicMax(&out[1], hi);
+   }
+}
+int32_t ldb_column_range(ldb_ctx* ctx, const ldb_table* t, int32_t col, int64_t* lo, int64_t* hi) {
+   if (!t || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "column_range: bad column %d", col);
+   const ldb_column& c = t->cols[(size_t) col];
+   const int ty = c.type.type;
+   const bool ok = ty == LDB_T_INT8 || ty == LDB_T_INT16 || ty == LDB_T_INT32 || ty == LDB_T_INT64 || ty == LDB_T_DATE32 ||
+                   (ty == LDB_T_DECIMAL128 && c.type.precision < 19);
+   if (!ok) return LDB_ERR_UNSUPPORTED;
+   if (!c.has_range) {
+      long long* d_out = (long long*) (ctx->d_scratch + 40);
+      const long long init[2] = {INT64_MAX, INT64_MIN};
+      long long got[2] = {0, -1};
+      if (t->n_rows > 0) {
+         DCol dc;
+         memset(&dc, 0, sizeof(dc));
+         dc.values = (uint64_t) c.values;
+         dc.type = ty;
+         dc.width = c.width;
+         dc.precision = c.type.precision;
+         dc.scale = c.type.scale;
+         LDB_HIP(hipMemcpyAsync(d_out, init, 16, hipMemcpyHostToDevice, ctx->stream));
+         hipLaunchKernelGGL(k_column_range, dim3(std::min(ldb_grid_for(ctx, t->n_rows, 256, 8), 256)), dim3(256), 0, ctx->stream, dc, (uint64_t) t->n_rows, d_out);
+         LDB_HIP(hipMemcpyAsync(got, d_out, 16, hipMemcpyDeviceToHost, ctx->stream));
+         LDB_HIP(hipStreamSynchronize(ctx->stream));
+      }
+      c.vmin = got[0];
+      c.vmax = got[1];
+      c.has_range = true;
+   }
+   *lo = c.vmin;
+   *hi = c.vmax;
+   return LDB_OK;
+}
+
 void ldb_order_preds(DPred* preds, int32_t n) {
    std::stable_sort(preds, preds + n, [](const DPred& a, const DPred& b) { return pred_cost(a) < pred_cost(b); });
    ldb_mark_same_col(preds, n);

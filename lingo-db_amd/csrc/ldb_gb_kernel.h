@@ -86,10 +86,17 @@ struct DGroupBy {
    uint64_t g_acc; // uint64_t*: word w of slot p at g_acc[w * g_cap + p]
    uint64_t g_flags; // uint32_t*: [0] = overflow
    uint32_t lds_slots, lds_reps; // S (pow2), R (pow2)
+   int64_t kmin; // ordered_slots: smallest key value
+   uint64_t kmult; // ordered_slots: global slot = ((key - kmin) * kmult) >> 32
    // ---- metadata (+ the addresses inside the DCols, which are run-time too)
    int32_t n_preds, n_cols, n_accs, n_words, n_cpreds, n_outs;
    int32_t keyless, use_lds;
-   int32_t batch_rows, pad0; // rows per thread per iteration of the specialised kernel (1, 2, 4 or 8)
+   int32_t batch_rows; // rows per thread per iteration of the specialised kernel (1, 2, 4 or 8)
+   // single integer key, high-cardinality mode: a group's global slot follows the key's position in
+   // the column's value range instead of its hash — input clustered on the key (lineitem on
+   // l_orderkey) then walks the table almost sequentially, and the groups come out in key order.
+   // Long probe runs (skewed keys) raise flag bit 1 and the host retries hashed.
+   int32_t ordered_slots;
    DKeys keys;
    DPred preds[LDB_MAX_PREDS];
    DPred cpreds[GB_MAX_CPREDS];
@@ -394,7 +401,16 @@ __device__ __forceinline__ uint64_t d_global_slot(const DGroupBy& m, const DGrou
    const uint64_t mine = (h & 0xFFFFFFFF00000000ull) | (uint64_t) ((uint32_t) i + 1u);
    uint64_t pos = (h ^ (h >> 29)) & mask;
    const KV keys(m.keys, d->keys);
+   if (m.ordered_slots) {
+      const CV c = keys.col(0);
+      const uint32_t row = d_phys_row(c, i);
+      if (d_valid(c, row)) pos = (((uint64_t) (d_load_i64(c, row) - d->kmin) * d->kmult) >> 32) & mask; // a NULL key keeps its hashed slot
+   }
    for (uint64_t step = 0; step <= mask; step++) {
+      if (m.ordered_slots && step == 512) { // skewed keys: give up at once (runs cost O(length^2)), the host retries hashed
+         atomicOr(gptr_mut<uint32_t>(d->g_flags), 2u);
+         return ~0ull;
+      }
       unsigned long long w = __hip_atomic_load(&gk[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (w == 0) {
          unsigned long long old = atomicCAS(&gk[pos], 0ull, (unsigned long long) mine);

@@ -442,6 +442,19 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    const uint64_t cap_max = next_pow2_u64(std::max<uint64_t>(1024, (uint64_t) in->n_rows * 2));
    if (cap > cap_max) cap = cap_max;
 
+   // ordered global slots (DGroupBy::ordered_slots): one integer key with a 32-bit value range
+   unsigned __int128 key_range = 0;
+   static const bool gb_ordered = !(getenv("LDB_GB_ORDERED") && getenv("LDB_GB_ORDERED")[0] == '0');
+   if (gb_ordered && !h->use_lds && n_keys == 1 && in->n_rows > 0) {
+      int64_t lo = 0, hi = -1;
+      const ldb_rel_side& ks = in->sides[(size_t) keys[0].side];
+      if (!ks.table->cols[(size_t) keys[0].col].skewed && ldb_column_range(ctx, ks.table, keys[0].col, &lo, &hi) == LDB_OK && hi >= lo &&
+          (unsigned __int128) ((__int128) hi - lo) < ((unsigned __int128) 1 << 32)) {
+         h->ordered_slots = 1;
+         h->kmin = lo;
+         key_range = (unsigned __int128) ((__int128) hi - lo) + 1;
+      }
+   }
    uint32_t* d_flags;
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_flags, 64));
    DGroupBy* d = nullptr;
@@ -451,6 +464,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    std::vector<uint8_t*> out_valid((size_t) n_aggs, nullptr);
    for (int attempt = 0;; attempt++) {
       h->g_cap = cap;
+      h->kmult = h->ordered_slots ? (uint64_t) ((((unsigned __int128) cap) << 32) / key_range) : 0;
       uint64_t *gk, *ga;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &gk, 8 * (size_t) cap));
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &ga, 8 * (size_t) cap * (size_t) nw));
@@ -481,11 +495,16 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       LDB_HIP(hipGetLastError());
       uint64_t flags = 0;
       LDB_TRY(ldb_read_u64(ctx, d_flags, &flags));
-      if ((flags & 1) == 0) break;
-      // global table overflowed: retry larger (the estimate was too low)
+      if ((flags & 3) == 0) break;
       ldb_dev_free(ctx, gk);
       ldb_dev_free(ctx, ga);
       ldb_dev_free(ctx, d);
+      if ((flags & 2) && h->ordered_slots) { // long probe runs: this key distribution needs hashed slots
+         h->ordered_slots = 0;
+         in->sides[(size_t) keys[0].side].table->cols[(size_t) keys[0].col].skewed = true;
+         if ((flags & 1) == 0) continue;
+      }
+      // global table overflowed: retry larger (the estimate was too low)
       if (cap >= cap_max) LDB_FAIL(LDB_ERR_HIP, "groupby: global table overflow at maximum capacity");
       cap = std::min(cap * 8, cap_max);
    }

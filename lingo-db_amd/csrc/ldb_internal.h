@@ -43,7 +43,15 @@ struct ldb_column {
    int64_t value_bytes = 0; // bytes in `values`
    int64_t null_count = 0;
    bool owned = true;
+   // value range of a fixed-width integer-like column, computed on first use and cached (the
+   // kind of per-column statistic a catalog keeps; see ldb_column_range)
+   mutable bool has_range = false;
+   mutable int64_t vmin = 0, vmax = -1;
+   mutable bool skewed = false; // ordered hash-table slots over this column gave long probe runs once: do not try again
 };
+// [min, max] over all physical rows of an integer-like column (NULL slots included: a superset is
+// fine for its users); cached in the column.  LDB_ERR_UNSUPPORTED for other types.
+int32_t ldb_column_range(ldb_ctx* ctx, const struct ldb_table* t, int32_t col, int64_t* lo, int64_t* hi);
 
 struct ldb_prof_pending {
    const char* name;

@@ -31,10 +31,14 @@ struct ldb_hashtable {
    uint64_t cap = 0;
    int32_t key32 = 0;
    int32_t unique = 0;
+   int32_t ordered_slots = 0; // KEY32: slots follow the key order (DJoin::ordered_slots)
+   int64_t kmin = 0, kmax = -1;
+   uint64_t kmult = 0;
 };
 
 // ---------------------------------------------------------------- ahead-of-time (generic) kernels
 __global__ void k_join_build(const DJoin* __restrict__ d) { join_build_body(*d, d); }
+__global__ void k_join_key_range(const DJoin* __restrict__ d, long long* __restrict__ out) { join_key_range_body(*d, d, out); }
 __global__ void k_join_probe_pairs(const DJoin* __restrict__ d) { join_probe_pairs_body(*d, d); }
 __global__ void k_join_probe_pairs_count(const DJoin* __restrict__ d) { join_probe_pairs_count_body(*d, d); }
 __global__ void k_join_probe_count(const DJoin* __restrict__ d) { join_probe_count_body(*d, d); }
@@ -64,6 +68,8 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
       memcpy(meta.get(), h, sizeof(DJoin));
       meta->n_rows = meta->cap = meta->slots = meta->out_probe = meta->out_build = meta->out_cap = 0;
       meta->counter = meta->bitmap = meta->mark = meta->match = meta->flags = 0;
+      meta->kmin = meta->kmax = 0;
+      meta->kmult = 0;
       ldb_jit_strip_keys(meta->bkeys);
       ldb_jit_strip_keys(meta->pkeys);
       for (int p = 0; p < LDB_MAX_PREDS; p++) ldb_jit_strip_pred(meta->ppreds[p]);
@@ -150,19 +156,49 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
    h->slots = (uint64_t) ht->slots;
    h->key32 = ht->key32;
    uint32_t* dflags = (uint32_t*) (ctx->d_scratch + 24);
-   if (build_unique) {
-      LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
-      h->flags = (uint64_t) dflags;
-      h->has_flags = 1;
+   LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
+   h->flags = (uint64_t) dflags;
+   h->has_flags = 1;
+   // KEY32: slots in key order (see DJoin::ordered_slots) — needs the build key range first
+   static const bool ordered_enabled = !(getenv("LDB_JOIN_ORDERED") && getenv("LDB_JOIN_ORDERED")[0] == '0');
+   if (ht->key32 && ordered_enabled && build->n_rows > 0) {
+      long long* range = (long long*) (ctx->d_scratch + 32);
+      const long long init[2] = {INT64_MAX, INT64_MIN};
+      LDB_HIP(hipMemcpyAsync(range, init, 16, hipMemcpyHostToDevice, ctx->stream));
+      DJoin* dr;
+      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dr));
+      hipLaunchKernelGGL(k_join_key_range, dim3(std::min(ldb_grid_for(ctx, build->n_rows, 256, 8), 256)), dim3(256), 0, ctx->stream, dr, range);
+      long long got[2];
+      LDB_HIP(hipMemcpyAsync(got, range, 16, hipMemcpyDeviceToHost, ctx->stream));
+      LDB_HIP(hipStreamSynchronize(ctx->stream));
+      ldb_dev_free(ctx, dr);
+      if (got[0] <= got[1]) { // at least one non-NULL key
+         ht->ordered_slots = 1;
+         ht->kmin = got[0];
+         ht->kmax = got[1];
+         ht->kmult = (uint64_t) ((((unsigned __int128) ht->cap) << 32) / ((unsigned __int128) (got[1] - got[0]) + 1));
+      }
    }
-   DJoin* d;
-   LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-   if (build->n_rows) LDB_TRY(launch_join(ctx, h, d, ldb_grid_for(ctx, build->n_rows, 256, 8), "k_join_build", "k_join_build_spec", k_join_build));
-   ldb_dev_free(ctx, d);
-   if (build_unique) { // the caller's promise is verified: duplicates fall back to the general probe
+   for (int attempt = 0; attempt < 2; attempt++) {
+      h->ordered_slots = ht->ordered_slots;
+      h->kmin = ht->kmin;
+      h->kmax = ht->kmax;
+      h->kmult = ht->kmult;
+      DJoin* d;
+      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+      if (build->n_rows) LDB_TRY(launch_join(ctx, h, d, ldb_grid_for(ctx, build->n_rows, 256, 8), "k_join_build", "k_join_build_spec", k_join_build));
+      ldb_dev_free(ctx, d);
       uint64_t f = 0;
       LDB_TRY(ldb_read_u64(ctx, dflags, &f));
+      if ((f & 2) && ht->ordered_slots) { // long probe runs: this key distribution needs hashed slots
+         ht->ordered_slots = 0;
+         LDB_HIP(hipMemsetAsync(ht->slots, 0, 8 * (size_t) ht->cap, ctx->stream));
+         LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
+         continue;
+      }
+      // the caller's promise of unique keys is verified: duplicates fall back to the general probe
       if (f & 1) ht->unique = 0;
+      break;
    }
    *out = ht.release();
    return LDB_OK;
@@ -195,6 +231,10 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    h->cap = ht->cap;
    h->slots = (uint64_t) ht->slots;
    h->key32 = ht->key32;
+   h->ordered_slots = ht->ordered_slots;
+   h->kmin = ht->kmin;
+   h->kmax = ht->kmax;
+   h->kmult = ht->kmult;
    // a lazy probe relation brings its filter along: evaluated inside the probe kernel
    h->n_ppreds = (int32_t) probe->pending.size();
    for (size_t p = 0; p < probe->pending.size(); p++) h->ppreds[p] = probe->pending[p];

@@ -19,11 +19,19 @@ struct DJoin {
    uint64_t bitmap; // uint64_t*: SEMI / ANTI / unique-build INNER
    uint64_t mark; // uint8_t*: MARK
    uint64_t match; // uint32_t*: unique-build path: build row (or LDB_NULL_ROW) per probe row; pairs path: per-chunk counts / offsets
-   uint64_t flags; // uint32_t*: build: [0] |= 1 when two build rows carry the same key (or tag)
+   uint64_t flags; // uint32_t*: build: [0] |= 1 when two build rows carry the same key (or tag), |= 2 on a long probe run
+   int64_t kmin, kmax; // KEY32 + ordered slots: range of the build keys
+   uint64_t kmult; // slot = ((key - kmin) * kmult) >> 32
    // ---- metadata
    int32_t key32;
    int32_t kind;
-   int32_t has_bitmap, has_mark, has_flags, pad;
+   int32_t has_bitmap, has_mark, has_flags;
+   // KEY32 tables place a key at a slot proportional to its position in [kmin, kmax] instead of at
+   // its hash: fact tables are clustered on their foreign keys, so consecutive probe rows then
+   // touch neighbouring slots (cache lines are reused, the table is walked almost sequentially)
+   // instead of one random line each.  The build measures its probe runs and falls back to hashed
+   // slots (ordered_slots = 0) when the key distribution makes them long.
+   int32_t ordered_slots;
    DKeys bkeys;
    DKeys pkeys;
    // conjuncts of a lazy (not materialised) probe relation, evaluated per probe row before the
@@ -41,6 +49,14 @@ __device__ __forceinline__ bool d_probe_pass(const DJoin& m, const DJoin* __rest
    return pass;
 }
 
+// first slot of a key: hashed, or (KEY32 tables with ordered slots) proportional to the key's
+// position in the build key range
+#define JOIN_LONG_RUN 512
+__device__ __forceinline__ uint64_t d_join_slot(const DJoin& m, const DJoin* __restrict__ d, uint64_t h, int64_t key, uint64_t mask) {
+   if (m.key32 && m.ordered_slots) return (((uint64_t) (key - d->kmin) * d->kmult) >> 32) & mask;
+   return h & mask;
+}
+
 __device__ __forceinline__ void join_build_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows, mask = d->cap - 1;
    unsigned long long* slots = gptr_mut<unsigned long long>(d->slots);
@@ -50,19 +66,50 @@ __device__ __forceinline__ void join_build_body(const DJoin& m, const DJoin* __r
       uint64_t h = d_hash_keys(bkeys, i, &nul);
       if (nul) continue; // a NULL key can never be matched (eq on NULL is false)
       uint64_t word;
+      int64_t key = 0;
       if (m.key32) {
          const CV c = bkeys.col(0);
-         word = ((uint64_t) (uint32_t) d_load_i64(c, d_phys_row(c, i)) << 32) | (uint64_t) ((uint32_t) i + 1u);
+         key = d_load_i64(c, d_phys_row(c, i));
+         word = ((uint64_t) (uint32_t) key << 32) | (uint64_t) ((uint32_t) i + 1u);
       } else {
          word = (h & 0xFFFFFFFF00000000ull) | (uint64_t) ((uint32_t) i + 1u);
       }
-      uint64_t pos = h & mask;
+      uint64_t pos = d_join_slot(m, d, h, key, mask);
+      uint32_t steps = 0;
       for (;;) {
          unsigned long long old = atomicCAS(&slots[pos], 0ull, (unsigned long long) word);
          if (old == 0) break;
          if (m.has_flags && (old >> 32) == (word >> 32)) atomicOr(gptr_mut<uint32_t>(d->flags), 1u); // same key (KEY32) / same tag: not provably unique
          pos = (pos + 1) & mask;
+         if (++steps == JOIN_LONG_RUN && m.ordered_slots) { // skewed keys: give up at once (runs cost O(length^2)), the host rebuilds hashed
+            atomicOr(gptr_mut<uint32_t>(d->flags), 2u);
+            break;
+         }
       }
+   }
+}
+
+// min / max of the (single, integer) build key — the range the ordered slots are spread over
+__device__ __forceinline__ void join_key_range_body(const DJoin& m, const DJoin* __restrict__ d, long long* __restrict__ out) {
+   const uint64_t n = d->n_rows;
+   const KV bkeys(m.bkeys, d->bkeys);
+   const CV c = bkeys.col(0);
+   long long lo = 0x7FFFFFFFFFFFFFFFll, hi = -0x7FFFFFFFFFFFFFFFll - 1;
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      uint32_t row = d_phys_row(c, i);
+      if (!d_valid(c, row)) continue;
+      long long k = d_load_i64(c, row);
+      lo = k < lo ? k : lo;
+      hi = k > hi ? k : hi;
+   }
+   for (int off = 32; off > 0; off >>= 1) {
+      long long l2 = __shfl_down(lo, off), h2 = __shfl_down(hi, off);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+   }
+   if ((threadIdx.x & 63) == 0) {
+      atomicMin(&out[0], lo);
+      atomicMax(&out[1], hi);
    }
 }
 
@@ -82,6 +129,10 @@ __device__ __forceinline__ uint32_t d_probe_row(const DJoin& m, const DJoin* __r
       const CV c = pkeys.col(0);
       int64_t kv = d_load_i64(c, d_phys_row(c, i));
       if (kv != (int64_t) (int32_t) kv) return 0; // wider probe value can equal no 32-bit build key
+      if (m.ordered_slots) {
+         if (kv < d->kmin || kv > d->kmax) return 0; // outside the build key range
+         pos = d_join_slot(m, d, h, kv, mask);
+      }
       const uint32_t key = (uint32_t) kv;
       for (;;) {
          uint64_t w = slots[pos];

@@ -45,6 +45,32 @@ def test_build_side_semi_with_duplicate_build_keys(ctx, oracle):
             assert np.array_equal(gb.join_build(keys).probe(gp, keys, kind).rowids(0), want)
 
 
+def test_ordered_slots_fall_back_to_hashing_on_clustered_keys(ctx, oracle):
+    """KEY32 tables spread their slots over [min key, max key]; one outlier key squeezes all others
+    into a handful of slots → the build sees long probe runs and must rebuild hashed.  Results are
+    the same either way (and equal to the oracle's), including probe keys outside the key range."""
+    rng = np.random.default_rng(5)
+    dense = rng.permutation(200_000)[:60_000].astype(np.int32)
+    bk = np.concatenate([dense, np.array([2**31 - 1, -(2**31)], dtype=np.int32)])
+    pk = np.concatenate([rng.integers(-1000, 250_000, 90_000), np.array([2**31 - 1, -(2**31), 2**31 - 2])]).astype(np.int32)
+    b, p = pa.table({"k": pa.array(bk, pa.int32())}), pa.table({"k": pa.array(pk, pa.int32())})
+    gb, gp, hb, hp = ctx.register("ob", b).rel(), ctx.register("op", p).rel(), HostTable(b).rel(), HostTable(p).rel()
+    ht = gb.join_build([(0, 0)], unique=True)
+    for kind in (capi.JOIN_INNER, capi.JOIN_SEMI, capi.JOIN_ANTI, capi.JOIN_LEFT_OUTER):
+        op, ob, _ = oracle.join(hb, [(0, 0)], hp, [(0, 0)], kind)
+        out = ht.probe(gp, [(0, 0)], kind)
+        if kind in (capi.JOIN_SEMI, capi.JOIN_ANTI):
+            assert np.array_equal(out.rowids(0), op)
+        else:
+            assert sorted(zip(out.rowids(0).tolist(), out.rowids(1).tolist())) == sorted(zip(op.tolist(), ob.tolist()))
+    # and a well-spread key set of the same size keeps ordered slots: same answers again
+    b2 = pa.table({"k": pa.array(dense * 7, pa.int32())})
+    g2, h2 = ctx.register("ob2", b2).rel(), HostTable(b2).rel()
+    op, ob, _ = oracle.join(h2, [(0, 0)], hp, [(0, 0)], capi.JOIN_INNER)
+    out = g2.join_build([(0, 0)], unique=True).probe(gp, [(0, 0)], capi.JOIN_INNER)
+    assert sorted(zip(out.rowids(0).tolist(), out.rowids(1).tolist())) == sorted(zip(op.tolist(), ob.tolist()))
+
+
 def test_three_way_join_composition(ctx, oracle, data):
     """(lineitem ⋈ orders) result used as a build side again: row ids compose through both joins"""
     cu = tpch_data.host_table(tpch_data.CUSTOMER, N_ORDERS)

@@ -300,7 +300,12 @@ def test_groupby_run_combining_high_cardinality(ctx, oracle):
              api.agg(capi.AGG_SUM, api.col_expr((0, 1)), preds=cond), api.agg(capi.AGG_COUNT_STAR, preds=cond)]
     faggs = [api.agg(capi.AGG_SUM, api.col_expr((0, 2), True), out_type=capi.T_FLOAT64), api.agg(capi.AGG_MIN, api.col_expr((0, 2), True), out_type=capi.T_FLOAT64),
              api.agg(capi.AGG_MAX, api.col_expr((0, 2), True), out_type=capi.T_FLOAT64)]
-    for order in (np.arange(n), rng.permutation(n)):
+    # third variant: one far-away key squeezes all others into a few ORDERED global slots (the
+    # table is laid out by key position in [min, max]) → long probe runs → hashed retry
+    for order, outlier in ((np.arange(n), False), (rng.permutation(n), False), (np.arange(n), True)):
+        if outlier:
+            kk = list(kk)
+            kk[n // 2] = 2**31 - 5
         t = pa.table({"k": pa.array([kk[i] for i in order], pa.int64()), "v": pa.array([v[i] for i in order], pa.int64()), "x": pa.array(x[order], pa.float64())})
         g, h = ctx.register("runs", t).rel(), HostTable(t).rel()
         rep, vals, valid = oracle.groupby(h, [(0, 0)], iaggs)

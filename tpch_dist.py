@@ -9,6 +9,7 @@ of the small partial relations (replicate small build sides / par
 Every rank ends with the full result (the merge is replicated; it is microseconds of work).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -76,6 +77,7 @@ def replicate(runner, table, name):
         values, offsets, _, _ = table.col_ptrs(c)
         if table.coltype(c).type == capi.T_UTF8:
             off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()  # the fill runs on torch's stream, the copy below on the ctx stream
             _d2d(ctx, off.data_ptr(), offsets, 8 * (n + 1) if n else 0)
             ctx.sync()
             first, total = (int(off[0].item()), int((off[n] - off[0]).item())) if n else (0, 0)
@@ -153,5 +155,8 @@ def run_query(runner, q):
         top = _plan(ctx, "ldb_plan_tpch_q18_local", db.orders, db.lineitem)
         top100 = _plan(ctx, "ldb_plan_tpch_q18_mid", replicate(runner, top, "q18_tops"))
         named = _plan(ctx, "ldb_plan_tpch_q18_names", top100, db.customer)  # customers are sharded by rows
-        return _plan(ctx, "ldb_plan_tpch_q18_final", replicate(runner, named, "q18_named"))
+        allnamed = replicate(runner, named, "q18_named")
+        if os.environ.get("LDB_DIST_DEBUG"):
+            print(f"[rank {runner.dist.get_rank()}] named={named.to_arrow().to_pylist()}\n   gathered={allnamed.to_arrow().to_pylist()}", flush=True)
+        return _plan(ctx, "ldb_plan_tpch_q18_final", allnamed)
     raise ValueError(f"TPC-H Q{q} has no multi-GPU plan yet")
