@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — TPC-H (synthetic, dbgen-shaped) on the MI355X-native LingoDB operator runtime.
 
-  python bench.py --gpus N --steps K --warmup W [--sf 100] [--queries 1,6,3]
+  python bench.py --gpus N --steps K --warmup W [--sf 100] [--queries 1,6,3,4,12,18]
 
 One "step" = one pass of the implemented TPC-H queries over the HBM-resident database.
 N > 1: launched by torch.distributed.run, one rank per GPU; the database is sharded by order
@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sf", type=float, default=100.0)
-    ap.add_argument("--queries", default="1,6,3")
+    ap.add_argument("--queries", default="1,6,3,4,12,18", help="TPC-H queries of one step (all have single- and multi-GPU plans)")
     ap.add_argument("--narrow-decimals", type=int, default=0)
     ap.add_argument("--cpu-sample-sf", type=float, default=1.0, help="scale of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()

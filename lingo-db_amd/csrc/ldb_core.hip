@@ -430,7 +430,7 @@ extern "C" int32_t ldb_gpu_table_col_width(const ldb_table* t, int32_t col) {
 extern "C" int32_t ldb_gpu_table_col_ptrs(const ldb_table* t, int32_t col, void** values, void** offsets, void** validity, int64_t* value_bytes) {
    if (!t || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "col_ptrs: bad column %d", col);
    const ldb_column& c = t->cols[(size_t) col];
-   c.has_range = false; // the caller may write through the raw pointers
+   c.has_range = false, c.sorted_state = -1, c.skewed = false; // the caller may write through the raw pointers
    if (values) *values = c.values;
    if (offsets) *offsets = c.offsets;
    if (validity) *validity = c.validity;
@@ -442,7 +442,7 @@ extern "C" int32_t ldb_gpu_table_set_rows(ldb_table* t, int64_t n_rows) {
    for (auto& c : t->cols)
       if (c.type.type != LDB_T_UTF8 && n_rows * c.width > c.value_bytes) LDB_FAIL(LDB_ERR_INVALID, "set_rows: %ld rows exceed capacity of column %s", (long) n_rows, c.name.c_str());
    t->n_rows = n_rows;
-   for (auto& c : t->cols) c.has_range = false;
+   for (auto& c : t->cols) c.has_range = false, c.sorted_state = -1, c.skewed = false;
    return LDB_OK;
 }
 extern "C" int32_t ldb_gpu_table_read_fixed(ldb_ctx* ctx, const ldb_table* t, int32_t col, void* host_out, int64_t out_bytes) {
@@ -462,7 +462,7 @@ extern "C" int32_t ldb_gpu_table_write_fixed(ldb_ctx* ctx, ldb_table* t, int32_t
    if (in_bytes > c.value_bytes) LDB_FAIL(LDB_ERR_INVALID, "write_fixed: %ld bytes exceed column capacity %ld", (long) in_bytes, (long) c.value_bytes);
    if (in_bytes) LDB_HIP(hipMemcpyAsync(c.values, host_in, (size_t) in_bytes, hipMemcpyHostToDevice, ctx->stream));
    LDB_HIP(hipStreamSynchronize(ctx->stream));
-   c.has_range = false;
+   c.has_range = false, c.sorted_state = -1, c.skewed = false;
    return LDB_OK;
 }
 
@@ -792,6 +792,43 @@ int32_t ldb_column_range(ldb_ctx* ctx, const ldb_table* t, int32_t col, int64_t*
    }
    *lo = c.vmin;
    *hi = c.vmax;
+   return LDB_OK;
+}
+
+__global__ void k_column_sorted(DCol col, uint64_t n, unsigned int* __restrict__ unsorted) {
+   bool bad = false;
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x + 1; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+      bad = bad || d_load_i64(col, (uint32_t) i) < d_load_i64(col, (uint32_t) (i - 1));
+   if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(unsorted, 1u);
+}
+int32_t ldb_column_sorted(ldb_ctx* ctx, const ldb_table* t, int32_t col, bool* sorted) {
+   if (!t || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "column_sorted: bad column %d", col);
+   const ldb_column& c = t->cols[(size_t) col];
+   const int ty = c.type.type;
+   const bool ok = ty == LDB_T_INT8 || ty == LDB_T_INT16 || ty == LDB_T_INT32 || ty == LDB_T_INT64 || ty == LDB_T_DATE32 ||
+                   (ty == LDB_T_DECIMAL128 && c.type.precision < 19);
+   if (c.sorted_state < 0) {
+      if (!ok || c.validity) {
+         c.sorted_state = 0;
+      } else if (t->n_rows < 2) {
+         c.sorted_state = 1;
+      } else {
+         DCol dc;
+         memset(&dc, 0, sizeof(dc));
+         dc.values = (uint64_t) c.values;
+         dc.type = ty;
+         dc.width = c.width;
+         dc.precision = c.type.precision;
+         dc.scale = c.type.scale;
+         unsigned int* d_flag = (unsigned int*) (ctx->d_scratch + 44);
+         LDB_HIP(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
+         hipLaunchKernelGGL(k_column_sorted, dim3(ldb_grid_for(ctx, t->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dc, (uint64_t) t->n_rows, d_flag);
+         uint64_t f = 0;
+         LDB_TRY(ldb_read_u64(ctx, d_flag, &f));
+         c.sorted_state = (f & 1) ? 0 : 1;
+      }
+   }
+   *sorted = c.sorted_state == 1;
    return LDB_OK;
 }
 

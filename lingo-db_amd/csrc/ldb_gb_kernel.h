@@ -97,6 +97,15 @@ struct DGroupBy {
    // l_orderkey) then walks the table almost sequentially, and the groups come out in key order.
    // Long probe runs (skewed keys) raise flag bit 1 and the host retries hashed.
    int32_t ordered_slots;
+   // single key over a column that is SORTED (a cached column statistic), no filter: equal keys
+   // are adjacent, so group g is simply the g-th key change.  Pass 1 counts the key changes per
+   // 64-row chunk, a scan numbers the groups, pass 2 (this kernel) reduces each run in the wave and
+   // writes it to its dense slot — a run that starts and ends inside the wave with a PLAIN store,
+   // only runs crossing a wave boundary with atomics.  No hash table, no probing: Q18's 150 M-group
+   // GROUP BY l_orderkey needs ~2 atomics per 64 rows instead of 2 per group.
+   int32_t dense_sorted;
+   int32_t pad1;
+   uint64_t chunk_off; // uint32_t*: dense_sorted: number of groups that start before each 64-row chunk
    DKeys keys;
    DPred preds[LDB_MAX_PREDS];
    DPred cpreds[GB_MAX_CPREDS];
@@ -206,12 +215,23 @@ __device__ __forceinline__ void d_atomic_minmax_f64(unsigned long long* p, doubl
 struct Sink {
    unsigned long long* base; // word 0 of this slot
    uint64_t stride; // distance between consecutive words of one slot
+   bool plain = false; // this lane is the only contributor of its slot: store instead of atomics (run combining only)
    __device__ __forceinline__ unsigned long long* w(int k) const { return base + (uint64_t) k * stride; }
 };
+// `v` folded into an identity-initialised word by its only contributor, or atomically
+__device__ __forceinline__ void d_sink_add64(const Sink& s, int word, unsigned long long v) {
+   if (s.plain) *s.w(word) = v;
+   else atomicAdd(s.w(word), v);
+}
 
 // 128-bit SUM as two 64-bit words: the carry out of the low word is the only cross-word traffic
 __device__ __forceinline__ void d_sink_add128(const Sink& s, int word, u128 v) {
    unsigned long long lo = (unsigned long long) v, hi = (unsigned long long) (v >> 64);
+   if (s.plain) { // only contributor of a zero-initialised slot
+      *s.w(word) = lo;
+      *s.w(word + 1) = hi;
+      return;
+   }
    unsigned long long old = atomicAdd(s.w(word), lo);
    hi += (unsigned long long) (old + lo < old);
    if (hi) atomicAdd(s.w(word + 1), hi);
@@ -300,7 +320,7 @@ __device__ __forceinline__ void d_accumulate_runs(const DGroupBy& m, const DGrou
          if (ok) ok = d_eval_pred(PV(m.cpreds[acc.cpred[p]], d->cpreds[acc.cpred[p]]), i);
       if (acc.kind == ACC_COUNT && acc.count_rows) {
          unsigned long long c = d_seg_reduce<unsigned long long>(ok ? 1ull : 0ull, lane, run_end, add_u64);
-         if (apply && c) atomicAdd(s.w(acc.word), c);
+         if (apply && c) d_sink_add64(s, acc.word, c);
          continue;
       }
       if (acc.e.is_float) {
@@ -309,13 +329,16 @@ __device__ __forceinline__ void d_accumulate_runs(const DGroupBy& m, const DGrou
          switch (acc.kind) {
             case ACC_COUNT: {
                unsigned long long c = d_seg_reduce<unsigned long long>(ok ? 1ull : 0ull, lane, run_end, add_u64);
-               if (apply && c) atomicAdd(s.w(acc.word), c);
+               if (apply && c) d_sink_add64(s, acc.word, c);
                break;
             }
             case ACC_SUMF64: {
                unsigned long long c = d_seg_reduce<unsigned long long>(ok ? 1ull : 0ull, lane, run_end, add_u64);
                double r = d_seg_reduce<double>(ok ? fv : 0.0, lane, run_end, [](double x, double y) { return x + y; });
-               if (apply && c) atomicAdd((double*) s.w(acc.word), r);
+               if (apply && c) {
+                  if (s.plain) *(double*) s.w(acc.word) = r;
+                  else atomicAdd((double*) s.w(acc.word), r);
+               }
                break;
             }
             case ACC_MINF64: {
@@ -336,12 +359,12 @@ __device__ __forceinline__ void d_accumulate_runs(const DGroupBy& m, const DGrou
       switch (acc.kind) {
          case ACC_COUNT: {
             unsigned long long c = d_seg_reduce<unsigned long long>(ok ? 1ull : 0ull, lane, run_end, add_u64);
-            if (apply && c) atomicAdd(s.w(acc.word), c);
+            if (apply && c) d_sink_add64(s, acc.word, c);
             break;
          }
          case ACC_SUM64: {
             unsigned long long r = d_seg_reduce<unsigned long long>(ok ? (unsigned long long) v : 0ull, lane, run_end, add_u64);
-            if (apply && r) atomicAdd(s.w(acc.word), r);
+            if (apply && r) d_sink_add64(s, acc.word, r);
             break;
          }
          case ACC_SUM128: {
@@ -525,13 +548,31 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
             const bool head = pass && !same;
             const uint64_t headmask = __ballot(head), passmask = __ballot(pass);
             if (passmask == 0) continue; // wave-uniform
-            uint64_t g = ~0ull;
-            if (head) g = d_global_slot(m, d, h, i);
             const uint64_t above = lane >= 63 ? 0ull : (~0ull << (lane + 1));
             const uint64_t brk = (headmask | ~passmask) & above; // first lane after this one that is not a member of its run
             const uint32_t run_end = !pass ? lane : (brk ? (uint32_t) __builtin_ctzll(brk) - 1u : 63u);
+            uint64_t g = ~0ull;
+            bool plain = false;
+            if (m.dense_sorted) {
+               // sorted key column: group number = key changes up to this row (see DGroupBy::dense_sorted).
+               // The wave's rows are one aligned 64-row chunk (i - lane is a multiple of 64).
+               bool true_head = head; // lanes > 0: key differs from the previous lane's
+               if (lane == 0 && pass) true_head = i == 0 || !d_keys_equal(keys, i - 1, keys, i, true);
+               bool cont = false; // does the chunk's last run continue into the next chunk?
+               if (lane == 63 && pass && i + 1 < n) cont = d_keys_equal(keys, i, keys, i + 1, true);
+               cont = __shfl(cont ? 1 : 0, 63) != 0;
+               const uint64_t thmask = __ballot(true_head);
+               if (head) {
+                  const uint64_t upto = lane >= 63 ? ~0ull : ((2ull << lane) - 1ull);
+                  g = (uint64_t) gptr<uint32_t>(d->chunk_off)[i >> 6] + (uint64_t) __popcll(thmask & upto) - 1ull;
+                  plain = true_head && !(run_end == 63 && cont); // the whole group lives inside this run
+                  if (true_head) gptr_mut<unsigned long long>(d->g_keys)[g] = (h & 0xFFFFFFFF00000000ull) | (unsigned long long) ((uint32_t) i + 1u);
+               }
+            } else if (head) {
+               g = d_global_slot(m, d, h, i);
+            }
             const bool apply = head && g != ~0ull;
-            Sink s{g_acc + (apply ? g : 0), g_cap};
+            Sink s{g_acc + (apply ? g : 0), g_cap, plain};
             d_accumulate_runs(m, d, rvv[u], rvalidv[u], i, pass, apply, lane, run_end, s);
          }
          continue;
@@ -593,5 +634,19 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
       }
       Sink dst{g_acc + g, g_cap};
       d_combine(m, src, dst);
+   }
+}
+
+// dense_sorted pass 1: key changes per 64-row chunk (→ exclusive scan → DGroupBy::chunk_off)
+__device__ __forceinline__ void gb_sorted_heads_body(const DGroupBy& m, const DGroupBy* __restrict__ d, uint32_t* __restrict__ chunk_cnt) {
+   const uint64_t n = d->n_rows, n_chunks = (n + 63) / 64;
+   const uint32_t lane = threadIdx.x & 63;
+   const KV keys(m.keys, d->keys);
+   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+   for (uint64_t c = wave; c < n_chunks; c += n_waves) {
+      const uint64_t i = c * 64 + lane;
+      const bool th = i < n && (i == 0 || !d_keys_equal(keys, i - 1, keys, i, true));
+      const uint64_t mask = __ballot(th);
+      if (lane == 0) chunk_cnt[c] = (uint32_t) __popcll(mask);
    }
 }

@@ -36,6 +36,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned long long gb_lds_dyn[];
 // generic ahead-of-time kernel: metadata and addresses both come from the descriptor in memory
 __global__ __launch_bounds__(GB_BLOCK) void k_groupby(const DGroupBy* __restrict__ d) { gb_body<1>(*d, d, gb_lds_dyn); }
 
+__global__ void k_gb_sorted_heads(const DGroupBy* __restrict__ d, uint32_t* __restrict__ chunk_cnt) { gb_sorted_heads_body(*d, d, chunk_cnt); }
+
 __global__ void k_gb_init(uint64_t* keys, uint64_t* acc, const DGroupBy* __restrict__ d) {
    const uint64_t cap = d->g_cap;
    const int nw = d->n_words;
@@ -455,6 +457,32 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          key_range = (unsigned __int128) ((__int128) hi - lo) + 1;
       }
    }
+   // sorted key column, no filter (DGroupBy::dense_sorted): number the groups by key changes
+   uint32_t* chunk_off = nullptr;
+   static const bool gb_sorted = !(getenv("LDB_GB_SORTED") && getenv("LDB_GB_SORTED")[0] == '0');
+   if (gb_sorted && !h->use_lds && n_keys == 1 && h->n_preds == 0 && in->n_rows > 0) {
+      const ldb_rel_side& ks = in->sides[(size_t) keys[0].side];
+      bool sorted = false;
+      if (!ks.rowids) LDB_TRY(ldb_column_sorted(ctx, ks.table, keys[0].col, &sorted));
+      if (sorted) {
+         const int64_t n_chunks = (in->n_rows + 63) / 64;
+         uint32_t* chunk_cnt;
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &chunk_cnt, 4 * (size_t) n_chunks));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &chunk_off, 4 * (size_t) n_chunks));
+         DGroupBy* dh;
+         LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dh));
+         hipLaunchKernelGGL(k_gb_sorted_heads, dim3(ldb_grid_for(ctx, in->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dh, chunk_cnt);
+         LDB_TRY(ldb_exclusive_scan_u32(ctx, chunk_cnt, chunk_off, n_chunks, (uint64_t*) ctx->d_scratch));
+         uint64_t groups = 0;
+         LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &groups));
+         ldb_dev_free(ctx, dh);
+         ldb_dev_free(ctx, chunk_cnt);
+         h->dense_sorted = 1;
+         h->ordered_slots = 0;
+         h->chunk_off = (uint64_t) chunk_off;
+         cap = std::max<uint64_t>(1, groups); // the dense group array: exactly one slot per group
+      }
+   }
    uint32_t* d_flags;
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_flags, 64));
    DGroupBy* d = nullptr;
@@ -508,6 +536,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       if (cap >= cap_max) LDB_FAIL(LDB_ERR_HIP, "groupby: global table overflow at maximum capacity");
       cap = std::min(cap * 8, cap_max);
    }
+   ldb_dev_free(ctx, chunk_off);
    // ---- finalize
    // upper bound of groups = min(cap, rows) (+1 for keyless)
    uint64_t max_groups = h->keyless ? 1 : std::min<uint64_t>(cap, (uint64_t) in->n_rows);

@@ -48,10 +48,13 @@ struct ldb_column {
    mutable bool has_range = false;
    mutable int64_t vmin = 0, vmax = -1;
    mutable bool skewed = false; // ordered hash-table slots over this column gave long probe runs once: do not try again
+   mutable int8_t sorted_state = -1; // -1 unknown, 0 no, 1 values are non-decreasing and there are no NULLs (ldb_column_sorted)
 };
 // [min, max] over all physical rows of an integer-like column (NULL slots included: a superset is
 // fine for its users); cached in the column.  LDB_ERR_UNSUPPORTED for other types.
 int32_t ldb_column_range(ldb_ctx* ctx, const struct ldb_table* t, int32_t col, int64_t* lo, int64_t* hi);
+// is the (integer-like, NOT NULL) column stored in non-decreasing order?  Cached like the range.
+int32_t ldb_column_sorted(ldb_ctx* ctx, const struct ldb_table* t, int32_t col, bool* sorted);
 
 struct ldb_prof_pending {
    const char* name;

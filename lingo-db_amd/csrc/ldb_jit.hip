@@ -219,6 +219,7 @@ static void gb_meta(const DGroupBy* h, DGroupBy* m) {
    m->lds_slots = m->lds_reps = 0;
    m->kmin = 0;
    m->kmult = 0;
+   m->chunk_off = 0;
    ldb_jit_strip_keys(m->keys);
    for (int p = 0; p < LDB_MAX_PREDS; p++) ldb_jit_strip_pred(m->preds[p]);
    for (int p = 0; p < GB_MAX_CPREDS; p++) ldb_jit_strip_pred(m->cpreds[p]);

@@ -302,10 +302,13 @@ def test_groupby_run_combining_high_cardinality(ctx, oracle):
              api.agg(capi.AGG_MAX, api.col_expr((0, 2), True), out_type=capi.T_FLOAT64)]
     # third variant: one far-away key squeezes all others into a few ORDERED global slots (the
     # table is laid out by key position in [min, max]) → long probe runs → hashed retry
-    for order, outlier in ((np.arange(n), False), (rng.permutation(n), False), (np.arange(n), True)):
+    # fourth variant: sorted key column without NULLs → the dense "group = key change" path (no hash table)
+    for order, outlier, nonull in ((np.arange(n), False, False), (rng.permutation(n), False, False), (np.arange(n), True, False), (np.arange(n), False, True)):
         if outlier:
             kk = list(kk)
             kk[n // 2] = 2**31 - 5
+        if nonull:
+            kk = [int(x) for x in k]
         t = pa.table({"k": pa.array([kk[i] for i in order], pa.int64()), "v": pa.array([v[i] for i in order], pa.int64()), "x": pa.array(x[order], pa.float64())})
         g, h = ctx.register("runs", t).rel(), HostTable(t).rel()
         rep, vals, valid = oracle.groupby(h, [(0, 0)], iaggs)
