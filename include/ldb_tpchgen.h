@@ -81,6 +81,7 @@ static inline void ldb_tpch_c_name(int64_t custkey, char* out) {
 enum { P_PARTKEY = 0,
        P_SIZE,
        P_RETAILPRICE,
+       P_NAME, /* five colour words separated by blanks (TPC-H spec 4.2.3: P_NAME) */
        P_NCOLS };
 enum { S_SUPPKEY = 0,
        S_NATIONKEY,
@@ -251,6 +252,21 @@ static const char* const ldb_tpch_instructs[LDB_TPCH_NINSTR] = {"DELIVER IN PERS
 static const char* const ldb_tpch_nations[25] = {"ALGERIA", "ARGENTINA", "BRAZIL", "CANADA", "EGYPT", "ETHIOPIA", "FRANCE", "GERMANY", "INDIA", "INDONESIA", "IRAN", "IRAQ", "JAPAN", "JORDAN", "KENYA", "MOROCCO", "MOZAMBIQUE", "PERU", "CHINA", "ROMANIA", "SAUDI ARABIA", "VIETNAM", "RUSSIA", "UNITED KINGDOM", "UNITED STATES"};
 static const int32_t ldb_tpch_nation_region[25] = {0, 1, 1, 1, 4, 0, 3, 3, 2, 2, 4, 4, 2, 4, 0, 0, 0, 1, 2, 3, 4, 2, 3, 3, 1};
 static const char* const ldb_tpch_regions[5] = {"AFRICA", "AMERICA", "ASIA", "EUROPE", "MIDDLE EAST"};
+
+/* p_name vocabulary: the 92 colour words of the TPC-H specification (clause 4.2.3, P_NAME) */
+#define LDB_TPCH_NCOLORS 92
+#define LDB_TPCH_PNAME_WORDS 5
+static const char* const ldb_tpch_colors[LDB_TPCH_NCOLORS] = {
+   "almond", "antique", "aquamarine", "azure", "beige", "bisque", "black", "blanched", "blue", "blush", "brown", "burlywood", "burnished", "chartreuse", "chiffon",
+   "chocolate", "coral", "cornflower", "cornsilk", "cream", "cyan", "dark", "deep", "dim", "dodger", "drab", "firebrick", "floral", "forest", "frosted", "gainsboro",
+   "ghost", "goldenrod", "green", "grey", "honeydew", "hot", "indian", "ivory", "khaki", "lace", "lavender", "lawn", "lemon", "light", "lime", "linen", "magenta",
+   "maroon", "medium", "metallic", "midnight", "mint", "misty", "moccasin", "navajo", "navy", "olive", "orange", "orchid", "pale", "papaya", "peach", "peru", "pink",
+   "plum", "powder", "puff", "purple", "red", "rose", "rosy", "royal", "saddle", "salmon", "sandy", "seashell", "sienna", "sky", "slate", "smoke", "snow", "spring",
+   "steel", "tan", "thistle", "tomato", "turquoise", "violet", "wheat", "white", "yellow"};
+/* colour index of word j (0..4) of the name of part row `part_idx` (independent draws: a colour may repeat) */
+LDB_HD int32_t ldb_tpch_p_name_word(int64_t part_idx, int32_t j) {
+   return (int32_t) (ldb_rnd(LDB_TPCH_PART, P_NAME * 8 + j, (uint64_t) part_idx) % LDB_TPCH_NCOLORS);
+}
 
 LDB_HD int32_t ldb_tpch_c_segment_idx(int64_t cust_idx) {
    return (int32_t) (ldb_rnd(LDB_TPCH_CUSTOMER, C_MKTSEGMENT, (uint64_t) cust_idx) % LDB_TPCH_NSEG);

@@ -294,6 +294,17 @@ __device__ __forceinline__ bool d_pred_is_simple(const DPred& pm) {
    return narrow && pm.rhs_kind == LDB_RHS_INT && pm.op != LDB_F_IN && pm.op != LDB_F_NOTNULL;
 }
 
+__device__ __forceinline__ bool d_type_is_narrow_int(const DCol& c) {
+   const int t = c.type;
+   return t == LDB_T_INT8 || t == LDB_T_INT16 || t == LDB_T_INT32 || t == LDB_T_INT64 || t == LDB_T_DATE32 || t == LDB_T_CHAR4 || t == LDB_T_BOOL8 ||
+          (t == LDB_T_DECIMAL128 && c.precision < 19);
+}
+// column-vs-column comparison of two dense (no row ids, no NULLs) narrow integer columns
+__device__ __forceinline__ bool d_pred_is_colcol_dense(const DPred& pm) {
+   return pm.rhs_kind == LDB_RHS_COLUMN && pm.op != LDB_F_IN && pm.op != LDB_F_NOTNULL && d_type_is_narrow_int(pm.col) && d_type_is_narrow_int(pm.rhs) && !pm.col.rowids &&
+          !pm.col.validity && !pm.rhs.rowids && !pm.rhs.validity;
+}
+
 // A conjunction over U rows of the same thread, predicate-major, load phase separated from the
 // compare phase: the U loads of one conjunct are independent and issue back to back under their
 // own exec masks (memory-level parallelism: one memory round trip per conjunct column for the
@@ -345,6 +356,16 @@ __device__ __forceinline__ void d_eval_conj_batch(const DPred* mp, const DPred* 
          for (int u = 0; u < U; u++) {
             const bool c = fits ? d_cmp_vals<int64_t>(mp[p].op, val[u], (int64_t) mp[p].lo) : d_cmp_apply(mp[p].op, mp[p].hi < 0 ? 1 : -1);
             pass[u] = pass[u] & ok[u] & c; // unconditional: no branch to correlate with the load's
+         }
+      } else if (d_pred_is_colcol_dense(mp[p])) {
+         // column vs column, both dense narrow integers (l_commitdate < l_receiptdate): the same
+         // branch-free scheme with two loads per row
+         const CV a = pv.col(), b = pv.rhs();
+#pragma unroll
+         for (int u = 0; u < U; u++) {
+            const uint32_t r = pass[u] ? (uint32_t) rows[u] : 0u;
+            const int64_t x = d_load_i64(a, r), y = d_load_i64(b, r);
+            pass[u] = pass[u] & d_cmp_vals<int64_t>(mp[p].op, x, y);
          }
       } else {
 #pragma unroll

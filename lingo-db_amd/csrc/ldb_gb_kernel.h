@@ -529,22 +529,37 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
          hv[u] = 0;
          rvalidv[u] = 0;
          if (passv[u]) {
-            if (!m.keyless) hv[u] = d_hash_keys(keys, rowsv[u]);
+            if (!m.keyless && !m.dense_sorted) hv[u] = d_hash_keys(keys, rowsv[u]); // (dense_sorted: no table, no hash)
             d_load_vals(m, d, rowsv[u], rvv[u], rvalidv[u]);
          }
       }
       if (!use_lds) {
          // high-cardinality path: runs of neighbouring lanes with the same key are combined in the
          // wave, the run's head lane does the one lookup and the atomics (see d_accumulate_runs)
+         // every memory access the combining step depends on is issued here for the whole batch
+         // (key of the previous row, the chunk's group base, the next chunk's first key), so the
+         // loop below only shuffles, stores and issues atomics: without this each batch row paid
+         // three dependent round trips of its own and the kernel ran at latency, not bandwidth
+         bool eqprev[ROWS], eqnext[ROWS];
+         uint32_t gbase[ROWS];
+#pragma unroll
+         for (int u = 0; u < ROWS; u++) {
+            const uint64_t i = rowsv[u];
+            eqprev[u] = passv[u] && i > 0 && (m.keyless || d_keys_equal(keys, i - 1, keys, i, true));
+            eqnext[u] = false;
+            gbase[u] = 0;
+            if (m.dense_sorted) {
+               if (lane == 63 && passv[u] && i + 1 < n) eqnext[u] = d_keys_equal(keys, i, keys, i + 1, true);
+               if (passv[u]) gbase[u] = gptr<uint32_t>(d->chunk_off)[i >> 6];
+            }
+         }
 #pragma unroll
          for (int u = 0; u < ROWS; u++) {
             const uint64_t i = rowsv[u];
             const bool pass = passv[u];
             const uint64_t h = hv[u];
-            const uint64_t hprev = __shfl_up((unsigned long long) h, 1);
             const bool pprev = __shfl_up(pass ? 1 : 0, 1) != 0;
-            bool same = lane > 0 && pass && pprev && hprev == h; // lane - 1 holds row i - 1
-            if (same && !m.keyless) same = d_keys_equal(keys, i - 1, keys, i, true);
+            const bool same = lane > 0 && pass && pprev && eqprev[u]; // lane - 1 holds row i - 1
             const bool head = pass && !same;
             const uint64_t headmask = __ballot(head), passmask = __ballot(pass);
             if (passmask == 0) continue; // wave-uniform
@@ -556,15 +571,12 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
             if (m.dense_sorted) {
                // sorted key column: group number = key changes up to this row (see DGroupBy::dense_sorted).
                // The wave's rows are one aligned 64-row chunk (i - lane is a multiple of 64).
-               bool true_head = head; // lanes > 0: key differs from the previous lane's
-               if (lane == 0 && pass) true_head = i == 0 || !d_keys_equal(keys, i - 1, keys, i, true);
-               bool cont = false; // does the chunk's last run continue into the next chunk?
-               if (lane == 63 && pass && i + 1 < n) cont = d_keys_equal(keys, i, keys, i + 1, true);
-               cont = __shfl(cont ? 1 : 0, 63) != 0;
+               const bool true_head = pass && !eqprev[u]; // the key changes at this row (lane 0 included)
+               const bool cont = __shfl(eqnext[u] ? 1 : 0, 63) != 0; // does the chunk's last run continue into the next chunk?
                const uint64_t thmask = __ballot(true_head);
                if (head) {
                   const uint64_t upto = lane >= 63 ? ~0ull : ((2ull << lane) - 1ull);
-                  g = (uint64_t) gptr<uint32_t>(d->chunk_off)[i >> 6] + (uint64_t) __popcll(thmask & upto) - 1ull;
+                  g = (uint64_t) gbase[u] + (uint64_t) __popcll(thmask & upto) - 1ull;
                   plain = true_head && !(run_end == 63 && cont); // the whole group lives inside this run
                   if (true_head) gptr_mut<unsigned long long>(d->g_keys)[g] = (h & 0xFFFFFFFF00000000ull) | (unsigned long long) ((uint32_t) i + 1u);
                }

@@ -471,7 +471,19 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &chunk_off, 4 * (size_t) n_chunks));
          DGroupBy* dh;
          LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dh));
-         hipLaunchKernelGGL(k_gb_sorted_heads, dim3(ldb_grid_for(ctx, in->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dh, chunk_cnt);
+         {
+            const int hgrid = ldb_grid_for(ctx, in->n_rows, 256, 8);
+            hipFunction_t spec = nullptr;
+            std::string why;
+            if (ldb_jit_wanted(in->n_rows)) spec = ldb_jit_groupby_kernel(h, "k_gb_sorted_heads_spec", &why);
+            LdbProf prof_(ctx, "k_gb_sorted_heads");
+            if (spec) {
+               void* params[] = {(void*) &dh, (void*) &chunk_cnt};
+               LDB_HIP(hipModuleLaunchKernel(spec, (unsigned) hgrid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
+            } else {
+               hipLaunchKernelGGL(k_gb_sorted_heads, dim3(hgrid), dim3(256), 0, ctx->stream, dh, chunk_cnt);
+            }
+         }
          LDB_TRY(ldb_exclusive_scan_u32(ctx, chunk_cnt, chunk_off, n_chunks, (uint64_t*) ctx->d_scratch));
          uint64_t groups = 0;
          LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &groups));

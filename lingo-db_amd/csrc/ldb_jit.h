@@ -30,6 +30,7 @@ void ldb_jit_strip_keys(DKeys& k);
 
 // specialised group-by kernel for the metadata of `h`
 hipFunction_t ldb_jit_groupby(const DGroupBy* h, std::string* why);
+hipFunction_t ldb_jit_groupby_kernel(const DGroupBy* h, const char* kernel, std::string* why); // any kernel of the group-by translation unit
 
 // statistics for tests / bench: kernels compiled, cache hits, total compile milliseconds
 extern "C" int32_t ldb_gpu_jit_stats(int64_t* compiled, int64_t* cache_hits, double* compile_ms);

@@ -209,7 +209,8 @@ hipFunction_t ldb_jit_kernel(const char* header, const char* struct_name, const 
 static const char* GB_SPEC_SRC =
    "extern __shared__ __attribute__((aligned(16))) unsigned long long gb_lds_dyn[];\n"
    "#ifndef GB_ROWS\n#define GB_ROWS (LDB_META.batch_rows > 0 ? LDB_META.batch_rows : 4)\n#endif\n"
-   "extern \"C\" __global__ __launch_bounds__(GB_BLOCK) void k_groupby_spec(const DGroupBy* __restrict__ d) { gb_body<GB_ROWS>(LDB_META, d, gb_lds_dyn); }\n";
+   "extern \"C\" __global__ __launch_bounds__(GB_BLOCK) void k_groupby_spec(const DGroupBy* __restrict__ d) { gb_body<GB_ROWS>(LDB_META, d, gb_lds_dyn); }\n"
+   "extern \"C\" __global__ void k_gb_sorted_heads_spec(const DGroupBy* __restrict__ d, uint32_t* __restrict__ chunk_cnt) { gb_sorted_heads_body(LDB_META, d, chunk_cnt); }\n";
 
 static void gb_meta(const DGroupBy* h, DGroupBy* m) {
    memcpy(m, h, sizeof(DGroupBy));
@@ -227,11 +228,12 @@ static void gb_meta(const DGroupBy* h, DGroupBy* m) {
    for (int o = 0; o < GB_MAX_OUT; o++) m->outs[o].out_values = m->outs[o].out_valid = 0;
 }
 
-hipFunction_t ldb_jit_groupby(const DGroupBy* h, std::string* why) {
+hipFunction_t ldb_jit_groupby_kernel(const DGroupBy* h, const char* kernel, std::string* why) {
    auto meta = std::make_unique<DGroupBy>();
    gb_meta(h, meta.get());
-   return ldb_jit_kernel("ldb_gb_kernel.h", "DGroupBy", GB_SPEC_SRC, "k_groupby_spec", meta.get(), sizeof(DGroupBy), why);
+   return ldb_jit_kernel("ldb_gb_kernel.h", "DGroupBy", GB_SPEC_SRC, kernel, meta.get(), sizeof(DGroupBy), why);
 }
+hipFunction_t ldb_jit_groupby(const DGroupBy* h, std::string* why) { return ldb_jit_groupby_kernel(h, "k_groupby_spec", why); }
 
 // Compile-only check (no device needed): specialise the group-by kernel for a TPC-H-Q1-shaped
 // descriptor and report the hiprtc log.  Used by the CPU-side tests and __graft_entry__.build().

@@ -134,6 +134,32 @@ __global__ void k_gen_cname(int64_t row0, uint64_t n, int64_t* offs, char* out) 
    }
 }
 
+// p_name = five colour words separated by blanks: variable width → lengths, scan, fill
+struct ColorDomain {
+   int32_t off[LDB_TPCH_NCOLORS + 1];
+   char blob[704];
+};
+__global__ void k_gen_pname_lens(ColorDomain dom, int64_t row0, uint64_t n, int64_t* lens) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      int64_t len = LDB_TPCH_PNAME_WORDS - 1;
+      for (int j = 0; j < LDB_TPCH_PNAME_WORDS; j++) {
+         int32_t k = ldb_tpch_p_name_word(row0 + (int64_t) i, j);
+         len += dom.off[k + 1] - dom.off[k];
+      }
+      lens[i] = len;
+   }
+}
+__global__ void k_gen_pname_fill(ColorDomain dom, int64_t row0, uint64_t n, const int64_t* offs, char* out) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      int64_t o = offs[i];
+      for (int j = 0; j < LDB_TPCH_PNAME_WORDS; j++) {
+         int32_t k = ldb_tpch_p_name_word(row0 + (int64_t) i, j);
+         if (j) out[o++] = ' ';
+         for (int32_t b = dom.off[k]; b < dom.off[k + 1]; b++) out[o++] = dom.blob[b];
+      }
+   }
+}
+
 static const char* const* domain_strings(int32_t table, int32_t col) {
    if (table == LDB_TPCH_LINEITEM && col == L_SHIPINSTRUCT) return ldb_tpch_instructs;
    if (table == LDB_TPCH_LINEITEM && col == L_SHIPMODE) return ldb_tpch_shipmodes;
@@ -156,7 +182,7 @@ struct ColDef {
 static const ColDef LINEITEM_COLS[L_NCOLS] = {{"l_orderkey", CT_I32}, {"l_partkey", CT_I32}, {"l_suppkey", CT_I32}, {"l_linenumber", CT_I32}, {"l_quantity", CT_DEC}, {"l_extendedprice", CT_DEC}, {"l_discount", CT_DEC}, {"l_tax", CT_DEC}, {"l_returnflag", CT_CH}, {"l_linestatus", CT_CH}, {"l_shipdate", CT_DATE}, {"l_commitdate", CT_DATE}, {"l_receiptdate", CT_DATE}, {"l_shipinstruct", CT_STR}, {"l_shipmode", CT_STR}};
 static const ColDef ORDERS_COLS[O_NCOLS] = {{"o_orderkey", CT_I32}, {"o_custkey", CT_I32}, {"o_orderstatus", CT_CH}, {"o_totalprice", CT_DEC}, {"o_orderdate", CT_DATE}, {"o_orderpriority", CT_STR}, {"o_shippriority", CT_I32}};
 static const ColDef CUSTOMER_COLS[C_NCOLS] = {{"c_custkey", CT_I32}, {"c_nationkey", CT_I32}, {"c_acctbal", CT_DEC}, {"c_mktsegment", CT_STR}, {"c_name", CT_STR}};
-static const ColDef PART_COLS[P_NCOLS] = {{"p_partkey", CT_I32}, {"p_size", CT_I32}, {"p_retailprice", CT_DEC}};
+static const ColDef PART_COLS[P_NCOLS] = {{"p_partkey", CT_I32}, {"p_size", CT_I32}, {"p_retailprice", CT_DEC}, {"p_name", CT_STR}};
 static const ColDef SUPPLIER_COLS[S_NCOLS] = {{"s_suppkey", CT_I32}, {"s_nationkey", CT_I32}, {"s_acctbal", CT_DEC}};
 static const ColDef PARTSUPP_COLS[PS_NCOLS] = {{"ps_partkey", CT_I32}, {"ps_suppkey", CT_I32}, {"ps_availqty", CT_I32}, {"ps_supplycost", CT_DEC}};
 static const ColDef NATION_COLS[N_NCOLS] = {{"n_nationkey", CT_I32}, {"n_regionkey", CT_I32}, {"n_name", CT_STR}};
@@ -225,6 +251,29 @@ extern "C" int32_t ldb_gpu_tpch_generate(ldb_ctx* ctx, int32_t table_id, int64_t
          LDB_TRY(ldb_dev_alloc(ctx, &col.values, (size_t) col.value_bytes));
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &col.offsets, 8 * (size_t) (n + 1)));
          hipLaunchKernelGGL(k_gen_cname, dim3(grid), dim3(256), 0, ctx->stream, b, (uint64_t) n, col.offsets, (char*) col.values);
+      } else if (col.type.type == LDB_T_UTF8 && table_id == LDB_TPCH_PART && c == P_NAME) {
+         ColorDomain dom;
+         memset(&dom, 0, sizeof(dom));
+         int pos = 0;
+         for (int k = 0; k < LDB_TPCH_NCOLORS; k++) {
+            dom.off[k] = pos;
+            size_t len = strlen(ldb_tpch_colors[k]);
+            if (pos + len > sizeof(dom.blob)) LDB_FAIL(LDB_ERR_INVALID, "tpch_generate: colour vocabulary exceeds its buffer");
+            memcpy(dom.blob + pos, ldb_tpch_colors[k], len);
+            pos += (int) len;
+         }
+         dom.off[LDB_TPCH_NCOLORS] = pos;
+         int64_t* lens;
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &lens, 8 * (size_t) (n + 1)));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &col.offsets, 8 * (size_t) (n + 1)));
+         if (n) hipLaunchKernelGGL(k_gen_pname_lens, dim3(grid), dim3(256), 0, ctx->stream, dom, b, (uint64_t) n, lens);
+         LDB_TRY(ldb_exclusive_scan_i64(ctx, lens, col.offsets, n, col.offsets + n));
+         uint64_t total = 0;
+         LDB_TRY(ldb_read_u64(ctx, col.offsets + n, &total));
+         ldb_dev_free(ctx, lens);
+         col.value_bytes = (int64_t) total;
+         LDB_TRY(ldb_dev_alloc(ctx, &col.values, (size_t) total));
+         if (n) hipLaunchKernelGGL(k_gen_pname_fill, dim3(grid), dim3(256), 0, ctx->stream, dom, b, (uint64_t) n, (const int64_t*) col.offsets, (char*) col.values);
       } else if (col.type.type == LDB_T_UTF8) {
          const char* const* strs = domain_strings(table_id, c);
          StrDomain dom;
