@@ -197,7 +197,21 @@ int32_t ldb_gpu_materialize(ldb_ctx* ctx, ldb_rel* r, const ldb_colref* cols, in
 
 /* ------------------------------------------------------------------ scan + filter (a2, a3, a4) */
 /* FilterOp mirrors lingodb::runtime::FilterOp (include/lingodb/runtime/storage/TableStorage.h:14-24). */
-typedef enum { LDB_F_EQ = 0, LDB_F_NEQ = 1, LDB_F_LT = 2, LDB_F_LTE = 3, LDB_F_GT = 4, LDB_F_GTE = 5, LDB_F_NOTNULL = 6, LDB_F_IN = 7 } ldb_filter_op;
+typedef enum {
+   LDB_F_EQ = 0,
+   LDB_F_NEQ = 1,
+   LDB_F_LT = 2,
+   LDB_F_LTE = 3,
+   LDB_F_GT = 4,
+   LDB_F_GTE = 5,
+   LDB_F_NOTNULL = 6,
+   LDB_F_IN = 7,
+   /* beyond FilterOp: string predicates the reference evaluates in generated code by calling
+    * StringRuntime::like (src/runtime/StringRuntime.cpp:134-136; escape '\\').  utf8 column,
+    * rhs_kind = STRING, pattern in (str, str_len). */
+   LDB_F_LIKE = 8,
+   LDB_F_NOT_LIKE = 9
+} ldb_filter_op;
 typedef enum { LDB_RHS_INT = 0, LDB_RHS_STRING = 1, LDB_RHS_COLUMN = 2, LDB_RHS_FLOAT = 3 } ldb_rhs_kind;
 
 /* One conjunct.  Constants are already typed against the column (the host mirror of

@@ -691,7 +691,9 @@ int32_t ldb_make_dpred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out) {
    out->lo = p->value_lo;
    out->hi = p->value_hi;
    out->f = p->value_f64;
-   if (p->op < LDB_F_EQ || p->op > LDB_F_IN) LDB_FAIL(LDB_ERR_INVALID, "filter: bad op %d", p->op);
+   if (p->op < LDB_F_EQ || p->op > LDB_F_NOT_LIKE) LDB_FAIL(LDB_ERR_INVALID, "filter: bad op %d", p->op);
+   if ((p->op == LDB_F_LIKE || p->op == LDB_F_NOT_LIKE) && (out->col.type != LDB_T_UTF8 || p->rhs_kind != LDB_RHS_STRING))
+      LDB_FAIL(LDB_ERR_INVALID, "filter: LIKE needs a utf8 column and a string pattern");
    if (p->op == LDB_F_NOTNULL) return LDB_OK;
    bool is_str = out->col.type == LDB_T_UTF8;
    if (p->rhs_kind == LDB_RHS_COLUMN) {
@@ -739,7 +741,7 @@ static int pred_cost(const DPred& p) {
    const bool str = p.col.type == LDB_T_UTF8;
    const bool wide = (p.col.type == LDB_T_DECIMAL128 && p.col.precision >= 19) || p.col.type == LDB_T_FLOAT64 || p.col.type == LDB_T_FLOAT32;
    if (p.op == LDB_F_NOTNULL) return 0;
-   if (str) return p.op == LDB_F_IN || p.rhs_kind == LDB_RHS_COLUMN ? 6 : 5;
+   if (str) return p.op == LDB_F_LIKE || p.op == LDB_F_NOT_LIKE ? 7 : (p.op == LDB_F_IN || p.rhs_kind == LDB_RHS_COLUMN ? 6 : 5);
    if (wide) return 3;
    if (p.rhs_kind == LDB_RHS_COLUMN || p.op == LDB_F_IN) return 2;
    return 1;

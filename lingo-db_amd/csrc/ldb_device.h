@@ -194,6 +194,73 @@ __device__ inline int d_str_cmp(const uint8_t* a, uint32_t la, const uint8_t* b,
    }
    return la < lb ? -1 : (la > lb ? 1 : 0);
 }
+// SQL LIKE with the reference's semantics (StringRuntime::like → iterativeLike,
+// src/runtime/StringRuntime.cpp:28-93, escape '\\'): a character = UTF-8 lead byte + continuation
+// bytes, two characters are equal when their lead bytes are, '_' = one character, '%' = any number;
+// an escape right after a %/_ run is stepped over and the character behind it matches like an
+// unescaped one; a pattern ending in a lone escape never matches.  The reference recurses at every
+// '%'; here one restart point (the latest '%') is kept — for LIKE patterns retrying from the most
+// recent '%' is equivalent — so no device stack is needed.
+__device__ __forceinline__ uint32_t d_utf8_len(const uint8_t* p, uint32_t left) {
+   uint32_t k = 1;
+   while (k < left && (p[k] >> 6) == 2) k++;
+   return k;
+}
+__device__ inline bool d_like(const uint8_t* s, uint32_t sl, const uint8_t* p, uint32_t pl) {
+   uint32_t si = 0, pi = 0, star_p = 0, star_s = 0;
+   bool have_star = false;
+   for (;;) {
+      bool mismatch = false;
+      if (pi < pl && si < sl) {
+         const uint8_t pc = p[pi];
+         if (pc == '%') {
+            pi++;
+            while (pi < pl && (p[pi] == '%' || p[pi] == '_')) {
+               if (p[pi] == '_') {
+                  if (si >= sl) return false;
+                  si += d_utf8_len(s + si, sl - si);
+               }
+               pi++;
+            }
+            if (pi >= pl) return true;
+            if (p[pi] == '\\') {
+               pi += d_utf8_len(p + pi, pl - pi);
+               if (pi >= pl) return false;
+            }
+            have_star = true;
+            star_p = pi;
+            star_s = si;
+            continue;
+         } else if (pc == '\\') {
+            uint32_t q = pi + d_utf8_len(p + pi, pl - pi);
+            if (q >= pl || p[q] != s[si]) {
+               mismatch = true;
+            } else {
+               si += d_utf8_len(s + si, sl - si);
+               pi = q + d_utf8_len(p + q, pl - q);
+            }
+         } else if (pc == '_' || pc == s[si]) {
+            si += d_utf8_len(s + si, sl - si);
+            pi += d_utf8_len(p + pi, pl - pi);
+         } else {
+            mismatch = true;
+         }
+      } else if (si >= sl) {
+         while (pi < pl && p[pi] == '%') pi++;
+         return pi >= pl;
+      } else {
+         mismatch = true; // pattern used up, string is not
+      }
+      if (mismatch) {
+         if (!have_star) return false;
+         star_s += d_utf8_len(s + star_s, sl - star_s);
+         if (star_s >= sl) return false;
+         si = star_s;
+         pi = star_p;
+      }
+   }
+}
+
 __device__ __forceinline__ bool d_cmp_apply(int op, int c3) {
    switch (op) {
       case LDB_F_EQ: return c3 == 0;
@@ -251,6 +318,7 @@ __device__ __forceinline__ bool d_eval_pred(PV p, uint64_t i) {
          }
          return false;
       }
+      if (p.m.op == LDB_F_LIKE || p.m.op == LDB_F_NOT_LIKE) return d_like(a, la, (const uint8_t*) p.m.str, (uint32_t) p.m.str_len) == (p.m.op == LDB_F_LIKE);
       return d_cmp_apply(p.m.op, d_str_cmp(a, la, (const uint8_t*) p.m.str, (uint32_t) p.m.str_len));
    }
    if (d_is_flt(col)) {

@@ -542,15 +542,32 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
          // three dependent round trips of its own and the kernel ran at latency, not bandwidth
          bool eqprev[ROWS], eqnext[ROWS];
          uint32_t gbase[ROWS];
+         if (m.dense_sorted) {
+            // one dense NOT NULL integer key (what the sorted statistic guarantees): branch-free
+            // clamped loads of the previous / own / next key for the whole batch, compares after
+            const CV kc = keys.col(0);
+            long long kcur[ROWS], kprev[ROWS], knext[ROWS];
 #pragma unroll
-         for (int u = 0; u < ROWS; u++) {
-            const uint64_t i = rowsv[u];
-            eqprev[u] = passv[u] && i > 0 && (m.keyless || d_keys_equal(keys, i - 1, keys, i, true));
-            eqnext[u] = false;
-            gbase[u] = 0;
-            if (m.dense_sorted) {
-               if (lane == 63 && passv[u] && i + 1 < n) eqnext[u] = d_keys_equal(keys, i, keys, i + 1, true);
-               if (passv[u]) gbase[u] = gptr<uint32_t>(d->chunk_off)[i >> 6];
+            for (int u = 0; u < ROWS; u++) {
+               const uint64_t ii = rowsv[u] < n ? rowsv[u] : n - 1;
+               kcur[u] = d_load_i64(kc, (uint32_t) ii);
+               kprev[u] = d_load_i64(kc, (uint32_t) (ii > 0 ? ii - 1 : 0));
+               knext[u] = d_load_i64(kc, (uint32_t) (ii + 1 < n ? ii + 1 : ii));
+               gbase[u] = gptr<uint32_t>(d->chunk_off)[ii >> 6];
+            }
+#pragma unroll
+            for (int u = 0; u < ROWS; u++) {
+               const uint64_t i = rowsv[u];
+               eqprev[u] = passv[u] & (i > 0) & (kprev[u] == kcur[u]);
+               eqnext[u] = (lane == 63) & passv[u] & (i + 1 < n) & (knext[u] == kcur[u]);
+            }
+         } else {
+#pragma unroll
+            for (int u = 0; u < ROWS; u++) {
+               const uint64_t i = rowsv[u];
+               eqprev[u] = passv[u] && i > 0 && (m.keyless || d_keys_equal(keys, i - 1, keys, i, true));
+               eqnext[u] = false;
+               gbase[u] = 0;
             }
          }
 #pragma unroll

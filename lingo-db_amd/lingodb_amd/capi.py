@@ -24,7 +24,7 @@ LDB_ERR_NO_DEVICE = -5
 # ldb_type
 T_INT8, T_INT16, T_INT32, T_INT64, T_DATE32, T_DECIMAL128, T_CHAR4, T_UTF8, T_FLOAT64, T_FLOAT32, T_BOOL8 = range(11)
 # ldb_filter_op / rhs kind
-F_EQ, F_NEQ, F_LT, F_LTE, F_GT, F_GTE, F_NOTNULL, F_IN = range(8)
+F_EQ, F_NEQ, F_LT, F_LTE, F_GT, F_GTE, F_NOTNULL, F_IN, F_LIKE, F_NOT_LIKE = range(10)
 RHS_INT, RHS_STRING, RHS_COLUMN, RHS_FLOAT = range(4)
 # ldb_agg_fn
 AGG_SUM, AGG_MIN, AGG_MAX, AGG_COUNT, AGG_COUNT_STAR, AGG_ANY, AGG_AVG = range(7)

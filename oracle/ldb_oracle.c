@@ -230,6 +230,76 @@ static inline i128 make_i128(uint64_t lo, int64_t hi) { return (i128) (((u128) (
  * native type, decimals as __int128, strings as string_view, IN = membership); residual
  * column-vs-column compares follow db.cmp on the loaded values.  A NULL operand fails every
  * comparison (the reference emits a NOTNULL filter first, Pushdown.cpp:266-408). */
+/* SQL LIKE as the reference evaluates it (StringRuntime::like → iterativeLike,
+ * src/runtime/StringRuntime.cpp:28-93, 134-136; escape character '\\').  Restated from its
+ * behaviour, quirks included:
+ *   - a "character" is a UTF-8 lead byte plus its continuation bytes (nextChar :18-26);
+ *   - two characters are equal when their LEAD bytes are equal (`*p == *s`, :84): continuation
+ *     bytes are skipped, never compared;
+ *   - '_' consumes one character, '%' any number; after a run of %/_ an escape character is
+ *     stepped over and the character behind it is then matched like an unescaped one (:65-70 hand
+ *     the recursion a pattern that starts behind the escape);
+ *   - a pattern that ends in a lone escape never matches (:33-36, :67-69). */
+static size_t like_char_len(const uint8_t* p, size_t left) { /* bytes of the character at p (left > 0) */
+   size_t k = 1;
+   while (k < left && (p[k] >> 6) == 2) k++;
+   return k;
+}
+static int like_match(const uint8_t* s, size_t sl, const uint8_t* p, size_t pl) {
+   while (pl > 0 && sl > 0) {
+      if (*p == '\\') {
+         size_t e = like_char_len(p, pl);
+         p += e;
+         pl -= e;
+         if (pl == 0 || *p != *s) return 0;
+         size_t a = like_char_len(s, sl), b = like_char_len(p, pl);
+         s += a, sl -= a, p += b, pl -= b;
+      } else if (*p == '%') {
+         p++, pl--;
+         while (pl > 0 && (*p == '%' || *p == '_')) { /* collapse the wildcard run */
+            if (*p == '_') {
+               if (sl == 0) return 0;
+               size_t a = like_char_len(s, sl);
+               s += a, sl -= a;
+            }
+            p++, pl--;
+         }
+         if (pl == 0) return 1;
+         if (*p == '\\') {
+            size_t e = like_char_len(p, pl);
+            p += e, pl -= e;
+            if (pl == 0) return 0;
+         }
+         while (sl > 0) { /* try the rest of the pattern at every remaining position */
+            if (like_match(s, sl, p, pl)) return 1;
+            size_t a = like_char_len(s, sl);
+            s += a, sl -= a;
+         }
+         return 0;
+      } else if (*p == '_' || *p == *s) {
+         size_t a = like_char_len(s, sl), b = like_char_len(p, pl);
+         s += a, sl -= a, p += b, pl -= b;
+      } else {
+         return 0;
+      }
+   }
+   while (pl > 0 && *p == '%') p++, pl--;
+   return sl == 0 && pl == 0;
+}
+int32_t ora_like(const uint8_t* s, int64_t sl, const uint8_t* p, int64_t pl) { return like_match(s, (size_t) sl, p, (size_t) pl); }
+
+/* extract(year from date) on a date32 (days since 1970-01-01): DateRuntime::extractYear
+ * (src/runtime/DateRuntime.cpp:99-101) = civil year of the day (proleptic Gregorian, UTC). */
+int64_t ora_extract_year(int64_t days) {
+   int64_t z = days + 719468; /* days since 0000-03-01 */
+   int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+   int64_t doe = z - era * 146097; /* [0, 146096] */
+   int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365; /* [0, 399] */
+   int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100); /* [0, 365], March-based */
+   int64_t mp = (5 * doy + 2) / 153; /* March = 0 */
+   return yoe + era * 400 + (mp >= 10 ? 1 : 0);
+}
+
 static int eval_pred(const ora_rel* r, const ldb_filter_desc* p, int64_t i) {
    const ora_col* c = rel_col(r, p->col);
    int64_t row;
@@ -261,6 +331,8 @@ static int eval_pred(const ora_rel* r, const ldb_filter_desc* p, int64_t i) {
             if (str_cmp(a, la, (const uint8_t*) p->in_strs[k], (uint32_t) p->in_str_lens[k]) == 0) return 1;
          return 0;
       }
+      if (p->op == LDB_F_LIKE || p->op == LDB_F_NOT_LIKE)
+         return like_match(a, la, (const uint8_t*) p->str, (size_t) p->str_len) == (p->op == LDB_F_LIKE);
       return cmp_apply(p->op, str_cmp(a, la, (const uint8_t*) p->str, (uint32_t) p->str_len));
    }
    if (is_float(c)) {

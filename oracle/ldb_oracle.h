@@ -75,6 +75,9 @@ int64_t ora_topk(const ora_rel* in, const ldb_sort_spec* specs, int32_t n_specs,
 void ora_eval_expr(const ora_rel* in, const ldb_expr* e, int64_t* out_lohi);
 /* partition id per row: (hash >> 16) % nparts */
 void ora_partition_ids(const ora_rel* in, const ldb_colref* keys, int32_t n_keys, int32_t nparts, int32_t* out);
+/* SQL LIKE (StringRuntime::like, escape '\\') and extract(year from date32) (DateRuntime::extractYear) */
+int32_t ora_like(const uint8_t* s, int64_t sl, const uint8_t* p, int64_t pl);
+int64_t ora_extract_year(int64_t days);
 int32_t ora_num_cores(void);
 
 #ifdef __cplusplus

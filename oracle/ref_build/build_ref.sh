@@ -26,6 +26,9 @@ SRCS=(
   src/runtime/ThreadLocal.cpp
   src/runtime/ExecutionContext.cpp
   src/runtime/Sorting.cpp
+  src/runtime/StringRuntime.cpp
+  src/runtime/ListRuntime.cpp
+  src/runtime/DateRuntime.cpp
   src/utility/Tracer.cpp
   src/utility/Setting.cpp
 )

@@ -20,6 +20,8 @@
 #include "lingodb/runtime/PreAggregationHashtable.h"
 #include "lingodb/runtime/ThreadLocal.h"
 #include "lingodb/runtime/helpers.h"
+#include "lingodb/runtime/DateRuntime.h"
+#include "lingodb/runtime/StringRuntime.h"
 #include "lingodb/runtime/storage/Restrictions.h"
 #include "lingodb/scheduler/Scheduler.h"
 #include "lingodb/scheduler/Tasks.h"
@@ -288,5 +290,13 @@ int64_t ref_groupby_int64(const int64_t* keys, const uint64_t* hashes, const int
       &o);
    return o.n;
 }
+
+// StringRuntime::like (src/runtime/StringRuntime.cpp:134-136) and DateRuntime::extractYear
+// (src/runtime/DateRuntime.cpp:99-101) — the real functions the generated code calls for LIKE and
+// extract(year from …); pin the oracle's restatements of both.
+int32_t ref_like(const char* str, int64_t str_len, const char* pat, int64_t pat_len) {
+   return runtime::StringRuntime::like(runtime::VarLen32::fromDataAndLen(str, (size_t) str_len, runtime::StorageClass::TRANSIENT), runtime::VarLen32::fromDataAndLen(pat, (size_t) pat_len, runtime::StorageClass::TRANSIENT)) ? 1 : 0;
+}
+int64_t ref_extract_year(int64_t date_ns) { return runtime::DateRuntime::extractYear(date_ns); }
 
 } // extern "C"

@@ -187,6 +187,10 @@ class Oracle:
         lib.ora_eval_expr.argtypes = [C.POINTER(OraRel), C.POINTER(capi.Expr), P]
         lib.ora_partition_ids.argtypes = [C.POINTER(OraRel), C.POINTER(ColRef), C.c_int32, C.c_int32, P]
         lib.ora_num_cores.restype = C.c_int32
+        lib.ora_like.restype = C.c_int32
+        lib.ora_like.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]
+        lib.ora_extract_year.restype = C.c_int64
+        lib.ora_extract_year.argtypes = [C.c_int64]
 
     # scalar
     def hash64(self, v):
@@ -271,6 +275,14 @@ class Oracle:
 
     def num_cores(self):
         return self.lib.ora_num_cores()
+
+    def like(self, s, pattern):
+        s = s.encode() if isinstance(s, str) else s
+        pattern = pattern.encode() if isinstance(pattern, str) else pattern
+        return bool(self.lib.ora_like(s, len(s), pattern, len(pattern)))
+
+    def extract_year(self, days):
+        return int(self.lib.ora_extract_year(int(days)))
 
 
 def load():

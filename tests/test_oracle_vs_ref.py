@@ -172,3 +172,36 @@ def test_groupby_vs_reference_preaggregation_hashtable(ref, oracle):
     rep, v, _ = oracle.groupby(rel, [(0, 0)], aggs, threads=3)
     got = sorted((int(keys[r]), (s if s < 1 << 63 else s - (1 << 64)), c) for r, (s, c) in zip(rep, v))
     assert got == want
+
+
+def test_like_vs_reference_string_runtime(ref, oracle):
+    """the oracle's LIKE restatement against the real StringRuntime::like: random strings over a
+    small alphabet (so that matches happen) with multi-byte characters, patterns with % _ and
+    escapes — including the reference's quirks (lead-byte comparison, escape after a wildcard run)"""
+    ref.ref_like.restype = C.c_int32
+    ref.ref_like.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]
+    rng = np.random.default_rng(7)
+    alpha = ["a", "b", "c", "é", "è", "ß", "€", "%", "_", "\\"]
+    palpha = ["a", "b", "c", "é", "è", "€", "%", "%", "_", "_", "\\"]
+    cases = [("", ""), ("", "%"), ("abc", "abc"), ("abc", "a%"), ("abc", "%c"), ("abc", "%b%"), ("abc", "a_c"), ("abc", "a\\bc"), ("a%c", "a\\%c"),
+             ("abc", "abc\\"), ("abc", "%\\"), ("a%b", "%\\%b"), ("é", "è"), ("forest green lace", "%green%"), ("PROMO BRUSHED", "PROMO%")]
+    for _ in range(20000):
+        s = "".join(rng.choice(alpha, rng.integers(0, 9)))
+        p = "".join(rng.choice(palpha, rng.integers(0, 7)))
+        cases.append((s, p))
+    bad = []
+    for s, p in cases:
+        sb, pb = s.encode(), p.encode()
+        want = bool(ref.ref_like(sb, len(sb), pb, len(pb)))
+        if oracle.like(sb, pb) != want:
+            bad.append((s, p, want))
+    assert not bad, bad[:10]
+
+
+def test_extract_year_vs_reference_date_runtime(ref, oracle):
+    ref.ref_extract_year.restype = C.c_int64
+    ref.ref_extract_year.argtypes = [C.c_int64]
+    rng = np.random.default_rng(8)
+    days = list(range(-800, 800)) + list(range(10950, 11330)) + rng.integers(-100000, 100000, 5000).tolist()  # (a date in ns overflows int64 beyond ±106751 days)
+    for d in days:
+        assert oracle.extract_year(d) == ref.ref_extract_year(d * 86_400_000_000_000), d
