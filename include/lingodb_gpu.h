@@ -251,6 +251,17 @@ int32_t ldb_gpu_scan_count(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* pre
  * Output: a 1-column LDB_T_INT64 device table (`hash`). */
 int32_t ldb_gpu_hash_keys(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* keys, int32_t n_keys, ldb_table** out);
 
+/* ------------------------------------------------------------------ scalar functions as computed columns */
+/* The generated code calls runtime functions per tuple (rt::DateRuntime::extractYear …,
+ * src/runtime/DateRuntime.cpp:99-101); where such a value is a group key or join key it becomes a
+ * computed column here: one device column with a value per row of `in` (NULL in → NULL out),
+ * attached to the relation with ldb_gpu_rel_zip. */
+typedef enum { LDB_FN_EXTRACT_YEAR = 0 /* date32 → int64 civil year */ } ldb_scalar_fn;
+int32_t ldb_gpu_map_column(ldb_ctx* ctx, ldb_rel* in, ldb_colref col, int32_t fn, const char* name, ldb_table** out);
+/* `in` extended by a table of exactly ldb_gpu_rel_rows(in) rows as a new LAST side (identity row
+ * ids); the table must outlive the relation. */
+int32_t ldb_gpu_rel_zip(ldb_ctx* ctx, ldb_rel* in, const ldb_table* t, ldb_rel** out);
+
 /* ------------------------------------------------------------------ expressions (a16) */
 /* Integer/decimal expression in sum-of-products normal form:
  *     value = Σ_t sign_t * ( Π_f (a_f + b_f * col_f) ) / 10^div_pow10_t      (128-bit, wrapping)

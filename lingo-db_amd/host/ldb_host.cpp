@@ -561,6 +561,93 @@ extern "C" int32_t ldb_plan_tpch_q18(ldb_ctx* ctx, const ldb_table* cust, const 
    });
 }
 
+namespace {
+// string predicate evaluated in generated code (StringRuntime::like), not a pushed-down restriction
+struct LikePred {
+   std::string pattern;
+   ldb_filter_desc d;
+   LikePred(ldb_colref c, std::string pat, bool negate = false) : pattern(std::move(pat)) {
+      memset(&d, 0, sizeof(d));
+      d.col = c;
+      d.op = negate ? LDB_F_NOT_LIKE : LDB_F_LIKE;
+      d.rhs_kind = LDB_RHS_STRING;
+      d.str = pattern.data();
+      d.str_len = (int32_t) pattern.size();
+   }
+};
+} // namespace
+
+// TPC-H Q9 (resources/sql/tpch/9.sql): profit per nation and year over the lineitems of "green"
+// parts — part ⋈ lineitem ⋈ partsupp (two-column key) ⋈ supplier ⋈ nation ⋈ orders, amount =
+// l_extendedprice·(1 − l_discount) − ps_supplycost·l_quantity, grouped by (n_name, year(o_orderdate)).
+// Join order by cardinality: the LIKE filter keeps 5.4 % of part; everything else is reduced by it.
+extern "C" int32_t ldb_plan_tpch_q9(ldb_ctx* ctx, const ldb_table* part, const ldb_table* supp, const ldb_table* li, const ldb_table* ps, const ldb_table* ord,
+                                    const ldb_table* nat, ldb_table** result) {
+   return guarded([&] {
+      Rel p0(ctx), p1(ctx), l0(ctx), lp(ctx), ps0(ctx), ps1(ctx), lps(ctx), s0(ctx), lpss(ctx), n0(ctx), all(ctx), m0(ctx), o0(ctx), om(ctx), omy(ctx), g(ctx), sorted(ctx);
+      check(ldb_gpu_rel_from_table(ctx, part, &p0.r), "q9 part");
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q9 lineitem");
+      check(ldb_gpu_rel_from_table(ctx, ps, &ps0.r), "q9 partsupp");
+      check(ldb_gpu_rel_from_table(ctx, supp, &s0.r), "q9 supplier");
+      check(ldb_gpu_rel_from_table(ctx, nat, &n0.r), "q9 nation");
+      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q9 orders");
+      LikePred green({0, colOf(part, "p_name")}, "%green%");
+      check(ldb_gpu_scan_filter(ctx, p0.r, &green.d, 1, &p1.r), "q9 filter part");
+      // green parts: hash table on p_partkey, probed by lineitem (inner) and by partsupp (semi)
+      Ht hp(ctx), hps(ctx), hs(ctx), hn(ctx), hm(ctx);
+      ldb_colref pk{0, colOf(part, "p_partkey")}, lpk{0, colOf(li, "l_partkey")}, lsk{0, colOf(li, "l_suppkey")}, pspk{0, colOf(ps, "ps_partkey")}, pssk{0, colOf(ps, "ps_suppkey")};
+      check(ldb_gpu_join_build(ctx, p1.r, &pk, 1, 1, &hp.h), "q9 build part");
+      check(ldb_gpu_join_probe(ctx, hp.h, l0.r, &lpk, 1, LDB_JOIN_SEMI, &lp.r, nullptr), "q9 lineitem of green parts"); // p_partkey = l_partkey: no part column is needed later
+      check(ldb_gpu_join_probe(ctx, hp.h, ps0.r, &pspk, 1, LDB_JOIN_SEMI, &ps1.r, nullptr), "q9 partsupp of green parts");
+      // partsupp on (ps_partkey, ps_suppkey) = (l_partkey, l_suppkey)
+      ldb_colref psk2[2] = {pspk, pssk}, lk2[2] = {lpk, lsk};
+      check(ldb_gpu_join_build(ctx, ps1.r, psk2, 2, 1, &hps.h), "q9 build partsupp");
+      check(ldb_gpu_join_probe(ctx, hps.h, lp.r, lk2, 2, LDB_JOIN_INNER, &lps.r, nullptr), "q9 probe partsupp"); // sides: lineitem, partsupp
+      // supplier, then nation through s_nationkey
+      ldb_colref sk{0, colOf(supp, "s_suppkey")};
+      check(ldb_gpu_join_build(ctx, s0.r, &sk, 1, 1, &hs.h), "q9 build supplier");
+      check(ldb_gpu_join_probe(ctx, hs.h, lps.r, &lsk, 1, LDB_JOIN_INNER, &lpss.r, nullptr), "q9 probe supplier"); // lineitem, partsupp, supplier
+      ldb_colref nk{0, colOf(nat, "n_nationkey")}, snk{2, colOf(supp, "s_nationkey")};
+      check(ldb_gpu_join_build(ctx, n0.r, &nk, 1, 1, &hn.h), "q9 build nation");
+      check(ldb_gpu_join_probe(ctx, hn.h, lpss.r, &snk, 1, LDB_JOIN_INNER, &all.r, nullptr), "q9 probe nation"); // lineitem, partsupp, supplier, nation
+      // narrow to the columns still needed, then orders: the reduced side is the hash table
+      ldb_colref keep[6] = {{0, colOf(li, "l_orderkey")}, {0, colOf(li, "l_extendedprice")}, {0, colOf(li, "l_discount")}, {0, colOf(li, "l_quantity")},
+                            {1, colOf(ps, "ps_supplycost")}, {3, colOf(nat, "n_name")}};
+      Table m(ctx), years(ctx), grouped(ctx);
+      check(ldb_gpu_materialize(ctx, all.r, keep, 6, &m.t), "q9 materialize");
+      check(ldb_gpu_rel_from_table(ctx, m.t, &m0.r), "q9 rel");
+      ldb_colref mok{0, 0}, ook{0, colOf(ord, "o_orderkey")};
+      check(ldb_gpu_join_build(ctx, m0.r, &mok, 1, 0, &hm.h), "q9 build reduced lineitem");
+      check(ldb_gpu_join_probe(ctx, hm.h, o0.r, &ook, 1, LDB_JOIN_INNER, &om.r, nullptr), "q9 probe orders"); // sides: orders, m
+      // o_year = extract(year from o_orderdate) as a computed column (third side)
+      check(ldb_gpu_map_column(ctx, om.r, {0, colOf(ord, "o_orderdate")}, LDB_FN_EXTRACT_YEAR, "o_year", &years.t), "q9 extract year");
+      check(ldb_gpu_rel_zip(ctx, om.r, years.t, &omy.r), "q9 zip year");
+      ldb_colref ext{1, 1}, disc{1, 2}, qty{1, 3}, cost{1, 4};
+      DecimalType te = decOf(m.t, 1), td = decOf(m.t, 2), tq = decOf(m.t, 3), tc = decOf(m.t, 4), t1md;
+      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, td, &t1md);
+      DecimalType tRev = typeAfterMul(te, t1md), tCost = typeAfterMul(tc, tq), tAmount = higherDecimalType(tRev, tCost);
+      if (tRev.s != tCost.s || tRev.s != te.s + t1md.s) throw std::runtime_error("q9: unexpected scales");
+      ldb_expr amount;
+      memset(&amount, 0, sizeof(amount));
+      amount.n_terms = 2;
+      amount.t[0].n_factors = 2;
+      amount.t[0].f[0] = colFactor(ext);
+      amount.t[0].f[1] = oneMinusDisc;
+      amount.t[1].n_factors = 2;
+      amount.t[1].negate = 1;
+      amount.t[1].f[0] = colFactor(cost);
+      amount.t[1].f[1] = colFactor(qty);
+      ldb_agg_spec agg = sumDec(amount, tAmount);
+      ldb_colref keys[2] = {{1, 5}, {2, 0}};
+      check(ldb_gpu_groupby(ctx, omy.r, nullptr, 0, keys, 2, &agg, 1, 25 * 8, &grouped.t), "q9 groupby");
+      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q9 rel");
+      ldb_sort_spec specs[2] = {{{0, 0}, 0, 0}, {{0, 1}, 1, 0}};
+      check(ldb_gpu_sort(ctx, g.r, specs, 2, &sorted.r), "q9 sort");
+      ldb_colref outc[3] = {{0, 0}, {0, 1}, {0, 2}};
+      check(ldb_gpu_materialize(ctx, sorted.r, outc, 3, result), "q9 materialize");
+   });
+}
+
 // ---------------------------------------------------------------- multi-GPU plan pieces
 // Row-range sharded fact tables: every rank runs the *_partial plan on its shard, the tiny partial
 // tables are exchanged over RCCL, and *_final merges them exactly as the reference merges
@@ -790,6 +877,114 @@ extern "C" int32_t ldb_plan_tpch_q18_final(ldb_ctx* ctx, const ldb_table* rows, 
       check(ldb_gpu_topk(ctx, in.r, specs, 2, 100, &top.r), "q18 final topk");
       ldb_colref outc[6] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}};
       check(ldb_gpu_materialize(ctx, top.r, outc, 6, result), "q18 final materialize");
+   });
+}
+
+// Q9 multi-GPU (broadcast the filtered part keys, co-partition lineitem and partsupp
+// on the part key with one all-to-all each, join locally, merge the tiny partial aggregates).
+// lineitem/orders are sharded by order ranges (co-located), part / partsupp / supplier by rows.
+// Step 1 (per shard): the keys of this shard's "green" parts → all-gathered by the caller.
+extern "C" int32_t ldb_plan_tpch_q9_green(ldb_ctx* ctx, const ldb_table* part, ldb_table** result) {
+   return guarded([&] {
+      Rel p0(ctx), p1(ctx);
+      check(ldb_gpu_rel_from_table(ctx, part, &p0.r), "q9 part");
+      LikePred green({0, colOf(part, "p_name")}, "%green%");
+      check(ldb_gpu_scan_filter(ctx, p0.r, &green.d, 1, &p1.r), "q9 filter part");
+      ldb_colref pk{0, colOf(part, "p_partkey")};
+      check(ldb_gpu_materialize(ctx, p1.r, &pk, 1, result), "q9 green keys");
+   });
+}
+// Step 2a (per shard): this shard's lineitems of green parts joined with their (co-located)
+// orders, as rows (l_partkey, l_suppkey, o_year, l_extendedprice, l_discount, l_quantity) grouped
+// by destination rank = hash-radix of l_partkey; counts[world] rows per destination.
+extern "C" int32_t ldb_plan_tpch_q9_lineitem_side(ldb_ctx* ctx, const ldb_table* greenkeys, const ldb_table* li, const ldb_table* ord, int32_t world, ldb_table** result,
+                                                  int64_t* counts) {
+   return guarded([&] {
+      Rel g0(ctx), l0(ctx), lp(ctx), o0(ctx), lo(ctx), loy(ctx);
+      check(ldb_gpu_rel_from_table(ctx, greenkeys, &g0.r), "q9 green keys");
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q9 lineitem");
+      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q9 orders");
+      Ht hg(ctx), ho(ctx);
+      ldb_colref gk{0, 0}, lpk{0, colOf(li, "l_partkey")}, lok{0, colOf(li, "l_orderkey")}, ook{0, colOf(ord, "o_orderkey")};
+      check(ldb_gpu_join_build(ctx, g0.r, &gk, 1, 1, &hg.h), "q9 build green");
+      check(ldb_gpu_join_probe(ctx, hg.h, l0.r, &lpk, 1, LDB_JOIN_SEMI, &lp.r, nullptr), "q9 lineitem of green parts");
+      check(ldb_gpu_join_build(ctx, lp.r, &lok, 1, 0, &ho.h), "q9 build reduced lineitem");
+      check(ldb_gpu_join_probe(ctx, ho.h, o0.r, &ook, 1, LDB_JOIN_INNER, &lo.r, nullptr), "q9 probe orders"); // sides: orders, lineitem
+      Table years(ctx);
+      check(ldb_gpu_map_column(ctx, lo.r, {0, colOf(ord, "o_orderdate")}, LDB_FN_EXTRACT_YEAR, "o_year", &years.t), "q9 extract year");
+      check(ldb_gpu_rel_zip(ctx, lo.r, years.t, &loy.r), "q9 zip year");
+      ldb_colref key{1, lpk.col};
+      ldb_colref cols[6] = {{1, lpk.col}, {1, colOf(li, "l_suppkey")}, {2, 0}, {1, colOf(li, "l_extendedprice")}, {1, colOf(li, "l_discount")}, {1, colOf(li, "l_quantity")}};
+      check(ldb_gpu_partition(ctx, loy.r, &key, 1, world, cols, 6, result, counts), "q9 partition lineitem side");
+   });
+}
+// Step 2b (per shard): this shard's partsupp rows of green parts (ps_partkey, ps_suppkey,
+// ps_supplycost), partitioned by the same hash-radix of the part key.
+extern "C" int32_t ldb_plan_tpch_q9_partsupp_side(ldb_ctx* ctx, const ldb_table* greenkeys, const ldb_table* ps, int32_t world, ldb_table** result, int64_t* counts) {
+   return guarded([&] {
+      Rel g0(ctx), ps0(ctx), ps1(ctx);
+      check(ldb_gpu_rel_from_table(ctx, greenkeys, &g0.r), "q9 green keys");
+      check(ldb_gpu_rel_from_table(ctx, ps, &ps0.r), "q9 partsupp");
+      Ht hg(ctx);
+      ldb_colref gk{0, 0}, pspk{0, colOf(ps, "ps_partkey")};
+      check(ldb_gpu_join_build(ctx, g0.r, &gk, 1, 1, &hg.h), "q9 build green");
+      check(ldb_gpu_join_probe(ctx, hg.h, ps0.r, &pspk, 1, LDB_JOIN_SEMI, &ps1.r, nullptr), "q9 partsupp of green parts");
+      ldb_colref cols[3] = {pspk, {0, colOf(ps, "ps_suppkey")}, {0, colOf(ps, "ps_supplycost")}};
+      check(ldb_gpu_partition(ctx, ps1.r, &pspk, 1, world, cols, 3, result, counts), "q9 partition partsupp side");
+   });
+}
+// Step 3 (per rank, after the two all-to-alls): received lineitem rows ⋈ received partsupp rows
+// on (partkey, suppkey) ⋈ supplier (replicated) ⋈ nation, partial SUM per (n_name, o_year).
+extern "C" int32_t ldb_plan_tpch_q9_join(ldb_ctx* ctx, const ldb_table* lrows, const ldb_table* psrows, const ldb_table* supp, const ldb_table* nat, ldb_table** result) {
+   return guarded([&] {
+      Rel l0(ctx), ps0(ctx), s0(ctx), n0(ctx), lps(ctx), lpss(ctx), all(ctx);
+      check(ldb_gpu_rel_from_table(ctx, lrows, &l0.r), "q9 lineitem rows");
+      check(ldb_gpu_rel_from_table(ctx, psrows, &ps0.r), "q9 partsupp rows");
+      check(ldb_gpu_rel_from_table(ctx, supp, &s0.r), "q9 supplier");
+      check(ldb_gpu_rel_from_table(ctx, nat, &n0.r), "q9 nation");
+      Ht hps(ctx), hs(ctx), hn(ctx);
+      ldb_colref psk2[2] = {{0, 0}, {0, 1}}, lk2[2] = {{0, 0}, {0, 1}}, lsk{0, 1};
+      check(ldb_gpu_join_build(ctx, ps0.r, psk2, 2, 1, &hps.h), "q9 build partsupp");
+      check(ldb_gpu_join_probe(ctx, hps.h, l0.r, lk2, 2, LDB_JOIN_INNER, &lps.r, nullptr), "q9 probe partsupp"); // sides: lrows, psrows
+      ldb_colref sk{0, colOf(supp, "s_suppkey")};
+      check(ldb_gpu_join_build(ctx, s0.r, &sk, 1, 1, &hs.h), "q9 build supplier");
+      check(ldb_gpu_join_probe(ctx, hs.h, lps.r, &lsk, 1, LDB_JOIN_INNER, &lpss.r, nullptr), "q9 probe supplier"); // lrows, psrows, supplier
+      ldb_colref nk{0, colOf(nat, "n_nationkey")}, snk{2, colOf(supp, "s_nationkey")};
+      check(ldb_gpu_join_build(ctx, n0.r, &nk, 1, 1, &hn.h), "q9 build nation");
+      check(ldb_gpu_join_probe(ctx, hn.h, lpss.r, &snk, 1, LDB_JOIN_INNER, &all.r, nullptr), "q9 probe nation"); // lrows, psrows, supplier, nation
+      ldb_colref ext{0, 3}, disc{0, 4}, qty{0, 5}, cost{1, 2};
+      DecimalType te = decOf(lrows, 3), td = decOf(lrows, 4), tq = decOf(lrows, 5), tc = decOf(psrows, 2), t1md;
+      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, td, &t1md);
+      DecimalType tRev = typeAfterMul(te, t1md), tCost = typeAfterMul(tc, tq), tAmount = higherDecimalType(tRev, tCost);
+      ldb_expr amount;
+      memset(&amount, 0, sizeof(amount));
+      amount.n_terms = 2;
+      amount.t[0].n_factors = 2;
+      amount.t[0].f[0] = colFactor(ext);
+      amount.t[0].f[1] = oneMinusDisc;
+      amount.t[1].n_factors = 2;
+      amount.t[1].negate = 1;
+      amount.t[1].f[0] = colFactor(cost);
+      amount.t[1].f[1] = colFactor(qty);
+      ldb_agg_spec agg = sumDec(amount, tAmount);
+      ldb_colref keys[2] = {{3, colOf(nat, "n_name")}, {0, 2}};
+      check(ldb_gpu_groupby(ctx, all.r, nullptr, 0, keys, 2, &agg, 1, 25 * 8, result), "q9 partial groupby");
+   });
+}
+// Step 4 (replicated): add up the gathered partial sums and order the result.
+extern "C" int32_t ldb_plan_tpch_q9_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result) {
+   return guarded([&] {
+      Rel in(ctx), g(ctx), sorted(ctx);
+      check(ldb_gpu_rel_from_table(ctx, partials, &in.r), "q9 final");
+      ldb_colref keys[2] = {{0, 0}, {0, 1}};
+      ldb_agg_spec agg = sumDec(product({colFactor({0, 2})}), decOf(partials, 2));
+      Table grouped(ctx);
+      check(ldb_gpu_groupby(ctx, in.r, nullptr, 0, keys, 2, &agg, 1, 25 * 8, &grouped.t), "q9 final groupby");
+      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q9 final rel");
+      ldb_sort_spec specs[2] = {{{0, 0}, 0, 0}, {{0, 1}, 1, 0}};
+      check(ldb_gpu_sort(ctx, g.r, specs, 2, &sorted.r), "q9 final sort");
+      ldb_colref outc[3] = {{0, 0}, {0, 1}, {0, 2}};
+      check(ldb_gpu_materialize(ctx, sorted.r, outc, 3, result), "q9 final materialize");
    });
 }
 

@@ -74,6 +74,8 @@ int32_t ldb_plan_tpch_q3(ldb_ctx* ctx, const ldb_table* customer, const ldb_tabl
 int32_t ldb_plan_tpch_q4(ldb_ctx* ctx, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q12(ldb_ctx* ctx, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q18(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q9(ldb_ctx* ctx, const ldb_table* part, const ldb_table* supplier, const ldb_table* lineitem, const ldb_table* partsupp, const ldb_table* orders,
+                         const ldb_table* nation, ldb_table** result);
 const char* ldb_plan_last_error(void);
 // multi-GPU pieces: shard-local partial plans + merges of the exchanged partial tables
 int32_t ldb_plan_tpch_q1_partial(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
@@ -88,6 +90,15 @@ int32_t ldb_plan_tpch_q18_local(ldb_ctx* ctx, const ldb_table* orders, const ldb
 int32_t ldb_plan_tpch_q18_mid(ldb_ctx* ctx, const ldb_table* tops, ldb_table** result);
 int32_t ldb_plan_tpch_q18_names(ldb_ctx* ctx, const ldb_table* top100, const ldb_table* customer, ldb_table** result);
 int32_t ldb_plan_tpch_q18_final(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
+// Q9: green part keys → (all-gather) → lineitem side / partsupp side partitioned by hash-radix of the
+// part key (counts[world] rows per destination) → (two all-to-alls) → local joins + partial sums →
+// (all-gather) → final
+int32_t ldb_plan_tpch_q9_green(ldb_ctx* ctx, const ldb_table* part, ldb_table** result);
+int32_t ldb_plan_tpch_q9_lineitem_side(ldb_ctx* ctx, const ldb_table* greenkeys, const ldb_table* lineitem, const ldb_table* orders, int32_t world, ldb_table** result,
+                                       int64_t* counts);
+int32_t ldb_plan_tpch_q9_partsupp_side(ldb_ctx* ctx, const ldb_table* greenkeys, const ldb_table* partsupp, int32_t world, ldb_table** result, int64_t* counts);
+int32_t ldb_plan_tpch_q9_join(ldb_ctx* ctx, const ldb_table* lrows, const ldb_table* psrows, const ldb_table* supplier, const ldb_table* nation, ldb_table** result);
+int32_t ldb_plan_tpch_q9_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
 // test hooks for the host logic (date / decimal parsing, decimal typing rules)
 int32_t ldb_host_parse_date32(const char* s, int32_t* out);
 int32_t ldb_host_parse_decimal(const char* s, int32_t scale, int64_t* lo, int64_t* hi);

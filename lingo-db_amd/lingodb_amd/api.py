@@ -274,6 +274,18 @@ class Rel:
         tab = Table(self.ctx, t)
         return tab.read_fixed(0).view(np.uint64)
 
+    def map_column(self, col, fn=capi.FN_EXTRACT_YEAR, name="year"):
+        """scalar function of one column as a new 1-column table (one value per row of this relation)"""
+        t = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_map_column(self.ctx.h, self.h, colref(*col), fn, name.encode(), C.byref(t)))
+        return Table(self.ctx, t)
+
+    def zip(self, table):
+        """this relation plus `table` (same row count) as a new last side"""
+        r = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_rel_zip(self.ctx.h, self.h, table.h, C.byref(r)))
+        return Rel(self.ctx, r, self.deps + [table])
+
     def groupby(self, keys, aggs, plist=(), est_groups=0):
         parr, np_, keep = preds_array(list(plist))
         karr, nk = _refs(keys)
@@ -465,6 +477,11 @@ class Context:
     def plan_q12(self, orders, lineitem):
         t = C.c_void_p()
         check_plan(capi.host_lib().ldb_plan_tpch_q12(self.h, orders.h, lineitem.h, C.byref(t)))
+        return Table(self, t)
+
+    def plan_q9(self, part, supplier, lineitem, partsupp, orders, nation):
+        t = C.c_void_p()
+        check_plan(capi.host_lib().ldb_plan_tpch_q9(self.h, part.h, supplier.h, lineitem.h, partsupp.h, orders.h, nation.h, C.byref(t)))
         return Table(self, t)
 
     def plan_q18(self, customer, orders, lineitem):

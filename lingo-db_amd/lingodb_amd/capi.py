@@ -30,6 +30,8 @@ RHS_INT, RHS_STRING, RHS_COLUMN, RHS_FLOAT = range(4)
 AGG_SUM, AGG_MIN, AGG_MAX, AGG_COUNT, AGG_COUNT_STAR, AGG_ANY, AGG_AVG = range(7)
 # ldb_join_kind
 JOIN_INNER, JOIN_SEMI, JOIN_ANTI, JOIN_LEFT_OUTER, JOIN_MARK, JOIN_SINGLE, JOIN_SEMI_BUILD, JOIN_ANTI_BUILD = range(8)
+# ldb_scalar_fn
+FN_EXTRACT_YEAR = 0
 
 
 class ColType(C.Structure):
@@ -169,6 +171,8 @@ GPU_API = {
     "ldb_gpu_scan_filter": (i32, [P, P, C.POINTER(FilterDesc), i32, PP]),
     "ldb_gpu_scan_count": (i32, [P, P, C.POINTER(FilterDesc), i32, C.POINTER(i64)]),
     "ldb_gpu_hash_keys": (i32, [P, P, C.POINTER(ColRef), i32, PP]),
+    "ldb_gpu_map_column": (i32, [P, P, ColRef, i32, C.c_char_p, PP]),
+    "ldb_gpu_rel_zip": (i32, [P, P, P, PP]),
     "ldb_gpu_groupby": (i32, [P, P, C.POINTER(FilterDesc), i32, C.POINTER(ColRef), i32, C.POINTER(AggSpec), i32, i64, PP]),
     "ldb_gpu_join_build": (i32, [P, P, C.POINTER(ColRef), i32, i32, PP]),
     "ldb_gpu_hashtable_release": (i32, [P, P]),
@@ -191,6 +195,7 @@ HOST_API = {
     "ldb_plan_tpch_q4": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q12": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q18": (i32, [P, P, P, P, PP]),
+    "ldb_plan_tpch_q9": (i32, [P, P, P, P, P, P, P, PP]),
     "ldb_plan_last_error": (C.c_char_p, []),
     "ldb_plan_tpch_q1_partial": (i32, [P, P, PP]),
     "ldb_plan_tpch_q1_final": (i32, [P, P, PP]),
@@ -204,6 +209,11 @@ HOST_API = {
     "ldb_plan_tpch_q18_mid": (i32, [P, P, PP]),
     "ldb_plan_tpch_q18_names": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q18_final": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q9_green": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q9_lineitem_side": (i32, [P, P, P, P, i32, PP, C.POINTER(i64)]),
+    "ldb_plan_tpch_q9_partsupp_side": (i32, [P, P, P, i32, PP, C.POINTER(i64)]),
+    "ldb_plan_tpch_q9_join": (i32, [P, P, P, P, P, PP]),
+    "ldb_plan_tpch_q9_final": (i32, [P, P, PP]),
     "ldb_host_parse_date32": (i32, [C.c_char_p, C.POINTER(i32)]),
     "ldb_host_parse_decimal": (i32, [C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64)]),
     "ldb_host_decimal_type": (None, [i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),

@@ -182,6 +182,26 @@ def test_hash_keys_parity_all_types(ctx, oracle):
         assert np.array_equal(g.hash_keys(keys), oracle.hash_keys(h, keys)), keys
 
 
+def test_like_filters_match_oracle(ctx, oracle):
+    """LIKE / NOT LIKE conjuncts (StringRuntime::like semantics): TPC-H part names, and random
+    strings with multi-byte characters, escapes and NULLs against every pattern shape"""
+    part = tpch_data.host_table(tpch_data.PART, 45000, cols=[0, 3])  # 6000 names (the recursive oracle is exponential in the number of %)
+    g, h = ctx.register("part_like", part).rel(), HostTable(part).rel()
+    for pat in ("%green%", "forest%", "%lace", "%a%e%i%", "_o%", "%", ""):
+        for op in (capi.F_LIKE, capi.F_NOT_LIKE):
+            plist = [api.pred((0, 1), op, pat)]
+            assert np.array_equal(g.scan_filter(plist).rowids(0), oracle.scan_filter(h, plist)), (pat, op)
+    rng = np.random.default_rng(9)
+    alpha = ["a", "b", "c", "é", "è", "€", "%", "_", "\\"]
+    strs = [None if rng.integers(0, 20) == 0 else "".join(rng.choice(alpha, rng.integers(0, 10))) for _ in range(30000)]
+    t = pa.table({"s": pa.array(strs, pa.string()), "k": pa.array(range(len(strs)), pa.int32())})
+    g, h = ctx.register("rnd_like", t).rel(), HostTable(t).rel()
+    for pat in ("%a%", "a%b", "%é", "è%", "_", "__%", "%\\%%", "%\\_%", "a\\", "%\\", "%€_", "%%b%%c%%", "ab", "%a_c%"):
+        plist = [api.pred((0, 0), capi.F_LIKE, pat), api.pred((0, 1), capi.F_GTE, 10)]
+        assert np.array_equal(g.scan_filter(plist).rowids(0), oracle.scan_filter(h, plist)), pat
+        assert g.scan_count([api.pred((0, 0), capi.F_NOT_LIKE, pat)]) == len(oracle.scan_filter(h, [api.pred((0, 0), capi.F_NOT_LIKE, pat)])), pat
+
+
 # ---------------------------------------------------------------- group-by (a9, a10, a11, a14, a16)
 def q1_aggs():
     f = api.factor

@@ -81,6 +81,35 @@ def test_q12(ctx, db):
     assert result_rows(got) == want
 
 
+def test_q9(ctx):
+    """six-way join with a LIKE filter, a two-column join key, a two-term decimal expression and a
+    computed group key (extract year): against a dict/numpy evaluation of resources/sql/tpch/9.sql"""
+    n = 60_000
+    T = tpch_data
+    li = T.host_table(T.LINEITEM, n, cols=[0, 1, 2, 4, 5, 6])
+    od = T.host_table(T.ORDERS, n, cols=[0, 4])
+    pa_ = T.host_table(T.PART, n, cols=[0, 3])
+    su = T.host_table(T.SUPPLIER, n, cols=[0, 1])
+    ps = T.host_table(T.PARTSUPP, n, cols=[0, 1, 3])
+    na = T.host_table(T.NATION, n, cols=[0, 2])
+    green = {k for k, nm in zip(np_col(pa_, "p_partkey").tolist(), np_col(pa_, "p_name").tolist()) if "green" in nm}
+    assert 0 < len(green) < pa_.num_rows
+    cost = {(p, s): c for p, s, c in zip(np_col(ps, "ps_partkey").tolist(), np_col(ps, "ps_suppkey").tolist(), np_col(ps, "ps_supplycost").tolist())}
+    snat = dict(zip(np_col(su, "s_suppkey").tolist(), np_col(su, "s_nationkey").tolist()))
+    nname = dict(zip(np_col(na, "n_nationkey").tolist(), np_col(na, "n_name").tolist()))
+    oyear = {k: (EPOCH + datetime.timedelta(days=int(d))).year for k, d in zip(np_col(od, "o_orderkey").tolist(), np_col(od, "o_orderdate").tolist())}
+    profit = collections.defaultdict(int)
+    cols = [np_col(li, c).tolist() for c in ("l_orderkey", "l_partkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount")]
+    for ok, pk, sk, qty, ext, disc in zip(*cols):
+        if pk in green:
+            profit[(nname[snat[sk]], oyear[ok])] += ext * (100 - disc) - cost[(pk, sk)] * qty  # both terms at scale 4
+    want = sorted(((nat, yr, amt) for (nat, yr), amt in profit.items()), key=lambda r: (r[0], -r[1]))
+    reg = lambda name, t: ctx.register(name, t)
+    got = ctx.plan_q9(reg("q9_part", pa_), reg("q9_supp", su), reg("q9_li", li), reg("q9_ps", ps), reg("q9_od", od), reg("q9_nat", na)).to_arrow()
+    assert got.schema.field(1).type == pa.int64() and got.schema.field(2).type == pa.decimal128(33, 4)
+    assert result_rows(got) == want
+
+
 def test_q18(ctx, db):
     li, od, cu = db["li"], db["od"], db["cu"]
     lkey, qty = np_col(li, "l_orderkey"), np_col(li, "l_quantity")

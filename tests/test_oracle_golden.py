@@ -228,3 +228,29 @@ def test_keyless_empty_input(oracle):
     rel = HostTable(t).rel()
     rep, vals, valid = oracle.groupby(rel, [], [api.agg(capi.AGG_SUM, api.col_expr((0, 0))), api.agg(capi.AGG_COUNT_STAR)])
     assert len(rep) == 1 and vals[0][1] == 0 and list(valid[0]) == [0, 1]
+
+
+def test_like_known_answers(oracle):
+    """SQL LIKE: the TPC-H patterns (queries 2, 9, 13, 14, 16, 20 of resources/sql/tpch) and the
+    standard's wildcard / escape rules, plus the reference's documented quirks (see ora_like)."""
+    yes = [("forest green lace", "%green%"), ("green", "%green%"), ("PROMO BRUSHED TIN", "PROMO%"), ("LARGE BRASS", "%BRASS"),
+           ("special packages requests", "%special%requests%"), ("MEDIUM POLISHED COPPER", "MEDIUM POLISHED%"), ("", ""), ("", "%"), ("abc", "a_c"), ("abc", "___"),
+           ("a%c", "a\\%c"), ("a_c", "a\\_c"), ("ab", "%%a%b%%"), ("é", "_"), ("é", "è")]  # last: lead bytes compare equal (reference quirk)
+    no = [("forest grey lace", "%green%"), ("SPROMO", "PROMO%"), ("BRASSY", "%BRASS"), ("special", "%special%requests%"), ("abc", "a_"), ("abc", "____"), ("abc", "ABC"),
+          ("a%c", "a\\_c"), ("abc", "abc\\"), ("", "_"), ("é", "__")]
+    for s, p in yes:
+        assert oracle.like(s, p), (s, p)
+    for s, p in no:
+        assert not oracle.like(s, p), (s, p)
+    t = pa.table({"s": pa.array([s for s, _ in yes] + [None]), "k": pa.array(range(len(yes) + 1), pa.int32())})
+    rel = HostTable(t).rel()
+    assert oracle.scan_filter(rel, [api.pred((0, 0), capi.F_LIKE, "%green%")]).tolist() == [0, 1]
+    assert oracle.scan_filter(rel, [api.pred((0, 0), capi.F_NOT_LIKE, "%green%")]).tolist() == list(range(2, len(yes)))  # NULL fails both
+
+
+def test_extract_year_known_answers(oracle):
+    import datetime
+
+    for d in ["1970-01-01", "1969-12-31", "1992-01-01", "1995-12-31", "1996-02-29", "1998-08-02", "2000-03-01", "1900-03-01", "2400-02-29", "0001-01-01"]:
+        day = (datetime.date.fromisoformat(d) - datetime.date(1970, 1, 1)).days
+        assert oracle.extract_year(day) == int(d[:4]), d

@@ -128,6 +128,31 @@ def replicate(runner, table, name):
     return res
 
 
+def _plan_partitioned(ctx, name, world, *tables):
+    """a plan piece that ends in ldb_gpu_partition: returns (table with the rows grouped by
+    destination rank, rows per destination)"""
+    t = C.c_void_p()
+    counts = (C.c_int64 * world)()
+    check_plan(getattr(capi.host_lib(), name)(ctx.h, *[x.h for x in tables], world, C.byref(t), counts))
+    return Table(ctx, t), [int(c) for c in counts]
+
+
+def shuffle(runner, table, send_counts, name):
+    """the all-to-all of the hash-radix shuffle: `table` holds send_counts[j] rows for
+    rank j, in rank order (ldb_gpu_partition's layout); returns the rows this rank receives from
+    every peer.  One grouped point-to-point exchange per column (each peer pair has its own xGMI
+    link); fixed-width columns only."""
+    cols, widths = table_to_tensors(runner.ctx, table)
+    staged = runner.dist.get_backend() == "gloo"
+    if staged:
+        cols = [c.cpu() for c in cols]
+    out, recv_counts = ldist.alltoall_columns(runner.dist, cols, widths, send_counts)
+    if staged:
+        out = [c.cuda() for c in out]
+    torch.cuda.synchronize()
+    return tensors_to_table(runner.ctx, table, out, sum(int(c) for c in recv_counts), name)
+
+
 def run_query(runner, q):
     ctx, db = runner.ctx, runner.db
     if q == 1:
@@ -159,4 +184,15 @@ def run_query(runner, q):
         if os.environ.get("LDB_DIST_DEBUG"):
             print(f"[rank {runner.dist.get_rank()}] named={named.to_arrow().to_pylist()}\n   gathered={allnamed.to_arrow().to_pylist()}", flush=True)
         return _plan(ctx, "ldb_plan_tpch_q18_final", allnamed)
+    if q == 9:
+        world = runner.world
+        if "supplier_all" not in runner.cache:  # a static dimension table: replicated once
+            runner.cache["supplier_all"] = replicate(runner, db.supplier, "supplier_all")
+        green = replicate(runner, _plan(ctx, "ldb_plan_tpch_q9_green", db.part), "q9_green")
+        lside, lcounts = _plan_partitioned(ctx, "ldb_plan_tpch_q9_lineitem_side", world, green, db.lineitem, db.orders)
+        pside, pcounts = _plan_partitioned(ctx, "ldb_plan_tpch_q9_partsupp_side", world, green, db.partsupp)
+        lrows = shuffle(runner, lside, lcounts, "q9_lrows")  # co-partition both sides on the part key
+        psrows = shuffle(runner, pside, pcounts, "q9_psrows")
+        part = _plan(ctx, "ldb_plan_tpch_q9_join", lrows, psrows, runner.cache["supplier_all"], db.nation)
+        return _plan(ctx, "ldb_plan_tpch_q9_final", replicate(runner, part, "q9_partials"))
     raise ValueError(f"TPC-H Q{q} has no multi-GPU plan yet")

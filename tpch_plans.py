@@ -9,7 +9,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
-LINEITEM, ORDERS, CUSTOMER = 0, 1, 2
+LINEITEM, ORDERS, CUSTOMER, PART, SUPPLIER, PARTSUPP, NATION = 0, 1, 2, 3, 4, 5, 6
 # column ids of include/ldb_tpchgen.h
 L_ORDERKEY, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, L_TAX, L_RETURNFLAG, L_LINESTATUS, L_SHIPDATE = 0, 4, 5, 6, 7, 8, 9, 10
 L_COMMITDATE, L_RECEIPTDATE, L_SHIPMODE = 11, 12, 14
@@ -36,6 +36,8 @@ class Database:
             lcols |= {L_ORDERKEY, L_SHIPDATE, L_COMMITDATE, L_RECEIPTDATE, L_SHIPMODE}
         if 18 in queries:
             lcols |= {L_ORDERKEY, L_QUANTITY}
+        if 9 in queries:
+            lcols |= {L_ORDERKEY, 1, 2, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT}  # + l_partkey, l_suppkey
         lcols |= {L_EXTENDEDPRICE, L_SHIPDATE}  # hbm_ceiling() calibration scans
         self.lineitem = ctx.tpch_generate(LINEITEM, n_orders, rank, world, sorted(lcols), narrow)
         self.orders = self.customer = None
@@ -50,6 +52,13 @@ class Database:
         if 18 in queries:
             ocols |= {O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_TOTALPRICE}
             ccols |= {C_CUSTKEY, C_NAME}
+        self.part = self.supplier = self.partsupp = self.nation = None
+        if 9 in queries:  # (single-GPU plan only so far)
+            ocols |= {O_ORDERKEY, O_ORDERDATE}
+            self.part = ctx.tpch_generate(PART, n_orders, rank, world, [0, 3], narrow)  # p_partkey, p_name
+            self.supplier = ctx.tpch_generate(SUPPLIER, n_orders, rank, world, [0, 1], narrow)  # s_suppkey, s_nationkey
+            self.partsupp = ctx.tpch_generate(PARTSUPP, n_orders, rank, world, [0, 1, 3], narrow)  # ps_partkey, ps_suppkey, ps_supplycost
+            self.nation = ctx.tpch_generate(NATION, n_orders, rank, world, [0, 2], narrow)  # n_nationkey, n_name
         if ocols:
             self.orders = ctx.tpch_generate(ORDERS, n_orders, rank, world, sorted(ocols), narrow)
         if ccols:
@@ -61,6 +70,7 @@ class Runner:
     def __init__(self, ctx, db, world, dist, torch):
         self.ctx, self.db, self.world, self.dist, self.torch = ctx, db, world, dist, torch
         self.last = {}
+        self.cache = {}  # replicated dimension tables (multi-GPU plans)
 
     def run(self, q):
         if self.world > 1:
@@ -79,6 +89,8 @@ class Runner:
             res = self.ctx.plan_q12(self.db.orders, self.db.lineitem)
         elif q == 18:
             res = self.ctx.plan_q18(self.db.customer, self.db.orders, self.db.lineitem)
+        elif q == 9:
+            res = self.ctx.plan_q9(self.db.part, self.db.supplier, self.db.lineitem, self.db.partsupp, self.db.orders, self.db.nation)
         else:
             raise ValueError(f"TPC-H Q{q} has no plan yet")
         self.last[q] = res
