@@ -20,8 +20,8 @@ extern "C" const char* ldb_gpu_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------- memory
 int32_t ldb_dev_alloc(ldb_ctx* ctx, void** out, size_t bytes) {
-   if (bytes == 0) bytes = 16;
-   LDB_HIP(hipMallocAsync(out, bytes, ctx->stream));
+   // 16 bytes of slack behind every buffer: string kernels read through an 8-byte window (d_bytes8)
+   LDB_HIP(hipMallocAsync(out, bytes + 16, ctx->stream));
    return LDB_OK;
 }
 void ldb_dev_free(ldb_ctx* ctx, void* p) {

@@ -206,7 +206,31 @@ __device__ __forceinline__ uint32_t d_utf8_len(const uint8_t* p, uint32_t left) 
    while (k < left && (p[k] >> 6) == 2) k++;
    return k;
 }
-__device__ inline bool d_like(const uint8_t* s, uint32_t sl, const uint8_t* p, uint32_t pl) {
+// Bytes of one string through an 8-byte window: a matcher that walks the string byte by byte then
+// issues one (unaligned) 8-byte global load per 8 bytes instead of 8 dependent byte loads — the
+// LIKE scan over 20 M part names was latency-bound on those (5.3 ms).  The window may read up to
+// 7 bytes past the string: every device buffer carries that slack (ldb_dev_alloc).
+struct d_bytes8 {
+   const uint8_t* b;
+   uint32_t wbase = 0xFFFFFFFFu;
+   uint64_t w = 0;
+   __device__ __forceinline__ explicit d_bytes8(const uint8_t* base) : b(base) {}
+   __device__ __forceinline__ uint8_t operator[](uint32_t k) {
+      if ((k & ~7u) != wbase) {
+         wbase = k & ~7u;
+         typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+         w = *(const LDB_GLOBAL u64_unaligned*) (b + wbase);
+      }
+      return (uint8_t) (w >> (8 * (k & 7u)));
+   }
+};
+__device__ __forceinline__ uint32_t d_utf8_len_at(d_bytes8& s, uint32_t at, uint32_t sl) {
+   uint32_t k = 1;
+   while (at + k < sl && (s[at + k] >> 6) == 2) k++;
+   return k;
+}
+__device__ inline bool d_like(const uint8_t* sptr, uint32_t sl, const uint8_t* p, uint32_t pl) {
+   d_bytes8 s(sptr);
    uint32_t si = 0, pi = 0, star_p = 0, star_s = 0;
    bool have_star = false;
    for (;;) {
@@ -218,7 +242,7 @@ __device__ inline bool d_like(const uint8_t* s, uint32_t sl, const uint8_t* p, u
             while (pi < pl && (p[pi] == '%' || p[pi] == '_')) {
                if (p[pi] == '_') {
                   if (si >= sl) return false;
-                  si += d_utf8_len(s + si, sl - si);
+                  si += d_utf8_len_at(s, si, sl);
                }
                pi++;
             }
@@ -236,11 +260,11 @@ __device__ inline bool d_like(const uint8_t* s, uint32_t sl, const uint8_t* p, u
             if (q >= pl || p[q] != s[si]) {
                mismatch = true;
             } else {
-               si += d_utf8_len(s + si, sl - si);
+               si += d_utf8_len_at(s, si, sl);
                pi = q + d_utf8_len(p + q, pl - q);
             }
          } else if (pc == '_' || pc == s[si]) {
-            si += d_utf8_len(s + si, sl - si);
+            si += d_utf8_len_at(s, si, sl);
             pi += d_utf8_len(p + pi, pl - pi);
          } else {
             mismatch = true;
@@ -253,7 +277,7 @@ __device__ inline bool d_like(const uint8_t* s, uint32_t sl, const uint8_t* p, u
       }
       if (mismatch) {
          if (!have_star) return false;
-         star_s += d_utf8_len(s + star_s, sl - star_s);
+         star_s += d_utf8_len_at(s, star_s, sl);
          if (star_s >= sl) return false;
          si = star_s;
          pi = star_p;

@@ -34,6 +34,7 @@ struct ldb_hashtable {
    int32_t ordered_slots = 0; // KEY32: slots follow the key order (DJoin::ordered_slots)
    int64_t kmin = 0, kmax = -1;
    uint64_t kmult = 0;
+   uint32_t* key_bits = nullptr; // one bit per key value of [kmin, kmax] (DJoin::has_key_bits), or NULL
 };
 
 // ---------------------------------------------------------------- ahead-of-time (generic) kernels
@@ -70,6 +71,7 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
       meta->counter = meta->bitmap = meta->mark = meta->match = meta->flags = 0;
       meta->kmin = meta->kmax = 0;
       meta->kmult = 0;
+      meta->key_bits = 0;
       ldb_jit_strip_keys(meta->bkeys);
       ldb_jit_strip_keys(meta->pkeys);
       for (int p = 0; p < LDB_MAX_PREDS; p++) ldb_jit_strip_pred(meta->ppreds[p]);
@@ -177,6 +179,13 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
          ht->kmin = got[0];
          ht->kmax = got[1];
          ht->kmult = (uint64_t) ((((unsigned __int128) ht->cap) << 32) / ((unsigned __int128) (got[1] - got[0]) + 1));
+         // one bit per key value when that fits the L2 comfortably (DJoin::has_key_bits)
+         const unsigned __int128 range = (unsigned __int128) ((__int128) got[1] - got[0]) + 1;
+         if (range <= ((unsigned __int128) 1 << 27)) { // <= 16 MB of bits
+            const size_t words = (size_t) ((range + 31) / 32);
+            LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->key_bits, 4 * words));
+            LDB_HIP(hipMemsetAsync(ht->key_bits, 0, 4 * words, ctx->stream));
+         }
       }
    }
    for (int attempt = 0; attempt < 2; attempt++) {
@@ -184,6 +193,8 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
       h->kmin = ht->kmin;
       h->kmax = ht->kmax;
       h->kmult = ht->kmult;
+      h->key_bits = (uint64_t) ht->key_bits;
+      h->has_key_bits = ht->key_bits ? 1 : 0;
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
       if (build->n_rows) LDB_TRY(launch_join(ctx, h, d, ldb_grid_for(ctx, build->n_rows, 256, 8), "k_join_build", "k_join_build_spec", k_join_build));
@@ -192,6 +203,8 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
       LDB_TRY(ldb_read_u64(ctx, dflags, &f));
       if ((f & 2) && ht->ordered_slots) { // long probe runs: this key distribution needs hashed slots
          ht->ordered_slots = 0;
+         ldb_dev_free(ctx, ht->key_bits);
+         ht->key_bits = nullptr;
          LDB_HIP(hipMemsetAsync(ht->slots, 0, 8 * (size_t) ht->cap, ctx->stream));
          LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
          continue;
@@ -206,6 +219,7 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
 extern "C" int32_t ldb_gpu_hashtable_release(ldb_ctx* ctx, ldb_hashtable* ht) {
    if (!ht) return LDB_OK;
    ldb_dev_free(ctx, ht->slots);
+   ldb_dev_free(ctx, ht->key_bits);
    delete ht;
    return LDB_OK;
 }
@@ -235,6 +249,8 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    h->kmin = ht->kmin;
    h->kmax = ht->kmax;
    h->kmult = ht->kmult;
+   h->key_bits = (uint64_t) ht->key_bits;
+   h->has_key_bits = ht->key_bits ? 1 : 0;
    // a lazy probe relation brings its filter along: evaluated inside the probe kernel
    h->n_ppreds = (int32_t) probe->pending.size();
    for (size_t p = 0; p < probe->pending.size(); p++) h->ppreds[p] = probe->pending[p];

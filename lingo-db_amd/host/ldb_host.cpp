@@ -607,14 +607,16 @@ extern "C" int32_t ldb_plan_tpch_q9(ldb_ctx* ctx, const ldb_table* part, const l
       ldb_colref sk{0, colOf(supp, "s_suppkey")};
       check(ldb_gpu_join_build(ctx, s0.r, &sk, 1, 1, &hs.h), "q9 build supplier");
       check(ldb_gpu_join_probe(ctx, hs.h, lps.r, &lsk, 1, LDB_JOIN_INNER, &lpss.r, nullptr), "q9 probe supplier"); // lineitem, partsupp, supplier
-      ldb_colref nk{0, colOf(nat, "n_nationkey")}, snk{2, colOf(supp, "s_nationkey")};
-      check(ldb_gpu_join_build(ctx, n0.r, &nk, 1, 1, &hn.h), "q9 build nation");
-      check(ldb_gpu_join_probe(ctx, hn.h, lpss.r, &snk, 1, LDB_JOIN_INNER, &all.r, nullptr), "q9 probe nation"); // lineitem, partsupp, supplier, nation
+      // The nation join is deferred (eager aggregation): the 32 M joined rows are first summed per
+      // (s_nationkey, o_year) — integer keys — and only the ≤ 175 partial rows meet nation; the
+      // final GROUP BY (n_name, o_year) re-aggregates them, so the result is the query's even if two
+      // nations shared a name.  Grouping 32 M rows on a string reached through three row-id
+      // indirections cost 6.9 ms, this 0.5 ms.
       // narrow to the columns still needed, then orders: the reduced side is the hash table
       ldb_colref keep[6] = {{0, colOf(li, "l_orderkey")}, {0, colOf(li, "l_extendedprice")}, {0, colOf(li, "l_discount")}, {0, colOf(li, "l_quantity")},
-                            {1, colOf(ps, "ps_supplycost")}, {3, colOf(nat, "n_name")}};
-      Table m(ctx), years(ctx), grouped(ctx);
-      check(ldb_gpu_materialize(ctx, all.r, keep, 6, &m.t), "q9 materialize");
+                            {1, colOf(ps, "ps_supplycost")}, {2, colOf(supp, "s_nationkey")}};
+      Table m(ctx), years(ctx), partial(ctx), grouped(ctx);
+      check(ldb_gpu_materialize(ctx, lpss.r, keep, 6, &m.t), "q9 materialize");
       check(ldb_gpu_rel_from_table(ctx, m.t, &m0.r), "q9 rel");
       ldb_colref mok{0, 0}, ook{0, colOf(ord, "o_orderkey")};
       check(ldb_gpu_join_build(ctx, m0.r, &mok, 1, 0, &hm.h), "q9 build reduced lineitem");
@@ -639,7 +641,16 @@ extern "C" int32_t ldb_plan_tpch_q9(ldb_ctx* ctx, const ldb_table* part, const l
       amount.t[1].f[1] = colFactor(qty);
       ldb_agg_spec agg = sumDec(amount, tAmount);
       ldb_colref keys[2] = {{1, 5}, {2, 0}};
-      check(ldb_gpu_groupby(ctx, omy.r, nullptr, 0, keys, 2, &agg, 1, 25 * 8, &grouped.t), "q9 groupby");
+      check(ldb_gpu_groupby(ctx, omy.r, nullptr, 0, keys, 2, &agg, 1, 25 * 8, &partial.t), "q9 groupby nationkey, year");
+      // partial (s_nationkey, o_year, sum) ⋈ nation → GROUP BY (n_name, o_year)
+      check(ldb_gpu_rel_from_table(ctx, partial.t, &all.r), "q9 rel");
+      ldb_colref nk{0, colOf(nat, "n_nationkey")}, pnk{0, 0};
+      Rel pn(ctx);
+      check(ldb_gpu_join_build(ctx, n0.r, &nk, 1, 1, &hn.h), "q9 build nation");
+      check(ldb_gpu_join_probe(ctx, hn.h, all.r, &pnk, 1, LDB_JOIN_INNER, &pn.r, nullptr), "q9 probe nation"); // sides: partial, nation
+      ldb_agg_spec resum = sumDec(product({colFactor({0, 2})}), tAmount);
+      ldb_colref keys2[2] = {{1, colOf(nat, "n_name")}, {0, 1}};
+      check(ldb_gpu_groupby(ctx, pn.r, nullptr, 0, keys2, 2, &resum, 1, 25 * 8, &grouped.t), "q9 groupby");
       check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q9 rel");
       ldb_sort_spec specs[2] = {{{0, 0}, 0, 0}, {{0, 1}, 1, 0}};
       check(ldb_gpu_sort(ctx, g.r, specs, 2, &sorted.r), "q9 sort");
@@ -949,9 +960,7 @@ extern "C" int32_t ldb_plan_tpch_q9_join(ldb_ctx* ctx, const ldb_table* lrows, c
       ldb_colref sk{0, colOf(supp, "s_suppkey")};
       check(ldb_gpu_join_build(ctx, s0.r, &sk, 1, 1, &hs.h), "q9 build supplier");
       check(ldb_gpu_join_probe(ctx, hs.h, lps.r, &lsk, 1, LDB_JOIN_INNER, &lpss.r, nullptr), "q9 probe supplier"); // lrows, psrows, supplier
-      ldb_colref nk{0, colOf(nat, "n_nationkey")}, snk{2, colOf(supp, "s_nationkey")};
-      check(ldb_gpu_join_build(ctx, n0.r, &nk, 1, 1, &hn.h), "q9 build nation");
-      check(ldb_gpu_join_probe(ctx, hn.h, lpss.r, &snk, 1, LDB_JOIN_INNER, &all.r, nullptr), "q9 probe nation"); // lrows, psrows, supplier, nation
+      (void) nat; // nation is joined after the merge (eager aggregation on the integer key, see ldb_plan_tpch_q9)
       ldb_colref ext{0, 3}, disc{0, 4}, qty{0, 5}, cost{1, 2};
       DecimalType te = decOf(lrows, 3), td = decOf(lrows, 4), tq = decOf(lrows, 5), tc = decOf(psrows, 2), t1md;
       ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, td, &t1md);
@@ -967,19 +976,25 @@ extern "C" int32_t ldb_plan_tpch_q9_join(ldb_ctx* ctx, const ldb_table* lrows, c
       amount.t[1].f[0] = colFactor(cost);
       amount.t[1].f[1] = colFactor(qty);
       ldb_agg_spec agg = sumDec(amount, tAmount);
-      ldb_colref keys[2] = {{3, colOf(nat, "n_name")}, {0, 2}};
-      check(ldb_gpu_groupby(ctx, all.r, nullptr, 0, keys, 2, &agg, 1, 25 * 8, result), "q9 partial groupby");
+      ldb_colref keys[2] = {{2, colOf(supp, "s_nationkey")}, {0, 2}};
+      check(ldb_gpu_groupby(ctx, lpss.r, nullptr, 0, keys, 2, &agg, 1, 25 * 8, result), "q9 partial groupby");
    });
 }
-// Step 4 (replicated): add up the gathered partial sums and order the result.
-extern "C" int32_t ldb_plan_tpch_q9_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result) {
+// Step 4 (replicated): the gathered partial sums (s_nationkey, o_year, sum) ⋈ nation, added up per
+// (n_name, o_year), ordered.
+extern "C" int32_t ldb_plan_tpch_q9_final(ldb_ctx* ctx, const ldb_table* partials, const ldb_table* nat, ldb_table** result) {
    return guarded([&] {
-      Rel in(ctx), g(ctx), sorted(ctx);
+      Rel in(ctx), n0(ctx), pn(ctx), g(ctx), sorted(ctx);
       check(ldb_gpu_rel_from_table(ctx, partials, &in.r), "q9 final");
-      ldb_colref keys[2] = {{0, 0}, {0, 1}};
+      check(ldb_gpu_rel_from_table(ctx, nat, &n0.r), "q9 final nation");
+      Ht hn(ctx);
+      ldb_colref nk{0, colOf(nat, "n_nationkey")}, pnk{0, 0};
+      check(ldb_gpu_join_build(ctx, n0.r, &nk, 1, 1, &hn.h), "q9 build nation");
+      check(ldb_gpu_join_probe(ctx, hn.h, in.r, &pnk, 1, LDB_JOIN_INNER, &pn.r, nullptr), "q9 probe nation"); // sides: partials, nation
+      ldb_colref keys[2] = {{1, colOf(nat, "n_name")}, {0, 1}};
       ldb_agg_spec agg = sumDec(product({colFactor({0, 2})}), decOf(partials, 2));
       Table grouped(ctx);
-      check(ldb_gpu_groupby(ctx, in.r, nullptr, 0, keys, 2, &agg, 1, 25 * 8, &grouped.t), "q9 final groupby");
+      check(ldb_gpu_groupby(ctx, pn.r, nullptr, 0, keys, 2, &agg, 1, 25 * 8, &grouped.t), "q9 final groupby");
       check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q9 final rel");
       ldb_sort_spec specs[2] = {{{0, 0}, 0, 0}, {{0, 1}, 1, 0}};
       check(ldb_gpu_sort(ctx, g.r, specs, 2, &sorted.r), "q9 final sort");

@@ -98,7 +98,7 @@ int32_t ldb_plan_tpch_q9_lineitem_side(ldb_ctx* ctx, const ldb_table* greenkeys,
                                        int64_t* counts);
 int32_t ldb_plan_tpch_q9_partsupp_side(ldb_ctx* ctx, const ldb_table* greenkeys, const ldb_table* partsupp, int32_t world, ldb_table** result, int64_t* counts);
 int32_t ldb_plan_tpch_q9_join(ldb_ctx* ctx, const ldb_table* lrows, const ldb_table* psrows, const ldb_table* supplier, const ldb_table* nation, ldb_table** result);
-int32_t ldb_plan_tpch_q9_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
+int32_t ldb_plan_tpch_q9_final(ldb_ctx* ctx, const ldb_table* partials, const ldb_table* nation, ldb_table** result);
 // test hooks for the host logic (date / decimal parsing, decimal typing rules)
 int32_t ldb_host_parse_date32(const char* s, int32_t* out);
 int32_t ldb_host_parse_decimal(const char* s, int32_t scale, int64_t* lo, int64_t* hi);

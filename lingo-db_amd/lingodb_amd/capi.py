@@ -213,7 +213,7 @@ HOST_API = {
     "ldb_plan_tpch_q9_lineitem_side": (i32, [P, P, P, P, i32, PP, C.POINTER(i64)]),
     "ldb_plan_tpch_q9_partsupp_side": (i32, [P, P, P, i32, PP, C.POINTER(i64)]),
     "ldb_plan_tpch_q9_join": (i32, [P, P, P, P, P, PP]),
-    "ldb_plan_tpch_q9_final": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q9_final": (i32, [P, P, P, PP]),
     "ldb_host_parse_date32": (i32, [C.c_char_p, C.POINTER(i32)]),
     "ldb_host_parse_decimal": (i32, [C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64)]),
     "ldb_host_decimal_type": (None, [i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),

@@ -202,6 +202,32 @@ def test_like_filters_match_oracle(ctx, oracle):
         assert g.scan_count([api.pred((0, 0), capi.F_NOT_LIKE, pat)]) == len(oracle.scan_filter(h, [api.pred((0, 0), capi.F_NOT_LIKE, pat)])), pat
 
 
+def test_map_column_extract_year_and_zip(ctx, oracle):
+    """extract(year from date) as a computed column: device values = oracle's restatement of
+    DateRuntime::extractYear (itself pinned against the reference), NULL in → NULL out, through
+    row ids of a filtered relation, usable as a group key after rel_zip"""
+    rng = np.random.default_rng(12)
+    n = 50000
+    days = rng.integers(-30000, 60000, n)
+    dates = [None if i % 17 == 0 else datetime.date(1970, 1, 1) + datetime.timedelta(days=int(d)) for i, d in enumerate(days)]
+    t = pa.table({"d": pa.array(dates, pa.date32()), "v": pa.array(rng.integers(0, 100, n), pa.int64())})
+    g = ctx.register("dates", t).rel()
+    want = [None if dt is None else oracle.extract_year(int(d)) for dt, d in zip(dates, days)]
+    assert want[1] == dates[1].year
+    assert g.map_column((0, 0)).to_arrow().column(0).to_pylist() == want
+    sel = g.scan_filter([api.pred((0, 1), capi.F_LT, 50)])
+    ids = sel.rowids(0)
+    years = sel.map_column((0, 0))
+    assert years.to_arrow().column(0).to_pylist() == [want[i] for i in ids]
+    zipped = sel.zip(years)
+    assert zipped.sides == 2 and zipped.rows == len(ids)
+    got = {r[0]: r[1] for r in rows_of(zipped.groupby([(1, 0)], [api.agg(capi.AGG_SUM, api.col_expr((0, 1)))]).to_arrow())}
+    exp = {}
+    for i in ids:
+        exp[want[i]] = exp.get(want[i], 0) + int(t.column(1)[int(i)].as_py())
+    assert got == exp
+
+
 # ---------------------------------------------------------------- group-by (a9, a10, a11, a14, a16)
 def q1_aggs():
     f = api.factor

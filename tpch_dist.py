@@ -194,5 +194,5 @@ def run_query(runner, q):
         lrows = shuffle(runner, lside, lcounts, "q9_lrows")  # co-partition both sides on the part key
         psrows = shuffle(runner, pside, pcounts, "q9_psrows")
         part = _plan(ctx, "ldb_plan_tpch_q9_join", lrows, psrows, runner.cache["supplier_all"], db.nation)
-        return _plan(ctx, "ldb_plan_tpch_q9_final", replicate(runner, part, "q9_partials"))
+        return _plan(ctx, "ldb_plan_tpch_q9_final", replicate(runner, part, "q9_partials"), db.nation)
     raise ValueError(f"TPC-H Q{q} has no multi-GPU plan yet")
