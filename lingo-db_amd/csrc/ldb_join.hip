@@ -35,6 +35,8 @@ struct ldb_hashtable {
    int64_t kmin = 0, kmax = -1;
    uint64_t kmult = 0;
    uint32_t* key_bits = nullptr; // one bit per key value of [kmin, kmax] (DJoin::has_key_bits), or NULL
+   int32_t chained = 0; // one slot per distinct key, rows linked through next[] (DJoin::chained)
+   uint32_t* next = nullptr;
 };
 
 // ---------------------------------------------------------------- ahead-of-time (generic) kernels
@@ -72,6 +74,7 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
       meta->kmin = meta->kmax = 0;
       meta->kmult = 0;
       meta->key_bits = 0;
+      meta->next = 0;
       ldb_jit_strip_keys(meta->bkeys);
       ldb_jit_strip_keys(meta->pkeys);
       for (int p = 0; p < LDB_MAX_PREDS; p++) ldb_jit_strip_pred(meta->ppreds[p]);
@@ -188,29 +191,46 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
          }
       }
    }
-   for (int attempt = 0; attempt < 2; attempt++) {
+   // up to three passes: ordered slots → hashed slots (skewed key range) → chained (a key repeats so
+   // often that one slot per row gives long runs); each pass stops early when it sees such a run
+   static const bool force_chained = getenv("LDB_JOIN_CHAINED") && getenv("LDB_JOIN_CHAINED")[0] == '1'; // tests
+   if (force_chained) {
+      ht->ordered_slots = 0;
+      ldb_dev_free(ctx, ht->key_bits);
+      ht->key_bits = nullptr;
+      ht->chained = 1;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) (build->n_rows ? build->n_rows : 1)));
+   }
+   for (int attempt = 0; attempt < 3; attempt++) {
       h->ordered_slots = ht->ordered_slots;
       h->kmin = ht->kmin;
       h->kmax = ht->kmax;
       h->kmult = ht->kmult;
       h->key_bits = (uint64_t) ht->key_bits;
       h->has_key_bits = ht->key_bits ? 1 : 0;
+      h->chained = ht->chained;
+      h->next = (uint64_t) ht->next;
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
       if (build->n_rows) LDB_TRY(launch_join(ctx, h, d, ldb_grid_for(ctx, build->n_rows, 256, 8), "k_join_build", "k_join_build_spec", k_join_build));
       ldb_dev_free(ctx, d);
       uint64_t f = 0;
       LDB_TRY(ldb_read_u64(ctx, dflags, &f));
-      if ((f & 2) && ht->ordered_slots) { // long probe runs: this key distribution needs hashed slots
-         ht->ordered_slots = 0;
-         ldb_dev_free(ctx, ht->key_bits);
-         ht->key_bits = nullptr;
+      if ((f & 2) && !ht->chained) {
+         if (ht->ordered_slots) { // this key distribution needs hashed slots
+            ht->ordered_slots = 0;
+            ldb_dev_free(ctx, ht->key_bits);
+            ht->key_bits = nullptr;
+         } else { // hashed and still long runs: duplicates → chain them
+            ht->chained = 1;
+            LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) build->n_rows));
+         }
          LDB_HIP(hipMemsetAsync(ht->slots, 0, 8 * (size_t) ht->cap, ctx->stream));
          LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
          continue;
       }
       // the caller's promise of unique keys is verified: duplicates fall back to the general probe
-      if (f & 1) ht->unique = 0;
+      if ((f & 1) || ht->chained) ht->unique = 0;
       break;
    }
    *out = ht.release();
@@ -220,6 +240,7 @@ extern "C" int32_t ldb_gpu_hashtable_release(ldb_ctx* ctx, ldb_hashtable* ht) {
    if (!ht) return LDB_OK;
    ldb_dev_free(ctx, ht->slots);
    ldb_dev_free(ctx, ht->key_bits);
+   ldb_dev_free(ctx, ht->next);
    delete ht;
    return LDB_OK;
 }
@@ -251,6 +272,8 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    h->kmult = ht->kmult;
    h->key_bits = (uint64_t) ht->key_bits;
    h->has_key_bits = ht->key_bits ? 1 : 0;
+   h->chained = ht->chained;
+   h->next = (uint64_t) ht->next;
    // a lazy probe relation brings its filter along: evaluated inside the probe kernel
    h->n_ppreds = (int32_t) probe->pending.size();
    for (size_t p = 0; p < probe->pending.size(); p++) h->ppreds[p] = probe->pending[p];

@@ -23,6 +23,7 @@ struct DJoin {
    int64_t kmin, kmax; // KEY32 + ordered slots: range of the build keys
    uint64_t kmult; // slot = ((key - kmin) * kmult) >> 32
    uint64_t key_bits; // uint32_t*: has_key_bits: bit (key - kmin) set ⇔ key is in the table
+   uint64_t next; // uint32_t*: chained: next[row] = following row of the same key + 1 (0 = end)
    // ---- metadata
    int32_t key32;
    int32_t kind;
@@ -43,6 +44,12 @@ struct DJoin {
    // part keys over a 20 M range: 2.5 MB, L2-resident, against a 32 MB slot array), so a selective
    // probe of unclustered keys (600 M random l_partkey values, 5.4 % hits) mostly never leaves L2.
    int32_t has_key_bits;
+   // Duplicate-heavy build keys: the default layout spends one slot per build ROW, so a key that
+   // repeats d times costs O(d^2) slot visits to insert and O(d) extra per probe miss in its run.
+   // When a build pass reports such runs the table is rebuilt CHAINED: one slot per distinct key,
+   // the key's rows linked through next[] — the reference's layout (chained HashIndexedView).
+   int32_t chained;
+   int32_t pad3;
    DPred ppreds[LDB_MAX_PREDS];
 };
 
@@ -86,6 +93,31 @@ __device__ __forceinline__ void join_build_body(const DJoin& m, const DJoin* __r
          atomicOr(gptr_mut<uint32_t>(d->key_bits) + (r >> 5), 1u << (r & 31));
       }
       uint32_t steps = 0;
+      if (m.chained) {
+         // one slot per DISTINCT key; the rows of a key hang off it through next[] (push-front with a
+         // CAS on the slot word, like the reference's HashIndexedView::build, LazyJoinHashtable.cpp:12-34).
+         // Insertion cost no longer depends on how often a key repeats.
+         uint32_t* next = gptr_mut<uint32_t>(d->next);
+         for (;;) {
+            unsigned long long w = __hip_atomic_load(&slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (w == 0) {
+               next[i] = 0;
+               w = atomicCAS(&slots[pos], 0ull, (unsigned long long) word);
+               if (w == 0) break;
+            }
+            if ((w >> 32) == (word >> 32) && (m.key32 || d_keys_equal(bkeys, (uint64_t) ((uint32_t) w - 1u), bkeys, i, false))) {
+               for (;;) { // same key: become the new head
+                  next[i] = (uint32_t) w;
+                  const unsigned long long old = atomicCAS(&slots[pos], w, (unsigned long long) word);
+                  if (old == w) break;
+                  w = old; // another row of this key got in first (the key part of the word is unchanged)
+               }
+               break;
+            }
+            pos = (pos + 1) & mask;
+         }
+         continue;
+      }
       for (;;) {
          unsigned long long old = atomicCAS(&slots[pos], 0ull, (unsigned long long) word);
          if (old == 0) break;
@@ -98,7 +130,10 @@ __device__ __forceinline__ void join_build_body(const DJoin& m, const DJoin* __r
             if ((__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) == 0) atomicOr(f, 1u);
          }
          pos = (pos + 1) & mask;
-         if (++steps == JOIN_LONG_RUN && m.ordered_slots) { // skewed keys: give up at once (runs cost O(length^2)), the host rebuilds hashed
+         // a long run: skewed keys under ordered slots, or a key that repeats very often (one slot
+         // per ROW makes runs cost O(length^2)).  Give up at once; the host rebuilds — hashed first,
+         // then chained.
+         if (++steps == JOIN_LONG_RUN && m.has_flags) {
             atomicOr(gptr_mut<uint32_t>(d->flags), 2u);
             break;
          }
@@ -130,6 +165,18 @@ __device__ __forceinline__ void join_key_range_body(const DJoin& m, const DJoin*
    }
 }
 
+// chained tables: the rows of one key, head first (next[row] = following row + 1, 0 = end)
+template <typename EMIT>
+__device__ __forceinline__ uint32_t d_probe_chain(const DJoin* __restrict__ d, uint32_t head_plus1, EMIT emit) {
+   const uint32_t* next = gptr<uint32_t>(d->next);
+   uint32_t matches = 0;
+   for (uint32_t r = head_plus1; r != 0; r = next[r - 1u]) {
+      matches++;
+      if (!emit(r - 1u)) break;
+   }
+   return matches;
+}
+
 // One probe row → visits its slot run.  EMIT is called for every match with the build row and
 // returns whether to keep scanning.
 template <typename EMIT>
@@ -159,6 +206,7 @@ __device__ __forceinline__ uint32_t d_probe_row(const DJoin& m, const DJoin* __r
          uint64_t w = slots[pos];
          if (w == 0) break;
          if ((uint32_t) (w >> 32) == key) {
+            if (m.chained) return d_probe_chain(d, (uint32_t) w, emit); // the key's only slot: its rows are the chain
             matches++;
             if (!emit((uint32_t) w - 1u)) break;
          }
@@ -170,6 +218,7 @@ __device__ __forceinline__ uint32_t d_probe_row(const DJoin& m, const DJoin* __r
          uint64_t w = slots[pos];
          if (w == 0) break;
          if ((w >> 32) == (h >> 32) && d_keys_equal(bkeys, (uint64_t) ((uint32_t) w - 1u), pkeys, i, false)) {
+            if (m.chained) return d_probe_chain(d, (uint32_t) w, emit);
             matches++;
             if (!emit((uint32_t) w - 1u)) break;
          }

@@ -1003,6 +1003,97 @@ extern "C" int32_t ldb_plan_tpch_q9_final(ldb_ctx* ctx, const ldb_table* partial
    });
 }
 
+// ---------------------------------------------------------------- TPC-H Q5 (resources/sql/tpch/5.sql)
+// Revenue per nation of one region from orders of one year where customer and supplier are of the
+// same nation.  The plan is built from four pieces so that the multi-GPU run can exchange the two
+// small reduced dimension tables between them (customers are sharded by rows, orders by ranges):
+//   q5_customers / q5_suppliers: rows of the region's nations → (key, nationkey)
+//   q5_local: orders of the year ⋈ those customers ⋈ lineitem ⋈ those suppliers on
+//             (l_suppkey, c_nationkey) = (s_suppkey, s_nationkey) → SUM per nationkey
+//   q5_final: (gathered) partial sums ⋈ nation → GROUP BY n_name, ORDER BY revenue DESC
+namespace {
+// rows of `t` whose `nationCol` is a nation of region 'ASIA', as a table (keyCol, nationCol)
+void regionMembers(ldb_ctx* ctx, const ldb_table* t, const char* keyCol, const char* nationCol, const ldb_table* nat, const ldb_table* reg, ldb_table** result) {
+   Rel r0(ctx), r1(ctx), n0(ctx), n1(ctx), t0(ctx), t1(ctx);
+   check(ldb_gpu_rel_from_table(ctx, reg, &r0.r), "q5 region");
+   check(ldb_gpu_rel_from_table(ctx, nat, &n0.r), "q5 nation");
+   check(ldb_gpu_rel_from_table(ctx, t, &t0.r), "q5 dimension");
+   auto rr = Restrictions::create({{"r_name", FilterOp::EQ, std::string("ASIA"), {}}}, reg);
+   check(ldb_gpu_scan_filter(ctx, r0.r, rr->data(), rr->size(), &r1.r), "q5 filter region");
+   Ht hr(ctx), hn(ctx);
+   ldb_colref rk{0, colOf(reg, "r_regionkey")}, nrk{0, colOf(nat, "n_regionkey")}, nk{0, colOf(nat, "n_nationkey")}, tn{0, colOf(t, nationCol)};
+   check(ldb_gpu_join_build(ctx, r1.r, &rk, 1, 1, &hr.h), "q5 build region");
+   check(ldb_gpu_join_probe(ctx, hr.h, n0.r, &nrk, 1, LDB_JOIN_SEMI, &n1.r, nullptr), "q5 nations of the region");
+   check(ldb_gpu_join_build(ctx, n1.r, &nk, 1, 1, &hn.h), "q5 build nations");
+   check(ldb_gpu_join_probe(ctx, hn.h, t0.r, &tn, 1, LDB_JOIN_SEMI, &t1.r, nullptr), "q5 rows of those nations");
+   ldb_colref outc[2] = {{0, colOf(t, keyCol)}, tn};
+   check(ldb_gpu_materialize(ctx, t1.r, outc, 2, result), "q5 materialize");
+}
+} // namespace
+extern "C" int32_t ldb_plan_tpch_q5_customers(ldb_ctx* ctx, const ldb_table* cust, const ldb_table* nat, const ldb_table* reg, ldb_table** result) {
+   return guarded([&] { regionMembers(ctx, cust, "c_custkey", "c_nationkey", nat, reg, result); });
+}
+extern "C" int32_t ldb_plan_tpch_q5_suppliers(ldb_ctx* ctx, const ldb_table* supp, const ldb_table* nat, const ldb_table* reg, ldb_table** result) {
+   return guarded([&] { regionMembers(ctx, supp, "s_suppkey", "s_nationkey", nat, reg, result); });
+}
+extern "C" int32_t ldb_plan_tpch_q5_local(ldb_ctx* ctx, const ldb_table* custs, const ldb_table* supps, const ldb_table* ord, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel c0(ctx), s0(ctx), o0(ctx), o1(ctx), l0(ctx), oc(ctx), loc(ctx), locs(ctx);
+      check(ldb_gpu_rel_from_table(ctx, custs, &c0.r), "q5 customers");
+      check(ldb_gpu_rel_from_table(ctx, supps, &s0.r), "q5 suppliers");
+      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q5 orders");
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q5 lineitem");
+      auto ro = Restrictions::create({{"o_orderdate", FilterOp::GTE, std::string("1994-01-01"), {}}, {"o_orderdate", FilterOp::LT, std::string("1995-01-01"), {}}}, ord);
+      check(ldb_gpu_scan_filter(ctx, o0.r, ro->data(), ro->size(), &o1.r), "q5 filter orders");
+      Ht hc(ctx), ho(ctx), hs(ctx);
+      ldb_colref ck{0, 0}, ock{0, colOf(ord, "o_custkey")}, ook{0, colOf(ord, "o_orderkey")}, lok{0, colOf(li, "l_orderkey")};
+      check(ldb_gpu_join_build(ctx, c0.r, &ck, 1, 1, &hc.h), "q5 build customers");
+      check(ldb_gpu_join_probe(ctx, hc.h, o1.r, &ock, 1, LDB_JOIN_INNER, &oc.r, nullptr), "q5 probe orders"); // sides: orders, customers
+      check(ldb_gpu_join_build(ctx, oc.r, &ook, 1, 1, &ho.h), "q5 build orders");
+      check(ldb_gpu_join_probe(ctx, ho.h, l0.r, &lok, 1, LDB_JOIN_INNER, &loc.r, nullptr), "q5 probe lineitem"); // sides: lineitem, orders, customers
+      // supplier of the lineitem must be of the customer's nation: two-column key
+      ldb_colref sk2[2] = {{0, 0}, {0, 1}}, lk2[2] = {{0, colOf(li, "l_suppkey")}, {2, 1}};
+      check(ldb_gpu_join_build(ctx, s0.r, sk2, 2, 1, &hs.h), "q5 build suppliers");
+      check(ldb_gpu_join_probe(ctx, hs.h, loc.r, lk2, 2, LDB_JOIN_SEMI, &locs.r, nullptr), "q5 semi join suppliers"); // (s_suppkey is a key: at most one partner)
+      ldb_colref ext{0, colOf(li, "l_extendedprice")}, disc{0, colOf(li, "l_discount")};
+      DecimalType t1md;
+      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, decOf(li, disc.col), &t1md);
+      DecimalType tRev = typeAfterMul(decOf(li, ext.col), t1md);
+      ldb_agg_spec agg = sumDec(product({colFactor(ext), oneMinusDisc}), tRev);
+      ldb_colref key{2, 1}; // c_nationkey (= s_nationkey)
+      check(ldb_gpu_groupby(ctx, locs.r, nullptr, 0, &key, 1, &agg, 1, 25, result), "q5 partial groupby");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q5_final(ldb_ctx* ctx, const ldb_table* partials, const ldb_table* nat, ldb_table** result) {
+   return guarded([&] {
+      Rel in(ctx), n0(ctx), pn(ctx), g(ctx), sorted(ctx);
+      check(ldb_gpu_rel_from_table(ctx, partials, &in.r), "q5 final");
+      check(ldb_gpu_rel_from_table(ctx, nat, &n0.r), "q5 final nation");
+      Ht hn(ctx);
+      ldb_colref nk{0, colOf(nat, "n_nationkey")}, pnk{0, 0};
+      check(ldb_gpu_join_build(ctx, n0.r, &nk, 1, 1, &hn.h), "q5 build nation");
+      check(ldb_gpu_join_probe(ctx, hn.h, in.r, &pnk, 1, LDB_JOIN_INNER, &pn.r, nullptr), "q5 probe nation"); // sides: partials, nation
+      ldb_colref key{1, colOf(nat, "n_name")};
+      ldb_agg_spec agg = sumDec(product({colFactor({0, 1})}), decOf(partials, 1));
+      Table grouped(ctx);
+      check(ldb_gpu_groupby(ctx, pn.r, nullptr, 0, &key, 1, &agg, 1, 25, &grouped.t), "q5 final groupby");
+      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q5 final rel");
+      ldb_sort_spec spec{{0, 1}, 1, 0};
+      check(ldb_gpu_sort(ctx, g.r, &spec, 1, &sorted.r), "q5 final sort");
+      ldb_colref outc[2] = {{0, 0}, {0, 1}};
+      check(ldb_gpu_materialize(ctx, sorted.r, outc, 2, result), "q5 final materialize");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q5(ldb_ctx* ctx, const ldb_table* cust, const ldb_table* ord, const ldb_table* li, const ldb_table* supp, const ldb_table* nat, const ldb_table* reg,
+                                    ldb_table** result) {
+   Table custs(ctx), supps(ctx), partial(ctx);
+   int32_t s = ldb_plan_tpch_q5_customers(ctx, cust, nat, reg, &custs.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q5_suppliers(ctx, supp, nat, reg, &supps.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q5_local(ctx, custs.t, supps.t, ord, li, &partial.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q5_final(ctx, partial.t, nat, result);
+   return s;
+}
+
 // ---------------------------------------------------------------- C hooks for the host-logic tests
 extern "C" int32_t ldb_host_parse_date32(const char* s, int32_t* out) {
    return guarded([&] { *out = parseDate32(s); });

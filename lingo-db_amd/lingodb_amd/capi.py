@@ -196,6 +196,11 @@ HOST_API = {
     "ldb_plan_tpch_q12": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q18": (i32, [P, P, P, P, PP]),
     "ldb_plan_tpch_q9": (i32, [P, P, P, P, P, P, P, PP]),
+    "ldb_plan_tpch_q5": (i32, [P, P, P, P, P, P, P, PP]),
+    "ldb_plan_tpch_q5_customers": (i32, [P, P, P, P, PP]),
+    "ldb_plan_tpch_q5_suppliers": (i32, [P, P, P, P, PP]),
+    "ldb_plan_tpch_q5_local": (i32, [P, P, P, P, P, PP]),
+    "ldb_plan_tpch_q5_final": (i32, [P, P, P, PP]),
     "ldb_plan_last_error": (C.c_char_p, []),
     "ldb_plan_tpch_q1_partial": (i32, [P, P, PP]),
     "ldb_plan_tpch_q1_final": (i32, [P, P, PP]),

@@ -71,6 +71,33 @@ def test_ordered_slots_fall_back_to_hashing_on_clustered_keys(ctx, oracle):
     assert sorted(zip(out.rowids(0).tolist(), out.rowids(1).tolist())) == sorted(zip(op.tolist(), ob.tolist()))
 
 
+def test_duplicate_heavy_build_keys_use_chains(ctx, oracle):
+    """a build key that repeats tens of thousands of times: one slot per row would make the build
+    quadratic, so the table is rebuilt chained (one slot per distinct key, rows linked) — every
+    join kind must still agree with the oracle, for integer and for string keys"""
+    rng = np.random.default_rng(13)
+    nb = 120_000
+    bk = rng.integers(0, 5, nb).astype(np.int32)
+    names = np.array(["alpha", "beta", "a considerably longer key string", "delta", "epsilon"])
+    b = pa.table({"k": pa.array(bk, pa.int32()), "s": pa.array(names[bk])})
+    pk = np.array([0, 3, 7, 4, 4, -1], dtype=np.int32)
+    p = pa.table({"k": pa.array(pk, pa.int32()), "s": pa.array(["alpha", "delta", "nope", "epsilon", "epsilon", "zeta"])})
+    gb, gp, hb, hp = ctx.register("dupb", b).rel(), ctx.register("dupp", p).rel(), HostTable(b).rel(), HostTable(p).rel()
+    for keys in ([(0, 0)], [(0, 1)], [(0, 0), (0, 1)]):
+        ht = gb.join_build(keys)
+        for kind in (capi.JOIN_INNER, capi.JOIN_LEFT_OUTER):
+            op, ob, _ = oracle.join(hb, keys, hp, keys, kind)
+            out = ht.probe(gp, keys, kind)
+            got = np.stack([out.rowids(0), out.rowids(1)], axis=1)
+            want = np.stack([op, ob], axis=1)
+            assert got.shape == want.shape
+            assert np.array_equal(got[np.lexsort((got[:, 1], got[:, 0]))], want[np.lexsort((want[:, 1], want[:, 0]))]), (keys, kind)
+        for kind in (capi.JOIN_SEMI, capi.JOIN_ANTI, capi.JOIN_SEMI_BUILD, capi.JOIN_ANTI_BUILD):
+            want, _, _ = oracle.join(hb, keys, hp, keys, kind)
+            assert np.array_equal(ht.probe(gp, keys, kind).rowids(0), want), (keys, kind)
+        assert ht.probe_count(gp, keys) == len(oracle.join(hb, keys, hp, keys, capi.JOIN_INNER)[0])
+
+
 def test_three_way_join_composition(ctx, oracle, data):
     """(lineitem ⋈ orders) result used as a build side again: row ids compose through both joins"""
     cu = tpch_data.host_table(tpch_data.CUSTOMER, N_ORDERS)

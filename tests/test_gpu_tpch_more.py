@@ -81,6 +81,37 @@ def test_q12(ctx, db):
     assert result_rows(got) == want
 
 
+def test_q5(ctx):
+    """region → nations → customers / suppliers, orders of one year, the two-column
+    (l_suppkey, c_nationkey) = (s_suppkey, s_nationkey) join, revenue per nation: against a dict
+    evaluation of resources/sql/tpch/5.sql"""
+    n = 90_000
+    T = tpch_data
+    li = T.host_table(T.LINEITEM, n, cols=[0, 2, 5, 6])
+    od = T.host_table(T.ORDERS, n, cols=[0, 1, 4])
+    cu = T.host_table(T.CUSTOMER, n, cols=[0, 1])
+    su = T.host_table(T.SUPPLIER, n, cols=[0, 1])
+    na = T.host_table(T.NATION, n, cols=[0, 1, 2])
+    re_ = T.host_table(T.REGION, n, cols=[0, 1])
+    asia = {k for k, nm in zip(np_col(re_, "r_regionkey").tolist(), np_col(re_, "r_name").tolist()) if nm == "ASIA"}
+    nations = {k: nm for k, rk, nm in zip(np_col(na, "n_nationkey").tolist(), np_col(na, "n_regionkey").tolist(), np_col(na, "n_name").tolist()) if rk in asia}
+    assert len(nations) == 5
+    cnat = {k: nk for k, nk in zip(np_col(cu, "c_custkey").tolist(), np_col(cu, "c_nationkey").tolist()) if nk in nations}
+    snat = {k: nk for k, nk in zip(np_col(su, "s_suppkey").tolist(), np_col(su, "s_nationkey").tolist()) if nk in nations}
+    onat = {ok: cnat[ck] for ok, ck, d in zip(np_col(od, "o_orderkey").tolist(), np_col(od, "o_custkey").tolist(), np_col(od, "o_orderdate").tolist())
+            if days("1994-01-01") <= d < days("1995-01-01") and ck in cnat}
+    rev = collections.defaultdict(int)
+    for ok, sk, ext, disc in zip(*[np_col(li, c).tolist() for c in ("l_orderkey", "l_suppkey", "l_extendedprice", "l_discount")]):
+        nk = onat.get(ok)
+        if nk is not None and snat.get(sk) == nk:
+            rev[nations[nk]] += ext * (100 - disc)
+    want = sorted(rev.items(), key=lambda r: -r[1])
+    assert len(want) >= 3
+    reg = lambda name, t: ctx.register(name, t)
+    got = result_rows(ctx.plan_q5(reg("q5_cu", cu), reg("q5_od", od), reg("q5_li", li), reg("q5_su", su), reg("q5_na", na), reg("q5_re", re_)).to_arrow())
+    assert [r[1] for r in got] == [r[1] for r in want] and sorted(got) == sorted(want)  # ORDER BY revenue DESC
+
+
 def test_q9(ctx):
     """six-way join with a LIKE filter, a two-column join key, a two-term decimal expression and a
     computed group key (extract year): against a dict/numpy evaluation of resources/sql/tpch/9.sql"""

@@ -184,6 +184,11 @@ def run_query(runner, q):
         if os.environ.get("LDB_DIST_DEBUG"):
             print(f"[rank {runner.dist.get_rank()}] named={named.to_arrow().to_pylist()}\n   gathered={allnamed.to_arrow().to_pylist()}", flush=True)
         return _plan(ctx, "ldb_plan_tpch_q18_final", allnamed)
+    if q == 5:  # the two reduced dimension tables are all-gathered, the rest is shard-local
+        custs = replicate(runner, _plan(ctx, "ldb_plan_tpch_q5_customers", db.customer, db.nation, db.region), "q5_customers")
+        supps = replicate(runner, _plan(ctx, "ldb_plan_tpch_q5_suppliers", db.supplier, db.nation, db.region), "q5_suppliers")
+        part = _plan(ctx, "ldb_plan_tpch_q5_local", custs, supps, db.orders, db.lineitem)
+        return _plan(ctx, "ldb_plan_tpch_q5_final", replicate(runner, part, "q5_partials"), db.nation)
     if q == 9:
         world = runner.world
         if "supplier_all" not in runner.cache:  # a static dimension table: replicated once
