@@ -27,9 +27,12 @@ __device__ __forceinline__ bool d_eval_conj(const DScan& m, const DScan* __restr
 }
 
 // the conjunction over U rows of one thread, predicate-major (ldb_device.h d_eval_conj_batch)
+// (both scan kernels give every wave 64 consecutive rows per batch slot, so string conjuncts may
+// stage through LDS: one LDS_STR_STAGE region per wave of the 256-thread block)
 template <int U>
 __device__ __forceinline__ void d_eval_conj_batch(const DScan& m, const DScan* __restrict__ d, const uint64_t (&rows)[U], bool (&pass)[U]) {
-   d_eval_conj_batch<U>(m.preds, d->preds, m.n_preds, rows, pass);
+   __shared__ __attribute__((aligned(8))) uint8_t str_stage[SCAN_BLOCK / LDB_WAVE][LDS_STR_STAGE + 8 + 64]; // strings, slack, pattern
+   d_eval_conj_batch<U>(m.preds, d->preds, m.n_preds, rows, pass, d->n_rows, str_stage[threadIdx.x >> 6]);
 }
 
 // One block = 16384 consecutive rows; each wave handles 64 of the block's 256 bitmap words,
