@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sf", type=float, default=100.0)
-    ap.add_argument("--queries", default="1,3,4,5,6,9,12,18", help="TPC-H queries of one step (all have single- and multi-GPU plans)")
+    ap.add_argument("--queries", default="1,3,4,5,6,7,9,12,18", help="TPC-H queries of one step (all have single- and multi-GPU plans)")
     ap.add_argument("--narrow-decimals", type=int, default=0)
     ap.add_argument("--cpu-sample-sf", type=float, default=1.0, help="scale of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -136,6 +136,17 @@ def main():
                         "avg_kernel_ms": round(avg_ms, 4), "launches": n_l, "algorithmic_bytes_per_launch": rows_local * bpr,
                         "bytes_per_row": bpr}
         extras = {}
+        if 6 in queries:
+            # the scan headline of SURVEY §8(d): Q6-shape filter + sum.  Algorithmic bytes = full
+            # filter columns (shipdate 4 + discount 16 + quantity 16) + 16 per row passing the date
+            # range (~15 %); the kernel reads less than that (conjunct columns only for surviving
+            # rows: PMC traffic in profiles/r01_pmc_q6_sf100.json), so the figure can exceed the HBM peak.
+            n6, ms6 = kernel_ms.get((6, "k_groupby"), [0, 0.0])
+            if n6:
+                wd = 8 if args.narrow_decimals else 16
+                q6_bytes = rows_local * (4 + 2 * wd) + 0.152 * rows_local * wd
+                extras["scan_q6"] = {"kernel_ms": round(ms6 / n6, 4), "algorithmic_gbs": round(q6_bytes / (ms6 / n6 * 1e-3) / 1e9, 1),
+                                     "rows_per_s_G": round(rows_local / (ms6 / n6 * 1e-3) / 1e9, 1)}
         if 3 in queries:
             n_p, ms_p = kernel_ms.get((3, "k_join_probe_pairs"), [0, 0.0])
             if n_p:

@@ -1094,6 +1094,102 @@ extern "C" int32_t ldb_plan_tpch_q5(ldb_ctx* ctx, const ldb_table* cust, const l
    return s;
 }
 
+// ---------------------------------------------------------------- TPC-H Q7 (resources/sql/tpch/7.sql)
+// Trade volume between two nations per year.  (n1 = A and n2 = B) or (n1 = B and n2 = A) is
+// evaluated as: both nations ∈ {A, B} (pushed into the two dimension tables) and n1 <> n2 (a residual
+// column-vs-column conjunct).  Pieces as for Q5: the two reduced dimension tables can be
+// all-gathered between `q7_members` and `q7_local`.
+namespace {
+void nationMembers(ldb_ctx* ctx, const ldb_table* t, const char* keyCol, const char* nationCol, const ldb_table* nat, ldb_table** result) {
+   Rel n0(ctx), n1(ctx), t0(ctx), t1(ctx);
+   check(ldb_gpu_rel_from_table(ctx, nat, &n0.r), "q7 nation");
+   check(ldb_gpu_rel_from_table(ctx, t, &t0.r), "q7 dimension");
+   auto rn = Restrictions::create({{"n_name", FilterOp::IN, {}, std::vector<std::string>{"FRANCE", "GERMANY"}}}, nat);
+   check(ldb_gpu_scan_filter(ctx, n0.r, rn->data(), rn->size(), &n1.r), "q7 filter nation");
+   Ht hn(ctx);
+   ldb_colref nk{0, colOf(nat, "n_nationkey")}, tn{0, colOf(t, nationCol)};
+   check(ldb_gpu_join_build(ctx, n1.r, &nk, 1, 1, &hn.h), "q7 build nations");
+   check(ldb_gpu_join_probe(ctx, hn.h, t0.r, &tn, 1, LDB_JOIN_SEMI, &t1.r, nullptr), "q7 rows of the two nations");
+   ldb_colref outc[2] = {{0, colOf(t, keyCol)}, tn};
+   check(ldb_gpu_materialize(ctx, t1.r, outc, 2, result), "q7 materialize");
+}
+} // namespace
+extern "C" int32_t ldb_plan_tpch_q7_customers(ldb_ctx* ctx, const ldb_table* cust, const ldb_table* nat, ldb_table** result) {
+   return guarded([&] { nationMembers(ctx, cust, "c_custkey", "c_nationkey", nat, result); });
+}
+extern "C" int32_t ldb_plan_tpch_q7_suppliers(ldb_ctx* ctx, const ldb_table* supp, const ldb_table* nat, ldb_table** result) {
+   return guarded([&] { nationMembers(ctx, supp, "s_suppkey", "s_nationkey", nat, result); });
+}
+// partial result: (s_nationkey, c_nationkey, l_year, SUM(volume))
+extern "C" int32_t ldb_plan_tpch_q7_local(ldb_ctx* ctx, const ldb_table* custs, const ldb_table* supps, const ldb_table* ord, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel c0(ctx), s0(ctx), o0(ctx), l0(ctx), l1(ctx), ls(ctx), m0(ctx), om(ctx), omc(ctx), diff(ctx), withYear(ctx);
+      check(ldb_gpu_rel_from_table(ctx, custs, &c0.r), "q7 customers");
+      check(ldb_gpu_rel_from_table(ctx, supps, &s0.r), "q7 suppliers");
+      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q7 orders");
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q7 lineitem");
+      auto rl = Restrictions::create({{"l_shipdate", FilterOp::GTE, std::string("1995-01-01"), {}}, {"l_shipdate", FilterOp::LTE, std::string("1996-12-31"), {}}}, li);
+      check(ldb_gpu_scan_filter(ctx, l0.r, rl->data(), rl->size(), &l1.r), "q7 filter lineitem");
+      Ht hs(ctx), hm(ctx), hc(ctx);
+      ldb_colref sk{0, 0}, lsk{0, colOf(li, "l_suppkey")};
+      check(ldb_gpu_join_build(ctx, s0.r, &sk, 1, 1, &hs.h), "q7 build suppliers");
+      check(ldb_gpu_join_probe(ctx, hs.h, l1.r, &lsk, 1, LDB_JOIN_INNER, &ls.r, nullptr), "q7 probe lineitem"); // sides: lineitem, suppliers
+      // narrow, then orders probe the reduced lineitem side (it is the smaller one)
+      ldb_colref keep[5] = {{0, colOf(li, "l_orderkey")}, {0, colOf(li, "l_shipdate")}, {0, colOf(li, "l_extendedprice")}, {0, colOf(li, "l_discount")}, {1, 1}};
+      Table m(ctx), years(ctx);
+      check(ldb_gpu_materialize(ctx, ls.r, keep, 5, &m.t), "q7 materialize");
+      check(ldb_gpu_rel_from_table(ctx, m.t, &m0.r), "q7 rel");
+      ldb_colref mok{0, 0}, ook{0, colOf(ord, "o_orderkey")};
+      check(ldb_gpu_join_build(ctx, m0.r, &mok, 1, 0, &hm.h), "q7 build reduced lineitem");
+      check(ldb_gpu_join_probe(ctx, hm.h, o0.r, &ook, 1, LDB_JOIN_INNER, &om.r, nullptr), "q7 probe orders"); // sides: orders, m
+      ldb_colref ck{0, 0}, ock{0, colOf(ord, "o_custkey")};
+      check(ldb_gpu_join_build(ctx, c0.r, &ck, 1, 1, &hc.h), "q7 build customers");
+      check(ldb_gpu_join_probe(ctx, hc.h, om.r, &ock, 1, LDB_JOIN_INNER, &omc.r, nullptr), "q7 probe customers"); // sides: orders, m, customers
+      ldb_filter_desc differ = colCompare({1, 4}, FilterOp::NEQ, {2, 1}); // s_nationkey <> c_nationkey
+      check(ldb_gpu_scan_filter(ctx, omc.r, &differ, 1, &diff.r), "q7 nations differ");
+      check(ldb_gpu_map_column(ctx, diff.r, {1, 1}, LDB_FN_EXTRACT_YEAR, "l_year", &years.t), "q7 extract year");
+      check(ldb_gpu_rel_zip(ctx, diff.r, years.t, &withYear.r), "q7 zip year");
+      ldb_colref ext{1, 2}, disc{1, 3};
+      DecimalType t1md;
+      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, decOf(m.t, 3), &t1md);
+      DecimalType tVol = typeAfterMul(decOf(m.t, 2), t1md);
+      ldb_agg_spec agg = sumDec(product({colFactor(ext), oneMinusDisc}), tVol);
+      ldb_colref keys[3] = {{1, 4}, {2, 1}, {3, 0}};
+      check(ldb_gpu_groupby(ctx, withYear.r, nullptr, 0, keys, 3, &agg, 1, 16, result), "q7 partial groupby");
+   });
+}
+// (gathered) partials ⋈ nation (supplier side) ⋈ nation (customer side) → names, re-aggregated, ordered
+extern "C" int32_t ldb_plan_tpch_q7_final(ldb_ctx* ctx, const ldb_table* partials, const ldb_table* nat, ldb_table** result) {
+   return guarded([&] {
+      Rel in(ctx), n0(ctx), p1(ctx), p2(ctx), g(ctx), sorted(ctx);
+      check(ldb_gpu_rel_from_table(ctx, partials, &in.r), "q7 final");
+      check(ldb_gpu_rel_from_table(ctx, nat, &n0.r), "q7 final nation");
+      Ht hn(ctx);
+      ldb_colref nk{0, colOf(nat, "n_nationkey")}, snk{0, 0}, cnk{0, 1};
+      check(ldb_gpu_join_build(ctx, n0.r, &nk, 1, 1, &hn.h), "q7 build nation");
+      check(ldb_gpu_join_probe(ctx, hn.h, in.r, &snk, 1, LDB_JOIN_INNER, &p1.r, nullptr), "q7 supplier nation"); // sides: partials, nation(supp)
+      check(ldb_gpu_join_probe(ctx, hn.h, p1.r, &cnk, 1, LDB_JOIN_INNER, &p2.r, nullptr), "q7 customer nation"); // sides: partials, nation(supp), nation(cust)
+      const int32_t nn = colOf(nat, "n_name");
+      ldb_colref keys[3] = {{1, nn}, {2, nn}, {0, 2}};
+      ldb_agg_spec agg = sumDec(product({colFactor({0, 3})}), decOf(partials, 3));
+      Table grouped(ctx);
+      check(ldb_gpu_groupby(ctx, p2.r, nullptr, 0, keys, 3, &agg, 1, 16, &grouped.t), "q7 final groupby");
+      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q7 final rel");
+      ldb_sort_spec specs[3] = {{{0, 0}, 0, 0}, {{0, 1}, 0, 0}, {{0, 2}, 0, 0}};
+      check(ldb_gpu_sort(ctx, g.r, specs, 3, &sorted.r), "q7 final sort");
+      ldb_colref outc[4] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}};
+      check(ldb_gpu_materialize(ctx, sorted.r, outc, 4, result), "q7 final materialize");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q7(ldb_ctx* ctx, const ldb_table* cust, const ldb_table* ord, const ldb_table* li, const ldb_table* supp, const ldb_table* nat, ldb_table** result) {
+   Table custs(ctx), supps(ctx), partial(ctx);
+   int32_t s = ldb_plan_tpch_q7_customers(ctx, cust, nat, &custs.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q7_suppliers(ctx, supp, nat, &supps.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q7_local(ctx, custs.t, supps.t, ord, li, &partial.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q7_final(ctx, partial.t, nat, result);
+   return s;
+}
+
 // ---------------------------------------------------------------- C hooks for the host-logic tests
 extern "C" int32_t ldb_host_parse_date32(const char* s, int32_t* out) {
    return guarded([&] { *out = parseDate32(s); });

@@ -83,6 +83,12 @@ int32_t ldb_plan_tpch_q5_customers(ldb_ctx* ctx, const ldb_table* customer, cons
 int32_t ldb_plan_tpch_q5_suppliers(ldb_ctx* ctx, const ldb_table* supplier, const ldb_table* nation, const ldb_table* region, ldb_table** result);
 int32_t ldb_plan_tpch_q5_local(ldb_ctx* ctx, const ldb_table* custs, const ldb_table* supps, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q5_final(ldb_ctx* ctx, const ldb_table* partials, const ldb_table* nation, ldb_table** result);
+int32_t ldb_plan_tpch_q7(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* orders, const ldb_table* lineitem, const ldb_table* supplier, const ldb_table* nation,
+                         ldb_table** result);
+int32_t ldb_plan_tpch_q7_customers(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* nation, ldb_table** result);
+int32_t ldb_plan_tpch_q7_suppliers(ldb_ctx* ctx, const ldb_table* supplier, const ldb_table* nation, ldb_table** result);
+int32_t ldb_plan_tpch_q7_local(ldb_ctx* ctx, const ldb_table* custs, const ldb_table* supps, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q7_final(ldb_ctx* ctx, const ldb_table* partials, const ldb_table* nation, ldb_table** result);
 const char* ldb_plan_last_error(void);
 // multi-GPU pieces: shard-local partial plans + merges of the exchanged partial tables
 int32_t ldb_plan_tpch_q1_partial(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);

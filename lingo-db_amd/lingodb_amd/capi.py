@@ -197,6 +197,11 @@ HOST_API = {
     "ldb_plan_tpch_q18": (i32, [P, P, P, P, PP]),
     "ldb_plan_tpch_q9": (i32, [P, P, P, P, P, P, P, PP]),
     "ldb_plan_tpch_q5": (i32, [P, P, P, P, P, P, P, PP]),
+    "ldb_plan_tpch_q7": (i32, [P, P, P, P, P, P, PP]),
+    "ldb_plan_tpch_q7_customers": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q7_suppliers": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q7_local": (i32, [P, P, P, P, P, PP]),
+    "ldb_plan_tpch_q7_final": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q5_customers": (i32, [P, P, P, P, PP]),
     "ldb_plan_tpch_q5_suppliers": (i32, [P, P, P, P, PP]),
     "ldb_plan_tpch_q5_local": (i32, [P, P, P, P, P, PP]),

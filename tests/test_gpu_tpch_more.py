@@ -112,6 +112,36 @@ def test_q5(ctx):
     assert [r[1] for r in got] == [r[1] for r in want] and sorted(got) == sorted(want)  # ORDER BY revenue DESC
 
 
+def test_q7(ctx):
+    """volume shipped between two nations per year: the OR of the two nation pairs, a residual
+    column-vs-column conjunct across join sides, extract(year from l_shipdate) as a group key —
+    against a dict evaluation of resources/sql/tpch/7.sql"""
+    n = 120_000
+    T = tpch_data
+    li = T.host_table(T.LINEITEM, n, cols=[0, 2, 5, 6, 10])
+    od = T.host_table(T.ORDERS, n, cols=[0, 1])
+    cu = T.host_table(T.CUSTOMER, n, cols=[0, 1])
+    su = T.host_table(T.SUPPLIER, n, cols=[0, 1])
+    na = T.host_table(T.NATION, n, cols=[0, 1, 2])
+    nname = dict(zip(np_col(na, "n_nationkey").tolist(), np_col(na, "n_name").tolist()))
+    cnat = {k: nname[nk] for k, nk in zip(np_col(cu, "c_custkey").tolist(), np_col(cu, "c_nationkey").tolist())}
+    snat = {k: nname[nk] for k, nk in zip(np_col(su, "s_suppkey").tolist(), np_col(su, "s_nationkey").tolist())}
+    ocust = dict(zip(np_col(od, "o_orderkey").tolist(), np_col(od, "o_custkey").tolist()))
+    vol = collections.defaultdict(int)
+    cols = [np_col(li, c).tolist() for c in ("l_orderkey", "l_suppkey", "l_extendedprice", "l_discount", "l_shipdate")]
+    for ok, sk, ext, disc, ship in zip(*cols):
+        if not (days("1995-01-01") <= ship <= days("1996-12-31")):
+            continue
+        n1, n2 = snat[sk], cnat[ocust[ok]]
+        if (n1 == "FRANCE" and n2 == "GERMANY") or (n1 == "GERMANY" and n2 == "FRANCE"):
+            vol[(n1, n2, (EPOCH + datetime.timedelta(days=ship)).year)] += ext * (100 - disc)
+    want = sorted((a, b, y, v) for (a, b, y), v in vol.items())
+    assert len(want) == 4
+    reg = lambda name, t: ctx.register(name, t)
+    got = result_rows(ctx.plan_q7(reg("q7_cu", cu), reg("q7_od", od), reg("q7_li", li), reg("q7_su", su), reg("q7_na", na)).to_arrow())
+    assert got == want
+
+
 def test_q9(ctx):
     """six-way join with a LIKE filter, a two-column join key, a two-term decimal expression and a
     computed group key (extract year): against a dict/numpy evaluation of resources/sql/tpch/9.sql"""

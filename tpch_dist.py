@@ -189,6 +189,11 @@ def run_query(runner, q):
         supps = replicate(runner, _plan(ctx, "ldb_plan_tpch_q5_suppliers", db.supplier, db.nation, db.region), "q5_suppliers")
         part = _plan(ctx, "ldb_plan_tpch_q5_local", custs, supps, db.orders, db.lineitem)
         return _plan(ctx, "ldb_plan_tpch_q5_final", replicate(runner, part, "q5_partials"), db.nation)
+    if q == 7:  # like Q5: all-gather the customers / suppliers of the two nations, then shard-local
+        custs = replicate(runner, _plan(ctx, "ldb_plan_tpch_q7_customers", db.customer, db.nation), "q7_customers")
+        supps = replicate(runner, _plan(ctx, "ldb_plan_tpch_q7_suppliers", db.supplier, db.nation), "q7_suppliers")
+        part = _plan(ctx, "ldb_plan_tpch_q7_local", custs, supps, db.orders, db.lineitem)
+        return _plan(ctx, "ldb_plan_tpch_q7_final", replicate(runner, part, "q7_partials"), db.nation)
     if q == 9:
         world = runner.world
         if "supplier_all" not in runner.cache:  # a static dimension table: replicated once

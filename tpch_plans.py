@@ -38,8 +38,8 @@ class Database:
             lcols |= {L_ORDERKEY, L_QUANTITY}
         if 9 in queries:
             lcols |= {L_ORDERKEY, 1, 2, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT}  # + l_partkey, l_suppkey
-        if 5 in queries:
-            lcols |= {L_ORDERKEY, 2, L_EXTENDEDPRICE, L_DISCOUNT}  # + l_suppkey
+        if 5 in queries or 7 in queries:
+            lcols |= {L_ORDERKEY, 2, L_EXTENDEDPRICE, L_DISCOUNT, L_SHIPDATE}  # + l_suppkey
         lcols |= {L_EXTENDEDPRICE, L_SHIPDATE}  # hbm_ceiling() calibration scans
         self.lineitem = ctx.tpch_generate(LINEITEM, n_orders, rank, world, sorted(lcols), narrow)
         self.orders = self.customer = None
@@ -63,7 +63,10 @@ class Database:
             ocols |= {O_ORDERKEY, O_CUSTKEY, O_ORDERDATE}
             ccols |= {C_CUSTKEY, 1}  # + c_nationkey
             self.region = ctx.tpch_generate(7, n_orders, rank, world, [0, 1], narrow)  # r_regionkey, r_name
-        if 9 in queries or 5 in queries:
+        if 7 in queries:
+            ocols |= {O_ORDERKEY, O_CUSTKEY}
+            ccols |= {C_CUSTKEY, 1}  # + c_nationkey
+        if 9 in queries or 5 in queries or 7 in queries:
             self.supplier = ctx.tpch_generate(SUPPLIER, n_orders, rank, world, [0, 1], narrow)  # s_suppkey, s_nationkey
             self.nation = ctx.tpch_generate(NATION, n_orders, rank, world, [0, 1, 2], narrow)  # n_nationkey, n_regionkey, n_name
         if ocols:
@@ -98,6 +101,8 @@ class Runner:
             res = self.ctx.plan_q18(self.db.customer, self.db.orders, self.db.lineitem)
         elif q == 5:
             res = self.ctx.plan_q5(self.db.customer, self.db.orders, self.db.lineitem, self.db.supplier, self.db.nation, self.db.region)
+        elif q == 7:
+            res = self.ctx.plan_q7(self.db.customer, self.db.orders, self.db.lineitem, self.db.supplier, self.db.nation)
         elif q == 9:
             res = self.ctx.plan_q9(self.db.part, self.db.supplier, self.db.lineitem, self.db.partsupp, self.db.orders, self.db.nation)
         else:
