@@ -35,13 +35,20 @@ def allgather_columns(dist, cols, widths, n_rows):
     dist.all_gather(counts_t, cnt)
     counts = [int(c.item()) for c in counts_t]
     cap = max(max(counts), 1)
+    # all columns travel in ONE collective: each rank's message is [col0 | col1 | …], every
+    # column region padded to cap rows (small-message latency, not bandwidth, bounds these
+    # exchanges on xGMI: a partial-aggregate table is a few KB in ~10 columns)
+    region = [0]
+    for w in widths:
+        region.append(region[-1] + cap * w)
+    packed = torch.zeros(max(region[-1], 1), dtype=torch.uint8, device=device)
+    for k, (c, w) in enumerate(zip(cols, widths)):
+        packed[region[k] : region[k] + n_rows * w] = c[: n_rows * w]
+    parts = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(parts, packed)
     out = []
-    for c, w in zip(cols, widths):
-        padded = torch.zeros(cap * w, dtype=torch.uint8, device=device)
-        padded[: n_rows * w] = c[: n_rows * w]
-        parts = [torch.empty(cap * w, dtype=torch.uint8, device=device) for _ in range(world)]
-        dist.all_gather(parts, padded)
-        out.append(torch.cat([p[: counts[r] * w] for r, p in enumerate(parts)]))
+    for k, w in enumerate(widths):
+        out.append(torch.cat([p[region[k] : region[k] + counts[r] * w] for r, p in enumerate(parts)]))
     return out, counts
 
 
@@ -58,24 +65,36 @@ def alltoall_columns(dist, cols, widths, send_counts):
     recv_off = [0]
     for c in recv_counts:
         recv_off.append(recv_off[-1] + int(c))
+    # one message per peer pair carrying that peer's rows of EVERY column ([col0 rows | col1 rows | …]),
+    # all pairs in one grouped batch: world-1 sends + world-1 receives per exchange
+    total_w = sum(widths)
+    ops, inbox = [], {}
+    for peer in range(world):
+        ns, nr = int(send_counts[peer]), recv_counts[peer]
+        if peer == rank:
+            continue
+        if ns:
+            msg = torch.cat([c[send_off[peer] * w : send_off[peer + 1] * w] for c, w in zip(cols, widths)]) if len(cols) > 1 else \
+                cols[0][send_off[peer] * widths[0] : send_off[peer + 1] * widths[0]].contiguous()
+            ops.append(dist.P2POp(dist.isend, msg, peer))
+        if nr:
+            inbox[peer] = torch.empty(nr * total_w, dtype=torch.uint8, device=device)
+            ops.append(dist.P2POp(dist.irecv, inbox[peer], peer))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     outs = []
+    col_off = 0  # byte offset of column k inside a peer's message, in units of that peer's row count
     for c, w in zip(cols, widths):
-        recv = torch.empty(max(recv_off[-1], 1) * w, dtype=torch.uint8, device=device)
-        ops = []
+        pieces = []
         for peer in range(world):
-            s = c[send_off[peer] * w : send_off[peer + 1] * w]
-            r = recv[recv_off[peer] * w : recv_off[peer + 1] * w]
+            n = recv_counts[peer]
             if peer == rank:
-                r.copy_(s)
-                continue
-            if s.numel():
-                ops.append(dist.P2POp(dist.isend, s.contiguous(), peer))
-            if r.numel():
-                ops.append(dist.P2POp(dist.irecv, r, peer))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        outs.append(recv[: recv_off[-1] * w])
+                pieces.append(c[send_off[rank] * w : send_off[rank + 1] * w])
+            elif n:
+                pieces.append(inbox[peer][col_off * n : (col_off + w) * n])
+        outs.append(torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.uint8, device=device))
+        col_off += w
     return outs, recv_counts
 
 

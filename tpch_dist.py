@@ -140,8 +140,8 @@ def _plan_partitioned(ctx, name, world, *tables):
 def shuffle(runner, table, send_counts, name):
     """the all-to-all of the hash-radix shuffle: `table` holds send_counts[j] rows for
     rank j, in rank order (ldb_gpu_partition's layout); returns the rows this rank receives from
-    every peer.  One grouped point-to-point exchange per column (each peer pair has its own xGMI
-    link); fixed-width columns only."""
+    every peer.  One grouped point-to-point exchange for the whole table (one message per peer pair
+    carrying all columns; each peer pair has its own xGMI link); fixed-width columns only."""
     cols, widths = table_to_tensors(runner.ctx, table)
     staged = runner.dist.get_backend() == "gloo"
     if staged:
