@@ -1190,6 +1190,115 @@ extern "C" int32_t ldb_plan_tpch_q7(ldb_ctx* ctx, const ldb_table* cust, const l
    return s;
 }
 
+// ---------------------------------------------------------------- TPC-H Q11 (resources/sql/tpch/11.sql)
+// Stock value per part held by one nation's suppliers, HAVING value > 0.0001 × the total.
+// ps_supplycost decimal(12,2) × ps_availqty (int32 → decimal(19,0), sql_analyzer.cpp:3125-3141);
+// the scalar subquery is the SUM over the same groups, `sum × 0.0001` has scale 2+4, so after the
+// cast to the common scale the comparison is value·10^4 > total in integers, i.e.
+// value > floor(total / 10^4) — the constant of the HAVING filter.
+// Pieces (the single-GPU plan is their composition): q11_suppliers → [all-gather] → q11_groups →
+// [q11_partition + all-to-all on the hash of ps_partkey → q11_merge: a part's four partsupp rows
+// may straddle two row shards] → q11_total → [all-gather] → q11_filter → [all-gather] → q11_sort.
+namespace {
+ldb_agg_spec sumOfCol(const ldb_table* t, int32_t col) { return sumDec(product({colFactor({0, col})}), decOf(t, col)); }
+void groupByFirstCol(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result, const char* what) {
+   Rel in(ctx);
+   check(ldb_gpu_rel_from_table(ctx, rows, &in.r), what);
+   ldb_colref key{0, 0};
+   ldb_agg_spec agg = sumOfCol(rows, 1);
+   check(ldb_gpu_groupby(ctx, in.r, nullptr, 0, &key, 1, &agg, 1, std::max<int64_t>(ldb_gpu_table_rows(rows), 16), result), what);
+}
+} // namespace
+extern "C" int32_t ldb_plan_tpch_q11_suppliers(ldb_ctx* ctx, const ldb_table* supp, const ldb_table* nat, ldb_table** result) {
+   return guarded([&] {
+      Rel n0(ctx), n1(ctx), s0(ctx), s1(ctx);
+      check(ldb_gpu_rel_from_table(ctx, nat, &n0.r), "q11 nation");
+      check(ldb_gpu_rel_from_table(ctx, supp, &s0.r), "q11 supplier");
+      auto rn = Restrictions::create({{"n_name", FilterOp::EQ, std::string("GERMANY"), {}}}, nat);
+      check(ldb_gpu_scan_filter(ctx, n0.r, rn->data(), rn->size(), &n1.r), "q11 filter nation");
+      Ht hn(ctx);
+      ldb_colref nk{0, colOf(nat, "n_nationkey")}, sn{0, colOf(supp, "s_nationkey")}, sk{0, colOf(supp, "s_suppkey")};
+      check(ldb_gpu_join_build(ctx, n1.r, &nk, 1, 1, &hn.h), "q11 build nation");
+      check(ldb_gpu_join_probe(ctx, hn.h, s0.r, &sn, 1, LDB_JOIN_SEMI, &s1.r, nullptr), "q11 suppliers of the nation");
+      check(ldb_gpu_materialize(ctx, s1.r, &sk, 1, result), "q11 materialize suppliers");
+   });
+}
+// (ps_partkey, SUM(ps_supplycost * ps_availqty)) over this shard's partsupp rows of those suppliers
+extern "C" int32_t ldb_plan_tpch_q11_groups(ldb_ctx* ctx, const ldb_table* suppkeys, const ldb_table* ps, ldb_table** result) {
+   return guarded([&] {
+      Rel s0(ctx), ps0(ctx), ps1(ctx);
+      check(ldb_gpu_rel_from_table(ctx, suppkeys, &s0.r), "q11 supplier keys");
+      check(ldb_gpu_rel_from_table(ctx, ps, &ps0.r), "q11 partsupp");
+      Ht hs(ctx);
+      ldb_colref sk{0, 0}, pssk{0, colOf(ps, "ps_suppkey")}, pspk{0, colOf(ps, "ps_partkey")};
+      check(ldb_gpu_join_build(ctx, s0.r, &sk, 1, 1, &hs.h), "q11 build suppliers");
+      check(ldb_gpu_join_probe(ctx, hs.h, ps0.r, &pssk, 1, LDB_JOIN_SEMI, &ps1.r, nullptr), "q11 partsupp of those suppliers");
+      ldb_colref cost{0, colOf(ps, "ps_supplycost")}, qty{0, colOf(ps, "ps_availqty")};
+      DecimalType tVal = typeAfterMul(decOf(ps, cost.col), {19, 0});
+      ldb_agg_spec agg = sumDec(product({colFactor(cost), colFactor(qty)}), tVal);
+      const int64_t expected = std::max<int64_t>(ldb_gpu_table_rows(ps) / 16, 1024); // one nation of 25, ≤ 4 rows per part
+      check(ldb_gpu_groupby(ctx, ps1.r, nullptr, 0, &pspk, 1, &agg, 1, expected, result), "q11 groupby");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q11_partition(ldb_ctx* ctx, const ldb_table* groups, int32_t world, ldb_table** result, int64_t* counts) {
+   return guarded([&] {
+      Rel g0(ctx);
+      check(ldb_gpu_rel_from_table(ctx, groups, &g0.r), "q11 partial groups");
+      ldb_colref cols[2] = {{0, 0}, {0, 1}};
+      check(ldb_gpu_partition(ctx, g0.r, &cols[0], 1, world, cols, 2, result, counts), "q11 partition");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q11_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result) {
+   return guarded([&] { groupByFirstCol(ctx, rows, result, "q11 merge"); });
+}
+extern "C" int32_t ldb_plan_tpch_q11_total(ldb_ctx* ctx, const ldb_table* groups, ldb_table** result) {
+   return guarded([&] {
+      Rel g0(ctx);
+      check(ldb_gpu_rel_from_table(ctx, groups, &g0.r), "q11 total");
+      ldb_agg_spec agg = sumOfCol(groups, 1);
+      check(ldb_gpu_groupby(ctx, g0.r, nullptr, 0, nullptr, 0, &agg, 1, 1, result), "q11 total");
+   });
+}
+// `totals`: one row per rank (the partial sums of the scalar subquery)
+extern "C" int32_t ldb_plan_tpch_q11_filter(ldb_ctx* ctx, const ldb_table* groups, const ldb_table* totals, ldb_table** result) {
+   return guarded([&] {
+      const int64_t n = ldb_gpu_table_rows(totals);
+      std::vector<__int128> parts((size_t) std::max<int64_t>(n, 1), 0);
+      if (n) check(ldb_gpu_table_read_fixed(ctx, totals, 0, parts.data(), n * 16), "q11 read totals");
+      __int128 total = 0;
+      for (int64_t i = 0; i < n; i++) total += parts[(size_t) i];
+      Rel g0(ctx), g1(ctx);
+      check(ldb_gpu_rel_from_table(ctx, groups, &g0.r), "q11 groups");
+      ldb_filter_desc having;
+      memset(&having, 0, sizeof(having));
+      having.col = {0, 1};
+      having.op = (int32_t) FilterOp::GT;
+      setInt(having, total / 10000);
+      check(ldb_gpu_scan_filter(ctx, g0.r, &having, 1, &g1.r), "q11 having");
+      ldb_colref outc[2] = {{0, 0}, {0, 1}};
+      check(ldb_gpu_materialize(ctx, g1.r, outc, 2, result), "q11 materialize");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q11_sort(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result) {
+   return guarded([&] {
+      Rel in(ctx), sorted(ctx);
+      check(ldb_gpu_rel_from_table(ctx, rows, &in.r), "q11 sort");
+      ldb_sort_spec spec{{0, 1}, 1, 0};
+      check(ldb_gpu_sort(ctx, in.r, &spec, 1, &sorted.r), "q11 sort");
+      ldb_colref outc[2] = {{0, 0}, {0, 1}};
+      check(ldb_gpu_materialize(ctx, sorted.r, outc, 2, result), "q11 materialize sorted");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q11(ldb_ctx* ctx, const ldb_table* ps, const ldb_table* supp, const ldb_table* nat, ldb_table** result) {
+   Table supps(ctx), groups(ctx), total(ctx), kept(ctx);
+   int32_t s = ldb_plan_tpch_q11_suppliers(ctx, supp, nat, &supps.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q11_groups(ctx, supps.t, ps, &groups.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q11_total(ctx, groups.t, &total.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q11_filter(ctx, groups.t, total.t, &kept.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q11_sort(ctx, kept.t, result);
+   return s;
+}
+
 // ---------------------------------------------------------------- C hooks for the host-logic tests
 extern "C" int32_t ldb_host_parse_date32(const char* s, int32_t* out) {
    return guarded([&] { *out = parseDate32(s); });

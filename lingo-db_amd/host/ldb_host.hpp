@@ -89,6 +89,15 @@ int32_t ldb_plan_tpch_q7_customers(ldb_ctx* ctx, const ldb_table* customer, cons
 int32_t ldb_plan_tpch_q7_suppliers(ldb_ctx* ctx, const ldb_table* supplier, const ldb_table* nation, ldb_table** result);
 int32_t ldb_plan_tpch_q7_local(ldb_ctx* ctx, const ldb_table* custs, const ldb_table* supps, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q7_final(ldb_ctx* ctx, const ldb_table* partials, const ldb_table* nation, ldb_table** result);
+// Q11 and its pieces (suppliers → groups → [partition → all-to-all → merge] → total → filter → sort)
+int32_t ldb_plan_tpch_q11(ldb_ctx* ctx, const ldb_table* partsupp, const ldb_table* supplier, const ldb_table* nation, ldb_table** result);
+int32_t ldb_plan_tpch_q11_suppliers(ldb_ctx* ctx, const ldb_table* supplier, const ldb_table* nation, ldb_table** result);
+int32_t ldb_plan_tpch_q11_groups(ldb_ctx* ctx, const ldb_table* suppkeys, const ldb_table* partsupp, ldb_table** result);
+int32_t ldb_plan_tpch_q11_partition(ldb_ctx* ctx, const ldb_table* groups, int32_t world, ldb_table** result, int64_t* counts);
+int32_t ldb_plan_tpch_q11_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
+int32_t ldb_plan_tpch_q11_total(ldb_ctx* ctx, const ldb_table* groups, ldb_table** result);
+int32_t ldb_plan_tpch_q11_filter(ldb_ctx* ctx, const ldb_table* groups, const ldb_table* totals, ldb_table** result);
+int32_t ldb_plan_tpch_q11_sort(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
 const char* ldb_plan_last_error(void);
 // multi-GPU pieces: shard-local partial plans + merges of the exchanged partial tables
 int32_t ldb_plan_tpch_q1_partial(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);

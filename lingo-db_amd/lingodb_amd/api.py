@@ -489,6 +489,11 @@ class Context:
         check_plan(capi.host_lib().ldb_plan_tpch_q7(self.h, customer.h, orders.h, lineitem.h, supplier.h, nation.h, C.byref(t)))
         return Table(self, t)
 
+    def plan_q11(self, partsupp, supplier, nation):
+        t = C.c_void_p()
+        check_plan(capi.host_lib().ldb_plan_tpch_q11(self.h, partsupp.h, supplier.h, nation.h, C.byref(t)))
+        return Table(self, t)
+
     def plan_q9(self, part, supplier, lineitem, partsupp, orders, nation):
         t = C.c_void_p()
         check_plan(capi.host_lib().ldb_plan_tpch_q9(self.h, part.h, supplier.h, lineitem.h, partsupp.h, orders.h, nation.h, C.byref(t)))

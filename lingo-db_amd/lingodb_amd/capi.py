@@ -202,6 +202,14 @@ HOST_API = {
     "ldb_plan_tpch_q7_suppliers": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q7_local": (i32, [P, P, P, P, P, PP]),
     "ldb_plan_tpch_q7_final": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q11": (i32, [P, P, P, P, PP]),
+    "ldb_plan_tpch_q11_suppliers": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q11_groups": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q11_partition": (i32, [P, P, i32, PP, C.POINTER(i64)]),
+    "ldb_plan_tpch_q11_merge": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q11_total": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q11_filter": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q11_sort": (i32, [P, P, PP]),
     "ldb_plan_tpch_q5_customers": (i32, [P, P, P, P, PP]),
     "ldb_plan_tpch_q5_suppliers": (i32, [P, P, P, P, PP]),
     "ldb_plan_tpch_q5_local": (i32, [P, P, P, P, P, PP]),

@@ -171,6 +171,33 @@ def test_q9(ctx):
     assert result_rows(got) == want
 
 
+def test_q11(ctx):
+    """decimal × int32 product as the aggregate argument, a high-cardinality group-by, a scalar
+    subquery (the total) turned into the HAVING constant, ORDER BY value desc — against a dict
+    evaluation of resources/sql/tpch/11.sql.  value > total * 0.0001 at the common scale 6 is
+    value * 10^4 > total in integers."""
+    n = 300_000
+    T = tpch_data
+    ps = T.host_table(T.PARTSUPP, n, cols=[0, 1, 2, 3])
+    su = T.host_table(T.SUPPLIER, n, cols=[0, 1])
+    na = T.host_table(T.NATION, n, cols=[0, 1, 2])
+    germany = {k for k, nm in zip(np_col(na, "n_nationkey").tolist(), np_col(na, "n_name").tolist()) if nm == "GERMANY"}
+    supps = {k for k, nk in zip(np_col(su, "s_suppkey").tolist(), np_col(su, "s_nationkey").tolist()) if nk in germany}
+    assert len(germany) == 1 and supps
+    value = collections.defaultdict(int)
+    for pk, sk, qty, cost in zip(*[np_col(ps, c).tolist() for c in ("ps_partkey", "ps_suppkey", "ps_availqty", "ps_supplycost")]):
+        if sk in supps:
+            value[pk] += cost * qty
+    total = sum(value.values())
+    want = sorted(((pk, v) for pk, v in value.items() if v * 10_000 > total), key=lambda r: -r[1])
+    assert 0 < len(want) < len(value)
+    reg = lambda name, t: ctx.register(name, t)
+    got = ctx.plan_q11(reg("q11_ps", ps), reg("q11_su", su), reg("q11_na", na)).to_arrow()
+    assert got.schema.field(1).type == pa.decimal128(31, 2)  # decimal(12,2) × decimal(19,0)
+    rows = result_rows(got)
+    assert [r[1] for r in rows] == [r[1] for r in want] and sorted(rows) == sorted(want)
+
+
 def test_q18(ctx, db):
     li, od, cu = db["li"], db["od"], db["cu"]
     lkey, qty = np_col(li, "l_orderkey"), np_col(li, "l_quantity")

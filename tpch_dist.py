@@ -205,4 +205,15 @@ def run_query(runner, q):
         psrows = shuffle(runner, pside, pcounts, "q9_psrows")
         part = _plan(ctx, "ldb_plan_tpch_q9_join", lrows, psrows, runner.cache["supplier_all"], db.nation)
         return _plan(ctx, "ldb_plan_tpch_q9_final", replicate(runner, part, "q9_partials"), db.nation)
+    if q == 11:
+        # partsupp is sharded by rows, so a part's rows may straddle two shards: the shard-local
+        # groups are re-partitioned on the hash of ps_partkey (the high-cardinality group-by exchange
+        # of SURVEY §8(e)) and merged; the scalar subquery's total is the sum of the ranks' totals
+        supps = replicate(runner, _plan(ctx, "ldb_plan_tpch_q11_suppliers", db.supplier, db.nation), "q11_suppliers")
+        local = _plan(ctx, "ldb_plan_tpch_q11_groups", supps, db.partsupp)
+        parts, counts = _plan_partitioned(ctx, "ldb_plan_tpch_q11_partition", runner.world, local)
+        groups = _plan(ctx, "ldb_plan_tpch_q11_merge", shuffle(runner, parts, counts, "q11_rows"))
+        totals = replicate(runner, _plan(ctx, "ldb_plan_tpch_q11_total", groups), "q11_totals")
+        kept = _plan(ctx, "ldb_plan_tpch_q11_filter", groups, totals)
+        return _plan(ctx, "ldb_plan_tpch_q11_sort", replicate(runner, kept, "q11_kept"))
     raise ValueError(f"TPC-H Q{q} has no multi-GPU plan yet")

@@ -58,7 +58,8 @@ class Database:
         if 9 in queries:
             ocols |= {O_ORDERKEY, O_ORDERDATE}
             self.part = ctx.tpch_generate(PART, n_orders, rank, world, [0, 3], narrow)  # p_partkey, p_name
-            self.partsupp = ctx.tpch_generate(PARTSUPP, n_orders, rank, world, [0, 1, 3], narrow)  # ps_partkey, ps_suppkey, ps_supplycost
+        if 9 in queries or 11 in queries:  # ps_partkey, ps_suppkey, [ps_availqty,] ps_supplycost
+            self.partsupp = ctx.tpch_generate(PARTSUPP, n_orders, rank, world, [0, 1, 2, 3] if 11 in queries else [0, 1, 3], narrow)
         if 5 in queries:
             ocols |= {O_ORDERKEY, O_CUSTKEY, O_ORDERDATE}
             ccols |= {C_CUSTKEY, 1}  # + c_nationkey
@@ -66,7 +67,7 @@ class Database:
         if 7 in queries:
             ocols |= {O_ORDERKEY, O_CUSTKEY}
             ccols |= {C_CUSTKEY, 1}  # + c_nationkey
-        if 9 in queries or 5 in queries or 7 in queries:
+        if any(q in queries for q in (5, 7, 9, 11)):
             self.supplier = ctx.tpch_generate(SUPPLIER, n_orders, rank, world, [0, 1], narrow)  # s_suppkey, s_nationkey
             self.nation = ctx.tpch_generate(NATION, n_orders, rank, world, [0, 1, 2], narrow)  # n_nationkey, n_regionkey, n_name
         if ocols:
@@ -103,6 +104,8 @@ class Runner:
             res = self.ctx.plan_q5(self.db.customer, self.db.orders, self.db.lineitem, self.db.supplier, self.db.nation, self.db.region)
         elif q == 7:
             res = self.ctx.plan_q7(self.db.customer, self.db.orders, self.db.lineitem, self.db.supplier, self.db.nation)
+        elif q == 11:
+            res = self.ctx.plan_q11(self.db.partsupp, self.db.supplier, self.db.nation)
         elif q == 9:
             res = self.ctx.plan_q9(self.db.part, self.db.supplier, self.db.lineitem, self.db.partsupp, self.db.orders, self.db.nation)
         else:
