@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 // ---------------------------------------------------------------- errors
@@ -78,6 +79,14 @@ struct ldb_ctx {
    // small pinned staging area for counts read back from the device
    int64_t* h_scratch = nullptr; // pinned, 64 words
    int64_t* d_scratch = nullptr; // device, 64 words
+   // Block cache in front of the stream-ordered pool (ldb_dev_alloc / ldb_dev_free): every operator
+   // call allocates ~10 temporaries, and a hipMallocAsync + hipFreeAsync pair costs ~15 µs of host
+   // time — more than many of the kernels between them.  All work of a context is ordered on
+   // ctx->stream, so a freed block may be handed to the next allocation without any wait.
+   bool cache_on = true;
+   size_t cache_bytes = 0, cache_cap = 0; // bytes parked in free lists / their limit
+   std::unordered_map<void*, size_t> live; // block → its size class (bytes)
+   std::unordered_map<size_t, std::vector<void*>> parked; // size class → free blocks
 };
 
 struct ldb_table {

@@ -167,16 +167,25 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
    // KEY32: slots in key order (see DJoin::ordered_slots) — needs the build key range first
    static const bool ordered_enabled = !(getenv("LDB_JOIN_ORDERED") && getenv("LDB_JOIN_ORDERED")[0] == '0');
    if (ht->key32 && ordered_enabled && build->n_rows > 0) {
-      long long* range = (long long*) (ctx->d_scratch + 32);
-      const long long init[2] = {INT64_MAX, INT64_MIN};
-      LDB_HIP(hipMemcpyAsync(range, init, 16, hipMemcpyHostToDevice, ctx->stream));
-      DJoin* dr;
-      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dr));
-      hipLaunchKernelGGL(k_join_key_range, dim3(std::min(ldb_grid_for(ctx, build->n_rows, 256, 8), 256)), dim3(256), 0, ctx->stream, dr, range);
       long long got[2];
-      LDB_HIP(hipMemcpyAsync(got, range, 16, hipMemcpyDeviceToHost, ctx->stream));
-      LDB_HIP(hipStreamSynchronize(ctx->stream));
-      ldb_dev_free(ctx, dr);
+      // the key column's cached statistic (a superset of the build rows' range, free after its first
+      // use) when it has one; otherwise one pass over the build keys
+      const ldb_table* kt = build->sides[(size_t) keys[0].side].table;
+      int64_t clo = 0, chi = -1;
+      if (!kt->cols[(size_t) keys[0].col].validity && ldb_column_range(ctx, kt, keys[0].col, &clo, &chi) == LDB_OK && clo <= chi) {
+         got[0] = clo;
+         got[1] = chi;
+      } else {
+         long long* range = (long long*) (ctx->d_scratch + 32);
+         const long long init[2] = {INT64_MAX, INT64_MIN};
+         LDB_HIP(hipMemcpyAsync(range, init, 16, hipMemcpyHostToDevice, ctx->stream));
+         DJoin* dr;
+         LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dr));
+         hipLaunchKernelGGL(k_join_key_range, dim3(std::min(ldb_grid_for(ctx, build->n_rows, 256, 8), 256)), dim3(256), 0, ctx->stream, dr, range);
+         LDB_HIP(hipMemcpyAsync(got, range, 16, hipMemcpyDeviceToHost, ctx->stream));
+         LDB_HIP(hipStreamSynchronize(ctx->stream));
+         ldb_dev_free(ctx, dr);
+      }
       if (got[0] <= got[1]) { // at least one non-NULL key
          ht->ordered_slots = 1;
          ht->kmin = got[0];
