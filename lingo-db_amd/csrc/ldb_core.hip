@@ -74,7 +74,21 @@ void ldb_dev_free(ldb_ctx* ctx, void* p) {
 }
 int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_out) {
    LDB_TRY(ldb_dev_alloc(ctx, dev_out, bytes));
-   // pageable source: the runtime stages the bytes before returning, so `host` may be a local
+   // descriptors (a few KB) are staged through a pinned ring so that the copy is a plain async DMA
+   // (a pageable source makes the runtime stage it synchronously, ~10 µs per call); `host` may be a
+   // local either way.  A slot is reused only after the stream has drained (wrap → synchronize).
+   const size_t need = (bytes + 63) & ~(size_t) 63;
+   if (ctx->h_ring && need <= LDB_RING_BYTES / 8) {
+      if (ctx->ring_pos + need > LDB_RING_BYTES) {
+         LDB_HIP(hipStreamSynchronize(ctx->stream));
+         ctx->ring_pos = 0;
+      }
+      void* slot = ctx->h_ring + ctx->ring_pos;
+      ctx->ring_pos += need;
+      memcpy(slot, host, bytes);
+      LDB_HIP(hipMemcpyAsync(*dev_out, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+      return LDB_OK;
+   }
    LDB_HIP(hipMemcpyAsync(*dev_out, host, bytes, hipMemcpyHostToDevice, ctx->stream));
    return LDB_OK;
 }
@@ -114,6 +128,7 @@ extern "C" int32_t ldb_gpu_ctx_create(int32_t device_id, void* stream, ldb_ctx**
    size_t hbm_free = 0, hbm_total = 0;
    if (hipMemGetInfo(&hbm_free, &hbm_total) == hipSuccess) ctx->cache_cap = hbm_total / 4;
    LDB_HIP(hipHostMalloc((void**) &ctx->h_scratch, 64 * sizeof(int64_t), hipHostMallocDefault));
+   LDB_HIP(hipHostMalloc((void**) &ctx->h_ring, LDB_RING_BYTES, hipHostMallocDefault));
    LDB_HIP(hipMalloc((void**) &ctx->d_scratch, 64 * sizeof(int64_t)));
    *out = ctx.release();
    return LDB_OK;
@@ -130,6 +145,7 @@ extern "C" int32_t ldb_gpu_ctx_destroy(ldb_ctx* ctx) {
    }
    for (auto e : ctx->prof_free) (void) hipEventDestroy(e);
    if (ctx->h_scratch) (void) hipHostFree(ctx->h_scratch);
+   if (ctx->h_ring) (void) hipHostFree(ctx->h_ring);
    if (ctx->d_scratch) (void) hipFree(ctx->d_scratch);
    if (ctx->own_stream) (void) hipStreamDestroy(ctx->stream);
    delete ctx;

@@ -66,6 +66,7 @@ struct ldb_prof_total {
    int64_t launches = 0;
    double ms = 0;
 };
+#define LDB_RING_BYTES ((size_t) 1 << 20)
 struct ldb_ctx {
    bool prof_on = false;
    std::vector<ldb_prof_pending> prof_pending;
@@ -83,6 +84,8 @@ struct ldb_ctx {
    // call allocates ~10 temporaries, and a hipMallocAsync + hipFreeAsync pair costs ~15 µs of host
    // time — more than many of the kernels between them.  All work of a context is ordered on
    // ctx->stream, so a freed block may be handed to the next allocation without any wait.
+   uint8_t* h_ring = nullptr; // pinned staging ring of ldb_dev_upload
+   size_t ring_pos = 0;
    bool cache_on = true;
    size_t cache_bytes = 0, cache_cap = 0; // bytes parked in free lists / their limit
    std::unordered_map<void*, size_t> live; // block → its size class (bytes)

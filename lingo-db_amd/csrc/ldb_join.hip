@@ -499,19 +499,24 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
    r->n_rows = (int64_t) produced;
    const int cg = ldb_grid_for(ctx, (int64_t) produced, 256, 8);
    auto add_sides = [&](ldb_rel* src, uint32_t* sel) -> int32_t {
+      bool sel_taken = false; // the first identity side IS the selection vector: hand it over, no copy
       for (auto& s : src->sides) {
          ldb_rel_side ns{s.table, nullptr, true};
-         LDB_TRY(ldb_dev_alloc(ctx, (void**) &ns.rowids, 4 * (size_t) (produced ? produced : 1)));
-         if (produced) hipLaunchKernelGGL(k_compose_null, dim3(cg), dim3(256), 0, ctx->stream, (const uint32_t*) s.rowids, (const uint32_t*) sel, ns.rowids, produced);
+         if (!s.rowids && !sel_taken) {
+            ns.rowids = sel;
+            sel_taken = true;
+         } else {
+            LDB_TRY(ldb_dev_alloc(ctx, (void**) &ns.rowids, 4 * (size_t) (produced ? produced : 1)));
+            if (produced) hipLaunchKernelGGL(k_compose_null, dim3(cg), dim3(256), 0, ctx->stream, (const uint32_t*) s.rowids, (const uint32_t*) sel, ns.rowids, produced);
+         }
          r->sides.push_back(ns);
       }
+      if (!sel_taken) ldb_dev_free(ctx, sel);
       return LDB_OK;
    };
    LDB_TRY(add_sides(probe, op));
    LDB_TRY(add_sides(ht->build, ob));
    LDB_HIP(hipGetLastError());
-   ldb_dev_free(ctx, op);
-   ldb_dev_free(ctx, ob);
    *out = r;
    return LDB_OK;
 }
