@@ -143,14 +143,24 @@ __global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restri
    }
 }
 
-__global__ void k_pack_valid_bytes(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bitmap, uint64_t n) {
+// per-group validity bytes → Arrow bitmap; *nulls += number of zero bytes (one atomic per wave of a
+// bounded grid)
+__global__ void k_pack_valid_bytes(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bitmap, uint64_t n, unsigned long long* __restrict__ nulls) {
    uint64_t nb = (n + 7) / 8;
+   unsigned int zeros = 0;
    for (uint64_t b = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; b < nb; b += (uint64_t) gridDim.x * blockDim.x) {
       uint8_t m = 0;
       for (int k = 0; k < 8; k++)
-         if (b * 8 + k < n && bytes[b * 8 + k]) m |= (uint8_t) (1u << k);
+         if (b * 8 + k < n) {
+            if (bytes[b * 8 + k])
+               m |= (uint8_t) (1u << k);
+            else
+               zeros++;
+         }
       bitmap[b] = m;
    }
+   for (int off = 32; off > 0; off >>= 1) zeros += __shfl_down(zeros, off);
+   if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(nulls, (unsigned long long) zeros);
 }
 
 // ---------------------------------------------------------------- host side
@@ -592,6 +602,25 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       if (s != LDB_OK) return s;
    }
    ldb_gpu_rel_release(ctx, reps);
+   // pack the per-group validity bytes of nullable aggregates; the NULL counts of all of them come
+   // back in one read
+   unsigned long long* d_nulls = (unsigned long long*) (ctx->d_scratch + 48); // GB_MAX_OUT = 16 words
+   std::vector<uint8_t*> bitmaps((size_t) n_aggs, nullptr);
+   bool any_valid = false;
+   for (int32_t a = 0; a < n_aggs; a++) {
+      if (!out_valid[(size_t) a]) continue;
+      if (!any_valid) LDB_HIP(hipMemsetAsync(d_nulls, 0, 8 * GB_MAX_OUT, ctx->stream));
+      any_valid = true;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmaps[(size_t) a], (size_t) ((n_groups + 7) / 8 + 1)));
+      if (n_groups)
+         hipLaunchKernelGGL(k_pack_valid_bytes, dim3(ldb_grid_for(ctx, (int64_t) n_groups, 256, 4)), dim3(256), 0, ctx->stream, out_valid[(size_t) a], bitmaps[(size_t) a], n_groups,
+                            d_nulls + a);
+      ldb_dev_free(ctx, out_valid[(size_t) a]);
+   }
+   if (any_valid) {
+      LDB_HIP(hipMemcpyAsync(ctx->h_scratch, d_nulls, 8 * GB_MAX_OUT, hipMemcpyDeviceToHost, ctx->stream));
+      LDB_HIP(hipStreamSynchronize(ctx->stream));
+   }
    for (int32_t a = 0; a < n_aggs; a++) {
       ldb_column& c = res->cols[(size_t) (n_keys + a)];
       char nm[32];
@@ -602,22 +631,13 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       c.values = out_vals[(size_t) a];
       c.value_bytes = (int64_t) n_groups * c.width;
       c.owned = true;
-      if (out_valid[(size_t) a]) {
-         // pack the per-group validity bytes; drop the bitmap when nothing is NULL
-         uint8_t* bm;
-         LDB_TRY(ldb_dev_alloc(ctx, (void**) &bm, (size_t) ((n_groups + 7) / 8 + 1)));
-         if (n_groups) hipLaunchKernelGGL(k_pack_valid_bytes, dim3(ldb_grid_for(ctx, (int64_t) n_groups, 256, 4)), dim3(256), 0, ctx->stream, out_valid[(size_t) a], bm, n_groups);
-         std::vector<uint8_t> hb((size_t) (n_groups ? n_groups : 1));
-         if (n_groups) LDB_HIP(hipMemcpyAsync(hb.data(), out_valid[(size_t) a], (size_t) n_groups, hipMemcpyDeviceToHost, ctx->stream));
-         LDB_HIP(hipStreamSynchronize(ctx->stream));
-         int64_t nulls = 0;
-         for (uint64_t g = 0; g < n_groups; g++) nulls += hb[(size_t) g] ? 0 : 1;
-         ldb_dev_free(ctx, out_valid[(size_t) a]);
+      if (bitmaps[(size_t) a]) { // drop the bitmap when nothing is NULL
+         const int64_t nulls = ctx->h_scratch[a];
          if (nulls) {
-            c.validity = bm;
+            c.validity = bitmaps[(size_t) a];
             c.null_count = nulls;
          } else {
-            ldb_dev_free(ctx, bm);
+            ldb_dev_free(ctx, bitmaps[(size_t) a]);
          }
       }
    }
