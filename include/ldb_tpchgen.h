@@ -82,6 +82,7 @@ enum { P_PARTKEY = 0,
        P_SIZE,
        P_RETAILPRICE,
        P_NAME, /* five colour words separated by blanks (TPC-H spec 4.2.3: P_NAME) */
+       P_TYPE, /* three syllables, one from each of the TYPES lists (spec 4.2.2.13) */
        P_NCOLS };
 enum { S_SUPPKEY = 0,
        S_NATIONKEY,
@@ -267,6 +268,23 @@ static const char* const ldb_tpch_colors[LDB_TPCH_NCOLORS] = {
 LDB_HD int32_t ldb_tpch_p_name_word(int64_t part_idx, int32_t j) {
    return (int32_t) (ldb_rnd(LDB_TPCH_PART, P_NAME * 8 + j, (uint64_t) part_idx) % LDB_TPCH_NCOLORS);
 }
+
+/* p_type vocabulary: syllable 1 (6 words), syllable 2 (5), syllable 3 (5) in one list */
+#define LDB_TPCH_NTYPEWORDS 16
+#define LDB_TPCH_PTYPE_WORDS 3
+static const char* const ldb_tpch_typewords[LDB_TPCH_NTYPEWORDS] = {"STANDARD", "SMALL", "MEDIUM", "LARGE", "ECONOMY", "PROMO", "ANODIZED", "BURNISHED", "PLATED", "POLISHED",
+                                                                    "BRUSHED", "TIN", "NICKEL", "BRASS", "STEEL", "COPPER"};
+LDB_HD int32_t ldb_tpch_p_type_word(int64_t part_idx, int32_t j) {
+   const uint64_t r = ldb_rnd(LDB_TPCH_PART, P_TYPE * 8 + j, (uint64_t) part_idx);
+   return j == 0 ? (int32_t) (r % 6) : (j == 1 ? 6 + (int32_t) (r % 5) : 11 + (int32_t) (r % 5));
+}
+/* "word columns" (utf8 values made of blank-separated vocabulary words): words per value (0 = not
+ * a word column) and the vocabulary index of word j */
+LDB_HD int32_t ldb_tpch_wordcol_words(int32_t table, int32_t col) {
+   if (table != LDB_TPCH_PART) return 0;
+   return col == P_NAME ? LDB_TPCH_PNAME_WORDS : (col == P_TYPE ? LDB_TPCH_PTYPE_WORDS : 0);
+}
+LDB_HD int32_t ldb_tpch_wordcol_word(int32_t col, int64_t row, int32_t j) { return col == P_NAME ? ldb_tpch_p_name_word(row, j) : ldb_tpch_p_type_word(row, j); }
 
 LDB_HD int32_t ldb_tpch_c_segment_idx(int64_t cust_idx) {
    return (int32_t) (ldb_rnd(LDB_TPCH_CUSTOMER, C_MKTSEGMENT, (uint64_t) cust_idx) % LDB_TPCH_NSEG);

@@ -258,6 +258,17 @@ int32_t ldb_gpu_hash_keys(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* keys, int
  * attached to the relation with ldb_gpu_rel_zip. */
 typedef enum { LDB_FN_EXTRACT_YEAR = 0 /* date32 → int64 civil year */ } ldb_scalar_fn;
 int32_t ldb_gpu_map_column(ldb_ctx* ctx, ldb_rel* in, ldb_colref col, int32_t fn, const char* name, ldb_table** out);
+/* Arithmetic on aggregate results (a16): `literal * num / den` over two decimal or integer columns
+ * as one decimal128(out_precision, out_scale) column,
+ *    out = ((((num * mul) sdiv 10^mul_div_pow10) * 10^pow10) sdiv den   in wrapping 128-bit arithmetic,
+ * i.e. DecimalMulOpLowering (LowerToStd.cpp:653-677; mul_div_pow10 = sLit + sNum − sProduct, non-zero
+ * only when the product's scale was clamped) followed by DecimalOpScaledLowering (:631-651;
+ * pow10 = sRes + sDen − sProduct).  `mul` (mul_lo/mul_hi) is the literal as an integer at its own
+ * scale (1 for a plain division); the exponents and the result type come from the caller's type
+ * derivation (sql_analyzer.cpp:3083-3159).  NULL in → NULL out; den = 0 → NULL (undefined in the
+ * reference). */
+int32_t ldb_gpu_map_muldiv(ldb_ctx* ctx, ldb_rel* in, ldb_colref num, int64_t mul_lo, int64_t mul_hi, int32_t mul_div_pow10, int32_t pow10, ldb_colref den,
+                           int32_t out_precision, int32_t out_scale, const char* name, ldb_table** out);
 /* `in` extended by a table of exactly ldb_gpu_rel_rows(in) rows as a new LAST side (identity row
  * ids); the table must outlive the relation. */
 int32_t ldb_gpu_rel_zip(ldb_ctx* ctx, ldb_rel* in, const ldb_table* t, ldb_rel** out);

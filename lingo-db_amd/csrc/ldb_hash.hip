@@ -98,6 +98,60 @@ extern "C" int32_t ldb_gpu_map_column(ldb_ctx* ctx, ldb_rel* in, ldb_colref col,
    return LDB_OK;
 }
 
+// literal * num / den over decimal (or integer) columns, e.g. Q14's 100.00 * sum(..) / sum(..):
+// DecimalMulOpLowering (reference LowerToStd.cpp:653-677) then DecimalOpScaledLowering (:631-651),
+//   out = ((((num * mul) sdiv 10^mul_div) * 10^pow10) sdiv den   in wrapping 128-bit arithmetic.
+__global__ void k_map_muldiv(DCol num, DCol den, i128 mul, int mul_div, int pow10, uint64_t n, i128* __restrict__ out, uint8_t* __restrict__ valid_bytes) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      const uint32_t rn = d_phys_row(num, i), rd = d_phys_row(den, i);
+      bool ok = d_valid(num, rn) && d_valid(den, rd);
+      i128 v = 0;
+      if (ok) {
+         const i128 d = d_load_i128(den, rd);
+         if (d == 0) {
+            ok = false; // the reference's sdiv by zero is undefined; NULL here
+         } else {
+            i128 prod = (i128) ((u128) d_load_i128(num, rn) * (u128) mul);
+            if (mul_div > 0) prod = d_sdiv128(prod, d_pow10(mul_div));
+            v = d_sdiv128((i128) ((u128) prod * (u128) d_pow10(pow10)), d);
+         }
+      }
+      out[i] = v;
+      valid_bytes[i] = ok ? 1 : 0;
+   }
+}
+extern "C" int32_t ldb_gpu_map_muldiv(ldb_ctx* ctx, ldb_rel* in, ldb_colref num, int64_t mul_lo, int64_t mul_hi, int32_t mul_div_pow10, int32_t pow10, ldb_colref den,
+                                      int32_t out_precision, int32_t out_scale, const char* name, ldb_table** out) {
+   if (!ctx || !in || !out) LDB_FAIL(LDB_ERR_INVALID, "map_muldiv: NULL argument");
+   if (pow10 < 0 || pow10 > 38 || mul_div_pow10 < 0 || mul_div_pow10 > 38) LDB_FAIL(LDB_ERR_INVALID, "map_muldiv: exponents %d, %d", mul_div_pow10, pow10);
+   LDB_TRY(ldb_rel_force(ctx, in));
+   DCol dn, dd;
+   LDB_TRY(ldb_make_dcol(in, num, &dn));
+   LDB_TRY(ldb_make_dcol(in, den, &dd));
+   auto numeric = [](const DCol& c) { return c.type == LDB_T_DECIMAL128 || c.type == LDB_T_INT64 || c.type == LDB_T_INT32 || c.type == LDB_T_INT16 || c.type == LDB_T_INT8; };
+   if (!numeric(dn) || !numeric(dd)) LDB_FAIL(LDB_ERR_INVALID, "map_muldiv: decimal or integer columns expected");
+   ldb_coltype t = {LDB_T_DECIMAL128, out_precision, out_scale, 0};
+   const char* nm = name ? name : "ratio";
+   ldb_table* res;
+   LDB_TRY(ldb_gpu_table_alloc(ctx, "mapped", 1, &t, &nm, in->n_rows, nullptr, 0, &res));
+   const int64_t n = in->n_rows;
+   uint8_t *vb, *bm;
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &vb, (size_t) (n ? n : 1)));
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &bm, (size_t) ((n + 7) / 8 + 1)));
+   const int grid = ldb_grid_for(ctx, n, 256, 8);
+   const i128 mul = (i128) (((u128) (uint64_t) mul_hi << 64) | (uint64_t) mul_lo);
+   if (n) {
+      hipLaunchKernelGGL(k_map_muldiv, dim3(grid), dim3(256), 0, ctx->stream, dn, dd, mul, (int) mul_div_pow10, (int) pow10, (uint64_t) n, (i128*) res->cols[0].values, vb);
+      hipLaunchKernelGGL(k_pack_bytes_to_bits, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*) vb, bm, (uint64_t) n);
+   }
+   res->cols[0].validity = bm;
+   res->cols[0].null_count = -1; // unknown (Arrow convention)
+   ldb_dev_free(ctx, vb);
+   LDB_HIP(hipGetLastError());
+   *out = res;
+   return LDB_OK;
+}
+
 // a relation extended by a dense table of exactly its row count (a computed column): the new side
 // is the last one, with identity row ids
 extern "C" int32_t ldb_gpu_rel_zip(ldb_ctx* ctx, ldb_rel* in, const ldb_table* t, ldb_rel** out) {

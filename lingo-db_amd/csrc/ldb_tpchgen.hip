@@ -139,21 +139,21 @@ struct ColorDomain {
    int32_t off[LDB_TPCH_NCOLORS + 1];
    char blob[704];
 };
-__global__ void k_gen_pname_lens(ColorDomain dom, int64_t row0, uint64_t n, int64_t* lens) {
+__global__ void k_gen_pname_lens(ColorDomain dom, int32_t col, int32_t words, int64_t row0, uint64_t n, int64_t* lens) {
    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-      int64_t len = LDB_TPCH_PNAME_WORDS - 1;
-      for (int j = 0; j < LDB_TPCH_PNAME_WORDS; j++) {
-         int32_t k = ldb_tpch_p_name_word(row0 + (int64_t) i, j);
+      int64_t len = words - 1;
+      for (int j = 0; j < words; j++) {
+         int32_t k = ldb_tpch_wordcol_word(col, row0 + (int64_t) i, j);
          len += dom.off[k + 1] - dom.off[k];
       }
       lens[i] = len;
    }
 }
-__global__ void k_gen_pname_fill(ColorDomain dom, int64_t row0, uint64_t n, const int64_t* offs, char* out) {
+__global__ void k_gen_pname_fill(ColorDomain dom, int32_t col, int32_t words, int64_t row0, uint64_t n, const int64_t* offs, char* out) {
    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
       int64_t o = offs[i];
-      for (int j = 0; j < LDB_TPCH_PNAME_WORDS; j++) {
-         int32_t k = ldb_tpch_p_name_word(row0 + (int64_t) i, j);
+      for (int j = 0; j < words; j++) {
+         int32_t k = ldb_tpch_wordcol_word(col, row0 + (int64_t) i, j);
          if (j) out[o++] = ' ';
          for (int32_t b = dom.off[k]; b < dom.off[k + 1]; b++) out[o++] = dom.blob[b];
       }
@@ -182,7 +182,7 @@ struct ColDef {
 static const ColDef LINEITEM_COLS[L_NCOLS] = {{"l_orderkey", CT_I32}, {"l_partkey", CT_I32}, {"l_suppkey", CT_I32}, {"l_linenumber", CT_I32}, {"l_quantity", CT_DEC}, {"l_extendedprice", CT_DEC}, {"l_discount", CT_DEC}, {"l_tax", CT_DEC}, {"l_returnflag", CT_CH}, {"l_linestatus", CT_CH}, {"l_shipdate", CT_DATE}, {"l_commitdate", CT_DATE}, {"l_receiptdate", CT_DATE}, {"l_shipinstruct", CT_STR}, {"l_shipmode", CT_STR}};
 static const ColDef ORDERS_COLS[O_NCOLS] = {{"o_orderkey", CT_I32}, {"o_custkey", CT_I32}, {"o_orderstatus", CT_CH}, {"o_totalprice", CT_DEC}, {"o_orderdate", CT_DATE}, {"o_orderpriority", CT_STR}, {"o_shippriority", CT_I32}};
 static const ColDef CUSTOMER_COLS[C_NCOLS] = {{"c_custkey", CT_I32}, {"c_nationkey", CT_I32}, {"c_acctbal", CT_DEC}, {"c_mktsegment", CT_STR}, {"c_name", CT_STR}};
-static const ColDef PART_COLS[P_NCOLS] = {{"p_partkey", CT_I32}, {"p_size", CT_I32}, {"p_retailprice", CT_DEC}, {"p_name", CT_STR}};
+static const ColDef PART_COLS[P_NCOLS] = {{"p_partkey", CT_I32}, {"p_size", CT_I32}, {"p_retailprice", CT_DEC}, {"p_name", CT_STR}, {"p_type", CT_STR}};
 static const ColDef SUPPLIER_COLS[S_NCOLS] = {{"s_suppkey", CT_I32}, {"s_nationkey", CT_I32}, {"s_acctbal", CT_DEC}};
 static const ColDef PARTSUPP_COLS[PS_NCOLS] = {{"ps_partkey", CT_I32}, {"ps_suppkey", CT_I32}, {"ps_availqty", CT_I32}, {"ps_supplycost", CT_DEC}};
 static const ColDef NATION_COLS[N_NCOLS] = {{"n_nationkey", CT_I32}, {"n_regionkey", CT_I32}, {"n_name", CT_STR}};
@@ -251,29 +251,32 @@ extern "C" int32_t ldb_gpu_tpch_generate(ldb_ctx* ctx, int32_t table_id, int64_t
          LDB_TRY(ldb_dev_alloc(ctx, &col.values, (size_t) col.value_bytes));
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &col.offsets, 8 * (size_t) (n + 1)));
          hipLaunchKernelGGL(k_gen_cname, dim3(grid), dim3(256), 0, ctx->stream, b, (uint64_t) n, col.offsets, (char*) col.values);
-      } else if (col.type.type == LDB_T_UTF8 && table_id == LDB_TPCH_PART && c == P_NAME) {
+      } else if (col.type.type == LDB_T_UTF8 && ldb_tpch_wordcol_words(table_id, c)) { // p_name, p_type
+         const int words = ldb_tpch_wordcol_words(table_id, c);
+         const char* const* vocab = c == P_NAME ? ldb_tpch_colors : ldb_tpch_typewords;
+         const int n_vocab = c == P_NAME ? LDB_TPCH_NCOLORS : LDB_TPCH_NTYPEWORDS;
          ColorDomain dom;
          memset(&dom, 0, sizeof(dom));
          int pos = 0;
-         for (int k = 0; k < LDB_TPCH_NCOLORS; k++) {
+         for (int k = 0; k < n_vocab; k++) {
             dom.off[k] = pos;
-            size_t len = strlen(ldb_tpch_colors[k]);
-            if (pos + len > sizeof(dom.blob)) LDB_FAIL(LDB_ERR_INVALID, "tpch_generate: colour vocabulary exceeds its buffer");
-            memcpy(dom.blob + pos, ldb_tpch_colors[k], len);
+            size_t len = strlen(vocab[k]);
+            if (pos + len > sizeof(dom.blob)) LDB_FAIL(LDB_ERR_INVALID, "tpch_generate: vocabulary exceeds its buffer");
+            memcpy(dom.blob + pos, vocab[k], len);
             pos += (int) len;
          }
-         dom.off[LDB_TPCH_NCOLORS] = pos;
+         dom.off[n_vocab] = pos;
          int64_t* lens;
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &lens, 8 * (size_t) (n + 1)));
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &col.offsets, 8 * (size_t) (n + 1)));
-         if (n) hipLaunchKernelGGL(k_gen_pname_lens, dim3(grid), dim3(256), 0, ctx->stream, dom, b, (uint64_t) n, lens);
+         if (n) hipLaunchKernelGGL(k_gen_pname_lens, dim3(grid), dim3(256), 0, ctx->stream, dom, (int32_t) c, (int32_t) words, b, (uint64_t) n, lens);
          LDB_TRY(ldb_exclusive_scan_i64(ctx, lens, col.offsets, n, col.offsets + n));
          uint64_t total = 0;
          LDB_TRY(ldb_read_u64(ctx, col.offsets + n, &total));
          ldb_dev_free(ctx, lens);
          col.value_bytes = (int64_t) total;
          LDB_TRY(ldb_dev_alloc(ctx, &col.values, (size_t) total));
-         if (n) hipLaunchKernelGGL(k_gen_pname_fill, dim3(grid), dim3(256), 0, ctx->stream, dom, b, (uint64_t) n, (const int64_t*) col.offsets, (char*) col.values);
+         if (n) hipLaunchKernelGGL(k_gen_pname_fill, dim3(grid), dim3(256), 0, ctx->stream, dom, (int32_t) c, (int32_t) words, b, (uint64_t) n, (const int64_t*) col.offsets, (char*) col.values);
       } else if (col.type.type == LDB_T_UTF8) {
          const char* const* strs = domain_strings(table_id, c);
          StrDomain dom;

@@ -1299,6 +1299,73 @@ extern "C" int32_t ldb_plan_tpch_q11(ldb_ctx* ctx, const ldb_table* ps, const ld
    return s;
 }
 
+// ---------------------------------------------------------------- TPC-H Q14 (resources/sql/tpch/14.sql)
+// 100.00 * sum(case when p_type like 'PROMO%' then rev else 0 end) / sum(rev) over one month of
+// lineitem ⋈ part.  Pieces: q14_promo (keys of the PROMO parts: LIKE runs once per part, not per
+// lineitem) → [all-gather] → q14_local (lineitem of the month ⋈ part keys; the CASE is a left outer
+// join with the promo keys + a NOT NULL condition on its key) → [all-gather of the two partial
+// sums] → q14_final (add, then the literal·sum/sum arithmetic of ldb_gpu_map_muldiv).
+// Types: rev decimal(33,4) (as Q3); 100.00 is decimal(5,2); product decimal(38,6); quotient
+// typeAfterDiv → decimal(38,6), scaled by 10^(6 + 4 − 6).
+extern "C" int32_t ldb_plan_tpch_q14_promo(ldb_ctx* ctx, const ldb_table* part, ldb_table** result) {
+   return guarded([&] {
+      Rel p0(ctx), p1(ctx);
+      check(ldb_gpu_rel_from_table(ctx, part, &p0.r), "q14 part");
+      LikePred promo({0, colOf(part, "p_type")}, "PROMO%");
+      check(ldb_gpu_scan_filter(ctx, p0.r, &promo.d, 1, &p1.r), "q14 filter part");
+      ldb_colref key{0, colOf(part, "p_partkey")};
+      check(ldb_gpu_materialize(ctx, p1.r, &key, 1, result), "q14 materialize promo keys");
+   });
+}
+// `partkeys`: any table with a p_partkey column holding every part key (the part table itself, or
+// its replicated key column); result: one row (SUM(promo rev), SUM(rev))
+extern "C" int32_t ldb_plan_tpch_q14_local(ldb_ctx* ctx, const ldb_table* promokeys, const ldb_table* partkeys, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel pr0(ctx), pk0(ctx), l0(ctx), l1(ctx), lp(ctx), lpp(ctx);
+      check(ldb_gpu_rel_from_table(ctx, promokeys, &pr0.r), "q14 promo keys");
+      check(ldb_gpu_rel_from_table(ctx, partkeys, &pk0.r), "q14 part keys");
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q14 lineitem");
+      auto rl = Restrictions::create({{"l_shipdate", FilterOp::GTE, std::string("1995-09-01"), {}}, {"l_shipdate", FilterOp::LT, std::string("1995-10-01"), {}}}, li);
+      check(ldb_gpu_scan_filter(ctx, l0.r, rl->data(), rl->size(), &l1.r), "q14 filter lineitem");
+      Ht hp(ctx), hpromo(ctx);
+      ldb_colref pk{0, colOf(partkeys, "p_partkey")}, prk{0, 0}, lpk{0, colOf(li, "l_partkey")};
+      check(ldb_gpu_join_build(ctx, pk0.r, &pk, 1, 1, &hp.h), "q14 build part");
+      check(ldb_gpu_join_probe(ctx, hp.h, l1.r, &lpk, 1, LDB_JOIN_SEMI, &lp.r, nullptr), "q14 lineitem with a part"); // p_partkey is a key: the join adds no rows
+      check(ldb_gpu_join_build(ctx, pr0.r, &prk, 1, 1, &hpromo.h), "q14 build promo keys");
+      check(ldb_gpu_join_probe(ctx, hpromo.h, lp.r, &lpk, 1, LDB_JOIN_LEFT_OUTER, &lpp.r, nullptr), "q14 mark promo lines"); // sides: lineitem, promo keys
+      ldb_colref ext{0, colOf(li, "l_extendedprice")}, disc{0, colOf(li, "l_discount")};
+      DecimalType t1md;
+      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, decOf(li, disc.col), &t1md);
+      DecimalType tRev = typeAfterMul(decOf(li, ext.col), t1md);
+      ldb_agg_spec aggs[2] = {sumDec(product({colFactor(ext), oneMinusDisc}), tRev), sumDec(product({colFactor(ext), oneMinusDisc}), tRev)};
+      aggs[0].n_preds = 1;
+      memset(&aggs[0].preds[0], 0, sizeof(ldb_filter_desc));
+      aggs[0].preds[0].col = {1, 0};
+      aggs[0].preds[0].op = LDB_F_NOTNULL;
+      check(ldb_gpu_groupby(ctx, lpp.r, nullptr, 0, nullptr, 0, aggs, 2, 1, result), "q14 partial sums");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q14_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result) {
+   return guarded([&] {
+      Rel in(ctx), s0(ctx);
+      check(ldb_gpu_rel_from_table(ctx, partials, &in.r), "q14 final");
+      ldb_agg_spec aggs[2] = {sumOfCol(partials, 0), sumOfCol(partials, 1)};
+      Table sums(ctx);
+      check(ldb_gpu_groupby(ctx, in.r, nullptr, 0, nullptr, 0, aggs, 2, 1, &sums.t), "q14 add partials");
+      check(ldb_gpu_rel_from_table(ctx, sums.t, &s0.r), "q14 sums");
+      const DecimalType tSum = decOf(partials, 0), lit{5, 2}; // 100.00
+      const DecimalType tMul = typeAfterMul(lit, tSum), tDiv = typeAfterDiv(tMul, tSum);
+      check(ldb_gpu_map_muldiv(ctx, s0.r, {0, 0}, 10000, 0, lit.s + tSum.s - tMul.s, tDiv.s + tSum.s - tMul.s, {0, 1}, tDiv.p, tDiv.s, "promo_revenue", result), "q14 ratio");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q14(ldb_ctx* ctx, const ldb_table* part, const ldb_table* li, ldb_table** result) {
+   Table promo(ctx), partial(ctx);
+   int32_t s = ldb_plan_tpch_q14_promo(ctx, part, &promo.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q14_local(ctx, promo.t, part, li, &partial.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q14_final(ctx, partial.t, result);
+   return s;
+}
+
 // ---------------------------------------------------------------- C hooks for the host-logic tests
 extern "C" int32_t ldb_host_parse_date32(const char* s, int32_t* out) {
    return guarded([&] { *out = parseDate32(s); });

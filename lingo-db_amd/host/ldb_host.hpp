@@ -98,6 +98,11 @@ int32_t ldb_plan_tpch_q11_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table**
 int32_t ldb_plan_tpch_q11_total(ldb_ctx* ctx, const ldb_table* groups, ldb_table** result);
 int32_t ldb_plan_tpch_q11_filter(ldb_ctx* ctx, const ldb_table* groups, const ldb_table* totals, ldb_table** result);
 int32_t ldb_plan_tpch_q11_sort(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
+// Q14 and its pieces (promo part keys → [all-gather] → local partial sums → [all-gather] → final ratio)
+int32_t ldb_plan_tpch_q14(ldb_ctx* ctx, const ldb_table* part, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q14_promo(ldb_ctx* ctx, const ldb_table* part, ldb_table** result);
+int32_t ldb_plan_tpch_q14_local(ldb_ctx* ctx, const ldb_table* promokeys, const ldb_table* partkeys, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q14_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
 const char* ldb_plan_last_error(void);
 // multi-GPU pieces: shard-local partial plans + merges of the exchanged partial tables
 int32_t ldb_plan_tpch_q1_partial(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);

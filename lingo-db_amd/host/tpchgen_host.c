@@ -56,7 +56,7 @@ static void put_dec(void* out, int64_t i, int64_t v) {
 static int col_kind(int32_t table, int32_t col) {
    if (ldb_tpch_str_domain(table, col)) return 2;
    if (table == LDB_TPCH_CUSTOMER && col == C_NAME) return 2;
-   if (table == LDB_TPCH_PART && col == P_NAME) return 2;
+   if (ldb_tpch_wordcol_words(table, col)) return 2;
    switch (table) {
       case LDB_TPCH_LINEITEM: return (col >= L_QUANTITY && col <= L_TAX) ? 1 : 0;
       case LDB_TPCH_ORDERS: return col == O_TOTALPRICE ? 1 : 0;
@@ -83,12 +83,14 @@ int64_t ldb_tpch_host_column(int32_t table, int32_t col, int64_t n_orders, int32
       if (bytes) *bytes = n * LDB_TPCH_CNAME_LEN;
       return n;
    }
-   if (kind == 2 && table == LDB_TPCH_PART && col == P_NAME) {
+   if (kind == 2 && ldb_tpch_wordcol_words(table, col)) { /* p_name, p_type */
+      const int words = ldb_tpch_wordcol_words(table, col);
+      const char* const* vocab = col == P_NAME ? ldb_tpch_colors : ldb_tpch_typewords;
       int64_t pos = 0;
       for (int64_t i = 0; i < n; i++) {
          if (offsets_out) offsets_out[i] = pos;
-         for (int j = 0; j < LDB_TPCH_PNAME_WORDS; j++) {
-            const char* w = ldb_tpch_colors[ldb_tpch_p_name_word(b + i, j)];
+         for (int j = 0; j < words; j++) {
+            const char* w = vocab[ldb_tpch_wordcol_word(col, b + i, j)];
             size_t len = strlen(w);
             if (j) {
                if (out) ((char*) out)[pos] = ' ';

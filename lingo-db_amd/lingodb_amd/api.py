@@ -280,6 +280,17 @@ class Rel:
         check(self.ctx.lib.ldb_gpu_map_column(self.ctx.h, self.h, colref(*col), fn, name.encode(), C.byref(t)))
         return Table(self.ctx, t)
 
+    def map_muldiv(self, num, den, mul=1, mul_div_pow10=0, pow10=0, precision=38, scale=6, name="ratio"):
+        """decimal `mul * num / den` per row as a new 1-column decimal128(precision, scale) table:
+        ((num * mul) sdiv 10^mul_div_pow10) * 10^pow10 sdiv den in wrapping 128-bit arithmetic"""
+        t = C.c_void_p()
+        m = int(mul) & ((1 << 128) - 1)
+        lo, hi = m & ((1 << 64) - 1), m >> 64
+        lo = lo - (1 << 64) if lo >> 63 else lo
+        hi = hi - (1 << 64) if hi >> 63 else hi
+        check(self.ctx.lib.ldb_gpu_map_muldiv(self.ctx.h, self.h, colref(*num), lo, hi, mul_div_pow10, pow10, colref(*den), precision, scale, name.encode(), C.byref(t)))
+        return Table(self.ctx, t)
+
     def zip(self, table):
         """this relation plus `table` (same row count) as a new last side"""
         r = C.c_void_p()
@@ -487,6 +498,11 @@ class Context:
     def plan_q7(self, customer, orders, lineitem, supplier, nation):
         t = C.c_void_p()
         check_plan(capi.host_lib().ldb_plan_tpch_q7(self.h, customer.h, orders.h, lineitem.h, supplier.h, nation.h, C.byref(t)))
+        return Table(self, t)
+
+    def plan_q14(self, part, lineitem):
+        t = C.c_void_p()
+        check_plan(capi.host_lib().ldb_plan_tpch_q14(self.h, part.h, lineitem.h, C.byref(t)))
         return Table(self, t)
 
     def plan_q11(self, partsupp, supplier, nation):

@@ -173,6 +173,7 @@ GPU_API = {
     "ldb_gpu_hash_keys": (i32, [P, P, C.POINTER(ColRef), i32, PP]),
     "ldb_gpu_map_column": (i32, [P, P, ColRef, i32, C.c_char_p, PP]),
     "ldb_gpu_rel_zip": (i32, [P, P, P, PP]),
+    "ldb_gpu_map_muldiv": (i32, [P, P, ColRef, i64, i64, i32, i32, ColRef, i32, i32, C.c_char_p, PP]),
     "ldb_gpu_groupby": (i32, [P, P, C.POINTER(FilterDesc), i32, C.POINTER(ColRef), i32, C.POINTER(AggSpec), i32, i64, PP]),
     "ldb_gpu_join_build": (i32, [P, P, C.POINTER(ColRef), i32, i32, PP]),
     "ldb_gpu_hashtable_release": (i32, [P, P]),
@@ -202,6 +203,10 @@ HOST_API = {
     "ldb_plan_tpch_q7_suppliers": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q7_local": (i32, [P, P, P, P, P, PP]),
     "ldb_plan_tpch_q7_final": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q14": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q14_promo": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q14_local": (i32, [P, P, P, P, PP]),
+    "ldb_plan_tpch_q14_final": (i32, [P, P, PP]),
     "ldb_plan_tpch_q11": (i32, [P, P, P, P, PP]),
     "ldb_plan_tpch_q11_suppliers": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q11_groups": (i32, [P, P, P, PP]),

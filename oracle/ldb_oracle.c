@@ -300,6 +300,29 @@ int64_t ora_extract_year(int64_t days) {
    return yoe + era * 400 + (mp >= 10 ? 1 : 0);
 }
 
+/* literal * num / den on decimals (Q14's `100.00 * sum(..) / sum(..)`): DecimalMulOpLowering
+ * (LowerToStd.cpp:653-677: sign-extend to the result width, multiply, sdiv by 10^(sL+sR-sRes) when
+ * the result scale was clamped) followed by DecimalOpScaledLowering (:631-651:
+ * (left * 10^(sRes + sR - sL)) sdiv right).  128-bit wrapping arithmetic (result types with
+ * p >= 19); values as {lo, hi} words.  Returns 0 (no value) when den is 0: undefined there. */
+static i128 pow10_i128(int k) {
+   i128 r = 1;
+   while (k-- > 0) r *= 10;
+   return r;
+}
+int32_t ora_decimal_muldiv(const int64_t num[2], const int64_t mul[2], int32_t mul_div_pow10, int32_t pow10, const int64_t den[2], int64_t out[2]) {
+   i128 n = (i128) (((u128) (uint64_t) num[1] << 64) | (uint64_t) num[0]);
+   i128 m = (i128) (((u128) (uint64_t) mul[1] << 64) | (uint64_t) mul[0]);
+   i128 d = (i128) (((u128) (uint64_t) den[1] << 64) | (uint64_t) den[0]);
+   if (d == 0) return 0;
+   i128 prod = (i128) ((u128) n * (u128) m);
+   if (mul_div_pow10 > 0) prod = prod / pow10_i128(mul_div_pow10);
+   i128 q = (i128) ((u128) prod * (u128) pow10_i128(pow10)) / d;
+   out[0] = (int64_t) (uint64_t) q;
+   out[1] = (int64_t) (q >> 64);
+   return 1;
+}
+
 static int eval_pred(const ora_rel* r, const ldb_filter_desc* p, int64_t i) {
    const ora_col* c = rel_col(r, p->col);
    int64_t row;

@@ -191,6 +191,9 @@ class Oracle:
         lib.ora_like.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]
         lib.ora_extract_year.restype = C.c_int64
         lib.ora_extract_year.argtypes = [C.c_int64]
+        p64 = C.POINTER(C.c_int64)
+        lib.ora_decimal_muldiv.restype = C.c_int32
+        lib.ora_decimal_muldiv.argtypes = [p64, p64, C.c_int32, C.c_int32, p64, p64]
 
     # scalar
     def hash64(self, v):
@@ -283,6 +286,20 @@ class Oracle:
 
     def extract_year(self, days):
         return int(self.lib.ora_extract_year(int(days)))
+
+    def decimal_muldiv(self, num, mul, mul_div_pow10, pow10, den):
+        """((num * mul) sdiv 10^mul_div_pow10) * 10^pow10 sdiv den on 128-bit wrapping integers; None if den == 0"""
+
+        def words(v):
+            v &= (1 << 128) - 1
+            return (C.c_int64 * 2)(C.c_int64(v & ((1 << 64) - 1)).value, C.c_int64(v >> 64).value)
+
+        out = (C.c_int64 * 2)()
+        ok = self.lib.ora_decimal_muldiv(words(num), words(mul), mul_div_pow10, pow10, words(den), out)
+        if not ok:
+            return None
+        v = ((out[1] & ((1 << 64) - 1)) << 64) | (out[0] & ((1 << 64) - 1))
+        return v - (1 << 128) if v >> 127 else v
 
 
 def load():

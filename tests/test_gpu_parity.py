@@ -228,6 +228,41 @@ def test_map_column_extract_year_and_zip(ctx, oracle):
     assert got == exp
 
 
+def test_map_muldiv_vs_oracle(ctx, oracle):
+    """literal * a / b over decimal columns (arithmetic on aggregate results): device values = the
+    oracle's restatement of DecimalMulOpLowering + DecimalOpScaledLowering, bit-exact, including
+    negative operands (truncation toward zero), 128-bit wrap-around, NULL in → NULL, b = 0 → NULL"""
+    import decimal
+
+    rng = np.random.default_rng(14)
+    n = 4000
+    nums = [int(rng.integers(-10**17, 10**17)) * int(rng.integers(1, 10**12)) for _ in range(n)]
+    dens = [int(rng.integers(-10**9, 10**9)) * int(rng.integers(1, 10**6)) for _ in range(n)]
+    dens[5] = 0
+    dens[77] = 0
+    nulls_a, nulls_b = set(range(3, n, 41)), set(range(9, n, 53))
+    ctxd = decimal.Context(prec=60)
+    dec = lambda v, s: ctxd.create_decimal(v).scaleb(-s, ctxd)
+    t = pa.table({"a": pa.array([None if i in nulls_a else dec(v, 4) for i, v in enumerate(nums)], pa.decimal128(38, 4)),
+                  "b": pa.array([None if i in nulls_b else dec(v, 4) for i, v in enumerate(dens)], pa.decimal128(33, 4)),
+                  "c": pa.array(rng.integers(1, 1000, n).astype(np.int32))})
+    g = ctx.register("muldiv", t).rel()
+    for mul, mdiv, p10 in [(10000, 0, 4), (1, 0, 6), (-12345, 2, 4), (10**20, 0, 10)]:
+        got = g.map_muldiv((0, 0), (0, 1), mul=mul, mul_div_pow10=mdiv, pow10=p10, precision=38, scale=6).to_arrow()
+        assert got.schema.field(0).type == pa.decimal128(38, 6)
+        vals = [None if v is None else int(v.scaleb(6, ctxd)) for v in (x.as_py() for x in got.column(0))]
+        want = [None if (i in nulls_a or i in nulls_b) else oracle.decimal_muldiv(nums[i], mul, mdiv, p10, dens[i]) for i in range(n)]
+        assert want[5] is None and want[0] is not None
+        assert vals == want, (mul, mdiv, p10)
+    # an int32 divisor, through the row ids of a filtered relation
+    sel = g.scan_filter([api.pred((0, 2), capi.F_LT, 500)])
+    ids = sel.rowids(0)
+    got = sel.map_muldiv((0, 0), (0, 2), mul=1, pow10=2).to_arrow()
+    vals = [None if v is None else int(v.scaleb(6, ctxd)) for v in (x.as_py() for x in got.column(0))]
+    cs = t.column(2).to_pylist()
+    assert vals == [None if int(i) in nulls_a else oracle.decimal_muldiv(nums[int(i)], 1, 0, 2, cs[int(i)]) for i in ids]
+
+
 # ---------------------------------------------------------------- group-by (a9, a10, a11, a14, a16)
 def q1_aggs():
     f = api.factor

@@ -198,6 +198,31 @@ def test_q11(ctx):
     assert [r[1] for r in rows] == [r[1] for r in want] and sorted(rows) == sorted(want)
 
 
+def test_q14(ctx):
+    """promo revenue share: a LIKE prefix filter on part, the CASE as an outer join + NOT NULL
+    condition, and arithmetic on two aggregate results (100.00 * sum / sum with the reference's
+    decimal typing: decimal(38,6), integer division truncating toward zero) — against an integer
+    evaluation of resources/sql/tpch/14.sql"""
+    n = 400_000
+    T = tpch_data
+    li = T.host_table(T.LINEITEM, n, cols=[1, 5, 6, 10])
+    pt = T.host_table(T.PART, n, cols=[0, 4])
+    promo = {k for k, ty in zip(np_col(pt, "p_partkey").tolist(), np_col(pt, "p_type").tolist()) if ty.startswith("PROMO")}
+    assert 0 < len(promo) < pt.num_rows and all(len(ty.split(" ")) == 3 for ty in np_col(pt, "p_type").tolist()[:100])
+    a = b = 0
+    for pk, ext, disc, ship in zip(*[np_col(li, c).tolist() for c in ("l_partkey", "l_extendedprice", "l_discount", "l_shipdate")]):
+        if days("1995-09-01") <= ship < days("1995-10-01"):
+            rev = ext * (100 - disc)  # scale 4
+            b += rev
+            a += rev if pk in promo else 0
+    assert 0 < a < b
+    want = (a * 10000) * 10**4 // b  # (100.00 * a) at scale 6, then * 10^(6 + 4 - 6), sdiv b (all positive)
+    got = ctx.plan_q14(ctx.register("q14_part", pt), ctx.register("q14_li", li)).to_arrow()
+    assert got.num_rows == 1 and got.schema.field(0).type == pa.decimal128(38, 6) and got.schema.field(0).name == "promo_revenue"
+    assert result_rows(got) == [(want,)]
+    assert 10 * 10**6 < want < 25 * 10**6  # about one sixth of the revenue
+
+
 def test_q18(ctx, db):
     li, od, cu = db["li"], db["od"], db["cu"]
     lkey, qty = np_col(li, "l_orderkey"), np_col(li, "l_quantity")

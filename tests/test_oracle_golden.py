@@ -254,3 +254,24 @@ def test_extract_year_known_answers(oracle):
     for d in ["1970-01-01", "1969-12-31", "1992-01-01", "1995-12-31", "1996-02-29", "1998-08-02", "2000-03-01", "1900-03-01", "2400-02-29", "0001-01-01"]:
         day = (datetime.date.fromisoformat(d) - datetime.date(1970, 1, 1)).days
         assert oracle.extract_year(day) == int(d[:4]), d
+
+
+def test_decimal_muldiv_known_answers(oracle):
+    """literal * a / b on decimals (DecimalMulOpLowering + DecimalOpScaledLowering, LowerToStd.cpp:631-677):
+    hand-computed cases, C truncation toward zero, 128-bit wrap-around, the clamped-scale division."""
+    # 100.00 * 1.0000 / 3.0000 at result scale 6: ((10000 * 10000) * 10^4) / 30000
+    assert oracle.decimal_muldiv(10000, 10000, 0, 4, 30000) == 33333333
+    assert oracle.decimal_muldiv(-10000, 10000, 0, 4, 30000) == -33333333  # sdiv truncates toward zero
+    assert oracle.decimal_muldiv(10000, 10000, 0, 4, -30000) == -33333333
+    assert oracle.decimal_muldiv(20000, 10000, 0, 4, 30000) == 66666666  # 66.666666, not rounded
+    # product scale clamped by 2 digits: the product is divided by 10^2 first (and truncated there)
+    assert oracle.decimal_muldiv(12345, 999, 2, 4, 7) == ((12345 * 999) // 100) * 10**4 // 7
+    # plain division (mul = 1), AVG-like: 7.00 / 2 with pow10 = 4
+    assert oracle.decimal_muldiv(700, 1, 0, 4, 2) == 3500000
+    assert oracle.decimal_muldiv(5, 1, 0, 0, 0) is None  # division by zero has no value
+    # wrap-around: the scaled product does not fit 128 bits — the low 128 bits are divided (two's complement)
+    big = 10**30
+    wrapped = (big * 10**10) & ((1 << 128) - 1)
+    wrapped = wrapped - (1 << 128) if wrapped >> 127 else wrapped
+    want = abs(wrapped) // 3 * (1 if wrapped >= 0 else -1)
+    assert oracle.decimal_muldiv(big, 1, 0, 10, 3) == want

@@ -19,7 +19,7 @@ SCHEMAS = {
     ORDERS: [("o_orderkey", pa.int32()), ("o_custkey", pa.int32()), ("o_orderstatus", CH), ("o_totalprice", DEC),
              ("o_orderdate", pa.date32()), ("o_orderpriority", pa.string()), ("o_shippriority", pa.int32())],
     CUSTOMER: [("c_custkey", pa.int32()), ("c_nationkey", pa.int32()), ("c_acctbal", DEC), ("c_mktsegment", pa.string()), ("c_name", pa.string())],
-    PART: [("p_partkey", pa.int32()), ("p_size", pa.int32()), ("p_retailprice", DEC), ("p_name", pa.string())],
+    PART: [("p_partkey", pa.int32()), ("p_size", pa.int32()), ("p_retailprice", DEC), ("p_name", pa.string()), ("p_type", pa.string())],
     SUPPLIER: [("s_suppkey", pa.int32()), ("s_nationkey", pa.int32()), ("s_acctbal", DEC)],
     PARTSUPP: [("ps_partkey", pa.int32()), ("ps_suppkey", pa.int32()), ("ps_availqty", pa.int32()), ("ps_supplycost", DEC)],
     NATION: [("n_nationkey", pa.int32()), ("n_regionkey", pa.int32()), ("n_name", pa.string())],

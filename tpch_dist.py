@@ -216,4 +216,14 @@ def run_query(runner, q):
         totals = replicate(runner, _plan(ctx, "ldb_plan_tpch_q11_total", groups), "q11_totals")
         kept = _plan(ctx, "ldb_plan_tpch_q11_filter", groups, totals)
         return _plan(ctx, "ldb_plan_tpch_q11_sort", replicate(runner, kept, "q11_kept"))
+    if q == 14:
+        # lineitem is sharded by orders, part by rows: the PROMO part keys (1/6 of part) are all-gathered
+        # per query, the part key column (the inner join's build side) once; the two partial sums are
+        # added before the ratio is formed
+        if "part_keys_all" not in runner.cache:
+            kc = [c for c in range(db.part.n_cols) if db.part.col_name(c) == "p_partkey"][0]
+            runner.cache["part_keys_all"] = replicate(runner, db.part.rel().materialize([(0, kc)]), "part_keys_all")
+        promo = replicate(runner, _plan(ctx, "ldb_plan_tpch_q14_promo", db.part), "q14_promo")
+        part = _plan(ctx, "ldb_plan_tpch_q14_local", promo, runner.cache["part_keys_all"], db.lineitem)
+        return _plan(ctx, "ldb_plan_tpch_q14_final", replicate(runner, part, "q14_partials"))
     raise ValueError(f"TPC-H Q{q} has no multi-GPU plan yet")

@@ -40,6 +40,8 @@ class Database:
             lcols |= {L_ORDERKEY, 1, 2, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT}  # + l_partkey, l_suppkey
         if 5 in queries or 7 in queries:
             lcols |= {L_ORDERKEY, 2, L_EXTENDEDPRICE, L_DISCOUNT, L_SHIPDATE}  # + l_suppkey
+        if 14 in queries:
+            lcols |= {1, L_EXTENDEDPRICE, L_DISCOUNT, L_SHIPDATE}  # + l_partkey
         lcols |= {L_EXTENDEDPRICE, L_SHIPDATE}  # hbm_ceiling() calibration scans
         self.lineitem = ctx.tpch_generate(LINEITEM, n_orders, rank, world, sorted(lcols), narrow)
         self.orders = self.customer = None
@@ -57,7 +59,8 @@ class Database:
         self.part = self.supplier = self.partsupp = self.nation = self.region = None
         if 9 in queries:
             ocols |= {O_ORDERKEY, O_ORDERDATE}
-            self.part = ctx.tpch_generate(PART, n_orders, rank, world, [0, 3], narrow)  # p_partkey, p_name
+        if 9 in queries or 14 in queries:  # p_partkey, [p_name,] [p_type]
+            self.part = ctx.tpch_generate(PART, n_orders, rank, world, [0] + ([3] if 9 in queries else []) + ([4] if 14 in queries else []), narrow)
         if 9 in queries or 11 in queries:  # ps_partkey, ps_suppkey, [ps_availqty,] ps_supplycost
             self.partsupp = ctx.tpch_generate(PARTSUPP, n_orders, rank, world, [0, 1, 2, 3] if 11 in queries else [0, 1, 3], narrow)
         if 5 in queries:
@@ -104,6 +107,8 @@ class Runner:
             res = self.ctx.plan_q5(self.db.customer, self.db.orders, self.db.lineitem, self.db.supplier, self.db.nation, self.db.region)
         elif q == 7:
             res = self.ctx.plan_q7(self.db.customer, self.db.orders, self.db.lineitem, self.db.supplier, self.db.nation)
+        elif q == 14:
+            res = self.ctx.plan_q14(self.db.part, self.db.lineitem)
         elif q == 11:
             res = self.ctx.plan_q11(self.db.partsupp, self.db.supplier, self.db.nation)
         elif q == 9:
