@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sf", type=float, default=100.0)
-    ap.add_argument("--queries", default="1,3,4,5,6,7,9,11,12,14,18", help="TPC-H queries of one step (all have single- and multi-GPU plans)")
+    ap.add_argument("--queries", default="1,3,4,5,6,7,8,9,11,12,14,18", help="TPC-H queries of one step (all have single- and multi-GPU plans)")
     ap.add_argument("--narrow-decimals", type=int, default=0)
     ap.add_argument("--cpu-sample-sf", type=float, default=1.0, help="scale of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()

@@ -1013,12 +1013,13 @@ extern "C" int32_t ldb_plan_tpch_q9_final(ldb_ctx* ctx, const ldb_table* partial
 //   q5_final: (gathered) partial sums ⋈ nation → GROUP BY n_name, ORDER BY revenue DESC
 namespace {
 // rows of `t` whose `nationCol` is a nation of region 'ASIA', as a table (keyCol, nationCol)
-void regionMembers(ldb_ctx* ctx, const ldb_table* t, const char* keyCol, const char* nationCol, const ldb_table* nat, const ldb_table* reg, ldb_table** result) {
+void regionMembers(ldb_ctx* ctx, const ldb_table* t, const char* keyCol, const char* nationCol, const ldb_table* nat, const ldb_table* reg, ldb_table** result,
+                   const char* regionName = "ASIA") {
    Rel r0(ctx), r1(ctx), n0(ctx), n1(ctx), t0(ctx), t1(ctx);
    check(ldb_gpu_rel_from_table(ctx, reg, &r0.r), "q5 region");
    check(ldb_gpu_rel_from_table(ctx, nat, &n0.r), "q5 nation");
    check(ldb_gpu_rel_from_table(ctx, t, &t0.r), "q5 dimension");
-   auto rr = Restrictions::create({{"r_name", FilterOp::EQ, std::string("ASIA"), {}}}, reg);
+   auto rr = Restrictions::create({{"r_name", FilterOp::EQ, std::string(regionName), {}}}, reg);
    check(ldb_gpu_scan_filter(ctx, r0.r, rr->data(), rr->size(), &r1.r), "q5 filter region");
    Ht hr(ctx), hn(ctx);
    ldb_colref rk{0, colOf(reg, "r_regionkey")}, nrk{0, colOf(nat, "n_regionkey")}, nk{0, colOf(nat, "n_nationkey")}, tn{0, colOf(t, nationCol)};
@@ -1363,6 +1364,97 @@ extern "C" int32_t ldb_plan_tpch_q14(ldb_ctx* ctx, const ldb_table* part, const 
    int32_t s = ldb_plan_tpch_q14_promo(ctx, part, &promo.t);
    if (s == LDB_OK) s = ldb_plan_tpch_q14_local(ctx, promo.t, part, li, &partial.t);
    if (s == LDB_OK) s = ldb_plan_tpch_q14_final(ctx, partial.t, result);
+   return s;
+}
+
+// ---------------------------------------------------------------- TPC-H Q8 (resources/sql/tpch/8.sql)
+// Market share of one nation's suppliers within a region, per order year, for one part type:
+// sum(case when n2.n_name = 'BRAZIL' then volume else 0 end) / sum(volume).  The part-type filter
+// keeps 1/150 of part, so lineitem is reduced by it first; orders (two years) probe the reduced
+// lineitem side; customers of the region are a semi join.  Pieces: q8_parts, q8_customers →
+// [all-gather] → q8_local (partial sums per year) → [all-gather] → q8_final (add, divide, order).
+extern "C" int32_t ldb_plan_tpch_q8_parts(ldb_ctx* ctx, const ldb_table* part, ldb_table** result) {
+   return guarded([&] {
+      Rel p0(ctx), p1(ctx);
+      check(ldb_gpu_rel_from_table(ctx, part, &p0.r), "q8 part");
+      auto rp = Restrictions::create({{"p_type", FilterOp::EQ, std::string("ECONOMY ANODIZED STEEL"), {}}}, part);
+      check(ldb_gpu_scan_filter(ctx, p0.r, rp->data(), rp->size(), &p1.r), "q8 filter part");
+      ldb_colref key{0, colOf(part, "p_partkey")};
+      check(ldb_gpu_materialize(ctx, p1.r, &key, 1, result), "q8 materialize part keys");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q8_customers(ldb_ctx* ctx, const ldb_table* cust, const ldb_table* nat, const ldb_table* reg, ldb_table** result) {
+   return guarded([&] { regionMembers(ctx, cust, "c_custkey", "c_nationkey", nat, reg, result, "AMERICA"); });
+}
+// partial result: (o_year, SUM(volume of the nation's suppliers), SUM(volume))
+extern "C" int32_t ldb_plan_tpch_q8_local(ldb_ctx* ctx, const ldb_table* partkeys, const ldb_table* custs, const ldb_table* supp, const ldb_table* ord, const ldb_table* li,
+                                          const ldb_table* nat, ldb_table** result) {
+   return guarded([&] {
+      Rel pk0(ctx), c0(ctx), s0(ctx), o0(ctx), o1(ctx), l0(ctx), n0(ctx), lp(ctx), ls(ctx), m0(ctx), om(ctx), omc(ctx), omn(ctx), withYear(ctx);
+      check(ldb_gpu_rel_from_table(ctx, partkeys, &pk0.r), "q8 part keys");
+      check(ldb_gpu_rel_from_table(ctx, custs, &c0.r), "q8 customers");
+      check(ldb_gpu_rel_from_table(ctx, supp, &s0.r), "q8 supplier");
+      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q8 orders");
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q8 lineitem");
+      check(ldb_gpu_rel_from_table(ctx, nat, &n0.r), "q8 nation");
+      Ht hp(ctx), hs(ctx), hm(ctx), hc(ctx), hn(ctx);
+      ldb_colref k0{0, 0}, lpk{0, colOf(li, "l_partkey")}, lsk{0, colOf(li, "l_suppkey")}, sk{0, colOf(supp, "s_suppkey")};
+      check(ldb_gpu_join_build(ctx, pk0.r, &k0, 1, 1, &hp.h), "q8 build part keys");
+      check(ldb_gpu_join_probe(ctx, hp.h, l0.r, &lpk, 1, LDB_JOIN_SEMI, &lp.r, nullptr), "q8 lineitem of the part type");
+      check(ldb_gpu_join_build(ctx, s0.r, &sk, 1, 1, &hs.h), "q8 build supplier");
+      check(ldb_gpu_join_probe(ctx, hs.h, lp.r, &lsk, 1, LDB_JOIN_INNER, &ls.r, nullptr), "q8 probe supplier"); // sides: lineitem, supplier
+      ldb_colref keep[4] = {{0, colOf(li, "l_orderkey")}, {0, colOf(li, "l_extendedprice")}, {0, colOf(li, "l_discount")}, {1, colOf(supp, "s_nationkey")}};
+      Table m(ctx), years(ctx);
+      check(ldb_gpu_materialize(ctx, ls.r, keep, 4, &m.t), "q8 materialize");
+      check(ldb_gpu_rel_from_table(ctx, m.t, &m0.r), "q8 rel");
+      auto ro = Restrictions::create({{"o_orderdate", FilterOp::GTE, std::string("1995-01-01"), {}}, {"o_orderdate", FilterOp::LTE, std::string("1996-12-31"), {}}}, ord);
+      check(ldb_gpu_scan_filter(ctx, o0.r, ro->data(), ro->size(), &o1.r), "q8 filter orders");
+      ldb_colref ook{0, colOf(ord, "o_orderkey")}, ock{0, colOf(ord, "o_custkey")}, msn{1, 3}, nk{0, colOf(nat, "n_nationkey")};
+      check(ldb_gpu_join_build(ctx, m0.r, &k0, 1, 0, &hm.h), "q8 build reduced lineitem");
+      check(ldb_gpu_join_probe(ctx, hm.h, o1.r, &ook, 1, LDB_JOIN_INNER, &om.r, nullptr), "q8 probe orders"); // sides: orders, m
+      check(ldb_gpu_join_build(ctx, c0.r, &k0, 1, 1, &hc.h), "q8 build customers");
+      check(ldb_gpu_join_probe(ctx, hc.h, om.r, &ock, 1, LDB_JOIN_SEMI, &omc.r, nullptr), "q8 customers of the region");
+      check(ldb_gpu_join_build(ctx, n0.r, &nk, 1, 1, &hn.h), "q8 build nation");
+      check(ldb_gpu_join_probe(ctx, hn.h, omc.r, &msn, 1, LDB_JOIN_INNER, &omn.r, nullptr), "q8 supplier nation"); // sides: orders, m, nation
+      check(ldb_gpu_map_column(ctx, omn.r, {0, colOf(ord, "o_orderdate")}, LDB_FN_EXTRACT_YEAR, "o_year", &years.t), "q8 extract year");
+      check(ldb_gpu_rel_zip(ctx, omn.r, years.t, &withYear.r), "q8 zip year"); // sides: orders, m, nation, year
+      ldb_colref ext{1, 1}, disc{1, 2};
+      DecimalType t1md;
+      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, decOf(m.t, 2), &t1md);
+      DecimalType tVol = typeAfterMul(decOf(m.t, 1), t1md);
+      ldb_agg_spec aggs[2] = {sumDec(product({colFactor(ext), oneMinusDisc}), tVol), sumDec(product({colFactor(ext), oneMinusDisc}), tVol)};
+      auto brazil = Restrictions::create({{"n_name", FilterOp::EQ, std::string("BRAZIL"), {}}}, nat, 2);
+      aggs[0].n_preds = 1;
+      aggs[0].preds[0] = brazil->data()[0];
+      ldb_colref key{3, 0};
+      check(ldb_gpu_groupby(ctx, withYear.r, nullptr, 0, &key, 1, aggs, 2, 8, result), "q8 partial groupby");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q8_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result) {
+   return guarded([&] {
+      Rel in(ctx), g(ctx), gz(ctx), sorted(ctx);
+      check(ldb_gpu_rel_from_table(ctx, partials, &in.r), "q8 final");
+      ldb_colref key{0, 0};
+      ldb_agg_spec aggs[2] = {sumOfCol(partials, 1), sumOfCol(partials, 2)};
+      Table grouped(ctx), share(ctx);
+      check(ldb_gpu_groupby(ctx, in.r, nullptr, 0, &key, 1, aggs, 2, 8, &grouped.t), "q8 add partials");
+      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q8 sums");
+      const DecimalType tSum = decOf(partials, 1), tDiv = typeAfterDiv(tSum, tSum);
+      check(ldb_gpu_map_muldiv(ctx, g.r, {0, 1}, 1, 0, 0, tDiv.s + tSum.s - tSum.s, {0, 2}, tDiv.p, tDiv.s, "mkt_share", &share.t), "q8 ratio");
+      check(ldb_gpu_rel_zip(ctx, g.r, share.t, &gz.r), "q8 zip ratio");
+      ldb_sort_spec spec{{0, 0}, 0, 0};
+      check(ldb_gpu_sort(ctx, gz.r, &spec, 1, &sorted.r), "q8 sort");
+      ldb_colref outc[2] = {{0, 0}, {1, 0}};
+      check(ldb_gpu_materialize(ctx, sorted.r, outc, 2, result), "q8 materialize");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q8(ldb_ctx* ctx, const ldb_table* part, const ldb_table* supp, const ldb_table* li, const ldb_table* ord, const ldb_table* cust,
+                                    const ldb_table* nat, const ldb_table* reg, ldb_table** result) {
+   Table parts(ctx), custs(ctx), partial(ctx);
+   int32_t s = ldb_plan_tpch_q8_parts(ctx, part, &parts.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q8_customers(ctx, cust, nat, reg, &custs.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q8_local(ctx, parts.t, custs.t, supp, ord, li, nat, &partial.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q8_final(ctx, partial.t, result);
    return s;
 }
 

@@ -103,6 +103,14 @@ int32_t ldb_plan_tpch_q14(ldb_ctx* ctx, const ldb_table* part, const ldb_table* 
 int32_t ldb_plan_tpch_q14_promo(ldb_ctx* ctx, const ldb_table* part, ldb_table** result);
 int32_t ldb_plan_tpch_q14_local(ldb_ctx* ctx, const ldb_table* promokeys, const ldb_table* partkeys, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q14_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
+// Q8 and its pieces (part keys, customers of the region → [all-gather] → local partial sums per year → [all-gather] → final)
+int32_t ldb_plan_tpch_q8(ldb_ctx* ctx, const ldb_table* part, const ldb_table* supplier, const ldb_table* lineitem, const ldb_table* orders, const ldb_table* customer,
+                         const ldb_table* nation, const ldb_table* region, ldb_table** result);
+int32_t ldb_plan_tpch_q8_parts(ldb_ctx* ctx, const ldb_table* part, ldb_table** result);
+int32_t ldb_plan_tpch_q8_customers(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* nation, const ldb_table* region, ldb_table** result);
+int32_t ldb_plan_tpch_q8_local(ldb_ctx* ctx, const ldb_table* partkeys, const ldb_table* custs, const ldb_table* supplier, const ldb_table* orders, const ldb_table* lineitem,
+                               const ldb_table* nation, ldb_table** result);
+int32_t ldb_plan_tpch_q8_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
 const char* ldb_plan_last_error(void);
 // multi-GPU pieces: shard-local partial plans + merges of the exchanged partial tables
 int32_t ldb_plan_tpch_q1_partial(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);

@@ -500,6 +500,11 @@ class Context:
         check_plan(capi.host_lib().ldb_plan_tpch_q7(self.h, customer.h, orders.h, lineitem.h, supplier.h, nation.h, C.byref(t)))
         return Table(self, t)
 
+    def plan_q8(self, part, supplier, lineitem, orders, customer, nation, region):
+        t = C.c_void_p()
+        check_plan(capi.host_lib().ldb_plan_tpch_q8(self.h, part.h, supplier.h, lineitem.h, orders.h, customer.h, nation.h, region.h, C.byref(t)))
+        return Table(self, t)
+
     def plan_q14(self, part, lineitem):
         t = C.c_void_p()
         check_plan(capi.host_lib().ldb_plan_tpch_q14(self.h, part.h, lineitem.h, C.byref(t)))

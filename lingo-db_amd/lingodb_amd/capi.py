@@ -203,6 +203,11 @@ HOST_API = {
     "ldb_plan_tpch_q7_suppliers": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q7_local": (i32, [P, P, P, P, P, PP]),
     "ldb_plan_tpch_q7_final": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q8": (i32, [P, P, P, P, P, P, P, P, PP]),
+    "ldb_plan_tpch_q8_parts": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q8_customers": (i32, [P, P, P, P, PP]),
+    "ldb_plan_tpch_q8_local": (i32, [P, P, P, P, P, P, P, PP]),
+    "ldb_plan_tpch_q8_final": (i32, [P, P, PP]),
     "ldb_plan_tpch_q14": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q14_promo": (i32, [P, P, PP]),
     "ldb_plan_tpch_q14_local": (i32, [P, P, P, P, PP]),

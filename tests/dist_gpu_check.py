@@ -24,7 +24,7 @@ def main():
     import tpch_plans
 
     n_orders = int(os.environ.get("LDB_CHECK_ORDERS", "150003"))  # enough orders for Q18's HAVING to keep some
-    queries = [1, 6, 3, 4, 12, 18, 9, 5, 7, 11, 14]
+    queries = [1, 6, 3, 4, 12, 18, 9, 5, 7, 11, 14, 8]
     ctx = ldb.Context(dev)
     db = tpch_plans.Database(ctx, n_orders, rank, world, queries, False)
     runner = tpch_plans.Runner(ctx, db, world, dist, torch)

@@ -223,6 +223,42 @@ def test_q14(ctx):
     assert 10 * 10**6 < want < 25 * 10**6  # about one sixth of the revenue
 
 
+def test_q8(ctx):
+    """eight-table join (two nation roles, region, a part-type equality filter), extract(year) as the
+    group key, a conditional sum on a joined string column and the per-group ratio of two sums
+    (decimal(38,6), truncating division) — against an integer evaluation of resources/sql/tpch/8.sql"""
+    n = 600_000
+    T = tpch_data
+    li = T.host_table(T.LINEITEM, n, cols=[0, 1, 2, 5, 6])
+    od = T.host_table(T.ORDERS, n, cols=[0, 1, 4])
+    cu = T.host_table(T.CUSTOMER, n, cols=[0, 1])
+    su = T.host_table(T.SUPPLIER, n, cols=[0, 1])
+    pt = T.host_table(T.PART, n, cols=[0, 4])
+    na = T.host_table(T.NATION, n, cols=[0, 1, 2])
+    re_ = T.host_table(T.REGION, n, cols=[0, 1])
+    parts = {k for k, ty in zip(np_col(pt, "p_partkey").tolist(), np_col(pt, "p_type").tolist()) if ty == "ECONOMY ANODIZED STEEL"}
+    assert parts
+    america = {k for k, nm in zip(np_col(re_, "r_regionkey").tolist(), np_col(re_, "r_name").tolist()) if nm == "AMERICA"}
+    nname = dict(zip(np_col(na, "n_nationkey").tolist(), np_col(na, "n_name").tolist()))
+    am_nations = {k for k, rk in zip(np_col(na, "n_nationkey").tolist(), np_col(na, "n_regionkey").tolist()) if rk in america}
+    am_cust = {k for k, nk in zip(np_col(cu, "c_custkey").tolist(), np_col(cu, "c_nationkey").tolist()) if nk in am_nations}
+    snat = {k: nname[nk] for k, nk in zip(np_col(su, "s_suppkey").tolist(), np_col(su, "s_nationkey").tolist())}
+    oinfo = {ok: (EPOCH + datetime.timedelta(days=int(d))).year for ok, ck, d in zip(np_col(od, "o_orderkey").tolist(), np_col(od, "o_custkey").tolist(), np_col(od, "o_orderdate").tolist())
+             if days("1995-01-01") <= d <= days("1996-12-31") and ck in am_cust}
+    num, den = collections.defaultdict(int), collections.defaultdict(int)
+    for ok, pk, sk, ext, disc in zip(*[np_col(li, c).tolist() for c in ("l_orderkey", "l_partkey", "l_suppkey", "l_extendedprice", "l_discount")]):
+        if pk in parts and ok in oinfo:
+            vol = ext * (100 - disc)
+            den[oinfo[ok]] += vol
+            num[oinfo[ok]] += vol if snat[sk] == "BRAZIL" else 0
+    want = [(y, num[y] * 10**6 // den[y]) for y in sorted(den)]
+    assert [y for y, _ in want] == [1995, 1996] and any(v > 0 for _, v in want)
+    reg = lambda name, t: ctx.register(name, t)
+    got = ctx.plan_q8(reg("q8_part", pt), reg("q8_su", su), reg("q8_li", li), reg("q8_od", od), reg("q8_cu", cu), reg("q8_na", na), reg("q8_re", re_)).to_arrow()
+    assert got.schema.field(1).type == pa.decimal128(38, 6) and got.schema.names == ["o_year", "mkt_share"]
+    assert result_rows(got) == want
+
+
 def test_q18(ctx, db):
     li, od, cu = db["li"], db["od"], db["cu"]
     lkey, qty = np_col(li, "l_orderkey"), np_col(li, "l_quantity")

@@ -226,4 +226,14 @@ def run_query(runner, q):
         promo = replicate(runner, _plan(ctx, "ldb_plan_tpch_q14_promo", db.part), "q14_promo")
         part = _plan(ctx, "ldb_plan_tpch_q14_local", promo, runner.cache["part_keys_all"], db.lineitem)
         return _plan(ctx, "ldb_plan_tpch_q14_final", replicate(runner, part, "q14_partials"))
+    if q == 8:
+        # the part keys of the type (1/150 of part) and the region's customers are all-gathered, the
+        # supplier table once; lineitem and orders are co-located, so the joins and the partial sums
+        # per year are shard-local
+        if "supplier_all" not in runner.cache:
+            runner.cache["supplier_all"] = replicate(runner, db.supplier, "supplier_all")
+        parts = replicate(runner, _plan(ctx, "ldb_plan_tpch_q8_parts", db.part), "q8_parts")
+        custs = replicate(runner, _plan(ctx, "ldb_plan_tpch_q8_customers", db.customer, db.nation, db.region), "q8_customers")
+        part = _plan(ctx, "ldb_plan_tpch_q8_local", parts, custs, runner.cache["supplier_all"], db.orders, db.lineitem, db.nation)
+        return _plan(ctx, "ldb_plan_tpch_q8_final", replicate(runner, part, "q8_partials"))
     raise ValueError(f"TPC-H Q{q} has no multi-GPU plan yet")

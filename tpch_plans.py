@@ -42,6 +42,8 @@ class Database:
             lcols |= {L_ORDERKEY, 2, L_EXTENDEDPRICE, L_DISCOUNT, L_SHIPDATE}  # + l_suppkey
         if 14 in queries:
             lcols |= {1, L_EXTENDEDPRICE, L_DISCOUNT, L_SHIPDATE}  # + l_partkey
+        if 8 in queries:
+            lcols |= {L_ORDERKEY, 1, 2, L_EXTENDEDPRICE, L_DISCOUNT}  # + l_partkey, l_suppkey
         lcols |= {L_EXTENDEDPRICE, L_SHIPDATE}  # hbm_ceiling() calibration scans
         self.lineitem = ctx.tpch_generate(LINEITEM, n_orders, rank, world, sorted(lcols), narrow)
         self.orders = self.customer = None
@@ -59,18 +61,18 @@ class Database:
         self.part = self.supplier = self.partsupp = self.nation = self.region = None
         if 9 in queries:
             ocols |= {O_ORDERKEY, O_ORDERDATE}
-        if 9 in queries or 14 in queries:  # p_partkey, [p_name,] [p_type]
-            self.part = ctx.tpch_generate(PART, n_orders, rank, world, [0] + ([3] if 9 in queries else []) + ([4] if 14 in queries else []), narrow)
+        if any(q in queries for q in (8, 9, 14)):  # p_partkey, [p_name,] [p_type]
+            self.part = ctx.tpch_generate(PART, n_orders, rank, world, [0] + ([3] if 9 in queries else []) + ([4] if 14 in queries or 8 in queries else []), narrow)
         if 9 in queries or 11 in queries:  # ps_partkey, ps_suppkey, [ps_availqty,] ps_supplycost
             self.partsupp = ctx.tpch_generate(PARTSUPP, n_orders, rank, world, [0, 1, 2, 3] if 11 in queries else [0, 1, 3], narrow)
-        if 5 in queries:
+        if 5 in queries or 8 in queries:
             ocols |= {O_ORDERKEY, O_CUSTKEY, O_ORDERDATE}
             ccols |= {C_CUSTKEY, 1}  # + c_nationkey
             self.region = ctx.tpch_generate(7, n_orders, rank, world, [0, 1], narrow)  # r_regionkey, r_name
         if 7 in queries:
             ocols |= {O_ORDERKEY, O_CUSTKEY}
             ccols |= {C_CUSTKEY, 1}  # + c_nationkey
-        if any(q in queries for q in (5, 7, 9, 11)):
+        if any(q in queries for q in (5, 7, 8, 9, 11)):
             self.supplier = ctx.tpch_generate(SUPPLIER, n_orders, rank, world, [0, 1], narrow)  # s_suppkey, s_nationkey
             self.nation = ctx.tpch_generate(NATION, n_orders, rank, world, [0, 1, 2], narrow)  # n_nationkey, n_regionkey, n_name
         if ocols:
@@ -109,6 +111,8 @@ class Runner:
             res = self.ctx.plan_q7(self.db.customer, self.db.orders, self.db.lineitem, self.db.supplier, self.db.nation)
         elif q == 14:
             res = self.ctx.plan_q14(self.db.part, self.db.lineitem)
+        elif q == 8:
+            res = self.ctx.plan_q8(self.db.part, self.db.supplier, self.db.lineitem, self.db.orders, self.db.customer, self.db.nation, self.db.region)
         elif q == 11:
             res = self.ctx.plan_q11(self.db.partsupp, self.db.supplier, self.db.nation)
         elif q == 9:
