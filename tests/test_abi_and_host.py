@@ -118,6 +118,11 @@ def test_decimal_typing_rules_q1_worked_example():
     assert dec_type(0, (12, 2), (12, 2)) == (24, 4)  # Q6 revenue
     assert dec_type(0, (38, 6), (38, 6)) == (38, 6)  # scale clamp: s > 6 and p - s > 32
     assert dec_type(1, (12, 2), (12, 2)) == (26, 14)
+    # Q14: 100.00 * sum(rev) / sum(rev); Q8: sum / sum; Q11: ps_supplycost * ps_availqty (int → decimal(19,0))
+    assert dec_type(0, (5, 2), (33, 4)) == (38, 6)
+    assert dec_type(1, (38, 6), (33, 4)) == (38, 6)  # raw (75,39): p - s = 36 > 32 and s > 6
+    assert dec_type(1, (33, 4), (33, 4)) == (38, 6)
+    assert dec_type(0, (12, 2), (19, 0)) == (31, 2)
 
 
 # ---------------------------------------------------------------- host generator invariants (include/ldb_tpchgen.h)
