@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py — TPC-H (synthetic, dbgen-shaped) on the MI355X-native LingoDB operator runtime.
 
-  python bench.py --gpus N --steps K --warmup W [--sf 100] [--queries 1,6,3,4,12,18]
+  python bench.py --gpus N --steps K --warmup W [--sf 100] [--queries 1,3,4,5,6,7,8,9,11,12,14,18]
 
-One "step" = one pass of the implemented TPC-H queries over the HBM-resident database.
+One "step" = one pass of the implemented TPC-H queries over the HBM-resident database, each query
+ending with its result rows handed to the host.
 N > 1: launched by torch.distributed.run, one rank per GPU; the database is sharded by order
 ranges (strong scaling: the total is SF `--sf`), partial results are merged over RCCL.
 Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
