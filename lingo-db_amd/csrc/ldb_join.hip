@@ -42,6 +42,7 @@ struct ldb_hashtable {
 // ---------------------------------------------------------------- ahead-of-time (generic) kernels
 __global__ void k_join_build(const DJoin* __restrict__ d) { join_build_body(*d, d); }
 __global__ void k_join_key_range(const DJoin* __restrict__ d, long long* __restrict__ out) { join_key_range_body(*d, d, out); }
+__global__ void k_join_key_bits(const DJoin* __restrict__ d) { join_key_bits_body(*d, d); }
 __global__ void k_join_probe_pairs(const DJoin* __restrict__ d) { join_probe_pairs_body(*d, d); }
 __global__ void k_join_probe_pairs_count(const DJoin* __restrict__ d) { join_probe_pairs_count_body(*d, d); }
 __global__ void k_join_probe_count(const DJoin* __restrict__ d) { join_probe_count_body(*d, d); }
@@ -221,6 +222,7 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
       h->next = (uint64_t) ht->next;
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+      if (build->n_rows && h->has_key_bits && h->ordered_slots) hipLaunchKernelGGL(k_join_key_bits, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d);
       if (build->n_rows) LDB_TRY(launch_join(ctx, h, d, ldb_grid_for(ctx, build->n_rows, 256, 8), "k_join_build", "k_join_build_spec", k_join_build));
       ldb_dev_free(ctx, d);
       uint64_t f = 0;

@@ -95,11 +95,7 @@ __device__ __forceinline__ void join_build_body(const DJoin& m, const DJoin* __r
       } else {
          word = (h & 0xFFFFFFFF00000000ull) | (uint64_t) ((uint32_t) i + 1u);
       }
-      uint64_t pos = d_join_slot(m, d, h, key, mask);
-      if (m.key32 && m.ordered_slots && m.has_key_bits) {
-         const uint64_t r = (uint64_t) (key - d->kmin);
-         atomicOr(gptr_mut<uint32_t>(d->key_bits) + (r >> 5), 1u << (r & 31));
-      }
+      uint64_t pos = d_join_slot(m, d, h, key, mask); // (the key bits are set by join_key_bits_body, a pass of its own)
       uint32_t steps = 0;
       if (m.chained) {
          // one slot per DISTINCT key; the rows of a key hang off it through next[] (push-front with a
@@ -170,6 +166,40 @@ __device__ __forceinline__ void join_key_range_body(const DJoin& m, const DJoin*
    if ((threadIdx.x & 63) == 0) {
       atomicMin(&out[0], lo);
       atomicMax(&out[1], hi);
+   }
+}
+
+// has_key_bits: set bit (key - kmin) for every build key.  Build sides are usually key-ordered
+// (a primary key column, or a filtered subset of one), so the lanes of a wave hit the same 32-bit
+// word: adjacent lanes with the same word OR their bits together first and only the first lane of
+// each run issues the atomic (32x fewer atomics on one address for a dense key column; any lane
+// order stays correct — a run split in two just issues two atomics).
+__device__ __forceinline__ void join_key_bits_body(const DJoin& m, const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows;
+   const KV bkeys(m.bkeys, d->bkeys);
+   const CV c = bkeys.col(0);
+   uint32_t* bits = gptr_mut<uint32_t>(d->key_bits);
+   const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+   for (uint64_t base = blockIdx.x * (uint64_t) blockDim.x; base < n; base += stride) { // uniform trip count per block
+      const uint64_t i = base + threadIdx.x;
+      unsigned long long w = ~0ull;
+      uint32_t v = 0;
+      if (i < n) {
+         const uint32_t row = d_phys_row(c, i);
+         if (d_valid(c, row)) {
+            const uint64_t r = (uint64_t) (d_load_i64(c, row) - d->kmin);
+            w = r >> 5;
+            v = 1u << (r & 31);
+         }
+      }
+      for (int off = 1; off < 64; off <<= 1) { // a run may span the whole wave (duplicate keys)
+         const unsigned long long w2 = __shfl_down(w, off);
+         const uint32_t v2 = __shfl_down(v, off);
+         if (w2 == w) v |= v2; // (past the end of the wave __shfl_down returns the lane's own value)
+      }
+      const unsigned long long wprev = __shfl_up(w, 1);
+      const bool leader = (threadIdx.x & 63) == 0 || wprev != w;
+      if (leader && w != ~0ull) atomicOr(bits + w, v);
    }
 }
 
