@@ -70,6 +70,29 @@ def test_allgather_columns(world):
         assert k == want_k and v == want_v and counts == [5 + 3 * r for r in range(world)]
 
 
+def _do_allgather_ragged_widths(rank, world):
+    """three columns of 4 / 16 / 1 bytes per row in ONE packed message; rank 1 contributes nothing"""
+    from lingodb_amd import dist as ldist
+
+    n = 0 if rank == 1 else 3 + rank
+    a = (np.arange(n) + 10 * rank).astype(np.int32)
+    b = (np.arange(2 * n) + 1000 * rank).astype(np.int64)  # 16 bytes per row
+    c = (np.arange(n) + rank).astype(np.uint8)
+    cols = [torch.from_numpy(x.view(np.uint8).copy()) if n else torch.zeros(1, dtype=torch.uint8) for x in (a, b, c)]
+    out, counts = ldist.allgather_columns(dist, cols, [4, 16, 1], n)
+    return out[0].numpy().view(np.int32).tolist(), out[1].numpy().view(np.int64).tolist(), out[2].numpy().tolist(), counts
+
+
+def test_allgather_packed_columns_with_an_empty_rank():
+    res = _run(3, "_do_allgather_ragged_widths")
+    ns = [3, 0, 5]
+    want_a = sum([(np.arange(n) + 10 * r).tolist() for r, n in enumerate(ns)], [])
+    want_b = sum([(np.arange(2 * n) + 1000 * r).tolist() for r, n in enumerate(ns)], [])
+    want_c = sum([(np.arange(n) + r).tolist() for r, n in enumerate(ns)], [])
+    for a, b, c, counts in res:
+        assert (a, b, c, counts) == (want_a, want_b, want_c, ns)
+
+
 # ---------------------------------------------------------------- re-partition (all-to-all shuffle)
 def _do_alltoall(rank, world):
     import oracle_bind
