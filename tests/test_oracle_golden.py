@@ -259,6 +259,12 @@ def test_extract_year_known_answers(oracle):
 def test_decimal_muldiv_known_answers(oracle):
     """literal * a / b on decimals (DecimalMulOpLowering + DecimalOpScaledLowering, LowerToStd.cpp:631-677):
     hand-computed cases, C truncation toward zero, 128-bit wrap-around, the clamped-scale division."""
+    # the reference's own vectors for the two lowerings (test/lit/DB/decimalops.mlir:39-51):
+    # db.mul decimal<12,8> x decimal<12,8> -> decimal<24,16>; db.div decimal<12,8> / decimal<12,8> -> decimal<32,20>
+    assert oracle.decimal_muldiv(-1000000001, -1000000001, 0, 0, 1) == 1000000002000000001  # (-10.00000001)^2 = 100.0000002000000001
+    assert oracle.decimal_muldiv(1000000005, 1000000005, 0, 0, 1) == 1000000010000000025  # 10.00000005^2 = 100.0000010000000025
+    assert oracle.decimal_muldiv(-1000000001, 1, 0, 20 + 8 - 8, -1000000001) == 10**20  # 1.00000000000000000000
+    assert oracle.decimal_muldiv(1000000005, 1, 0, 20 + 8 - 8, 1000000005) == 10**20
     # 100.00 * 1.0000 / 3.0000 at result scale 6: ((10000 * 10000) * 10^4) / 30000
     assert oracle.decimal_muldiv(10000, 10000, 0, 4, 30000) == 33333333
     assert oracle.decimal_muldiv(-10000, 10000, 0, 4, 30000) == -33333333  # sdiv truncates toward zero
