@@ -1,0 +1,80 @@
+"""The C oracle against tests/golden/ — answers of the reference's own runtime objects
+(Hash.cpp, Restrictions.cpp, LazyJoinHashtable.cpp, PreAggregationHashtable.cpp,
+StringRuntime.cpp, DateRuntime.cpp) recorded by tests/golden/make_ref_golden.py.  Unlike
+test_oracle_vs_ref.py this needs neither /root/reference nor oracle/_ref, so the pin travels."""
+import numpy as np
+import pyarrow as pa
+
+from lingodb_amd import api, capi
+from oracle_bind import HostTable
+import golden_io
+import tpch_data
+
+
+def _h64(x):
+    m = (x * 11400714819323198549) & (2 ** 64 - 1)
+    return m ^ int.from_bytes(m.to_bytes(8, "little"), "big")
+
+
+def test_oracle_hash_vs_golden(oracle):
+    """db.hash (LowerToStd.cpp:1065-1152, what generated code computes and what the oracle and
+    the kernels follow) against the reference runtime's dbHashApplyColumn (Hash.cpp:58-247).
+    The two agree on every type and on NULLs of every fixed-width type (NULL folds nothing), with
+    one divergence INSIDE the reference: a NULL *string* is skipped by the lowering
+    (LowerToStd.cpp:1118-1132) but folded as the default VarLen32 image {len 0, first4 0xffffffff}
+    by the runtime (Hash.cpp:228-230, helpers.h:193).  The hot path follows the lowering; the
+    fixture rows with a NULL string are checked against the runtime's rule instead."""
+    t = golden_io.types_table()
+    h = HostTable(t).rel()
+    cases = golden_io.hash_cases()
+    assert len(cases) == 17
+    s_null = np.array([v is None for v in t.column(10).to_pylist()])
+    assert 10 < s_null.sum() < 40
+    for keys, want in cases:
+        got = oracle.hash_keys(h, [(0, k) for k in keys])
+        rows = ~s_null if 10 in keys else np.ones(len(want), bool)
+        assert np.array_equal(got[rows], want[rows]), keys
+    single = dict((tuple(k), w) for k, w in cases)[(10,)]
+    assert set(single[s_null].tolist()) == {_h64(0xFFFFFFFF << 32) ^ 0}  # h64(first64) ^ bswap(h64(last64 = 0))
+    assert not oracle.hash_keys(h, [(0, 10)])[s_null].any()  # db.hash: NULL contributes nothing
+
+
+def test_oracle_filters_vs_golden(oracle):
+    meta, cases = golden_io.filter_cases()
+    li = tpch_data.host_table(tpch_data.LINEITEM, meta["orders"])
+    assert li.num_rows == meta["lineitem_rows"]
+    h = HostTable(li).rel()
+    nonempty = 0
+    for case, want in cases:
+        got = oracle.scan_filter(h, golden_io.preds_of(case, li.schema), threads=2)
+        assert np.array_equal(got, want), case
+        nonempty += len(want) > 0
+    assert nonempty >= 6
+
+
+def test_oracle_join_vs_golden(oracle):
+    z = golden_io.npz("ref_join.npz")
+    b, p = (HostTable(pa.table({"k": pa.array(z[k])})).rel() for k in ("build_keys", "probe_keys"))
+    gp, gb, _ = oracle.join(b, [(0, 0)], p, [(0, 0)], capi.JOIN_INNER, threads=3)
+    order = np.lexsort((gb, gp))
+    assert np.array_equal(gp[order], z["probe_rows"]) and np.array_equal(gb[order], z["build_rows"])
+
+
+def test_oracle_groupby_vs_golden(oracle):
+    z = golden_io.npz("ref_groupby.npz")
+    rel = HostTable(pa.table({"k": pa.array(z["keys"]), "v": pa.array(z["vals"])})).rel()
+    rep, v, _ = oracle.groupby(rel, [(0, 0)], [api.agg(capi.AGG_SUM, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT_STAR)], threads=3)
+    got = sorted((int(z["keys"][r]), (s if s < 1 << 63 else s - (1 << 64)), c) for r, (s, c) in zip(rep, v))
+    assert got == list(zip(z["group_keys"].tolist(), z["sums"].tolist(), z["counts"].tolist()))
+
+
+def test_oracle_like_vs_golden(oracle):
+    cases = golden_io.like_cases()
+    assert len(cases) > 3000 and any(w for _, _, w in cases)
+    bad = [(s, p, w) for s, p, w in cases if oracle.like(s.encode(), p.encode()) != w]
+    assert not bad, bad[:10]
+
+
+def test_oracle_extract_year_vs_golden(oracle):
+    for d, y in golden_io.year_cases():
+        assert oracle.extract_year(d) == y, d
