@@ -73,3 +73,43 @@ def like_cases():
 def year_cases():
     with open(os.path.join(GOLDEN, "ref_extract_year.json")) as f:
         return json.load(f)
+
+
+# ---------------------------------------------------------------- test/sqlite-small/join.test
+def sqlite_join_cases():
+    with open(os.path.join(GOLDEN, "sqlite_small_join.json")) as f:
+        return json.load(f)
+
+
+def run_sqlite_join_case(case, join):
+    """Evaluates one transcribed join.test case with `join(build_values, probe_values, kind) ->
+    (probe_rows, build_rows, marks)` (row indices into the two value lists; build_rows holds
+    capi.LDB_NULL_ROW for the unmatched rows of an outer join; marks only for JOIN_MARK) and
+    returns the result rows in the reference's `rowsort` order.  The mapping SQL → operator is
+    the reference's: the preserved side of an outer join probes, EXISTS / NOT EXISTS are semi /
+    anti joins of the outer query's rows, `= some` is a mark join
+    (RelAlgToSubOp.cpp:1217-1294), a full outer join adds the unmatched build rows."""
+    s, t, kind = case["s"], case["t"], case["kind"]
+    val = lambda side, r: None if r == capi.LDB_NULL_ROW else side[r]  # noqa: E731
+    if kind == "inner":
+        pr, br, _ = join(t, s, capi.JOIN_INNER)
+        rows = [[s[p]] for p in pr]
+    elif kind == "left_outer":
+        pr, br, _ = join(t, s, capi.JOIN_LEFT_OUTER)
+        rows = [[s[p], val(t, b)] for p, b in zip(pr, br)]
+    elif kind == "right_outer":
+        pr, br, _ = join(s, t, capi.JOIN_LEFT_OUTER)
+        rows = [[val(s, b), t[p]] for p, b in zip(pr, br)]
+    elif kind == "full_outer":
+        pr, br, _ = join(t, s, capi.JOIN_LEFT_OUTER)
+        rows = [[s[p], val(t, b)] for p, b in zip(pr, br)]
+        ur, _, _ = join(t, s, capi.JOIN_ANTI_BUILD)
+        rows += [[None, t[u]] for u in ur]
+    elif kind in ("semi", "anti"):
+        pr, _, _ = join(t, s, capi.JOIN_SEMI if kind == "semi" else capi.JOIN_ANTI)
+        rows = [[s[p]] for p in pr]
+    else:
+        pr, _, marks = join(t, s, capi.JOIN_MARK)
+        rows = [[s[p], bool(m)] for p, m in zip(pr, marks)]
+    key = lambda r: [(v is None, v) for v in r]  # noqa: E731
+    return sorted(rows, key=key), sorted(case["expected"], key=key)

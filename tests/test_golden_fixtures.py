@@ -78,3 +78,24 @@ def test_oracle_like_vs_golden(oracle):
 def test_oracle_extract_year_vs_golden(oracle):
     for d, y in golden_io.year_cases():
         assert oracle.extract_year(d) == y, d
+
+
+def _nullable_i64(values):
+    return pa.table({"v": pa.array(values, pa.int64())})
+
+
+def test_oracle_sqlite_small_join_cases(oracle):
+    """the reference's SQL-level join tests (inner / NULL keys / left, right, full outer / semi /
+    anti / mark, mixed int-decimal keys) through the oracle's join"""
+    def join(build, probe, kind):
+        b, p = HostTable(_nullable_i64(build)).rel(), HostTable(_nullable_i64(probe)).rel()
+        pr, br, mark = oracle.join(b, [(0, 0)], p, [(0, 0)], kind)
+        if kind == capi.JOIN_MARK:
+            return list(range(len(probe))), None, mark.tolist()
+        return pr.tolist(), None if br is None else br.tolist(), None
+
+    cases = golden_io.sqlite_join_cases()
+    assert len(cases) == 22
+    for case in cases:
+        got, want = golden_io.run_sqlite_join_case(case, join)
+        assert got == want, case["source"]

@@ -97,3 +97,30 @@ def test_device_extract_year_vs_reference_date_runtime(ctx):
     t = pa.table({"d": pa.array(np.array([d for d, _ in cases], dtype=np.int32), pa.int32()).cast(pa.date32())})
     got = ctx.register("golden_dates", t).rel().map_column((0, 0)).to_arrow().column(0).to_pylist()
     assert got == [y for _, y in cases]
+
+
+def test_device_sqlite_small_join_cases(ctx):
+    """the reference's SQL-level join tests (test/sqlite-small/join.test: inner, NULL keys, left /
+    right / full outer, semi, anti, mark, mixed int-decimal keys) through the C-ABI join"""
+    serial = [0]
+
+    def rel_of(values):
+        serial[0] += 1
+        return ctx.register(f"sqlite_join_{serial[0]}", pa.table({"v": pa.array(values, pa.int64())})).rel()
+
+    def join(build, probe, kind):
+        b, p = rel_of(build), rel_of(probe)
+        ht = b.join_build([(0, 0)])
+        if kind == capi.JOIN_MARK:
+            _, mark = ht.probe(p, [(0, 0)], kind)
+            return list(range(len(probe))), None, mark.read_fixed(0).tolist()
+        out = ht.probe(p, [(0, 0)], kind)
+        if kind in (capi.JOIN_INNER, capi.JOIN_LEFT_OUTER):
+            return out.rowids(0).tolist(), out.rowids(out.sides - 1).tolist(), None
+        return out.rowids(0).tolist(), None, None
+
+    cases = golden_io.sqlite_join_cases()
+    assert len(cases) == 22
+    for case in cases:
+        got, want = golden_io.run_sqlite_join_case(case, join)
+        assert got == want, case["source"]
