@@ -1300,6 +1300,95 @@ extern "C" int32_t ldb_plan_tpch_q11(ldb_ctx* ctx, const ldb_table* ps, const ld
    return s;
 }
 
+// ---------------------------------------------------------------- TPC-H Q10 (resources/sql/tpch/10.sql)
+// Returned-item revenue per customer of one quarter, top 20.  Pieces (the single-GPU plan is their
+// composition; multi-GPU: orders/lineitem are co-located, a customer's orders are not, so the
+// shard-local (o_custkey, revenue) groups are hash-radix partitioned on the key, exchanged and
+// merged like Q11's groups before the top-20 is taken).  c_custkey = o_custkey is a foreign key
+// and c_nationkey = n_nationkey too, so neither join drops a group: the aggregation runs on
+// o_custkey before the customer join and only the 20 winners are joined with customer and nation
+// (the other group-by columns are functionally dependent on c_custkey).  The generated customer
+// table carries c_custkey, c_name, c_acctbal, c_nationkey; c_address / c_phone / c_comment are not
+// generated and not returned.
+// Step 1 (per shard): orders of the quarter ⋈ returned lineitems, SUM per o_custkey.
+extern "C" int32_t ldb_plan_tpch_q10_local(ldb_ctx* ctx, const ldb_table* ord, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel o0(ctx), o1(ctx), l0(ctx), l1(ctx), lo(ctx);
+      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q10 orders");
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q10 lineitem");
+      auto ro = Restrictions::create({{"o_orderdate", FilterOp::GTE, std::string("1993-10-01"), {}}, {"o_orderdate", FilterOp::LT, std::string("1994-01-01"), {}}}, ord);
+      auto rl = Restrictions::create({{"l_returnflag", FilterOp::EQ, std::string("R"), {}}}, li);
+      check(ldb_gpu_scan_filter(ctx, o0.r, ro->data(), ro->size(), &o1.r), "q10 filter orders");
+      check(ldb_gpu_scan_filter(ctx, l0.r, rl->data(), rl->size(), &l1.r), "q10 filter lineitem");
+      Ht ho(ctx);
+      ldb_colref ook{0, colOf(ord, "o_orderkey")}, lok{0, colOf(li, "l_orderkey")};
+      check(ldb_gpu_join_build(ctx, o1.r, &ook, 1, 1, &ho.h), "q10 build orders");
+      check(ldb_gpu_join_probe(ctx, ho.h, l1.r, &lok, 1, LDB_JOIN_INNER, &lo.r, nullptr), "q10 probe lineitem"); // sides: lineitem, orders
+      ldb_colref ext{0, colOf(li, "l_extendedprice")}, disc{0, colOf(li, "l_discount")};
+      DecimalType t1md;
+      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, decOf(li, disc.col), &t1md);
+      DecimalType tRev = typeAfterMul(decOf(li, ext.col), t1md);
+      ldb_agg_spec agg = sumDec(product({colFactor(ext), oneMinusDisc}), tRev);
+      ldb_colref key{1, colOf(ord, "o_custkey")};
+      const int64_t est = ldb_gpu_rel_rows(ctx, lo.r);
+      check(ldb_gpu_groupby(ctx, lo.r, nullptr, 0, &key, 1, &agg, 1, est > 0 ? est : 1, result), "q10 groupby");
+   });
+}
+// Multi-GPU only: route the shard-local groups to the rank that owns hash(o_custkey), re-aggregate.
+extern "C" int32_t ldb_plan_tpch_q10_partition(ldb_ctx* ctx, const ldb_table* groups, int32_t world, ldb_table** result, int64_t* counts) {
+   return ldb_plan_tpch_q11_partition(ctx, groups, world, result, counts);
+}
+extern "C" int32_t ldb_plan_tpch_q10_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result) {
+   return guarded([&] { groupByFirstCol(ctx, rows, result, "q10 merge"); });
+}
+// Step 2: the 20 groups with the highest revenue of a (custkey, revenue) table.
+extern "C" int32_t ldb_plan_tpch_q10_top(ldb_ctx* ctx, const ldb_table* groups, ldb_table** result) {
+   return guarded([&] {
+      Rel g(ctx), top(ctx);
+      check(ldb_gpu_rel_from_table(ctx, groups, &g.r), "q10 top");
+      ldb_sort_spec spec{{0, 1}, 1, 0};
+      check(ldb_gpu_topk(ctx, g.r, &spec, 1, 20, &top.r), "q10 topk");
+      ldb_colref outc[2] = {{0, 0}, {0, 1}};
+      check(ldb_gpu_materialize(ctx, top.r, outc, 2, result), "q10 top materialize");
+   });
+}
+// Step 3 (per customer shard): c_name, c_acctbal and n_name of the winners whose customer lives here.
+extern "C" int32_t ldb_plan_tpch_q10_names(ldb_ctx* ctx, const ldb_table* top20, const ldb_table* cust, const ldb_table* nat, ldb_table** result) {
+   return guarded([&] {
+      Rel t0(ctx), c0(ctx), n0(ctx), ct(ctx), ctn(ctx);
+      check(ldb_gpu_rel_from_table(ctx, top20, &t0.r), "q10 names");
+      check(ldb_gpu_rel_from_table(ctx, cust, &c0.r), "q10 names customer");
+      check(ldb_gpu_rel_from_table(ctx, nat, &n0.r), "q10 names nation");
+      Ht ht(ctx), hn(ctx);
+      ldb_colref tk{0, 0}, ck{0, colOf(cust, "c_custkey")}, cn{0, colOf(cust, "c_nationkey")}, nk{0, colOf(nat, "n_nationkey")};
+      check(ldb_gpu_join_build(ctx, t0.r, &tk, 1, 0, &ht.h), "q10 names build");
+      check(ldb_gpu_join_probe(ctx, ht.h, c0.r, &ck, 1, LDB_JOIN_INNER, &ct.r, nullptr), "q10 names probe"); // sides: customer, top20
+      check(ldb_gpu_join_build(ctx, n0.r, &nk, 1, 1, &hn.h), "q10 build nation");
+      check(ldb_gpu_join_probe(ctx, hn.h, ct.r, &cn, 1, LDB_JOIN_INNER, &ctn.r, nullptr), "q10 probe nation"); // sides: customer, top20, nation
+      ldb_colref outc[5] = {ck, {0, colOf(cust, "c_name")}, {1, 1}, {0, colOf(cust, "c_acctbal")}, {2, colOf(nat, "n_name")}};
+      check(ldb_gpu_materialize(ctx, ctn.r, outc, 5, result), "q10 names materialize");
+   });
+}
+// Step 4: ORDER BY revenue DESC LIMIT 20 over the named rows.
+extern "C" int32_t ldb_plan_tpch_q10_final(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result) {
+   return guarded([&] {
+      Rel in(ctx), top(ctx);
+      check(ldb_gpu_rel_from_table(ctx, rows, &in.r), "q10 final");
+      ldb_sort_spec spec{{0, 2}, 1, 0};
+      check(ldb_gpu_topk(ctx, in.r, &spec, 1, 20, &top.r), "q10 final topk");
+      ldb_colref outc[5] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}};
+      check(ldb_gpu_materialize(ctx, top.r, outc, 5, result), "q10 final materialize");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q10(ldb_ctx* ctx, const ldb_table* cust, const ldb_table* ord, const ldb_table* li, const ldb_table* nat, ldb_table** result) {
+   Table groups(ctx), top(ctx), named(ctx);
+   int32_t s = ldb_plan_tpch_q10_local(ctx, ord, li, &groups.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q10_top(ctx, groups.t, &top.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q10_names(ctx, top.t, cust, nat, &named.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q10_final(ctx, named.t, result);
+   return s;
+}
+
 // ---------------------------------------------------------------- TPC-H Q14 (resources/sql/tpch/14.sql)
 // 100.00 * sum(case when p_type like 'PROMO%' then rev else 0 end) / sum(rev) over one month of
 // lineitem ⋈ part.  Pieces: q14_promo (keys of the PROMO parts: LIKE runs once per part, not per

@@ -121,6 +121,14 @@ int32_t ldb_plan_tpch_q3_local(ldb_ctx* ctx, const ldb_table* custkeys, const ld
 int32_t ldb_plan_tpch_q3_final(ldb_ctx* ctx, const ldb_table* tops, ldb_table** result);
 int32_t ldb_plan_tpch_q4_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
 int32_t ldb_plan_tpch_q12_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
+// Q10 pieces: shard-local (o_custkey, revenue) groups; [multi-GPU: partition + merge on the key;] top 20; names; order
+int32_t ldb_plan_tpch_q10(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* orders, const ldb_table* lineitem, const ldb_table* nation, ldb_table** result);
+int32_t ldb_plan_tpch_q10_local(ldb_ctx* ctx, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q10_partition(ldb_ctx* ctx, const ldb_table* groups, int32_t world, ldb_table** result, int64_t* counts);
+int32_t ldb_plan_tpch_q10_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
+int32_t ldb_plan_tpch_q10_top(ldb_ctx* ctx, const ldb_table* groups, ldb_table** result);
+int32_t ldb_plan_tpch_q10_names(ldb_ctx* ctx, const ldb_table* top20, const ldb_table* customer, const ldb_table* nation, ldb_table** result);
+int32_t ldb_plan_tpch_q10_final(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
 int32_t ldb_plan_tpch_q18_local(ldb_ctx* ctx, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q18_mid(ldb_ctx* ctx, const ldb_table* tops, ldb_table** result);
 int32_t ldb_plan_tpch_q18_names(ldb_ctx* ctx, const ldb_table* top100, const ldb_table* customer, ldb_table** result);

@@ -520,6 +520,11 @@ class Context:
         check_plan(capi.host_lib().ldb_plan_tpch_q9(self.h, part.h, supplier.h, lineitem.h, partsupp.h, orders.h, nation.h, C.byref(t)))
         return Table(self, t)
 
+    def plan_q10(self, customer, orders, lineitem, nation):
+        t = C.c_void_p()
+        check_plan(capi.host_lib().ldb_plan_tpch_q10(self.h, customer.h, orders.h, lineitem.h, nation.h, C.byref(t)))
+        return Table(self, t)
+
     def plan_q18(self, customer, orders, lineitem):
         t = C.c_void_p()
         check_plan(capi.host_lib().ldb_plan_tpch_q18(self.h, customer.h, orders.h, lineitem.h, C.byref(t)))

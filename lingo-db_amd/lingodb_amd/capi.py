@@ -216,6 +216,7 @@ HOST_API = {
     "ldb_plan_tpch_q11_suppliers": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q11_groups": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q11_partition": (i32, [P, P, i32, PP, C.POINTER(i64)]),
+    "ldb_plan_tpch_q10_partition": (i32, [P, P, i32, PP, C.POINTER(i64)]),
     "ldb_plan_tpch_q11_merge": (i32, [P, P, PP]),
     "ldb_plan_tpch_q11_total": (i32, [P, P, PP]),
     "ldb_plan_tpch_q11_filter": (i32, [P, P, P, PP]),
@@ -233,6 +234,12 @@ HOST_API = {
     "ldb_plan_tpch_q3_final": (i32, [P, P, PP]),
     "ldb_plan_tpch_q4_final": (i32, [P, P, PP]),
     "ldb_plan_tpch_q12_final": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q10": (i32, [P, P, P, P, P, PP]),
+    "ldb_plan_tpch_q10_local": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q10_merge": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q10_top": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q10_names": (i32, [P, P, P, P, PP]),
+    "ldb_plan_tpch_q10_final": (i32, [P, P, PP]),
     "ldb_plan_tpch_q18_local": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q18_mid": (i32, [P, P, PP]),
     "ldb_plan_tpch_q18_names": (i32, [P, P, P, PP]),

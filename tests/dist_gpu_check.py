@@ -24,7 +24,7 @@ def main():
     import tpch_plans
 
     n_orders = int(os.environ.get("LDB_CHECK_ORDERS", "150003"))  # enough orders for Q18's HAVING to keep some
-    queries = [1, 6, 3, 4, 12, 18, 9, 5, 7, 11, 14, 8]
+    queries = [int(q) for q in os.environ.get("LDB_CHECK_QUERIES", "1,6,3,4,12,18,9,5,7,11,14,8").split(",")]
     ctx = ldb.Context(dev)
     db = tpch_plans.Database(ctx, n_orders, rank, world, queries, False)
     runner = tpch_plans.Runner(ctx, db, world, dist, torch)
@@ -41,6 +41,9 @@ def main():
             elif q == 18:  # ORDER BY o_totalprice desc, o_orderdate; column names differ between the plans
                 va, vb = [tuple(r.values()) for r in a], [tuple(r.values()) for r in b]
                 same = [(r[4], r[3]) for r in va] == [(r[4], r[3]) for r in vb] and sorted(map(repr, va)) == sorted(map(repr, vb)) and len(va) > 0
+            elif q == 10:  # ORDER BY revenue desc only
+                va, vb = [tuple(r.values()) for r in a], [tuple(r.values()) for r in b]
+                same = [r[2] for r in va] == [r[2] for r in vb] and sorted(map(repr, va)) == sorted(map(repr, vb)) and len(va) == 20
             elif q == 11:  # ORDER BY value desc only
                 va, vb = [tuple(r.values()) for r in a], [tuple(r.values()) for r in b]
                 same = [r[1] for r in va] == [r[1] for r in vb] and sorted(va) == sorted(vb) and len(va) > 0

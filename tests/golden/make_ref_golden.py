@@ -13,7 +13,7 @@ exist on the GPU box, so its answers travel as these files:
   ref_extract_year.json    DateRuntime::extractYear answers
 
 Run from the repo root where /root/reference exists:  python tests/golden/make_ref_golden.py
-Consumers: tests/test_golden_fixtures.py (oracle, CPU) and tests/test_gpu_golden.py (HIP path)."""
+Consumers: tests/test_golden_fixtures.py (oracle, CPU) and tests/test_gpu_z_golden.py (HIP path)."""
 import ctypes as C
 import decimal
 import json

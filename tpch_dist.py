@@ -216,6 +216,18 @@ def run_query(runner, q):
         totals = replicate(runner, _plan(ctx, "ldb_plan_tpch_q11_total", groups), "q11_totals")
         kept = _plan(ctx, "ldb_plan_tpch_q11_filter", groups, totals)
         return _plan(ctx, "ldb_plan_tpch_q11_sort", replicate(runner, kept, "q11_kept"))
+    if q == 10:
+        # orders and their lineitems are co-located but a customer's orders are spread over the
+        # shards: the shard-local (o_custkey, revenue) groups are re-partitioned on the hash of the
+        # key and merged (Q11's exchange); every rank's 20 best merged groups are all-gathered, the
+        # global 20 looked up in the row-sharded customer table, and the gathered rows ordered
+        local = _plan(ctx, "ldb_plan_tpch_q10_local", db.orders, db.lineitem)
+        parts, counts = _plan_partitioned(ctx, "ldb_plan_tpch_q10_partition", runner.world, local)
+        groups = _plan(ctx, "ldb_plan_tpch_q10_merge", shuffle(runner, parts, counts, "q10_rows"))
+        tops = replicate(runner, _plan(ctx, "ldb_plan_tpch_q10_top", groups), "q10_tops")
+        top20 = _plan(ctx, "ldb_plan_tpch_q10_top", tops)
+        named = _plan(ctx, "ldb_plan_tpch_q10_names", top20, db.customer, db.nation)
+        return _plan(ctx, "ldb_plan_tpch_q10_final", replicate(runner, named, "q10_named"))
     if q == 14:
         # lineitem is sharded by orders, part by rows: the PROMO part keys (1/6 of part) are all-gathered
         # per query, the part key column (the inner join's build side) once; the two partial sums are
