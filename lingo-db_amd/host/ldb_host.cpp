@@ -1389,6 +1389,97 @@ extern "C" int32_t ldb_plan_tpch_q10(ldb_ctx* ctx, const ldb_table* cust, const 
    return s;
 }
 
+// ---------------------------------------------------------------- TPC-H Q15 (resources/sql/tpch/15.sql)
+// The revenue view (SUM per l_suppkey over one quarter's lineitems), its maximum (scalar subquery)
+// and the suppliers that reach it.  Pieces: q15_local (shard-local groups; multi-GPU re-partitions
+// and merges them on the key like Q10), q15_max (the best group: top-1 by revenue — MAX over a
+// 128-bit decimal as an ordered select), q15_winners (groups whose revenue equals the maximum: the
+// scalar is read back and becomes the constant of an EQ filter, as the reference materialises
+// the subquery first), q15_final (⋈ supplier on the key, ORDER BY s_suppkey).  The generated
+// supplier table carries s_suppkey, s_nationkey, s_acctbal; s_name / s_address / s_phone are not
+// generated and not returned.
+extern "C" int32_t ldb_plan_tpch_q15_local(ldb_ctx* ctx, const ldb_table* li, ldb_table** result) {
+   return guarded([&] {
+      Rel l0(ctx), l1(ctx);
+      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q15 lineitem");
+      auto rl = Restrictions::create({{"l_shipdate", FilterOp::GTE, std::string("1996-01-01"), {}}, {"l_shipdate", FilterOp::LT, std::string("1996-04-01"), {}}}, li);
+      check(ldb_gpu_scan_filter(ctx, l0.r, rl->data(), rl->size(), &l1.r), "q15 filter lineitem");
+      ldb_colref ext{0, colOf(li, "l_extendedprice")}, disc{0, colOf(li, "l_discount")}, key{0, colOf(li, "l_suppkey")};
+      DecimalType t1md;
+      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, decOf(li, disc.col), &t1md);
+      DecimalType tRev = typeAfterMul(decOf(li, ext.col), t1md);
+      ldb_agg_spec agg = sumDec(product({colFactor(ext), oneMinusDisc}), tRev);
+      const int64_t est = std::max<int64_t>(ldb_gpu_table_rows(li) / 512, 1024); // ≈ 600 lineitems per supplier
+      check(ldb_gpu_groupby(ctx, l1.r, nullptr, 0, &key, 1, &agg, 1, est, result), "q15 groupby");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q15_partition(ldb_ctx* ctx, const ldb_table* groups, int32_t world, ldb_table** result, int64_t* counts) {
+   return ldb_plan_tpch_q11_partition(ctx, groups, world, result, counts);
+}
+extern "C" int32_t ldb_plan_tpch_q15_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result) {
+   return guarded([&] { groupByFirstCol(ctx, rows, result, "q15 merge"); });
+}
+extern "C" int32_t ldb_plan_tpch_q15_max(ldb_ctx* ctx, const ldb_table* groups, ldb_table** result) {
+   return guarded([&] {
+      Rel g(ctx), top(ctx);
+      check(ldb_gpu_rel_from_table(ctx, groups, &g.r), "q15 max");
+      ldb_sort_spec spec{{0, 1}, 1, 0};
+      check(ldb_gpu_topk(ctx, g.r, &spec, 1, 1, &top.r), "q15 max topk");
+      ldb_colref outc[2] = {{0, 0}, {0, 1}};
+      check(ldb_gpu_materialize(ctx, top.r, outc, 2, result), "q15 max materialize");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q15_winners(ldb_ctx* ctx, const ldb_table* groups, const ldb_table* best, ldb_table** result) {
+   return guarded([&] {
+      Rel g0(ctx), g1(ctx);
+      check(ldb_gpu_rel_from_table(ctx, groups, &g0.r), "q15 groups");
+      ldb_filter_desc eq;
+      memset(&eq, 0, sizeof(eq));
+      eq.col = {0, 1};
+      if (ldb_gpu_table_rows(best) > 0) {
+         __int128 mx = 0;
+         check(ldb_gpu_table_read_fixed(ctx, best, 1, &mx, 16), "q15 read max");
+         eq.op = (int32_t) FilterOp::EQ;
+         setInt(eq, mx);
+      } else { // no lineitem in the quarter: MAX is NULL and `= NULL` keeps nothing
+         eq.op = (int32_t) FilterOp::LT;
+         eq.rhs_kind = LDB_RHS_COLUMN;
+         eq.rhs_col = {0, 1};
+      }
+      check(ldb_gpu_scan_filter(ctx, g0.r, &eq, 1, &g1.r), "q15 filter");
+      ldb_colref outc[2] = {{0, 0}, {0, 1}};
+      check(ldb_gpu_materialize(ctx, g1.r, outc, 2, result), "q15 materialize");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q15_final(ldb_ctx* ctx, const ldb_table* winners, const ldb_table* supp, ldb_table** result) {
+   return guarded([&] {
+      Rel w0(ctx), s0(ctx), sw(ctx), sorted(ctx);
+      check(ldb_gpu_rel_from_table(ctx, winners, &w0.r), "q15 winners");
+      check(ldb_gpu_rel_from_table(ctx, supp, &s0.r), "q15 supplier");
+      Ht hw(ctx);
+      ldb_colref wk{0, 0}, sk{0, colOf(supp, "s_suppkey")};
+      check(ldb_gpu_join_build(ctx, w0.r, &wk, 1, 1, &hw.h), "q15 build winners");
+      check(ldb_gpu_join_probe(ctx, hw.h, s0.r, &sk, 1, LDB_JOIN_INNER, &sw.r, nullptr), "q15 probe supplier"); // sides: supplier, winners
+      Table joined(ctx);
+      ldb_colref jc[2] = {sk, {1, 1}};
+      check(ldb_gpu_materialize(ctx, sw.r, jc, 2, &joined.t), "q15 materialize");
+      Rel j(ctx);
+      check(ldb_gpu_rel_from_table(ctx, joined.t, &j.r), "q15 rel");
+      ldb_sort_spec spec{{0, 0}, 0, 0};
+      check(ldb_gpu_sort(ctx, j.r, &spec, 1, &sorted.r), "q15 sort");
+      ldb_colref outc[2] = {{0, 0}, {0, 1}};
+      check(ldb_gpu_materialize(ctx, sorted.r, outc, 2, result), "q15 final materialize");
+   });
+}
+extern "C" int32_t ldb_plan_tpch_q15(ldb_ctx* ctx, const ldb_table* supp, const ldb_table* li, ldb_table** result) {
+   Table groups(ctx), best(ctx), winners(ctx);
+   int32_t s = ldb_plan_tpch_q15_local(ctx, li, &groups.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q15_max(ctx, groups.t, &best.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q15_winners(ctx, groups.t, best.t, &winners.t);
+   if (s == LDB_OK) s = ldb_plan_tpch_q15_final(ctx, winners.t, supp, result);
+   return s;
+}
+
 // ---------------------------------------------------------------- TPC-H Q14 (resources/sql/tpch/14.sql)
 // 100.00 * sum(case when p_type like 'PROMO%' then rev else 0 end) / sum(rev) over one month of
 // lineitem ⋈ part.  Pieces: q14_promo (keys of the PROMO parts: LIKE runs once per part, not per

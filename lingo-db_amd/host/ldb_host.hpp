@@ -129,6 +129,14 @@ int32_t ldb_plan_tpch_q10_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table**
 int32_t ldb_plan_tpch_q10_top(ldb_ctx* ctx, const ldb_table* groups, ldb_table** result);
 int32_t ldb_plan_tpch_q10_names(ldb_ctx* ctx, const ldb_table* top20, const ldb_table* customer, const ldb_table* nation, ldb_table** result);
 int32_t ldb_plan_tpch_q10_final(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
+// Q15 pieces: shard-local (l_suppkey, revenue) groups; [multi-GPU: partition + merge;] best group; groups equal to it; supplier join + order
+int32_t ldb_plan_tpch_q15(ldb_ctx* ctx, const ldb_table* supplier, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q15_local(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
+int32_t ldb_plan_tpch_q15_partition(ldb_ctx* ctx, const ldb_table* groups, int32_t world, ldb_table** result, int64_t* counts);
+int32_t ldb_plan_tpch_q15_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
+int32_t ldb_plan_tpch_q15_max(ldb_ctx* ctx, const ldb_table* groups, ldb_table** result);
+int32_t ldb_plan_tpch_q15_winners(ldb_ctx* ctx, const ldb_table* groups, const ldb_table* best, ldb_table** result);
+int32_t ldb_plan_tpch_q15_final(ldb_ctx* ctx, const ldb_table* winners, const ldb_table* supplier, ldb_table** result);
 int32_t ldb_plan_tpch_q18_local(ldb_ctx* ctx, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q18_mid(ldb_ctx* ctx, const ldb_table* tops, ldb_table** result);
 int32_t ldb_plan_tpch_q18_names(ldb_ctx* ctx, const ldb_table* top100, const ldb_table* customer, ldb_table** result);

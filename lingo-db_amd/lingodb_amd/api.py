@@ -525,6 +525,18 @@ class Context:
         check_plan(capi.host_lib().ldb_plan_tpch_q10(self.h, customer.h, orders.h, lineitem.h, nation.h, C.byref(t)))
         return Table(self, t)
 
+    def plan_q15(self, supplier, lineitem):
+        t = C.c_void_p()
+        check_plan(capi.host_lib().ldb_plan_tpch_q15(self.h, supplier.h, lineitem.h, C.byref(t)))
+        return Table(self, t)
+
+    def load_ipc(self, name, path, narrow_decimals=False):
+        """registers one Arrow IPC file as a table — the reference keeps one `<table>.arrow` IPC
+        file per table and reads all its record batches (LingoDBTable.cpp:27-54, loadTable)"""
+        with pa.OSFile(path, "rb") as f:
+            table = pa.ipc.open_file(f).read_all()
+        return self.register(name, table, narrow_decimals)
+
     def plan_q18(self, customer, orders, lineitem):
         t = C.c_void_p()
         check_plan(capi.host_lib().ldb_plan_tpch_q18(self.h, customer.h, orders.h, lineitem.h, C.byref(t)))

@@ -216,6 +216,7 @@ HOST_API = {
     "ldb_plan_tpch_q11_suppliers": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q11_groups": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q11_partition": (i32, [P, P, i32, PP, C.POINTER(i64)]),
+    "ldb_plan_tpch_q15_partition": (i32, [P, P, i32, PP, C.POINTER(i64)]),
     "ldb_plan_tpch_q10_partition": (i32, [P, P, i32, PP, C.POINTER(i64)]),
     "ldb_plan_tpch_q11_merge": (i32, [P, P, PP]),
     "ldb_plan_tpch_q11_total": (i32, [P, P, PP]),
@@ -240,6 +241,12 @@ HOST_API = {
     "ldb_plan_tpch_q10_top": (i32, [P, P, PP]),
     "ldb_plan_tpch_q10_names": (i32, [P, P, P, P, PP]),
     "ldb_plan_tpch_q10_final": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q15": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q15_local": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q15_merge": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q15_max": (i32, [P, P, PP]),
+    "ldb_plan_tpch_q15_winners": (i32, [P, P, P, PP]),
+    "ldb_plan_tpch_q15_final": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q18_local": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q18_mid": (i32, [P, P, PP]),
     "ldb_plan_tpch_q18_names": (i32, [P, P, P, PP]),

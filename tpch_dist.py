@@ -228,6 +228,18 @@ def run_query(runner, q):
         top20 = _plan(ctx, "ldb_plan_tpch_q10_top", tops)
         named = _plan(ctx, "ldb_plan_tpch_q10_names", top20, db.customer, db.nation)
         return _plan(ctx, "ldb_plan_tpch_q10_final", replicate(runner, named, "q10_named"))
+    if q == 15:
+        # a supplier's lineitems are spread over the shards: exchange + merge of the groups as in Q10;
+        # the maximum of the ranks' best groups is the view's maximum; every rank keeps its groups
+        # that reach it, the gathered winners are joined with the (once replicated) supplier table
+        if "supplier_all" not in runner.cache:
+            runner.cache["supplier_all"] = replicate(runner, db.supplier, "supplier_all")
+        local = _plan(ctx, "ldb_plan_tpch_q15_local", db.lineitem)
+        parts, counts = _plan_partitioned(ctx, "ldb_plan_tpch_q15_partition", runner.world, local)
+        groups = _plan(ctx, "ldb_plan_tpch_q15_merge", shuffle(runner, parts, counts, "q15_rows"))
+        best = _plan(ctx, "ldb_plan_tpch_q15_max", replicate(runner, _plan(ctx, "ldb_plan_tpch_q15_max", groups), "q15_best"))
+        winners = replicate(runner, _plan(ctx, "ldb_plan_tpch_q15_winners", groups, best), "q15_winners")
+        return _plan(ctx, "ldb_plan_tpch_q15_final", winners, runner.cache["supplier_all"])
     if q == 14:
         # lineitem is sharded by orders, part by rows: the PROMO part keys (1/6 of part) are all-gathered
         # per query, the part key column (the inner join's build side) once; the two partial sums are

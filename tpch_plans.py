@@ -38,6 +38,8 @@ class Database:
             lcols |= {L_ORDERKEY, L_QUANTITY}
         if 10 in queries:
             lcols |= {L_ORDERKEY, L_EXTENDEDPRICE, L_DISCOUNT, L_RETURNFLAG}
+        if 15 in queries:
+            lcols |= {2, L_EXTENDEDPRICE, L_DISCOUNT, L_SHIPDATE}  # + l_suppkey
         if 9 in queries:
             lcols |= {L_ORDERKEY, 1, 2, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT}  # + l_partkey, l_suppkey
         if 5 in queries or 7 in queries:
@@ -79,6 +81,8 @@ class Database:
             ccols |= {C_CUSTKEY, 1}  # + c_nationkey
         if 10 in queries and not any(q in queries for q in (5, 7, 8, 9, 11)):
             self.nation = ctx.tpch_generate(NATION, n_orders, rank, world, [0, 1, 2], narrow)
+        if 15 in queries and not any(q in queries for q in (5, 7, 8, 9, 11)):
+            self.supplier = ctx.tpch_generate(SUPPLIER, n_orders, rank, world, [0, 1], narrow)
         if any(q in queries for q in (5, 7, 8, 9, 11)):
             self.supplier = ctx.tpch_generate(SUPPLIER, n_orders, rank, world, [0, 1], narrow)  # s_suppkey, s_nationkey
             self.nation = ctx.tpch_generate(NATION, n_orders, rank, world, [0, 1, 2], narrow)  # n_nationkey, n_regionkey, n_name
@@ -114,6 +118,8 @@ class Runner:
             res = self.ctx.plan_q18(self.db.customer, self.db.orders, self.db.lineitem)
         elif q == 10:
             res = self.ctx.plan_q10(self.db.customer, self.db.orders, self.db.lineitem, self.db.nation)
+        elif q == 15:
+            res = self.ctx.plan_q15(self.db.supplier, self.db.lineitem)
         elif q == 5:
             res = self.ctx.plan_q5(self.db.customer, self.db.orders, self.db.lineitem, self.db.supplier, self.db.nation, self.db.region)
         elif q == 7:
