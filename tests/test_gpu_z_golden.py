@@ -124,3 +124,32 @@ def test_device_sqlite_small_join_cases(ctx):
     for case in cases:
         got, want = golden_io.run_sqlite_join_case(case, join)
         assert got == want, case["source"]
+
+
+def test_device_sqlite_small_groupby_cases(ctx):
+    """the reference's SQL-level group-by tests (test/sqlite-small/groupby.test): NULL group keys
+    produced by an outer join (:1-6), DISTINCT → join → COUNT per key → SUM (:22-27, three times in
+    the file), and an outer join above a group-by (:49-56); expected rows are the file's"""
+    i64 = lambda v: pa.array(v, pa.int64())  # noqa: E731
+    count = api.agg(capi.AGG_COUNT_STAR)
+    # select a,b,count(*) from (values(1),(2)) s(x) left outer join (values(1,2,2)) t(y,a,b) on x=y group by a,b
+    s = ctx.register("gb_s", pa.table({"x": i64([1, 2])})).rel()
+    t = ctx.register("gb_t", pa.table({"y": i64([1]), "a": i64([2]), "b": i64([2])})).rel()
+    st = t.join_build([(0, 0)]).probe(s, [(0, 0)], capi.JOIN_LEFT_OUTER)  # sides: s, t
+    got = st.groupby([(1, 1), (1, 2)], [count]).to_arrow().to_pylist()
+    assert sorted((tuple(r.values()) for r in got), key=repr) == sorted([(2, 2, 1), (None, None, 1)], key=repr)
+    # WITH set AS (SELECT DISTINCT i FROM ints), groupjoin AS (SELECT count(*) c FROM set s, dups d WHERE s.i = d.i GROUP BY s.i) SELECT sum(c)
+    ints = ctx.register("gb_ints", pa.table({"i": i64([1, 2, 3, 4])})).rel()
+    dups = ctx.register("gb_dups", pa.table({"i": i64([1, 1, 2, 2, 3, 3])})).rel()
+    distinct = ints.groupby([(0, 0)], [count])
+    ds = distinct.rel().join_build([(0, 0)], unique=True).probe(dups, [(0, 0)], capi.JOIN_INNER)  # sides: dups, set
+    per_key = ds.groupby([(1, 0)], [count])
+    assert sorted(tuple(r.values()) for r in per_key.to_arrow().to_pylist()) == [(1, 2), (2, 2), (3, 2)]
+    total = per_key.rel().groupby([], [api.agg(capi.AGG_SUM, api.col_expr((0, 1)))]).to_arrow().to_pylist()
+    assert [int(v) for r in total for v in r.values()] == [6]
+    # WITH lower_groupby AS (SELECT i, count(*) FROM dups GROUP BY i) SELECT * FROM ints i LEFT JOIN lower_groupby l ON i.i = l.i
+    lower = dups.groupby([(0, 0)], [count])
+    il = lower.rel().join_build([(0, 0)], unique=True).probe(ints, [(0, 0)], capi.JOIN_LEFT_OUTER)  # sides: ints, lower
+    out = il.materialize([(0, 0), (1, 0), (1, 1)]).to_arrow()  # two columns are called "i": read by position
+    rows = list(zip(*[out.column(c).to_pylist() for c in range(3)]))
+    assert sorted(rows, key=repr) == sorted([(1, 1, 2), (2, 2, 2), (3, 3, 2), (4, None, None)], key=repr)
