@@ -32,7 +32,11 @@ enum { LDB_TPCH_LINEITEM = 0,
        LDB_TPCH_SUPPLIER = 4,
        LDB_TPCH_PARTSUPP = 5,
        LDB_TPCH_NATION = 6,
-       LDB_TPCH_REGION = 7 };
+       LDB_TPCH_REGION = 7,
+       /* bench support, not a TPC-H table: one int32 column `k_orderkey` with as many rows as lineitem,
+        * each the key of a uniformly random order — an UNCLUSTERED foreign-key probe side with a 100 %
+        * match rate (the case radix-partitioned joins exist for; l_orderkey itself is clustered) */
+       LDB_TPCH_PROBEKEYS = 8 };
 
 /* lineitem columns (index = column id in the generated table when all columns are requested) */
 enum { L_ORDERKEY = 0,
@@ -58,12 +62,14 @@ enum { O_ORDERKEY = 0,
        O_ORDERDATE,
        O_ORDERPRIORITY,
        O_SHIPPRIORITY,
+       O_COMMENT, /* pseudo text (vocabulary below); '%special%requests%' occurs naturally (Q13) */
        O_NCOLS };
 enum { C_CUSTKEY = 0,
        C_NATIONKEY,
        C_ACCTBAL,
        C_MKTSEGMENT,
        C_NAME, /* "Customer#%09d" of the customer key: fixed 18 bytes (TPC-H spec 4.2.3) */
+       C_PHONE, /* "CC-ddd-ddd-dddd", CC = c_nationkey + 10 (spec 4.2.2.9) */
        C_NCOLS };
 #define LDB_TPCH_CNAME_LEN 18
 /* writes the 18 bytes of c_name for customer key `custkey` */
@@ -83,10 +89,17 @@ enum { P_PARTKEY = 0,
        P_RETAILPRICE,
        P_NAME, /* five colour words separated by blanks (TPC-H spec 4.2.3: P_NAME) */
        P_TYPE, /* three syllables, one from each of the TYPES lists (spec 4.2.2.13) */
+       P_BRAND, /* "Brand#MN", M = manufacturer 1..5, N = 1..5 */
+       P_CONTAINER, /* two syllables: {SM,LG,MED,JUMBO,WRAP} x {CASE,BOX,BAG,JAR,PKG,PACK,CAN,DRUM} */
+       P_MFGR, /* "Manufacturer#M" */
        P_NCOLS };
 enum { S_SUPPKEY = 0,
        S_NATIONKEY,
        S_ACCTBAL,
+       S_NAME, /* "Supplier#%09d" */
+       S_ADDRESS, /* 10..25 random letters */
+       S_PHONE,
+       S_COMMENT, /* pseudo text; one supplier in 200 carries "Customer ... Complaints" (Q16) */
        S_NCOLS };
 enum { PS_PARTKEY = 0,
        PS_SUPPKEY,
@@ -316,6 +329,122 @@ LDB_HD int32_t ldb_tpch_str_domain(int32_t table, int32_t col) {
    if (table == LDB_TPCH_NATION && col == N_NAME) return 25;
    if (table == LDB_TPCH_REGION && col == R_NAME) return 5;
    return 0;
+}
+
+/* ---- generated text columns (p_brand, p_container, p_mfgr, s_name, s_address, s_phone, s_comment,
+ * o_comment, c_phone): ldb_tpch_text writes the value of (table, col, row) to `out` (capacity
+ * LDB_TPCH_TEXT_MAX) and returns its length; ldb_tpch_is_text tells whether a column is one. */
+#define LDB_TPCH_TEXT_MAX 104
+LDB_HD int32_t ldb_tpch_is_text(int32_t table, int32_t col) {
+   if (table == LDB_TPCH_PART) return col == P_BRAND || col == P_CONTAINER || col == P_MFGR;
+   if (table == LDB_TPCH_SUPPLIER) return col == S_NAME || col == S_ADDRESS || col == S_PHONE || col == S_COMMENT;
+   if (table == LDB_TPCH_ORDERS) return col == O_COMMENT;
+   if (table == LDB_TPCH_CUSTOMER) return col == C_PHONE;
+   return 0;
+}
+LDB_HD int32_t ldb_tpch_put(char* out, int32_t pos, const char* s) {
+   while (*s) out[pos++] = *s++;
+   return pos;
+}
+LDB_HD int32_t ldb_tpch_put_num(char* out, int32_t pos, int64_t v, int32_t digits) { /* zero padded */
+   for (int32_t i = digits - 1; i >= 0; i--) {
+      out[pos + i] = (char) ('0' + v % 10);
+      v /= 10;
+   }
+   return pos + digits;
+}
+LDB_HD int32_t ldb_tpch_phone(char* out, int32_t nationkey, uint64_t r) {
+   int32_t p = ldb_tpch_put_num(out, 0, nationkey + 10, 2);
+   out[p++] = '-';
+   p = ldb_tpch_put_num(out, p, (int64_t) (100 + r % 900), 3);
+   out[p++] = '-';
+   p = ldb_tpch_put_num(out, p, (int64_t) (100 + (r >> 16) % 900), 3);
+   out[p++] = '-';
+   return ldb_tpch_put_num(out, p, (int64_t) (1000 + (r >> 32) % 9000), 4);
+}
+/* word k (0..31) of the comment vocabulary appended at out[pos] */
+LDB_HD int32_t ldb_tpch_put_word(char* out, int32_t pos, int32_t k) {
+   const char blob[] = "furiously\0quickly\0carefully\0blithely\0slyly\0regular\0final\0ironic\0even\0bold\0silent\0pending\0express\0unusual\0special\0requests\0"
+                       "deposits\0packages\0accounts\0instructions\0foxes\0ideas\0theodolites\0pinto\0beans\0platelets\0asymptotes\0courts\0dolphins\0excuses\0sleep\0wake";
+   int32_t at = 0;
+   for (int32_t w = 0; w < (k & 31); w++) {
+      while (blob[at]) at++;
+      at++;
+   }
+   return ldb_tpch_put(out, pos, blob + at);
+}
+/* blank-separated vocabulary words up to `cap` bytes; `inject` != 0 puts "Customer" … "Complaints" in */
+LDB_HD int32_t ldb_tpch_comment(char* out, int32_t table, int32_t col, int64_t row, int32_t cap, int32_t inject) {
+   const uint64_t r0 = ldb_rnd((uint32_t) table, (uint32_t) col * 8u, (uint64_t) row);
+   const int32_t n_words = 4 + (int32_t) (r0 % 6); /* 4..9 words */
+   int32_t pos = 0;
+   for (int32_t j = 0; j < n_words; j++) {
+      const uint64_t r = ldb_rnd((uint32_t) table, (uint32_t) col * 8u + 1u, (uint64_t) row * 16u + (uint64_t) j);
+      if (pos + 14 > cap) break; /* the longest word has 12 bytes */
+      if (j) out[pos++] = ' ';
+      if (inject && j == 1) pos = ldb_tpch_put(out, pos, "Customer");
+      else if (inject && j == 3) pos = ldb_tpch_put(out, pos, "Complaints");
+      else pos = ldb_tpch_put_word(out, pos, (int32_t) (r & 31));
+   }
+   return pos;
+}
+LDB_HD int32_t ldb_tpch_s_nationkey(int64_t supp_idx) { return (int32_t) (ldb_rnd(LDB_TPCH_SUPPLIER, S_NATIONKEY, (uint64_t) supp_idx) % 25); }
+LDB_HD int32_t ldb_tpch_p_mfgr(int64_t part_idx) { return 1 + (int32_t) (ldb_rnd(LDB_TPCH_PART, P_MFGR, (uint64_t) part_idx) % 5); }
+LDB_HD int32_t ldb_tpch_text(int32_t table, int32_t col, int64_t row, char* out) {
+   int32_t p = 0;
+   if (table == LDB_TPCH_PART) {
+      if (col == P_BRAND) {
+         p = ldb_tpch_put(out, 0, "Brand#");
+         out[p++] = (char) ('0' + ldb_tpch_p_mfgr(row));
+         out[p++] = (char) ('1' + ldb_rnd(LDB_TPCH_PART, P_BRAND, (uint64_t) row) % 5);
+         return p;
+      }
+      if (col == P_MFGR) {
+         p = ldb_tpch_put(out, 0, "Manufacturer#");
+         out[p++] = (char) ('0' + ldb_tpch_p_mfgr(row));
+         return p;
+      }
+      /* P_CONTAINER */
+      const uint64_t r = ldb_rnd(LDB_TPCH_PART, P_CONTAINER, (uint64_t) row);
+      switch (r % 5) {
+         case 0: p = ldb_tpch_put(out, 0, "SM "); break;
+         case 1: p = ldb_tpch_put(out, 0, "LG "); break;
+         case 2: p = ldb_tpch_put(out, 0, "MED "); break;
+         case 3: p = ldb_tpch_put(out, 0, "JUMBO "); break;
+         default: p = ldb_tpch_put(out, 0, "WRAP "); break;
+      }
+      switch ((r >> 8) % 8) {
+         case 0: return ldb_tpch_put(out, p, "CASE");
+         case 1: return ldb_tpch_put(out, p, "BOX");
+         case 2: return ldb_tpch_put(out, p, "BAG");
+         case 3: return ldb_tpch_put(out, p, "JAR");
+         case 4: return ldb_tpch_put(out, p, "PKG");
+         case 5: return ldb_tpch_put(out, p, "PACK");
+         case 6: return ldb_tpch_put(out, p, "CAN");
+         default: return ldb_tpch_put(out, p, "DRUM");
+      }
+   }
+   if (table == LDB_TPCH_SUPPLIER) {
+      if (col == S_NAME) {
+         p = ldb_tpch_put(out, 0, "Supplier#");
+         return ldb_tpch_put_num(out, p, row + 1, 9);
+      }
+      if (col == S_PHONE) return ldb_tpch_phone(out, ldb_tpch_s_nationkey(row), ldb_rnd(LDB_TPCH_SUPPLIER, S_PHONE, (uint64_t) row));
+      if (col == S_ADDRESS) {
+         const uint64_t r0 = ldb_rnd(LDB_TPCH_SUPPLIER, S_ADDRESS, (uint64_t) row);
+         const int32_t len = 10 + (int32_t) (r0 % 16);
+         for (int32_t i = 0; i < len; i++) {
+            const uint64_t r = ldb_rnd(LDB_TPCH_SUPPLIER, S_ADDRESS * 8 + 1, (uint64_t) row * 32u + (uint64_t) i);
+            out[i] = (char) ((r % 2 ? 'a' : 'A') + (r >> 8) % 26);
+         }
+         return len;
+      }
+      /* S_COMMENT */
+      return ldb_tpch_comment(out, table, col, row, 101, ldb_rnd(LDB_TPCH_SUPPLIER, S_COMMENT * 8 + 2, (uint64_t) row) % 200 == 0);
+   }
+   if (table == LDB_TPCH_ORDERS) return ldb_tpch_comment(out, table, col, row, 79, 0);
+   /* customer.c_phone */
+   return ldb_tpch_phone(out, ldb_tpch_c_nationkey(row), ldb_rnd(LDB_TPCH_CUSTOMER, C_PHONE, (uint64_t) row));
 }
 
 /* ---- slices: rank `part` of `n_parts` owns a contiguous block of each table.  Orders (and

@@ -145,6 +145,15 @@ int32_t ldb_gpu_prof_names(ldb_ctx* ctx, char* buf, int32_t cap);
 int32_t ldb_gpu_jit_stats(int64_t* compiled, int64_t* cache_hits, double* compile_ms);
 int32_t ldb_gpu_jit_compile_check(char* log, int32_t cap);
 
+/* Process-wide tuning options (each also readable from the environment as LDB_<NAME> on first use):
+ *   jit (0/1), jit_min_rows      — run-time kernel specialisation and its row threshold (default 4 M)
+ *   lazy_filter (0/1), lazy_min_rows — filters fused into the consuming kernel (default >= 1 M rows)
+ *   join_ordered, join_chained, join_radix, join_radix_min_rows, probe_batch, gb_ordered, gb_sorted
+ * Tests use it to drive ONE process through both the generic and the specialised / fused code
+ * paths (the reference has the same kind of switch: LINGODB_EXECUTION_MODE, Execution.cpp:224-228). */
+int32_t ldb_gpu_set_option(const char* name, int64_t value);
+int64_t ldb_gpu_get_option(const char* name); /* -1 when never set and no default was read yet */
+
 /* ------------------------------------------------------------------ tables (a1) */
 /* Replaces LingoDBTable::ensureLoaded + TableChunk flattening (LingoDBTable.cpp:27-54,
  * 200-225).  `schema` is a struct schema (format "+s"); each batch a struct array whose
@@ -367,6 +376,19 @@ int64_t ldb_gpu_hashtable_slots(const ldb_hashtable* ht);
  * 1-column BOOL8 table.  NULL keys never match. */
 int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys,
                            int32_t kind, ldb_rel** out, ldb_table** mark_out);
+/* The same with residual conjuncts of the join predicate: a key match counts only when every
+ * `probe_col OP build_col` holds on the candidate pair (integer / decimal / date columns; NULL
+ * operands fail).  In the reference a non-equality part of a join predicate is the filter behind
+ * the lookup (SpecializeSubOpPass.cpp:152-205) — e.g. Q21's l2.l_suppkey <> l1.l_suppkey inside
+ * EXISTS / NOT EXISTS (semi / anti join with residual, RelAlgToSubOp.cpp:1340-1410). */
+typedef struct {
+   ldb_colref probe_col;
+   ldb_colref build_col;
+   int32_t op; /* LDB_F_EQ .. LDB_F_GTE */
+   int32_t reserved;
+} ldb_join_residual;
+int32_t ldb_gpu_join_probe_residual(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind,
+                                    const ldb_join_residual* resid, int32_t n_resid, ldb_rel** out, ldb_table** mark_out);
 /* count matches only — the probe micro-benchmark kernel (Grows/s) */
 int32_t ldb_gpu_join_probe_count(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys,
                                  int64_t* matches);

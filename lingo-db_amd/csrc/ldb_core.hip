@@ -18,6 +18,36 @@ void ldb_set_error(const char* fmt, ...) {
 }
 extern "C" const char* ldb_gpu_last_error(void) { return g_err; }
 
+// ---------------------------------------------------------------- options
+// Process-wide tuning knobs: first read comes from the environment (LDB_<NAME>), later
+// ldb_gpu_set_option calls override it — so a test can run the same process through both the
+// generic and the run-time specialised / lazily fused code paths.
+#include <mutex>
+static std::mutex g_opt_mu;
+static std::unordered_map<std::string, int64_t> g_opts;
+int64_t ldb_option(const char* name, int64_t dflt) {
+   std::lock_guard<std::mutex> lock(g_opt_mu);
+   auto it = g_opts.find(name);
+   if (it != g_opts.end()) return it->second;
+   std::string env = "LDB_";
+   for (const char* c = name; *c; c++) env += (char) toupper((unsigned char) *c);
+   int64_t v = dflt;
+   if (const char* e = getenv(env.c_str())) v = atoll(e);
+   g_opts[name] = v;
+   return v;
+}
+extern "C" int32_t ldb_gpu_set_option(const char* name, int64_t value) {
+   if (!name) LDB_FAIL(LDB_ERR_INVALID, "set_option: NULL name");
+   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "join_radix", "join_radix_min_rows", "probe_batch"};
+   bool ok = false;
+   for (const char* k : known) ok |= strcmp(k, name) == 0;
+   if (!ok) LDB_FAIL(LDB_ERR_INVALID, "set_option: unknown option '%s'", name);
+   std::lock_guard<std::mutex> lock(g_opt_mu);
+   g_opts[name] = value;
+   return LDB_OK;
+}
+extern "C" int64_t ldb_gpu_get_option(const char* name) { return name ? ldb_option(name, -1) : -1; }
+
 // ---------------------------------------------------------------- memory
 // size classes of the block cache: 8 per doubling (≤ 12.5 % internal waste), 256 B minimum
 static size_t ldb_size_class(size_t bytes) {
@@ -324,6 +354,12 @@ extern "C" int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct
    int64_t rows = 0;
    for (int64_t b = 0; b < n_batches; b++) {
       if (batches[b]->n_children != schema->n_children) LDB_FAIL(LDB_ERR_INVALID, "batch %ld has %ld children, schema %ld", (long) b, (long) batches[b]->n_children, (long) schema->n_children);
+      // a sliced struct array (parent offset / length) selects rows [offset, offset + length) of every child
+      for (int64_t c = 0; c < schema->n_children; c++) {
+         const struct ArrowArray* ch = batches[b]->children[c];
+         if (batches[b]->offset < 0 || batches[b]->length < 0 || ch->length < batches[b]->offset + batches[b]->length)
+            LDB_FAIL(LDB_ERR_INVALID, "batch %ld: child %ld has %ld rows, the struct slice needs %ld", (long) b, (long) c, (long) ch->length, (long) (batches[b]->offset + batches[b]->length));
+      }
       rows += batches[b]->length;
    }
    if (rows >= (int64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "table_register: %ld rows exceed uint32 row ids", (long) rows);
@@ -341,10 +377,11 @@ extern "C" int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct
       bool any_null = false;
       for (int64_t b = 0; b < n_batches; b++) {
          struct ArrowArray* a = batches[b]->children[c];
+            const int64_t alen = batches[b]->length, aoff = batches[b]->offset + a->offset; // the parent's slice applies to every child
          if (a->null_count != 0 && a->buffers[0]) {
             const uint8_t* v = (const uint8_t*) a->buffers[0];
-            for (int64_t i = 0; i < a->length && !any_null; i++) {
-               int64_t k = i + a->offset;
+            for (int64_t i = 0; i < alen && !any_null; i++) {
+               int64_t k = i + aoff;
                if (!((v[k >> 3] >> (k & 7)) & 1)) any_null = true;
             }
          }
@@ -354,9 +391,10 @@ extern "C" int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct
          int64_t pos = 0;
          for (int64_t b = 0; b < n_batches; b++) {
             struct ArrowArray* a = batches[b]->children[c];
+            const int64_t alen = batches[b]->length, aoff = batches[b]->offset + a->offset; // the parent's slice applies to every child
             const uint8_t* v = (const uint8_t*) a->buffers[0];
-            for (int64_t i = 0; i < a->length; i++, pos++) {
-               int64_t k = i + a->offset;
+            for (int64_t i = 0; i < alen; i++, pos++) {
+               int64_t k = i + aoff;
                bool ok = !v || ((v[k >> 3] >> (k & 7)) & 1);
                if (ok) bm[(size_t) (pos >> 3)] |= (uint8_t) (1u << (pos & 7));
                else col.null_count++;
@@ -372,14 +410,15 @@ extern "C" int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct
          offs[0] = 0;
          for (int64_t b = 0; b < n_batches; b++) {
             struct ArrowArray* a = batches[b]->children[c];
-            for (int64_t i = 0; i < a->length; i++) {
+            const int64_t alen = batches[b]->length, aoff = batches[b]->offset + a->offset; // the parent's slice applies to every child
+            for (int64_t i = 0; i < alen; i++) {
                int64_t lo, hi;
                if (large) {
-                  const int64_t* o = (const int64_t*) a->buffers[1] + a->offset;
+                  const int64_t* o = (const int64_t*) a->buffers[1] + aoff;
                   lo = o[i];
                   hi = o[i + 1];
                } else {
-                  const int32_t* o = (const int32_t*) a->buffers[1] + a->offset;
+                  const int32_t* o = (const int32_t*) a->buffers[1] + aoff;
                   lo = o[i];
                   hi = o[i + 1];
                }
@@ -394,16 +433,17 @@ extern "C" int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct
          int64_t dpos = 0;
          for (int64_t b = 0; b < n_batches; b++) {
             struct ArrowArray* a = batches[b]->children[c];
-            if (a->length == 0) continue;
+            const int64_t alen = batches[b]->length, aoff = batches[b]->offset + a->offset; // the parent's slice applies to every child
+            if (alen == 0) continue;
             int64_t lo, hi;
             if (large) {
-               const int64_t* o = (const int64_t*) a->buffers[1] + a->offset;
+               const int64_t* o = (const int64_t*) a->buffers[1] + aoff;
                lo = o[0];
-               hi = o[a->length];
+               hi = o[alen];
             } else {
-               const int32_t* o = (const int32_t*) a->buffers[1] + a->offset;
+               const int32_t* o = (const int32_t*) a->buffers[1] + aoff;
                lo = o[0];
-               hi = o[a->length];
+               hi = o[alen];
             }
             if (hi > lo) LDB_HIP(hipMemcpyAsync((uint8_t*) col.values + dpos, (const uint8_t*) a->buffers[2] + lo, (size_t) (hi - lo), hipMemcpyHostToDevice, ctx->stream));
             dpos += hi - lo;
@@ -417,17 +457,18 @@ extern "C" int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct
          std::vector<int64_t> tmp;
          for (int64_t b = 0; b < n_batches; b++) {
             struct ArrowArray* a = batches[b]->children[c];
-            if (a->length == 0) continue;
-            const uint8_t* src = (const uint8_t*) a->buffers[1] + a->offset * src_w;
+            const int64_t alen = batches[b]->length, aoff = batches[b]->offset + a->offset; // the parent's slice applies to every child
+            if (alen == 0) continue;
+            const uint8_t* src = (const uint8_t*) a->buffers[1] + aoff * src_w;
             if (src_w == col.width) {
-               LDB_HIP(hipMemcpyAsync((uint8_t*) col.values + pos * col.width, src, (size_t) (a->length * src_w), hipMemcpyHostToDevice, ctx->stream));
+               LDB_HIP(hipMemcpyAsync((uint8_t*) col.values + pos * col.width, src, (size_t) (alen * src_w), hipMemcpyHostToDevice, ctx->stream));
             } else { // narrowed decimal: keep the low 64 bits (the value fits, p < 19)
-               tmp.resize((size_t) a->length);
-               for (int64_t i = 0; i < a->length; i++) memcpy(&tmp[(size_t) i], src + i * 16, 8);
-               LDB_HIP(hipMemcpyAsync((uint8_t*) col.values + pos * 8, tmp.data(), (size_t) (a->length * 8), hipMemcpyHostToDevice, ctx->stream));
+               tmp.resize((size_t) alen);
+               for (int64_t i = 0; i < alen; i++) memcpy(&tmp[(size_t) i], src + i * 16, 8);
+               LDB_HIP(hipMemcpyAsync((uint8_t*) col.values + pos * 8, tmp.data(), (size_t) (alen * 8), hipMemcpyHostToDevice, ctx->stream));
                LDB_HIP(hipStreamSynchronize(ctx->stream));
             }
-            pos += a->length;
+            pos += alen;
          }
          LDB_HIP(hipStreamSynchronize(ctx->stream));
       }

@@ -456,7 +456,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
 
    // ordered global slots (DGroupBy::ordered_slots): one integer key with a 32-bit value range
    unsigned __int128 key_range = 0;
-   static const bool gb_ordered = !(getenv("LDB_GB_ORDERED") && getenv("LDB_GB_ORDERED")[0] == '0');
+   const bool gb_ordered = ldb_option("gb_ordered", 1) != 0;
    if (gb_ordered && !h->use_lds && n_keys == 1 && in->n_rows > 0) {
       int64_t lo = 0, hi = -1;
       const ldb_rel_side& ks = in->sides[(size_t) keys[0].side];
@@ -469,7 +469,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    }
    // sorted key column, no filter (DGroupBy::dense_sorted): number the groups by key changes
    uint32_t* chunk_off = nullptr;
-   static const bool gb_sorted = !(getenv("LDB_GB_SORTED") && getenv("LDB_GB_SORTED")[0] == '0');
+   const bool gb_sorted = ldb_option("gb_sorted", 1) != 0;
    if (gb_sorted && !h->use_lds && n_keys == 1 && h->n_preds == 0 && in->n_rows > 0) {
       const ldb_rel_side& ks = in->sides[(size_t) keys[0].side];
       bool sorted = false;
@@ -485,7 +485,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
             const int hgrid = ldb_grid_for(ctx, in->n_rows, 256, 8);
             hipFunction_t spec = nullptr;
             std::string why;
-            if (ldb_jit_wanted(in->n_rows)) spec = ldb_jit_groupby_kernel(h, "k_gb_sorted_heads_spec", &why);
+            if (ldb_jit_wanted(in->n_rows)) spec = ldb_jit_groupby_kernel(ctx->device, h, "k_gb_sorted_heads_spec", &why);
             LdbProf prof_(ctx, "k_gb_sorted_heads");
             if (spec) {
                void* params[] = {(void*) &dh, (void*) &chunk_cnt};
@@ -530,7 +530,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          hipFunction_t spec = nullptr;
          if (ldb_jit_wanted(in->n_rows)) {
             std::string why;
-            spec = ldb_jit_groupby(h, &why);
+            spec = ldb_jit_groupby(ctx->device, h, &why);
             if (!spec) ldb_set_error("groupby: specialised kernel unavailable (%s); using the generic kernel", why.c_str());
          }
          if (spec) {

@@ -30,6 +30,9 @@ void ldb_set_error(const char* fmt, ...);
       if (s_ != LDB_OK) return s_; \
    } while (0)
 
+// process-wide option (env LDB_<NAME> on first use, ldb_gpu_set_option afterwards)
+int64_t ldb_option(const char* name, int64_t dflt);
+
 // device-visible descriptors (DCol, DPred, DKeys) live in ldb_devtypes.h
 #include "ldb_devtypes.h"
 

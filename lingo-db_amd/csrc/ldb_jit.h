@@ -13,10 +13,10 @@ bool ldb_jit_wanted(int64_t n_rows);
 
 // Generic entry: compile (or fetch from the cache) a module made of
 //    #include "<header>";  constexpr <struct_name> LDB_META = <meta bytes>;  <kernels_src>
-// and return `kernel_name` from it.  `meta` must be pointer-free metadata (addresses stripped with
+// and return `kernel_name` from it, loaded into `device` (one module per device and architecture).  `meta` must be pointer-free metadata (addresses stripped with
 // the helpers below).  Returns nullptr (reason in *why) when hiprtc is unavailable or the
 // compilation fails — callers then launch their generic ahead-of-time kernel.
-hipFunction_t ldb_jit_kernel(const char* header, const char* struct_name, const char* kernels_src, const char* kernel_name, const void* meta, size_t meta_bytes,
+hipFunction_t ldb_jit_kernel(int device, const char* header, const char* struct_name, const char* kernels_src, const char* kernel_name, const void* meta, size_t meta_bytes,
                              std::string* why);
 // compile only (no device needed, nothing cached): used by the device-less build check
 bool ldb_jit_compile_only(const char* header, const char* struct_name, const char* kernels_src, const void* meta, size_t meta_bytes, std::string* log);
@@ -29,8 +29,8 @@ void ldb_jit_strip_pred(DPred& p);
 void ldb_jit_strip_keys(DKeys& k);
 
 // specialised group-by kernel for the metadata of `h`
-hipFunction_t ldb_jit_groupby(const DGroupBy* h, std::string* why);
-hipFunction_t ldb_jit_groupby_kernel(const DGroupBy* h, const char* kernel, std::string* why); // any kernel of the group-by translation unit
+hipFunction_t ldb_jit_groupby(int device, const DGroupBy* h, std::string* why);
+hipFunction_t ldb_jit_groupby_kernel(int device, const DGroupBy* h, const char* kernel, std::string* why); // any kernel of the group-by translation unit
 
 // statistics for tests / bench: kernels compiled, cache hits, total compile milliseconds
 extern "C" int32_t ldb_gpu_jit_stats(int64_t* compiled, int64_t* cache_hits, double* compile_ms);

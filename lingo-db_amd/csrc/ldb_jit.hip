@@ -29,16 +29,7 @@ static std::unordered_map<uint64_t, std::vector<std::unique_ptr<JitModule>>> g_c
 static int64_t g_compiled = 0, g_hits = 0;
 static double g_compile_ms = 0;
 
-bool ldb_jit_wanted(int64_t n_rows) {
-   static int enabled = -1;
-   static int64_t min_rows = 4000000;
-   if (enabled < 0) {
-      const char* e = getenv("LDB_JIT");
-      enabled = (e && e[0] == '0') ? 0 : 1;
-      if (const char* m = getenv("LDB_JIT_MIN_ROWS")) min_rows = atoll(m);
-   }
-   return enabled && n_rows >= min_rows;
-}
+bool ldb_jit_wanted(int64_t n_rows) { return ldb_option("jit", 1) != 0 && n_rows >= ldb_option("jit_min_rows", 4000000); }
 
 static uint64_t fnv1a(const unsigned char* p, size_t n, uint64_t h = 1469598103934665603ull) {
    for (size_t i = 0; i < n; i++) {
@@ -86,7 +77,7 @@ static std::string build_source(const char* header, const char* struct_name, con
 }
 
 // compile only (no device needed); code object into *code
-static bool compile(const std::string& src, std::vector<char>* code, std::string* err) {
+static bool compile(const std::string& src, std::vector<char>* code, std::string* err, const char* arch = "gfx950") {
    std::vector<const char*> names, texts;
    for (int i = 0; i < g_n_headers; i++) {
       names.push_back(g_headers[i].name);
@@ -112,7 +103,8 @@ static bool compile(const std::string& src, std::vector<char>* code, std::string
    // The descriptor loops (LDB_UNROLL) must unroll completely or nothing folds: before unrolling
    // their bodies hold the whole generic interpreter, which exceeds the default pragma-unroll
    // size limit and silently leaves a generic loop reading the constexpr descriptor from memory.
-   std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-mllvm", "-pragma-unroll-threshold=4000000"};
+   const std::string arch_opt = std::string("--offload-arch=") + arch;
+   std::vector<const char*> opts = {arch_opt.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics", "-mllvm", "-pragma-unroll-threshold=4000000"};
    for (auto& e : extra) opts.push_back(e.c_str());
    hiprtcResult r = hiprtcCompileProgram(prog, (int) opts.size(), opts.data());
    if (r != HIPRTC_SUCCESS) {
@@ -137,10 +129,31 @@ bool ldb_jit_compile_only(const char* header, const char* struct_name, const cha
    return compile(build_source(header, struct_name, kernels_src, (const unsigned char*) meta, meta_bytes), &code, log);
 }
 
-hipFunction_t ldb_jit_kernel(const char* header, const char* struct_name, const char* kernels_src, const char* kernel_name, const void* meta, size_t meta_bytes,
+// gcnArchName of a device ("gfx950:sramecc+:xnack-"), cached
+static std::string device_arch(int device) {
+   static std::mutex mu;
+   static std::unordered_map<int, std::string> archs;
+   std::lock_guard<std::mutex> lock(mu);
+   auto it = archs.find(device);
+   if (it != archs.end()) return it->second;
+   hipDeviceProp_t prop;
+   std::string a = "gfx950";
+   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.gcnArchName[0]) a = prop.gcnArchName;
+   archs[device] = a;
+   return a;
+}
+
+hipFunction_t ldb_jit_kernel(int device, const char* header, const char* struct_name, const char* kernels_src, const char* kernel_name, const void* meta, size_t meta_bytes,
                              std::string* why) {
+   // a module is loaded into ONE device: the cache is keyed by device too, and the load happens
+   // with that device current (a process may hold contexts on several GPUs)
+   const std::string arch = device_arch(device);
    std::string key;
    key.reserve(meta_bytes + 256);
+   key += std::to_string(device);
+   key += '|';
+   key += arch;
+   key += '|';
    key += header;
    key += '|';
    key += struct_name;
@@ -167,7 +180,7 @@ hipFunction_t ldb_jit_kernel(const char* header, const char* struct_name, const 
             fclose(f);
          }
       }
-      bool ok = compile(src, &e->code, &e->error);
+      bool ok = compile(src, &e->code, &e->error, arch.c_str());
       g_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (ok) {
          if (const char* dir = getenv("LDB_JIT_DUMP_DIR")) { // code objects for llvm-objdump inspection
@@ -178,7 +191,12 @@ hipFunction_t ldb_jit_kernel(const char* header, const char* struct_name, const 
                fclose(f);
             }
          }
-         if (hipModuleLoadData(&e->module, e->code.data()) != hipSuccess) {
+         int prev = -1;
+         (void) hipGetDevice(&prev);
+         (void) hipSetDevice(device);
+         const hipError_t le = hipModuleLoadData(&e->module, e->code.data());
+         if (prev >= 0 && prev != device) (void) hipSetDevice(prev);
+         if (le != hipSuccess) {
             e->error = "hipModuleLoadData failed for the specialised kernel";
             e->module = nullptr;
          } else {
@@ -228,12 +246,12 @@ static void gb_meta(const DGroupBy* h, DGroupBy* m) {
    for (int o = 0; o < GB_MAX_OUT; o++) m->outs[o].out_values = m->outs[o].out_valid = 0;
 }
 
-hipFunction_t ldb_jit_groupby_kernel(const DGroupBy* h, const char* kernel, std::string* why) {
+hipFunction_t ldb_jit_groupby_kernel(int device, const DGroupBy* h, const char* kernel, std::string* why) {
    auto meta = std::make_unique<DGroupBy>();
    gb_meta(h, meta.get());
-   return ldb_jit_kernel("ldb_gb_kernel.h", "DGroupBy", GB_SPEC_SRC, kernel, meta.get(), sizeof(DGroupBy), why);
+   return ldb_jit_kernel(device, "ldb_gb_kernel.h", "DGroupBy", GB_SPEC_SRC, kernel, meta.get(), sizeof(DGroupBy), why);
 }
-hipFunction_t ldb_jit_groupby(const DGroupBy* h, std::string* why) { return ldb_jit_groupby_kernel(h, "k_groupby_spec", why); }
+hipFunction_t ldb_jit_groupby(int device, const DGroupBy* h, std::string* why) { return ldb_jit_groupby_kernel(device, h, "k_groupby_spec", why); }
 
 // Compile-only check (no device needed): specialise the group-by kernel for a TPC-H-Q1-shaped
 // descriptor and report the hiprtc log.  Used by the CPU-side tests and __graft_entry__.build().

@@ -79,8 +79,12 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
       ldb_jit_strip_keys(meta->bkeys);
       ldb_jit_strip_keys(meta->pkeys);
       for (int p = 0; p < LDB_MAX_PREDS; p++) ldb_jit_strip_pred(meta->ppreds[p]);
+      for (int k = 0; k < LDB_MAX_RESID; k++) {
+         ldb_jit_strip_col(meta->resid[k].pcol);
+         ldb_jit_strip_col(meta->resid[k].bcol);
+      }
       std::string why;
-      spec = ldb_jit_kernel("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, spec_name, meta.get(), sizeof(DJoin), &why);
+      spec = ldb_jit_kernel(ctx->device, "ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, spec_name, meta.get(), sizeof(DJoin), &why);
    }
    LdbProf prof_(ctx, prof_name);
    if (spec) {
@@ -166,7 +170,7 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
    h->flags = (uint64_t) dflags;
    h->has_flags = 1;
    // KEY32: slots in key order (see DJoin::ordered_slots) — needs the build key range first
-   static const bool ordered_enabled = !(getenv("LDB_JOIN_ORDERED") && getenv("LDB_JOIN_ORDERED")[0] == '0');
+   const bool ordered_enabled = ldb_option("join_ordered", 1) != 0;
    if (ht->key32 && ordered_enabled && build->n_rows > 0) {
       long long got[2];
       // the key column's cached statistic (a superset of the build rows' range, free after its first
@@ -203,7 +207,7 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
    }
    // up to three passes: ordered slots → hashed slots (skewed key range) → chained (a key repeats so
    // often that one slot per row gives long runs); each pass stops early when it sees such a run
-   static const bool force_chained = getenv("LDB_JOIN_CHAINED") && getenv("LDB_JOIN_CHAINED")[0] == '1'; // tests
+   const bool force_chained = ldb_option("join_chained", 0) == 1; // tests
    if (force_chained) {
       ht->ordered_slots = 0;
       ldb_dev_free(ctx, ht->key_bits);
@@ -257,7 +261,8 @@ extern "C" int32_t ldb_gpu_hashtable_release(ldb_ctx* ctx, ldb_hashtable* ht) {
 }
 extern "C" int64_t ldb_gpu_hashtable_slots(const ldb_hashtable* ht) { return ht ? (int64_t) ht->cap : -1; }
 
-static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, DJoin* h) {
+static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, DJoin* h, const ldb_join_residual* resid = nullptr,
+                               int32_t n_resid = 0) {
    if ((size_t) n_keys != ht->keys.size()) LDB_FAIL(LDB_ERR_INVALID, "join_probe: %d probe keys vs %zu build keys", n_keys, ht->keys.size());
    memset(h, 0, sizeof(*h));
    LDB_TRY(ldb_make_dkeys(ht->build, ht->keys.data(), n_keys, &h->bkeys));
@@ -285,10 +290,22 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    h->has_key_bits = ht->key_bits ? 1 : 0;
    h->chained = ht->chained;
    h->next = (uint64_t) ht->next;
+   h->build_unique = (ht->unique && !ht->chained) ? 1 : 0;
    // a lazy probe relation brings its filter along: evaluated inside the probe kernel
    h->n_ppreds = (int32_t) probe->pending.size();
    for (size_t p = 0; p < probe->pending.size(); p++) h->ppreds[p] = probe->pending[p];
    ldb_order_preds(h->ppreds, h->n_ppreds);
+   if (n_resid < 0 || n_resid > LDB_MAX_RESID || (n_resid && !resid)) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: %d residual conjuncts (max %d)", n_resid, LDB_MAX_RESID);
+   h->n_resid = n_resid;
+   for (int32_t k = 0; k < n_resid; k++) {
+      LDB_TRY(ldb_make_dcol(probe, resid[k].probe_col, &h->resid[k].pcol));
+      LDB_TRY(ldb_make_dcol(ht->build, resid[k].build_col, &h->resid[k].bcol));
+      const int op = resid[k].op;
+      if (op < LDB_F_EQ || op > LDB_F_GTE) LDB_FAIL(LDB_ERR_INVALID, "join_probe: residual %d: comparison operator expected", k);
+      for (const DCol* c : {&h->resid[k].pcol, &h->resid[k].bcol})
+         if (c->type == LDB_T_UTF8 || c->type == LDB_T_FLOAT32 || c->type == LDB_T_FLOAT64) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: residual %d: integer / decimal / date columns only", k);
+      h->resid[k].op = op;
+   }
    return LDB_OK;
 }
 
@@ -312,6 +329,11 @@ extern "C" int32_t ldb_gpu_join_probe_count(ldb_ctx* ctx, ldb_hashtable* ht, ldb
 
 extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind, ldb_rel** out,
                                       ldb_table** mark_out) {
+   return ldb_gpu_join_probe_residual(ctx, ht, probe, keys, n_keys, kind, nullptr, 0, out, mark_out);
+}
+
+extern "C" int32_t ldb_gpu_join_probe_residual(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind,
+                                               const ldb_join_residual* resid, int32_t n_resid, ldb_rel** out, ldb_table** mark_out) {
    if (!ctx || !ht || !probe || !out) LDB_FAIL(LDB_ERR_INVALID, "join_probe: NULL argument");
    if (kind < LDB_JOIN_INNER || kind > LDB_JOIN_ANTI_BUILD) LDB_FAIL(LDB_ERR_INVALID, "join_probe: bad kind %d", kind);
    // kinds that emit a row for EVERY probe row (outer / single / mark) need the filtered row set itself
@@ -320,7 +342,7 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
    if (kind == LDB_JOIN_SEMI_BUILD || kind == LDB_JOIN_ANTI_BUILD) {
       // flag the build rows that some probe row matches, then keep (SEMI) / drop (ANTI) them
       auto hb = std::make_unique<DJoin>();
-      LDB_TRY(make_probe_desc(ht, probe, keys, n_keys, hb.get()));
+      LDB_TRY(make_probe_desc(ht, probe, keys, n_keys, hb.get(), resid, n_resid));
       hb->kind = kind;
       const int64_t nb = ht->build->n_rows, nbw = (nb + 63) / 64;
       uint8_t* flags;
@@ -360,7 +382,7 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
       LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: result would have more than %d sides (materialize first)", LDB_MAX_SIDES);
    auto hp = std::make_unique<DJoin>();
    DJoin* h = hp.get();
-   LDB_TRY(make_probe_desc(ht, probe, keys, n_keys, h));
+   LDB_TRY(make_probe_desc(ht, probe, keys, n_keys, h, resid, n_resid));
    h->kind = kind;
    unsigned long long* counter = (unsigned long long*) (ctx->d_scratch + 16);
    h->counter = (uint64_t) counter;

@@ -7,6 +7,13 @@
 #pragma once
 #include "ldb_keys.h"
 
+#define LDB_MAX_RESID 2
+struct DJoinResid {
+   DCol pcol; // read at the probe relation's logical row
+   DCol bcol; // read at the build relation's logical row
+   int32_t op; // ldb_filter_op comparison: pcol OP bcol
+   int32_t pad;
+};
 struct DJoin {
    // ---- run-time part
    uint64_t n_rows; // rows of the relation the kernel iterates (build or probe)
@@ -49,7 +56,15 @@ struct DJoin {
    // When a build pass reports such runs the table is rebuilt CHAINED: one slot per distinct key,
    // the key's rows linked through next[] — the reference's layout (chained HashIndexedView).
    int32_t chained;
-   int32_t pad3;
+   // the build keys are known to be unique (verified by the build): a probe stops at its first key match
+   int32_t build_unique;
+   // residual conjuncts of the join predicate beyond the key equality, each comparing a probe-side
+   // column with a build-side column of the candidate pair (Q21's l2.l_suppkey <> l1.l_suppkey): a
+   // key match only counts when all of them hold (NULL operands fail).  The reference evaluates them
+   // as the filter behind the lookup (SpecializeSubOpPass.cpp:152-205 injects map + filter).
+   int32_t n_resid;
+   int32_t pad4;
+   DJoinResid resid[LDB_MAX_RESID];
    DPred ppreds[LDB_MAX_PREDS];
 };
 
@@ -203,80 +218,177 @@ __device__ __forceinline__ void join_key_bits_body(const DJoin& m, const DJoin* 
    }
 }
 
-// chained tables: the rows of one key, head first (next[row] = following row + 1, 0 = end)
-template <typename EMIT>
-__device__ __forceinline__ uint32_t d_probe_chain(const DJoin* __restrict__ d, uint32_t head_plus1, EMIT emit) {
-   const uint32_t* next = gptr<uint32_t>(d->next);
-   uint32_t matches = 0;
-   for (uint32_t r = head_plus1; r != 0; r = next[r - 1u]) {
-      matches++;
-      if (!emit(r - 1u)) break;
+// residual conjuncts on the candidate pair (probe logical row i, build logical row brow)
+__device__ __forceinline__ bool d_resid_ok(const DJoin& m, const DJoin* __restrict__ d, uint64_t i, uint32_t brow) {
+   bool ok = true;
+   const int nr = m.n_resid;
+   LDB_UNROLL
+   for (int k = 0; k < nr; k++) {
+      if (ok) {
+         const CV pc(m.resid[k].pcol, d->resid[k].pcol), bc(m.resid[k].bcol, d->resid[k].bcol);
+         const uint32_t pr = d_phys_row(pc, i), br = d_phys_row(bc, brow);
+         if (!d_valid(pc, pr) || !d_valid(bc, br)) {
+            ok = false;
+         } else if (d_is_wide(pc) || d_is_wide(bc)) {
+            ok = d_cmp_vals<i128>(m.resid[k].op, d_load_i128(pc, pr), d_load_i128(bc, br));
+         } else {
+            ok = d_cmp_vals<int64_t>(m.resid[k].op, d_load_i64(pc, pr), d_load_i64(bc, br));
+         }
+      }
    }
-   return matches;
+   return ok;
 }
 
-// One probe row → visits its slot run.  EMIT is called for every match with the build row and
-// returns whether to keep scanning.
-template <typename EMIT>
-__device__ __forceinline__ uint32_t d_probe_row(const DJoin& m, const DJoin* __restrict__ d, uint64_t i, EMIT emit) {
+// U probe rows of one lane, phase-separated for memory-level parallelism.  A probe is a chain of
+// dependent loads (key → [key bit] → slot → next slot …): one row at a time a wave has ONE such
+// chain in flight per lane and the kernel runs at memory LATENCY (600 M FK probes: 112 Grows/s,
+// 0.17 of the HBM roofline although it moves no more than the algorithmic bytes).  Here the U key
+// loads issue back to back, then the U key-bit loads, then the first TWO slots of every row (the
+// second is in the same 64 B line seven times out of eight), with no control dependence between
+// them (a dead row loads element 0 — one broadcast line); only then the rows are resolved, and
+// for unique ordered KEY32 tables almost every row resolves from its prefetched slots without
+// entering the walk loop.  EMIT(u, build_row) is called per match in the order row-major / slot
+// order and returns whether to keep scanning that row.
+template <int U, typename EMIT>
+__device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __restrict__ d, const uint64_t (&rows)[U], const bool (&act)[U], uint32_t (&matches)[U],
+                                              EMIT emit) {
    const KV pkeys(m.pkeys, d->pkeys);
-   bool nul;
-   uint64_t h = d_hash_keys(pkeys, i, &nul);
-   if (nul) return 0;
    const uint64_t mask = d->cap - 1;
    const uint64_t* slots = gptr<uint64_t>(d->slots);
-   uint64_t pos = d_join_slot(m, d, h, 0, mask); // hashed start slot (ordered KEY32 tables: recomputed from the key below)
-   uint32_t matches = 0;
+   uint64_t pos[U], tag[U];
+   bool live[U];
+#pragma unroll
+   for (int u = 0; u < U; u++) {
+      matches[u] = 0;
+      live[u] = act[u];
+      pos[u] = 0;
+      tag[u] = 0;
+   }
    if (m.key32) {
       const CV c = pkeys.col(0);
-      int64_t kv = d_load_i64(c, d_phys_row(c, i));
-      if (kv != (int64_t) (int32_t) kv) return 0; // wider probe value can equal no 32-bit build key
-      if (m.ordered_slots) {
-         if (kv < d->kmin || kv > d->kmax) return 0; // outside the build key range
-         if (m.has_key_bits) {
-            const uint64_t r = (uint64_t) (kv - d->kmin);
-            if (((gptr<uint32_t>(d->key_bits)[r >> 5] >> (r & 31)) & 1u) == 0) return 0; // not a build key
+      int64_t kv[U];
+      if (!c.m.rowids && !c.m.validity) {
+#pragma unroll
+         for (int u = 0; u < U; u++) kv[u] = d_load_i64(c, act[u] ? (uint32_t) rows[u] : 0u); // callers guarantee n >= 1
+      } else {
+         uint32_t pr[U];
+#pragma unroll
+         for (int u = 0; u < U; u++) pr[u] = act[u] ? d_phys_row(c, rows[u]) : LDB_NULL_ROW;
+#pragma unroll
+         for (int u = 0; u < U; u++) {
+            kv[u] = 0;
+            if (act[u]) {
+               if (d_valid(c, pr[u])) kv[u] = d_load_i64(c, pr[u]);
+               else live[u] = false; // a NULL key matches nothing
+            }
          }
-         pos = d_join_slot(m, d, h, kv, mask);
       }
-      const uint32_t key = (uint32_t) kv;
-      for (;;) {
-         uint64_t w = slots[pos];
-         if (w == 0) break;
-         if ((uint32_t) (w >> 32) == key) {
-            if (m.chained) return d_probe_chain(d, (uint32_t) w, emit); // the key's only slot: its rows are the chain
-            matches++;
-            if (!emit((uint32_t) w - 1u)) break;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         if (kv[u] != (int64_t) (int32_t) kv[u]) live[u] = false; // a wider probe value can equal no 32-bit build key
+         tag[u] = (uint64_t) (uint32_t) kv[u];
+      }
+      if (m.ordered_slots) {
+         const int64_t kmin = d->kmin, kmax = d->kmax;
+#pragma unroll
+         for (int u = 0; u < U; u++) live[u] = live[u] && kv[u] >= kmin && kv[u] <= kmax; // outside the build key range
+         if (m.has_key_bits) {
+            const uint32_t* bits = gptr<uint32_t>(d->key_bits);
+            uint32_t bw[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) bw[u] = bits[live[u] ? (uint64_t) (kv[u] - kmin) >> 5 : 0];
+#pragma unroll
+            for (int u = 0; u < U; u++) live[u] = live[u] && ((bw[u] >> ((uint64_t) (kv[u] - kmin) & 31)) & 1u); // not a build key
          }
-         pos = (pos + 1) & mask;
+         const uint64_t kmult = d->kmult;
+#pragma unroll
+         for (int u = 0; u < U; u++) pos[u] = live[u] ? ((((uint64_t) (kv[u] - kmin) * kmult) >> 32) & mask) : 0;
+      } else {
+#pragma unroll
+         for (int u = 0; u < U; u++)
+            if (live[u]) pos[u] = d_join_slot(m, d, d_hash_keys(pkeys, rows[u]), 0, mask);
       }
    } else {
-      const KV bkeys(m.bkeys, d->bkeys);
-      for (;;) {
-         uint64_t w = slots[pos];
-         if (w == 0) break;
-         if ((w >> 32) == (h >> 32) && d_keys_equal(bkeys, (uint64_t) ((uint32_t) w - 1u), pkeys, i, false)) {
-            if (m.chained) return d_probe_chain(d, (uint32_t) w, emit);
-            matches++;
-            if (!emit((uint32_t) w - 1u)) break;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         if (act[u]) {
+            bool nul;
+            const uint64_t h = d_hash_keys(pkeys, rows[u], &nul);
+            live[u] = !nul;
+            tag[u] = h >> 32;
+            pos[u] = nul ? 0 : d_join_slot(m, d, h, 0, mask);
          }
-         pos = (pos + 1) & mask;
       }
    }
-   return matches;
+   // the first two slots of every row, unconditionally
+   uint64_t w0[U], w1[U];
+#pragma unroll
+   for (int u = 0; u < U; u++) {
+      w0[u] = slots[pos[u]];
+      w1[u] = slots[(pos[u] + 1) & mask];
+   }
+   const KV bkeys(m.bkeys, d->bkeys);
+#pragma unroll
+   for (int u = 0; u < U; u++) {
+      if (!live[u]) continue;
+      uint64_t p = pos[u], w = w0[u];
+      uint32_t step = 0;
+      for (;;) {
+         if (w == 0) break;
+         if ((w >> 32) == tag[u] && (m.key32 || d_keys_equal(bkeys, (uint64_t) ((uint32_t) w - 1u), pkeys, rows[u], false))) {
+            if (m.chained) { // the key's only slot: its rows are the chain
+               const uint32_t* next = gptr<uint32_t>(d->next);
+               for (uint32_t r = (uint32_t) w; r != 0; r = next[r - 1u]) {
+                  if (m.n_resid == 0 || d_resid_ok(m, d, rows[u], r - 1u)) {
+                     matches[u]++;
+                     if (!emit(u, r - 1u)) break;
+                  }
+               }
+               break;
+            }
+            bool stop = false;
+            if (m.n_resid == 0 || d_resid_ok(m, d, rows[u], (uint32_t) w - 1u)) {
+               matches[u]++;
+               stop = !emit(u, (uint32_t) w - 1u);
+            }
+            if (stop || m.build_unique) break;
+         }
+         p = (p + 1) & mask;
+         step++;
+         w = step == 1 ? w1[u] : slots[p];
+      }
+   }
 }
+
+// one probe row (the kinds that have no batch to offer)
+template <typename EMIT>
+__device__ __forceinline__ uint32_t d_probe_row(const DJoin& m, const DJoin* __restrict__ d, uint64_t i, EMIT emit) {
+   const uint64_t rows[1] = {i};
+   const bool act[1] = {true};
+   uint32_t mt[1];
+   d_probe_batch<1>(m, d, rows, act, mt, [&](int, uint32_t b) { return emit(b); });
+   return mt[0];
+}
+
+#ifndef JOIN_BATCH
+#define JOIN_BATCH 8 // probe rows in flight per lane
+#endif
 
 // INNER / LEFT_OUTER / SINGLE with possibly duplicated build keys, two passes and no atomics on
 // an output cursor (one contended cursor address serialises at ~10 ns per wave-append in the
 // L2: Q12's 150 M-row probe spent 22 ms there).  Pass 1 counts the rows every 64-row chunk
 // produces, a device scan turns the counts into chunk offsets, pass 2 re-walks (the slot runs are
 // now cache-resident) and every lane writes its pairs at chunk offset + in-wave prefix: output in
-// probe order, sized exactly.
-// rows one probe row contributes: its matches, or one NULL-padded row when an outer join finds none
-__device__ __forceinline__ uint32_t d_pairs_of_row(const DJoin& m, const DJoin* __restrict__ d, uint64_t i) {
-   if (!d_probe_pass(m, d, i)) return 0; // (the host only fuses filters for INNER here)
-   uint32_t c = d_probe_row(m, d, i, [&](uint32_t) { return m.kind != LDB_JOIN_SINGLE; });
-   return (m.kind != LDB_JOIN_INNER && c == 0) ? 1u : c;
+// probe order, sized exactly.  A wave handles JP_U consecutive chunks per iteration (batched probe).
+#define JP_U 4
+// rows each probe row of the batch contributes: its matches, or one NULL-padded row when an outer join finds none
+template <int U>
+__device__ __forceinline__ void d_pairs_of_rows(const DJoin& m, const DJoin* __restrict__ d, const uint64_t (&rows)[U], bool (&act)[U], uint32_t (&cnt)[U]) {
+   d_eval_conj_batch<U>(m.ppreds, d->ppreds, m.n_ppreds, rows, act); // (the host only fuses filters for INNER here)
+   d_probe_batch<U>(m, d, rows, act, cnt, [&](int, uint32_t) { return m.kind != LDB_JOIN_SINGLE; });
+#pragma unroll
+   for (int u = 0; u < U; u++)
+      if (act[u] && m.kind != LDB_JOIN_INNER && cnt[u] == 0) cnt[u] = 1u;
 }
 __device__ __forceinline__ void join_probe_pairs_count_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows;
@@ -286,12 +398,23 @@ __device__ __forceinline__ void join_probe_pairs_count_body(const DJoin& m, cons
    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
    uint32_t* chunk_cnt = gptr_mut<uint32_t>(d->match);
    unsigned long long total = 0; // exact 64-bit row count (the 32-bit offsets cannot detect > 4 G rows)
-   for (uint64_t w = wave; w < n_chunks; w += n_waves) {
-      const uint64_t i = w * 64 + lane;
-      uint32_t c = i < n ? d_pairs_of_row(m, d, i) : 0u;
-      for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-      if (lane == 0) chunk_cnt[w] = c;
-      total += c;
+   for (uint64_t w0 = wave * JP_U; w0 < n_chunks; w0 += n_waves * JP_U) {
+      uint64_t rows[JP_U];
+      bool act[JP_U];
+      uint32_t c[JP_U];
+#pragma unroll
+      for (int u = 0; u < JP_U; u++) {
+         rows[u] = (w0 + u) * 64 + lane;
+         act[u] = rows[u] < n;
+      }
+      d_pairs_of_rows<JP_U>(m, d, rows, act, c);
+#pragma unroll
+      for (int u = 0; u < JP_U; u++) {
+         uint32_t s = c[u];
+         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+         if (lane == 0 && w0 + u < n_chunks) chunk_cnt[w0 + u] = s;
+         total += s;
+      }
    }
    if (lane == 0 && total) atomicAdd(gptr_mut<unsigned long long>(d->counter), total);
 }
@@ -304,45 +427,70 @@ __device__ __forceinline__ void join_probe_pairs_body(const DJoin& m, const DJoi
    const uint32_t* chunk_off = gptr<uint32_t>(d->match);
    uint32_t* out_probe = gptr_mut<uint32_t>(d->out_probe);
    uint32_t* out_build = gptr_mut<uint32_t>(d->out_build);
-   for (uint64_t w = wave; w < n_chunks; w += n_waves) {
-      const uint64_t i = w * 64 + lane;
-      const uint32_t c = i < n ? d_pairs_of_row(m, d, i) : 0u;
-      uint32_t incl = c;
-      for (int off = 1; off < 64; off <<= 1) {
-         uint32_t up = __shfl_up(incl, off);
-         if (lane >= (uint32_t) off) incl += up;
+   for (uint64_t w0 = wave * JP_U; w0 < n_chunks; w0 += n_waves * JP_U) {
+      uint64_t rows[JP_U], at[JP_U];
+      bool act[JP_U];
+      uint32_t c[JP_U], emitted[JP_U];
+#pragma unroll
+      for (int u = 0; u < JP_U; u++) {
+         rows[u] = (w0 + u) * 64 + lane;
+         act[u] = rows[u] < n;
       }
-      if (c != 0) {
-         const uint64_t at = (uint64_t) chunk_off[w] + (incl - c);
-         uint32_t emitted = 0;
-         d_probe_row(m, d, i, [&](uint32_t brow) {
-            out_probe[at + emitted] = (uint32_t) i;
-            out_build[at + emitted] = brow;
-            emitted++;
-            return m.kind != LDB_JOIN_SINGLE;
-         });
-         if (emitted == 0) { // unmatched (or NULL-key) probe row of an outer join
-            out_probe[at] = (uint32_t) i;
-            out_build[at] = LDB_NULL_ROW;
+      d_pairs_of_rows<JP_U>(m, d, rows, act, c);
+#pragma unroll
+      for (int u = 0; u < JP_U; u++) {
+         uint32_t incl = c[u];
+         for (int off = 1; off < 64; off <<= 1) {
+            uint32_t up = __shfl_up(incl, off);
+            if (lane >= (uint32_t) off) incl += up;
+         }
+         at[u] = (uint64_t) (w0 + u < n_chunks ? chunk_off[w0 + u] : 0u) + (incl - c[u]);
+         emitted[u] = 0;
+         act[u] = act[u] && c[u] != 0;
+      }
+      uint32_t again[JP_U];
+      d_probe_batch<JP_U>(m, d, rows, act, again, [&](int u, uint32_t brow) {
+         out_probe[at[u] + emitted[u]] = (uint32_t) rows[u];
+         out_build[at[u] + emitted[u]] = brow;
+         emitted[u]++;
+         return m.kind != LDB_JOIN_SINGLE;
+      });
+#pragma unroll
+      for (int u = 0; u < JP_U; u++) {
+         if (act[u] && emitted[u] == 0) { // unmatched (or NULL-key) probe row of an outer join
+            out_probe[at[u]] = (uint32_t) rows[u];
+            out_build[at[u]] = LDB_NULL_ROW;
          }
       }
    }
 }
 
-// count matches only — the probe micro-benchmark kernel (Grows/s)
+// count matches only — the probe micro-benchmark kernel (Grows/s).  A wave owns tiles of
+// 64 x JOIN_BATCH consecutive rows: the batch's key loads are JOIN_BATCH coalesced 256-byte
+// segments next to each other and, for clustered keys, its slots share cache lines.
 __device__ __forceinline__ void join_probe_count_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows;
    unsigned long long local = 0;
-   const uint64_t tid = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x, nth = (uint64_t) gridDim.x * blockDim.x;
-   for (uint64_t i0 = tid; i0 < n; i0 += 4 * nth) {
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+   const uint64_t n_tiles = (n + 64 * JOIN_BATCH - 1) / (64 * JOIN_BATCH);
+   for (uint64_t t = wave; t < n_tiles; t += n_waves) {
+      uint64_t rows[JOIN_BATCH];
+      bool act[JOIN_BATCH];
+      uint32_t mt[JOIN_BATCH];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-         const uint64_t i = i0 + (uint64_t) u * nth;
-         if (i < n && d_probe_pass(m, d, i)) local += d_probe_row(m, d, i, [](uint32_t) { return true; });
+      for (int u = 0; u < JOIN_BATCH; u++) {
+         rows[u] = (t * JOIN_BATCH + u) * 64 + lane;
+         act[u] = rows[u] < n;
       }
+      d_eval_conj_batch<JOIN_BATCH>(m.ppreds, d->ppreds, m.n_ppreds, rows, act);
+      d_probe_batch<JOIN_BATCH>(m, d, rows, act, mt, [](int, uint32_t) { return true; });
+#pragma unroll
+      for (int u = 0; u < JOIN_BATCH; u++) local += mt[u];
    }
    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
-   if ((threadIdx.x & 63) == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter) + 1, local);
+   if (lane == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter) + 1, local);
 }
 
 // ---------------------------------------------------------------- fused filter: LDS-staged compaction
@@ -351,11 +499,13 @@ __device__ __forceinline__ void join_probe_count_body(const DJoin& m, const DJoi
 // Q3's lineitem side).  So a workgroup first filters a TILE of JT_ROWS consecutive rows
 // (predicate-major, JT_U rows per thread, coalesced), compacts the survivors' tile-relative row
 // numbers into an LDS queue (ballot + popcount rank, one LDS atomic per wave and batch row), and
-// then probes from the queue with every lane busy.  Results that must stay in row order go through
-// a per-tile bitmap in LDS (JT_ROWS / 64 words) that is written out once per tile.
+// then probes from the queue with every lane busy, JT_PB queue entries per lane at a time (batched
+// probe).  Results that must stay in row order go through a per-tile bitmap in LDS (JT_ROWS / 64
+// words) that is written out once per tile.
 #define JT_BLOCK 256
 #define JT_U 8
 #define JT_ROWS (JT_BLOCK * JT_U)
+#define JT_PB 4
 struct JoinTile {
    unsigned short q[JT_ROWS];
    unsigned long long bm[JT_ROWS / 64];
@@ -385,77 +535,89 @@ __device__ __forceinline__ void d_tile_filter(const DJoin& m, const DJoin* __res
    }
    __syncthreads();
 }
-
-__device__ __forceinline__ void join_probe_unique_filtered_body(const DJoin& m, const DJoin* __restrict__ d) {
-   __shared__ JoinTile st;
-   const uint64_t n = d->n_rows;
-   const uint64_t n_words = (n + 63) / 64, n_tiles = (n + JT_ROWS - 1) / JT_ROWS;
-   uint64_t* bitmap = gptr_mut<uint64_t>(d->bitmap);
-   uint32_t* match = gptr_mut<uint32_t>(d->match);
-   unsigned long long local = 0;
-   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-      const uint64_t base = tile * JT_ROWS;
-      d_tile_filter(m, d, base, n, st);
-      const uint32_t qn = st.qn;
-      for (uint32_t j = threadIdx.x; j < qn; j += JT_BLOCK) {
-         const uint32_t r = st.q[j];
-         uint32_t b = LDB_NULL_ROW;
-         d_probe_row(m, d, base + r, [&](uint32_t x) {
-            b = x;
-            return false;
-         });
-         if (b != LDB_NULL_ROW) {
-            match[base + r] = b;
-            atomicOr(&st.bm[r >> 6], 1ull << (r & 63));
-         }
+// probe the tile's queue, JT_PB entries per lane at a time; ON_MATCH(tile-relative row, build row) → keep scanning?
+// AFTER(tile-relative row, #matches) runs once per queued row
+template <typename ON_MATCH, typename AFTER>
+__device__ __forceinline__ void d_tile_probe(const DJoin& m, const DJoin* __restrict__ d, uint64_t base, JoinTile& st, ON_MATCH on_match, AFTER after) {
+   const uint32_t qn = st.qn;
+   for (uint32_t j0 = 0; j0 < qn; j0 += JT_PB * JT_BLOCK) {
+      uint64_t rows[JT_PB];
+      uint32_t rel[JT_PB], mt[JT_PB];
+      bool act[JT_PB];
+#pragma unroll
+      for (int u = 0; u < JT_PB; u++) {
+         const uint32_t j = j0 + (uint32_t) u * JT_BLOCK + threadIdx.x;
+         act[u] = j < qn;
+         rel[u] = act[u] ? st.q[j] : 0u;
+         rows[u] = base + rel[u];
       }
-      __syncthreads();
-      if (threadIdx.x < JT_ROWS / 64) {
-         const uint64_t w = tile * (JT_ROWS / 64) + threadIdx.x;
-         if (w < n_words) {
-            bitmap[w] = st.bm[threadIdx.x];
-            local += (unsigned long long) __popcll(st.bm[threadIdx.x]);
-         }
-      }
-      __syncthreads();
+      d_probe_batch<JT_PB>(m, d, rows, act, mt, [&](int u, uint32_t b) { return on_match(rel[u], b); });
+#pragma unroll
+      for (int u = 0; u < JT_PB; u++)
+         if (act[u]) after(rel[u], mt[u]);
    }
+}
+// write the tile's LDS bitmap out and count its bits; ends with a barrier
+__device__ __forceinline__ void d_tile_flush(const DJoin* __restrict__ d, uint64_t tile, uint64_t n_words, JoinTile& st, unsigned long long& local) {
+   uint64_t* bitmap = gptr_mut<uint64_t>(d->bitmap);
+   __syncthreads();
+   if (threadIdx.x < JT_ROWS / 64) {
+      const uint64_t w = tile * (JT_ROWS / 64) + threadIdx.x;
+      if (w < n_words) {
+         bitmap[w] = st.bm[threadIdx.x];
+         local += (unsigned long long) __popcll(st.bm[threadIdx.x]);
+      }
+   }
+   __syncthreads();
+}
+__device__ __forceinline__ void d_block_count_add(const DJoin* __restrict__ d, unsigned long long local) {
    if (threadIdx.x < 64) {
       for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
       if (threadIdx.x == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter), local);
    }
 }
 
+__device__ __forceinline__ void join_probe_unique_filtered_body(const DJoin& m, const DJoin* __restrict__ d) {
+   __shared__ JoinTile st;
+   const uint64_t n = d->n_rows;
+   const uint64_t n_words = (n + 63) / 64, n_tiles = (n + JT_ROWS - 1) / JT_ROWS;
+   uint32_t* match = gptr_mut<uint32_t>(d->match);
+   unsigned long long local = 0;
+   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      const uint64_t base = tile * JT_ROWS;
+      d_tile_filter(m, d, base, n, st);
+      d_tile_probe(
+         m, d, base, st,
+         [&](uint32_t r, uint32_t b) {
+            match[base + r] = b;
+            atomicOr(&st.bm[r >> 6], 1ull << (r & 63));
+            return false;
+         },
+         [](uint32_t, uint32_t) {});
+      d_tile_flush(d, tile, n_words, st, local);
+   }
+   d_block_count_add(d, local);
+}
+
 // SEMI / ANTI / MARK: existence per probe row → bitmap word per wave (rows in ascending order)
+#define JE_U 4
 __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows;
    if (m.n_ppreds > 0) { // fused filter: tile compaction (never MARK: the host forces those)
       __shared__ JoinTile st;
       const uint64_t n_words = (n + 63) / 64, n_tiles = (n + JT_ROWS - 1) / JT_ROWS;
-      uint64_t* bitmap = gptr_mut<uint64_t>(d->bitmap);
       unsigned long long local = 0;
       for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
          const uint64_t base = tile * JT_ROWS;
          d_tile_filter(m, d, base, n, st);
-         const uint32_t qn = st.qn;
-         for (uint32_t j = threadIdx.x; j < qn; j += JT_BLOCK) {
-            const uint32_t r = st.q[j];
-            const bool hit = d_probe_row(m, d, base + r, [](uint32_t) { return false; }) != 0;
-            if (m.kind == LDB_JOIN_ANTI ? !hit : hit) atomicOr(&st.bm[r >> 6], 1ull << (r & 63));
-         }
-         __syncthreads();
-         if (threadIdx.x < JT_ROWS / 64) {
-            const uint64_t w = tile * (JT_ROWS / 64) + threadIdx.x;
-            if (w < n_words) {
-               bitmap[w] = st.bm[threadIdx.x];
-               local += (unsigned long long) __popcll(st.bm[threadIdx.x]);
-            }
-         }
-         __syncthreads();
+         d_tile_probe(
+            m, d, base, st, [](uint32_t, uint32_t) { return false; },
+            [&](uint32_t r, uint32_t hits) {
+               if (m.kind == LDB_JOIN_ANTI ? hits == 0 : hits != 0) atomicOr(&st.bm[r >> 6], 1ull << (r & 63));
+            });
+         d_tile_flush(d, tile, n_words, st, local);
       }
-      if (threadIdx.x < 64) {
-         for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
-         if (threadIdx.x == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter), local);
-      }
+      d_block_count_add(d, local);
       return;
    }
    const uint64_t n_words = (n + 63) / 64;
@@ -465,17 +627,26 @@ __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJo
    uint64_t* bitmap = gptr_mut<uint64_t>(d->bitmap);
    uint8_t* mark = gptr_mut<uint8_t>(d->mark);
    unsigned long long local = 0;
-   for (uint64_t w = wave; w < n_words; w += n_waves) {
-      uint64_t i = w * 64 + lane;
-      bool hit = false;
-      const bool pass = i < n && d_probe_pass(m, d, i); // rows a fused filter rejects do not exist
-      if (pass) hit = d_probe_row(m, d, i, [](uint32_t) { return false; }) != 0;
-      bool keep = pass && (m.kind == LDB_JOIN_ANTI ? !hit : hit);
-      if (m.has_mark && i < n) mark[i] = hit ? 1 : 0;
-      uint64_t mm = __ballot(keep);
-      if (lane == 0) {
-         bitmap[w] = mm;
-         local += (unsigned long long) __popcll(mm);
+   for (uint64_t w0 = wave * JE_U; w0 < n_words; w0 += n_waves * JE_U) {
+      uint64_t rows[JE_U];
+      bool act[JE_U];
+      uint32_t mt[JE_U];
+#pragma unroll
+      for (int u = 0; u < JE_U; u++) {
+         rows[u] = (w0 + u) * 64 + lane;
+         act[u] = rows[u] < n;
+      }
+      d_probe_batch<JE_U>(m, d, rows, act, mt, [](int, uint32_t) { return false; });
+#pragma unroll
+      for (int u = 0; u < JE_U; u++) {
+         const bool hit = mt[u] != 0;
+         const bool keep = act[u] && (m.kind == LDB_JOIN_ANTI ? !hit : hit);
+         if (m.has_mark && act[u]) mark[rows[u]] = hit ? 1 : 0;
+         const uint64_t mm = __ballot(keep);
+         if (lane == 0 && w0 + u < n_words) {
+            bitmap[w0 + u] = mm;
+            local += (unsigned long long) __popcll(mm);
+         }
       }
    }
    if (lane == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter), local);
@@ -494,27 +665,34 @@ __device__ __forceinline__ void join_probe_markbuild_body(const DJoin& m, const 
       for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
          const uint64_t base = tile * JT_ROWS;
          d_tile_filter(m, d, base, n, st);
-         const uint32_t qn = st.qn;
-         for (uint32_t j = threadIdx.x; j < qn; j += JT_BLOCK)
-            d_probe_row(m, d, base + st.q[j], [&](uint32_t b) {
+         d_tile_probe(
+            m, d, base, st,
+            [&](uint32_t, uint32_t b) {
                flags[b] = 1;
                return true;
-            });
+            },
+            [](uint32_t, uint32_t) {});
          __syncthreads();
       }
       return;
    }
-   const uint64_t tid = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x, nth = (uint64_t) gridDim.x * blockDim.x;
-   for (uint64_t i0 = tid; i0 < n; i0 += 2 * nth) {
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+   const uint64_t n_tiles = (n + 64 * JE_U - 1) / (64 * JE_U);
+   for (uint64_t t = wave; t < n_tiles; t += n_waves) {
+      uint64_t rows[JE_U];
+      bool act[JE_U];
+      uint32_t mt[JE_U];
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-         const uint64_t i = i0 + (uint64_t) u * nth;
-         if (i < n && d_probe_pass(m, d, i))
-            d_probe_row(m, d, i, [&](uint32_t b) {
-               flags[b] = 1;
-               return true;
-            });
+      for (int u = 0; u < JE_U; u++) {
+         rows[u] = (t * JE_U + u) * 64 + lane;
+         act[u] = rows[u] < n;
       }
+      d_probe_batch<JE_U>(m, d, rows, act, mt, [&](int, uint32_t b) {
+         flags[b] = 1;
+         return true;
+      });
    }
 }
 // flags (one byte per build row) → ballot bitmap of the rows to keep (+ their count)
@@ -540,7 +718,7 @@ __device__ __forceinline__ void join_flags_bitmap_body(const uint8_t* __restrict
 // Unique build side (primary-key joins: every TPC-H join): a probe row has at most one match, so
 // the kernel writes match[i] densely (coalesced) plus a ballot bitmap, and the pairs are produced
 // by the ordered bitmap expansion — no atomics on an output cursor, deterministic ascending
-// order.  Two words (128 rows) per wave iteration keep two independent probes in flight.
+// order.  JE_U consecutive words (256 rows) per wave iteration, probed as one batch.
 __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJoin* __restrict__ d) {
    if (m.n_ppreds > 0 && m.has_bitmap) { // INNER with a fused filter
       join_probe_unique_filtered_body(m, d);
@@ -554,41 +732,29 @@ __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJo
    uint64_t* bitmap = gptr_mut<uint64_t>(d->bitmap);
    uint32_t* match = gptr_mut<uint32_t>(d->match);
    unsigned long long local = 0;
-   for (uint64_t w0 = wave; w0 < n_words; w0 += 2 * n_waves) {
-      uint32_t brow[2];
-      uint64_t rows[2];
-      bool pass[2];
+   for (uint64_t w0 = wave * JE_U; w0 < n_words; w0 += n_waves * JE_U) {
+      uint32_t brow[JE_U], mt[JE_U];
+      uint64_t rows[JE_U];
+      bool act[JE_U], pass[JE_U];
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-         const uint64_t w = w0 + (uint64_t) u * n_waves;
-         rows[u] = w * 64 + lane;
-         pass[u] = w < n_words && rows[u] < n;
-      }
-      d_eval_conj_batch<2>(m.ppreds, d->ppreds, m.n_ppreds, rows, pass); // fused filter of a lazy probe side
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-         const uint64_t w = w0 + (uint64_t) u * n_waves;
-         const uint64_t i = w * 64 + lane;
+      for (int u = 0; u < JE_U; u++) {
+         rows[u] = (w0 + u) * 64 + lane;
+         act[u] = pass[u] = rows[u] < n;
          brow[u] = LDB_NULL_ROW;
-         if (pass[u]) {
-            uint32_t b = LDB_NULL_ROW;
-            d_probe_row(m, d, i, [&](uint32_t x) {
-               b = x;
-               return false;
-            });
-            brow[u] = b;
-         }
       }
+      d_eval_conj_batch<JE_U>(m.ppreds, d->ppreds, m.n_ppreds, rows, pass); // fused filter of a lazy probe side
+      d_probe_batch<JE_U>(m, d, rows, pass, mt, [&](int u, uint32_t x) {
+         brow[u] = x;
+         return false;
+      });
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-         const uint64_t w = w0 + (uint64_t) u * n_waves;
-         const uint64_t i = w * 64 + lane;
+      for (int u = 0; u < JE_U; u++) {
          // INNER reads match[] only at the bitmap's set bits: unmatched rows are not written (a
          // selective join would otherwise stream 4 B per probe row for nothing)
-         if (w < n_words && i < n && (brow[u] != LDB_NULL_ROW || !m.has_bitmap)) match[i] = brow[u];
-         uint64_t mm = __ballot(brow[u] != LDB_NULL_ROW);
-         if (lane == 0 && w < n_words) {
-            if (m.has_bitmap) bitmap[w] = mm;
+         if (act[u] && (brow[u] != LDB_NULL_ROW || !m.has_bitmap)) match[rows[u]] = brow[u];
+         const uint64_t mm = __ballot(brow[u] != LDB_NULL_ROW);
+         if (lane == 0 && w0 + u < n_words) {
+            if (m.has_bitmap) bitmap[w0 + u] = mm;
             local += (unsigned long long) __popcll(mm);
          }
       }

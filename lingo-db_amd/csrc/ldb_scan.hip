@@ -153,7 +153,7 @@ static int32_t scan_run(ldb_ctx* ctx, ldb_rel* in, const DScan& h, uint32_t** se
          DScan meta;
          scan_meta(&h, &meta);
          std::string why;
-         spec = ldb_jit_kernel("ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, "k_scan_bitmap_spec", &meta, sizeof(meta), &why);
+         spec = ldb_jit_kernel(ctx->device, "ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, "k_scan_bitmap_spec", &meta, sizeof(meta), &why);
       }
       LdbProf prof_(ctx, "k_scan_bitmap");
       if (spec) {
@@ -182,14 +182,7 @@ static int32_t scan_run(ldb_ctx* ctx, ldb_rel* in, const DScan& h, uint32_t** se
 // lazy filters: on by default for dense relations of >= LDB_LAZY_MIN_ROWS rows (default 1 M);
 // LDB_LAZY_FILTER=0 materialises every filter immediately
 static bool lazy_wanted(const ldb_rel* in) {
-   static int enabled = -1;
-   static int64_t min_rows = 1 << 20;
-   if (enabled < 0) {
-      const char* e = getenv("LDB_LAZY_FILTER");
-      enabled = (e && e[0] == '0') ? 0 : 1;
-      if (const char* m = getenv("LDB_LAZY_MIN_ROWS")) min_rows = atoll(m);
-   }
-   if (!enabled || in->n_rows < min_rows) return false;
+   if (ldb_option("lazy_filter", 1) == 0 || in->n_rows < ldb_option("lazy_min_rows", 1 << 20)) return false;
    for (auto& s : in->sides)
       if (s.rowids) return false;
    return true;
@@ -258,7 +251,7 @@ extern "C" int32_t ldb_gpu_scan_count(ldb_ctx* ctx, ldb_rel* in, const ldb_filte
          DScan meta;
          scan_meta(&h, &meta);
          std::string why;
-         spec = ldb_jit_kernel("ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, "k_scan_count_spec", &meta, sizeof(meta), &why);
+         spec = ldb_jit_kernel(ctx->device, "ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, "k_scan_count_spec", &meta, sizeof(meta), &why);
       }
       unsigned long long* total = (unsigned long long*) ctx->d_scratch;
       const int grid = ldb_grid_for(ctx, in->n_rows, SCAN_BLOCK, 8);

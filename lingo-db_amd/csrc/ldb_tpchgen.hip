@@ -126,6 +126,28 @@ __global__ void k_gen_str_fill(StrDomain dom, int32_t table, int32_t col, int64_
    }
 }
 
+// generated text columns (ldb_tpch_text): lengths → scan → fill, each thread renders its row into a
+// small local buffer
+__global__ void k_gen_text_lens(int32_t table, int32_t col, int64_t row0, uint64_t n, int64_t* lens) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      char buf[LDB_TPCH_TEXT_MAX];
+      lens[i] = ldb_tpch_text(table, col, row0 + (int64_t) i, buf);
+   }
+}
+__global__ void k_gen_text_fill(int32_t table, int32_t col, int64_t row0, uint64_t n, const int64_t* offs, char* out) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      char buf[LDB_TPCH_TEXT_MAX];
+      const int32_t len = ldb_tpch_text(table, col, row0 + (int64_t) i, buf);
+      const int64_t o = offs[i];
+      for (int32_t b = 0; b < len; b++) out[o + b] = buf[b];
+   }
+}
+// bench support: keys of uniformly random orders (LDB_TPCH_PROBEKEYS)
+__global__ void k_gen_probekeys(int32_t* out, int64_t n_orders, int64_t row0, uint64_t n) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+      out[i] = ldb_tpch_orderkey((int64_t) (ldb_rnd(LDB_TPCH_PROBEKEYS, 0, (uint64_t) (row0 + (int64_t) i)) % (uint64_t) n_orders));
+}
+
 // c_name = "Customer#%09d": fixed width, so offsets are closed-form
 __global__ void k_gen_cname(int64_t row0, uint64_t n, int64_t* offs, char* out) {
    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i <= n; i += (uint64_t) gridDim.x * blockDim.x) {
@@ -180,13 +202,14 @@ struct ColDef {
 #define CT_CH {LDB_T_CHAR4, 0, 0, 0}
 #define CT_STR {LDB_T_UTF8, 0, 0, 0}
 static const ColDef LINEITEM_COLS[L_NCOLS] = {{"l_orderkey", CT_I32}, {"l_partkey", CT_I32}, {"l_suppkey", CT_I32}, {"l_linenumber", CT_I32}, {"l_quantity", CT_DEC}, {"l_extendedprice", CT_DEC}, {"l_discount", CT_DEC}, {"l_tax", CT_DEC}, {"l_returnflag", CT_CH}, {"l_linestatus", CT_CH}, {"l_shipdate", CT_DATE}, {"l_commitdate", CT_DATE}, {"l_receiptdate", CT_DATE}, {"l_shipinstruct", CT_STR}, {"l_shipmode", CT_STR}};
-static const ColDef ORDERS_COLS[O_NCOLS] = {{"o_orderkey", CT_I32}, {"o_custkey", CT_I32}, {"o_orderstatus", CT_CH}, {"o_totalprice", CT_DEC}, {"o_orderdate", CT_DATE}, {"o_orderpriority", CT_STR}, {"o_shippriority", CT_I32}};
-static const ColDef CUSTOMER_COLS[C_NCOLS] = {{"c_custkey", CT_I32}, {"c_nationkey", CT_I32}, {"c_acctbal", CT_DEC}, {"c_mktsegment", CT_STR}, {"c_name", CT_STR}};
-static const ColDef PART_COLS[P_NCOLS] = {{"p_partkey", CT_I32}, {"p_size", CT_I32}, {"p_retailprice", CT_DEC}, {"p_name", CT_STR}, {"p_type", CT_STR}};
-static const ColDef SUPPLIER_COLS[S_NCOLS] = {{"s_suppkey", CT_I32}, {"s_nationkey", CT_I32}, {"s_acctbal", CT_DEC}};
+static const ColDef ORDERS_COLS[O_NCOLS] = {{"o_orderkey", CT_I32}, {"o_custkey", CT_I32}, {"o_orderstatus", CT_CH}, {"o_totalprice", CT_DEC}, {"o_orderdate", CT_DATE}, {"o_orderpriority", CT_STR}, {"o_shippriority", CT_I32}, {"o_comment", CT_STR}};
+static const ColDef CUSTOMER_COLS[C_NCOLS] = {{"c_custkey", CT_I32}, {"c_nationkey", CT_I32}, {"c_acctbal", CT_DEC}, {"c_mktsegment", CT_STR}, {"c_name", CT_STR}, {"c_phone", CT_STR}};
+static const ColDef PART_COLS[P_NCOLS] = {{"p_partkey", CT_I32}, {"p_size", CT_I32}, {"p_retailprice", CT_DEC}, {"p_name", CT_STR}, {"p_type", CT_STR}, {"p_brand", CT_STR}, {"p_container", CT_STR}, {"p_mfgr", CT_STR}};
+static const ColDef SUPPLIER_COLS[S_NCOLS] = {{"s_suppkey", CT_I32}, {"s_nationkey", CT_I32}, {"s_acctbal", CT_DEC}, {"s_name", CT_STR}, {"s_address", CT_STR}, {"s_phone", CT_STR}, {"s_comment", CT_STR}};
 static const ColDef PARTSUPP_COLS[PS_NCOLS] = {{"ps_partkey", CT_I32}, {"ps_suppkey", CT_I32}, {"ps_availqty", CT_I32}, {"ps_supplycost", CT_DEC}};
 static const ColDef NATION_COLS[N_NCOLS] = {{"n_nationkey", CT_I32}, {"n_regionkey", CT_I32}, {"n_name", CT_STR}};
 static const ColDef REGION_COLS[R_NCOLS] = {{"r_regionkey", CT_I32}, {"r_name", CT_STR}};
+static const ColDef PROBEKEYS_COLS[1] = {{"k_orderkey", CT_I32}};
 
 static int table_def(int32_t table, const ColDef** cols, int* n_cols, const char** name) {
    switch (table) {
@@ -198,6 +221,7 @@ static int table_def(int32_t table, const ColDef** cols, int* n_cols, const char
       case LDB_TPCH_PARTSUPP: *cols = PARTSUPP_COLS; *n_cols = PS_NCOLS; *name = "partsupp"; return 0;
       case LDB_TPCH_NATION: *cols = NATION_COLS; *n_cols = N_NCOLS; *name = "nation"; return 0;
       case LDB_TPCH_REGION: *cols = REGION_COLS; *n_cols = R_NCOLS; *name = "region"; return 0;
+      case LDB_TPCH_PROBEKEYS: *cols = PROBEKEYS_COLS; *n_cols = 1; *name = "probekeys"; return 0;
       default: return -1;
    }
 }
@@ -206,6 +230,7 @@ static int table_def(int32_t table, const ColDef** cols, int* n_cols, const char
 static void table_slice(int32_t table, int64_t n_orders, int32_t part, int32_t n_parts, int64_t* begin, int64_t* end) {
    int64_t ob, oe;
    switch (table) {
+      case LDB_TPCH_PROBEKEYS:
       case LDB_TPCH_LINEITEM:
          ldb_tpch_order_slice(n_orders, part, n_parts, &ob, &oe);
          *begin = ldb_tpch_line_offset(ob);
@@ -251,6 +276,18 @@ extern "C" int32_t ldb_gpu_tpch_generate(ldb_ctx* ctx, int32_t table_id, int64_t
          LDB_TRY(ldb_dev_alloc(ctx, &col.values, (size_t) col.value_bytes));
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &col.offsets, 8 * (size_t) (n + 1)));
          hipLaunchKernelGGL(k_gen_cname, dim3(grid), dim3(256), 0, ctx->stream, b, (uint64_t) n, col.offsets, (char*) col.values);
+      } else if (col.type.type == LDB_T_UTF8 && ldb_tpch_is_text(table_id, c)) { // p_brand, s_comment, o_comment, c_phone …
+         int64_t* lens;
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &lens, 8 * (size_t) (n + 1)));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &col.offsets, 8 * (size_t) (n + 1)));
+         if (n) hipLaunchKernelGGL(k_gen_text_lens, dim3(grid), dim3(256), 0, ctx->stream, table_id, (int32_t) c, b, (uint64_t) n, lens);
+         LDB_TRY(ldb_exclusive_scan_i64(ctx, lens, col.offsets, n, col.offsets + n));
+         uint64_t total = 0;
+         LDB_TRY(ldb_read_u64(ctx, col.offsets + n, &total));
+         ldb_dev_free(ctx, lens);
+         col.value_bytes = (int64_t) total;
+         LDB_TRY(ldb_dev_alloc(ctx, &col.values, (size_t) total));
+         if (n) hipLaunchKernelGGL(k_gen_text_fill, dim3(grid), dim3(256), 0, ctx->stream, table_id, (int32_t) c, b, (uint64_t) n, (const int64_t*) col.offsets, (char*) col.values);
       } else if (col.type.type == LDB_T_UTF8 && ldb_tpch_wordcol_words(table_id, c)) { // p_name, p_type
          const int words = ldb_tpch_wordcol_words(table_id, c);
          const char* const* vocab = c == P_NAME ? ldb_tpch_colors : ldb_tpch_typewords;
@@ -318,6 +355,7 @@ extern "C" int32_t ldb_gpu_tpch_generate(ldb_ctx* ctx, int32_t table_id, int64_t
          case LDB_TPCH_PART: hipLaunchKernelGGL(k_gen_part, dim3(grid), dim3(256), 0, ctx->stream, g, n_orders, b, (uint64_t) n); break;
          case LDB_TPCH_SUPPLIER: hipLaunchKernelGGL(k_gen_supplier, dim3(grid), dim3(256), 0, ctx->stream, g, n_orders, b, (uint64_t) n); break;
          case LDB_TPCH_PARTSUPP: hipLaunchKernelGGL(k_gen_partsupp, dim3(grid), dim3(256), 0, ctx->stream, g, n_orders, b, (uint64_t) n); break;
+         case LDB_TPCH_PROBEKEYS: hipLaunchKernelGGL(k_gen_probekeys, dim3(grid), dim3(256), 0, ctx->stream, (int32_t*) g.values[0], n_orders, b, (uint64_t) n); break;
          case LDB_TPCH_NATION: hipLaunchKernelGGL(k_gen_nation, dim3(grid), dim3(256), 0, ctx->stream, g, b, (uint64_t) n); break;
          default: hipLaunchKernelGGL(k_gen_region, dim3(grid), dim3(256), 0, ctx->stream, g, b, (uint64_t) n); break;
       }

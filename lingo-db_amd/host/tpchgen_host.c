@@ -9,6 +9,7 @@
 static void slice(int32_t table, int64_t n_orders, int32_t part, int32_t n_parts, int64_t* begin, int64_t* end) {
    int64_t ob, oe;
    switch (table) {
+      case LDB_TPCH_PROBEKEYS:
       case LDB_TPCH_LINEITEM:
          ldb_tpch_order_slice(n_orders, part, n_parts, &ob, &oe);
          *begin = ldb_tpch_line_offset(ob);
@@ -54,7 +55,7 @@ static void put_dec(void* out, int64_t i, int64_t v) {
 
 /* kind of a column: 0 = int32-like (4 bytes), 1 = decimal128 (16 bytes), 2 = utf8 */
 static int col_kind(int32_t table, int32_t col) {
-   if (ldb_tpch_str_domain(table, col)) return 2;
+   if (ldb_tpch_str_domain(table, col) || ldb_tpch_is_text(table, col)) return 2;
    if (table == LDB_TPCH_CUSTOMER && col == C_NAME) return 2;
    if (ldb_tpch_wordcol_words(table, col)) return 2;
    switch (table) {
@@ -81,6 +82,19 @@ int64_t ldb_tpch_host_column(int32_t table, int32_t col, int64_t n_orders, int32
       }
       if (offsets_out) offsets_out[n] = n * LDB_TPCH_CNAME_LEN;
       if (bytes) *bytes = n * LDB_TPCH_CNAME_LEN;
+      return n;
+   }
+   if (kind == 2 && ldb_tpch_is_text(table, col)) { /* p_brand, s_comment, o_comment, c_phone … */
+      int64_t pos = 0;
+      char buf[LDB_TPCH_TEXT_MAX];
+      for (int64_t i = 0; i < n; i++) {
+         const int32_t len = ldb_tpch_text(table, col, b + i, buf);
+         if (offsets_out) offsets_out[i] = pos;
+         if (out) memcpy((char*) out + pos, buf, (size_t) len);
+         pos += len;
+      }
+      if (offsets_out) offsets_out[n] = pos;
+      if (bytes) *bytes = pos;
       return n;
    }
    if (kind == 2 && ldb_tpch_wordcol_words(table, col)) { /* p_name, p_type */
@@ -187,6 +201,7 @@ int64_t ldb_tpch_host_column(int32_t table, int32_t col, int64_t n_orders, int32
             else put_dec(out, i, ldb_uniform(LDB_TPCH_PARTSUPP, PS_SUPPLYCOST, (uint64_t) r, 100, 100000));
             break;
          }
+         case LDB_TPCH_PROBEKEYS: o32[i] = ldb_tpch_orderkey((int64_t) (ldb_rnd(LDB_TPCH_PROBEKEYS, 0, (uint64_t) r) % (uint64_t) n_orders)); break;
          case LDB_TPCH_NATION:
             if (col == N_NATIONKEY) o32[i] = (int32_t) r;
             else o32[i] = ldb_tpch_nation_region[r % 25];

@@ -359,10 +359,17 @@ class HashTable:
     def slots(self):
         return self.ctx.lib.ldb_gpu_hashtable_slots(self.h)
 
-    def probe(self, probe_rel, keys, kind=capi.JOIN_INNER):
+    def probe(self, probe_rel, keys, kind=capi.JOIN_INNER, residual=()):
+        """residual: [(probe_col, op, build_col)] — extra `probe_col OP build_col` conjuncts of the join predicate"""
         arr, n = _refs(keys)
         r, m = C.c_void_p(), C.c_void_p()
-        check(self.ctx.lib.ldb_gpu_join_probe(self.ctx.h, self.h, probe_rel.h, arr, n, kind, C.byref(r), C.byref(m)))
+        if residual:
+            ra = (capi.JoinResidual * len(residual))()
+            for i, (pc, op, bc) in enumerate(residual):
+                ra[i].probe_col, ra[i].op, ra[i].build_col = colref(*pc), op, colref(*bc)
+            check(self.ctx.lib.ldb_gpu_join_probe_residual(self.ctx.h, self.h, probe_rel.h, arr, n, kind, ra, len(residual), C.byref(r), C.byref(m)))
+        else:
+            check(self.ctx.lib.ldb_gpu_join_probe(self.ctx.h, self.h, probe_rel.h, arr, n, kind, C.byref(r), C.byref(m)))
         out = Rel(self.ctx, r, probe_rel.deps + self.build.deps + [self.build])
         if kind == capi.JOIN_MARK:
             return out, Table(self.ctx, m)

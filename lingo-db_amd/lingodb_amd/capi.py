@@ -92,6 +92,10 @@ class SortSpec(C.Structure):
     _fields_ = [("col", ColRef), ("descending", C.c_int32), ("reserved", C.c_int32)]
 
 
+class JoinResidual(C.Structure):
+    _fields_ = [("probe_col", ColRef), ("build_col", ColRef), ("op", C.c_int32), ("reserved", C.c_int32)]
+
+
 class ArrowSchema(C.Structure):
     pass
 
@@ -147,6 +151,8 @@ GPU_API = {
     "ldb_gpu_prof_names": (i32, [P, C.c_char_p, i32]),
     "ldb_gpu_jit_stats": (i32, [C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),
     "ldb_gpu_jit_compile_check": (i32, [C.c_char_p, i32]),
+    "ldb_gpu_set_option": (i32, [C.c_char_p, i64]),
+    "ldb_gpu_get_option": (i64, [C.c_char_p]),
     "ldb_gpu_table_register": (i32, [P, C.c_char_p, C.POINTER(ArrowSchema), C.POINTER(C.POINTER(ArrowArray)), i64, i32, PP]),
     "ldb_gpu_table_alloc": (i32, [P, C.c_char_p, i32, C.POINTER(ColType), C.POINTER(C.c_char_p), i64, C.POINTER(i64), i32, PP]),
     "ldb_gpu_table_release": (i32, [P, P]),
@@ -179,6 +185,7 @@ GPU_API = {
     "ldb_gpu_hashtable_release": (i32, [P, P]),
     "ldb_gpu_hashtable_slots": (i64, [P]),
     "ldb_gpu_join_probe": (i32, [P, P, P, C.POINTER(ColRef), i32, i32, PP, PP]),
+    "ldb_gpu_join_probe_residual": (i32, [P, P, P, C.POINTER(ColRef), i32, i32, C.POINTER(JoinResidual), i32, PP, PP]),
     "ldb_gpu_join_probe_count": (i32, [P, P, P, C.POINTER(ColRef), i32, C.POINTER(i64)]),
     "ldb_gpu_sort": (i32, [P, P, C.POINTER(SortSpec), i32, PP]),
     "ldb_gpu_topk": (i32, [P, P, C.POINTER(SortSpec), i32, i64, PP]),

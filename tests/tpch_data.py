@@ -8,7 +8,7 @@ import pyarrow as pa
 
 from lingodb_amd import capi
 
-LINEITEM, ORDERS, CUSTOMER, PART, SUPPLIER, PARTSUPP, NATION, REGION = range(8)
+LINEITEM, ORDERS, CUSTOMER, PART, SUPPLIER, PARTSUPP, NATION, REGION, PROBEKEYS = range(9)
 DEC = pa.decimal128(12, 2)
 CH = pa.binary(4)
 SCHEMAS = {
@@ -17,13 +17,16 @@ SCHEMAS = {
                ("l_returnflag", CH), ("l_linestatus", CH), ("l_shipdate", pa.date32()), ("l_commitdate", pa.date32()),
                ("l_receiptdate", pa.date32()), ("l_shipinstruct", pa.string()), ("l_shipmode", pa.string())],
     ORDERS: [("o_orderkey", pa.int32()), ("o_custkey", pa.int32()), ("o_orderstatus", CH), ("o_totalprice", DEC),
-             ("o_orderdate", pa.date32()), ("o_orderpriority", pa.string()), ("o_shippriority", pa.int32())],
-    CUSTOMER: [("c_custkey", pa.int32()), ("c_nationkey", pa.int32()), ("c_acctbal", DEC), ("c_mktsegment", pa.string()), ("c_name", pa.string())],
-    PART: [("p_partkey", pa.int32()), ("p_size", pa.int32()), ("p_retailprice", DEC), ("p_name", pa.string()), ("p_type", pa.string())],
-    SUPPLIER: [("s_suppkey", pa.int32()), ("s_nationkey", pa.int32()), ("s_acctbal", DEC)],
+             ("o_orderdate", pa.date32()), ("o_orderpriority", pa.string()), ("o_shippriority", pa.int32()), ("o_comment", pa.string())],
+    CUSTOMER: [("c_custkey", pa.int32()), ("c_nationkey", pa.int32()), ("c_acctbal", DEC), ("c_mktsegment", pa.string()), ("c_name", pa.string()), ("c_phone", pa.string())],
+    PART: [("p_partkey", pa.int32()), ("p_size", pa.int32()), ("p_retailprice", DEC), ("p_name", pa.string()), ("p_type", pa.string()),
+           ("p_brand", pa.string()), ("p_container", pa.string()), ("p_mfgr", pa.string())],
+    SUPPLIER: [("s_suppkey", pa.int32()), ("s_nationkey", pa.int32()), ("s_acctbal", DEC), ("s_name", pa.string()), ("s_address", pa.string()),
+               ("s_phone", pa.string()), ("s_comment", pa.string())],
     PARTSUPP: [("ps_partkey", pa.int32()), ("ps_suppkey", pa.int32()), ("ps_availqty", pa.int32()), ("ps_supplycost", DEC)],
     NATION: [("n_nationkey", pa.int32()), ("n_regionkey", pa.int32()), ("n_name", pa.string())],
     REGION: [("r_regionkey", pa.int32()), ("r_name", pa.string())],
+    PROBEKEYS: [("k_orderkey", pa.int32())],
 }
 
 

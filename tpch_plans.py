@@ -157,11 +157,22 @@ class Runner:
             out["probe_ms"] = round(avg, 4)
             out["probe_grows_per_s"] = round(rows / (avg * 1e-3) / 1e9, 3)
             # byte models of SURVEY §8(d): key 4 B + slot 8 B algorithmic; 4 B + one 64 B sector per random access
-            out["algorithmic_gbs"] = round(rows * 12 / (avg * 1e-3) / 1e9, 1)
-            out["sector_model_gbs"] = round(rows * 68 / (avg * 1e-3) / 1e9, 1)
+            out["algorithmic_gbs"] = round(rows * 12 / (avg * 1e-3) / 1e9, 1)  # key 4 B + slot 8 B per probe
         if n_b:
             out["build_ms"] = round(ms_b / n_b, 4)
             out["build_grows_per_s"] = round(db.orders.rows / (ms_b / n_b * 1e-3) / 1e9, 3)
+        # unclustered control: the keys of uniformly random orders (same build side, 100 % match) — no
+        # locality between consecutive probe rows, every probe is a random access into the slot array
+        pk = ctx.tpch_generate(8, db.n_orders, db.rank, db.world, [0])
+        ctx.prof_reset()
+        for _ in range(reps):
+            m2 = ht.probe_count(pk.rel(), [(0, 0)])
+        n_p, ms_p = ctx.prof_all().get("k_join_probe_count", (0, 0.0))
+        if n_p:
+            avg = ms_p / n_p
+            out["unclustered"] = {"probe_rows": pk.rows, "matches": m2, "probe_ms": round(avg, 4), "probe_grows_per_s": round(pk.rows / (avg * 1e-3) / 1e9, 3),
+                                  "algorithmic_gbs": round(pk.rows * 12 / (avg * 1e-3) / 1e9, 1)}
+        pk.release()
         ht.release()
         # selective variant: build side filtered to ≈10 % of orders (o_orderdate < 1992-09-01)
         ctx.prof_reset()
