@@ -251,6 +251,11 @@ typedef struct {
  * holds the passing rows in ascending row order (the order of the reference's selection
  * vectors inside a morsel, morsels in table order). */
 int32_t ldb_gpu_scan_filter(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds, int32_t n_preds, ldb_rel** out);
+/* Disjunctive normal form: rows satisfying (clause 0) OR (clause 1) OR …, each clause a conjunction
+ * of clause_sizes[c] consecutive entries of `preds` (<= 4 clauses, <= 24 conjuncts in all) — TPC-H
+ * Q19's three alternatives.  The reference evaluates such a predicate as generated residual code
+ * (db.or of db.and trees); ascending row order as for ldb_gpu_scan_filter. */
+int32_t ldb_gpu_scan_filter_dnf(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds, const int32_t* clause_sizes, int32_t n_clauses, ldb_rel** out);
 /* count only (no selection written) */
 int32_t ldb_gpu_scan_count(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds, int32_t n_preds, int64_t* count);
 
@@ -278,6 +283,45 @@ int32_t ldb_gpu_map_column(ldb_ctx* ctx, ldb_rel* in, ldb_colref col, int32_t fn
  * reference). */
 int32_t ldb_gpu_map_muldiv(ldb_ctx* ctx, ldb_rel* in, ldb_colref num, int64_t mul_lo, int64_t mul_hi, int32_t mul_div_pow10, int32_t pow10, ldb_colref den,
                            int32_t out_precision, int32_t out_scale, const char* name, ldb_table** out);
+/* General scalar projection (a16): one computed column from a POSTFIX program over the columns of
+ * `in`, evaluated per row on a stack (depth <= 8) of nullable 128-bit integers in wrapping
+ * arithmetic — the db.add / db.sub / db.mul / db.div trees of DecimalBinOpLowering,
+ * DecimalMulOpLowering and DecimalOpScaledLowering (LowerToStd.cpp:622-699) once the frontend has
+ * fixed the scales (casts = MUL_POW10 / SDIV_POW10, sql_analyzer.cpp:3058-3159), comparisons
+ * (:374-466), CASE (scf.if on db.derive_truth) and NULL handling.  Arithmetic and comparisons yield
+ * NULL when an operand is NULL; AND / OR are three-valued; SDIV by zero yields NULL.
+ * out_type: INT32 / INT64 / DATE32 / DECIMAL128(p, s) / BOOL8. */
+typedef enum {
+   LDB_X_COL = 0, /* push column `col` (integer, decimal, date, char(1), bool) */
+   LDB_X_CONST = 1, /* push the 128-bit constant (lo, hi) */
+   LDB_X_ADD = 2,
+   LDB_X_SUB = 3, /* a b → a - b */
+   LDB_X_MUL = 4,
+   LDB_X_SDIV = 5, /* a b → a sdiv b (truncating, arith.divsi) */
+   LDB_X_MUL_POW10 = 6, /* a → a * 10^arg */
+   LDB_X_SDIV_POW10 = 7, /* a → a sdiv 10^arg */
+   LDB_X_NEG = 8,
+   LDB_X_CMP = 9, /* a b → a OP b, arg = ldb_filter_op (EQ .. GTE) */
+   LDB_X_AND = 10,
+   LDB_X_OR = 11,
+   LDB_X_NOT = 12,
+   LDB_X_SELECT = 13, /* c a b → (c is true) ? a : b */
+   LDB_X_ISNULL = 14,
+   LDB_X_COALESCE = 15 /* a b → a unless NULL, then b */
+} ldb_xop;
+typedef struct {
+   int32_t op; /* ldb_xop */
+   int32_t arg;
+   ldb_colref col;
+   int64_t lo;
+   int64_t hi;
+} ldb_xinstr;
+#define LDB_MAX_XPROG 32
+int32_t ldb_gpu_map_expr(ldb_ctx* ctx, ldb_rel* in, const ldb_xinstr* prog, int32_t n_instr, ldb_coltype out_type, const char* name, ldb_table** out);
+/* substring(col from `from` for `for_len`) of a utf8 column as a new utf8 column, character
+ * (UTF-8) positions from 1 with the reference's legalisation of out-of-range arguments
+ * (StringRuntime::substr, src/runtime/StringRuntime.cpp:292-319).  NULL in → NULL out. */
+int32_t ldb_gpu_map_substr(ldb_ctx* ctx, ldb_rel* in, ldb_colref col, int64_t from, int64_t for_len, const char* name, ldb_table** out);
 /* `in` extended by a table of exactly ldb_gpu_rel_rows(in) rows as a new LAST side (identity row
  * ids); the table must outlive the relation. */
 int32_t ldb_gpu_rel_zip(ldb_ctx* ctx, ldb_rel* in, const ldb_table* t, ldb_rel** out);

@@ -121,6 +121,15 @@ static bool compile(const std::string& src, std::vector<char>* code, std::string
    code->resize(cs);
    hiprtcGetCode(prog, code->data());
    hiprtcDestroyProgram(&prog);
+   if (const char* dir = getenv("LDB_JIT_DUMP_ALL")) { // every code object, numbered (offline ISA / register-usage inspection)
+      static int seq = 0;
+      char path[512];
+      snprintf(path, sizeof(path), "%s/ldb_spec_%03d.co", dir, seq++);
+      if (FILE* f = fopen(path, "wb")) {
+         fwrite(code->data(), 1, code->size(), f);
+         fclose(f);
+      }
+   }
    return cs > 0;
 }
 
@@ -139,6 +148,7 @@ static std::string device_arch(int device) {
    hipDeviceProp_t prop;
    std::string a = "gfx950";
    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.gcnArchName[0]) a = prop.gcnArchName;
+   if (const char* o = getenv("LDB_JIT_ARCH")) a = o; // experiments: e.g. the processor name without target features
    archs[device] = a;
    return a;
 }

@@ -98,15 +98,27 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
 }
 
 bool ldb_join_jit_check(std::string* log) {
+   // representative shape: a fact table with a fused two-conjunct date filter probing a unique,
+   // ordered KEY32 table that also keeps key bits (TPC-H Q7's lineitem → supplier probe)
    auto m = std::make_unique<DJoin>();
    memset(m.get(), 0, sizeof(DJoin));
    m->key32 = 1;
    m->kind = LDB_JOIN_INNER;
    m->has_bitmap = 1;
+   m->ordered_slots = 1;
+   m->has_key_bits = 1;
+   m->build_unique = 1;
    m->bkeys.n_keys = m->pkeys.n_keys = 1;
    m->bkeys.cols[0].type = m->pkeys.cols[0].type = LDB_T_INT32;
    m->bkeys.cols[0].width = m->pkeys.cols[0].width = 4;
-   m->pkeys.cols[0].rowids = 1;
+   m->n_ppreds = 2;
+   for (int p = 0; p < 2; p++) {
+      m->ppreds[p].col.type = LDB_T_DATE32;
+      m->ppreds[p].col.width = 4;
+      m->ppreds[p].op = p ? LDB_F_LTE : LDB_F_GTE;
+      m->ppreds[p].lo = p ? 9861 : 9131;
+      m->ppreds[p].same_col = p;
+   }
    return ldb_jit_compile_only("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, m.get(), sizeof(DJoin), log);
 }
 
@@ -133,6 +145,29 @@ __global__ void k_compose_null(const uint32_t* __restrict__ ids, const uint32_t*
       uint32_t s = sel[i];
       out[i] = s == LDB_NULL_ROW ? LDB_NULL_ROW : (ids ? ids[s] : s);
    }
+}
+
+// debug_check option: largest row id of a selection vector (LDB_NULL_ROW ignored)
+__global__ void k_max_rowid(const uint32_t* __restrict__ ids, uint64_t n, unsigned int* __restrict__ out) {
+   unsigned int mx = 0;
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      const uint32_t v = ids[i];
+      if (v != LDB_NULL_ROW && v > mx) mx = v;
+   }
+   if (mx) atomicMax(out, mx);
+}
+static int32_t debug_check_ids(ldb_ctx* ctx, const char* what, const uint32_t* ids, uint64_t n, int64_t limit, const DJoin* h) {
+   if (!ids || !n) return LDB_OK;
+   unsigned int* d = (unsigned int*) (ctx->d_scratch + 40);
+   LDB_HIP(hipMemsetAsync(d, 0, 8, ctx->stream));
+   hipLaunchKernelGGL(k_max_rowid, dim3(ldb_grid_for(ctx, (int64_t) n, 256, 4)), dim3(256), 0, ctx->stream, ids, n, d);
+   uint64_t mx = 0;
+   LDB_TRY(ldb_read_u64(ctx, d, &mx));
+   mx &= 0xFFFFFFFFull;
+   if ((int64_t) mx >= limit)
+      LDB_FAIL(LDB_ERR_INVALID, "debug_check: %s row id %llu >= %lld (kind %d key32 %d ordered %d key_bits %d chained %d unique %d n_ppreds %d n_rows %llu cap %llu)", what, (unsigned long long) mx,
+               (long long) limit, h->kind, h->key32, h->ordered_slots, h->has_key_bits, h->chained, h->build_unique, h->n_ppreds, (unsigned long long) h->n_rows, (unsigned long long) h->cap);
+   return LDB_OK;
 }
 
 static uint64_t next_pow2_u64(uint64_t v) {
@@ -461,8 +496,14 @@ extern "C" int32_t ldb_gpu_join_probe_residual(ldb_ctx* ctx, ldb_hashtable* ht, 
       LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+      if (getenv("LDB_DEBUG_COUNTS")) LDB_HIP(hipMemsetAsync(counter, 0, 48, ctx->stream));
       if (n) LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_unique", "k_join_probe_unique_spec", k_join_probe_unique));
       ldb_dev_free(ctx, d);
+      if (getenv("LDB_DEBUG_COUNTS")) {
+         uint64_t c[3];
+         for (int k = 0; k < 3; k++) LDB_TRY(ldb_read_u64(ctx, counter + 2 + k, &c[k]));
+         fprintf(stderr, "[debug counts] queued %llu key-bit hits %llu matches %llu\n", (unsigned long long) c[0], (unsigned long long) c[1], (unsigned long long) c[2]);
+      }
       if (kind == LDB_JOIN_INNER) {
          LDB_TRY(ldb_read_u64(ctx, counter, &produced));
          uint32_t *pop, *off;
@@ -517,6 +558,10 @@ extern "C" int32_t ldb_gpu_join_probe_residual(ldb_ctx* ctx, ldb_hashtable* ht, 
       }
       ldb_dev_free(ctx, chunk_cnt);
       ldb_dev_free(ctx, chunk_off);
+   }
+   if (ldb_option("debug_check", 0)) {
+      LDB_TRY(debug_check_ids(ctx, "probe", op, produced, probe->n_rows, h));
+      LDB_TRY(debug_check_ids(ctx, "build", ob, produced, ht->build->n_rows, h));
    }
    // result relation: probe sides composed with op, build sides composed with ob
    ldb_rel* r = ldb_rel_new(ctx);

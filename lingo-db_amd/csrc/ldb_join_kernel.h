@@ -244,8 +244,8 @@ __device__ __forceinline__ bool d_resid_ok(const DJoin& m, const DJoin* __restri
 // chain in flight per lane and the kernel runs at memory LATENCY (600 M FK probes: 112 Grows/s,
 // 0.17 of the HBM roofline although it moves no more than the algorithmic bytes).  Here the U key
 // loads issue back to back, then the U key-bit loads, then the first TWO slots of every row (the
-// second is in the same 64 B line seven times out of eight), with no control dependence between
-// them (a dead row loads element 0 — one broadcast line); only then the rows are resolved, and
+// second is in the same 64 B line seven times out of eight), each load predicated on its row still
+// being alive (EXEC mask only — no wait between them); only then the rows are resolved, and
 // for unique ordered KEY32 tables almost every row resolves from its prefetched slots without
 // entering the walk loop.  EMIT(u, build_row) is called per match in the order row-major / slot
 // order and returns whether to keep scanning that row.
@@ -269,7 +269,10 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
       int64_t kv[U];
       if (!c.m.rowids && !c.m.validity) {
 #pragma unroll
-         for (int u = 0; u < U; u++) kv[u] = d_load_i64(c, act[u] ? (uint32_t) rows[u] : 0u); // callers guarantee n >= 1
+         for (int u = 0; u < U; u++) {
+            kv[u] = 0;
+            if (act[u]) kv[u] = d_load_i64(c, (uint32_t) rows[u]); // (EXEC-predicated: the batch's loads still issue back to back)
+         }
       } else {
          uint32_t pr[U];
 #pragma unroll
@@ -292,11 +295,18 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
          const int64_t kmin = d->kmin, kmax = d->kmax;
 #pragma unroll
          for (int u = 0; u < U; u++) live[u] = live[u] && kv[u] >= kmin && kv[u] <= kmax; // outside the build key range
+#ifndef JOIN_NO_KEYBITS
          if (m.has_key_bits) {
+#else
+         if (false) {
+#endif
             const uint32_t* bits = gptr<uint32_t>(d->key_bits);
             uint32_t bw[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) bw[u] = bits[live[u] ? (uint64_t) (kv[u] - kmin) >> 5 : 0];
+            for (int u = 0; u < U; u++) {
+               bw[u] = 0;
+               if (live[u]) bw[u] = bits[(uint64_t) (kv[u] - kmin) >> 5];
+            }
 #pragma unroll
             for (int u = 0; u < U; u++) live[u] = live[u] && ((bw[u] >> ((uint64_t) (kv[u] - kmin) & 31)) & 1u); // not a build key
          }
@@ -320,12 +330,20 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
          }
       }
    }
-   // the first two slots of every row, unconditionally
+   // the first two slots of every live row
    uint64_t w0[U], w1[U];
 #pragma unroll
    for (int u = 0; u < U; u++) {
+#ifndef JOIN_LOAD_DEAD
+      w0[u] = w1[u] = 0;
+      if (!live[u]) continue; // (predicated by EXEC: the live lanes' loads still issue back to back)
+#endif
       w0[u] = slots[pos[u]];
+#ifndef JOIN_NO_PREFETCH2
       w1[u] = slots[(pos[u] + 1) & mask];
+#else
+      w1[u] = 0;
+#endif
    }
    const KV bkeys(m.bkeys, d->bkeys);
 #pragma unroll
@@ -351,11 +369,19 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
                matches[u]++;
                stop = !emit(u, (uint32_t) w - 1u);
             }
+#ifndef JOIN_NO_UNIQUE_BREAK
             if (stop || m.build_unique) break;
+#else
+            if (stop) break;
+#endif
          }
          p = (p + 1) & mask;
          step++;
+#ifndef JOIN_NO_PREFETCH2
          w = step == 1 ? w1[u] : slots[p];
+#else
+         w = slots[p];
+#endif
       }
    }
 }
@@ -368,6 +394,19 @@ __device__ __forceinline__ uint32_t d_probe_row(const DJoin& m, const DJoin* __r
    uint32_t mt[1];
    d_probe_batch<1>(m, d, rows, act, mt, [&](int, uint32_t b) { return emit(b); });
    return mt[0];
+}
+
+// first matching build row of each batch row (LDB_NULL_ROW = none): what the unique-build, SEMI /
+// ANTI / MARK kinds need — no side effects inside the walk, the callers store afterwards
+template <int U>
+__device__ __forceinline__ void d_probe_first(const DJoin& m, const DJoin* __restrict__ d, const uint64_t (&rows)[U], const bool (&act)[U], uint32_t (&brow)[U]) {
+   uint32_t mt[U];
+#pragma unroll
+   for (int u = 0; u < U; u++) brow[u] = LDB_NULL_ROW;
+   d_probe_batch<U>(m, d, rows, act, mt, [&](int u, uint32_t b) {
+      brow[u] = b;
+      return false;
+   });
 }
 
 #ifndef JOIN_BATCH
@@ -505,7 +544,9 @@ __device__ __forceinline__ void join_probe_count_body(const DJoin& m, const DJoi
 #define JT_BLOCK 256
 #define JT_U 8
 #define JT_ROWS (JT_BLOCK * JT_U)
+#ifndef JT_PB
 #define JT_PB 4
+#endif
 struct JoinTile {
    unsigned short q[JT_ROWS];
    unsigned long long bm[JT_ROWS / 64];
@@ -539,6 +580,9 @@ __device__ __forceinline__ void d_tile_filter(const DJoin& m, const DJoin* __res
 // AFTER(tile-relative row, #matches) runs once per queued row
 template <typename ON_MATCH, typename AFTER>
 __device__ __forceinline__ void d_tile_probe(const DJoin& m, const DJoin* __restrict__ d, uint64_t base, JoinTile& st, ON_MATCH on_match, AFTER after) {
+#ifdef JT_EXTRA_SYNC
+   __syncthreads();
+#endif
    const uint32_t qn = st.qn;
    for (uint32_t j0 = 0; j0 < qn; j0 += JT_PB * JT_BLOCK) {
       uint64_t rows[JT_PB];
@@ -555,6 +599,49 @@ __device__ __forceinline__ void d_tile_probe(const DJoin& m, const DJoin* __rest
 #pragma unroll
       for (int u = 0; u < JT_PB; u++)
          if (act[u]) after(rel[u], mt[u]);
+   }
+}
+// the same for the kinds that only need each queued row's FIRST match: AFTER(tile-relative row, build row | LDB_NULL_ROW)
+template <typename AFTER>
+__device__ __forceinline__ void d_tile_probe_first(const DJoin& m, const DJoin* __restrict__ d, uint64_t base, JoinTile& st, AFTER after) {
+   const uint32_t qn = st.qn;
+   for (uint32_t j0 = 0; j0 < qn; j0 += JT_PB * JT_BLOCK) {
+      uint64_t rows[JT_PB];
+      uint32_t rel[JT_PB], brow[JT_PB];
+      bool act[JT_PB];
+#pragma unroll
+      for (int u = 0; u < JT_PB; u++) {
+         const uint32_t j = j0 + (uint32_t) u * JT_BLOCK + threadIdx.x;
+         act[u] = j < qn;
+         rel[u] = act[u] ? st.q[j] : 0u;
+         rows[u] = base + rel[u];
+      }
+      d_probe_first<JT_PB>(m, d, rows, act, brow);
+#ifdef JOIN_DEBUG_COUNTS
+      {
+         unsigned long long* dc = gptr_mut<unsigned long long>(d->counter);
+         unsigned long long q = 0, hit = 0, inr = 0;
+#pragma unroll
+         for (int u = 0; u < JT_PB; u++) {
+            q += act[u] ? 1 : 0;
+            hit += (act[u] && brow[u] != LDB_NULL_ROW) ? 1 : 0;
+            if (act[u]) {
+               const CV c = KV(m.pkeys, d->pkeys).col(0);
+               const int64_t kv = d_load_i64(c, (uint32_t) rows[u]);
+               if (kv >= d->kmin && kv <= d->kmax) {
+                  const uint64_t r = (uint64_t) (kv - d->kmin);
+                  inr += (gptr<uint32_t>(d->key_bits)[r >> 5] >> (r & 31)) & 1u;
+               }
+            }
+         }
+         atomicAdd(dc + 2, q);
+         atomicAdd(dc + 3, inr);
+         atomicAdd(dc + 4, hit);
+      }
+#endif
+#pragma unroll
+      for (int u = 0; u < JT_PB; u++)
+         if (act[u]) after(rel[u], brow[u]);
    }
 }
 // write the tile's LDS bitmap out and count its bits; ends with a barrier
@@ -586,14 +673,12 @@ __device__ __forceinline__ void join_probe_unique_filtered_body(const DJoin& m, 
    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
       const uint64_t base = tile * JT_ROWS;
       d_tile_filter(m, d, base, n, st);
-      d_tile_probe(
-         m, d, base, st,
-         [&](uint32_t r, uint32_t b) {
+      d_tile_probe_first(m, d, base, st, [&](uint32_t r, uint32_t b) {
+         if (b != LDB_NULL_ROW) {
             match[base + r] = b;
             atomicOr(&st.bm[r >> 6], 1ull << (r & 63));
-            return false;
-         },
-         [](uint32_t, uint32_t) {});
+         }
+      });
       d_tile_flush(d, tile, n_words, st, local);
    }
    d_block_count_add(d, local);
@@ -610,11 +695,9 @@ __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJo
       for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
          const uint64_t base = tile * JT_ROWS;
          d_tile_filter(m, d, base, n, st);
-         d_tile_probe(
-            m, d, base, st, [](uint32_t, uint32_t) { return false; },
-            [&](uint32_t r, uint32_t hits) {
-               if (m.kind == LDB_JOIN_ANTI ? hits == 0 : hits != 0) atomicOr(&st.bm[r >> 6], 1ull << (r & 63));
-            });
+         d_tile_probe_first(m, d, base, st, [&](uint32_t r, uint32_t b) {
+            if (m.kind == LDB_JOIN_ANTI ? b == LDB_NULL_ROW : b != LDB_NULL_ROW) atomicOr(&st.bm[r >> 6], 1ull << (r & 63));
+         });
          d_tile_flush(d, tile, n_words, st, local);
       }
       d_block_count_add(d, local);
@@ -630,16 +713,16 @@ __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJo
    for (uint64_t w0 = wave * JE_U; w0 < n_words; w0 += n_waves * JE_U) {
       uint64_t rows[JE_U];
       bool act[JE_U];
-      uint32_t mt[JE_U];
+      uint32_t first[JE_U];
 #pragma unroll
       for (int u = 0; u < JE_U; u++) {
          rows[u] = (w0 + u) * 64 + lane;
          act[u] = rows[u] < n;
       }
-      d_probe_batch<JE_U>(m, d, rows, act, mt, [](int, uint32_t) { return false; });
+      d_probe_first<JE_U>(m, d, rows, act, first);
 #pragma unroll
       for (int u = 0; u < JE_U; u++) {
-         const bool hit = mt[u] != 0;
+         const bool hit = first[u] != LDB_NULL_ROW;
          const bool keep = act[u] && (m.kind == LDB_JOIN_ANTI ? !hit : hit);
          if (m.has_mark && act[u]) mark[rows[u]] = hit ? 1 : 0;
          const uint64_t mm = __ballot(keep);
@@ -733,20 +816,16 @@ __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJo
    uint32_t* match = gptr_mut<uint32_t>(d->match);
    unsigned long long local = 0;
    for (uint64_t w0 = wave * JE_U; w0 < n_words; w0 += n_waves * JE_U) {
-      uint32_t brow[JE_U], mt[JE_U];
+      uint32_t brow[JE_U];
       uint64_t rows[JE_U];
       bool act[JE_U], pass[JE_U];
 #pragma unroll
       for (int u = 0; u < JE_U; u++) {
          rows[u] = (w0 + u) * 64 + lane;
          act[u] = pass[u] = rows[u] < n;
-         brow[u] = LDB_NULL_ROW;
       }
       d_eval_conj_batch<JE_U>(m.ppreds, d->ppreds, m.n_ppreds, rows, pass); // fused filter of a lazy probe side
-      d_probe_batch<JE_U>(m, d, rows, pass, mt, [&](int u, uint32_t x) {
-         brow[u] = x;
-         return false;
-      });
+      d_probe_first<JE_U>(m, d, rows, pass, brow);
 #pragma unroll
       for (int u = 0; u < JE_U; u++) {
          // INNER reads match[] only at the bitmap's set bits: unmatched rows are not written (a

@@ -128,9 +128,10 @@ int32_t ldb_rel_select(ldb_ctx* ctx, ldb_rel* in, uint32_t* sel, int64_t n_sel, 
    return LDB_OK;
 }
 
-// run the conjunction over the dense base rows of `in` → ascending row numbers (device, owned by caller)
-static int32_t scan_run(ldb_ctx* ctx, ldb_rel* in, const DScan& h, uint32_t** sel_out, uint64_t* total_out) {
-   const int64_t n = in->n_rows;
+// bitmap → ascending row numbers (device, owned by caller).  `launch(bitmap, block_counts)` runs the
+// kernel that evaluates the predicate: one ballot word per 64 rows + passing rows per 16384-row block.
+template <typename LAUNCH>
+static int32_t scan_run_with(ldb_ctx* ctx, int64_t n, LAUNCH launch, uint32_t** sel_out, uint64_t* total_out) {
    const int64_t n_words = (n + 63) / 64;
    const int64_t n_blocks = (n_words + SCAN_WORDS_PER_BLOCK - 1) / SCAN_WORDS_PER_BLOCK;
    uint32_t* sel;
@@ -140,29 +141,12 @@ static int32_t scan_run(ldb_ctx* ctx, ldb_rel* in, const DScan& h, uint32_t** se
       *total_out = 0;
       return LDB_OK;
    }
-   DScan* d;
    uint64_t* bitmap;
    uint32_t *counts, *offsets;
-   LDB_TRY(ldb_dev_upload(ctx, &h, sizeof(h), (void**) &d));
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmap, sizeof(uint64_t) * (size_t) n_words));
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &counts, sizeof(uint32_t) * (size_t) n_blocks));
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &offsets, sizeof(uint32_t) * (size_t) n_blocks));
-   {
-      hipFunction_t spec = nullptr;
-      if (ldb_jit_wanted(n)) {
-         DScan meta;
-         scan_meta(&h, &meta);
-         std::string why;
-         spec = ldb_jit_kernel(ctx->device, "ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, "k_scan_bitmap_spec", &meta, sizeof(meta), &why);
-      }
-      LdbProf prof_(ctx, "k_scan_bitmap");
-      if (spec) {
-         void* params[] = {(void*) &d, (void*) &bitmap, (void*) &counts};
-         LDB_HIP(hipModuleLaunchKernel(spec, (unsigned) n_blocks, 1, 1, SCAN_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
-      } else {
-         hipLaunchKernelGGL(k_scan_bitmap, dim3((unsigned) n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, d, bitmap, counts);
-      }
-   }
+   LDB_TRY(launch(bitmap, counts, (unsigned) n_blocks));
    LDB_HIP(hipGetLastError());
    LDB_TRY(ldb_exclusive_scan_u32(ctx, counts, offsets, n_blocks, (uint64_t*) ctx->d_scratch));
    uint64_t total = 0;
@@ -170,13 +154,117 @@ static int32_t scan_run(ldb_ctx* ctx, ldb_rel* in, const DScan& h, uint32_t** se
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &sel, sizeof(uint32_t) * (size_t) (total ? total : 1)));
    if (total) hipLaunchKernelGGL(k_scan_expand, dim3((unsigned) n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, bitmap, offsets, sel, (uint64_t) n);
    LDB_HIP(hipGetLastError());
-   ldb_dev_free(ctx, d);
    ldb_dev_free(ctx, bitmap);
    ldb_dev_free(ctx, counts);
    ldb_dev_free(ctx, offsets);
    *sel_out = sel;
    *total_out = total;
    return LDB_OK;
+}
+
+// run the conjunction over the dense base rows of `in` → ascending row numbers (device, owned by caller)
+static int32_t scan_run(ldb_ctx* ctx, ldb_rel* in, const DScan& h, uint32_t** sel_out, uint64_t* total_out) {
+   const int64_t n = in->n_rows;
+   DScan* d = nullptr;
+   if (n) LDB_TRY(ldb_dev_upload(ctx, &h, sizeof(h), (void**) &d));
+   const int32_t st = scan_run_with(
+      ctx, n,
+      [&](uint64_t* bitmap, uint32_t* counts, unsigned n_blocks) -> int32_t {
+         hipFunction_t spec = nullptr;
+         if (ldb_jit_wanted(n)) {
+            DScan meta;
+            scan_meta(&h, &meta);
+            std::string why;
+            spec = ldb_jit_kernel(ctx->device, "ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, "k_scan_bitmap_spec", &meta, sizeof(meta), &why);
+         }
+         LdbProf prof_(ctx, "k_scan_bitmap");
+         if (spec) {
+            void* params[] = {(void*) &d, (void*) &bitmap, (void*) &counts};
+            LDB_HIP(hipModuleLaunchKernel(spec, n_blocks, 1, 1, SCAN_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
+         } else {
+            hipLaunchKernelGGL(k_scan_bitmap, dim3(n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, d, bitmap, counts);
+         }
+         return LDB_OK;
+      },
+      sel_out, total_out);
+   ldb_dev_free(ctx, d);
+   return st;
+}
+
+// ---------------------------------------------------------------- disjunctive normal form
+// OR of up to DNF_MAX_CLAUSES conjunctions (TPC-H Q19's three brand/container/quantity/size
+// alternatives).  The reference keeps such a predicate as generated residual code — db.or over
+// db.and trees after the optimiser has pulled the common conjuncts out — and
+// evaluates it per tuple; here one pass evaluates clause after clause per row (a row that already
+// passed skips the remaining clauses) into the same ballot bitmap the conjunctive scan produces.
+#define DNF_MAX_CLAUSES 4
+#define DNF_MAX_PREDS 24
+struct DScanDnf {
+   uint64_t n_rows;
+   int32_t n_clauses;
+   int32_t clause_end[DNF_MAX_CLAUSES]; // preds [clause_end[c-1], clause_end[c]) form clause c
+   int32_t pad;
+   DPred preds[DNF_MAX_PREDS];
+};
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_bitmap_dnf(const DScanDnf* __restrict__ d, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ block_counts) {
+   __shared__ uint32_t s_cnt[SCAN_BLOCK / LDB_WAVE];
+   const uint64_t n = d->n_rows;
+   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const uint64_t word0 = (uint64_t) blockIdx.x * SCAN_WORDS_PER_BLOCK;
+   uint32_t cnt = 0;
+   for (uint32_t w = wave; w < SCAN_WORDS_PER_BLOCK; w += SCAN_BLOCK / LDB_WAVE) {
+      const uint64_t i = (word0 + w) * 64 + lane;
+      bool pass = false;
+      if (i < n) {
+         int p = 0;
+         for (int c = 0; c < d->n_clauses && !pass; c++) {
+            bool cp = true;
+            for (; p < d->clause_end[c]; p++)
+               if (cp) cp = d_eval_pred(PV(d->preds[p]), i);
+            pass = cp;
+         }
+      }
+      const uint64_t mask = __ballot(pass);
+      if (lane == 0 && (word0 + w) * 64 < n) bitmap[word0 + w] = mask;
+      cnt += (uint32_t) __popcll(mask);
+   }
+   if (lane == 0) s_cnt[wave] = cnt;
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int k = 0; k < SCAN_BLOCK / LDB_WAVE; k++) t += s_cnt[k];
+      block_counts[blockIdx.x] = t;
+   }
+}
+extern "C" int32_t ldb_gpu_scan_filter_dnf(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds, const int32_t* clause_sizes, int32_t n_clauses, ldb_rel** out) {
+   if (!ctx || !in || !out || !preds || !clause_sizes) LDB_FAIL(LDB_ERR_INVALID, "scan_filter_dnf: NULL argument");
+   if (n_clauses < 1 || n_clauses > DNF_MAX_CLAUSES) LDB_FAIL(LDB_ERR_UNSUPPORTED, "scan_filter_dnf: %d clauses (max %d)", n_clauses, DNF_MAX_CLAUSES);
+   LDB_TRY(ldb_rel_force(ctx, in));
+   auto hp = std::make_unique<DScanDnf>();
+   memset(hp.get(), 0, sizeof(DScanDnf));
+   hp->n_rows = (uint64_t) in->n_rows;
+   hp->n_clauses = n_clauses;
+   int32_t total_preds = 0;
+   for (int32_t c = 0; c < n_clauses; c++) {
+      if (clause_sizes[c] < 0 || total_preds + clause_sizes[c] > DNF_MAX_PREDS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "scan_filter_dnf: more than %d conjuncts in all", DNF_MAX_PREDS);
+      for (int32_t p = 0; p < clause_sizes[c]; p++, total_preds++) LDB_TRY(ldb_make_dpred(in, &preds[total_preds], &hp->preds[total_preds]));
+      hp->clause_end[c] = total_preds;
+   }
+   DScanDnf* d = nullptr;
+   if (in->n_rows) LDB_TRY(ldb_dev_upload(ctx, hp.get(), sizeof(DScanDnf), (void**) &d));
+   uint32_t* sel;
+   uint64_t total;
+   const int32_t st = scan_run_with(
+      ctx, in->n_rows,
+      [&](uint64_t* bitmap, uint32_t* counts, unsigned n_blocks) -> int32_t {
+         LdbProf prof_(ctx, "k_scan_bitmap_dnf");
+         hipLaunchKernelGGL(k_scan_bitmap_dnf, dim3(n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, (const DScanDnf*) d, bitmap, counts);
+         return LDB_OK;
+      },
+      &sel, &total);
+   ldb_dev_free(ctx, d);
+   LDB_TRY(st);
+   return ldb_rel_select(ctx, in, sel, (int64_t) total, out);
 }
 
 // lazy filters: on by default for dense relations of >= LDB_LAZY_MIN_ROWS rows (default 1 M);

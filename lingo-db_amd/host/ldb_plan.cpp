@@ -1,0 +1,967 @@
+// ldb_plan.cpp — plans as DATA: a JSON list of execution steps interpreted over the C-ABI.
+//
+// LingoDB hands a query to its backend as `subop.execution_step`s (one per pipeline,
+// src/compiler/Dialect/SubOperator/Transforms/OrganizeExecutionStepsPass.cpp; walked by
+// handleExecutionStepCPU, SubOpToControlFlow.cpp:4363-4395) and can dump them as JSON
+// (tools/ct/mlir-subop-to-json.cpp: {"type":"execution_step","subops":[{"subop":"scan", …}]}).
+// This file is the receiving end a GPU `ExecutionBackend` needs: a step list with the same
+// vocabulary, at the granularity of the C-ABI (scan + filter, lookup + scan_list = join_probe,
+// reduce + merge = groupby, …), each step's callbacks replaced by declarative descriptors.  The
+// plan text is data — the TPC-H plans under lingo-db_amd/plans/ are JSON files, not C++ functions;
+// INTEGRATION.md shows the LingoDB-side emitter that would produce the same documents.
+//
+// Column references are NAMES, resolved against the tables a relation was built from; constants
+// are SQL literals typed against the column by the mirror of Restrictions::create; scalar
+// expressions are trees typed by the reference's decimal rules (sql_analyzer.cpp:3058-3159) and
+// compiled either into the aggregate normal form (ldb_expr) or into a postfix program (ldb_xinstr).
+#include "ldb_host.hpp"
+#include <cctype>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <sstream>
+
+using namespace lingodb::runtime::gpu;
+
+namespace {
+
+// ================================================================== minimal JSON
+struct J {
+   enum Kind { NUL, BOOL, NUM, STR, ARR, OBJ } kind = NUL;
+   bool b = false;
+   double num = 0;
+   int64_t inum = 0;
+   bool isInt = false;
+   std::string str;
+   std::vector<J> arr;
+   std::vector<std::pair<std::string, J>> obj;
+   const J* get(const char* key) const {
+      for (auto& kv : obj)
+         if (kv.first == key) return &kv.second;
+      return nullptr;
+   }
+   const J& at(const char* key) const {
+      const J* v = get(key);
+      if (!v) throw std::runtime_error(std::string("plan: missing field '") + key + "'");
+      return *v;
+   }
+   const std::string& s(const char* key) const {
+      const J& v = at(key);
+      if (v.kind != STR) throw std::runtime_error(std::string("plan: field '") + key + "' must be a string");
+      return v.str;
+   }
+   std::string sOr(const char* key, const std::string& d) const {
+      const J* v = get(key);
+      return v && v->kind == STR ? v->str : d;
+   }
+   int64_t iOr(const char* key, int64_t d) const {
+      const J* v = get(key);
+      return v && v->kind == NUM ? (v->isInt ? v->inum : (int64_t) v->num) : d;
+   }
+   bool bOr(const char* key, bool d) const {
+      const J* v = get(key);
+      return v && v->kind == BOOL ? v->b : d;
+   }
+};
+struct JParser {
+   const char* p;
+   explicit JParser(const char* text) : p(text) {}
+   [[noreturn]] void fail(const char* what) { throw std::runtime_error(std::string("plan JSON: ") + what + " near '" + std::string(p).substr(0, 24) + "'"); }
+   void ws() {
+      while (*p && isspace((unsigned char) *p)) p++;
+   }
+   J value() {
+      ws();
+      J j;
+      if (*p == '{') {
+         p++;
+         j.kind = J::OBJ;
+         ws();
+         if (*p == '}') {
+            p++;
+            return j;
+         }
+         for (;;) {
+            ws();
+            if (*p != '"') fail("object key expected");
+            std::string k = string();
+            ws();
+            if (*p++ != ':') fail("':' expected");
+            j.obj.emplace_back(std::move(k), value());
+            ws();
+            if (*p == ',') {
+               p++;
+               continue;
+            }
+            if (*p == '}') {
+               p++;
+               return j;
+            }
+            fail("',' or '}' expected");
+         }
+      }
+      if (*p == '[') {
+         p++;
+         j.kind = J::ARR;
+         ws();
+         if (*p == ']') {
+            p++;
+            return j;
+         }
+         for (;;) {
+            j.arr.push_back(value());
+            ws();
+            if (*p == ',') {
+               p++;
+               continue;
+            }
+            if (*p == ']') {
+               p++;
+               return j;
+            }
+            fail("',' or ']' expected");
+         }
+      }
+      if (*p == '"') {
+         j.kind = J::STR;
+         j.str = string();
+         return j;
+      }
+      if (!strncmp(p, "true", 4)) {
+         p += 4;
+         j.kind = J::BOOL;
+         j.b = true;
+         return j;
+      }
+      if (!strncmp(p, "false", 5)) {
+         p += 5;
+         j.kind = J::BOOL;
+         return j;
+      }
+      if (!strncmp(p, "null", 4)) {
+         p += 4;
+         return j;
+      }
+      if (*p == '-' || isdigit((unsigned char) *p)) {
+         const char* b = p;
+         if (*p == '-') p++;
+         while (isdigit((unsigned char) *p)) p++;
+         bool isInt = true;
+         if (*p == '.' || *p == 'e' || *p == 'E') {
+            isInt = false;
+            while (*p && (isdigit((unsigned char) *p) || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) p++;
+         }
+         j.kind = J::NUM;
+         j.isInt = isInt;
+         std::string t(b, p);
+         if (isInt) j.inum = std::stoll(t);
+         j.num = std::stod(t);
+         return j;
+      }
+      fail("value expected");
+   }
+   std::string string() {
+      std::string out;
+      p++; // opening quote
+      while (*p && *p != '"') {
+         if (*p == '\\') {
+            p++;
+            switch (*p) {
+               case 'n': out += '\n'; break;
+               case 't': out += '\t'; break;
+               case 'u': { // \uXXXX (BMP only) → UTF-8
+                  unsigned cp = 0;
+                  for (int i = 1; i <= 4; i++) cp = cp * 16 + (unsigned) (isdigit((unsigned char) p[i]) ? p[i] - '0' : (tolower(p[i]) - 'a' + 10));
+                  p += 4;
+                  if (cp < 0x80) out += (char) cp;
+                  else if (cp < 0x800) {
+                     out += (char) (0xC0 | (cp >> 6));
+                     out += (char) (0x80 | (cp & 0x3F));
+                  } else {
+                     out += (char) (0xE0 | (cp >> 12));
+                     out += (char) (0x80 | ((cp >> 6) & 0x3F));
+                     out += (char) (0x80 | (cp & 0x3F));
+                  }
+                  break;
+               }
+               default: out += *p; break; // \" \\ \/
+            }
+            p++;
+         } else {
+            out += *p++;
+         }
+      }
+      if (*p != '"') fail("unterminated string");
+      p++;
+      return out;
+   }
+};
+
+// ================================================================== environment
+struct Value {
+   enum Kind { TABLE, REL, HT } kind = TABLE;
+   const ldb_table* table = nullptr;
+   ldb_rel* rel = nullptr;
+   ldb_hashtable* ht = nullptr;
+   bool owned = false;
+   std::vector<const ldb_table*> sides; // REL: the table behind each side; HT: the sides of its build relation
+   ldb_rel* lazyRel = nullptr; // TABLE used as a relation
+};
+
+struct Scalar { // expression type: integer (p = 0) or decimal(p, s), date, bool
+   enum Kind { INT, DEC, DATE, BOOL } kind = INT;
+   int32_t p = 0, s = 0;
+};
+
+struct Interp {
+   ldb_ctx* ctx;
+   std::map<std::string, Value> env;
+   std::vector<ldb_table*> hidden; // computed-column tables that live as long as the plan run
+   std::vector<std::unique_ptr<Restrictions>> keepRestr; // constant storage the descriptors point into
+   std::vector<std::unique_ptr<std::string>> keepStr;
+   std::string result;
+   explicit Interp(ldb_ctx* c) : ctx(c) {}
+   ~Interp() {
+      // hash tables first (they reference relations), then relations, then tables
+      for (auto& kv : env)
+         if (kv.second.kind == Value::HT && kv.second.owned && kv.second.ht) ldb_gpu_hashtable_release(ctx, kv.second.ht);
+      for (auto& kv : env) {
+         if (kv.second.lazyRel) ldb_gpu_rel_release(ctx, kv.second.lazyRel);
+         if (kv.second.kind == Value::REL && kv.second.owned && kv.second.rel) ldb_gpu_rel_release(ctx, kv.second.rel);
+      }
+      for (auto& kv : env)
+         if (kv.second.kind == Value::TABLE && kv.second.owned && kv.second.table && kv.first != result) ldb_gpu_table_release(ctx, const_cast<ldb_table*>(kv.second.table));
+      for (auto* t : hidden) ldb_gpu_table_release(ctx, t);
+   }
+
+   Value& val(const std::string& name) {
+      auto it = env.find(name);
+      if (it == env.end()) throw std::runtime_error("plan: unknown value '" + name + "'");
+      return it->second;
+   }
+   // a value as a relation (tables get an identity relation on first use)
+   ldb_rel* relOf(const std::string& name, std::vector<const ldb_table*>** sides = nullptr) {
+      Value& v = val(name);
+      if (v.kind == Value::HT) throw std::runtime_error("plan: '" + name + "' is a hash table, a relation is expected");
+      if (v.kind == Value::TABLE) {
+         if (!v.lazyRel) check(ldb_gpu_rel_from_table(ctx, v.table, &v.lazyRel), "scan");
+         if (v.sides.empty()) v.sides = {v.table};
+         if (sides) *sides = &v.sides;
+         return v.lazyRel;
+      }
+      if (sides) *sides = &v.sides;
+      return v.rel;
+   }
+   void put(const std::string& name, Value v) {
+      if (env.count(name)) throw std::runtime_error("plan: value '" + name + "' defined twice");
+      env.emplace(name, std::move(v));
+   }
+   void putRel(const std::string& name, ldb_rel* r, std::vector<const ldb_table*> sides) {
+      Value v;
+      v.kind = Value::REL;
+      v.rel = r;
+      v.owned = true;
+      v.sides = std::move(sides);
+      put(name, std::move(v));
+   }
+   void putTable(const std::string& name, ldb_table* t) {
+      Value v;
+      v.kind = Value::TABLE;
+      v.table = t;
+      v.owned = true;
+      put(name, std::move(v));
+   }
+
+   // "name" or "side:name" → column reference inside a relation with the given side tables
+   static ldb_colref resolve(const std::vector<const ldb_table*>& sides, const std::string& ref, const char* what) {
+      const auto colon = ref.find(':');
+      if (colon != std::string::npos && colon > 0 && isdigit((unsigned char) ref[0])) {
+         const int side = std::stoi(ref.substr(0, colon));
+         if (side < 0 || (size_t) side >= sides.size()) throw std::runtime_error(std::string(what) + ": side out of range in '" + ref + "'");
+         const int32_t c = ldb_gpu_table_col_index(sides[(size_t) side], ref.substr(colon + 1).c_str());
+         if (c < 0) throw std::runtime_error(std::string(what) + ": no column '" + ref + "'");
+         return {side, c};
+      }
+      for (size_t s = 0; s < sides.size(); s++) {
+         const int32_t c = ldb_gpu_table_col_index(sides[s], ref.c_str());
+         if (c >= 0) return {(int32_t) s, c};
+      }
+      throw std::runtime_error(std::string(what) + ": no column '" + ref + "' in the relation");
+   }
+   static ldb_coltype typeOf(const std::vector<const ldb_table*>& sides, ldb_colref c) {
+      ldb_coltype t;
+      ldb_gpu_table_coltype(sides[(size_t) c.side], c.col, &t);
+      return t;
+   }
+
+   // ------------------------------------------------------------ predicates
+   static int32_t opOf(const std::string& op) {
+      static const std::map<std::string, int32_t> ops = {{"EQ", LDB_F_EQ},   {"NEQ", LDB_F_NEQ}, {"LT", LDB_F_LT}, {"LTE", LDB_F_LTE},   {"GT", LDB_F_GT},
+                                                         {"GTE", LDB_F_GTE}, {"NOTNULL", LDB_F_NOTNULL}, {"IN", LDB_F_IN}, {"LIKE", LDB_F_LIKE}, {"NOT LIKE", LDB_F_NOT_LIKE}};
+      auto it = ops.find(op);
+      if (it == ops.end()) throw std::runtime_error("plan: unknown comparison '" + op + "'");
+      return it->second;
+   }
+   // value of row 0 of a 1-row table's column as a 128-bit integer (scalar subquery results)
+   __int128 readScalar(const std::string& table, const std::string& col) {
+      Value& v = val(table);
+      if (v.kind != Value::TABLE) throw std::runtime_error("plan: scalar source '" + table + "' must be a table");
+      if (ldb_gpu_table_rows(v.table) < 1) throw std::runtime_error("plan: scalar source '" + table + "' is empty");
+      const int32_t c = ldb_gpu_table_col_index(v.table, col.c_str());
+      if (c < 0) throw std::runtime_error("plan: scalar source has no column '" + col + "'");
+      const int32_t w = ldb_gpu_table_col_width(v.table, c);
+      const int64_t rows = ldb_gpu_table_rows(v.table);
+      std::vector<uint8_t> buf((size_t) (rows * w));
+      check(ldb_gpu_table_read_fixed(ctx, v.table, c, buf.data(), (int64_t) buf.size()), "scalar read");
+      __int128 x = 0;
+      if (w == 16) memcpy(&x, buf.data(), 16);
+      else if (w == 8) {
+         int64_t t;
+         memcpy(&t, buf.data(), 8);
+         x = t;
+      } else {
+         int32_t t;
+         memcpy(&t, buf.data(), 4);
+         x = t;
+      }
+      return x;
+   }
+   static __int128 floorDiv(__int128 a, __int128 b) {
+      __int128 q = a / b;
+      if ((a % b != 0) && ((a < 0) != (b < 0))) q--;
+      return q;
+   }
+   ldb_filter_desc pred(const std::vector<const ldb_table*>& sides, const J& jp) {
+      const std::string& opName = jp.s("op");
+      const int32_t op = opOf(opName);
+      const ldb_colref c = resolve(sides, jp.s("col"), "filter");
+      const ldb_table* tab = sides[(size_t) c.side];
+      const std::string colName = ldb_gpu_table_col_name(tab, c.col);
+      if (const J* rc = jp.get("rhs_col")) { // residual column-vs-column conjunct (generated db.compare in the reference)
+         ldb_filter_desc d;
+         memset(&d, 0, sizeof(d));
+         d.col = c;
+         d.op = op;
+         d.rhs_kind = LDB_RHS_COLUMN;
+         d.rhs_col = resolve(sides, rc->str, "filter rhs");
+         return d;
+      }
+      if (op == LDB_F_LIKE || op == LDB_F_NOT_LIKE) { // StringRuntime::like, evaluated in generated code
+         keepStr.push_back(std::make_unique<std::string>(jp.s("value")));
+         ldb_filter_desc d;
+         memset(&d, 0, sizeof(d));
+         d.col = c;
+         d.op = op;
+         d.rhs_kind = LDB_RHS_STRING;
+         d.str = keepStr.back()->data();
+         d.str_len = (int32_t) keepStr.back()->size();
+         return d;
+      }
+      if (const J* sc = jp.get("scalar")) { // column OP (scalar subquery result): the constant is read back from the device
+         __int128 x = readScalar(sc->s("from"), sc->s("col"));
+         // the two sides of the comparison are cast to a common decimal type first; with
+         // x at scale sx and the column at scale sc <= sx:  col * 10^k OP x  ⇔  col OP' floor-ish(x / 10^k)
+         const int64_t k = sc->iOr("div_pow10", 0);
+         if (k > 0) {
+            __int128 m = 1;
+            for (int64_t i = 0; i < k; i++) m *= 10;
+            const __int128 fl = floorDiv(x, m);
+            const bool exact = fl * m == x;
+            // col*m > x ⇔ col > floor(x/m);  col*m >= x ⇔ col > floor(x/m) unless exact;  col*m < x ⇔ col <= floor unless exact …
+            ldb_filter_desc d;
+            memset(&d, 0, sizeof(d));
+            d.col = c;
+            d.rhs_kind = LDB_RHS_INT;
+            int32_t o = op;
+            __int128 v = fl;
+            switch (op) {
+               case LDB_F_GT: o = LDB_F_GT; break;
+               case LDB_F_GTE: o = exact ? LDB_F_GTE : LDB_F_GT; break;
+               case LDB_F_LT: o = exact ? LDB_F_LT : LDB_F_LTE; break;
+               case LDB_F_LTE: o = LDB_F_LTE; break;
+               case LDB_F_EQ:
+                  if (!exact) { // never true: compare with an impossible pair
+                     o = LDB_F_LT;
+                     v = ((__int128) 1) << 126;
+                     v = -v;
+                  }
+                  break;
+               default: throw std::runtime_error("plan: scalar comparison operator not supported");
+            }
+            d.op = o;
+            d.value_lo = (uint64_t) v;
+            d.value_hi = (int64_t) (v >> 64);
+            return d;
+         }
+         ldb_filter_desc d;
+         memset(&d, 0, sizeof(d));
+         d.col = c;
+         d.op = op;
+         d.rhs_kind = LDB_RHS_INT;
+         d.value_lo = (uint64_t) x;
+         d.value_hi = (int64_t) (x >> 64);
+         return d;
+      }
+      // column vs constant: typed by the mirror of Restrictions::create (Restrictions.cpp:392-521)
+      FilterDescription fd;
+      fd.columnName = colName;
+      fd.op = (FilterOp) op;
+      if (op == LDB_F_IN) {
+         const J& vals = jp.at("values");
+         if (vals.kind != J::ARR || vals.arr.empty()) throw std::runtime_error("plan: IN needs a non-empty 'values' array");
+         if (vals.arr[0].kind == J::STR) {
+            std::vector<std::string> v;
+            for (auto& e : vals.arr) v.push_back(e.str);
+            fd.values = v;
+         } else {
+            std::vector<int64_t> v;
+            for (auto& e : vals.arr) v.push_back(e.inum);
+            fd.values = v;
+         }
+      } else if (op != LDB_F_NOTNULL) {
+         const J& v = jp.at("value");
+         if (v.kind == J::STR) fd.value = v.str;
+         else if (v.kind == J::NUM && v.isInt) fd.value = v.inum;
+         else if (v.kind == J::NUM) fd.value = v.num;
+         else throw std::runtime_error("plan: filter constant must be a string or a number");
+      }
+      keepRestr.push_back(Restrictions::create({fd}, tab, c.side));
+      return keepRestr.back()->data()[0];
+   }
+   std::vector<ldb_filter_desc> preds(const std::vector<const ldb_table*>& sides, const J* list) {
+      std::vector<ldb_filter_desc> out;
+      if (!list) return out;
+      for (auto& jp : list->arr) out.push_back(pred(sides, jp));
+      return out;
+   }
+
+   // ------------------------------------------------------------ expressions
+   static Scalar scalarOfCol(const ldb_coltype& t) {
+      Scalar s;
+      switch (t.type) {
+         case LDB_T_DECIMAL128: s.kind = Scalar::DEC; s.p = t.precision; s.s = t.scale; break;
+         case LDB_T_DATE32: s.kind = Scalar::DATE; break;
+         case LDB_T_BOOL8: s.kind = Scalar::BOOL; break;
+         case LDB_T_INT8:
+         case LDB_T_INT16:
+         case LDB_T_INT32:
+         case LDB_T_INT64:
+         case LDB_T_CHAR4: s.kind = Scalar::INT; break;
+         default: throw std::runtime_error("plan: expression over a non-numeric column");
+      }
+      return s;
+   }
+   static DecimalType asDec(const Scalar& s) { return s.kind == Scalar::DEC ? DecimalType{s.p, s.s} : DecimalType{19, 0}; } // int → decimal(19,0), sql_analyzer.cpp:3125-3141
+   static Scalar decScalar(DecimalType t) {
+      Scalar s;
+      s.kind = Scalar::DEC;
+      s.p = t.p;
+      s.s = t.s;
+      return s;
+   }
+   // decimal literal "0.2" → decimal(2,1) value 2 (sql_analyzer.cpp:2103-2113: p = digits, s = digits after the point)
+   static bool decimalLiteral(const std::string& txt, __int128* v, Scalar* t) {
+      const auto dot = txt.find('.');
+      if (dot == std::string::npos) return false;
+      for (size_t i = 0; i < txt.size(); i++)
+         if (!(isdigit((unsigned char) txt[i]) || txt[i] == '.' || (i == 0 && txt[i] == '-'))) return false;
+      const int32_t s = (int32_t) (txt.size() - dot - 1);
+      const bool neg = txt[0] == '-';
+      const int32_t p = (int32_t) txt.size() - 1 - (neg ? 1 : 0);
+      *v = parseDecimal(txt, s);
+      *t = decScalar({p, s});
+      return true;
+   }
+
+   struct XB { // postfix program under construction
+      std::vector<ldb_xinstr> ins;
+      void push(int32_t op, int32_t arg = 0, ldb_colref c = {0, 0}, __int128 k = 0) {
+         ldb_xinstr x;
+         memset(&x, 0, sizeof(x));
+         x.op = op;
+         x.arg = arg;
+         x.col = c;
+         x.lo = (int64_t) (uint64_t) k;
+         x.hi = (int64_t) (k >> 64);
+         ins.push_back(x);
+      }
+   };
+   static void castTo(XB& b, const Scalar& from, const DecimalType& to) { // db.cast to a decimal of larger-or-equal scale
+      const int32_t fs = from.kind == Scalar::DEC ? from.s : 0;
+      if (to.s > fs) b.push(LDB_X_MUL_POW10, to.s - fs);
+      else if (to.s < fs) b.push(LDB_X_SDIV_POW10, fs - to.s);
+   }
+   // compile an expression tree into postfix code; returns its type
+   Scalar compileX(const std::vector<const ldb_table*>& sides, const J& e, XB& b) {
+      if (e.kind == J::NUM) {
+         if (!e.isInt) throw std::runtime_error("plan: write decimal literals as strings (\"0.2\")");
+         b.push(LDB_X_CONST, 0, {0, 0}, (__int128) e.inum);
+         return Scalar{};
+      }
+      if (e.kind == J::STR) {
+         __int128 v;
+         Scalar t;
+         if (decimalLiteral(e.str, &v, &t)) {
+            b.push(LDB_X_CONST, 0, {0, 0}, v);
+            return t;
+         }
+         const ldb_colref c = resolve(sides, e.str, "expression");
+         b.push(LDB_X_COL, 0, c);
+         return scalarOfCol(typeOf(sides, c));
+      }
+      if (e.kind != J::OBJ || e.obj.size() != 1) throw std::runtime_error("plan: expression node must be {\"op\": [args]}");
+      const std::string& op = e.obj[0].first;
+      const J& args = e.obj[0].second;
+      auto arity = [&](size_t n) {
+         if (args.kind != J::ARR || args.arr.size() != n) throw std::runtime_error("plan: '" + op + "' takes " + std::to_string(n) + " arguments");
+      };
+      if (op == "add" || op == "sub") {
+         arity(2);
+         XB lb, rb;
+         const Scalar l = compileX(sides, args.arr[0], lb), r = compileX(sides, args.arr[1], rb);
+         if (l.kind == Scalar::INT && r.kind == Scalar::INT) {
+            b.ins.insert(b.ins.end(), lb.ins.begin(), lb.ins.end());
+            b.ins.insert(b.ins.end(), rb.ins.begin(), rb.ins.end());
+            b.push(op == "add" ? LDB_X_ADD : LDB_X_SUB);
+            return Scalar{};
+         }
+         const DecimalType t = higherDecimalType(asDec(l), asDec(r)); // DecimalBinOpLowering after the frontend's casts (LowerToStd.cpp:680-699)
+         b.ins.insert(b.ins.end(), lb.ins.begin(), lb.ins.end());
+         castTo(b, l, t);
+         b.ins.insert(b.ins.end(), rb.ins.begin(), rb.ins.end());
+         castTo(b, r, t);
+         b.push(op == "add" ? LDB_X_ADD : LDB_X_SUB);
+         return decScalar(t);
+      }
+      if (op == "mul") {
+         arity(2);
+         const Scalar l = compileX(sides, args.arr[0], b);
+         const Scalar r = compileX(sides, args.arr[1], b);
+         b.push(LDB_X_MUL);
+         if (l.kind == Scalar::INT && r.kind == Scalar::INT) return Scalar{};
+         const DecimalType dl = asDec(l), dr = asDec(r), t = typeAfterMul(dl, dr); // DecimalMulOpLowering (LowerToStd.cpp:653-677)
+         if (dl.s + dr.s > t.s) b.push(LDB_X_SDIV_POW10, dl.s + dr.s - t.s);
+         return decScalar(t);
+      }
+      if (op == "div") {
+         arity(2);
+         const Scalar l = compileX(sides, args.arr[0], b);
+         XB rb;
+         const Scalar r = compileX(sides, args.arr[1], rb);
+         const DecimalType dl = asDec(l), dr = asDec(r), t = typeAfterDiv(dl, dr); // DecimalOpScaledLowering (LowerToStd.cpp:631-651)
+         const int32_t k = t.s + dr.s - dl.s;
+         if (k < 0) throw std::runtime_error("plan: decimal division with a negative scale adjustment");
+         b.push(LDB_X_MUL_POW10, k);
+         b.ins.insert(b.ins.end(), rb.ins.begin(), rb.ins.end());
+         b.push(LDB_X_SDIV);
+         return decScalar(t);
+      }
+      if (op == "cmp") { // ["GT", a, b]
+         arity(3);
+         const int32_t cmp = opOf(args.arr[0].str);
+         if (cmp > LDB_F_GTE) throw std::runtime_error("plan: cmp needs EQ/NEQ/LT/LTE/GT/GTE");
+         XB lb, rb;
+         const Scalar l = compileX(sides, args.arr[1], lb), r = compileX(sides, args.arr[2], rb);
+         b.ins.insert(b.ins.end(), lb.ins.begin(), lb.ins.end());
+         if (l.kind == Scalar::DEC || r.kind == Scalar::DEC) {
+            const DecimalType t = higherDecimalType(asDec(l), asDec(r));
+            castTo(b, l, t);
+            b.ins.insert(b.ins.end(), rb.ins.begin(), rb.ins.end());
+            castTo(b, r, t);
+         } else {
+            b.ins.insert(b.ins.end(), rb.ins.begin(), rb.ins.end());
+         }
+         b.push(LDB_X_CMP, cmp);
+         Scalar s;
+         s.kind = Scalar::BOOL;
+         return s;
+      }
+      if (op == "and" || op == "or") {
+         arity(2);
+         compileX(sides, args.arr[0], b);
+         compileX(sides, args.arr[1], b);
+         b.push(op == "and" ? LDB_X_AND : LDB_X_OR);
+         Scalar s;
+         s.kind = Scalar::BOOL;
+         return s;
+      }
+      if (op == "not" || op == "isnull") {
+         arity(1);
+         compileX(sides, args.arr[0], b);
+         b.push(op == "not" ? LDB_X_NOT : LDB_X_ISNULL);
+         Scalar s;
+         s.kind = Scalar::BOOL;
+         return s;
+      }
+      if (op == "coalesce" || op == "case") { // coalesce(a, b) / case when c then a else b
+         const bool isCase = op == "case";
+         arity(isCase ? 3 : 2);
+         if (isCase) compileX(sides, args.arr[0], b);
+         XB lb, rb;
+         const Scalar l = compileX(sides, args.arr[isCase ? 1 : 0], lb), r = compileX(sides, args.arr[isCase ? 2 : 1], rb);
+         Scalar out = l;
+         b.ins.insert(b.ins.end(), lb.ins.begin(), lb.ins.end());
+         if (l.kind == Scalar::DEC || r.kind == Scalar::DEC) {
+            const DecimalType t = higherDecimalType(asDec(l), asDec(r));
+            castTo(b, l, t);
+            b.ins.insert(b.ins.end(), rb.ins.begin(), rb.ins.end());
+            castTo(b, r, t);
+            out = decScalar(t);
+         } else {
+            b.ins.insert(b.ins.end(), rb.ins.begin(), rb.ins.end());
+         }
+         b.push(isCase ? LDB_X_SELECT : LDB_X_COALESCE);
+         return out;
+      }
+      if (op == "neg") {
+         arity(1);
+         const Scalar t = compileX(sides, args.arr[0], b);
+         b.push(LDB_X_NEG);
+         return t;
+      }
+      throw std::runtime_error("plan: unknown expression operator '" + op + "'");
+   }
+
+   // aggregate argument → the sum-of-products normal form of ldb_expr (what the decimal lowerings
+   // reduce to once the scales are fixed); returns the result type
+   struct Factor {
+      bool isCol = false, isConst = false;
+      ldb_colref col{0, 0};
+      __int128 k = 0; // constant (unscaled)
+      int sign = 1; // (k + sign * col)
+      bool constPlus = false;
+      Scalar type;
+   };
+   Factor factorOf(const std::vector<const ldb_table*>& sides, const J& e) {
+      Factor f;
+      if (e.kind == J::NUM) {
+         f.isConst = true;
+         f.k = e.inum;
+         return f;
+      }
+      if (e.kind == J::STR) {
+         __int128 v;
+         Scalar t;
+         if (decimalLiteral(e.str, &v, &t)) {
+            f.isConst = true;
+            f.k = v;
+            f.type = t;
+            return f;
+         }
+         f.isCol = true;
+         f.col = resolve(sides, e.str, "aggregate");
+         f.type = scalarOfCol(typeOf(sides, f.col));
+         return f;
+      }
+      if (e.kind == J::OBJ && e.obj.size() == 1 && (e.obj[0].first == "add" || e.obj[0].first == "sub")) { // (k ± col)
+         const J& a = e.obj[0].second;
+         if (a.kind == J::ARR && a.arr.size() == 2 && a.arr[0].kind == J::NUM && a.arr[1].kind == J::STR) {
+            f.constPlus = true;
+            f.col = resolve(sides, a.arr[1].str, "aggregate");
+            const Scalar ct = scalarOfCol(typeOf(sides, f.col));
+            f.sign = e.obj[0].first == "add" ? 1 : -1;
+            if (ct.kind == Scalar::DEC) { // int literal → decimal(19,0) → common scale of the column (sql_analyzer.cpp:3125-3141)
+               f.type = decScalar(higherDecimalType({19, 0}, {ct.p, ct.s}));
+               f.k = (__int128) a.arr[0].inum * pow10i(ct.s);
+            } else {
+               f.type = ct;
+               f.k = a.arr[0].inum;
+            }
+            return f;
+         }
+      }
+      throw std::runtime_error("plan: aggregate factors must be a column, a literal or (integer ± column)");
+   }
+   Scalar termOf(const std::vector<const ldb_table*>& sides, const J& e, ldb_term* t) {
+      memset(t, 0, sizeof(*t));
+      std::vector<const J*> fs;
+      if (e.kind == J::OBJ && e.obj.size() == 1 && e.obj[0].first == "mul") {
+         for (auto& a : e.obj[0].second.arr) fs.push_back(&a);
+      } else {
+         fs.push_back(&e);
+      }
+      if (fs.size() > LDB_MAX_FACTORS) throw std::runtime_error("plan: more than 3 factors in an aggregate product");
+      Scalar type;
+      bool first = true;
+      for (auto* fe : fs) {
+         const Factor f = factorOf(sides, *fe);
+         ldb_factor& o = t->f[t->n_factors++];
+         if (f.isConst) {
+            o = {0, {0, 0}, (int64_t) f.k, 0};
+         } else if (f.constPlus) {
+            o = {1, f.col, (int64_t) f.k, f.sign};
+         } else {
+            o = {1, f.col, 0, 1};
+         }
+         if (first) {
+            type = f.type;
+            first = false;
+         } else if (type.kind == Scalar::DEC || f.type.kind == Scalar::DEC) {
+            const DecimalType a = asDec(type), b2 = asDec(f.type), r = typeAfterMul(a, b2);
+            if (a.s + b2.s != r.s) t->div_pow10 += a.s + b2.s - r.s; // clamped scale: truncating divide (LowerToStd.cpp:653-677)
+            type = decScalar(r);
+         }
+      }
+      return type;
+   }
+   Scalar aggExpr(const std::vector<const ldb_table*>& sides, const J& e, ldb_expr* out) {
+      memset(out, 0, sizeof(*out));
+      if (e.kind == J::OBJ && e.obj.size() == 1 && (e.obj[0].first == "add" || e.obj[0].first == "sub")) {
+         const J& a = e.obj[0].second;
+         const bool constPlusCol = a.kind == J::ARR && a.arr.size() == 2 && a.arr[0].kind == J::NUM && a.arr[1].kind == J::STR;
+         if (!constPlusCol) { // difference / sum of two products (Q9's amount)
+            if (a.kind != J::ARR || a.arr.size() != 2) throw std::runtime_error("plan: add/sub take two arguments");
+            out->n_terms = 2;
+            const Scalar l = termOf(sides, a.arr[0], &out->t[0]), r = termOf(sides, a.arr[1], &out->t[1]);
+            out->t[1].negate = e.obj[0].first == "sub";
+            if (l.kind != Scalar::DEC && r.kind != Scalar::DEC) return Scalar{};
+            const DecimalType dl = asDec(l), dr = asDec(r), t = higherDecimalType(dl, dr);
+            // bring both terms to the common scale with one more constant factor
+            ldb_term* ts[2] = {&out->t[0], &out->t[1]};
+            const DecimalType ds[2] = {dl, dr};
+            for (int i = 0; i < 2; i++) {
+               if (ds[i].s < t.s) {
+                  if (ts[i]->n_factors >= LDB_MAX_FACTORS) throw std::runtime_error("plan: no room for the scale factor in an aggregate term");
+                  ts[i]->f[ts[i]->n_factors++] = {0, {0, 0}, pow10i(t.s - ds[i].s), 0};
+               }
+            }
+            return decScalar(t);
+         }
+      }
+      out->n_terms = 1;
+      return termOf(sides, e, &out->t[0]);
+   }
+
+   // ------------------------------------------------------------ steps
+   void run(const J& plan, const char* const* names, const ldb_table* const* tables, int32_t n) {
+      for (int32_t i = 0; i < n; i++) {
+         Value v;
+         v.kind = Value::TABLE;
+         v.table = tables[i];
+         put(names[i], v);
+      }
+      const J& steps = plan.at("steps");
+      result = plan.sOr("result", "result");
+      for (auto& st : steps.arr) {
+         try {
+            step(st);
+         } catch (const std::exception& e) {
+            throw std::runtime_error(plan.sOr("name", "plan") + ": step '" + st.sOr("op", "?") + "' → '" + st.sOr("out", "") + "': " + e.what());
+         }
+      }
+   }
+
+   std::vector<ldb_colref> cols(const std::vector<const ldb_table*>& sides, const J& list, const char* what) {
+      std::vector<ldb_colref> out;
+      for (auto& c : list.arr) out.push_back(resolve(sides, c.kind == J::STR ? c.str : c.s("col"), what));
+      return out;
+   }
+
+   void step(const J& st) {
+      const std::string& op = st.s("op");
+      if (op == "scan") { // subop.scan_refs over a table (get_external)
+         Value& t = val(st.s("table"));
+         if (t.kind != Value::TABLE) throw std::runtime_error("scan: not a table");
+         ldb_rel* r;
+         check(ldb_gpu_rel_from_table(ctx, t.table, &r), "scan");
+         putRel(st.s("out"), r, {t.table});
+      } else if (op == "filter") {
+         std::vector<const ldb_table*>* sides;
+         ldb_rel* in = relOf(st.s("in"), &sides);
+         auto ps = preds(*sides, &st.at("preds"));
+         ldb_rel* r;
+         check(ldb_gpu_scan_filter(ctx, in, ps.data(), (int32_t) ps.size(), &r), "filter");
+         putRel(st.s("out"), r, *sides);
+      } else if (op == "filter_dnf") {
+         std::vector<const ldb_table*>* sides;
+         ldb_rel* in = relOf(st.s("in"), &sides);
+         std::vector<ldb_filter_desc> all;
+         std::vector<int32_t> sizes;
+         for (auto& cl : st.at("clauses").arr) {
+            auto ps = preds(*sides, &cl);
+            sizes.push_back((int32_t) ps.size());
+            all.insert(all.end(), ps.begin(), ps.end());
+         }
+         ldb_rel* r;
+         check(ldb_gpu_scan_filter_dnf(ctx, in, all.data(), sizes.data(), (int32_t) sizes.size(), &r), "filter_dnf");
+         putRel(st.s("out"), r, *sides);
+      } else if (op == "join_build") {
+         std::vector<const ldb_table*>* sides;
+         ldb_rel* in = relOf(st.s("in"), &sides);
+         auto keys = cols(*sides, st.at("keys"), "join_build");
+         Value v;
+         v.kind = Value::HT;
+         v.owned = true;
+         v.sides = *sides;
+         check(ldb_gpu_join_build(ctx, in, keys.data(), (int32_t) keys.size(), st.bOr("unique", false) ? 1 : 0, &v.ht), "join_build");
+         put(st.s("out"), std::move(v));
+      } else if (op == "join_probe") {
+         Value& ht = val(st.s("ht"));
+         if (ht.kind != Value::HT) throw std::runtime_error("join_probe: 'ht' is not a hash table");
+         std::vector<const ldb_table*>* sides;
+         ldb_rel* in = relOf(st.s("in"), &sides);
+         auto keys = cols(*sides, st.at("keys"), "join_probe");
+         static const std::map<std::string, int32_t> kinds = {{"inner", LDB_JOIN_INNER}, {"semi", LDB_JOIN_SEMI}, {"anti", LDB_JOIN_ANTI}, {"left_outer", LDB_JOIN_LEFT_OUTER},
+                                                             {"mark", LDB_JOIN_MARK},   {"single", LDB_JOIN_SINGLE}, {"semi_build", LDB_JOIN_SEMI_BUILD}, {"anti_build", LDB_JOIN_ANTI_BUILD}};
+         auto kit = kinds.find(st.sOr("kind", "inner"));
+         if (kit == kinds.end()) throw std::runtime_error("join_probe: unknown kind");
+         const int32_t kind = kit->second;
+         std::vector<ldb_join_residual> resid;
+         if (const J* rs = st.get("residual"))
+            for (auto& r : rs->arr) resid.push_back({resolve(*sides, r.s("probe"), "residual probe"), resolve(ht.sides, r.s("build"), "residual build"), opOf(r.s("op")), 0});
+         ldb_rel* r;
+         ldb_table* mark = nullptr;
+         check(ldb_gpu_join_probe_residual(ctx, ht.ht, in, keys.data(), (int32_t) keys.size(), kind, resid.data(), (int32_t) resid.size(), &r, &mark), "join_probe");
+         std::vector<const ldb_table*> outSides;
+         if (kind == LDB_JOIN_SEMI_BUILD || kind == LDB_JOIN_ANTI_BUILD) {
+            outSides = ht.sides;
+         } else {
+            outSides = *sides;
+            if (kind == LDB_JOIN_INNER || kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE) outSides.insert(outSides.end(), ht.sides.begin(), ht.sides.end());
+         }
+         putRel(st.s("out"), r, std::move(outSides));
+         if (mark) {
+            if (const J* mo = st.get("mark_out")) putTable(mo->str, mark);
+            else hidden.push_back(mark);
+         }
+      } else if (op == "groupby") {
+         std::vector<const ldb_table*>* sides;
+         ldb_rel* in = relOf(st.s("in"), &sides);
+         auto ps = preds(*sides, st.get("preds"));
+         std::vector<ldb_colref> keys;
+         if (const J* k = st.get("keys")) keys = cols(*sides, *k, "groupby key");
+         std::vector<ldb_agg_spec> aggs;
+         std::vector<std::string> names;
+         for (auto& ja : st.at("aggs").arr) {
+            ldb_agg_spec a;
+            memset(&a, 0, sizeof(a));
+            const std::string fn = ja.s("fn");
+            names.push_back(ja.sOr("as", ""));
+            if (const J* when = ja.get("when")) { // sum(case when <conjunction> then x else 0 end)
+               auto wp = preds(*sides, when);
+               if (wp.size() > LDB_MAX_AGG_PREDS) throw std::runtime_error("groupby: more than 3 conjuncts in a conditional aggregate");
+               a.n_preds = (int32_t) wp.size();
+               for (size_t p = 0; p < wp.size(); p++) a.preds[p] = wp[p];
+            }
+            if (fn == "count_star") {
+               a.fn = LDB_AGG_COUNT_STAR;
+               a.out_type = LDB_T_INT64;
+            } else {
+               const Scalar t = aggExpr(*sides, ja.at("expr"), &a.arg);
+               if (fn == "count") {
+                  a.fn = LDB_AGG_COUNT;
+                  a.out_type = LDB_T_INT64;
+               } else {
+                  static const std::map<std::string, int32_t> fns = {{"sum", LDB_AGG_SUM}, {"min", LDB_AGG_MIN}, {"max", LDB_AGG_MAX}, {"any", LDB_AGG_ANY}, {"avg", LDB_AGG_AVG}};
+                  auto fit = fns.find(fn);
+                  if (fit == fns.end()) throw std::runtime_error("groupby: unknown aggregate '" + fn + "'");
+                  a.fn = fit->second;
+                  if (t.kind == Scalar::DEC) { // SUM / MIN / MAX keep the argument type (sql_analyzer.cpp:2631-2632)
+                     DecimalType dt{t.p, t.s};
+                     a.wide = dt.wide();
+                     a.out_type = LDB_T_DECIMAL128;
+                     a.out_precision = dt.p;
+                     a.out_scale = dt.s;
+                     if (a.fn == LDB_AGG_AVG) { // SUM / COUNT with the divisor typed decimal(19,0) (:2636-2642)
+                        const DecimalType r = avgType(dt);
+                        a.avg_pow10 = r.s - dt.s;
+                        a.out_precision = r.p;
+                        a.out_scale = r.s;
+                     }
+                  } else if (t.kind == Scalar::DATE) {
+                     a.out_type = LDB_T_DATE32;
+                  } else {
+                     a.out_type = ja.sOr("type", "int64") == "int32" ? LDB_T_INT32 : LDB_T_INT64;
+                     if (a.fn == LDB_AGG_AVG) throw std::runtime_error("groupby: avg over integers is not supported (cast to decimal)");
+                  }
+               }
+            }
+            aggs.push_back(a);
+         }
+         int64_t est = st.iOr("est_groups", 0);
+         if (st.sOr("est_groups_from", "") == "rows") est = std::max<int64_t>(1, ldb_gpu_rel_rows(ctx, in));
+         ldb_table* out;
+         check(ldb_gpu_groupby(ctx, in, ps.data(), (int32_t) ps.size(), keys.data(), (int32_t) keys.size(), aggs.data(), (int32_t) aggs.size(), est, &out), "groupby");
+         for (size_t a = 0; a < names.size(); a++)
+            if (!names[a].empty()) ldb_gpu_table_rename_col(out, (int32_t) (keys.size() + a), names[a].c_str());
+         if (const J* kn = st.get("key_names"))
+            for (size_t k = 0; k < kn->arr.size() && k < keys.size(); k++) ldb_gpu_table_rename_col(out, (int32_t) k, kn->arr[k].str.c_str());
+         putTable(st.s("out"), out);
+      } else if (op == "map") { // subop.map: one computed column, attached as a new last side
+         std::vector<const ldb_table*>* sides;
+         ldb_rel* in = relOf(st.s("in"), &sides);
+         const std::string as = st.s("as");
+         ldb_table* t = nullptr;
+         const std::string fn = st.sOr("fn", "");
+         if (fn == "extract_year") {
+            check(ldb_gpu_map_column(ctx, in, resolve(*sides, st.s("col"), "map"), LDB_FN_EXTRACT_YEAR, as.c_str(), &t), "map extract_year");
+         } else if (fn == "substr") {
+            check(ldb_gpu_map_substr(ctx, in, resolve(*sides, st.s("col"), "map"), st.iOr("from", 1), st.iOr("for", 1 << 30), as.c_str(), &t), "map substr");
+         } else {
+            XB b;
+            const Scalar ty = compileX(*sides, st.at("expr"), b);
+            ldb_coltype ct = {LDB_T_INT64, 0, 0, 1};
+            if (ty.kind == Scalar::DEC) ct = {LDB_T_DECIMAL128, ty.p, ty.s, 1};
+            else if (ty.kind == Scalar::BOOL) ct = {LDB_T_BOOL8, 0, 0, 1};
+            else if (ty.kind == Scalar::DATE) ct = {LDB_T_DATE32, 0, 0, 1};
+            check(ldb_gpu_map_expr(ctx, in, b.ins.data(), (int32_t) b.ins.size(), ct, as.c_str(), &t), "map expr");
+         }
+         hidden.push_back(t);
+         ldb_rel* r;
+         check(ldb_gpu_rel_zip(ctx, in, t, &r), "map zip");
+         auto outSides = *sides;
+         outSides.push_back(t);
+         putRel(st.s("out"), r, std::move(outSides));
+      } else if (op == "sort" || op == "topk") {
+         std::vector<const ldb_table*>* sides;
+         ldb_rel* in = relOf(st.s("in"), &sides);
+         std::vector<ldb_sort_spec> specs;
+         for (auto& b : st.at("by").arr) specs.push_back({resolve(*sides, b.kind == J::STR ? b.str : b.s("col"), "sort"), b.kind == J::OBJ && b.bOr("desc", false) ? 1 : 0, 0});
+         ldb_rel* r;
+         if (op == "sort") check(ldb_gpu_sort(ctx, in, specs.data(), (int32_t) specs.size(), &r), "sort");
+         else check(ldb_gpu_topk(ctx, in, specs.data(), (int32_t) specs.size(), st.at("k").inum, &r), "topk");
+         putRel(st.s("out"), r, *sides);
+      } else if (op == "materialize") { // MaterializeTableLowering: gather the listed columns
+         std::vector<const ldb_table*>* sides;
+         ldb_rel* in = relOf(st.s("in"), &sides);
+         auto cs = cols(*sides, st.at("cols"), "materialize");
+         ldb_table* t;
+         check(ldb_gpu_materialize(ctx, in, cs.data(), (int32_t) cs.size(), &t), "materialize");
+         size_t i = 0;
+         for (auto& c : st.at("cols").arr) {
+            if (c.kind == J::OBJ)
+               if (const J* as = c.get("as")) ldb_gpu_table_rename_col(t, (int32_t) i, as->str.c_str());
+            i++;
+         }
+         putTable(st.s("out"), t);
+      } else {
+         throw std::runtime_error("unknown step");
+      }
+   }
+};
+
+thread_local std::string g_plan_json_err;
+
+} // namespace
+
+// Run a JSON plan over the named input tables; *result = the table named by the plan's "result".
+extern "C" int32_t ldb_plan_run_json(ldb_ctx* ctx, const char* plan_json, const char* const* table_names, const ldb_table* const* tables, int32_t n_tables, ldb_table** result) {
+   if (!ctx || !plan_json || !result || n_tables < 0) {
+      g_plan_json_err = "plan_run_json: bad argument";
+      return LDB_ERR_INVALID;
+   }
+   try {
+      JParser parser(plan_json);
+      const J plan = parser.value();
+      Interp in(ctx);
+      in.run(plan, table_names, tables, n_tables);
+      Value& r = in.val(in.result);
+      if (r.kind != Value::TABLE || !r.owned) throw std::runtime_error("plan: result '" + in.result + "' must be a table produced by the plan");
+      *result = const_cast<ldb_table*>(r.table);
+      return LDB_OK;
+   } catch (const std::exception& e) {
+      g_plan_json_err = e.what();
+      return LDB_ERR_INVALID;
+   }
+}
+extern "C" const char* ldb_plan_json_last_error(void) { return g_plan_json_err.c_str(); }

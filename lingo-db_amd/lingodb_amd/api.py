@@ -261,6 +261,41 @@ class Rel:
         check(self.ctx.lib.ldb_gpu_scan_filter(self.ctx.h, self.h, arr, n, C.byref(r)))
         return Rel(self.ctx, r, self.deps)
 
+    def scan_filter_dnf(self, clauses):
+        """clauses: list of predicate lists; rows satisfying ANY clause (each a conjunction)"""
+        flat = [p for cl in clauses for p in cl]
+        arr, n, keep = preds_array(flat)
+        sizes = (C.c_int32 * len(clauses))(*[len(cl) for cl in clauses])
+        r = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_scan_filter_dnf(self.ctx.h, self.h, arr, sizes, len(clauses), C.byref(r)))
+        return Rel(self.ctx, r, self.deps)
+
+    def map_expr(self, prog, out_type=capi.T_INT64, p=0, s=0, name="expr"):
+        """prog: postfix list of ("col", (side, col)) | ("const", int) | ("add",) … | ("cmp", F_op) | ("mul10", k) | ("div10", k)"""
+        ops = {"add": capi.X_ADD, "sub": capi.X_SUB, "mul": capi.X_MUL, "sdiv": capi.X_SDIV, "neg": capi.X_NEG, "and": capi.X_AND, "or": capi.X_OR, "not": capi.X_NOT,
+               "select": capi.X_SELECT, "isnull": capi.X_ISNULL, "coalesce": capi.X_COALESCE}
+        arr = (capi.XInstr * len(prog))()
+        for i, ins in enumerate(prog):
+            if ins[0] == "col":
+                arr[i].op, arr[i].col = capi.X_COL, colref(*ins[1])
+            elif ins[0] == "const":
+                lo, hi = _split128(ins[1])
+                arr[i].op, arr[i].lo, arr[i].hi = capi.X_CONST, lo if lo < 1 << 63 else lo - (1 << 64), hi
+            elif ins[0] == "cmp":
+                arr[i].op, arr[i].arg = capi.X_CMP, ins[1]
+            elif ins[0] in ("mul10", "div10"):
+                arr[i].op, arr[i].arg = (capi.X_MUL_POW10 if ins[0] == "mul10" else capi.X_SDIV_POW10), ins[1]
+            else:
+                arr[i].op = ops[ins[0]]
+        t = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_map_expr(self.ctx.h, self.h, arr, len(prog), ColType(out_type, p, s, 1), name.encode(), C.byref(t)))
+        return Table(self.ctx, t)
+
+    def map_substr(self, col, start, length, name="substr"):
+        t = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_map_substr(self.ctx.h, self.h, colref(*col), start, length, name.encode(), C.byref(t)))
+        return Table(self.ctx, t)
+
     def scan_count(self, plist):
         arr, n, keep = preds_array(plist)
         c = C.c_int64()

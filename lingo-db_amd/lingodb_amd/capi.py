@@ -96,6 +96,13 @@ class JoinResidual(C.Structure):
     _fields_ = [("probe_col", ColRef), ("build_col", ColRef), ("op", C.c_int32), ("reserved", C.c_int32)]
 
 
+class XInstr(C.Structure):
+    _fields_ = [("op", C.c_int32), ("arg", C.c_int32), ("col", ColRef), ("lo", C.c_int64), ("hi", C.c_int64)]
+
+
+X_COL, X_CONST, X_ADD, X_SUB, X_MUL, X_SDIV, X_MUL_POW10, X_SDIV_POW10, X_NEG, X_CMP, X_AND, X_OR, X_NOT, X_SELECT, X_ISNULL, X_COALESCE = range(16)
+
+
 class ArrowSchema(C.Structure):
     pass
 
@@ -175,6 +182,9 @@ GPU_API = {
     "ldb_gpu_rel_read_rowids": (i32, [P, P, i32, C.POINTER(C.c_uint32), i64]),
     "ldb_gpu_materialize": (i32, [P, P, C.POINTER(ColRef), i32, PP]),
     "ldb_gpu_scan_filter": (i32, [P, P, C.POINTER(FilterDesc), i32, PP]),
+    "ldb_gpu_scan_filter_dnf": (i32, [P, P, C.POINTER(FilterDesc), C.POINTER(i32), i32, PP]),
+    "ldb_gpu_map_expr": (i32, [P, P, C.POINTER(XInstr), i32, ColType, C.c_char_p, PP]),
+    "ldb_gpu_map_substr": (i32, [P, P, ColRef, i64, i64, C.c_char_p, PP]),
     "ldb_gpu_scan_count": (i32, [P, P, C.POINTER(FilterDesc), i32, C.POINTER(i64)]),
     "ldb_gpu_hash_keys": (i32, [P, P, C.POINTER(ColRef), i32, PP]),
     "ldb_gpu_map_column": (i32, [P, P, ColRef, i32, C.c_char_p, PP]),
