@@ -174,6 +174,8 @@ int32_t ldb_gpu_table_cols(const ldb_table* t);
 int32_t ldb_gpu_table_coltype(const ldb_table* t, int32_t col, ldb_coltype* out);
 int32_t ldb_gpu_table_col_index(const ldb_table* t, const char* name); /* -1 if absent */
 const char* ldb_gpu_table_col_name(const ldb_table* t, int32_t col);
+/* rename a column (result tables: group-by names its aggregates agg0, agg1, …) */
+int32_t ldb_gpu_table_rename_col(ldb_table* t, int32_t col, const char* name);
 /* width in bytes of one value as resident on the device (8 for narrowed decimals) */
 int32_t ldb_gpu_table_col_width(const ldb_table* t, int32_t col);
 /* raw device pointers (for RCCL exchange / zero-copy wrap); offsets/validity may be NULL */

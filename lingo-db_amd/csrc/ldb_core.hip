@@ -514,6 +514,11 @@ extern "C" int32_t ldb_gpu_table_release(ldb_ctx* ctx, ldb_table* t) {
    delete t;
    return LDB_OK;
 }
+extern "C" int32_t ldb_gpu_table_rename_col(ldb_table* t, int32_t col, const char* name) {
+   if (!t || !name || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "rename_col: bad argument");
+   t->cols[(size_t) col].name = name;
+   return LDB_OK;
+}
 extern "C" int64_t ldb_gpu_table_rows(const ldb_table* t) { return t ? t->n_rows : -1; }
 extern "C" int32_t ldb_gpu_table_cols(const ldb_table* t) { return t ? (int32_t) t->cols.size() : -1; }
 extern "C" int32_t ldb_gpu_table_coltype(const ldb_table* t, int32_t col, ldb_coltype* out) {

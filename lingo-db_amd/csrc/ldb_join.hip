@@ -34,6 +34,8 @@ struct ldb_hashtable {
    int32_t ordered_slots = 0; // KEY32: slots follow the key order (DJoin::ordered_slots)
    int64_t kmin = 0, kmax = -1;
    uint64_t kmult = 0;
+   uint32_t kmult32 = 0, ksh = 0; // DJoin::slot32
+   int32_t slot32 = 0;
    uint32_t* key_bits = nullptr; // one bit per key value of [kmin, kmax] (DJoin::has_key_bits), or NULL
    int32_t chained = 0; // one slot per distinct key, rows linked through next[] (DJoin::chained)
    uint32_t* next = nullptr;
@@ -74,6 +76,7 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
       meta->counter = meta->bitmap = meta->mark = meta->match = meta->flags = 0;
       meta->kmin = meta->kmax = 0;
       meta->kmult = 0;
+      meta->kmult32 = meta->ksh = 0;
       meta->key_bits = 0;
       meta->next = 0;
       ldb_jit_strip_keys(meta->bkeys);
@@ -108,6 +111,7 @@ bool ldb_join_jit_check(std::string* log) {
    m->ordered_slots = 1;
    m->has_key_bits = 1;
    m->build_unique = 1;
+   m->slot32 = 1;
    m->bkeys.n_keys = m->pkeys.n_keys = 1;
    m->bkeys.cols[0].type = m->pkeys.cols[0].type = LDB_T_INT32;
    m->bkeys.cols[0].width = m->pkeys.cols[0].width = 4;
@@ -118,6 +122,13 @@ bool ldb_join_jit_check(std::string* log) {
       m->ppreds[p].op = p ? LDB_F_LTE : LDB_F_GTE;
       m->ppreds[p].lo = p ? 9861 : 9131;
       m->ppreds[p].same_col = p;
+   }
+   if (const char* shape = getenv("LDB_JIT_CHECK_SHAPE")) { // offline ISA inspection of other shapes
+      if (!strcmp(shape, "fk_count")) { // the FK probe micro-benchmark: no filter, key range too wide for key bits
+         m->n_ppreds = 0;
+         m->has_key_bits = 0;
+         m->has_bitmap = 0;
+      }
    }
    return ldb_jit_compile_only("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, m.get(), sizeof(DJoin), log);
 }
@@ -231,6 +242,19 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
          ht->kmin = got[0];
          ht->kmax = got[1];
          ht->kmult = (uint64_t) ((((unsigned __int128) ht->cap) << 32) / ((unsigned __int128) (got[1] - got[0]) + 1));
+         {
+            // 32-bit slot arithmetic: slot = mulhi32((key - kmin) << ksh, kmult32) with (range << ksh) in [cap, 2 cap)
+            const unsigned __int128 range128 = (unsigned __int128) ((__int128) got[1] - got[0]) + 1;
+            if (ht->cap <= (1ull << 31) && range128 <= ((unsigned __int128) 1 << 32) && got[0] >= INT32_MIN && got[1] <= INT32_MAX) {
+               uint64_t range = (uint64_t) range128;
+               uint32_t ksh = 0;
+               while ((range << ksh) < ht->cap) ksh++;
+               const unsigned __int128 km = (((unsigned __int128) ht->cap) << 32) / (unsigned __int128) (range << ksh);
+               ht->kmult32 = km > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) km;
+               ht->ksh = ksh;
+               ht->slot32 = 1;
+            }
+         }
          // one bit per key value when that fits the L2 comfortably (DJoin::has_key_bits)
          const unsigned __int128 range = (unsigned __int128) ((__int128) got[1] - got[0]) + 1;
          if (range <= ((unsigned __int128) 1 << 27)) { // <= 16 MB of bits
@@ -255,6 +279,9 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
       h->kmin = ht->kmin;
       h->kmax = ht->kmax;
       h->kmult = ht->kmult;
+      h->kmult32 = ht->kmult32;
+      h->ksh = ht->ksh;
+      h->slot32 = ht->ordered_slots ? ht->slot32 : 0;
       h->key_bits = (uint64_t) ht->key_bits;
       h->has_key_bits = ht->key_bits ? 1 : 0;
       h->chained = ht->chained;
@@ -321,6 +348,9 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    h->kmin = ht->kmin;
    h->kmax = ht->kmax;
    h->kmult = ht->kmult;
+   h->kmult32 = ht->kmult32;
+   h->ksh = ht->ksh;
+   h->slot32 = ht->ordered_slots ? ht->slot32 : 0;
    h->key_bits = (uint64_t) ht->key_bits;
    h->has_key_bits = ht->key_bits ? 1 : 0;
    h->chained = ht->chained;

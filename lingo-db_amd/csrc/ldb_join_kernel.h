@@ -29,6 +29,7 @@ struct DJoin {
    uint64_t flags; // uint32_t*: build: [0] |= 1 when two build rows carry the same key (or tag), |= 2 on a long probe run
    int64_t kmin, kmax; // KEY32 + ordered slots: range of the build keys
    uint64_t kmult; // slot = ((key - kmin) * kmult) >> 32
+   uint32_t kmult32, ksh; // slot32: slot = mulhi32((key - kmin) << ksh, kmult32) — one 32-bit multiply
    uint64_t key_bits; // uint32_t*: has_key_bits: bit (key - kmin) set ⇔ key is in the table
    uint64_t next; // uint32_t*: chained: next[row] = following row of the same key + 1 (0 = end)
    // ---- metadata
@@ -63,7 +64,9 @@ struct DJoin {
    // key match only counts when all of them hold (NULL operands fail).  The reference evaluates them
    // as the filter behind the lookup (SpecializeSubOpPass.cpp:152-205 injects map + filter).
    int32_t n_resid;
-   int32_t pad4;
+   // ordered slots computed in 32-bit arithmetic (capacity <= 2^31 and a key range below 2^32: every table
+   // of 32-bit keys up to a billion rows); 64-bit integer multiplies are four quarter-rate instructions
+   int32_t slot32;
    DJoinResid resid[LDB_MAX_RESID];
    DPred ppreds[LDB_MAX_PREDS];
 };
@@ -81,7 +84,10 @@ __device__ __forceinline__ bool d_probe_pass(const DJoin& m, const DJoin* __rest
 // position in the build key range
 #define JOIN_LONG_RUN 512
 __device__ __forceinline__ uint64_t d_join_slot(const DJoin& m, const DJoin* __restrict__ d, uint64_t h, int64_t key, uint64_t mask) {
-   if (m.key32 && m.ordered_slots) return (((uint64_t) (key - d->kmin) * d->kmult) >> 32) & mask;
+   if (m.key32 && m.ordered_slots) {
+      if (m.slot32) return (uint64_t) __umulhi(((uint32_t) key - (uint32_t) d->kmin) << d->ksh, d->kmult32);
+      return (((uint64_t) (key - d->kmin) * d->kmult) >> 32) & mask;
+   }
    // The reference indexes its chained table with `hash & mask`; under OPEN ADDRESSING the low bits
    // of db.hash are not good enough — structured keys such as (ps_partkey, ps_suppkey) produced
    // probe runs of 500+ slots in a table filled to 26 % (Q9's two-column join: 17 ms → 1 ms).  A
@@ -244,8 +250,9 @@ __device__ __forceinline__ bool d_resid_ok(const DJoin& m, const DJoin* __restri
 // chain in flight per lane and the kernel runs at memory LATENCY (600 M FK probes: 112 Grows/s,
 // 0.17 of the HBM roofline although it moves no more than the algorithmic bytes).  Here the U key
 // loads issue back to back, then the U key-bit loads, then the first TWO slots of every row (the
-// second is in the same 64 B line seven times out of eight), each load predicated on its row still
-// being alive (EXEC mask only — no wait between them); only then the rows are resolved, and
+// second is in the same 64 B line seven times out of eight; slot loads are predicated on the row
+// still being alive — their values are not needed before the resolve phase, so no wait separates
+// them — key / key-bit loads are branch-free, a dead row reads element 0); only then the rows are resolved, and
 // for unique ordered KEY32 tables almost every row resolves from its prefetched slots without
 // entering the walk loop.  EMIT(u, build_row) is called per match in the order row-major / slot
 // order and returns whether to keep scanning that row.
@@ -266,12 +273,22 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
    }
    if (m.key32) {
       const CV c = pkeys.col(0);
-      int64_t kv[U];
+      // a 4-byte integer probe column (every TPC-H foreign key) stays in 32-bit registers
+      const bool narrow = c.m.width == 4 && c.m.type != LDB_T_FLOAT32;
+      uint32_t k32[U];
       if (!c.m.rowids && !c.m.validity) {
+         // branch-free (a dead row reads row 0; callers guarantee n >= 1): a predicated load would
+         // need its value at the join point — one wait per load instead of one per batch
 #pragma unroll
          for (int u = 0; u < U; u++) {
-            kv[u] = 0;
-            if (act[u]) kv[u] = d_load_i64(c, (uint32_t) rows[u]); // (EXEC-predicated: the batch's loads still issue back to back)
+            const uint32_t row = act[u] ? (uint32_t) rows[u] : 0u;
+            if (narrow) {
+               k32[u] = (uint32_t) gptr<int32_t>(c.p.values)[row];
+            } else {
+               const int64_t kv = d_load_i64(c, row);
+               if (kv != (int64_t) (int32_t) kv) live[u] = false; // a wider probe value can equal no 32-bit build key
+               k32[u] = (uint32_t) kv;
+            }
          }
       } else {
          uint32_t pr[U];
@@ -279,40 +296,46 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
          for (int u = 0; u < U; u++) pr[u] = act[u] ? d_phys_row(c, rows[u]) : LDB_NULL_ROW;
 #pragma unroll
          for (int u = 0; u < U; u++) {
-            kv[u] = 0;
+            k32[u] = 0;
             if (act[u]) {
-               if (d_valid(c, pr[u])) kv[u] = d_load_i64(c, pr[u]);
-               else live[u] = false; // a NULL key matches nothing
+               if (d_valid(c, pr[u])) {
+                  const int64_t kv = d_load_i64(c, pr[u]);
+                  if (kv != (int64_t) (int32_t) kv) live[u] = false;
+                  k32[u] = (uint32_t) kv;
+               } else {
+                  live[u] = false; // a NULL key matches nothing
+               }
             }
          }
       }
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-         if (kv[u] != (int64_t) (int32_t) kv[u]) live[u] = false; // a wider probe value can equal no 32-bit build key
-         tag[u] = (uint64_t) (uint32_t) kv[u];
-      }
+      for (int u = 0; u < U; u++) tag[u] = (uint64_t) k32[u];
       if (m.ordered_slots) {
-         const int64_t kmin = d->kmin, kmax = d->kmax;
+         // (key - kmin) as an unsigned 32-bit offset: keys below kmin wrap to values above the span
+         const uint32_t kmin32 = (uint32_t) d->kmin, span = (uint32_t) (d->kmax - d->kmin);
+         uint32_t r[U];
 #pragma unroll
-         for (int u = 0; u < U; u++) live[u] = live[u] && kv[u] >= kmin && kv[u] <= kmax; // outside the build key range
-#ifndef JOIN_NO_KEYBITS
+         for (int u = 0; u < U; u++) {
+            r[u] = k32[u] - kmin32;
+            live[u] = live[u] && r[u] <= span; // outside the build key range
+         }
          if (m.has_key_bits) {
-#else
-         if (false) {
-#endif
             const uint32_t* bits = gptr<uint32_t>(d->key_bits);
             uint32_t bw[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-               bw[u] = 0;
-               if (live[u]) bw[u] = bits[(uint64_t) (kv[u] - kmin) >> 5];
-            }
+            for (int u = 0; u < U; u++) bw[u] = bits[live[u] ? r[u] >> 5 : 0u];
 #pragma unroll
-            for (int u = 0; u < U; u++) live[u] = live[u] && ((bw[u] >> ((uint64_t) (kv[u] - kmin) & 31)) & 1u); // not a build key
+            for (int u = 0; u < U; u++) live[u] = live[u] && ((bw[u] >> (r[u] & 31u)) & 1u); // not a build key
          }
-         const uint64_t kmult = d->kmult;
+         if (m.slot32) {
+            const uint32_t kmult32 = d->kmult32, ksh = d->ksh;
 #pragma unroll
-         for (int u = 0; u < U; u++) pos[u] = live[u] ? ((((uint64_t) (kv[u] - kmin) * kmult) >> 32) & mask) : 0;
+            for (int u = 0; u < U; u++) pos[u] = live[u] ? (uint64_t) __umulhi(r[u] << ksh, kmult32) : 0;
+         } else {
+            const uint64_t kmult = d->kmult;
+#pragma unroll
+            for (int u = 0; u < U; u++) pos[u] = live[u] ? ((((uint64_t) r[u] * kmult) >> 32) & mask) : 0;
+         }
       } else {
 #pragma unroll
          for (int u = 0; u < U; u++)
@@ -410,7 +433,7 @@ __device__ __forceinline__ void d_probe_first(const DJoin& m, const DJoin* __res
 }
 
 #ifndef JOIN_BATCH
-#define JOIN_BATCH 8 // probe rows in flight per lane
+#define JOIN_BATCH 4 // probe rows in flight per lane (8 costs more in occupancy than it gains: 3.2 vs 4.0 ms on 600 M FK probes)
 #endif
 
 // INNER / LEFT_OUTER / SINGLE with possibly duplicated build keys, two passes and no atomics on

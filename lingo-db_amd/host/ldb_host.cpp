@@ -92,6 +92,7 @@ std::unique_ptr<Restrictions> Restrictions::create(const std::vector<FilterDescr
             setInt(d, intVal);
             break;
          }
+         case LDB_T_BOOL8: // (device-side computed columns only)
          case LDB_T_INT8:
          case LDB_T_INT16:
          case LDB_T_INT32:

@@ -112,6 +112,11 @@ int32_t ldb_plan_tpch_q8_local(ldb_ctx* ctx, const ldb_table* partkeys, const ld
                                const ldb_table* nation, ldb_table** result);
 int32_t ldb_plan_tpch_q8_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
 const char* ldb_plan_last_error(void);
+// Plans as data (ldb_plan.cpp): a JSON step list — the shape of the reference's execution-step dump
+// (tools/ct/mlir-subop-to-json.cpp) at the granularity of the C-ABI — interpreted over the named
+// input tables; *result = the table the plan names as its result (caller releases).
+int32_t ldb_plan_run_json(ldb_ctx* ctx, const char* plan_json, const char* const* table_names, const ldb_table* const* tables, int32_t n_tables, ldb_table** result);
+const char* ldb_plan_json_last_error(void);
 // multi-GPU pieces: shard-local partial plans + merges of the exchanged partial tables
 int32_t ldb_plan_tpch_q1_partial(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q1_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);

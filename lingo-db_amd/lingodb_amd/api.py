@@ -572,6 +572,24 @@ class Context:
         check_plan(capi.host_lib().ldb_plan_tpch_q15(self.h, supplier.h, lineitem.h, C.byref(t)))
         return Table(self, t)
 
+    def run_plan(self, plan, tables):
+        """interprets a JSON plan (text, or the name of a file under lingo-db_amd/plans/) over {name: Table}"""
+        import os
+
+        text = plan
+        if not plan.lstrip().startswith("{"):
+            path = plan if os.path.exists(plan) else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plans", plan)
+            with open(path) as f:
+                text = f.read()
+        names = list(tables)
+        narr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        tarr = (C.c_void_p * len(names))(*[tables[n].h for n in names])
+        t = C.c_void_p()
+        st = capi.host_lib().ldb_plan_run_json(self.h, text.encode(), narr, tarr, len(names), C.byref(t))
+        if st != capi.LDB_OK:
+            raise capi.LdbError(st, capi.host_lib().ldb_plan_json_last_error().decode(errors="replace"))
+        return Table(self, t)
+
     def load_ipc(self, name, path, narrow_decimals=False):
         """registers one Arrow IPC file as a table — the reference keeps one `<table>.arrow` IPC
         file per table and reads all its record batches (LingoDBTable.cpp:27-54, loadTable)"""

@@ -168,6 +168,7 @@ GPU_API = {
     "ldb_gpu_table_coltype": (i32, [P, i32, C.POINTER(ColType)]),
     "ldb_gpu_table_col_index": (i32, [P, C.c_char_p]),
     "ldb_gpu_table_col_name": (C.c_char_p, [P, i32]),
+    "ldb_gpu_table_rename_col": (i32, [P, i32, C.c_char_p]),
     "ldb_gpu_table_col_width": (i32, [P, i32]),
     "ldb_gpu_table_col_ptrs": (i32, [P, i32, PP, PP, PP, C.POINTER(i64)]),
     "ldb_gpu_table_set_rows": (i32, [P, i64]),
@@ -244,6 +245,8 @@ HOST_API = {
     "ldb_plan_tpch_q5_local": (i32, [P, P, P, P, P, PP]),
     "ldb_plan_tpch_q5_final": (i32, [P, P, P, PP]),
     "ldb_plan_last_error": (C.c_char_p, []),
+    "ldb_plan_run_json": (i32, [P, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(P), i32, PP]),
+    "ldb_plan_json_last_error": (C.c_char_p, []),
     "ldb_plan_tpch_q1_partial": (i32, [P, P, PP]),
     "ldb_plan_tpch_q1_final": (i32, [P, P, PP]),
     "ldb_plan_tpch_q6_final": (i32, [P, P, PP]),
