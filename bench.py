@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sf", type=float, default=100.0)
-    ap.add_argument("--queries", default="1,3,4,5,6,7,8,9,11,12,14,18", help="TPC-H queries of one step (all have single- and multi-GPU plans)")
+    ap.add_argument("--queries", default="", help="TPC-H queries of one step (default: all 22 on one GPU; the 14 with multi-GPU plans when --gpus > 1)")
     ap.add_argument("--narrow-decimals", type=int, default=0)
     ap.add_argument("--cpu-sample-sf", type=float, default=1.0, help="scale of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -72,7 +72,9 @@ def main():
     import lingodb_amd as ldb
     import tpch_plans
 
-    queries = [int(q) for q in args.queries.split(",") if q]
+    ALL22 = list(range(1, 23))
+    DIST14 = [1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 18]
+    queries = [int(q) for q in args.queries.split(",") if q] or (ALL22 if world == 1 else DIST14)
     n_orders = int(round(args.sf * ORDERS_PER_SF))
     ctx = ldb.Context(local_rank)
     info = ctx.device_info()

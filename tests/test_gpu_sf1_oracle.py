@@ -1,0 +1,66 @@
+"""All 22 TPC-H plans at SF1 on the code path the SF100 bench numbers come from — kernels specialised
+at run time by hiprtc (>= 4 M rows), base-table filters fused lazily into their consumers (>= 1 M
+rows) — against the ORACLE legs (oracle/tpch_legs.py: the C restatement of the reference's CPU path
+plus numpy for what follows the first aggregation) over the same generated data.  Integer / decimal
+results bit-exact; LIMIT queries are compared on their ORDER BY keys plus membership (ties beyond
+the keys are unspecified in the reference too)."""
+import ctypes as C
+
+import pyarrow as pa
+import pytest
+
+import tpch_legs
+import tpch_plans
+from test_gpu_tpch_new import result_rows
+
+pytestmark = pytest.mark.gpu
+N_ORDERS = 1_500_000  # SF 1: 6 000 000 lineitem rows
+ALL = list(range(1, 23))
+
+
+def canon(table):
+    """GPU result rows in the legs' conventions (char(1) = int32 of its 4 bytes)"""
+    rows = result_rows(table)
+    fsb = [i for i in range(table.num_columns) if pa.types.is_fixed_size_binary(table.schema.field(i).type)]
+    if fsb:
+        rows = [tuple(int.from_bytes(v, "little", signed=True) if i in fsb else v for i, v in enumerate(r)) for r in rows]
+    return rows
+
+
+@pytest.fixture(scope="module")
+def world(ctx):
+    from lingodb_amd import capi
+
+    lib = capi.gpu_lib()
+    assert lib.ldb_gpu_get_option(b"jit_min_rows") in (-1, 4000000) and lib.ldb_gpu_get_option(b"lazy_min_rows") in (-1, 1 << 20), "this test needs the library defaults"
+    db = tpch_plans.Database(ctx, N_ORDERS, 0, 1, ALL, False)
+    runner = tpch_plans.Runner(ctx, db, 1, None, None)
+    legs = tpch_legs.Legs(N_ORDERS)
+    n0, h0, ms0 = C.c_int64(), C.c_int64(), C.c_double()
+    lib.ldb_gpu_jit_stats(C.byref(n0), C.byref(h0), C.byref(ms0))
+    yield runner, legs
+    n1, h1, ms1 = C.c_int64(), C.c_int64(), C.c_double()
+    lib.ldb_gpu_jit_stats(C.byref(n1), C.byref(h1), C.byref(ms1))
+    assert n1.value + h1.value > n0.value + h0.value + 20, "the SF1 plans did not run on specialised kernels"
+
+
+LIMITS = {3: (10, lambda r: (-r[1], r[2])), 10: (20, lambda r: -r[2]), 18: (100, lambda r: (-r[4], r[3]))}
+
+
+@pytest.mark.parametrize("q", ALL)
+def test_plan_matches_oracle(world, q):
+    runner, legs = world
+    got = canon(runner.run(q).to_arrow())
+    want = legs.run(q)
+    assert want, "empty oracle result: the check would be vacuous"
+    if q in LIMITS:
+        k, key = LIMITS[q]
+        assert len(got) == min(k, len(want))
+        assert [key(r) for r in got] == [key(r) for r in want[: len(got)]]
+        assert set(got) <= set(want) or q == 10  # the Q10 leg lists only the 64 best customers
+        if q == 10:
+            assert set(got) <= set(want)
+    elif q in (5, 11):  # ORDER BY one aggregate: equal values may swap
+        assert [r[1] for r in got] == [r[1] for r in want] and sorted(got) == sorted(want)
+    else:
+        assert got == want

@@ -1,42 +1,17 @@
 """TPC-H Q2 / Q13 / Q16 / Q17 / Q19 / Q20 / Q21 / Q22 as JSON plans (lingo-db_amd/plans/tpch/*.json →
 libldb_host.so's plan interpreter → C-ABI → HIP kernels) against an independent evaluation of the
 SQL text (resources/sql/tpch/*.sql of the reference) with pandas / Python integers over the same
-generated tables.  Decimals are compared as unscaled integers: bit-exact.
+generated tables (tests/tpch_sql.py).  Decimals are compared as unscaled integers: bit-exact.
 Runs twice (conftest kernel_mode): library defaults, then every kernel run-time specialised and every
 base-table filter fused lazily into its consumer."""
-import datetime
-
-import numpy as np
-import pandas as pd
 import pyarrow as pa
 import pytest
 
 import tpch_data as T
+import tpch_sql
 
 pytestmark = pytest.mark.gpu
-EPOCH = datetime.date(1970, 1, 1)
 N = 300_000  # SF 0.2
-
-
-def days(s):
-    return (datetime.date.fromisoformat(s) - EPOCH).days
-
-
-def frame(table):
-    """pyarrow table → pandas with decimals as unscaled int64, dates as day numbers, char(1) as str"""
-    cols = {}
-    for name in table.column_names:
-        col = table.column(name).combine_chunks()
-        t = col.type
-        if pa.types.is_decimal(t):
-            cols[name] = np.frombuffer(col.buffers()[1], dtype=np.int64)[::2][col.offset : col.offset + len(col)].copy()
-        elif pa.types.is_date32(t) or pa.types.is_int32(t):
-            cols[name] = np.frombuffer(col.buffers()[1], dtype=np.int32)[col.offset : col.offset + len(col)].astype(np.int64)
-        elif pa.types.is_fixed_size_binary(t):
-            cols[name] = [v.as_py().rstrip(b"\0").decode() for v in col]
-        else:
-            cols[name] = col.to_pylist()
-    return pd.DataFrame(cols)
 
 
 def result_rows(table):
@@ -47,186 +22,53 @@ def result_rows(table):
         if pa.types.is_decimal(t):
             out.append([None if v.as_py() is None else int(v.as_py().scaleb(t.scale)) for v in col])
         elif pa.types.is_date32(t):
-            out.append([(v.as_py() - EPOCH).days for v in col])
+            out.append([(v.as_py() - tpch_sql.EPOCH).days for v in col])
         else:
             out.append(col.to_pylist())
     return list(zip(*out)) if out else []
 
 
-class DB:
-    def __init__(self, ctx):
-        self.ctx = ctx
-        self.host, self.dev, self.df = {}, {}, {}
-
-    def get(self, name, table_id, cols):
-        key = (name, tuple(cols))
-        if key not in self.host:
-            self.host[key] = T.host_table(table_id, N, cols=cols)
-            self.dev[key] = self.ctx.register(name, self.host[key])
-            self.df[key] = frame(self.host[key])
-        return self.dev[key], self.df[key]
+@pytest.fixture(scope="module")
+def host():
+    return tpch_sql.Tables(N)
 
 
 @pytest.fixture(scope="module")
-def db(ctx):
-    return DB(ctx)
+def dev(ctx, host):
+    cache = {}
+
+    def get(q):
+        tabs = {}
+        for name, (tid, cols) in tpch_sql.INPUTS[q].items():
+            key = (tid, tuple(cols))
+            if key not in cache:
+                cache[key] = ctx.register(name, host.arrow(tid, cols))
+            tabs[name] = cache[key]
+        return tabs
+
+    return get
 
 
-def like(series, *fragments, prefix=False, suffix=False):
-    """SQL LIKE with %-separated literal fragments"""
-    import re
-
-    pat = ("" if prefix else ".*") + ".*".join(re.escape(f) for f in fragments) + ("" if suffix else ".*")
-    rx = re.compile("^" + pat + "$", re.S)
-    return series.map(lambda s: rx.match(s) is not None)
+MIN_ROWS = {2: 50, 13: 10, 16: 1000, 17: 1, 19: 1, 20: 3, 21: 20, 22: 7}
 
 
-def test_q19(ctx, db):
-    gli, li = db.get("lineitem", T.LINEITEM, [1, 4, 5, 6, 13, 14])
-    gpa, pa_ = db.get("part", T.PART, [0, 1, 5, 6])
-    j = li.merge(pa_, left_on="l_partkey", right_on="p_partkey")
-    common = j.l_shipmode.isin(["AIR", "AIR REG"]) & (j.l_shipinstruct == "DELIVER IN PERSON")
-    c1 = (j.p_brand == "Brand#12") & j.p_container.isin(["SM CASE", "SM BOX", "SM PACK", "SM PKG"]) & (j.l_quantity >= 100) & (j.l_quantity <= 1100) & j.p_size.between(1, 5)
-    c2 = (j.p_brand == "Brand#23") & j.p_container.isin(["MED BAG", "MED BOX", "MED PKG", "MED PACK"]) & (j.l_quantity >= 1000) & (j.l_quantity <= 2000) & j.p_size.between(1, 10)
-    c3 = (j.p_brand == "Brand#34") & j.p_container.isin(["LG CASE", "LG BOX", "LG PACK", "LG PKG"]) & (j.l_quantity >= 2000) & (j.l_quantity <= 3000) & j.p_size.between(1, 15)
-    sel = j[common & (c1 | c2 | c3)]
-    assert len(sel) > 3
-    want = int((sel.l_extendedprice * (100 - sel.l_discount)).sum())
-    got = ctx.run_plan("tpch/q19.json", {"lineitem": gli, "part": gpa}).to_arrow()
-    assert got.schema.field(0).type == pa.decimal128(33, 4)
-    assert result_rows(got) == [(want,)]
-
-
-def test_q22(ctx, db):
-    gcu, cu = db.get("customer", T.CUSTOMER, [0, 2, 5])
-    god, od = db.get("orders", T.ORDERS, [0, 1])
-    cu = cu.assign(cntrycode=cu.c_phone.str[:2])
-    c2 = cu[cu.cntrycode.isin(["13", "31", "23", "29", "30", "18", "17"])]
-    pos = c2[c2.c_acctbal > 0]
-    avg = (int(pos.c_acctbal.sum()) * 10**19) // len(pos)  # decimal(31,21): (sum * 10^19) sdiv count
-    c4 = c2[c2.c_acctbal.map(lambda v: int(v) * 10**19 > avg)]
-    c5 = c4[~c4.c_custkey.isin(set(od.o_custkey.tolist()))]
-    g = c5.groupby("cntrycode").agg(numcust=("c_custkey", "size"), tot=("c_acctbal", "sum")).reset_index().sort_values("cntrycode")
-    want = [(r.cntrycode, int(r.numcust), int(r.tot)) for r in g.itertuples()]
-    assert len(want) == 7
-    got = ctx.run_plan("tpch/q22.json", {"customer": gcu, "orders": god}).to_arrow()
+@pytest.mark.parametrize("q", sorted(tpch_sql.SQL))
+def test_query(ctx, host, dev, q):
+    want = tpch_sql.evaluate(q, host)
+    assert len(want) >= MIN_ROWS[q] and want[0][0] is not None
+    got = ctx.run_plan("tpch/q%d.json" % q, dev(q)).to_arrow()
+    if q == 19:
+        assert got.schema.field(0).type == pa.decimal128(33, 4)
+    if q == 17:
+        assert got.schema.field(0).type == pa.decimal128(17, 6)
     assert result_rows(got) == want
 
 
-def test_q13(ctx, db):
-    gcu, cu = db.get("customer", T.CUSTOMER, [0])
-    god, od = db.get("orders", T.ORDERS, [0, 1, 7])
-    keep = od[~like(od.o_comment, "special", "requests")]
-    assert 0.9 < len(keep) / len(od) < 0.999
-    cnt = keep.groupby("o_custkey").size()
-    c_count = cu.c_custkey.map(cnt).fillna(0).astype(np.int64)
-    g = c_count.value_counts()
-    want = sorted(((int(c), int(n)) for c, n in g.items()), key=lambda r: (-r[1], -r[0]))
-    assert want[0][0] == 0 or any(c == 0 for c, _ in want)  # a third of the customers never order
-    got = ctx.run_plan("tpch/q13.json", {"customer": gcu, "orders": god}).to_arrow()
-    assert result_rows(got) == want
-
-
-def test_q16(ctx, db):
-    gpa, pa_ = db.get("part", T.PART, [0, 1, 4, 5])
-    gps, ps = db.get("partsupp", T.PARTSUPP, [0, 1])
-    gsu, su = db.get("supplier", T.SUPPLIER, [0, 6])
-    bad = set(su[like(su.s_comment, "Customer", "Complaints")].s_suppkey.tolist())
-    assert len(bad) >= 1
-    p1 = pa_[(pa_.p_brand != "Brand#45") & ~pa_.p_type.str.startswith("MEDIUM POLISHED") & pa_.p_size.isin([49, 14, 23, 45, 19, 3, 36, 9])]
-    j = ps.merge(p1, left_on="ps_partkey", right_on="p_partkey")
-    j = j[~j.ps_suppkey.isin(bad)]
-    g = j.groupby(["p_brand", "p_type", "p_size"]).ps_suppkey.nunique().reset_index(name="cnt")
-    want = sorted(((r.p_brand, r.p_type, int(r.p_size), int(r.cnt)) for r in g.itertuples()), key=lambda r: (-r[3], r[0], r[1], r[2]))
-    assert len(want) > 1000
-    got = ctx.run_plan("tpch/q16.json", {"part": gpa, "partsupp": gps, "supplier": gsu}).to_arrow()
-    assert result_rows(got) == want
-
-
-def test_q17(ctx, db):
-    gli, li = db.get("lineitem", T.LINEITEM, [1, 4, 5, 6, 13, 14])
-    gpa, pa_ = db.get("part", T.PART, [0, 1, 5, 6])
-    keys = set(pa_[(pa_.p_brand == "Brand#23") & (pa_.p_container == "MED BOX")].p_partkey.tolist())
-    l1 = li[li.l_partkey.isin(keys)]
-    stats = l1.groupby("l_partkey").l_quantity.agg(["sum", "size"])
-    avg21 = {k: (int(r["sum"]) * 10**19) // int(r["size"]) for k, r in stats.iterrows()}  # avg(l_quantity): decimal(31,21)
-    # l_quantity < 0.2 * avg: 0.2 is decimal(2,1), the product decimal(33,22); l_quantity is cast to it (x 10^20)
-    small = l1[[int(q) * 10**20 < 2 * avg21[k] for q, k in zip(l1.l_quantity, l1.l_partkey)]]
-    assert len(small) > 5
-    want = (int(small.l_extendedprice.sum()) * 10**5) // 70  # sum / 7.0 → decimal(17,6)
-    got = ctx.run_plan("tpch/q17.json", {"lineitem": gli, "part": gpa}).to_arrow()
-    assert got.schema.field(0).type == pa.decimal128(17, 6)
-    assert result_rows(got) == [(want,)]
-
-
-def test_q20(ctx, db):
-    gli, li = db.get("lineitem20", T.LINEITEM, [1, 2, 4, 10])
-    gpa, pa_ = db.get("part20", T.PART, [0, 3])
-    gps, ps = db.get("partsupp20", T.PARTSUPP, [0, 1, 2])
-    gsu, su = db.get("supplier20", T.SUPPLIER, [0, 1, 3, 4])
-    gna, na = db.get("nation", T.NATION, [0, 1, 2])
-    forest = set(pa_[pa_.p_name.str.startswith("forest")].p_partkey.tolist())
-    l1 = li[(li.l_shipdate >= days("1994-01-01")) & (li.l_shipdate < days("1995-01-01")) & li.l_partkey.isin(forest)]
-    qty = l1.groupby(["l_partkey", "l_suppkey"]).l_quantity.sum().to_dict()
-    ps1 = ps[ps.ps_partkey.isin(forest)]
-    ok = [sk for pk, sk, av in zip(ps1.ps_partkey, ps1.ps_suppkey, ps1.ps_availqty) if (pk, sk) in qty and int(av) * 1000 > 5 * int(qty[(pk, sk)])]
-    canada = set(na[na.n_name == "CANADA"].n_nationkey.tolist())
-    s = su[su.s_nationkey.isin(canada) & su.s_suppkey.isin(set(ok))].sort_values("s_name")
-    want = [(r.s_name, r.s_address) for r in s.itertuples()]
-    assert len(want) >= 3
-    got = ctx.run_plan("tpch/q20.json", {"lineitem": gli, "part": gpa, "partsupp": gps, "supplier": gsu, "nation": gna}).to_arrow()
-    assert result_rows(got) == want
-
-
-def test_q21(ctx, db):
-    gli, li = db.get("lineitem21", T.LINEITEM, [0, 2, 11, 12])
-    god, od = db.get("orders21", T.ORDERS, [0, 2])
-    gsu, su = db.get("supplier20", T.SUPPLIER, [0, 1, 3, 4])
-    gna, na = db.get("nation", T.NATION, [0, 1, 2])
-    saudi = set(na[na.n_name == "SAUDI ARABIA"].n_nationkey.tolist())
-    sname = {k: n for k, n, nk in zip(su.s_suppkey, su.s_name, su.s_nationkey) if nk in saudi}
-    forders = set(od[od.o_orderstatus == "F"].o_orderkey.tolist())
-    by_order_all, by_order_late = {}, {}
-    late = li.l_receiptdate > li.l_commitdate
-    for ok, sk, lt in zip(li.l_orderkey.tolist(), li.l_suppkey.tolist(), late.tolist()):
-        by_order_all.setdefault(ok, set()).add(sk)
-        if lt:
-            by_order_late.setdefault(ok, set()).add(sk)
-    cnt = {}
-    for ok, sk, lt in zip(li.l_orderkey.tolist(), li.l_suppkey.tolist(), late.tolist()):
-        if lt and sk in sname and ok in forders and len(by_order_all[ok] - {sk}) > 0 and len(by_order_late[ok] - {sk}) == 0:
-            cnt[sname[sk]] = cnt.get(sname[sk], 0) + 1
-    want = sorted(cnt.items(), key=lambda r: (-r[1], r[0]))[:100]
-    assert len(want) >= 20
-    got = ctx.run_plan("tpch/q21.json", {"lineitem": gli, "orders": god, "supplier": gsu, "nation": gna}).to_arrow()
-    assert result_rows(got) == want
-
-
-def test_q2(ctx, db):
-    gpa, pa_ = db.get("part2", T.PART, [0, 1, 4, 7])
-    gps, ps = db.get("partsupp2", T.PARTSUPP, [0, 1, 3])
-    gsu, su = db.get("supplier2", T.SUPPLIER, [0, 1, 2, 3, 4, 5, 6])
-    gna, na = db.get("nation", T.NATION, [0, 1, 2])
-    gre, re_ = db.get("region", T.REGION, [0, 1])
-    eur = set(re_[re_.r_name == "EUROPE"].r_regionkey.tolist())
-    n1 = na[na.n_regionkey.isin(eur)]
-    sn = su.merge(n1, left_on="s_nationkey", right_on="n_nationkey")
-    p1 = pa_[(pa_.p_size == 15) & pa_.p_type.str.endswith("BRASS")]
-    allj = ps.merge(p1, left_on="ps_partkey", right_on="p_partkey").merge(sn, left_on="ps_suppkey", right_on="s_suppkey")
-    mins = allj.groupby("ps_partkey").ps_supplycost.transform("min")
-    best = allj[allj.ps_supplycost == mins]
-    rows = [(int(r.s_acctbal), r.s_name, r.n_name, int(r.p_partkey), r.p_mfgr, r.s_address, r.s_phone, r.s_comment) for r in best.itertuples()]
-    want = sorted(rows, key=lambda r: (-r[0], r[2], r[1], r[3]))[:100]
-    assert len(want) >= 50
-    got = ctx.run_plan("tpch/q2.json", {"part": gpa, "supplier": gsu, "partsupp": gps, "nation": gna, "region": gre}).to_arrow()
-    assert result_rows(got) == want
-
-
-def test_plan_errors_are_reported(ctx, db):
+def test_plan_errors_are_reported(ctx, dev):
     """unknown columns / operators come back as an error string, never as a crash"""
     from lingodb_amd import capi
 
-    gna, _ = db.get("nation", T.NATION, [0, 1, 2])
+    gna = dev(20)["nation"]
     for bad in ('{"steps": [{"op": "filter", "in": "nation", "out": "x", "preds": [{"col": "nope", "op": "EQ", "value": 1}]}], "result": "x"}',
                 '{"steps": [{"op": "frobnicate", "out": "x"}], "result": "x"}', '{"steps": [', '{"steps": [], "result": "nation"}'):
         with pytest.raises(capi.LdbError):

@@ -17,6 +17,11 @@ O_ORDERKEY, O_CUSTKEY, O_TOTALPRICE, O_ORDERDATE, O_ORDERPRIORITY, O_SHIPPRIORIT
 C_CUSTKEY, C_MKTSEGMENT, C_NAME = 0, 3, 4
 
 
+# plans that are data (lingo-db_amd/plans/tpch/qN.json, interpreted by libldb_host.so) and the tables they read
+JSON_PLANS = {2: ["part", "supplier", "partsupp", "nation", "region"], 13: ["customer", "orders"], 16: ["part", "partsupp", "supplier"], 17: ["lineitem", "part"],
+              19: ["lineitem", "part"], 20: ["lineitem", "part", "partsupp", "supplier", "nation"], 21: ["lineitem", "orders", "supplier", "nation"], 22: ["customer", "orders"]}
+
+
 class Database:
     """Slice rank/world of the SF database, generated straight into HBM (only the columns the
     selected queries touch — the reference likewise scans only referenced columns)."""
@@ -48,6 +53,14 @@ class Database:
             lcols |= {1, L_EXTENDEDPRICE, L_DISCOUNT, L_SHIPDATE}  # + l_partkey
         if 8 in queries:
             lcols |= {L_ORDERKEY, 1, 2, L_EXTENDEDPRICE, L_DISCOUNT}  # + l_partkey, l_suppkey
+        if 17 in queries:
+            lcols |= {1, L_QUANTITY, L_EXTENDEDPRICE}
+        if 19 in queries:
+            lcols |= {1, L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, 13, L_SHIPMODE}  # + l_partkey, l_shipinstruct
+        if 20 in queries:
+            lcols |= {1, 2, L_QUANTITY, L_SHIPDATE}
+        if 21 in queries:
+            lcols |= {L_ORDERKEY, 2, L_COMMITDATE, L_RECEIPTDATE}
         lcols |= {L_EXTENDEDPRICE, L_SHIPDATE}  # hbm_ceiling() calibration scans
         self.lineitem = ctx.tpch_generate(LINEITEM, n_orders, rank, world, sorted(lcols), narrow)
         self.orders = self.customer = None
@@ -65,13 +78,33 @@ class Database:
         if 10 in queries:
             ocols |= {O_ORDERKEY, O_CUSTKEY, O_ORDERDATE}
             ccols |= {C_CUSTKEY, 1, 2, C_NAME}  # + c_nationkey, c_acctbal
+        if 13 in queries:
+            ocols |= {O_CUSTKEY, 7}  # + o_comment
+            ccols |= {C_CUSTKEY}
+        if 21 in queries:
+            ocols |= {O_ORDERKEY, 2}  # + o_orderstatus
+        if 22 in queries:
+            ocols |= {O_CUSTKEY}
+            ccols |= {C_CUSTKEY, 2, 5}  # + c_acctbal, c_phone
         self.part = self.supplier = self.partsupp = self.nation = self.region = None
         if 9 in queries:
             ocols |= {O_ORDERKEY, O_ORDERDATE}
+        pcols = set()
         if any(q in queries for q in (8, 9, 14)):  # p_partkey, [p_name,] [p_type]
-            self.part = ctx.tpch_generate(PART, n_orders, rank, world, [0] + ([3] if 9 in queries else []) + ([4] if 14 in queries or 8 in queries else []), narrow)
+            pcols |= {0} | ({3} if 9 in queries else set()) | ({4} if 14 in queries or 8 in queries else set())
+        for q, cs in ((2, {0, 1, 4, 7}), (16, {0, 1, 4, 5}), (17, {0, 5, 6}), (19, {0, 1, 5, 6}), (20, {0, 3})):
+            if q in queries:
+                pcols |= cs
+        if pcols:
+            self.part = ctx.tpch_generate(PART, n_orders, rank, world, sorted(pcols), narrow)
+        pscols = set()
         if 9 in queries or 11 in queries:  # ps_partkey, ps_suppkey, [ps_availqty,] ps_supplycost
-            self.partsupp = ctx.tpch_generate(PARTSUPP, n_orders, rank, world, [0, 1, 2, 3] if 11 in queries else [0, 1, 3], narrow)
+            pscols |= {0, 1, 2, 3} if 11 in queries else {0, 1, 3}
+        for q, cs in ((2, {0, 1, 3}), (16, {0, 1}), (20, {0, 1, 2})):
+            if q in queries:
+                pscols |= cs
+        if pscols:
+            self.partsupp = ctx.tpch_generate(PARTSUPP, n_orders, rank, world, sorted(pscols), narrow)
         if 5 in queries or 8 in queries:
             ocols |= {O_ORDERKEY, O_CUSTKEY, O_ORDERDATE}
             ccols |= {C_CUSTKEY, 1}  # + c_nationkey
@@ -86,6 +119,16 @@ class Database:
         if any(q in queries for q in (5, 7, 8, 9, 11)):
             self.supplier = ctx.tpch_generate(SUPPLIER, n_orders, rank, world, [0, 1], narrow)  # s_suppkey, s_nationkey
             self.nation = ctx.tpch_generate(NATION, n_orders, rank, world, [0, 1, 2], narrow)  # n_nationkey, n_regionkey, n_name
+        scols = set()
+        for q, cs in ((2, {0, 1, 2, 3, 4, 5, 6}), (16, {0, 6}), (20, {0, 1, 3, 4}), (21, {0, 1, 3})):
+            if q in queries:
+                scols |= cs
+        if scols:  # the wider supplier table of the queries that show supplier strings (s_name, s_address, …)
+            self.supplier_full = ctx.tpch_generate(SUPPLIER, n_orders, rank, world, sorted(scols | {0, 1}), narrow)
+            if self.nation is None:
+                self.nation = ctx.tpch_generate(NATION, n_orders, rank, world, [0, 1, 2], narrow)
+        if 2 in queries and self.region is None:
+            self.region = ctx.tpch_generate(7, n_orders, rank, world, [0, 1], narrow)
         if ocols:
             self.orders = ctx.tpch_generate(ORDERS, n_orders, rank, world, sorted(ocols), narrow)
         if ccols:
@@ -130,12 +173,25 @@ class Runner:
             res = self.ctx.plan_q8(self.db.part, self.db.supplier, self.db.lineitem, self.db.orders, self.db.customer, self.db.nation, self.db.region)
         elif q == 11:
             res = self.ctx.plan_q11(self.db.partsupp, self.db.supplier, self.db.nation)
+        elif q in JSON_PLANS:
+            db = self.db
+            avail = {"lineitem": db.lineitem, "orders": db.orders, "customer": db.customer, "part": db.part, "partsupp": db.partsupp,
+                     "supplier": getattr(db, "supplier_full", None) or db.supplier, "nation": db.nation, "region": db.region}
+            res = self.ctx.run_plan(self.plan_text(q), {n: avail[n] for n in JSON_PLANS[q]})
         elif q == 9:
             res = self.ctx.plan_q9(self.db.part, self.db.supplier, self.db.lineitem, self.db.partsupp, self.db.orders, self.db.nation)
         else:
             raise ValueError(f"TPC-H Q{q} has no plan yet")
         self.last[q] = res
         return res
+
+    def plan_text(self, q):
+        if not hasattr(self, "plans"):
+            self.plans = {}
+        if q not in self.plans:
+            with open(os.path.join(ROOT, "lingo-db_amd", "plans", "tpch", "q%d.json" % q)) as f:
+                self.plans[q] = f.read()
+        return self.plans[q]
 
     def probe_microbench(self, reps=3):
         """FK probe of l_orderkey into a table built on o_orderkey (100 % match), SURVEY §8(d)."""
