@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--queries", default="", help="TPC-H queries of one step (default: all 22 on one GPU; the 14 with multi-GPU plans when --gpus > 1)")
     ap.add_argument("--narrow-decimals", type=int, default=0)
     ap.add_argument("--cpu-sample-sf", type=float, default=1.0, help="scale of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-runs", default="1+3", help="CPU baseline protocol warm-up+measured (the reference's benchmark.py uses 3+10)")
     args = ap.parse_args()
 
     import torch
@@ -96,6 +97,8 @@ def main():
             runner.run(q).to_arrow()
     timers = {q: ctx.timer() for q in queries}
     q_ms = {q: 0.0 for q in queries}
+    q_runs = {q: [] for q in queries}
+    results = {}
     kernel_ms = {}  # (query, kernel) -> [launches, ms]
     ctx.prof_reset()
     barrier()
@@ -103,9 +106,10 @@ def main():
     for _ in range(args.steps):
         for q in queries:
             ctx.timer_start(timers[q])
-            runner.run(q).to_arrow()
+            results[q] = runner.run(q).to_arrow()
             ctx.timer_stop(timers[q])
-            q_ms[q] += ctx.timer_ms(timers[q])
+            q_runs[q].append(ctx.timer_ms(timers[q]))
+            q_ms[q] += q_runs[q][-1]
             for k, (n, ms) in ctx.prof_all().items():
                 e = kernel_ms.setdefault((q, k), [0, 0.0])
                 e[0] += n
@@ -142,16 +146,26 @@ def main():
                         "bytes_per_row": bpr}
         extras = {}
         if 6 in queries:
-            # the scan headline of SURVEY §8(d): Q6-shape filter + sum.  Algorithmic bytes = full
-            # filter columns (shipdate 4 + discount 16 + quantity 16) + 16 per row passing the date
-            # range (~15 %); the kernel reads less than that (conjunct columns only for surviving
-            # rows: PMC traffic in profiles/r01_pmc_q6_sf100.json), so the figure can exceed the HBM peak.
+            # the scan headline of SURVEY §8(d): Q6-shape filter + sum.  The kernel reads its conjunct
+            # columns only for rows that survived the earlier conjuncts, so the HBM bytes it moves are
+            # BELOW the full-column figure (shipdate 4 + discount 16 + quantity 16 B/row); the roofline
+            # fraction therefore uses the bytes the PMC pass measured for this kernel, when a summary of
+            # the matching configuration is committed, and the 4-byte first-conjunct column otherwise.
             n6, ms6 = kernel_ms.get((6, "k_groupby"), [0, 0.0])
             if n6:
-                wd = 8 if args.narrow_decimals else 16
-                q6_bytes = rows_local * (4 + 2 * wd) + 0.152 * rows_local * wd
-                extras["scan_q6"] = {"kernel_ms": round(ms6 / n6, 4), "algorithmic_gbs": round(q6_bytes / (ms6 / n6 * 1e-3) / 1e9, 1),
-                                     "rows_per_s_G": round(rows_local / (ms6 / n6 * 1e-3) / 1e9, 1)}
+                t6 = ms6 / n6 * 1e-3
+                extras["scan_q6"] = {"kernel_ms": round(ms6 / n6, 4), "rows_per_s_G": round(rows_local / t6 / 1e9, 1)}
+                pmc6 = os.path.join(ROOT, "profiles", "r02_pmc_q6_sf%g.json" % args.sf)
+                if not os.path.exists(pmc6):
+                    pmc6 = os.path.join(ROOT, "profiles", "r01_pmc_q6_sf%g.json" % args.sf)
+                if world == 1 and os.path.exists(pmc6):
+                    with open(pmc6) as f:
+                        k6 = json.load(f)["kernels"]
+                    k6 = k6.get("k_groupby_spec") or k6.get("k_groupby")
+                    if k6:
+                        gbs = k6["fetch_bytes"] / t6 / 1e9
+                        extras["scan_q6"].update({"hbm_gbs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": round(k6["fetch_bytes"]),
+                                                  "traffic_source": os.path.relpath(pmc6, ROOT)})
         if 3 in queries:
             n_p, ms_p = kernel_ms.get((3, "k_join_probe_pairs"), [0, 0.0])
             if n_p:
@@ -162,7 +176,9 @@ def main():
             # runs of this same command; tools/pmc_summary.py calibrates the gfx950 FETCH_SIZE unit on a
             # kernel of known byte count).  Counters cannot be read from inside the timed process, so the
             # committed summary of the matching configuration is quoted; null when there is none.
-            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_q%d_sf%g%s.json" % (roof_q, args.sf, "_narrow" if args.narrow_decimals else ""))
+            pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_q%d_sf%g%s.json" % (roof_q, args.sf, "_narrow" if args.narrow_decimals else ""))
+            if not os.path.exists(pmc_path):
+                pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_q%d_sf%g%s.json" % (roof_q, args.sf, "_narrow" if args.narrow_decimals else ""))
             if world == 1 and os.path.exists(pmc_path):
                 with open(pmc_path) as f:
                     pmc = json.load(f)
@@ -172,9 +188,37 @@ def main():
                     roofline["traffic_source"] = os.path.relpath(pmc_path, ROOT)
         probe = runner.probe_microbench() if any(q in queries for q in (3, 4, 18)) else None  # needs o_orderkey, o_orderdate, l_orderkey
         ceiling = runner.hbm_ceiling()
+        # further kernels against the same HBM roofline (algorithmic bytes per SURVEY §8(d))
+        more = []
+        if probe and "probe_ms" in probe:
+            for name, sub in (("FK probe, clustered keys (l_orderkey → o_orderkey, 100 % match)", probe), ("FK probe, unclustered keys (random order keys, 100 % match)", probe.get("unclustered")),
+                              ("FK probe, radix-partitioned (unclustered keys)", probe.get("unclustered_radix"))):
+                if sub and "probe_ms" in sub:
+                    gbs = sub["probe_rows"] * 12 / (sub["probe_ms"] * 1e-3) / 1e9
+                    more.append({"kernel": "k_join_probe_count: " + name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                 "bytes_per_row": 12, "grows_per_s": sub["probe_grows_per_s"], "avg_kernel_ms": sub["probe_ms"]})
+        n18, ms18 = kernel_ms.get((18, "k_groupby"), [0, 0.0])
+        if n18:
+            wd = 8 if args.narrow_decimals else 16
+            b18 = rows_local * (4 + wd) + (db.orders.rows if db.orders else 0) * 32 * 2  # rows x (key + agg input) + groups x entry x 2
+            gbs = b18 / (ms18 / n18 * 1e-3) / 1e9
+            more.append({"kernel": "k_groupby (TPC-H Q18: 600 M rows → 150 M groups)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes_per_launch": b18, "avg_kernel_ms": round(ms18 / n18, 4)})
+        # result checksums (one per query, of the rows handed to the host) + conservation laws that tie the
+        # SF100 results to an independent kernel path: the oracle cannot run at this size in seconds
+        import zlib
+
+        checks = {"checksum": {"Q%d" % q: "%08x" % (zlib.crc32(repr(results[q].to_pylist()).encode()) & 0xFFFFFFFF) for q in queries if q in results}}
+        if world == 1 and 1 in results:
+            from lingodb_amd import api, capi
+
+            n_pass = db.lineitem.rel().scan_count([api.pred((0, db.lineitem.col("l_shipdate")), capi.F_LTE, 10471)])
+            checks["q1_count_conservation"] = bool(sum(results[1].column(9).to_pylist()) == n_pass)  # Σ count(*) over groups == rows passing the filter (scan kernel)
+        if world == 1 and 6 in results and 1 in results:
+            checks["q6_rows"] = results[6].num_rows == 1
         cpu = None
         if world == 1 and args.cpu_sample_sf > 0:
-            cpu = tpch_plans.cpu_baseline(queries, args.cpu_sample_sf)
+            cpu = tpch_plans.cpu_baseline(queries, args.cpu_sample_sf, args.cpu_runs)
         out = {
             "metric": "tpch_sf%g_geomean_ms" % args.sf,
             "value": round(geomean([per_query[q] for q in queries]), 4),
@@ -192,6 +236,11 @@ def main():
                 args.sf, "+".join("Q%d" % q for q in queries), world), "queries": queries, "rows_lineitem_total": int(db.n_lineitem_total),
                 "narrow_decimals": bool(args.narrow_decimals), "device": info["name"]},
             "per_query_ms": {"Q%d" % q: round(v, 4) for q, v in per_query.items()},
+            "per_query_median_ms": {"Q%d" % q: round(sorted(q_runs[q])[len(q_runs[q]) // 2], 4) for q in queries},
+            "per_query_min_ms": {"Q%d" % q: round(min(q_runs[q]), 4) for q in queries},
+            "kernel_share": round(sum(v[1] for v in kernel_ms.values()) / max(sum(q_ms.values()), 1e-9), 4),
+            "roofline_more": more,
+            "checks": checks,
             "kernel_ms_per_step": {"Q%d:%s" % (q, k): round(v[1] / args.steps, 4) for (q, k), v in sorted(kernel_ms.items())},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -181,6 +181,191 @@ static int32_t debug_check_ids(ldb_ctx* ctx, const char* what, const uint32_t* i
    return LDB_OK;
 }
 
+
+// ---------------------------------------------------------------- radix clustering of the probe side
+// An ordered KEY32 table is walked almost sequentially by a probe side that is clustered on the key
+// (lineitem → orders).  An UNCLUSTERED probe side (random keys into a multi-GB slot array) pays one
+// random DRAM access per row: 600 M probes into a 4.3 GB table run at 33 Grows/s against 190 for
+// clustered keys.  The radix path first partitions the probe rows by SLOT RANGE — partition p holds
+// the rows whose slot falls into [p, p + 1) * cap / P, P chosen so that one range is ~1 MB — with a
+// histogram pass and a scatter pass (workgroup-private LDS cursors, (key, row) tuples written to
+// contiguous per-(workgroup, partition) runs), and then probes the partitioned keys: every
+// partition's slot range stays resident in the L2 / Infinity Cache while its rows are processed,
+// and the ordinary probe kernels run on a dense key column again.  The reference has no
+// counterpart (its chained table takes the cache misses, LazyJoinHashtable.cpp:12-34); this is the
+// radix-partitioned join of the north star with the partitions held in cache instead of LDS.
+#define RX_BLOCK 256
+#define RX_MAX_PARTS 4096
+struct DRadix {
+   uint64_t n;
+   uint64_t values; // probe key column (4-byte integers)
+   uint64_t rowids; // its relation side's row ids or 0
+   int64_t kmin, kmax;
+   uint64_t kmult, mask;
+   uint32_t kmult32, ksh, slot32, pshift, nparts, grid;
+   uint64_t rows_per_wg;
+};
+__device__ __forceinline__ uint32_t d_radix_part(const DRadix& d, uint32_t key) {
+   const uint32_t r = key - (uint32_t) d.kmin;
+   if (r > (uint32_t) (d.kmax - d.kmin)) return 0; // no slot: matches nothing, any partition will do
+   const uint64_t pos = d.slot32 ? (uint64_t) __umulhi(r << d.ksh, d.kmult32) : ((((uint64_t) r * d.kmult) >> 32) & d.mask);
+   return (uint32_t) (pos >> d.pshift);
+}
+__device__ __forceinline__ uint32_t d_radix_key(const DRadix& d, uint64_t i) {
+   const uint32_t row = d.rowids ? gptr<uint32_t>(d.rowids)[i] : (uint32_t) i;
+   return row == LDB_NULL_ROW ? 0x80000000u : (uint32_t) gptr<int32_t>(d.values)[row];
+}
+__global__ __launch_bounds__(RX_BLOCK) void k_radix_hist(DRadix d, uint32_t* __restrict__ hist) {
+   __shared__ uint32_t h[RX_MAX_PARTS];
+   for (uint32_t p = threadIdx.x; p < d.nparts; p += RX_BLOCK) h[p] = 0;
+   __syncthreads();
+   const uint64_t b = blockIdx.x * d.rows_per_wg, e = b + d.rows_per_wg < d.n ? b + d.rows_per_wg : d.n;
+   for (uint64_t i = b + threadIdx.x; i < e; i += RX_BLOCK) atomicAdd(&h[d_radix_part(d, d_radix_key(d, i))], 1u);
+   __syncthreads();
+   for (uint32_t p = threadIdx.x; p < d.nparts; p += RX_BLOCK) hist[(uint64_t) p * d.grid + blockIdx.x] = h[p];
+}
+__global__ __launch_bounds__(RX_BLOCK) void k_radix_scatter(DRadix d, const uint32_t* __restrict__ offs, uint32_t* __restrict__ key_out, uint32_t* __restrict__ perm_out) {
+   __shared__ uint32_t cur[RX_MAX_PARTS];
+   for (uint32_t p = threadIdx.x; p < d.nparts; p += RX_BLOCK) cur[p] = offs[(uint64_t) p * d.grid + blockIdx.x];
+   __syncthreads();
+   const uint64_t b = blockIdx.x * d.rows_per_wg, e = b + d.rows_per_wg < d.n ? b + d.rows_per_wg : d.n;
+   for (uint64_t i = b + threadIdx.x; i < e; i += RX_BLOCK) {
+      const uint32_t key = d_radix_key(d, i);
+      const uint32_t at = atomicAdd(&cur[d_radix_part(d, key)], 1u);
+      key_out[at] = key;
+      perm_out[at] = (uint32_t) i;
+   }
+}
+// how local is the probe order already?  Share of sampled neighbouring rows whose slots lie within 64 KB
+__global__ void k_radix_locality(DRadix d, uint64_t stride, unsigned int* __restrict__ out) {
+   const uint64_t t = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x;
+   const uint64_t i = t * stride;
+   unsigned int near = 0, valid = 0;
+   if (i + 1 < d.n) {
+      const uint32_t a = d_radix_key(d, i) - (uint32_t) d.kmin, c = d_radix_key(d, i + 1) - (uint32_t) d.kmin;
+      const uint64_t pa = d.slot32 ? (uint64_t) __umulhi(a << d.ksh, d.kmult32) : ((((uint64_t) a * d.kmult) >> 32) & d.mask);
+      const uint64_t pc = d.slot32 ? (uint64_t) __umulhi(c << d.ksh, d.kmult32) : ((((uint64_t) c * d.kmult) >> 32) & d.mask);
+      valid = 1;
+      near = (pa > pc ? pa - pc : pc - pa) < 8192 ? 1 : 0;
+   }
+   const unsigned long long mn = __ballot(near), mv = __ballot(valid);
+   if ((threadIdx.x & 63) == 0) {
+      atomicAdd(out, (unsigned int) __popcll(mn));
+      atomicAdd(out + 1, (unsigned int) __popcll(mv));
+   }
+}
+
+struct RadixProbe { // the clustered stand-in for a probe relation
+   ldb_rel* rel = nullptr; // sides: [keys table (identity)] + the probe's sides through the permutation
+   ldb_table* keys = nullptr;
+};
+static void radix_release(ldb_ctx* ctx, RadixProbe& rp) {
+   if (rp.rel) ldb_gpu_rel_release(ctx, rp.rel);
+   if (rp.keys) ldb_gpu_table_release(ctx, rp.keys);
+   rp.rel = nullptr;
+   rp.keys = nullptr;
+}
+// decides whether to cluster and, if so, builds the clustered relation; rp.rel stays NULL otherwise
+static int32_t radix_prepare(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind, RadixProbe& rp) {
+   // 0 off (default), 1 whenever possible, -1 auto (locality sample + size thresholds).  Off by default: on
+   // MI355X the direct probe of unclustered keys already runs at the HBM random-access rate (46 Grows/s
+   // into a 4.3 GB table), the partition pass costs more than the L2-resident probe (56 Grows/s) wins back
+   // — see DESIGN.md §Join for the measured crossover
+   const int64_t mode = ldb_option("join_radix", 0);
+   if (mode == 0 || n_keys != 1 || !ht->key32 || !ht->ordered_slots || ht->chained || probe->n_rows < 2) return LDB_OK;
+   if (kind == LDB_JOIN_MARK || kind == LDB_JOIN_SEMI || kind == LDB_JOIN_ANTI) return LDB_OK; // results promised in probe order
+   if (probe->sides.size() + 1 + ht->build->sides.size() > LDB_MAX_SIDES) return LDB_OK;
+   DCol kc;
+   LDB_TRY(ldb_make_dcol(probe, keys[0], &kc));
+   if (kc.width != 4 || kc.validity || kc.type == LDB_T_FLOAT32) return LDB_OK;
+   if (mode < 0 && (ht->cap * 8 < (uint64_t) ldb_option("join_radix_min_table_bytes", 64ll << 20) || probe->n_rows < ldb_option("join_radix_min_rows", 16ll << 20))) return LDB_OK;
+   LDB_TRY(ldb_rel_force(ctx, probe));
+   LDB_TRY(ldb_make_dcol(probe, keys[0], &kc));
+   const int64_t n = probe->n_rows;
+   DRadix d;
+   memset(&d, 0, sizeof(d));
+   d.n = (uint64_t) n;
+   d.values = kc.values;
+   d.rowids = kc.rowids;
+   d.kmin = ht->kmin;
+   d.kmax = ht->kmax;
+   d.kmult = ht->kmult;
+   d.mask = ht->cap - 1;
+   d.kmult32 = ht->kmult32;
+   d.ksh = ht->ksh;
+   d.slot32 = (uint32_t) ht->slot32;
+   if (mode < 0) { // already clustered on the key?  then the table is walked sequentially as it is
+      unsigned int* dl = (unsigned int*) (ctx->d_scratch + 40);
+      LDB_HIP(hipMemsetAsync(dl, 0, 8, ctx->stream));
+      const uint64_t samples = 1 << 16, stride = std::max<uint64_t>(1, (uint64_t) n / samples);
+      hipLaunchKernelGGL(k_radix_locality, dim3((unsigned) (samples / 256)), dim3(256), 0, ctx->stream, d, stride, dl);
+      uint64_t both = 0;
+      LDB_TRY(ldb_read_u64(ctx, dl, &both));
+      const uint64_t near = both & 0xFFFFFFFFull, valid = both >> 32;
+      if (valid == 0 || near * 2 >= valid) return LDB_OK;
+   }
+   // partitions of ~1 MB of slots each
+   uint32_t nparts = 16;
+   const uint64_t part_bytes = (uint64_t) ldb_option("join_radix_part_bytes", 1 << 20);
+   while (nparts < RX_MAX_PARTS && (ht->cap * 8) / nparts > part_bytes) nparts <<= 1;
+   uint32_t lg = 0;
+   while ((1ull << lg) < ht->cap) lg++;
+   uint32_t lp = 0;
+   while ((1u << lp) < nparts) lp++;
+   if (lg < lp) return LDB_OK;
+   d.nparts = nparts;
+   d.pshift = lg - lp;
+   d.grid = (uint32_t) std::min<int64_t>(ctx->cus * 8, (n + 4095) / 4096);
+   d.rows_per_wg = ((uint64_t) n + d.grid - 1) / d.grid;
+   uint32_t *hist, *offs, *perm;
+   const size_t hn = (size_t) nparts * d.grid;
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &hist, 4 * hn));
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &offs, 4 * hn));
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &perm, 4 * (size_t) n));
+   ldb_coltype kt = {LDB_T_INT32, 0, 0, 0};
+   kt.type = kc.type;
+   const char* nm = "radix_key";
+   LDB_TRY(ldb_gpu_table_alloc(ctx, "radix_keys", 1, &kt, &nm, n, nullptr, 0, &rp.keys));
+   {
+      LdbProf prof_(ctx, "k_radix_hist");
+      hipLaunchKernelGGL(k_radix_hist, dim3(d.grid), dim3(RX_BLOCK), 0, ctx->stream, d, hist);
+   }
+   LDB_TRY(ldb_exclusive_scan_u32(ctx, hist, offs, (int64_t) hn, nullptr));
+   {
+      LdbProf prof_(ctx, "k_radix_scatter");
+      hipLaunchKernelGGL(k_radix_scatter, dim3(d.grid), dim3(RX_BLOCK), 0, ctx->stream, d, (const uint32_t*) offs, (uint32_t*) rp.keys->cols[0].values, perm);
+   }
+   LDB_HIP(hipGetLastError());
+   ldb_dev_free(ctx, hist);
+   ldb_dev_free(ctx, offs);
+   ldb_rel* r = ldb_rel_new(ctx);
+   r->n_rows = n;
+   r->sides.push_back(ldb_rel_side{rp.keys, nullptr, false});
+   bool perm_taken = false;
+   const int cg = ldb_grid_for(ctx, n, 256, 8);
+   for (auto& s : probe->sides) {
+      ldb_rel_side ns{s.table, nullptr, true};
+      if (!s.rowids && !perm_taken) {
+         ns.rowids = perm;
+         perm_taken = true;
+      } else {
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &ns.rowids, 4 * (size_t) n));
+         hipLaunchKernelGGL(k_compose_null, dim3(cg), dim3(256), 0, ctx->stream, (const uint32_t*) s.rowids, (const uint32_t*) perm, ns.rowids, (uint64_t) n);
+      }
+      r->sides.push_back(ns);
+   }
+   if (!perm_taken) ldb_dev_free(ctx, perm);
+   LDB_HIP(hipGetLastError());
+   rp.rel = r;
+   return LDB_OK;
+}
+// drop the key-table side a clustered probe put in front of the probe's own sides
+static void radix_strip(ldb_ctx* ctx, ldb_rel* r) {
+   if (r->sides.empty()) return;
+   if (r->sides[0].owned) ldb_dev_free(ctx, r->sides[0].rowids);
+   r->sides.erase(r->sides.begin());
+}
+
 static uint64_t next_pow2_u64(uint64_t v) {
    uint64_t p = 1;
    while (p < v) p <<= 1;
@@ -374,8 +559,22 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    return LDB_OK;
 }
 
+static int32_t probe_count_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int64_t* matches, bool radix_ok);
 extern "C" int32_t ldb_gpu_join_probe_count(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int64_t* matches) {
+   return probe_count_impl(ctx, ht, probe, keys, n_keys, matches, true);
+}
+static int32_t probe_count_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int64_t* matches, bool radix_ok) {
    if (!ctx || !ht || !probe || !matches) LDB_FAIL(LDB_ERR_INVALID, "join_probe_count: NULL argument");
+   if (radix_ok) {
+      RadixProbe rp;
+      LDB_TRY(radix_prepare(ctx, ht, probe, keys, n_keys, LDB_JOIN_INNER, rp));
+      if (rp.rel) { // an unclustered probe side: partitioned by slot range first
+         const ldb_colref k0 = {0, 0};
+         const int32_t st = probe_count_impl(ctx, ht, rp.rel, &k0, 1, matches, false);
+         radix_release(ctx, rp);
+         return st;
+      }
+   }
    auto hp = std::make_unique<DJoin>();
    LDB_TRY(make_probe_desc(ht, probe, keys, n_keys, hp.get()));
    hp->kind = LDB_JOIN_INNER;
@@ -397,10 +596,29 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
    return ldb_gpu_join_probe_residual(ctx, ht, probe, keys, n_keys, kind, nullptr, 0, out, mark_out);
 }
 
+static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind, const ldb_join_residual* resid, int32_t n_resid,
+                          ldb_rel** out, ldb_table** mark_out, bool radix_ok);
 extern "C" int32_t ldb_gpu_join_probe_residual(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind,
                                                const ldb_join_residual* resid, int32_t n_resid, ldb_rel** out, ldb_table** mark_out) {
+   return probe_impl(ctx, ht, probe, keys, n_keys, kind, resid, n_resid, out, mark_out, true);
+}
+static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind, const ldb_join_residual* resid, int32_t n_resid,
+                          ldb_rel** out, ldb_table** mark_out, bool radix_ok) {
    if (!ctx || !ht || !probe || !out) LDB_FAIL(LDB_ERR_INVALID, "join_probe: NULL argument");
    if (kind < LDB_JOIN_INNER || kind > LDB_JOIN_ANTI_BUILD) LDB_FAIL(LDB_ERR_INVALID, "join_probe: bad kind %d", kind);
+   if (radix_ok) {
+      RadixProbe rp;
+      LDB_TRY(radix_prepare(ctx, ht, probe, keys, n_keys, kind, rp));
+      if (rp.rel) { // an unclustered probe side: partitioned by slot range first, then the ordinary kernels
+         const ldb_colref k0 = {0, 0};
+         std::vector<ldb_join_residual> rs(resid, resid + (n_resid > 0 ? n_resid : 0));
+         for (auto& x : rs) x.probe_col.side += 1; // the key table sits in front of the probe's sides
+         const int32_t st = probe_impl(ctx, ht, rp.rel, &k0, 1, kind, rs.data(), n_resid, out, mark_out, false);
+         if (st == LDB_OK && kind != LDB_JOIN_SEMI_BUILD && kind != LDB_JOIN_ANTI_BUILD) radix_strip(ctx, *out);
+         radix_release(ctx, rp);
+         return st;
+      }
+   }
    // kinds that emit a row for EVERY probe row (outer / single / mark) need the filtered row set itself
    if (kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE || kind == LDB_JOIN_MARK) LDB_TRY(ldb_rel_force(ctx, probe));
    const bool pairs = kind == LDB_JOIN_INNER || kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE;

@@ -363,9 +363,10 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
 #endif
       w0[u] = slots[pos[u]];
 #ifndef JOIN_NO_PREFETCH2
-      w1[u] = slots[(pos[u] + 1) & mask];
-#else
-      w1[u] = 0;
+      // the second slot only for tables with duplicate keys (their rows sit in consecutive slots): for a
+      // unique table it is needed after a collision only, and fetching it always costs an unclustered
+      // probe 40 % (600 M random probes: 18.3 → 13.0 ms) for 5 % on a clustered one
+      if (!m.build_unique) w1[u] = slots[(pos[u] + 1) & mask];
 #endif
    }
    const KV bkeys(m.bkeys, d->bkeys);
@@ -401,7 +402,7 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
          p = (p + 1) & mask;
          step++;
 #ifndef JOIN_NO_PREFETCH2
-         w = step == 1 ? w1[u] : slots[p];
+         w = (step == 1 && !m.build_unique) ? w1[u] : slots[p];
 #else
          w = slots[p];
 #endif

@@ -26,5 +26,8 @@ def test_oracle_q10_q15_legs(monkeypatch):
         if days("1996-01-01") <= d < days("1996-04-01"):
             q15[sk] += ext * (100 - disc)
     assert len(q10) > 100 and len(q15) > 50
-    assert got[10] == dict(q10)
-    assert got[15] == dict(q15)
+    # the legs return result ROWS now: Q10 = the best customers (c_custkey, c_name, revenue, c_acctbal, n_name), Q15 = the best suppliers
+    ranked = sorted(q10.items(), key=lambda r: -r[1])
+    assert [r[2] for r in got[10][:20]] == [r[1] for r in ranked[:20]] and all(q10[r[0]] == r[2] for r in got[10])
+    best = max(q15.values())
+    assert got[15] == sorted((k, v) for k, v in q15.items() if v == best)

@@ -18,7 +18,20 @@ def run(name, ht, rel, key):
     out[name] = {"ms": round(ms / k, 4), "grows_per_s": round(rel.rows / (ms / k * 1e-3) / 1e9, 2), "matches": m}
 ht = od.rel().join_build([(0, 0)], unique=True)
 out["build_ms"] = round(ctx.prof_all().get("k_join_build", (1, 0.0))[1], 3)
+L = capi.gpu_lib()
+L.ldb_gpu_set_option(b"join_radix", 0)
 run("clustered", ht, li.rel(), 0); run("unclustered", ht, pk.rel(), 0)
+L.ldb_gpu_set_option(b"join_radix", -1)
+def run_radix(name, ht, rel, key):
+    ht.probe_count(rel, [(0, key)]); ctx.prof_reset()
+    for _ in range(a.reps): m = ht.probe_count(rel, [(0, key)])
+    pr = ctx.prof_all()
+    tot = sum(pr.get(k, (0, 0.0))[1] for k in ("k_join_probe_count", "k_radix_hist", "k_radix_scatter")) / a.reps
+    out[name] = {"ms": round(tot, 4), "grows_per_s": round(rel.rows / (tot * 1e-3) / 1e9, 2), "matches": m, "kernels_ms": {k: round(v[1] / a.reps, 4) for k, v in pr.items()}}
+if os.environ.get("PB_RADIX"):
+    L.ldb_gpu_set_option(b"join_radix", 1); L.ldb_gpu_set_option(b"join_radix_part_bytes", 1 << 28)
+    run_radix("unclustered_radix", ht, pk.rel(), 0)
+L.ldb_gpu_set_option(b"join_radix", 0)
 for opt in os.environ.get("PB_OPTS", "").split(","):
     if opt:
         k, v = opt.split("="); capi.gpu_lib().ldb_gpu_set_option(k.encode(), int(v))

@@ -56,4 +56,22 @@ for it in range(reps):
     a, b = r.rowids(0), r.rowids(1)
     good = r.rows == want_pairs and np.array_equal(ook[a], lok[b]) and len(np.unique(b)) == len(b) and bool(np.isin(b, lsel).all())
     report(f"inner pairs #{it}", good)
+# radix clustering of the probe side forced on: same pairs / counts as without it
+L = capi.gpu_lib()
+pkt = ctx.tpch_generate(8, n, cols=[0])
+hod = od.rel().join_build([(0, 0)], unique=True)
+pkv = np.frombuffer(pkt.read_fixed(0).tobytes(), dtype=np.int32)
+okey_to_row = np.zeros(int(ook.max()) + 1, dtype=np.int64) - 1
+okey_to_row[ook] = np.arange(len(ook))
+for mode in (0, 1):
+    L.ldb_gpu_set_option(b"join_radix", mode)
+    report(f"count radix={mode}", hod.probe_count(pkt.rel(), [(0, 0)]) == pkt.rows)
+    r = hod.probe(pkt.rel(), [(0, 0)])
+    a, b = r.rowids(0), r.rowids(1)
+    report(f"inner radix={mode}", r.rows == pkt.rows and r.sides == 2 and len(np.unique(a)) == len(a) and np.array_equal(okey_to_row[pkv[a]], b.astype(np.int64)))
+    sb = hod.probe(pkt.rel(), [(0, 0)], capi.JOIN_SEMI_BUILD)
+    report(f"semi_build radix={mode}", np.array_equal(sb.rowids(0), np.unique(okey_to_row[pkv]).astype(np.uint32)))
+    lo = hs.probe(pkt.rel(), [(0, 0)], capi.JOIN_LEFT_OUTER)  # mostly unmatched: supplier keys vs order keys
+    report(f"left_outer radix={mode}", lo.rows == pkt.rows)
+L.ldb_gpu_set_option(b"join_radix", -1)
 print("ALL OK" if ok else "FAILED")

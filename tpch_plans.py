@@ -195,6 +195,8 @@ class Runner:
 
     def probe_microbench(self, reps=3):
         """FK probe of l_orderkey into a table built on o_orderkey (100 % match), SURVEY §8(d)."""
+        from lingodb_amd import api, capi
+
         ctx, db = self.ctx, self.db
         orel, lrel = db.orders.rel(), db.lineitem.rel()
         ok, lk = db.orders.col("o_orderkey"), db.lineitem.col("l_orderkey")
@@ -228,12 +230,25 @@ class Runner:
             avg = ms_p / n_p
             out["unclustered"] = {"probe_rows": pk.rows, "matches": m2, "probe_ms": round(avg, 4), "probe_grows_per_s": round(pk.rows / (avg * 1e-3) / 1e9, 3),
                                   "algorithmic_gbs": round(pk.rows * 12 / (avg * 1e-3) / 1e9, 1)}
+            # the same through the radix path (probe side partitioned by slot range first; off by default):
+            # partition passes + probe of the partitioned keys, 256 MB of slots per partition
+            lib = capi.gpu_lib()
+            lib.ldb_gpu_set_option(b"join_radix", 1)
+            lib.ldb_gpu_set_option(b"join_radix_part_bytes", 1 << 28)
+            ht.probe_count(pk.rel(), [(0, 0)])
+            ctx.prof_reset()
+            for _ in range(reps):
+                m3 = ht.probe_count(pk.rel(), [(0, 0)])
+            pr = ctx.prof_all()
+            lib.ldb_gpu_set_option(b"join_radix", 0)
+            tot = sum(pr.get(k, (0, 0.0))[1] for k in ("k_join_probe_count", "k_radix_hist", "k_radix_scatter")) / reps
+            if tot > 0:
+                out["unclustered_radix"] = {"probe_rows": pk.rows, "matches": m3, "probe_ms": round(tot, 4), "probe_grows_per_s": round(pk.rows / (tot * 1e-3) / 1e9, 3),
+                                            "kernels_ms": {k: round(v[1] / reps, 4) for k, v in pr.items()}, "partition_bytes": 1 << 28}
         pk.release()
         ht.release()
         # selective variant: build side filtered to ≈10 % of orders (o_orderdate < 1992-09-01)
         ctx.prof_reset()
-        from lingodb_amd import api, capi
-
         sel = orel.scan_filter([api.pred((0, db.orders.col("o_orderdate")), capi.F_LT, 8279)])
         ht = sel.join_build([(0, ok)], unique=True)
         for _ in range(reps):
@@ -292,130 +307,40 @@ class Runner:
 
 
 # ---------------------------------------------------------------- CPU baseline (oracle = reported, non-target)
-def cpu_baseline(queries, sample_sf):
-    """The oracle restatement of the reference CPU path (oracle/ldb_oracle.c, kind "port") timed on
-    this host's cores over a bounded sample: the same generator at `sample_sf`, all cores,
-    morsel size 20 000.  Median of 3 runs per query; value = geomean over the queries."""
+def cpu_baseline(queries, sample_sf, runs="1+3"):
+    """The oracle legs (oracle/tpch_legs.py: the C restatement of the reference's CPU path — morsels of
+    20 000 rows, HashIndexedView / PreAggregationHashtable restated — plus numpy for the few rows after
+    the first aggregation; kind "port") timed on this host's cores over a bounded sample: the SAME
+    generator as the GPU leg at `sample_sf`, every benched query, `runs` = warm-up+measured passes
+    (the reference's tools/scripts/benchmark.py uses 3+10), median and min per query."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import statistics
 
-    import oracle_bind
-    import tpch_data
-    from lingodb_amd import api, capi
+    import tpch_legs
 
-    oracle = oracle_bind.load()
-    cores = oracle.num_cores()
     n_orders = int(round(sample_sf * 1_500_000))
-    li = oracle_bind.HostTable(tpch_data.host_table(tpch_data.LINEITEM, n_orders, cols=[0, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14]))
-    # column positions inside the trimmed lineitem table
-    LK, QTY, EXT, DISC, TAX, RF, LS, SHIP, COMMIT, RECEIPT, MODE = range(11)
-    f = api.factor
-    D = capi.T_DECIMAL128
-
-    def q1():
-        dp = api.expr([{"factors": [f(0, 1, (0, EXT)), f(100, -1, (0, DISC))]}])
-        ch = api.expr([{"factors": [f(0, 1, (0, EXT)), f(100, -1, (0, DISC)), f(100, 1, (0, TAX))]}])
-        aggs = [api.agg(capi.AGG_SUM, api.col_expr((0, QTY)), out_type=D, p=12, s=2), api.agg(capi.AGG_SUM, api.col_expr((0, EXT)), out_type=D, p=12, s=2),
-                api.agg(capi.AGG_SUM, dp, wide=True, out_type=D, p=33, s=4), api.agg(capi.AGG_SUM, ch, wide=True, out_type=D, p=38, s=6),
-                api.agg(capi.AGG_AVG, api.col_expr((0, QTY)), out_type=D, p=31, s=21, avg_pow10=19), api.agg(capi.AGG_AVG, api.col_expr((0, EXT)), out_type=D, p=31, s=21, avg_pow10=19),
-                api.agg(capi.AGG_AVG, api.col_expr((0, DISC)), out_type=D, p=31, s=21, avg_pow10=19), api.agg(capi.AGG_COUNT_STAR)]
-        return oracle.groupby(li.rel(), [(0, RF), (0, LS)], aggs, [api.pred((0, SHIP), capi.F_LTE, 10471)], threads=cores)
-
-    def q6():
-        aggs = [api.agg(capi.AGG_SUM, api.expr([{"factors": [f(0, 1, (0, EXT)), f(0, 1, (0, DISC))]}]), wide=True, out_type=D, p=24, s=4)]
-        plist = [api.pred((0, SHIP), capi.F_GTE, 8766), api.pred((0, SHIP), capi.F_LT, 9131), api.pred((0, DISC), capi.F_GTE, 5), api.pred((0, DISC), capi.F_LTE, 7),
-                 api.pred((0, QTY), capi.F_LT, 2400)]
-        return oracle.groupby(li.rel(), [], aggs, plist, threads=cores)
-
-    od = cu = None
-    if 3 in queries:
-        od = oracle_bind.HostTable(tpch_data.host_table(tpch_data.ORDERS, n_orders, cols=[0, 1, 4, 6]))
-        cu = oracle_bind.HostTable(tpch_data.host_table(tpch_data.CUSTOMER, n_orders, cols=[0, 3]))
-
-    def q3():
-        hc, ho, hl = cu.rel(), od.rel(), li.rel()
-        c1 = hc.select(oracle.scan_filter(hc, [api.pred((0, 1), capi.F_EQ, "BUILDING")], cores))
-        o1 = ho.select(oracle.scan_filter(ho, [api.pred((0, 2), capi.F_LT, 9204)], cores))
-        l1 = hl.select(oracle.scan_filter(hl, [api.pred((0, SHIP), capi.F_GT, 9204)], cores))
-        op, ob, _ = oracle.join(c1, [(0, 0)], o1, [(0, 1)], capi.JOIN_INNER, cores)
-        co = oracle_bind.HostRel([(od, o1.phys(0)[op]), (cu, c1.phys(0)[ob])], len(op))
-        lp, lb, _ = oracle.join(co, [(0, 0)], l1, [(0, LK)], capi.JOIN_INNER, cores)
-        lco = oracle_bind.HostRel([(li, l1.phys(0)[lp]), (od, co.phys(0)[lb]), (cu, co.phys(1)[lb])], len(lp))
-        agg = api.agg(capi.AGG_SUM, api.expr([{"factors": [f(0, 1, (0, EXT)), f(100, -1, (0, DISC))]}]), wide=True, out_type=D, p=33, s=4)
-        rep, vals, valid = oracle.groupby(lco, [(0, LK), (1, 2), (1, 3)], [agg], threads=cores)
-        return len(rep)
-
-    od2 = None
-    if 4 in queries or 12 in queries:
-        od2 = oracle_bind.HostTable(tpch_data.host_table(tpch_data.ORDERS, n_orders, cols=[0, 4, 5]))  # o_orderkey, o_orderdate, o_orderpriority
-
-    def q4():
-        ho, hl = od2.rel(), li.rel()
-        o1 = ho.select(oracle.scan_filter(ho, [api.pred((0, 1), capi.F_GTE, 8582), api.pred((0, 1), capi.F_LT, 8674)], cores))
-        l1 = hl.select(oracle.scan_filter(hl, [api.pred((0, COMMIT), capi.F_LT, rhs_col=(0, RECEIPT))], cores))
-        keep, _, _ = oracle.join(o1, [(0, 0)], l1, [(0, LK)], capi.JOIN_SEMI_BUILD, cores)
-        osel = oracle_bind.HostRel([(od2, o1.phys(0)[keep])], len(keep))
-        return oracle.groupby(osel, [(0, 2)], [api.agg(capi.AGG_COUNT_STAR)], threads=cores)
-
-    def q12():
-        ho, hl = od2.rel(), li.rel()
-        lp = [api.pred((0, RECEIPT), capi.F_GTE, 8766), api.pred((0, RECEIPT), capi.F_LT, 9131), api.pred((0, COMMIT), capi.F_LT, rhs_col=(0, RECEIPT)),
-              api.pred((0, SHIP), capi.F_LT, rhs_col=(0, COMMIT)), api.pred((0, MODE), capi.F_IN, values=["MAIL", "SHIP"])]
-        l1 = hl.select(oracle.scan_filter(hl, lp, cores))
-        op, ob, _ = oracle.join(l1, [(0, LK)], ho, [(0, 0)], capi.JOIN_INNER, cores)
-        ol = oracle_bind.HostRel([(od2, op), (li, l1.phys(0)[ob])], len(op))
-        one = api.expr([{"factors": [f(1, 0)]}])
-        high = [api.pred((0, 2), capi.F_IN, values=["1-URGENT", "2-HIGH"])]
-        low = [api.pred((0, 2), capi.F_NEQ, "1-URGENT"), api.pred((0, 2), capi.F_NEQ, "2-HIGH")]
-        aggs = [api.agg(capi.AGG_SUM, one, out_type=capi.T_INT32, preds=high), api.agg(capi.AGG_SUM, one, out_type=capi.T_INT32, preds=low)]
-        return oracle.groupby(ol, [(1, MODE)], aggs, threads=cores)
-
-    od3 = None
-    if 10 in queries:
-        od3 = oracle_bind.HostTable(tpch_data.host_table(tpch_data.ORDERS, n_orders, cols=[0, 1, 4]))  # o_orderkey, o_custkey, o_orderdate
-    revenue = api.agg(capi.AGG_SUM, api.expr([{"factors": [f(0, 1, (0, EXT)), f(100, -1, (0, DISC))]}]), wide=True, out_type=D, p=33, s=4)
-
-    def q10():
-        """the 600 M-row part of Q10: orders of the quarter ⋈ returned lineitems, SUM per o_custkey
-        (the top-20 and the 20 customer / nation lookups behind it are not timed on either side's favour)"""
-        ho, hl = od3.rel(), li.rel()
-        o1 = ho.select(oracle.scan_filter(ho, [api.pred((0, 2), capi.F_GTE, 8674), api.pred((0, 2), capi.F_LT, 8766)], cores))
-        l1 = hl.select(oracle.scan_filter(hl, [api.pred((0, RF), capi.F_EQ, ord("R"))], cores))
-        lp, lb, _ = oracle.join(o1, [(0, 0)], l1, [(0, LK)], capi.JOIN_INNER, cores)
-        lo = oracle_bind.HostRel([(li, l1.phys(0)[lp]), (od3, o1.phys(0)[lb])], len(lp))
-        rep, vals, _ = oracle.groupby(lo, [(1, 1)], [revenue], threads=cores)
-        return {int(od3.arrow.column(1)[int(lo.phys(1)[r])].as_py()): v[0] for r, v in zip(rep, vals)} if sample_sf <= 0.02 else len(rep)
-
-    li15 = None
-    if 15 in queries:
-        li15 = oracle_bind.HostTable(tpch_data.host_table(tpch_data.LINEITEM, n_orders, cols=[2, 5, 6, 10]))  # l_suppkey, ext, disc, shipdate
-
-    def q15():
-        """the revenue view of Q15 (fused shipdate filter + SUM per l_suppkey) and its maximum"""
-        agg = api.agg(capi.AGG_SUM, api.expr([{"factors": [f(0, 1, (0, 1)), f(100, -1, (0, 2))]}]), wide=True, out_type=D, p=33, s=4)
-        rep, vals, _ = oracle.groupby(li15.rel(), [(0, 0)], [agg], [api.pred((0, 3), capi.F_GTE, 9496), api.pred((0, 3), capi.F_LT, 9587)], threads=cores)
-        best = max((v[0] for v in vals), default=None)
-        return {int(li15.arrow.column(0)[int(r)].as_py()): v[0] for r, v in zip(rep, vals)} if sample_sf <= 0.02 else (len(rep), best)
-
-    fns = {1: q1, 6: q6, 3: q3, 4: q4, 12: q12, 10: q10, 15: q15}
+    legs = tpch_legs.Legs(n_orders, queries=list(queries))
     if os.environ.get("LDB_CPU_BASELINE_RESULTS"):  # tests: the legs' results instead of their times
-        return {q: fns[q]() for q in queries if q in fns}
-    per = {}
-    queries = [q for q in queries if q in fns]  # the CPU leg covers the headline queries
-    if not queries:
-        return None
+        return {q: legs.run(q) for q in queries}
+    warm, measured = (int(x) for x in runs.split("+"))
+    for tid in tpch_legs.Legs.NEED:  # host generation is registration time, not query time
+        if any(q in tpch_legs.Legs.NEED[tid] for q in queries):
+            legs.table(tid)
+    med, mn = {}, {}
     for q in queries:
         ts = []
-        for _ in range(3):
+        for r in range(warm + measured):
             t0 = time.perf_counter()
-            fns[q]()
-            ts.append((time.perf_counter() - t0) * 1000.0)
-        per[q] = statistics.median(ts)
+            legs.run(q)
+            if r >= warm:
+                ts.append((time.perf_counter() - t0) * 1000.0)
+        med[q], mn[q] = statistics.median(ts), min(ts)
     import math
 
-    gm = math.exp(sum(math.log(max(v, 1e-9)) for v in per.values()) / len(per))
-    return {"value": round(gm, 3), "unit": "ms", "cores": cores, "kind": "port",
-            "sample": "SF%g (%d lineitem rows): oracle restatement of the reference CPU path, %d threads, morsel 20000, median of 3; "
-                      "geomean over %s — NOT the SF of `value` (scale linearly for a rough comparison)" % (
-                          sample_sf, li.struct.n_rows, cores, "+".join("Q%d" % q for q in queries)),
-            "per_query_ms": {"Q%d" % q: round(v, 3) for q, v in per.items()}, "sample_sf": sample_sf}
+    gm = math.exp(sum(math.log(max(v, 1e-9)) for v in med.values()) / len(med))
+    return {"value": round(gm, 3), "unit": "ms", "cores": legs.threads, "kind": "port",
+            "sample": "SF%g (%d orders; same generator and seed as the GPU leg, which runs SF of `value`): oracle restatement of the reference CPU path "
+                      "(reference binary not buildable offline), %d threads, morsel 20000, %d warm-up + %d measured passes; geomean of the per-query medians over %s "
+                      "— scale linearly with SF for a rough comparison" % (sample_sf, n_orders, legs.threads, warm, measured, "+".join("Q%d" % q for q in queries)),
+            "per_query_median_ms": {"Q%d" % q: round(v, 3) for q, v in med.items()}, "per_query_min_ms": {"Q%d" % q: round(v, 3) for q, v in mn.items()}, "sample_sf": sample_sf}
