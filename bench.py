@@ -81,6 +81,25 @@ def main():
     info = ctx.device_info()
     db = tpch_plans.Database(ctx, n_orders, rank, world, queries, bool(args.narrow_decimals))
     runner = tpch_plans.Runner(ctx, db, world, dist if world > 1 else None, torch)
+    exchange = "none"
+    if world > 1:
+        # the exchange runs inside the library over RCCL (ldb_gpu_allgather / ldb_gpu_alltoall on the ctx stream);
+        # torch.distributed only carries the 128-byte communicator id and the timing reductions.  gloo (tests on
+        # one GPU) and LDB_COMM=torch keep the torch.distributed staging path of tpch_dist.py
+        exchange = "torch.distributed (%s)" % backend
+        if backend == "nccl" and os.environ.get("LDB_COMM", "rccl") == "rccl":
+            from lingodb_amd import api
+
+            def exchange_id(ident):
+                box = [ident]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+
+            try:
+                runner.comm = api.Comm(ctx, rank, world, exchange_id)
+                exchange = "librccl inside liblingodb_gpu.so (grouped send/recv on the ctx stream)"
+            except Exception as e:  # keep the bench alive on the proven path; the line says which path ran
+                print(f"[bench] rank {rank}: in-library RCCL communicator failed ({e}); using torch.distributed", file=sys.stderr, flush=True)
 
     def barrier():
         ctx.sync()
@@ -234,7 +253,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "TPC-H SF%g %s on %d x MI355X, Arrow columns resident in HBM (synthetic dbgen-shaped data, seed 20260925)" % (
                 args.sf, "+".join("Q%d" % q for q in queries), world), "queries": queries, "rows_lineitem_total": int(db.n_lineitem_total),
-                "narrow_decimals": bool(args.narrow_decimals), "device": info["name"]},
+                "narrow_decimals": bool(args.narrow_decimals), "device": info["name"], "exchange": exchange},
             "per_query_ms": {"Q%d" % q: round(v, 4) for q, v in per_query.items()},
             "per_query_median_ms": {"Q%d" % q: round(sorted(q_runs[q])[len(q_runs[q]) // 2], 4) for q in queries},
             "per_query_min_ms": {"Q%d" % q: round(min(q_runs[q]), 4) for q in queries},

@@ -460,6 +460,29 @@ int32_t ldb_gpu_topk(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int3
 int32_t ldb_gpu_partition(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* keys, int32_t n_keys, int32_t nparts,
                           const ldb_colref* cols, int32_t n_cols, ldb_table** out, int64_t* counts);
 
+/* The exchange itself: RCCL over xGMI, one rank (= one ldb_ctx) per GPU.  Rank 0 makes a 128-byte id
+ * (ldb_gpu_comm_unique_id = ncclGetUniqueId), the host process hands it to every rank by whatever
+ * channel it has (the LingoDB side: its session layer; the tests: torch.distributed / a file), and
+ * every rank joins with ldb_gpu_comm_create.  All transfers are issued on the context's stream as ONE
+ * grouped batch of point-to-point sends / receives per call (every peer pair has its own xGMI
+ * link), straight into the column buffers of the result table. */
+typedef struct ldb_comm ldb_comm;
+int32_t ldb_gpu_comm_unique_id(void* id128);
+int32_t ldb_gpu_comm_create(ldb_ctx* ctx, int32_t rank, int32_t world, const void* id128, ldb_comm** out);
+int32_t ldb_gpu_comm_destroy(ldb_comm* comm);
+int32_t ldb_gpu_comm_rank(const ldb_comm* comm);
+int32_t ldb_gpu_comm_world(const ldb_comm* comm);
+/* every rank's rows of `t` concatenated in rank order on every rank (replicated small build sides,
+ * partial aggregates; fixed-width and utf8 columns, validity bitmaps travel along) */
+int32_t ldb_gpu_allgather(ldb_ctx* ctx, ldb_comm* comm, const ldb_table* t, const char* name, ldb_table** out);
+/* `t` holds send_counts[p] rows for rank p, in rank order (ldb_gpu_partition's layout): the result holds
+ * the rows this rank receives from rank 0, 1, … in that order */
+int32_t ldb_gpu_alltoall(ldb_ctx* ctx, ldb_comm* comm, const ldb_table* t, const int64_t* send_counts, const char* name, ldb_table** out);
+/* hash-radix shuffle = ldb_gpu_partition (dest = (db.hash(keys) >> 16) % world) + ldb_gpu_alltoall:
+ * afterwards equal keys are on the same rank (one all-to-all per repartitioned input) */
+int32_t ldb_gpu_shuffle(ldb_ctx* ctx, ldb_comm* comm, ldb_rel* in, const ldb_colref* keys, int32_t n_keys, const ldb_colref* cols, int32_t n_cols, const char* name,
+                        ldb_table** out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -417,6 +417,50 @@ class HashTable:
         return c.value
 
 
+class Comm:
+    """RCCL communicator of the library (one rank per GPU): the id made on rank 0 reaches the others through
+    `exchange_id(bytes | None) -> bytes` (e.g. a torch.distributed broadcast)"""
+
+    def __init__(self, ctx, rank, world, exchange_id):
+        # a Python process that will import torch must do so BEFORE librccl is bound: torch ships its own
+        # librccl / HIP runtime copies and a second copy loaded afterwards aborts at interpreter exit
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        self.ctx, self.rank, self.world = ctx, rank, world
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            check(ctx.lib.ldb_gpu_comm_unique_id(buf))
+        ident = exchange_id(buf.raw if rank == 0 else None)
+        h = C.c_void_p()
+        check(ctx.lib.ldb_gpu_comm_create(ctx.h, rank, world, C.create_string_buffer(ident, 128), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.ldb_gpu_comm_destroy(self.h)
+            self.h = None
+
+    def allgather(self, table, name="gathered"):
+        t = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_allgather(self.ctx.h, self.h, table.h, name.encode(), C.byref(t)))
+        return Table(self.ctx, t)
+
+    def alltoall(self, table, send_counts, name="exchanged"):
+        cnt = (C.c_int64 * self.world)(*[int(c) for c in send_counts])
+        t = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_alltoall(self.ctx.h, self.h, table.h, cnt, name.encode(), C.byref(t)))
+        return Table(self.ctx, t)
+
+    def shuffle(self, rel, keys, cols, name="shuffled"):
+        karr, nk = _refs(keys)
+        carr, ncol = _refs(cols)
+        t = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_shuffle(self.ctx.h, self.h, rel.h, karr, nk, carr, ncol, name.encode(), C.byref(t)))
+        return Table(self.ctx, t)
+
+
 class Context:
     def __init__(self, device=0, stream=None):
         self.lib = capi.gpu_lib()

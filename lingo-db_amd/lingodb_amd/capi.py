@@ -201,6 +201,14 @@ GPU_API = {
     "ldb_gpu_sort": (i32, [P, P, C.POINTER(SortSpec), i32, PP]),
     "ldb_gpu_topk": (i32, [P, P, C.POINTER(SortSpec), i32, i64, PP]),
     "ldb_gpu_partition": (i32, [P, P, C.POINTER(ColRef), i32, i32, C.POINTER(ColRef), i32, PP, C.POINTER(i64)]),
+    "ldb_gpu_comm_unique_id": (i32, [P]),
+    "ldb_gpu_comm_create": (i32, [P, i32, i32, P, PP]),
+    "ldb_gpu_comm_destroy": (i32, [P]),
+    "ldb_gpu_comm_rank": (i32, [P]),
+    "ldb_gpu_comm_world": (i32, [P]),
+    "ldb_gpu_allgather": (i32, [P, P, P, C.c_char_p, PP]),
+    "ldb_gpu_alltoall": (i32, [P, P, P, C.POINTER(i64), C.c_char_p, PP]),
+    "ldb_gpu_shuffle": (i32, [P, P, P, C.POINTER(ColRef), i32, C.POINTER(ColRef), i32, C.c_char_p, PP]),
     # include/ldb_tpchgen.h (device generator)
     "ldb_gpu_tpch_generate": (i32, [P, i32, i64, i32, i32, u64, i32, PP]),
 }

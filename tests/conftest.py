@@ -16,6 +16,12 @@ SPEC_MODULES = {"test_gpu_parity", "test_gpu_joins_more", "test_gpu_tpch_more", 
                 "test_gpu_new_ops"}
 
 
+try:  # torch first: it ships its own HIP runtime / RCCL copies, which must be the ones the process binds (see api.Comm)
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

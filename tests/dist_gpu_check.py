@@ -28,6 +28,15 @@ def main():
     ctx = ldb.Context(dev)
     db = tpch_plans.Database(ctx, n_orders, rank, world, queries, False)
     runner = tpch_plans.Runner(ctx, db, world, dist, torch)
+    if backend == "nccl":  # the exchange inside the library (RCCL); torch.distributed only carries the communicator id
+        from lingodb_amd import api
+
+        def exchange_id(ident):
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        runner.comm = api.Comm(ctx, rank, world, exchange_id)
     got = {q: runner.run(q).to_arrow() for q in queries}
     ok = True
     if rank == 0:
@@ -53,7 +62,7 @@ def main():
             if not same:
                 print(a[:3], b[:3], flush=True)
             ok = ok and same
-    flag = torch.tensor([1 if ok else 0])
+    flag = torch.tensor([1 if ok else 0], device="cuda" if backend == "nccl" else "cpu")
     dist.broadcast(flag, 0)
     dist.barrier()
     dist.destroy_process_group()

@@ -70,6 +70,8 @@ def replicate(runner, table, name):
     separate gather of its bytes, and the offsets are rebuilt on arrival.
     NULLs: the exchanged partial tables carry validity only for empty-input SUMs; callers pass
     NOT NULL tables."""
+    if getattr(runner, "comm", None) is not None:  # RCCL inside the library (ldb_gpu_allgather): no torch staging, validity travels along
+        return runner.comm.allgather(table, name)
     ctx, n, nc = runner.ctx, table.rows, table.n_cols
     staged = runner.dist.get_backend() == "gloo"  # functional testing of the N>1 path on one GPU
     cols, widths, blobs = [], [], {}
@@ -142,6 +144,8 @@ def shuffle(runner, table, send_counts, name):
     rank j, in rank order (ldb_gpu_partition's layout); returns the rows this rank receives from
     every peer.  One grouped point-to-point exchange for the whole table (one message per peer pair
     carrying all columns; each peer pair has its own xGMI link); fixed-width columns only."""
+    if getattr(runner, "comm", None) is not None:  # RCCL inside the library (ldb_gpu_alltoall)
+        return runner.comm.alltoall(table, send_counts, name)
     cols, widths = table_to_tensors(runner.ctx, table)
     staged = runner.dist.get_backend() == "gloo"
     if staged:
