@@ -288,6 +288,31 @@ static int like_match(const uint8_t* s, size_t sl, const uint8_t* p, size_t pl) 
 }
 int32_t ora_like(const uint8_t* s, int64_t sl, const uint8_t* p, int64_t pl) { return like_match(s, (size_t) sl, p, (size_t) pl); }
 
+/* substring(str from `from` for `len`): StringRuntime::substr (src/runtime/StringRuntime.cpp:292-319) with
+ * charIndexToByteIndex (:102-135): positions count UTF-8 characters from 1, positions before the string
+ * count towards the length, from / to beyond the end are truncated to it.  Writes the byte range. */
+static size_t char_to_byte(const uint8_t* s, size_t byte_len, size_t char_index, size_t known_byte, size_t known_char) {
+   for (; known_byte < byte_len; known_byte++) {
+      if ((s[known_byte] >> 6) != 2) { /* not a continuation byte */
+         if (known_char == char_index) return known_byte;
+         known_char++;
+      }
+   }
+   return byte_len;
+}
+void ora_substr(const uint8_t* s, int64_t sl, int64_t from, int64_t len, int64_t* out_begin, int64_t* out_end) {
+   int64_t legal_len = len > 0 ? len : 0;
+   size_t legal_from = (size_t) (from > 1 ? from : 1);
+   int64_t to_raw = from + legal_len;
+   size_t legal_to = to_raw > (int64_t) legal_from ? (size_t) to_raw : legal_from;
+   legal_from--;
+   legal_to--;
+   size_t b0 = char_to_byte(s, (size_t) sl, legal_from, 0, 0);
+   size_t b1 = char_to_byte(s, (size_t) sl, legal_to, b0, legal_from);
+   *out_begin = (int64_t) b0;
+   *out_end = (int64_t) b1;
+}
+
 /* extract(year from date) on a date32 (days since 1970-01-01): DateRuntime::extractYear
  * (src/runtime/DateRuntime.cpp:99-101) = civil year of the day (proleptic Gregorian, UTC). */
 int64_t ora_extract_year(int64_t days) {

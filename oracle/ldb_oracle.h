@@ -78,6 +78,8 @@ void ora_partition_ids(const ora_rel* in, const ldb_colref* keys, int32_t n_keys
 /* SQL LIKE (StringRuntime::like, escape '\\') and extract(year from date32) (DateRuntime::extractYear) */
 int32_t ora_like(const uint8_t* s, int64_t sl, const uint8_t* p, int64_t pl);
 int64_t ora_extract_year(int64_t days);
+/* substring(str from `from` for `len`) (StringRuntime::substr): byte range [begin, end) of the result inside str */
+void ora_substr(const uint8_t* s, int64_t sl, int64_t from, int64_t len, int64_t* out_begin, int64_t* out_end);
 int32_t ora_decimal_muldiv(const int64_t num[2], const int64_t mul[2], int32_t mul_div_pow10, int32_t pow10, const int64_t den[2], int64_t out[2]);
 int32_t ora_num_cores(void);
 

@@ -26,6 +26,9 @@ SRCS=(
   src/runtime/ThreadLocal.cpp
   src/runtime/ExecutionContext.cpp
   src/runtime/Sorting.cpp
+  src/runtime/Heap.cpp
+  src/runtime/SimpleState.cpp
+  src/runtime/Hashtable.cpp
   src/runtime/StringRuntime.cpp
   src/runtime/ListRuntime.cpp
   src/runtime/DateRuntime.cpp

@@ -20,6 +20,9 @@
 #include "lingodb/runtime/PreAggregationHashtable.h"
 #include "lingodb/runtime/ThreadLocal.h"
 #include "lingodb/runtime/helpers.h"
+#include "lingodb/runtime/Heap.h"
+#include "lingodb/runtime/Hashtable.h"
+#include "lingodb/runtime/SimpleState.h"
 #include "lingodb/runtime/DateRuntime.h"
 #include "lingodb/runtime/StringRuntime.h"
 #include "lingodb/runtime/storage/Restrictions.h"
@@ -298,5 +301,175 @@ int32_t ref_like(const char* str, int64_t str_len, const char* pat, int64_t pat_
    return runtime::StringRuntime::like(runtime::VarLen32::fromDataAndLen(str, (size_t) str_len, runtime::StorageClass::TRANSIENT), runtime::VarLen32::fromDataAndLen(pat, (size_t) pat_len, runtime::StorageClass::TRANSIENT)) ? 1 : 0;
 }
 int64_t ref_extract_year(int64_t date_ns) { return runtime::DateRuntime::extractYear(date_ns); }
+// StringRuntime::substr (src/runtime/StringRuntime.cpp:292-319): the real function behind SUBSTRING(… FROM … FOR …)
+int64_t ref_substr(const char* str, int64_t str_len, int64_t from, int64_t len, char* out, int64_t cap) {
+   runtime::VarLen32 r = runtime::StringRuntime::substr(runtime::VarLen32::fromDataAndLen(str, (size_t) str_len, runtime::StorageClass::TRANSIENT), from, len);
+   const int64_t n = (int64_t) r.getLen();
+   if (n <= cap) memcpy(out, r.data(), (size_t) n);
+   return n;
+}
+
+
+// ---- sort / top-k / key-less aggregation / generic hash map through the reference's own objects
+// Rows = {int64 keys[k], int64 row number}; the comparator restates db.sort_compare (LowerToStd.cpp:
+// 1046-1064: per key lt / eq selects, DESC by operand swap) as the generated `bool(uint8_t*, uint8_t*)`
+// the reference passes to GrowingBuffer::sort / Heap::create.  The row number is the last (ascending)
+// key so that the order is total: std::sort and the heap leave ties unspecified.
+static int32_t g_sort_k;
+static const int32_t* g_sort_desc;
+static bool sortCmp(uint8_t* l, uint8_t* r) {
+   const int64_t *a = reinterpret_cast<const int64_t*>(l), *b = reinterpret_cast<const int64_t*>(r);
+   for (int32_t j = 0; j < g_sort_k; j++) {
+      const int64_t x = g_sort_desc[j] ? b[j] : a[j], y = g_sort_desc[j] ? a[j] : b[j];
+      if (x < y) return true;
+      if (!(x == y)) return false;
+   }
+   return a[g_sort_k] < b[g_sort_k];
+}
+// GrowingBuffer::insert x n, GrowingBuffer::sort (GrowingBuffer.cpp:54-78 → parallelSort, Sorting.cpp:343-393, above 512 rows)
+int32_t ref_sort_rows(const int64_t* keys, int32_t k, const int32_t* desc, int64_t n, int32_t threads, uint32_t* out_perm) {
+   CtxScope scope(threads);
+   g_sort_k = k;
+   g_sort_desc = desc;
+   const size_t typeSize = sizeof(int64_t) * (size_t) (k + 1);
+   int32_t rc = 0;
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>(1, 1, [&](size_t, size_t, size_t) {
+      auto* gb = runtime::GrowingBuffer::create(runtime::GrowingBufferAllocator::getDefaultAllocator(), typeSize, 1024);
+      for (int64_t i = 0; i < n; i++) {
+         int64_t* row = reinterpret_cast<int64_t*>(gb->insert());
+         memcpy(row, keys + i * k, sizeof(int64_t) * (size_t) k);
+         row[k] = i;
+      }
+      runtime::Buffer sorted = gb->sort(sortCmp);
+      if (sorted.numElements != typeSize * (size_t) n) {
+         rc = -1;
+         return;
+      }
+      for (int64_t i = 0; i < n; i++) out_perm[i] = (uint32_t) reinterpret_cast<const int64_t*>(sorted.ptr + (size_t) i * typeSize)[k];
+   }));
+   return rc;
+}
+// Heap::create / insert per worker, Heap::merge, getBuffer (Heap.cpp:8-72): the k_top first rows of the order
+int64_t ref_topk_rows(const int64_t* keys, int32_t k, const int32_t* desc, int64_t n, int64_t k_top, int32_t threads, uint32_t* out_perm) {
+   CtxScope scope(threads);
+   g_sort_k = k;
+   g_sort_desc = desc;
+   const size_t typeSize = sizeof(int64_t) * (size_t) (k + 1);
+   struct Arg {
+      size_t kTop, typeSize;
+   } arg{(size_t) k_top, typeSize};
+   auto* tl = runtime::ThreadLocal::create([](uint8_t* a) -> uint8_t* {
+      auto* x = reinterpret_cast<Arg*>(a);
+      return reinterpret_cast<uint8_t*>(runtime::Heap::create(x->kTop, x->typeSize, sortCmp));
+   }, reinterpret_cast<uint8_t*>(&arg));
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>((size_t) n, 20000, [&](size_t b, size_t e, size_t) {
+      auto* heap = reinterpret_cast<runtime::Heap*>(tl->getLocal());
+      std::vector<int64_t> row((size_t) k + 1);
+      for (size_t i = b; i < e; i++) {
+         memcpy(row.data(), keys + i * (size_t) k, sizeof(int64_t) * (size_t) k);
+         row[(size_t) k] = (int64_t) i;
+         heap->insert(reinterpret_cast<uint8_t*>(row.data()));
+      }
+   }));
+   int64_t got = 0;
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>(1, 1, [&](size_t, size_t, size_t) {
+      runtime::Heap* merged = runtime::Heap::merge(tl);
+      if (!merged) return;
+      runtime::Buffer buf = merged->getBuffer();
+      got = (int64_t) (buf.numElements / typeSize);
+      for (int64_t i = 0; i < got; i++) out_perm[i] = (uint32_t) reinterpret_cast<const int64_t*>(buf.ptr + (size_t) i * typeSize)[k];
+   }));
+   return got;
+}
+// SimpleState::create per worker + SimpleState::merge with the generated combine (SimpleState.cpp:8-30,
+// MergeThreadLocalSimpleState, SubOpToControlFlow.cpp:1733): key-less SUM + COUNT over the rows passing `keep`
+struct SumCount {
+   __int128 sum;
+   int64_t count;
+};
+int32_t ref_simple_state_sum(const int64_t* vals, const uint8_t* keep, int64_t n, int32_t threads, int64_t out_lohi[2], int64_t* out_count) {
+   CtxScope scope(threads);
+   auto* tl = runtime::ThreadLocal::create([](uint8_t*) -> uint8_t* {
+      auto* st = reinterpret_cast<SumCount*>(runtime::SimpleState::create(sizeof(SumCount)));
+      st->sum = 0;
+      st->count = 0;
+      return reinterpret_cast<uint8_t*>(st);
+   }, nullptr);
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>((size_t) n, 20000, [&](size_t b, size_t e, size_t) {
+      auto* st = reinterpret_cast<SumCount*>(tl->getLocal());
+      for (size_t i = b; i < e; i++)
+         if (!keep || keep[i]) {
+            st->sum += vals[i];
+            st->count++;
+         }
+   }));
+   SumCount total{0, 0};
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>(1, 1, [&](size_t, size_t, size_t) {
+      auto* m = reinterpret_cast<SumCount*>(runtime::SimpleState::merge(tl, [](uint8_t* dst, uint8_t* src) {
+         reinterpret_cast<SumCount*>(dst)->sum += reinterpret_cast<SumCount*>(src)->sum;
+         reinterpret_cast<SumCount*>(dst)->count += reinterpret_cast<SumCount*>(src)->count;
+      }));
+      if (m) total = *m;
+   }));
+   out_lohi[0] = (int64_t) (uint64_t) total.sum;
+   out_lohi[1] = (int64_t) (total.sum >> 64);
+   *out_count = total.count;
+   return 0;
+}
+// the generic Hashtable (Hashtable.cpp:16-150: chained, doubling, thread-local tables merged with
+// mergeEntries): group-by of int64 keys with SUM + COUNT, as the non-pre-aggregated HashMap lowering uses it
+int64_t ref_hashtable_groupby_int64(const int64_t* keys, const uint64_t* hashes, const int64_t* vals, int64_t n, int64_t* out_keys, int64_t* out_sums, int64_t* out_counts,
+                                    int64_t cap, int32_t threads) {
+   CtxScope scope(threads);
+   const size_t typeSize = sizeof(void*) + sizeof(size_t) + sizeof(AggContent); // Entry{next, hashValue, content}
+   auto* tl = runtime::ThreadLocal::create([](uint8_t* arg) -> uint8_t* {
+      auto* ht = runtime::Hashtable::create(*reinterpret_cast<size_t*>(arg), 16);
+      ht->setEqFn(aggEq);
+      return reinterpret_cast<uint8_t*>(ht);
+   }, reinterpret_cast<uint8_t*>(const_cast<size_t*>(&typeSize)));
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>((size_t) n, 20000, [&](size_t b, size_t e, size_t) {
+      auto* ht = reinterpret_cast<runtime::Hashtable*>(tl->getLocal());
+      for (size_t i = b; i < e; i++) {
+         AggContent probe{keys[i], 0, 0};
+         const size_t before = ht->size();
+         auto* c = reinterpret_cast<AggContent*>(ht->lookUpOrInsert(hashes[i], reinterpret_cast<uint8_t*>(&probe)));
+         if (ht->size() != before) { // a fresh entry: the generated code initialises the new group's state here
+            c->key = keys[i];
+            c->sum = 0;
+            c->count = 0;
+         }
+         c->sum += vals[i];
+         c->count += 1;
+      }
+   }));
+   int64_t got = 0;
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>(1, 1, [&](size_t, size_t, size_t) {
+      auto* merged = runtime::Hashtable::merge(tl, aggEq, aggCombine);
+      if (!merged) return;
+      struct Out {
+         int64_t *keys, *sums, *counts;
+         int64_t n, cap;
+         size_t typeSize;
+      } o{out_keys, out_sums, out_counts, 0, cap, typeSize};
+      runtime::BufferIterator::iterate(
+         merged->createIterator(), false,
+         [](runtime::Buffer buf, void* arg) {
+            auto* st = reinterpret_cast<Out*>(arg);
+            const size_t cnt = buf.numElements / st->typeSize;
+            for (size_t k = 0; k < cnt; k++) {
+               auto* c = reinterpret_cast<AggContent*>(buf.ptr + k * st->typeSize + sizeof(void*) + sizeof(size_t));
+               if (st->n < st->cap) {
+                  st->keys[st->n] = c->key;
+                  st->sums[st->n] = c->sum;
+                  st->counts[st->n] = c->count;
+               }
+               st->n++;
+            }
+         },
+         &o);
+      got = o.n;
+   }));
+   return got;
+}
 
 } // extern "C"

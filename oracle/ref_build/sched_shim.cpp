@@ -6,6 +6,7 @@
 // from a worker (it runs the child task on the calling thread plus helper threads).
 #include <mutex>
 #include "lingodb/scheduler/Scheduler.h"
+#include "lingodb/runtime/ExecutionContext.h"
 
 #include <atomic>
 #include <cstdlib>
@@ -41,7 +42,14 @@ void runTask(lingodb::scheduler::Task* task) {
          runOn(task, w);
       });
    }
-   if (nested) runOn(task, self);
+   if (nested) {
+      // the calling worker takes part in the child task; Task::teardown() clears the thread's current
+      // ExecutionContext, which the rest of the PARENT task on this thread still needs (the reference's
+      // fibers give every task its own stack: parallelSort continues after its child tasks)
+      auto* saved = lingodb::runtime::getCurrentExecutionContext();
+      runOn(task, self);
+      lingodb::runtime::setCurrentExecutionContext(saved);
+   }
    for (auto& h : helpers) h.join();
 }
 } // namespace

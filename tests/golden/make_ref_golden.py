@@ -11,6 +11,9 @@ exist on the GPU box, so its answers travel as these files:
   ref_groupby.npz          PreAggregationHashtable fragment insert + merge, (key, sum, count)  (a9, a10)
   ref_like.json            StringRuntime::like answers
   ref_extract_year.json    DateRuntime::extractYear answers
+  ref_substr.json          StringRuntime::substr answers
+  ref_sort.npz             GrowingBuffer::sort / parallelSort permutations (multi-key, DESC), Heap top-k prefixes,
+                           SimpleState SUM + COUNT, generic Hashtable group-by                (a11, a12, a13, a14)
 
 Run from the repo root where /root/reference exists:  python tests/golden/make_ref_golden.py
 Consumers: tests/test_golden_fixtures.py (oracle, CPU) and tests/test_gpu_z_golden.py (HIP path)."""
@@ -44,6 +47,12 @@ FILTER_CASES = [
     [{"col": "l_shipmode", "op": "GTE", "v": "TRUCK"}],
     [{"col": "l_orderkey", "op": "LT", "v": 0}],
 ]
+
+
+def tv_table_hashes(ora, keys):
+    """db.hash of an int64 key column through the oracle (pinned against the reference's Hash.cpp above)"""
+    t = oracle_bind.HostTable(pa.table({"k": pa.array(keys, pa.int64())}))
+    return ora.hash_keys(t.rel(), [(0, 0)])
 
 
 def types_table():
@@ -133,6 +142,62 @@ def main():
     out = [[s, pt, bool(lib.ref_like(s.encode(), len(s.encode()), pt.encode(), len(pt.encode())))] for s, pt in cases]
     with open(os.path.join(HERE, "ref_like.json"), "w") as f:
         json.dump(out, f, ensure_ascii=True)
+
+    # ---- substr
+    lib.ref_substr.restype = C.c_int64
+    lib.ref_substr.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_int64]
+    rng = np.random.default_rng(11)
+    alpha_s = list("ab-12 xyz") + ["é", "€", "ß", "𝄞"]
+    sub = []
+    for _ in range(1500):
+        st = "".join(rng.choice(alpha_s, rng.integers(0, 20)))
+        fr, ln = int(rng.integers(-3, 24)), int(rng.integers(-2, 24))
+        buf = C.create_string_buffer(256)
+        b = st.encode()
+        n = lib.ref_substr(b, len(b), fr, ln, buf, 256)
+        sub.append([st, fr, ln, buf.raw[:n].decode()])
+    with open(os.path.join(HERE, "ref_substr.json"), "w") as f:
+        json.dump(sub, f, ensure_ascii=True)
+
+    # ---- sort / top-k / key-less aggregation / generic hash map (Sorting.cpp, Heap.cpp, SimpleState.cpp, Hashtable.cpp)
+    lib.ref_sort_rows.restype = C.c_int32
+    lib.ref_sort_rows.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+    lib.ref_topk_rows.restype = C.c_int64
+    lib.ref_topk_rows.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
+    lib.ref_simple_state_sum.restype = C.c_int32
+    lib.ref_simple_state_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.ref_hashtable_groupby_int64.restype = C.c_int64
+    lib.ref_hashtable_groupby_int64.argtypes = [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 3 + [C.c_int64, C.c_int32]
+    rng = np.random.default_rng(12)
+    out = {}
+    for name, n, k, desc in (("small", 300, 2, [0, 1]), ("tie_heavy", 5000, 3, [1, 0, 0]), ("large", 200000, 2, [1, 1])):  # > 512 rows → parallelSort
+        keys = np.stack([rng.integers(0, 5 if j == 0 else 1000, n) for j in range(k)], axis=1).astype(np.int64)
+        if name == "large":
+            keys[:, 0] = rng.integers(-10**12, 10**12, n)
+        d = np.array(desc, dtype=np.int32)
+        perm = np.zeros(n, dtype=np.uint32)
+        assert lib.ref_sort_rows(keys.ctypes.data, k, d.ctypes.data, n, 4, perm.ctypes.data) == 0
+        out[f"{name}_keys"], out[f"{name}_desc"], out[f"{name}_perm"] = keys, d, perm
+        for kt in (1, 10, 100):
+            top = np.zeros(kt, dtype=np.uint32)
+            got = lib.ref_topk_rows(keys.ctypes.data, k, d.ctypes.data, n, kt, 4, top.ctypes.data)
+            out[f"{name}_top{kt}"] = top[:got]
+    vals = rng.integers(-10**15, 10**15, 100000).astype(np.int64)
+    keep = (rng.integers(0, 3, 100000) > 0).astype(np.uint8)
+    lohi, cnt = (C.c_int64 * 2)(), C.c_int64()
+    lib.ref_simple_state_sum(vals.ctypes.data, keep.ctypes.data, len(vals), 4, lohi, C.byref(cnt))
+    out["ss_vals"], out["ss_keep"], out["ss_sum_lohi"], out["ss_count"] = vals, keep, np.array([lohi[0], lohi[1]], dtype=np.int64), np.array([cnt.value])
+    nothing = np.zeros(len(vals), dtype=np.uint8)
+    lib.ref_simple_state_sum(vals.ctypes.data, nothing.ctypes.data, len(vals), 4, lohi, C.byref(cnt))
+    out["ss_empty_count"] = np.array([cnt.value])
+    gk = rng.integers(0, 3000, 150000).astype(np.int64) * 7919 - 10**6
+    gv = rng.integers(-10**9, 10**9, 150000).astype(np.int64)
+    ht = tv_table_hashes(ora, gk)
+    ok_, os_, oc_ = np.zeros(4000, np.int64), np.zeros(4000, np.int64), np.zeros(4000, np.int64)
+    g = lib.ref_hashtable_groupby_int64(gk.ctypes.data, ht.ctypes.data, gv.ctypes.data, len(gk), ok_.ctypes.data, os_.ctypes.data, oc_.ctypes.data, 4000, 4)
+    order = np.argsort(ok_[:g])
+    out["ht_keys"], out["ht_vals"], out["ht_out_keys"], out["ht_out_sums"], out["ht_out_counts"] = gk, gv, ok_[:g][order], os_[:g][order], oc_[:g][order]
+    np.savez_compressed(os.path.join(HERE, "ref_sort.npz"), **out)
 
     # ---- extract(year)
     rng = np.random.default_rng(8)

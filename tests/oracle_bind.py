@@ -189,6 +189,8 @@ class Oracle:
         lib.ora_num_cores.restype = C.c_int32
         lib.ora_like.restype = C.c_int32
         lib.ora_like.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]
+        lib.ora_substr.restype = None
+        lib.ora_substr.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.ora_extract_year.restype = C.c_int64
         lib.ora_extract_year.argtypes = [C.c_int64]
         p64 = C.POINTER(C.c_int64)
@@ -283,6 +285,12 @@ class Oracle:
         s = s.encode() if isinstance(s, str) else s
         pattern = pattern.encode() if isinstance(pattern, str) else pattern
         return bool(self.lib.ora_like(s, len(s), pattern, len(pattern)))
+
+    def substr(self, s, start, length):
+        b = s.encode() if isinstance(s, str) else s
+        b0, b1 = C.c_int64(), C.c_int64()
+        self.lib.ora_substr(b, len(b), start, length, C.byref(b0), C.byref(b1))
+        return b[b0.value : b1.value]
 
     def extract_year(self, days):
         return int(self.lib.ora_extract_year(int(days)))

@@ -7,7 +7,10 @@ import pyarrow as pa
 
 from lingodb_amd import api, capi
 from oracle_bind import HostTable
+import os
+
 import golden_io
+from golden_io import GOLDEN
 import tpch_data
 
 
@@ -99,3 +102,66 @@ def test_oracle_sqlite_small_join_cases(oracle):
     for case in cases:
         got, want = golden_io.run_sqlite_join_case(case, join)
         assert got == want, case["source"]
+
+
+# ---- sort / top-k / key-less aggregation / generic hash map / substr: answers of the reference's own
+# Sorting.cpp (GrowingBuffer::sort → parallelSort), Heap.cpp, SimpleState.cpp, Hashtable.cpp, StringRuntime::substr
+def _sort_cases():
+    import numpy as np
+
+    z = np.load(os.path.join(GOLDEN, "ref_sort.npz"))
+    return z, ["small", "tie_heavy", "large"]
+
+
+def _keys_table(keys):
+    import pyarrow as pa
+
+    return pa.table({"k%d" % j: pa.array(keys[:, j], pa.int64()) for j in range(keys.shape[1])})
+
+
+def test_oracle_sort_and_topk_match_reference_objects(oracle):
+    import numpy as np
+
+    from lingodb_amd import api
+    from oracle_bind import HostTable
+
+    z, names = _sort_cases()
+    for name in names:
+        keys, desc, perm = z[name + "_keys"], z[name + "_desc"], z[name + "_perm"]
+        t = HostTable(_keys_table(keys))
+        specs = [api.sort_spec((0, j), bool(desc[j])) for j in range(keys.shape[1])]
+        assert np.array_equal(oracle.sort(t.rel(), specs), perm), name  # the oracle's sort is stable = the fixture's row-number tie-break
+        for kt in (1, 10, 100):
+            assert np.array_equal(oracle.topk(t.rel(), specs, kt), z[f"{name}_top{kt}"]), (name, kt)
+
+
+def test_oracle_keyless_and_hashmap_match_reference_objects(oracle):
+    import numpy as np
+    import pyarrow as pa
+
+    from lingodb_amd import api, capi
+    from oracle_bind import HostTable
+
+    z, _ = _sort_cases()
+    t = HostTable(pa.table({"v": pa.array(z["ss_vals"], pa.int64()), "keep": pa.array(z["ss_keep"].astype(np.int32), pa.int32())}))
+    aggs = [api.agg(capi.AGG_SUM, api.col_expr((0, 0)), wide=True, out_type=capi.T_DECIMAL128, p=38, s=0), api.agg(capi.AGG_COUNT_STAR)]
+    _, vals, valid = oracle.groupby(t.rel(), [], aggs, [api.pred((0, 1), capi.F_EQ, 1)])
+    want = (int(z["ss_sum_lohi"][1]) << 64) | (int(z["ss_sum_lohi"][0]) & 0xFFFFFFFFFFFFFFFF)
+    sgn = lambda v: v - (1 << 128) if v >= 1 << 127 else v
+    assert sgn(vals[0][0]) == sgn(want) and vals[0][1] == int(z["ss_count"][0])
+    _, vals0, valid0 = oracle.groupby(t.rel(), [], aggs, [api.pred((0, 1), capi.F_EQ, 7)])  # nothing passes: SUM is NULL, COUNT 0 (SimpleState over no rows)
+    assert not valid0[0][0] and vals0[0][1] == 0 == int(z["ss_empty_count"][0])
+    g = HostTable(pa.table({"k": pa.array(z["ht_keys"], pa.int64()), "v": pa.array(z["ht_vals"], pa.int64())}))
+    rep, gv, _ = oracle.groupby(g.rel(), [(0, 0)], [api.agg(capi.AGG_SUM, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT_STAR)])
+    got = sorted((int(z["ht_keys"][r]), sgn(v[0]), v[1]) for r, v in zip(rep, gv))
+    assert got == list(zip(z["ht_out_keys"].tolist(), z["ht_out_sums"].tolist(), z["ht_out_counts"].tolist()))
+
+
+def test_oracle_substr_matches_reference_string_runtime(oracle):
+    import json
+
+    with open(os.path.join(GOLDEN, "ref_substr.json")) as f:
+        cases = json.load(f)
+    assert len(cases) >= 1000
+    for s, fr, ln, want in cases:
+        assert oracle.substr(s, fr, ln).decode() == want, (s, fr, ln)

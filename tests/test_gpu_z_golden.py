@@ -153,3 +153,57 @@ def test_device_sqlite_small_groupby_cases(ctx):
     out = il.materialize([(0, 0), (1, 0), (1, 1)]).to_arrow()  # two columns are called "i": read by position
     rows = list(zip(*[out.column(c).to_pylist() for c in range(3)]))
     assert sorted(rows, key=repr) == sorted([(1, 1, 2), (2, 2, 2), (3, 3, 2), (4, None, None)], key=repr)
+
+
+# ---- Sorting.cpp / Heap.cpp / SimpleState.cpp / Hashtable.cpp / StringRuntime::substr answers (ref_sort.npz, ref_substr.json)
+def test_sort_topk_keyless_hashmap_match_reference_objects(ctx):
+    import os
+
+    import numpy as np
+    import pyarrow as pa
+
+    from golden_io import GOLDEN
+    from lingodb_amd import api, capi
+
+    z = np.load(os.path.join(GOLDEN, "ref_sort.npz"))
+    for name in ("small", "tie_heavy", "large"):
+        keys, desc, perm = z[name + "_keys"], z[name + "_desc"], z[name + "_perm"]
+        dev = ctx.register("sortkeys_" + name, pa.table({"k%d" % j: pa.array(keys[:, j], pa.int64()) for j in range(keys.shape[1])}))
+        specs = [api.sort_spec((0, j), bool(desc[j])) for j in range(keys.shape[1])]
+        assert np.array_equal(dev.rel().sort(specs).rowids(0), perm), name  # ldb_gpu_sort is stable = the fixture's row-number tie-break
+        for kt in (1, 10, 100):
+            assert np.array_equal(dev.rel().topk(specs, kt).rowids(0), z[f"{name}_top{kt}"]), (name, kt)
+    t = ctx.register("ss", pa.table({"v": pa.array(z["ss_vals"], pa.int64()), "keep": pa.array(z["ss_keep"].astype(np.int32), pa.int32())}))
+    aggs = [api.agg(capi.AGG_SUM, api.col_expr((0, 0)), wide=True, out_type=capi.T_DECIMAL128, p=38, s=0), api.agg(capi.AGG_COUNT_STAR)]
+    row = t.rel().groupby([], aggs, [api.pred((0, 1), capi.F_EQ, 1)]).to_arrow().to_pylist()[0]
+    want = (int(z["ss_sum_lohi"][1]) << 64) | (int(z["ss_sum_lohi"][0]) & 0xFFFFFFFFFFFFFFFF)
+    want = want - (1 << 128) if want >> 127 else want
+    assert int(row["agg0"]) == want and row["agg1"] == int(z["ss_count"][0])
+    none = t.rel().groupby([], aggs, [api.pred((0, 1), capi.F_EQ, 7)]).to_arrow().to_pylist()[0]
+    assert none["agg0"] is None and none["agg1"] == 0
+    g = ctx.register("htg", pa.table({"k": pa.array(z["ht_keys"], pa.int64()), "v": pa.array(z["ht_vals"], pa.int64())}))
+    res = g.rel().groupby([(0, 0)], [api.agg(capi.AGG_SUM, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT_STAR)], est_groups=3000).to_arrow()
+    got = sorted(zip(res.column(0).to_pylist(), res.column(1).to_pylist(), res.column(2).to_pylist()))
+    assert got == list(zip(z["ht_out_keys"].tolist(), z["ht_out_sums"].tolist(), z["ht_out_counts"].tolist()))
+
+
+def test_substr_matches_reference_string_runtime(ctx):
+    import json
+    import os
+
+    import pyarrow as pa
+
+    from golden_io import GOLDEN
+
+    with open(os.path.join(GOLDEN, "ref_substr.json")) as f:
+        cases = json.load(f)
+    by_args = {}
+    for s, fr, ln, want in cases:
+        by_args.setdefault((fr, ln), []).append((s, want))
+    done = 0
+    for (fr, ln), rows in sorted(by_args.items(), key=lambda kv: -len(kv[1]))[:60]:
+        dev = ctx.register("substr_in", pa.table({"s": pa.array([r[0] for r in rows] + [None])}))
+        got = dev.rel().map_substr((0, 0), fr, ln).to_arrow().column(0).to_pylist()
+        assert got == [r[1] for r in rows] + [None], (fr, ln)
+        done += len(rows)
+    assert done >= 100
