@@ -138,6 +138,10 @@ int32_t ldb_gpu_prof_reset(ldb_ctx* ctx);
 int32_t ldb_gpu_prof_get(ldb_ctx* ctx, const char* kernel_name, int64_t* launches, double* total_ms);
 /* names of all kernels seen so far, '\n'-separated, into buf */
 int32_t ldb_gpu_prof_names(ldb_ctx* ctx, char* buf, int32_t cap);
+/* Trace marker: launches the empty kernel `k_ldb_marker` with a grid of `id` (1 … 65535)
+ * workgroups on the ctx stream.  A `rocprofv3 --kernel-trace` of a run that brackets each query with
+ * markers can be cut into per-query timelines by the marker's grid size (tools/timeline_summary.py). */
+int32_t ldb_gpu_prof_marker(ldb_ctx* ctx, int32_t id);
 
 /* Run-time kernel specialisation (the role LLVM JIT plays in the reference,
  * src/execution/LLVMBackends.cpp:219-406): kernels compiled / cache hits / compile time so far,

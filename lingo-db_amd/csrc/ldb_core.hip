@@ -197,6 +197,14 @@ extern "C" int32_t ldb_gpu_device_info(ldb_ctx* ctx, char* name, int32_t name_ca
    return LDB_OK;
 }
 
+__global__ void k_ldb_marker() {}
+extern "C" int32_t ldb_gpu_prof_marker(ldb_ctx* ctx, int32_t id) {
+   if (!ctx || id < 1 || id > 65535) LDB_FAIL(LDB_ERR_INVALID, "prof_marker: id must be in 1..65535");
+   hipLaunchKernelGGL(k_ldb_marker, dim3((unsigned) id), dim3(64), 0, ctx->stream);
+   LDB_HIP(hipGetLastError());
+   return LDB_OK;
+}
+
 extern "C" int32_t ldb_gpu_timer_create(ldb_ctx* ctx, int32_t* timer_id) {
    hipEvent_t a, b;
    LDB_HIP(hipEventCreate(&a));
@@ -952,7 +960,7 @@ int32_t ldb_column_range(ldb_ctx* ctx, const ldb_table* t, int32_t col, int64_t*
          dc.precision = c.type.precision;
          dc.scale = c.type.scale;
          LDB_HIP(hipMemcpyAsync(d_out, init, 16, hipMemcpyHostToDevice, ctx->stream));
-         hipLaunchKernelGGL(k_column_range, dim3(std::min(ldb_grid_for(ctx, t->n_rows, 256, 8), 256)), dim3(256), 0, ctx->stream, dc, (uint64_t) t->n_rows, d_out);
+         hipLaunchKernelGGL(k_column_range, dim3(ldb_grid_for(ctx, t->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dc, (uint64_t) t->n_rows, d_out);
          LDB_HIP(hipMemcpyAsync(got, d_out, 16, hipMemcpyDeviceToHost, ctx->stream));
          LDB_HIP(hipStreamSynchronize(ctx->stream));
       }
@@ -1027,27 +1035,24 @@ __global__ void k_gather_fixed(const T* __restrict__ src, const uint32_t* __rest
       dst[i] = v;
    }
 }
-__global__ void k_gather_valid(const uint8_t* __restrict__ validity, const uint32_t* __restrict__ rowids, uint8_t* __restrict__ out_bytes, uint64_t n) {
-   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-      uint32_t r = rowids ? rowids[i] : (uint32_t) i;
-      bool ok = r != LDB_NULL_ROW && (!validity || ((validity[r >> 3] >> (r & 7)) & 1));
-      out_bytes[i] = ok ? 1 : 0;
-   }
-}
-__global__ void k_pack_valid(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bitmap, uint64_t n, unsigned long long* null_count) {
-   uint64_t nb = (n + 7) / 8;
-   for (uint64_t b = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; b < nb; b += (uint64_t) gridDim.x * blockDim.x) {
-      uint8_t m = 0;
-      int nulls = 0;
-      for (int k = 0; k < 8; k++) {
-         uint64_t i = b * 8 + k;
-         if (i < n) {
-            if (bytes[i]) m |= (uint8_t) (1u << k);
-            else nulls++;
-         }
+// validity bitmap of a gathered column + its NULL count in one pass: one row per lane, the wave's
+// ballot is the 64-bit bitmap word (the bitmap buffer is 8-byte granular: ldb_dev_alloc pads)
+__global__ void k_gather_validity(const uint8_t* __restrict__ validity, const uint32_t* __restrict__ rowids, uint64_t* __restrict__ bitmap_words, uint64_t n,
+                                  unsigned long long* __restrict__ null_count) {
+   const uint64_t n_pad = (n + 63) & ~(uint64_t) 63;
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n_pad; i += (uint64_t) gridDim.x * blockDim.x) {
+      bool ok = false;
+      if (i < n) {
+         const uint32_t r = rowids ? rowids[i] : (uint32_t) i;
+         ok = r != LDB_NULL_ROW && (!validity || ((validity[r >> 3] >> (r & 7)) & 1));
       }
-      bitmap[b] = m;
-      if (nulls) atomicAdd(null_count, (unsigned long long) nulls);
+      const uint64_t m = __ballot(ok);
+      if ((threadIdx.x & 63) == 0) {
+         bitmap_words[i >> 6] = m;
+         const uint64_t rows_here = n - i >= 64 ? ~(uint64_t) 0 : (((uint64_t) 1 << (n - i)) - 1);
+         const int nulls = __popcll(~m & rows_here);
+         if (nulls) atomicAdd(null_count, (unsigned long long) nulls);
+      }
    }
 }
 __global__ void k_str_lens(const int64_t* __restrict__ offsets, const uint32_t* __restrict__ rowids, int64_t* __restrict__ lens, uint64_t n) {
@@ -1057,7 +1062,8 @@ __global__ void k_str_lens(const int64_t* __restrict__ offsets, const uint32_t* 
    }
 }
 __global__ void k_str_copy(const uint8_t* __restrict__ src, const int64_t* __restrict__ src_off, const uint32_t* __restrict__ rowids,
-                           const int64_t* __restrict__ dst_off, uint8_t* __restrict__ dst, uint64_t n) {
+                           int64_t* __restrict__ dst_off, uint8_t* __restrict__ dst, uint64_t n, int64_t total) {
+   if (blockIdx.x == 0 && threadIdx.x == 0) dst_off[n] = total; // the closing offset of the Arrow layout
    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
       uint32_t r = rowids ? rowids[i] : (uint32_t) i;
       if (r == LDB_NULL_ROW) continue;
@@ -1070,80 +1076,112 @@ struct u128x {
    uint64_t a, b;
 };
 
-// gather one column of `r` into a new owned column
-int32_t ldb_gather_column(ldb_ctx* ctx, const ldb_rel* r, ldb_colref ref, ldb_column* out) {
-   DCol dcol;
-   LDB_TRY(ldb_make_dcol(r, ref, &dcol));
-   struct {
-      const uint32_t* rowids;
-   } dc{(const uint32_t*) dcol.rowids};
-   const ldb_column& src = r->sides[(size_t) ref.side].table->cols[(size_t) ref.col];
+// Gather columns of `r` into new owned columns.  All launches of all columns are queued first; the
+// NULL counts of the nullable ones and the byte totals of the string ones come back in ONE read
+// (one stream synchronisation per call, none when no column is nullable or a string).  A column
+// can be NULL in the result only if the source column has a validity bitmap or its side carries
+// outer-join padding (ldb_rel_side::may_null).
+int32_t ldb_gather_columns(ldb_ctx* ctx, const ldb_rel* r, const ldb_colref* refs, int32_t n_cols, ldb_column* outs) {
    const uint64_t n = (uint64_t) r->n_rows;
-   out->name = src.name;
-   out->type = src.type;
-   out->width = src.width;
-   out->owned = true;
-   int grid = ldb_grid_for(ctx, (int64_t) n, 256, 8);
-   bool outer = false; // rows may carry LDB_NULL_ROW only through rowids
-   if (dc.rowids) outer = true;
-   if (src.validity || outer) {
-      uint8_t* bytes;
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &bytes, (size_t) n));
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &out->validity, (size_t) ((n + 7) / 8)));
-      LDB_HIP(hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
-      hipLaunchKernelGGL(k_gather_valid, dim3(grid), dim3(256), 0, ctx->stream, src.validity, dc.rowids, bytes, n);
-      hipLaunchKernelGGL(k_pack_valid, dim3(grid), dim3(256), 0, ctx->stream, bytes, out->validity, n, (unsigned long long*) ctx->d_scratch);
-      uint64_t nulls = 0;
-      LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &nulls));
-      ldb_dev_free(ctx, bytes);
-      out->null_count = (int64_t) nulls;
-      if (nulls == 0) {
-         ldb_dev_free(ctx, out->validity);
-         out->validity = nullptr;
+   const int grid = ldb_grid_for(ctx, (int64_t) n, 256, 8);
+   struct Pending {
+      int32_t col;
+      int slot_nulls = -1, slot_bytes = -1;
+      const uint32_t* rowids = nullptr;
+      int64_t* lens = nullptr;
+   };
+   std::vector<Pending> pend((size_t) n_cols);
+   int n_slots = 0;
+   for (int32_t c = 0; c < n_cols; c++) {
+      const ldb_rel_side& side = r->sides[(size_t) refs[c].side];
+      const ldb_column& src = side.table->cols[(size_t) refs[c].col];
+      pend[(size_t) c].col = c;
+      if (src.validity || (side.rowids && side.may_null)) pend[(size_t) c].slot_nulls = n_slots++;
+      if (src.type.type == LDB_T_UTF8) pend[(size_t) c].slot_bytes = n_slots++;
+   }
+   unsigned long long* d_words = nullptr;
+   if (n_slots) {
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_words, 8 * (size_t) n_slots));
+      LDB_HIP(hipMemsetAsync(d_words, 0, 8 * (size_t) n_slots, ctx->stream));
+   }
+   for (int32_t c = 0; c < n_cols; c++) {
+      Pending& p = pend[(size_t) c];
+      DCol dcol;
+      LDB_TRY(ldb_make_dcol(r, refs[c], &dcol));
+      p.rowids = (const uint32_t*) dcol.rowids;
+      const ldb_column& src = r->sides[(size_t) refs[c].side].table->cols[(size_t) refs[c].col];
+      ldb_column* out = &outs[c];
+      out->name = src.name;
+      out->type = src.type;
+      out->width = src.width;
+      out->owned = true;
+      if (p.slot_nulls >= 0) {
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &out->validity, (size_t) ((n + 7) / 8 + 8)));
+         if (n) hipLaunchKernelGGL(k_gather_validity, dim3(grid), dim3(256), 0, ctx->stream, src.validity, p.rowids, (uint64_t*) out->validity, n, d_words + p.slot_nulls);
+      }
+      if (src.type.type == LDB_T_UTF8) {
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &p.lens, sizeof(int64_t) * (size_t) (n + 1)));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &out->offsets, sizeof(int64_t) * (size_t) (n + 1)));
+         hipLaunchKernelGGL(k_str_lens, dim3(grid), dim3(256), 0, ctx->stream, src.offsets, p.rowids, p.lens, n);
+         LDB_TRY(ldb_exclusive_scan_i64(ctx, p.lens, out->offsets, (int64_t) n, (int64_t*) (d_words + p.slot_bytes)));
+      } else {
+         out->value_bytes = (int64_t) n * src.width;
+         LDB_TRY(ldb_dev_alloc(ctx, &out->values, (size_t) out->value_bytes));
+         switch (src.width) {
+            case 1: hipLaunchKernelGGL(k_gather_fixed<uint8_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*) src.values, p.rowids, (uint8_t*) out->values, n); break;
+            case 2: hipLaunchKernelGGL(k_gather_fixed<uint16_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint16_t*) src.values, p.rowids, (uint16_t*) out->values, n); break;
+            case 4: hipLaunchKernelGGL(k_gather_fixed<uint32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*) src.values, p.rowids, (uint32_t*) out->values, n); break;
+            case 8: hipLaunchKernelGGL(k_gather_fixed<uint64_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint64_t*) src.values, p.rowids, (uint64_t*) out->values, n); break;
+            default: hipLaunchKernelGGL(k_gather_fixed<u128x>, dim3(grid), dim3(256), 0, ctx->stream, (const u128x*) src.values, p.rowids, (u128x*) out->values, n); break;
+         }
       }
    }
-   if (src.type.type == LDB_T_UTF8) {
-      int64_t* lens;
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &lens, sizeof(int64_t) * (size_t) (n + 1)));
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &out->offsets, sizeof(int64_t) * (size_t) (n + 1)));
-      hipLaunchKernelGGL(k_str_lens, dim3(grid), dim3(256), 0, ctx->stream, src.offsets, dc.rowids, lens, n);
-      LDB_TRY(ldb_exclusive_scan_i64(ctx, lens, out->offsets, (int64_t) n, out->offsets + n));
-      uint64_t total = 0;
-      LDB_TRY(ldb_read_u64(ctx, out->offsets + n, &total));
-      ldb_dev_free(ctx, lens);
-      out->value_bytes = (int64_t) total;
-      LDB_TRY(ldb_dev_alloc(ctx, &out->values, (size_t) total));
-      hipLaunchKernelGGL(k_str_copy, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*) src.values, src.offsets, dc.rowids, out->offsets,
-                         (uint8_t*) out->values, n);
-   } else {
-      out->value_bytes = (int64_t) n * src.width;
-      LDB_TRY(ldb_dev_alloc(ctx, &out->values, (size_t) out->value_bytes));
-      switch (src.width) {
-         case 1: hipLaunchKernelGGL(k_gather_fixed<uint8_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*) src.values, dc.rowids, (uint8_t*) out->values, n); break;
-         case 2: hipLaunchKernelGGL(k_gather_fixed<uint16_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint16_t*) src.values, dc.rowids, (uint16_t*) out->values, n); break;
-         case 4: hipLaunchKernelGGL(k_gather_fixed<uint32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*) src.values, dc.rowids, (uint32_t*) out->values, n); break;
-         case 8: hipLaunchKernelGGL(k_gather_fixed<uint64_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint64_t*) src.values, dc.rowids, (uint64_t*) out->values, n); break;
-         default: hipLaunchKernelGGL(k_gather_fixed<u128x>, dim3(grid), dim3(256), 0, ctx->stream, (const u128x*) src.values, dc.rowids, (u128x*) out->values, n); break;
+   LDB_HIP(hipGetLastError());
+   if (!n_slots) return LDB_OK;
+   std::vector<unsigned long long> words((size_t) n_slots);
+   LDB_HIP(hipMemcpyAsync(words.data(), d_words, 8 * (size_t) n_slots, hipMemcpyDeviceToHost, ctx->stream));
+   LDB_HIP(hipStreamSynchronize(ctx->stream));
+   ldb_dev_free(ctx, d_words);
+   for (int32_t c = 0; c < n_cols; c++) {
+      Pending& p = pend[(size_t) c];
+      ldb_column* out = &outs[c];
+      if (p.slot_nulls >= 0) {
+         out->null_count = (int64_t) words[(size_t) p.slot_nulls];
+         if (out->null_count == 0) {
+            ldb_dev_free(ctx, out->validity);
+            out->validity = nullptr;
+         }
+      }
+      if (p.slot_bytes >= 0) {
+         const ldb_column& src = r->sides[(size_t) refs[c].side].table->cols[(size_t) refs[c].col];
+         const uint64_t total = words[(size_t) p.slot_bytes];
+         ldb_dev_free(ctx, p.lens);
+         out->value_bytes = (int64_t) total;
+         LDB_TRY(ldb_dev_alloc(ctx, &out->values, (size_t) total));
+         hipLaunchKernelGGL(k_str_copy, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*) src.values, src.offsets, p.rowids, out->offsets, (uint8_t*) out->values, n,
+                            (int64_t) total);
       }
    }
    LDB_HIP(hipGetLastError());
    return LDB_OK;
 }
+int32_t ldb_gather_column(ldb_ctx* ctx, const ldb_rel* r, ldb_colref ref, ldb_column* out) { return ldb_gather_columns(ctx, r, &ref, 1, out); }
 
 extern "C" int32_t ldb_gpu_materialize(ldb_ctx* ctx, ldb_rel* r, const ldb_colref* cols, int32_t n_cols, ldb_table** out) {
    if (!ctx || !r || !out || n_cols < 0) LDB_FAIL(LDB_ERR_INVALID, "materialize: bad argument");
    LDB_TRY(ldb_rel_force(ctx, r));
+   for (int32_t c = 0; c < n_cols; c++)
+      if (cols[c].side < 0 || (size_t) cols[c].side >= r->sides.size() || cols[c].col < 0 || (size_t) cols[c].col >= r->sides[(size_t) cols[c].side].table->cols.size())
+         LDB_FAIL(LDB_ERR_INVALID, "materialize: column %d:%d out of range", cols[c].side, cols[c].col);
    auto t = std::make_unique<ldb_table>();
    t->ctx = ctx;
    t->name = "materialized";
    t->n_rows = r->n_rows;
    t->cols.resize((size_t) n_cols);
-   for (int32_t c = 0; c < n_cols; c++) {
-      int32_t s = ldb_gather_column(ctx, r, cols[c], &t->cols[(size_t) c]);
-      if (s != LDB_OK) {
-         ldb_gpu_table_release(ctx, t.release());
-         return s;
-      }
+   int32_t s = ldb_gather_columns(ctx, r, cols, n_cols, t->cols.data());
+   if (s != LDB_OK) {
+      ldb_gpu_table_release(ctx, t.release());
+      return s;
    }
    *out = t.release();
    return LDB_OK;
@@ -1151,8 +1189,8 @@ extern "C" int32_t ldb_gpu_materialize(ldb_ctx* ctx, ldb_rel* r, const ldb_colre
 
 // ---------------------------------------------------------------- exclusive scans
 // Single-pass-per-level scan: per-block sums → recursive scan of the sums → add back.
-template <typename T, typename TO>
-__global__ void k_scan_block(const T* __restrict__ in, TO* __restrict__ out, TO* __restrict__ block_sums, uint64_t n) {
+template <typename T, typename TO, typename TT>
+__global__ void k_scan_block(const T* __restrict__ in, TO* __restrict__ out, TO* __restrict__ block_sums, uint64_t n, TT* __restrict__ total) {
    __shared__ TO sh[256];
    const int ITEMS = 8;
    uint64_t base = (uint64_t) blockIdx.x * 256 * ITEMS + (uint64_t) threadIdx.x * ITEMS;
@@ -1172,7 +1210,10 @@ __global__ void k_scan_block(const T* __restrict__ in, TO* __restrict__ out, TO*
       __syncthreads();
    }
    TO excl = sh[threadIdx.x] - sum;
-   if (threadIdx.x == 255 && block_sums) block_sums[blockIdx.x] = sh[255];
+   if (threadIdx.x == 255) {
+      if (block_sums) block_sums[blockIdx.x] = sh[255];
+      if (total && gridDim.x == 1) *total = (TT) sh[255]; // the last level of the recursion holds the grand total
+   }
 #pragma unroll
    for (int k = 0; k < ITEMS; k++) {
       if (base + k < n) out[base + k] = excl;
@@ -1188,43 +1229,32 @@ __global__ void k_scan_add(TO* __restrict__ out, const TO* __restrict__ block_of
    for (int k = 0; k < ITEMS; k++)
       if (base + k < n) out[base + k] += add;
 }
-template <typename TO>
-__global__ void k_store_total(const TO* last_excl, const TO* last_sum_src, TO* total) { *total = *last_excl + *last_sum_src; }
-
-template <typename T, typename TO>
-static int32_t scan_impl(ldb_ctx* ctx, const T* d_in, TO* d_out, int64_t n, TO* d_total) {
+template <typename T, typename TO, typename TT>
+static int32_t scan_impl(ldb_ctx* ctx, const T* d_in, TO* d_out, int64_t n, TT* d_total) {
    if (n <= 0) {
-      if (d_total) LDB_HIP(hipMemsetAsync(d_total, 0, sizeof(TO), ctx->stream));
+      if (d_total) LDB_HIP(hipMemsetAsync(d_total, 0, sizeof(TT), ctx->stream));
       return LDB_OK;
    }
    const int64_t per_block = 256 * 8;
    int64_t nb = (n + per_block - 1) / per_block;
-   TO* sums;
-   LDB_TRY(ldb_dev_alloc(ctx, (void**) &sums, sizeof(TO) * (size_t) (nb + 1)));
-   hipLaunchKernelGGL((k_scan_block<T, TO>), dim3((unsigned) nb), dim3(256), 0, ctx->stream, d_in, d_out, sums, (uint64_t) n);
+   TO* sums = nullptr;
+   if (nb > 1) LDB_TRY(ldb_dev_alloc(ctx, (void**) &sums, sizeof(TO) * (size_t) (nb + 1)));
+   hipLaunchKernelGGL((k_scan_block<T, TO, TT>), dim3((unsigned) nb), dim3(256), 0, ctx->stream, d_in, d_out, sums, (uint64_t) n, d_total);
    if (nb > 1) {
       TO* sums_scanned;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &sums_scanned, sizeof(TO) * (size_t) (nb + 1)));
-      LDB_TRY((scan_impl<TO, TO>(ctx, sums, sums_scanned, nb, d_total)));
+      LDB_TRY((scan_impl<TO, TO, TT>(ctx, sums, sums_scanned, nb, d_total)));
       hipLaunchKernelGGL((k_scan_add<TO>), dim3((unsigned) nb), dim3(256), 0, ctx->stream, d_out, sums_scanned, (uint64_t) n);
       ldb_dev_free(ctx, sums_scanned);
-   } else if (d_total) {
-      LDB_HIP(hipMemcpyAsync(d_total, sums, sizeof(TO), hipMemcpyDeviceToDevice, ctx->stream));
+      ldb_dev_free(ctx, sums);
    }
-   ldb_dev_free(ctx, sums);
    LDB_HIP(hipGetLastError());
    return LDB_OK;
 }
 int32_t ldb_exclusive_scan_u32(ldb_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, uint64_t* d_total) {
-   // totals are reported as 64-bit: scan in 64-bit when a total is requested through a temp
-   if (!d_total) return scan_impl<uint32_t, uint32_t>(ctx, d_in, d_out, n, nullptr);
-   uint32_t* t32 = (uint32_t*) (ctx->d_scratch + 8);
-   LDB_TRY((scan_impl<uint32_t, uint32_t>(ctx, d_in, d_out, n, t32)));
-   // widen
-   LDB_HIP(hipMemsetAsync(d_total, 0, 8, ctx->stream));
-   LDB_HIP(hipMemcpyAsync(d_total, t32, 4, hipMemcpyDeviceToDevice, ctx->stream));
-   return LDB_OK;
+   // the running sums are 32-bit (callers bound their totals by the uint32 row-id space); the total is stored widened
+   return scan_impl<uint32_t, uint32_t, uint64_t>(ctx, d_in, d_out, n, d_total);
 }
 int32_t ldb_exclusive_scan_i64(ldb_ctx* ctx, const int64_t* d_in, int64_t* d_out, int64_t n, int64_t* d_total) {
-   return scan_impl<int64_t, int64_t>(ctx, d_in, d_out, n, d_total);
+   return scan_impl<int64_t, int64_t, int64_t>(ctx, d_in, d_out, n, d_total);
 }

@@ -145,7 +145,9 @@ __global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restri
 
 // per-group validity bytes → Arrow bitmap; *nulls += number of zero bytes (one atomic per wave of a
 // bounded grid)
-__global__ void k_pack_valid_bytes(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bitmap, uint64_t n, unsigned long long* __restrict__ nulls) {
+// (the row count is read on the device: the launch is queued before the host knows the number of groups)
+__global__ void k_pack_valid_bytes(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bitmap, const unsigned long long* __restrict__ d_n, unsigned long long* __restrict__ nulls) {
+   const uint64_t n = (uint64_t) *d_n;
    uint64_t nb = (n + 7) / 8;
    unsigned int zeros = 0;
    for (uint64_t b = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; b < nb; b += (uint64_t) gridDim.x * blockDim.x) {
@@ -165,7 +167,7 @@ __global__ void k_pack_valid_bytes(const uint8_t* __restrict__ bytes, uint8_t* _
 
 // ---------------------------------------------------------------- host side
 int32_t ldb_rel_select(ldb_ctx* ctx, ldb_rel* in, uint32_t* sel, int64_t n_sel, ldb_rel** out);
-int32_t ldb_gather_column(ldb_ctx* ctx, const ldb_rel* r, ldb_colref ref, ldb_column* out);
+int32_t ldb_gather_columns(ldb_ctx* ctx, const ldb_rel* r, const ldb_colref* refs, int32_t n_cols, ldb_column* outs);
 
 static uint64_t next_pow2_u64(uint64_t v) {
    uint64_t p = 1;
@@ -505,13 +507,33 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          cap = std::max<uint64_t>(1, groups); // the dense group array: exactly one slot per group
       }
    }
-   uint32_t* d_flags;
-   LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_flags, 64));
+   // One control block per call, read back ONCE per attempt: [0] the kernel's overflow / long-probe
+   // flags, [1] the number of groups (total of the occupancy scan), [2 + a] NULLs of aggregate a.
+   // The finalisation (occupancy → scan → k_gb_finalize → validity packing) is queued right behind
+   // the aggregation kernel without waiting for its flags; an overflow (rare: the estimate was far
+   // too low) throws that work away and retries with a larger table.
+   const size_t ctl_bytes = 8 * (size_t) (2 + GB_MAX_OUT);
+   unsigned long long* d_ctl;
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_ctl, ctl_bytes));
+   unsigned long long ctl[2 + GB_MAX_OUT];
    DGroupBy* d = nullptr;
    uint64_t n_groups = 0;
    uint32_t* rep_rows = nullptr;
    std::vector<void*> out_vals((size_t) n_aggs, nullptr);
    std::vector<uint8_t*> out_valid((size_t) n_aggs, nullptr);
+   std::vector<uint8_t*> bitmaps((size_t) n_aggs, nullptr);
+   auto drop_outputs = [&]() {
+      ldb_dev_free(ctx, rep_rows);
+      rep_rows = nullptr;
+      for (int32_t a = 0; a < n_aggs; a++) {
+         ldb_dev_free(ctx, out_vals[(size_t) a]);
+         ldb_dev_free(ctx, out_valid[(size_t) a]);
+         ldb_dev_free(ctx, bitmaps[(size_t) a]);
+         out_vals[(size_t) a] = nullptr;
+         out_valid[(size_t) a] = nullptr;
+         bitmaps[(size_t) a] = nullptr;
+      }
+   };
    for (int attempt = 0;; attempt++) {
       h->g_cap = cap;
       h->kmult = h->ordered_slots ? (uint64_t) ((((unsigned __int128) cap) << 32) / key_range) : 0;
@@ -520,8 +542,21 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &ga, 8 * (size_t) cap * (size_t) nw));
       h->g_keys = (uint64_t) gk;
       h->g_acc = (uint64_t) ga;
-      h->g_flags = (uint64_t) d_flags;
-      LDB_HIP(hipMemsetAsync(d_flags, 0, 64, ctx->stream));
+      h->g_flags = (uint64_t) d_ctl;
+      // upper bound of groups = min(cap, rows) (1 for keyless)
+      const uint64_t max_groups = std::max<uint64_t>(1, h->keyless ? 1 : std::min<uint64_t>(cap, (uint64_t) in->n_rows));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &rep_rows, 4 * (size_t) max_groups));
+      for (int32_t a = 0; a < n_aggs; a++) {
+         LDB_TRY(ldb_dev_alloc(ctx, &out_vals[(size_t) a], (size_t) oinfo[(size_t) a].width * (size_t) max_groups));
+         h->outs[a].out_values = (uint64_t) out_vals[(size_t) a];
+         h->outs[a].out_valid = 0;
+         if (h->outs[a].cnt_acc >= 0 || h->outs[a].cnt_rows_acc >= 0 || h->outs[a].fn == LDB_AGG_ANY) {
+            LDB_TRY(ldb_dev_alloc(ctx, (void**) &out_valid[(size_t) a], (size_t) max_groups));
+            LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmaps[(size_t) a], (size_t) ((max_groups + 7) / 8 + 1)));
+            h->outs[a].out_valid = (uint64_t) out_valid[(size_t) a];
+         }
+      }
+      LDB_HIP(hipMemsetAsync(d_ctl, 0, ctl_bytes, ctx->stream));
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
       hipLaunchKernelGGL(k_gb_init, dim3(ldb_grid_for(ctx, (int64_t) cap, 256, 8)), dim3(256), 0, ctx->stream, gk, ga, d);
       if (in->n_rows) {
@@ -543,12 +578,35 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          }
       }
       LDB_HIP(hipGetLastError());
-      uint64_t flags = 0;
-      LDB_TRY(ldb_read_u64(ctx, d_flags, &flags));
-      if ((flags & 3) == 0) break;
+      // ---- finalize (speculative: valid only if the flags come back clean)
+      {
+         LdbProf prof_(ctx, "k_gb_finalize");
+         const int64_t n_chunks = (int64_t) ((cap + 63) / 64);
+         uint32_t *pop, *off;
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) n_chunks));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) n_chunks));
+         const int fgrid = ldb_grid_for(ctx, (int64_t) cap, 256, 8);
+         hipLaunchKernelGGL(k_gb_occupancy, dim3(fgrid), dim3(256), 0, ctx->stream, (const uint64_t*) h->g_keys, cap, pop);
+         LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, n_chunks, (uint64_t*) (d_ctl + 1)));
+         hipLaunchKernelGGL(k_gb_finalize, dim3(fgrid), dim3(256), 0, ctx->stream, d, rep_rows, (const uint32_t*) off);
+         for (int32_t a = 0; a < n_aggs; a++)
+            if (out_valid[(size_t) a])
+               hipLaunchKernelGGL(k_pack_valid_bytes, dim3(ldb_grid_for(ctx, (int64_t) max_groups, 256 * 8, 4)), dim3(256), 0, ctx->stream, out_valid[(size_t) a], bitmaps[(size_t) a],
+                                  (const unsigned long long*) (d_ctl + 1), d_ctl + 2 + a);
+         LDB_HIP(hipGetLastError());
+         ldb_dev_free(ctx, pop);
+         ldb_dev_free(ctx, off);
+      }
+      static_assert(sizeof(ctl) <= 64 * sizeof(int64_t), "control block must fit the pinned scratch words");
+      LDB_HIP(hipMemcpyAsync(ctx->h_scratch, d_ctl, ctl_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      LDB_HIP(hipStreamSynchronize(ctx->stream));
+      memcpy(ctl, ctx->h_scratch, ctl_bytes);
       ldb_dev_free(ctx, gk);
       ldb_dev_free(ctx, ga);
       ldb_dev_free(ctx, d);
+      const uint64_t flags = (uint64_t) ctl[0];
+      if ((flags & 3) == 0) break;
+      drop_outputs();
       if ((flags & 2) && h->ordered_slots) { // long probe runs: this key distribution needs hashed slots
          h->ordered_slots = 0;
          in->sides[(size_t) keys[0].side].table->cols[(size_t) keys[0].col].skewed = true;
@@ -559,67 +617,22 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       cap = std::min(cap * 8, cap_max);
    }
    ldb_dev_free(ctx, chunk_off);
-   // ---- finalize
-   // upper bound of groups = min(cap, rows) (+1 for keyless)
-   uint64_t max_groups = h->keyless ? 1 : std::min<uint64_t>(cap, (uint64_t) in->n_rows);
-   LDB_TRY(ldb_dev_alloc(ctx, (void**) &rep_rows, 4 * (size_t) (max_groups ? max_groups : 1)));
+   ldb_dev_free(ctx, d_ctl);
+   n_groups = (uint64_t) ctl[1];
    for (int32_t a = 0; a < n_aggs; a++) {
-      LDB_TRY(ldb_dev_alloc(ctx, &out_vals[(size_t) a], (size_t) oinfo[(size_t) a].width * (size_t) (max_groups ? max_groups : 1)));
-      h->outs[a].out_values = (uint64_t) out_vals[(size_t) a];
-      if (h->outs[a].cnt_acc >= 0 || h->outs[a].cnt_rows_acc >= 0 || h->outs[a].fn == LDB_AGG_ANY) {
-         LDB_TRY(ldb_dev_alloc(ctx, (void**) &out_valid[(size_t) a], (size_t) (max_groups ? max_groups : 1)));
-         h->outs[a].out_valid = (uint64_t) out_valid[(size_t) a];
-      }
+      ldb_dev_free(ctx, out_valid[(size_t) a]);
+      out_valid[(size_t) a] = nullptr;
    }
-   ldb_dev_free(ctx, d);
-   LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-   {
-      const int64_t n_chunks = (int64_t) ((cap + 63) / 64);
-      uint32_t *pop, *off;
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) n_chunks));
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) n_chunks));
-      const int fgrid = ldb_grid_for(ctx, (int64_t) cap, 256, 8);
-      hipLaunchKernelGGL(k_gb_occupancy, dim3(fgrid), dim3(256), 0, ctx->stream, (const uint64_t*) h->g_keys, cap, pop);
-      LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, n_chunks, (uint64_t*) ctx->d_scratch));
-      hipLaunchKernelGGL(k_gb_finalize, dim3(fgrid), dim3(256), 0, ctx->stream, d, rep_rows, (const uint32_t*) off);
-      LDB_HIP(hipGetLastError());
-      LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &n_groups));
-      ldb_dev_free(ctx, pop);
-      ldb_dev_free(ctx, off);
-   }
-   ldb_dev_free(ctx, (void*) h->g_keys);
-   ldb_dev_free(ctx, (void*) h->g_acc);
-   ldb_dev_free(ctx, d);
-   ldb_dev_free(ctx, d_flags);
 
    // ---- result table: key columns = gather of representative rows, then aggregates
    res->n_rows = (int64_t) n_groups;
    res->cols.resize((size_t) (n_keys + n_aggs));
    ldb_rel* reps = nullptr;
    LDB_TRY(ldb_rel_select(ctx, in, rep_rows, (int64_t) n_groups, &reps));
-   for (int32_t k = 0; k < n_keys; k++) {
-      int32_t s = ldb_gather_column(ctx, reps, keys[k], &res->cols[(size_t) k]);
+   {
+      const int32_t s = n_keys ? ldb_gather_columns(ctx, reps, keys, n_keys, res->cols.data()) : LDB_OK;
+      ldb_gpu_rel_release(ctx, reps);
       if (s != LDB_OK) return s;
-   }
-   ldb_gpu_rel_release(ctx, reps);
-   // pack the per-group validity bytes of nullable aggregates; the NULL counts of all of them come
-   // back in one read
-   unsigned long long* d_nulls = (unsigned long long*) (ctx->d_scratch + 48); // GB_MAX_OUT = 16 words
-   std::vector<uint8_t*> bitmaps((size_t) n_aggs, nullptr);
-   bool any_valid = false;
-   for (int32_t a = 0; a < n_aggs; a++) {
-      if (!out_valid[(size_t) a]) continue;
-      if (!any_valid) LDB_HIP(hipMemsetAsync(d_nulls, 0, 8 * GB_MAX_OUT, ctx->stream));
-      any_valid = true;
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmaps[(size_t) a], (size_t) ((n_groups + 7) / 8 + 1)));
-      if (n_groups)
-         hipLaunchKernelGGL(k_pack_valid_bytes, dim3(ldb_grid_for(ctx, (int64_t) n_groups, 256, 4)), dim3(256), 0, ctx->stream, out_valid[(size_t) a], bitmaps[(size_t) a], n_groups,
-                            d_nulls + a);
-      ldb_dev_free(ctx, out_valid[(size_t) a]);
-   }
-   if (any_valid) {
-      LDB_HIP(hipMemcpyAsync(ctx->h_scratch, d_nulls, 8 * GB_MAX_OUT, hipMemcpyDeviceToHost, ctx->stream));
-      LDB_HIP(hipStreamSynchronize(ctx->stream));
    }
    for (int32_t a = 0; a < n_aggs; a++) {
       ldb_column& c = res->cols[(size_t) (n_keys + a)];
@@ -632,7 +645,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       c.value_bytes = (int64_t) n_groups * c.width;
       c.owned = true;
       if (bitmaps[(size_t) a]) { // drop the bitmap when nothing is NULL
-         const int64_t nulls = ctx->h_scratch[a];
+         const int64_t nulls = (int64_t) ctl[2 + a];
          if (nulls) {
             c.validity = bitmaps[(size_t) a];
             c.null_count = nulls;

@@ -162,7 +162,7 @@ extern "C" int32_t ldb_gpu_rel_zip(ldb_ctx* ctx, ldb_rel* in, const ldb_table* t
    ldb_rel* r = ldb_rel_new(ctx);
    r->n_rows = in->n_rows;
    for (auto& s : in->sides) {
-      ldb_rel_side ns{s.table, nullptr, false};
+      ldb_rel_side ns{s.table, nullptr, false, s.may_null};
       if (s.rowids) {
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &ns.rowids, 4 * (size_t) (in->n_rows ? in->n_rows : 1)));
          if (in->n_rows) LDB_HIP(hipMemcpyAsync(ns.rowids, s.rowids, 4 * (size_t) in->n_rows, hipMemcpyDeviceToDevice, ctx->stream));

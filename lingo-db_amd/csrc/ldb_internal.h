@@ -106,6 +106,7 @@ struct ldb_rel_side {
    const ldb_table* table = nullptr;
    uint32_t* rowids = nullptr; // device, NULL = identity
    bool owned = false;
+   bool may_null = false; // rowids may hold LDB_NULL_ROW (outer-join padding): only then gathered columns need a validity pass
 };
 struct ldb_rel {
    ldb_ctx* ctx = nullptr;

@@ -344,7 +344,7 @@ static int32_t radix_prepare(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, co
    bool perm_taken = false;
    const int cg = ldb_grid_for(ctx, n, 256, 8);
    for (auto& s : probe->sides) {
-      ldb_rel_side ns{s.table, nullptr, true};
+      ldb_rel_side ns{s.table, nullptr, true, s.may_null};
       if (!s.rowids && !perm_taken) {
          ns.rowids = perm;
          perm_taken = true;
@@ -417,7 +417,7 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
          LDB_HIP(hipMemcpyAsync(range, init, 16, hipMemcpyHostToDevice, ctx->stream));
          DJoin* dr;
          LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dr));
-         hipLaunchKernelGGL(k_join_key_range, dim3(std::min(ldb_grid_for(ctx, build->n_rows, 256, 8), 256)), dim3(256), 0, ctx->stream, dr, range);
+         hipLaunchKernelGGL(k_join_key_range, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dr, range);
          LDB_HIP(hipMemcpyAsync(got, range, 16, hipMemcpyDeviceToHost, ctx->stream));
          LDB_HIP(hipStreamSynchronize(ctx->stream));
          ldb_dev_free(ctx, dr);
@@ -699,7 +699,7 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
          ldb_rel* r = ldb_rel_new(ctx);
          r->n_rows = n;
          for (auto& s : probe->sides) {
-            ldb_rel_side ns{s.table, nullptr, false};
+            ldb_rel_side ns{s.table, nullptr, false, s.may_null};
             if (s.rowids) {
                LDB_TRY(ldb_dev_alloc(ctx, (void**) &ns.rowids, 4 * (size_t) (n ? n : 1)));
                if (n) LDB_HIP(hipMemcpyAsync(ns.rowids, s.rowids, 4 * (size_t) n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -815,10 +815,12 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
    ldb_rel* r = ldb_rel_new(ctx);
    r->n_rows = (int64_t) produced;
    const int cg = ldb_grid_for(ctx, (int64_t) produced, 256, 8);
-   auto add_sides = [&](ldb_rel* src, uint32_t* sel) -> int32_t {
+   // LEFT_OUTER / SINGLE pad the build sides of unmatched probe rows with LDB_NULL_ROW
+   const bool pads = kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE;
+   auto add_sides = [&](ldb_rel* src, uint32_t* sel, bool sel_may_null) -> int32_t {
       bool sel_taken = false; // the first identity side IS the selection vector: hand it over, no copy
       for (auto& s : src->sides) {
-         ldb_rel_side ns{s.table, nullptr, true};
+         ldb_rel_side ns{s.table, nullptr, true, s.may_null || sel_may_null};
          if (!s.rowids && !sel_taken) {
             ns.rowids = sel;
             sel_taken = true;
@@ -831,8 +833,8 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       if (!sel_taken) ldb_dev_free(ctx, sel);
       return LDB_OK;
    };
-   LDB_TRY(add_sides(probe, op));
-   LDB_TRY(add_sides(ht->build, ob));
+   LDB_TRY(add_sides(probe, op, false));
+   LDB_TRY(add_sides(ht->build, ob, pads));
    LDB_HIP(hipGetLastError());
    *out = r;
    return LDB_OK;

@@ -105,6 +105,7 @@ int32_t ldb_rel_select(ldb_ctx* ctx, ldb_rel* in, uint32_t* sel, int64_t n_sel, 
    for (auto& s : in->sides) {
       ldb_rel_side ns;
       ns.table = s.table;
+      ns.may_null = s.may_null;
       if (!s.rowids) {
          if (!sel_used) {
             ns.rowids = sel;

@@ -383,25 +383,40 @@ static int32_t sort_perm(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, 
    h->n_rows = n;
    h->n_specs = n_specs;
    const int grid = ldb_grid_for(ctx, (int64_t) n, 256, 8);
-   int off = 0;
+   // pre-checks of all keys in one round trip: word 0 = "a key holds a NULL", word 1 + s = longest string of key s
+   unsigned long long* d_chk = nullptr;
+   bool any_chk = false;
    for (int s = 0; s < n_specs; s++) {
       DSortSpec& sp = h->specs[s];
       LDB_TRY(ldb_make_dcol(in, specs[s].col, &sp.col));
       sp.descending = specs[s].descending ? 1 : 0;
-      sp.byte_off = off;
-      // db.sort_compare is only defined for non-nullable operands (LowerToStd.cpp:1050-1052)
-      if ((sp.col.validity || sp.col.rowids) && n) {
-         LDB_HIP(hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
-         hipLaunchKernelGGL(k_all_valid, dim3(grid), dim3(256), 0, ctx->stream, sp.col, n, (unsigned int*) ctx->d_scratch);
-         uint64_t f = 0;
-         LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &f));
-         if (f & 1) LDB_FAIL(LDB_ERR_UNSUPPORTED, "sort: key %d contains NULLs (nullable sort keys are not lowered to db.sort_compare)", s);
+      const bool padded = sp.col.rowids && in->sides[(size_t) specs[s].col.side].may_null; // outer-join padding
+      if (n && (sp.col.validity || padded || sp.col.type == LDB_T_UTF8)) {
+         if (!any_chk) {
+            LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_chk, 8 * (size_t) (1 + SORT_MAX_SPECS)));
+            LDB_HIP(hipMemsetAsync(d_chk, 0, 8 * (size_t) (1 + SORT_MAX_SPECS), ctx->stream));
+            any_chk = true;
+         }
+         // db.sort_compare is only defined for non-nullable operands (LowerToStd.cpp:1050-1052)
+         if (sp.col.validity || padded) hipLaunchKernelGGL(k_all_valid, dim3(grid), dim3(256), 0, ctx->stream, sp.col, n, (unsigned int*) d_chk);
+         if (sp.col.type == LDB_T_UTF8) hipLaunchKernelGGL(k_str_maxlen, dim3(grid), dim3(256), 0, ctx->stream, sp.col, n, d_chk + 1 + s);
       }
+   }
+   unsigned long long chk[1 + SORT_MAX_SPECS] = {0};
+   if (any_chk) {
+      LDB_HIP(hipGetLastError());
+      LDB_HIP(hipMemcpyAsync(ctx->h_scratch, d_chk, sizeof(chk), hipMemcpyDeviceToHost, ctx->stream));
+      LDB_HIP(hipStreamSynchronize(ctx->stream));
+      memcpy(chk, ctx->h_scratch, sizeof(chk));
+      ldb_dev_free(ctx, d_chk);
+      if (chk[0] & 1) LDB_FAIL(LDB_ERR_UNSUPPORTED, "sort: a key contains NULLs (nullable sort keys are not lowered to db.sort_compare)");
+   }
+   int off = 0;
+   for (int s = 0; s < n_specs; s++) {
+      DSortSpec& sp = h->specs[s];
+      sp.byte_off = off;
       if (sp.col.type == LDB_T_UTF8) {
-         LDB_HIP(hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
-         if (n) hipLaunchKernelGGL(k_str_maxlen, dim3(grid), dim3(256), 0, ctx->stream, sp.col, n, (unsigned long long*) ctx->d_scratch);
-         uint64_t m = 0;
-         LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &m));
+         const uint64_t m = chk[1 + s];
          if (m > 256) LDB_FAIL(LDB_ERR_UNSUPPORTED, "sort: string key longer than 256 bytes");
          sp.str_pad = (int32_t) m;
          sp.nbytes = sp.str_pad + 4;

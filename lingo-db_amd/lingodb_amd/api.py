@@ -503,6 +503,10 @@ class Context:
     def prof_enable(self, on=True):
         check(self.lib.ldb_gpu_prof_enable(self.h, 1 if on else 0))
 
+    def prof_marker(self, marker_id):
+        """empty kernel with a grid of `marker_id` workgroups: cuts a rocprofv3 kernel trace into per-query pieces"""
+        check(self.lib.ldb_gpu_prof_marker(self.h, int(marker_id)))
+
     def prof_reset(self):
         check(self.lib.ldb_gpu_prof_reset(self.h))
 
