@@ -252,6 +252,12 @@ struct Interp {
       if (sides) *sides = &v.sides;
       return v.rel;
    }
+   int64_t rowsOf(const std::string& name) {
+      Value& v = val(name);
+      if (v.kind == Value::TABLE) return ldb_gpu_table_rows(v.table);
+      if (v.kind == Value::REL) return ldb_gpu_rel_rows(ctx, v.rel);
+      throw std::runtime_error("plan: '" + name + "' has no row count");
+   }
    void put(const std::string& name, Value v) {
       if (env.count(name)) throw std::runtime_error("plan: value '" + name + "' defined twice");
       env.emplace(name, std::move(v));
@@ -358,6 +364,15 @@ struct Interp {
          return d;
       }
       if (const J* sc = jp.get("scalar")) { // column OP (scalar subquery result): the constant is read back from the device
+         if (rowsOf(sc->s("from")) < 1) { // the subquery returned no row: NULL, and a comparison with NULL keeps nothing
+            ldb_filter_desc d;
+            memset(&d, 0, sizeof(d));
+            d.col = c;
+            d.op = LDB_F_LT;
+            d.rhs_kind = LDB_RHS_COLUMN;
+            d.rhs_col = c;
+            return d;
+         }
          __int128 x = readScalar(sc->s("from"), sc->s("col"));
          // the two sides of the comparison are cast to a common decimal type first; with
          // x at scale sx and the column at scale sc <= sx:  col * 10^k OP x  ⇔  col OP' floor-ish(x / 10^k)
@@ -878,7 +893,17 @@ struct Interp {
             }
             aggs.push_back(a);
          }
-         int64_t est = st.iOr("est_groups", 0);
+         // expected number of groups (sizes the hash table; a low estimate costs a retry, never a wrong result):
+         // a number, "est_groups_from": "rows" (the input's row count), or {"rows_of": value, "div": d, "min": m}
+         int64_t est = 0;
+         if (const J* eg = st.get("est_groups")) {
+            if (eg->kind == J::OBJ) {
+               est = rowsOf(eg->s("rows_of")) / std::max<int64_t>(1, eg->iOr("div", 1));
+               est = std::max<int64_t>(est, eg->iOr("min", 1));
+            } else {
+               est = eg->inum;
+            }
+         }
          if (st.sOr("est_groups_from", "") == "rows") est = std::max<int64_t>(1, ldb_gpu_rel_rows(ctx, in));
          ldb_table* out;
          check(ldb_gpu_groupby(ctx, in, ps.data(), (int32_t) ps.size(), keys.data(), (int32_t) keys.size(), aggs.data(), (int32_t) aggs.size(), est, &out), "groupby");

@@ -1,0 +1,61 @@
+"""The fourteen plans that were C++ functions in round 1 (Q1 3 4 5 6 7 8 9 10 11 12 14 15 18), now
+lingo-db_amd/plans/tpch/qN.json interpreted by libldb_host.so (ldb_plan_run_json), give the rows —
+values and Arrow types — of the compiled plan functions over the same device tables.  (Both are
+checked against independent evaluations elsewhere: the compiled ones in test_gpu_parity /
+test_gpu_tpch_more / test_gpu_z_tpch_q10, the interpreted ones — what bench.py runs — against the
+oracle legs in test_gpu_sf1_oracle.)  Runs under both kernel modes (conftest kernel_mode)."""
+import json
+import os
+
+import pyarrow as pa
+import pyarrow.compute  # noqa: F401
+import pytest
+
+import tpch_data
+import tpch_plans
+from test_gpu_tpch_new import result_rows
+
+pytestmark = pytest.mark.gpu
+N_ORDERS = 300_000  # SF 0.2
+PORTED = [1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 18]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def runner(ctx):
+    db = tpch_plans.Database(ctx, N_ORDERS, 0, 1, PORTED, False)
+    return tpch_plans.Runner(ctx, db, 1, None, None)
+
+
+@pytest.mark.parametrize("q", PORTED)
+def test_interpreted_equals_compiled(runner, q):
+    got = runner.run(q).to_arrow()
+    want = runner.run_compiled(q).to_arrow()
+    assert want.num_rows > 0
+    assert [f.type for f in got.schema] == [f.type for f in want.schema]
+    assert result_rows(got) == result_rows(want)
+
+
+def test_q15_without_lineitems_in_the_quarter(ctx):
+    """the scalar subquery returns no row: MAX is NULL, `= NULL` keeps nothing (the plan's scalar filter must not fail)"""
+    T = tpch_data
+    li = T.host_table(T.LINEITEM, 20_000, cols=[2, 5, 6, 10])
+    su = T.host_table(T.SUPPLIER, 20_000, cols=[0, 1])
+    from test_gpu_tpch_more import days
+
+    none = li.filter(pa.compute.less(li.column("l_shipdate"), pa.scalar(days("1996-01-01"), pa.int32()).cast(pa.date32())))
+    res = ctx.run_plan("tpch/q15.json", {"supplier": ctx.register("q15j_su", su), "lineitem": ctx.register("q15j_li", none)})
+    assert res.rows == 0
+
+
+def test_group_estimates_from_other_values(ctx):
+    """est_groups as {"rows_of", "div", "min"}: a far too low estimate only costs a retry"""
+    T = tpch_data
+    li = T.host_table(T.LINEITEM, 50_000, cols=[0, 4])
+    na = T.host_table(T.NATION, 50_000, cols=[0, 1, 2])
+    plan = {"steps": [{"op": "groupby", "in": "lineitem", "keys": ["l_orderkey"], "aggs": [{"fn": "count_star", "as": "n"}],
+                       "est_groups": {"rows_of": "nation", "div": 5, "min": 2}, "out": "g"},
+                      {"op": "groupby", "in": "g", "keys": [], "aggs": [{"fn": "sum", "expr": "n", "as": "rows"}, {"fn": "count_star", "as": "groups"}], "est_groups": 1, "out": "result"}],
+            "result": "result"}
+    got = ctx.run_plan(json.dumps(plan), {"lineitem": ctx.register("eg_li", li), "nation": ctx.register("eg_na", na)}).to_arrow()
+    assert got.column(0).to_pylist() == [li.num_rows] and got.column(1).to_pylist() == [50_000]

@@ -17,9 +17,27 @@ O_ORDERKEY, O_CUSTKEY, O_TOTALPRICE, O_ORDERDATE, O_ORDERPRIORITY, O_SHIPPRIORIT
 C_CUSTKEY, C_MKTSEGMENT, C_NAME = 0, 3, 4
 
 
-# plans that are data (lingo-db_amd/plans/tpch/qN.json, interpreted by libldb_host.so) and the tables they read
-JSON_PLANS = {2: ["part", "supplier", "partsupp", "nation", "region"], 13: ["customer", "orders"], 16: ["part", "partsupp", "supplier"], 17: ["lineitem", "part"],
-              19: ["lineitem", "part"], 20: ["lineitem", "part", "partsupp", "supplier", "nation"], 21: ["lineitem", "orders", "supplier", "nation"], 22: ["customer", "orders"]}
+# Every single-GPU plan is data: lingo-db_amd/plans/tpch/qN.json, interpreted by libldb_host.so
+# (ldb_plan_run_json).  Per query: plan input name → Database attribute.  Queries that show supplier
+# strings read the wider supplier table.
+_T = {n: n for n in ("lineitem", "orders", "customer", "part", "partsupp", "supplier", "nation", "region")}
+
+
+def _inputs(*names, **over):
+    d = {n: _T[n] for n in names}
+    d.update(over)
+    return d
+
+
+JSON_PLANS = {
+    1: _inputs("lineitem"), 6: _inputs("lineitem"), 3: _inputs("customer", "orders", "lineitem"), 4: _inputs("orders", "lineitem"), 12: _inputs("orders", "lineitem"),
+    18: _inputs("customer", "orders", "lineitem"), 9: _inputs("part", "supplier", "lineitem", "partsupp", "orders", "nation"),
+    5: _inputs("customer", "orders", "lineitem", "supplier", "nation", "region"), 7: _inputs("customer", "orders", "lineitem", "supplier", "nation"),
+    8: _inputs("part", "supplier", "lineitem", "orders", "customer", "nation", "region"), 10: _inputs("customer", "orders", "lineitem", "nation"),
+    11: _inputs("partsupp", "supplier", "nation"), 14: _inputs("part", "lineitem"), 15: _inputs("supplier", "lineitem"),
+    2: _inputs("part", "partsupp", "nation", "region", supplier="supplier_full"), 13: _inputs("customer", "orders"), 16: _inputs("part", "partsupp", supplier="supplier_full"),
+    17: _inputs("lineitem", "part"), 19: _inputs("lineitem", "part"), 20: _inputs("lineitem", "part", "partsupp", "nation", supplier="supplier_full"),
+    21: _inputs("lineitem", "orders", "nation", supplier="supplier_full"), 22: _inputs("customer", "orders")}
 
 
 class Database:
@@ -147,43 +165,49 @@ class Runner:
             import tpch_dist
 
             res = tpch_dist.run_query(self, q)
-        elif q == 1:
-            res = self.ctx.plan_q1(self.db.lineitem)
-        elif q == 6:
-            res = self.ctx.plan_q6(self.db.lineitem)
-        elif q == 3:
-            res = self.ctx.plan_q3(self.db.customer, self.db.orders, self.db.lineitem)
-        elif q == 4:
-            res = self.ctx.plan_q4(self.db.orders, self.db.lineitem)
-        elif q == 12:
-            res = self.ctx.plan_q12(self.db.orders, self.db.lineitem)
-        elif q == 18:
-            res = self.ctx.plan_q18(self.db.customer, self.db.orders, self.db.lineitem)
-        elif q == 10:
-            res = self.ctx.plan_q10(self.db.customer, self.db.orders, self.db.lineitem, self.db.nation)
-        elif q == 15:
-            res = self.ctx.plan_q15(self.db.supplier, self.db.lineitem)
-        elif q == 5:
-            res = self.ctx.plan_q5(self.db.customer, self.db.orders, self.db.lineitem, self.db.supplier, self.db.nation, self.db.region)
-        elif q == 7:
-            res = self.ctx.plan_q7(self.db.customer, self.db.orders, self.db.lineitem, self.db.supplier, self.db.nation)
-        elif q == 14:
-            res = self.ctx.plan_q14(self.db.part, self.db.lineitem)
-        elif q == 8:
-            res = self.ctx.plan_q8(self.db.part, self.db.supplier, self.db.lineitem, self.db.orders, self.db.customer, self.db.nation, self.db.region)
-        elif q == 11:
-            res = self.ctx.plan_q11(self.db.partsupp, self.db.supplier, self.db.nation)
         elif q in JSON_PLANS:
-            db = self.db
-            avail = {"lineitem": db.lineitem, "orders": db.orders, "customer": db.customer, "part": db.part, "partsupp": db.partsupp,
-                     "supplier": getattr(db, "supplier_full", None) or db.supplier, "nation": db.nation, "region": db.region}
-            res = self.ctx.run_plan(self.plan_text(q), {n: avail[n] for n in JSON_PLANS[q]})
-        elif q == 9:
-            res = self.ctx.plan_q9(self.db.part, self.db.supplier, self.db.lineitem, self.db.partsupp, self.db.orders, self.db.nation)
+            res = self.ctx.run_plan(self.plan_text(q), self.plan_inputs(q))
         else:
             raise ValueError(f"TPC-H Q{q} has no plan yet")
         self.last[q] = res
         return res
+
+    def plan_inputs(self, q):
+        return {name: getattr(self.db, attr) for name, attr in JSON_PLANS[q].items()}
+
+    def run_compiled(self, q):
+        """the round-1 C++ plan functions of libldb_host.so (their pieces are what the multi-GPU plans
+        call between exchanges); kept to check that the interpreted plans give the same rows"""
+        db, ctx = self.db, self.ctx
+        if q == 1:
+            return ctx.plan_q1(db.lineitem)
+        if q == 6:
+            return ctx.plan_q6(db.lineitem)
+        if q == 3:
+            return ctx.plan_q3(db.customer, db.orders, db.lineitem)
+        if q == 4:
+            return ctx.plan_q4(db.orders, db.lineitem)
+        if q == 12:
+            return ctx.plan_q12(db.orders, db.lineitem)
+        if q == 18:
+            return ctx.plan_q18(db.customer, db.orders, db.lineitem)
+        if q == 10:
+            return ctx.plan_q10(db.customer, db.orders, db.lineitem, db.nation)
+        if q == 15:
+            return ctx.plan_q15(db.supplier, db.lineitem)
+        if q == 5:
+            return ctx.plan_q5(db.customer, db.orders, db.lineitem, db.supplier, db.nation, db.region)
+        if q == 7:
+            return ctx.plan_q7(db.customer, db.orders, db.lineitem, db.supplier, db.nation)
+        if q == 14:
+            return ctx.plan_q14(db.part, db.lineitem)
+        if q == 8:
+            return ctx.plan_q8(db.part, db.supplier, db.lineitem, db.orders, db.customer, db.nation, db.region)
+        if q == 11:
+            return ctx.plan_q11(db.partsupp, db.supplier, db.nation)
+        if q == 9:
+            return ctx.plan_q9(db.part, db.supplier, db.lineitem, db.partsupp, db.orders, db.nation)
+        raise ValueError(f"TPC-H Q{q} has no compiled plan")
 
     def plan_text(self, q):
         if not hasattr(self, "plans"):
