@@ -903,8 +903,40 @@ int32_t ldb_make_dpred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out) {
       if (p->str_len < 0 || p->str_len > LDB_STR_INLINE) LDB_FAIL(LDB_ERR_UNSUPPORTED, "filter: string constant of %d bytes (max %d)", p->str_len, LDB_STR_INLINE);
       out->str_len = p->str_len;
       memcpy(out->str, p->str, (size_t) p->str_len);
+      if (p->op == LDB_F_LIKE || p->op == LDB_F_NOT_LIKE) ldb_like_plan(out);
    }
    return LDB_OK;
+}
+
+// "Simple" LIKE patterns — ASCII literals separated by '%', no '_' and no escape: %A%B%, A%, %A,
+// A%B … — are matched by position instead of by row (ldb_device.h d_like_simple_wave).  For such a
+// pattern byte-wise substring search IS the reference's character-wise iterativeLike
+// (StringRuntime.cpp:28-93): an ASCII pattern byte never equals a UTF-8 lead or continuation byte.
+// Plan: n_in = number of literal segments (0 = not simple), in_off[2j] / in_off[2j+1] = start and
+// length of segment j inside str, lo bit 0 / bit 1 = the pattern is anchored at the start / end.
+void ldb_like_plan(DPred* d) {
+   d->n_in = 0;
+   const int n = d->str_len;
+   int nseg = 0, seg_start = -1, off[2 * LDB_LIKE_MAX_SEG];
+   for (int k = 0; k <= n; k++) {
+      const unsigned char c = k < n ? (unsigned char) d->str[k] : (unsigned char) '%';
+      if (k < n && (c >= 0x80 || c == '_' || c == '\\')) return;
+      if (c == '%') {
+         if (seg_start >= 0) {
+            if (nseg == LDB_LIKE_MAX_SEG || k - seg_start > 16) return;
+            off[2 * nseg] = seg_start;
+            off[2 * nseg + 1] = k - seg_start;
+            nseg++;
+            seg_start = -1;
+         }
+      } else if (seg_start < 0) {
+         seg_start = k;
+      }
+   }
+   if (nseg == 0) return; // "", "%", "%%": the general matcher decides at once
+   for (int j = 0; j < 2 * nseg; j++) d->in_off[j] = off[j];
+   d->n_in = nseg;
+   d->lo = (d->str[0] != '%' ? 1u : 0u) | (d->str[n - 1] != '%' ? 2u : 0u);
 }
 
 // marks conjuncts whose lhs column is the previous conjunct's (range filters): the batched

@@ -36,6 +36,7 @@ struct DCol {
 #define LDB_MAX_PREDS 8
 #define LDB_MAX_IN 8
 #define LDB_STR_INLINE 48
+#define LDB_LIKE_MAX_SEG 4 // literal segments of a "simple" LIKE pattern (host: ldb_like_plan)
 struct DPred {
    DCol col;
    DCol rhs;

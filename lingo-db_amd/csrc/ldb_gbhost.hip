@@ -534,7 +534,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          bitmaps[(size_t) a] = nullptr;
       }
    };
-   for (int attempt = 0;; attempt++) {
+   for (;;) {
       h->g_cap = cap;
       h->kmult = h->ordered_slots ? (uint64_t) ((((unsigned __int128) cap) << 32) / key_range) : 0;
       uint64_t *gk, *ga;

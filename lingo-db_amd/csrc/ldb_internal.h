@@ -141,6 +141,7 @@ int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_
 int32_t ldb_make_dcol(const ldb_rel* r, ldb_colref ref, DCol* out);
 int32_t ldb_make_dpred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out);
 void ldb_mark_same_col(DPred* preds, int32_t n);
+void ldb_like_plan(DPred* d);
 void ldb_order_preds(DPred* preds, int32_t n);
 int32_t ldb_make_dkeys(const ldb_rel* r, const ldb_colref* keys, int32_t n_keys, DKeys* out);
 int32_t ldb_width_of(const ldb_coltype& t, int narrow);

@@ -47,6 +47,19 @@ bool ldb_scan_jit_check(std::string* log) {
    m.preds[1].rhs_kind = LDB_RHS_STRING;
    m.preds[1].str_len = 8;
    memcpy(m.preds[1].str, "BUILDING", 8);
+   // a "simple" LIKE pattern: the position-parallel matcher with the segments as compile-time constants
+   m.n_preds = 3;
+   m.preds[2].col.type = LDB_T_UTF8;
+   m.preds[2].col.offsets = 1;
+   m.preds[2].op = LDB_F_NOT_LIKE;
+   m.preds[2].rhs_kind = LDB_RHS_STRING;
+   m.preds[2].str_len = 18;
+   memcpy(m.preds[2].str, "%special%requests%", 18);
+   ldb_like_plan(&m.preds[2]);
+   if (m.preds[2].n_in != 2) {
+      if (log) *log = "scan jit check: the LIKE pattern was not planned as two segments";
+      return false;
+   }
    return ldb_jit_compile_only("ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, &m, sizeof(m), log);
 }
 

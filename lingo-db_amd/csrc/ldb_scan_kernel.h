@@ -31,7 +31,7 @@ __device__ __forceinline__ bool d_eval_conj(const DScan& m, const DScan* __restr
 // stage through LDS: one LDS_STR_STAGE region per wave of the 256-thread block)
 template <int U>
 __device__ __forceinline__ void d_eval_conj_batch(const DScan& m, const DScan* __restrict__ d, const uint64_t (&rows)[U], bool (&pass)[U]) {
-   __shared__ __attribute__((aligned(8))) uint8_t str_stage[SCAN_BLOCK / LDB_WAVE][LDS_STR_STAGE + 8 + 64]; // strings, slack, pattern
+   __shared__ __attribute__((aligned(8))) uint8_t str_stage[SCAN_BLOCK / LDB_WAVE][LDS_STR_BYTES]; // strings, match bitmaps, pattern
    d_eval_conj_batch<U>(m.preds, d->preds, m.n_preds, rows, pass, d->n_rows, str_stage[threadIdx.x >> 6]);
 }
 

@@ -202,6 +202,29 @@ def test_like_filters_match_oracle(ctx, oracle):
         assert g.scan_count([api.pred((0, 0), capi.F_NOT_LIKE, pat)]) == len(oracle.scan_filter(h, [api.pred((0, 0), capi.F_NOT_LIKE, pat)])), pat
 
 
+def test_like_simple_patterns_position_parallel(ctx, oracle):
+    """ASCII literals separated by '%' take the position-parallel matcher (ldb_like_plan /
+    d_like_simple_wave) on dense non-NULL string columns: every anchoring, 1-4 segments, segments of
+    1-16 bytes, overlapping occurrences, multi-byte text, strings around the LDS stage limit (the
+    wave falls back to the row-wise matcher) — all against the oracle's StringRuntime::like."""
+    rng = np.random.default_rng(77)
+    alpha = ["a", "b", "c", "é", " "]
+    short = ["".join(rng.choice(alpha, rng.integers(0, 31), p=[0.4, 0.3, 0.2, 0.05, 0.05])) for _ in range(40000)]
+    long_ = ["".join(rng.choice(["a", "b"], rng.integers(60, 220))) for _ in range(6000)]
+    for name, strs in (("short", short), ("long", long_)):
+        t = pa.table({"s": pa.array(strs, pa.string())})
+        g, h = ctx.register("like_pp_" + name, t).rel(), HostTable(t).rel()
+        pats = ["%ab%", "ab%", "%ab", "ab", "a%", "%a", "ab%ba", "%ab%ba%", "ab%ba%", "%ab%ba", "%aa%aa%", "a%b%c%a", "%a%b%c%a%", "%a%b%c%a%b%",
+                "%abababab%", "%ababababa%", "%abababababababab%", "%ababababababababa%", "abc%", "%cba", "% %", "%b a%", "%a%%b%", "%c"]
+        for pat in pats:
+            for op in (capi.F_LIKE, capi.F_NOT_LIKE):
+                plist = [api.pred((0, 0), op, pat)]
+                got = g.scan_filter(plist).rowids(0)
+                want = oracle.scan_filter(h, plist)
+                assert np.array_equal(got, want), (name, pat, op, len(got), len(want))
+        assert len(oracle.scan_filter(h, [api.pred((0, 0), capi.F_LIKE, "%ab%ba%")])) > 100
+
+
 def test_map_column_extract_year_and_zip(ctx, oracle):
     """extract(year from date) as a computed column: device values = oracle's restatement of
     DateRuntime::extractYear (itself pinned against the reference), NULL in → NULL out, through

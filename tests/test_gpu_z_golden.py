@@ -176,8 +176,7 @@ def test_sort_topk_keyless_hashmap_match_reference_objects(ctx):
     t = ctx.register("ss", pa.table({"v": pa.array(z["ss_vals"], pa.int64()), "keep": pa.array(z["ss_keep"].astype(np.int32), pa.int32())}))
     aggs = [api.agg(capi.AGG_SUM, api.col_expr((0, 0)), wide=True, out_type=capi.T_DECIMAL128, p=38, s=0), api.agg(capi.AGG_COUNT_STAR)]
     row = t.rel().groupby([], aggs, [api.pred((0, 1), capi.F_EQ, 1)]).to_arrow().to_pylist()[0]
-    want = (int(z["ss_sum_lohi"][1]) << 64) | (int(z["ss_sum_lohi"][0]) & 0xFFFFFFFFFFFFFFFF)
-    want = want - (1 << 128) if want >> 127 else want
+    want = (int(z["ss_sum_lohi"][1]) << 64) | (int(z["ss_sum_lohi"][0]) & 0xFFFFFFFFFFFFFFFF)  # hi is signed: already the two's-complement value
     assert int(row["agg0"]) == want and row["agg1"] == int(z["ss_count"][0])
     none = t.rel().groupby([], aggs, [api.pred((0, 1), capi.F_EQ, 7)]).to_arrow().to_pylist()[0]
     assert none["agg0"] is None and none["agg1"] == 0
