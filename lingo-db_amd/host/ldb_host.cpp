@@ -327,103 +327,6 @@ int32_t guarded(F&& f) {
 
 extern "C" const char* ldb_plan_last_error(void) { return g_plan_err.c_str(); }
 
-// TPC-H Q1 (resources/sql/tpch/1.sql): scan lineitem with the pushed-down l_shipdate filter,
-// group by (l_returnflag, l_linestatus), 4 SUM + 3 AVG + COUNT(*), order by the keys.
-extern "C" int32_t ldb_plan_tpch_q1(ldb_ctx* ctx, const ldb_table* li, ldb_table** result) {
-   return guarded([&] {
-      Rel scan(ctx), sorted(ctx);
-      check(ldb_gpu_rel_from_table(ctx, li, &scan.r), "q1 scan");
-      // date '1998-12-01' - interval '90' day is constant-folded by the frontend
-      auto restr = Restrictions::create({{"l_shipdate", FilterOp::LTE, std::string("1998-09-02"), {}}}, li);
-      ldb_colref qty{0, colOf(li, "l_quantity")}, ext{0, colOf(li, "l_extendedprice")}, disc{0, colOf(li, "l_discount")}, tax{0, colOf(li, "l_tax")};
-      ldb_colref keys[2] = {{0, colOf(li, "l_returnflag")}, {0, colOf(li, "l_linestatus")}};
-      DecimalType tq = decOf(li, qty.col), te = decOf(li, ext.col), td = decOf(li, disc.col), tt = decOf(li, tax.col);
-      DecimalType t1md, t1pt;
-      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, td, &t1md);
-      ldb_factor onePlusTax = constPlusCol(1, +1, tax, tt, &t1pt);
-      DecimalType tDiscPrice = typeAfterMul(te, t1md); // decimal(33,4)
-      DecimalType tCharge = typeAfterMul(tDiscPrice, t1pt); // decimal(38,6)
-      if (tDiscPrice.s != te.s + t1md.s || tCharge.s != tDiscPrice.s + t1pt.s) throw std::runtime_error("q1: unexpected scale clamp");
-      ldb_agg_spec aggs[8] = {
-         sumDec(product({colFactor(qty)}), tq),
-         sumDec(product({colFactor(ext)}), te),
-         sumDec(product({colFactor(ext), oneMinusDisc}), tDiscPrice),
-         sumDec(product({colFactor(ext), oneMinusDisc, onePlusTax}), tCharge),
-         avgDec(product({colFactor(qty)}), tq),
-         avgDec(product({colFactor(ext)}), te),
-         avgDec(product({colFactor(disc)}), td),
-         countStar()};
-      Table grouped(ctx);
-      check(ldb_gpu_groupby(ctx, scan.r, restr->data(), restr->size(), keys, 2, aggs, 8, /*est_groups*/ 6, &grouped.t), "q1 groupby");
-      Rel g(ctx);
-      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q1 rel");
-      ldb_sort_spec specs[2] = {{{0, 0}, 0, 0}, {{0, 1}, 0, 0}};
-      check(ldb_gpu_sort(ctx, g.r, specs, 2, &sorted.r), "q1 sort");
-      ldb_colref outc[10];
-      for (int c = 0; c < 10; c++) outc[c] = {0, c};
-      check(ldb_gpu_materialize(ctx, sorted.r, outc, 10, result), "q1 materialize");
-   });
-}
-
-// TPC-H Q6 (resources/sql/tpch/6.sql): pure scan + key-less SUM (SimpleState).
-extern "C" int32_t ldb_plan_tpch_q6(ldb_ctx* ctx, const ldb_table* li, ldb_table** result) {
-   return guarded([&] {
-      Rel scan(ctx);
-      check(ldb_gpu_rel_from_table(ctx, li, &scan.r), "q6 scan");
-      // 0.06 - 0.01 / 0.06 + 0.01 are folded to decimal constants; BETWEEN → two inclusive filters
-      auto restr = Restrictions::create({{"l_shipdate", FilterOp::GTE, std::string("1994-01-01"), {}},
-                                         {"l_shipdate", FilterOp::LT, std::string("1995-01-01"), {}},
-                                         {"l_discount", FilterOp::GTE, std::string("0.05"), {}},
-                                         {"l_discount", FilterOp::LTE, std::string("0.07"), {}},
-                                         {"l_quantity", FilterOp::LT, (int64_t) 24, {}}},
-                                        li);
-      ldb_colref ext{0, colOf(li, "l_extendedprice")}, disc{0, colOf(li, "l_discount")};
-      DecimalType tr = typeAfterMul(decOf(li, ext.col), decOf(li, disc.col)); // decimal(24,4)
-      ldb_agg_spec agg = sumDec(product({colFactor(ext), colFactor(disc)}), tr);
-      check(ldb_gpu_groupby(ctx, scan.r, restr->data(), restr->size(), nullptr, 0, &agg, 1, 1, result), "q6 aggregate");
-   });
-}
-
-// TPC-H Q3 (resources/sql/tpch/3.sql): customer ⋈ orders ⋈ lineitem, group by 3 keys, top-10.
-extern "C" int32_t ldb_plan_tpch_q3(ldb_ctx* ctx, const ldb_table* cust, const ldb_table* ord, const ldb_table* li, ldb_table** result) {
-   return guarded([&] {
-      Rel c0(ctx), c1(ctx), o0(ctx), o1(ctx), l0(ctx), l1(ctx), co(ctx), lco(ctx), top(ctx);
-      check(ldb_gpu_rel_from_table(ctx, cust, &c0.r), "q3 customer");
-      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q3 orders");
-      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q3 lineitem");
-      auto rc = Restrictions::create({{"c_mktsegment", FilterOp::EQ, std::string("BUILDING"), {}}}, cust);
-      auto ro = Restrictions::create({{"o_orderdate", FilterOp::LT, std::string("1995-03-15"), {}}}, ord);
-      auto rl = Restrictions::create({{"l_shipdate", FilterOp::GT, std::string("1995-03-15"), {}}}, li);
-      check(ldb_gpu_scan_filter(ctx, c0.r, rc->data(), rc->size(), &c1.r), "q3 filter customer");
-      check(ldb_gpu_scan_filter(ctx, o0.r, ro->data(), ro->size(), &o1.r), "q3 filter orders");
-      check(ldb_gpu_scan_filter(ctx, l0.r, rl->data(), rl->size(), &l1.r), "q3 filter lineitem");
-      // build on the filtered customers (primary key), probe with the filtered orders
-      Ht hc(ctx), ho(ctx);
-      ldb_colref ck{0, colOf(cust, "c_custkey")}, ock{0, colOf(ord, "o_custkey")};
-      check(ldb_gpu_join_build(ctx, c1.r, &ck, 1, 1, &hc.h), "q3 build customer");
-      check(ldb_gpu_join_probe(ctx, hc.h, o1.r, &ock, 1, LDB_JOIN_INNER, &co.r, nullptr), "q3 probe orders"); // sides: orders, customer
-      ldb_colref ook{0, colOf(ord, "o_orderkey")}, lok{0, colOf(li, "l_orderkey")};
-      check(ldb_gpu_join_build(ctx, co.r, &ook, 1, 1, &ho.h), "q3 build orders");
-      check(ldb_gpu_join_probe(ctx, ho.h, l1.r, &lok, 1, LDB_JOIN_INNER, &lco.r, nullptr), "q3 probe lineitem"); // sides: lineitem, orders, customer
-      ldb_colref ext{0, colOf(li, "l_extendedprice")}, disc{0, colOf(li, "l_discount")};
-      DecimalType t1md;
-      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, decOf(li, disc.col), &t1md);
-      DecimalType tRev = typeAfterMul(decOf(li, ext.col), t1md);
-      ldb_agg_spec agg = sumDec(product({colFactor(ext), oneMinusDisc}), tRev);
-      ldb_colref keys[3] = {lok, {1, colOf(ord, "o_orderdate")}, {1, colOf(ord, "o_shippriority")}};
-      Table grouped(ctx);
-      int64_t est = ldb_gpu_rel_rows(ctx, lco.r);
-      check(ldb_gpu_groupby(ctx, lco.r, nullptr, 0, keys, 3, &agg, 1, est > 0 ? est : 1, &grouped.t), "q3 groupby");
-      Rel g(ctx);
-      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q3 rel");
-      // order by revenue desc, o_orderdate limit 10; output l_orderkey, revenue, o_orderdate, o_shippriority
-      ldb_sort_spec specs[2] = {{{0, 3}, 1, 0}, {{0, 1}, 0, 0}};
-      check(ldb_gpu_topk(ctx, g.r, specs, 2, 10, &top.r), "q3 topk");
-      ldb_colref outc[4] = {{0, 0}, {0, 3}, {0, 1}, {0, 2}};
-      check(ldb_gpu_materialize(ctx, top.r, outc, 4, result), "q3 materialize");
-   });
-}
-
 namespace {
 // residual column-vs-column conjunct (evaluated by generated db.compare in the reference, not by
 // Restrictions: only column-vs-constant filters are pushed into the scan)
@@ -436,131 +339,7 @@ ldb_filter_desc colCompare(ldb_colref a, FilterOp op, ldb_colref b) {
    d.rhs_col = b;
    return d;
 }
-std::vector<ldb_filter_desc> conj(const Restrictions& r, std::initializer_list<ldb_filter_desc> more) {
-   std::vector<ldb_filter_desc> v(r.data(), r.data() + r.size());
-   v.insert(v.end(), more.begin(), more.end());
-   return v;
-}
-// sum(case when <preds> then 1 else 0 end): integer literals are int32, SUM keeps the argument
-// type (sql_analyzer.cpp:2617-2631) → int32
-ldb_agg_spec sumCaseOne(const Restrictions& when) {
-   ldb_agg_spec a;
-   memset(&a, 0, sizeof(a));
-   a.fn = LDB_AGG_SUM;
-   a.arg.n_terms = 1;
-   a.arg.t[0].n_factors = 1;
-   a.arg.t[0].f[0] = {0, {0, 0}, 1, 0};
-   a.out_type = LDB_T_INT32;
-   if (when.size() > LDB_MAX_AGG_PREDS) throw std::runtime_error("conditional aggregate: too many conjuncts");
-   a.n_preds = when.size();
-   for (int32_t p = 0; p < when.size(); p++) a.preds[p] = when.data()[p];
-   return a;
-}
 } // namespace
-
-// TPC-H Q4 (resources/sql/tpch/4.sql): orders of one quarter that have a late lineitem (EXISTS →
-// semi join, orders kept = the hash-table side), count per o_orderpriority, ordered by it.
-extern "C" int32_t ldb_plan_tpch_q4(ldb_ctx* ctx, const ldb_table* ord, const ldb_table* li, ldb_table** result) {
-   return guarded([&] {
-      Rel o0(ctx), o1(ctx), l0(ctx), l1(ctx), osel(ctx), sorted(ctx);
-      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q4 orders");
-      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q4 lineitem");
-      auto ro = Restrictions::create({{"o_orderdate", FilterOp::GTE, std::string("1993-07-01"), {}}, {"o_orderdate", FilterOp::LT, std::string("1993-10-01"), {}}}, ord);
-      check(ldb_gpu_scan_filter(ctx, o0.r, ro->data(), ro->size(), &o1.r), "q4 filter orders");
-      ldb_filter_desc late = colCompare({0, colOf(li, "l_commitdate")}, FilterOp::LT, {0, colOf(li, "l_receiptdate")});
-      check(ldb_gpu_scan_filter(ctx, l0.r, &late, 1, &l1.r), "q4 filter lineitem");
-      Ht ho(ctx);
-      ldb_colref ook{0, colOf(ord, "o_orderkey")}, lok{0, colOf(li, "l_orderkey")};
-      check(ldb_gpu_join_build(ctx, o1.r, &ook, 1, 1, &ho.h), "q4 build orders");
-      check(ldb_gpu_join_probe(ctx, ho.h, l1.r, &lok, 1, LDB_JOIN_SEMI_BUILD, &osel.r, nullptr), "q4 semi join");
-      ldb_colref key{0, colOf(ord, "o_orderpriority")};
-      ldb_agg_spec cnt = countStar();
-      Table grouped(ctx);
-      check(ldb_gpu_groupby(ctx, osel.r, nullptr, 0, &key, 1, &cnt, 1, 5, &grouped.t), "q4 groupby");
-      Rel g(ctx);
-      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q4 rel");
-      ldb_sort_spec spec{{0, 0}, 0, 0};
-      check(ldb_gpu_sort(ctx, g.r, &spec, 1, &sorted.r), "q4 sort");
-      ldb_colref outc[2] = {{0, 0}, {0, 1}};
-      check(ldb_gpu_materialize(ctx, sorted.r, outc, 2, result), "q4 materialize");
-   });
-}
-
-// TPC-H Q12 (resources/sql/tpch/12.sql): late lineitems of two ship modes in one year ⋈ orders,
-// per l_shipmode the number of high / low priority orders (conditional sums), ordered by mode.
-// The few filtered lineitems are the hash-table side; all orders probe it.
-extern "C" int32_t ldb_plan_tpch_q12(ldb_ctx* ctx, const ldb_table* ord, const ldb_table* li, ldb_table** result) {
-   return guarded([&] {
-      Rel o0(ctx), l0(ctx), l1(ctx), ol(ctx), sorted(ctx);
-      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q12 orders");
-      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q12 lineitem");
-      auto rl = Restrictions::create({{"l_shipmode", FilterOp::IN, {}, std::vector<std::string>{"MAIL", "SHIP"}},
-                                      {"l_receiptdate", FilterOp::GTE, std::string("1994-01-01"), {}},
-                                      {"l_receiptdate", FilterOp::LT, std::string("1995-01-01"), {}}},
-                                     li);
-      ldb_colref commit{0, colOf(li, "l_commitdate")}, receipt{0, colOf(li, "l_receiptdate")}, ship{0, colOf(li, "l_shipdate")};
-      auto lp = conj(*rl, {colCompare(commit, FilterOp::LT, receipt), colCompare(ship, FilterOp::LT, commit)});
-      check(ldb_gpu_scan_filter(ctx, l0.r, lp.data(), (int32_t) lp.size(), &l1.r), "q12 filter lineitem");
-      Ht hl(ctx);
-      ldb_colref lok{0, colOf(li, "l_orderkey")}, ook{0, colOf(ord, "o_orderkey")};
-      check(ldb_gpu_join_build(ctx, l1.r, &lok, 1, 0, &hl.h), "q12 build lineitem");
-      check(ldb_gpu_join_probe(ctx, hl.h, o0.r, &ook, 1, LDB_JOIN_INNER, &ol.r, nullptr), "q12 probe orders"); // sides: orders, lineitem
-      auto high = Restrictions::create({{"o_orderpriority", FilterOp::IN, {}, std::vector<std::string>{"1-URGENT", "2-HIGH"}}}, ord, 0);
-      auto low = Restrictions::create({{"o_orderpriority", FilterOp::NEQ, std::string("1-URGENT"), {}}, {"o_orderpriority", FilterOp::NEQ, std::string("2-HIGH"), {}}}, ord, 0);
-      ldb_agg_spec aggs[2] = {sumCaseOne(*high), sumCaseOne(*low)};
-      ldb_colref key{1, colOf(li, "l_shipmode")};
-      Table grouped(ctx);
-      check(ldb_gpu_groupby(ctx, ol.r, nullptr, 0, &key, 1, aggs, 2, 2, &grouped.t), "q12 groupby");
-      Rel g(ctx);
-      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q12 rel");
-      ldb_sort_spec spec{{0, 0}, 0, 0};
-      check(ldb_gpu_sort(ctx, g.r, &spec, 1, &sorted.r), "q12 sort");
-      ldb_colref outc[3] = {{0, 0}, {0, 1}, {0, 2}};
-      check(ldb_gpu_materialize(ctx, sorted.r, outc, 3, result), "q12 materialize");
-   });
-}
-
-// TPC-H Q18 (resources/sql/tpch/18.sql): orders whose lineitems sum to more than 300 units — a
-// group-by with one group per order (1.5 M x SF groups) — joined back to customer, orders and
-// lineitem, grouped, top-100 by (o_totalprice desc, o_orderdate).
-extern "C" int32_t ldb_plan_tpch_q18(ldb_ctx* ctx, const ldb_table* cust, const ldb_table* ord, const ldb_table* li, ldb_table** result) {
-   return guarded([&] {
-      Rel l0(ctx), o0(ctx), c0(ctx), g0(ctx), g1(ctx), o1(ctx), co(ctx), lco(ctx), top(ctx);
-      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q18 lineitem");
-      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q18 orders");
-      check(ldb_gpu_rel_from_table(ctx, cust, &c0.r), "q18 customer");
-      ldb_colref lok{0, colOf(li, "l_orderkey")}, qty{0, colOf(li, "l_quantity")};
-      DecimalType tq = decOf(li, qty.col);
-      ldb_agg_spec sumq = sumDec(product({colFactor(qty)}), tq);
-      Table perOrder(ctx);
-      check(ldb_gpu_groupby(ctx, l0.r, nullptr, 0, &lok, 1, &sumq, 1, std::max<int64_t>(1, ldb_gpu_table_rows(ord)), &perOrder.t), "q18 group by l_orderkey");
-      check(ldb_gpu_rel_from_table(ctx, perOrder.t, &g0.r), "q18 rel");
-      auto having = Restrictions::create({{"agg0", FilterOp::GT, (int64_t) 300, {}}}, perOrder.t);
-      check(ldb_gpu_scan_filter(ctx, g0.r, having->data(), having->size(), &g1.r), "q18 having");
-      // o_orderkey IN (subquery) → semi join, the small key set is the hash table
-      Ht hk(ctx), ho(ctx), hco(ctx);
-      ldb_colref gk{0, 0}, ook{0, colOf(ord, "o_orderkey")};
-      check(ldb_gpu_join_build(ctx, g1.r, &gk, 1, 1, &hk.h), "q18 build keys");
-      check(ldb_gpu_join_probe(ctx, hk.h, o0.r, &ook, 1, LDB_JOIN_SEMI, &o1.r, nullptr), "q18 semi join orders");
-      // customer ⋈ those orders (hash table on the few orders, customers probe)
-      ldb_colref ock{0, colOf(ord, "o_custkey")}, ck{0, colOf(cust, "c_custkey")};
-      check(ldb_gpu_join_build(ctx, o1.r, &ock, 1, 0, &ho.h), "q18 build orders");
-      check(ldb_gpu_join_probe(ctx, ho.h, c0.r, &ck, 1, LDB_JOIN_INNER, &co.r, nullptr), "q18 probe customer"); // sides: customer, orders
-      // lineitem ⋈ that on the order key
-      ldb_colref cok{1, ook.col};
-      check(ldb_gpu_join_build(ctx, co.r, &cok, 1, 1, &hco.h), "q18 build customer-orders");
-      check(ldb_gpu_join_probe(ctx, hco.h, l0.r, &lok, 1, LDB_JOIN_INNER, &lco.r, nullptr), "q18 probe lineitem"); // sides: lineitem, customer, orders
-      ldb_colref keys[5] = {{1, colOf(cust, "c_name")}, {1, ck.col}, {2, ook.col}, {2, colOf(ord, "o_orderdate")}, {2, colOf(ord, "o_totalprice")}};
-      Table grouped(ctx);
-      check(ldb_gpu_groupby(ctx, lco.r, nullptr, 0, keys, 5, &sumq, 1, std::max<int64_t>(1, ldb_gpu_rel_rows(ctx, co.r)), &grouped.t), "q18 groupby");
-      Rel g(ctx);
-      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q18 rel");
-      ldb_sort_spec specs[2] = {{{0, 4}, 1, 0}, {{0, 3}, 0, 0}};
-      check(ldb_gpu_topk(ctx, g.r, specs, 2, 100, &top.r), "q18 topk");
-      ldb_colref outc[6] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}};
-      check(ldb_gpu_materialize(ctx, top.r, outc, 6, result), "q18 materialize");
-   });
-}
 
 namespace {
 // string predicate evaluated in generated code (StringRuntime::like), not a pushed-down restriction
@@ -578,88 +357,9 @@ struct LikePred {
 };
 } // namespace
 
-// TPC-H Q9 (resources/sql/tpch/9.sql): profit per nation and year over the lineitems of "green"
-// parts — part ⋈ lineitem ⋈ partsupp (two-column key) ⋈ supplier ⋈ nation ⋈ orders, amount =
-// l_extendedprice·(1 − l_discount) − ps_supplycost·l_quantity, grouped by (n_name, year(o_orderdate)).
-// Join order by cardinality: the LIKE filter keeps 5.4 % of part; everything else is reduced by it.
-extern "C" int32_t ldb_plan_tpch_q9(ldb_ctx* ctx, const ldb_table* part, const ldb_table* supp, const ldb_table* li, const ldb_table* ps, const ldb_table* ord,
-                                    const ldb_table* nat, ldb_table** result) {
-   return guarded([&] {
-      Rel p0(ctx), p1(ctx), l0(ctx), lp(ctx), ps0(ctx), ps1(ctx), lps(ctx), s0(ctx), lpss(ctx), n0(ctx), all(ctx), m0(ctx), o0(ctx), om(ctx), omy(ctx), g(ctx), sorted(ctx);
-      check(ldb_gpu_rel_from_table(ctx, part, &p0.r), "q9 part");
-      check(ldb_gpu_rel_from_table(ctx, li, &l0.r), "q9 lineitem");
-      check(ldb_gpu_rel_from_table(ctx, ps, &ps0.r), "q9 partsupp");
-      check(ldb_gpu_rel_from_table(ctx, supp, &s0.r), "q9 supplier");
-      check(ldb_gpu_rel_from_table(ctx, nat, &n0.r), "q9 nation");
-      check(ldb_gpu_rel_from_table(ctx, ord, &o0.r), "q9 orders");
-      LikePred green({0, colOf(part, "p_name")}, "%green%");
-      check(ldb_gpu_scan_filter(ctx, p0.r, &green.d, 1, &p1.r), "q9 filter part");
-      // green parts: hash table on p_partkey, probed by lineitem (inner) and by partsupp (semi)
-      Ht hp(ctx), hps(ctx), hs(ctx), hn(ctx), hm(ctx);
-      ldb_colref pk{0, colOf(part, "p_partkey")}, lpk{0, colOf(li, "l_partkey")}, lsk{0, colOf(li, "l_suppkey")}, pspk{0, colOf(ps, "ps_partkey")}, pssk{0, colOf(ps, "ps_suppkey")};
-      check(ldb_gpu_join_build(ctx, p1.r, &pk, 1, 1, &hp.h), "q9 build part");
-      check(ldb_gpu_join_probe(ctx, hp.h, l0.r, &lpk, 1, LDB_JOIN_SEMI, &lp.r, nullptr), "q9 lineitem of green parts"); // p_partkey = l_partkey: no part column is needed later
-      check(ldb_gpu_join_probe(ctx, hp.h, ps0.r, &pspk, 1, LDB_JOIN_SEMI, &ps1.r, nullptr), "q9 partsupp of green parts");
-      // partsupp on (ps_partkey, ps_suppkey) = (l_partkey, l_suppkey)
-      ldb_colref psk2[2] = {pspk, pssk}, lk2[2] = {lpk, lsk};
-      check(ldb_gpu_join_build(ctx, ps1.r, psk2, 2, 1, &hps.h), "q9 build partsupp");
-      check(ldb_gpu_join_probe(ctx, hps.h, lp.r, lk2, 2, LDB_JOIN_INNER, &lps.r, nullptr), "q9 probe partsupp"); // sides: lineitem, partsupp
-      // supplier, then nation through s_nationkey
-      ldb_colref sk{0, colOf(supp, "s_suppkey")};
-      check(ldb_gpu_join_build(ctx, s0.r, &sk, 1, 1, &hs.h), "q9 build supplier");
-      check(ldb_gpu_join_probe(ctx, hs.h, lps.r, &lsk, 1, LDB_JOIN_INNER, &lpss.r, nullptr), "q9 probe supplier"); // lineitem, partsupp, supplier
-      // The nation join is deferred (eager aggregation): the 32 M joined rows are first summed per
-      // (s_nationkey, o_year) — integer keys — and only the ≤ 175 partial rows meet nation; the
-      // final GROUP BY (n_name, o_year) re-aggregates them, so the result is the query's even if two
-      // nations shared a name.  Grouping 32 M rows on a string reached through three row-id
-      // indirections cost 6.9 ms, this 0.5 ms.
-      // narrow to the columns still needed, then orders: the reduced side is the hash table
-      ldb_colref keep[6] = {{0, colOf(li, "l_orderkey")}, {0, colOf(li, "l_extendedprice")}, {0, colOf(li, "l_discount")}, {0, colOf(li, "l_quantity")},
-                            {1, colOf(ps, "ps_supplycost")}, {2, colOf(supp, "s_nationkey")}};
-      Table m(ctx), years(ctx), partial(ctx), grouped(ctx);
-      check(ldb_gpu_materialize(ctx, lpss.r, keep, 6, &m.t), "q9 materialize");
-      check(ldb_gpu_rel_from_table(ctx, m.t, &m0.r), "q9 rel");
-      ldb_colref mok{0, 0}, ook{0, colOf(ord, "o_orderkey")};
-      check(ldb_gpu_join_build(ctx, m0.r, &mok, 1, 0, &hm.h), "q9 build reduced lineitem");
-      check(ldb_gpu_join_probe(ctx, hm.h, o0.r, &ook, 1, LDB_JOIN_INNER, &om.r, nullptr), "q9 probe orders"); // sides: orders, m
-      // o_year = extract(year from o_orderdate) as a computed column (third side)
-      check(ldb_gpu_map_column(ctx, om.r, {0, colOf(ord, "o_orderdate")}, LDB_FN_EXTRACT_YEAR, "o_year", &years.t), "q9 extract year");
-      check(ldb_gpu_rel_zip(ctx, om.r, years.t, &omy.r), "q9 zip year");
-      ldb_colref ext{1, 1}, disc{1, 2}, qty{1, 3}, cost{1, 4};
-      DecimalType te = decOf(m.t, 1), td = decOf(m.t, 2), tq = decOf(m.t, 3), tc = decOf(m.t, 4), t1md;
-      ldb_factor oneMinusDisc = constPlusCol(1, -1, disc, td, &t1md);
-      DecimalType tRev = typeAfterMul(te, t1md), tCost = typeAfterMul(tc, tq), tAmount = higherDecimalType(tRev, tCost);
-      if (tRev.s != tCost.s || tRev.s != te.s + t1md.s) throw std::runtime_error("q9: unexpected scales");
-      ldb_expr amount;
-      memset(&amount, 0, sizeof(amount));
-      amount.n_terms = 2;
-      amount.t[0].n_factors = 2;
-      amount.t[0].f[0] = colFactor(ext);
-      amount.t[0].f[1] = oneMinusDisc;
-      amount.t[1].n_factors = 2;
-      amount.t[1].negate = 1;
-      amount.t[1].f[0] = colFactor(cost);
-      amount.t[1].f[1] = colFactor(qty);
-      ldb_agg_spec agg = sumDec(amount, tAmount);
-      ldb_colref keys[2] = {{1, 5}, {2, 0}};
-      check(ldb_gpu_groupby(ctx, omy.r, nullptr, 0, keys, 2, &agg, 1, 25 * 8, &partial.t), "q9 groupby nationkey, year");
-      // partial (s_nationkey, o_year, sum) ⋈ nation → GROUP BY (n_name, o_year)
-      check(ldb_gpu_rel_from_table(ctx, partial.t, &all.r), "q9 rel");
-      ldb_colref nk{0, colOf(nat, "n_nationkey")}, pnk{0, 0};
-      Rel pn(ctx);
-      check(ldb_gpu_join_build(ctx, n0.r, &nk, 1, 1, &hn.h), "q9 build nation");
-      check(ldb_gpu_join_probe(ctx, hn.h, all.r, &pnk, 1, LDB_JOIN_INNER, &pn.r, nullptr), "q9 probe nation"); // sides: partial, nation
-      ldb_agg_spec resum = sumDec(product({colFactor({0, 2})}), tAmount);
-      ldb_colref keys2[2] = {{1, colOf(nat, "n_name")}, {0, 1}};
-      check(ldb_gpu_groupby(ctx, pn.r, nullptr, 0, keys2, 2, &resum, 1, 25 * 8, &grouped.t), "q9 groupby");
-      check(ldb_gpu_rel_from_table(ctx, grouped.t, &g.r), "q9 rel");
-      ldb_sort_spec specs[2] = {{{0, 0}, 0, 0}, {{0, 1}, 1, 0}};
-      check(ldb_gpu_sort(ctx, g.r, specs, 2, &sorted.r), "q9 sort");
-      ldb_colref outc[3] = {{0, 0}, {0, 1}, {0, 2}};
-      check(ldb_gpu_materialize(ctx, sorted.r, outc, 3, result), "q9 materialize");
-   });
-}
-
+// The single-GPU TPC-H plans are data (lingo-db_amd/plans/tpch/qN.json, interpreted by ldb_plan.cpp).
+// What follows are the PIECES of the multi-GPU plans: the shard-local parts and the merges that run
+// between the exchanges of tpch_dist.py.
 // ---------------------------------------------------------------- multi-GPU plan pieces
 // Row-range sharded fact tables: every rank runs the *_partial plan on its shard, the tiny partial
 // tables are exchanged over RCCL, and *_final merges them exactly as the reference merges
@@ -1086,15 +786,6 @@ extern "C" int32_t ldb_plan_tpch_q5_final(ldb_ctx* ctx, const ldb_table* partial
       check(ldb_gpu_materialize(ctx, sorted.r, outc, 2, result), "q5 final materialize");
    });
 }
-extern "C" int32_t ldb_plan_tpch_q5(ldb_ctx* ctx, const ldb_table* cust, const ldb_table* ord, const ldb_table* li, const ldb_table* supp, const ldb_table* nat, const ldb_table* reg,
-                                    ldb_table** result) {
-   Table custs(ctx), supps(ctx), partial(ctx);
-   int32_t s = ldb_plan_tpch_q5_customers(ctx, cust, nat, reg, &custs.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q5_suppliers(ctx, supp, nat, reg, &supps.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q5_local(ctx, custs.t, supps.t, ord, li, &partial.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q5_final(ctx, partial.t, nat, result);
-   return s;
-}
 
 // ---------------------------------------------------------------- TPC-H Q7 (resources/sql/tpch/7.sql)
 // Trade volume between two nations per year.  (n1 = A and n2 = B) or (n1 = B and n2 = A) is
@@ -1182,14 +873,6 @@ extern "C" int32_t ldb_plan_tpch_q7_final(ldb_ctx* ctx, const ldb_table* partial
       ldb_colref outc[4] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}};
       check(ldb_gpu_materialize(ctx, sorted.r, outc, 4, result), "q7 final materialize");
    });
-}
-extern "C" int32_t ldb_plan_tpch_q7(ldb_ctx* ctx, const ldb_table* cust, const ldb_table* ord, const ldb_table* li, const ldb_table* supp, const ldb_table* nat, ldb_table** result) {
-   Table custs(ctx), supps(ctx), partial(ctx);
-   int32_t s = ldb_plan_tpch_q7_customers(ctx, cust, nat, &custs.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q7_suppliers(ctx, supp, nat, &supps.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q7_local(ctx, custs.t, supps.t, ord, li, &partial.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q7_final(ctx, partial.t, nat, result);
-   return s;
 }
 
 // ---------------------------------------------------------------- TPC-H Q11 (resources/sql/tpch/11.sql)
@@ -1291,15 +974,6 @@ extern "C" int32_t ldb_plan_tpch_q11_sort(ldb_ctx* ctx, const ldb_table* rows, l
       check(ldb_gpu_materialize(ctx, sorted.r, outc, 2, result), "q11 materialize sorted");
    });
 }
-extern "C" int32_t ldb_plan_tpch_q11(ldb_ctx* ctx, const ldb_table* ps, const ldb_table* supp, const ldb_table* nat, ldb_table** result) {
-   Table supps(ctx), groups(ctx), total(ctx), kept(ctx);
-   int32_t s = ldb_plan_tpch_q11_suppliers(ctx, supp, nat, &supps.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q11_groups(ctx, supps.t, ps, &groups.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q11_total(ctx, groups.t, &total.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q11_filter(ctx, groups.t, total.t, &kept.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q11_sort(ctx, kept.t, result);
-   return s;
-}
 
 // ---------------------------------------------------------------- TPC-H Q10 (resources/sql/tpch/10.sql)
 // Returned-item revenue per customer of one quarter, top 20.  Pieces (the single-GPU plan is their
@@ -1380,14 +1054,6 @@ extern "C" int32_t ldb_plan_tpch_q10_final(ldb_ctx* ctx, const ldb_table* rows, 
       ldb_colref outc[5] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}};
       check(ldb_gpu_materialize(ctx, top.r, outc, 5, result), "q10 final materialize");
    });
-}
-extern "C" int32_t ldb_plan_tpch_q10(ldb_ctx* ctx, const ldb_table* cust, const ldb_table* ord, const ldb_table* li, const ldb_table* nat, ldb_table** result) {
-   Table groups(ctx), top(ctx), named(ctx);
-   int32_t s = ldb_plan_tpch_q10_local(ctx, ord, li, &groups.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q10_top(ctx, groups.t, &top.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q10_names(ctx, top.t, cust, nat, &named.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q10_final(ctx, named.t, result);
-   return s;
 }
 
 // ---------------------------------------------------------------- TPC-H Q15 (resources/sql/tpch/15.sql)
@@ -1472,14 +1138,6 @@ extern "C" int32_t ldb_plan_tpch_q15_final(ldb_ctx* ctx, const ldb_table* winner
       check(ldb_gpu_materialize(ctx, sorted.r, outc, 2, result), "q15 final materialize");
    });
 }
-extern "C" int32_t ldb_plan_tpch_q15(ldb_ctx* ctx, const ldb_table* supp, const ldb_table* li, ldb_table** result) {
-   Table groups(ctx), best(ctx), winners(ctx);
-   int32_t s = ldb_plan_tpch_q15_local(ctx, li, &groups.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q15_max(ctx, groups.t, &best.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q15_winners(ctx, groups.t, best.t, &winners.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q15_final(ctx, winners.t, supp, result);
-   return s;
-}
 
 // ---------------------------------------------------------------- TPC-H Q14 (resources/sql/tpch/14.sql)
 // 100.00 * sum(case when p_type like 'PROMO%' then rev else 0 end) / sum(rev) over one month of
@@ -1539,13 +1197,6 @@ extern "C" int32_t ldb_plan_tpch_q14_final(ldb_ctx* ctx, const ldb_table* partia
       const DecimalType tMul = typeAfterMul(lit, tSum), tDiv = typeAfterDiv(tMul, tSum);
       check(ldb_gpu_map_muldiv(ctx, s0.r, {0, 0}, 10000, 0, lit.s + tSum.s - tMul.s, tDiv.s + tSum.s - tMul.s, {0, 1}, tDiv.p, tDiv.s, "promo_revenue", result), "q14 ratio");
    });
-}
-extern "C" int32_t ldb_plan_tpch_q14(ldb_ctx* ctx, const ldb_table* part, const ldb_table* li, ldb_table** result) {
-   Table promo(ctx), partial(ctx);
-   int32_t s = ldb_plan_tpch_q14_promo(ctx, part, &promo.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q14_local(ctx, promo.t, part, li, &partial.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q14_final(ctx, partial.t, result);
-   return s;
 }
 
 // ---------------------------------------------------------------- TPC-H Q8 (resources/sql/tpch/8.sql)
@@ -1628,15 +1279,6 @@ extern "C" int32_t ldb_plan_tpch_q8_final(ldb_ctx* ctx, const ldb_table* partial
       ldb_colref outc[2] = {{0, 0}, {1, 0}};
       check(ldb_gpu_materialize(ctx, sorted.r, outc, 2, result), "q8 materialize");
    });
-}
-extern "C" int32_t ldb_plan_tpch_q8(ldb_ctx* ctx, const ldb_table* part, const ldb_table* supp, const ldb_table* li, const ldb_table* ord, const ldb_table* cust,
-                                    const ldb_table* nat, const ldb_table* reg, ldb_table** result) {
-   Table parts(ctx), custs(ctx), partial(ctx);
-   int32_t s = ldb_plan_tpch_q8_parts(ctx, part, &parts.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q8_customers(ctx, cust, nat, reg, &custs.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q8_local(ctx, parts.t, custs.t, supp, ord, li, nat, &partial.t);
-   if (s == LDB_OK) s = ldb_plan_tpch_q8_final(ctx, partial.t, result);
-   return s;
 }
 
 // ---------------------------------------------------------------- C hooks for the host-logic tests

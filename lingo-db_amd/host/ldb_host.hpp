@@ -66,31 +66,20 @@ void check(int32_t status, const char* what);
 } // namespace lingodb::runtime::gpu
 
 extern "C" {
-// TPC-H plans (hand-built pipeline DAGs in place of the MLIR-produced execution steps).
-// Inputs: device tables with the TPC-H column names; result: device table (caller releases).
-int32_t ldb_plan_tpch_q1(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q6(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q3(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q4(ldb_ctx* ctx, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q12(ldb_ctx* ctx, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q18(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q9(ldb_ctx* ctx, const ldb_table* part, const ldb_table* supplier, const ldb_table* lineitem, const ldb_table* partsupp, const ldb_table* orders,
-                         const ldb_table* nation, ldb_table** result);
-int32_t ldb_plan_tpch_q5(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* orders, const ldb_table* lineitem, const ldb_table* supplier, const ldb_table* nation,
-                         const ldb_table* region, ldb_table** result);
-// Q5 pieces (the single-GPU plan is their composition; multi-GPU all-gathers between them)
+// The single-GPU TPC-H plans are data: lingo-db_amd/plans/tpch/qN.json run by ldb_plan_run_json (below).
+// The functions here are the PIECES of the multi-GPU plans (shard-local parts and merges between the
+// exchanges).  Inputs: device tables with the TPC-H column names; result: device table
+// (caller releases).
+// Q5 pieces (multi-GPU all-gathers between them)
 int32_t ldb_plan_tpch_q5_customers(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* nation, const ldb_table* region, ldb_table** result);
 int32_t ldb_plan_tpch_q5_suppliers(ldb_ctx* ctx, const ldb_table* supplier, const ldb_table* nation, const ldb_table* region, ldb_table** result);
 int32_t ldb_plan_tpch_q5_local(ldb_ctx* ctx, const ldb_table* custs, const ldb_table* supps, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q5_final(ldb_ctx* ctx, const ldb_table* partials, const ldb_table* nation, ldb_table** result);
-int32_t ldb_plan_tpch_q7(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* orders, const ldb_table* lineitem, const ldb_table* supplier, const ldb_table* nation,
-                         ldb_table** result);
 int32_t ldb_plan_tpch_q7_customers(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* nation, ldb_table** result);
 int32_t ldb_plan_tpch_q7_suppliers(ldb_ctx* ctx, const ldb_table* supplier, const ldb_table* nation, ldb_table** result);
 int32_t ldb_plan_tpch_q7_local(ldb_ctx* ctx, const ldb_table* custs, const ldb_table* supps, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q7_final(ldb_ctx* ctx, const ldb_table* partials, const ldb_table* nation, ldb_table** result);
-// Q11 and its pieces (suppliers → groups → [partition → all-to-all → merge] → total → filter → sort)
-int32_t ldb_plan_tpch_q11(ldb_ctx* ctx, const ldb_table* partsupp, const ldb_table* supplier, const ldb_table* nation, ldb_table** result);
+// Q11 pieces (suppliers → groups → [partition → all-to-all → merge] → total → filter → sort)
 int32_t ldb_plan_tpch_q11_suppliers(ldb_ctx* ctx, const ldb_table* supplier, const ldb_table* nation, ldb_table** result);
 int32_t ldb_plan_tpch_q11_groups(ldb_ctx* ctx, const ldb_table* suppkeys, const ldb_table* partsupp, ldb_table** result);
 int32_t ldb_plan_tpch_q11_partition(ldb_ctx* ctx, const ldb_table* groups, int32_t world, ldb_table** result, int64_t* counts);
@@ -98,14 +87,11 @@ int32_t ldb_plan_tpch_q11_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table**
 int32_t ldb_plan_tpch_q11_total(ldb_ctx* ctx, const ldb_table* groups, ldb_table** result);
 int32_t ldb_plan_tpch_q11_filter(ldb_ctx* ctx, const ldb_table* groups, const ldb_table* totals, ldb_table** result);
 int32_t ldb_plan_tpch_q11_sort(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
-// Q14 and its pieces (promo part keys → [all-gather] → local partial sums → [all-gather] → final ratio)
-int32_t ldb_plan_tpch_q14(ldb_ctx* ctx, const ldb_table* part, const ldb_table* lineitem, ldb_table** result);
+// Q14 pieces (promo part keys → [all-gather] → local partial sums → [all-gather] → final ratio)
 int32_t ldb_plan_tpch_q14_promo(ldb_ctx* ctx, const ldb_table* part, ldb_table** result);
 int32_t ldb_plan_tpch_q14_local(ldb_ctx* ctx, const ldb_table* promokeys, const ldb_table* partkeys, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q14_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
-// Q8 and its pieces (part keys, customers of the region → [all-gather] → local partial sums per year → [all-gather] → final)
-int32_t ldb_plan_tpch_q8(ldb_ctx* ctx, const ldb_table* part, const ldb_table* supplier, const ldb_table* lineitem, const ldb_table* orders, const ldb_table* customer,
-                         const ldb_table* nation, const ldb_table* region, ldb_table** result);
+// Q8 pieces (part keys, customers of the region → [all-gather] → local partial sums per year → [all-gather] → final)
 int32_t ldb_plan_tpch_q8_parts(ldb_ctx* ctx, const ldb_table* part, ldb_table** result);
 int32_t ldb_plan_tpch_q8_customers(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* nation, const ldb_table* region, ldb_table** result);
 int32_t ldb_plan_tpch_q8_local(ldb_ctx* ctx, const ldb_table* partkeys, const ldb_table* custs, const ldb_table* supplier, const ldb_table* orders, const ldb_table* lineitem,
@@ -127,7 +113,6 @@ int32_t ldb_plan_tpch_q3_final(ldb_ctx* ctx, const ldb_table* tops, ldb_table** 
 int32_t ldb_plan_tpch_q4_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
 int32_t ldb_plan_tpch_q12_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
 // Q10 pieces: shard-local (o_custkey, revenue) groups; [multi-GPU: partition + merge on the key;] top 20; names; order
-int32_t ldb_plan_tpch_q10(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* orders, const ldb_table* lineitem, const ldb_table* nation, ldb_table** result);
 int32_t ldb_plan_tpch_q10_local(ldb_ctx* ctx, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q10_partition(ldb_ctx* ctx, const ldb_table* groups, int32_t world, ldb_table** result, int64_t* counts);
 int32_t ldb_plan_tpch_q10_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
@@ -135,7 +120,6 @@ int32_t ldb_plan_tpch_q10_top(ldb_ctx* ctx, const ldb_table* groups, ldb_table**
 int32_t ldb_plan_tpch_q10_names(ldb_ctx* ctx, const ldb_table* top20, const ldb_table* customer, const ldb_table* nation, ldb_table** result);
 int32_t ldb_plan_tpch_q10_final(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
 // Q15 pieces: shard-local (l_suppkey, revenue) groups; [multi-GPU: partition + merge;] best group; groups equal to it; supplier join + order
-int32_t ldb_plan_tpch_q15(ldb_ctx* ctx, const ldb_table* supplier, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q15_local(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q15_partition(ldb_ctx* ctx, const ldb_table* groups, int32_t world, ldb_table** result, int64_t* counts);
 int32_t ldb_plan_tpch_q15_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);

@@ -554,71 +554,51 @@ class Context:
         check(self.lib.ldb_gpu_tpch_generate(self.h, table_id, n_orders, part, n_parts, mask, 1 if narrow_decimals else 0, C.byref(h)))
         return Table(self, h)
 
-    # ---- plans (C++ host mirror)
+    # ---- plans: data (lingo-db_amd/plans/tpch/qN.json) interpreted by libldb_host.so; these wrappers only name the inputs
+    def _tpch(self, q, **tables):
+        return self.run_plan("tpch/q%d.json" % q, tables)
+
     def plan_q1(self, lineitem):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q1(self.h, lineitem.h, C.byref(t)))
-        return Table(self, t)
+        return self._tpch(1, lineitem=lineitem)
 
     def plan_q6(self, lineitem):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q6(self.h, lineitem.h, C.byref(t)))
-        return Table(self, t)
+        return self._tpch(6, lineitem=lineitem)
 
     def plan_q3(self, customer, orders, lineitem):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q3(self.h, customer.h, orders.h, lineitem.h, C.byref(t)))
-        return Table(self, t)
+        return self._tpch(3, customer=customer, orders=orders, lineitem=lineitem)
 
     def plan_q4(self, orders, lineitem):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q4(self.h, orders.h, lineitem.h, C.byref(t)))
-        return Table(self, t)
+        return self._tpch(4, orders=orders, lineitem=lineitem)
 
     def plan_q12(self, orders, lineitem):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q12(self.h, orders.h, lineitem.h, C.byref(t)))
-        return Table(self, t)
+        return self._tpch(12, orders=orders, lineitem=lineitem)
 
     def plan_q5(self, customer, orders, lineitem, supplier, nation, region):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q5(self.h, customer.h, orders.h, lineitem.h, supplier.h, nation.h, region.h, C.byref(t)))
-        return Table(self, t)
+        return self._tpch(5, customer=customer, orders=orders, lineitem=lineitem, supplier=supplier, nation=nation, region=region)
 
     def plan_q7(self, customer, orders, lineitem, supplier, nation):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q7(self.h, customer.h, orders.h, lineitem.h, supplier.h, nation.h, C.byref(t)))
-        return Table(self, t)
+        return self._tpch(7, customer=customer, orders=orders, lineitem=lineitem, supplier=supplier, nation=nation)
 
     def plan_q8(self, part, supplier, lineitem, orders, customer, nation, region):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q8(self.h, part.h, supplier.h, lineitem.h, orders.h, customer.h, nation.h, region.h, C.byref(t)))
-        return Table(self, t)
+        return self._tpch(8, part=part, supplier=supplier, lineitem=lineitem, orders=orders, customer=customer, nation=nation, region=region)
 
     def plan_q14(self, part, lineitem):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q14(self.h, part.h, lineitem.h, C.byref(t)))
-        return Table(self, t)
+        return self._tpch(14, part=part, lineitem=lineitem)
 
     def plan_q11(self, partsupp, supplier, nation):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q11(self.h, partsupp.h, supplier.h, nation.h, C.byref(t)))
-        return Table(self, t)
+        return self._tpch(11, partsupp=partsupp, supplier=supplier, nation=nation)
 
     def plan_q9(self, part, supplier, lineitem, partsupp, orders, nation):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q9(self.h, part.h, supplier.h, lineitem.h, partsupp.h, orders.h, nation.h, C.byref(t)))
-        return Table(self, t)
+        return self._tpch(9, part=part, supplier=supplier, lineitem=lineitem, partsupp=partsupp, orders=orders, nation=nation)
 
     def plan_q10(self, customer, orders, lineitem, nation):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q10(self.h, customer.h, orders.h, lineitem.h, nation.h, C.byref(t)))
-        return Table(self, t)
+        return self._tpch(10, customer=customer, orders=orders, lineitem=lineitem, nation=nation)
 
     def plan_q15(self, supplier, lineitem):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q15(self.h, supplier.h, lineitem.h, C.byref(t)))
-        return Table(self, t)
+        return self._tpch(15, supplier=supplier, lineitem=lineitem)
+
+    def plan_q18(self, customer, orders, lineitem):
+        return self._tpch(18, customer=customer, orders=orders, lineitem=lineitem)
 
     def run_plan(self, plan, tables):
         """interprets a JSON plan (text, or the name of a file under lingo-db_amd/plans/) over {name: Table}"""
@@ -644,8 +624,3 @@ class Context:
         with pa.OSFile(path, "rb") as f:
             table = pa.ipc.open_file(f).read_all()
         return self.register(name, table, narrow_decimals)
-
-    def plan_q18(self, customer, orders, lineitem):
-        t = C.c_void_p()
-        check_plan(capi.host_lib().ldb_plan_tpch_q18(self.h, customer.h, orders.h, lineitem.h, C.byref(t)))
-        return Table(self, t)

@@ -217,29 +217,17 @@ GPU_API = {
 HOST_API = {
     "ldb_tpch_host_rows": (i64, [i32, i64, i32, i32]),
     "ldb_tpch_host_column": (i64, [i32, i32, i64, i32, i32, P, C.POINTER(i64), C.POINTER(i64)]),
-    "ldb_plan_tpch_q1": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q6": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q3": (i32, [P, P, P, P, PP]),
-    "ldb_plan_tpch_q4": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q12": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q18": (i32, [P, P, P, P, PP]),
-    "ldb_plan_tpch_q9": (i32, [P, P, P, P, P, P, P, PP]),
-    "ldb_plan_tpch_q5": (i32, [P, P, P, P, P, P, P, PP]),
-    "ldb_plan_tpch_q7": (i32, [P, P, P, P, P, P, PP]),
     "ldb_plan_tpch_q7_customers": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q7_suppliers": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q7_local": (i32, [P, P, P, P, P, PP]),
     "ldb_plan_tpch_q7_final": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q8": (i32, [P, P, P, P, P, P, P, P, PP]),
     "ldb_plan_tpch_q8_parts": (i32, [P, P, PP]),
     "ldb_plan_tpch_q8_customers": (i32, [P, P, P, P, PP]),
     "ldb_plan_tpch_q8_local": (i32, [P, P, P, P, P, P, P, PP]),
     "ldb_plan_tpch_q8_final": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q14": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q14_promo": (i32, [P, P, PP]),
     "ldb_plan_tpch_q14_local": (i32, [P, P, P, P, PP]),
     "ldb_plan_tpch_q14_final": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q11": (i32, [P, P, P, P, PP]),
     "ldb_plan_tpch_q11_suppliers": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q11_groups": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q11_partition": (i32, [P, P, i32, PP, C.POINTER(i64)]),
@@ -264,13 +252,11 @@ HOST_API = {
     "ldb_plan_tpch_q3_final": (i32, [P, P, PP]),
     "ldb_plan_tpch_q4_final": (i32, [P, P, PP]),
     "ldb_plan_tpch_q12_final": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q10": (i32, [P, P, P, P, P, PP]),
     "ldb_plan_tpch_q10_local": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q10_merge": (i32, [P, P, PP]),
     "ldb_plan_tpch_q10_top": (i32, [P, P, PP]),
     "ldb_plan_tpch_q10_names": (i32, [P, P, P, P, PP]),
     "ldb_plan_tpch_q10_final": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q15": (i32, [P, P, P, PP]),
     "ldb_plan_tpch_q15_local": (i32, [P, P, PP]),
     "ldb_plan_tpch_q15_merge": (i32, [P, P, PP]),
     "ldb_plan_tpch_q15_max": (i32, [P, P, PP]),

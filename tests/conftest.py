@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 # filter fused lazily into its consumer — the code path the SF100 bench numbers come from, which
 # the default thresholds (>= 4 M / >= 1 M rows) would never reach at test sizes.
 SPEC_MODULES = {"test_gpu_parity", "test_gpu_joins_more", "test_gpu_tpch_more", "test_gpu_z_golden", "test_gpu_z_tpch_q10", "test_gpu_tpch_new",
-                "test_gpu_new_ops", "test_gpu_plans_json"}
+                "test_gpu_new_ops"}
 
 
 try:  # torch first: it ships its own HIP runtime / RCCL copies, which must be the ones the process binds (see api.Comm)

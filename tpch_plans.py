@@ -175,40 +175,6 @@ class Runner:
     def plan_inputs(self, q):
         return {name: getattr(self.db, attr) for name, attr in JSON_PLANS[q].items()}
 
-    def run_compiled(self, q):
-        """the round-1 C++ plan functions of libldb_host.so (their pieces are what the multi-GPU plans
-        call between exchanges); kept to check that the interpreted plans give the same rows"""
-        db, ctx = self.db, self.ctx
-        if q == 1:
-            return ctx.plan_q1(db.lineitem)
-        if q == 6:
-            return ctx.plan_q6(db.lineitem)
-        if q == 3:
-            return ctx.plan_q3(db.customer, db.orders, db.lineitem)
-        if q == 4:
-            return ctx.plan_q4(db.orders, db.lineitem)
-        if q == 12:
-            return ctx.plan_q12(db.orders, db.lineitem)
-        if q == 18:
-            return ctx.plan_q18(db.customer, db.orders, db.lineitem)
-        if q == 10:
-            return ctx.plan_q10(db.customer, db.orders, db.lineitem, db.nation)
-        if q == 15:
-            return ctx.plan_q15(db.supplier, db.lineitem)
-        if q == 5:
-            return ctx.plan_q5(db.customer, db.orders, db.lineitem, db.supplier, db.nation, db.region)
-        if q == 7:
-            return ctx.plan_q7(db.customer, db.orders, db.lineitem, db.supplier, db.nation)
-        if q == 14:
-            return ctx.plan_q14(db.part, db.lineitem)
-        if q == 8:
-            return ctx.plan_q8(db.part, db.supplier, db.lineitem, db.orders, db.customer, db.nation, db.region)
-        if q == 11:
-            return ctx.plan_q11(db.partsupp, db.supplier, db.nation)
-        if q == 9:
-            return ctx.plan_q9(db.part, db.supplier, db.lineitem, db.partsupp, db.orders, db.nation)
-        raise ValueError(f"TPC-H Q{q} has no compiled plan")
-
     def plan_text(self, q):
         if not hasattr(self, "plans"):
             self.plans = {}
