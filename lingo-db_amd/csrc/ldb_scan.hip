@@ -314,7 +314,13 @@ extern "C" int32_t ldb_gpu_scan_filter(ldb_ctx* ctx, ldb_rel* in, const ldb_filt
    if (!ctx || !in || !out) LDB_FAIL(LDB_ERR_INVALID, "scan_filter: NULL argument");
    if (n_preds < 0 || n_preds > LDB_MAX_PREDS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "scan: %d predicates (max %d)", n_preds, LDB_MAX_PREDS);
    if (!in->pending.empty() && in->pending.size() + (size_t) n_preds > LDB_MAX_PREDS) LDB_TRY(ldb_rel_force(ctx, in));
-   if (!in->pending.empty() || lazy_wanted(in)) {
+   // LIKE conjuncts are evaluated by the scan kernel, whose waves stage their 64 strings in LDS and
+   // match by position (d_like_simple_wave); fused into a consumer they would run the row-wise
+   // matcher (Q13's o_comment filter inside the group-by kernel: 84 ms instead of 4 + 10)
+   bool has_like = false;
+   for (int32_t p = 0; p < n_preds; p++) has_like = has_like || preds[p].op == LDB_F_LIKE || preds[p].op == LDB_F_NOT_LIKE;
+   if (has_like && !in->pending.empty()) LDB_TRY(ldb_rel_force(ctx, in));
+   if (!has_like && (!in->pending.empty() || lazy_wanted(in))) {
       // stay lazy: the conjuncts (compiled against the dense sides) travel with the relation
       std::vector<DPred> all = in->pending;
       for (int32_t p = 0; p < n_preds; p++) {
