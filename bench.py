@@ -238,6 +238,14 @@ def main():
         cpu = None
         if world == 1 and args.cpu_sample_sf > 0:
             cpu = tpch_plans.cpu_baseline(queries, args.cpu_sample_sf, args.cpu_runs)
+        # all kernels, helpers included: Σ kernel durations ÷ wall span per query from a rocprofv3 kernel trace of the
+        # same plans on the same data (tools/query_timeline.py + tools/timeline_summary.py; profile, not this run)
+        gpu_busy = None
+        tl_path = os.path.join(ROOT, "profiles", "r02_query_timeline_sf%g.json" % args.sf)
+        if world == 1 and os.path.exists(tl_path):
+            with open(tl_path) as f:
+                tl = json.load(f)
+            gpu_busy = {"share": tl["total"]["busy_share"], "busy_ms": tl["total"]["busy"], "span_ms": tl["total"]["span"], "source": os.path.relpath(tl_path, ROOT)}
         out = {
             "metric": "tpch_sf%g_geomean_ms" % args.sf,
             "value": round(geomean([per_query[q] for q in queries]), 4),
@@ -257,7 +265,10 @@ def main():
             "per_query_ms": {"Q%d" % q: round(v, 4) for q, v in per_query.items()},
             "per_query_median_ms": {"Q%d" % q: round(sorted(q_runs[q])[len(q_runs[q]) // 2], 4) for q in queries},
             "per_query_min_ms": {"Q%d" % q: round(min(q_runs[q]), 4) for q in queries},
+            # share of the per-query time inside the operators' HIP-event-bracketed kernels (the main kernel of every
+            # operator + the group-by finalisation; helper launches — scans, compactions, gathers — are not bracketed)
             "kernel_share": round(sum(v[1] for v in kernel_ms.values()) / max(sum(q_ms.values()), 1e-9), 4),
+            "gpu_busy": gpu_busy,
             "roofline_more": more,
             "checks": checks,
             "kernel_ms_per_step": {"Q%d:%s" % (q, k): round(v[1] / args.steps, 4) for (q, k), v in sorted(kernel_ms.items())},

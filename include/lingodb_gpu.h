@@ -476,6 +476,11 @@ int32_t ldb_gpu_comm_create(ldb_ctx* ctx, int32_t rank, int32_t world, const voi
 int32_t ldb_gpu_comm_destroy(ldb_comm* comm);
 int32_t ldb_gpu_comm_rank(const ldb_comm* comm);
 int32_t ldb_gpu_comm_world(const ldb_comm* comm);
+/* Validity of one column as one byte per row (1 = valid; all ones when the column has no bitmap) into a
+ * device buffer of n_rows bytes, and the reverse (the bitmap is attached only if some byte is 0).  For
+ * exchanges done outside the library (the torch.distributed test double of ldb_gpu_allgather). */
+int32_t ldb_gpu_table_validity_bytes(ldb_ctx* ctx, const ldb_table* t, int32_t col, void* d_bytes);
+int32_t ldb_gpu_table_set_validity_bytes(ldb_ctx* ctx, ldb_table* t, int32_t col, const void* d_bytes);
 /* every rank's rows of `t` concatenated in rank order on every rank (replicated small build sides,
  * partial aggregates; fixed-width and utf8 columns, validity bitmaps travel along) */
 int32_t ldb_gpu_allgather(ldb_ctx* ctx, ldb_comm* comm, const ldb_table* t, const char* name, ldb_table** out);

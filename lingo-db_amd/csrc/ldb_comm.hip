@@ -137,6 +137,37 @@ __global__ void k_count_zero_bytes(const uint8_t* __restrict__ bytes, uint64_t n
    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
+// ---------------------------------------------------------------- validity as bytes (exchanges done outside the library)
+// The torch.distributed test double of the exchange (tpch_dist.replicate) moves flat byte buffers: a
+// column's validity travels as one byte per row and is re-attached on arrival.
+extern "C" int32_t ldb_gpu_table_validity_bytes(ldb_ctx* ctx, const ldb_table* t, int32_t col, void* d_bytes) {
+   if (!ctx || !t || !d_bytes || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "table_validity_bytes: bad argument");
+   const int64_t n = t->n_rows;
+   if (n) hipLaunchKernelGGL(k_bits_to_bytes, dim3(ldb_grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, (const uint8_t*) t->cols[(size_t) col].validity, (uint8_t*) d_bytes, (uint64_t) n);
+   LDB_HIP(hipGetLastError());
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_table_set_validity_bytes(ldb_ctx* ctx, ldb_table* t, int32_t col, const void* d_bytes) {
+   if (!ctx || !t || !d_bytes || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "table_set_validity_bytes: bad argument");
+   ldb_column& c = t->cols[(size_t) col];
+   if (!c.owned) LDB_FAIL(LDB_ERR_INVALID, "table_set_validity_bytes: the table does not own its buffers");
+   const int64_t n = t->n_rows;
+   unsigned long long* d_nulls = (unsigned long long*) ctx->d_scratch;
+   LDB_HIP(hipMemsetAsync(d_nulls, 0, 8, ctx->stream));
+   if (n) hipLaunchKernelGGL(k_count_zero_bytes, dim3(ldb_grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, (const uint8_t*) d_bytes, (uint64_t) n, d_nulls);
+   uint64_t nulls = 0;
+   LDB_TRY(ldb_read_u64(ctx, d_nulls, &nulls));
+   ldb_dev_free(ctx, c.validity);
+   c.validity = nullptr;
+   c.null_count = (int64_t) nulls;
+   if (nulls) {
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &c.validity, (size_t) ((n + 7) / 8 + 1)));
+      hipLaunchKernelGGL(k_bytes_to_bits, dim3(ldb_grid_for(ctx, (n + 7) / 8, 256, 8)), dim3(256), 0, ctx->stream, (const uint8_t*) d_bytes, c.validity, (uint64_t) n);
+      LDB_HIP(hipGetLastError());
+   }
+   return LDB_OK;
+}
+
 // ---------------------------------------------------------------- the exchange
 // Every rank sends the rows [send_off[p], send_off[p] + send_cnt[p]) of `t` to peer p and receives
 // recv_cnt[p] rows from it; the result holds the received rows in peer order.  allgather = every peer

@@ -89,9 +89,9 @@ __global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restri
                // counts are integers; handled below
             } else if (out.fn == LDB_AGG_ANY) {
                RowVals rv;
-               uint32_t rvalid;
-               d_load_vals(*d, d, rep, rv, rvalid);
-               ok = d_eval_flt(*d, out.e, rv, rvalid, &v);
+               uint32_t rvalid = 0;
+               if (d->n_rows) d_load_vals(*d, d, rep, rv, rvalid);
+               ok = d->n_rows != 0 && d_eval_flt(*d, out.e, rv, rvalid, &v);
             } else {
                v = __longlong_as_double((long long) acc[(uint64_t) d->accs[out.acc].word * cap]);
                if (out.fn == LDB_AGG_AVG && ok) v = v / (double) cnt;
@@ -110,6 +110,10 @@ __global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restri
                ok = true;
                break;
             case LDB_AGG_ANY: {
+               if (d->n_rows == 0) { // key-less aggregation over no rows: the pre-seeded group has no representative row
+                  ok = false;
+                  break;
+               }
                RowVals rv;
                uint32_t rvalid;
                d_load_vals(*d, d, rep, rv, rvalid);
@@ -613,7 +617,11 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          if ((flags & 1) == 0) continue;
       }
       // global table overflowed: retry larger (the estimate was too low)
-      if (cap >= cap_max) LDB_FAIL(LDB_ERR_HIP, "groupby: global table overflow at maximum capacity");
+      if (cap >= cap_max) {
+         ldb_dev_free(ctx, d_ctl);
+         ldb_dev_free(ctx, chunk_off);
+         LDB_FAIL(LDB_ERR_HIP, "groupby: global table overflow at maximum capacity");
+      }
       cap = std::min(cap * 8, cap_max);
    }
    ldb_dev_free(ctx, chunk_off);

@@ -39,6 +39,13 @@ struct ldb_hashtable {
    uint32_t* key_bits = nullptr; // one bit per key value of [kmin, kmax] (DJoin::has_key_bits), or NULL
    int32_t chained = 0; // one slot per distinct key, rows linked through next[] (DJoin::chained)
    uint32_t* next = nullptr;
+   // the table owns its device buffers: an early error return from the build frees them with the object
+   ~ldb_hashtable() {
+      if (!ctx) return;
+      ldb_dev_free(ctx, slots);
+      ldb_dev_free(ctx, key_bits);
+      ldb_dev_free(ctx, next);
+   }
 };
 
 // ---------------------------------------------------------------- ahead-of-time (generic) kernels
@@ -499,11 +506,8 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
    return LDB_OK;
 }
 extern "C" int32_t ldb_gpu_hashtable_release(ldb_ctx* ctx, ldb_hashtable* ht) {
-   if (!ht) return LDB_OK;
-   ldb_dev_free(ctx, ht->slots);
-   ldb_dev_free(ctx, ht->key_bits);
-   ldb_dev_free(ctx, ht->next);
-   delete ht;
+   (void) ctx;
+   delete ht; // ~ldb_hashtable frees slots / key bits / chains
    return LDB_OK;
 }
 extern "C" int64_t ldb_gpu_hashtable_slots(const ldb_hashtable* ht) { return ht ? (int64_t) ht->cap : -1; }

@@ -62,6 +62,16 @@ def main():
             if not same:
                 print(a[:3], b[:3], flush=True)
             ok = ok and same
+    # NULLs survive the exchange (a shard whose keyless partial SUM saw no row sends a NULL, not a 0)
+    import pyarrow as pa
+    import tpch_dist
+
+    mine = pa.table({"v": pa.array([None] if rank == 0 else [10 * rank], pa.int64()), "w": pa.array([rank], pa.int32())})
+    allv = tpch_dist.replicate(runner, ctx.register("nulls_%d" % rank, mine), "nulls_all").to_arrow()
+    same = allv.column(0).to_pylist() == [None] + [10 * r for r in range(1, world)] and allv.column(1).to_pylist() == list(range(world))
+    if rank == 0:
+        print(f"[dist-check] NULL exchange: {'OK' if same else 'MISMATCH'} {allv.column(0).to_pylist()}", flush=True)
+    ok = ok and same
     flag = torch.tensor([1 if ok else 0], device="cuda" if backend == "nccl" else "cpu")
     dist.broadcast(flag, 0)
     dist.barrier()

@@ -27,4 +27,4 @@ def test_sharded_plans_match_single_gpu(world):
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_check.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("OK") == 12, r.stdout
+    assert r.stdout.count("OK") == 13, r.stdout  # 12 queries + the NULL exchange

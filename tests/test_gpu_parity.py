@@ -333,6 +333,11 @@ def test_groupby_keyless_q6_and_empty(ctx, oracle, tpch):
     got = tpch["gli"].rel().groupby([], aggs2, none)
     assert rows_of(got.to_arrow()) == [(None, 0)]
     assert list(valid[0]) == [0, 1]
+    # ANY over no rows is NULL too (the pre-seeded key-less group has no representative row), also on a table without any row
+    any_agg = [api.agg(capi.AGG_ANY, api.col_expr((0, 0)), out_type=capi.T_INT32), api.agg(capi.AGG_COUNT_STAR)]
+    assert rows_of(tpch["gli"].rel().groupby([], any_agg, none).to_arrow()) == [(None, 0)]
+    empty = ctx.register("no_rows", pa.table({"k": pa.array([], pa.int32())}))
+    assert rows_of(empty.rel().groupby([], any_agg).to_arrow()) == [(None, 0)]
 
 
 def test_groupby_conditional_and_two_term_expressions(ctx, oracle, tpch):

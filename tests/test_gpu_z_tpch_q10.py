@@ -86,4 +86,4 @@ def test_q10_q15_sharded_match_single_gpu():
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_check.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("OK") == 2, r.stdout
+    assert r.stdout.count("OK") == 3, r.stdout  # Q10, Q15 + the NULL exchange

@@ -68,8 +68,9 @@ def replicate(runner, table, name):
     """all-gather a small table: every rank gets the concatenation in rank order.  Fixed-width
     columns travel as they are; a utf8 column travels as its lengths (int64 per row) plus one
     separate gather of its bytes, and the offsets are rebuilt on arrival.
-    NULLs: the exchanged partial tables carry validity only for empty-input SUMs; callers pass
-    NOT NULL tables."""
+    NULLs: a column that has a validity bitmap on ANY rank travels with one validity byte per row
+    (ldb_gpu_table_validity_bytes → gather → ldb_gpu_table_set_validity_bytes): a keyless partial
+    SUM of a shard without qualifying rows stays NULL and the merge ignores it."""
     if getattr(runner, "comm", None) is not None:  # RCCL inside the library (ldb_gpu_allgather): no torch staging, validity travels along
         return runner.comm.allgather(table, name)
     ctx, n, nc = runner.ctx, table.rows, table.n_cols
@@ -94,6 +95,15 @@ def replicate(runner, table, name):
             _d2d(ctx, t.data_ptr(), values, n * w)
             cols.append(t)
             widths.append(w)
+    # which columns carry NULLs anywhere: agreed by a MAX over the ranks' flags (one tiny collective)
+    flags = torch.tensor([1 if table.col_ptrs(c)[2] else 0 for c in range(nc)] or [0], dtype=torch.int32, device="cpu" if staged else "cuda")
+    runner.dist.all_reduce(flags, op=runner.dist.ReduceOp.MAX)
+    nullable = [c for c in range(nc) if int(flags[c].item())] if nc else []
+    for c in nullable:
+        vb = torch.empty(max(n, 1), dtype=torch.uint8, device="cuda")
+        check(ctx.lib.ldb_gpu_table_validity_bytes(ctx.h, table.h, c, C.c_void_p(vb.data_ptr())))
+        cols.append(vb)
+        widths.append(1)
     ctx.sync()
 
     def gather(tensors, ws, rows):
@@ -126,6 +136,8 @@ def replicate(runner, table, name):
             _d2d(ctx, values, data[c][0][0].data_ptr(), sum(data[c][1]))
         else:
             _d2d(ctx, values, out[c].data_ptr(), n_all * res.col_width(c))
+    for k, c in enumerate(nullable):
+        check(ctx.lib.ldb_gpu_table_set_validity_bytes(ctx.h, res.h, c, C.c_void_p(out[nc + k].data_ptr())))
     ctx.sync()
     return res
 
