@@ -256,9 +256,10 @@ __device__ __forceinline__ bool d_resid_ok(const DJoin& m, const DJoin* __restri
 // for unique ordered KEY32 tables almost every row resolves from its prefetched slots without
 // entering the walk loop.  EMIT(u, build_row) is called per match in the order row-major / slot
 // order and returns whether to keep scanning that row.
+// `pre` (optional): the batch's keys, already loaded by the caller one iteration ahead (d_prefetch_keys32).
 template <int U, typename EMIT>
 __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __restrict__ d, const uint64_t (&rows)[U], const bool (&act)[U], uint32_t (&matches)[U],
-                                              EMIT emit) {
+                                              EMIT emit, const uint32_t* pre = nullptr) {
    const KV pkeys(m.pkeys, d->pkeys);
    const uint64_t mask = d->cap - 1;
    const uint64_t* slots = gptr<uint64_t>(d->slots);
@@ -282,7 +283,9 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
 #pragma unroll
          for (int u = 0; u < U; u++) {
             const uint32_t row = act[u] ? (uint32_t) rows[u] : 0u;
-            if (narrow) {
+            if (narrow && pre) {
+               k32[u] = pre[u];
+            } else if (narrow) {
                k32[u] = (uint32_t) gptr<int32_t>(c.p.values)[row];
             } else {
                const int64_t kv = d_load_i64(c, row);
@@ -423,14 +426,38 @@ __device__ __forceinline__ uint32_t d_probe_row(const DJoin& m, const DJoin* __r
 // first matching build row of each batch row (LDB_NULL_ROW = none): what the unique-build, SEMI /
 // ANTI / MARK kinds need — no side effects inside the walk, the callers store afterwards
 template <int U>
-__device__ __forceinline__ void d_probe_first(const DJoin& m, const DJoin* __restrict__ d, const uint64_t (&rows)[U], const bool (&act)[U], uint32_t (&brow)[U]) {
+__device__ __forceinline__ void d_probe_first(const DJoin& m, const DJoin* __restrict__ d, const uint64_t (&rows)[U], const bool (&act)[U], uint32_t (&brow)[U],
+                                              const uint32_t* pre = nullptr) {
    uint32_t mt[U];
 #pragma unroll
    for (int u = 0; u < U; u++) brow[u] = LDB_NULL_ROW;
-   d_probe_batch<U>(m, d, rows, act, mt, [&](int u, uint32_t b) {
-      brow[u] = b;
-      return false;
-   });
+   d_probe_batch<U>(
+      m, d, rows, act, mt,
+      [&](int u, uint32_t b) {
+         brow[u] = b;
+         return false;
+      },
+      pre);
+}
+
+// Software pipelining of the probe's first dependent load.  A wave's iterations are serial chains
+// key → [key bit] → slot → resolve, and the PMC passes over the FK-probe micro-benchmark
+// (profiles/r02_pmc_probe.txt) show the waves parked on s_waitcnt for 83 % of their cycles while the
+// memory side moves only 2 TB/s: latency, not bandwidth.  The keys of the wave's NEXT batch are
+// therefore loaded before the current batch is probed, so they travel while its slots do — for the
+// common shape, a dense 4-byte key column without a fused filter (rows past the end read row 0).
+__device__ __forceinline__ bool d_keys_prefetchable(const DJoin& m) {
+   return m.key32 && m.n_ppreds == 0 && m.pkeys.cols[0].width == 4 && m.pkeys.cols[0].type != LDB_T_FLOAT32 && !m.pkeys.cols[0].rowids && !m.pkeys.cols[0].validity;
+}
+template <int U>
+__device__ __forceinline__ void d_prefetch_keys32(const DJoin* __restrict__ d, uint64_t row0, uint64_t n, uint32_t (&k)[U]) {
+   const int32_t* keys = gptr<int32_t>(d->pkeys.cols[0].values);
+   const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+   for (int u = 0; u < U; u++) {
+      const uint64_t r = row0 + (uint64_t) u * 64 + lane;
+      k[u] = (uint32_t) keys[r < n ? r : 0];
+   }
 }
 
 #ifndef JOIN_BATCH
@@ -446,9 +473,10 @@ __device__ __forceinline__ void d_probe_first(const DJoin& m, const DJoin* __res
 #define JP_U 4
 // rows each probe row of the batch contributes: its matches, or one NULL-padded row when an outer join finds none
 template <int U>
-__device__ __forceinline__ void d_pairs_of_rows(const DJoin& m, const DJoin* __restrict__ d, const uint64_t (&rows)[U], bool (&act)[U], uint32_t (&cnt)[U]) {
+__device__ __forceinline__ void d_pairs_of_rows(const DJoin& m, const DJoin* __restrict__ d, const uint64_t (&rows)[U], bool (&act)[U], uint32_t (&cnt)[U],
+                                                const uint32_t* pre = nullptr) {
    d_eval_conj_batch<U>(m.ppreds, d->ppreds, m.n_ppreds, rows, act); // (the host only fuses filters for INNER here)
-   d_probe_batch<U>(m, d, rows, act, cnt, [&](int, uint32_t) { return m.kind != LDB_JOIN_SINGLE; });
+   d_probe_batch<U>(m, d, rows, act, cnt, [&](int, uint32_t) { return m.kind != LDB_JOIN_SINGLE; }, pre);
 #pragma unroll
    for (int u = 0; u < U; u++)
       if (act[u] && m.kind != LDB_JOIN_INNER && cnt[u] == 0) cnt[u] = 1u;
@@ -461,6 +489,9 @@ __device__ __forceinline__ void join_probe_pairs_count_body(const DJoin& m, cons
    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
    uint32_t* chunk_cnt = gptr_mut<uint32_t>(d->match);
    unsigned long long total = 0; // exact 64-bit row count (the 32-bit offsets cannot detect > 4 G rows)
+   const bool pf = d_keys_prefetchable(m);
+   uint32_t nk[JP_U] = {0}, ck[JP_U];
+   if (pf) d_prefetch_keys32<JP_U>(d, wave * JP_U * 64, n, nk);
    for (uint64_t w0 = wave * JP_U; w0 < n_chunks; w0 += n_waves * JP_U) {
       uint64_t rows[JP_U];
       bool act[JP_U];
@@ -469,8 +500,10 @@ __device__ __forceinline__ void join_probe_pairs_count_body(const DJoin& m, cons
       for (int u = 0; u < JP_U; u++) {
          rows[u] = (w0 + u) * 64 + lane;
          act[u] = rows[u] < n;
+         ck[u] = nk[u];
       }
-      d_pairs_of_rows<JP_U>(m, d, rows, act, c);
+      if (pf) d_prefetch_keys32<JP_U>(d, (w0 + n_waves * JP_U) * 64, n, nk);
+      d_pairs_of_rows<JP_U>(m, d, rows, act, c, pf ? ck : nullptr);
 #pragma unroll
       for (int u = 0; u < JP_U; u++) {
          uint32_t s = c[u];
@@ -538,6 +571,9 @@ __device__ __forceinline__ void join_probe_count_body(const DJoin& m, const DJoi
    const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
    const uint64_t n_tiles = (n + 64 * JOIN_BATCH - 1) / (64 * JOIN_BATCH);
+   const bool pf = d_keys_prefetchable(m);
+   uint32_t nk[JOIN_BATCH] = {0}, ck[JOIN_BATCH];
+   if (pf) d_prefetch_keys32<JOIN_BATCH>(d, wave * JOIN_BATCH * 64, n, nk);
    for (uint64_t t = wave; t < n_tiles; t += n_waves) {
       uint64_t rows[JOIN_BATCH];
       bool act[JOIN_BATCH];
@@ -546,9 +582,11 @@ __device__ __forceinline__ void join_probe_count_body(const DJoin& m, const DJoi
       for (int u = 0; u < JOIN_BATCH; u++) {
          rows[u] = (t * JOIN_BATCH + u) * 64 + lane;
          act[u] = rows[u] < n;
+         ck[u] = nk[u];
       }
+      if (pf) d_prefetch_keys32<JOIN_BATCH>(d, (t + n_waves) * JOIN_BATCH * 64, n, nk);
       d_eval_conj_batch<JOIN_BATCH>(m.ppreds, d->ppreds, m.n_ppreds, rows, act);
-      d_probe_batch<JOIN_BATCH>(m, d, rows, act, mt, [](int, uint32_t) { return true; });
+      d_probe_batch<JOIN_BATCH>(m, d, rows, act, mt, [](int, uint32_t) { return true; }, pf ? ck : nullptr);
 #pragma unroll
       for (int u = 0; u < JOIN_BATCH; u++) local += mt[u];
    }
@@ -734,6 +772,9 @@ __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJo
    uint64_t* bitmap = gptr_mut<uint64_t>(d->bitmap);
    uint8_t* mark = gptr_mut<uint8_t>(d->mark);
    unsigned long long local = 0;
+   const bool pf = d_keys_prefetchable(m);
+   uint32_t nk[JE_U] = {0}, ck[JE_U];
+   if (pf) d_prefetch_keys32<JE_U>(d, wave * JE_U * 64, n, nk);
    for (uint64_t w0 = wave * JE_U; w0 < n_words; w0 += n_waves * JE_U) {
       uint64_t rows[JE_U];
       bool act[JE_U];
@@ -742,8 +783,10 @@ __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJo
       for (int u = 0; u < JE_U; u++) {
          rows[u] = (w0 + u) * 64 + lane;
          act[u] = rows[u] < n;
+         ck[u] = nk[u];
       }
-      d_probe_first<JE_U>(m, d, rows, act, first);
+      if (pf) d_prefetch_keys32<JE_U>(d, (w0 + n_waves * JE_U) * 64, n, nk);
+      d_probe_first<JE_U>(m, d, rows, act, first, pf ? ck : nullptr);
 #pragma unroll
       for (int u = 0; u < JE_U; u++) {
          const bool hit = first[u] != LDB_NULL_ROW;
@@ -787,6 +830,9 @@ __device__ __forceinline__ void join_probe_markbuild_body(const DJoin& m, const 
    const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
    const uint64_t n_tiles = (n + 64 * JE_U - 1) / (64 * JE_U);
+   const bool pf = d_keys_prefetchable(m);
+   uint32_t nk[JE_U] = {0}, ck[JE_U];
+   if (pf) d_prefetch_keys32<JE_U>(d, wave * JE_U * 64, n, nk);
    for (uint64_t t = wave; t < n_tiles; t += n_waves) {
       uint64_t rows[JE_U];
       bool act[JE_U];
@@ -795,11 +841,16 @@ __device__ __forceinline__ void join_probe_markbuild_body(const DJoin& m, const 
       for (int u = 0; u < JE_U; u++) {
          rows[u] = (t * JE_U + u) * 64 + lane;
          act[u] = rows[u] < n;
+         ck[u] = nk[u];
       }
-      d_probe_batch<JE_U>(m, d, rows, act, mt, [&](int, uint32_t b) {
-         flags[b] = 1;
-         return true;
-      });
+      if (pf) d_prefetch_keys32<JE_U>(d, (t + n_waves) * JE_U * 64, n, nk);
+      d_probe_batch<JE_U>(
+         m, d, rows, act, mt,
+         [&](int, uint32_t b) {
+            flags[b] = 1;
+            return true;
+         },
+         pf ? ck : nullptr);
    }
 }
 // flags (one byte per build row) → ballot bitmap of the rows to keep (+ their count)
@@ -839,6 +890,9 @@ __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJo
    uint64_t* bitmap = gptr_mut<uint64_t>(d->bitmap);
    uint32_t* match = gptr_mut<uint32_t>(d->match);
    unsigned long long local = 0;
+   const bool pf = d_keys_prefetchable(m);
+   uint32_t nk[JE_U] = {0}, ck[JE_U];
+   if (pf) d_prefetch_keys32<JE_U>(d, wave * JE_U * 64, n, nk);
    for (uint64_t w0 = wave * JE_U; w0 < n_words; w0 += n_waves * JE_U) {
       uint32_t brow[JE_U];
       uint64_t rows[JE_U];
@@ -847,9 +901,11 @@ __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJo
       for (int u = 0; u < JE_U; u++) {
          rows[u] = (w0 + u) * 64 + lane;
          act[u] = pass[u] = rows[u] < n;
+         ck[u] = nk[u];
       }
+      if (pf) d_prefetch_keys32<JE_U>(d, (w0 + n_waves * JE_U) * 64, n, nk);
       d_eval_conj_batch<JE_U>(m.ppreds, d->ppreds, m.n_ppreds, rows, pass); // fused filter of a lazy probe side
-      d_probe_first<JE_U>(m, d, rows, pass, brow);
+      d_probe_first<JE_U>(m, d, rows, pass, brow, pf ? ck : nullptr);
 #pragma unroll
       for (int u = 0; u < JE_U; u++) {
          // INNER reads match[] only at the bitmap's set bits: unmatched rows are not written (a
