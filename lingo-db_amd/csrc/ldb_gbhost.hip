@@ -243,6 +243,12 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    if (!ctx || !in || !out) LDB_FAIL(LDB_ERR_INVALID, "groupby: NULL argument");
    if (n_preds < 0 || n_preds > LDB_MAX_PREDS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: %d predicates (max %d)", n_preds, LDB_MAX_PREDS);
    if (in->pending.size() + (size_t) n_preds > LDB_MAX_PREDS) LDB_TRY(ldb_rel_force(ctx, in)); // else: a lazy input's conjuncts are fused below
+   if (n_keys == 0 && !in->pending.empty()) // key-less ANY needs a representative row that passed the filter: materialise a lazy input
+      for (int32_t a = 0; a < n_aggs; a++)
+         if (aggs[a].fn == LDB_AGG_ANY) {
+            LDB_TRY(ldb_rel_force(ctx, in));
+            break;
+         }
    if (n_aggs < 0 || n_aggs > GB_MAX_OUT) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: %d aggregates (max %d)", n_aggs, GB_MAX_OUT);
    if (in->n_rows >= (int64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: too many rows");
    auto hp = std::make_unique<DGroupBy>();
@@ -396,7 +402,10 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
             if (nullable || h->keyless || sp.n_preds) LDB_TRY(need_counter(&o.cnt_acc));
             break;
          }
-         case LDB_AGG_ANY: break; // evaluated on the representative row
+         case LDB_AGG_ANY: // evaluated on the group's representative row
+            // the key-less group is pre-seeded with row 0 as its representative, which need not pass a fused filter
+            if (h->keyless && h->n_preds > 0) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: ANY in a key-less aggregation with fused predicates (filter the relation first)");
+            break;
          default: LDB_FAIL(LDB_ERR_INVALID, "groupby: unknown aggregate function %d", sp.fn);
       }
       ldb_coltype ot{};
