@@ -46,7 +46,19 @@ extern "C" int32_t ldb_gpu_set_option(const char* name, int64_t value) {
    g_opts[name] = value;
    return LDB_OK;
 }
-extern "C" int64_t ldb_gpu_get_option(const char* name) { return name ? ldb_option(name, -1) : -1; }
+// the value in effect if the option was set or read before, else what LDB_<NAME> says, else -1 ("the
+// use site's default"); never caches anything itself
+extern "C" int64_t ldb_gpu_get_option(const char* name) {
+   if (!name) return -1;
+   std::lock_guard<std::mutex> lock(g_opt_mu);
+   auto it = g_opts.find(name);
+   if (it != g_opts.end()) return it->second;
+   std::string env = "LDB_";
+   for (const char* c = name; *c; c++) env += (char) toupper((unsigned char) *c);
+   if (const char* e = getenv(env.c_str())) return atoll(e);
+   return -1;
+}
+/* (ldb_gpu_set_option(name, v) with the use site's default restores the default behaviour) */
 
 // ---------------------------------------------------------------- memory
 // size classes of the block cache: 8 per doubling (≤ 12.5 % internal waste), 256 B minimum

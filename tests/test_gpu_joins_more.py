@@ -116,3 +116,48 @@ def test_three_way_join_composition(ctx, oracle, data):
     t = loc.materialize([(0, 0), (1, 0), (2, 0), (1, 1)]).to_arrow()
     assert t.column(0).to_pylist() == t.column(1).to_pylist()  # l_orderkey == o_orderkey
     assert t.column(2).to_pylist() == t.column(3).to_pylist()  # c_custkey == o_custkey
+
+
+def test_radix_clustered_probe_gives_the_direct_probe_results(ctx, oracle, data):
+    """join_radix = 1 clusters the probe side by slot range before probing (north_star's radix-partitioned
+    probe; off by default, DESIGN.md §2 Join): same pairs, rows and counts as the direct probe and as the
+    oracle — unique and duplicated build keys, a filtered (row-id) probe side, outer-join padding, build-side
+    semi / anti — with partitions small enough that the test tables span many of them."""
+    lib = capi.gpu_lib()
+    opred = [api.pred((0, 4), capi.F_GTE, 8582), api.pred((0, 4), capi.F_LT, 9300)]
+    lpred = [api.pred((0, 10), capi.F_GTE, 8800)]
+    ho = data["hod"].rel().select(oracle.scan_filter(data["hod"].rel(), opred))
+    hl = data["hli"].rel().select(oracle.scan_filter(data["hli"].rel(), lpred))
+
+    def run():
+        out = {}
+        go = data["god"].rel().scan_filter(opred)
+        gl = data["gli"].rel().scan_filter(lpred)
+        gl.rows  # force the filter: a row-id probe side
+        hu = go.join_build([(0, 0)], unique=True)
+        out["count"] = hu.probe_count(gl, [(0, 0)])
+        r = hu.probe(gl, [(0, 0)])
+        out["inner"] = sorted(zip(r.rowids(0).tolist(), r.rowids(1).tolist()))
+        r = hu.probe(gl, [(0, 0)], capi.JOIN_LEFT_OUTER)
+        out["left_outer"] = sorted(zip(r.rowids(0).tolist(), r.rowids(1).tolist()))
+        out["semi_build"] = hu.probe(gl, [(0, 0)], capi.JOIN_SEMI_BUILD).rowids(0).tolist()
+        out["anti_build"] = hu.probe(gl, [(0, 0)], capi.JOIN_ANTI_BUILD).rowids(0).tolist()
+        hd = gl.join_build([(0, 0)])  # duplicated build keys: lineitems per order; orders probe
+        r = hd.probe(go, [(0, 0)])
+        out["pairs"] = sorted(zip(r.rowids(0).tolist(), r.rowids(1).tolist()))
+        return out
+
+    try:
+        lib.ldb_gpu_set_option(b"join_radix_part_bytes", 4096)
+        lib.ldb_gpu_set_option(b"join_radix", 0)
+        direct = run()
+        lib.ldb_gpu_set_option(b"join_radix", 1)
+        radix = run()
+    finally:
+        lib.ldb_gpu_set_option(b"join_radix", 0)
+        lib.ldb_gpu_set_option(b"join_radix_part_bytes", 1 << 20)
+    assert radix == direct
+    want, wb, _ = oracle.join(ho, [(0, 0)], hl, [(0, 0)], capi.JOIN_INNER, threads=2)
+    assert len(direct["inner"]) == len(want) == direct["count"] and len(want) > 1000
+    assert direct["inner"] == sorted(zip(hl.phys(0)[want].tolist(), ho.phys(0)[wb].tolist()))
+    assert len(direct["left_outer"]) == len(hl.phys(0))
