@@ -104,8 +104,16 @@ struct DGroupBy {
    // only runs crossing a wave boundary with atomics.  No hash table, no probing: Q18's 150 M-group
    // GROUP BY l_orderkey needs ~2 atomics per 64 rows instead of 2 per group.
    int32_t dense_sorted;
-   int32_t pad1;
+   // single NOT NULL integer key whose value range fits the table: slot = key - kmin, no slot word,
+   // no probing, no key verification — a row costs its accumulator atomics only (the hashed / ordered
+   // paths add a random slot read and a random read of the representative row's key: Q13's 148 M-row
+   // count per customer 11.4 → see DESIGN.md).  Occupancy = the unconditional row counter
+   // `direct_word`; the output key column is written from the slot number by k_gb_finalize.
+   int32_t direct;
    uint64_t chunk_off; // uint32_t*: dense_sorted: number of groups that start before each 64-row chunk
+   uint64_t direct_keys_out; // device address of the output key column (run-time)
+   int32_t direct_word; // accumulator word of the row counter
+   int32_t direct_key_width; // 4, 8 or 16 bytes per output key
    DKeys keys;
    DPred preds[LDB_MAX_PREDS];
    DPred cpreds[GB_MAX_CPREDS];
@@ -447,6 +455,13 @@ __device__ __forceinline__ uint64_t d_global_slot(const DGroupBy& m, const DGrou
    return ~0ull;
 }
 
+// direct-address mode (DGroupBy::direct): the slot IS the key
+__device__ __forceinline__ uint64_t d_direct_slot(const DGroupBy& m, const DGroupBy* __restrict__ d, uint64_t i) {
+   const KV keys(m.keys, d->keys);
+   const CV c = keys.col(0);
+   return (uint64_t) (d_load_i64(c, d_phys_row(c, i)) - d->kmin);
+}
+
 // find-or-insert the group of logical row i in replica `rep` of the workgroup's LDS table;
 // returns the slot or -1 (table region full / long probe run → caller uses the global table)
 __device__ __forceinline__ int32_t d_lds_slot(const DGroupBy& m, KV keys, unsigned long long* l_keys, uint32_t S, uint32_t R, uint32_t rep, uint64_t h, uint64_t i) {
@@ -529,7 +544,7 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
          hv[u] = 0;
          rvalidv[u] = 0;
          if (passv[u]) {
-            if (!m.keyless && !m.dense_sorted) hv[u] = d_hash_keys(keys, rowsv[u]); // (dense_sorted: no table, no hash)
+            if (!m.keyless && !m.dense_sorted && !m.direct) hv[u] = d_hash_keys(keys, rowsv[u]); // (dense_sorted / direct: no hash)
             d_load_vals(m, d, rowsv[u], rvv[u], rvalidv[u]);
          }
       }
@@ -598,7 +613,7 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
                   if (true_head) gptr_mut<unsigned long long>(d->g_keys)[g] = (h & 0xFFFFFFFF00000000ull) | (unsigned long long) ((uint32_t) i + 1u);
                }
             } else if (head) {
-               g = d_global_slot(m, d, h, i);
+               g = m.direct ? d_direct_slot(m, d, i) : d_global_slot(m, d, h, i);
             }
             const bool apply = head && g != ~0ull;
             Sink s{g_acc + (apply ? g : 0), g_cap, plain};

@@ -59,15 +59,28 @@ __global__ void k_gb_occupancy(const uint64_t* __restrict__ g_keys, uint64_t cap
 }
 __global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restrict__ rep_rows, const uint32_t* __restrict__ chunk_off) {
    const uint64_t cap = d->g_cap;
+   // occupancy: the slot word, or in direct-address mode the group's row counter
+   const uint64_t* occ = d->direct ? (const uint64_t*) d->g_acc + (uint64_t) d->direct_word * cap : (const uint64_t*) d->g_keys;
    for (uint64_t p = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; p < ((cap + 63) & ~63ull); p += (uint64_t) gridDim.x * blockDim.x) {
       // the grid stride is a multiple of the wave size: a wave covers one aligned 64-slot chunk
-      uint64_t w = p < cap ? ((const uint64_t*) d->g_keys)[p] : 0;
+      uint64_t w = p < cap ? occ[p] : 0;
       const uint64_t occ = __ballot(w != 0);
       if (w == 0) continue;
       const uint32_t lane = threadIdx.x & 63;
       uint64_t g = (uint64_t) chunk_off[p >> 6] + (uint64_t) __popcll(occ & ((1ull << lane) - 1ull));
-      uint32_t rep = (uint32_t) w - 1u;
-      rep_rows[g] = rep;
+      uint32_t rep = (uint32_t) w - 1u; // (meaningless in direct mode: no aggregate reads the representative row there)
+      if (d->direct) { // the key IS the slot number
+         const long long key = (long long) d->kmin + (long long) p;
+         switch (d->direct_key_width) {
+            case 4: ((int32_t*) d->direct_keys_out)[g] = (int32_t) key; break;
+            case 8: ((int64_t*) d->direct_keys_out)[g] = (int64_t) key; break;
+            default:
+               ((int64_t*) d->direct_keys_out)[2 * g] = (int64_t) key;
+               ((int64_t*) d->direct_keys_out)[2 * g + 1] = key < 0 ? -1 : 0;
+         }
+      } else {
+         rep_rows[g] = rep;
+      }
       const uint64_t* acc = (const uint64_t*) d->g_acc + p;
       for (int o = 0; o < d->n_outs; o++) {
          const DOut& out = d->outs[o];
@@ -431,7 +444,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    }
 
    // ---- geometry
-   const int nw = h->n_words;
+   int nw = h->n_words;
    const size_t slot_bytes = 8 * (size_t) (1 + nw);
    const size_t lds_budget = 60 * 1024;
    uint64_t est = est_groups > 0 ? (uint64_t) est_groups : 0;
@@ -520,6 +533,32 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          cap = std::max<uint64_t>(1, groups); // the dense group array: exactly one slot per group
       }
    }
+   // direct-address slots (DGroupBy::direct): one NOT NULL integer key whose value range is at most twice
+   // the expected number of groups — the table is indexed by key - kmin
+   void* direct_keys = nullptr;
+   const ldb_column* direct_src = nullptr;
+   if (ldb_option("gb_direct", 1) != 0 && h->ordered_slots && !h->dense_sorted && n_keys == 1) {
+      const ldb_rel_side& ks = in->sides[(size_t) keys[0].side];
+      const ldb_column& kc = ks.table->cols[(size_t) keys[0].col];
+      bool any_fn = false;
+      for (int32_t a = 0; a < n_aggs; a++) any_fn = any_fn || aggs[a].fn == LDB_AGG_ANY;
+      const uint64_t expect = std::max<uint64_t>(est ? est : (uint64_t) in->n_rows, 1024);
+      if (!any_fn && !kc.validity && !(ks.rowids && ks.may_null) && (kc.width == 4 || kc.width == 8 || kc.width == 16) && key_range <= (unsigned __int128) expect * 2 &&
+          key_range <= ((unsigned __int128) 1 << 30)) {
+         DAcc rows;
+         memset(&rows, 0, sizeof(rows));
+         rows.kind = ACC_COUNT;
+         rows.count_rows = 1;
+         int32_t idx;
+         LDB_TRY(add_acc(rows, 1, 0, &idx)); // (an existing COUNT(*) accumulator is reused)
+         nw = h->n_words;
+         h->direct = 1;
+         h->direct_word = h->accs[idx].word;
+         h->direct_key_width = kc.width;
+         direct_src = &kc;
+         cap = std::max<uint64_t>(1024, next_pow2_u64((uint64_t) key_range));
+      }
+   }
    // One control block per call, read back ONCE per attempt: [0] the kernel's overflow / long-probe
    // flags, [1] the number of groups (total of the occupancy scan), [2 + a] NULLs of aggregate a.
    // The finalisation (occupancy → scan → k_gb_finalize → validity packing) is queued right behind
@@ -538,6 +577,8 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    auto drop_outputs = [&]() {
       ldb_dev_free(ctx, rep_rows);
       rep_rows = nullptr;
+      ldb_dev_free(ctx, direct_keys);
+      direct_keys = nullptr;
       for (int32_t a = 0; a < n_aggs; a++) {
          ldb_dev_free(ctx, out_vals[(size_t) a]);
          ldb_dev_free(ctx, out_valid[(size_t) a]);
@@ -558,7 +599,12 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       h->g_flags = (uint64_t) d_ctl;
       // upper bound of groups = min(cap, rows) (1 for keyless)
       const uint64_t max_groups = std::max<uint64_t>(1, h->keyless ? 1 : std::min<uint64_t>(cap, (uint64_t) in->n_rows));
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &rep_rows, 4 * (size_t) max_groups));
+      if (h->direct) {
+         LDB_TRY(ldb_dev_alloc(ctx, &direct_keys, (size_t) h->direct_key_width * (size_t) max_groups));
+         h->direct_keys_out = (uint64_t) direct_keys;
+      } else {
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &rep_rows, 4 * (size_t) max_groups));
+      }
       for (int32_t a = 0; a < n_aggs; a++) {
          LDB_TRY(ldb_dev_alloc(ctx, &out_vals[(size_t) a], (size_t) oinfo[(size_t) a].width * (size_t) max_groups));
          h->outs[a].out_values = (uint64_t) out_vals[(size_t) a];
@@ -581,12 +627,13 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
             spec = ldb_jit_groupby(ctx->device, h, &why);
             if (!spec) ldb_set_error("groupby: specialised kernel unavailable (%s); using the generic kernel", why.c_str());
          }
+         const char* prof_name = h->direct ? "k_groupby_direct" : "k_groupby"; // (the same kernel; the name tells the profile which slot scheme ran)
          if (spec) {
-            LdbProf prof_(ctx, "k_groupby");
+            LdbProf prof_(ctx, prof_name);
             void* params[] = {(void*) &d};
             LDB_HIP(hipModuleLaunchKernel(spec, (unsigned) grid, 1, 1, GB_BLOCK, 1, 1, (unsigned) lds_bytes, ctx->stream, params, nullptr));
          } else {
-            LdbProf prof_(ctx, "k_groupby");
+            LdbProf prof_(ctx, prof_name);
             hipLaunchKernelGGL(k_groupby, dim3(grid), dim3(GB_BLOCK), lds_bytes, ctx->stream, d);
          }
       }
@@ -599,7 +646,8 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) n_chunks));
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) n_chunks));
          const int fgrid = ldb_grid_for(ctx, (int64_t) cap, 256, 8);
-         hipLaunchKernelGGL(k_gb_occupancy, dim3(fgrid), dim3(256), 0, ctx->stream, (const uint64_t*) h->g_keys, cap, pop);
+         const uint64_t* occ = h->direct ? (const uint64_t*) h->g_acc + (uint64_t) h->direct_word * cap : (const uint64_t*) h->g_keys;
+         hipLaunchKernelGGL(k_gb_occupancy, dim3(fgrid), dim3(256), 0, ctx->stream, occ, cap, pop);
          LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, n_chunks, (uint64_t*) (d_ctl + 1)));
          hipLaunchKernelGGL(k_gb_finalize, dim3(fgrid), dim3(256), 0, ctx->stream, d, rep_rows, (const uint32_t*) off);
          for (int32_t a = 0; a < n_aggs; a++)
@@ -644,9 +692,17 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    // ---- result table: key columns = gather of representative rows, then aggregates
    res->n_rows = (int64_t) n_groups;
    res->cols.resize((size_t) (n_keys + n_aggs));
-   ldb_rel* reps = nullptr;
-   LDB_TRY(ldb_rel_select(ctx, in, rep_rows, (int64_t) n_groups, &reps));
-   {
+   if (h->direct) { // the key column was written by k_gb_finalize
+      ldb_column& kc = res->cols[0];
+      kc.name = direct_src->name;
+      kc.type = direct_src->type;
+      kc.width = direct_src->width;
+      kc.values = direct_keys;
+      kc.value_bytes = (int64_t) n_groups * kc.width;
+      kc.owned = true;
+   } else {
+      ldb_rel* reps = nullptr;
+      LDB_TRY(ldb_rel_select(ctx, in, rep_rows, (int64_t) n_groups, &reps));
       const int32_t s = n_keys ? ldb_gather_columns(ctx, reps, keys, n_keys, res->cols.data()) : LDB_OK;
       ldb_gpu_rel_release(ctx, reps);
       if (s != LDB_OK) return s;

@@ -245,6 +245,7 @@ static void gb_meta(const DGroupBy* h, DGroupBy* m) {
    m->n_rows = 0;
    m->g_cap = 0;
    m->g_keys = m->g_acc = m->g_flags = 0;
+   m->direct_keys_out = 0;
    m->lds_slots = m->lds_reps = 0;
    m->kmin = 0;
    m->kmult = 0;

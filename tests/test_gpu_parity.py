@@ -432,6 +432,49 @@ def test_groupby_run_combining_high_cardinality(ctx, oracle):
             assert s == pytest.approx(vals[gi][0], rel=1e-9, abs=1e-9) and mn == vals[gi][1] and mx == vals[gi][2]
 
 
+def test_groupby_direct_address_slots(ctx, oracle):
+    """one NOT NULL integer key whose value range is at most twice the expected groups: the table is indexed by
+    key - min (DGroupBy::direct) — no slot word, no probing, the key column written from the slot number.  Random
+    key order, gaps, negative keys, int32 / int64 / date32 keys, a fused filter, conditional and 128-bit aggregates,
+    AVG, MIN / MAX with NULL values, a row-id (filtered) input; same rows as the oracle and as the hashed path."""
+    rng = np.random.default_rng(23)
+    n = 120000
+    lib = capi.gpu_lib()
+    f = api.factor
+    for ktype, lo in ((pa.int32(), -7000), (pa.int64(), 3_000_000_000), (pa.date32(), 9000)):
+        keys = lo + rng.integers(0, 40000, n) * (1 if ktype == pa.date32() else 2)
+        kcol = pa.array(keys.astype(np.int32), pa.int32()).cast(pa.date32()) if ktype == pa.date32() else pa.array(keys, ktype)
+        v = [None if x % 7 == 0 else int(x) for x in rng.integers(-10**9, 10**9, n)]
+        t = pa.table({"k": kcol, "v": pa.array(v, pa.int64()), "w": pa.array(rng.integers(0, 100, n), pa.int32())})
+        g, h = ctx.register("direct_keys", t), HostTable(t)
+        sq = api.expr([{"factors": [f(0, 1, (0, 1)), f(0, 1, (0, 1)), f(3, 1, (0, 2))]}])
+        cond = [api.pred((0, 2), capi.F_GTE, 50)]
+        aggs = [api.agg(capi.AGG_SUM, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT_STAR), api.agg(capi.AGG_MIN, api.col_expr((0, 1))), api.agg(capi.AGG_MAX, api.col_expr((0, 1))),
+                api.agg(capi.AGG_SUM, sq, wide=True, out_type=capi.T_DECIMAL128, p=38, s=0), api.agg(capi.AGG_SUM, api.col_expr((0, 2)), preds=cond),
+                api.agg(capi.AGG_COUNT, api.col_expr((0, 1)))]
+        filt = [api.pred((0, 2), capi.F_LT, 90)]
+        for plist, pre in ((filt, False), ([], True), ([], False)):
+            grel, hrel = g.rel(), h.rel()
+            if pre:  # a row-id input
+                grel = grel.scan_filter(filt)
+                grel.rows
+                hrel = hrel.select(oracle.scan_filter(h.rel(), filt))
+            rep, vals, valid = oracle.groupby(hrel, [(0, 0)], aggs, plist)
+            ctx.prof_reset()
+            ctx.prof_enable(True)
+            got = grel.groupby([(0, 0)], aggs, plist, est_groups=40000)
+            assert ctx.prof_all().get("k_groupby_direct", (0, 0.0))[0] >= 1, "the direct-address path did not run"
+            assert_groupby_equal(got, hrel, [(0, 0)], rep, vals, valid)
+            lib.ldb_gpu_set_option(b"gb_direct", 0)
+            try:
+                hashed = grel.groupby([(0, 0)], aggs, plist, est_groups=40000)
+            finally:
+                lib.ldb_gpu_set_option(b"gb_direct", 1)
+            assert sorted(rows_of(hashed.to_arrow()), key=repr) == sorted(rows_of(got.to_arrow()), key=repr)
+            assert got.to_arrow().schema.field(0).type == ktype
+    ctx.prof_enable(False)
+
+
 # ---------------------------------------------------------------- joins (a6, a7, a8)
 def pairs(rel):
     return sorted(zip(rel.rowids(0).tolist(), rel.rowids(rel.sides - 1).tolist()))
