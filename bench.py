@@ -95,11 +95,40 @@ def main():
                 dist.broadcast_object_list(box, src=0)
                 return box[0]
 
+            def all_ranks_ok(ok):  # every rank must take the same path: agree on the MIN of the local verdicts
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return int(flag.item()) == 1
+
+            comm, good = None, False
             try:
-                runner.comm = api.Comm(ctx, rank, world, exchange_id)
-                exchange = "librccl inside liblingodb_gpu.so (grouped send/recv on the ctx stream)"
+                comm = api.Comm(ctx, rank, world, exchange_id)
+                good = True
             except Exception as e:  # keep the bench alive on the proven path; the line says which path ran
                 print(f"[bench] rank {rank}: in-library RCCL communicator failed ({e}); using torch.distributed", file=sys.stderr, flush=True)
+            if all_ranks_ok(good):
+                good = False
+                try:  # one tiny all-gather with a string column and a NULL before any query depends on it
+                    import pyarrow as pa
+
+                    mine = ctx.register("comm_selftest", pa.table({"r": pa.array([rank, rank], pa.int32()), "s": pa.array(["x" * rank, None], pa.string())}))
+                    got = comm.allgather(mine, "comm_selftest_all").to_arrow()
+                    good = (got.column(0).to_pylist() == [r for r in range(world) for _ in (0, 1)]
+                            and got.column(1).to_pylist() == [v for r in range(world) for v in ("x" * r, None)])
+                    if not good:
+                        print(f"[bench] rank {rank}: in-library all-gather self-test returned {got.to_pylist()}", file=sys.stderr, flush=True)
+                except Exception as e:
+                    print(f"[bench] rank {rank}: in-library all-gather self-test failed ({e})", file=sys.stderr, flush=True)
+                good = all_ranks_ok(good)
+            else:
+                good = False
+            if good:
+                runner.comm = comm
+                exchange = "librccl inside liblingodb_gpu.so (grouped send/recv on the ctx stream)"
+            else:
+                if comm is not None:
+                    comm.close()
+                exchange = "torch.distributed (%s; the in-library RCCL exchange was not usable on every rank)" % backend
 
     def barrier():
         ctx.sync()
