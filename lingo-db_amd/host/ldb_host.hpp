@@ -103,6 +103,8 @@ const char* ldb_plan_last_error(void);
 // input tables; *result = the table the plan names as its result (caller releases).
 int32_t ldb_plan_run_json(ldb_ctx* ctx, const char* plan_json, const char* const* table_names, const ldb_table* const* tables, int32_t n_tables, ldb_table** result);
 const char* ldb_plan_json_last_error(void);
+// structure check without a device: parse, known steps with their required fields, values defined before use
+int32_t ldb_plan_json_check(const char* plan_json, const char* const* input_names, int32_t n_inputs);
 // multi-GPU pieces: shard-local partial plans + merges of the exchanged partial tables
 int32_t ldb_plan_tpch_q1_partial(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
 int32_t ldb_plan_tpch_q1_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);

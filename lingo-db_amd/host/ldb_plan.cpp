@@ -990,3 +990,59 @@ extern "C" int32_t ldb_plan_run_json(ldb_ctx* ctx, const char* plan_json, const 
    }
 }
 extern "C" const char* ldb_plan_json_last_error(void) { return g_plan_json_err.c_str(); }
+
+// Device-less check of a plan's structure (what an emitter can verify before shipping a plan): the text
+// parses, every step has a known "op" with its required fields, every value a step reads was named as an
+// input or produced by an earlier step, no value is produced twice, and the result is produced by a step.
+// Column names and types are only known at run time (ldb_plan_run_json).
+extern "C" int32_t ldb_plan_json_check(const char* plan_json, const char* const* input_names, int32_t n_inputs) {
+   if (!plan_json || n_inputs < 0) {
+      g_plan_json_err = "plan_json_check: bad argument";
+      return LDB_ERR_INVALID;
+   }
+   try {
+      JParser parser(plan_json);
+      const J plan = parser.value();
+      if (plan.kind != J::OBJ) throw std::runtime_error("plan: the top level must be an object");
+      std::map<std::string, bool> known; // name → produced by a step (false: an input)
+      for (int32_t i = 0; i < n_inputs; i++) known[input_names[i]] = false;
+      if (const J* in = plan.get("inputs"))
+         for (auto& e : in->arr)
+            if (!known.count(e.str)) {
+               if (n_inputs > 0) throw std::runtime_error("plan: input '" + e.str + "' is not provided");
+               known[e.str] = false;
+            }
+      struct Shape {
+         const char* op;
+         std::vector<const char*> reads, needs;
+      };
+      static const std::vector<Shape> shapes = {{"scan", {"table"}, {}},           {"filter", {"in"}, {"preds"}},        {"filter_dnf", {"in"}, {"clauses"}},
+                                                {"join_build", {"in"}, {"keys"}},  {"join_probe", {"ht", "in"}, {"keys"}}, {"groupby", {"in"}, {"aggs"}},
+                                                {"map", {"in"}, {"as"}},           {"sort", {"in"}, {"by"}},             {"topk", {"in"}, {"by", "k"}},
+                                                {"materialize", {"in"}, {"cols"}}};
+      const J& steps = plan.at("steps");
+      if (steps.kind != J::ARR) throw std::runtime_error("plan: 'steps' must be an array");
+      for (auto& st : steps.arr) {
+         const std::string& op = st.s("op");
+         const Shape* sh = nullptr;
+         for (auto& c : shapes)
+            if (op == c.op) sh = &c;
+         if (!sh) throw std::runtime_error("plan: unknown step '" + op + "'");
+         const std::string& out = st.s("out");
+         for (const char* r : sh->reads)
+            if (!known.count(st.s(r))) throw std::runtime_error("plan: step '" + op + "' → '" + out + "' reads '" + st.s(r) + "' before it exists");
+         for (const char* f : sh->needs) (void) st.at(f);
+         if (op == "map" && !st.get("expr") && !st.get("fn")) throw std::runtime_error("plan: map → '" + out + "' needs 'expr' or 'fn'");
+         if (known.count(out)) throw std::runtime_error("plan: value '" + out + "' defined twice");
+         known[out] = true;
+         if (const J* mo = st.get("mark_out")) known[mo->str] = true;
+      }
+      const std::string result = plan.sOr("result", "result");
+      auto it = known.find(result);
+      if (it == known.end() || !it->second) throw std::runtime_error("plan: result '" + result + "' is not produced by a step");
+      return LDB_OK;
+   } catch (const std::exception& e) {
+      g_plan_json_err = e.what();
+      return LDB_ERR_INVALID;
+   }
+}

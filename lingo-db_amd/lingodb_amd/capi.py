@@ -246,6 +246,7 @@ HOST_API = {
     "ldb_plan_last_error": (C.c_char_p, []),
     "ldb_plan_run_json": (i32, [P, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(P), i32, PP]),
     "ldb_plan_json_last_error": (C.c_char_p, []),
+    "ldb_plan_json_check": (i32, [C.c_char_p, C.POINTER(C.c_char_p), i32]),
     "ldb_plan_tpch_q1_partial": (i32, [P, P, PP]),
     "ldb_plan_tpch_q1_final": (i32, [P, P, PP]),
     "ldb_plan_tpch_q6_final": (i32, [P, P, PP]),

@@ -18,3 +18,42 @@ def test_every_plan_file_is_listed():
         outs = [s["out"] for s in plan["steps"]]
         assert len(outs) == len(set(outs)) and plan["result"] in outs
         assert {s["op"] for s in plan["steps"]} <= STEP_OPS
+
+
+def _check(text, inputs):
+    import ctypes as C
+
+    from lingodb_amd import capi
+
+    lib = capi.host_lib()
+    arr = (C.c_char_p * max(len(inputs), 1))(*[n.encode() for n in inputs])
+    st = lib.ldb_plan_json_check(text.encode(), arr, len(inputs))
+    return st, lib.ldb_plan_json_last_error().decode(errors="replace")
+
+
+def test_plan_files_pass_the_interpreters_structure_check():
+    """the interpreter's own parser and step table accept every shipped plan (no device needed):
+    values are defined before use, never twice, and the result is produced by a step"""
+    for q in range(1, 23):
+        with open(os.path.join(ROOT, "lingo-db_amd", "plans", "tpch", "q%d.json" % q)) as f:
+            text = f.read()
+        st, err = _check(text, sorted(tpch_plans.JSON_PLANS[q]))
+        assert st == 0, (q, err)
+
+
+def test_structure_check_names_what_is_wrong():
+    ok = '{"steps": [{"op": "filter", "in": "t", "out": "a", "preds": []}, {"op": "materialize", "in": "a", "cols": [], "out": "r"}], "result": "r"}'
+    assert _check(ok, ["t"])[0] == 0
+    cases = [
+        ('{"steps": [', "plan JSON"),
+        ('{"steps": [{"op": "frobnicate", "out": "x"}], "result": "x"}', "unknown step"),
+        ('{"steps": [{"op": "filter", "in": "nope", "out": "a", "preds": []}], "result": "a"}', "before it exists"),
+        ('{"steps": [{"op": "filter", "in": "t", "out": "a"}], "result": "a"}', "preds"),
+        ('{"steps": [{"op": "filter", "in": "t", "out": "a", "preds": []}, {"op": "sort", "in": "a", "by": [], "out": "a"}], "result": "a"}', "defined twice"),
+        ('{"steps": [{"op": "filter", "in": "t", "out": "a", "preds": []}], "result": "t"}', "not produced"),
+        ('{"inputs": ["u"], "steps": [], "result": "u"}', "not provided"),
+        ('{"steps": [{"op": "map", "in": "t", "as": "c", "out": "m"}], "result": "m"}', "expr"),
+    ]
+    for text, needle in cases:
+        st, err = _check(text, ["t"])
+        assert st != 0 and needle in err, (text, err)
