@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--queries", default="", help="TPC-H queries of one step (default: all 22 on one GPU; the 14 with multi-GPU plans when --gpus > 1)")
     ap.add_argument("--narrow-decimals", type=int, default=0)
     ap.add_argument("--cpu-sample-sf", type=float, default=1.0, help="scale of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-runs", default="1+3", help="CPU baseline protocol warm-up+measured (the reference's benchmark.py uses 3+10)")
+    ap.add_argument("--cpu-runs", default="3+10", help="CPU baseline protocol warm-up+measured passes (3+10 = the reference's tools/scripts/benchmark.py; ≈ 30 s of CPU work at SF1)")
     args = ap.parse_args()
 
     import torch
