@@ -257,6 +257,12 @@ typedef struct {
  * holds the passing rows in ascending row order (the order of the reference's selection
  * vectors inside a morsel, morsels in table order). */
 int32_t ldb_gpu_scan_filter(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds, int32_t n_preds, ldb_rel** out);
+/* How a LIKE / NOT LIKE pattern will be matched (no device needed): *n_segments = 0 → the general matcher
+ * (StringRuntime::like semantics: '_', escapes, non-ASCII); otherwise the pattern is ASCII literals separated
+ * by '%' (≤ 4 of ≤ 16 bytes) and is matched by position inside the scan kernel — seg[2j], seg[2j+1] = start and
+ * length of literal j in the pattern, *anchors bit 0 / bit 1 = no leading / trailing '%'. */
+int32_t ldb_gpu_like_plan(const char* pattern, int32_t len, int32_t* n_segments, int32_t* seg, int32_t* anchors);
+
 /* Disjunctive normal form: rows satisfying (clause 0) OR (clause 1) OR …, each clause a conjunction
  * of clause_sizes[c] consecutive entries of `preds` (<= 4 clauses, <= 24 conjuncts in all) — TPC-H
  * Q19's three alternatives.  The reference evaluates such a predicate as generated residual code

@@ -926,6 +926,23 @@ int32_t ldb_make_dpred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out) {
 // (StringRuntime.cpp:28-93): an ASCII pattern byte never equals a UTF-8 lead or continuation byte.
 // Plan: n_in = number of literal segments (0 = not simple), in_off[2j] / in_off[2j+1] = start and
 // length of segment j inside str, lo bit 0 / bit 1 = the pattern is anchored at the start / end.
+void ldb_like_plan(DPred* d);
+// the planner's verdict on a pattern, for host-side tests and for an emitter that wants to know which
+// matcher a LIKE will get: *n_segments = 0 → general matcher; else seg[2j] / seg[2j+1] = start / length of
+// literal j inside the pattern and *anchors bit 0 / bit 1 = anchored at the start / end.  No device needed.
+extern "C" int32_t ldb_gpu_like_plan(const char* pattern, int32_t len, int32_t* n_segments, int32_t* seg, int32_t* anchors) {
+   if (!pattern || !n_segments || len < 0 || len > LDB_STR_INLINE) LDB_FAIL(LDB_ERR_INVALID, "like_plan: bad argument (patterns are at most %d bytes)", LDB_STR_INLINE);
+   DPred d;
+   memset(&d, 0, sizeof(d));
+   d.str_len = len;
+   memcpy(d.str, pattern, (size_t) len);
+   ldb_like_plan(&d);
+   *n_segments = d.n_in;
+   if (seg)
+      for (int j = 0; j < 2 * d.n_in; j++) seg[j] = d.in_off[j];
+   if (anchors) *anchors = d.n_in ? (int32_t) (d.lo & 3) : 0;
+   return LDB_OK;
+}
 void ldb_like_plan(DPred* d) {
    d->n_in = 0;
    const int n = d->str_len;

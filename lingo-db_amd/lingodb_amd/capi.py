@@ -154,6 +154,7 @@ GPU_API = {
     "ldb_gpu_timer_elapsed_ms": (i32, [P, i32, C.POINTER(C.c_float)]),
     "ldb_gpu_prof_enable": (i32, [P, i32]),
     "ldb_gpu_prof_marker": (i32, [P, i32]),
+    "ldb_gpu_like_plan": (i32, [C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "ldb_gpu_table_validity_bytes": (i32, [P, P, i32, P]),
     "ldb_gpu_table_set_validity_bytes": (i32, [P, P, i32, P]),
     "ldb_gpu_prof_reset": (i32, [P]),

@@ -149,3 +149,27 @@ def test_runtime_specialiser_compiles_without_a_device():
     buf = C.create_string_buffer(16000)
     st = capi.gpu_lib().ldb_gpu_jit_compile_check(buf, 16000)
     assert st == 0, buf.value.decode(errors="replace")
+
+
+def test_like_planner_classifies_patterns():
+    """which LIKE patterns get the position-parallel matcher (ASCII literals separated by '%', <= 4 segments
+    of <= 16 bytes) and which stay with the general one ('_', escapes, non-ASCII, only wildcards)"""
+    lib = capi.gpu_lib()
+
+    def plan(pat):
+        b = pat.encode()
+        n, anchors = C.c_int32(), C.c_int32()
+        seg = (C.c_int32 * 8)()
+        assert lib.ldb_gpu_like_plan(b, len(b), C.byref(n), seg, C.byref(anchors)) == 0
+        return n.value, [(seg[2 * j], seg[2 * j + 1]) for j in range(n.value)], anchors.value
+
+    assert plan("%special%requests%") == (2, [(1, 7), (9, 8)], 0)  # TPC-H Q13
+    assert plan("%Customer%Complaints%") == (2, [(1, 8), (10, 10)], 0)  # Q16: a 10-byte segment (two-word compare)
+    assert plan("PROMO%") == (1, [(0, 5)], 1) and plan("%BRASS") == (1, [(1, 5)], 2) and plan("%green%") == (1, [(1, 5)], 0)
+    assert plan("MEDIUM POLISHED%") == (1, [(0, 15)], 1)
+    assert plan("abc") == (1, [(0, 3)], 3)  # no wildcard: equality, anchored at both ends
+    assert plan("a%%b%c%d") == (4, [(0, 1), (3, 1), (5, 1), (7, 1)], 3)  # consecutive '%' collapse
+    for general in ("", "%", "%%", "_o%", "%a_c%", "%\\%%", "a\\", "%é", "a%b%c%d%e", "%" + "x" * 17 + "%"):
+        assert plan(general)[0] == 0, general
+    n = C.c_int32()
+    assert lib.ldb_gpu_like_plan(b"x" * 49, 49, C.byref(n), None, None) != 0  # longer than the descriptor's inline constant
