@@ -57,3 +57,36 @@ def test_structure_check_names_what_is_wrong():
     for text, needle in cases:
         st, err = _check(text, ["t"])
         assert st != 0 and needle in err, (text, err)
+
+
+def test_database_generates_every_column_a_plan_names():
+    """bench.py's Database generates only the columns the selected queries touch: every TPC-H column a plan
+    file names must be among them, per query (checked with a recording stand-in for the device context)"""
+    import re
+
+    import tpch_data
+
+    class Recorder:
+        def __init__(self):
+            self.tables = {}
+
+        def tpch_generate(self, table_id, n_orders, part=0, n_parts=1, cols=None, narrow_decimals=False):
+            names = [tpch_data.SCHEMAS[table_id][c][0] for c in (cols if cols is not None else range(len(tpch_data.SCHEMAS[table_id])))]
+            self.tables.setdefault(table_id, set()).update(names)
+            return ("table", table_id, tuple(names))
+
+    all_cols = {name: tid for tid, fields in tpch_data.SCHEMAS.items() for name, _ in fields}
+    for q in range(1, 23):
+        rec = Recorder()
+        db = tpch_plans.Database(rec, 1500, 0, 1, [q], False)
+        with open(os.path.join(ROOT, "lingo-db_amd", "plans", "tpch", "q%d.json" % q)) as f:
+            text = f.read()
+        provided = {name: getattr(db, attr) for name, attr in tpch_plans.JSON_PLANS[q].items()}
+        assert all(v is not None for v in provided.values()), (q, provided)
+        for col in set(re.findall(r'"(?:\d:)?((?:l|o|c|p|ps|s|n|r)_[a-z]+)"', text)):
+            if col not in all_cols:
+                continue  # a name the plan itself introduces (`as`, key_names)
+            table = {"l": "lineitem", "o": "orders", "c": "customer", "p": "part", "ps": "partsupp", "s": "supplier", "n": "nation", "r": "region"}[col.split("_")[0]]
+            if table not in provided:
+                continue
+            assert col in provided[table][2], (q, col, sorted(provided[table][2]))
