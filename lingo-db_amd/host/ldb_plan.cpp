@@ -70,7 +70,16 @@ struct JParser {
    void ws() {
       while (*p && isspace((unsigned char) *p)) p++;
    }
+   int depth = 0; // nesting of the value being parsed (plans nest ~6 deep; a bound keeps a hostile text from exhausting the stack)
+   struct Nest {
+      JParser& jp;
+      explicit Nest(JParser& q) : jp(q) {
+         if (++jp.depth > 64) jp.fail("nesting deeper than 64");
+      }
+      ~Nest() { jp.depth--; }
+   };
    J value() {
+      Nest nest(*this);
       ws();
       J j;
       if (*p == '{') {

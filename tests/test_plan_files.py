@@ -53,6 +53,7 @@ def test_structure_check_names_what_is_wrong():
         ('{"steps": [{"op": "filter", "in": "t", "out": "a", "preds": []}], "result": "t"}', "not produced"),
         ('{"inputs": ["u"], "steps": [], "result": "u"}', "not provided"),
         ('{"steps": [{"op": "map", "in": "t", "as": "c", "out": "m"}], "result": "m"}', "expr"),
+        ('{"steps": ' + "[" * 100 + "]" * 100 + ', "result": "x"}', "nesting"),
     ]
     for text, needle in cases:
         st, err = _check(text, ["t"])
