@@ -425,6 +425,8 @@ int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_colref* keys,
                            ldb_hashtable** out);
 int32_t ldb_gpu_hashtable_release(ldb_ctx* ctx, ldb_hashtable* ht);
 int64_t ldb_gpu_hashtable_slots(const ldb_hashtable* ht);
+// bytes of the slot array (8 B per open-addressing slot; 4 B per key value of a direct-addressed table)
+int64_t ldb_gpu_hashtable_bytes(const ldb_hashtable* ht);
 /* Replaces LookupHashIndexedViewLowering + ScanListLowering (SubOpToControlFlow.cpp:2558-2586,
  * 2254-2313).  Output relation: INNER / LEFT_OUTER / SINGLE → sides = probe sides then build sides,
  * one row per match (LEFT_OUTER/SINGLE: unmatched probe rows carry LDB_NULL_ROW on build sides);
@@ -470,23 +472,26 @@ int32_t ldb_gpu_topk(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int3
 int32_t ldb_gpu_partition(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* keys, int32_t n_keys, int32_t nparts,
                           const ldb_colref* cols, int32_t n_cols, ldb_table** out, int64_t* counts);
 
-/* The exchange itself: RCCL over xGMI, one rank (= one ldb_ctx) per GPU.  Rank 0 makes a 128-byte id
- * (ldb_gpu_comm_unique_id = ncclGetUniqueId), the host process hands it to every rank by whatever
- * channel it has (the LingoDB side: its session layer; the tests: torch.distributed / a file), and
- * every rank joins with ldb_gpu_comm_create.  All transfers are issued on the context's stream as ONE
- * grouped batch of point-to-point sends / receives per call (every peer pair has its own xGMI
- * link), straight into the column buffers of the result table. */
+/* The exchange itself: one rank (= one ldb_ctx) per GPU.  Rank 0 makes a 128-byte id, the host process hands
+ * it to every rank by whatever channel it has (the LingoDB side: its session layer; bench.py:
+ * torch.distributed; the tests: a file), and every rank joins with ldb_gpu_comm_create.  Two transports
+ * (option `comm_transport`, read by ldb_gpu_comm_unique_id; the id carries the choice to every rank):
+ *   0 = RCCL over xGMI (default; id = ncclGetUniqueId): all transfers are issued on the context's stream as
+ *       ONE grouped batch of point-to-point sends / receives per call (every peer pair has its own xGMI
+ *       link), straight into the column buffers of the result table;
+ *   1 = host-staged through POSIX shared memory: the ranks are processes of one node and may share a GPU
+ *       (RCCL refuses that).  Same grouped-transfer interface, so every world > 1 code path of the exchange
+ *       runs under test on a one-GPU box; also the fallback when RCCL cannot be initialised.  Waits are
+ *       bounded by option `comm_timeout_ms` (default 120 000).
+ * The reference has no counterpart (single process: src/runtime/GPU/CUDA/CMakeLists.txt:9 "we do not support
+ * multi-gpu"); SURVEY §8(e) assigns the design to this library. */
 typedef struct ldb_comm ldb_comm;
 int32_t ldb_gpu_comm_unique_id(void* id128);
 int32_t ldb_gpu_comm_create(ldb_ctx* ctx, int32_t rank, int32_t world, const void* id128, ldb_comm** out);
 int32_t ldb_gpu_comm_destroy(ldb_comm* comm);
 int32_t ldb_gpu_comm_rank(const ldb_comm* comm);
 int32_t ldb_gpu_comm_world(const ldb_comm* comm);
-/* Validity of one column as one byte per row (1 = valid; all ones when the column has no bitmap) into a
- * device buffer of n_rows bytes, and the reverse (the bitmap is attached only if some byte is 0).  For
- * exchanges done outside the library (the torch.distributed test double of ldb_gpu_allgather). */
-int32_t ldb_gpu_table_validity_bytes(ldb_ctx* ctx, const ldb_table* t, int32_t col, void* d_bytes);
-int32_t ldb_gpu_table_set_validity_bytes(ldb_ctx* ctx, ldb_table* t, int32_t col, const void* d_bytes);
+const char* ldb_gpu_comm_transport(const ldb_comm* comm); /* "rccl" | "shm" */
 /* every rank's rows of `t` concatenated in rank order on every rank (replicated small build sides,
  * partial aggregates; fixed-width and utf8 columns, validity bitmaps travel along) */
 int32_t ldb_gpu_allgather(ldb_ctx* ctx, ldb_comm* comm, const ldb_table* t, const char* name, ldb_table** out);

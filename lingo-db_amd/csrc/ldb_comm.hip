@@ -14,8 +14,17 @@
 #include "ldb_internal.h"
 #include "ldb_device.h"
 #include <rccl/rccl.h>
+#include <atomic>
+#include <chrono>
+#include <cctype>
+#include <cerrno>
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <memory>
+#include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <vector>
 
 // librccl is bound at run time, on the first communicator call: a process that already carries an
@@ -31,8 +40,8 @@ struct Rccl {
    decltype(&::ncclGroupEnd) GroupEnd = nullptr;
    decltype(&::ncclSend) Send = nullptr;
    decltype(&::ncclRecv) Recv = nullptr;
-   decltype(&::ncclAllGather) AllGather = nullptr;
    bool ok = false;
+   std::string why;
 };
 Rccl& rccl() {
    static Rccl r;
@@ -51,67 +60,292 @@ Rccl& rccl() {
          r.GroupEnd = (decltype(r.GroupEnd)) dlsym(h, "ncclGroupEnd");
          r.Send = (decltype(r.Send)) dlsym(h, "ncclSend");
          r.Recv = (decltype(r.Recv)) dlsym(h, "ncclRecv");
-         r.AllGather = (decltype(r.AllGather)) dlsym(h, "ncclAllGather");
-         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GetErrorString && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllGather;
+         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GetErrorString && r.GroupStart && r.GroupEnd && r.Send && r.Recv;
+         if (!r.ok) r.why = "symbols missing";
+      } else {
+         const char* e = dlerror(); // (a second dlerror() call returns NULL: keep the first answer)
+         r.why = e ? e : "dlopen failed";
       }
    }
    return r;
 }
-} // namespace
-#define ncclGetUniqueId rccl().GetUniqueId
-#define ncclCommInitRank rccl().CommInitRank
-#define ncclCommDestroy rccl().CommDestroy
-#define ncclGetErrorString rccl().GetErrorString
-#define ncclGroupStart rccl().GroupStart
-#define ncclGroupEnd rccl().GroupEnd
-#define ncclSend rccl().Send
-#define ncclRecv rccl().Recv
-#define ncclAllGather rccl().AllGather
-
-struct ldb_comm {
-   ncclComm_t comm = nullptr;
-   int32_t rank = 0, world = 1;
-};
 
 #define LDB_NCCL(expr)                                                                                   \
    do {                                                                                                  \
       ncclResult_t r_ = (expr);                                                                          \
       if (r_ != ncclSuccess) {                                                                           \
-         ldb_set_error("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__);      \
+         ldb_set_error("%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(r_), __FILE__, __LINE__);   \
          return LDB_ERR_HIP;                                                                             \
       }                                                                                                  \
    } while (0)
 
+// ---------------------------------------------------------------- transports
+// The exchange needs exactly one primitive: a GROUP of point-to-point byte transfers between the ranks
+// (every rank lists its sends and receives; transfers of one (sender, receiver) pair match in order).
+// Two transports implement it:
+//   RCCL  — ncclGroupStart … ncclSend / ncclRecv … ncclGroupEnd on the ctx stream: one rank per GPU, xGMI.
+//   SHM   — host-staged through POSIX shared memory: ranks are processes of one node that may SHARE a GPU
+//           (RCCL refuses two ranks on one device).  The sender copies its bytes device → a /dev/shm segment
+//           per (sender, receiver) pair, a barrier in a shared control segment publishes them, the receiver
+//           copies segment → device.  It exists so that every world > 1 path of this file — metadata
+//           all-to-all, displacement arithmetic, offset / bitmap rebuild on arrival — runs under test on a
+//           one-GPU box, and as the fallback when RCCL cannot be initialised; it is not a fast path.
+struct Transport {
+   virtual ~Transport() {}
+   virtual const char* name() const = 0;
+   virtual int32_t group_start() = 0;
+   virtual int32_t send(const void* d_ptr, size_t bytes, int peer) = 0;
+   virtual int32_t recv(void* d_ptr, size_t bytes, int peer) = 0;
+   virtual int32_t group_end() = 0; // the transfers are complete or ordered on the ctx stream afterwards
+   virtual void group_abort() = 0; // error path: leave no group open
+};
+
+struct RcclTransport : Transport {
+   ldb_ctx* ctx;
+   ncclComm_t comm = nullptr;
+   bool open = false;
+   explicit RcclTransport(ldb_ctx* c) : ctx(c) {}
+   ~RcclTransport() override {
+      if (comm) (void) rccl().CommDestroy(comm);
+   }
+   const char* name() const override { return "rccl"; }
+   int32_t group_start() override {
+      LDB_NCCL(rccl().GroupStart());
+      open = true;
+      return LDB_OK;
+   }
+   int32_t send(const void* p, size_t bytes, int peer) override {
+      LDB_NCCL(rccl().Send(p, bytes, ncclUint8, peer, comm, ctx->stream));
+      return LDB_OK;
+   }
+   int32_t recv(void* p, size_t bytes, int peer) override {
+      LDB_NCCL(rccl().Recv(p, bytes, ncclUint8, peer, comm, ctx->stream));
+      return LDB_OK;
+   }
+   int32_t group_end() override {
+      open = false;
+      LDB_NCCL(rccl().GroupEnd());
+      return LDB_OK;
+   }
+   void group_abort() override {
+      if (open) (void) rccl().GroupEnd();
+      open = false;
+   }
+};
+
+static const char SHM_MAGIC[8] = {'L', 'D', 'B', 'S', 'H', 'M', '0', '1'};
+struct ShmControl { // zero-filled on creation = the valid initial state
+   std::atomic<uint32_t> arrived;
+   std::atomic<uint32_t> generation;
+   std::atomic<uint32_t> failed; // a rank gave up: everybody else stops waiting
+};
+struct ShmTransport : Transport {
+   ldb_ctx* ctx;
+   int rank, world;
+   std::string token; // from the unique id
+   ShmControl* ctl = nullptr;
+   uint64_t seq = 0;
+   struct Op {
+      bool is_send;
+      void* ptr;
+      size_t bytes;
+      int peer;
+   };
+   std::vector<Op> ops;
+   ShmTransport(ldb_ctx* c, int r, int w, std::string t) : ctx(c), rank(r), world(w), token(std::move(t)) {}
+   std::string ctl_name() const { return "/ldbcomm_" + token + "_ctl"; }
+   std::string seg_name(uint64_t s, int from, int to) const { return "/ldbcomm_" + token + "_" + std::to_string(s) + "_" + std::to_string(from) + "_" + std::to_string(to); }
+   int32_t open_control() {
+      const int fd = shm_open(ctl_name().c_str(), O_CREAT | O_RDWR, 0600);
+      if (fd < 0) LDB_FAIL(LDB_ERR_HIP, "shm transport: shm_open(%s) failed: %s", ctl_name().c_str(), strerror(errno));
+      if (ftruncate(fd, sizeof(ShmControl)) != 0) {
+         close(fd);
+         LDB_FAIL(LDB_ERR_HIP, "shm transport: ftruncate failed: %s", strerror(errno));
+      }
+      void* p = mmap(nullptr, sizeof(ShmControl), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      close(fd);
+      if (p == MAP_FAILED) LDB_FAIL(LDB_ERR_HIP, "shm transport: mmap failed: %s", strerror(errno));
+      ctl = (ShmControl*) p;
+      return LDB_OK;
+   }
+   ~ShmTransport() override {
+      if (ctl) {
+         (void) barrier(); // nobody unlinks while a peer may still open
+         munmap(ctl, sizeof(ShmControl));
+         if (rank == 0) shm_unlink(ctl_name().c_str());
+      }
+   }
+   const char* name() const override { return "shm"; }
+   // sense-reversing barrier over the ranks; bounded (a lost rank must not hang the others — or a GPU box)
+   int32_t barrier() {
+      const int64_t limit_ms = ldb_option("comm_timeout_ms", 120000);
+      const uint32_t gen = ctl->generation.load(std::memory_order_acquire);
+      if (ctl->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t) world) {
+         ctl->arrived.store(0, std::memory_order_relaxed);
+         ctl->generation.fetch_add(1, std::memory_order_acq_rel);
+         return LDB_OK;
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      for (uint64_t spin = 0;; spin++) {
+         if (ctl->generation.load(std::memory_order_acquire) != gen) return LDB_OK;
+         if (ctl->failed.load(std::memory_order_acquire)) LDB_FAIL(LDB_ERR_HIP, "shm transport: a peer rank failed");
+         if (spin > 1000) usleep(50);
+         if ((spin & 1023) == 1023 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > (double) limit_ms) {
+            ctl->failed.store(1, std::memory_order_release);
+            LDB_FAIL(LDB_ERR_HIP, "shm transport: barrier timed out after %ld ms (rank %d of %d)", (long) limit_ms, rank, world);
+         }
+      }
+   }
+   int32_t group_start() override {
+      ops.clear();
+      return LDB_OK;
+   }
+   int32_t send(const void* p, size_t bytes, int peer) override {
+      ops.push_back({true, const_cast<void*>(p), bytes, peer});
+      return LDB_OK;
+   }
+   int32_t recv(void* p, size_t bytes, int peer) override {
+      ops.push_back({false, p, bytes, peer});
+      return LDB_OK;
+   }
+   void group_abort() override {
+      ops.clear();
+      if (ctl) ctl->failed.store(1, std::memory_order_release);
+   }
+   struct Mapping { // RAII: one mapped segment
+      void* p = MAP_FAILED;
+      size_t bytes = 0;
+      ~Mapping() {
+         if (p != MAP_FAILED) munmap(p, bytes);
+      }
+   };
+   int32_t map_segment(const std::string& name, size_t bytes, bool create, Mapping* m) {
+      const int fd = shm_open(name.c_str(), create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDONLY, 0600);
+      if (fd < 0) LDB_FAIL(LDB_ERR_HIP, "shm transport: shm_open(%s) failed: %s", name.c_str(), strerror(errno));
+      if (create && ftruncate(fd, (off_t) bytes) != 0) {
+         close(fd);
+         LDB_FAIL(LDB_ERR_HIP, "shm transport: ftruncate(%zu) failed: %s", bytes, strerror(errno));
+      }
+      m->p = mmap(nullptr, bytes, create ? (PROT_READ | PROT_WRITE) : PROT_READ, MAP_SHARED, fd, 0);
+      close(fd);
+      if (m->p == MAP_FAILED) LDB_FAIL(LDB_ERR_HIP, "shm transport: mmap(%s, %zu) failed: %s", name.c_str(), bytes, strerror(errno));
+      m->bytes = bytes;
+      return LDB_OK;
+   }
+   int32_t group_end_inner() {
+      LDB_HIP(hipStreamSynchronize(ctx->stream)); // what is sent was produced on the ctx stream
+      std::vector<size_t> out_bytes((size_t) world, 0), in_bytes((size_t) world, 0);
+      for (auto& o : ops) (o.is_send ? out_bytes : in_bytes)[(size_t) o.peer] += o.bytes;
+      // 1. write: one segment per receiving peer, the sends to it back to back in issue order
+      for (int p = 0; p < world; p++) {
+         if (p == rank || out_bytes[(size_t) p] == 0) continue;
+         Mapping m;
+         LDB_TRY(map_segment(seg_name(seq, rank, p), out_bytes[(size_t) p], true, &m));
+         size_t at = 0;
+         for (auto& o : ops)
+            if (o.is_send && o.peer == p && o.bytes) {
+               LDB_HIP(hipMemcpy((char*) m.p + at, o.ptr, o.bytes, hipMemcpyDeviceToHost));
+               at += o.bytes;
+            }
+      }
+      LDB_TRY(barrier()); // every segment of this round is written
+      // 2. read: transfers of a pair match in order
+      for (int p = 0; p < world; p++) {
+         if (in_bytes[(size_t) p] == 0) continue;
+         if (p == rank) { // to myself: device to device, sends and receives pair up in order
+            size_t si = 0;
+            for (auto& r : ops) {
+               if (r.is_send || r.peer != rank || !r.bytes) continue;
+               while (si < ops.size() && !(ops[si].is_send && ops[si].peer == rank && ops[si].bytes)) si++;
+               if (si == ops.size() || ops[si].bytes != r.bytes) LDB_FAIL(LDB_ERR_INVALID, "shm transport: self transfer sizes do not pair up");
+               LDB_HIP(hipMemcpy(r.ptr, ops[si].ptr, r.bytes, hipMemcpyDeviceToDevice));
+               si++;
+            }
+            continue;
+         }
+         Mapping m;
+         LDB_TRY(map_segment(seg_name(seq, p, rank), in_bytes[(size_t) p], false, &m));
+         size_t at = 0;
+         for (auto& o : ops)
+            if (!o.is_send && o.peer == p && o.bytes) {
+               LDB_HIP(hipMemcpy(o.ptr, (const char*) m.p + at, o.bytes, hipMemcpyHostToDevice));
+               at += o.bytes;
+            }
+      }
+      LDB_TRY(barrier()); // every segment of this round is read: the writers remove theirs
+      return LDB_OK;
+   }
+   int32_t group_end() override {
+      const int32_t st = group_end_inner();
+      for (int p = 0; p < world; p++)
+         if (p != rank) shm_unlink(seg_name(seq, rank, p).c_str()); // (absent when nothing was sent: ignored)
+      seq++;
+      ops.clear();
+      if (st != LDB_OK && ctl) ctl->failed.store(1, std::memory_order_release);
+      return st;
+   }
+};
+} // namespace
+
+struct ldb_comm {
+   std::unique_ptr<Transport> t;
+   int32_t rank = 0, world = 1;
+};
+
 extern "C" int32_t ldb_gpu_comm_unique_id(void* id128) {
    if (!id128) LDB_FAIL(LDB_ERR_INVALID, "comm_unique_id: NULL argument");
-   if (!rccl().ok) LDB_FAIL(LDB_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+   memset(id128, 0, 128);
+   if (ldb_option("comm_transport", 0) == 1) { // host-staged transport: the id names the shared segments
+      memcpy(id128, SHM_MAGIC, 8);
+      unsigned char rnd[12] = {0};
+      if (FILE* f = fopen("/dev/urandom", "rb")) {
+         (void) !fread(rnd, 1, sizeof(rnd), f);
+         fclose(f);
+      }
+      char* tok = (char*) id128 + 8;
+      snprintf(tok, 64, "%08x", (unsigned) getpid());
+      for (int i = 0; i < 12; i++) snprintf(tok + 8 + 2 * i, 3, "%02x", rnd[i]);
+      return LDB_OK;
+   }
+   if (!rccl().ok) LDB_FAIL(LDB_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded: %s", rccl().why.c_str());
    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
    ncclUniqueId id;
-   LDB_NCCL(ncclGetUniqueId(&id));
+   LDB_NCCL(rccl().GetUniqueId(&id));
    memcpy(id128, &id, sizeof(id));
    return LDB_OK;
 }
 extern "C" int32_t ldb_gpu_comm_create(ldb_ctx* ctx, int32_t rank, int32_t world, const void* id128, ldb_comm** out) {
    if (!ctx || !id128 || !out || world < 1 || rank < 0 || rank >= world) LDB_FAIL(LDB_ERR_INVALID, "comm_create: bad argument");
-   if (!rccl().ok) LDB_FAIL(LDB_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded");
    LDB_HIP(hipSetDevice(ctx->device));
    auto c = std::make_unique<ldb_comm>();
    c->rank = rank;
    c->world = world;
-   ncclUniqueId id;
-   memcpy(&id, id128, sizeof(id));
-   LDB_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
+   if (!memcmp(id128, SHM_MAGIC, 8)) {
+      char tok[65] = {0};
+      memcpy(tok, (const char*) id128 + 8, 64);
+      for (char* q = tok; *q; q++)
+         if (!isxdigit((unsigned char) *q)) LDB_FAIL(LDB_ERR_INVALID, "comm_create: malformed shm transport id");
+      auto t = std::make_unique<ShmTransport>(ctx, rank, world, tok);
+      LDB_TRY(t->open_control());
+      c->t = std::move(t);
+   } else {
+      if (!rccl().ok) LDB_FAIL(LDB_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded: %s", rccl().why.c_str());
+      auto t = std::make_unique<RcclTransport>(ctx);
+      ncclUniqueId id;
+      memcpy(&id, id128, sizeof(id));
+      LDB_NCCL(rccl().CommInitRank(&t->comm, world, id, rank));
+      c->t = std::move(t);
+   }
    *out = c.release();
    return LDB_OK;
 }
 extern "C" int32_t ldb_gpu_comm_destroy(ldb_comm* c) {
-   if (!c) return LDB_OK;
-   if (c->comm) (void) ncclCommDestroy(c->comm);
-   delete c;
+   delete c; // the transport's destructor closes the communicator / the shared segments
    return LDB_OK;
 }
 extern "C" int32_t ldb_gpu_comm_rank(const ldb_comm* c) { return c ? c->rank : 0; }
 extern "C" int32_t ldb_gpu_comm_world(const ldb_comm* c) { return c ? c->world : 1; }
+extern "C" const char* ldb_gpu_comm_transport(const ldb_comm* c) { return c && c->t ? c->t->name() : "none"; }
 
 // ---------------------------------------------------------------- small kernels
 __global__ void k_offsets_to_lens(const int64_t* __restrict__ offs, int64_t* __restrict__ lens, uint64_t n) {
@@ -172,171 +406,240 @@ extern "C" int32_t ldb_gpu_table_set_validity_bytes(ldb_ctx* ctx, ldb_table* t, 
 // Every rank sends the rows [send_off[p], send_off[p] + send_cnt[p]) of `t` to peer p and receives
 // recv_cnt[p] rows from it; the result holds the received rows in peer order.  allgather = every peer
 // gets all rows; alltoall = ldb_gpu_partition's layout.
+namespace {
+struct DevBufs { // device temporaries of one exchange: released on every return path
+   ldb_ctx* ctx;
+   std::vector<void*> ptrs;
+   explicit DevBufs(ldb_ctx* c) : ctx(c) {}
+   ~DevBufs() {
+      for (void* p : ptrs) ldb_dev_free(ctx, p);
+   }
+   template <typename T>
+   int32_t alloc(T** out, size_t bytes) {
+      void* p = nullptr;
+      LDB_TRY(ldb_dev_alloc(ctx, &p, bytes ? bytes : 8));
+      ptrs.push_back(p);
+      *out = (T*) p;
+      return LDB_OK;
+   }
+};
+struct TableGuard { // the partially built result table
+   ldb_ctx* ctx;
+   ldb_table* t = nullptr;
+   explicit TableGuard(ldb_ctx* c) : ctx(c) {}
+   ~TableGuard() {
+      if (t) ldb_gpu_table_release(ctx, t);
+   }
+   ldb_table* release() {
+      ldb_table* r = t;
+      t = nullptr;
+      return r;
+   }
+};
+struct GroupGuard { // never leave a transfer group open on an error return
+   Transport* t;
+   bool open = false;
+   explicit GroupGuard(Transport* tr) : t(tr) {}
+   int32_t start() {
+      LDB_TRY(t->group_start());
+      open = true;
+      return LDB_OK;
+   }
+   int32_t end() {
+      open = false;
+      return t->group_end();
+   }
+   ~GroupGuard() {
+      if (open) t->group_abort();
+   }
+};
+} // namespace
+
+// a result column with the SOURCE column's width (a table may mix 8-byte narrowed decimals with the
+// 16-byte decimals group-by and map produce: one `narrow` flag per table cannot describe it)
+static int32_t alloc_like(ldb_ctx* ctx, const ldb_table* t, const char* name, int64_t n_rows, const std::vector<int64_t>& data_bytes, ldb_table** out) {
+   const int nc = (int) t->cols.size();
+   std::vector<ldb_coltype> types((size_t) nc);
+   std::vector<const char*> names((size_t) nc);
+   for (int k = 0; k < nc; k++) {
+      types[(size_t) k] = t->cols[(size_t) k].type;
+      names[(size_t) k] = t->cols[(size_t) k].name.c_str();
+   }
+   ldb_table* res = nullptr;
+   LDB_TRY(ldb_gpu_table_alloc(ctx, name, nc, types.data(), names.data(), n_rows, data_bytes.data(), 0, &res));
+   for (int k = 0; k < nc; k++) {
+      const ldb_column& src = t->cols[(size_t) k];
+      ldb_column& dst = res->cols[(size_t) k];
+      if (src.type.type == LDB_T_UTF8 || dst.width == src.width) continue;
+      ldb_dev_free(ctx, dst.values);
+      dst.values = nullptr;
+      dst.width = src.width;
+      dst.value_bytes = n_rows * (int64_t) src.width;
+      const int32_t st = ldb_dev_alloc(ctx, &dst.values, (size_t) (dst.value_bytes ? dst.value_bytes : 8));
+      if (st != LDB_OK) {
+         ldb_gpu_table_release(ctx, res);
+         return st;
+      }
+   }
+   *out = res;
+   return LDB_OK;
+}
+
 static int32_t exchange(ldb_ctx* ctx, ldb_comm* c, const ldb_table* t, const std::vector<int64_t>& send_off, const std::vector<int64_t>& send_cnt, const char* name,
                         ldb_table** out) {
    const int world = c->world;
    const int nc = (int) t->cols.size();
+   Transport* tr = c->t.get();
+   DevBufs bufs(ctx);
    std::vector<int> ucols; // utf8 columns
    for (int k = 0; k < nc; k++)
       if (t->cols[(size_t) k].type.type == LDB_T_UTF8) ucols.push_back(k);
    const int nu = (int) ucols.size();
-   // ---- metadata: per destination peer [rows, bytes of every utf8 column, validity flag of every column]
-   const int mw = 1 + nu + nc; // words per (sender, receiver) pair
+   // ---- metadata per destination peer: [rows, bytes of every utf8 column, per column: validity flag, width, type]
+   const int mw = 1 + nu + 3 * nc; // words per (sender, receiver) pair
    std::vector<int64_t> meta((size_t) world * mw, 0);
    std::vector<std::vector<int64_t>> h_offs((size_t) nu);
-   for (int u = 0; u < nu; u++) { // byte ranges of the utf8 columns per peer: the offsets at the run boundaries
+   for (int u = 0; u < nu; u++) { // byte ranges of the utf8 columns per peer: the offsets at the run boundaries, ONE read-back per column
       const ldb_column& col = t->cols[(size_t) ucols[(size_t) u]];
-      h_offs[(size_t) u].resize((size_t) world * 2);
+      h_offs[(size_t) u].assign((size_t) world * 2, 0);
       for (int p = 0; p < world; p++) {
-         int64_t b[2] = {0, 0};
-         if (send_cnt[(size_t) p] > 0) {
-            LDB_HIP(hipMemcpyAsync(&b[0], col.offsets + send_off[(size_t) p], 8, hipMemcpyDeviceToHost, ctx->stream));
-            LDB_HIP(hipMemcpyAsync(&b[1], col.offsets + send_off[(size_t) p] + send_cnt[(size_t) p], 8, hipMemcpyDeviceToHost, ctx->stream));
-            LDB_HIP(hipStreamSynchronize(ctx->stream));
-         }
-         h_offs[(size_t) u][(size_t) p * 2] = b[0];
-         h_offs[(size_t) u][(size_t) p * 2 + 1] = b[1];
+         if (send_cnt[(size_t) p] <= 0) continue;
+         LDB_HIP(hipMemcpyAsync(&h_offs[(size_t) u][(size_t) p * 2], col.offsets + send_off[(size_t) p], 8, hipMemcpyDeviceToHost, ctx->stream));
+         LDB_HIP(hipMemcpyAsync(&h_offs[(size_t) u][(size_t) p * 2 + 1], col.offsets + send_off[(size_t) p] + send_cnt[(size_t) p], 8, hipMemcpyDeviceToHost, ctx->stream));
       }
    }
+   if (nu) LDB_HIP(hipStreamSynchronize(ctx->stream));
    for (int p = 0; p < world; p++) {
       int64_t* m = &meta[(size_t) p * mw];
       m[0] = send_cnt[(size_t) p];
       for (int u = 0; u < nu; u++) m[1 + u] = h_offs[(size_t) u][(size_t) p * 2 + 1] - h_offs[(size_t) u][(size_t) p * 2];
-      for (int k = 0; k < nc; k++) m[1 + nu + k] = t->cols[(size_t) k].validity ? 1 : 0;
+      for (int k = 0; k < nc; k++) {
+         m[1 + nu + 3 * k] = t->cols[(size_t) k].validity ? 1 : 0;
+         m[1 + nu + 3 * k + 1] = t->cols[(size_t) k].width;
+         m[1 + nu + 3 * k + 2] = t->cols[(size_t) k].type.type;
+      }
    }
    // all-to-all of the metadata rows: meta[p] goes to peer p
    int64_t *d_send, *d_recv;
-   LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_send, 8 * meta.size()));
-   LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_recv, 8 * meta.size()));
+   LDB_TRY(bufs.alloc(&d_send, 8 * meta.size()));
+   LDB_TRY(bufs.alloc(&d_recv, 8 * meta.size()));
    LDB_HIP(hipMemcpyAsync(d_send, meta.data(), 8 * meta.size(), hipMemcpyHostToDevice, ctx->stream));
    LDB_HIP(hipStreamSynchronize(ctx->stream)); // (meta is a host vector)
-   LDB_NCCL(ncclGroupStart());
+   GroupGuard grp(tr);
+   LDB_TRY(grp.start());
    for (int p = 0; p < world; p++) {
-      LDB_NCCL(ncclSend(d_send + (size_t) p * mw, (size_t) mw, ncclInt64, p, c->comm, ctx->stream));
-      LDB_NCCL(ncclRecv(d_recv + (size_t) p * mw, (size_t) mw, ncclInt64, p, c->comm, ctx->stream));
+      LDB_TRY(tr->send(d_send + (size_t) p * mw, 8 * (size_t) mw, p));
+      LDB_TRY(tr->recv(d_recv + (size_t) p * mw, 8 * (size_t) mw, p));
    }
-   LDB_NCCL(ncclGroupEnd());
+   LDB_TRY(grp.end());
    std::vector<int64_t> rmeta((size_t) world * mw);
    LDB_HIP(hipMemcpyAsync(rmeta.data(), d_recv, 8 * rmeta.size(), hipMemcpyDeviceToHost, ctx->stream));
    LDB_HIP(hipStreamSynchronize(ctx->stream));
-   ldb_dev_free(ctx, d_send);
-   ldb_dev_free(ctx, d_recv);
+   // ---- every rank must have passed the same schema (count is implied by mw: a mismatch garbles the words below)
+   for (int p = 0; p < world; p++)
+      for (int k = 0; k < nc; k++) {
+         const int64_t w = rmeta[(size_t) p * mw + 1 + nu + 3 * k + 1], ty = rmeta[(size_t) p * mw + 1 + nu + 3 * k + 2];
+         if (w != t->cols[(size_t) k].width || ty != t->cols[(size_t) k].type.type)
+            LDB_FAIL(LDB_ERR_INVALID, "exchange: rank %d sends column %d as type %ld / %ld bytes, rank %d has type %d / %d bytes", p, k, (long) ty, (long) w, c->rank,
+                     (int) t->cols[(size_t) k].type.type, t->cols[(size_t) k].width);
+      }
    // ---- result table
    std::vector<int64_t> recv_cnt((size_t) world), recv_off((size_t) world + 1, 0);
    for (int p = 0; p < world; p++) {
       recv_cnt[(size_t) p] = rmeta[(size_t) p * mw];
+      if (recv_cnt[(size_t) p] < 0) LDB_FAIL(LDB_ERR_INVALID, "exchange: negative row count from rank %d", p);
       recv_off[(size_t) p + 1] = recv_off[(size_t) p] + recv_cnt[(size_t) p];
    }
    const int64_t n_all = recv_off[(size_t) world];
    if (n_all >= (int64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "exchange: %ld received rows exceed uint32 row ids", (long) n_all);
-   std::vector<ldb_coltype> types((size_t) nc);
-   std::vector<const char*> names((size_t) nc);
    std::vector<int64_t> data_bytes((size_t) nc, 0);
+   // a column is nullable on arrival when ANY sender has NULLs in it.  Every sender reports its flags to every
+   // peer, so all ranks compute the same OR and take part in the validity transfer of the same columns.
    std::vector<bool> any_valid((size_t) nc, false);
-   bool narrow = false;
-   for (int k = 0; k < nc; k++) {
-      types[(size_t) k] = t->cols[(size_t) k].type;
-      names[(size_t) k] = t->cols[(size_t) k].name.c_str();
-      if (types[(size_t) k].type == LDB_T_DECIMAL128 && t->cols[(size_t) k].width == 8) narrow = true;
-      for (int p = 0; p < world; p++) any_valid[(size_t) k] = any_valid[(size_t) k] || rmeta[(size_t) p * mw + 1 + nu + k] != 0;
-      // a column is nullable on arrival when ANY sender has NULLs in it: every rank must take part in the
-      // validity exchange of such a column, so the senders' flags are agreed on by one more tiny exchange
-   }
+   for (int k = 0; k < nc; k++)
+      for (int p = 0; p < world; p++) any_valid[(size_t) k] = any_valid[(size_t) k] || rmeta[(size_t) p * mw + 1 + nu + 3 * k] != 0;
    for (int u = 0; u < nu; u++)
       for (int p = 0; p < world; p++) data_bytes[(size_t) ucols[(size_t) u]] += rmeta[(size_t) p * mw + 1 + u];
-   {  // agree on the validity flags: OR over all ranks (a sender without NULLs still sends all-ones bytes)
-      std::vector<int64_t> mine((size_t) nc), all((size_t) nc * (size_t) world);
-      for (int k = 0; k < nc; k++) mine[(size_t) k] = t->cols[(size_t) k].validity ? 1 : 0;
-      int64_t *dm, *da;
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &dm, 8 * (size_t) nc));
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &da, 8 * (size_t) nc * (size_t) world));
-      LDB_HIP(hipMemcpyAsync(dm, mine.data(), 8 * (size_t) nc, hipMemcpyHostToDevice, ctx->stream));
-      LDB_HIP(hipStreamSynchronize(ctx->stream));
-      LDB_NCCL(ncclAllGather(dm, da, (size_t) nc, ncclInt64, c->comm, ctx->stream));
-      LDB_HIP(hipMemcpyAsync(all.data(), da, 8 * all.size(), hipMemcpyDeviceToHost, ctx->stream));
-      LDB_HIP(hipStreamSynchronize(ctx->stream));
-      ldb_dev_free(ctx, dm);
-      ldb_dev_free(ctx, da);
-      for (int k = 0; k < nc; k++) {
-         any_valid[(size_t) k] = false;
-         for (int p = 0; p < world; p++) any_valid[(size_t) k] = any_valid[(size_t) k] || all[(size_t) p * nc + k] != 0;
-      }
-   }
-   ldb_table* res;
-   LDB_TRY(ldb_gpu_table_alloc(ctx, name ? name : "exchanged", nc, types.data(), names.data(), n_all, data_bytes.data(), narrow ? 1 : 0, &res));
+   TableGuard res(ctx);
+   LDB_TRY(alloc_like(ctx, t, name ? name : "exchanged", n_all, data_bytes, &res.t));
    const int64_t n_mine = t->n_rows;
    const int grid_in = ldb_grid_for(ctx, n_mine, 256, 8), grid_out = ldb_grid_for(ctx, n_all, 256, 8);
    // ---- staging for strings (lengths) and validity (one byte per row)
    std::vector<int64_t*> lens_in((size_t) nu, nullptr), lens_out((size_t) nu, nullptr);
    std::vector<uint8_t*> vb_in((size_t) nc, nullptr), vb_out((size_t) nc, nullptr);
    for (int u = 0; u < nu; u++) {
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &lens_in[(size_t) u], 8 * (size_t) (n_mine + 1)));
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &lens_out[(size_t) u], 8 * (size_t) (n_all + 1)));
+      LDB_TRY(bufs.alloc(&lens_in[(size_t) u], 8 * (size_t) (n_mine + 1)));
+      LDB_TRY(bufs.alloc(&lens_out[(size_t) u], 8 * (size_t) (n_all + 1)));
       if (n_mine) hipLaunchKernelGGL(k_offsets_to_lens, dim3(grid_in), dim3(256), 0, ctx->stream, (const int64_t*) t->cols[(size_t) ucols[(size_t) u]].offsets, lens_in[(size_t) u], (uint64_t) n_mine);
    }
    for (int k = 0; k < nc; k++) {
       if (!any_valid[(size_t) k]) continue;
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &vb_in[(size_t) k], (size_t) (n_mine + 1)));
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &vb_out[(size_t) k], (size_t) (n_all + 1)));
+      LDB_TRY(bufs.alloc(&vb_in[(size_t) k], (size_t) (n_mine + 1)));
+      LDB_TRY(bufs.alloc(&vb_out[(size_t) k], (size_t) (n_all + 1)));
       if (n_mine) hipLaunchKernelGGL(k_bits_to_bytes, dim3(grid_in), dim3(256), 0, ctx->stream, (const uint8_t*) t->cols[(size_t) k].validity, vb_in[(size_t) k], (uint64_t) n_mine);
    }
    LDB_HIP(hipGetLastError());
    // ---- ONE grouped batch: every column's values (+ string lengths + validity bytes) to / from every peer
    std::vector<int64_t> ubyte_off((size_t) nu, 0); // running byte displacement of the received string data per utf8 column
-   LDB_NCCL(ncclGroupStart());
+   LDB_TRY(grp.start());
    for (int p = 0; p < world; p++) {
       const int64_t so = send_off[(size_t) p], sn = send_cnt[(size_t) p], ro = recv_off[(size_t) p], rn = recv_cnt[(size_t) p];
       int u = 0;
       for (int k = 0; k < nc; k++) {
          const ldb_column& col = t->cols[(size_t) k];
-         ldb_column& dst = res->cols[(size_t) k];
+         ldb_column& dst = res.t->cols[(size_t) k];
          if (col.type.type == LDB_T_UTF8) {
             const int64_t sb0 = h_offs[(size_t) u][(size_t) p * 2], sbytes = h_offs[(size_t) u][(size_t) p * 2 + 1] - sb0, rbytes = rmeta[(size_t) p * mw + 1 + u];
-            if (sn) LDB_NCCL(ncclSend(lens_in[(size_t) u] + so, (size_t) sn, ncclInt64, p, c->comm, ctx->stream));
-            if (rn) LDB_NCCL(ncclRecv(lens_out[(size_t) u] + ro, (size_t) rn, ncclInt64, p, c->comm, ctx->stream));
-            if (sbytes) LDB_NCCL(ncclSend((const uint8_t*) col.values + sb0, (size_t) sbytes, ncclUint8, p, c->comm, ctx->stream));
-            if (rbytes) LDB_NCCL(ncclRecv((uint8_t*) dst.values + ubyte_off[(size_t) u], (size_t) rbytes, ncclUint8, p, c->comm, ctx->stream));
+            if (sn) LDB_TRY(tr->send(lens_in[(size_t) u] + so, 8 * (size_t) sn, p));
+            if (rn) LDB_TRY(tr->recv(lens_out[(size_t) u] + ro, 8 * (size_t) rn, p));
+            if (sbytes) LDB_TRY(tr->send((const uint8_t*) col.values + sb0, (size_t) sbytes, p));
+            if (rbytes) LDB_TRY(tr->recv((uint8_t*) dst.values + ubyte_off[(size_t) u], (size_t) rbytes, p));
             ubyte_off[(size_t) u] += rbytes;
             u++;
          } else {
-            const size_t w = (size_t) col.width;
-            if (sn) LDB_NCCL(ncclSend((const uint8_t*) col.values + (size_t) so * w, (size_t) sn * w, ncclUint8, p, c->comm, ctx->stream));
-            if (rn) LDB_NCCL(ncclRecv((uint8_t*) dst.values + (size_t) ro * w, (size_t) rn * w, ncclUint8, p, c->comm, ctx->stream));
+            const size_t w = (size_t) col.width; // == dst.width (alloc_like) == every sender's width (checked above)
+            if (sn) LDB_TRY(tr->send((const uint8_t*) col.values + (size_t) so * w, (size_t) sn * w, p));
+            if (rn) LDB_TRY(tr->recv((uint8_t*) dst.values + (size_t) ro * w, (size_t) rn * w, p));
          }
          if (any_valid[(size_t) k]) {
-            if (sn) LDB_NCCL(ncclSend(vb_in[(size_t) k] + so, (size_t) sn, ncclUint8, p, c->comm, ctx->stream));
-            if (rn) LDB_NCCL(ncclRecv(vb_out[(size_t) k] + ro, (size_t) rn, ncclUint8, p, c->comm, ctx->stream));
+            if (sn) LDB_TRY(tr->send(vb_in[(size_t) k] + so, (size_t) sn, p));
+            if (rn) LDB_TRY(tr->recv(vb_out[(size_t) k] + ro, (size_t) rn, p));
          }
       }
    }
-   LDB_NCCL(ncclGroupEnd());
+   LDB_TRY(grp.end());
    // ---- rebuild offsets / validity bitmaps on arrival
    for (int u = 0; u < nu; u++) {
-      ldb_column& dst = res->cols[(size_t) ucols[(size_t) u]];
+      ldb_column& dst = res.t->cols[(size_t) ucols[(size_t) u]];
       LDB_TRY(ldb_exclusive_scan_i64(ctx, lens_out[(size_t) u], dst.offsets, n_all, dst.offsets + n_all));
-      ldb_dev_free(ctx, lens_in[(size_t) u]);
-      ldb_dev_free(ctx, lens_out[(size_t) u]);
    }
-   bool counted = false;
-   unsigned long long* d_nulls = (unsigned long long*) (ctx->d_scratch + 48);
-   for (int k = 0; k < nc; k++) {
-      if (!any_valid[(size_t) k]) continue;
-      ldb_column& dst = res->cols[(size_t) k];
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &dst.validity, (size_t) ((n_all + 7) / 8 + 1)));
-      if (n_all) hipLaunchKernelGGL(k_bytes_to_bits, dim3(grid_out), dim3(256), 0, ctx->stream, (const uint8_t*) vb_out[(size_t) k], dst.validity, (uint64_t) n_all);
-      LDB_HIP(hipMemsetAsync(d_nulls, 0, 8, ctx->stream));
-      if (n_all) hipLaunchKernelGGL(k_count_zero_bytes, dim3(grid_out), dim3(256), 0, ctx->stream, (const uint8_t*) vb_out[(size_t) k], (uint64_t) n_all, d_nulls);
-      uint64_t nulls = 0;
-      LDB_TRY(ldb_read_u64(ctx, d_nulls, &nulls));
-      dst.null_count = (int64_t) nulls;
-      dst.type.nullable = 1;
-      counted = true;
-      ldb_dev_free(ctx, vb_in[(size_t) k]);
-      ldb_dev_free(ctx, vb_out[(size_t) k]);
+   // NULL counts of all nullable columns: counted on the device, ONE read-back
+   std::vector<int> vcols;
+   for (int k = 0; k < nc; k++)
+      if (any_valid[(size_t) k]) vcols.push_back(k);
+   if (!vcols.empty()) {
+      unsigned long long* d_nulls;
+      LDB_TRY(bufs.alloc(&d_nulls, 8 * vcols.size()));
+      LDB_HIP(hipMemsetAsync(d_nulls, 0, 8 * vcols.size(), ctx->stream));
+      for (size_t v = 0; v < vcols.size(); v++) {
+         ldb_column& dst = res.t->cols[(size_t) vcols[v]];
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &dst.validity, (size_t) ((n_all + 7) / 8 + 1)));
+         if (n_all) {
+            hipLaunchKernelGGL(k_bytes_to_bits, dim3(grid_out), dim3(256), 0, ctx->stream, (const uint8_t*) vb_out[(size_t) vcols[v]], dst.validity, (uint64_t) n_all);
+            hipLaunchKernelGGL(k_count_zero_bytes, dim3(grid_out), dim3(256), 0, ctx->stream, (const uint8_t*) vb_out[(size_t) vcols[v]], (uint64_t) n_all, d_nulls + v);
+         }
+      }
+      std::vector<unsigned long long> nulls(vcols.size(), 0);
+      LDB_HIP(hipMemcpyAsync(nulls.data(), d_nulls, 8 * vcols.size(), hipMemcpyDeviceToHost, ctx->stream));
+      LDB_HIP(hipStreamSynchronize(ctx->stream));
+      for (size_t v = 0; v < vcols.size(); v++) {
+         ldb_column& dst = res.t->cols[(size_t) vcols[v]];
+         dst.null_count = (int64_t) nulls[v];
+         dst.type.nullable = 1;
+      }
    }
-   (void) counted;
    LDB_HIP(hipGetLastError());
-   *out = res;
+   *out = res.release();
    return LDB_OK;
 }
 
@@ -361,10 +664,8 @@ extern "C" int32_t ldb_gpu_alltoall(ldb_ctx* ctx, ldb_comm* c, const ldb_table* 
 extern "C" int32_t ldb_gpu_shuffle(ldb_ctx* ctx, ldb_comm* c, ldb_rel* in, const ldb_colref* keys, int32_t n_keys, const ldb_colref* cols, int32_t n_cols, const char* name,
                                    ldb_table** out) {
    if (!ctx || !c || !in || !out) LDB_FAIL(LDB_ERR_INVALID, "shuffle: NULL argument");
-   ldb_table* packed = nullptr;
+   TableGuard packed(ctx);
    std::vector<int64_t> counts((size_t) c->world, 0);
-   LDB_TRY(ldb_gpu_partition(ctx, in, keys, n_keys, c->world, cols, n_cols, &packed, counts.data()));
-   const int32_t st = ldb_gpu_alltoall(ctx, c, packed, counts.data(), name, out);
-   ldb_gpu_table_release(ctx, packed);
-   return st;
+   LDB_TRY(ldb_gpu_partition(ctx, in, keys, n_keys, c->world, cols, n_cols, &packed.t, counts.data()));
+   return ldb_gpu_alltoall(ctx, c, packed.t, counts.data(), name, out);
 }

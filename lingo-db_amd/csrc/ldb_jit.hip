@@ -135,7 +135,18 @@ static bool compile(const std::string& src, std::vector<char>* code, std::string
 
 bool ldb_jit_compile_only(const char* header, const char* struct_name, const char* kernels_src, const void* meta, size_t meta_bytes, std::string* log) {
    std::vector<char> code;
-   return compile(build_source(header, struct_name, kernels_src, (const unsigned char*) meta, meta_bytes), &code, log);
+   const bool ok = compile(build_source(header, struct_name, kernels_src, (const unsigned char*) meta, meta_bytes), &code, log);
+   if (ok)
+      if (const char* dir = getenv("LDB_JIT_DUMP_DIR")) { // offline ISA inspection of the check shapes (no GPU needed)
+         static int seq = 0;
+         char path[512];
+         snprintf(path, sizeof(path), "%s/check_%s_%d.co", dir, struct_name, seq++);
+         if (FILE* f = fopen(path, "wb")) {
+            fwrite(code.data(), 1, code.size(), f);
+            fclose(f);
+         }
+      }
+   return ok;
 }
 
 // gcnArchName of a device ("gfx950:sramecc+:xnack-"), cached

@@ -39,6 +39,8 @@ struct ldb_hashtable {
    uint32_t* key_bits = nullptr; // one bit per key value of [kmin, kmax] (DJoin::has_key_bits), or NULL
    int32_t chained = 0; // one slot per distinct key, rows linked through next[] (DJoin::chained)
    uint32_t* next = nullptr;
+   int32_t direct = 0; // slots = uint32_t[kmax - kmin + 1] indexed by key - kmin (DJoin::direct)
+   size_t slot_bytes = 0; // bytes of the slot array (cap x 8, or cap x 4 when direct)
    // the table owns its device buffers: an early error return from the build frees them with the object
    ~ldb_hashtable() {
       if (!ctx) return;
@@ -94,7 +96,17 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
          ldb_jit_strip_col(meta->resid[k].bcol);
       }
       std::string why;
-      spec = ldb_jit_kernel(ctx->device, "ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, spec_name, meta.get(), sizeof(DJoin), &why);
+      // only the wanted kernel's wrapper goes into the translation unit: compiling all seven for every
+      // descriptor made a new probe shape cost 7x its share of hiprtc time
+      std::string one;
+      for (const char* line = JOIN_SPEC_SRC; *line;) {
+         const char* nl = strchr(line, '\n');
+         const size_t len = nl ? (size_t) (nl - line) + 1 : strlen(line);
+         std::string l(line, len);
+         if (l.find(std::string(" ") + spec_name + "(") != std::string::npos) one = l;
+         line += len;
+      }
+      spec = ldb_jit_kernel(ctx->device, "ldb_join_kernel.h", "DJoin", one.empty() ? JOIN_SPEC_SRC : one.c_str(), spec_name, meta.get(), sizeof(DJoin), &why);
    }
    LdbProf prof_(ctx, prof_name);
    if (spec) {
@@ -137,6 +149,13 @@ bool ldb_join_jit_check(std::string* log) {
          m->has_bitmap = 0;
       }
    }
+   if (!ldb_jit_compile_only("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, m.get(), sizeof(DJoin), log)) return false;
+   // second shape: the FK probe into a direct-addressed table (no key bits: the two-deep pipeline of DProbePipe)
+   m->n_ppreds = 0;
+   m->ordered_slots = 0;
+   m->slot32 = 0;
+   m->has_key_bits = 0;
+   m->direct = 1;
    return ldb_jit_compile_only("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, m.get(), sizeof(DJoin), log);
 }
 
@@ -397,11 +416,7 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
    const DCol& k0 = h->bkeys.cols[0];
    ht->key32 = (n_keys == 1 && (k0.type == LDB_T_INT32 || k0.type == LDB_T_DATE32 || k0.type == LDB_T_CHAR4 || k0.type == LDB_T_INT16 || k0.type == LDB_T_INT8)) ? 1 : 0;
    ht->cap = std::max<uint64_t>(64, next_pow2_u64((uint64_t) build->n_rows * 2));
-   LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->slots, 8 * (size_t) ht->cap));
-   LDB_HIP(hipMemsetAsync(ht->slots, 0, 8 * (size_t) ht->cap, ctx->stream));
    h->n_rows = (uint64_t) build->n_rows;
-   h->cap = ht->cap;
-   h->slots = (uint64_t) ht->slots;
    h->key32 = ht->key32;
    uint32_t* dflags = (uint32_t*) (ctx->d_scratch + 24);
    LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
@@ -429,7 +444,22 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
          LDB_HIP(hipStreamSynchronize(ctx->stream));
          ldb_dev_free(ctx, dr);
       }
-      if (got[0] <= got[1]) { // at least one non-NULL key
+      // DIRECT addressing when the key range is at most a few times the build rows (primary keys, and
+      // filtered subsets of one): the table is then no larger than the open-addressing array it replaces
+      // (4 B x range against 8 B x nextPow2(2n) in [16n, 32n) bytes) and a probe is one 4-byte load
+      const unsigned __int128 range0 = got[0] <= got[1] ? (unsigned __int128) ((__int128) got[1] - got[0]) + 1 : 0;
+      if (range0 > 0 && ldb_option("join_direct", 1) != 0 && range0 <= (unsigned __int128) std::max<int64_t>(1024, 8 * build->n_rows) && range0 < ((unsigned __int128) 1 << 31) &&
+          got[0] >= INT32_MIN && got[1] <= INT32_MAX) {
+         ht->direct = 1;
+         ht->kmin = got[0];
+         ht->kmax = got[1];
+         ht->cap = (uint64_t) range0;
+         if (range0 <= ((unsigned __int128) 1 << 27) && range0 >= 4096) { // key bits: 32x smaller than the table, L2-resident for selective builds
+            const size_t words = (size_t) ((range0 + 31) / 32);
+            LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->key_bits, 4 * words));
+            LDB_HIP(hipMemsetAsync(ht->key_bits, 0, 4 * words, ctx->stream));
+         }
+      } else if (got[0] <= got[1]) { // at least one non-NULL key
          ht->ordered_slots = 1;
          ht->kmin = got[0];
          ht->kmax = got[1];
@@ -459,14 +489,22 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
    // up to three passes: ordered slots → hashed slots (skewed key range) → chained (a key repeats so
    // often that one slot per row gives long runs); each pass stops early when it sees such a run
    const bool force_chained = ldb_option("join_chained", 0) == 1; // tests
-   if (force_chained) {
+   if (force_chained && !ht->direct) {
       ht->ordered_slots = 0;
       ldb_dev_free(ctx, ht->key_bits);
       ht->key_bits = nullptr;
+   }
+   if (force_chained || (ht->direct && !build_unique)) { // a direct table without the promise of unique keys chains from the start
       ht->chained = 1;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) (build->n_rows ? build->n_rows : 1)));
    }
+   ht->slot_bytes = (ht->direct ? 4 : 8) * (size_t) ht->cap;
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->slots, ht->slot_bytes));
+   LDB_HIP(hipMemsetAsync(ht->slots, 0, ht->slot_bytes, ctx->stream));
+   h->cap = ht->cap;
+   h->slots = (uint64_t) ht->slots;
    for (int attempt = 0; attempt < 3; attempt++) {
+      h->direct = ht->direct;
       h->ordered_slots = ht->ordered_slots;
       h->kmin = ht->kmin;
       h->kmax = ht->kmax;
@@ -480,11 +518,18 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
       h->next = (uint64_t) ht->next;
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-      if (build->n_rows && h->has_key_bits && h->ordered_slots) hipLaunchKernelGGL(k_join_key_bits, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d);
+      if (build->n_rows && h->has_key_bits && (h->ordered_slots || h->direct)) hipLaunchKernelGGL(k_join_key_bits, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d);
       if (build->n_rows) LDB_TRY(launch_join(ctx, h, d, ldb_grid_for(ctx, build->n_rows, 256, 8), "k_join_build", "k_join_build_spec", k_join_build));
       ldb_dev_free(ctx, d);
       uint64_t f = 0;
       LDB_TRY(ldb_read_u64(ctx, dflags, &f));
+      if (ht->direct && (f & 1) && !ht->chained) { // duplicate keys in a direct table: chain them
+         ht->chained = 1;
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) build->n_rows));
+         LDB_HIP(hipMemsetAsync(ht->slots, 0, ht->slot_bytes, ctx->stream));
+         LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
+         continue;
+      }
       if ((f & 2) && !ht->chained) {
          if (ht->ordered_slots) { // this key distribution needs hashed slots
             ht->ordered_slots = 0;
@@ -494,7 +539,7 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
             ht->chained = 1;
             LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) build->n_rows));
          }
-         LDB_HIP(hipMemsetAsync(ht->slots, 0, 8 * (size_t) ht->cap, ctx->stream));
+         LDB_HIP(hipMemsetAsync(ht->slots, 0, ht->slot_bytes, ctx->stream));
          LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
          continue;
       }
@@ -511,6 +556,7 @@ extern "C" int32_t ldb_gpu_hashtable_release(ldb_ctx* ctx, ldb_hashtable* ht) {
    return LDB_OK;
 }
 extern "C" int64_t ldb_gpu_hashtable_slots(const ldb_hashtable* ht) { return ht ? (int64_t) ht->cap : -1; }
+extern "C" int64_t ldb_gpu_hashtable_bytes(const ldb_hashtable* ht) { return ht ? (int64_t) ht->slot_bytes : -1; }
 
 static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, DJoin* h, const ldb_join_residual* resid = nullptr,
                                int32_t n_resid = 0) {
@@ -534,6 +580,7 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    h->slots = (uint64_t) ht->slots;
    h->key32 = ht->key32;
    h->ordered_slots = ht->ordered_slots;
+   h->direct = ht->direct;
    h->kmin = ht->kmin;
    h->kmax = ht->kmax;
    h->kmult = ht->kmult;

@@ -67,6 +67,13 @@ struct DJoin {
    // ordered slots computed in 32-bit arithmetic (capacity <= 2^31 and a key range below 2^32: every table
    // of 32-bit keys up to a billion rows); 64-bit integer multiplies are four quarter-rate instructions
    int32_t slot32;
+   // DIRECT addressing (KEY32, key range at most a few times the build rows — every primary key of TPC-H):
+   // `slots` is a uint32_t array indexed by (key - kmin) holding build row + 1 (0 = no such key).  No
+   // hash, no tag, no collision walk, 4 bytes per key VALUE instead of 8 bytes per slot of a half-empty
+   // table; clustered probes (lineitem → orders) sweep it sequentially.  Duplicate keys chain through
+   // next[] (`chained`: push-front with one atomic exchange per build row).
+   int32_t direct;
+   int32_t pad_;
    DJoinResid resid[LDB_MAX_RESID];
    DPred ppreds[LDB_MAX_PREDS];
 };
@@ -103,6 +110,26 @@ __device__ __forceinline__ void join_build_body(const DJoin& m, const DJoin* __r
    const uint64_t n = d->n_rows, mask = d->cap - 1;
    unsigned long long* slots = gptr_mut<unsigned long long>(d->slots);
    const KV bkeys(m.bkeys, d->bkeys);
+   if (m.direct) {
+      uint32_t* tab = gptr_mut<uint32_t>(d->slots);
+      uint32_t* next = gptr_mut<uint32_t>(d->next);
+      const CV c = bkeys.col(0);
+      for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+         const uint32_t row = d_phys_row(c, i);
+         if (!d_valid(c, row)) continue; // a NULL key can never be matched
+         const uint64_t r = (uint64_t) (d_load_i64(c, row) - d->kmin);
+         if (m.chained) {
+            next[i] = atomicExch(&tab[r], (uint32_t) i + 1u); // push-front: the previous head (or 0) follows this row
+         } else {
+            const uint32_t old = atomicCAS(&tab[r], 0u, (uint32_t) i + 1u);
+            if (old != 0 && m.has_flags) { // a second row with this key: the host rebuilds chained
+               uint32_t* f = gptr_mut<uint32_t>(d->flags);
+               if ((__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) == 0) atomicOr(f, 1u);
+            }
+         }
+      }
+      return;
+   }
    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
       bool nul;
       uint64_t h = d_hash_keys(bkeys, i, &nul);
@@ -245,6 +272,31 @@ __device__ __forceinline__ bool d_resid_ok(const DJoin& m, const DJoin* __restri
    return ok;
 }
 
+// direct-addressed table: resolve the batch from its table words (0 = no such key)
+template <int U, typename EMIT>
+__device__ __forceinline__ void d_direct_resolve(const DJoin& m, const DJoin* __restrict__ d, const uint64_t (&rows)[U], const bool (&live)[U], const uint32_t (&hw)[U], bool bits_only,
+                                                 uint32_t (&matches)[U], EMIT emit) {
+#pragma unroll
+   for (int u = 0; u < U; u++) {
+      if (!live[u] || hw[u] == 0) continue;
+      if (bits_only) {
+         matches[u]++;
+         (void) emit(u, 0u);
+      } else if (m.chained) {
+         const uint32_t* next = gptr<uint32_t>(d->next);
+         for (uint32_t r = hw[u]; r != 0; r = next[r - 1u]) {
+            if (m.n_resid == 0 || d_resid_ok(m, d, rows[u], r - 1u)) {
+               matches[u]++;
+               if (!emit(u, r - 1u)) break;
+            }
+         }
+      } else if (m.n_resid == 0 || d_resid_ok(m, d, rows[u], hw[u] - 1u)) {
+         matches[u]++;
+         (void) emit(u, hw[u] - 1u);
+      }
+   }
+}
+
 // U probe rows of one lane, phase-separated for memory-level parallelism.  A probe is a chain of
 // dependent loads (key → [key bit] → slot → next slot …): one row at a time a wave has ONE such
 // chain in flight per lane and the kernel runs at memory LATENCY (600 M FK probes: 112 Grows/s,
@@ -259,7 +311,7 @@ __device__ __forceinline__ bool d_resid_ok(const DJoin& m, const DJoin* __restri
 // `pre` (optional): the batch's keys, already loaded by the caller one iteration ahead (d_prefetch_keys32).
 template <int U, typename EMIT>
 __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __restrict__ d, const uint64_t (&rows)[U], const bool (&act)[U], uint32_t (&matches)[U],
-                                              EMIT emit, const uint32_t* pre = nullptr) {
+                                              EMIT emit, const uint32_t* pre = nullptr, const uint32_t* prew = nullptr) {
    const KV pkeys(m.pkeys, d->pkeys);
    const uint64_t mask = d->cap - 1;
    const uint64_t* slots = gptr<uint64_t>(d->slots);
@@ -271,6 +323,13 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
       live[u] = act[u];
       pos[u] = 0;
       tag[u] = 0;
+   }
+   if (m.direct && prew) { // the batch's table words came through the pipeline (already 0 for keys outside the table's range)
+      uint32_t hw[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) hw[u] = prew[u];
+      d_direct_resolve<U>(m, d, rows, live, hw, false, matches, emit);
+      return;
    }
    if (m.key32) {
       const CV c = pkeys.col(0);
@@ -313,7 +372,7 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
       }
 #pragma unroll
       for (int u = 0; u < U; u++) tag[u] = (uint64_t) k32[u];
-      if (m.ordered_slots) {
+      if (m.ordered_slots || m.direct) {
          // (key - kmin) as an unsigned 32-bit offset: keys below kmin wrap to values above the span
          const uint32_t kmin32 = (uint32_t) d->kmin, span = (uint32_t) (d->kmax - d->kmin);
          uint32_t r[U];
@@ -330,7 +389,10 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
 #pragma unroll
             for (int u = 0; u < U; u++) live[u] = live[u] && ((bw[u] >> (r[u] & 31u)) & 1u); // not a build key
          }
-         if (m.slot32) {
+         if (m.direct) {
+#pragma unroll
+            for (int u = 0; u < U; u++) pos[u] = live[u] ? (uint64_t) r[u] : 0;
+         } else if (m.slot32) {
             const uint32_t kmult32 = d->kmult32, ksh = d->ksh;
 #pragma unroll
             for (int u = 0; u < U; u++) pos[u] = live[u] ? (uint64_t) __umulhi(r[u] << ksh, kmult32) : 0;
@@ -355,6 +417,21 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
             pos[u] = nul ? 0 : d_join_slot(m, d, h, 0, mask);
          }
       }
+   }
+   if (m.direct) {
+      // one 4-byte word per key value: build row + 1 (the head of the key's chain when `chained`)
+      const uint32_t* tab = gptr<uint32_t>(d->slots);
+      uint32_t hw[U];
+      // existence kinds over a table with key bits: the bit already answered, the build row is never used
+      const bool bits_only = m.has_key_bits && m.n_resid == 0 && (m.kind == LDB_JOIN_SEMI || m.kind == LDB_JOIN_ANTI || m.kind == LDB_JOIN_MARK);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         hw[u] = 0;
+         if (!live[u]) continue;
+         hw[u] = bits_only ? 1u : tab[pos[u]];
+      }
+      d_direct_resolve<U>(m, d, rows, live, hw, bits_only, matches, emit);
+      return;
    }
    // the first two slots of every live row
    uint64_t w0[U], w1[U];
@@ -427,7 +504,7 @@ __device__ __forceinline__ uint32_t d_probe_row(const DJoin& m, const DJoin* __r
 // ANTI / MARK kinds need — no side effects inside the walk, the callers store afterwards
 template <int U>
 __device__ __forceinline__ void d_probe_first(const DJoin& m, const DJoin* __restrict__ d, const uint64_t (&rows)[U], const bool (&act)[U], uint32_t (&brow)[U],
-                                              const uint32_t* pre = nullptr) {
+                                              const uint32_t* pre = nullptr, const uint32_t* prew = nullptr) {
    uint32_t mt[U];
 #pragma unroll
    for (int u = 0; u < U; u++) brow[u] = LDB_NULL_ROW;
@@ -437,7 +514,7 @@ __device__ __forceinline__ void d_probe_first(const DJoin& m, const DJoin* __res
          brow[u] = b;
          return false;
       },
-      pre);
+      pre, prew);
 }
 
 // Software pipelining of the probe's first dependent load.  A wave's iterations are serial chains
@@ -451,15 +528,107 @@ __device__ __forceinline__ bool d_keys_prefetchable(const DJoin& m) {
 }
 template <int U>
 __device__ __forceinline__ void d_prefetch_keys32(const DJoin* __restrict__ d, uint64_t row0, uint64_t n, uint32_t (&k)[U]) {
-   const int32_t* keys = gptr<int32_t>(d->pkeys.cols[0].values);
+   // row0 is wave-uniform: the tile's base and the rows left from there are scalar, a lane only compares its
+   // 32-bit offset (rows past the end read the tile's first row — or row 0 when the whole tile lies past the end)
+   const uint64_t base = row0 < n ? row0 : 0;
+   const uint64_t left = n - base;
+   const uint32_t left32 = left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) left;
+   const int32_t* kt = gptr<int32_t>(d->pkeys.cols[0].values) + base;
    const uint32_t lane = threadIdx.x & 63;
 #pragma unroll
    for (int u = 0; u < U; u++) {
-      const uint64_t r = row0 + (uint64_t) u * 64 + lane;
-      k[u] = (uint32_t) keys[r < n ? r : 0];
+      const uint32_t o = (uint32_t) u * 64u + lane;
+      k[u] = (uint32_t) kt[o < left32 ? o : 0u];
    }
 }
+// The per-wave software pipeline of the probe loops.  A probe is the dependent chain key → table word →
+// resolve; a wave that walks it tile by tile spends one memory round trip per link.  With a dense 4-byte key
+// column the keys of the NEXT tile are loaded while the current one is probed (`pf`), and for a direct
+// table without key bits the chain is pipelined two deep (`pw`): in the step of tile s the table words of
+// tile s+1 and the keys of tile s+2 are issued BEFORE tile s is resolved, so every load has a whole
+// iteration to arrive and no wait drains the queue (vmcnt counts in order; what a step waits for is older
+// than the 2U loads it just issued).  Issue order over the steps: … keys(s+1), words(s) | keys(s+2), words(s+1) | …
+//   LDB_PIN(x): x must be in its register HERE — the compiler puts the s_waitcnt of the producing load at
+//   this point, not earlier, and moves no memory access across.  Without the pins the scheduler rotates the
+//   loop back into issue-then-consume.
+//   Two sets of word registers alternate (template parameter P of step): copying a register whose load is
+//   still in flight would wait for it, so the loops are unrolled by two instead of rotating registers.
+#define LDB_PIN(x) asm volatile("" : "+v"(x))
+template <int P>
+struct DPar {
+   static constexpr int v = P;
+};
+template <int U>
+struct DProbePipe {
+   // (pf / pw are recomputed from the — compile-time — metadata at every use: as members they would keep the
+   // struct in memory and the specialised kernel could not fold them)
+   static __device__ __forceinline__ bool pf(const DJoin& m) { return d_keys_prefetchable(m); }
+   static __device__ __forceinline__ bool pw(const DJoin& m) { return d_keys_prefetchable(m) && m.direct && !m.has_key_bits; }
+   uint64_t stride; // rows between a wave's consecutive tiles
+   uint32_t ck[U], cw[U]; // pf: keys of the tile being resolved;  pw: its table words
+   uint32_t k[U]; // keys in flight (pf: of the coming tile; pw: of the tile after the coming one once its step ran)
+   uint32_t w[2][U]; // pw: table words in flight, alternating sets
+   bool inr[2][U]; // pw: key inside the table's range
+   // the table offsets of the keys in k[] (→ inr[set]); the words are loaded by words_at
+   __device__ __forceinline__ void offsets_of(const DJoin* __restrict__ d, int set, uint32_t (&r)[U]) {
+      const uint32_t kmin32 = (uint32_t) d->kmin, span = (uint32_t) (d->kmax - d->kmin);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         r[u] = k[u] - kmin32;
+         inr[set][u] = r[u] <= span;
+         r[u] = inr[set][u] ? r[u] : 0u;
+      }
+   }
+   __device__ __forceinline__ void words_at(const DJoin* __restrict__ d, int set, const uint32_t (&r)[U]) {
+      const uint32_t* tab = gptr<uint32_t>(d->slots);
+#pragma unroll
+      for (int u = 0; u < U; u++) w[set][u] = tab[r[u]];
+   }
+   __device__ __forceinline__ void start(const DJoin& m, const DJoin* __restrict__ d, uint64_t row0, uint64_t stride_rows, uint64_t n) {
+      stride = stride_rows;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         ck[u] = cw[u] = k[u] = w[0][u] = w[1][u] = 0;
+         inr[0][u] = inr[1][u] = false;
+      }
+      if (pf(m)) d_prefetch_keys32<U>(d, row0, n, k);
+      if (pw(m)) {
+         uint32_t r[U];
+         offsets_of(d, 0, r);
+         d_prefetch_keys32<U>(d, row0 + stride, n, k);
+         words_at(d, 0, r);
+      }
+   }
+   // at the top of the iteration over the tile starting at row0: afterwards ck / cw belong to that tile.
+   // Steps alternate P = 0, 1, 0, … starting with 0.
+   template <int P>
+   __device__ __forceinline__ void step(const DJoin& m, const DJoin* __restrict__ d, uint64_t row0, uint64_t n, DPar<P>) {
+      if (pw(m)) {
+#pragma unroll
+         for (int u = 0; u < U; u++) LDB_PIN(k[u]); // keys(s+1) are here (words(s) may still be in flight)
+         uint32_t r[U];
+         offsets_of(d, 1 - P, r);
+         d_prefetch_keys32<U>(d, row0 + 2 * stride, n, k); // keys(s+2), into the registers just consumed
+         asm volatile("" : : : "memory"); // (keeps the key loads ahead of the word loads in issue order; no wait)
+         words_at(d, 1 - P, r); // words(s+1)
+#pragma unroll
+         for (int u = 0; u < U; u++) LDB_PIN(w[P][u]); // words(s) are here
+#pragma unroll
+         for (int u = 0; u < U; u++) cw[u] = inr[P][u] ? w[P][u] : 0u;
+      } else if (pf(m)) {
+#pragma unroll
+         for (int u = 0; u < U; u++) ck[u] = k[u];
+         d_prefetch_keys32<U>(d, row0 + stride, n, k);
+      }
+   }
+   __device__ __forceinline__ const uint32_t* keys(const DJoin& m) const { return pf(m) && !pw(m) ? ck : nullptr; }
+   __device__ __forceinline__ const uint32_t* words(const DJoin& m) const { return pw(m) ? cw : nullptr; }
+};
 
+// global wave number as a wave-uniform (scalar) value: the tile loops then run on scalar control flow
+__device__ __forceinline__ uint64_t d_wave_id() {
+   return (uint64_t) blockIdx.x * (blockDim.x >> 6) + (uint64_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+}
 #ifndef JOIN_BATCH
 #define JOIN_BATCH 4 // probe rows in flight per lane (8 costs more in occupancy than it gains: 3.2 vs 4.0 ms on 600 M FK probes)
 #endif
@@ -474,9 +643,9 @@ __device__ __forceinline__ void d_prefetch_keys32(const DJoin* __restrict__ d, u
 // rows each probe row of the batch contributes: its matches, or one NULL-padded row when an outer join finds none
 template <int U>
 __device__ __forceinline__ void d_pairs_of_rows(const DJoin& m, const DJoin* __restrict__ d, const uint64_t (&rows)[U], bool (&act)[U], uint32_t (&cnt)[U],
-                                                const uint32_t* pre = nullptr) {
+                                                const uint32_t* pre = nullptr, const uint32_t* prew = nullptr) {
    d_eval_conj_batch<U>(m.ppreds, d->ppreds, m.n_ppreds, rows, act); // (the host only fuses filters for INNER here)
-   d_probe_batch<U>(m, d, rows, act, cnt, [&](int, uint32_t) { return m.kind != LDB_JOIN_SINGLE; }, pre);
+   d_probe_batch<U>(m, d, rows, act, cnt, [&](int, uint32_t) { return m.kind != LDB_JOIN_SINGLE; }, pre, prew);
 #pragma unroll
    for (int u = 0; u < U; u++)
       if (act[u] && m.kind != LDB_JOIN_INNER && cnt[u] == 0) cnt[u] = 1u;
@@ -485,14 +654,13 @@ __device__ __forceinline__ void join_probe_pairs_count_body(const DJoin& m, cons
    const uint64_t n = d->n_rows;
    const uint64_t n_chunks = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;
-   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t wave = d_wave_id();
    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
    uint32_t* chunk_cnt = gptr_mut<uint32_t>(d->match);
    unsigned long long total = 0; // exact 64-bit row count (the 32-bit offsets cannot detect > 4 G rows)
-   const bool pf = d_keys_prefetchable(m);
-   uint32_t nk[JP_U] = {0}, ck[JP_U];
-   if (pf) d_prefetch_keys32<JP_U>(d, wave * JP_U * 64, n, nk);
-   for (uint64_t w0 = wave * JP_U; w0 < n_chunks; w0 += n_waves * JP_U) {
+   DProbePipe<JP_U> pipe;
+   pipe.start(m, d, wave * JP_U * 64, n_waves * JP_U * 64, n);
+   auto tile = [&](uint64_t w0, auto par) __attribute__((always_inline)) {
       uint64_t rows[JP_U];
       bool act[JP_U];
       uint32_t c[JP_U];
@@ -500,10 +668,9 @@ __device__ __forceinline__ void join_probe_pairs_count_body(const DJoin& m, cons
       for (int u = 0; u < JP_U; u++) {
          rows[u] = (w0 + u) * 64 + lane;
          act[u] = rows[u] < n;
-         ck[u] = nk[u];
       }
-      if (pf) d_prefetch_keys32<JP_U>(d, (w0 + n_waves * JP_U) * 64, n, nk);
-      d_pairs_of_rows<JP_U>(m, d, rows, act, c, pf ? ck : nullptr);
+      pipe.step(m, d, w0 * 64, n, par);
+      d_pairs_of_rows<JP_U>(m, d, rows, act, c, pipe.keys(m), pipe.words(m));
 #pragma unroll
       for (int u = 0; u < JP_U; u++) {
          uint32_t s = c[u];
@@ -511,14 +678,20 @@ __device__ __forceinline__ void join_probe_pairs_count_body(const DJoin& m, cons
          if (lane == 0 && w0 + u < n_chunks) chunk_cnt[w0 + u] = s;
          total += s;
       }
+   };
+   uint64_t w00 = wave * JP_U;
+   for (; w00 + (n_waves * JP_U) < n_chunks; w00 += 2 * (n_waves * JP_U)) { // two tiles per trip: the pipeline's word registers alternate
+      tile(w00, DPar<0>{});
+      tile(w00 + (n_waves * JP_U), DPar<1>{});
    }
+   if (w00 < n_chunks) tile(w00, DPar<0>{});
    if (lane == 0 && total) atomicAdd(gptr_mut<unsigned long long>(d->counter), total);
 }
 __device__ __forceinline__ void join_probe_pairs_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows;
    const uint64_t n_chunks = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;
-   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t wave = d_wave_id();
    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
    const uint32_t* chunk_off = gptr<uint32_t>(d->match);
    uint32_t* out_probe = gptr_mut<uint32_t>(d->out_probe);
@@ -568,13 +741,12 @@ __device__ __forceinline__ void join_probe_count_body(const DJoin& m, const DJoi
    const uint64_t n = d->n_rows;
    unsigned long long local = 0;
    const uint32_t lane = threadIdx.x & 63;
-   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t wave = d_wave_id();
    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
    const uint64_t n_tiles = (n + 64 * JOIN_BATCH - 1) / (64 * JOIN_BATCH);
-   const bool pf = d_keys_prefetchable(m);
-   uint32_t nk[JOIN_BATCH] = {0}, ck[JOIN_BATCH];
-   if (pf) d_prefetch_keys32<JOIN_BATCH>(d, wave * JOIN_BATCH * 64, n, nk);
-   for (uint64_t t = wave; t < n_tiles; t += n_waves) {
+   DProbePipe<JOIN_BATCH> pipe;
+   pipe.start(m, d, wave * JOIN_BATCH * 64, n_waves * JOIN_BATCH * 64, n);
+   auto tile = [&](uint64_t t, auto par) __attribute__((always_inline)) {
       uint64_t rows[JOIN_BATCH];
       bool act[JOIN_BATCH];
       uint32_t mt[JOIN_BATCH];
@@ -582,14 +754,19 @@ __device__ __forceinline__ void join_probe_count_body(const DJoin& m, const DJoi
       for (int u = 0; u < JOIN_BATCH; u++) {
          rows[u] = (t * JOIN_BATCH + u) * 64 + lane;
          act[u] = rows[u] < n;
-         ck[u] = nk[u];
       }
-      if (pf) d_prefetch_keys32<JOIN_BATCH>(d, (t + n_waves) * JOIN_BATCH * 64, n, nk);
+      pipe.step(m, d, t * JOIN_BATCH * 64, n, par);
       d_eval_conj_batch<JOIN_BATCH>(m.ppreds, d->ppreds, m.n_ppreds, rows, act);
-      d_probe_batch<JOIN_BATCH>(m, d, rows, act, mt, [](int, uint32_t) { return true; }, pf ? ck : nullptr);
+      d_probe_batch<JOIN_BATCH>(m, d, rows, act, mt, [](int, uint32_t) { return true; }, pipe.keys(m), pipe.words(m));
 #pragma unroll
       for (int u = 0; u < JOIN_BATCH; u++) local += mt[u];
+   };
+   uint64_t t0 = wave;
+   for (; t0 + (n_waves) < n_tiles; t0 += 2 * (n_waves)) { // two tiles per trip: the pipeline's word registers alternate
+      tile(t0, DPar<0>{});
+      tile(t0 + (n_waves), DPar<1>{});
    }
+   if (t0 < n_tiles) tile(t0, DPar<0>{});
    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
    if (lane == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter) + 1, local);
 }
@@ -767,15 +944,14 @@ __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJo
    }
    const uint64_t n_words = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;
-   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t wave = d_wave_id();
    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
    uint64_t* bitmap = gptr_mut<uint64_t>(d->bitmap);
    uint8_t* mark = gptr_mut<uint8_t>(d->mark);
    unsigned long long local = 0;
-   const bool pf = d_keys_prefetchable(m);
-   uint32_t nk[JE_U] = {0}, ck[JE_U];
-   if (pf) d_prefetch_keys32<JE_U>(d, wave * JE_U * 64, n, nk);
-   for (uint64_t w0 = wave * JE_U; w0 < n_words; w0 += n_waves * JE_U) {
+   DProbePipe<JE_U> pipe;
+   pipe.start(m, d, wave * JE_U * 64, n_waves * JE_U * 64, n);
+   auto tile = [&](uint64_t w0, auto par) __attribute__((always_inline)) {
       uint64_t rows[JE_U];
       bool act[JE_U];
       uint32_t first[JE_U];
@@ -783,10 +959,9 @@ __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJo
       for (int u = 0; u < JE_U; u++) {
          rows[u] = (w0 + u) * 64 + lane;
          act[u] = rows[u] < n;
-         ck[u] = nk[u];
       }
-      if (pf) d_prefetch_keys32<JE_U>(d, (w0 + n_waves * JE_U) * 64, n, nk);
-      d_probe_first<JE_U>(m, d, rows, act, first, pf ? ck : nullptr);
+      pipe.step(m, d, w0 * 64, n, par);
+      d_probe_first<JE_U>(m, d, rows, act, first, pipe.keys(m), pipe.words(m));
 #pragma unroll
       for (int u = 0; u < JE_U; u++) {
          const bool hit = first[u] != LDB_NULL_ROW;
@@ -798,7 +973,13 @@ __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJo
             local += (unsigned long long) __popcll(mm);
          }
       }
+   };
+   uint64_t w00 = wave * JE_U;
+   for (; w00 + (n_waves * JE_U) < n_words; w00 += 2 * (n_waves * JE_U)) { // two tiles per trip: the pipeline's word registers alternate
+      tile(w00, DPar<0>{});
+      tile(w00 + (n_waves * JE_U), DPar<1>{});
    }
+   if (w00 < n_words) tile(w00, DPar<0>{});
    if (lane == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter), local);
 }
 
@@ -827,13 +1008,12 @@ __device__ __forceinline__ void join_probe_markbuild_body(const DJoin& m, const 
       return;
    }
    const uint32_t lane = threadIdx.x & 63;
-   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t wave = d_wave_id();
    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
    const uint64_t n_tiles = (n + 64 * JE_U - 1) / (64 * JE_U);
-   const bool pf = d_keys_prefetchable(m);
-   uint32_t nk[JE_U] = {0}, ck[JE_U];
-   if (pf) d_prefetch_keys32<JE_U>(d, wave * JE_U * 64, n, nk);
-   for (uint64_t t = wave; t < n_tiles; t += n_waves) {
+   DProbePipe<JE_U> pipe;
+   pipe.start(m, d, wave * JE_U * 64, n_waves * JE_U * 64, n);
+   auto tile = [&](uint64_t t, auto par) __attribute__((always_inline)) {
       uint64_t rows[JE_U];
       bool act[JE_U];
       uint32_t mt[JE_U];
@@ -841,24 +1021,29 @@ __device__ __forceinline__ void join_probe_markbuild_body(const DJoin& m, const 
       for (int u = 0; u < JE_U; u++) {
          rows[u] = (t * JE_U + u) * 64 + lane;
          act[u] = rows[u] < n;
-         ck[u] = nk[u];
       }
-      if (pf) d_prefetch_keys32<JE_U>(d, (t + n_waves) * JE_U * 64, n, nk);
+      pipe.step(m, d, t * JE_U * 64, n, par);
       d_probe_batch<JE_U>(
          m, d, rows, act, mt,
          [&](int, uint32_t b) {
             flags[b] = 1;
             return true;
          },
-         pf ? ck : nullptr);
+         pipe.keys(m), pipe.words(m));
+   };
+   uint64_t t0 = wave;
+   for (; t0 + (n_waves) < n_tiles; t0 += 2 * (n_waves)) { // two tiles per trip: the pipeline's word registers alternate
+      tile(t0, DPar<0>{});
+      tile(t0 + (n_waves), DPar<1>{});
    }
+   if (t0 < n_tiles) tile(t0, DPar<0>{});
 }
 // flags (one byte per build row) → ballot bitmap of the rows to keep (+ their count)
 __device__ __forceinline__ void join_flags_bitmap_body(const uint8_t* __restrict__ flags, uint64_t n, int anti, uint64_t* __restrict__ bitmap,
                                                        unsigned long long* __restrict__ counter) {
    const uint64_t n_words = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;
-   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t wave = d_wave_id();
    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
    unsigned long long local = 0;
    for (uint64_t w = wave; w < n_words; w += n_waves) {
@@ -885,15 +1070,14 @@ __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJo
    const uint64_t n = d->n_rows;
    const uint64_t n_words = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;
-   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+   const uint64_t wave = d_wave_id();
    const uint64_t n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
    uint64_t* bitmap = gptr_mut<uint64_t>(d->bitmap);
    uint32_t* match = gptr_mut<uint32_t>(d->match);
    unsigned long long local = 0;
-   const bool pf = d_keys_prefetchable(m);
-   uint32_t nk[JE_U] = {0}, ck[JE_U];
-   if (pf) d_prefetch_keys32<JE_U>(d, wave * JE_U * 64, n, nk);
-   for (uint64_t w0 = wave * JE_U; w0 < n_words; w0 += n_waves * JE_U) {
+   DProbePipe<JE_U> pipe;
+   pipe.start(m, d, wave * JE_U * 64, n_waves * JE_U * 64, n);
+   auto tile = [&](uint64_t w0, auto par) __attribute__((always_inline)) {
       uint32_t brow[JE_U];
       uint64_t rows[JE_U];
       bool act[JE_U], pass[JE_U];
@@ -901,11 +1085,10 @@ __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJo
       for (int u = 0; u < JE_U; u++) {
          rows[u] = (w0 + u) * 64 + lane;
          act[u] = pass[u] = rows[u] < n;
-         ck[u] = nk[u];
       }
-      if (pf) d_prefetch_keys32<JE_U>(d, (w0 + n_waves * JE_U) * 64, n, nk);
+      pipe.step(m, d, w0 * 64, n, par);
       d_eval_conj_batch<JE_U>(m.ppreds, d->ppreds, m.n_ppreds, rows, pass); // fused filter of a lazy probe side
-      d_probe_first<JE_U>(m, d, rows, pass, brow, pf ? ck : nullptr);
+      d_probe_first<JE_U>(m, d, rows, pass, brow, pipe.keys(m), pipe.words(m));
 #pragma unroll
       for (int u = 0; u < JE_U; u++) {
          // INNER reads match[] only at the bitmap's set bits: unmatched rows are not written (a
@@ -917,6 +1100,12 @@ __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJo
             local += (unsigned long long) __popcll(mm);
          }
       }
+   };
+   uint64_t w00 = wave * JE_U;
+   for (; w00 + (n_waves * JE_U) < n_words; w00 += 2 * (n_waves * JE_U)) { // two tiles per trip: the pipeline's word registers alternate
+      tile(w00, DPar<0>{});
+      tile(w00 + (n_waves * JE_U), DPar<1>{});
    }
+   if (w00 < n_words) tile(w00, DPar<0>{});
    if (lane == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter), local);
 }

@@ -394,6 +394,10 @@ class HashTable:
     def slots(self):
         return self.ctx.lib.ldb_gpu_hashtable_slots(self.h)
 
+    @property
+    def table_bytes(self):
+        return self.ctx.lib.ldb_gpu_hashtable_bytes(self.h)
+
     def probe(self, probe_rel, keys, kind=capi.JOIN_INNER, residual=()):
         """residual: [(probe_col, op, build_col)] — extra `probe_col OP build_col` conjuncts of the join predicate"""
         arr, n = _refs(keys)

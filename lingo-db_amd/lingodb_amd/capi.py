@@ -199,6 +199,7 @@ GPU_API = {
     "ldb_gpu_join_build": (i32, [P, P, C.POINTER(ColRef), i32, i32, PP]),
     "ldb_gpu_hashtable_release": (i32, [P, P]),
     "ldb_gpu_hashtable_slots": (i64, [P]),
+    "ldb_gpu_hashtable_bytes": (i64, [P]),
     "ldb_gpu_join_probe": (i32, [P, P, P, C.POINTER(ColRef), i32, i32, PP, PP]),
     "ldb_gpu_join_probe_residual": (i32, [P, P, P, C.POINTER(ColRef), i32, i32, C.POINTER(JoinResidual), i32, PP, PP]),
     "ldb_gpu_join_probe_count": (i32, [P, P, P, C.POINTER(ColRef), i32, C.POINTER(i64)]),
@@ -210,6 +211,7 @@ GPU_API = {
     "ldb_gpu_comm_destroy": (i32, [P]),
     "ldb_gpu_comm_rank": (i32, [P]),
     "ldb_gpu_comm_world": (i32, [P]),
+    "ldb_gpu_comm_transport": (C.c_char_p, [P]),
     "ldb_gpu_allgather": (i32, [P, P, P, C.c_char_p, PP]),
     "ldb_gpu_alltoall": (i32, [P, P, P, C.POINTER(i64), C.c_char_p, PP]),
     "ldb_gpu_shuffle": (i32, [P, P, P, C.POINTER(ColRef), i32, C.POINTER(ColRef), i32, C.c_char_p, PP]),
