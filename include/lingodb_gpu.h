@@ -189,6 +189,8 @@ int32_t ldb_gpu_table_col_ptrs(const ldb_table* t, int32_t col, void** values, v
 int32_t ldb_gpu_table_set_rows(ldb_table* t, int64_t n_rows);
 /* blocking D2H copy of a fixed-width column's values (n_rows * width bytes) */
 int32_t ldb_gpu_table_read_fixed(ldb_ctx* ctx, const ldb_table* t, int32_t col, void* host_out, int64_t out_bytes);
+/* is `row` of the column non-NULL?  (scalar-subquery results: a key-less aggregate over no rows is one NULL row) */
+int32_t ldb_gpu_table_row_valid(ldb_ctx* ctx, const ldb_table* t, int32_t col, int64_t row, int32_t* valid);
 /* blocking H2D copy into a fixed-width column */
 int32_t ldb_gpu_table_write_fixed(ldb_ctx* ctx, ldb_table* t, int32_t col, const void* host_in, int64_t in_bytes);
 /* device-to-device copy on the ctx stream (moving column buffers to / from RCCL exchange buffers) */
@@ -492,6 +494,13 @@ int32_t ldb_gpu_comm_destroy(ldb_comm* comm);
 int32_t ldb_gpu_comm_rank(const ldb_comm* comm);
 int32_t ldb_gpu_comm_world(const ldb_comm* comm);
 const char* ldb_gpu_comm_transport(const ldb_comm* comm); /* "rccl" | "shm" */
+/* the host-staged transport without a device (host pointers): CPU tests of the protocol with world > 1, and
+ * exchange of host-side metadata between the ranks' host programs */
+int32_t ldb_gpu_comm_create_host(int32_t rank, int32_t world, const void* id128, ldb_comm** out);
+/* raw all-to-all of bytes (one grouped batch): send_bytes[p] bytes of `send` (peer runs back to back) go to peer p,
+ * recv_bytes[p] bytes from peer p arrive in `recv` (peer runs back to back).  Device pointers for a device
+ * communicator, host pointers for ldb_gpu_comm_create_host */
+int32_t ldb_gpu_comm_alltoall_bytes(ldb_comm* comm, const void* send, const int64_t* send_bytes, void* recv, const int64_t* recv_bytes);
 /* every rank's rows of `t` concatenated in rank order on every rank (replicated small build sides,
  * partial aggregates; fixed-width and utf8 columns, validity bitmaps travel along) */
 int32_t ldb_gpu_allgather(ldb_ctx* ctx, ldb_comm* comm, const ldb_table* t, const char* name, ldb_table** out);

@@ -232,8 +232,18 @@ struct ShmTransport : Transport {
       m->bytes = bytes;
       return LDB_OK;
    }
+   // ctx == NULL: host mode (ldb_gpu_comm_create_host) — the "device" pointers are host memory; the protocol
+   // (segments, barriers, ordering of a pair's transfers) is what the CPU tests exercise with world 2 and 3
+   int32_t copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+      if (!ctx) {
+         memcpy(dst, src, bytes);
+         return LDB_OK;
+      }
+      LDB_HIP(hipMemcpy(dst, src, bytes, kind));
+      return LDB_OK;
+   }
    int32_t group_end_inner() {
-      LDB_HIP(hipStreamSynchronize(ctx->stream)); // what is sent was produced on the ctx stream
+      if (ctx) LDB_HIP(hipStreamSynchronize(ctx->stream)); // what is sent was produced on the ctx stream
       std::vector<size_t> out_bytes((size_t) world, 0), in_bytes((size_t) world, 0);
       for (auto& o : ops) (o.is_send ? out_bytes : in_bytes)[(size_t) o.peer] += o.bytes;
       // 1. write: one segment per receiving peer, the sends to it back to back in issue order
@@ -244,7 +254,7 @@ struct ShmTransport : Transport {
          size_t at = 0;
          for (auto& o : ops)
             if (o.is_send && o.peer == p && o.bytes) {
-               LDB_HIP(hipMemcpy((char*) m.p + at, o.ptr, o.bytes, hipMemcpyDeviceToHost));
+               LDB_TRY(copy((char*) m.p + at, o.ptr, o.bytes, hipMemcpyDeviceToHost));
                at += o.bytes;
             }
       }
@@ -258,7 +268,7 @@ struct ShmTransport : Transport {
                if (r.is_send || r.peer != rank || !r.bytes) continue;
                while (si < ops.size() && !(ops[si].is_send && ops[si].peer == rank && ops[si].bytes)) si++;
                if (si == ops.size() || ops[si].bytes != r.bytes) LDB_FAIL(LDB_ERR_INVALID, "shm transport: self transfer sizes do not pair up");
-               LDB_HIP(hipMemcpy(r.ptr, ops[si].ptr, r.bytes, hipMemcpyDeviceToDevice));
+               LDB_TRY(copy(r.ptr, ops[si].ptr, r.bytes, hipMemcpyDeviceToDevice));
                si++;
             }
             continue;
@@ -268,7 +278,7 @@ struct ShmTransport : Transport {
          size_t at = 0;
          for (auto& o : ops)
             if (!o.is_send && o.peer == p && o.bytes) {
-               LDB_HIP(hipMemcpy(o.ptr, (const char*) m.p + at, o.bytes, hipMemcpyHostToDevice));
+               LDB_TRY(copy(o.ptr, (const char*) m.p + at, o.bytes, hipMemcpyHostToDevice));
                at += o.bytes;
             }
       }
@@ -339,6 +349,24 @@ extern "C" int32_t ldb_gpu_comm_create(ldb_ctx* ctx, int32_t rank, int32_t world
    *out = c.release();
    return LDB_OK;
 }
+// a communicator over the host-staged transport WITHOUT a device: transfers move host memory.  For CPU tests
+// of the transport's protocol and for exchanging host-side metadata between the ranks' host programs.
+extern "C" int32_t ldb_gpu_comm_create_host(int32_t rank, int32_t world, const void* id128, ldb_comm** out) {
+   if (!id128 || !out || world < 1 || rank < 0 || rank >= world) LDB_FAIL(LDB_ERR_INVALID, "comm_create_host: bad argument");
+   if (memcmp(id128, SHM_MAGIC, 8)) LDB_FAIL(LDB_ERR_INVALID, "comm_create_host: the id is not a host-staged transport id (set option comm_transport = 1 before ldb_gpu_comm_unique_id)");
+   char tok[65] = {0};
+   memcpy(tok, (const char*) id128 + 8, 64);
+   for (char* q = tok; *q; q++)
+      if (!isxdigit((unsigned char) *q)) LDB_FAIL(LDB_ERR_INVALID, "comm_create_host: malformed id");
+   auto c = std::make_unique<ldb_comm>();
+   c->rank = rank;
+   c->world = world;
+   auto t = std::make_unique<ShmTransport>(nullptr, rank, world, tok);
+   LDB_TRY(t->open_control());
+   c->t = std::move(t);
+   *out = c.release();
+   return LDB_OK;
+}
 extern "C" int32_t ldb_gpu_comm_destroy(ldb_comm* c) {
    delete c; // the transport's destructor closes the communicator / the shared segments
    return LDB_OK;
@@ -369,37 +397,6 @@ __global__ void k_count_zero_bytes(const uint8_t* __restrict__ bytes, uint64_t n
    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) c += bytes[i] ? 0 : 1;
    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
-}
-
-// ---------------------------------------------------------------- validity as bytes (exchanges done outside the library)
-// The torch.distributed test double of the exchange (tpch_dist.replicate) moves flat byte buffers: a
-// column's validity travels as one byte per row and is re-attached on arrival.
-extern "C" int32_t ldb_gpu_table_validity_bytes(ldb_ctx* ctx, const ldb_table* t, int32_t col, void* d_bytes) {
-   if (!ctx || !t || !d_bytes || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "table_validity_bytes: bad argument");
-   const int64_t n = t->n_rows;
-   if (n) hipLaunchKernelGGL(k_bits_to_bytes, dim3(ldb_grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, (const uint8_t*) t->cols[(size_t) col].validity, (uint8_t*) d_bytes, (uint64_t) n);
-   LDB_HIP(hipGetLastError());
-   return LDB_OK;
-}
-extern "C" int32_t ldb_gpu_table_set_validity_bytes(ldb_ctx* ctx, ldb_table* t, int32_t col, const void* d_bytes) {
-   if (!ctx || !t || !d_bytes || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "table_set_validity_bytes: bad argument");
-   ldb_column& c = t->cols[(size_t) col];
-   if (!c.owned) LDB_FAIL(LDB_ERR_INVALID, "table_set_validity_bytes: the table does not own its buffers");
-   const int64_t n = t->n_rows;
-   unsigned long long* d_nulls = (unsigned long long*) ctx->d_scratch;
-   LDB_HIP(hipMemsetAsync(d_nulls, 0, 8, ctx->stream));
-   if (n) hipLaunchKernelGGL(k_count_zero_bytes, dim3(ldb_grid_for(ctx, n, 256, 8)), dim3(256), 0, ctx->stream, (const uint8_t*) d_bytes, (uint64_t) n, d_nulls);
-   uint64_t nulls = 0;
-   LDB_TRY(ldb_read_u64(ctx, d_nulls, &nulls));
-   ldb_dev_free(ctx, c.validity);
-   c.validity = nullptr;
-   c.null_count = (int64_t) nulls;
-   if (nulls) {
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &c.validity, (size_t) ((n + 7) / 8 + 1)));
-      hipLaunchKernelGGL(k_bytes_to_bits, dim3(ldb_grid_for(ctx, (n + 7) / 8, 256, 8)), dim3(256), 0, ctx->stream, (const uint8_t*) d_bytes, c.validity, (uint64_t) n);
-      LDB_HIP(hipGetLastError());
-   }
-   return LDB_OK;
 }
 
 // ---------------------------------------------------------------- the exchange
@@ -668,4 +665,21 @@ extern "C" int32_t ldb_gpu_shuffle(ldb_ctx* ctx, ldb_comm* c, ldb_rel* in, const
    std::vector<int64_t> counts((size_t) c->world, 0);
    LDB_TRY(ldb_gpu_partition(ctx, in, keys, n_keys, c->world, cols, n_cols, &packed.t, counts.data()));
    return ldb_gpu_alltoall(ctx, c, packed.t, counts.data(), name, out);
+}
+
+// raw all-to-all of bytes: send_bytes[p] bytes from `send` (peer runs back to back) to peer p, recv_bytes[p]
+// bytes from peer p into `recv` (peer runs back to back) — one group of point-to-point transfers
+extern "C" int32_t ldb_gpu_comm_alltoall_bytes(ldb_comm* c, const void* send, const int64_t* send_bytes, void* recv, const int64_t* recv_bytes) {
+   if (!c || !send_bytes || !recv_bytes) LDB_FAIL(LDB_ERR_INVALID, "comm_alltoall_bytes: NULL argument");
+   GroupGuard grp(c->t.get());
+   LDB_TRY(grp.start());
+   size_t so = 0, ro = 0;
+   for (int p = 0; p < c->world; p++) {
+      if (send_bytes[p] < 0 || recv_bytes[p] < 0) LDB_FAIL(LDB_ERR_INVALID, "comm_alltoall_bytes: negative size");
+      if (send_bytes[p]) LDB_TRY(c->t->send((const char*) send + so, (size_t) send_bytes[p], p));
+      if (recv_bytes[p]) LDB_TRY(c->t->recv((char*) recv + ro, (size_t) recv_bytes[p], p));
+      so += (size_t) send_bytes[p];
+      ro += (size_t) recv_bytes[p];
+   }
+   return grp.end();
 }

@@ -587,6 +587,17 @@ extern "C" int32_t ldb_gpu_table_read_fixed(ldb_ctx* ctx, const ldb_table* t, in
    LDB_HIP(hipStreamSynchronize(ctx->stream));
    return LDB_OK;
 }
+extern "C" int32_t ldb_gpu_table_row_valid(ldb_ctx* ctx, const ldb_table* t, int32_t col, int64_t row, int32_t* valid) {
+   if (!ctx || !t || !valid || col < 0 || (size_t) col >= t->cols.size() || row < 0 || row >= t->n_rows) LDB_FAIL(LDB_ERR_INVALID, "row_valid: bad argument");
+   const ldb_column& c = t->cols[(size_t) col];
+   *valid = 1;
+   if (!c.validity) return LDB_OK;
+   uint8_t byte = 0xFF;
+   LDB_HIP(hipMemcpyAsync(&byte, c.validity + (row >> 3), 1, hipMemcpyDeviceToHost, ctx->stream));
+   LDB_HIP(hipStreamSynchronize(ctx->stream));
+   *valid = (byte >> (row & 7)) & 1;
+   return LDB_OK;
+}
 extern "C" int32_t ldb_gpu_table_write_fixed(ldb_ctx* ctx, ldb_table* t, int32_t col, const void* host_in, int64_t in_bytes) {
    if (!t || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "write_fixed: bad column %d", col);
    ldb_column& c = t->cols[(size_t) col];

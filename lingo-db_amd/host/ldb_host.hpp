@@ -66,81 +66,16 @@ void check(int32_t status, const char* what);
 } // namespace lingodb::runtime::gpu
 
 extern "C" {
-// The single-GPU TPC-H plans are data: lingo-db_amd/plans/tpch/qN.json run by ldb_plan_run_json (below).
-// The functions here are the PIECES of the multi-GPU plans (shard-local parts and merges between the
-// exchanges).  Inputs: device tables with the TPC-H column names; result: device table
-// (caller releases).
-// Q5 pieces (multi-GPU all-gathers between them)
-int32_t ldb_plan_tpch_q5_customers(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* nation, const ldb_table* region, ldb_table** result);
-int32_t ldb_plan_tpch_q5_suppliers(ldb_ctx* ctx, const ldb_table* supplier, const ldb_table* nation, const ldb_table* region, ldb_table** result);
-int32_t ldb_plan_tpch_q5_local(ldb_ctx* ctx, const ldb_table* custs, const ldb_table* supps, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q5_final(ldb_ctx* ctx, const ldb_table* partials, const ldb_table* nation, ldb_table** result);
-int32_t ldb_plan_tpch_q7_customers(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* nation, ldb_table** result);
-int32_t ldb_plan_tpch_q7_suppliers(ldb_ctx* ctx, const ldb_table* supplier, const ldb_table* nation, ldb_table** result);
-int32_t ldb_plan_tpch_q7_local(ldb_ctx* ctx, const ldb_table* custs, const ldb_table* supps, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q7_final(ldb_ctx* ctx, const ldb_table* partials, const ldb_table* nation, ldb_table** result);
-// Q11 pieces (suppliers → groups → [partition → all-to-all → merge] → total → filter → sort)
-int32_t ldb_plan_tpch_q11_suppliers(ldb_ctx* ctx, const ldb_table* supplier, const ldb_table* nation, ldb_table** result);
-int32_t ldb_plan_tpch_q11_groups(ldb_ctx* ctx, const ldb_table* suppkeys, const ldb_table* partsupp, ldb_table** result);
-int32_t ldb_plan_tpch_q11_partition(ldb_ctx* ctx, const ldb_table* groups, int32_t world, ldb_table** result, int64_t* counts);
-int32_t ldb_plan_tpch_q11_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
-int32_t ldb_plan_tpch_q11_total(ldb_ctx* ctx, const ldb_table* groups, ldb_table** result);
-int32_t ldb_plan_tpch_q11_filter(ldb_ctx* ctx, const ldb_table* groups, const ldb_table* totals, ldb_table** result);
-int32_t ldb_plan_tpch_q11_sort(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
-// Q14 pieces (promo part keys → [all-gather] → local partial sums → [all-gather] → final ratio)
-int32_t ldb_plan_tpch_q14_promo(ldb_ctx* ctx, const ldb_table* part, ldb_table** result);
-int32_t ldb_plan_tpch_q14_local(ldb_ctx* ctx, const ldb_table* promokeys, const ldb_table* partkeys, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q14_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
-// Q8 pieces (part keys, customers of the region → [all-gather] → local partial sums per year → [all-gather] → final)
-int32_t ldb_plan_tpch_q8_parts(ldb_ctx* ctx, const ldb_table* part, ldb_table** result);
-int32_t ldb_plan_tpch_q8_customers(ldb_ctx* ctx, const ldb_table* customer, const ldb_table* nation, const ldb_table* region, ldb_table** result);
-int32_t ldb_plan_tpch_q8_local(ldb_ctx* ctx, const ldb_table* partkeys, const ldb_table* custs, const ldb_table* supplier, const ldb_table* orders, const ldb_table* lineitem,
-                               const ldb_table* nation, ldb_table** result);
-int32_t ldb_plan_tpch_q8_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
 const char* ldb_plan_last_error(void);
 // Plans as data (ldb_plan.cpp): a JSON step list — the shape of the reference's execution-step dump
 // (tools/ct/mlir-subop-to-json.cpp) at the granularity of the C-ABI — interpreted over the named
 // input tables; *result = the table the plan names as its result (caller releases).
 int32_t ldb_plan_run_json(ldb_ctx* ctx, const char* plan_json, const char* const* table_names, const ldb_table* const* tables, int32_t n_tables, ldb_table** result);
+int32_t ldb_plan_run_json_comm(ldb_ctx* ctx, ldb_comm* comm, const char* plan_json, const char* const* table_names, const ldb_table* const* tables, int32_t n_tables,
+                               ldb_table** result);
 const char* ldb_plan_json_last_error(void);
 // structure check without a device: parse, known steps with their required fields, values defined before use
 int32_t ldb_plan_json_check(const char* plan_json, const char* const* input_names, int32_t n_inputs);
-// multi-GPU pieces: shard-local partial plans + merges of the exchanged partial tables
-int32_t ldb_plan_tpch_q1_partial(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q1_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
-int32_t ldb_plan_tpch_q6_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
-int32_t ldb_plan_tpch_q3_customers(ldb_ctx* ctx, const ldb_table* customer, ldb_table** result);
-int32_t ldb_plan_tpch_q3_local(ldb_ctx* ctx, const ldb_table* custkeys, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q3_final(ldb_ctx* ctx, const ldb_table* tops, ldb_table** result);
-int32_t ldb_plan_tpch_q4_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
-int32_t ldb_plan_tpch_q12_final(ldb_ctx* ctx, const ldb_table* partials, ldb_table** result);
-// Q10 pieces: shard-local (o_custkey, revenue) groups; [multi-GPU: partition + merge on the key;] top 20; names; order
-int32_t ldb_plan_tpch_q10_local(ldb_ctx* ctx, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q10_partition(ldb_ctx* ctx, const ldb_table* groups, int32_t world, ldb_table** result, int64_t* counts);
-int32_t ldb_plan_tpch_q10_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
-int32_t ldb_plan_tpch_q10_top(ldb_ctx* ctx, const ldb_table* groups, ldb_table** result);
-int32_t ldb_plan_tpch_q10_names(ldb_ctx* ctx, const ldb_table* top20, const ldb_table* customer, const ldb_table* nation, ldb_table** result);
-int32_t ldb_plan_tpch_q10_final(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
-// Q15 pieces: shard-local (l_suppkey, revenue) groups; [multi-GPU: partition + merge;] best group; groups equal to it; supplier join + order
-int32_t ldb_plan_tpch_q15_local(ldb_ctx* ctx, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q15_partition(ldb_ctx* ctx, const ldb_table* groups, int32_t world, ldb_table** result, int64_t* counts);
-int32_t ldb_plan_tpch_q15_merge(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
-int32_t ldb_plan_tpch_q15_max(ldb_ctx* ctx, const ldb_table* groups, ldb_table** result);
-int32_t ldb_plan_tpch_q15_winners(ldb_ctx* ctx, const ldb_table* groups, const ldb_table* best, ldb_table** result);
-int32_t ldb_plan_tpch_q15_final(ldb_ctx* ctx, const ldb_table* winners, const ldb_table* supplier, ldb_table** result);
-int32_t ldb_plan_tpch_q18_local(ldb_ctx* ctx, const ldb_table* orders, const ldb_table* lineitem, ldb_table** result);
-int32_t ldb_plan_tpch_q18_mid(ldb_ctx* ctx, const ldb_table* tops, ldb_table** result);
-int32_t ldb_plan_tpch_q18_names(ldb_ctx* ctx, const ldb_table* top100, const ldb_table* customer, ldb_table** result);
-int32_t ldb_plan_tpch_q18_final(ldb_ctx* ctx, const ldb_table* rows, ldb_table** result);
-// Q9: green part keys → (all-gather) → lineitem side / partsupp side partitioned by hash-radix of the
-// part key (counts[world] rows per destination) → (two all-to-alls) → local joins + partial sums →
-// (all-gather) → final
-int32_t ldb_plan_tpch_q9_green(ldb_ctx* ctx, const ldb_table* part, ldb_table** result);
-int32_t ldb_plan_tpch_q9_lineitem_side(ldb_ctx* ctx, const ldb_table* greenkeys, const ldb_table* lineitem, const ldb_table* orders, int32_t world, ldb_table** result,
-                                       int64_t* counts);
-int32_t ldb_plan_tpch_q9_partsupp_side(ldb_ctx* ctx, const ldb_table* greenkeys, const ldb_table* partsupp, int32_t world, ldb_table** result, int64_t* counts);
-int32_t ldb_plan_tpch_q9_join(ldb_ctx* ctx, const ldb_table* lrows, const ldb_table* psrows, const ldb_table* supplier, const ldb_table* nation, ldb_table** result);
-int32_t ldb_plan_tpch_q9_final(ldb_ctx* ctx, const ldb_table* partials, const ldb_table* nation, ldb_table** result);
 // test hooks for the host logic (date / decimal parsing, decimal typing rules)
 int32_t ldb_host_parse_date32(const char* s, int32_t* out);
 int32_t ldb_host_parse_decimal(const char* s, int32_t scale, int64_t* lo, int64_t* hi);

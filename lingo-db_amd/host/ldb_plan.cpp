@@ -175,12 +175,16 @@ struct JParser {
       while (*p && *p != '"') {
          if (*p == '\\') {
             p++;
+            if (!*p) fail("unterminated escape"); // (never step over the terminating NUL)
             switch (*p) {
                case 'n': out += '\n'; break;
                case 't': out += '\t'; break;
                case 'u': { // \uXXXX (BMP only) → UTF-8
                   unsigned cp = 0;
-                  for (int i = 1; i <= 4; i++) cp = cp * 16 + (unsigned) (isdigit((unsigned char) p[i]) ? p[i] - '0' : (tolower(p[i]) - 'a' + 10));
+                  for (int i = 1; i <= 4; i++) {
+                     if (!isxdigit((unsigned char) p[i])) fail("\\u needs four hex digits"); // (also stops at the NUL)
+                     cp = cp * 16 + (unsigned) (isdigit((unsigned char) p[i]) ? p[i] - '0' : (tolower(p[i]) - 'a' + 10));
+                  }
                   p += 4;
                   if (cp < 0x80) out += (char) cp;
                   else if (cp < 0x800) {
@@ -224,6 +228,7 @@ struct Scalar { // expression type: integer (p = 0) or decimal(p, s), date, bool
 
 struct Interp {
    ldb_ctx* ctx;
+   ldb_comm* comm = nullptr; // exchange steps: NULL = one rank (allgather is a copy, shuffle a materialize)
    std::map<std::string, Value> env;
    std::vector<ldb_table*> hidden; // computed-column tables that live as long as the plan run
    std::vector<std::unique_ptr<Restrictions>> keepRestr; // constant storage the descriptors point into
@@ -341,6 +346,16 @@ struct Interp {
       }
       return x;
    }
+   // row 0 of the scalar source is NULL (SimpleState over an empty input yields one NULL row)
+   bool scalarIsNull(const std::string& table, const std::string& col) {
+      Value& v = val(table);
+      if (v.kind != Value::TABLE) throw std::runtime_error("plan: scalar source '" + table + "' must be a table");
+      const int32_t c = ldb_gpu_table_col_index(v.table, col.c_str());
+      if (c < 0) throw std::runtime_error("plan: scalar source has no column '" + col + "'");
+      int32_t valid = 1;
+      check(ldb_gpu_table_row_valid(ctx, v.table, c, 0, &valid), "scalar validity");
+      return valid == 0;
+   }
    static __int128 floorDiv(__int128 a, __int128 b) {
       __int128 q = a / b;
       if ((a % b != 0) && ((a < 0) != (b < 0))) q--;
@@ -373,7 +388,7 @@ struct Interp {
          return d;
       }
       if (const J* sc = jp.get("scalar")) { // column OP (scalar subquery result): the constant is read back from the device
-         if (rowsOf(sc->s("from")) < 1) { // the subquery returned no row: NULL, and a comparison with NULL keeps nothing
+         if (rowsOf(sc->s("from")) < 1 || scalarIsNull(sc->s("from"), sc->s("col"))) { // no row, or a NULL (a key-less aggregate over no rows): a comparison with NULL keeps nothing
             ldb_filter_desc d;
             memset(&d, 0, sizeof(d));
             d.col = c;
@@ -386,6 +401,7 @@ struct Interp {
          // the two sides of the comparison are cast to a common decimal type first; with
          // x at scale sx and the column at scale sc <= sx:  col * 10^k OP x  ⇔  col OP' floor-ish(x / 10^k)
          const int64_t k = sc->iOr("div_pow10", 0);
+         if (k < 0 || k > 38) throw std::runtime_error("plan: div_pow10 must be in [0, 38]");
          if (k > 0) {
             __int128 m = 1;
             for (int64_t i = 0; i < k; i++) m *= 10;
@@ -872,6 +888,11 @@ struct Interp {
                a.out_type = LDB_T_INT64;
             } else {
                const Scalar t = aggExpr(*sides, ja.at("expr"), &a.arg);
+               if (const J* cnt = ja.get("count")) { // AVG over exchanged partials: SUM(expr) / SUM(count) — the merge of (sum, count) pairs
+                  if (fn != "avg") throw std::runtime_error("groupby: 'count' belongs to fn avg");
+                  a.has_count_expr = 1;
+                  aggExpr(*sides, *cnt, &a.count_expr);
+               }
                if (fn == "count") {
                   a.fn = LDB_AGG_COUNT;
                   a.out_type = LDB_T_INT64;
@@ -968,6 +989,35 @@ struct Interp {
             i++;
          }
          putTable(st.s("out"), t);
+      } else if (op == "allgather") { // every rank's rows of a (small) table, concatenated in rank order on every rank
+         Value& t = val(st.s("in"));
+         if (t.kind != Value::TABLE) throw std::runtime_error("allgather: 'in' must be a table (materialize first)");
+         ldb_table* out = nullptr;
+         if (comm) {
+            check(ldb_gpu_allgather(ctx, comm, t.table, st.s("out").c_str(), &out), "allgather");
+         } else { // one rank: a copy
+            std::vector<const ldb_table*>* sides;
+            ldb_rel* in = relOf(st.s("in"), &sides);
+            std::vector<ldb_colref> all;
+            for (int32_t c = 0; c < ldb_gpu_table_cols(t.table); c++) all.push_back({0, c});
+            check(ldb_gpu_materialize(ctx, in, all.data(), (int32_t) all.size(), &out), "allgather (one rank)");
+         }
+         putTable(st.s("out"), out);
+      } else if (op == "shuffle") { // hash-radix re-partition on db.hash(keys): afterwards equal keys are on one rank
+         std::vector<const ldb_table*>* sides;
+         ldb_rel* in = relOf(st.s("in"), &sides);
+         auto keys = cols(*sides, st.at("keys"), "shuffle key");
+         auto cs = cols(*sides, st.at("cols"), "shuffle");
+         ldb_table* out = nullptr;
+         if (comm) check(ldb_gpu_shuffle(ctx, comm, in, keys.data(), (int32_t) keys.size(), cs.data(), (int32_t) cs.size(), st.s("out").c_str(), &out), "shuffle");
+         else check(ldb_gpu_materialize(ctx, in, cs.data(), (int32_t) cs.size(), &out), "shuffle (one rank)");
+         size_t i = 0;
+         for (auto& c : st.at("cols").arr) {
+            if (c.kind == J::OBJ)
+               if (const J* as = c.get("as")) ldb_gpu_table_rename_col(out, (int32_t) i, as->str.c_str());
+            i++;
+         }
+         putTable(st.s("out"), out);
       } else {
          throw std::runtime_error("unknown step");
       }
@@ -980,6 +1030,12 @@ thread_local std::string g_plan_json_err;
 
 // Run a JSON plan over the named input tables; *result = the table named by the plan's "result".
 extern "C" int32_t ldb_plan_run_json(ldb_ctx* ctx, const char* plan_json, const char* const* table_names, const ldb_table* const* tables, int32_t n_tables, ldb_table** result) {
+   return ldb_plan_run_json_comm(ctx, nullptr, plan_json, table_names, tables, n_tables, result);
+}
+// the same with a communicator: the plan's `allgather` / `shuffle` steps exchange rows with the other ranks
+// (every rank runs the same plan text over its shard)
+extern "C" int32_t ldb_plan_run_json_comm(ldb_ctx* ctx, ldb_comm* comm, const char* plan_json, const char* const* table_names, const ldb_table* const* tables, int32_t n_tables,
+                                          ldb_table** result) {
    if (!ctx || !plan_json || !result || n_tables < 0) {
       g_plan_json_err = "plan_run_json: bad argument";
       return LDB_ERR_INVALID;
@@ -988,6 +1044,7 @@ extern "C" int32_t ldb_plan_run_json(ldb_ctx* ctx, const char* plan_json, const 
       JParser parser(plan_json);
       const J plan = parser.value();
       Interp in(ctx);
+      in.comm = comm;
       in.run(plan, table_names, tables, n_tables);
       Value& r = in.val(in.result);
       if (r.kind != Value::TABLE || !r.owned) throw std::runtime_error("plan: result '" + in.result + "' must be a table produced by the plan");
@@ -1028,7 +1085,7 @@ extern "C" int32_t ldb_plan_json_check(const char* plan_json, const char* const*
       static const std::vector<Shape> shapes = {{"scan", {"table"}, {}},           {"filter", {"in"}, {"preds"}},        {"filter_dnf", {"in"}, {"clauses"}},
                                                 {"join_build", {"in"}, {"keys"}},  {"join_probe", {"ht", "in"}, {"keys"}}, {"groupby", {"in"}, {"aggs"}},
                                                 {"map", {"in"}, {"as"}},           {"sort", {"in"}, {"by"}},             {"topk", {"in"}, {"by", "k"}},
-                                                {"materialize", {"in"}, {"cols"}}};
+                                                {"materialize", {"in"}, {"cols"}}, {"allgather", {"in"}, {}},           {"shuffle", {"in"}, {"keys", "cols"}}};
       const J& steps = plan.at("steps");
       if (steps.kind != J::ARR) throw std::runtime_error("plan: 'steps' must be an array");
       for (auto& st : steps.arr) {

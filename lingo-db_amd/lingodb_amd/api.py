@@ -422,24 +422,36 @@ class HashTable:
 
 
 class Comm:
-    """RCCL communicator of the library (one rank per GPU): the id made on rank 0 reaches the others through
-    `exchange_id(bytes | None) -> bytes` (e.g. a torch.distributed broadcast)"""
+    """Communicator of the library (one rank per ldb_ctx): the 128-byte id made on rank 0 reaches the others
+    through `exchange_id(bytes | None) -> bytes` (a torch.distributed broadcast, a file, …).
+    transport "rccl" (one rank per GPU, xGMI) or "shm" (host-staged; ranks of one node, may share a GPU)."""
 
-    def __init__(self, ctx, rank, world, exchange_id):
+    def __init__(self, ctx, rank, world, exchange_id, transport="rccl"):
         # a Python process that will import torch must do so BEFORE librccl is bound: torch ships its own
         # librccl / HIP runtime copies and a second copy loaded afterwards aborts at interpreter exit
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        if transport == "rccl":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         self.ctx, self.rank, self.world = ctx, rank, world
         buf = C.create_string_buffer(128)
+        err = None
         if rank == 0:
-            check(ctx.lib.ldb_gpu_comm_unique_id(buf))
-        ident = exchange_id(buf.raw if rank == 0 else None)
+            ctx.lib.ldb_gpu_set_option(b"comm_transport", 1 if transport == "shm" else 0)
+            try:
+                check(ctx.lib.ldb_gpu_comm_unique_id(buf))
+            except Exception as e:  # the peers are waiting for the id: hand them a sentinel first, then fail everywhere
+                err = e
+        ident = exchange_id((b"" if err else buf.raw) if rank == 0 else None)
+        if err:
+            raise err
+        if not ident:
+            raise capi.LdbError(-1, "rank 0 could not create a communicator id")
         h = C.c_void_p()
         check(ctx.lib.ldb_gpu_comm_create(ctx.h, rank, world, C.create_string_buffer(ident, 128), C.byref(h)))
         self.h = h
+        self.transport = ctx.lib.ldb_gpu_comm_transport(h).decode()
 
     def close(self):
         if self.h:
@@ -604,8 +616,9 @@ class Context:
     def plan_q18(self, customer, orders, lineitem):
         return self._tpch(18, customer=customer, orders=orders, lineitem=lineitem)
 
-    def run_plan(self, plan, tables):
-        """interprets a JSON plan (text, or the name of a file under lingo-db_amd/plans/) over {name: Table}"""
+    def run_plan(self, plan, tables, comm=None):
+        """interprets a JSON plan (text, or the name of a file under lingo-db_amd/plans/) over {name: Table};
+        with a Comm the plan's allgather / shuffle steps exchange rows with the other ranks"""
         import os
 
         text = plan
@@ -617,7 +630,7 @@ class Context:
         narr = (C.c_char_p * len(names))(*[n.encode() for n in names])
         tarr = (C.c_void_p * len(names))(*[tables[n].h for n in names])
         t = C.c_void_p()
-        st = capi.host_lib().ldb_plan_run_json(self.h, text.encode(), narr, tarr, len(names), C.byref(t))
+        st = capi.host_lib().ldb_plan_run_json_comm(self.h, comm.h if comm is not None else None, text.encode(), narr, tarr, len(names), C.byref(t))
         if st != capi.LDB_OK:
             raise capi.LdbError(st, capi.host_lib().ldb_plan_json_last_error().decode(errors="replace"))
         return Table(self, t)

@@ -155,8 +155,6 @@ GPU_API = {
     "ldb_gpu_prof_enable": (i32, [P, i32]),
     "ldb_gpu_prof_marker": (i32, [P, i32]),
     "ldb_gpu_like_plan": (i32, [C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
-    "ldb_gpu_table_validity_bytes": (i32, [P, P, i32, P]),
-    "ldb_gpu_table_set_validity_bytes": (i32, [P, P, i32, P]),
     "ldb_gpu_prof_reset": (i32, [P]),
     "ldb_gpu_prof_get": (i32, [P, C.c_char_p, C.POINTER(i64), C.POINTER(C.c_double)]),
     "ldb_gpu_prof_names": (i32, [P, C.c_char_p, i32]),
@@ -177,6 +175,7 @@ GPU_API = {
     "ldb_gpu_table_col_ptrs": (i32, [P, i32, PP, PP, PP, C.POINTER(i64)]),
     "ldb_gpu_table_set_rows": (i32, [P, i64]),
     "ldb_gpu_table_read_fixed": (i32, [P, P, i32, P, i64]),
+    "ldb_gpu_table_row_valid": (i32, [P, P, i32, i64, C.POINTER(C.c_int32)]),
     "ldb_gpu_table_write_fixed": (i32, [P, P, i32, P, i64]),
     "ldb_gpu_memcpy_d2d": (i32, [P, P, P, i64]),
     "ldb_gpu_export": (i32, [P, P, C.POINTER(ArrowSchema), C.POINTER(ArrowArray)]),
@@ -212,6 +211,8 @@ GPU_API = {
     "ldb_gpu_comm_rank": (i32, [P]),
     "ldb_gpu_comm_world": (i32, [P]),
     "ldb_gpu_comm_transport": (C.c_char_p, [P]),
+    "ldb_gpu_comm_create_host": (i32, [i32, i32, P, PP]),
+    "ldb_gpu_comm_alltoall_bytes": (i32, [P, P, C.POINTER(C.c_int64), P, C.POINTER(C.c_int64)]),
     "ldb_gpu_allgather": (i32, [P, P, P, C.c_char_p, PP]),
     "ldb_gpu_alltoall": (i32, [P, P, P, C.POINTER(i64), C.c_char_p, PP]),
     "ldb_gpu_shuffle": (i32, [P, P, P, C.POINTER(ColRef), i32, C.POINTER(ColRef), i32, C.c_char_p, PP]),
@@ -222,61 +223,11 @@ GPU_API = {
 HOST_API = {
     "ldb_tpch_host_rows": (i64, [i32, i64, i32, i32]),
     "ldb_tpch_host_column": (i64, [i32, i32, i64, i32, i32, P, C.POINTER(i64), C.POINTER(i64)]),
-    "ldb_plan_tpch_q7_customers": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q7_suppliers": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q7_local": (i32, [P, P, P, P, P, PP]),
-    "ldb_plan_tpch_q7_final": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q8_parts": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q8_customers": (i32, [P, P, P, P, PP]),
-    "ldb_plan_tpch_q8_local": (i32, [P, P, P, P, P, P, P, PP]),
-    "ldb_plan_tpch_q8_final": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q14_promo": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q14_local": (i32, [P, P, P, P, PP]),
-    "ldb_plan_tpch_q14_final": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q11_suppliers": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q11_groups": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q11_partition": (i32, [P, P, i32, PP, C.POINTER(i64)]),
-    "ldb_plan_tpch_q15_partition": (i32, [P, P, i32, PP, C.POINTER(i64)]),
-    "ldb_plan_tpch_q10_partition": (i32, [P, P, i32, PP, C.POINTER(i64)]),
-    "ldb_plan_tpch_q11_merge": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q11_total": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q11_filter": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q11_sort": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q5_customers": (i32, [P, P, P, P, PP]),
-    "ldb_plan_tpch_q5_suppliers": (i32, [P, P, P, P, PP]),
-    "ldb_plan_tpch_q5_local": (i32, [P, P, P, P, P, PP]),
-    "ldb_plan_tpch_q5_final": (i32, [P, P, P, PP]),
     "ldb_plan_last_error": (C.c_char_p, []),
     "ldb_plan_run_json": (i32, [P, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(P), i32, PP]),
+    "ldb_plan_run_json_comm": (i32, [P, P, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(P), i32, PP]),
     "ldb_plan_json_last_error": (C.c_char_p, []),
     "ldb_plan_json_check": (i32, [C.c_char_p, C.POINTER(C.c_char_p), i32]),
-    "ldb_plan_tpch_q1_partial": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q1_final": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q6_final": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q3_customers": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q3_local": (i32, [P, P, P, P, PP]),
-    "ldb_plan_tpch_q3_final": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q4_final": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q12_final": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q10_local": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q10_merge": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q10_top": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q10_names": (i32, [P, P, P, P, PP]),
-    "ldb_plan_tpch_q10_final": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q15_local": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q15_merge": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q15_max": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q15_winners": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q15_final": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q18_local": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q18_mid": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q18_names": (i32, [P, P, P, PP]),
-    "ldb_plan_tpch_q18_final": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q9_green": (i32, [P, P, PP]),
-    "ldb_plan_tpch_q9_lineitem_side": (i32, [P, P, P, P, i32, PP, C.POINTER(i64)]),
-    "ldb_plan_tpch_q9_partsupp_side": (i32, [P, P, P, i32, PP, C.POINTER(i64)]),
-    "ldb_plan_tpch_q9_join": (i32, [P, P, P, P, P, PP]),
-    "ldb_plan_tpch_q9_final": (i32, [P, P, P, PP]),
     "ldb_host_parse_date32": (i32, [C.c_char_p, C.POINTER(i32)]),
     "ldb_host_parse_decimal": (i32, [C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64)]),
     "ldb_host_decimal_type": (None, [i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),

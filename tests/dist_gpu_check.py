@@ -1,82 +1,122 @@
-"""Launched by torch.distributed.run (see test_gpu_dist.py): runs the sharded multi-rank TPC-H plans
-(tpch_dist.py) and checks on rank 0 that they return exactly what the single-GPU plans return on
-the unsharded database.  With LDB_DIST_BACKEND=gloo all ranks share GPU 0 (functional check of the
-N>1 path on a 1-GPU box); with nccl it needs one GPU per rank."""
+"""One rank of the N > 1 check (started `world` times by test_gpu_dist.py, or by torch.distributed.run on a
+multi-GPU node): runs the SHARDED TPC-H plans (lingo-db_amd/plans/tpch/dist/) through the library's own
+exchange — ldb_gpu_allgather / ldb_gpu_shuffle behind the plan interpreter's allgather / shuffle steps — and
+checks on rank 0 that they return exactly what the single-GPU plans return on the unsharded database.
+
+Transport (LDB_CHECK_TRANSPORT): "shm" = host-staged, all ranks may share GPU 0 (the one-GPU box);
+"rccl" = one GPU per rank.  The 128-byte communicator id travels through a file (LDB_ID_FILE); no torch."""
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lingo-db_amd"))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
+
+def file_exchange(path, rank):
+    def exchange(ident):
+        if rank == 0:
+            with open(path + ".tmp", "wb") as f:
+                f.write(ident)
+            os.replace(path + ".tmp", path)
+            return ident
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > 120:
+                raise TimeoutError("communicator id file never appeared")
+            time.sleep(0.01)
+        with open(path, "rb") as f:
+            return f.read()
+
+    return exchange
+
+
+def rows_of(t):
+    return list(zip(*[c.to_pylist() for c in t.columns])) if t.num_columns else []
+
+
+def same_result(q, va, vb):
+    """ORDER BY keys compared in order, ties beyond them as sets (the SQL leaves their order open)"""
+    order = {3: lambda r: (r[1], r[2]), 18: lambda r: (r[4], r[3]), 10: lambda r: r[2], 11: lambda r: r[1], 2: lambda r: (r[0], r[2], r[1], r[3]),
+             21: lambda r: (r[1], r[0]), 13: lambda r: (r[1], r[0]), 16: lambda r: (r[3], r[0], r[1], r[2])}
+    if q in order:
+        return [order[q](r) for r in va] == [order[q](r) for r in vb] and sorted(map(repr, va)) == sorted(map(repr, vb))
+    return va == vb
 
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    backend = os.environ.get("LDB_DIST_BACKEND", "nccl")
-    dev = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
-    torch.cuda.set_device(dev)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend)
+    transport = os.environ.get("LDB_CHECK_TRANSPORT", "shm")
     import lingodb_amd as ldb
+    from lingodb_amd import api, capi
     import tpch_plans
 
+    n_dev = capi.gpu_lib().ldb_gpu_device_count() if hasattr(capi.gpu_lib(), "ldb_gpu_device_count") else 1
+    dev = (int(os.environ.get("LOCAL_RANK", rank)) % max(n_dev, 1)) if transport == "shm" else int(os.environ.get("LOCAL_RANK", rank))
     n_orders = int(os.environ.get("LDB_CHECK_ORDERS", "150003"))  # enough orders for Q18's HAVING to keep some
-    queries = [int(q) for q in os.environ.get("LDB_CHECK_QUERIES", "1,6,3,4,12,18,9,5,7,11,14,8").split(",")]
+    queries = [int(q) for q in os.environ.get("LDB_CHECK_QUERIES", ",".join(str(q) for q in range(1, 23))).split(",")]
     ctx = ldb.Context(dev)
-    db = tpch_plans.Database(ctx, n_orders, rank, world, queries, False)
-    runner = tpch_plans.Runner(ctx, db, world, dist, torch)
-    if backend == "nccl":  # the exchange inside the library (RCCL); torch.distributed only carries the communicator id
-        from lingodb_amd import api
-
-        def exchange_id(ident):
-            box = [ident]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-
-        runner.comm = api.Comm(ctx, rank, world, exchange_id)
-    got = {q: runner.run(q).to_arrow() for q in queries}
+    capi.gpu_lib().ldb_gpu_set_option(b"comm_timeout_ms", 60000)
+    comm = api.Comm(ctx, rank, world, file_exchange(os.environ["LDB_ID_FILE"], rank), transport=transport)
+    db = tpch_plans.Database(ctx, n_orders, rank, world, queries, bool(int(os.environ.get("LDB_CHECK_NARROW", "0"))))
+    runner = tpch_plans.Runner(ctx, db, world, None, None, comm=comm)
     ok = True
+    got = {}
+    for q in queries:
+        got[q] = runner.run(q).to_arrow()
     if rank == 0:
-        full = tpch_plans.Database(ctx, n_orders, 0, 1, queries, False)
-        single = tpch_plans.Runner(ctx, full, 1, None, torch)
+        full = tpch_plans.Database(ctx, n_orders, 0, 1, queries, bool(int(os.environ.get("LDB_CHECK_NARROW", "0"))))
+        single = tpch_plans.Runner(ctx, full, 1, None, None)
         for q in queries:
             want = single.run(q).to_arrow()
-            # positional rows: the interpreted single-GPU plans name their columns after the SQL text, the sharded plan pieces do not
-            va = list(zip(*[c.to_pylist() for c in got[q].columns])) if got[q].num_columns else []
-            vb = list(zip(*[c.to_pylist() for c in want.columns])) if want.num_columns else []
-            a, b = va, vb
-            if q == 3:  # ORDER BY revenue desc, o_orderdate: ties beyond the keys are unspecified
-                same = [(r[1], r[2]) for r in va] == [(r[1], r[2]) for r in vb]
-            elif q == 18:  # ORDER BY o_totalprice desc, o_orderdate
-                same = [(r[4], r[3]) for r in va] == [(r[4], r[3]) for r in vb] and sorted(map(repr, va)) == sorted(map(repr, vb)) and len(va) > 0
-            elif q == 10:  # ORDER BY revenue desc only
-                same = [r[2] for r in va] == [r[2] for r in vb] and sorted(map(repr, va)) == sorted(map(repr, vb)) and len(va) == 20
-            elif q == 11:  # ORDER BY value desc only
-                same = [r[1] for r in va] == [r[1] for r in vb] and sorted(va) == sorted(vb) and len(va) > 0
-            else:
-                same = va == vb
-            print(f"[dist-check] Q{q}: {'OK' if same else 'MISMATCH'} ({len(a)} rows, world={world}, backend={backend})", flush=True)
+            va, vb = rows_of(got[q]), rows_of(want)
+            same = same_result(q, va, vb) and (len(vb) > 0 or q in (15,))
+            print(f"[dist-check] Q{q}: {'OK' if same else 'MISMATCH'} ({len(va)} rows, world={world}, transport={comm.transport})", flush=True)
             if not same:
-                print(a[:3], b[:3], flush=True)
+                print("   sharded:", va[:3], "\n   single: ", vb[:3], flush=True)
             ok = ok and same
-    # NULLs survive the exchange (a shard whose keyless partial SUM saw no row sends a NULL, not a 0)
-    import pyarrow as pa
-    import tpch_dist
+    # the exchange itself on ragged inputs: strings, NULLs, a narrow (8-byte) decimal key next to a 16-byte aggregate, empty ranks
+    import decimal
 
-    mine = pa.table({"v": pa.array([None] if rank == 0 else [10 * rank], pa.int64()), "w": pa.array([rank], pa.int32())})
-    allv = tpch_dist.replicate(runner, ctx.register("nulls_%d" % rank, mine), "nulls_all").to_arrow()
-    same = allv.column(0).to_pylist() == [None] + [10 * r for r in range(1, world)] and allv.column(1).to_pylist() == list(range(world))
+    import pyarrow as pa
+
+    n_mine = 0 if rank == 1 else 3 + rank
+    mine = pa.table({"k": pa.array([rank * 10 + i for i in range(n_mine)], pa.int32()),
+                     "s": pa.array([None if i == 1 else "r%d-%s" % (rank, "x" * (i * 5)) for i in range(n_mine)], pa.string()),
+                     "d": pa.array([decimal.Decimal(rank * 100 + i) / 100 for i in range(n_mine)], pa.decimal128(12, 2)),
+                     "v": pa.array([None if (rank + i) % 3 == 0 else rank * 1000 + i for i in range(n_mine)], pa.int64())})
+    t = ctx.register("x_%d" % rank, mine, True)  # narrow: d is 8 bytes wide on the device
+    mixed = ctx.run_plan('{"steps": [{"op": "groupby", "in": "t", "keys": ["k"], "aggs": [{"fn": "sum", "expr": "d", "as": "dsum"}], "est_groups": 8, "key_names": ["gk"], "out": "g"},'
+                         ' {"op": "join_build", "in": "g", "keys": ["gk"], "unique": true, "out": "h"}, {"op": "join_probe", "ht": "h", "in": "t", "keys": ["k"], "out": "j"},'
+                         ' {"op": "materialize", "in": "j", "cols": ["k", "d", "s", "v", "dsum"], "out": "result"}], "result": "result"}', {"t": t})  # d: 8 bytes, dsum: 16 bytes
+    assert mixed.col_width(1) == 8 and mixed.col_width(4) == 16, (mixed.col_width(1), mixed.col_width(4))
+    allv = comm.allgather(mixed, "mixed_all").to_arrow()
+    want_rows = []
+    for r in range(world):
+        nr = 0 if r == 1 else 3 + r
+        for i in range(nr):
+            d = decimal.Decimal(r * 100 + i) / 100
+            want_rows.append((r * 10 + i, d, None if i == 1 else "r%d-%s" % (r, "x" * (i * 5)), None if (r + i) % 3 == 0 else r * 1000 + i, d))
+    same = rows_of(allv) == want_rows
     if rank == 0:
-        print(f"[dist-check] NULL exchange: {'OK' if same else 'MISMATCH'} {allv.column(0).to_pylist()}", flush=True)
+        print(f"[dist-check] mixed-width / string / NULL all-gather: {'OK' if same else 'MISMATCH'}", flush=True)
+        if not same:
+            print(rows_of(allv)[:4], want_rows[:4], flush=True)
     ok = ok and same
-    flag = torch.tensor([1 if ok else 0], device="cuda" if backend == "nccl" else "cpu")
-    dist.broadcast(flag, 0)
-    dist.barrier()
-    dist.destroy_process_group()
-    sys.exit(0 if int(flag.item()) else 1)
+    # hash shuffle: afterwards equal keys are on one rank and nothing is lost
+    sh = comm.shuffle(mixed.rel(), [(0, 0)], [(0, 0), (0, 2)], "shuffled").to_arrow()
+    keys_here = sh.column(0).to_pylist()
+    cnt = ctx.register("cnt_%d" % rank, pa.table({"n": pa.array([len(keys_here)], pa.int64()), "k": pa.array([",".join(map(str, sorted(keys_here)))], pa.string())}))
+    allc = comm.allgather(cnt, "cnt_all").to_arrow()
+    sets = [set(map(int, s.split(","))) if s else set() for s in allc.column(1).to_pylist()]
+    same = sum(allc.column(0).to_pylist()) == len(want_rows) and all(not (sets[a] & sets[b]) for a in range(world) for b in range(a + 1, world))
+    if rank == 0:
+        print(f"[dist-check] hash shuffle: {'OK' if same else 'MISMATCH'} {allc.column(0).to_pylist()}", flush=True)
+    ok = ok and same
+    comm.close()
+    ctx.close()
+    sys.exit(0 if ok else 1)
 
 
 if __name__ == "__main__":

@@ -16,9 +16,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def comm(ctx):
-    c = api.Comm(ctx, 0, 1, lambda ident: ident)
+@pytest.fixture(scope="module", params=["rccl", "shm"])
+def comm(ctx, request):
+    """one rank over either transport: RCCL (a send to self inside the grouped batch) or the host-staged one"""
+    c = api.Comm(ctx, 0, 1, lambda ident: ident, transport=request.param)
+    assert c.transport == request.param
     yield c
     c.close()
 
@@ -59,10 +61,12 @@ def test_sharded_plans_over_rccl_two_gpus():
 
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs: the first multi-GPU box runs the sharded plans over the in-library RCCL exchange")
-    from test_gpu_dist import _free_port
+    import tempfile
 
-    env = dict(os.environ, LDB_DIST_BACKEND="nccl", LDB_CHECK_QUERIES="1,3,6,9,10,11")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dist_gpu_check.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, WORLD_SIZE="2", LDB_ID_FILE=os.path.join(tmp, "comm.id"), LDB_CHECK_TRANSPORT="rccl")
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_check.py")], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+        outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert outs[0].count(": OK") == 22 + 2, outs[0]

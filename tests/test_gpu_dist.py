@@ -1,10 +1,11 @@
-"""N>1 path on the GPU box: the sharded plans + exchange (tpch_dist.py) must reproduce the
-single-GPU results bit-exactly.  The box has ONE GPU, so the two ranks share it and the
-collectives run over gloo (host-staged); on a multi-GPU node the same script runs over RCCL."""
+"""N > 1 on the GPU box: all 22 sharded plans + the in-library exchange must reproduce the single-GPU results
+bit-exactly.  The box has ONE GPU, so the ranks share it and the exchange runs over the library's host-staged
+transport (comm_transport = 1); every other line of the exchange — metadata all-to-all, displacements, offset
+and bitmap rebuild — is the code RCCL runs under on a multi-GPU node."""
 import os
-import socket
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -12,19 +13,47 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def run_ranks(world, extra_env=None, timeout=900):
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, WORLD_SIZE=str(world), LDB_ID_FILE=os.path.join(tmp, "comm.id"), LDB_CHECK_TRANSPORT="shm", **(extra_env or {}))
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_check.py")], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        outs = []
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=timeout)[0])
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+        return [p.returncode for p in procs], outs
 
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_plans_match_single_gpu(world):
-    env = dict(os.environ, LDB_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_check.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("OK") == 13, r.stdout  # 12 queries + the NULL exchange
+    codes, outs = run_ranks(world)
+    assert all(c == 0 for c in codes), "\n".join(o[-3000:] for o in outs)
+    assert outs[0].count(": OK") == 22 + 2, outs[0]
+
+
+def test_sharded_plans_with_narrow_decimals():
+    """--narrow-decimals: 8-byte decimal columns next to the 16-byte aggregates group-by produces"""
+    codes, outs = run_ranks(2, {"LDB_CHECK_NARROW": "1", "LDB_CHECK_QUERIES": "1,3,10,15,18,11"})
+    assert all(c == 0 for c in codes), "\n".join(o[-3000:] for o in outs)
+    assert outs[0].count(": OK") == 6 + 2, outs[0]
+
+
+def test_sharded_plans_on_one_rank_equal_the_single_gpu_plans():
+    """the sharded plan text without a communicator (allgather = copy, shuffle = materialize)"""
+    sys.path.insert(0, ROOT)
+    import lingodb_amd as ldb
+    import tpch_plans
+    from dist_gpu_check import rows_of, same_result
+
+    ctx = ldb.Context(0)
+    queries = list(range(1, 23))
+    db = tpch_plans.Database(ctx, 30002, 0, 1, queries, False)
+    a, b = tpch_plans.Runner(ctx, db, 1, None, None, force_dist=True), tpch_plans.Runner(ctx, db, 1, None, None)
+    for q in queries:
+        assert same_result(q, rows_of(a.run(q).to_arrow()), rows_of(b.run(q).to_arrow())), q
+    ctx.close()

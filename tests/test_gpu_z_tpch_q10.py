@@ -13,7 +13,6 @@ import pytest
 
 import tpch_data
 from test_gpu_tpch_more import days, np_col, result_rows
-from test_gpu_dist import _free_port
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -78,12 +77,3 @@ def test_load_ipc_file(ctx, tmp_path):
             w.write_batch(b)
     dev = ctx.load_ipc("orders_ipc", path)
     assert dev.rows == t.num_rows and result_rows(dev.to_arrow()) == result_rows(t)
-
-
-def test_q10_q15_sharded_match_single_gpu():
-    env = dict(os.environ, LDB_DIST_BACKEND="gloo", LDB_CHECK_QUERIES="10,15")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_gpu_check.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("OK") == 3, r.stdout  # Q10, Q15 + the NULL exchange

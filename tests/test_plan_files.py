@@ -54,6 +54,9 @@ def test_structure_check_names_what_is_wrong():
         ('{"inputs": ["u"], "steps": [], "result": "u"}', "not provided"),
         ('{"steps": [{"op": "map", "in": "t", "as": "c", "out": "m"}], "result": "m"}', "expr"),
         ('{"steps": ' + "[" * 100 + "]" * 100 + ', "result": "x"}', "nesting"),
+        ('{"steps": [], "result": "x\\', "unterminated escape"),  # a text ending inside an escape must not be read past its end
+        ('{"steps": [], "result": "\\u12G4"}', "four hex digits"),
+        ('{"steps": [], "result": "\\u12', "four hex digits"),
     ]
     for text, needle in cases:
         st, err = _check(text, ["t"])
@@ -91,3 +94,50 @@ def test_database_generates_every_column_a_plan_names():
             if table not in provided:
                 continue
             assert col in provided[table][2], (q, col, sorted(provided[table][2]))
+
+
+# ---------------------------------------------------------------- the sharded plans (plans/tpch/dist)
+DIST_OPS = STEP_OPS | {"allgather", "shuffle"}
+
+
+def _dist_plan(q):
+    with open(os.path.join(ROOT, "lingo-db_amd", "plans", "tpch", "dist", "q%d.json" % q)) as f:
+        text = f.read()
+    return text, json.loads(text)
+
+
+def test_every_query_has_a_sharded_plan_with_an_exchange():
+    """all 22 queries are sharded as DATA: each plan has at least one exchange step, only reads inputs the runner
+    provides (the query's tables + the replicated dimension tables it declares), and passes the structure check"""
+    for q in range(1, 23):
+        text, plan = _dist_plan(q)
+        assert plan["ref"] == "resources/sql/tpch/%d.sql" % q
+        ops = [s["op"] for s in plan["steps"]]
+        assert set(ops) <= DIST_OPS and ("allgather" in ops or "shuffle" in ops), (q, ops)
+        rep = plan.get("replicated_inputs", {})
+        assert set(plan["inputs"]) <= set(tpch_plans.JSON_PLANS[q]) | set(rep), (q, plan["inputs"])
+        for name, spec in rep.items():
+            assert spec["table"] in tpch_plans.JSON_PLANS[q], (q, name, spec)
+        st, err = _check(text, sorted(plan["inputs"]))
+        assert st == 0, (q, err)
+
+
+def test_sharded_plans_are_what_the_generator_writes():
+    """tools/write_tpch_dist_plans.py derives the sharded plans from the single-GPU ones: the committed files are its output"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("write_tpch_dist_plans", os.path.join(ROOT, "tools", "write_tpch_dist_plans.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for q in range(1, 23):
+        _, plan = _dist_plan(q)
+        assert plan["steps"] == json.loads(json.dumps(mod.PLANS[q]["steps"])), q
+
+
+def test_exchange_steps_are_checked():
+    ok = '{"steps": [{"op": "materialize", "in": "t", "cols": ["a"], "out": "m"}, {"op": "allgather", "in": "m", "out": "g"}, {"op": "shuffle", "in": "g", "keys": ["a"], "cols": ["a"], "out": "r"}], "result": "r"}'
+    assert _check(ok, ["t"])[0] == 0
+    st, err = _check('{"steps": [{"op": "shuffle", "in": "t", "cols": ["a"], "out": "r"}], "result": "r"}', ["t"])
+    assert st != 0 and "keys" in err
+    st, err = _check('{"steps": [{"op": "allgather", "in": "nope", "out": "r"}], "result": "r"}', ["t"])
+    assert st != 0 and "before it exists" in err

@@ -155,32 +155,60 @@ class Database:
 
 
 class Runner:
-    def __init__(self, ctx, db, world, dist, torch):
+    """Runs TPC-H query q as data: the single-GPU plan lingo-db_amd/plans/tpch/qN.json, or — with a communicator
+    (world > 1) or dist=True — the sharded plan plans/tpch/dist/qN.json, whose allgather / shuffle steps go
+    through the library's exchange (ldb_plan_run_json_comm)."""
+
+    def __init__(self, ctx, db, world, dist, torch, comm=None, force_dist=False):
         self.ctx, self.db, self.world, self.dist, self.torch = ctx, db, world, dist, torch
+        self.comm = comm  # api.Comm or None
+        self.force_dist = force_dist
         self.last = {}
-        self.cache = {}  # replicated dimension tables (multi-GPU plans)
+        self.cache = {}  # replicated dimension tables of the sharded plans: all-gathered once per database
+        self.plans = {}
+        self.meta = {}
+
+    def sharded(self):
+        return self.world > 1 or self.force_dist
 
     def run(self, q):
-        if self.world > 1:
-            import tpch_dist
-
-            res = tpch_dist.run_query(self, q)
-        elif q in JSON_PLANS:
-            res = self.ctx.run_plan(self.plan_text(q), self.plan_inputs(q))
-        else:
-            raise ValueError(f"TPC-H Q{q} has no plan yet")
+        if q not in JSON_PLANS:
+            raise ValueError(f"TPC-H Q{q} has no plan")
+        if self.world > 1 and self.comm is None:
+            raise RuntimeError("world > 1 needs a communicator (api.Comm)")
+        res = self.ctx.run_plan(self.plan_text(q), self.plan_inputs(q), comm=self.comm)
         self.last[q] = res
         return res
 
     def plan_inputs(self, q):
-        return {name: getattr(self.db, attr) for name, attr in JSON_PLANS[q].items()}
+        inputs = {name: getattr(self.db, attr) for name, attr in JSON_PLANS[q].items()}
+        if self.sharded():
+            self.plan_text(q)
+            for name, spec in self.meta[q].get("replicated_inputs", {}).items():
+                key = (name, spec["table"], tuple(spec.get("cols", ())))
+                if key not in self.cache:  # a static dimension table: one all-gather per database, itself a (one- or two-step) plan
+                    steps = []
+                    src = "t"
+                    if spec.get("cols"):
+                        steps.append({"op": "materialize", "in": "t", "cols": spec["cols"], "out": "m"})
+                        src = "m"
+                    steps.append({"op": "allgather", "in": src, "out": "result"})
+                    import json
+
+                    self.cache[key] = self.ctx.run_plan(json.dumps({"name": "replicate_" + name, "inputs": ["t"], "steps": steps, "result": "result"}),
+                                                        {"t": inputs[spec["table"]]}, comm=self.comm)
+                inputs[name] = self.cache[key]
+            inputs = {n: t for n, t in inputs.items() if n in self.meta[q]["inputs"]}
+        return inputs
 
     def plan_text(self, q):
-        if not hasattr(self, "plans"):
-            self.plans = {}
         if q not in self.plans:
-            with open(os.path.join(ROOT, "lingo-db_amd", "plans", "tpch", "q%d.json" % q)) as f:
+            sub = ("dist", "q%d.json" % q) if self.sharded() else ("q%d.json" % q,)
+            with open(os.path.join(ROOT, "lingo-db_amd", "plans", "tpch", *sub)) as f:
                 self.plans[q] = f.read()
+            import json
+
+            self.meta[q] = json.loads(self.plans[q])
         return self.plans[q]
 
     def probe_microbench(self, reps=3):
