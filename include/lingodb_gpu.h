@@ -136,6 +136,9 @@ int32_t ldb_gpu_timer_elapsed_ms(ldb_ctx* ctx, int32_t timer_id, float* ms); /* 
 int32_t ldb_gpu_prof_enable(ldb_ctx* ctx, int32_t on);
 int32_t ldb_gpu_prof_reset(ldb_ctx* ctx);
 int32_t ldb_gpu_prof_get(ldb_ctx* ctx, const char* kernel_name, int64_t* launches, double* total_ms);
+/* the longest single launch of that kernel since the last reset (the roofline of an operator that launches one
+ * kernel on inputs of very different size is priced on its LARGEST launch, not on the average) */
+int32_t ldb_gpu_prof_get_max(ldb_ctx* ctx, const char* kernel_name, double* max_ms);
 /* names of all kernels seen so far, '\n'-separated, into buf */
 int32_t ldb_gpu_prof_names(ldb_ctx* ctx, char* buf, int32_t cap);
 /* Trace marker: launches the empty kernel `k_ldb_marker` with a grid of `id` (1 … 65535)
@@ -416,7 +419,14 @@ typedef enum {
     * least one (SEMI_BUILD) / no (ANTI_BUILD) matching probe row, in ascending build order — the
     * reference's reverseSides scheme (translateHJWithMarker, RelAlgToSubOp.cpp:1248-1287) */
    LDB_JOIN_SEMI_BUILD = 6,
-   LDB_JOIN_ANTI_BUILD = 7
+   LDB_JOIN_ANTI_BUILD = 7,
+   /* outer joins that (also) keep the BUILD side's unmatched rows — the reference's HashMultiMap whose entries carry a
+    * marker set by matching probe tuples and scanned afterwards (include/lingodb/runtime/HashMultiMap.h:6-35,
+    * OuterJoinLowering / FullOuterJoinLowering with reverseSides, RelAlgToSubOp.cpp:1217-1294, 1446-1527): the result is
+    * the INNER (RIGHT_OUTER) / LEFT_OUTER (FULL_OUTER) pairs followed by the build rows no probe row matched, their
+    * probe sides padded with LDB_NULL_ROW */
+   LDB_JOIN_RIGHT_OUTER = 8,
+   LDB_JOIN_FULL_OUTER = 9
 } ldb_join_kind;
 
 /* Replaces GrowingBuffer::insert materialisation + HashIndexedView::build
@@ -474,6 +484,34 @@ int32_t ldb_gpu_topk(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, int3
 int32_t ldb_gpu_partition(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* keys, int32_t n_keys, int32_t nparts,
                           const ldb_colref* cols, int32_t n_cols, ldb_table** out, int64_t* counts);
 
+/* ------------------------------------------------------------------ set operations, window functions */
+/* Replaces UnionAllLowering / UnionDistinctLowering / CountingSetOperationLowering
+ * (src/compiler/Conversion/RelAlgToSubOp/RelAlgToSubOp.cpp:622-930): the reference keeps a map keyed by ALL columns with
+ * one i64 counter per input and emits per key one row (distinct semantics: UNION; INTERSECT needs both counters > 0,
+ * EXCEPT the left > 0 and the right = 0) or min(c1, c2) / max(c1 - c2, 0) rows (INTERSECT ALL / EXCEPT ALL).  NULLs
+ * compare equal (the lowering's `isa` compare block).  The two column lists must have pairwise equal types (the
+ * frontend inserts the casts).  Output: a table with the left input's column names; row order unspecified. */
+typedef enum { LDB_SET_UNION_ALL = 0, LDB_SET_UNION = 1, LDB_SET_INTERSECT = 2, LDB_SET_INTERSECT_ALL = 3, LDB_SET_EXCEPT = 4, LDB_SET_EXCEPT_ALL = 5 } ldb_set_op;
+int32_t ldb_gpu_set_op(ldb_ctx* ctx, ldb_rel* left, const ldb_colref* left_cols, ldb_rel* right, const ldb_colref* right_cols, int32_t n_cols, int32_t op, ldb_table** out);
+
+/* Replaces WindowLowering (RelAlgToSubOp.cpp:2193-2553) with its SegmentTreeView (include/lingodb/runtime/SegmentTreeView.h:11-43):
+ * rows are ordered by (PARTITION BY keys, ORDER BY keys); the frame of a row is ROWS BETWEEN frame_from AND frame_to as
+ * offsets from the current row (negative = preceding, 0 = current row, LDB_FRAME_UNBOUNDED_* = partition begin / end),
+ * each end clamped into the partition (OffsetReferenceByLowering, SubOpToControlFlow.cpp:3860-3885 — so a frame is never
+ * empty).  LDB_WIN_RANK = entries between the frame begin and the current row + 1 (RankWindowFunc :2043-2058; row-number
+ * semantics, as in the reference); SUM / MIN / MAX (NULL when the frame holds only NULLs) / COUNT (non-NULL values) /
+ * COUNT_STAR over the frame.  Output: *out_rel = the input's rows in window order, *out_cols = one column per function
+ * aligned with it (attach it with ldb_gpu_rel_zip).  Integer / decimal / date argument columns. */
+typedef enum { LDB_WIN_RANK = 0, LDB_WIN_SUM = 1, LDB_WIN_MIN = 2, LDB_WIN_MAX = 3, LDB_WIN_COUNT = 4, LDB_WIN_COUNT_STAR = 5 } ldb_window_fn_kind;
+typedef struct {
+   int32_t fn; /* ldb_window_fn_kind */
+   ldb_colref col; /* argument (ignored by RANK / COUNT_STAR) */
+} ldb_window_fn;
+#define LDB_FRAME_UNBOUNDED_PRECEDING INT64_MIN
+#define LDB_FRAME_UNBOUNDED_FOLLOWING INT64_MAX
+int32_t ldb_gpu_window(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* part_keys, int32_t n_part, const ldb_sort_spec* order, int32_t n_order, int64_t frame_from, int64_t frame_to,
+                       const ldb_window_fn* fns, int32_t n_fns, ldb_rel** out_rel, ldb_table** out_cols);
+
 /* The exchange itself: one rank (= one ldb_ctx) per GPU.  Rank 0 makes a 128-byte id, the host process hands
  * it to every rank by whatever channel it has (the LingoDB side: its session layer; bench.py:
  * torch.distributed; the tests: a file), and every rank joins with ldb_gpu_comm_create.  Two transports
@@ -488,6 +526,7 @@ int32_t ldb_gpu_partition(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* keys, int
  * The reference has no counterpart (single process: src/runtime/GPU/CUDA/CMakeLists.txt:9 "we do not support
  * multi-gpu"); SURVEY §8(e) assigns the design to this library. */
 typedef struct ldb_comm ldb_comm;
+int32_t ldb_gpu_comm_available(void); /* 1 = librccl is loadable in this process (transport 0 can work) */
 int32_t ldb_gpu_comm_unique_id(void* id128);
 int32_t ldb_gpu_comm_create(ldb_ctx* ctx, int32_t rank, int32_t world, const void* id128, ldb_comm** out);
 int32_t ldb_gpu_comm_destroy(ldb_comm* comm);

@@ -324,6 +324,8 @@ extern "C" int32_t ldb_gpu_comm_unique_id(void* id128) {
    memcpy(id128, &id, sizeof(id));
    return LDB_OK;
 }
+// 1 when librccl can be loaded in this process (a cheap probe every rank runs BEFORE any of them waits for an id)
+extern "C" int32_t ldb_gpu_comm_available(void) { return rccl().ok ? 1 : 0; }
 extern "C" int32_t ldb_gpu_comm_create(ldb_ctx* ctx, int32_t rank, int32_t world, const void* id128, ldb_comm** out) {
    if (!ctx || !id128 || !out || world < 1 || rank < 0 || rank >= world) LDB_FAIL(LDB_ERR_INVALID, "comm_create: bad argument");
    LDB_HIP(hipSetDevice(ctx->device));

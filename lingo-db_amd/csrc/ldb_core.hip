@@ -276,11 +276,12 @@ static void prof_fold(ldb_ctx* ctx) {
          for (auto& x : ctx->prof_totals)
             if (x.name == p.name) t = &x;
          if (!t) {
-            ctx->prof_totals.push_back({p.name, 0, 0});
+            ctx->prof_totals.push_back({p.name, 0, 0, 0});
             t = &ctx->prof_totals.back();
          }
          t->launches++;
          t->ms += ms;
+         if (ms > t->max_ms) t->max_ms = ms;
       }
       ctx->prof_free.push_back(p.start);
       ctx->prof_free.push_back(p.stop);
@@ -309,6 +310,14 @@ extern "C" int32_t ldb_gpu_prof_get(ldb_ctx* ctx, const char* kernel_name, int64
          if (launches) *launches = x.launches;
          if (total_ms) *total_ms = x.ms;
       }
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_prof_get_max(ldb_ctx* ctx, const char* kernel_name, double* max_ms) {
+   if (!ctx || !kernel_name || !max_ms) LDB_FAIL(LDB_ERR_INVALID, "prof_get_max: NULL argument");
+   prof_fold(ctx);
+   *max_ms = 0;
+   for (auto& x : ctx->prof_totals)
+      if (x.name == kernel_name) *max_ms = x.max_ms;
    return LDB_OK;
 }
 extern "C" int32_t ldb_gpu_prof_names(ldb_ctx* ctx, char* buf, int32_t cap) {

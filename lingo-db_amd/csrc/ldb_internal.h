@@ -68,6 +68,7 @@ struct ldb_prof_total {
    std::string name;
    int64_t launches = 0;
    double ms = 0;
+   double max_ms = 0; // the longest single launch (an operator may launch the same kernel on inputs of very different size)
 };
 #define LDB_RING_BYTES ((size_t) 1 << 20)
 struct ldb_ctx {

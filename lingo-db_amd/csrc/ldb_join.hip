@@ -184,6 +184,12 @@ __global__ void k_compose_null(const uint32_t* __restrict__ ids, const uint32_t*
    }
 }
 
+// first[0, na) then second[0, nb) (identity when NULL), or na rows followed by nb NULL rows (pad_nulls)
+__global__ void k_concat_rowids(const uint32_t* __restrict__ first, uint64_t na, const uint32_t* __restrict__ second, uint64_t nb, int pad_nulls, uint32_t* __restrict__ out) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < na + nb; i += (uint64_t) gridDim.x * blockDim.x)
+      out[i] = i < na ? (first ? first[i] : (uint32_t) i) : (pad_nulls ? LDB_NULL_ROW : (second ? second[i - na] : (uint32_t) (i - na)));
+}
+
 // debug_check option: largest row id of a selection vector (LDB_NULL_ROW ignored)
 __global__ void k_max_rowid(const uint32_t* __restrict__ ids, uint64_t n, unsigned int* __restrict__ out) {
    unsigned int mx = 0;
@@ -656,7 +662,39 @@ extern "C" int32_t ldb_gpu_join_probe_residual(ldb_ctx* ctx, ldb_hashtable* ht, 
 static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind, const ldb_join_residual* resid, int32_t n_resid,
                           ldb_rel** out, ldb_table** mark_out, bool radix_ok) {
    if (!ctx || !ht || !probe || !out) LDB_FAIL(LDB_ERR_INVALID, "join_probe: NULL argument");
-   if (kind < LDB_JOIN_INNER || kind > LDB_JOIN_ANTI_BUILD) LDB_FAIL(LDB_ERR_INVALID, "join_probe: bad kind %d", kind);
+   if (kind < LDB_JOIN_INNER || kind > LDB_JOIN_FULL_OUTER) LDB_FAIL(LDB_ERR_INVALID, "join_probe: bad kind %d", kind);
+   if (kind == LDB_JOIN_RIGHT_OUTER || kind == LDB_JOIN_FULL_OUTER) {
+      // the pairs of the inner / left-outer join, then the build rows whose marker no probe tuple set (the reference
+      // scans its HashMultiMap for unmarked entries after the probe pipeline, translateHJWithMarker)
+      struct RelHold {
+         ldb_ctx* ctx;
+         ldb_rel* r = nullptr;
+         ~RelHold() {
+            if (r) ldb_gpu_rel_release(ctx, r);
+         }
+      } pairs{ctx}, unm{ctx};
+      LDB_TRY(probe_impl(ctx, ht, probe, keys, n_keys, kind == LDB_JOIN_RIGHT_OUTER ? LDB_JOIN_INNER : LDB_JOIN_LEFT_OUTER, resid, n_resid, &pairs.r, nullptr, radix_ok));
+      LDB_TRY(probe_impl(ctx, ht, probe, keys, n_keys, LDB_JOIN_ANTI_BUILD, resid, n_resid, &unm.r, nullptr, radix_ok));
+      const int64_t n1 = pairs.r->n_rows, n2 = unm.r->n_rows, nn = n1 + n2;
+      if (nn >= (int64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: %ld result rows exceed uint32 row ids", (long) nn);
+      const size_t np = probe->sides.size(), nb = ht->build->sides.size();
+      if (pairs.r->sides.size() != np + nb || unm.r->sides.size() != nb) LDB_FAIL(LDB_ERR_INVALID, "join_probe: outer join pieces do not line up");
+      ldb_rel* r = ldb_rel_new(ctx);
+      r->n_rows = nn;
+      const int cg = ldb_grid_for(ctx, nn, 256, 8);
+      for (size_t j = 0; j < np + nb; j++) {
+         const ldb_rel_side& a = pairs.r->sides[j];
+         ldb_rel_side ns{a.table, nullptr, true, true};
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &ns.rowids, 4 * (size_t) (nn ? nn : 1)));
+         const uint32_t* tail = j >= np ? unm.r->sides[j - np].rowids : nullptr;
+         if (nn) hipLaunchKernelGGL(k_concat_rowids, dim3(cg), dim3(256), 0, ctx->stream, (const uint32_t*) a.rowids, (uint64_t) n1, tail, (uint64_t) n2, j < np ? 1 : 0, ns.rowids);
+         if (j >= np) ns.may_null = a.may_null || unm.r->sides[j - np].may_null;
+         r->sides.push_back(ns);
+      }
+      LDB_HIP(hipGetLastError());
+      *out = r;
+      return LDB_OK;
+   }
    if (radix_ok) {
       RadixProbe rp;
       LDB_TRY(radix_prepare(ctx, ht, probe, keys, n_keys, kind, rp));

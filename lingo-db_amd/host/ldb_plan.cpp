@@ -842,7 +842,8 @@ struct Interp {
          ldb_rel* in = relOf(st.s("in"), &sides);
          auto keys = cols(*sides, st.at("keys"), "join_probe");
          static const std::map<std::string, int32_t> kinds = {{"inner", LDB_JOIN_INNER}, {"semi", LDB_JOIN_SEMI}, {"anti", LDB_JOIN_ANTI}, {"left_outer", LDB_JOIN_LEFT_OUTER},
-                                                             {"mark", LDB_JOIN_MARK},   {"single", LDB_JOIN_SINGLE}, {"semi_build", LDB_JOIN_SEMI_BUILD}, {"anti_build", LDB_JOIN_ANTI_BUILD}};
+                                                             {"mark", LDB_JOIN_MARK},   {"single", LDB_JOIN_SINGLE}, {"semi_build", LDB_JOIN_SEMI_BUILD}, {"anti_build", LDB_JOIN_ANTI_BUILD},
+                                                             {"right_outer", LDB_JOIN_RIGHT_OUTER}, {"full_outer", LDB_JOIN_FULL_OUTER}};
          auto kit = kinds.find(st.sOr("kind", "inner"));
          if (kit == kinds.end()) throw std::runtime_error("join_probe: unknown kind");
          const int32_t kind = kit->second;
@@ -857,7 +858,8 @@ struct Interp {
             outSides = ht.sides;
          } else {
             outSides = *sides;
-            if (kind == LDB_JOIN_INNER || kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE) outSides.insert(outSides.end(), ht.sides.begin(), ht.sides.end());
+            if (kind == LDB_JOIN_INNER || kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE || kind == LDB_JOIN_RIGHT_OUTER || kind == LDB_JOIN_FULL_OUTER)
+               outSides.insert(outSides.end(), ht.sides.begin(), ht.sides.end());
          }
          putRel(st.s("out"), r, std::move(outSides));
          if (mark) {

@@ -360,6 +360,28 @@ class Rel:
         check(self.ctx.lib.ldb_gpu_sort(self.ctx.h, self.h, arr, len(specs), C.byref(r)))
         return Rel(self.ctx, r, self.deps)
 
+    def set_op(self, other, op, cols=None, other_cols=None):
+        """UNION [ALL] / INTERSECT [ALL] / EXCEPT [ALL] of the listed columns (default: all columns of side 0) → Table"""
+        n = self.deps[0].n_cols if cols is None else len(cols)
+        a, na = _refs(cols if cols is not None else [(0, c) for c in range(n)])
+        b, nb = _refs(other_cols if other_cols is not None else (cols if cols is not None else [(0, c) for c in range(n)]))
+        assert na == nb
+        t = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_set_op(self.ctx.h, self.h, a, other.h, b, na, op, C.byref(t)))
+        return Table(self.ctx, t)
+
+    def window(self, part_keys, order, fns, frame=(capi.FRAME_UNBOUNDED_PRECEDING, 0)):
+        """fns: [(capi.WIN_*, (side, col) | None)] → (rows in window order: Rel, one column per function: Table)"""
+        pk, npk = _refs(part_keys)
+        oarr = (SortSpec * max(len(order), 1))(*order)
+        farr = (capi.WindowFn * len(fns))()
+        for i, (fn, col) in enumerate(fns):
+            farr[i].fn = fn
+            farr[i].col = colref(*(col if col is not None else (0, 0)))
+        r, t = C.c_void_p(), C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_window(self.ctx.h, self.h, pk, npk, oarr, len(order), frame[0], frame[1], farr, len(fns), C.byref(r), C.byref(t)))
+        return Rel(self.ctx, r, self.deps), Table(self.ctx, t)
+
     def topk(self, specs, k):
         arr = (SortSpec * len(specs))(*specs)
         r = C.c_void_p()
@@ -530,6 +552,11 @@ class Context:
         n, ms = C.c_int64(), C.c_double()
         check(self.lib.ldb_gpu_prof_get(self.h, name.encode(), C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def prof_max(self, name):
+        ms = C.c_double()
+        check(self.lib.ldb_gpu_prof_get_max(self.h, name.encode(), C.byref(ms)))
+        return ms.value
 
     def prof_all(self):
         buf = C.create_string_buffer(4096)

@@ -29,7 +29,10 @@ RHS_INT, RHS_STRING, RHS_COLUMN, RHS_FLOAT = range(4)
 # ldb_agg_fn
 AGG_SUM, AGG_MIN, AGG_MAX, AGG_COUNT, AGG_COUNT_STAR, AGG_ANY, AGG_AVG = range(7)
 # ldb_join_kind
-JOIN_INNER, JOIN_SEMI, JOIN_ANTI, JOIN_LEFT_OUTER, JOIN_MARK, JOIN_SINGLE, JOIN_SEMI_BUILD, JOIN_ANTI_BUILD = range(8)
+JOIN_INNER, JOIN_SEMI, JOIN_ANTI, JOIN_LEFT_OUTER, JOIN_MARK, JOIN_SINGLE, JOIN_SEMI_BUILD, JOIN_ANTI_BUILD, JOIN_RIGHT_OUTER, JOIN_FULL_OUTER = range(10)
+SET_UNION_ALL, SET_UNION, SET_INTERSECT, SET_INTERSECT_ALL, SET_EXCEPT, SET_EXCEPT_ALL = range(6)
+WIN_RANK, WIN_SUM, WIN_MIN, WIN_MAX, WIN_COUNT, WIN_COUNT_STAR = range(6)
+FRAME_UNBOUNDED_PRECEDING, FRAME_UNBOUNDED_FOLLOWING = -(2 ** 63), 2 ** 63 - 1
 # ldb_scalar_fn
 FN_EXTRACT_YEAR = 0
 
@@ -90,6 +93,10 @@ class AggSpec(C.Structure):
 
 class SortSpec(C.Structure):
     _fields_ = [("col", ColRef), ("descending", C.c_int32), ("reserved", C.c_int32)]
+
+
+class WindowFn(C.Structure):
+    _fields_ = [("fn", C.c_int32), ("col", ColRef)]
 
 
 class JoinResidual(C.Structure):
@@ -157,6 +164,7 @@ GPU_API = {
     "ldb_gpu_like_plan": (i32, [C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "ldb_gpu_prof_reset": (i32, [P]),
     "ldb_gpu_prof_get": (i32, [P, C.c_char_p, C.POINTER(i64), C.POINTER(C.c_double)]),
+    "ldb_gpu_prof_get_max": (i32, [P, C.c_char_p, C.POINTER(C.c_double)]),
     "ldb_gpu_prof_names": (i32, [P, C.c_char_p, i32]),
     "ldb_gpu_jit_stats": (i32, [C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),
     "ldb_gpu_jit_compile_check": (i32, [C.c_char_p, i32]),
@@ -210,7 +218,10 @@ GPU_API = {
     "ldb_gpu_comm_destroy": (i32, [P]),
     "ldb_gpu_comm_rank": (i32, [P]),
     "ldb_gpu_comm_world": (i32, [P]),
+    "ldb_gpu_set_op": (i32, [P, P, C.POINTER(ColRef), P, C.POINTER(ColRef), i32, i32, PP]),
+    "ldb_gpu_window": (i32, [P, P, C.POINTER(ColRef), i32, C.POINTER(SortSpec), i32, i64, i64, C.POINTER(WindowFn), i32, PP, PP]),
     "ldb_gpu_comm_transport": (C.c_char_p, [P]),
+    "ldb_gpu_comm_available": (i32, []),
     "ldb_gpu_comm_create_host": (i32, [i32, i32, P, PP]),
     "ldb_gpu_comm_alltoall_bytes": (i32, [P, P, C.POINTER(C.c_int64), P, C.POINTER(C.c_int64)]),
     "ldb_gpu_allgather": (i32, [P, P, P, C.c_char_p, PP]),

@@ -227,18 +227,19 @@ class Runner:
         n_b, ms_b = prof.get("k_join_build", (0, 0.0))
         n_p, ms_p = prof.get("k_join_probe_count", (0, 0.0))
         rows = db.lineitem.rows
-        out = {"probe_rows": rows, "build_rows": db.orders.rows, "matches": matches, "table_slots": ht.slots, "slot_bytes": 8}
+        out = {"probe_rows": rows, "build_rows": db.orders.rows, "matches": matches, "table_slots": ht.slots, "table_bytes": ht.table_bytes,
+               "slot_bytes": ht.table_bytes // max(ht.slots, 1)}  # 4 = direct-addressed (one word per key value), 8 = open addressing
         if n_p:
             avg = ms_p / n_p
             out["probe_ms"] = round(avg, 4)
             out["probe_grows_per_s"] = round(rows / (avg * 1e-3) / 1e9, 3)
-            # byte models of SURVEY §8(d): key 4 B + slot 8 B algorithmic; 4 B + one 64 B sector per random access
-            out["algorithmic_gbs"] = round(rows * 12 / (avg * 1e-3) / 1e9, 1)  # key 4 B + slot 8 B per probe
+            # byte model of SURVEY §8(d): key 4 B + one table word per probe (the sector-granular figure is the PMC traffic)
+            out["algorithmic_gbs"] = round(rows * (4 + out["slot_bytes"]) / (avg * 1e-3) / 1e9, 1)
         if n_b:
             out["build_ms"] = round(ms_b / n_b, 4)
             out["build_grows_per_s"] = round(db.orders.rows / (ms_b / n_b * 1e-3) / 1e9, 3)
         # unclustered control: the keys of uniformly random orders (same build side, 100 % match) — no
-        # locality between consecutive probe rows, every probe is a random access into the slot array
+        # locality between consecutive probe rows, every probe is a random access into the table
         pk = ctx.tpch_generate(8, db.n_orders, db.rank, db.world, [0])
         ctx.prof_reset()
         for _ in range(reps):
@@ -247,22 +248,7 @@ class Runner:
         if n_p:
             avg = ms_p / n_p
             out["unclustered"] = {"probe_rows": pk.rows, "matches": m2, "probe_ms": round(avg, 4), "probe_grows_per_s": round(pk.rows / (avg * 1e-3) / 1e9, 3),
-                                  "algorithmic_gbs": round(pk.rows * 12 / (avg * 1e-3) / 1e9, 1)}
-            # the same through the radix path (probe side partitioned by slot range first; off by default):
-            # partition passes + probe of the partitioned keys, 256 MB of slots per partition
-            lib = capi.gpu_lib()
-            lib.ldb_gpu_set_option(b"join_radix", 1)
-            lib.ldb_gpu_set_option(b"join_radix_part_bytes", 1 << 28)
-            ht.probe_count(pk.rel(), [(0, 0)])
-            ctx.prof_reset()
-            for _ in range(reps):
-                m3 = ht.probe_count(pk.rel(), [(0, 0)])
-            pr = ctx.prof_all()
-            lib.ldb_gpu_set_option(b"join_radix", 0)
-            tot = sum(pr.get(k, (0, 0.0))[1] for k in ("k_join_probe_count", "k_radix_hist", "k_radix_scatter")) / reps
-            if tot > 0:
-                out["unclustered_radix"] = {"probe_rows": pk.rows, "matches": m3, "probe_ms": round(tot, 4), "probe_grows_per_s": round(pk.rows / (tot * 1e-3) / 1e9, 3),
-                                            "kernels_ms": {k: round(v[1] / reps, 4) for k, v in pr.items()}, "partition_bytes": 1 << 28}
+                                  "algorithmic_gbs": round(pk.rows * (4 + out["slot_bytes"]) / (avg * 1e-3) / 1e9, 1)}
         pk.release()
         ht.release()
         # selective variant: build side filtered to ≈10 % of orders (o_orderdate < 1992-09-01)
@@ -274,7 +260,7 @@ class Runner:
         n_p, ms_p = ctx.prof_all().get("k_join_probe_count", (0, 0.0))
         if n_p:
             avg = ms_p / n_p
-            out["selective"] = {"build_rows": sel.rows, "matches": matches, "table_slots": ht.slots, "probe_ms": round(avg, 4),
+            out["selective"] = {"build_rows": sel.rows, "matches": matches, "table_slots": ht.slots, "slot_bytes": ht.table_bytes // max(ht.slots, 1), "probe_ms": round(avg, 4),
                                 "probe_grows_per_s": round(rows / (avg * 1e-3) / 1e9, 3)}
         ht.release()
         sel.release()
@@ -325,14 +311,30 @@ class Runner:
 
 
 # ---------------------------------------------------------------- CPU baseline (oracle = reported, non-target)
-def cpu_baseline(queries, sample_sf, runs="1+3"):
+def _canon(table):
+    """GPU result rows in the oracle legs' conventions (decimals unscaled, dates as days, char(1) as the int32 of its 4 bytes)"""
+    import pyarrow as pa
+    from test_gpu_tpch_new import result_rows
+
+    rows = result_rows(table)
+    fsb = [i for i in range(table.num_columns) if pa.types.is_fixed_size_binary(table.schema.field(i).type)]
+    if fsb:
+        rows = [tuple(int.from_bytes(v, "little", signed=True) if i in fsb else v for i, v in enumerate(r)) for r in rows]
+    return rows
+
+
+def cpu_baseline(queries, sample_sf, runs="1+3", budget_s=100.0, ctx=None, narrow=False, checks=None):
     """The oracle legs (oracle/tpch_legs.py: the C restatement of the reference's CPU path — morsels of
     20 000 rows, HashIndexedView / PreAggregationHashtable restated — plus numpy for the few rows after
     the first aggregation; kind "port") timed on this host's cores over a bounded sample: the SAME
-    generator as the GPU leg at `sample_sf`, every benched query, `runs` = warm-up+measured passes
-    (the reference's tools/scripts/benchmark.py uses 3+10), median and min per query."""
+    generator as the GPU leg at `sample_sf`, `runs` = warm-up+measured passes per query (the reference's
+    tools/scripts/benchmark.py uses 3+10), median and min per query.  No new leg starts after `budget_s`
+    seconds; the line names the queries that were measured.  With a device context the GPU runs the same
+    sample (same plans, same generator, same SF) so the two geomeans stand beside each other, and the GPU's
+    Q1 / Q6 / Q3 results of that sample are compared bit-exactly with the legs' (`checks`)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import math
     import statistics
 
     import tpch_legs
@@ -342,23 +344,61 @@ def cpu_baseline(queries, sample_sf, runs="1+3"):
     if os.environ.get("LDB_CPU_BASELINE_RESULTS"):  # tests: the legs' results instead of their times
         return {q: legs.run(q) for q in queries}
     warm, measured = (int(x) for x in runs.split("+"))
+    t_gen = time.perf_counter()
     for tid in tpch_legs.Legs.NEED:  # host generation is registration time, not query time
         if any(q in tpch_legs.Legs.NEED[tid] for q in queries):
             legs.table(tid)
-    med, mn = {}, {}
-    for q in queries:
+    gen_s = time.perf_counter() - t_gen
+    med, mn, leg_rows = {}, {}, {}
+    t_start = time.perf_counter()
+    order = [q for q in (1, 6, 3) if q in queries] + [q for q in queries if q not in (1, 6, 3)]  # the three configs[1..2] queries first: they carry the oracle check
+    for q in order:
+        if time.perf_counter() - t_start > budget_s and q not in (1, 6, 3):
+            continue
         ts = []
         for r in range(warm + measured):
             t0 = time.perf_counter()
-            legs.run(q)
+            rows = legs.run(q)
             if r >= warm:
                 ts.append((time.perf_counter() - t0) * 1000.0)
+        leg_rows[q] = rows
         med[q], mn[q] = statistics.median(ts), min(ts)
-    import math
-
-    gm = math.exp(sum(math.log(max(v, 1e-9)) for v in med.values()) / len(med))
-    return {"value": round(gm, 3), "unit": "ms", "cores": legs.threads, "kind": "port",
-            "sample": "SF%g (%d orders; same generator and seed as the GPU leg, which runs SF of `value`): oracle restatement of the reference CPU path "
-                      "(reference binary not buildable offline), %d threads, morsel 20000, %d warm-up + %d measured passes; geomean of the per-query medians over %s "
-                      "— scale linearly with SF for a rough comparison" % (sample_sf, n_orders, legs.threads, warm, measured, "+".join("Q%d" % q for q in queries)),
-            "per_query_median_ms": {"Q%d" % q: round(v, 3) for q, v in med.items()}, "per_query_min_ms": {"Q%d" % q: round(v, 3) for q, v in mn.items()}, "sample_sf": sample_sf}
+    done = [q for q in queries if q in med]
+    gm = math.exp(sum(math.log(max(med[q], 1e-9)) for q in done) / max(len(done), 1))
+    out = {"value": round(gm, 3), "unit": "ms", "cores": legs.threads, "kind": "port",
+           "sample": "SF%g (%d orders; same generator and seed as the GPU leg): oracle restatement of the reference CPU path (reference binary not buildable offline), "
+                     "%d threads, morsel 20000, %d warm-up + %d measured passes per query; geomean of the per-query medians over %s%s" % (
+                         sample_sf, n_orders, legs.threads, warm, measured, "+".join("Q%d" % q for q in done),
+                         "" if len(done) == len(queries) else " (time budget %g s: %s not measured)" % (budget_s, "+".join("Q%d" % q for q in queries if q not in med))),
+           "per_query_median_ms": {"Q%d" % q: round(med[q], 3) for q in done}, "per_query_min_ms": {"Q%d" % q: round(mn[q], 3) for q in done}, "sample_sf": sample_sf,
+           "host_generation_s": round(gen_s, 2)}
+    if ctx is not None:
+        # the GPU on the SAME sample: same plans, generator, seed and SF — the number to read beside `value`
+        sdb = Database(ctx, n_orders, 0, 1, list(queries), narrow)
+        srun = Runner(ctx, sdb, 1, None, None)
+        g_med = {}
+        got = {}
+        for q in done:
+            ts = []
+            for r in range(1 + 3):
+                t0 = time.perf_counter()
+                got[q] = srun.run(q).to_arrow()
+                ctx.sync()
+                if r >= 1:
+                    ts.append((time.perf_counter() - t0) * 1000.0)
+            g_med[q] = statistics.median(ts)
+        out["gpu_same_sample"] = {"value": round(math.exp(sum(math.log(max(g_med[q], 1e-9)) for q in done) / max(len(done), 1)), 3), "unit": "ms",
+                                  "per_query_median_ms": {"Q%d" % q: round(g_med[q], 3) for q in done}, "protocol": "1 warm-up + 3 measured, host wall clock around plan + result hand-over"}
+        if checks is not None:  # BASELINE configs[1] / [2] at the sample scale: bit-exact against the oracle legs, in this run
+            ver = {}
+            for q in (1, 6, 3):
+                if q not in got or q not in leg_rows:
+                    continue
+                g, w = _canon(got[q]), leg_rows[q]
+                if q == 3:  # LIMIT 10: ORDER BY keys in order + membership (ties beyond the keys are unspecified)
+                    key = lambda r: (-r[1], r[2])  # noqa: E731
+                    ver["Q3"] = bool(len(g) == min(10, len(w)) and [key(r) for r in g] == [key(r) for r in w[: len(g)]] and set(g) <= set(w))
+                else:
+                    ver["Q%d" % q] = bool(g == w and len(w) > 0)
+            checks["oracle_bit_exact_at_sample_sf%g" % sample_sf] = ver
+    return out
