@@ -39,7 +39,8 @@ struct ldb_hashtable {
    uint32_t* key_bits = nullptr; // one bit per key value of [kmin, kmax] (DJoin::has_key_bits), or NULL
    int32_t chained = 0; // one slot per distinct key, rows linked through next[] (DJoin::chained)
    uint32_t* next = nullptr;
-   int32_t direct = 0; // slots = uint32_t[kmax - kmin + 1] indexed by key - kmin (DJoin::direct)
+   int32_t direct = 0; // 1: slots = uint32_t[kmax - kmin + 1] indexed by key - kmin; 2: rank-bitmap words (DJoin::direct)
+   int32_t rank_sorted = 0; // direct == 2: a key's rank IS its build row (ascending keys without NULLs); else next[] = rank → row
    size_t slot_bytes = 0; // bytes of the slot array (cap x 8, or cap x 4 when direct)
    // the table owns its device buffers: an early error return from the build frees them with the object
    ~ldb_hashtable() {
@@ -54,6 +55,15 @@ struct ldb_hashtable {
 __global__ void k_join_build(const DJoin* __restrict__ d) { join_build_body(*d, d); }
 __global__ void k_join_key_range(const DJoin* __restrict__ d, long long* __restrict__ out) { join_key_range_body(*d, d, out); }
 __global__ void k_join_key_bits(const DJoin* __restrict__ d) { join_key_bits_body(*d, d); }
+__global__ void k_join_rank_bits(const DJoin* __restrict__ d) { join_rank_bits_body(*d, d); }
+__global__ void k_join_rank_perm(const DJoin* __restrict__ d) { join_rank_perm_body(*d, d); }
+// rank-bitmap build, pass 2: popcounts of the presence halves → (scan) → prefix halves
+__global__ void k_rank_pop(const uint64_t* __restrict__ tab, uint64_t n_words, uint32_t* __restrict__ pop) {
+   for (uint64_t w = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; w < n_words; w += (uint64_t) gridDim.x * blockDim.x) pop[w] = (uint32_t) __popc((uint32_t) tab[w]);
+}
+__global__ void k_rank_prefix(uint64_t* __restrict__ tab, uint64_t n_words, const uint32_t* __restrict__ off) {
+   for (uint64_t w = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; w < n_words; w += (uint64_t) gridDim.x * blockDim.x) tab[w] = (tab[w] & 0xFFFFFFFFull) | ((uint64_t) off[w] << 32);
+}
 __global__ void k_join_probe_pairs(const DJoin* __restrict__ d) { join_probe_pairs_body(*d, d); }
 __global__ void k_join_probe_pairs_count(const DJoin* __restrict__ d) { join_probe_pairs_count_body(*d, d); }
 __global__ void k_join_probe_count(const DJoin* __restrict__ d) { join_probe_count_body(*d, d); }
@@ -156,6 +166,13 @@ bool ldb_join_jit_check(std::string* log) {
    m->slot32 = 0;
    m->has_key_bits = 0;
    m->direct = 1;
+   if (!ldb_jit_compile_only("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, m.get(), sizeof(DJoin), log)) return false;
+   // third shape: the rank-bitmap table with ascending build keys (pipelined too), then with a rank → row permutation
+   m->direct = 2;
+   m->rank_sorted = 1;
+   if (!ldb_jit_compile_only("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, m.get(), sizeof(DJoin), log)) return false;
+   m->rank_sorted = 0;
+   m->kind = LDB_JOIN_SEMI;
    return ldb_jit_compile_only("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, m.get(), sizeof(DJoin), log);
 }
 
@@ -454,6 +471,77 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
       // filtered subsets of one): the table is then no larger than the open-addressing array it replaces
       // (4 B x range against 8 B x nextPow2(2n) in [16n, 32n) bytes) and a probe is one 4-byte load
       const unsigned __int128 range0 = got[0] <= got[1] ? (unsigned __int128) ((__int128) got[1] - got[0]) + 1 : 0;
+      // RANK-BITMAP table for (promised) unique keys over a range of at most 64 values per build row: range / 4 bytes,
+      // one 8-byte load per probe, no collisions, nothing to clear but the words (DJoin::direct == 2)
+      bool ranked = false;
+      if (range0 > 0 && build_unique && ldb_option("join_direct", 1) != 0 && ldb_option("join_rank", 1) != 0 && range0 <= ((unsigned __int128) 1 << 32) &&
+          range0 <= (unsigned __int128) std::max<int64_t>(4096, 64 * build->n_rows) && got[0] >= INT32_MIN && got[1] <= INT32_MAX && build->n_rows < (int64_t) LDB_NULL_ROW) {
+         const uint64_t n_words = (uint64_t) (range0 / 32) + 1;
+         uint64_t* tab = nullptr;
+         uint32_t *pop = nullptr, *off = nullptr;
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &tab, 8 * (size_t) n_words));
+         ht->slots = tab; // (owned by the table object from here on: freed on every error return)
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) n_words));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) n_words));
+         LDB_HIP(hipMemsetAsync(tab, 0, 8 * (size_t) n_words, ctx->stream));
+         unsigned long long* counter = (unsigned long long*) (ctx->d_scratch + 16);
+         uint64_t* d_total = (uint64_t*) (ctx->d_scratch + 18);
+         LDB_HIP(hipMemsetAsync(counter, 0, 24, ctx->stream));
+         h->direct = 2;
+         h->kmin = got[0];
+         h->kmax = got[1];
+         h->slots = (uint64_t) tab;
+         h->counter = (uint64_t) counter;
+         DJoin* dr;
+         LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dr));
+         {
+            LdbProf prof_(ctx, "k_join_build");
+            hipLaunchKernelGGL(k_join_rank_bits, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dr);
+            hipLaunchKernelGGL(k_rank_pop, dim3(ldb_grid_for(ctx, (int64_t) n_words, 256, 8)), dim3(256), 0, ctx->stream, (const uint64_t*) tab, n_words, pop);
+         }
+         LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, (int64_t) n_words, d_total));
+         hipLaunchKernelGGL(k_rank_prefix, dim3(ldb_grid_for(ctx, (int64_t) n_words, 256, 8)), dim3(256), 0, ctx->stream, tab, n_words, (const uint32_t*) off);
+         LDB_HIP(hipGetLastError());
+         uint64_t back[3] = {0, 0, 0}; // non-NULL keys, —, distinct keys
+         uint32_t fl[2] = {0, 0};
+         LDB_HIP(hipMemcpyAsync(back, counter, 24, hipMemcpyDeviceToHost, ctx->stream));
+         LDB_HIP(hipMemcpyAsync(fl, dflags, 8, hipMemcpyDeviceToHost, ctx->stream));
+         LDB_HIP(hipStreamSynchronize(ctx->stream));
+         ldb_dev_free(ctx, pop);
+         ldb_dev_free(ctx, off);
+         if (back[0] == back[2]) { // every non-NULL key set a bit of its own: unique
+            ranked = true;
+            ht->direct = 2;
+            ht->kmin = got[0];
+            ht->kmax = got[1];
+            ht->cap = (uint64_t) range0;
+            ht->slot_bytes = 8 * (size_t) n_words;
+            ht->rank_sorted = (fl[0] & 4u) ? 0 : 1;
+            if (!ht->rank_sorted) {
+               LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) (build->n_rows ? build->n_rows : 1)));
+               h->next = (uint64_t) ht->next;
+               DJoin* dp;
+               LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dp));
+               hipLaunchKernelGGL(k_join_rank_perm, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dp);
+               LDB_HIP(hipGetLastError());
+               ldb_dev_free(ctx, dp);
+            }
+         } else { // duplicate keys: the promise does not hold — the general layouts below
+            ldb_dev_free(ctx, tab);
+            ht->slots = nullptr;
+            h->direct = 0;
+            h->slots = 0;
+            h->counter = 0;
+            ht->unique = 0;
+            build_unique = 0;
+         }
+         ldb_dev_free(ctx, dr);
+         LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
+      }
+      if (ranked) {
+         *out = ht.release();
+         return LDB_OK;
+      }
       if (range0 > 0 && ldb_option("join_direct", 1) != 0 && range0 <= (unsigned __int128) std::max<int64_t>(1024, 8 * build->n_rows) && range0 < ((unsigned __int128) 1 << 31) &&
           got[0] >= INT32_MIN && got[1] <= INT32_MAX) {
          ht->direct = 1;
@@ -587,6 +675,7 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    h->key32 = ht->key32;
    h->ordered_slots = ht->ordered_slots;
    h->direct = ht->direct;
+   h->rank_sorted = ht->rank_sorted;
    h->kmin = ht->kmin;
    h->kmax = ht->kmax;
    h->kmult = ht->kmult;

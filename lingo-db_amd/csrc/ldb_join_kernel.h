@@ -72,8 +72,16 @@ struct DJoin {
    // hash, no tag, no collision walk, 4 bytes per key VALUE instead of 8 bytes per slot of a half-empty
    // table; clustered probes (lineitem → orders) sweep it sequentially.  Duplicate keys chain through
    // next[] (`chained`: push-front with one atomic exchange per build row).
+   // direct == 2, the RANK-BITMAP table (unique keys): `slots` is a uint64_t array with one word per 32 key VALUES,
+   //   low half  = presence bits of the keys (key - kmin) in [32w, 32w + 32),
+   //   high half = number of build keys below 32w (exclusive prefix of the popcounts),
+   // so a probe is ONE 8-byte load: hit ⇔ its bit is set, and the key's rank = prefix + popcount(bits below it).  The
+   // build row of rank r is r itself when the build keys are strictly ascending without NULLs (`rank_sorted`: a
+   // primary-key table or a filtered subset of one), else perm[r] (`next` carries perm).  range / 4 bytes in all —
+   // 150 MB for the 600 M key values of o_orderkey at SF100, whatever fraction of the orders the build side keeps —
+   // against 4 bytes per key VALUE for direct == 1 and 16-32 bytes per build ROW for open addressing.
    int32_t direct;
-   int32_t pad_;
+   int32_t rank_sorted;
    DJoinResid resid[LDB_MAX_RESID];
    DPred ppreds[LDB_MAX_PREDS];
 };
@@ -251,6 +259,78 @@ __device__ __forceinline__ void join_key_bits_body(const DJoin& m, const DJoin* 
    }
 }
 
+// rank-bitmap word → rank + 1 of key offset r (0 = the key is not in the table)
+__device__ __forceinline__ uint32_t d_rank_word(uint64_t w, uint32_t r) {
+   const uint32_t bits = (uint32_t) w, b = r & 31u;
+   if (!((bits >> b) & 1u)) return 0u;
+   return (uint32_t) (w >> 32) + (uint32_t) __popc(bits & ((1u << b) - 1u)) + 1u;
+}
+// rank-bitmap table (DJoin::direct == 2), build pass 1: presence bits into the low halves of the 64-bit words, the
+// number of non-NULL build keys (counter[0]; equals the number of set bits iff the keys are unique) and whether the
+// keys are strictly ascending without NULLs (flags |= 4 otherwise: then a key's rank is not its row and the
+// build adds the rank → row permutation).  Lanes whose keys fall into the same word OR their bits together first.
+__device__ __forceinline__ void join_rank_bits_body(const DJoin& m, const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows;
+   const KV bkeys(m.bkeys, d->bkeys);
+   const CV c = bkeys.col(0);
+   uint32_t* lo = gptr_mut<uint32_t>(d->slots);
+   const uint32_t lane = threadIdx.x & 63;
+   const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+   unsigned long long present = 0;
+   bool unordered = false;
+   for (uint64_t base = blockIdx.x * (uint64_t) blockDim.x; base < n; base += stride) { // uniform trip count per block
+      const uint64_t i = base + threadIdx.x;
+      unsigned long long w = ~0ull;
+      uint32_t v = 0;
+      bool valid = false;
+      if (i < n) {
+         const uint32_t row = d_phys_row(c, i);
+         if (d_valid(c, row)) {
+            const int64_t key = d_load_i64(c, row);
+            const uint64_t r = (uint64_t) (key - d->kmin);
+            w = r >> 5;
+            v = 1u << (r & 31);
+            valid = true;
+            if (i > 0) {
+               const uint32_t prow = d_phys_row(c, i - 1);
+               if (!d_valid(c, prow) || !(d_load_i64(c, prow) < key)) unordered = true;
+            }
+         } else {
+            unordered = true;
+         }
+      }
+      present += (unsigned long long) __popcll(__ballot(valid));
+      for (int off = 1; off < 64; off <<= 1) {
+         const unsigned long long w2 = __shfl_down(w, off);
+         const uint32_t v2 = __shfl_down(v, off);
+         if (w2 == w) v |= v2;
+      }
+      const unsigned long long wprev = __shfl_up(w, 1);
+      const bool leader = lane == 0 || wprev != w;
+      if (leader && w != ~0ull) atomicOr(lo + 2 * w, v);
+   }
+   if (__ballot(unordered) != 0 && lane == 0) {
+      uint32_t* f = gptr_mut<uint32_t>(d->flags);
+      if ((__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u) == 0) atomicOr(f, 4u);
+   }
+   if (lane == 0 && present) atomicAdd(gptr_mut<unsigned long long>(d->counter), present);
+}
+// pass 3 (only when the keys are not ascending): perm[rank(key of row i)] = i
+__device__ __forceinline__ void join_rank_perm_body(const DJoin& m, const DJoin* __restrict__ d) {
+   const uint64_t n = d->n_rows;
+   const KV bkeys(m.bkeys, d->bkeys);
+   const CV c = bkeys.col(0);
+   const uint64_t* tab = gptr<uint64_t>(d->slots);
+   uint32_t* perm = gptr_mut<uint32_t>(d->next);
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+      const uint32_t row = d_phys_row(c, i);
+      if (!d_valid(c, row)) continue;
+      const uint32_t r = (uint32_t) (d_load_i64(c, row) - d->kmin);
+      const uint32_t rk = d_rank_word(tab[r >> 5], r);
+      if (rk) perm[rk - 1u] = (uint32_t) i;
+   }
+}
+
 // residual conjuncts on the candidate pair (probe logical row i, build logical row brow)
 __device__ __forceinline__ bool d_resid_ok(const DJoin& m, const DJoin* __restrict__ d, uint64_t i, uint32_t brow) {
    bool ok = true;
@@ -418,6 +498,27 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
          }
       }
    }
+   if (m.direct == 2) {
+      const uint64_t* tab = gptr<uint64_t>(d->slots);
+      const uint32_t* perm = gptr<uint32_t>(d->next);
+      const bool bits_only = m.n_resid == 0 && (m.kind == LDB_JOIN_SEMI || m.kind == LDB_JOIN_ANTI || m.kind == LDB_JOIN_MARK);
+      uint64_t ww[U];
+      uint32_t hw[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         ww[u] = 0;
+         if (live[u]) ww[u] = tab[pos[u] >> 5];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) hw[u] = live[u] ? d_rank_word(ww[u], (uint32_t) pos[u]) : 0u;
+      if (!m.rank_sorted && !bits_only) {
+#pragma unroll
+         for (int u = 0; u < U; u++)
+            if (hw[u]) hw[u] = perm[hw[u] - 1u] + 1u;
+      }
+      d_direct_resolve<U>(m, d, rows, live, hw, bits_only, matches, emit);
+      return;
+   }
    if (m.direct) {
       // one 4-byte word per key value: build row + 1 (the head of the key's chain when `chained`)
       const uint32_t* tab = gptr<uint32_t>(d->slots);
@@ -554,6 +655,7 @@ __device__ __forceinline__ void d_prefetch_keys32(const DJoin* __restrict__ d, u
 //   Two sets of word registers alternate (template parameter P of step): copying a register whose load is
 //   still in flight would wait for it, so the loops are unrolled by two instead of rotating registers.
 #define LDB_PIN(x) asm volatile("" : "+v"(x))
+#define LDB_PIN64(x) asm volatile("" : "+v"(x)) // (a 64-bit value: a VGPR pair)
 template <int P>
 struct DPar {
    static constexpr int v = P;
@@ -563,40 +665,42 @@ struct DProbePipe {
    // (pf / pw are recomputed from the — compile-time — metadata at every use: as members they would keep the
    // struct in memory and the specialised kernel could not fold them)
    static __device__ __forceinline__ bool pf(const DJoin& m) { return d_keys_prefetchable(m); }
-   static __device__ __forceinline__ bool pw(const DJoin& m) { return d_keys_prefetchable(m) && m.direct && !m.has_key_bits; }
+   static __device__ __forceinline__ bool pw(const DJoin& m) { return d_keys_prefetchable(m) && ((m.direct == 1 && !m.has_key_bits) || (m.direct == 2 && m.rank_sorted)); }
    uint64_t stride; // rows between a wave's consecutive tiles
    uint32_t ck[U], cw[U]; // pf: keys of the tile being resolved;  pw: its table words
    uint32_t k[U]; // keys in flight (pf: of the coming tile; pw: of the tile after the coming one once its step ran)
-   uint32_t w[2][U]; // pw: table words in flight, alternating sets
-   bool inr[2][U]; // pw: key inside the table's range
-   // the table offsets of the keys in k[] (→ inr[set]); the words are loaded by words_at
-   __device__ __forceinline__ void offsets_of(const DJoin* __restrict__ d, int set, uint32_t (&r)[U]) {
+   uint64_t w[2][U]; // pw: table words in flight, alternating sets (direct == 1 uses the low half)
+   uint32_t off[2][U]; // pw: the keys' table offsets (key - kmin), ~0 = outside the table's range
+   // the table offsets of the keys in k[]; the words are loaded by words_at
+   __device__ __forceinline__ void offsets_of(const DJoin* __restrict__ d, int set) {
       const uint32_t kmin32 = (uint32_t) d->kmin, span = (uint32_t) (d->kmax - d->kmin);
 #pragma unroll
       for (int u = 0; u < U; u++) {
-         r[u] = k[u] - kmin32;
-         inr[set][u] = r[u] <= span;
-         r[u] = inr[set][u] ? r[u] : 0u;
+         const uint32_t r = k[u] - kmin32;
+         off[set][u] = r <= span ? r : 0xFFFFFFFFu;
       }
    }
-   __device__ __forceinline__ void words_at(const DJoin* __restrict__ d, int set, const uint32_t (&r)[U]) {
-      const uint32_t* tab = gptr<uint32_t>(d->slots);
+   __device__ __forceinline__ void words_at(const DJoin& m, const DJoin* __restrict__ d, int set) {
 #pragma unroll
-      for (int u = 0; u < U; u++) w[set][u] = tab[r[u]];
+      for (int u = 0; u < U; u++) {
+         const uint32_t r = off[set][u] == 0xFFFFFFFFu ? 0u : off[set][u];
+         if (m.direct == 2) w[set][u] = gptr<uint64_t>(d->slots)[r >> 5];
+         else w[set][u] = (uint64_t) gptr<uint32_t>(d->slots)[r];
+      }
    }
    __device__ __forceinline__ void start(const DJoin& m, const DJoin* __restrict__ d, uint64_t row0, uint64_t stride_rows, uint64_t n) {
       stride = stride_rows;
 #pragma unroll
       for (int u = 0; u < U; u++) {
-         ck[u] = cw[u] = k[u] = w[0][u] = w[1][u] = 0;
-         inr[0][u] = inr[1][u] = false;
+         ck[u] = cw[u] = k[u] = 0;
+         w[0][u] = w[1][u] = 0;
+         off[0][u] = off[1][u] = 0xFFFFFFFFu;
       }
       if (pf(m)) d_prefetch_keys32<U>(d, row0, n, k);
       if (pw(m)) {
-         uint32_t r[U];
-         offsets_of(d, 0, r);
+         offsets_of(d, 0);
          d_prefetch_keys32<U>(d, row0 + stride, n, k);
-         words_at(d, 0, r);
+         words_at(m, d, 0);
       }
    }
    // at the top of the iteration over the tile starting at row0: afterwards ck / cw belong to that tile.
@@ -606,15 +710,17 @@ struct DProbePipe {
       if (pw(m)) {
 #pragma unroll
          for (int u = 0; u < U; u++) LDB_PIN(k[u]); // keys(s+1) are here (words(s) may still be in flight)
-         uint32_t r[U];
-         offsets_of(d, 1 - P, r);
+         offsets_of(d, 1 - P);
          d_prefetch_keys32<U>(d, row0 + 2 * stride, n, k); // keys(s+2), into the registers just consumed
          asm volatile("" : : : "memory"); // (keeps the key loads ahead of the word loads in issue order; no wait)
-         words_at(d, 1 - P, r); // words(s+1)
+         words_at(m, d, 1 - P); // words(s+1)
 #pragma unroll
-         for (int u = 0; u < U; u++) LDB_PIN(w[P][u]); // words(s) are here
+         for (int u = 0; u < U; u++) LDB_PIN64(w[P][u]); // words(s) are here
 #pragma unroll
-         for (int u = 0; u < U; u++) cw[u] = inr[P][u] ? w[P][u] : 0u;
+         for (int u = 0; u < U; u++) { // → build row + 1 of every row of the tile (0 = no partner)
+            if (off[P][u] == 0xFFFFFFFFu) cw[u] = 0u;
+            else cw[u] = m.direct == 2 ? d_rank_word(w[P][u], off[P][u]) : (uint32_t) w[P][u];
+         }
       } else if (pf(m)) {
 #pragma unroll
          for (int u = 0; u < U; u++) ck[u] = k[u];
@@ -625,6 +731,22 @@ struct DProbePipe {
    __device__ __forceinline__ const uint32_t* words(const DJoin& m) const { return pw(m) ? cw : nullptr; }
 };
 
+// a wave's tiles first, first + stride, … < bound.  With the two-deep pipeline (pw) two tiles per trip, so that its
+// word registers alternate without copies; otherwise one tile per trip (three inlined copies of every tile body
+// cost the other shapes registers — 49 → 65 VGPRs on the pairs kernel, one wave per SIMD less — for nothing)
+template <int U, typename TILE>
+__device__ __forceinline__ void d_tile_loop(const DJoin& m, uint64_t first, uint64_t bound, uint64_t stride, TILE tile) {
+   if (DProbePipe<U>::pw(m)) {
+      uint64_t t0 = first;
+      for (; t0 + stride < bound; t0 += 2 * stride) {
+         tile(t0, DPar<0>{});
+         tile(t0 + stride, DPar<1>{});
+      }
+      if (t0 < bound) tile(t0, DPar<0>{});
+   } else {
+      for (uint64_t t0 = first; t0 < bound; t0 += stride) tile(t0, DPar<0>{});
+   }
+}
 // global wave number as a wave-uniform (scalar) value: the tile loops then run on scalar control flow
 __device__ __forceinline__ uint64_t d_wave_id() {
    return (uint64_t) blockIdx.x * (blockDim.x >> 6) + (uint64_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
@@ -679,12 +801,7 @@ __device__ __forceinline__ void join_probe_pairs_count_body(const DJoin& m, cons
          total += s;
       }
    };
-   uint64_t w00 = wave * JP_U;
-   for (; w00 + (n_waves * JP_U) < n_chunks; w00 += 2 * (n_waves * JP_U)) { // two tiles per trip: the pipeline's word registers alternate
-      tile(w00, DPar<0>{});
-      tile(w00 + (n_waves * JP_U), DPar<1>{});
-   }
-   if (w00 < n_chunks) tile(w00, DPar<0>{});
+   d_tile_loop<JP_U>(m, wave * JP_U, n_chunks, n_waves * JP_U, tile);
    if (lane == 0 && total) atomicAdd(gptr_mut<unsigned long long>(d->counter), total);
 }
 __device__ __forceinline__ void join_probe_pairs_body(const DJoin& m, const DJoin* __restrict__ d) {
@@ -761,12 +878,7 @@ __device__ __forceinline__ void join_probe_count_body(const DJoin& m, const DJoi
 #pragma unroll
       for (int u = 0; u < JOIN_BATCH; u++) local += mt[u];
    };
-   uint64_t t0 = wave;
-   for (; t0 + (n_waves) < n_tiles; t0 += 2 * (n_waves)) { // two tiles per trip: the pipeline's word registers alternate
-      tile(t0, DPar<0>{});
-      tile(t0 + (n_waves), DPar<1>{});
-   }
-   if (t0 < n_tiles) tile(t0, DPar<0>{});
+   d_tile_loop<JOIN_BATCH>(m, wave, n_tiles, n_waves, tile);
    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
    if (lane == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter) + 1, local);
 }
@@ -974,12 +1086,7 @@ __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJo
          }
       }
    };
-   uint64_t w00 = wave * JE_U;
-   for (; w00 + (n_waves * JE_U) < n_words; w00 += 2 * (n_waves * JE_U)) { // two tiles per trip: the pipeline's word registers alternate
-      tile(w00, DPar<0>{});
-      tile(w00 + (n_waves * JE_U), DPar<1>{});
-   }
-   if (w00 < n_words) tile(w00, DPar<0>{});
+   d_tile_loop<JE_U>(m, wave * JE_U, n_words, n_waves * JE_U, tile);
    if (lane == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter), local);
 }
 
@@ -1031,12 +1138,7 @@ __device__ __forceinline__ void join_probe_markbuild_body(const DJoin& m, const 
          },
          pipe.keys(m), pipe.words(m));
    };
-   uint64_t t0 = wave;
-   for (; t0 + (n_waves) < n_tiles; t0 += 2 * (n_waves)) { // two tiles per trip: the pipeline's word registers alternate
-      tile(t0, DPar<0>{});
-      tile(t0 + (n_waves), DPar<1>{});
-   }
-   if (t0 < n_tiles) tile(t0, DPar<0>{});
+   d_tile_loop<JE_U>(m, wave, n_tiles, n_waves, tile);
 }
 // flags (one byte per build row) → ballot bitmap of the rows to keep (+ their count)
 __device__ __forceinline__ void join_flags_bitmap_body(const uint8_t* __restrict__ flags, uint64_t n, int anti, uint64_t* __restrict__ bitmap,
@@ -1101,11 +1203,6 @@ __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJo
          }
       }
    };
-   uint64_t w00 = wave * JE_U;
-   for (; w00 + (n_waves * JE_U) < n_words; w00 += 2 * (n_waves * JE_U)) { // two tiles per trip: the pipeline's word registers alternate
-      tile(w00, DPar<0>{});
-      tile(w00 + (n_waves * JE_U), DPar<1>{});
-   }
-   if (w00 < n_words) tile(w00, DPar<0>{});
+   d_tile_loop<JE_U>(m, wave * JE_U, n_words, n_waves * JE_U, tile);
    if (lane == 0 && local) atomicAdd(gptr_mut<unsigned long long>(d->counter), local);
 }

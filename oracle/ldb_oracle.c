@@ -1337,3 +1337,133 @@ int64_t ora_topk(const ora_rel* in, const ldb_sort_spec* specs, int32_t n_specs,
    free(full);
    return n;
 }
+
+/* ================================================================== SURVEY §8(f).4: SegmentTreeView, windows, set operations */
+typedef struct ora_st_node {
+   int64_t left_min, right_max;
+   struct ora_st_node *left, *right;
+   __int128 v;
+   int ok;
+} ora_st_node;
+/* the generated combine functions: a NULL state is the identity; COUNT and SUM add, MIN / MAX select */
+static void ora_st_combine(int fn, __int128* v, int* ok, __int128 v2, int ok2) {
+   if (!ok2) return;
+   if (!*ok) {
+      *v = v2;
+      *ok = 1;
+      return;
+   }
+   if (fn == LDB_WIN_MIN) *v = v2 < *v ? v2 : *v;
+   else if (fn == LDB_WIN_MAX) *v = v2 > *v ? v2 : *v;
+   else *v = (__int128) ((unsigned __int128) *v + (unsigned __int128) v2);
+}
+/* SegmentTreeView::buildRecursively (src/runtime/SegmentTreeView.cpp:22-47): from / to inclusive, split at from + (to - from) / 2 */
+static ora_st_node* ora_st_build(ora_st_node* pool, int64_t* used, const int64_t* vals, const uint8_t* valid, int fn, int64_t from, int64_t to) {
+   ora_st_node* t = &pool[(*used)++];
+   t->left_min = from;
+   t->right_max = to;
+   t->left = t->right = NULL;
+   if (from == to) { /* createInitialStateFn(entry) */
+      const int ok = valid ? valid[from] != 0 : 1;
+      if (fn == LDB_WIN_COUNT) {
+         t->v = ok ? 1 : 0;
+         t->ok = 1;
+      } else {
+         t->v = ok ? (__int128) (((unsigned __int128) (uint64_t) vals[2 * from + 1] << 64) | (uint64_t) vals[2 * from]) : 0;
+         t->ok = ok;
+      }
+      return t;
+   }
+   const int64_t mid = from + (to - from) / 2;
+   t->left = ora_st_build(pool, used, vals, valid, fn, from, mid);
+   t->right = ora_st_build(pool, used, vals, valid, fn, mid + 1, to);
+   t->v = t->left->v;
+   t->ok = t->left->ok;
+   ora_st_combine(fn, &t->v, &t->ok, t->right->v, t->right->ok); /* combineStatesFn(inner, left, right) */
+   return t;
+}
+/* SegmentTreeView::lookupRecursively (:67-79) */
+static void ora_st_lookup(const ora_st_node* t, int fn, int64_t from, int64_t to, __int128* v, int* ok, int* first) {
+   if (from <= t->left_min && to >= t->right_max) {
+      if (*first) {
+         *v = t->v;
+         *ok = t->ok;
+         *first = 0;
+      } else {
+         ora_st_combine(fn, v, ok, t->v, t->ok);
+      }
+   } else if (from <= t->right_max && to >= t->left_min) {
+      ora_st_lookup(t->left, fn, from, to, v, ok, first);
+      ora_st_lookup(t->right, fn, from, to, v, ok, first);
+   }
+}
+int32_t ora_segment_tree(const int64_t* vals_lohi, const uint8_t* valid, int64_t n, int32_t fn, const int64_t* from, const int64_t* to, int64_t nq, int64_t* out_lohi, uint8_t* out_valid) {
+   if (n <= 0 || fn < LDB_WIN_SUM || fn > LDB_WIN_COUNT) return -1;
+   ora_st_node* pool = (ora_st_node*) malloc(sizeof(ora_st_node) * (size_t) (2 * n));
+   int64_t used = 0;
+   ora_st_node* root = ora_st_build(pool, &used, vals_lohi, valid, fn, 0, n - 1);
+   for (int64_t q = 0; q < nq; q++) {
+      if (from[q] > to[q] || from[q] < 0 || to[q] >= n) { /* lookup throws "from must be <= to" */
+         free(pool);
+         return -2;
+      }
+      __int128 v = 0;
+      int ok = 0, first = 1;
+      ora_st_lookup(root, fn, from[q], to[q], &v, &ok, &first);
+      out_lohi[2 * q] = (int64_t) (uint64_t) v;
+      out_lohi[2 * q + 1] = (int64_t) (v >> 64);
+      out_valid[q] = (uint8_t) (fn == LDB_WIN_COUNT ? 1 : ok);
+   }
+   free(pool);
+   return 0;
+}
+int32_t ora_window(const int64_t* vals_lohi, const uint8_t* valid, const int64_t* part_start, const int64_t* part_end, int64_t n, int32_t fn, int64_t frame_from, int64_t frame_to,
+                   int64_t* out_lohi, uint8_t* out_valid) {
+   /* per partition a continuous view (its sorted buffer) with its own segment tree, as WindowLowering builds them */
+   for (int64_t p0 = 0; p0 < n;) {
+      const int64_t st = part_start[p0], en = part_end[p0], len = en - st;
+      ora_st_node* pool = NULL;
+      ora_st_node* root = NULL;
+      if (fn >= LDB_WIN_SUM && fn <= LDB_WIN_COUNT) {
+         pool = (ora_st_node*) malloc(sizeof(ora_st_node) * (size_t) (2 * len));
+         int64_t used = 0;
+         root = ora_st_build(pool, &used, vals_lohi + 2 * st, valid ? valid + st : NULL, fn, 0, len - 1);
+      }
+      for (int64_t i = st; i < en; i++) {
+         const int64_t cur = i - st, last = len - 1;
+         /* GetBeginReference = 0, GetEndReference = len - 1, OffsetReferenceBy = min(len - 1, max(0, cur + off)) */
+         int64_t lo = frame_from == INT64_MIN ? 0 : (frame_from == 0 ? cur : cur + frame_from);
+         int64_t hi = frame_to == INT64_MAX ? last : (frame_to == 0 ? cur : cur + frame_to);
+         lo = lo < 0 ? 0 : (lo > last ? last : lo);
+         hi = hi < 0 ? 0 : (hi > last ? last : hi);
+         __int128 v = 0;
+         int ok = 1;
+         if (fn == LDB_WIN_RANK) v = cur - lo + 1; /* EntriesBetween(frame begin, current) + 1 */
+         else if (fn == LDB_WIN_COUNT_STAR) v = hi >= lo ? hi - lo + 1 : 0;
+         else if (hi >= lo) {
+            int first = 1;
+            ok = 0;
+            ora_st_lookup(root, fn, lo, hi, &v, &ok, &first);
+            if (fn == LDB_WIN_COUNT) ok = 1;
+         } else {
+            ok = fn == LDB_WIN_COUNT;
+         }
+         out_lohi[2 * i] = (int64_t) (uint64_t) v;
+         out_lohi[2 * i + 1] = (int64_t) (v >> 64);
+         out_valid[i] = (uint8_t) ok;
+      }
+      free(pool);
+      p0 = en;
+   }
+   return 0;
+}
+int64_t ora_setop_multiplicity(int32_t op, int64_t l, int64_t r) {
+   switch (op) {
+      case LDB_SET_UNION: return 1;
+      case LDB_SET_INTERSECT: return (l > 0 && r > 0) ? 1 : 0; /* leftNonZero && rightNonZero (:878-881) */
+      case LDB_SET_EXCEPT: return (l > 0 && r == 0) ? 1 : 0; /* leftNonZero && rightZero (:875-877) */
+      case LDB_SET_INTERSECT_ALL: return l > r ? r : l; /* select(l > r, r, l) (:898-900) */
+      case LDB_SET_EXCEPT_ALL: return l - r < 0 ? 0 : l - r; /* max(l - r, 0) (:893-896) */
+      default: return l + r; /* UNION ALL: every row of both inputs */
+   }
+}

@@ -81,6 +81,18 @@ int64_t ora_extract_year(int64_t days);
 /* substring(str from `from` for `len`) (StringRuntime::substr): byte range [begin, end) of the result inside str */
 void ora_substr(const uint8_t* s, int64_t sl, int64_t from, int64_t len, int64_t* out_begin, int64_t* out_end);
 int32_t ora_decimal_muldiv(const int64_t num[2], const int64_t mul[2], int32_t mul_div_pow10, int32_t pow10, const int64_t den[2], int64_t out[2]);
+/* ---- §8(f).4 state types
+ * SegmentTreeView (src/runtime/SegmentTreeView.cpp:18-79): recursive build over entries {value, valid}, lookup(from, to)
+ * inclusive; fn = ldb_window_fn_kind SUM / MIN / MAX / COUNT with the generated combine functions' NULL handling
+ * (RelAlgToSubOp.cpp:1843-2027).  128-bit values as (lo, hi) pairs. */
+int32_t ora_segment_tree(const int64_t* vals_lohi, const uint8_t* valid, int64_t n, int32_t fn, const int64_t* from, const int64_t* to, int64_t nq, int64_t* out_lohi, uint8_t* out_valid);
+/* WindowLowering (RelAlgToSubOp.cpp:2193-2553) over rows already in window order: part_start[i] / part_end[i] = first row and
+ * one-past-last row of row i's partition; frame offsets as in ldb_gpu_window (INT64_MIN / INT64_MAX = unbounded), both ends
+ * clamped into the partition (OffsetReferenceByLowering, SubOpToControlFlow.cpp:3860-3885); RANK = current - frame begin + 1 */
+int32_t ora_window(const int64_t* vals_lohi, const uint8_t* valid, const int64_t* part_start, const int64_t* part_end, int64_t n, int32_t fn, int64_t frame_from, int64_t frame_to,
+                   int64_t* out_lohi, uint8_t* out_valid);
+/* CountingSetOperationLowering (RelAlgToSubOp.cpp:735-930): rows of a result group from the two per-input counters */
+int64_t ora_setop_multiplicity(int32_t op, int64_t c_left, int64_t c_right);
 int32_t ora_num_cores(void);
 
 #ifdef __cplusplus

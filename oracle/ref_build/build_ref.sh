@@ -29,6 +29,7 @@ SRCS=(
   src/runtime/Heap.cpp
   src/runtime/SimpleState.cpp
   src/runtime/Hashtable.cpp
+  src/runtime/SegmentTreeView.cpp
   src/runtime/StringRuntime.cpp
   src/runtime/ListRuntime.cpp
   src/runtime/DateRuntime.cpp

@@ -23,6 +23,7 @@
 #include "lingodb/runtime/Heap.h"
 #include "lingodb/runtime/Hashtable.h"
 #include "lingodb/runtime/SimpleState.h"
+#include "lingodb/runtime/SegmentTreeView.h"
 #include "lingodb/runtime/DateRuntime.h"
 #include "lingodb/runtime/StringRuntime.h"
 #include "lingodb/runtime/storage/Restrictions.h"
@@ -472,4 +473,56 @@ int64_t ref_hashtable_groupby_int64(const int64_t* keys, const uint64_t* hashes,
    return got;
 }
 
+
+// The REAL SegmentTreeView (src/runtime/SegmentTreeView.cpp:18-110) over entries {int64 value, valid}: the generated
+// createInitialStateFn / combineStatesFn of WindowLowering's aggregate functions (RelAlgToSubOp.cpp:1843-2027: a NULL
+// state is the identity, SUM adds, MIN / MAX select, COUNT counts the non-NULL entries) restated as C callbacks, then
+// lookup(from[q], to[q]) per query.  fn: 1 SUM, 2 MIN, 3 MAX, 4 COUNT (the ids of include/lingodb_gpu.h's ldb_window_fn_kind).
+extern "C++" {
+namespace {
+struct WinEntry {
+   int64_t v;
+   int64_t ok;
+};
+template <int FN>
+void winInit(unsigned char* state, unsigned char* entry) {
+   auto* e = reinterpret_cast<WinEntry*>(entry);
+   auto* s = reinterpret_cast<WinEntry*>(state);
+   if (FN == 4) *s = {e->ok ? 1 : 0, 1};
+   else *s = {e->ok ? e->v : 0, e->ok};
+}
+template <int FN>
+void winCombine(unsigned char* out, unsigned char* l, unsigned char* r) {
+   const WinEntry a = *reinterpret_cast<WinEntry*>(l), b = *reinterpret_cast<WinEntry*>(r);
+   WinEntry o;
+   if (!a.ok) o = b;
+   else if (!b.ok) o = a;
+   else if (FN == 2) o = {b.v < a.v ? b.v : a.v, 1};
+   else if (FN == 3) o = {b.v > a.v ? b.v : a.v, 1};
+   else o = {(int64_t) ((uint64_t) a.v + (uint64_t) b.v), 1};
+   *reinterpret_cast<WinEntry*>(out) = o;
+}
+} // namespace
+} // extern "C++"
+int32_t ref_segment_tree(const int64_t* vals, const uint8_t* valid, int64_t n, int32_t fn, const int64_t* from, const int64_t* to, int64_t nq, int64_t* out_vals, uint8_t* out_valid) {
+   CtxScope scope(1);
+   std::vector<WinEntry> entries((size_t) n);
+   for (int64_t i = 0; i < n; i++) entries[(size_t) i] = {vals[i], valid ? valid[i] : 1};
+   runtime::Buffer buf{(size_t) n * sizeof(WinEntry), reinterpret_cast<uint8_t*>(entries.data())};
+   runtime::SegmentTreeView* view = nullptr;
+   switch (fn) {
+      case 1: view = runtime::SegmentTreeView::build(buf, sizeof(WinEntry), winInit<1>, winCombine<1>, sizeof(WinEntry)); break;
+      case 2: view = runtime::SegmentTreeView::build(buf, sizeof(WinEntry), winInit<2>, winCombine<2>, sizeof(WinEntry)); break;
+      case 3: view = runtime::SegmentTreeView::build(buf, sizeof(WinEntry), winInit<3>, winCombine<3>, sizeof(WinEntry)); break;
+      case 4: view = runtime::SegmentTreeView::build(buf, sizeof(WinEntry), winInit<4>, winCombine<4>, sizeof(WinEntry)); break;
+      default: return -1;
+   }
+   for (int64_t q = 0; q < nq; q++) {
+      WinEntry res{0, 0};
+      view->lookup(reinterpret_cast<uint8_t*>(&res), (size_t) from[q], (size_t) to[q]);
+      out_vals[q] = res.v;
+      out_valid[q] = (uint8_t) (res.ok ? 1 : 0);
+   }
+   return 0;
+}
 } // extern "C"

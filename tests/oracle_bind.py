@@ -196,6 +196,12 @@ class Oracle:
         p64 = C.POINTER(C.c_int64)
         lib.ora_decimal_muldiv.restype = C.c_int32
         lib.ora_decimal_muldiv.argtypes = [p64, p64, C.c_int32, C.c_int32, p64, p64]
+        lib.ora_segment_tree.restype = C.c_int32
+        lib.ora_segment_tree.argtypes = [P, P, C.c_int64, C.c_int32, P, P, C.c_int64, P, P]
+        lib.ora_window.restype = C.c_int32
+        lib.ora_window.argtypes = [P, P, P, P, C.c_int64, C.c_int32, C.c_int64, C.c_int64, P, P]
+        lib.ora_setop_multiplicity.restype = C.c_int64
+        lib.ora_setop_multiplicity.argtypes = [C.c_int32, C.c_int64, C.c_int64]
 
     # scalar
     def hash64(self, v):
@@ -308,6 +314,47 @@ class Oracle:
             return None
         v = ((out[1] & ((1 << 64) - 1)) << 64) | (out[0] & ((1 << 64) - 1))
         return v - (1 << 128) if v >> 127 else v
+
+
+def _lohi(vals):
+    """python ints → int64[n, 2] (lo, hi) two's complement pairs"""
+    out = np.empty((len(vals), 2), dtype=np.int64)
+    for i, v in enumerate(vals):
+        v &= (1 << 128) - 1
+        out[i, 0] = C.c_int64(v & ((1 << 64) - 1)).value
+        out[i, 1] = C.c_int64(v >> 64).value
+    return out
+
+
+def _from_lohi(a):
+    out = []
+    for lo, hi in a.tolist():
+        v = ((hi & ((1 << 64) - 1)) << 64) | (lo & ((1 << 64) - 1))
+        out.append(v - (1 << 128) if v >> 127 else v)
+    return out
+
+
+def segment_tree(oracle, vals, valid, fn, frm, to):
+    """ora_segment_tree: vals python ints, valid 0/1, queries (from[q], to[q]) inclusive → [(value | None)]"""
+    n, nq = len(vals), len(frm)
+    v, ok = _lohi(vals), np.asarray(valid, dtype=np.uint8)
+    f, t = np.asarray(frm, dtype=np.int64), np.asarray(to, dtype=np.int64)
+    ov, ook = np.zeros((nq, 2), np.int64), np.zeros(nq, np.uint8)
+    st = oracle.lib.ora_segment_tree(v.ctypes.data, ok.ctypes.data, n, fn, f.ctypes.data, t.ctypes.data, nq, ov.ctypes.data, ook.ctypes.data)
+    assert st == 0, st
+    return [x if k else None for x, k in zip(_from_lohi(ov), ook.tolist())]
+
+
+def window(oracle, vals, valid, part_start, part_end, fn, frame_from, frame_to):
+    """ora_window over rows already in window order → [(value | None)] per row"""
+    n = len(part_start)
+    v = _lohi(vals) if vals is not None else np.zeros((n, 2), np.int64)
+    ok = np.asarray(valid, dtype=np.uint8) if valid is not None else np.ones(n, np.uint8)
+    ps, pe = np.asarray(part_start, dtype=np.int64), np.asarray(part_end, dtype=np.int64)
+    ov, ook = np.zeros((n, 2), np.int64), np.zeros(n, np.uint8)
+    st = oracle.lib.ora_window(v.ctypes.data, ok.ctypes.data, ps.ctypes.data, pe.ctypes.data, n, fn, frame_from, frame_to, ov.ctypes.data, ook.ctypes.data)
+    assert st == 0, st
+    return [x if k else None for x, k in zip(_from_lohi(ov), ook.tolist())]
 
 
 def load():

@@ -165,3 +165,18 @@ def test_oracle_substr_matches_reference_string_runtime(oracle):
     assert len(cases) >= 1000
     for s, fr, ln, want in cases:
         assert oracle.substr(s, fr, ln).decode() == want, (s, fr, ln)
+
+
+def test_window_frames_match_the_reference_segment_tree(oracle):
+    """ora_window (frames clamped into the partition + the restated SegmentTreeView) against the answers of the
+    reference's real SegmentTreeView for ten frames x SUM / MIN / MAX / COUNT (tests/golden/ref_segtree.npz)"""
+    import oracle_bind
+
+    z = np.load(os.path.join(golden_io.GOLDEN, "ref_segtree.npz"))
+    vals, valid = [int(v) for v in z["vals"]], z["valid"]
+    n = len(vals)
+    for fi, (frm, to) in enumerate(z["frames"].tolist()):
+        for fn in (1, 2, 3, 4):
+            want = [int(v) if (k or fn == 4) else None for v, k in zip(z["f%d_fn%d_val" % (fi, fn)].tolist(), z["f%d_fn%d_ok" % (fi, fn)].tolist())]
+            got = oracle_bind.window(oracle, vals, valid, [0] * n, [n] * n, fn, frm, to)
+            assert got == want, (fi, fn)

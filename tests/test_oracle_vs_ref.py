@@ -205,3 +205,28 @@ def test_extract_year_vs_reference_date_runtime(ref, oracle):
     days = list(range(-800, 800)) + list(range(10950, 11330)) + rng.integers(-100000, 100000, 5000).tolist()  # (a date in ns overflows int64 beyond ±106751 days)
     for d in days:
         assert oracle.extract_year(d) == ref.ref_extract_year(d * 86_400_000_000_000), d
+
+
+def test_segment_tree_restatement_equals_the_real_segment_tree_view(oracle):
+    """ora_segment_tree (recursive build / lookup restated) against src/runtime/SegmentTreeView.cpp compiled in place:
+    SUM / MIN / MAX / COUNT states with NULL entries, random inclusive ranges incl. single entries and the whole view"""
+    import oracle_bind
+
+    lib = C.CDLL(REF_LIB)
+    lib.ref_segment_tree.restype = C.c_int32
+    lib.ref_segment_tree.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 3, 17, 1000):
+        vals = rng.integers(-10 ** 14, 10 ** 14, n).astype(np.int64)
+        valid = (rng.integers(0, 4, n) > 0).astype(np.uint8)
+        frm = rng.integers(0, n, 400).astype(np.int64)
+        to = np.minimum(n - 1, frm + rng.integers(0, max(1, n), 400)).astype(np.int64)
+        frm[0], to[0] = 0, n - 1
+        for fn in (1, 2, 3, 4):
+            ov, ok = np.zeros(len(frm), np.int64), np.zeros(len(frm), np.uint8)
+            assert lib.ref_segment_tree(vals.ctypes.data, valid.ctypes.data, n, fn, frm.ctypes.data, to.ctypes.data, len(frm), ov.ctypes.data, ok.ctypes.data) == 0
+            want = [int(v) if k else None for v, k in zip(ov.tolist(), ok.tolist())]
+            got = oracle_bind.segment_tree(oracle, [int(v) for v in vals], valid, fn, frm, to)
+            if fn == 4:
+                want = [int(v) for v in ov.tolist()]  # COUNT is never NULL
+            assert got == want, (n, fn)

@@ -228,13 +228,13 @@ class Runner:
         n_p, ms_p = prof.get("k_join_probe_count", (0, 0.0))
         rows = db.lineitem.rows
         out = {"probe_rows": rows, "build_rows": db.orders.rows, "matches": matches, "table_slots": ht.slots, "table_bytes": ht.table_bytes,
-               "slot_bytes": ht.table_bytes // max(ht.slots, 1)}  # 4 = direct-addressed (one word per key value), 8 = open addressing
+               "bytes_per_key_value": round(ht.table_bytes / max(ht.slots, 1), 3)}  # 0.25 = rank bitmap, 4 = direct words, 8 x slots/keys = open addressing
         if n_p:
             avg = ms_p / n_p
             out["probe_ms"] = round(avg, 4)
             out["probe_grows_per_s"] = round(rows / (avg * 1e-3) / 1e9, 3)
             # byte model of SURVEY §8(d): key 4 B + one table word per probe (the sector-granular figure is the PMC traffic)
-            out["algorithmic_gbs"] = round(rows * (4 + out["slot_bytes"]) / (avg * 1e-3) / 1e9, 1)
+            out["survey_model_gbs"] = round(rows * 12 / (avg * 1e-3) / 1e9, 1)
         if n_b:
             out["build_ms"] = round(ms_b / n_b, 4)
             out["build_grows_per_s"] = round(db.orders.rows / (ms_b / n_b * 1e-3) / 1e9, 3)
@@ -248,7 +248,7 @@ class Runner:
         if n_p:
             avg = ms_p / n_p
             out["unclustered"] = {"probe_rows": pk.rows, "matches": m2, "probe_ms": round(avg, 4), "probe_grows_per_s": round(pk.rows / (avg * 1e-3) / 1e9, 3),
-                                  "algorithmic_gbs": round(pk.rows * (4 + out["slot_bytes"]) / (avg * 1e-3) / 1e9, 1)}
+                                  "survey_model_gbs": round(pk.rows * 12 / (avg * 1e-3) / 1e9, 1)}
         pk.release()
         ht.release()
         # selective variant: build side filtered to ≈10 % of orders (o_orderdate < 1992-09-01)
@@ -260,7 +260,7 @@ class Runner:
         n_p, ms_p = ctx.prof_all().get("k_join_probe_count", (0, 0.0))
         if n_p:
             avg = ms_p / n_p
-            out["selective"] = {"build_rows": sel.rows, "matches": matches, "table_slots": ht.slots, "slot_bytes": ht.table_bytes // max(ht.slots, 1), "probe_ms": round(avg, 4),
+            out["selective"] = {"build_rows": sel.rows, "matches": matches, "table_slots": ht.slots, "table_bytes": ht.table_bytes, "probe_ms": round(avg, 4),
                                 "probe_grows_per_s": round(rows / (avg * 1e-3) / 1e9, 3)}
         ht.release()
         sel.release()
