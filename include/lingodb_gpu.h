@@ -185,6 +185,14 @@ const char* ldb_gpu_table_col_name(const ldb_table* t, int32_t col);
 int32_t ldb_gpu_table_rename_col(ldb_table* t, int32_t col, const char* name);
 /* width in bytes of one value as resident on the device (8 for narrowed decimals) */
 int32_t ldb_gpu_table_col_width(const ldb_table* t, int32_t col);
+/* utf8 dictionary encoding (the reference stores char(n) / varchar as utf8, LingoDBTable.cpp:184-191): a
+ * column with at most 1024 distinct strings gets an ORDER-PRESERVING dictionary beside its strings — codes follow the
+ * bytewise string order of StringRuntime.cpp:242-256 — so predicates with constants test 4-byte codes and GROUP BY / ORDER
+ * BY keys hash and compare codes; results, joins and the exchange still see the strings.  ldb_gpu_table_register and the
+ * generator call it for every utf8 column (option `dict_encode`, tables of at least `dict_min_rows` rows); an explicit
+ * call encodes a column of a smaller table.  *n_distinct / the return of _dict_size: dictionary entries, -1 = not encoded. */
+int32_t ldb_gpu_table_dict_encode(ldb_ctx* ctx, ldb_table* t, int32_t col, int32_t* n_distinct);
+int32_t ldb_gpu_table_dict_size(const ldb_table* t, int32_t col);
 /* raw device pointers (for RCCL exchange / zero-copy wrap); offsets/validity may be NULL */
 int32_t ldb_gpu_table_col_ptrs(const ldb_table* t, int32_t col, void** values, void** offsets, void** validity,
                                int64_t* value_bytes);

@@ -38,7 +38,7 @@ int64_t ldb_option(const char* name, int64_t dflt) {
 }
 extern "C" int32_t ldb_gpu_set_option(const char* name, int64_t value) {
    if (!name) LDB_FAIL(LDB_ERR_INVALID, "set_option: NULL name");
-   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "gb_direct", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "comm_transport", "comm_timeout_ms"};
+   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "gb_direct", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms"};
    bool ok = false;
    for (const char* k : known) ok |= strcmp(k, name) == 0;
    if (!ok) LDB_FAIL(LDB_ERR_INVALID, "set_option: unknown option '%s'", name);
@@ -502,6 +502,7 @@ extern "C" int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct
          LDB_HIP(hipStreamSynchronize(ctx->stream));
       }
    }
+   LDB_TRY(ldb_table_dict_encode_all(ctx, t.get())); // low-cardinality utf8 columns get an order-preserving dictionary
    *out = t.release();
    return LDB_OK;
 }
@@ -539,6 +540,7 @@ extern "C" int32_t ldb_gpu_table_release(ldb_ctx* ctx, ldb_table* t) {
       ldb_dev_free(ctx, c.values);
       ldb_dev_free(ctx, c.offsets);
       ldb_dev_free(ctx, c.validity);
+      ldb_column_dict_release(ctx, c);
    }
    delete t;
    return LDB_OK;
@@ -911,6 +913,11 @@ int32_t ldb_make_dpred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out) {
       return LDB_OK;
    }
    if (is_str != (p->rhs_kind == LDB_RHS_STRING)) LDB_FAIL(LDB_ERR_INVALID, "filter: constant kind %d does not match column type %d", p->rhs_kind, out->col.type);
+   if (is_str) { // a dictionary-encoded column: the predicate becomes a test on the 4-byte codes
+      bool done = false;
+      LDB_TRY(ldb_dict_rewrite_pred(r, p, out, &done));
+      if (done) return LDB_OK;
+   }
    if (p->op == LDB_F_IN) {
       if (p->n_in < 0 || p->n_in > LDB_MAX_IN) LDB_FAIL(LDB_ERR_UNSUPPORTED, "filter: IN list of %d values (max %d)", p->n_in, LDB_MAX_IN);
       out->n_in = p->n_in;

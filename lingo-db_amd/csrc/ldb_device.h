@@ -398,6 +398,10 @@ __device__ __forceinline__ bool d_eval_pred(PV p, uint64_t i) {
    // narrow integer path: the constant is a 128-bit value; a column value (fits i64) compares
    // against it exactly after placing the constant relative to the i64 range
    int64_t a = d_load_i64(col, row);
+   if (p.m.op == 100) { // LDB_F_CODESET: dictionary code of a utf8 column against the set of codes the string predicate accepts
+      const uint32_t c = (uint32_t) a;
+      return c < 1024u && (((uint8_t) p.m.in_blob[c >> 3] >> (c & 7u)) & 1u);
+   }
    if (p.m.op == LDB_F_IN) {
       for (int k = 0; k < p.m.n_in; k++) {
          bool fits = (p.m.in_hi[k] == ((int64_t) p.m.in_lo[k] >> 63));

@@ -233,7 +233,9 @@ struct GbBuilder {
                LDB_TRY(add_col(tm.f[f].col, &idx));
                out->t[t].f[f].col_idx = idx;
                const ldb_column& c = in->sides[(size_t) tm.f[f].col.side].table->cols[(size_t) tm.f[f].col.col];
-               if (c.validity || in->sides[(size_t) tm.f[f].col.side].rowids) *nullable = *nullable || c.validity != nullptr;
+               const ldb_rel_side& sd = in->sides[(size_t) tm.f[f].col.side];
+               // NULL-able: the column has a validity bitmap, or its side can carry outer-join padding (LDB_NULL_ROW row ids)
+               *nullable = *nullable || c.validity != nullptr || (sd.rowids && sd.may_null);
                bool colf = c.type.type == LDB_T_FLOAT64 || c.type.type == LDB_T_FLOAT32;
                if (colf && !e->is_float) LDB_FAIL(LDB_ERR_INVALID, "expression: float column in an integer expression (set is_float)");
             }
@@ -274,7 +276,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    n_preds = h->n_preds;
    ldb_order_preds(h->preds, n_preds); // cheap conjuncts first, same-column neighbours marked
    h->batch_rows = n_preds >= 2 ? 8 : 4;
-   LDB_TRY(ldb_make_dkeys(in, keys, n_keys, &h->keys));
+   LDB_TRY(ldb_make_dkeys_dict(in, keys, n_keys, &h->keys)); // (dictionary codes stand in for low-cardinality strings: hashing and equality only)
    h->keyless = n_keys == 0;
    GbBuilder b{in, h, {}};
 

@@ -47,6 +47,15 @@ struct ldb_column {
    int64_t value_bytes = 0; // bytes in `values`
    int64_t null_count = 0;
    bool owned = true;
+   // utf8 dictionary (the reference stores char(n) / varchar as utf8, LingoDBTable.cpp:184-191): for a
+   // column with few distinct strings, built at registration — an ORDER-PRESERVING dictionary (codes follow the bytewise
+   // order of the strings, StringRuntime.cpp:242-256) kept BESIDE the strings: dict_codes[row] = code (0xFFFFFFFF for
+   // NULL), `dict` = the distinct strings in code order.  Predicates with constants become code-set tests, group-by and
+   // sort keys read the 4-byte codes; results still show the strings (ldb_dict.hip).
+   uint32_t* dict_codes = nullptr; // device, one per physical row (owned with the column)
+   struct ldb_table* dict = nullptr; // one utf8 column, dict_size rows (owned)
+   int32_t dict_size = 0;
+   std::unordered_map<std::string, std::string>* dict_pred_cache = nullptr; // predicate bytes → 128-byte code set
    // value range of a fixed-width integer-like column, computed on first use and cached (the
    // kind of per-column statistic a catalog keeps; see ldb_column_range)
    mutable bool has_range = false;
@@ -145,6 +154,19 @@ void ldb_mark_same_col(DPred* preds, int32_t n);
 void ldb_like_plan(DPred* d);
 void ldb_order_preds(DPred* preds, int32_t n);
 int32_t ldb_make_dkeys(const ldb_rel* r, const ldb_colref* keys, int32_t n_keys, DKeys* out);
+// the same with dictionary-encoded utf8 columns replaced by their int32 code columns — for consumers that only hash /
+// compare / order the key INSIDE one relation (group-by, sort); never for joins, hash_keys or the exchange's partitioning
+int32_t ldb_make_dcol_dict(const ldb_rel* r, ldb_colref ref, DCol* out);
+int32_t ldb_make_dkeys_dict(const ldb_rel* r, const ldb_colref* keys, int32_t n_keys, DKeys* out);
+// builds the dictionary of a utf8 column if it has at most max_distinct distinct strings (a no-op otherwise)
+int32_t ldb_table_dict_encode(ldb_ctx* ctx, ldb_table* t, int32_t col, int32_t max_distinct);
+int32_t ldb_table_dict_encode_all(ldb_ctx* ctx, ldb_table* t); // every eligible utf8 column (option dict_encode)
+void ldb_column_dict_release(ldb_ctx* ctx, ldb_column& c);
+// a string predicate with a constant over a dictionary-encoded column → a test on the codes; *done = false if not applicable
+int32_t ldb_dict_rewrite_pred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out, bool* done);
+#define LDB_F_CODESET 100 /* internal DPred op: pass iff bit (code) of in_blob is set */
+#define LDB_RHS_CODESET 100
+#define LDB_DICT_MAX 1024 /* codes per dictionary = bits of DPred::in_blob */
 int32_t ldb_width_of(const ldb_coltype& t, int narrow);
 
 // launch geometry: blocks for a grid-stride kernel over n items

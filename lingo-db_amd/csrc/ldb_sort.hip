@@ -388,7 +388,7 @@ static int32_t sort_perm(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, 
    bool any_chk = false;
    for (int s = 0; s < n_specs; s++) {
       DSortSpec& sp = h->specs[s];
-      LDB_TRY(ldb_make_dcol(in, specs[s].col, &sp.col));
+      LDB_TRY(ldb_make_dcol_dict(in, specs[s].col, &sp.col)); // (an order-preserving dictionary: sorting the codes sorts the strings)
       sp.descending = specs[s].descending ? 1 : 0;
       const bool padded = sp.col.rowids && in->sides[(size_t) specs[s].col.side].may_null; // outer-join padding
       if (n && (sp.col.validity || padded || sp.col.type == LDB_T_UTF8)) {

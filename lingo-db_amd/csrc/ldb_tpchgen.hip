@@ -362,6 +362,7 @@ extern "C" int32_t ldb_gpu_tpch_generate(ldb_ctx* ctx, int32_t table_id, int64_t
    }
    LDB_HIP(hipGetLastError());
    LDB_HIP(hipStreamSynchronize(ctx->stream));
+   LDB_TRY(ldb_table_dict_encode_all(ctx, t.get())); // as ldb_gpu_table_register does for imported tables
    *out = t.release();
    return LDB_OK;
 }

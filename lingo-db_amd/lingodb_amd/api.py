@@ -196,6 +196,15 @@ class Table:
         check(self.ctx.lib.ldb_gpu_table_coltype(self.h, i, C.byref(t)))
         return t
 
+    def dict_size(self, i):
+        """entries of the column's utf8 dictionary, -1 = not dictionary-encoded"""
+        return self.ctx.lib.ldb_gpu_table_dict_size(self.h, i)
+
+    def dict_encode(self, i):
+        n = C.c_int32()
+        check(self.ctx.lib.ldb_gpu_table_dict_encode(self.ctx.h, self.h, i, C.byref(n)))
+        return n.value
+
     def col_width(self, i):
         return self.ctx.lib.ldb_gpu_table_col_width(self.h, i)
 

@@ -183,6 +183,8 @@ GPU_API = {
     "ldb_gpu_table_col_ptrs": (i32, [P, i32, PP, PP, PP, C.POINTER(i64)]),
     "ldb_gpu_table_set_rows": (i32, [P, i64]),
     "ldb_gpu_table_read_fixed": (i32, [P, P, i32, P, i64]),
+    "ldb_gpu_table_dict_encode": (i32, [P, P, i32, C.POINTER(C.c_int32)]),
+    "ldb_gpu_table_dict_size": (i32, [P, i32]),
     "ldb_gpu_table_row_valid": (i32, [P, P, i32, i64, C.POINTER(C.c_int32)]),
     "ldb_gpu_table_write_fixed": (i32, [P, P, i32, P, i64]),
     "ldb_gpu_memcpy_d2d": (i32, [P, P, P, i64]),

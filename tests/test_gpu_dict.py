@@ -1,0 +1,126 @@
+"""utf8 dictionary encoding at registration (csrc/ldb_dict.hip): every result must be what the string path
+gives — the tests run each operator twice, on a table registered with dictionaries (the default) and on the same table
+registered with option dict_encode = 0, and on small inputs also against Python's own string semantics (bytewise order =
+std::string_view order, StringRuntime.cpp:242-256)."""
+import collections
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from lingodb_amd import api, capi
+
+pytestmark = pytest.mark.gpu
+WORDS = ["", "AIR", "AIR REG", "FOB", "MAIL", "RAIL", "REG AIR", "SHIP", "TRUCK", "Zürich", "a", "ab", "abc", "b", "ünïcode", "中文"]
+
+
+def make(n, seed=1, nulls=True):
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, len(WORDS), n)
+    s = [None if nulls and i % 17 == 3 else WORDS[k] for i, k in enumerate(idx.tolist())]
+    return pa.table({"s": pa.array(s, pa.string()), "v": pa.array(rng.integers(0, 1000, n).astype(np.int64)), "k": pa.array(rng.integers(0, 50, n).astype(np.int32))})
+
+
+@pytest.fixture(scope="module")
+def tables(ctx):
+    t = make(50_000)
+    lib = capi.gpu_lib()
+    enc = ctx.register("dict_on", t)
+    lib.ldb_gpu_set_option(b"dict_encode", 0)
+    try:
+        plain = ctx.register("dict_off", t)
+    finally:
+        lib.ldb_gpu_set_option(b"dict_encode", 1)
+    assert enc.dict_size(0) == len(WORDS) and plain.dict_size(0) == -1
+    return t, enc, plain
+
+
+PREDS = [(capi.F_EQ, "MAIL", None), (capi.F_NEQ, "MAIL", None), (capi.F_LT, "FOB", None), (capi.F_LTE, "FOB", None), (capi.F_GT, "a", None), (capi.F_GTE, "ab", None),
+         (capi.F_EQ, "not there", None), (capi.F_NEQ, "not there", None), (capi.F_LT, "", None), (capi.F_GTE, "", None),
+         (capi.F_IN, None, ["MAIL", "SHIP", "nope"]), (capi.F_IN, None, ["nope"]), (capi.F_LIKE, "%AIR%", None), (capi.F_NOT_LIKE, "%AIR%", None),
+         (capi.F_LIKE, "a%", None), (capi.F_LIKE, "_", None), (capi.F_LIKE, "%", None), (capi.F_LIKE, "R_IL", None), (capi.F_LIKE, "Z%ch", None)]
+
+
+@pytest.mark.parametrize("op,value,values", PREDS)
+def test_predicates_equal_the_string_path(tables, op, value, values):
+    t, enc, plain = tables
+    mk = lambda: [api.pred((0, 0), op, value, values=values)]  # noqa: E731
+    a, b = enc.rel().scan_filter(mk()).rowids(0), plain.rel().scan_filter(mk()).rowids(0)
+    assert np.array_equal(a, b), (op, value, values)
+    s = t.column(0).to_pylist()
+    import re
+
+    def like(x, pat):
+        rx = "".join(".*" if ch == "%" else "." if ch == "_" else re.escape(ch) for ch in pat)
+        return re.fullmatch(rx, x, re.S) is not None
+
+    cmp_ = {capi.F_EQ: lambda x: x == value, capi.F_NEQ: lambda x: x != value, capi.F_LT: lambda x: x.encode() < value.encode(), capi.F_LTE: lambda x: x.encode() <= value.encode(),
+            capi.F_GT: lambda x: x.encode() > value.encode(), capi.F_GTE: lambda x: x.encode() >= value.encode(), capi.F_IN: lambda x: x in values,
+            capi.F_LIKE: lambda x: like(x, value), capi.F_NOT_LIKE: lambda x: not like(x, value)}[op]
+    assert a.tolist() == [i for i, x in enumerate(s) if x is not None and cmp_(x)]
+    # the same conjunct fused into a count (the batched evaluator) and next to an integer conjunct
+    both = lambda: [api.pred((0, 2), capi.F_LT, 25), api.pred((0, 0), op, value, values=values)]  # noqa: E731
+    assert enc.rel().scan_count(both()) == plain.rel().scan_count(both())
+
+
+def test_group_by_and_sort_on_codes(tables):
+    t, enc, plain = tables
+    aggs = lambda: [api.agg(capi.AGG_SUM, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT_STAR)]  # noqa: E731
+    for keys in ([(0, 0)], [(0, 0), (0, 2)], [(0, 2), (0, 0)]):
+        ga, gb = enc.rel().groupby(keys, aggs(), est_groups=2000).to_arrow(), plain.rel().groupby(keys, aggs(), est_groups=2000).to_arrow()
+        rows = lambda g: collections.Counter(zip(*[c.to_pylist() for c in g.columns]))  # noqa: E731
+        assert rows(ga) == rows(gb) and ga.schema == gb.schema, keys  # key columns come out as utf8 either way, NULL group included
+    nn = [api.pred((0, 0), capi.F_NOTNULL)]
+    specs = [api.sort_spec((0, 0), True), api.sort_spec((0, 2))]
+    fa, fb = enc.rel().scan_filter(nn), plain.rel().scan_filter([api.pred((0, 0), capi.F_NOTNULL)])
+    sa, sb = fa.sort(specs).materialize([(0, 0), (0, 2)]).to_arrow(), fb.sort(specs).materialize([(0, 0), (0, 2)]).to_arrow()
+    assert sa.equals(sb)
+    s = sa.column(0).to_pylist()
+    assert all(s[i].encode() >= s[i + 1].encode() for i in range(len(s) - 1))  # bytewise descending: the dictionary preserves string order
+    ta = fa.topk([api.sort_spec((0, 0)), api.sort_spec((0, 1), True)], 37).materialize([(0, 0), (0, 1)]).to_arrow()
+    tb = fb.topk([api.sort_spec((0, 0)), api.sort_spec((0, 1), True)], 37).materialize([(0, 0), (0, 1)]).to_arrow()
+    assert ta.equals(tb)
+
+
+def test_joins_and_hashes_still_see_strings(tables, ctx):
+    """joins, db.hash and the shuffle's partitioning must not depend on a rank-local dictionary"""
+    t, enc, plain = tables
+    assert np.array_equal(enc.rel().hash_keys([(0, 0)]), plain.rel().hash_keys([(0, 0)]))
+    dim = ctx.register("dict_dim", pa.table({"w": pa.array(["MAIL", "SHIP", "abc", "zzz"]), "n": pa.array([1, 2, 3, 4], pa.int32())}))
+    ja = dim.rel().join_build([(0, 0)], unique=True).probe(enc.rel(), [(0, 0)])
+    jb = dim.rel().join_build([(0, 0)], unique=True).probe(plain.rel(), [(0, 0)])
+    assert np.array_equal(ja.rowids(0), jb.rowids(0)) and np.array_equal(ja.rowids(1), jb.rowids(1)) and ja.rows > 0
+    pa_, ca = enc.rel().partition([(0, 0)], 3, [(0, 0), (0, 1)])
+    pb_, cb = plain.rel().partition([(0, 0)], 3, [(0, 0), (0, 1)])
+    assert ca == cb and pa_.to_arrow().equals(pb_.to_arrow())
+
+
+def test_high_cardinality_columns_are_left_alone(ctx):
+    n = 100_000
+    t = pa.table({"c": pa.array(["comment %d" % (i * 7919 % n) for i in range(n)]), "few": pa.array(["x%d" % (i % 3) for i in range(n)])})
+    dev = ctx.register("dict_hi", t)
+    assert dev.dict_size(0) == -1 and dev.dict_size(1) == 3
+    small = ctx.register("dict_small", t.slice(0, 100))  # below dict_min_rows: not encoded automatically …
+    assert small.dict_size(1) == -1
+    assert small.dict_encode(1) == 3 and small.dict_size(1) == 3  # … but on request
+    got = small.rel().scan_filter([api.pred((0, 1), capi.F_EQ, "x1")]).rowids(0)
+    assert got.tolist() == [i for i in range(100) if i % 3 == 1]
+
+
+def test_tpch_q12_q16_q19_unchanged_by_the_dictionary(ctx):
+    """the three plans whose string predicates / group keys go through codes now: same rows with dict_encode = 0"""
+    import tpch_plans
+
+    lib = capi.gpu_lib()
+    queries = [12, 16, 19, 4, 3]
+    on = tpch_plans.Runner(ctx, tpch_plans.Database(ctx, 60_000, 0, 1, queries, False), 1, None, None)
+    assert on.db.lineitem.dict_size(on.db.lineitem.col("l_shipmode")) == 7
+    lib.ldb_gpu_set_option(b"dict_encode", 0)
+    try:
+        off = tpch_plans.Runner(ctx, tpch_plans.Database(ctx, 60_000, 0, 1, queries, False), 1, None, None)
+        assert off.db.lineitem.dict_size(off.db.lineitem.col("l_shipmode")) == -1
+        want = {q: off.run(q).to_arrow() for q in queries}
+    finally:
+        lib.ldb_gpu_set_option(b"dict_encode", 1)
+    for q in queries:
+        assert on.run(q).to_arrow().equals(want[q]), q
