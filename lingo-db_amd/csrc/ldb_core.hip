@@ -38,7 +38,7 @@ int64_t ldb_option(const char* name, int64_t dflt) {
 }
 extern "C" int32_t ldb_gpu_set_option(const char* name, int64_t value) {
    if (!name) LDB_FAIL(LDB_ERR_INVALID, "set_option: NULL name");
-   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "gb_direct", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms"};
+   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "gb_direct", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms"};
    bool ok = false;
    for (const char* k : known) ok |= strcmp(k, name) == 0;
    if (!ok) LDB_FAIL(LDB_ERR_INVALID, "set_option: unknown option '%s'", name);
@@ -1206,6 +1206,15 @@ int32_t ldb_gather_columns(ldb_ctx* ctx, const ldb_rel* r, const ldb_colref* ref
       if (p.slot_nulls >= 0) {
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &out->validity, (size_t) ((n + 7) / 8 + 8)));
          if (n) hipLaunchKernelGGL(k_gather_validity, dim3(grid), dim3(256), 0, ctx->stream, src.validity, p.rowids, (uint64_t*) out->validity, n, d_words + p.slot_nulls);
+      }
+      if (src.type.type == LDB_T_UTF8 && src.dict_codes && src.dict && n >= 64) {
+         // the gathered column inherits the source's dictionary: codes gathered alongside, the dictionary table shared
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &out->dict_codes, 4 * (size_t) n));
+         hipLaunchKernelGGL(k_gather_fixed<uint32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*) src.dict_codes, p.rowids, out->dict_codes, n);
+         out->dict = src.dict;
+         out->dict->dict_refs++;
+         out->dict_size = src.dict_size;
+         out->dict_pred_cache = new std::unordered_map<std::string, std::string>();
       }
       if (src.type.type == LDB_T_UTF8) {
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &p.lens, sizeof(int64_t) * (size_t) (n + 1)));

@@ -19,7 +19,10 @@
 //     which takes the branch-free batched path).  Sets are cached per column and predicate text;
 //   * GROUP BY / ORDER BY keys read the codes (ldb_make_dkeys_dict / ldb_make_dcol_dict): hashing and comparing 4 bytes
 //     instead of strings, and because the dictionary preserves order, sorting codes sorts strings.  Output key columns
-//     are still gathered from the strings.
+//     are still gathered from the strings;
+//   * a column GATHERED from a dictionary-encoded one (ldb_gpu_materialize, the key columns of a group-by result) inherits
+//     the dictionary: its codes are gathered alongside and the dictionary table is shared — the second-level GROUP BY and
+//     the ORDER BY over Q16's 28 k result groups run on codes too.
 // Joins, db.hash (ldb_gpu_hash_keys) and the exchange's hash partitioning keep the strings: their hashes must agree with
 // the other side / the other ranks, whose dictionaries differ.
 #include "ldb_internal.h"
@@ -31,7 +34,7 @@
 void ldb_column_dict_release(ldb_ctx* ctx, ldb_column& c) {
    ldb_dev_free(ctx, c.dict_codes);
    c.dict_codes = nullptr;
-   if (c.dict) ldb_gpu_table_release(ctx, c.dict);
+   if (c.dict && --c.dict->dict_refs == 0) ldb_gpu_table_release(ctx, c.dict);
    c.dict = nullptr;
    c.dict_size = 0;
    delete c.dict_pred_cache;

@@ -110,6 +110,7 @@ struct ldb_table {
    std::string name;
    int64_t n_rows = 0;
    std::vector<ldb_column> cols;
+   int32_t dict_refs = 1; // a dictionary table is shared by the columns gathered from the one it was built for
 };
 
 struct ldb_rel_side {

@@ -40,7 +40,9 @@ struct ldb_hashtable {
    int32_t chained = 0; // one slot per distinct key, rows linked through next[] (DJoin::chained)
    uint32_t* next = nullptr;
    int32_t direct = 0; // 1: slots = uint32_t[kmax - kmin + 1] indexed by key - kmin; 2: rank-bitmap words (DJoin::direct)
-   int32_t rank_sorted = 0; // direct == 2: a key's rank IS its build row (ascending keys without NULLs); else next[] = rank → row
+   int32_t rank_sorted = 0;
+   uint32_t* coarse = nullptr; // one bit per 64 key values (DJoin::has_coarse), or NULL
+   uint32_t coarse_words = 0; // direct == 2: a key's rank IS its build row (ascending keys without NULLs); else next[] = rank → row
    size_t slot_bytes = 0; // bytes of the slot array (cap x 8, or cap x 4 when direct)
    // the table owns its device buffers: an early error return from the build frees them with the object
    ~ldb_hashtable() {
@@ -48,6 +50,7 @@ struct ldb_hashtable {
       ldb_dev_free(ctx, slots);
       ldb_dev_free(ctx, key_bits);
       ldb_dev_free(ctx, next);
+      ldb_dev_free(ctx, coarse);
    }
 };
 
@@ -60,6 +63,18 @@ __global__ void k_join_rank_perm(const DJoin* __restrict__ d) { join_rank_perm_b
 // rank-bitmap build, pass 2: popcounts of the presence halves → (scan) → prefix halves
 __global__ void k_rank_pop(const uint64_t* __restrict__ tab, uint64_t n_words, uint32_t* __restrict__ pop) {
    for (uint64_t w = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; w < n_words; w += (uint64_t) gridDim.x * blockDim.x) pop[w] = (uint32_t) __popc((uint32_t) tab[w]);
+}
+// coarse bit b ⇔ some build key among the 64 key values of rank words 2b, 2b + 1
+__global__ void k_rank_coarse(const uint64_t* __restrict__ tab, uint64_t n_words, uint32_t* __restrict__ coarse, uint32_t coarse_words) {
+   for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < coarse_words; c += gridDim.x * blockDim.x) {
+      uint32_t m = 0;
+      for (uint32_t b = 0; b < 32; b++) {
+         const uint64_t w = ((uint64_t) c * 32 + b) * 2;
+         const uint32_t any = (w < n_words ? (uint32_t) tab[w] : 0u) | (w + 1 < n_words ? (uint32_t) tab[w + 1] : 0u);
+         if (any) m |= 1u << b;
+      }
+      coarse[c] = m;
+   }
 }
 __global__ void k_rank_prefix(uint64_t* __restrict__ tab, uint64_t n_words, const uint32_t* __restrict__ off) {
    for (uint64_t w = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; w < n_words; w += (uint64_t) gridDim.x * blockDim.x) tab[w] = (tab[w] & 0xFFFFFFFFull) | ((uint64_t) off[w] << 32);
@@ -98,6 +113,8 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
       meta->kmult32 = meta->ksh = 0;
       meta->key_bits = 0;
       meta->next = 0;
+      meta->coarse = 0;
+      meta->coarse_words = 0;
       ldb_jit_strip_keys(meta->bkeys);
       ldb_jit_strip_keys(meta->pkeys);
       for (int p = 0; p < LDB_MAX_PREDS; p++) ldb_jit_strip_pred(meta->ppreds[p]);
@@ -118,12 +135,17 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
       }
       spec = ldb_jit_kernel(ctx->device, "ldb_join_kernel.h", "DJoin", one.empty() ? JOIN_SPEC_SRC : one.c_str(), spec_name, meta.get(), sizeof(DJoin), &why);
    }
+   // a launch with a coarse key bitmap: 512-thread workgroups, each staging the bitmap (<= 40 KB) in dynamic LDS — four of
+   // them share a CU's 160 KB, i.e. the same 32 waves per CU as the 256-thread launches
+   const unsigned block = h->has_coarse ? 512u : 256u;
+   const unsigned lds = h->has_coarse ? 4u * h->coarse_words : 0u;
+   if (h->has_coarse) grid = (int) std::max<int64_t>(1, std::min<int64_t>(((int64_t) h->n_rows + 511) / 512, (int64_t) ctx->cus * 4));
    LdbProf prof_(ctx, prof_name);
    if (spec) {
       void* params[] = {(void*) &d};
-      LDB_HIP(hipModuleLaunchKernel(spec, (unsigned) grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
+      LDB_HIP(hipModuleLaunchKernel(spec, (unsigned) grid, 1, 1, block, 1, 1, lds, ctx->stream, params, nullptr));
    } else {
-      hipLaunchKernelGGL(generic, dim3(grid), dim3(256), 0, ctx->stream, d);
+      hipLaunchKernelGGL(generic, dim3(grid), dim3(block), lds, ctx->stream, d);
    }
    LDB_HIP(hipGetLastError());
    return LDB_OK;
@@ -173,6 +195,10 @@ bool ldb_join_jit_check(std::string* log) {
    if (!ldb_jit_compile_only("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, m.get(), sizeof(DJoin), log)) return false;
    m->rank_sorted = 0;
    m->kind = LDB_JOIN_SEMI;
+   if (!ldb_jit_compile_only("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, m.get(), sizeof(DJoin), log)) return false;
+   // … and with the LDS-resident coarse key bitmap in front of it (512-thread workgroups)
+   m->rank_sorted = 1;
+   m->has_coarse = 1;
    return ldb_jit_compile_only("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, m.get(), sizeof(DJoin), log);
 }
 
@@ -189,6 +215,26 @@ __global__ void k_bitmap_expand(const uint64_t* __restrict__ bitmap, const uint3
       uint64_t m = bitmap[w];
       if ((m >> lane) & 1) out[word_off[w] + d_rank_in(m)] = (uint32_t) (w * 64 + lane);
    }
+}
+// the same for SPARSE bitmaps: one LANE per word — a wave reads 64 words with one coalesced load and only the lanes whose
+// word is non-zero write (a wave per word spends a whole iteration on every empty word: 9.4 M iterations for a 600 M-row
+// probe of which 95 % produce nothing)
+__global__ void k_bitmap_expand_sparse(const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ word_off, uint32_t* __restrict__ out, uint64_t n_words) {
+   for (uint64_t w = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; w < n_words; w += (uint64_t) gridDim.x * blockDim.x) {
+      uint64_t m = bitmap[w];
+      if (!m) continue;
+      uint32_t at = word_off[w];
+      const uint32_t base = (uint32_t) (w * 64);
+      while (m) {
+         out[at++] = base + (uint32_t) __builtin_ctzll(m);
+         m &= m - 1;
+      }
+   }
+}
+// picks the scheme by density: fewer than one set bit in eight → lane per word
+static void launch_bitmap_expand(ldb_ctx* ctx, const uint64_t* bitmap, const uint32_t* off, uint32_t* out, int64_t n_words, uint64_t total) {
+   if (total * 8 < (uint64_t) n_words * 64) hipLaunchKernelGGL(k_bitmap_expand_sparse, dim3(ldb_grid_for(ctx, n_words, 256, 8)), dim3(256), 0, ctx->stream, bitmap, off, out, (uint64_t) n_words);
+   else hipLaunchKernelGGL(k_bitmap_expand, dim3(ldb_grid_for(ctx, n_words * 64, 256, 8)), dim3(256), 0, ctx->stream, bitmap, off, out, (uint64_t) n_words);
 }
 __global__ void k_iota_u32j(uint32_t* out, uint64_t n) {
    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = (uint32_t) i;
@@ -517,6 +563,15 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
             ht->cap = (uint64_t) range0;
             ht->slot_bytes = 8 * (size_t) n_words;
             ht->rank_sorted = (fl[0] & 4u) ? 0 : 1;
+            // the LDS-resident coarse filter for selective builds over a small key range (DJoin::has_coarse): at most 40 KB
+            // (four 512-thread workgroups per CU) and worth it when most 64-key blocks are empty
+            const uint64_t cwords = (uint64_t) (range0 / 64 / 32) + 1;
+            if (ldb_option("join_coarse", 1) != 0 && cwords * 4 <= 40 * 1024 && (unsigned __int128) back[2] * 64 * 2 <= range0) {
+               LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->coarse, 4 * (size_t) cwords));
+               ht->coarse_words = (uint32_t) cwords;
+               hipLaunchKernelGGL(k_rank_coarse, dim3((unsigned) ((cwords + 255) / 256)), dim3(256), 0, ctx->stream, (const uint64_t*) tab, n_words, ht->coarse, (uint32_t) cwords);
+               LDB_HIP(hipGetLastError());
+            }
             if (!ht->rank_sorted) {
                LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) (build->n_rows ? build->n_rows : 1)));
                h->next = (uint64_t) ht->next;
@@ -689,6 +744,11 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    h->build_unique = (ht->unique && !ht->chained) ? 1 : 0;
    // a lazy probe relation brings its filter along: evaluated inside the probe kernel
    h->n_ppreds = (int32_t) probe->pending.size();
+   if (ht->coarse && probe->pending.empty() && probe->n_rows >= (1 << 22)) { // (the staging costs every workgroup 56 KB of loads: large probes only)
+      h->coarse = (uint64_t) ht->coarse;
+      h->coarse_words = ht->coarse_words;
+      h->has_coarse = 1;
+   }
    for (size_t p = 0; p < probe->pending.size(); p++) h->ppreds[p] = probe->pending[p];
    ldb_order_preds(h->ppreds, h->n_ppreds);
    if (n_resid < 0 || n_resid > LDB_MAX_RESID || (n_resid && !resid)) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: %d residual conjuncts (max %d)", n_resid, LDB_MAX_RESID);
@@ -830,7 +890,7 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       if (nbw) {
          hipLaunchKernelGGL(k_word_pop, dim3(ldb_grid_for(ctx, nbw, 256, 8)), dim3(256), 0, ctx->stream, bitmap, pop, (uint64_t) nbw);
          LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, nbw, nullptr));
-         if (total) hipLaunchKernelGGL(k_bitmap_expand, dim3(ldb_grid_for(ctx, nbw * 64, 256, 8)), dim3(256), 0, ctx->stream, bitmap, off, sel, (uint64_t) nbw);
+         if (total) launch_bitmap_expand(ctx, bitmap, off, sel, nbw, total);
       }
       LDB_HIP(hipGetLastError());
       ldb_dev_free(ctx, flags);
@@ -897,7 +957,7 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       if (n_words) {
          hipLaunchKernelGGL(k_word_pop, dim3(ldb_grid_for(ctx, n_words, 256, 8)), dim3(256), 0, ctx->stream, bitmap, pop, (uint64_t) n_words);
          LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, n_words, nullptr));
-         if (total) hipLaunchKernelGGL(k_bitmap_expand, dim3(ldb_grid_for(ctx, n_words * 64, 256, 8)), dim3(256), 0, ctx->stream, bitmap, off, sel, (uint64_t) n_words);
+         if (total) launch_bitmap_expand(ctx, bitmap, off, sel, n_words, total);
       }
       LDB_HIP(hipGetLastError());
       ldb_dev_free(ctx, bitmap);
@@ -940,7 +1000,7 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
          if (n_words && produced) {
             hipLaunchKernelGGL(k_word_pop, dim3(ldb_grid_for(ctx, n_words, 256, 8)), dim3(256), 0, ctx->stream, bitmap, pop, (uint64_t) n_words);
             LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, n_words, nullptr));
-            hipLaunchKernelGGL(k_bitmap_expand, dim3(ldb_grid_for(ctx, n_words * 64, 256, 8)), dim3(256), 0, ctx->stream, bitmap, off, op, (uint64_t) n_words);
+            launch_bitmap_expand(ctx, bitmap, off, op, n_words, produced);
             hipLaunchKernelGGL(k_compose_null, dim3(ldb_grid_for(ctx, (int64_t) produced, 256, 8)), dim3(256), 0, ctx->stream, (const uint32_t*) match, (const uint32_t*) op, ob, produced);
          }
          LDB_HIP(hipGetLastError());

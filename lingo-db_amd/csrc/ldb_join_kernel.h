@@ -32,6 +32,8 @@ struct DJoin {
    uint32_t kmult32, ksh; // slot32: slot = mulhi32((key - kmin) << ksh, kmult32) — one 32-bit multiply
    uint64_t key_bits; // uint32_t*: has_key_bits: bit (key - kmin) set ⇔ key is in the table
    uint64_t next; // uint32_t*: chained: next[row] = following row of the same key + 1 (0 = end)
+   uint64_t coarse; // const uint32_t*: has_coarse: one bit per 64 key values (any build key in that block?)
+   uint32_t coarse_words, pad_c;
    // ---- metadata
    int32_t key32;
    int32_t kind;
@@ -82,10 +84,26 @@ struct DJoin {
    // against 4 bytes per key VALUE for direct == 1 and 16-32 bytes per build ROW for open addressing.
    int32_t direct;
    int32_t rank_sorted;
+   // A selective build side over a small key range (Q17's 20 k of 20 M part keys) leaves almost every probe a miss, yet
+   // each miss costs its lane one L2 request for the table word: 600 M random 8-byte requests run at the L2's request
+   // rate (~200 G/s, 0.1 of the HBM roofline) although the 5 MB table sits in L2.  `has_coarse`: a bitmap with one bit per
+   // 64 key values (20 M keys: 39 KB) is copied into LDS by every workgroup (512 threads: four of them share a CU's 160 KB)
+   // and tested first — a clear bit proves the miss without leaving the CU.  Only for probe launches without a fused
+   // filter (the tile kernels are written for 256-thread workgroups).
+   int32_t has_coarse;
+   int32_t pad_m;
    DJoinResid resid[LDB_MAX_RESID];
    DPred ppreds[LDB_MAX_PREDS];
 };
 
+extern __shared__ uint32_t ldb_join_lds[]; // dynamic LDS of the probe kernels: the coarse key bitmap (has_coarse), else empty
+__device__ __forceinline__ void d_stage_coarse(const DJoin& m, const DJoin* __restrict__ d) {
+   if (!m.has_coarse) return;
+   const uint32_t* src = gptr<uint32_t>(d->coarse);
+   for (uint32_t i = threadIdx.x; i < d->coarse_words; i += blockDim.x) ldb_join_lds[i] = src[i];
+   __syncthreads();
+}
+__device__ __forceinline__ bool d_coarse_hit(uint32_t r) { return (ldb_join_lds[r >> 11] >> ((r >> 6) & 31u)) & 1u; }
 __device__ __forceinline__ bool d_probe_pass(const DJoin& m, const DJoin* __restrict__ d, uint64_t i) {
    bool pass = true;
    const int np = m.n_ppreds;
@@ -460,6 +478,7 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
          for (int u = 0; u < U; u++) {
             r[u] = k32[u] - kmin32;
             live[u] = live[u] && r[u] <= span; // outside the build key range
+            if (m.has_coarse) live[u] = live[u] && d_coarse_hit(live[u] ? r[u] : 0u); // no build key in its 64-key block (LDS)
          }
          if (m.has_key_bits) {
             const uint32_t* bits = gptr<uint32_t>(d->key_bits);
@@ -672,12 +691,13 @@ struct DProbePipe {
    uint64_t w[2][U]; // pw: table words in flight, alternating sets (direct == 1 uses the low half)
    uint32_t off[2][U]; // pw: the keys' table offsets (key - kmin), ~0 = outside the table's range
    // the table offsets of the keys in k[]; the words are loaded by words_at
-   __device__ __forceinline__ void offsets_of(const DJoin* __restrict__ d, int set) {
+   __device__ __forceinline__ void offsets_of(const DJoin* __restrict__ d, int set, bool has_coarse) {
       const uint32_t kmin32 = (uint32_t) d->kmin, span = (uint32_t) (d->kmax - d->kmin);
 #pragma unroll
       for (int u = 0; u < U; u++) {
          const uint32_t r = k[u] - kmin32;
          off[set][u] = r <= span ? r : 0xFFFFFFFFu;
+         if (has_coarse && r <= span && !d_coarse_hit(r)) off[set][u] = 0xFFFFFFFFu; // a proven miss never asks the L2 for its word
       }
    }
    __device__ __forceinline__ void words_at(const DJoin& m, const DJoin* __restrict__ d, int set) {
@@ -698,7 +718,7 @@ struct DProbePipe {
       }
       if (pf(m)) d_prefetch_keys32<U>(d, row0, n, k);
       if (pw(m)) {
-         offsets_of(d, 0);
+         offsets_of(d, 0, m.has_coarse != 0);
          d_prefetch_keys32<U>(d, row0 + stride, n, k);
          words_at(m, d, 0);
       }
@@ -710,7 +730,7 @@ struct DProbePipe {
       if (pw(m)) {
 #pragma unroll
          for (int u = 0; u < U; u++) LDB_PIN(k[u]); // keys(s+1) are here (words(s) may still be in flight)
-         offsets_of(d, 1 - P);
+         offsets_of(d, 1 - P, m.has_coarse != 0);
          d_prefetch_keys32<U>(d, row0 + 2 * stride, n, k); // keys(s+2), into the registers just consumed
          asm volatile("" : : : "memory"); // (keeps the key loads ahead of the word loads in issue order; no wait)
          words_at(m, d, 1 - P); // words(s+1)
@@ -774,6 +794,7 @@ __device__ __forceinline__ void d_pairs_of_rows(const DJoin& m, const DJoin* __r
 }
 __device__ __forceinline__ void join_probe_pairs_count_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows;
+   d_stage_coarse(m, d); // (a no-op unless the launch brought a coarse key bitmap)
    const uint64_t n_chunks = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;
    const uint64_t wave = d_wave_id();
@@ -806,6 +827,7 @@ __device__ __forceinline__ void join_probe_pairs_count_body(const DJoin& m, cons
 }
 __device__ __forceinline__ void join_probe_pairs_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows;
+   d_stage_coarse(m, d); // (a no-op unless the launch brought a coarse key bitmap)
    const uint64_t n_chunks = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;
    const uint64_t wave = d_wave_id();
@@ -856,6 +878,7 @@ __device__ __forceinline__ void join_probe_pairs_body(const DJoin& m, const DJoi
 // segments next to each other and, for clustered keys, its slots share cache lines.
 __device__ __forceinline__ void join_probe_count_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows;
+   d_stage_coarse(m, d); // (a no-op unless the launch brought a coarse key bitmap)
    unsigned long long local = 0;
    const uint32_t lane = threadIdx.x & 63;
    const uint64_t wave = d_wave_id();
@@ -1039,6 +1062,7 @@ __device__ __forceinline__ void join_probe_unique_filtered_body(const DJoin& m, 
 #define JE_U 4
 __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows;
+   d_stage_coarse(m, d); // (a no-op unless the launch brought a coarse key bitmap)
    if (m.n_ppreds > 0) { // fused filter: tile compaction (never MARK: the host forces those)
       __shared__ JoinTile st;
       const uint64_t n_words = (n + 63) / 64, n_tiles = (n + JT_ROWS - 1) / JT_ROWS;
@@ -1096,6 +1120,7 @@ __device__ __forceinline__ void join_probe_exists_body(const DJoin& m, const DJo
 // The flag store is idempotent, so no atomic is needed (the CPU path uses an atomic OR).
 __device__ __forceinline__ void join_probe_markbuild_body(const DJoin& m, const DJoin* __restrict__ d) {
    const uint64_t n = d->n_rows;
+   d_stage_coarse(m, d); // (a no-op unless the launch brought a coarse key bitmap)
    uint8_t* flags = gptr_mut<uint8_t>(d->mark);
    if (m.n_ppreds > 0) { // fused filter: tile compaction, then every lane probes
       __shared__ JoinTile st;
@@ -1169,6 +1194,7 @@ __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJo
       join_probe_unique_filtered_body(m, d);
       return;
    }
+   d_stage_coarse(m, d);
    const uint64_t n = d->n_rows;
    const uint64_t n_words = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;

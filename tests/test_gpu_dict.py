@@ -124,3 +124,21 @@ def test_tpch_q12_q16_q19_unchanged_by_the_dictionary(ctx):
         lib.ldb_gpu_set_option(b"dict_encode", 1)
     for q in queries:
         assert on.run(q).to_arrow().equals(want[q]), q
+
+
+def test_gathered_columns_inherit_the_dictionary(tables):
+    """a group-by result's key column and a materialised column keep the source's dictionary (codes gathered alongside):
+    the second-level GROUP BY / ORDER BY over them (TPC-H Q16's shape) still equals the string path"""
+    t, enc, plain = tables
+    aggs = lambda: [api.agg(capi.AGG_COUNT_STAR)]  # noqa: E731
+    g1a, g1b = enc.rel().groupby([(0, 0), (0, 2)], aggs(), est_groups=2000), plain.rel().groupby([(0, 0), (0, 2)], aggs(), est_groups=2000)
+    assert g1a.dict_size(0) == len(WORDS) and g1b.dict_size(0) == -1
+    g2a, g2b = g1a.rel().groupby([(0, 0)], aggs(), est_groups=64).to_arrow(), g1b.rel().groupby([(0, 0)], aggs(), est_groups=64).to_arrow()
+    rows = lambda g: collections.Counter(zip(*[c.to_pylist() for c in g.columns]))  # noqa: E731
+    assert rows(g2a) == rows(g2b) and g2a.num_rows == len(WORDS) + 1  # + the NULL group
+    m = enc.rel().scan_filter([api.pred((0, 2), capi.F_LT, 5), api.pred((0, 0), capi.F_NOTNULL)]).materialize([(0, 0), (0, 1)])
+    assert m.dict_size(0) == len(WORDS)
+    srt = m.rel().sort([api.sort_spec((0, 0)), api.sort_spec((0, 1))]).materialize([(0, 0), (0, 1)]).to_arrow()
+    s = srt.column(0).to_pylist()
+    assert all(s[i].encode() <= s[i + 1].encode() for i in range(len(s) - 1)) and len(s) == m.rows
+    assert m.rel().scan_filter([api.pred((0, 0), capi.F_LIKE, "%AIR%")]).rows == sum(1 for x in m.to_arrow().column(0).to_pylist() if "AIR" in x)
