@@ -444,6 +444,11 @@ typedef enum {
 int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_colref* keys, int32_t n_keys, int32_t build_unique,
                            ldb_hashtable** out);
 int32_t ldb_gpu_hashtable_release(ldb_ctx* ctx, ldb_hashtable* ht);
+/* The table's device hash index over its (primary-key) columns `cols`: built on first use over ALL rows, owned by the table
+ * and released with it — never by the caller.  Replaces the persisted LingoDBHashIndex (include/lingodb/runtime/
+ * LingoDBHashIndex.h:18-61) that index nested-loop joins look up (translateINLJ, RelAlgToSubOp.cpp:1129-1205): the index is
+ * an ordinary join table (for a dense primary key: the rank-bitmap layout, range / 4 bytes), probing it is ldb_gpu_join_probe. */
+int32_t ldb_gpu_table_index(ldb_ctx* ctx, ldb_table* t, const int32_t* cols, int32_t n_cols, ldb_hashtable** out);
 int64_t ldb_gpu_hashtable_slots(const ldb_hashtable* ht);
 // bytes of the slot array (8 B per open-addressing slot; 4 B per key value of a direct-addressed table)
 int64_t ldb_gpu_hashtable_bytes(const ldb_hashtable* ht);

@@ -533,8 +533,42 @@ extern "C" int32_t ldb_gpu_table_alloc(ldb_ctx* ctx, const char* name, int32_t n
    *out = t.release();
    return LDB_OK;
 }
+// The table's hash index over `cols` (primary key): built on first use with ldb_gpu_join_build over ALL rows, owned by the
+// table, released with it.  Replaces the reference's persisted LingoDBHashIndex (LingoDBHashIndex.h:18-61: hash → row id,
+// looked up by index nested-loop joins when the inner side is a bare base table whose primary key equals the join
+// columns, translateINLJ RelAlgToSubOp.cpp:1129-1205, OptimizeImplementations.cpp:226-245): here the index IS a join
+// table — for a dense primary key the rank-bitmap layout, range / 4 bytes — so probing it is the ordinary probe.
+extern "C" int32_t ldb_gpu_table_index(ldb_ctx* ctx, ldb_table* t, const int32_t* cols, int32_t n_cols, ldb_hashtable** out) {
+   if (!ctx || !t || !cols || !out || n_cols < 1 || n_cols > LDB_MAX_KEYS) LDB_FAIL(LDB_ERR_INVALID, "table_index: bad argument");
+   for (auto& ix : t->indexes)
+      if (ix.cols.size() == (size_t) n_cols && std::equal(ix.cols.begin(), ix.cols.end(), cols)) {
+         *out = ix.ht;
+         return LDB_OK;
+      }
+   ldb_table::Index ix;
+   ix.cols.assign(cols, cols + n_cols);
+   std::vector<ldb_colref> keys;
+   for (int32_t k = 0; k < n_cols; k++) {
+      if (cols[k] < 0 || (size_t) cols[k] >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "table_index: column %d out of range", cols[k]);
+      keys.push_back({0, cols[k]});
+   }
+   LDB_TRY(ldb_gpu_rel_from_table(ctx, t, &ix.rel));
+   const int32_t st = ldb_gpu_join_build(ctx, ix.rel, keys.data(), n_cols, 1, &ix.ht);
+   if (st != LDB_OK) {
+      ldb_gpu_rel_release(ctx, ix.rel);
+      return st;
+   }
+   t->indexes.push_back(ix);
+   *out = ix.ht;
+   return LDB_OK;
+}
 extern "C" int32_t ldb_gpu_table_release(ldb_ctx* ctx, ldb_table* t) {
    if (!t) return LDB_OK;
+   for (auto& ix : t->indexes) {
+      ldb_gpu_hashtable_release(ctx, ix.ht);
+      ldb_gpu_rel_release(ctx, ix.rel);
+   }
+   t->indexes.clear();
    for (auto& c : t->cols) {
       if (!c.owned) continue;
       ldb_dev_free(ctx, c.values);

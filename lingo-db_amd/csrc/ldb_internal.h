@@ -111,6 +111,14 @@ struct ldb_table {
    int64_t n_rows = 0;
    std::vector<ldb_column> cols;
    int32_t dict_refs = 1; // a dictionary table is shared by the columns gathered from the one it was built for
+   // device hash indexes over this table's key columns (ldb_gpu_table_index): built on first use, kept with the table —
+   // the counterpart of the reference's persisted LingoDBHashIndex (include/lingodb/runtime/LingoDBHashIndex.h:18-61)
+   struct Index {
+      std::vector<int32_t> cols;
+      struct ldb_rel* rel = nullptr; // identity relation over the table (what the hash table's build rows refer to)
+      struct ldb_hashtable* ht = nullptr;
+   };
+   std::vector<Index> indexes;
 };
 
 struct ldb_rel_side {

@@ -517,11 +517,12 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
       // filtered subsets of one): the table is then no larger than the open-addressing array it replaces
       // (4 B x range against 8 B x nextPow2(2n) in [16n, 32n) bytes) and a probe is one 4-byte load
       const unsigned __int128 range0 = got[0] <= got[1] ? (unsigned __int128) ((__int128) got[1] - got[0]) + 1 : 0;
-      // RANK-BITMAP table for (promised) unique keys over a range of at most 64 values per build row: range / 4 bytes,
-      // one 8-byte load per probe, no collisions, nothing to clear but the words (DJoin::direct == 2)
+      // RANK-BITMAP table for (promised) unique keys over a range of at most 64 values per build row — or any build side over
+      // a range of at most 2^26 values (a 16 MB table: a selective filter on a dimension table, Q17's 20 k of 20 M parts):
+      // range / 4 bytes, one 8-byte load per probe, no collisions, nothing to clear but the words (DJoin::direct == 2)
       bool ranked = false;
       if (range0 > 0 && build_unique && ldb_option("join_direct", 1) != 0 && ldb_option("join_rank", 1) != 0 && range0 <= ((unsigned __int128) 1 << 32) &&
-          range0 <= (unsigned __int128) std::max<int64_t>(4096, 64 * build->n_rows) && got[0] >= INT32_MIN && got[1] <= INT32_MAX && build->n_rows < (int64_t) LDB_NULL_ROW) {
+          (range0 <= (unsigned __int128) std::max<int64_t>(4096, 64 * build->n_rows) || range0 <= ((unsigned __int128) 1 << 26)) && got[0] >= INT32_MIN && got[1] <= INT32_MAX && build->n_rows < (int64_t) LDB_NULL_ROW) {
          const uint64_t n_words = (uint64_t) (range0 / 32) + 1;
          uint64_t* tab = nullptr;
          uint32_t *pop = nullptr, *off = nullptr;

@@ -833,7 +833,17 @@ struct Interp {
          v.kind = Value::HT;
          v.owned = true;
          v.sides = *sides;
-         check(ldb_gpu_join_build(ctx, in, keys.data(), (int32_t) keys.size(), st.bOr("unique", false) ? 1 : 0, &v.ht), "join_build");
+         Value& src = val(st.s("in"));
+         if (src.kind == Value::TABLE && st.bOr("unique", false) && st.bOr("index", true)) {
+            // a bare base table keyed by its primary key: the table's own (persistent) hash index — the reference's index
+            // nested-loop join over LingoDBHashIndex (translateINLJ); built once, reused by every later plan run
+            std::vector<int32_t> cs;
+            for (auto& k : keys) cs.push_back(k.col);
+            v.owned = false;
+            check(ldb_gpu_table_index(ctx, const_cast<ldb_table*>(src.table), cs.data(), (int32_t) cs.size(), &v.ht), "join_build (table index)");
+         } else {
+            check(ldb_gpu_join_build(ctx, in, keys.data(), (int32_t) keys.size(), st.bOr("unique", false) ? 1 : 0, &v.ht), "join_build");
+         }
          put(st.s("out"), std::move(v));
       } else if (op == "join_probe") {
          Value& ht = val(st.s("ht"));

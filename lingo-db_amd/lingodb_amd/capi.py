@@ -207,6 +207,7 @@ GPU_API = {
     "ldb_gpu_groupby": (i32, [P, P, C.POINTER(FilterDesc), i32, C.POINTER(ColRef), i32, C.POINTER(AggSpec), i32, i64, PP]),
     "ldb_gpu_join_build": (i32, [P, P, C.POINTER(ColRef), i32, i32, PP]),
     "ldb_gpu_hashtable_release": (i32, [P, P]),
+    "ldb_gpu_table_index": (i32, [P, P, C.POINTER(C.c_int32), i32, PP]),
     "ldb_gpu_hashtable_slots": (i64, [P]),
     "ldb_gpu_hashtable_bytes": (i64, [P]),
     "ldb_gpu_join_probe": (i32, [P, P, P, C.POINTER(ColRef), i32, i32, PP, PP]),

@@ -161,3 +161,42 @@ def test_radix_clustered_probe_gives_the_direct_probe_results(ctx, oracle, data)
     assert len(direct["inner"]) == len(want) == direct["count"] and len(want) > 1000
     assert direct["inner"] == sorted(zip(hl.phys(0)[want].tolist(), ho.phys(0)[wb].tolist()))
     assert len(direct["left_outer"]) == len(hl.phys(0))
+
+
+@pytest.mark.parametrize("table", ["rank+coarse", "rank", "direct", "open"])
+def test_selective_unique_build_large_probe_every_layout(ctx, table):
+    """a 0.2 % build side over a 2 M key range probed by 5 M unfiltered rows: the shape that gets the rank-bitmap table with
+    the LDS-resident coarse key bitmap in front of it (512-thread launches, specialised kernels) — every probe kind against
+    numpy, and the same through the other table layouts (join_coarse / join_rank / join_direct switched off in turn)"""
+    lib = capi.gpu_lib()
+    rng = np.random.default_rng(17)
+    keyspace = 2_000_000
+    bkeys = np.sort(rng.choice(keyspace, 4000, replace=False)).astype(np.int32) + 1000
+    if table != "rank+coarse":  # an unsorted build side: rank → row through the permutation
+        bkeys = rng.permutation(bkeys)
+    pkeys = rng.integers(0, keyspace + 3000, 5_000_000).astype(np.int32)
+    pkeys[::1000] = bkeys[rng.integers(0, len(bkeys), len(pkeys[::1000]))]  # guaranteed hits
+    b = ctx.register("sel_b_" + table.replace("+", "_"), pa.table({"k": pa.array(bkeys), "v": pa.array(np.arange(len(bkeys), dtype=np.int64))}))
+    p = ctx.register("sel_p_" + table.replace("+", "_"), pa.table({"k": pa.array(pkeys)}))
+    opts = {"rank+coarse": {}, "rank": {"join_coarse": 0}, "direct": {"join_rank": 0}, "open": {"join_direct": 0}}[table]
+    for k, v in opts.items():
+        lib.ldb_gpu_set_option(k.encode(), v)
+    lib.ldb_gpu_set_option(b"debug_check", 1)
+    try:
+        ht = b.rel().join_build([(0, 0)], unique=True)
+        pos = {int(k): i for i, k in enumerate(bkeys.tolist())}
+        hit = np.isin(pkeys, bkeys)
+        rows = np.nonzero(hit)[0]
+        want_build = np.array([pos[int(k)] for k in pkeys[rows]], dtype=np.uint32)
+        assert ht.probe_count(p.rel(), [(0, 0)]) == len(rows)
+        inner = ht.probe(p.rel(), [(0, 0)])
+        assert np.array_equal(inner.rowids(0), rows) and np.array_equal(inner.rowids(1), want_build)
+        assert np.array_equal(ht.probe(p.rel(), [(0, 0)], capi.JOIN_SEMI).rowids(0), rows)
+        assert np.array_equal(ht.probe(p.rel(), [(0, 0)], capi.JOIN_ANTI).rowids(0), np.nonzero(~hit)[0])
+        assert np.array_equal(ht.probe(p.rel(), [(0, 0)], capi.JOIN_SEMI_BUILD).rowids(0), np.unique(want_build))
+        lo = ht.probe(p.rel(), [(0, 0)], capi.JOIN_LEFT_OUTER)
+        assert lo.rows == len(pkeys) and int((lo.rowids(1) != 0xFFFFFFFF).sum()) == len(rows)
+    finally:
+        for k in opts:
+            lib.ldb_gpu_set_option(k.encode(), 1)
+        lib.ldb_gpu_set_option(b"debug_check", 0)

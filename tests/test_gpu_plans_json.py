@@ -68,3 +68,28 @@ def test_avg_merges_partial_sums_and_counts(ctx):
     dev = ctx.register("avg_merge_t", rows)
     a, b = ctx.run_plan(json.dumps(direct), {"t": dev}).to_arrow(), ctx.run_plan(json.dumps(merged), {"t": dev}).to_arrow()
     assert a.schema.field(1).type == b.schema.field(1).type and a.to_pylist() == b.to_pylist() and a.num_rows == 3
+
+
+def test_unique_join_over_a_base_table_uses_the_tables_index(ctx):
+    """join_build over a bare base table with a unique key = the table's persistent hash index (ldb_gpu_table_index, the
+    counterpart of LingoDBHashIndex + index nested-loop joins): built by the first plan run, reused by the next ones"""
+    T = tpch_data
+    od = ctx.register("ix_orders", T.host_table(T.ORDERS, 30_000, cols=[0, 1]))
+    li = ctx.register("ix_lineitem", T.host_table(T.LINEITEM, 30_000, cols=[0, 4]))
+    plan = json.dumps({"steps": [{"op": "join_build", "in": "orders", "keys": ["o_orderkey"], "unique": True, "out": "h"},
+                                 {"op": "join_probe", "ht": "h", "in": "lineitem", "keys": ["l_orderkey"], "kind": "inner", "out": "j"},
+                                 {"op": "groupby", "in": "j", "keys": [], "aggs": [{"fn": "count_star", "as": "n"}, {"fn": "sum", "expr": "o_custkey", "as": "s"}], "est_groups": 1, "out": "result"}],
+                       "result": "result"})
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    first = ctx.run_plan(plan, {"orders": od, "lineitem": li}).to_arrow().to_pylist()
+    builds_first = ctx.prof_all().get("k_join_build", (0, 0.0))[0]
+    ctx.prof_reset()
+    second = ctx.run_plan(plan, {"orders": od, "lineitem": li}).to_arrow().to_pylist()
+    builds_second = ctx.prof_all().get("k_join_build", (0, 0.0))[0]
+    ctx.prof_enable(False)
+    assert first == second and first[0]["n"] == li.rows
+    assert builds_first >= 1 and builds_second == 0
+    no_index = json.loads(plan)
+    no_index["steps"][0]["index"] = False  # an emitter may opt out (e.g. a table about to change)
+    assert ctx.run_plan(json.dumps(no_index), {"orders": od, "lineitem": li}).to_arrow().to_pylist() == first
