@@ -76,6 +76,13 @@ int32_t ldb_plan_run_json_comm(ldb_ctx* ctx, ldb_comm* comm, const char* plan_js
 const char* ldb_plan_json_last_error(void);
 // structure check without a device: parse, known steps with their required fields, values defined before use
 int32_t ldb_plan_json_check(const char* plan_json, const char* const* input_names, int32_t n_inputs);
+// ldb_subop.cpp: consumer of the reference's sub-operator dump (tools/ct/mlir-subop-to-json.cpp).  Translates the
+// execution_step / subops document into the step list above; LDB_ERR_UNSUPPORTED when an execution step has no device
+// pattern (ldb_subop_report: per step {"ref","subops","target":"gpu"|"cpu","reason"}), LDB_ERR_INVALID for a malformed
+// document or a too-small buffer (*needed = bytes to retry with).
+int32_t ldb_subop_translate(const char* dump_json, const char* name, char* plan_out, int64_t cap, int64_t* needed);
+const char* ldb_subop_last_error(void);
+const char* ldb_subop_report(void);
 // test hooks for the host logic (date / decimal parsing, decimal typing rules)
 int32_t ldb_host_parse_date32(const char* s, int32_t* out);
 int32_t ldb_host_parse_decimal(const char* s, int32_t scale, int64_t* lo, int64_t* hi);

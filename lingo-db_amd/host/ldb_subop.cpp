@@ -1,0 +1,974 @@
+// ldb_subop.cpp — consumer of the reference's OWN sub-operator dump.
+//
+// LingoDB's CPU backend walks `subop.execution_step`s (handleExecutionStepCPU, SubOpToControlFlow.cpp:4363-4395;
+// the GPU stub handleExecutionStepGPU, :4512-4548, is where a device backend plugs in) and the repository ships a
+// tool that prints exactly that IR as JSON: tools/ct/mlir-subop-to-json.cpp (`[{"type":"execution_step",
+// "subops":[{"subop":"get_external","meta":{tableName,mapping,filters}}, {"subop":"scan","mapping":[…]}, …],
+// "inputs","results","outerEdges","innerEdges"}]`, :434-560 and the sub-operator cases :560-850).  This file
+// reads that document and pattern-matches the sub-operator sequences the reference's lowerings produce onto
+// the C-ABI's operator-level steps (the step list ldb_plan.cpp interprets):
+//
+//   get_external + scan                         → a base table relation; meta.filters → restrictions
+//   map                                         → column bindings (expressions are inlined into their consumers)
+//   filter all_true                             → restrictions / the equality of a hash join
+//   lookup(SimpleState) | lookup_or_insert(HashMap) + reduce [+ create_thread_local / get_local / merge]
+//                                               → groupby (sum / count / count(*) / min / max; sum ÷ count → avg)
+//   materialize(Buffer) + create_hash_indexed_view + lookup(HashIndexedView) + nested_map{scan_list, gather,
+//     combine_tuple, map, filter}                → join_build + join_probe (inner)
+//   materialize(Buffer) + create_sorted_view    → sort          materialize(Heap) + scan → topk
+//   materialize(ResultTable)                    → materialize (the query result)
+//
+// Everything else is reported per execution step as "cpu" with the reason (the reference would run such a step on
+// its CPU backend; there is none here, so the translation as a whole fails with LDB_ERR_UNSUPPORTED and the report
+// says which step).  The dump loses a few facts a backend needs; the consumer relies on five small emitter
+// additions, listed in INTEGRATION.md §1b and in tools/write_subop_dumps.py (E1 " - " for db.sub, E3 get_local,
+// E4 sortBy/maxRows on create_sorted_view/create_heap, E5 primaryKey, E6 combine_tuple).  Group-by keys need no
+// extension: performAggregation names key members "keyval$n" and the later scan of the map re-defines the SAME
+// columns (RelAlgToSubOp.cpp:2158-2166, test/lit/RelAlg/lowering.mlir:37), so keys are read off that scan.
+#include "ldb_host.hpp"
+#include "ldb_json.hpp"
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <set>
+
+namespace {
+using ldbjson::J;
+using ldbjson::JParser;
+using ldbjson::quote;
+
+struct Unsupported : std::runtime_error {
+   using std::runtime_error::runtime_error;
+};
+
+// ------------------------------------------------------------------ expressions (the tool's expression_leaf / expression_inner)
+struct Expr;
+using ExprP = std::shared_ptr<Expr>;
+struct Expr {
+   enum Kind { COL, CONST_INT, CONST_STR, CONST_BOOL, MEMBER, REF, HASH, UNKNOWN, OP } kind = UNKNOWN;
+   std::string name; // COL: column name in the plan language; MEMBER: member; OP: add sub mul div cast cmp and or not isnull select between in
+   std::string cmp; // OP cmp: EQ NEQ LT LTE GT GTE
+   int64_t i = 0;
+   bool build = false; // COL gathered from the build side of the hash join being matched
+   std::vector<ExprP> args;
+};
+ExprP mk(Expr::Kind k, const std::string& name = "") {
+   auto e = std::make_shared<Expr>();
+   e->kind = k;
+   e->name = name;
+   return e;
+}
+ExprP stripCast(ExprP e) {
+   while (e->kind == Expr::OP && e->name == "cast") e = e->args[0];
+   return e;
+}
+std::string exprJson(const ExprP& e0) { // the plan language of ldb_plan.cpp (compileX)
+   const ExprP e = stripCast(e0); // db.cast is implicit there: operands are typed by the reference's decimal rules
+   switch (e->kind) {
+      case Expr::COL: return quote(e->name);
+      case Expr::CONST_INT: return std::to_string(e->i);
+      case Expr::CONST_STR: return quote(e->name);
+      case Expr::OP: {
+         if (e->name == "cmp") return "{\"cmp\": [" + quote(e->cmp) + ", " + exprJson(e->args[0]) + ", " + exprJson(e->args[1]) + "]}";
+         if (e->name == "select") return "{\"case\": [" + exprJson(e->args[0]) + ", " + exprJson(e->args[1]) + ", " + exprJson(e->args[2]) + "]}";
+         if (e->name == "add" || e->name == "sub" || e->name == "mul" || e->name == "div" || e->name == "and" || e->name == "or" || e->name == "not" || e->name == "isnull") {
+            std::string o = "{" + quote(e->name) + ": [";
+            if ((e->name == "and" || e->name == "or" || e->name == "mul") && e->args.size() > 2) { // n-ary in the dump, flattened for mul, nested for and/or
+               if (e->name == "mul") {
+                  for (size_t k = 0; k < e->args.size(); k++) o += (k ? ", " : "") + exprJson(e->args[k]);
+                  return o + "]}";
+               }
+               ExprP acc = e->args[0];
+               for (size_t k = 1; k < e->args.size(); k++) {
+                  ExprP n = mk(Expr::OP, e->name);
+                  n->args = {acc, e->args[k]};
+                  acc = n;
+               }
+               return exprJson(acc);
+            }
+            for (size_t k = 0; k < e->args.size(); k++) o += (k ? ", " : "") + exprJson(e->args[k]);
+            return o + "]}";
+         }
+         throw Unsupported("expression '" + e->name + "' has no device form");
+      }
+      default: throw Unsupported("expression leaf without a device form");
+   }
+}
+// (a * b) * c → one n-ary product, the form the aggregate normal form of ldb_plan.cpp recognises
+ExprP flattenMul(const ExprP& e) {
+   if (e->kind != Expr::OP) return e;
+   auto r = std::make_shared<Expr>(*e);
+   r->args.clear();
+   for (auto& a : e->args) {
+      ExprP f = flattenMul(a);
+      if (e->name == "mul" && f->kind == Expr::OP && f->name == "mul")
+         for (auto& g : f->args) r->args.push_back(g);
+      else
+         r->args.push_back(f);
+   }
+   return r;
+}
+
+// ------------------------------------------------------------------ what the walk keeps
+struct Stream {
+   std::string rel; // plan value holding the rows
+   bool bareTable = false; // `rel` is an input table nothing has been applied to yet (its restrictions are in `preds`)
+   std::vector<std::string> preds; // restrictions not yet applied (JSON objects of the plan language)
+   std::map<std::string, ExprP> cols; // column displayName ("lineitem::l_quantity") → what it is
+   std::vector<std::set<std::string>> unique; // column sets known to identify a row
+   std::string probeHiv, aggState; // the hash-indexed view being probed / the state being reduced into
+};
+struct AggSpec {
+   std::string member, fn;
+   ExprP arg; // null for count(*)
+};
+struct OutAgg {
+   std::string fn, expr, as;
+   bool used = false;
+};
+struct OutStep {
+   std::string op, out;
+   std::vector<std::pair<std::string, std::string>> fields; // key → raw JSON, in order
+   std::vector<OutAgg> aggs; // groupby
+};
+struct State {
+   enum Kind { UNKNOWN, TABLE, AGG, BUFFER, HIV, SORTED, HEAP, RESULT } kind = UNKNOWN;
+   std::string table; // TABLE
+   std::map<std::string, std::string> memberToIdent;
+   std::vector<std::string> filters, pkey;
+   Stream in; // AGG: the reduced stream; BUFFER/HEAP/RESULT/SORTED: the materialised one
+   std::vector<AggSpec> aggs;
+   int groupbyStep = -1; // AGG: index of the emitted groupby (emitted when the state is first scanned)
+   std::map<std::string, std::string> aggOut; // AGG: member → output column
+   std::map<std::string, ExprP> members; // BUFFER …: member → what was stored
+   std::shared_ptr<State> source; // HIV / SORTED: the buffer underneath
+   std::string ht; // HIV: the plan value of the built table
+   std::vector<std::string> htKeys;
+   bool htUnique = false;
+   std::vector<std::pair<std::string, bool>> sortBy; // member, descending
+   int64_t maxRows = -1;
+   bool emitted = false; // SORTED / HEAP: the sort / topk step exists and in.rel names its output
+};
+using StateP = std::shared_ptr<State>;
+
+struct Translator {
+   std::vector<OutStep> steps;
+   std::map<std::string, StateP> states; // "<step ref>#<resnr>" → state
+   std::map<std::string, std::pair<int, int>> aggCol; // output column name → (groupby step, agg index)
+   std::set<std::string> inputs;
+   std::string result;
+   std::string report; // JSON array body
+   int nval = 0;
+
+   std::string fresh(const char* stem) { return std::string(stem) + std::to_string(++nval); }
+   static std::string sanitize(std::string s) {
+      for (size_t p; (p = s.find("::")) != std::string::npos;) s.replace(p, 2, ".");
+      return s;
+   }
+   static std::string stripSuffix(const std::string& m) { // "revenue$4" → "revenue"
+      const size_t p = m.rfind('$');
+      return p == std::string::npos ? m : m.substr(0, p);
+   }
+
+   // ---------------------------------------------------------------- expressions
+   static bool strs(const J& e, std::initializer_list<const char*> want) {
+      const J& s = e.at("strings");
+      if (s.kind != J::ARR || s.arr.size() != want.size()) return false;
+      size_t k = 0;
+      for (const char* w : want)
+         if (s.arr[k++].str != w) return false;
+      return true;
+   }
+   ExprP convert(const J& e, const Stream& st) {
+      const std::string& type = e.s("type");
+      if (type == "expression_leaf") {
+         const std::string& leaf = e.s("leaf_type");
+         if (leaf == "column" || leaf == "external_column") {
+            auto it = st.cols.find(e.s("displayName"));
+            if (it == st.cols.end()) throw Unsupported("column '" + e.s("displayName") + "' is not defined on this stream");
+            return it->second;
+         }
+         if (leaf == "constant") {
+            const J& v = e.at("value");
+            if (v.kind == J::NUM && v.isInt) {
+               ExprP c = mk(Expr::CONST_INT);
+               c->i = v.inum;
+               return c;
+            }
+            if (v.kind == J::STR) return mk(Expr::CONST_STR, v.str);
+            if (v.kind == J::BOOL) {
+               ExprP c = mk(Expr::CONST_BOOL);
+               c->i = v.b;
+               return c;
+            }
+            throw Unsupported("floating-point constant");
+         }
+         if (leaf == "member") return mk(Expr::MEMBER, e.s("member"));
+         return mk(Expr::UNKNOWN); // "unknown" / "null": only legal inside the recognised aggregate bodies
+      }
+      if (type != "expression_inner") throw Unsupported("expression node of type '" + type + "'");
+      const J& subs = e.at("subExpressions");
+      std::vector<ExprP> a;
+      for (auto& s : subs.arr) a.push_back(convert(s, st));
+      auto op = [&](const char* name, size_t n) {
+         if (a.size() != n) throw Unsupported(std::string("malformed '") + name + "' expression");
+         ExprP r = mk(Expr::OP, name);
+         r->args = a;
+         return r;
+      };
+      const J& ss = e.at("strings");
+      const std::string first = ss.arr.empty() ? "" : ss.arr[0].str;
+      if (strs(e, {"", " * ", ""})) return op("mul", 2);
+      if (strs(e, {"", " + ", ""})) return op("add", 2);
+      if (strs(e, {"", " - ", ""})) return op("sub", 2); // emitter extension E1 (the tool prints " + " for db.sub today)
+      if (strs(e, {"", " / ", ""})) return op("div", 2);
+      if (strs(e, {"cast(", ")"})) return op("cast", 1);
+      if (strs(e, {"not ", ""})) return op("not", 1);
+      if (strs(e, {"", " is null"})) return op("isnull", 1);
+      if (strs(e, {"", " ? ", " : ", ""})) return op("select", 3);
+      if (strs(e, {"if ", " then ", " else ", ""})) return op("select", 3);
+      if (strs(e, {"", " between ", " and ", ""})) { // db.between: both bounds inclusive unless the emitter says otherwise
+         if (a.size() != 3) throw Unsupported("malformed between");
+         ExprP lo = mk(Expr::OP, "cmp"), hi = mk(Expr::OP, "cmp"), r = mk(Expr::OP, "and");
+         lo->cmp = "GTE", lo->args = {a[0], a[1]};
+         hi->cmp = "LTE", hi->args = {a[0], a[2]};
+         r->args = {lo, hi};
+         return r;
+      }
+      if (first == "hash(") { // hash(x) or hash(pack(x, y, …)): only the hashed columns matter
+         ExprP h = mk(Expr::HASH);
+         h->args = a.size() == 1 && a[0]->kind == Expr::OP && a[0]->name == "pack" ? a[0]->args : a;
+         return h;
+      }
+      if (first == "pack(") {
+         ExprP r = mk(Expr::OP, "pack");
+         r->args = a;
+         return r;
+      }
+      if (ss.arr.size() == 3 && ss.arr[0].str.empty() && ss.arr[2].str.empty() && a.size() == 2) { // db.compare: convertCmpPredicate, no spaces
+         static const std::pair<const char*, const char*> cmps[] = {{"=", "EQ"}, {"<>", "NEQ"}, {"<", "LT"}, {"<=", "LTE"}, {">", "GT"}, {">=", "GTE"}, {"isa", "EQ"}};
+         for (auto& c : cmps)
+            if (ss.arr[1].str == c.first) {
+               ExprP r = mk(Expr::OP, "cmp");
+               r->cmp = c.second;
+               r->args = a;
+               return r;
+            }
+      }
+      if (ss.arr.size() >= 3 && first.empty() && ss.arr[1].str == " and ") {
+         ExprP r = mk(Expr::OP, "and");
+         r->args = a;
+         return r;
+      }
+      if (ss.arr.size() >= 3 && first == "(" && ss.arr[1].str == " or ") {
+         ExprP r = mk(Expr::OP, "or");
+         r->args = a;
+         return r;
+      }
+      if (first.empty() && ss.arr.size() >= 3 && ss.arr[1].str == " in [") {
+         ExprP r = mk(Expr::OP, "in");
+         r->args = a;
+         return r;
+      }
+      throw Unsupported("expression '" + first + "…' (runtime call or operator without a device form)");
+   }
+
+   // ---------------------------------------------------------------- emission helpers
+   void flush(Stream& s) { // apply pending restrictions as a filter step
+      if (s.preds.empty()) {
+         s.bareTable = false;
+         return;
+      }
+      OutStep f;
+      f.op = "filter";
+      f.out = fresh("v");
+      std::string p = "[";
+      for (size_t k = 0; k < s.preds.size(); k++) p += (k ? ", " : "") + s.preds[k];
+      f.fields = {{"in", quote(s.rel)}, {"preds", p + "]"}};
+      steps.push_back(f);
+      s.rel = f.out;
+      s.preds.clear();
+      s.bareTable = false;
+   }
+   void use(const std::string& col) {
+      auto it = aggCol.find(col);
+      if (it != aggCol.end()) steps[(size_t) it->second.first].aggs[(size_t) it->second.second].used = true;
+   }
+   void useAll(const ExprP& e) {
+      if (e->kind == Expr::COL) use(e->name);
+      for (auto& a : e->args) useAll(a);
+   }
+   // a plain column holding `e` on the stream: a computed expression becomes a `map` step
+   std::string ensureCol(Stream& s, const ExprP& e0, const std::string& hint) {
+      const ExprP e = stripCast(e0);
+      if (e->kind == Expr::COL) {
+         use(e->name);
+         return e->name;
+      }
+      flush(s);
+      useAll(e);
+      OutStep m;
+      m.op = "map";
+      m.out = fresh("v");
+      const std::string as = sanitize(hint);
+      m.fields = {{"in", quote(s.rel)}, {"expr", exprJson(flattenMul(e))}, {"as", quote(as)}};
+      steps.push_back(m);
+      s.rel = m.out;
+      ExprP c = mk(Expr::COL, as);
+      for (auto& kv : s.cols)
+         if (kv.second == e0) kv.second = c;
+      return as;
+   }
+
+   // ---------------------------------------------------------------- states
+   StateP emitGroupBy(const StateP& st, const J& mapping) {
+      if (st->groupbyStep >= 0) return st;
+      Stream& in = st->in;
+      OutStep g;
+      g.op = "groupby";
+      g.out = fresh("g");
+      std::vector<std::string> keys;
+      for (auto& m : mapping.arr) {
+         const std::string& member = m.s("member");
+         if (member.rfind("keyval", 0) != 0) continue;
+         // the scan re-defines the grouped column itself: its binding on the reduced stream is the key
+         auto it = in.cols.find(m.at("column").s("displayName"));
+         if (it == in.cols.end()) throw Unsupported("group key '" + m.at("column").s("displayName") + "' is not a column of the aggregated stream");
+         keys.push_back(ensureCol(in, it->second, m.at("column").s("displayName")));
+      }
+      std::string kj = "[";
+      for (size_t k = 0; k < keys.size(); k++) kj += (k ? ", " : "") + quote(keys[k]);
+      kj += "]";
+      for (auto& a : st->aggs) {
+         OutAgg o;
+         o.fn = a.fn;
+         if (a.arg) {
+            useAll(a.arg);
+            o.expr = exprJson(flattenMul(a.arg));
+         }
+         std::string as;
+         for (auto& m : mapping.arr)
+            if (m.s("member") == a.member) as = sanitize(m.at("column").s("displayName"));
+         o.as = as.empty() ? sanitize(st->in.rel + "." + a.member) : as;
+         o.used = false;
+         st->aggOut[a.member] = o.as;
+         g.aggs.push_back(o);
+      }
+      g.fields = {{"in", quote(in.rel)}, {"keys", kj}};
+      if (keys.empty()) g.fields.push_back({"est_groups", "1"});
+      if (!in.preds.empty()) {
+         if (!in.bareTable) {
+            flush(in);
+            g.fields[0].second = quote(in.rel);
+         } else { // restrictions of the scanned table fuse into the aggregation kernel (scan → filter → aggregate in one pass)
+            std::string p = "[";
+            for (size_t k = 0; k < in.preds.size(); k++) p += (k ? ", " : "") + in.preds[k];
+            g.fields.push_back({"preds", p + "]"});
+         }
+      }
+      st->groupbyStep = (int) steps.size();
+      for (size_t k = 0; k < g.aggs.size(); k++) aggCol[g.aggs[k].as] = {st->groupbyStep, (int) k};
+      steps.push_back(g);
+      Stream out;
+      out.rel = g.out;
+      if (!keys.empty()) out.unique.push_back(std::set<std::string>(keys.begin(), keys.end()));
+      size_t kk = 0;
+      for (auto& m : mapping.arr) {
+         const std::string& member = m.s("member");
+         if (member.rfind("keyval", 0) == 0) st->aggOut[member] = keys[kk++];
+      }
+      st->in = out; // from here on the state IS the aggregated table
+      return st;
+   }
+
+   // ---------------------------------------------------------------- one execution step
+   struct StepCtx {
+      std::vector<StateP> args;
+      std::map<std::string, StateP> local; // "<ref>#<resnr>" of states created inside the step
+      std::map<std::string, Stream> streams; // by producing sub-operator
+      Stream* nested = nullptr; // the stream a nested_map hands to its body
+   };
+   StateP resolve(const J& acc, StepCtx& c) {
+      const std::string& t = acc.s("type");
+      if (t == "parentArg") {
+         const int64_t n = acc.iOr("argnr", -1);
+         if (n < 0 || (size_t) n >= c.args.size() || !c.args[(size_t) n]) throw Unsupported("state argument " + std::to_string(n) + " is not available");
+         return c.args[(size_t) n];
+      }
+      if (t == "node") {
+         const std::string id = acc.s("ref") + "#" + std::to_string(acc.iOr("resnr", 0));
+         auto it = c.local.find(id);
+         if (it != c.local.end()) return it->second;
+         auto jt = states.find(id);
+         if (jt != states.end()) return jt->second;
+         throw Unsupported("state '" + id + "' is produced by a sub-operator this consumer does not know");
+      }
+      throw Unsupported("state access of type '" + t + "'");
+   }
+   Stream& input(const J& op, StepCtx& c) {
+      for (auto& e : op.at("outerEdges").arr)
+         if (e.s("type") == "stream") {
+            auto it = c.streams.find(e.at("input").s("ref"));
+            if (it == c.streams.end()) throw Unsupported("stream input '" + e.at("input").s("ref") + "' is not produced in this step");
+            return it->second;
+         }
+      if (c.nested) return *c.nested;
+      throw Unsupported("sub-operator without a stream input");
+   }
+   static std::string predJson(const std::string& col, const std::string& op, const J* value, const J* values) {
+      std::string p = "{\"col\": " + quote(col) + ", \"op\": " + quote(op);
+      auto lit = [](const J& v) { return v.kind == J::STR ? quote(v.str) : v.kind == J::NUM && v.isInt ? std::to_string(v.inum) : std::to_string(v.num); };
+      if (values) {
+         p += ", \"values\": [";
+         for (size_t k = 0; k < values->arr.size(); k++) p += (k ? ", " : "") + lit(values->arr[k]);
+         p += "]";
+      } else if (value && op != "NOTNULL") {
+         p += ", \"value\": " + lit(*value);
+      }
+      return p + "}";
+   }
+
+   void joinOnEqualities(Stream& s, const ExprP& pred) {
+      StateP hiv = states.at(s.probeHiv);
+      std::vector<ExprP> conj;
+      std::function<void(const ExprP&)> split = [&](const ExprP& e) {
+         if (e->kind == Expr::OP && e->name == "and")
+            for (auto& a : e->args) split(a);
+         else
+            conj.push_back(e);
+      };
+      split(pred);
+      std::vector<std::string> probeKeys, buildKeys;
+      Stream& b = hiv->source->in;
+      for (auto& e : conj) {
+         if (!(e->kind == Expr::OP && e->name == "cmp" && e->cmp == "EQ")) throw Unsupported("hash join with a residual (non-equality) predicate");
+         ExprP l = stripCast(e->args[0]), r = stripCast(e->args[1]);
+         if (l->build && !r->build) std::swap(l, r);
+         if (l->build || !r->build) throw Unsupported("join equality does not compare a probe column with a gathered build column");
+         buildKeys.push_back(ensureCol(b, r, "build_key"));
+         probeKeys.push_back(ensureCol(s, l, "probe_key"));
+      }
+      auto list = [](const std::vector<std::string>& v) {
+         std::string o = "[";
+         for (size_t k = 0; k < v.size(); k++) o += (k ? ", " : "") + quote(v[k]);
+         return o + "]";
+      };
+      if (hiv->ht.empty()) {
+         flush(b);
+         bool uniq = false;
+         const std::set<std::string> ks(buildKeys.begin(), buildKeys.end());
+         for (auto& u : b.unique) {
+            bool sub = !u.empty();
+            for (auto& c : u) sub = sub && ks.count(c);
+            uniq = uniq || sub;
+         }
+         OutStep jb;
+         jb.op = "join_build";
+         jb.out = fresh("h");
+         jb.fields = {{"in", quote(b.rel)}, {"keys", list(buildKeys)}, {"unique", uniq ? "true" : "false"}};
+         steps.push_back(jb);
+         hiv->ht = jb.out;
+         hiv->htKeys = buildKeys;
+         hiv->htUnique = uniq;
+      } else if (hiv->htKeys != buildKeys) {
+         throw Unsupported("one hash-indexed view probed on two different key lists");
+      }
+      flush(s);
+      OutStep jp;
+      jp.op = "join_probe";
+      jp.out = fresh("j");
+      jp.fields = {{"ht", quote(hiv->ht)}, {"in", quote(s.rel)}, {"keys", list(probeKeys)}, {"kind", "\"inner\""}};
+      steps.push_back(jp);
+      s.rel = jp.out;
+      s.probeHiv.clear();
+      if (!hiv->htUnique) s.unique.clear(); // probe rows may repeat
+      for (auto& kv : s.cols)
+         if (kv.second->build) {
+            auto c = std::make_shared<Expr>(*kv.second);
+            c->build = false;
+            kv.second = c;
+         }
+   }
+
+   void handle(const J& op, StepCtx& c) {
+      const J* kindp = op.get("subop");
+      if (!kindp) throw Unsupported("a sub-operator the dump tool has no case for (\"operator\": \"unknown\")");
+      const std::string& kind = kindp->str;
+      const std::string& ref = op.s("ref");
+      auto newState = [&](State::Kind k) {
+         auto s = std::make_shared<State>();
+         s->kind = k;
+         c.local[ref + "#0"] = s;
+         return s;
+      };
+      if (kind == "get_external") {
+         const J& meta = op.at("meta");
+         StateP s = newState(State::TABLE);
+         s->table = meta.s("tableName");
+         inputs.insert(s->table);
+         for (auto& m : meta.at("mapping").arr) s->memberToIdent[m.s("memberName")] = m.s("identifier");
+         if (const J* fs = meta.get("filters"))
+            for (auto& f : fs->arr) {
+               const std::string& fop = f.s("op");
+               if (fop == "UNKNOWN") throw Unsupported("restriction with an unknown FilterOp");
+               s->filters.push_back(predJson(f.s("columnName"), fop, f.get("value"), f.get("values")));
+            }
+         if (const J* pk = meta.get("primaryKey")) // emitter extension E5
+            for (auto& k : pk->arr) s->pkey.push_back(k.str);
+         if (meta.get("index")) throw Unsupported("get_external over an external hash index");
+         return;
+      }
+      if (kind == "create_thread_local" || kind == "create_simple_state" || kind == "generic_create" || kind == "create_array" || kind == "create_from") {
+         newState(State::UNKNOWN);
+         return;
+      }
+      if (kind == "create_heap") {
+         StateP s = newState(State::HEAP);
+         s->maxRows = op.iOr("maxRows", -1); // emitter extension E4
+         if (const J* sb = op.get("sortBy"))
+            for (auto& k : sb->arr) s->sortBy.push_back({k.s("member"), k.sOr("direction", "asc") == "desc"});
+         if (s->maxRows < 0 || s->sortBy.empty()) throw Unsupported("create_heap without maxRows / sortBy (emitter extension E4)");
+         return;
+      }
+      if (kind == "get_local" || kind == "merge") { // thread-local plumbing of the parallelize pass: one state on a GPU
+         c.local[ref + "#0"] = resolve(op.at("accesses").arr.at(0), c);
+         return;
+      }
+      if (kind == "create_hash_indexed_view") {
+         StateP src = resolve(op.at("accesses").arr.at(0), c);
+         if (src->kind != State::BUFFER) throw Unsupported("hash-indexed view over a state that is not a materialised buffer");
+         StateP s = newState(State::HIV);
+         s->source = src;
+         return;
+      }
+      if (kind == "create_sorted_view") {
+         StateP src = resolve(op.at("accesses").arr.at(0), c);
+         if (src->kind != State::BUFFER) throw Unsupported("sorted view over a state that is not a materialised buffer");
+         const J* sb = op.get("sortBy"); // emitter extension E4
+         if (!sb || sb->arr.empty()) throw Unsupported("create_sorted_view without sortBy (emitter extension E4)");
+         StateP s = newState(State::SORTED);
+         s->source = src;
+         s->in = src->in;
+         s->members = src->members;
+         flush(s->in);
+         std::string by = "[";
+         for (size_t k = 0; k < sb->arr.size(); k++) {
+            auto it = s->members.find(sb->arr[k].s("member"));
+            if (it == s->members.end()) throw Unsupported("sort key '" + sb->arr[k].s("member") + "' is not a member of the buffer");
+            const std::string col = ensureCol(s->in, it->second, stripSuffix(it->first));
+            it->second = mk(Expr::COL, col);
+            by += (k ? ", " : "") + (sb->arr[k].sOr("direction", "asc") == "desc" ? "{\"col\": " + quote(col) + ", \"desc\": true}" : quote(col));
+         }
+         OutStep so;
+         so.op = "sort";
+         so.out = fresh("s");
+         so.fields = {{"in", quote(s->in.rel)}, {"by", by + "]"}};
+         steps.push_back(so);
+         s->in.rel = so.out;
+         return;
+      }
+      if (kind == "scan") {
+         StateP st = resolve(op.at("accesses").arr.at(0), c);
+         const J& mapping = op.at("mapping");
+         Stream s;
+         if (st->kind == State::TABLE) {
+            s.rel = st->table;
+            s.bareTable = true;
+            s.preds = st->filters;
+            if (!st->pkey.empty()) s.unique.push_back(std::set<std::string>(st->pkey.begin(), st->pkey.end()));
+            for (auto& m : mapping.arr) {
+               auto it = st->memberToIdent.find(m.s("member"));
+               if (it == st->memberToIdent.end()) throw Unsupported("scan of member '" + m.s("member") + "' that get_external does not map");
+               s.cols[m.at("column").s("displayName")] = mk(Expr::COL, it->second);
+            }
+         } else if (st->kind == State::AGG) {
+            emitGroupBy(st, mapping);
+            s = st->in;
+            for (auto& m : mapping.arr) {
+               auto it = st->aggOut.find(m.s("member"));
+               if (it == st->aggOut.end()) throw Unsupported("scan of member '" + m.s("member") + "' the aggregation does not produce");
+               s.cols[m.at("column").s("displayName")] = mk(Expr::COL, it->second);
+            }
+         } else if (st->kind == State::BUFFER || st->kind == State::SORTED || st->kind == State::HEAP || st->kind == State::RESULT) {
+            if (st->kind == State::HEAP && !st->emitted) { // the heap keeps the best maxRows rows: a top-k over what was materialised
+               flush(st->in);
+               std::string by = "[";
+               for (size_t k = 0; k < st->sortBy.size(); k++) {
+                  auto it = st->members.find(st->sortBy[k].first);
+                  if (it == st->members.end()) throw Unsupported("heap sort key '" + st->sortBy[k].first + "' was not materialised");
+                  const std::string col = ensureCol(st->in, it->second, stripSuffix(it->first));
+                  it->second = mk(Expr::COL, col);
+                  by += (k ? ", " : "") + (st->sortBy[k].second ? "{\"col\": " + quote(col) + ", \"desc\": true}" : quote(col));
+               }
+               OutStep tk;
+               tk.op = "topk";
+               tk.out = fresh("t");
+               tk.fields = {{"in", quote(st->in.rel)}, {"by", by + "]"}, {"k", std::to_string(st->maxRows)}};
+               steps.push_back(tk);
+               st->in.rel = tk.out;
+               st->emitted = true;
+            }
+            s.rel = st->in.rel;
+            s.preds = st->in.preds;
+            s.unique = st->in.unique;
+            for (auto& m : mapping.arr) {
+               auto it = st->members.find(m.s("member"));
+               if (it == st->members.end()) throw Unsupported("scan of member '" + m.s("member") + "' that was never materialised");
+               s.cols[m.at("column").s("displayName")] = it->second;
+            }
+         } else {
+            throw Unsupported("scan of a state nothing was written to");
+         }
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "nested_map") { // the body runs once per tuple of the input stream: inline it
+         Stream s = input(op, c);
+         Stream* outer = c.nested;
+         c.nested = &s;
+         std::string last;
+         if (const J* body = op.get("subops"))
+            for (auto& b : body->arr) {
+               handle(b, c);
+               if (b.get("subop") && c.streams.count(b.s("ref"))) last = b.s("ref");
+            }
+         c.nested = outer;
+         c.streams[ref] = last.empty() ? s : c.streams[last];
+         return;
+      }
+      if (kind == "scan_list") {
+         Stream s = input(op, c);
+         if (s.probeHiv.empty()) throw Unsupported("scan_list outside a hash-indexed-view lookup");
+         s.cols[op.at("elem").s("displayName")] = mk(Expr::REF);
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "gather") {
+         Stream s = input(op, c);
+         if (s.probeHiv.empty()) throw Unsupported("gather outside a hash join");
+         StateP hiv = states.at(s.probeHiv);
+         for (auto& m : op.at("mapping").arr) {
+            auto it = hiv->source->members.find(m.s("member"));
+            if (it == hiv->source->members.end()) throw Unsupported("gather of member '" + m.s("member") + "' that the build side did not materialise");
+            auto e = std::make_shared<Expr>(*stripCast(it->second));
+            if (e->kind != Expr::COL) { // a computed build column: give it a name on the build relation first
+               const std::string col = ensureCol(hiv->source->in, it->second, stripSuffix(it->first));
+               it->second = mk(Expr::COL, col);
+               e = std::make_shared<Expr>(*it->second);
+            }
+            e->build = true;
+            s.cols[m.at("column").s("displayName")] = e;
+         }
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "combine_tuple") { // emitter extension E6: a no-op for column bindings
+         c.streams[ref] = input(op, c);
+         return;
+      }
+      if (kind == "renaming") {
+         Stream s = input(op, c);
+         for (auto& r : op.at("renamed").arr) {
+            auto it = s.cols.find(r.at("old").s("displayName"));
+            if (it == s.cols.end()) throw Unsupported("renaming of an undefined column");
+            s.cols[r.at("new").s("displayName")] = it->second;
+         }
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "map") {
+         Stream s = input(op, c);
+         for (auto& cm : op.at("computed").arr) {
+            const std::string& name = cm.at("computed").s("displayName");
+            ExprP e = convert(cm.at("expression"), s);
+            // sum(x) / count(x) over one aggregation = avg(x) (the frontend's expansion of avg)
+            ExprP d = stripCast(e);
+            if (d->kind == Expr::OP && d->name == "div") {
+               ExprP n = stripCast(d->args[0]), m = stripCast(d->args[1]);
+               auto a = n->kind == Expr::COL ? aggCol.find(n->name) : aggCol.end();
+               auto b = m->kind == Expr::COL ? aggCol.find(m->name) : aggCol.end();
+               if (a != aggCol.end() && b != aggCol.end() && a->second.first == b->second.first) {
+                  OutStep& g = steps[(size_t) a->second.first];
+                  const OutAgg& sum = g.aggs[(size_t) a->second.second];
+                  const OutAgg& cnt = g.aggs[(size_t) b->second.second];
+                  if (sum.fn == "sum" && (cnt.fn == "count_star" || (cnt.fn == "count" && cnt.expr == sum.expr))) {
+                     OutAgg avg;
+                     avg.fn = "avg";
+                     avg.expr = sum.expr;
+                     avg.as = sanitize(name);
+                     aggCol[avg.as] = {a->second.first, (int) g.aggs.size()};
+                     g.aggs.push_back(avg);
+                     e = mk(Expr::COL, avg.as);
+                  }
+               }
+            }
+            s.cols[name] = e;
+         }
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "filter") {
+         Stream s = input(op, c);
+         if (op.sOr("semantic", "all_true") != "all_true") throw Unsupported("filter with all_false semantic");
+         for (auto& col : op.at("columns").arr) {
+            auto it = s.cols.find(col.s("displayName"));
+            if (it == s.cols.end()) throw Unsupported("filter on an undefined column");
+            const ExprP e = it->second;
+            if (!s.probeHiv.empty()) {
+               joinOnEqualities(s, e);
+               continue;
+            }
+            const ExprP p = stripCast(e);
+            if (p->kind == Expr::OP && p->name == "cmp") {
+               ExprP l = stripCast(p->args[0]), r = stripCast(p->args[1]);
+               std::string cmp = p->cmp;
+               if (l->kind != Expr::COL && r->kind == Expr::COL) {
+                  std::swap(l, r);
+                  static const std::pair<const char*, const char*> rev[] = {{"LT", "GT"}, {"GT", "LT"}, {"LTE", "GTE"}, {"GTE", "LTE"}, {"EQ", "EQ"}, {"NEQ", "NEQ"}};
+                  for (auto& rv : rev)
+                     if (cmp == rv.first) {
+                        cmp = rv.second;
+                        break;
+                     }
+               }
+               if (l->kind == Expr::COL && (r->kind == Expr::CONST_INT || r->kind == Expr::CONST_STR)) {
+                  use(l->name);
+                  s.preds.push_back("{\"col\": " + quote(l->name) + ", \"op\": " + quote(cmp) + ", \"value\": " + (r->kind == Expr::CONST_INT ? std::to_string(r->i) : quote(r->name)) + "}");
+                  continue;
+               }
+               if (l->kind == Expr::COL && r->kind == Expr::COL) {
+                  use(l->name), use(r->name);
+                  s.preds.push_back("{\"col\": " + quote(l->name) + ", \"op\": " + quote(cmp) + ", \"rhs_col\": " + quote(r->name) + "}");
+                  continue;
+               }
+            }
+            throw Unsupported("filter on a computed predicate that is not column-vs-constant or column-vs-column");
+         }
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "lookup" || kind == "lookup_or_insert") {
+         Stream s = input(op, c);
+         StateP st = resolve(op.at("accesses").arr.at(0), c);
+         const std::string stateType = op.sOr("stateType", "");
+         std::string id;
+         for (auto& kv : c.local)
+            if (kv.second == st) id = kv.first;
+         if (id.empty())
+            for (auto& kv : states)
+               if (kv.second == st) id = kv.first;
+         if (stateType == "HashIndexedView" && kind == "lookup") {
+            if (st->kind != State::HIV) throw Unsupported("lookup into a hash-indexed view that was not created from a buffer");
+            if (!s.probeHiv.empty()) throw Unsupported("nested hash-indexed-view lookups");
+            states[id] = st;
+            s.probeHiv = id;
+         } else if ((stateType == "SimpleState" && kind == "lookup") || (stateType == "HashMap" && kind == "lookup_or_insert")) {
+            if (st->kind != State::UNKNOWN) throw Unsupported("aggregation into a state that is already in use");
+            states[id] = st;
+            s.aggState = id;
+         } else {
+            throw Unsupported(kind + " on a " + (stateType.empty() ? "state" : stateType));
+         }
+         s.cols[op.at("reference").s("displayName")] = mk(Expr::REF);
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "reduce") {
+         Stream s = input(op, c);
+         if (s.aggState.empty()) throw Unsupported("reduce without a preceding lookup into an aggregation state");
+         StateP st = states.at(s.aggState);
+         if (st->kind != State::UNKNOWN) throw Unsupported("two pipelines reduce into one state");
+         for (auto& u : op.at("updated").arr) {
+            AggSpec a;
+            a.member = u.s("member");
+            ExprP e = convert(u.at("expression"), s);
+            auto isMember = [&](const ExprP& x) { return x->kind == Expr::MEMBER && x->name == a.member; };
+            // SumAggrFunc / CountAggrFunc / CountStarAggrFunc / Min / Max bodies (RelAlgToSubOp.cpp:1805-2020)
+            if (e->kind == Expr::OP && e->name == "select" && e->args[0]->kind == Expr::OP && e->args[0]->name == "isnull" && isMember(e->args[0]->args[0]) &&
+                e->args[2]->kind == Expr::OP && e->args[2]->name == "add") { // nullable state: isnull(state) ? arg : state + arg
+               a.fn = "sum";
+               a.arg = e->args[1];
+            } else if (e->kind == Expr::OP && e->name == "add" && isMember(e->args[0])) {
+               if (e->args[1]->kind == Expr::CONST_INT && e->args[1]->i == 1) a.fn = "count_star";
+               else {
+                  a.fn = "sum";
+                  a.arg = e->args[1];
+               }
+            } else if (e->kind == Expr::OP && e->name == "select" && e->args[0]->kind == Expr::OP && e->args[0]->name == "cmp" && isMember(e->args[0]->args[0]) && isMember(e->args[2])) {
+               a.fn = e->args[0]->cmp == "GT" ? "min" : e->args[0]->cmp == "LT" ? "max" : "";
+               a.arg = e->args[1];
+               if (a.fn.empty()) throw Unsupported("aggregate body with an unrecognised comparison");
+            } else {
+               throw Unsupported("aggregate body of member '" + a.member + "' is not sum / count / min / max");
+            }
+            if (a.arg && (a.arg->kind == Expr::UNKNOWN || a.arg->kind == Expr::MEMBER)) throw Unsupported("aggregate argument without a device form");
+            st->aggs.push_back(a);
+         }
+         st->kind = State::AGG;
+         s.aggState.clear();
+         st->in = s;
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "materialize") {
+         Stream s = input(op, c);
+         StateP st = resolve(op.at("accesses").arr.at(0), c);
+         const std::string stateType = op.sOr("stateType", "");
+         if (!s.probeHiv.empty()) throw Unsupported("materialize between a lookup and its join predicate");
+         if (stateType == "Heap") {
+            if (st->kind != State::HEAP) throw Unsupported("materialize into a heap create_heap did not describe");
+         } else if (stateType == "Buffer" || stateType == "ResultTable") {
+            if (st->kind != State::UNKNOWN) throw Unsupported("two pipelines materialise into one " + stateType);
+            st->kind = stateType == "Buffer" ? State::BUFFER : State::RESULT;
+         } else {
+            throw Unsupported("materialize into a " + stateType);
+         }
+         std::vector<std::string> order;
+         for (auto& m : op.at("mapping").arr) {
+            auto it = s.cols.find(m.at("column").s("displayName"));
+            if (it == s.cols.end()) throw Unsupported("materialize of an undefined column '" + m.at("column").s("displayName") + "'");
+            st->members[m.s("member")] = it->second;
+            order.push_back(m.s("member"));
+         }
+         st->in = s;
+         if (st->kind == State::RESULT) {
+            flush(st->in);
+            std::string cols = "[";
+            for (size_t k = 0; k < order.size(); k++) {
+               ExprP& e = st->members[order[k]];
+               if (stripCast(e)->kind == Expr::HASH || stripCast(e)->kind == Expr::REF) throw Unsupported("result column that is a hash or a reference");
+               const std::string col = ensureCol(st->in, e, stripSuffix(order[k]));
+               e = mk(Expr::COL, col);
+               cols += (k ? ", " : "") + quote(col);
+            }
+            OutStep m;
+            m.op = "materialize";
+            m.out = "result";
+            m.fields = {{"in", quote(st->in.rel)}, {"cols", cols + "]"}};
+            steps.push_back(m);
+            result = "result";
+         }
+         c.streams[ref] = s;
+         return;
+      }
+      throw Unsupported("sub-operator '" + kind + "' has no device pattern");
+   }
+
+   void addReport(const std::string& ref, bool gpu, const std::string& reason, size_t nSubops) {
+      if (!report.empty()) report += ", ";
+      report += "{\"ref\": " + quote(ref) + ", \"subops\": " + std::to_string(nSubops) + ", \"target\": " + (gpu ? "\"gpu\"" : "\"cpu\"") + (reason.empty() ? "" : ", \"reason\": " + quote(reason)) + "}";
+   }
+
+   bool run(const J& plan, std::string* err) {
+      if (plan.kind != J::ARR) throw std::runtime_error("subop dump: the document must be the array ToJson::run prints");
+      bool ok = true;
+      for (auto& node : plan.arr) {
+         const std::string& ref = node.s("ref");
+         StepCtx c;
+         const bool isStep = node.sOr("type", "") == "execution_step";
+         size_t nSub = isStep ? node.at("subops").arr.size() : 1;
+         if (!ok) { // after the first unsupported step nothing downstream can be placed
+            addReport(ref, false, "depends on a step that stays on the CPU", nSub);
+            continue;
+         }
+         try {
+            if (isStep) {
+               for (auto& e : node.at("outerEdges").arr) {
+                  if (e.s("type") != "requiredInput") continue;
+                  const std::string id = e.at("input").s("ref") + "#" + std::to_string(e.at("input").iOr("resnr", 0));
+                  const size_t argnr = (size_t) e.at("output").iOr("argnr", 0);
+                  if (c.args.size() <= argnr) c.args.resize(argnr + 1);
+                  auto it = states.find(id);
+                  c.args[argnr] = it == states.end() ? nullptr : it->second;
+               }
+               for (auto& op : node.at("subops").arr) handle(op, c);
+               if (const J* ie = node.get("innerEdges"))
+                  for (auto& e : ie->arr) {
+                     if (e.s("type") != "resultEdge") continue;
+                     const std::string id = e.at("input").s("ref") + "#" + std::to_string(e.at("input").iOr("resnr", 0));
+                     auto it = c.local.find(id);
+                     if (it == c.local.end()) throw Unsupported("step result '" + id + "' is not a state this consumer tracks");
+                     states[ref + "#" + std::to_string(e.at("output").iOr("resnr", 0))] = it->second;
+                  }
+            } else {
+               handle(node, c);
+               for (auto& kv : c.local) states[kv.first] = kv.second;
+            }
+            addReport(ref, true, "", nSub);
+         } catch (const Unsupported& u) {
+            ok = false;
+            addReport(ref, false, u.what(), nSub);
+            if (err->empty()) *err = "step " + ref + ": " + u.what();
+         }
+      }
+      if (ok && result.empty()) {
+         ok = false;
+         *err = "the dump never materialises into a ResultTable";
+      }
+      return ok;
+   }
+
+   std::string planJson(const std::string& name) const {
+      std::string o = "{\"name\": " + quote(name) + ", \"doc\": \"translated from a mlir-subop-to-json dump by ldb_subop_translate\", \"inputs\": [";
+      size_t k = 0;
+      for (auto& t : inputs) o += (k++ ? ", " : "") + quote(t);
+      o += "],\n \"steps\": [\n";
+      for (size_t s = 0; s < steps.size(); s++) {
+         const OutStep& st = steps[s];
+         o += "  {\"op\": " + quote(st.op);
+         for (auto& f : st.fields) o += ", " + quote(f.first) + ": " + f.second;
+         if (st.op == "groupby") {
+            o += ", \"aggs\": [";
+            bool first = true;
+            for (auto& a : st.aggs) {
+               if (!a.used) continue; // aggregates nothing downstream reads (the sum / count halves of an avg)
+               o += std::string(first ? "" : ", ") + "{\"fn\": " + quote(a.fn) + (a.expr.empty() ? "" : ", \"expr\": " + a.expr) + ", \"as\": " + quote(a.as) + "}";
+               first = false;
+            }
+            o += "]";
+         }
+         o += ", \"out\": " + quote(st.out) + "}" + (s + 1 < steps.size() ? ",\n" : "\n");
+      }
+      return o + " ], \"result\": " + quote(result) + "}\n";
+   }
+};
+
+std::string g_subop_err, g_subop_report;
+
+} // namespace
+
+// the translation of one dump: LDB_OK and the plan text (NUL-terminated) in plan_out; LDB_ERR_UNSUPPORTED when a step has
+// no device pattern (ldb_subop_report() says which); LDB_ERR_INVALID for a malformed document or a too-small buffer
+// (*needed receives the size to retry with)
+extern "C" int32_t ldb_subop_translate(const char* dump_json, const char* name, char* plan_out, int64_t cap, int64_t* needed) {
+   g_subop_err.clear();
+   g_subop_report = "[]";
+   if (needed) *needed = 0;
+   if (!dump_json) {
+      g_subop_err = "null dump";
+      return LDB_ERR_INVALID;
+   }
+   try {
+      JParser jp(dump_json);
+      const J doc = jp.value();
+      Translator t;
+      const bool ok = t.run(doc, &g_subop_err);
+      g_subop_report = "[" + t.report + "]";
+      if (!ok) return LDB_ERR_UNSUPPORTED;
+      const std::string text = t.planJson(name ? name : "subop_dump");
+      if (needed) *needed = (int64_t) text.size() + 1;
+      if (!plan_out || cap < (int64_t) text.size() + 1) {
+         g_subop_err = "output buffer too small";
+         return LDB_ERR_INVALID;
+      }
+      memcpy(plan_out, text.c_str(), text.size() + 1);
+      return LDB_OK;
+   } catch (const std::exception& e) {
+      g_subop_err = e.what();
+      return LDB_ERR_INVALID;
+   }
+}
+extern "C" const char* ldb_subop_last_error(void) { return g_subop_err.c_str(); }
+// per execution step: {"ref", "subops", "target": "gpu" | "cpu", "reason"} — the placement handleExecutionStepGPU would make
+extern "C" const char* ldb_subop_report(void) { return g_subop_report.c_str(); }

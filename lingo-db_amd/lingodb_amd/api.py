@@ -508,6 +508,31 @@ class Comm:
         return Table(self.ctx, t)
 
 
+def translate_subop_dump(dump, name="subop_dump"):
+    """(plan text, per-step placement report) for a dump of the reference's `mlir-subop-to-json`; raises LdbError
+    with the offending execution step when a step has no device pattern (needs no GPU)"""
+    import json
+    import os
+
+    text = dump
+    if not dump.lstrip().startswith("["):
+        with open(dump) as f:
+            text = f.read()
+    lib = capi.host_lib()
+    need = C.c_int64()
+    buf = C.create_string_buffer(1 << 16)
+    st = lib.ldb_subop_translate(text.encode(), name.encode(), buf, len(buf), C.byref(need))
+    if st == capi.LDB_ERR_INVALID and need.value > len(buf):
+        buf = C.create_string_buffer(need.value)
+        st = lib.ldb_subop_translate(text.encode(), name.encode(), buf, len(buf), C.byref(need))
+    report = json.loads(lib.ldb_subop_report().decode())
+    if st != capi.LDB_OK:
+        err = capi.LdbError(st, lib.ldb_subop_last_error().decode(errors="replace"))
+        err.report = report
+        raise err
+    return buf.value.decode(), report
+
+
 class Context:
     def __init__(self, device=0, stream=None):
         self.lib = capi.gpu_lib()
@@ -670,6 +695,11 @@ class Context:
         if st != capi.LDB_OK:
             raise capi.LdbError(st, capi.host_lib().ldb_plan_json_last_error().decode(errors="replace"))
         return Table(self, t)
+
+    def run_subop_dump(self, dump, tables, name="subop_dump", comm=None):
+        """runs a query from the reference's sub-operator dump (tools/ct/mlir-subop-to-json.cpp output, text or path):
+        translate_subop_dump → run_plan"""
+        return self.run_plan(translate_subop_dump(dump, name)[0], tables, comm=comm)
 
     def load_ipc(self, name, path, narrow_decimals=False):
         """registers one Arrow IPC file as a table — the reference keeps one `<table>.arrow` IPC

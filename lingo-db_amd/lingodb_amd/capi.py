@@ -19,6 +19,8 @@ LDB_MAX_AGG_PREDS = 3
 
 # ldb_status
 LDB_OK = 0
+LDB_ERR_INVALID = -1
+LDB_ERR_UNSUPPORTED = -2
 LDB_ERR_NO_DEVICE = -5
 
 # ldb_type
@@ -242,6 +244,9 @@ HOST_API = {
     "ldb_plan_run_json_comm": (i32, [P, P, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(P), i32, PP]),
     "ldb_plan_json_last_error": (C.c_char_p, []),
     "ldb_plan_json_check": (i32, [C.c_char_p, C.POINTER(C.c_char_p), i32]),
+    "ldb_subop_translate": (i32, [C.c_char_p, C.c_char_p, C.c_char_p, i64, C.POINTER(i64)]),
+    "ldb_subop_last_error": (C.c_char_p, []),
+    "ldb_subop_report": (C.c_char_p, []),
     "ldb_host_parse_date32": (i32, [C.c_char_p, C.POINTER(i32)]),
     "ldb_host_parse_decimal": (i32, [C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64)]),
     "ldb_host_decimal_type": (None, [i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),

@@ -64,3 +64,27 @@ def test_plan_matches_oracle(world, q):
         assert [r[1] for r in got] == [r[1] for r in want] and sorted(got) == sorted(want)
     else:
         assert got == want
+
+
+@pytest.mark.parametrize("q", [6, 1, 3])
+def test_subop_dump_matches_oracle(world, q):
+    """f1 end to end: the reference-schema dump of the query (tests/golden/subop_tpch_qN.json, the format of
+    tools/ct/mlir-subop-to-json.cpp) → ldb_subop_translate → the plan interpreter → the same oracle leg"""
+    import os
+
+    from lingodb_amd import api
+
+    runner, legs = world
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "subop_tpch_q%d.json" % q)
+    text, report = api.translate_subop_dump(path, "tpch_q%d" % q)
+    assert all(r["target"] == "gpu" for r in report)
+    got = canon(runner.ctx.run_plan(text, runner.plan_inputs(q)).to_arrow())
+    want = legs.run(q)
+    if q in LIMITS:
+        k, key = LIMITS[q]
+        assert len(got) == min(k, len(want))
+        assert [key(r) for r in got] == [key(r) for r in want[: len(got)]]
+        assert set(got) <= set(want)
+    else:
+        assert got == want
+    assert got == canon(runner.run(q).to_arrow()) or q in LIMITS  # and the hand-written plan file agrees row for row

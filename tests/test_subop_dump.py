@@ -1,0 +1,129 @@
+"""f1: the consumer of the reference's OWN dump schema (`tools/ct/mlir-subop-to-json.cpp`: execution_step / subops /
+get_external meta / outerEdges).  CPU half: the hand-authored dumps of Q6, Q1, Q3 (tests/golden/subop_tpch_q*.json,
+written by tools/write_subop_dumps.py field by field after the tool) translate into step lists that pass the plan
+checker and say the same thing as the hand-written plan files; steps without a device pattern are reported per
+execution step.  The GPU half (translator → interpreter → oracle) is tests/test_gpu_sf1_oracle.py."""
+import copy
+import json
+import os
+
+import pytest
+
+from lingodb_amd import api, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def dump(q):
+    with open(os.path.join(GOLD, "subop_tpch_q%d.json" % q)) as f:
+        return f.read()
+
+
+def hand_plan(q):
+    with open(os.path.join(ROOT, "lingo-db_amd", "plans", "tpch", "q%d.json" % q)) as f:
+        return json.load(f)
+
+
+def normal(plan):
+    """a plan's steps with value names numbered by first appearance and aggregate / estimate naming removed"""
+    names, out = {}, []
+    agg_names = {}
+
+    def val(n):
+        return names.setdefault(n, "#%d" % len(names)) if n not in plan["inputs"] else n
+
+    for st in plan["steps"]:
+        s = {"op": st["op"]}
+        for k in ("in", "ht"):
+            if k in st:
+                s[k] = val(st[k])
+        for k in ("keys", "kind", "unique", "k"):
+            if k in st:
+                s[k] = st[k]
+        if "preds" in st:
+            s["preds"] = sorted(json.dumps({**p, "value": str(p["value"])} if "value" in p else p, sort_keys=True) for p in st["preds"])
+        if "aggs" in st:
+            s["aggs"] = []
+            for a in st["aggs"]:
+                agg_names[a["as"]] = "agg%d" % len(agg_names)
+                s["aggs"].append((a["fn"], json.dumps(a.get("expr"))))
+        for k in ("by", "cols"):
+            if k in st:
+                s[k] = [({**c, "col": agg_names.get(c["col"], c["col"])} if isinstance(c, dict) else agg_names.get(c, c)) for c in st[k]]
+        val(st["out"])
+        out.append(s)
+    return out
+
+
+@pytest.mark.parametrize("q", [6, 1, 3])
+def test_dump_translates_to_a_checked_plan(q):
+    text, report = api.translate_subop_dump(dump(q), "tpch_q%d" % q)
+    plan = json.loads(text)
+    assert all(r["target"] == "gpu" for r in report) and len(report) == len(json.loads(dump(q)))
+    lib = capi.host_lib()
+    ins = plan["inputs"]
+    arr = (capi.C.c_char_p * len(ins))(*[n.encode() for n in ins])
+    assert lib.ldb_plan_json_check(text.encode(), arr, len(ins)) == capi.LDB_OK, lib.ldb_plan_json_last_error()
+    assert sorted(ins) == sorted(hand_plan(q)["inputs"])
+
+
+def test_q6_and_q1_say_what_the_hand_plans_say():
+    for q in (6, 1):
+        got = normal(json.loads(api.translate_subop_dump(dump(q))[0]))
+        want = normal(hand_plan(q))
+        if q == 6:  # the hand plan returns the group-by table itself; the dump materialises it into a ResultTable
+            assert got[-1]["op"] == "materialize" and got[:-1] == want
+            continue
+        # the aggregates come in the reduce's member order: compare as sets, and the result columns by position
+        assert [s["op"] for s in got] == [s["op"] for s in want]
+        assert sorted(got[0]["aggs"]) == sorted(want[0]["aggs"]) and got[0]["keys"] == want[0]["keys"] and got[0]["preds"] == want[0]["preds"]
+        assert got[1]["by"] == want[1]["by"] and len(got[2]["cols"]) == len(want[2]["cols"]) and got[2]["cols"][:2] == want[2]["cols"][:2]
+
+
+def test_q3_has_the_hand_plans_operators():
+    got = normal(json.loads(api.translate_subop_dump(dump(3))[0]))
+    want = normal(hand_plan(3))
+    key = lambda s: json.dumps({k: v for k, v in s.items() if k not in ("in", "ht")}, sort_keys=True, default=str)
+    assert sorted(map(key, got)) == sorted(map(key, want))
+    # … in an order that respects the data flow: both builds are unique (primary key; a key that stays unique through an N:1 join)
+    builds = [s for s in got if s["op"] == "join_build"]
+    assert [b["keys"] for b in builds] == [["c_custkey"], ["o_orderkey"]] and all(b["unique"] for b in builds)
+
+
+def test_steps_without_a_device_pattern_are_reported():
+    d = json.loads(dump(6))
+    pipe = next(n for n in d if any(s.get("subop") == "reduce" for s in n["subops"]))
+    bad = copy.deepcopy(d)
+    p2 = next(n for n in bad if n["ref"] == pipe["ref"])
+    p2["subops"].insert(2, {"ref": "x:1", "type": "suboperator", "outerEdges": [], "accesses": [], "operator": "unknown"})  # what the tool prints for an op it has no case for
+    with pytest.raises(capi.LdbError) as e:
+        api.translate_subop_dump(json.dumps(bad))
+    assert e.value.status == capi.LDB_ERR_UNSUPPORTED and pipe["ref"] in str(e.value)
+    rep = {r["ref"]: r for r in e.value.report}
+    assert rep[pipe["ref"]]["target"] == "cpu" and "no case" in rep[pipe["ref"]]["reason"]
+    assert rep[d[0]["ref"]]["target"] == "gpu" and rep[d[-1]["ref"]]["target"] == "cpu"  # what follows cannot be placed either
+    # the tool's own rendering of db.sub (" + ", mlir-subop-to-json.cpp:334) would silently change Q1: the dumps carry " - "
+    assert '" - "' in dump(1) and '" - "' in dump(3)
+    # a sub-operator with a case in the tool but no device pattern
+    bad = copy.deepcopy(d)
+    next(n for n in bad if n["ref"] == pipe["ref"])["subops"][1]["subop"] = "scatter"
+    with pytest.raises(capi.LdbError) as e:
+        api.translate_subop_dump(json.dumps(bad))
+    assert "scatter" in str(e.value)
+
+
+def test_malformed_documents_are_rejected():
+    for text in ("{}", "[{\"type\": \"execution_step\"}]", "[", "[1]"):
+        with pytest.raises(capi.LdbError) as e:
+            api.translate_subop_dump(text if text.startswith("[") else "[" + text)
+        assert e.value.status in (capi.LDB_ERR_INVALID, capi.LDB_ERR_UNSUPPORTED)
+
+
+def test_dumps_are_what_the_generator_writes(tmp_path):
+    import subprocess
+    import sys
+
+    before = {q: dump(q) for q in (6, 1, 3)}
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "write_subop_dumps.py")], stdout=subprocess.DEVNULL)
+    assert {q: dump(q) for q in (6, 1, 3)} == before

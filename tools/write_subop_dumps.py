@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Hand-authored sub-operator dumps of TPC-H Q6, Q1 and Q3 in the schema of the reference's
+`tools/ct/mlir-subop-to-json.cpp` (run by tools/ct/ct.py:134 on the snapshot after `subop-prepare-lowering`).
+The tool cannot be built here (MLIR), so every helper below restates ONE function of it and emits the same
+fields; the sub-operator sequences follow the reference's lowerings:
+
+  BaseTableLowering          RelAlgToSubOp.cpp:103-141   get_external (+ pushed-down FilterDescriptions) → scan
+  performAggregation         RelAlgToSubOp.cpp:2130-2190 create_simple_state | generic_create(map) → lookup |
+                                                         lookup_or_insert → reduce; members "aggrVal$n" / "keyval$n"
+  Sum/Count aggregate bodies RelAlgToSubOp.cpp:1805-2020 state + arg, state + 1, nullable-state select
+  translateHJ + Specialize   RelAlgToSubOp.cpp:1097-1128 materialize(buffer) → create_hash_indexed_view → lookup →
+                                                         nested_map { scan_list → gather → combine_tuple → map → filter }
+  Pushdown                   Pushdown.cpp:309-411        selections folded into the base table's filters
+
+Fields the tool does NOT emit today and a GPU backend needs (INTEGRATION.md §1b lists the one-line emitter
+changes); they are marked EXT below:
+  E1  db.sub is printed with the separator " + " (mlir-subop-to-json.cpp:334) — dumps here use " - "
+  E3  subop.get_local (the thread-local accessor the parallelize pass inserts) has no case → {"subop": "get_local"}
+  E4  create_sorted_view / create_heap carry no sort criteria → "sortBy": [{"member", "direction"}], "maxRows"
+  E5  get_external meta has no key information → optional "primaryKey": [identifiers]
+  E6  subop.combine_tuple has no case → {"subop": "combine_tuple"}
+
+Writes tests/golden/subop_tpch_q{6,1,3}.json."""
+import json
+import os
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def column(name, datatype):  # columnToJSON, mlir-subop-to-json.cpp:395-409
+    return {"datatype": datatype, "type": "expression_leaf", "leaf_type": "column", "displayName": name}
+
+
+def const(value, data_type):  # convertConstant, :204-228
+    return {"type": "expression_leaf", "leaf_type": "constant", "data_type": data_type, "value": value}
+
+
+def member(name):  # the `member` leaf of a reduce region argument, :826
+    return {"type": "expression_leaf", "leaf_type": "member", "member": name}
+
+
+def unknown():  # what the tool prints for an op it has no case for (db.nullable_get_val …), :344-348
+    return {"type": "expression_leaf", "leaf_type": "unknown"}
+
+
+def inner(strings, subs):  # innerExpression, :183-203
+    return {"type": "expression_inner", "strings": strings, "subExpressions": subs}
+
+
+def mul(a, b): return inner(["", " * ", ""], [a, b])
+def add(a, b): return inner(["", " + ", ""], [a, b])
+def sub(a, b): return inner(["", " - ", ""], [a, b])  # EXT E1
+def div(a, b): return inner(["", " / ", ""], [a, b])
+def cast(a): return inner(["cast(", ")"], [a])
+def eq(a, b): return inner(["", "=", ""], [a, b])  # convertCmpPredicate prints no spaces, :169-182
+def hash_(*cols): return inner(["hash("] + [")"], [cols[0]]) if len(cols) == 1 else inner(["hash(", ")"], [inner(["pack("] + [", "] * (len(cols) - 1) + [")"], list(cols))])
+def isnull(a): return inner(["", " is null"], [a])
+def select(c, a, b): return inner(["", " ? ", " : ", ""], [c, a, b])
+
+
+class Dump:
+    def __init__(self, name):
+        self.name, self.line, self.plan = name, 0, []
+
+    def ref(self):  # getOperationReference: "<file stem>:<line>", :367-381
+        self.line += 1
+        return "%s:%d" % (self.name, self.line)
+
+    def subop(self, kind, streams=(), accesses=(), **fields):  # the envelope of convertOperation, :433-445
+        r = self.ref()
+        node = {"ref": r, "type": "suboperator",
+                "outerEdges": [{"type": "stream", "input": {"type": "node", "ref": s, "resnr": 0}, "output": {"type": "node", "ref": r}} for s in streams],
+                "accesses": list(accesses), "subop": kind}
+        node.update(fields)
+        return node
+
+    def step(self, subops, inputs=(), results=()):
+        """execution_step, :446-500.  inputs: [(type string, producing step ref, result number)];
+        results: [(type string, ref of the inner op, its result number)]"""
+        r = self.ref()
+        node = {"ref": r, "type": "execution_step", "outerEdges": [], "accesses": [], "subops": subops, "inputs": [], "results": [], "innerEdges": []}
+        for i, (ty, src, resnr) in enumerate(inputs):
+            node["inputs"].append({"type": ty})
+            node["outerEdges"].append({"type": "requiredInput", "input": {"type": "node", "ref": src, "resnr": resnr}, "output": {"type": "node", "ref": r, "argnr": i}})
+        for i, (ty, src, resnr) in enumerate(results):
+            node["results"].append({"type": ty})
+            node["innerEdges"].append({"type": "resultEdge", "input": {"type": "node", "ref": src, "resnr": resnr}, "output": {"type": "parentResult", "resnr": i}})
+        if self.plan:  # ToJson::run chains the steps with "order" edges, :856-858
+            node["outerEdges"].append({"type": "order", "input": {"type": "node", "ref": self.plan[-1]["ref"]}, "output": {"type": "node", "ref": r}})
+        self.plan.append(node)
+        return r
+
+    def write(self):
+        path = os.path.join(OUT, "subop_%s.json" % self.name)
+        with open(path, "w") as f:
+            json.dump(self.plan, f, indent=1)
+            f.write("\n")
+        return path
+
+
+def arg(n): return {"type": "parentArg", "argnr": n}
+def node(ref, resnr=0): return {"type": "node", "ref": ref, "resnr": resnr}
+
+
+TYPES = {"l_orderkey": "int32", "l_partkey": "int32", "l_suppkey": "int32", "l_linenumber": "int32", "l_quantity": "decimal(12,2)",
+         "l_extendedprice": "decimal(12,2)", "l_discount": "decimal(12,2)", "l_tax": "decimal(12,2)", "l_returnflag": "char1",
+         "l_linestatus": "char1", "l_shipdate": "date", "l_commitdate": "date", "l_receiptdate": "date", "l_shipinstruct": "str",
+         "l_shipmode": "str", "l_comment": "str",
+         "o_orderkey": "int32", "o_custkey": "int32", "o_orderstatus": "char1", "o_totalprice": "decimal(12,2)", "o_orderdate": "date",
+         "o_orderpriority": "str", "o_clerk": "str", "o_shippriority": "int32", "o_comment": "str",
+         "c_custkey": "int32", "c_name": "str", "c_address": "str", "c_nationkey": "int32", "c_phone": "str", "c_acctbal": "decimal(12,2)",
+         "c_mktsegment": "str", "c_comment": "str"}
+TABLES = {"lineitem": [c for c in TYPES if c.startswith("l_")], "orders": [c for c in TYPES if c.startswith("o_")], "customer": [c for c in TYPES if c.startswith("c_")]}
+PKEY = {"orders": ["o_orderkey"], "customer": ["c_custkey"]}
+
+
+def get_external(d, table, filters):
+    """one step holding subop.get_external; meta = the deserialised ExternalDatasourceProperty (:508-560)"""
+    cols = TABLES[table]
+    meta = {"tableName": table, "mapping": [{"memberName": "%s$0" % c, "identifier": c} for c in cols],
+            "filters": [{"columnName": c, "columnId": 0, "op": op, "value": v} for c, op, v in filters]}
+    if table in PKEY:
+        meta["primaryKey"] = PKEY[table]  # EXT E5
+    op = d.subop("get_external", meta=meta)
+    ty = "Table[" + "".join("%s$0:%s," % (c, TYPES[c]) for c in cols) + "]"
+    return d.step([op], results=[(ty, op["ref"], 0)]), ty
+
+
+def col(table, c): return column("%s::%s" % (table, c), TYPES[c])
+def scan_mapping(table, cols): return [{"member": "%s$0" % c, "column": col(table, c)} for c in cols]
+
+
+def q6():
+    d = Dump("tpch_q6")
+    t, tty = get_external(d, "lineitem", [("l_shipdate", "GTE", "1994-01-01"), ("l_shipdate", "LT", "1995-01-01"), ("l_discount", "GTE", "0.05"),
+                                          ("l_discount", "LTE", "0.07"), ("l_quantity", "LT", "24")])
+    tl = d.subop("create_thread_local")  # the tool's first create_thread_local case prints no resultType (:501-504)
+    s_tl = d.step([tl], results=[("?", tl["ref"], 0)])
+    scan = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("lineitem", ["l_extendedprice", "l_discount"]))
+    prod = column("map0::tmp_attr0", "decimal(24,4)")
+    mp = d.subop("map", streams=[scan["ref"]], computed=[{"computed": prod, "expression": mul(col("lineitem", "l_extendedprice"), col("lineitem", "l_discount"))}])
+    loc = d.subop("get_local", accesses=[arg(1)])  # EXT E3
+    ref = column("lookup0::ref", "?")
+    lk = d.subop("lookup", streams=[mp["ref"]], accesses=[node(loc["ref"])], stateType="SimpleState", reference=ref)
+    # SumAggrFunc::aggregate with a nullable state and a non-nullable argument (RelAlgToSubOp.cpp:1996-2002):
+    # select(isnull(state), arg, nullable_get_val(state) + arg); the tool has no case for nullable_get_val
+    rd = d.subop("reduce", streams=[lk["ref"]], reference=ref,
+                 updated=[{"member": "aggrVal$0", "expression": select(isnull(member("aggrVal$0")), prod, add(unknown(), prod))}])
+    d.step([scan, mp, loc, lk, rd], inputs=[(tty, t, 0), ("?", s_tl, 0)])
+    mg = d.subop("merge", accesses=[arg(0)], stateType="SimpleState")
+    s_mg = d.step([mg], inputs=[("?", s_tl, 0)], results=[("?", mg["ref"], 0)])
+    rt = d.subop("generic_create")
+    rty = "ResultTable[revenue$0:nullable(decimal(24,4)),]"
+    s_rt = d.step([rt], results=[(rty, rt["ref"], 0)])
+    revenue = column("aggr0::tmp_attr1", "nullable(decimal(24,4))")
+    sc2 = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "aggrVal$0", "column": revenue}])
+    mat = d.subop("materialize", streams=[sc2["ref"]], accesses=[arg(1)], stateType="ResultTable", mapping=[{"member": "revenue$0", "column": revenue}])
+    d.step([sc2, mat], inputs=[("?", s_mg, 0), (rty, s_rt, 0)])
+    return d.write()
+
+
+def q1():
+    d = Dump("tpch_q1")
+    t, tty = get_external(d, "lineitem", [("l_shipdate", "LTE", "1998-09-02")])
+    tl = d.subop("create_thread_local")
+    s_tl = d.step([tl], results=[("?", tl["ref"], 0)])
+    L = lambda c: col("lineitem", c)
+    scan = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("lineitem", ["l_returnflag", "l_linestatus", "l_quantity", "l_extendedprice", "l_discount", "l_tax"]))
+    one = const(1, "decimal(12,2)")
+    disc = column("map0::tmp_attr0", "decimal(24,4)")
+    charge = column("map0::tmp_attr1", "decimal(36,6)")
+    mp = d.subop("map", streams=[scan["ref"]], computed=[
+        {"computed": disc, "expression": mul(L("l_extendedprice"), sub(one, L("l_discount")))},
+        {"computed": charge, "expression": mul(mul(L("l_extendedprice"), sub(one, L("l_discount"))), add(one, L("l_tax")))}])
+    loc = d.subop("get_local", accesses=[arg(1)])
+    ref = column("lookup0::ref", "?")
+    lk = d.subop("lookup_or_insert", streams=[mp["ref"]], accesses=[node(loc["ref"])], stateType="HashMap", reference=ref)
+    # the frontend splits avg(x) into sum(x) / count(x) (sql_analyzer); CountAggrFunc over a non-nullable
+    # argument and CountStarAggrFunc are both state + 1 (RelAlgToSubOp.cpp:1815-1837)
+    srcs = [L("l_quantity"), L("l_extendedprice"), disc, charge, L("l_quantity"), None, L("l_extendedprice"), None, L("l_discount"), None, None]
+    upd = []
+    for i, s in enumerate(srcs):
+        m = "aggrVal$%d" % i
+        upd.append({"member": m, "expression": add(member(m), s if s is not None else const(1, "int64"))})
+    rd = d.subop("reduce", streams=[lk["ref"]], reference=ref, updated=upd)
+    d.step([scan, mp, loc, lk, rd], inputs=[(tty, t, 0), ("?", s_tl, 0)])
+    mg = d.subop("merge", accesses=[arg(0)], stateType="HashMap")
+    s_mg = d.step([mg], inputs=[("?", s_tl, 0)], results=[("?", mg["ref"], 0)])
+    buf = d.subop("generic_create")
+    s_buf = d.step([buf], results=[("Buffer[...]", buf["ref"], 0)])
+    A = [column("aggr0::tmp_attr%d" % i, "decimal(38,2)" if i < 4 or i in (4, 6, 8) else "int64") for i in range(11)]
+    sc2 = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "keyval$0", "column": L("l_returnflag")}, {"member": "keyval$1", "column": L("l_linestatus")}] +
+                  [{"member": "aggrVal$%d" % i, "column": A[i]} for i in range(11)])
+    avgs = [column("map1::tmp_attr%d" % i, "decimal(38,8)") for i in range(3)]
+    mp2 = d.subop("map", streams=[sc2["ref"]], computed=[{"computed": avgs[i], "expression": div(A[4 + 2 * i], cast(A[5 + 2 * i]))} for i in range(3)])
+    outs = [("l_returnflag", L("l_returnflag")), ("l_linestatus", L("l_linestatus")), ("sum_qty", A[0]), ("sum_base_price", A[1]), ("sum_disc_price", A[2]),
+            ("sum_charge", A[3]), ("avg_qty", avgs[0]), ("avg_price", avgs[1]), ("avg_disc", avgs[2]), ("count_order", A[10])]
+    mat = d.subop("materialize", streams=[mp2["ref"]], accesses=[arg(1)], stateType="Buffer", mapping=[{"member": "%s$1" % n, "column": c} for n, c in outs])
+    d.step([sc2, mp2, mat], inputs=[("?", s_mg, 0), ("Buffer[...]", s_buf, 0)])
+    sv = d.subop("create_sorted_view", accesses=[arg(0)], sortBy=[{"member": "l_returnflag$1", "direction": "asc"}, {"member": "l_linestatus$1", "direction": "asc"}])  # EXT E4
+    s_sv = d.step([sv], inputs=[("Buffer[...]", s_buf, 0)], results=[("SortedView Buffer[...]", sv["ref"], 0)])
+    rt = d.subop("generic_create")
+    s_rt = d.step([rt], results=[("ResultTable[...]", rt["ref"], 0)])
+    final = [(n, column("sorted0::%s" % n, c["datatype"])) for n, c in outs]
+    sc3 = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "%s$1" % n, "column": c} for n, c in final])
+    mat2 = d.subop("materialize", streams=[sc3["ref"]], accesses=[arg(1)], stateType="ResultTable", mapping=[{"member": "%s$2" % n, "column": c} for n, c in final])
+    d.step([sc3, mat2], inputs=[("SortedView Buffer[...]", s_sv, 0), ("ResultTable[...]", s_rt, 0)])
+    return d.write()
+
+
+def hash_join_probe(d, stream_ref, hiv_arg, probe_key, build_cols, n):
+    """lookup into a hash-indexed view and the nested_map translateHJ builds around the matches; returns (ops, ref of the
+    nested_map, whose result stream the next sub-operator consumes)"""
+    lst = column("lookup%d::list" % n, "?")
+    ent = column("lookup%d::entryref" % n, "?")
+    lk = d.subop("lookup", streams=[stream_ref], accesses=[arg(hiv_arg)], stateType="HashIndexedView", reference=lst)
+    nm_ref = None
+    sl = d.subop("scan_list", accesses=[{"type": "nested_map_arg", "column": lst, "id": "pending"}], elem=ent)
+    ga = d.subop("gather", streams=[sl["ref"]], reference=ent, mapping=[{"member": m, "column": c} for m, c in build_cols])
+    ct = d.subop("combine_tuple", streams=[ga["ref"]])  # EXT E6
+    pred = column("map_hj%d::pred" % n, "int1")
+    mp = d.subop("map", streams=[ct["ref"]], computed=[{"computed": pred, "expression": eq(probe_key, build_cols[0][1])}])
+    fl = d.subop("filter", streams=[mp["ref"]], semantic="all_true", columns=[pred])
+    nm = d.subop("nested_map", streams=[lk["ref"]], inputs=[], subops=[sl, ga, ct, mp, fl])
+    sl["accesses"][0]["id"] = nm["ref"] + "_0"
+    return [lk, nm], nm["ref"]
+
+
+def q3():
+    d = Dump("tpch_q3")
+    C = lambda c: col("customer", c)
+    O = lambda c: col("orders", c)
+    L = lambda c: col("lineitem", c)
+    tc, tcty = get_external(d, "customer", [("c_mktsegment", "EQ", "BUILDING")])
+    to, toty = get_external(d, "orders", [("o_orderdate", "LT", "1995-03-15")])
+    tl_, tlty = get_external(d, "lineitem", [("l_shipdate", "GT", "1995-03-15")])
+    # build side 1: customer
+    b1 = d.subop("generic_create")
+    s_b1 = d.step([b1], results=[("Buffer[...]", b1["ref"], 0)])
+    sc = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("customer", ["c_custkey"]))
+    h1 = column("hj0::hash", "index")
+    m1 = d.subop("map", streams=[sc["ref"]], computed=[{"computed": h1, "expression": hash_(C("c_custkey"))}])
+    mt1 = d.subop("materialize", streams=[m1["ref"]], accesses=[arg(1)], stateType="Buffer", mapping=[{"member": "hash$0", "column": h1}, {"member": "c_custkey$1", "column": C("c_custkey")}])
+    d.step([sc, m1, mt1], inputs=[(tcty, tc, 0), ("Buffer[...]", s_b1, 0)])
+    v1 = d.subop("create_hash_indexed_view", accesses=[arg(0)])
+    s_v1 = d.step([v1], inputs=[("Buffer[...]", s_b1, 0)], results=[("?", v1["ref"], 0)])
+    # orders probe customer, the matches are build side 2
+    b2 = d.subop("generic_create")
+    s_b2 = d.step([b2], results=[("Buffer[...]", b2["ref"], 0)])
+    so = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("orders", ["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"]))
+    h2 = column("hj1::hash", "index")
+    m2 = d.subop("map", streams=[so["ref"]], computed=[{"computed": h2, "expression": hash_(O("o_custkey"))}])
+    probe1, after1 = hash_join_probe(d, m2["ref"], 1, O("o_custkey"), [("c_custkey$1", C("c_custkey"))], 0)
+    h3 = column("hj2::hash", "index")
+    m3 = d.subop("map", streams=[after1], computed=[{"computed": h3, "expression": hash_(O("o_orderkey"))}])
+    mt2 = d.subop("materialize", streams=[m3["ref"]], accesses=[arg(2)], stateType="Buffer",
+                  mapping=[{"member": "hash$2", "column": h3}, {"member": "o_orderkey$3", "column": O("o_orderkey")}, {"member": "o_orderdate$3", "column": O("o_orderdate")},
+                           {"member": "o_shippriority$3", "column": O("o_shippriority")}])
+    d.step([so, m2] + probe1 + [m3, mt2], inputs=[(toty, to, 0), ("?", s_v1, 0), ("Buffer[...]", s_b2, 0)])
+    v2 = d.subop("create_hash_indexed_view", accesses=[arg(0)])
+    s_v2 = d.step([v2], inputs=[("Buffer[...]", s_b2, 0)], results=[("?", v2["ref"], 0)])
+    # lineitem probes the joined orders and aggregates
+    hm = d.subop("generic_create")
+    s_hm = d.step([hm], results=[("?", hm["ref"], 0)])
+    sl = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("lineitem", ["l_orderkey", "l_extendedprice", "l_discount"]))
+    h4 = column("hj3::hash", "index")
+    m4 = d.subop("map", streams=[sl["ref"]], computed=[{"computed": h4, "expression": hash_(L("l_orderkey"))}])
+    probe2, after2 = hash_join_probe(d, m4["ref"], 1, L("l_orderkey"),
+                                     [("o_orderkey$3", O("o_orderkey")), ("o_orderdate$3", O("o_orderdate")), ("o_shippriority$3", O("o_shippriority"))], 1)
+    rev_in = column("map0::tmp_attr0", "decimal(24,4)")
+    m5 = d.subop("map", streams=[after2], computed=[{"computed": rev_in, "expression": mul(L("l_extendedprice"), sub(const(1, "decimal(12,2)"), L("l_discount")))}])
+    ref = column("lookup2::ref", "?")
+    lk = d.subop("lookup_or_insert", streams=[m5["ref"]], accesses=[arg(2)], stateType="HashMap", reference=ref)
+    rd = d.subop("reduce", streams=[lk["ref"]], reference=ref, updated=[{"member": "aggrVal$0", "expression": add(member("aggrVal$0"), rev_in)}])
+    d.step([sl, m4] + probe2 + [m5, lk, rd], inputs=[(tlty, tl_, 0), ("?", s_v2, 0), ("?", s_hm, 0)])
+    # top 10 by revenue desc, o_orderdate
+    revenue = column("aggr0::tmp_attr1", "decimal(38,4)")
+    hp = d.subop("create_heap", maxRows=10, sortBy=[{"member": "revenue$4", "direction": "desc"}, {"member": "o_orderdate$4", "direction": "asc"}])  # EXT E4
+    s_hp = d.step([hp], results=[("?", hp["ref"], 0)])
+    sg = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "keyval$0", "column": L("l_orderkey")}, {"member": "keyval$1", "column": O("o_orderdate")},
+                                                      {"member": "keyval$2", "column": O("o_shippriority")}, {"member": "aggrVal$0", "column": revenue}])
+    outs = [("l_orderkey", L("l_orderkey")), ("revenue", revenue), ("o_orderdate", O("o_orderdate")), ("o_shippriority", O("o_shippriority"))]
+    mh = d.subop("materialize", streams=[sg["ref"]], accesses=[arg(1)], stateType="Heap", mapping=[{"member": "%s$4" % n, "column": c} for n, c in outs])
+    d.step([sg, mh], inputs=[("?", s_hm, 0), ("?", s_hp, 0)])
+    rt = d.subop("generic_create")
+    s_rt = d.step([rt], results=[("ResultTable[...]", rt["ref"], 0)])
+    final = [(n, column("heap0::%s" % n, c["datatype"])) for n, c in outs]
+    sh = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "%s$4" % n, "column": c} for n, c in final])
+    mr = d.subop("materialize", streams=[sh["ref"]], accesses=[arg(1)], stateType="ResultTable", mapping=[{"member": "%s$5" % n, "column": c} for n, c in final])
+    d.step([sh, mr], inputs=[("?", s_hp, 0), ("ResultTable[...]", s_rt, 0)])
+    return d.write()
+
+
+if __name__ == "__main__":
+    for f in (q6, q1, q3):
+        print(f())
