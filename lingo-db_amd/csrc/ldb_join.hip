@@ -299,11 +299,12 @@ struct DRadix {
    uint64_t kmult, mask;
    uint32_t kmult32, ksh, slot32, pshift, nparts, grid;
    uint64_t rows_per_wg;
+   uint32_t direct, pad; // the table's layout (ldb_hashtable::direct): 1 = one slot per key value, 2 = one word per 32 key values
 };
 __device__ __forceinline__ uint32_t d_radix_part(const DRadix& d, uint32_t key) {
    const uint32_t r = key - (uint32_t) d.kmin;
    if (r > (uint32_t) (d.kmax - d.kmin)) return 0; // no slot: matches nothing, any partition will do
-   const uint64_t pos = d.slot32 ? (uint64_t) __umulhi(r << d.ksh, d.kmult32) : ((((uint64_t) r * d.kmult) >> 32) & d.mask);
+   const uint64_t pos = d.direct ? (uint64_t) (d.direct == 2 ? r >> 5 : r) : d.slot32 ? (uint64_t) __umulhi(r << d.ksh, d.kmult32) : ((((uint64_t) r * d.kmult) >> 32) & d.mask);
    return (uint32_t) (pos >> d.pshift);
 }
 __device__ __forceinline__ uint32_t d_radix_key(const DRadix& d, uint64_t i) {
@@ -338,8 +339,8 @@ __global__ void k_radix_locality(DRadix d, uint64_t stride, unsigned int* __rest
    unsigned int near = 0, valid = 0;
    if (i + 1 < d.n) {
       const uint32_t a = d_radix_key(d, i) - (uint32_t) d.kmin, c = d_radix_key(d, i + 1) - (uint32_t) d.kmin;
-      const uint64_t pa = d.slot32 ? (uint64_t) __umulhi(a << d.ksh, d.kmult32) : ((((uint64_t) a * d.kmult) >> 32) & d.mask);
-      const uint64_t pc = d.slot32 ? (uint64_t) __umulhi(c << d.ksh, d.kmult32) : ((((uint64_t) c * d.kmult) >> 32) & d.mask);
+      const uint64_t pa = d.direct ? (uint64_t) (d.direct == 2 ? a >> 5 : a) : d.slot32 ? (uint64_t) __umulhi(a << d.ksh, d.kmult32) : ((((uint64_t) a * d.kmult) >> 32) & d.mask);
+      const uint64_t pc = d.direct ? (uint64_t) (d.direct == 2 ? c >> 5 : c) : d.slot32 ? (uint64_t) __umulhi(c << d.ksh, d.kmult32) : ((((uint64_t) c * d.kmult) >> 32) & d.mask);
       valid = 1;
       near = (pa > pc ? pa - pc : pc - pa) < 8192 ? 1 : 0;
    }
@@ -367,13 +368,16 @@ static int32_t radix_prepare(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, co
    // into a 4.3 GB table), the partition pass costs more than the L2-resident probe (56 Grows/s) wins back
    // — see DESIGN.md §Join for the measured crossover
    const int64_t mode = ldb_option("join_radix", 0);
-   if (mode == 0 || n_keys != 1 || !ht->key32 || !ht->ordered_slots || ht->chained || probe->n_rows < 2) return LDB_OK;
+   if (mode == 0 || n_keys != 1 || !ht->key32 || !(ht->ordered_slots || ht->direct) || ht->chained || probe->n_rows < 2) return LDB_OK;
    if (kind == LDB_JOIN_MARK || kind == LDB_JOIN_SEMI || kind == LDB_JOIN_ANTI) return LDB_OK; // results promised in probe order
    if (probe->sides.size() + 1 + ht->build->sides.size() > LDB_MAX_SIDES) return LDB_OK;
    DCol kc;
    LDB_TRY(ldb_make_dcol(probe, keys[0], &kc));
    if (kc.width != 4 || kc.validity || kc.type == LDB_T_FLOAT32) return LDB_OK;
-   if (mode < 0 && (ht->cap * 8 < (uint64_t) ldb_option("join_radix_min_table_bytes", 64ll << 20) || probe->n_rows < ldb_option("join_radix_min_rows", 16ll << 20))) return LDB_OK;
+   // slots of the table and their size: a rank table has one 8-byte word per 32 key values
+   const uint64_t units = ht->direct == 2 ? (ht->cap + 31) / 32 : ht->cap;
+   const uint64_t unit_bytes = ht->direct == 1 ? 4 : 8;
+   if (mode < 0 && (units * unit_bytes < (uint64_t) ldb_option("join_radix_min_table_bytes", 64ll << 20) || probe->n_rows < ldb_option("join_radix_min_rows", 16ll << 20))) return LDB_OK;
    LDB_TRY(ldb_rel_force(ctx, probe));
    LDB_TRY(ldb_make_dcol(probe, keys[0], &kc));
    const int64_t n = probe->n_rows;
@@ -389,6 +393,7 @@ static int32_t radix_prepare(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, co
    d.kmult32 = ht->kmult32;
    d.ksh = ht->ksh;
    d.slot32 = (uint32_t) ht->slot32;
+   d.direct = (uint32_t) ht->direct;
    if (mode < 0) { // already clustered on the key?  then the table is walked sequentially as it is
       unsigned int* dl = (unsigned int*) (ctx->d_scratch + 40);
       LDB_HIP(hipMemsetAsync(dl, 0, 8, ctx->stream));
@@ -402,9 +407,9 @@ static int32_t radix_prepare(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, co
    // partitions of ~1 MB of slots each
    uint32_t nparts = 16;
    const uint64_t part_bytes = (uint64_t) ldb_option("join_radix_part_bytes", 1 << 20);
-   while (nparts < RX_MAX_PARTS && (ht->cap * 8) / nparts > part_bytes) nparts <<= 1;
+   while (nparts < RX_MAX_PARTS && (units * unit_bytes) / nparts > part_bytes) nparts <<= 1;
    uint32_t lg = 0;
-   while ((1ull << lg) < ht->cap) lg++;
+   while ((1ull << lg) < units) lg++;
    uint32_t lp = 0;
    while ((1u << lp) < nparts) lp++;
    if (lg < lp) return LDB_OK;

@@ -1,16 +1,57 @@
-import os, sys, json
+"""g1 evidence: the radix-partitioned probe against the direct probe, UNCLUSTERED foreign keys (600 M random
+l_orderkey-like keys → 150 M orders at SF100), for both table layouts (ordered 8-byte slots; the rank table),
+over partition sizes from LDS-sized to L2/MALL-sized.  Prints one JSON document: per configuration the
+per-kernel milliseconds (k_radix_hist, k_radix_scatter, the probe kernel, helpers), their sum, the algorithmic
+bytes of each pass and the matches (must equal the direct probe's).
+usage: python tools/radix_sweep.py [SF=100]"""
+import json
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "lingo-db_amd"), ROOT]
-import lingodb_amd as ldb
-from lingodb_amd import api, capi
-n = int(float(sys.argv[1]) * 1_500_000)
-ctx = ldb.Context(0); ctx.prof_enable(True); L = capi.gpu_lib()
-od = ctx.tpch_generate(1, n, cols=[0]); pk = ctx.tpch_generate(8, n, cols=[0])
-ht = od.rel().join_build([(0, 0)], unique=True)
-L.ldb_gpu_set_option(b"join_radix", 1)
-for pb in [1 << 18, 1 << 20, 1 << 22, 1 << 24, 1 << 26, 1 << 28]:
-    L.ldb_gpu_set_option(b"join_radix_part_bytes", pb)
-    ht.probe_count(pk.rel(), [(0, 0)]); ctx.prof_reset()
-    for _ in range(3): m = ht.probe_count(pk.rel(), [(0, 0)])
+import lingodb_amd as ldb  # noqa: E402
+from lingodb_amd import capi  # noqa: E402
+
+sf = float(sys.argv[1]) if len(sys.argv) > 1 else 100.0
+n = int(sf * 1_500_000)
+ctx = ldb.Context(0)
+ctx.prof_enable(True)
+L = capi.gpu_lib()
+od = ctx.tpch_generate(1, n, cols=[0])
+pk = ctx.tpch_generate(8, n, cols=[0])  # lineitem-sized column of uniformly random order keys
+rows = pk.rows
+out = {"sf": sf, "probe_rows": rows, "build_rows": od.rows, "runs": []}
+
+
+def timed(reps=3):
+    ht.probe_count(pk.rel(), [(0, 0)])
+    ctx.prof_reset()
+    for _ in range(reps):
+        m = ht.probe_count(pk.rel(), [(0, 0)])
     pr = ctx.prof_all()
-    print(pb >> 10, "KB/part", {k: round(v[1] / 3, 3) for k, v in pr.items()}, "total", round(sum(v[1] for v in pr.values()) / 3, 3), m, flush=True)
+    ks = {k: round(v[1] / reps, 3) for k, v in pr.items()}
+    return ks, round(sum(ks.values()), 3), m
+
+
+for rank in (0, 1):
+    L.ldb_gpu_set_option(b"join_rank", rank)
+    L.ldb_gpu_set_option(b"join_direct", rank)
+    ht = od.rel().join_build([(0, 0)], unique=True)
+    tb = ht.table_bytes()
+    L.ldb_gpu_set_option(b"join_radix", 0)
+    ks, total, m0 = timed()
+    out["runs"].append({"table": "rank" if rank else "ordered", "table_bytes": tb, "radix": False, "kernels_ms": ks, "total_ms": total, "matches": m0,
+                        "bytes": {"probe": rows * 4 + tb}})
+    L.ldb_gpu_set_option(b"join_radix", 1)
+    for pb in (1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 24, 1 << 26):
+        if tb // pb > 4096 * 1:  # RX_MAX_PARTS partitions at most
+            continue
+        L.ldb_gpu_set_option(b"join_radix_part_bytes", pb)
+        ks, total, m = timed()
+        assert m == m0, (m, m0)
+        out["runs"].append({"table": "rank" if rank else "ordered", "table_bytes": tb, "radix": True, "part_bytes": pb, "kernels_ms": ks, "total_ms": total, "matches": m,
+                            "bytes": {"hist": rows * 4, "scatter": rows * 4 + rows * 8, "probe": rows * 4 + tb}})
+    L.ldb_gpu_set_option(b"join_radix", 0)
+    del ht
+print(json.dumps(out, indent=1))
