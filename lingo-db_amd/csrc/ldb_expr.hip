@@ -14,19 +14,8 @@
 #include "ldb_device.h"
 #include <memory>
 
-#define XSTACK 8
-struct DXInstr {
-   int32_t op;
-   int32_t arg;
-   DCol col;
-   uint64_t lo;
-   int64_t hi;
-};
-struct DXProg {
-   int32_t n;
-   int32_t out_width; // 1, 4, 8 or 16 bytes per output value
-   DXInstr ins[LDB_MAX_XPROG];
-};
+#include "ldb_expr_kernel.h"
+#include "ldb_jit.h"
 
 __global__ void k_pack_bytes_to_bits_x(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bitmap, uint64_t n) {
    const uint64_t nb = (n + 7) / 8;
@@ -38,104 +27,27 @@ __global__ void k_pack_bytes_to_bits_x(const uint8_t* __restrict__ bytes, uint8_
    }
 }
 
-__global__ void k_map_expr(const DXProg* __restrict__ prog, uint64_t n, void* __restrict__ out, uint8_t* __restrict__ valid_bytes) {
-   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-      i128 st[XSTACK];
-      bool nul[XSTACK];
-      int sp = 0;
-      const int np = prog->n;
-      for (int k = 0; k < np; k++) {
-         const DXInstr& x = prog->ins[k];
-         switch (x.op) {
-            case LDB_X_COL: {
-               const uint32_t row = d_phys_row(x.col, i);
-               nul[sp] = !d_valid(x.col, row);
-               st[sp] = nul[sp] ? (i128) 0 : d_load_i128(x.col, row);
-               sp++;
-               break;
-            }
-            case LDB_X_CONST:
-               st[sp] = (i128) (((u128) (uint64_t) x.hi << 64) | x.lo);
-               nul[sp] = false;
-               sp++;
-               break;
-            case LDB_X_ADD:
-            case LDB_X_SUB:
-            case LDB_X_MUL:
-            case LDB_X_SDIV: {
-               const i128 b = st[--sp], a = st[sp - 1];
-               const bool nb = nul[sp];
-               bool nn = nul[sp - 1] || nb;
-               i128 r = 0;
-               if (!nn) {
-                  if (x.op == LDB_X_ADD) r = (i128) ((u128) a + (u128) b);
-                  else if (x.op == LDB_X_SUB) r = (i128) ((u128) a - (u128) b);
-                  else if (x.op == LDB_X_MUL) r = (i128) ((u128) a * (u128) b);
-                  else if (b == 0) nn = true; // arith.divsi by zero is undefined in the reference: NULL here
-                  else r = d_sdiv128(a, b);
-               }
-               st[sp - 1] = r;
-               nul[sp - 1] = nn;
-               break;
-            }
-            case LDB_X_MUL_POW10: st[sp - 1] = (i128) ((u128) st[sp - 1] * (u128) d_pow10(x.arg)); break;
-            case LDB_X_SDIV_POW10: st[sp - 1] = d_sdiv128(st[sp - 1], d_pow10(x.arg)); break;
-            case LDB_X_NEG: st[sp - 1] = (i128) ((u128) 0 - (u128) st[sp - 1]); break;
-            case LDB_X_CMP: { // arg = ldb_filter_op comparison; NULL if an operand is NULL
-               const i128 b = st[--sp], a = st[sp - 1];
-               nul[sp - 1] = nul[sp - 1] || nul[sp];
-               st[sp - 1] = d_cmp_vals<i128>(x.arg, a, b) ? 1 : 0;
-               break;
-            }
-            case LDB_X_AND: { // three-valued: false wins over NULL
-               const i128 b = st[--sp], a = st[sp - 1];
-               const bool na = nul[sp - 1], nb = nul[sp];
-               const bool fa = !na && a == 0, fb = !nb && b == 0;
-               nul[sp - 1] = !(fa || fb) && (na || nb);
-               st[sp - 1] = (fa || fb || na || nb) ? 0 : 1;
-               break;
-            }
-            case LDB_X_OR: { // three-valued: true wins over NULL
-               const i128 b = st[--sp], a = st[sp - 1];
-               const bool na = nul[sp - 1], nb = nul[sp];
-               const bool ta = !na && a != 0, tb = !nb && b != 0;
-               nul[sp - 1] = !(ta || tb) && (na || nb);
-               st[sp - 1] = (ta || tb) ? 1 : 0;
-               break;
-            }
-            case LDB_X_NOT: st[sp - 1] = st[sp - 1] == 0 ? 1 : 0; break;
-            case LDB_X_SELECT: { // cond a b → cond (true and not NULL, db.derive_truth) ? a : b
-               const i128 b = st[--sp], a = st[--sp];
-               const bool nb = nul[sp + 1], na = nul[sp];
-               const bool c = !nul[sp - 1] && st[sp - 1] != 0;
-               st[sp - 1] = c ? a : b;
-               nul[sp - 1] = c ? na : nb;
-               break;
-            }
-            case LDB_X_ISNULL:
-               st[sp - 1] = nul[sp - 1] ? 1 : 0;
-               nul[sp - 1] = false;
-               break;
-            default: { // LDB_X_COALESCE: a b → a unless NULL
-               const i128 b = st[--sp];
-               const bool nb = nul[sp];
-               if (nul[sp - 1]) {
-                  st[sp - 1] = b;
-                  nul[sp - 1] = nb;
-               }
-               break;
-            }
-         }
-      }
-      const i128 v = nul[0] ? (i128) 0 : st[0];
-      switch (prog->out_width) {
-         case 1: ((uint8_t*) out)[i] = v != 0 ? 1 : 0; break;
-         case 4: ((int32_t*) out)[i] = (int32_t) v; break;
-         case 8: ((int64_t*) out)[i] = (int64_t) v; break;
-         default: ((i128*) out)[i] = v; break;
-      }
-      valid_bytes[i] = nul[0] ? 0 : 1;
-   }
+__global__ void k_map_expr(const DXProg* __restrict__ prog, uint64_t n, void* __restrict__ out, uint8_t* __restrict__ valid_bytes) { map_expr_body(*prog, prog, n, out, valid_bytes); }
+// run-time specialised variant (hiprtc): the program — opcodes, constants, column types — as compile-time constants, so the
+// interpreter loop unrolls into straight-line code and the value stack lives in registers
+static const char* XPR_SPEC_SRC =
+   "extern \"C\" __global__ void k_map_expr_spec(const DXProg* __restrict__ prog, uint64_t n, void* __restrict__ out, uint8_t* __restrict__ valid_bytes) {\n"
+   "   map_expr_body(LDB_META, prog, n, out, valid_bytes);\n"
+   "}\n";
+bool ldb_expr_jit_check(std::string* log) { // coalesce(count, 0) * 2 <= 10 over a nullable int64 column
+   auto m = std::make_unique<DXProg>();
+   memset(m.get(), 0, sizeof(DXProg));
+   const int32_t ops[] = {LDB_X_COL, LDB_X_CONST, LDB_X_COALESCE, LDB_X_CONST, LDB_X_MUL, LDB_X_CONST, LDB_X_CMP};
+   m->n = 7;
+   m->out_width = 1;
+   for (int k = 0; k < 7; k++) m->ins[k].op = ops[k];
+   m->ins[0].col.type = LDB_T_INT64;
+   m->ins[0].col.width = 8;
+   m->ins[0].col.validity = 1;
+   m->ins[3].lo = 2;
+   m->ins[5].lo = 10;
+   m->ins[6].arg = LDB_F_LTE;
+   return ldb_jit_compile_only("ldb_expr_kernel.h", "DXProg", XPR_SPEC_SRC, m.get(), sizeof(DXProg), log);
 }
 
 extern "C" int32_t ldb_gpu_map_expr(ldb_ctx* ctx, ldb_rel* in, const ldb_xinstr* prog, int32_t n_instr, ldb_coltype out_type, const char* name, ldb_table** out) {
@@ -209,8 +121,23 @@ extern "C" int32_t ldb_gpu_map_expr(ldb_ctx* ctx, ldb_rel* in, const ldb_xinstr*
       DXProg* d;
       LDB_TRY(ldb_dev_upload(ctx, hp.get(), sizeof(DXProg), (void**) &d));
       {
+         hipFunction_t spec = nullptr;
+         if (ldb_jit_wanted(n)) {
+            auto meta = std::make_unique<DXProg>();
+            memcpy(meta.get(), hp.get(), sizeof(DXProg));
+            for (int k = 0; k < LDB_MAX_XPROG; k++) ldb_jit_strip_col(meta->ins[k].col);
+            std::string why;
+            spec = ldb_jit_kernel(ctx->device, "ldb_expr_kernel.h", "DXProg", XPR_SPEC_SRC, "k_map_expr_spec", meta.get(), sizeof(DXProg), &why);
+         }
          LdbProf prof_(ctx, "k_map_expr");
-         hipLaunchKernelGGL(k_map_expr, dim3(grid), dim3(256), 0, ctx->stream, (const DXProg*) d, (uint64_t) n, res->cols[0].values, vb);
+         if (spec) {
+            uint64_t nn = (uint64_t) n;
+            void* ov = res->cols[0].values;
+            void* params[] = {(void*) &d, (void*) &nn, (void*) &ov, (void*) &vb};
+            LDB_HIP(hipModuleLaunchKernel(spec, (unsigned) grid, 1, 1, 256, 1, 1, 0, ctx->stream, params, nullptr));
+         } else {
+            hipLaunchKernelGGL(k_map_expr, dim3(grid), dim3(256), 0, ctx->stream, (const DXProg*) d, (uint64_t) n, res->cols[0].values, vb);
+         }
       }
       hipLaunchKernelGGL(k_pack_bytes_to_bits_x, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*) vb, bm, (uint64_t) n);
       ldb_dev_free(ctx, d);

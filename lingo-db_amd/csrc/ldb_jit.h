@@ -23,6 +23,7 @@ bool ldb_jit_compile_only(const char* header, const char* struct_name, const cha
 // per-operator compile checks with a representative descriptor (ldb_scan.hip, ldb_join.hip)
 bool ldb_scan_jit_check(std::string* log);
 bool ldb_join_jit_check(std::string* log);
+bool ldb_expr_jit_check(std::string* log);
 // addresses → presence flags (0/1); what remains of a column / predicate / key set is metadata
 void ldb_jit_strip_col(DCol& c);
 void ldb_jit_strip_pred(DPred& p);

@@ -320,6 +320,7 @@ extern "C" int32_t ldb_gpu_jit_compile_check(char* log, int32_t cap) {
    bool ok = compile(build_source("ldb_gb_kernel.h", "DGroupBy", GB_SPEC_SRC, (const unsigned char*) meta.get(), sizeof(DGroupBy)), &code, &err);
    if (ok) ok = ldb_scan_jit_check(&err);
    if (ok) ok = ldb_join_jit_check(&err);
+   if (ok) ok = ldb_expr_jit_check(&err);
    if (log && cap > 0) snprintf(log, (size_t) cap, "%s", err.c_str());
    if (ok) {
       if (const char* dump = getenv("LDB_JIT_DUMP")) { // code object for llvm-objdump inspection

@@ -55,11 +55,12 @@ struct ldb_hashtable {
 };
 
 // ---------------------------------------------------------------- ahead-of-time (generic) kernels
-__global__ void k_join_build(const DJoin* __restrict__ d) { join_build_body(*d, d); }
-__global__ void k_join_key_range(const DJoin* __restrict__ d, long long* __restrict__ out) { join_key_range_body(*d, d, out); }
-__global__ void k_join_key_bits(const DJoin* __restrict__ d) { join_key_bits_body(*d, d); }
-__global__ void k_join_rank_bits(const DJoin* __restrict__ d) { join_rank_bits_body(*d, d); }
-__global__ void k_join_rank_perm(const DJoin* __restrict__ d) { join_rank_perm_body(*d, d); }
+// generic kernels: one translation unit each (ldb_join_gk_*.hip)
+__global__ void k_join_build(const DJoin* __restrict__ d);
+__global__ void k_join_key_range(const DJoin* __restrict__ d, long long* __restrict__ out);
+__global__ void k_join_key_bits(const DJoin* __restrict__ d);
+__global__ void k_join_rank_bits(const DJoin* __restrict__ d);
+__global__ void k_join_rank_perm(const DJoin* __restrict__ d);
 // rank-bitmap build, pass 2: popcounts of the presence halves → (scan) → prefix halves
 __global__ void k_rank_pop(const uint64_t* __restrict__ tab, uint64_t n_words, uint32_t* __restrict__ pop) {
    for (uint64_t w = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; w < n_words; w += (uint64_t) gridDim.x * blockDim.x) pop[w] = (uint32_t) __popc((uint32_t) tab[w]);
@@ -79,12 +80,12 @@ __global__ void k_rank_coarse(const uint64_t* __restrict__ tab, uint64_t n_words
 __global__ void k_rank_prefix(uint64_t* __restrict__ tab, uint64_t n_words, const uint32_t* __restrict__ off) {
    for (uint64_t w = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; w < n_words; w += (uint64_t) gridDim.x * blockDim.x) tab[w] = (tab[w] & 0xFFFFFFFFull) | ((uint64_t) off[w] << 32);
 }
-__global__ void k_join_probe_pairs(const DJoin* __restrict__ d) { join_probe_pairs_body(*d, d); }
-__global__ void k_join_probe_pairs_count(const DJoin* __restrict__ d) { join_probe_pairs_count_body(*d, d); }
-__global__ void k_join_probe_count(const DJoin* __restrict__ d) { join_probe_count_body(*d, d); }
-__global__ void k_join_probe_exists(const DJoin* __restrict__ d) { join_probe_exists_body(*d, d); }
-__global__ void k_join_probe_unique(const DJoin* __restrict__ d) { join_probe_unique_body(*d, d); }
-__global__ void k_join_probe_markbuild(const DJoin* __restrict__ d) { join_probe_markbuild_body(*d, d); }
+__global__ void k_join_probe_pairs(const DJoin* __restrict__ d);
+__global__ void k_join_probe_pairs_count(const DJoin* __restrict__ d);
+__global__ void k_join_probe_count(const DJoin* __restrict__ d);
+__global__ void k_join_probe_exists(const DJoin* __restrict__ d);
+__global__ void k_join_probe_unique(const DJoin* __restrict__ d);
+__global__ void k_join_probe_markbuild(const DJoin* __restrict__ d);
 __global__ void k_join_flags_bitmap(const uint8_t* __restrict__ flags, uint64_t n, int anti, uint64_t* __restrict__ bitmap, unsigned long long* __restrict__ counter) {
    join_flags_bitmap_body(flags, n, anti, bitmap, counter);
 }

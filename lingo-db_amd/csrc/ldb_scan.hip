@@ -28,6 +28,15 @@ static const char* SCAN_SPEC_SRC =
    "   scan_bitmap_body(LDB_META, d, bitmap, counts, s_cnt);\n"
    "}\n"
    "extern \"C\" __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_count_spec(const DScan* __restrict__ d, unsigned long long* __restrict__ total) { scan_count_body(LDB_META, d, total); }\n";
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_bitmap_dnf(const DScanDnf* __restrict__ d, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ block_counts) {
+   __shared__ uint32_t s_cnt[SCAN_BLOCK / LDB_WAVE];
+   scan_bitmap_dnf_body(*d, d, bitmap, block_counts, s_cnt);
+}
+static const char* DNF_SPEC_SRC =
+   "extern \"C\" __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_bitmap_dnf_spec(const DScanDnf* __restrict__ d, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ counts) {\n"
+   "   __shared__ uint32_t s_cnt[SCAN_BLOCK / LDB_WAVE];\n"
+   "   scan_bitmap_dnf_body(LDB_META, d, bitmap, counts, s_cnt);\n"
+   "}\n";
 static void scan_meta(const DScan* h, DScan* m) {
    memcpy(m, h, sizeof(DScan));
    m->n_rows = 0;
@@ -60,7 +69,18 @@ bool ldb_scan_jit_check(std::string* log) {
       if (log) *log = "scan jit check: the LIKE pattern was not planned as two segments";
       return false;
    }
-   return ldb_jit_compile_only("ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, &m, sizeof(m), log);
+   if (!ldb_jit_compile_only("ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, &m, sizeof(m), log)) return false;
+   // a two-clause disjunction over the same conjuncts
+   auto dn = std::make_unique<DScanDnf>();
+   memset(dn.get(), 0, sizeof(DScanDnf));
+   dn->n_clauses = 2;
+   dn->preds[0] = m.preds[0];
+   dn->preds[1] = m.preds[1];
+   dn->preds[2] = m.preds[0];
+   dn->preds[2].op = LDB_F_LT;
+   dn->clause_end[0] = 2;
+   dn->clause_end[1] = 3;
+   return ldb_jit_compile_only("ldb_scan_kernel.h", "DScanDnf", DNF_SPEC_SRC, dn.get(), sizeof(DScanDnf), log);
 }
 
 // Expand the bitmap into ascending row ids.  Each wave walks its words; the lane whose bit is
@@ -211,45 +231,6 @@ static int32_t scan_run(ldb_ctx* ctx, ldb_rel* in, const DScan& h, uint32_t** se
 // db.and trees after the optimiser has pulled the common conjuncts out — and
 // evaluates it per tuple; here one pass evaluates clause after clause per row (a row that already
 // passed skips the remaining clauses) into the same ballot bitmap the conjunctive scan produces.
-#define DNF_MAX_CLAUSES 4
-#define DNF_MAX_PREDS 24
-struct DScanDnf {
-   uint64_t n_rows;
-   int32_t n_clauses;
-   int32_t clause_end[DNF_MAX_CLAUSES]; // preds [clause_end[c-1], clause_end[c]) form clause c
-   int32_t pad;
-   DPred preds[DNF_MAX_PREDS];
-};
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_bitmap_dnf(const DScanDnf* __restrict__ d, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ block_counts) {
-   __shared__ uint32_t s_cnt[SCAN_BLOCK / LDB_WAVE];
-   const uint64_t n = d->n_rows;
-   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-   const uint64_t word0 = (uint64_t) blockIdx.x * SCAN_WORDS_PER_BLOCK;
-   uint32_t cnt = 0;
-   for (uint32_t w = wave; w < SCAN_WORDS_PER_BLOCK; w += SCAN_BLOCK / LDB_WAVE) {
-      const uint64_t i = (word0 + w) * 64 + lane;
-      bool pass = false;
-      if (i < n) {
-         int p = 0;
-         for (int c = 0; c < d->n_clauses && !pass; c++) {
-            bool cp = true;
-            for (; p < d->clause_end[c]; p++)
-               if (cp) cp = d_eval_pred(PV(d->preds[p]), i);
-            pass = cp;
-         }
-      }
-      const uint64_t mask = __ballot(pass);
-      if (lane == 0 && (word0 + w) * 64 < n) bitmap[word0 + w] = mask;
-      cnt += (uint32_t) __popcll(mask);
-   }
-   if (lane == 0) s_cnt[wave] = cnt;
-   __syncthreads();
-   if (threadIdx.x == 0) {
-      uint32_t t = 0;
-      for (int k = 0; k < SCAN_BLOCK / LDB_WAVE; k++) t += s_cnt[k];
-      block_counts[blockIdx.x] = t;
-   }
-}
 extern "C" int32_t ldb_gpu_scan_filter_dnf(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_desc* preds, const int32_t* clause_sizes, int32_t n_clauses, ldb_rel** out) {
    if (!ctx || !in || !out || !preds || !clause_sizes) LDB_FAIL(LDB_ERR_INVALID, "scan_filter_dnf: NULL argument");
    if (n_clauses < 1 || n_clauses > DNF_MAX_CLAUSES) LDB_FAIL(LDB_ERR_UNSUPPORTED, "scan_filter_dnf: %d clauses (max %d)", n_clauses, DNF_MAX_CLAUSES);
@@ -260,6 +241,7 @@ extern "C" int32_t ldb_gpu_scan_filter_dnf(ldb_ctx* ctx, ldb_rel* in, const ldb_
    hp->n_clauses = n_clauses;
    int32_t total_preds = 0;
    for (int32_t c = 0; c < n_clauses; c++) {
+      if (clause_sizes[c] == 0) LDB_FAIL(LDB_ERR_INVALID, "scan_filter_dnf: clause %d is empty", c);
       if (clause_sizes[c] < 0 || total_preds + clause_sizes[c] > DNF_MAX_PREDS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "scan_filter_dnf: more than %d conjuncts in all", DNF_MAX_PREDS);
       for (int32_t p = 0; p < clause_sizes[c]; p++, total_preds++) LDB_TRY(ldb_make_dpred(in, &preds[total_preds], &hp->preds[total_preds]));
       hp->clause_end[c] = total_preds;
@@ -271,8 +253,22 @@ extern "C" int32_t ldb_gpu_scan_filter_dnf(ldb_ctx* ctx, ldb_rel* in, const ldb_
    const int32_t st = scan_run_with(
       ctx, in->n_rows,
       [&](uint64_t* bitmap, uint32_t* counts, unsigned n_blocks) -> int32_t {
+         hipFunction_t spec = nullptr;
+         if (ldb_jit_wanted(in->n_rows)) { // the clause structure and every conjunct's type / operator / constant as compile-time constants
+            auto meta = std::make_unique<DScanDnf>();
+            memcpy(meta.get(), hp.get(), sizeof(DScanDnf));
+            meta->n_rows = 0;
+            for (int p = 0; p < DNF_MAX_PREDS; p++) ldb_jit_strip_pred(meta->preds[p]);
+            std::string why;
+            spec = ldb_jit_kernel(ctx->device, "ldb_scan_kernel.h", "DScanDnf", DNF_SPEC_SRC, "k_scan_bitmap_dnf_spec", meta.get(), sizeof(DScanDnf), &why);
+         }
          LdbProf prof_(ctx, "k_scan_bitmap_dnf");
-         hipLaunchKernelGGL(k_scan_bitmap_dnf, dim3(n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, (const DScanDnf*) d, bitmap, counts);
+         if (spec) {
+            void* params[] = {(void*) &d, (void*) &bitmap, (void*) &counts};
+            LDB_HIP(hipModuleLaunchKernel(spec, n_blocks, 1, 1, SCAN_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
+         } else {
+            hipLaunchKernelGGL(k_scan_bitmap_dnf, dim3(n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, (const DScanDnf*) d, bitmap, counts);
+         }
          return LDB_OK;
       },
       &sel, &total);

@@ -90,3 +90,55 @@ __device__ __forceinline__ void scan_count_body(const DScan& m, const DScan* __r
    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(total, (unsigned long long) cnt);
 }
+
+// ---- disjunctive normal form: OR of up to DNF_MAX_CLAUSES conjunctions over one pass (ldb_gpu_scan_filter_dnf)
+#define DNF_MAX_CLAUSES 4
+#define DNF_MAX_PREDS 24
+struct DScanDnf {
+   uint64_t n_rows; // run-time
+   int32_t n_clauses;
+   int32_t clause_end[DNF_MAX_CLAUSES]; // preds [clause_end[c-1], clause_end[c]) form clause c
+   int32_t pad;
+   DPred preds[DNF_MAX_PREDS];
+};
+// one row: clause after clause, a conjunct is evaluated only while its clause can still pass and no earlier clause has.
+// Written as ONE loop over the conjuncts so that the specialised build unrolls it into straight-line code (p and the
+// clause index are compile-time constants there).
+__device__ __forceinline__ bool d_eval_dnf(const DScanDnf& m, const DScanDnf* __restrict__ d, uint64_t i) {
+   bool pass = false, cp = true;
+   int c = 0;
+   const int total = m.clause_end[m.n_clauses - 1];
+   LDB_UNROLL
+   for (int p = 0; p < DNF_MAX_PREDS; p++) {
+      if (p < total) {
+         if (!pass && cp) cp = d_eval_pred(PV(m.preds[p], d->preds[p]), i);
+         if (p + 1 == m.clause_end[c]) {
+            pass = pass || cp;
+            cp = true;
+            c++;
+         }
+      }
+   }
+   return pass;
+}
+__device__ __forceinline__ void scan_bitmap_dnf_body(const DScanDnf& m, const DScanDnf* __restrict__ d, uint64_t* __restrict__ bitmap, uint32_t* __restrict__ block_counts,
+                                                     uint32_t* s_cnt) {
+   const uint64_t n = d->n_rows;
+   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const uint64_t word0 = (uint64_t) blockIdx.x * SCAN_WORDS_PER_BLOCK;
+   uint32_t cnt = 0;
+   for (uint32_t w = wave; w < SCAN_WORDS_PER_BLOCK; w += SCAN_BLOCK / LDB_WAVE) {
+      const uint64_t i = (word0 + w) * 64 + lane;
+      const bool pass = i < n && d_eval_dnf(m, d, i);
+      const uint64_t mask = __ballot(pass);
+      if (lane == 0 && (word0 + w) * 64 < n) bitmap[word0 + w] = mask;
+      cnt += (uint32_t) __popcll(mask);
+   }
+   if (lane == 0) s_cnt[wave] = cnt;
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int k = 0; k < SCAN_BLOCK / LDB_WAVE; k++) t += s_cnt[k];
+      block_counts[blockIdx.x] = t;
+   }
+}

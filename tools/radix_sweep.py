@@ -38,7 +38,7 @@ for rank in (0, 1):
     L.ldb_gpu_set_option(b"join_rank", rank)
     L.ldb_gpu_set_option(b"join_direct", rank)
     ht = od.rel().join_build([(0, 0)], unique=True)
-    tb = ht.table_bytes()
+    tb = ht.table_bytes
     L.ldb_gpu_set_option(b"join_radix", 0)
     ks, total, m0 = timed()
     out["runs"].append({"table": "rank" if rank else "ordered", "table_bytes": tb, "radix": False, "kernels_ms": ks, "total_ms": total, "matches": m0,
