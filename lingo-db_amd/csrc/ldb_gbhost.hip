@@ -47,6 +47,49 @@ __global__ void k_gb_init(uint64_t* keys, uint64_t* acc, const DGroupBy* __restr
    }
 }
 
+// ---------------------------------------------------------------- partitioned counting (direct slots, COUNT(*) only)
+// Q13's shape: 148 M rows → a row count per customer, 10 M random keys.  The direct path pays one global atomic per
+// row into a 128 MB table (23 G atomics/s: 6.3 ms).  Here the rows' slots are first radix-partitioned by slot range —
+// a histogram pass and a scatter pass with workgroup-private LDS cursors, 4 bytes per row each way — and then every
+// partition (16 K consecutive slots) is counted by ONE workgroup in 64 KB of LDS and written to the table with plain,
+// coalesced stores: no global atomics, ~2.5 GB of sequential traffic instead of 148 M random read-modify-writes.
+// Semantics of the reference unchanged (PreAggregationHashtable.cpp:46-158 reduces thread-local fragments per
+// partition; this is the same idea with LDS as the fragment).
+#define GBP_BLOCK 256
+#define GBP_SHIFT 14
+#define GBP_MAX_PARTS 4096
+__global__ __launch_bounds__(GBP_BLOCK) void k_gbp_hist(const DGroupBy* __restrict__ d, uint32_t nparts, uint64_t rows_per_wg, uint32_t* __restrict__ hist) {
+   __shared__ uint32_t h[GBP_MAX_PARTS];
+   for (uint32_t p = threadIdx.x; p < nparts; p += GBP_BLOCK) h[p] = 0;
+   __syncthreads();
+   const uint64_t n = d->n_rows, b = blockIdx.x * rows_per_wg, e = b + rows_per_wg < n ? b + rows_per_wg : n;
+   for (uint64_t i = b + threadIdx.x; i < e; i += GBP_BLOCK) atomicAdd(&h[(uint32_t) (d_direct_slot(*d, d, i) >> GBP_SHIFT)], 1u);
+   __syncthreads();
+   for (uint32_t p = threadIdx.x; p < nparts; p += GBP_BLOCK) hist[(uint64_t) p * gridDim.x + blockIdx.x] = h[p];
+}
+__global__ __launch_bounds__(GBP_BLOCK) void k_gbp_scatter(const DGroupBy* __restrict__ d, uint32_t nparts, uint64_t rows_per_wg, const uint32_t* __restrict__ offs, uint32_t* __restrict__ slots_out) {
+   __shared__ uint32_t cur[GBP_MAX_PARTS];
+   for (uint32_t p = threadIdx.x; p < nparts; p += GBP_BLOCK) cur[p] = offs[(uint64_t) p * gridDim.x + blockIdx.x];
+   __syncthreads();
+   const uint64_t n = d->n_rows, b = blockIdx.x * rows_per_wg, e = b + rows_per_wg < n ? b + rows_per_wg : n;
+   for (uint64_t i = b + threadIdx.x; i < e; i += GBP_BLOCK) {
+      const uint32_t slot = (uint32_t) d_direct_slot(*d, d, i);
+      slots_out[atomicAdd(&cur[slot >> GBP_SHIFT], 1u)] = slot;
+   }
+}
+__global__ __launch_bounds__(GBP_BLOCK) void k_gbp_count(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ offs, uint32_t grid0, uint32_t nparts, uint64_t n_total,
+                                                         uint64_t* __restrict__ counters) {
+   __shared__ uint32_t c[1u << GBP_SHIFT];
+   const uint32_t p = blockIdx.x;
+   for (uint32_t j = threadIdx.x; j < (1u << GBP_SHIFT); j += GBP_BLOCK) c[j] = 0;
+   __syncthreads();
+   const uint64_t b = offs[(uint64_t) p * grid0], e = p + 1 < nparts ? (uint64_t) offs[(uint64_t) (p + 1) * grid0] : n_total;
+   for (uint64_t i = b + threadIdx.x; i < e; i += GBP_BLOCK) atomicAdd(&c[slots[i] & ((1u << GBP_SHIFT) - 1)], 1u);
+   __syncthreads();
+   uint64_t* out = counters + ((uint64_t) p << GBP_SHIFT);
+   for (uint32_t j = threadIdx.x; j < (1u << GBP_SHIFT); j += GBP_BLOCK) out[j] = c[j];
+}
+
 // compact occupied slots → dense outputs
 // occupied slots per 64-slot chunk (→ exclusive scan → output position of every group).  A cursor
 // atomic per wave instead is one contended address: ~10 ns each in the L2 — 84 ms for the 8.4 M
@@ -620,7 +663,36 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       LDB_HIP(hipMemsetAsync(d_ctl, 0, ctl_bytes, ctx->stream));
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
       hipLaunchKernelGGL(k_gb_init, dim3(ldb_grid_for(ctx, (int64_t) cap, 256, 8)), dim3(256), 0, ctx->stream, gk, ga, d);
-      if (in->n_rows) {
+      // COUNT(*) per key over direct slots, many rows into a table far beyond the L2: partition, then count in LDS
+      const bool partitioned = h->direct && h->n_words == 1 && h->n_accs == 1 && h->n_preds == 0 && h->n_cpreds == 0 && cap >= (1ull << 20) && (cap >> GBP_SHIFT) <= GBP_MAX_PARTS &&
+         in->n_rows >= ldb_option("gb_partition_min_rows", 8ll << 20) && (uint64_t) in->n_rows < (1ull << 32) && ldb_option("gb_partition", 1) != 0;
+      if (partitioned) {
+         const uint32_t nparts = (uint32_t) (cap >> GBP_SHIFT);
+         const uint32_t g0 = (uint32_t) std::max<int64_t>(1, std::min<int64_t>((int64_t) ctx->cus * 4, (in->n_rows + 4095) / 4096));
+         const uint64_t rows_per_wg = ((uint64_t) in->n_rows + g0 - 1) / g0;
+         uint32_t *hist, *offs, *slots;
+         const size_t hn = (size_t) nparts * g0;
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &hist, 4 * hn));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &offs, 4 * hn));
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &slots, 4 * (size_t) in->n_rows));
+         {
+            LdbProf prof_(ctx, "k_gbp_hist");
+            hipLaunchKernelGGL(k_gbp_hist, dim3(g0), dim3(GBP_BLOCK), 0, ctx->stream, (const DGroupBy*) d, nparts, rows_per_wg, hist);
+         }
+         LDB_TRY(ldb_exclusive_scan_u32(ctx, hist, offs, (int64_t) hn, nullptr));
+         {
+            LdbProf prof_(ctx, "k_gbp_scatter");
+            hipLaunchKernelGGL(k_gbp_scatter, dim3(g0), dim3(GBP_BLOCK), 0, ctx->stream, (const DGroupBy*) d, nparts, rows_per_wg, (const uint32_t*) offs, slots);
+         }
+         {
+            LdbProf prof_(ctx, "k_gbp_count");
+            hipLaunchKernelGGL(k_gbp_count, dim3(nparts), dim3(GBP_BLOCK), 0, ctx->stream, (const uint32_t*) slots, (const uint32_t*) offs, g0, nparts, (uint64_t) in->n_rows,
+                               ga + (uint64_t) h->direct_word * cap);
+         }
+         ldb_dev_free(ctx, hist);
+         ldb_dev_free(ctx, offs);
+         ldb_dev_free(ctx, slots);
+      } else if (in->n_rows) {
          int per_cu = lds_bytes > 40 * 1024 ? 2 : 4;
          int grid = ldb_grid_for(ctx, in->n_rows, GB_BLOCK, per_cu);
          hipFunction_t spec = nullptr;

@@ -652,3 +652,48 @@ def test_specialised_kernel_matches_generic(ctx, oracle, tpch):
 
     if os.environ.get("LDB_JIT_MIN_ROWS") == "0":
         assert n1.value + h1.value > n0.value + h0.value, "specialised kernel was not used"
+
+
+def test_groupby_partitioned_lds_count(ctx):
+    """COUNT(*) per key over direct slots, table far beyond the L2 (Q13's customers): the slots are radix-partitioned
+    (histogram + scatter with LDS cursors) and every 16 K-slot partition is counted by one workgroup in LDS and
+    stored without atomics.  Same rows as numpy and as the atomic direct path; dense and row-id (filtered) inputs,
+    int32 / int64 keys, a key range that does not fill the last partition."""
+    rng = np.random.default_rng(31)
+    lib = capi.gpu_lib()
+    n = 3_000_000
+    lib.ldb_gpu_set_option(b"gb_partition_min_rows", 0)
+    try:
+        for ktype, lo, span in ((pa.int32(), -5, 1_300_000), (pa.int64(), 7_000_000_000, 2_100_000)):
+            keys = lo + rng.integers(0, span, n)
+            keys[:5] = lo + span - 1  # the top of the range is hit
+            w = rng.integers(0, 100, n)
+            t = pa.table({"k": pa.array(keys, ktype), "w": pa.array(w, pa.int32())})
+            g = ctx.register("part_keys", t)
+            aggs = [api.agg(capi.AGG_COUNT_STAR)]
+            for pre in (False, True):
+                grel = g.rel()
+                sel = np.ones(n, bool)
+                if pre:
+                    grel = grel.scan_filter([api.pred((0, 1), capi.F_LT, 70)])
+                    grel.rows
+                    sel = w < 70
+                ctx.prof_reset()
+                ctx.prof_enable(True)
+                got = grel.groupby([(0, 0)], aggs, est_groups=span)
+                prof = ctx.prof_all()
+                assert prof.get("k_gbp_count", (0, 0.0))[0] >= 1 and "k_groupby_direct" not in prof, "the partitioned path did not run"
+                uk, uc = np.unique(keys[sel], return_counts=True)
+                rows = sorted(rows_of(got.to_arrow()))
+                assert rows == [(int(k), int(c)) for k, c in zip(uk, uc)]
+                lib.ldb_gpu_set_option(b"gb_partition", 0)
+                try:
+                    ctx.prof_reset()
+                    atomic = grel.groupby([(0, 0)], aggs, est_groups=span)
+                    assert ctx.prof_all().get("k_groupby_direct", (0, 0.0))[0] >= 1
+                finally:
+                    lib.ldb_gpu_set_option(b"gb_partition", 1)
+                assert sorted(rows_of(atomic.to_arrow())) == rows
+    finally:
+        lib.ldb_gpu_set_option(b"gb_partition_min_rows", 8 << 20)
+        ctx.prof_enable(False)
