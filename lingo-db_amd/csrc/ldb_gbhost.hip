@@ -56,23 +56,24 @@ __global__ void k_gb_init(uint64_t* keys, uint64_t* acc, const DGroupBy* __restr
 // Semantics of the reference unchanged (PreAggregationHashtable.cpp:46-158 reduces thread-local fragments per
 // partition; this is the same idea with LDS as the fragment).
 #define GBP_BLOCK 256
+#define GBP_SBLOCK 1024 // histogram / scatter: few, large workgroups → long per-(workgroup, partition) runs, full cache lines
 #define GBP_SHIFT 14
 #define GBP_MAX_PARTS 4096
-__global__ __launch_bounds__(GBP_BLOCK) void k_gbp_hist(const DGroupBy* __restrict__ d, uint32_t nparts, uint64_t rows_per_wg, uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(GBP_SBLOCK) void k_gbp_hist(const DGroupBy* __restrict__ d, uint32_t nparts, uint64_t rows_per_wg, uint32_t* __restrict__ hist) {
    __shared__ uint32_t h[GBP_MAX_PARTS];
-   for (uint32_t p = threadIdx.x; p < nparts; p += GBP_BLOCK) h[p] = 0;
+   for (uint32_t p = threadIdx.x; p < nparts; p += GBP_SBLOCK) h[p] = 0;
    __syncthreads();
    const uint64_t n = d->n_rows, b = blockIdx.x * rows_per_wg, e = b + rows_per_wg < n ? b + rows_per_wg : n;
-   for (uint64_t i = b + threadIdx.x; i < e; i += GBP_BLOCK) atomicAdd(&h[(uint32_t) (d_direct_slot(*d, d, i) >> GBP_SHIFT)], 1u);
+   for (uint64_t i = b + threadIdx.x; i < e; i += GBP_SBLOCK) atomicAdd(&h[(uint32_t) (d_direct_slot(*d, d, i) >> GBP_SHIFT)], 1u);
    __syncthreads();
-   for (uint32_t p = threadIdx.x; p < nparts; p += GBP_BLOCK) hist[(uint64_t) p * gridDim.x + blockIdx.x] = h[p];
+   for (uint32_t p = threadIdx.x; p < nparts; p += GBP_SBLOCK) hist[(uint64_t) p * gridDim.x + blockIdx.x] = h[p];
 }
-__global__ __launch_bounds__(GBP_BLOCK) void k_gbp_scatter(const DGroupBy* __restrict__ d, uint32_t nparts, uint64_t rows_per_wg, const uint32_t* __restrict__ offs, uint32_t* __restrict__ slots_out) {
+__global__ __launch_bounds__(GBP_SBLOCK) void k_gbp_scatter(const DGroupBy* __restrict__ d, uint32_t nparts, uint64_t rows_per_wg, const uint32_t* __restrict__ offs, uint32_t* __restrict__ slots_out) {
    __shared__ uint32_t cur[GBP_MAX_PARTS];
-   for (uint32_t p = threadIdx.x; p < nparts; p += GBP_BLOCK) cur[p] = offs[(uint64_t) p * gridDim.x + blockIdx.x];
+   for (uint32_t p = threadIdx.x; p < nparts; p += GBP_SBLOCK) cur[p] = offs[(uint64_t) p * gridDim.x + blockIdx.x];
    __syncthreads();
    const uint64_t n = d->n_rows, b = blockIdx.x * rows_per_wg, e = b + rows_per_wg < n ? b + rows_per_wg : n;
-   for (uint64_t i = b + threadIdx.x; i < e; i += GBP_BLOCK) {
+   for (uint64_t i = b + threadIdx.x; i < e; i += GBP_SBLOCK) {
       const uint32_t slot = (uint32_t) d_direct_slot(*d, d, i);
       slots_out[atomicAdd(&cur[slot >> GBP_SHIFT], 1u)] = slot;
    }
@@ -668,7 +669,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          in->n_rows >= ldb_option("gb_partition_min_rows", 8ll << 20) && (uint64_t) in->n_rows < (1ull << 32) && ldb_option("gb_partition", 1) != 0;
       if (partitioned) {
          const uint32_t nparts = (uint32_t) (cap >> GBP_SHIFT);
-         const uint32_t g0 = (uint32_t) std::max<int64_t>(1, std::min<int64_t>((int64_t) ctx->cus * 4, (in->n_rows + 4095) / 4096));
+         const uint32_t g0 = (uint32_t) std::max<int64_t>(1, std::min<int64_t>((int64_t) ctx->cus, (in->n_rows + 16383) / 16384));
          const uint64_t rows_per_wg = ((uint64_t) in->n_rows + g0 - 1) / g0;
          uint32_t *hist, *offs, *slots;
          const size_t hn = (size_t) nparts * g0;
@@ -677,12 +678,12 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &slots, 4 * (size_t) in->n_rows));
          {
             LdbProf prof_(ctx, "k_gbp_hist");
-            hipLaunchKernelGGL(k_gbp_hist, dim3(g0), dim3(GBP_BLOCK), 0, ctx->stream, (const DGroupBy*) d, nparts, rows_per_wg, hist);
+            hipLaunchKernelGGL(k_gbp_hist, dim3(g0), dim3(GBP_SBLOCK), 0, ctx->stream, (const DGroupBy*) d, nparts, rows_per_wg, hist);
          }
          LDB_TRY(ldb_exclusive_scan_u32(ctx, hist, offs, (int64_t) hn, nullptr));
          {
             LdbProf prof_(ctx, "k_gbp_scatter");
-            hipLaunchKernelGGL(k_gbp_scatter, dim3(g0), dim3(GBP_BLOCK), 0, ctx->stream, (const DGroupBy*) d, nparts, rows_per_wg, (const uint32_t*) offs, slots);
+            hipLaunchKernelGGL(k_gbp_scatter, dim3(g0), dim3(GBP_SBLOCK), 0, ctx->stream, (const DGroupBy*) d, nparts, rows_per_wg, (const uint32_t*) offs, slots);
          }
          {
             LdbProf prof_(ctx, "k_gbp_count");
