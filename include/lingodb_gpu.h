@@ -170,6 +170,15 @@ int64_t ldb_gpu_get_option(const char* name); /* -1 when never set and no defaul
 int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct ArrowSchema* schema,
                                struct ArrowArray** batches, int64_t n_batches, int32_t narrow_decimals,
                                ldb_table** out);
+/* Arrow IPC FILE → device table, inside the library (LingoDBTable::ensureLoaded, LingoDBTable.cpp:27-54: one
+ * `<table>.arrow` file per table, all record batches).  The file is memory-mapped and its footer / schema / record-batch
+ * flatbuffers are read without libarrow; every batch is registered from the mapping (ldb_gpu_table_register semantics,
+ * incl. narrow_decimals and dictionary encoding).  Flat int8…int64 / float / decimal128 / date32 / utf8 / large_utf8 /
+ * fixed_size_binary columns, uncompressed, little-endian, no dictionary batches; anything else → LDB_ERR_UNSUPPORTED naming
+ * the column; a truncated or inconsistent file → LDB_ERR_INVALID (every offset is bounds-checked).
+ * ldb_gpu_ipc_describe: the parse alone, no device needed — JSON {"columns":[{"name","format","nullable"}],"batches":[rows…],"rows"}. */
+int32_t ldb_gpu_table_load_ipc(ldb_ctx* ctx, const char* name, const char* path, int32_t narrow_decimals, ldb_table** out);
+int32_t ldb_gpu_ipc_describe(const char* path, char* out, int64_t cap);
 /* Allocate an uninitialised device table (generator / shuffle receive side).
  * utf8 columns: data_bytes[i] = byte capacity of column i (ignored for fixed width). */
 int32_t ldb_gpu_table_alloc(ldb_ctx* ctx, const char* name, int32_t n_cols, const ldb_coltype* types,

@@ -508,6 +508,15 @@ class Comm:
         return Table(self.ctx, t)
 
 
+def describe_ipc(path):
+    """schema and batch sizes of an Arrow IPC file as the library's own reader sees them (no device needed)"""
+    import json
+
+    buf = C.create_string_buffer(1 << 20)
+    check(capi.gpu_lib().ldb_gpu_ipc_describe(str(path).encode(), buf, len(buf)))
+    return json.loads(buf.value.decode(errors="replace"))
+
+
 def translate_subop_dump(dump, name="subop_dump"):
     """(plan text, per-step placement report) for a dump of the reference's `mlir-subop-to-json`; raises LdbError
     with the offending execution step when a step has no device pattern (needs no GPU)"""
@@ -703,7 +712,8 @@ class Context:
 
     def load_ipc(self, name, path, narrow_decimals=False):
         """registers one Arrow IPC file as a table — the reference keeps one `<table>.arrow` IPC
-        file per table and reads all its record batches (LingoDBTable.cpp:27-54, loadTable)"""
-        with pa.OSFile(path, "rb") as f:
-            table = pa.ipc.open_file(f).read_all()
-        return self.register(name, table, narrow_decimals)
+        file per table and reads all its record batches (LingoDBTable.cpp:27-54, loadTable).  The library maps
+        and parses the file itself (ldb_gpu_table_load_ipc, csrc/ldb_ipc.hip); pyarrow is not involved."""
+        t = C.c_void_p()
+        check(self.lib.ldb_gpu_table_load_ipc(self.h, name.encode(), str(path).encode(), 1 if narrow_decimals else 0, C.byref(t)))
+        return Table(self, t)
