@@ -179,6 +179,12 @@ int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct ArrowSchem
  * ldb_gpu_ipc_describe: the parse alone, no device needed — JSON {"columns":[{"name","format","nullable"}],"batches":[rows…],"rows"}. */
 int32_t ldb_gpu_table_load_ipc(ldb_ctx* ctx, const char* name, const char* path, int32_t narrow_decimals, ldb_table** out);
 int32_t ldb_gpu_ipc_describe(const char* path, char* out, int64_t cap);
+/* Zone map of a column: min / max per 16 384 physical rows of a NOT NULL integer-like column, built on the
+ * first column-vs-constant comparison over it (one pass, cached with the table) and KEPT only when the zones are selective
+ * (sorted / clustered data: together they cover less than half of zones × value range).  Scan, fused-filter and probe
+ * kernels then fail the rows of a zone that cannot satisfy the comparison without loading the column (options `zone_maps`,
+ * `zone_min_rows`).  Returns the number of zones in use, 0 = none (wrong type, NULLs, small table, unselective), -1 = error. */
+int64_t ldb_gpu_table_zones(ldb_ctx* ctx, const ldb_table* t, int32_t col);
 /* Allocate an uninitialised device table (generator / shuffle receive side).
  * utf8 columns: data_bytes[i] = byte capacity of column i (ignored for fixed width). */
 int32_t ldb_gpu_table_alloc(ldb_ctx* ctx, const char* name, int32_t n_cols, const ldb_coltype* types,

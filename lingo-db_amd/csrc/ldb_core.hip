@@ -38,7 +38,7 @@ int64_t ldb_option(const char* name, int64_t dflt) {
 }
 extern "C" int32_t ldb_gpu_set_option(const char* name, int64_t value) {
    if (!name) LDB_FAIL(LDB_ERR_INVALID, "set_option: NULL name");
-   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "gb_direct", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms"};
+   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms"};
    bool ok = false;
    for (const char* k : known) ok |= strcmp(k, name) == 0;
    if (!ok) LDB_FAIL(LDB_ERR_INVALID, "set_option: unknown option '%s'", name);
@@ -574,6 +574,8 @@ extern "C" int32_t ldb_gpu_table_release(ldb_ctx* ctx, ldb_table* t) {
       ldb_dev_free(ctx, c.values);
       ldb_dev_free(ctx, c.offsets);
       ldb_dev_free(ctx, c.validity);
+      ldb_dev_free(ctx, c.zone_min);
+      ldb_dev_free(ctx, c.zone_max);
       ldb_column_dict_release(ctx, c);
    }
    delete t;
@@ -972,6 +974,12 @@ int32_t ldb_make_dpred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out) {
       }
       return LDB_OK;
    }
+   // zone map: column-vs-constant comparison over a dense, NOT NULL integer-like column of a large base table
+   if (!is_str && p->rhs_kind == LDB_RHS_INT && p->op >= LDB_F_EQ && p->op <= LDB_F_GTE && !out->col.rowids && !out->col.validity && out->hi == ((int64_t) out->lo >> 63) && r->ctx &&
+       ldb_option("zone_maps", 1) != 0) {
+      const ldb_table* zt = r->sides[(size_t) p->col.side].table;
+      if (zt->n_rows >= ldb_option("zone_min_rows", 1 << 20)) LDB_TRY(ldb_column_zones(r->ctx, zt, p->col.col, &out->zmin, &out->zmax));
+   }
    if (is_str) {
       if (p->str_len < 0 || p->str_len > LDB_STR_INLINE) LDB_FAIL(LDB_ERR_UNSUPPORTED, "filter: string constant of %d bytes (max %d)", p->str_len, LDB_STR_INLINE);
       out->str_len = p->str_len;
@@ -1095,6 +1103,91 @@ int32_t ldb_column_range(ldb_ctx* ctx, const ldb_table* t, int32_t col, int64_t*
    return LDB_OK;
 }
 
+// one workgroup per zone of LDB_ZONE_ROWS rows
+__global__ __launch_bounds__(256) void k_column_zones(DCol col, uint64_t n, int64_t* __restrict__ zmin, int64_t* __restrict__ zmax) {
+   __shared__ int64_t s_lo[4], s_hi[4];
+   const uint64_t b = (uint64_t) blockIdx.x << LDB_ZONE_SHIFT, e = b + LDB_ZONE_ROWS < n ? b + LDB_ZONE_ROWS : n;
+   int64_t lo = INT64_MAX, hi = INT64_MIN;
+   for (uint64_t i = b + threadIdx.x; i < e; i += 256) {
+      const int64_t v = d_load_i64(col, (uint32_t) i);
+      lo = v < lo ? v : lo;
+      hi = v > hi ? v : hi;
+   }
+   for (int o = 32; o > 0; o >>= 1) {
+      const int64_t l2 = __shfl_xor((long long) lo, o), h2 = __shfl_xor((long long) hi, o);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+   }
+   if ((threadIdx.x & 63) == 0) {
+      s_lo[threadIdx.x >> 6] = lo;
+      s_hi[threadIdx.x >> 6] = hi;
+   }
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      for (int k = 1; k < 4; k++) {
+         lo = s_lo[k] < lo ? s_lo[k] : lo;
+         hi = s_hi[k] > hi ? s_hi[k] : hi;
+      }
+      zmin[blockIdx.x] = lo;
+      zmax[blockIdx.x] = hi;
+   }
+}
+int32_t ldb_column_zones(ldb_ctx* ctx, const ldb_table* t, int32_t col, uint64_t* zmin, uint64_t* zmax) {
+   *zmin = *zmax = 0;
+   if (!t || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "column_zones: bad column %d", col);
+   const ldb_column& c = t->cols[(size_t) col];
+   const int ty = c.type.type;
+   const bool ok = ty == LDB_T_INT8 || ty == LDB_T_INT16 || ty == LDB_T_INT32 || ty == LDB_T_INT64 || ty == LDB_T_DATE32 || (ty == LDB_T_DECIMAL128 && c.type.precision < 19 && c.width == 8);
+   if (!ok || !c.owned || c.validity || t->n_rows < 2 * (int64_t) LDB_ZONE_ROWS) return LDB_OK; // (views share their owner's values: no statistics of their own)
+   if (c.zone_state < 0) {
+      const int64_t nz = (t->n_rows + LDB_ZONE_ROWS - 1) >> LDB_ZONE_SHIFT;
+      int64_t *zl, *zh;
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &zl, 8 * (size_t) nz));
+      LDB_TRY(ldb_dev_alloc(ctx, (void**) &zh, 8 * (size_t) nz));
+      DCol dc;
+      memset(&dc, 0, sizeof(dc));
+      dc.values = (uint64_t) c.values;
+      dc.type = ty;
+      dc.width = c.width;
+      dc.precision = c.type.precision;
+      dc.scale = c.type.scale;
+      hipLaunchKernelGGL(k_column_zones, dim3((unsigned) nz), dim3(256), 0, ctx->stream, dc, (uint64_t) t->n_rows, zl, zh);
+      std::vector<int64_t> hl((size_t) nz), hh((size_t) nz);
+      LDB_HIP(hipMemcpyAsync(hl.data(), zl, 8 * (size_t) nz, hipMemcpyDeviceToHost, ctx->stream));
+      LDB_HIP(hipMemcpyAsync(hh.data(), zh, 8 * (size_t) nz, hipMemcpyDeviceToHost, ctx->stream));
+      LDB_HIP(hipStreamSynchronize(ctx->stream));
+      // selective? the zones together must cover well under the whole value range (sorted / clustered columns do; a
+      // uniformly scattered column has every zone span the full range and a zone test could never exclude anything)
+      int64_t gl = INT64_MAX, gh = INT64_MIN;
+      long double span = 0;
+      for (int64_t z = 0; z < nz; z++) {
+         gl = std::min(gl, hl[(size_t) z]);
+         gh = std::max(gh, hh[(size_t) z]);
+         span += (long double) hh[(size_t) z] - (long double) hl[(size_t) z];
+      }
+      const long double full = ((long double) gh - (long double) gl) * (long double) nz;
+      const bool useful = full > 0 && span < 0.5L * full;
+      if (useful) {
+         c.zone_min = zl;
+         c.zone_max = zh;
+      } else {
+         ldb_dev_free(ctx, zl);
+         ldb_dev_free(ctx, zh);
+      }
+      c.zone_state = useful ? 1 : 0;
+   }
+   if (c.zone_state == 1) {
+      *zmin = (uint64_t) c.zone_min;
+      *zmax = (uint64_t) c.zone_max;
+   }
+   return LDB_OK;
+}
+
+extern "C" int64_t ldb_gpu_table_zones(ldb_ctx* ctx, const ldb_table* t, int32_t col) {
+   uint64_t a = 0, b = 0;
+   if (!ctx || ldb_column_zones(ctx, t, col, &a, &b) != LDB_OK) return -1;
+   return a ? (t->n_rows + LDB_ZONE_ROWS - 1) >> LDB_ZONE_SHIFT : 0;
+}
 __global__ void k_column_sorted(DCol col, uint64_t n, unsigned int* __restrict__ unsorted) {
    bool bad = false;
    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x + 1; i < n; i += (uint64_t) gridDim.x * blockDim.x)

@@ -339,6 +339,18 @@ __device__ __forceinline__ bool d_cmp_vals(int op, T a, T b) {
    }
 }
 
+// can ANY value in [zlo, zhi] satisfy `value op c`?  (zone maps: per-chunk min / max, the reference's counterpart is the
+// per-chunk statistics a scan uses to skip chunks)
+__device__ __forceinline__ bool d_zone_may_pass(int op, int64_t zlo, int64_t zhi, int64_t c) {
+   switch (op) {
+      case LDB_F_EQ: return zlo <= c && c <= zhi;
+      case LDB_F_NEQ: return !(zlo == c && zhi == c);
+      case LDB_F_LT: return zlo < c;
+      case LDB_F_LTE: return zlo <= c;
+      case LDB_F_GT: return zhi > c;
+      default: return zhi >= c; // LDB_F_GTE
+   }
+}
 // One conjunct on logical row i.  Semantics: Filter impls of reference
 // src/runtime/storage/Restrictions.cpp:67-321 (native-type compare, decimals as __int128,
 // strings as string_view, IN = membership); NULL operands fail.  All branches on p.m.* are
@@ -397,6 +409,10 @@ __device__ __forceinline__ bool d_eval_pred(PV p, uint64_t i) {
    }
    // narrow integer path: the constant is a 128-bit value; a column value (fits i64) compares
    // against it exactly after placing the constant relative to the i64 range
+   if (p.m.zmin) { // zone map (only ever attached to dense columns: row == i)
+      const uint64_t z = i >> LDB_ZONE_SHIFT;
+      if (!d_zone_may_pass(p.m.op, gptr<int64_t>(p.p.zmin)[z], gptr<int64_t>(p.p.zmax)[z], (int64_t) p.m.lo)) return false;
+   }
    int64_t a = d_load_i64(col, row);
    if (p.m.op == 100) { // LDB_F_CODESET: dictionary code of a utf8 column against the set of codes the string predicate accepts
       const uint32_t c = (uint32_t) a;
@@ -559,6 +575,16 @@ __device__ __forceinline__ void d_eval_conj_batch(const DPred* mp, const DPred* 
       const PV pv(mp[p], dp[p]);
       if (d_pred_is_simple(mp[p])) {
          const bool reuse = p > 0 && mp[p].same_col && d_pred_is_simple(mp[p - 1]);
+         if (mp[p].zmin) { // zone map attached (dense column, constant fits int64): rows of excluded zones fail before the load
+            const int64_t* zlo = gptr<int64_t>(dp[p].zmin);
+            const int64_t* zhi = gptr<int64_t>(dp[p].zmax);
+#pragma unroll
+            for (int u = 0; u < U; u++)
+               if (pass[u]) {
+                  const uint64_t z = rows[u] >> LDB_ZONE_SHIFT;
+                  pass[u] = d_zone_may_pass(mp[p].op, zlo[z], zhi[z], (int64_t) mp[p].lo);
+               }
+         }
          if (!reuse) {
             const CV col = pv.col();
             if (!col.m.rowids && !col.m.validity) {

@@ -54,7 +54,13 @@ struct DPred {
    int32_t in_off[LDB_MAX_IN + 1];
    int32_t same_col; // lhs column identical to the previous conjunct's (host: ldb_mark_same_col)
    char in_blob[LDB_MAX_IN * 16];
+   // zone map of the column (ldb_column_zones): int64 min / max per LDB_ZONE_ROWS physical rows, or 0.  Attached only to
+   // column-vs-constant comparisons over a dense column whose zones are selective (clustered / sorted data): a row whose
+   // zone cannot satisfy the comparison fails without its value being loaded.
+   uint64_t zmin, zmax;
 };
+#define LDB_ZONE_SHIFT 14
+#define LDB_ZONE_ROWS (1u << LDB_ZONE_SHIFT)
 
 #define LDB_MAX_KEYS 8
 struct DKeys {

@@ -62,7 +62,15 @@ struct ldb_column {
    mutable int64_t vmin = 0, vmax = -1;
    mutable bool skewed = false; // ordered hash-table slots over this column gave long probe runs once: do not try again
    mutable int8_t sorted_state = -1; // -1 unknown, 0 no, 1 values are non-decreasing and there are no NULLs (ldb_column_sorted)
+   // zone map: min / max per LDB_ZONE_ROWS physical rows (device, owned with the column), built on the first range
+   // predicate over the column; zone_state 0 = the zones span most of the value range (unclustered data): not used
+   mutable int64_t* zone_min = nullptr;
+   mutable int64_t* zone_max = nullptr;
+   mutable int8_t zone_state = -1; // -1 unknown, 0 useless, 1 useful
 };
+// zone map of an integer-like NOT NULL column: device addresses of the per-zone minima / maxima, or 0 / 0 when the type
+// does not qualify or the zones are not selective.  Built once per column (one pass over it), cached.
+int32_t ldb_column_zones(ldb_ctx* ctx, const struct ldb_table* t, int32_t col, uint64_t* zmin, uint64_t* zmax);
 // [min, max] over all physical rows of an integer-like column (NULL slots included: a superset is
 // fine for its users); cached in the column.  LDB_ERR_UNSUPPORTED for other types.
 int32_t ldb_column_range(ldb_ctx* ctx, const struct ldb_table* t, int32_t col, int64_t* lo, int64_t* hi);

@@ -49,6 +49,8 @@ void ldb_jit_strip_col(DCol& c) {
 void ldb_jit_strip_pred(DPred& p) {
    ldb_jit_strip_col(p.col);
    ldb_jit_strip_col(p.rhs);
+   p.zmin = p.zmin ? 1 : 0;
+   p.zmax = p.zmax ? 1 : 0;
 }
 void ldb_jit_strip_keys(DKeys& k) {
    for (int j = 0; j < LDB_MAX_KEYS; j++) ldb_jit_strip_col(k.cols[j]);

@@ -174,6 +174,7 @@ GPU_API = {
     "ldb_gpu_get_option": (i64, [C.c_char_p]),
     "ldb_gpu_table_register": (i32, [P, C.c_char_p, C.POINTER(ArrowSchema), C.POINTER(C.POINTER(ArrowArray)), i64, i32, PP]),
     "ldb_gpu_table_load_ipc": (i32, [P, C.c_char_p, C.c_char_p, i32, PP]),
+    "ldb_gpu_table_zones": (i64, [P, P, i32]),
     "ldb_gpu_ipc_describe": (i32, [C.c_char_p, C.c_char_p, i64]),
     "ldb_gpu_table_alloc": (i32, [P, C.c_char_p, i32, C.POINTER(ColType), C.POINTER(C.c_char_p), i64, C.POINTER(i64), i32, PP]),
     "ldb_gpu_table_release": (i32, [P, P]),
