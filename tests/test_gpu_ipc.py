@@ -39,7 +39,8 @@ def test_loaded_table_runs_a_plan_like_a_registered_one(ctx, tmp_path):
     plan = json.dumps({"name": "p", "inputs": ["t"], "steps": [
         {"op": "groupby", "in": "t", "keys": ["tiny"], "aggs": [{"fn": "sum", "expr": "price", "as": "s"}, {"fn": "count_star", "as": "n"}],
          "preds": [{"col": "day", "op": "GTE", "value": "1994-01-01"}], "out": "g"},
-        {"op": "sort", "in": "g", "by": ["tiny"], "out": "result"}], "result": "result"})
+        {"op": "sort", "in": "g", "by": ["tiny"], "out": "s"},
+        {"op": "materialize", "in": "s", "cols": ["tiny", "s", "n"], "out": "result"}], "result": "result"})
     a = ctx.run_plan(plan, {"t": ctx.load_ipc("t", tmp_path / "t.arrow")}).to_arrow().to_pylist()
     b = ctx.run_plan(plan, {"t": ctx.register("t", t)}).to_arrow().to_pylist()
     assert a == b and len(a) == 100
