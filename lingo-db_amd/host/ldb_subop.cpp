@@ -46,7 +46,7 @@ struct Unsupported : std::runtime_error {
 struct Expr;
 using ExprP = std::shared_ptr<Expr>;
 struct Expr {
-   enum Kind { COL, CONST_INT, CONST_STR, CONST_BOOL, MEMBER, REF, HASH, UNKNOWN, OP } kind = UNKNOWN;
+   enum Kind { COL, CONST_INT, CONST_STR, CONST_BOOL, MEMBER, REF, HASH, MARKER, FLAG, UNKNOWN, OP } kind = UNKNOWN; // MARKER: "a partner exists" of a probe row; FLAG: of a build row
    std::string name; // COL: column name in the plan language; MEMBER: member; OP: add sub mul div cast cmp and or not isnull select between in
    std::string cmp; // OP cmp: EQ NEQ LT LTE GT GTE
    int64_t i = 0;
@@ -118,6 +118,11 @@ struct Stream {
    std::map<std::string, ExprP> cols; // column displayName ("lineitem::l_quantity") → what it is
    std::vector<std::set<std::string>> unique; // column sets known to identify a row
    std::string probeHiv, aggState; // the hash-indexed view being probed / the state being reduced into
+   // the equalities of the hash join being matched are known, the join kind is not yet: inner unless the marker idiom of a
+   // semi / anti join follows (RelAlgToSubOp.cpp:1296-1375)
+   bool pending = false;
+   std::vector<std::string> probeKeys, buildKeys;
+   std::string flagState; // scan of a build buffer whose flag member a semi / anti join with reversed sides has set
 };
 struct AggSpec {
    std::string member, fn;
@@ -133,7 +138,7 @@ struct OutStep {
    std::vector<OutAgg> aggs; // groupby
 };
 struct State {
-   enum Kind { UNKNOWN, TABLE, AGG, BUFFER, HIV, SORTED, HEAP, RESULT } kind = UNKNOWN;
+   enum Kind { UNKNOWN, TABLE, AGG, BUFFER, HIV, SORTED, HEAP, RESULT, MARKER } kind = UNKNOWN;
    std::string table; // TABLE
    std::map<std::string, std::string> memberToIdent;
    std::vector<std::string> filters, pkey;
@@ -149,6 +154,11 @@ struct State {
    std::vector<std::pair<std::string, bool>> sortBy; // member, descending
    int64_t maxRows = -1;
    bool emitted = false; // SORTED / HEAP: the sort / topk step exists and in.rel names its output
+   // BUFFER that is the build side of a semi / anti join with reversed sides: the flag member, the probing stream (kept
+   // for the anti form, which is emitted when the flag filter says all_false) and the build rows with a partner
+   std::string flagMember, semiRel, antiRel;
+   std::shared_ptr<Stream> flagProbe;
+   std::shared_ptr<State> flagHiv;
 };
 using StateP = std::shared_ptr<State>;
 
@@ -429,7 +439,8 @@ struct Translator {
       return p + "}";
    }
 
-   void joinOnEqualities(Stream& s, const ExprP& pred) {
+   // the `=` conjuncts that follow the gather name the keys of the hash join
+   void resolveJoinKeys(Stream& s, const ExprP& pred) {
       StateP hiv = states.at(s.probeHiv);
       std::vector<ExprP> conj;
       std::function<void(const ExprP&)> split = [&](const ExprP& e) {
@@ -439,25 +450,30 @@ struct Translator {
             conj.push_back(e);
       };
       split(pred);
-      std::vector<std::string> probeKeys, buildKeys;
       Stream& b = hiv->source->in;
       for (auto& e : conj) {
          if (!(e->kind == Expr::OP && e->name == "cmp" && e->cmp == "EQ")) throw Unsupported("hash join with a residual (non-equality) predicate");
          ExprP l = stripCast(e->args[0]), r = stripCast(e->args[1]);
          if (l->build && !r->build) std::swap(l, r);
          if (l->build || !r->build) throw Unsupported("join equality does not compare a probe column with a gathered build column");
-         buildKeys.push_back(ensureCol(b, r, "build_key"));
-         probeKeys.push_back(ensureCol(s, l, "probe_key"));
+         s.buildKeys.push_back(ensureCol(b, r, "build_key"));
+         s.probeKeys.push_back(ensureCol(s, l, "probe_key"));
       }
-      auto list = [](const std::vector<std::string>& v) {
-         std::string o = "[";
-         for (size_t k = 0; k < v.size(); k++) o += (k ? ", " : "") + quote(v[k]);
-         return o + "]";
-      };
+      s.pending = true;
+   }
+   static std::string nameList(const std::vector<std::string>& v) {
+      std::string o = "[";
+      for (size_t k = 0; k < v.size(); k++) o += (k ? ", " : "") + quote(v[k]);
+      return o + "]";
+   }
+   // join_build (once per view) + join_probe of the pending join with the given kind; returns the output relation
+   std::string emitJoin(Stream& s, const std::string& kind) {
+      StateP hiv = states.at(s.probeHiv);
+      Stream& b = hiv->source->in;
       if (hiv->ht.empty()) {
          flush(b);
          bool uniq = false;
-         const std::set<std::string> ks(buildKeys.begin(), buildKeys.end());
+         const std::set<std::string> ks(s.buildKeys.begin(), s.buildKeys.end());
          for (auto& u : b.unique) {
             bool sub = !u.empty();
             for (auto& c : u) sub = sub && ks.count(c);
@@ -466,22 +482,31 @@ struct Translator {
          OutStep jb;
          jb.op = "join_build";
          jb.out = fresh("h");
-         jb.fields = {{"in", quote(b.rel)}, {"keys", list(buildKeys)}, {"unique", uniq ? "true" : "false"}};
+         jb.fields = {{"in", quote(b.rel)}, {"keys", nameList(s.buildKeys)}, {"unique", uniq ? "true" : "false"}};
          steps.push_back(jb);
          hiv->ht = jb.out;
-         hiv->htKeys = buildKeys;
+         hiv->htKeys = s.buildKeys;
          hiv->htUnique = uniq;
-      } else if (hiv->htKeys != buildKeys) {
+      } else if (hiv->htKeys != s.buildKeys) {
          throw Unsupported("one hash-indexed view probed on two different key lists");
       }
       flush(s);
       OutStep jp;
       jp.op = "join_probe";
       jp.out = fresh("j");
-      jp.fields = {{"ht", quote(hiv->ht)}, {"in", quote(s.rel)}, {"keys", list(probeKeys)}, {"kind", "\"inner\""}};
+      jp.fields = {{"ht", quote(hiv->ht)}, {"in", quote(s.rel)}, {"keys", nameList(s.probeKeys)}, {"kind", quote(kind)}};
       steps.push_back(jp);
-      s.rel = jp.out;
+      return jp.out;
+   }
+   // the pending join turns out to be an ordinary (inner) one: some other sub-operator consumes the matched pairs
+   void settle(Stream& s) {
+      if (!s.pending) return;
+      StateP hiv = states.at(s.probeHiv);
+      s.rel = emitJoin(s, "inner");
+      s.pending = false;
       s.probeHiv.clear();
+      s.probeKeys.clear();
+      s.buildKeys.clear();
       if (!hiv->htUnique) s.unique.clear(); // probe rows may repeat
       for (auto& kv : s.cols)
          if (kv.second->build) {
@@ -489,6 +514,27 @@ struct Translator {
             c->build = false;
             kv.second = c;
          }
+   }
+   // semi / anti join keeping the PROBE rows: the build columns are gone afterwards
+   void finishProbeSide(Stream& s, bool anti) {
+      s.rel = emitJoin(s, anti ? "anti" : "semi");
+      s.pending = false;
+      s.probeHiv.clear();
+      s.probeKeys.clear();
+      s.buildKeys.clear();
+      for (auto it = s.cols.begin(); it != s.cols.end();)
+         it = it->second->build || it->second->kind == Expr::MARKER ? s.cols.erase(it) : std::next(it);
+   }
+
+   std::string idOf(const StateP& st, StepCtx& c) {
+      for (auto& kv : states)
+         if (kv.second == st) return kv.first;
+      for (auto& kv : c.local)
+         if (kv.second == st) {
+            states[kv.first] = st;
+            return kv.first;
+         }
+      throw Unsupported("state without an identity");
    }
 
    void handle(const J& op, StepCtx& c) {
@@ -590,6 +636,9 @@ struct Translator {
                if (it == st->aggOut.end()) throw Unsupported("scan of member '" + m.s("member") + "' the aggregation does not produce");
                s.cols[m.at("column").s("displayName")] = mk(Expr::COL, it->second);
             }
+         } else if (st->kind == State::MARKER) { // the per-row marker of anyTuple: the pending join continues on the probe stream
+            s = st->in;
+            for (auto& m : mapping.arr) s.cols[m.at("column").s("displayName")] = mk(Expr::MARKER);
          } else if (st->kind == State::BUFFER || st->kind == State::SORTED || st->kind == State::HEAP || st->kind == State::RESULT) {
             if (st->kind == State::HEAP && !st->emitted) { // the heap keeps the best maxRows rows: a top-k over what was materialised
                flush(st->in);
@@ -616,6 +665,10 @@ struct Translator {
                auto it = st->members.find(m.s("member"));
                if (it == st->members.end()) throw Unsupported("scan of member '" + m.s("member") + "' that was never materialised");
                s.cols[m.at("column").s("displayName")] = it->second;
+               if (!st->flagMember.empty() && m.s("member") == st->flagMember) { // the flag a reversed semi / anti join has set
+                  s.cols[m.at("column").s("displayName")] = mk(Expr::FLAG);
+                  s.flagState = idOf(st, c);
+               }
             }
          } else {
             throw Unsupported("scan of a state nothing was written to");
@@ -679,6 +732,11 @@ struct Translator {
       }
       if (kind == "map") {
          Stream s = input(op, c);
+         if (s.pending) { // `map … = true` is the first sub-operator of the marker idioms; anything else consumes the pairs
+            bool marker = true;
+            for (auto& cm : op.at("computed").arr) marker = marker && convert(cm.at("expression"), s)->kind == Expr::CONST_BOOL;
+            if (!marker) settle(s);
+         }
          for (auto& cm : op.at("computed").arr) {
             const std::string& name = cm.at("computed").s("displayName");
             ExprP e = convert(cm.at("expression"), s);
@@ -710,15 +768,42 @@ struct Translator {
       }
       if (kind == "filter") {
          Stream s = input(op, c);
-         if (op.sOr("semantic", "all_true") != "all_true") throw Unsupported("filter with all_false semantic");
+         if (op.sOr("semantic", "all_true") != "all_true") { // none of the columns true: only the anti forms of the marker idioms
+            for (auto& col : op.at("columns").arr) {
+               auto it = s.cols.find(col.s("displayName"));
+               if (it == s.cols.end()) throw Unsupported("filter on an undefined column");
+               const Expr::Kind k = stripCast(it->second)->kind;
+               if (k == Expr::MARKER && s.pending) finishProbeSide(s, true);
+               else if (k == Expr::FLAG) {
+                  StateP buf = states.at(s.flagState);
+                  if (buf->antiRel.empty()) buf->antiRel = emitJoin(*buf->flagProbe, "anti_build");
+                  s.rel = buf->antiRel;
+                  s.flagState.clear();
+               } else throw Unsupported("filter with all_false semantic on a computed predicate");
+            }
+            c.streams[ref] = s;
+            return;
+         }
          for (auto& col : op.at("columns").arr) {
             auto it = s.cols.find(col.s("displayName"));
             if (it == s.cols.end()) throw Unsupported("filter on an undefined column");
             const ExprP e = it->second;
-            if (!s.probeHiv.empty()) {
-               joinOnEqualities(s, e);
+            if (stripCast(e)->kind == Expr::MARKER) { // anyTuple's marker: the probe row has (all_true) / lacks (all_false) a partner
+               if (!s.pending) throw Unsupported("marker filter without a pending hash join");
+               finishProbeSide(s, false);
                continue;
             }
+            if (stripCast(e)->kind == Expr::FLAG) { // flag member of a build buffer: build rows with a partner
+               StateP buf = states.at(s.flagState);
+               s.rel = buf->semiRel;
+               s.flagState.clear();
+               continue;
+            }
+            if (!s.probeHiv.empty() && !s.pending) {
+               resolveJoinKeys(s, e);
+               continue;
+            }
+            settle(s);
             const ExprP p = stripCast(e);
             if (p->kind == Expr::OP && p->name == "cmp") {
                ExprP l = stripCast(p->args[0]), r = stripCast(p->args[1]);
@@ -758,6 +843,7 @@ struct Translator {
          if (id.empty())
             for (auto& kv : states)
                if (kv.second == st) id = kv.first;
+         if (!(stateType == "SimpleState" && kind == "lookup")) settle(s);
          if (stateType == "HashIndexedView" && kind == "lookup") {
             if (st->kind != State::HIV) throw Unsupported("lookup into a hash-indexed view that was not created from a buffer");
             if (!s.probeHiv.empty()) throw Unsupported("nested hash-indexed-view lookups");
@@ -776,6 +862,7 @@ struct Translator {
       }
       if (kind == "reduce") {
          Stream s = input(op, c);
+         settle(s);
          if (s.aggState.empty()) throw Unsupported("reduce without a preceding lookup into an aggregation state");
          StateP st = states.at(s.aggState);
          if (st->kind != State::UNKNOWN) throw Unsupported("two pipelines reduce into one state");
@@ -815,6 +902,7 @@ struct Translator {
          Stream s = input(op, c);
          StateP st = resolve(op.at("accesses").arr.at(0), c);
          const std::string stateType = op.sOr("stateType", "");
+         settle(s);
          if (!s.probeHiv.empty()) throw Unsupported("materialize between a lookup and its join predicate");
          if (stateType == "Heap") {
             if (st->kind != State::HEAP) throw Unsupported("materialize into a heap create_heap did not describe");
@@ -848,6 +936,32 @@ struct Translator {
             m.fields = {{"in", quote(st->in.rel)}, {"cols", cols + "]"}};
             steps.push_back(m);
             result = "result";
+         }
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "scatter") { // only as part of the two marker idioms of semi / anti joins
+         Stream s = input(op, c);
+         if (!s.pending) throw Unsupported("scatter outside the marker idiom of a semi / anti join");
+         for (auto& m : op.at("mapping").arr) {
+            auto it = s.cols.find(m.at("column").s("displayName"));
+            if (it == s.cols.end() || it->second->kind != Expr::CONST_BOOL || !it->second->i) throw Unsupported("scatter of anything but the constant true");
+         }
+         if (!s.aggState.empty()) { // anyTuple (RelAlgToSubOp.cpp:1296-1305): a per-probe-row marker state → semi / anti keeping the probe side
+            StateP st = states.at(s.aggState);
+            st->kind = State::MARKER;
+            s.aggState.clear();
+            st->in = s;
+         } else { // translateNLWithMarker: the flag member of the matched build entry → semi / anti keeping the BUILD side
+            StateP hiv = states.at(s.probeHiv);
+            StateP buf = hiv->source;
+            const std::string& member = op.at("mapping").arr.at(0).s("member");
+            if (!buf->members.count(member)) throw Unsupported("scatter into member '" + member + "' that the build side did not materialise");
+            if (!buf->flagMember.empty()) throw Unsupported("two joins set flags in one build buffer");
+            buf->flagMember = member;
+            buf->semiRel = emitJoin(s, "semi_build");
+            buf->flagProbe = std::make_shared<Stream>(s);
+            s.pending = false;
          }
          c.streams[ref] = s;
          return;

@@ -66,7 +66,7 @@ def test_plan_matches_oracle(world, q):
         assert got == want
 
 
-@pytest.mark.parametrize("q", [6, 1, 3])
+@pytest.mark.parametrize("q", [6, 1, 3, 4, "4_probe_side"])
 def test_subop_dump_matches_oracle(world, q):
     """f1 end to end: the reference-schema dump of the query (tests/golden/subop_tpch_qN.json, the format of
     tools/ct/mlir-subop-to-json.cpp) → ldb_subop_translate → the plan interpreter → the same oracle leg"""
@@ -75,8 +75,9 @@ def test_subop_dump_matches_oracle(world, q):
     from lingodb_amd import api
 
     runner, legs = world
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "subop_tpch_q%d.json" % q)
-    text, report = api.translate_subop_dump(path, "tpch_q%d" % q)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "subop_tpch_q%s.json" % q)
+    text, report = api.translate_subop_dump(path, "tpch_q%s" % q)
+    q = 4 if q == "4_probe_side" else q  # the same query lowered without reverseSides
     assert all(r["target"] == "gpu" for r in report)
     got = canon(runner.ctx.run_plan(text, runner.plan_inputs(q)).to_arrow())
     want = legs.run(q)

@@ -16,7 +16,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def dump(q):
-    with open(os.path.join(GOLD, "subop_tpch_q%d.json" % q)) as f:
+    with open(os.path.join(GOLD, "subop_tpch_q%s.json" % q)) as f:
         return f.read()
 
 
@@ -56,16 +56,16 @@ def normal(plan):
     return out
 
 
-@pytest.mark.parametrize("q", [6, 1, 3])
+@pytest.mark.parametrize("q", [6, 1, 3, 4, "4_probe_side"])
 def test_dump_translates_to_a_checked_plan(q):
-    text, report = api.translate_subop_dump(dump(q), "tpch_q%d" % q)
+    text, report = api.translate_subop_dump(dump(q), "tpch_q%s" % q)
     plan = json.loads(text)
     assert all(r["target"] == "gpu" for r in report) and len(report) == len(json.loads(dump(q)))
     lib = capi.host_lib()
     ins = plan["inputs"]
     arr = (capi.C.c_char_p * len(ins))(*[n.encode() for n in ins])
     assert lib.ldb_plan_json_check(text.encode(), arr, len(ins)) == capi.LDB_OK, lib.ldb_plan_json_last_error()
-    assert sorted(ins) == sorted(hand_plan(q)["inputs"])
+    assert sorted(ins) == sorted(hand_plan(4 if q == "4_probe_side" else q)["inputs"])
 
 
 def test_q6_and_q1_say_what_the_hand_plans_say():
@@ -89,6 +89,33 @@ def test_q3_has_the_hand_plans_operators():
     # … in an order that respects the data flow: both builds are unique (primary key; a key that stays unique through an N:1 join)
     builds = [s for s in got if s["op"] == "join_build"]
     assert [b["keys"] for b in builds] == [["c_custkey"], ["o_orderkey"]] and all(b["unique"] for b in builds)
+
+
+def test_semi_joins_in_both_of_the_references_forms():
+    """SemiJoinLowering (RelAlgToSubOp.cpp:1340-1375): with reverseSides the build entries carry a flag member that matched
+    probes scatter to true and a later scan filters on (→ semi_build, exactly the hand-written Q4 plan); without it every
+    probe row owns a marker state (anyTuple) → semi.  The all_false filters are the anti joins."""
+    got = normal(json.loads(api.translate_subop_dump(dump(4))[0]))
+    want = normal(hand_plan(4))
+    key = lambda s: json.dumps({k: v for k, v in s.items() if k not in ("in", "ht")}, sort_keys=True, default=str)
+    assert sorted(map(key, got)) == sorted(map(key, want))  # the same operators (the build is emitted before the probe side's filter)
+    assert [s["op"] for s in got][-4:] == ["join_probe", "groupby", "sort", "materialize"]
+    probe = json.loads(api.translate_subop_dump(dump("4_probe_side"))[0])["steps"]
+    jb, jp = [s for s in probe if s["op"] == "join_build"][0], [s for s in probe if s["op"] == "join_probe"][0]
+    assert jb["keys"] == ["l_orderkey"] and jb["unique"] is False and jp["kind"] == "semi" and jp["keys"] == ["o_orderkey"]
+    # NOT EXISTS: the same dumps with the marker / flag filter turned to all_false
+    for q, kind in ((4, "anti_build"), ("4_probe_side", "anti")):
+        d = json.loads(dump(q))
+        hits = 0
+        for step in d:
+            for op in step["subops"]:
+                for o in [op] + op.get("subops", []):
+                    if o.get("subop") == "filter" and o["columns"][0]["displayName"] in ("materialized::marker", "marker::marker"):
+                        o["semantic"] = "all_false"
+                        hits += 1
+        assert hits == 1
+        steps = json.loads(api.translate_subop_dump(json.dumps(d))[0])["steps"]
+        assert [s["kind"] for s in steps if s["op"] == "join_probe"][-1] == kind
 
 
 def test_steps_without_a_device_pattern_are_reported():
@@ -124,6 +151,7 @@ def test_dumps_are_what_the_generator_writes(tmp_path):
     import subprocess
     import sys
 
-    before = {q: dump(q) for q in (6, 1, 3)}
+    qs = (6, 1, 3, 4, "4_probe_side")
+    before = {q: dump(q) for q in qs}
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "write_subop_dumps.py")], stdout=subprocess.DEVNULL)
-    assert {q: dump(q) for q in (6, 1, 3)} == before
+    assert {q: dump(q) for q in qs} == before

@@ -20,7 +20,13 @@ changes); they are marked EXT below:
   E5  get_external meta has no key information → optional "primaryKey": [identifiers]
   E6  subop.combine_tuple has no case → {"subop": "combine_tuple"}
 
-Writes tests/golden/subop_tpch_q{6,1,3}.json."""
+Q4 comes in the two forms the reference has for a semi join (SemiJoinLowering, RelAlgToSubOp.cpp:1340-1375): with
+`reverseSides` the ORDERS are the hash-table side and matched entries get a flag member scattered to true, the orders are
+then scanned back with a filter on the flag (translateNLWithMarker, :1217-1294) — tpch_q4; without it the lineitems are the
+hash-table side and every probing order carries a marker state set by the first partner (anyTuple, :1296-1305) —
+tpch_q4_probe_side.
+
+Writes tests/golden/subop_tpch_q{6,1,3,4}.json and subop_tpch_q4_probe_side.json."""
 import json
 import os
 
@@ -53,6 +59,7 @@ def sub(a, b): return inner(["", " - ", ""], [a, b])  # EXT E1
 def div(a, b): return inner(["", " / ", ""], [a, b])
 def cast(a): return inner(["cast(", ")"], [a])
 def eq(a, b): return inner(["", "=", ""], [a, b])  # convertCmpPredicate prints no spaces, :169-182
+def lt(a, b): return inner(["", "<", ""], [a, b])
 def hash_(*cols): return inner(["hash("] + [")"], [cols[0]]) if len(cols) == 1 else inner(["hash(", ")"], [inner(["pack("] + [", "] * (len(cols) - 1) + [")"], list(cols))])
 def isnull(a): return inner(["", " is null"], [a])
 def select(c, a, b): return inner(["", " ? ", " : ", ""], [c, a, b])
@@ -291,6 +298,127 @@ def q3():
     return d.write()
 
 
+def q4_tail(d, stream_ref, step_subops, step_inputs, O):
+    """GROUP BY o_orderpriority COUNT(*) ORDER BY o_orderpriority over `stream_ref`; appends to the given pipeline step"""
+    hm = d.subop("generic_create")
+    s_hm = d.step([hm], results=[("?", hm["ref"], 0)])
+    ref = column("lookup9::ref", "?")
+    lk = d.subop("lookup_or_insert", streams=[stream_ref], accesses=[arg(len(step_inputs))], stateType="HashMap", reference=ref)
+    rd = d.subop("reduce", streams=[lk["ref"]], reference=ref, updated=[{"member": "aggrVal$0", "expression": add(member("aggrVal$0"), const(1, "int64"))}])
+    d.step(step_subops + [lk, rd], inputs=step_inputs + [("?", s_hm, 0)])
+    buf = d.subop("generic_create")
+    s_buf = d.step([buf], results=[("Buffer[...]", buf["ref"], 0)])
+    cnt = column("aggr0::tmp_attr0", "int64")
+    sc = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "keyval$0", "column": O("o_orderpriority")}, {"member": "aggrVal$0", "column": cnt}])
+    outs = [("o_orderpriority", O("o_orderpriority")), ("order_count", cnt)]
+    mat = d.subop("materialize", streams=[sc["ref"]], accesses=[arg(1)], stateType="Buffer", mapping=[{"member": "%s$7" % n, "column": c} for n, c in outs])
+    d.step([sc, mat], inputs=[("?", s_hm, 0), ("Buffer[...]", s_buf, 0)])
+    sv = d.subop("create_sorted_view", accesses=[arg(0)], sortBy=[{"member": "o_orderpriority$7", "direction": "asc"}])  # EXT E4
+    s_sv = d.step([sv], inputs=[("Buffer[...]", s_buf, 0)], results=[("SortedView Buffer[...]", sv["ref"], 0)])
+    rt = d.subop("generic_create")
+    s_rt = d.step([rt], results=[("ResultTable[...]", rt["ref"], 0)])
+    final = [(n, column("sorted0::%s" % n, c["datatype"])) for n, c in outs]
+    s3 = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "%s$7" % n, "column": c} for n, c in final])
+    m3 = d.subop("materialize", streams=[s3["ref"]], accesses=[arg(1)], stateType="ResultTable", mapping=[{"member": "%s$8" % n, "column": c} for n, c in final])
+    d.step([s3, m3], inputs=[("SortedView Buffer[...]", s_sv, 0), ("ResultTable[...]", s_rt, 0)])
+
+
+ORDERS_Q4 = [("o_orderdate", "GTE", "1993-07-01"), ("o_orderdate", "LT", "1993-10-01")]
+
+
+def q4():
+    """reverseSides: orders are the build side, a flag member marks the orders that found a late lineitem"""
+    d = Dump("tpch_q4")
+    O = lambda c: col("orders", c)
+    L = lambda c: col("lineitem", c)
+    to, toty = get_external(d, "orders", ORDERS_Q4)
+    tl_, tlty = get_external(d, "lineitem", [])
+    b1 = d.subop("generic_create")
+    s_b1 = d.step([b1], results=[("Buffer[...]", b1["ref"], 0)])
+    so = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("orders", ["o_orderkey", "o_orderpriority"]))
+    h1 = column("hj0::hash", "index")
+    f0 = column("marker0::init", "int1")
+    m1 = d.subop("map", streams=[so["ref"]], computed=[{"computed": h1, "expression": hash_(O("o_orderkey"))}, {"computed": f0, "expression": const(False, "int1")}])
+    mt1 = d.subop("materialize", streams=[m1["ref"]], accesses=[arg(1)], stateType="Buffer",
+                  mapping=[{"member": "hash$0", "column": h1}, {"member": "o_orderkey$1", "column": O("o_orderkey")}, {"member": "o_orderpriority$1", "column": O("o_orderpriority")},
+                           {"member": "flag$2", "column": f0}])
+    d.step([so, m1, mt1], inputs=[(toty, to, 0), ("Buffer[...]", s_b1, 0)])
+    v1 = d.subop("create_hash_indexed_view", accesses=[arg(0)])
+    s_v1 = d.step([v1], inputs=[("Buffer[...]", s_b1, 0)], results=[("?", v1["ref"], 0)])
+    # lineitem (l_commitdate < l_receiptdate is column-vs-column: not pushed down) probes and flags
+    sl = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("lineitem", ["l_orderkey", "l_commitdate", "l_receiptdate"]))
+    late = column("map0::pred", "int1")
+    mp = d.subop("map", streams=[sl["ref"]], computed=[{"computed": late, "expression": lt(L("l_commitdate"), L("l_receiptdate"))}])
+    fl = d.subop("filter", streams=[mp["ref"]], semantic="all_true", columns=[late])
+    h2 = column("hj1::hash", "index")
+    m2 = d.subop("map", streams=[fl["ref"]], computed=[{"computed": h2, "expression": hash_(L("l_orderkey"))}])
+    lst, ent = column("lookup0::list", "?"), column("lookup0::entryref", "?")
+    lk = d.subop("lookup", streams=[m2["ref"]], accesses=[arg(1)], stateType="HashIndexedView", reference=lst)
+    sli = d.subop("scan_list", accesses=[{"type": "nested_map_arg", "column": lst, "id": "pending"}], elem=ent)
+    ga = d.subop("gather", streams=[sli["ref"]], reference=ent, mapping=[{"member": "o_orderkey$1", "column": O("o_orderkey")}])
+    ct = d.subop("combine_tuple", streams=[ga["ref"]])
+    pred = column("map_hj0::pred", "int1")
+    mq = d.subop("map", streams=[ct["ref"]], computed=[{"computed": pred, "expression": eq(L("l_orderkey"), O("o_orderkey"))}])
+    fq = d.subop("filter", streams=[mq["ref"]], semantic="all_true", columns=[pred])
+    mark = column("marker1::marker", "int1")
+    mb = d.subop("map", streams=[fq["ref"]], computed=[{"computed": mark, "expression": const(True, "int1")}])
+    sca = d.subop("scatter", streams=[mb["ref"]], reference=ent, mapping=[{"member": "flag$2", "column": mark}])
+    nm = d.subop("nested_map", streams=[lk["ref"]], inputs=[], subops=[sli, ga, ct, mq, fq, mb, sca])
+    sli["accesses"][0]["id"] = nm["ref"] + "_0"
+    d.step([sl, mp, fl, m2, lk, nm], inputs=[(tlty, tl_, 0), ("?", s_v1, 0)])
+    # the flagged orders
+    flag = column("materialized::marker", "int1")
+    sb = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "o_orderpriority$1", "column": O("o_orderpriority")}, {"member": "flag$2", "column": flag}])
+    ff = d.subop("filter", streams=[sb["ref"]], semantic="all_true", columns=[flag])
+    q4_tail(d, ff["ref"], [sb, ff], [("Buffer[...]", s_b1, 0)], O)
+    return d.write()
+
+
+def q4_probe_side():
+    """no reverseSides: the late lineitems are the build side, every probing order carries a marker state (anyTuple)"""
+    d = Dump("tpch_q4_probe_side")
+    O = lambda c: col("orders", c)
+    L = lambda c: col("lineitem", c)
+    to, toty = get_external(d, "orders", ORDERS_Q4)
+    tl_, tlty = get_external(d, "lineitem", [])
+    b1 = d.subop("generic_create")
+    s_b1 = d.step([b1], results=[("Buffer[...]", b1["ref"], 0)])
+    sl = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("lineitem", ["l_orderkey", "l_commitdate", "l_receiptdate"]))
+    late = column("map0::pred", "int1")
+    mp = d.subop("map", streams=[sl["ref"]], computed=[{"computed": late, "expression": lt(L("l_commitdate"), L("l_receiptdate"))}])
+    fl = d.subop("filter", streams=[mp["ref"]], semantic="all_true", columns=[late])
+    h1 = column("hj0::hash", "index")
+    m1 = d.subop("map", streams=[fl["ref"]], computed=[{"computed": h1, "expression": hash_(L("l_orderkey"))}])
+    mt1 = d.subop("materialize", streams=[m1["ref"]], accesses=[arg(1)], stateType="Buffer", mapping=[{"member": "hash$0", "column": h1}, {"member": "l_orderkey$1", "column": L("l_orderkey")}])
+    d.step([sl, mp, fl, m1, mt1], inputs=[(tlty, tl_, 0), ("Buffer[...]", s_b1, 0)])
+    v1 = d.subop("create_hash_indexed_view", accesses=[arg(0)])
+    s_v1 = d.step([v1], inputs=[("Buffer[...]", s_b1, 0)], results=[("?", v1["ref"], 0)])
+    so = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("orders", ["o_orderkey", "o_orderpriority"]))
+    h2 = column("hj1::hash", "index")
+    m2 = d.subop("map", streams=[so["ref"]], computed=[{"computed": h2, "expression": hash_(O("o_orderkey"))}])
+    lst, ent = column("lookup0::list", "?"), column("lookup0::entryref", "?")
+    lk = d.subop("lookup", streams=[m2["ref"]], accesses=[arg(1)], stateType="HashIndexedView", reference=lst)
+    sli = d.subop("scan_list", accesses=[{"type": "nested_map_arg", "column": lst, "id": "pending"}], elem=ent)
+    ga = d.subop("gather", streams=[sli["ref"]], reference=ent, mapping=[{"member": "l_orderkey$1", "column": L("l_orderkey")}])
+    ct = d.subop("combine_tuple", streams=[ga["ref"]])
+    pred = column("map_hj0::pred", "int1")
+    mq = d.subop("map", streams=[ct["ref"]], computed=[{"computed": pred, "expression": eq(O("o_orderkey"), L("l_orderkey"))}])
+    fq = d.subop("filter", streams=[mq["ref"]], semantic="all_true", columns=[pred])
+    ms = d.subop("create_simple_state")  # createMarkerState: <[marker$0 : i1]> initial false (test/lit/RelAlg/lowering.mlir:99-110)
+    bv = column("map_u_1::boolval", "int1")
+    mb = d.subop("map", streams=[fq["ref"]], computed=[{"computed": bv, "expression": const(True, "int1")}])
+    mref = column("lookup1::ref", "?")
+    ml = d.subop("lookup", streams=[mb["ref"]], accesses=[node(ms["ref"])], stateType="SimpleState", reference=mref)
+    sca = d.subop("scatter", streams=[ml["ref"]], reference=mref, mapping=[{"member": "marker$0", "column": bv}])
+    mk = column("marker::marker", "int1")
+    sm = d.subop("scan", accesses=[node(ms["ref"])], mapping=[{"member": "marker$0", "column": mk}])
+    fm = d.subop("filter", streams=[sm["ref"]], semantic="all_true", columns=[mk])
+    nm = d.subop("nested_map", streams=[lk["ref"]], inputs=[], subops=[sli, ga, ct, mq, fq, ms, mb, ml, sca, sm, fm])
+    sli["accesses"][0]["id"] = nm["ref"] + "_0"
+    q4_tail(d, nm["ref"], [so, m2, lk, nm], [(toty, to, 0), ("?", s_v1, 0)], O)
+    return d.write()
+
+
 if __name__ == "__main__":
-    for f in (q6, q1, q3):
+    for f in (q6, q1, q3, q4, q4_probe_side):
         print(f())
