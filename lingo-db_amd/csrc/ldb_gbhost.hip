@@ -695,6 +695,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          ldb_dev_free(ctx, slots);
       } else if (in->n_rows) {
          int per_cu = lds_bytes > 40 * 1024 ? 2 : 4;
+         if (const int64_t forced = ldb_option("gb_wgs_per_cu", 0)) per_cu = (int) std::max<int64_t>(1, std::min<int64_t>(forced, 16)); // experiments (Q1's line re-fetches)
          int grid = ldb_grid_for(ctx, in->n_rows, GB_BLOCK, per_cu);
          hipFunction_t spec = nullptr;
          if (ldb_jit_wanted(in->n_rows)) {

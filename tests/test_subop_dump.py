@@ -155,3 +155,56 @@ def test_dumps_are_what_the_generator_writes(tmp_path):
     before = {q: dump(q) for q in qs}
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "write_subop_dumps.py")], stdout=subprocess.DEVNULL)
     assert {q: dump(q) for q in qs} == before
+
+
+def test_mutated_dumps_never_crash_the_consumer():
+    """random structural damage to the five dumps (dropped fields, swapped types, re-targeted edges, shuffled or duplicated
+    sub-operators): a plan or an error status, never a crash"""
+    import random
+
+    rng = random.Random(11)
+
+    def nodes(x, acc):
+        if isinstance(x, dict):
+            acc.append(x)
+            for v in x.values():
+                nodes(v, acc)
+        elif isinstance(x, list):
+            acc.append(x)
+            for v in x:
+                nodes(v, acc)
+        return acc
+
+    outcomes = {"ok": 0, "err": 0}
+    for q in (6, 1, 3, 4, "4_probe_side"):
+        base = json.loads(dump(q))
+        for _ in range(120):
+            d = copy.deepcopy(base)
+            for _ in range(rng.randint(1, 3)):
+                n = rng.choice(nodes(d, []))
+                if isinstance(n, dict) and n:
+                    k = rng.choice(list(n))
+                    how = rng.randrange(4)
+                    if how == 0:
+                        del n[k]
+                    elif how == 1:
+                        n[k] = rng.choice([None, 7, "x", [], {}, True])
+                    elif how == 2 and isinstance(n[k], str):
+                        n[k] = n[k] + "_"
+                    else:
+                        n[rng.choice(["subop", "ref", "type", "member", "stateType"])] = n[k]
+                elif isinstance(n, list) and n:
+                    how = rng.randrange(3)
+                    if how == 0:
+                        n.pop(rng.randrange(len(n)))
+                    elif how == 1:
+                        n.append(copy.deepcopy(rng.choice(n)))
+                    else:
+                        rng.shuffle(n)
+            try:
+                api.translate_subop_dump(json.dumps(d))
+                outcomes["ok"] += 1
+            except capi.LdbError as e:
+                assert e.status in (capi.LDB_ERR_INVALID, capi.LDB_ERR_UNSUPPORTED)
+                outcomes["err"] += 1
+    assert outcomes["err"] > 100 and outcomes["ok"] > 20, outcomes
