@@ -43,6 +43,21 @@ __device__ __forceinline__ void scan_bitmap_body(const DScan& m, const DScan* __
    const uint64_t n = d->n_rows;
    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
    const uint64_t word0 = (uint64_t) blockIdx.x * SCAN_WORDS_PER_BLOCK;
+   // zone maps: this block's 16 384 rows are exactly one zone; if a conjunct's zone cannot match, the block is all zeros
+   static_assert(SCAN_WORDS_PER_BLOCK * 64 == LDB_ZONE_ROWS, "one scan block per zone");
+   {
+      bool excluded = false;
+      LDB_UNROLL
+      for (int p = 0; p < LDB_MAX_PREDS; p++)
+         if (p < m.n_preds && m.preds[p].zmin && d_pred_is_simple(m.preds[p]))
+            excluded = excluded || !d_zone_may_pass(m.preds[p].op, gptr<int64_t>(d->preds[p].zmin)[blockIdx.x], gptr<int64_t>(d->preds[p].zmax)[blockIdx.x], (int64_t) m.preds[p].lo);
+      if (excluded) { // (block-uniform)
+         for (uint32_t w = threadIdx.x; w < SCAN_WORDS_PER_BLOCK; w += SCAN_BLOCK)
+            if ((word0 + w) * 64 < n) bitmap[word0 + w] = 0;
+         if (threadIdx.x == 0) block_counts[blockIdx.x] = 0;
+         return;
+      }
+   }
    uint32_t cnt = 0;
    constexpr uint32_t WPW = SCAN_BLOCK / LDB_WAVE; // waves per block
    for (uint32_t w = wave; w < SCAN_WORDS_PER_BLOCK; w += 4 * WPW) {
