@@ -155,7 +155,13 @@ int32_t ldb_gpu_jit_compile_check(char* log, int32_t cap);
 /* Process-wide tuning options (each also readable from the environment as LDB_<NAME> on first use):
  *   jit (0/1), jit_min_rows      — run-time kernel specialisation and its row threshold (default 4 M)
  *   lazy_filter (0/1), lazy_min_rows — filters fused into the consuming kernel (default >= 1 M rows)
- *   join_ordered, join_chained, join_radix, join_radix_min_rows, probe_batch, gb_ordered, gb_sorted
+ *   join_ordered, join_chained, join_radix, join_radix_min_rows, join_radix_min_table_bytes, join_radix_part_bytes, probe_batch
+ *   join_direct, join_rank, join_coarse (0/1) — the direct / rank-bitmap / LDS coarse-bitmap table layouts (default on)
+ *   gb_ordered, gb_sorted, gb_direct, gb_partition (0/1), gb_partition_min_rows (8 M), gb_wgs_per_cu (0 = automatic)
+ *   dict_encode (0/1), dict_min_rows — utf8 dictionary encoding at registration
+ *   zone_maps (0/1), zone_min_rows (1 M) — zone maps of selective integer-like columns
+ *   comm_transport (0 = RCCL, 1 = shared memory), comm_timeout_ms — the exchange
+ *   debug_check (0/1) — range check of every row id a probe produces
  * Tests use it to drive ONE process through both the generic and the specialised / fused code
  * paths (the reference has the same kind of switch: LINGODB_EXECUTION_MODE, Execution.cpp:224-228). */
 int32_t ldb_gpu_set_option(const char* name, int64_t value);
