@@ -56,7 +56,7 @@ def normal(plan):
     return out
 
 
-@pytest.mark.parametrize("q", [6, 1, 3, 4, "4_probe_side"])
+@pytest.mark.parametrize("q", [6, 1, 3, 4, "4_probe_side", 5])
 def test_dump_translates_to_a_checked_plan(q):
     text, report = api.translate_subop_dump(dump(q), "tpch_q%s" % q)
     plan = json.loads(text)
@@ -118,6 +118,17 @@ def test_semi_joins_in_both_of_the_references_forms():
         assert [s["kind"] for s in steps if s["op"] == "join_probe"][-1] == kind
 
 
+def test_q5_five_chained_joins_with_a_composite_key():
+    steps = json.loads(api.translate_subop_dump(dump(5))[0])["steps"]
+    builds = [s for s in steps if s["op"] == "join_build"]
+    probes = [s for s in steps if s["op"] == "join_probe"]
+    assert [b["keys"] for b in builds] == [["r_regionkey"], ["n_nationkey"], ["c_custkey"], ["o_orderkey"], ["s_suppkey", "s_nationkey"]]
+    assert all(b["unique"] for b in builds)  # primary keys, kept unique through the N:1 joins below them
+    assert [p["keys"] for p in probes] == [["n_regionkey"], ["c_nationkey"], ["o_custkey"], ["l_orderkey"], ["l_suppkey", "c_nationkey"]]
+    assert all(p["kind"] == "inner" for p in probes)
+    assert steps[-3]["op"] == "groupby" and steps[-3]["keys"] == ["n_name"] and steps[-2]["by"] == [{"col": steps[-3]["aggs"][0]["as"], "desc": True}]
+
+
 def test_steps_without_a_device_pattern_are_reported():
     d = json.loads(dump(6))
     pipe = next(n for n in d if any(s.get("subop") == "reduce" for s in n["subops"]))
@@ -151,7 +162,7 @@ def test_dumps_are_what_the_generator_writes(tmp_path):
     import subprocess
     import sys
 
-    qs = (6, 1, 3, 4, "4_probe_side")
+    qs = (6, 1, 3, 4, "4_probe_side", 5)
     before = {q: dump(q) for q in qs}
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "write_subop_dumps.py")], stdout=subprocess.DEVNULL)
     assert {q: dump(q) for q in qs} == before
@@ -176,7 +187,7 @@ def test_mutated_dumps_never_crash_the_consumer():
         return acc
 
     outcomes = {"ok": 0, "err": 0}
-    for q in (6, 1, 3, 4, "4_probe_side"):
+    for q in (6, 1, 3, 4, "4_probe_side", 5):
         base = json.loads(dump(q))
         for _ in range(120):
             d = copy.deepcopy(base)

@@ -26,7 +26,9 @@ then scanned back with a filter on the flag (translateNLWithMarker, :1217-1294) 
 hash-table side and every probing order carries a marker state set by the first partner (anyTuple, :1296-1305) —
 tpch_q4_probe_side.
 
-Writes tests/golden/subop_tpch_q{6,1,3,4}.json and subop_tpch_q4_probe_side.json."""
+Q5 is the widest shape: six tables, five hash joins chained through build buffers, one of them on a composite key.
+
+Writes tests/golden/subop_tpch_q{6,1,3,4,5}.json and subop_tpch_q4_probe_side.json."""
 import json
 import os
 
@@ -116,9 +118,13 @@ TYPES = {"l_orderkey": "int32", "l_partkey": "int32", "l_suppkey": "int32", "l_l
          "o_orderkey": "int32", "o_custkey": "int32", "o_orderstatus": "char1", "o_totalprice": "decimal(12,2)", "o_orderdate": "date",
          "o_orderpriority": "str", "o_clerk": "str", "o_shippriority": "int32", "o_comment": "str",
          "c_custkey": "int32", "c_name": "str", "c_address": "str", "c_nationkey": "int32", "c_phone": "str", "c_acctbal": "decimal(12,2)",
-         "c_mktsegment": "str", "c_comment": "str"}
-TABLES = {"lineitem": [c for c in TYPES if c.startswith("l_")], "orders": [c for c in TYPES if c.startswith("o_")], "customer": [c for c in TYPES if c.startswith("c_")]}
-PKEY = {"orders": ["o_orderkey"], "customer": ["c_custkey"]}
+         "c_mktsegment": "str", "c_comment": "str",
+         "s_suppkey": "int32", "s_name": "str", "s_address": "str", "s_nationkey": "int32", "s_phone": "str", "s_acctbal": "decimal(12,2)", "s_comment": "str",
+         "n_nationkey": "int32", "n_name": "str", "n_regionkey": "int32", "n_comment": "str",
+         "r_regionkey": "int32", "r_name": "str", "r_comment": "str"}
+TABLES = {"lineitem": [c for c in TYPES if c.startswith("l_")], "orders": [c for c in TYPES if c.startswith("o_")], "customer": [c for c in TYPES if c.startswith("c_")],
+          "supplier": [c for c in TYPES if c.startswith("s_")], "nation": [c for c in TYPES if c.startswith("n_")], "region": [c for c in TYPES if c.startswith("r_")]}
+PKEY = {"orders": ["o_orderkey"], "customer": ["c_custkey"], "supplier": ["s_suppkey"], "nation": ["n_nationkey"], "region": ["r_regionkey"]}
 
 
 def get_external(d, table, filters):
@@ -419,6 +425,112 @@ def q4_probe_side():
     return d.write()
 
 
+def and_(*xs): return inner([""] + [" and "] * (len(xs) - 1) + [""], list(xs))
+
+
+def hash_join_probe_multi(d, stream_ref, hiv_arg, pairs, extra_cols, n):
+    """hash_join_probe for a composite key: `pairs` = [(probe column, (build member, build column))]; the equality is one
+    db.and over the pairs (createVerifyEqFnForTuple, RelAlgToSubOp.cpp:1067-1095)"""
+    lst = column("lookup%d::list" % n, "?")
+    ent = column("lookup%d::entryref" % n, "?")
+    lk = d.subop("lookup", streams=[stream_ref], accesses=[arg(hiv_arg)], stateType="HashIndexedView", reference=lst)
+    sl = d.subop("scan_list", accesses=[{"type": "nested_map_arg", "column": lst, "id": "pending"}], elem=ent)
+    ga = d.subop("gather", streams=[sl["ref"]], reference=ent, mapping=[{"member": m, "column": c} for _, (m, c) in pairs] + [{"member": m, "column": c} for m, c in extra_cols])
+    ct = d.subop("combine_tuple", streams=[ga["ref"]])
+    pred = column("map_hj%d::pred" % n, "int1")
+    cond = and_(*[eq(p, b[1]) for p, b in pairs]) if len(pairs) > 1 else eq(pairs[0][0], pairs[0][1][1])
+    mp = d.subop("map", streams=[ct["ref"]], computed=[{"computed": pred, "expression": cond}])
+    fl = d.subop("filter", streams=[mp["ref"]], semantic="all_true", columns=[pred])
+    nm = d.subop("nested_map", streams=[lk["ref"]], inputs=[], subops=[sl, ga, ct, mp, fl])
+    sl["accesses"][0]["id"] = nm["ref"] + "_0"
+    return [lk, nm], nm["ref"]
+
+
+def build_side(d, pipeline, last_ref, step_inputs, key_cols, payload, n):
+    """map hash(keys) → materialize into a fresh buffer → create_hash_indexed_view; returns the step ref of the view"""
+    buf = d.subop("generic_create")
+    s_buf = d.step([buf], results=[("Buffer[...]", buf["ref"], 0)])
+    h = column("hj_b%d::hash" % n, "index")
+    m = d.subop("map", streams=[last_ref], computed=[{"computed": h, "expression": hash_(*key_cols)}])
+    mt = d.subop("materialize", streams=[m["ref"]], accesses=[arg(len(step_inputs))], stateType="Buffer",
+                 mapping=[{"member": "hash$b%d" % n, "column": h}] + [{"member": mem, "column": c} for mem, c in payload])
+    d.step(pipeline + [m, mt], inputs=step_inputs + [("Buffer[...]", s_buf, 0)])
+    v = d.subop("create_hash_indexed_view", accesses=[arg(0)])
+    return d.step([v], inputs=[("Buffer[...]", s_buf, 0)], results=[("?", v["ref"], 0)])
+
+
+def q5():
+    """six tables, five hash joins (one on a composite key), GROUP BY a string column, ORDER BY the aggregate"""
+    d = Dump("tpch_q5")
+    T = lambda t: (lambda c: col(t, c))
+    C, O, L, S, N, R = T("customer"), T("orders"), T("lineitem"), T("supplier"), T("nation"), T("region")
+    tr, trty = get_external(d, "region", [("r_name", "EQ", "ASIA")])
+    tn, tnty = get_external(d, "nation", [])
+    tc, tcty = get_external(d, "customer", [])
+    to, toty = get_external(d, "orders", [("o_orderdate", "GTE", "1994-01-01"), ("o_orderdate", "LT", "1995-01-01")])
+    tl_, tlty = get_external(d, "lineitem", [])
+    ts, tsty = get_external(d, "supplier", [])
+    # region → view on r_regionkey
+    sr = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("region", ["r_regionkey"]))
+    v_r = build_side(d, [sr], sr["ref"], [(trty, tr, 0)], [R("r_regionkey")], [("r_regionkey$b0", R("r_regionkey"))], 0)
+    # nation ⋈ region → view on n_nationkey
+    sn = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("nation", ["n_nationkey", "n_name", "n_regionkey"]))
+    hn = column("hj_p0::hash", "index")
+    mn = d.subop("map", streams=[sn["ref"]], computed=[{"computed": hn, "expression": hash_(N("n_regionkey"))}])
+    p0, a0 = hash_join_probe_multi(d, mn["ref"], 1, [(N("n_regionkey"), ("r_regionkey$b0", R("r_regionkey")))], [], 10)
+    v_n = build_side(d, [sn, mn] + p0, a0, [(tnty, tn, 0), ("?", v_r, 0)], [N("n_nationkey")], [("n_nationkey$b1", N("n_nationkey")), ("n_name$b1", N("n_name"))], 1)
+    # customer ⋈ nation → view on c_custkey
+    sc = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("customer", ["c_custkey", "c_nationkey"]))
+    hc = column("hj_p1::hash", "index")
+    mc = d.subop("map", streams=[sc["ref"]], computed=[{"computed": hc, "expression": hash_(C("c_nationkey"))}])
+    p1, a1 = hash_join_probe_multi(d, mc["ref"], 1, [(C("c_nationkey"), ("n_nationkey$b1", N("n_nationkey")))], [("n_name$b1", N("n_name"))], 11)
+    v_c = build_side(d, [sc, mc] + p1, a1, [(tcty, tc, 0), ("?", v_n, 0)], [C("c_custkey")],
+                     [("c_custkey$b2", C("c_custkey")), ("c_nationkey$b2", C("c_nationkey")), ("n_name$b2", N("n_name"))], 2)
+    # orders ⋈ customer → view on o_orderkey
+    so = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("orders", ["o_orderkey", "o_custkey"]))
+    ho = column("hj_p2::hash", "index")
+    mo = d.subop("map", streams=[so["ref"]], computed=[{"computed": ho, "expression": hash_(O("o_custkey"))}])
+    p2, a2 = hash_join_probe_multi(d, mo["ref"], 1, [(O("o_custkey"), ("c_custkey$b2", C("c_custkey")))], [("c_nationkey$b2", C("c_nationkey")), ("n_name$b2", N("n_name"))], 12)
+    v_o = build_side(d, [so, mo] + p2, a2, [(toty, to, 0), ("?", v_c, 0)], [O("o_orderkey")],
+                     [("o_orderkey$b3", O("o_orderkey")), ("c_nationkey$b3", C("c_nationkey")), ("n_name$b3", N("n_name"))], 3)
+    # supplier → view on (s_suppkey, s_nationkey)
+    ss = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("supplier", ["s_suppkey", "s_nationkey"]))
+    v_s = build_side(d, [ss], ss["ref"], [(tsty, ts, 0)], [S("s_suppkey"), S("s_nationkey")], [("s_suppkey$b4", S("s_suppkey")), ("s_nationkey$b4", S("s_nationkey"))], 4)
+    # lineitem ⋈ orders ⋈ supplier, aggregate per nation name
+    hm = d.subop("generic_create")
+    s_hm = d.step([hm], results=[("?", hm["ref"], 0)])
+    sl = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("lineitem", ["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"]))
+    hl = column("hj_p3::hash", "index")
+    ml = d.subop("map", streams=[sl["ref"]], computed=[{"computed": hl, "expression": hash_(L("l_orderkey"))}])
+    p3, a3 = hash_join_probe_multi(d, ml["ref"], 1, [(L("l_orderkey"), ("o_orderkey$b3", O("o_orderkey")))], [("c_nationkey$b3", C("c_nationkey")), ("n_name$b3", N("n_name"))], 13)
+    hl2 = column("hj_p4::hash", "index")
+    ml2 = d.subop("map", streams=[a3], computed=[{"computed": hl2, "expression": hash_(L("l_suppkey"), C("c_nationkey"))}])
+    p4, a4 = hash_join_probe_multi(d, ml2["ref"], 2, [(L("l_suppkey"), ("s_suppkey$b4", S("s_suppkey"))), (C("c_nationkey"), ("s_nationkey$b4", S("s_nationkey")))], [], 14)
+    rev_in = column("map0::tmp_attr0", "decimal(24,4)")
+    m5 = d.subop("map", streams=[a4], computed=[{"computed": rev_in, "expression": mul(L("l_extendedprice"), sub(const(1, "decimal(12,2)"), L("l_discount")))}])
+    ref = column("lookup20::ref", "?")
+    lk = d.subop("lookup_or_insert", streams=[m5["ref"]], accesses=[arg(3)], stateType="HashMap", reference=ref)
+    rd = d.subop("reduce", streams=[lk["ref"]], reference=ref, updated=[{"member": "aggrVal$0", "expression": add(member("aggrVal$0"), rev_in)}])
+    d.step([sl, ml] + p3 + [ml2] + p4 + [m5, lk, rd], inputs=[(tlty, tl_, 0), ("?", v_o, 0), ("?", v_s, 0), ("?", s_hm, 0)])
+    # ORDER BY revenue DESC
+    buf = d.subop("generic_create")
+    s_buf = d.step([buf], results=[("Buffer[...]", buf["ref"], 0)])
+    revenue = column("aggr0::tmp_attr0", "decimal(38,4)")
+    sg = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "keyval$0", "column": N("n_name")}, {"member": "aggrVal$0", "column": revenue}])
+    outs = [("n_name", N("n_name")), ("revenue", revenue)]
+    mat = d.subop("materialize", streams=[sg["ref"]], accesses=[arg(1)], stateType="Buffer", mapping=[{"member": "%s$7" % n, "column": c} for n, c in outs])
+    d.step([sg, mat], inputs=[("?", s_hm, 0), ("Buffer[...]", s_buf, 0)])
+    sv = d.subop("create_sorted_view", accesses=[arg(0)], sortBy=[{"member": "revenue$7", "direction": "desc"}])  # EXT E4
+    s_sv = d.step([sv], inputs=[("Buffer[...]", s_buf, 0)], results=[("SortedView Buffer[...]", sv["ref"], 0)])
+    rt = d.subop("generic_create")
+    s_rt = d.step([rt], results=[("ResultTable[...]", rt["ref"], 0)])
+    final = [(n, column("sorted0::%s" % n, c["datatype"])) for n, c in outs]
+    s3 = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "%s$7" % n, "column": c} for n, c in final])
+    m3 = d.subop("materialize", streams=[s3["ref"]], accesses=[arg(1)], stateType="ResultTable", mapping=[{"member": "%s$8" % n, "column": c} for n, c in final])
+    d.step([s3, m3], inputs=[("SortedView Buffer[...]", s_sv, 0), ("ResultTable[...]", s_rt, 0)])
+    return d.write()
+
+
 if __name__ == "__main__":
-    for f in (q6, q1, q3, q4, q4_probe_side):
+    for f in (q6, q1, q3, q4, q4_probe_side, q5):
         print(f())
