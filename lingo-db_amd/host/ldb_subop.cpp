@@ -48,7 +48,7 @@ using ExprP = std::shared_ptr<Expr>;
 struct Expr {
    enum Kind { COL, CONST_INT, CONST_STR, CONST_BOOL, MEMBER, REF, HASH, MARKER, FLAG, UNKNOWN, OP } kind = UNKNOWN; // MARKER: "a partner exists" of a probe row; FLAG: of a build row
    std::string name; // COL: column name in the plan language; MEMBER: member; OP: add sub mul div cast cmp and or not isnull select between in
-   std::string cmp; // OP cmp: EQ NEQ LT LTE GT GTE
+   std::string cmp; // OP cmp: EQ NEQ LT LTE GT GTE; constants: the dump's data_type
    int64_t i = 0;
    bool build = false; // COL gathered from the build side of the hash join being matched
    std::vector<ExprP> args;
@@ -130,6 +130,7 @@ struct AggSpec {
 };
 struct OutAgg {
    std::string fn, expr, as;
+   std::string when, type; // conditional aggregate: sum(case when <conjunction> then x else 0 end); result type override
    bool used = false;
 };
 struct OutStep {
@@ -204,6 +205,7 @@ struct Translator {
             if (v.kind == J::NUM && v.isInt) {
                ExprP c = mk(Expr::CONST_INT);
                c->i = v.inum;
+               c->cmp = e.sOr("data_type", "");
                return c;
             }
             if (v.kind == J::STR) return mk(Expr::CONST_STR, v.str);
@@ -331,6 +333,49 @@ struct Translator {
       return as;
    }
 
+   // a condition as a conjunction of the plan language's restrictions: column-vs-constant comparisons, AND of such, and an
+   // OR of equalities on ONE column (→ IN); false when it is anything else
+   bool condPreds(const ExprP& c0, std::vector<std::string>& out) {
+      const ExprP c = stripCast(c0);
+      if (c->kind != Expr::OP) return false;
+      auto lit = [](const ExprP& k) { return k->kind == Expr::CONST_INT ? std::to_string(k->i) : quote(k->name); };
+      auto isConst = [](const ExprP& k) { return k->kind == Expr::CONST_INT || k->kind == Expr::CONST_STR; };
+      if (c->name == "and") {
+         for (auto& a : c->args)
+            if (!condPreds(a, out)) return false;
+         return true;
+      }
+      if (c->name == "cmp") {
+         ExprP l = stripCast(c->args[0]), r = stripCast(c->args[1]);
+         std::string op = c->cmp;
+         if (l->kind != Expr::COL && r->kind == Expr::COL) {
+            std::swap(l, r);
+            op = op == "LT" ? "GT" : op == "GT" ? "LT" : op == "LTE" ? "GTE" : op == "GTE" ? "LTE" : op;
+         }
+         if (l->kind != Expr::COL || !isConst(r)) return false;
+         use(l->name);
+         out.push_back("{\"col\": " + quote(l->name) + ", \"op\": " + quote(op) + ", \"value\": " + lit(r) + "}");
+         return true;
+      }
+      if (c->name == "or") {
+         std::string col, vals;
+         for (auto& a0 : c->args) {
+            const ExprP a = stripCast(a0);
+            if (!(a->kind == Expr::OP && a->name == "cmp" && a->cmp == "EQ")) return false;
+            ExprP l = stripCast(a->args[0]), r = stripCast(a->args[1]);
+            if (l->kind != Expr::COL) std::swap(l, r);
+            if (l->kind != Expr::COL || !isConst(r) || (!col.empty() && col != l->name)) return false;
+            col = l->name;
+            vals += (vals.empty() ? "" : ", ") + lit(r);
+         }
+         if (col.empty()) return false;
+         use(col);
+         out.push_back("{\"col\": " + quote(col) + ", \"op\": \"IN\", \"values\": [" + vals + "]}");
+         return true;
+      }
+      return false;
+   }
+
    // ---------------------------------------------------------------- states
    StateP emitGroupBy(const StateP& st, const J& mapping) {
       if (st->groupbyStep >= 0) return st;
@@ -354,8 +399,22 @@ struct Translator {
          OutAgg o;
          o.fn = a.fn;
          if (a.arg) {
-            useAll(a.arg);
-            o.expr = exprJson(flattenMul(a.arg));
+            const ExprP sel = stripCast(a.arg);
+            std::vector<std::string> when;
+            // sum(case when c then x else 0 end): a conditional aggregate (the reference computes the case in a map before the reduce)
+            if (a.fn == "sum" && sel->kind == Expr::OP && sel->name == "select" && stripCast(sel->args[2])->kind == Expr::CONST_INT && stripCast(sel->args[2])->i == 0 &&
+                condPreds(sel->args[0], when)) {
+               const ExprP then = stripCast(sel->args[1]);
+               useAll(then);
+               o.expr = exprJson(flattenMul(then));
+               o.when = "[";
+               for (size_t k = 0; k < when.size(); k++) o.when += (k ? ", " : "") + when[k];
+               o.when += "]";
+               if (then->kind == Expr::CONST_INT && then->cmp == "int32") o.type = "int32"; // integer literals are int32 and SUM keeps the type
+            } else {
+               useAll(a.arg);
+               o.expr = exprJson(flattenMul(a.arg));
+            }
          }
          std::string as;
          for (auto& m : mapping.arr)
@@ -1037,7 +1096,8 @@ struct Translator {
             bool first = true;
             for (auto& a : st.aggs) {
                if (!a.used) continue; // aggregates nothing downstream reads (the sum / count halves of an avg)
-               o += std::string(first ? "" : ", ") + "{\"fn\": " + quote(a.fn) + (a.expr.empty() ? "" : ", \"expr\": " + a.expr) + ", \"as\": " + quote(a.as) + "}";
+               o += std::string(first ? "" : ", ") + "{\"fn\": " + quote(a.fn) + (a.expr.empty() ? "" : ", \"expr\": " + a.expr) + (a.when.empty() ? "" : ", \"when\": " + a.when) +
+                    (a.type.empty() ? "" : ", \"type\": " + quote(a.type)) + ", \"as\": " + quote(a.as) + "}";
                first = false;
             }
             o += "]";

@@ -56,7 +56,7 @@ def normal(plan):
     return out
 
 
-@pytest.mark.parametrize("q", [6, 1, 3, 4, "4_probe_side", 5])
+@pytest.mark.parametrize("q", [6, 1, 3, 4, "4_probe_side", 5, 12])
 def test_dump_translates_to_a_checked_plan(q):
     text, report = api.translate_subop_dump(dump(q), "tpch_q%s" % q)
     plan = json.loads(text)
@@ -129,6 +129,19 @@ def test_q5_five_chained_joins_with_a_composite_key():
     assert steps[-3]["op"] == "groupby" and steps[-3]["keys"] == ["n_name"] and steps[-2]["by"] == [{"col": steps[-3]["aggs"][0]["as"], "desc": True}]
 
 
+def test_q12_conditional_aggregates_equal_the_hand_plan():
+    """`sum(case when … then 1 else 0 end)` arrives as a map computing the case (scf.if over an OR of equalities / an AND of
+    inequalities) and a plain SUM over it: recognised as conditional aggregates with IN / NEQ conjunctions; the IN restriction
+    travels in get_external's `values`"""
+    got = json.loads(api.translate_subop_dump(dump(12))[0])["steps"]
+    want = hand_plan(12)["steps"]
+    assert [s["op"] for s in got] == [s["op"] for s in want]
+    strip = lambda a: {k: v for k, v in a.items() if k != "as"}
+    assert [strip(a) for a in got[3]["aggs"]] == [strip(a) for a in want[3]["aggs"]]
+    assert got[0]["preds"] == want[0]["preds"] and got[1]["keys"] == want[1]["keys"] and got[1]["unique"] is False
+    assert got[3]["keys"] == ["l_shipmode"] and got[4]["by"] == ["l_shipmode"]
+
+
 def test_steps_without_a_device_pattern_are_reported():
     d = json.loads(dump(6))
     pipe = next(n for n in d if any(s.get("subop") == "reduce" for s in n["subops"]))
@@ -162,7 +175,7 @@ def test_dumps_are_what_the_generator_writes(tmp_path):
     import subprocess
     import sys
 
-    qs = (6, 1, 3, 4, "4_probe_side", 5)
+    qs = (6, 1, 3, 4, "4_probe_side", 5, 12)
     before = {q: dump(q) for q in qs}
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "write_subop_dumps.py")], stdout=subprocess.DEVNULL)
     assert {q: dump(q) for q in qs} == before
@@ -187,7 +200,7 @@ def test_mutated_dumps_never_crash_the_consumer():
         return acc
 
     outcomes = {"ok": 0, "err": 0}
-    for q in (6, 1, 3, 4, "4_probe_side", 5):
+    for q in (6, 1, 3, 4, "4_probe_side", 5, 12):
         base = json.loads(dump(q))
         for _ in range(120):
             d = copy.deepcopy(base)

@@ -28,7 +28,9 @@ tpch_q4_probe_side.
 
 Q5 is the widest shape: six tables, five hash joins chained through build buffers, one of them on a composite key.
 
-Writes tests/golden/subop_tpch_q{6,1,3,4,5}.json and subop_tpch_q4_probe_side.json."""
+Q12 adds the conditional aggregate: `sum(case when … then 1 else 0 end)` = a map computing the case + a plain SUM.
+
+Writes tests/golden/subop_tpch_q{6,1,3,4,5,12}.json and subop_tpch_q4_probe_side.json."""
 import json
 import os
 
@@ -62,6 +64,9 @@ def div(a, b): return inner(["", " / ", ""], [a, b])
 def cast(a): return inner(["cast(", ")"], [a])
 def eq(a, b): return inner(["", "=", ""], [a, b])  # convertCmpPredicate prints no spaces, :169-182
 def lt(a, b): return inner(["", "<", ""], [a, b])
+def neq(a, b): return inner(["", "<>", ""], [a, b])
+def or_(*xs): return inner(["("] + [" or "] * (len(xs) - 1) + [")"], list(xs))
+def if_(c, a, b): return inner(["if ", " then ", " else ", ""], [c, a, b])  # scf.if with one result, :336-343
 def hash_(*cols): return inner(["hash("] + [")"], [cols[0]]) if len(cols) == 1 else inner(["hash(", ")"], [inner(["pack("] + [", "] * (len(cols) - 1) + [")"], list(cols))])
 def isnull(a): return inner(["", " is null"], [a])
 def select(c, a, b): return inner(["", " ? ", " : ", ""], [c, a, b])
@@ -131,7 +136,7 @@ def get_external(d, table, filters):
     """one step holding subop.get_external; meta = the deserialised ExternalDatasourceProperty (:508-560)"""
     cols = TABLES[table]
     meta = {"tableName": table, "mapping": [{"memberName": "%s$0" % c, "identifier": c} for c in cols],
-            "filters": [{"columnName": c, "columnId": 0, "op": op, "value": v} for c, op, v in filters]}
+            "filters": [{"columnName": c, "columnId": 0, "op": op, ("values" if isinstance(v, list) else "value"): v} for c, op, v in filters]}  # IN carries `values` (:541-552)
     if table in PKEY:
         meta["primaryKey"] = PKEY[table]  # EXT E5
     op = d.subop("get_external", meta=meta)
@@ -531,6 +536,57 @@ def q5():
     return d.write()
 
 
+def q12():
+    """IN and range restrictions pushed into the scan, two column-vs-column filters, a non-unique build side, and the two
+    conditional counts: the frontend lowers `sum(case when … then 1 else 0 end)` to a map computing the case (scf.if) and a
+    plain SUM over it"""
+    d = Dump("tpch_q12")
+    O = lambda c: col("orders", c)
+    L = lambda c: col("lineitem", c)
+    tl_, tlty = get_external(d, "lineitem", [("l_shipmode", "IN", ["MAIL", "SHIP"]), ("l_receiptdate", "GTE", "1994-01-01"), ("l_receiptdate", "LT", "1995-01-01")])
+    to, toty = get_external(d, "orders", [])
+    sl = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("lineitem", ["l_orderkey", "l_shipmode", "l_shipdate", "l_commitdate", "l_receiptdate"]))
+    p1, p2 = column("map0::pred", "int1"), column("map1::pred", "int1")
+    m1 = d.subop("map", streams=[sl["ref"]], computed=[{"computed": p1, "expression": lt(L("l_commitdate"), L("l_receiptdate"))}])
+    f1 = d.subop("filter", streams=[m1["ref"]], semantic="all_true", columns=[p1])
+    m2 = d.subop("map", streams=[f1["ref"]], computed=[{"computed": p2, "expression": lt(L("l_shipdate"), L("l_commitdate"))}])
+    f2 = d.subop("filter", streams=[m2["ref"]], semantic="all_true", columns=[p2])
+    v_l = build_side(d, [sl, m1, f1, m2, f2], f2["ref"], [(tlty, tl_, 0)], [L("l_orderkey")], [("l_orderkey$b0", L("l_orderkey")), ("l_shipmode$b0", L("l_shipmode"))], 0)
+    hm = d.subop("generic_create")
+    s_hm = d.step([hm], results=[("?", hm["ref"], 0)])
+    so = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("orders", ["o_orderkey", "o_orderpriority"]))
+    ho = column("hj_p0::hash", "index")
+    mo = d.subop("map", streams=[so["ref"]], computed=[{"computed": ho, "expression": hash_(O("o_orderkey"))}])
+    pr, after = hash_join_probe_multi(d, mo["ref"], 1, [(O("o_orderkey"), ("l_orderkey$b0", L("l_orderkey")))], [("l_shipmode$b0", L("l_shipmode"))], 10)
+    hi, lo = column("map2::tmp_attr0", "int32"), column("map2::tmp_attr1", "int32")
+    urgent, high = const("1-URGENT", "str"), const("2-HIGH", "str")
+    one, zero = const(1, "int32"), const(0, "int32")
+    mc = d.subop("map", streams=[after], computed=[
+        {"computed": hi, "expression": if_(or_(eq(O("o_orderpriority"), urgent), eq(O("o_orderpriority"), high)), one, zero)},
+        {"computed": lo, "expression": if_(and_(neq(O("o_orderpriority"), urgent), neq(O("o_orderpriority"), high)), one, zero)}])
+    ref = column("lookup20::ref", "?")
+    lk = d.subop("lookup_or_insert", streams=[mc["ref"]], accesses=[arg(2)], stateType="HashMap", reference=ref)
+    rd = d.subop("reduce", streams=[lk["ref"]], reference=ref, updated=[{"member": "aggrVal$0", "expression": add(member("aggrVal$0"), hi)},
+                                                                        {"member": "aggrVal$1", "expression": add(member("aggrVal$1"), lo)}])
+    d.step([so, mo] + pr + [mc, lk, rd], inputs=[(toty, to, 0), ("?", v_l, 0), ("?", s_hm, 0)])
+    buf = d.subop("generic_create")
+    s_buf = d.step([buf], results=[("Buffer[...]", buf["ref"], 0)])
+    a0, a1 = column("aggr0::tmp_attr0", "int32"), column("aggr0::tmp_attr1", "int32")
+    sg = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "keyval$0", "column": L("l_shipmode")}, {"member": "aggrVal$0", "column": a0}, {"member": "aggrVal$1", "column": a1}])
+    outs = [("l_shipmode", L("l_shipmode")), ("high_line_count", a0), ("low_line_count", a1)]
+    mat = d.subop("materialize", streams=[sg["ref"]], accesses=[arg(1)], stateType="Buffer", mapping=[{"member": "%s$7" % n, "column": c} for n, c in outs])
+    d.step([sg, mat], inputs=[("?", s_hm, 0), ("Buffer[...]", s_buf, 0)])
+    sv = d.subop("create_sorted_view", accesses=[arg(0)], sortBy=[{"member": "l_shipmode$7", "direction": "asc"}])  # EXT E4
+    s_sv = d.step([sv], inputs=[("Buffer[...]", s_buf, 0)], results=[("SortedView Buffer[...]", sv["ref"], 0)])
+    rt = d.subop("generic_create")
+    s_rt = d.step([rt], results=[("ResultTable[...]", rt["ref"], 0)])
+    final = [(n, column("sorted0::%s" % n, c["datatype"])) for n, c in outs]
+    s3 = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "%s$7" % n, "column": c} for n, c in final])
+    m3 = d.subop("materialize", streams=[s3["ref"]], accesses=[arg(1)], stateType="ResultTable", mapping=[{"member": "%s$8" % n, "column": c} for n, c in final])
+    d.step([s3, m3], inputs=[("SortedView Buffer[...]", s_sv, 0), ("ResultTable[...]", s_rt, 0)])
+    return d.write()
+
+
 if __name__ == "__main__":
-    for f in (q6, q1, q3, q4, q4_probe_side, q5):
+    for f in (q6, q1, q3, q4, q4_probe_side, q5, q12):
         print(f())
