@@ -66,7 +66,7 @@ def test_plan_matches_oracle(world, q):
         assert got == want
 
 
-@pytest.mark.parametrize("q", [6, 1, 3, 4, "4_probe_side", 5, 12])
+@pytest.mark.parametrize("q", [6, 1, 3, 4, "4_probe_side", 5, 12, 18])
 def test_subop_dump_matches_oracle(world, q):
     """f1 end to end: the reference-schema dump of the query (tests/golden/subop_tpch_qN.json, the format of
     tools/ct/mlir-subop-to-json.cpp) → ldb_subop_translate → the plan interpreter → the same oracle leg"""

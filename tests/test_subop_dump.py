@@ -56,7 +56,7 @@ def normal(plan):
     return out
 
 
-@pytest.mark.parametrize("q", [6, 1, 3, 4, "4_probe_side", 5, 12])
+@pytest.mark.parametrize("q", [6, 1, 3, 4, "4_probe_side", 5, 12, 18])
 def test_dump_translates_to_a_checked_plan(q):
     text, report = api.translate_subop_dump(dump(q), "tpch_q%s" % q)
     plan = json.loads(text)
@@ -142,6 +142,12 @@ def test_q12_conditional_aggregates_equal_the_hand_plan():
     assert got[3]["keys"] == ["l_shipmode"] and got[4]["by"] == ["l_shipmode"]
 
 
+def test_q18_having_feeds_a_semi_join():
+    got = [(s["op"], s.get("kind"), s.get("keys")) for s in json.loads(api.translate_subop_dump(dump(18))[0])["steps"]]
+    want = [(s["op"], s.get("kind"), s.get("keys")) for s in hand_plan(18)["steps"]]
+    assert got == want  # group-by → HAVING filter → unique build → semi probe → two inner joins → five-key group-by → top 100
+
+
 def test_steps_without_a_device_pattern_are_reported():
     d = json.loads(dump(6))
     pipe = next(n for n in d if any(s.get("subop") == "reduce" for s in n["subops"]))
@@ -175,7 +181,7 @@ def test_dumps_are_what_the_generator_writes(tmp_path):
     import subprocess
     import sys
 
-    qs = (6, 1, 3, 4, "4_probe_side", 5, 12)
+    qs = (6, 1, 3, 4, "4_probe_side", 5, 12, 18)
     before = {q: dump(q) for q in qs}
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "write_subop_dumps.py")], stdout=subprocess.DEVNULL)
     assert {q: dump(q) for q in qs} == before
@@ -200,7 +206,7 @@ def test_mutated_dumps_never_crash_the_consumer():
         return acc
 
     outcomes = {"ok": 0, "err": 0}
-    for q in (6, 1, 3, 4, "4_probe_side", 5, 12):
+    for q in (6, 1, 3, 4, "4_probe_side", 5, 12, 18):
         base = json.loads(dump(q))
         for _ in range(120):
             d = copy.deepcopy(base)

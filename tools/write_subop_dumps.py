@@ -30,7 +30,9 @@ Q5 is the widest shape: six tables, five hash joins chained through build buffer
 
 Q12 adds the conditional aggregate: `sum(case when … then 1 else 0 end)` = a map computing the case + a plain SUM.
 
-Writes tests/golden/subop_tpch_q{6,1,3,4,5,12}.json and subop_tpch_q4_probe_side.json."""
+Q18 chains an aggregation with HAVING into the build side of a semi join, two inner joins, a five-key GROUP BY and a heap.
+
+Writes tests/golden/subop_tpch_q{6,1,3,4,5,12,18}.json and subop_tpch_q4_probe_side.json."""
 import json
 import os
 
@@ -587,6 +589,99 @@ def q12():
     return d.write()
 
 
+def hash_semi_probe(d, stream_ref, hiv_arg, probe_key, build, n):
+    """lookup + nested_map whose body ends in anyTuple's marker idiom (RelAlgToSubOp.cpp:1296-1305): the probe row survives if
+    any entry of its bucket satisfies the equality"""
+    lst, ent = column("lookup%d::list" % n, "?"), column("lookup%d::entryref" % n, "?")
+    lk = d.subop("lookup", streams=[stream_ref], accesses=[arg(hiv_arg)], stateType="HashIndexedView", reference=lst)
+    sli = d.subop("scan_list", accesses=[{"type": "nested_map_arg", "column": lst, "id": "pending"}], elem=ent)
+    ga = d.subop("gather", streams=[sli["ref"]], reference=ent, mapping=[{"member": build[0], "column": build[1]}])
+    ct = d.subop("combine_tuple", streams=[ga["ref"]])
+    pred = column("map_hj%d::pred" % n, "int1")
+    mq = d.subop("map", streams=[ct["ref"]], computed=[{"computed": pred, "expression": eq(probe_key, build[1])}])
+    fq = d.subop("filter", streams=[mq["ref"]], semantic="all_true", columns=[pred])
+    ms = d.subop("create_simple_state")
+    bv = column("map_u_%d::boolval" % n, "int1")
+    mb = d.subop("map", streams=[fq["ref"]], computed=[{"computed": bv, "expression": const(True, "int1")}])
+    mref = column("lookup%d::ref" % (n + 100), "?")
+    ml = d.subop("lookup", streams=[mb["ref"]], accesses=[node(ms["ref"])], stateType="SimpleState", reference=mref)
+    sca = d.subop("scatter", streams=[ml["ref"]], reference=mref, mapping=[{"member": "marker$%d" % n, "column": bv}])
+    mk = column("marker%d::marker" % n, "int1")
+    sm = d.subop("scan", accesses=[node(ms["ref"])], mapping=[{"member": "marker$%d" % n, "column": mk}])
+    fm = d.subop("filter", streams=[sm["ref"]], semantic="all_true", columns=[mk])
+    nm = d.subop("nested_map", streams=[lk["ref"]], inputs=[], subops=[sli, ga, ct, mq, fq, ms, mb, ml, sca, sm, fm])
+    sli["accesses"][0]["id"] = nm["ref"] + "_0"
+    return [lk, nm], nm["ref"]
+
+
+def q18():
+    """IN (subquery with GROUP BY … HAVING) = aggregation → filter on the aggregate → the build side of a semi join; then two
+    inner joins, a five-key GROUP BY with a string key and a top-100 heap"""
+    d = Dump("tpch_q18")
+    C, O, L = (lambda c: col("customer", c)), (lambda c: col("orders", c)), (lambda c: col("lineitem", c))
+    tl_, tlty = get_external(d, "lineitem", [])
+    to, toty = get_external(d, "orders", [])
+    tc, tcty = get_external(d, "customer", [])
+    # subquery: sum(l_quantity) per order
+    hm = d.subop("generic_create")
+    s_hm = d.step([hm], results=[("?", hm["ref"], 0)])
+    s1 = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("lineitem", ["l_orderkey", "l_quantity"]))
+    ref = column("lookup0::ref", "?")
+    lk = d.subop("lookup_or_insert", streams=[s1["ref"]], accesses=[arg(1)], stateType="HashMap", reference=ref)
+    rd = d.subop("reduce", streams=[lk["ref"]], reference=ref, updated=[{"member": "aggrVal$0", "expression": add(member("aggrVal$0"), L("l_quantity"))}])
+    d.step([s1, lk, rd], inputs=[(tlty, tl_, 0), ("?", s_hm, 0)])
+    # HAVING sum > 300 → build side of the semi join (the key column is re-defined by the scan of the map)
+    sq = column("aggr0::tmp_attr0", "decimal(38,2)")
+    sg = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "keyval$0", "column": L("l_orderkey")}, {"member": "aggrVal$0", "column": sq}])
+    hp = column("map0::pred", "int1")
+    mh = d.subop("map", streams=[sg["ref"]], computed=[{"computed": hp, "expression": inner(["", ">", ""], [sq, const("300", "decimal(38,2)")])}])
+    fh = d.subop("filter", streams=[mh["ref"]], semantic="all_true", columns=[hp])
+    v_k = build_side(d, [sg, mh, fh], fh["ref"], [("?", s_hm, 0)], [L("l_orderkey")], [("l_orderkey$b0", L("l_orderkey"))], 0)
+    # orders semi join the big orders → build on o_custkey
+    so = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("orders", ["o_orderkey", "o_custkey", "o_orderdate", "o_totalprice"]))
+    ho = column("hj_p0::hash", "index")
+    mo = d.subop("map", streams=[so["ref"]], computed=[{"computed": ho, "expression": hash_(O("o_orderkey"))}])
+    sp, after = hash_semi_probe(d, mo["ref"], 1, O("o_orderkey"), ("l_orderkey$b0", L("l_orderkey")), 10)
+    v_o = build_side(d, [so, mo] + sp, after, [(toty, to, 0), ("?", v_k, 0)], [O("o_custkey")],
+                     [("o_custkey$b1", O("o_custkey")), ("o_orderkey$b1", O("o_orderkey")), ("o_orderdate$b1", O("o_orderdate")), ("o_totalprice$b1", O("o_totalprice"))], 1)
+    # customer ⋈ those orders → build on o_orderkey
+    sc = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("customer", ["c_custkey", "c_name"]))
+    hc = column("hj_p1::hash", "index")
+    mc = d.subop("map", streams=[sc["ref"]], computed=[{"computed": hc, "expression": hash_(C("c_custkey"))}])
+    p1, a1 = hash_join_probe_multi(d, mc["ref"], 1, [(C("c_custkey"), ("o_custkey$b1", O("o_custkey")))],
+                                   [("o_orderkey$b1", O("o_orderkey")), ("o_orderdate$b1", O("o_orderdate")), ("o_totalprice$b1", O("o_totalprice"))], 11)
+    v_co = build_side(d, [sc, mc] + p1, a1, [(tcty, tc, 0), ("?", v_o, 0)], [O("o_orderkey")],
+                      [("o_orderkey$b2", O("o_orderkey")), ("c_name$b2", C("c_name")), ("c_custkey$b2", C("c_custkey")), ("o_orderdate$b2", O("o_orderdate")), ("o_totalprice$b2", O("o_totalprice"))], 2)
+    # lineitem ⋈, outer aggregation
+    hm2 = d.subop("generic_create")
+    s_hm2 = d.step([hm2], results=[("?", hm2["ref"], 0)])
+    s2 = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("lineitem", ["l_orderkey", "l_quantity"]))
+    hl = column("hj_p2::hash", "index")
+    ml = d.subop("map", streams=[s2["ref"]], computed=[{"computed": hl, "expression": hash_(L("l_orderkey"))}])
+    p2, a2 = hash_join_probe_multi(d, ml["ref"], 1, [(L("l_orderkey"), ("o_orderkey$b2", O("o_orderkey")))],
+                                   [("c_name$b2", C("c_name")), ("c_custkey$b2", C("c_custkey")), ("o_orderdate$b2", O("o_orderdate")), ("o_totalprice$b2", O("o_totalprice"))], 12)
+    ref2 = column("lookup30::ref", "?")
+    lk2 = d.subop("lookup_or_insert", streams=[a2], accesses=[arg(2)], stateType="HashMap", reference=ref2)
+    rd2 = d.subop("reduce", streams=[lk2["ref"]], reference=ref2, updated=[{"member": "aggrVal$1", "expression": add(member("aggrVal$1"), L("l_quantity"))}])
+    d.step([s2, ml] + p2 + [lk2, rd2], inputs=[(tlty, tl_, 0), ("?", v_co, 0), ("?", s_hm2, 0)])
+    # ORDER BY o_totalprice DESC, o_orderdate LIMIT 100
+    total = column("aggr1::tmp_attr0", "decimal(38,2)")
+    hp_ = d.subop("create_heap", maxRows=100, sortBy=[{"member": "o_totalprice$9", "direction": "desc"}, {"member": "o_orderdate$9", "direction": "asc"}])  # EXT E4
+    s_hp = d.step([hp_], results=[("?", hp_["ref"], 0)])
+    keys = [("keyval$0", C("c_name")), ("keyval$1", C("c_custkey")), ("keyval$2", O("o_orderkey")), ("keyval$3", O("o_orderdate")), ("keyval$4", O("o_totalprice"))]
+    sg2 = d.subop("scan", accesses=[arg(0)], mapping=[{"member": m, "column": c} for m, c in keys] + [{"member": "aggrVal$1", "column": total}])
+    outs = [("c_name", C("c_name")), ("c_custkey", C("c_custkey")), ("o_orderkey", O("o_orderkey")), ("o_orderdate", O("o_orderdate")), ("o_totalprice", O("o_totalprice")), ("sum_quantity", total)]
+    mh2 = d.subop("materialize", streams=[sg2["ref"]], accesses=[arg(1)], stateType="Heap", mapping=[{"member": "%s$9" % n, "column": c} for n, c in outs])
+    d.step([sg2, mh2], inputs=[("?", s_hm2, 0), ("?", s_hp, 0)])
+    rt = d.subop("generic_create")
+    s_rt = d.step([rt], results=[("ResultTable[...]", rt["ref"], 0)])
+    final = [(n, column("heap0::%s" % n, c["datatype"])) for n, c in outs]
+    sh = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "%s$9" % n, "column": c} for n, c in final])
+    mr = d.subop("materialize", streams=[sh["ref"]], accesses=[arg(1)], stateType="ResultTable", mapping=[{"member": "%s$10" % n, "column": c} for n, c in final])
+    d.step([sh, mr], inputs=[("?", s_hp, 0), ("ResultTable[...]", s_rt, 0)])
+    return d.write()
+
+
 if __name__ == "__main__":
-    for f in (q6, q1, q3, q4, q4_probe_side, q5, q12):
+    for f in (q6, q1, q3, q4, q4_probe_side, q5, q12, q18):
         print(f())
