@@ -493,6 +493,12 @@ typedef struct {
 } ldb_join_residual;
 int32_t ldb_gpu_join_probe_residual(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind,
                                     const ldb_join_residual* resid, int32_t n_resid, ldb_rel** out, ldb_table** mark_out);
+/* Nested-loop join (translateNLJ, RelAlgToSubOp.cpp:948-1033): no key equality — the join predicate is the conjunction of
+ * `resid` (0..2 column-vs-column comparisons between a probe and a build column; none = cross product).  Every build row is
+ * visited for every probe row, so this is for SMALL build sides (band joins against dimension tables, scalar-subquery
+ * cross products).  kinds: INNER, LEFT_OUTER, SEMI, ANTI, MARK, SINGLE, SEMI_BUILD, ANTI_BUILD; result sides as ldb_gpu_join_probe. */
+int32_t ldb_gpu_join_nl(ldb_ctx* ctx, ldb_rel* probe, ldb_rel* build, int32_t kind, const ldb_join_residual* resid, int32_t n_resid, ldb_rel** out,
+                        ldb_table** mark_out);
 /* count matches only — the probe micro-benchmark kernel (Grows/s) */
 int32_t ldb_gpu_join_probe_count(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys,
                                  int64_t* matches);

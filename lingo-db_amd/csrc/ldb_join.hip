@@ -1084,3 +1084,59 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
    *out = r;
    return LDB_OK;
 }
+
+// ---------------------------------------------------------------- nested-loop join
+// A join WITHOUT key equality (translateNLJ, reference RelAlgToSubOp.cpp:948-1033: the right side is materialised into a
+// buffer, every left tuple scans it and the join predicate filters the combinations).  Here: both sides get a constant key
+// column, the build side becomes ONE chain of a chained table, and the probe walks that chain evaluating the residual
+// conjuncts (column-vs-column comparisons between the sides, <= LDB_MAX_RESID) — the same walk every hash join with a residual
+// predicate does, so every join kind is available.  O(|probe| x |build|) by nature: meant for small build sides (band joins
+// against dimension tables, cross products of scalar subqueries).
+static void strip_table_sides(ldb_ctx* ctx, ldb_rel* r, const ldb_table* t) {
+   for (size_t k = 0; k < r->sides.size();) {
+      if (r->sides[k].table == t) {
+         if (r->sides[k].owned) ldb_dev_free(ctx, r->sides[k].rowids);
+         r->sides.erase(r->sides.begin() + (long) k);
+      } else {
+         k++;
+      }
+   }
+}
+extern "C" int32_t ldb_gpu_join_nl(ldb_ctx* ctx, ldb_rel* probe, ldb_rel* build, int32_t kind, const ldb_join_residual* resid, int32_t n_resid, ldb_rel** out, ldb_table** mark_out) {
+   if (!ctx || !probe || !build || !out) LDB_FAIL(LDB_ERR_INVALID, "join_nl: NULL argument");
+   if (n_resid < 0 || n_resid > LDB_MAX_RESID || (n_resid && !resid)) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_nl: %d predicate conjuncts (0..%d column-vs-column comparisons)", n_resid, LDB_MAX_RESID);
+   if (kind == LDB_JOIN_RIGHT_OUTER || kind == LDB_JOIN_FULL_OUTER) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_nl: right / full outer nested-loop joins");
+   LDB_TRY(ldb_rel_force(ctx, probe));
+   LDB_TRY(ldb_rel_force(ctx, build));
+   if (probe->sides.size() + 1 > LDB_MAX_SIDES || build->sides.size() + 1 > LDB_MAX_SIDES) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_nl: more than %d sides (materialize first)", LDB_MAX_SIDES - 1);
+   struct Tmp {
+      ldb_ctx* ctx;
+      ldb_table *kp = nullptr, *kb = nullptr;
+      ldb_rel *p2 = nullptr, *b2 = nullptr;
+      ldb_hashtable* ht = nullptr;
+      ~Tmp() {
+         if (ht) ldb_gpu_hashtable_release(ctx, ht);
+         if (p2) ldb_gpu_rel_release(ctx, p2);
+         if (b2) ldb_gpu_rel_release(ctx, b2);
+         if (kp) ldb_gpu_table_release(ctx, kp);
+         if (kb) ldb_gpu_table_release(ctx, kb);
+      }
+   } t{ctx};
+   const ldb_coltype kt = {LDB_T_INT32, 0, 0, 0};
+   const char* nm = "nl_key";
+   LDB_TRY(ldb_gpu_table_alloc(ctx, "nl_probe_key", 1, &kt, &nm, probe->n_rows, nullptr, 0, &t.kp));
+   LDB_TRY(ldb_gpu_table_alloc(ctx, "nl_build_key", 1, &kt, &nm, build->n_rows, nullptr, 0, &t.kb));
+   if (probe->n_rows) LDB_HIP(hipMemsetAsync(t.kp->cols[0].values, 0, 4 * (size_t) probe->n_rows, ctx->stream));
+   if (build->n_rows) LDB_HIP(hipMemsetAsync(t.kb->cols[0].values, 0, 4 * (size_t) build->n_rows, ctx->stream));
+   LDB_TRY(ldb_gpu_rel_zip(ctx, probe, t.kp, &t.p2));
+   LDB_TRY(ldb_gpu_rel_zip(ctx, build, t.kb, &t.b2));
+   const ldb_colref bkey = {(int32_t) build->sides.size(), 0}, pkey = {(int32_t) probe->sides.size(), 0};
+   LDB_TRY(ldb_gpu_join_build(ctx, t.b2, &bkey, 1, 0, &t.ht)); // one key value, not unique: one chain holding every build row
+   ldb_rel* r = nullptr;
+   LDB_TRY(ldb_gpu_join_probe_residual(ctx, t.ht, t.p2, &pkey, 1, kind, resid, n_resid, &r, mark_out));
+   strip_table_sides(ctx, r, t.kp); // the constant key columns are not part of the result
+   strip_table_sides(ctx, r, t.kb);
+   *out = r;
+   return LDB_OK;
+}
+

@@ -697,6 +697,28 @@ struct Interp {
             if (const J* mo = st.get("mark_out")) putTable(mo->str, mark);
             else hidden.push_back(mark);
          }
+      } else if (op == "join_nl") { // translateNLJ: no key equality, the predicate is the residual conjuncts (small build sides)
+         std::vector<const ldb_table*>*sides, *bsides;
+         ldb_rel* in = relOf(st.s("in"), &sides);
+         ldb_rel* build = relOf(st.s("build"), &bsides);
+         static const std::map<std::string, int32_t> kinds = {{"inner", LDB_JOIN_INNER}, {"semi", LDB_JOIN_SEMI}, {"anti", LDB_JOIN_ANTI}, {"left_outer", LDB_JOIN_LEFT_OUTER},
+                                                             {"semi_build", LDB_JOIN_SEMI_BUILD}, {"anti_build", LDB_JOIN_ANTI_BUILD}};
+         auto kit = kinds.find(st.sOr("kind", "inner"));
+         if (kit == kinds.end()) throw std::runtime_error("join_nl: unknown kind");
+         const int32_t kind = kit->second;
+         std::vector<ldb_join_residual> resid;
+         if (const J* rs = st.get("residual"))
+            for (auto& r : rs->arr) resid.push_back({resolve(*sides, r.s("probe"), "join_nl probe column"), resolve(*bsides, r.s("build"), "join_nl build column"), opOf(r.s("op")), 0});
+         ldb_rel* r;
+         check(ldb_gpu_join_nl(ctx, in, build, kind, resid.data(), (int32_t) resid.size(), &r, nullptr), "join_nl");
+         std::vector<const ldb_table*> outSides;
+         if (kind == LDB_JOIN_SEMI_BUILD || kind == LDB_JOIN_ANTI_BUILD) {
+            outSides = *bsides;
+         } else {
+            outSides = *sides;
+            if (kind == LDB_JOIN_INNER || kind == LDB_JOIN_LEFT_OUTER) outSides.insert(outSides.end(), bsides->begin(), bsides->end());
+         }
+         putRel(st.s("out"), r, std::move(outSides));
       } else if (op == "groupby") {
          std::vector<const ldb_table*>* sides;
          ldb_rel* in = relOf(st.s("in"), &sides);
@@ -918,7 +940,7 @@ extern "C" int32_t ldb_plan_json_check(const char* plan_json, const char* const*
       static const std::vector<Shape> shapes = {{"scan", {"table"}, {}},           {"filter", {"in"}, {"preds"}},        {"filter_dnf", {"in"}, {"clauses"}},
                                                 {"join_build", {"in"}, {"keys"}},  {"join_probe", {"ht", "in"}, {"keys"}}, {"groupby", {"in"}, {"aggs"}},
                                                 {"map", {"in"}, {"as"}},           {"sort", {"in"}, {"by"}},             {"topk", {"in"}, {"by", "k"}},
-                                                {"materialize", {"in"}, {"cols"}}, {"allgather", {"in"}, {}},           {"shuffle", {"in"}, {"keys", "cols"}}};
+                                                {"materialize", {"in"}, {"cols"}}, {"join_nl", {"in", "build"}, {}}, {"allgather", {"in"}, {}},           {"shuffle", {"in"}, {"keys", "cols"}}};
       const J& steps = plan.at("steps");
       if (steps.kind != J::ARR) throw std::runtime_error("plan: 'steps' must be an array");
       for (auto& st : steps.arr) {

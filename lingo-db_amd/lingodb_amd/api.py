@@ -263,6 +263,19 @@ class Rel:
         check(self.ctx.lib.ldb_gpu_rel_read_rowids(self.ctx.h, self.h, side, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size))
         return out[: self.rows]
 
+    def join_nl(self, build_rel, residual=(), kind=capi.JOIN_INNER):
+        """nested-loop join of this (probe) relation with `build_rel`: residual = [(probe_col, op, build_col)] is the whole
+        join predicate (none = cross product); every build row is visited per probe row — small build sides only"""
+        ra = (capi.JoinResidual * max(1, len(residual)))()
+        for i, (pc, op, bc) in enumerate(residual):
+            ra[i].probe_col, ra[i].op, ra[i].build_col = colref(*pc), op, colref(*bc)
+        r, m = C.c_void_p(), C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_join_nl(self.ctx.h, self.h, build_rel.h, kind, ra, len(residual), C.byref(r), C.byref(m)))
+        out = Rel(self.ctx, r, self.deps + build_rel.deps + [build_rel])
+        if kind == capi.JOIN_MARK:
+            return out, Table(self.ctx, m)
+        return out
+
     # ---- operators
     def scan_filter(self, plist):
         arr, n, keep = preds_array(plist)

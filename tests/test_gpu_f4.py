@@ -186,3 +186,45 @@ def test_full_outer_join_in_a_plan(ctx):
     got = ctx.run_plan(json.dumps(plan), {"l": ctx.register("fo_l", l), "r": ctx.register("fo_r", r)}).to_arrow()
     both = len(set(range(0, 3000, 2)) & set(range(0, 3000, 3)))
     assert got.column(1).to_pylist() == [1500] and got.column(2).to_pylist() == [1000] and got.column(0).to_pylist() == [1500 + 1000 - both]
+
+
+def test_nested_loop_join_equals_brute_force(ctx):
+    """translateNLJ (RelAlgToSubOp.cpp:948-1033): a join whose predicate has no equality — a band join
+    `lo <= x AND x < hi` against a small dimension table, and the cross product — for the pair-producing and the
+    existence kinds, against a numpy brute force; through the plan step as well."""
+    import json
+
+    import numpy as np
+
+    rng = np.random.default_rng(5)
+    n, m = 20000, 37
+    x = rng.integers(0, 1000, n).astype(np.int64)
+    lo = np.sort(rng.integers(0, 1000, m)).astype(np.int64)
+    hi = lo + rng.integers(0, 60, m)
+    probe = ctx.register("nl_probe", pa.table({"x": pa.array(x), "tag": pa.array(np.arange(n, dtype=np.int32))}))
+    build = ctx.register("nl_build", pa.table({"lo": pa.array(lo), "hi": pa.array(hi), "b": pa.array(np.arange(m, dtype=np.int32))}))
+    match = (x[:, None] >= lo[None, :]) & (x[:, None] < hi[None, :])
+    resid = [((0, 0), capi.F_GTE, (0, 0)), ((0, 0), capi.F_LT, (0, 1))]
+    pairs = probe.rel().join_nl(build.rel(), resid)
+    got = sorted(pairs.materialize([(0, 1), (1, 2)]).to_arrow().to_pylist(), key=lambda r: (r["tag"], r["b"]))
+    want = [{"tag": int(i), "b": int(j)} for i, j in zip(*np.nonzero(match))]
+    assert got == want and len(want) > 1000
+    semi = probe.rel().join_nl(build.rel(), resid, capi.JOIN_SEMI)
+    anti = probe.rel().join_nl(build.rel(), resid, capi.JOIN_ANTI)
+    has = match.any(axis=1)
+    assert sorted(r["tag"] for r in semi.materialize([(0, 1)]).to_arrow().to_pylist()) == list(np.nonzero(has)[0])
+    assert sorted(r["tag"] for r in anti.materialize([(0, 1)]).to_arrow().to_pylist()) == list(np.nonzero(~has)[0])
+    sb = probe.rel().join_nl(build.rel(), resid, capi.JOIN_SEMI_BUILD)
+    assert sorted(r["b"] for r in sb.materialize([(0, 2)]).to_arrow().to_pylist()) == list(np.nonzero(match.any(axis=0))[0])
+    lo_ = probe.rel().join_nl(build.rel(), resid, capi.JOIN_LEFT_OUTER)
+    assert lo_.rows == int(match.sum() + (~has).sum())
+    cross = build.rel().join_nl(build.rel(), ())
+    assert cross.rows == m * m
+    plan = json.dumps({"name": "band", "inputs": ["p", "b"], "steps": [
+        {"op": "join_nl", "in": "p", "build": "b", "residual": [{"probe": "x", "op": "GTE", "build": "lo"}, {"probe": "x", "op": "LT", "build": "hi"}], "out": "j"},
+        {"op": "groupby", "in": "j", "keys": ["b"], "aggs": [{"fn": "count_star", "as": "n"}], "out": "g"},
+        {"op": "sort", "in": "g", "by": ["b"], "out": "s"},
+        {"op": "materialize", "in": "s", "cols": ["b", "n"], "out": "result"}], "result": "result"})
+    rows = ctx.run_plan(plan, {"p": probe, "b": build}).to_arrow().to_pylist()
+    cnt = match.sum(axis=0)
+    assert rows == [{"b": int(j), "n": int(cnt[j])} for j in range(m) if cnt[j]]
