@@ -123,6 +123,7 @@ struct Stream {
    bool pending = false;
    std::vector<std::string> probeKeys, buildKeys;
    std::string flagState; // scan of a build buffer whose flag member a semi / anti join with reversed sides has set
+   std::string nlBuild; // nested-loop join (translateNLJ): the buffer being scanned once per tuple of this stream
 };
 struct AggSpec {
    std::string member, fn;
@@ -585,6 +586,50 @@ struct Translator {
          it = it->second->build || it->second->kind == Expr::MARKER ? s.cols.erase(it) : std::next(it);
    }
 
+   // nested-loop join: `pred` (may be null: cross product) is a conjunction of comparisons between a column of the outer
+   // stream and a column of the scanned buffer
+   void emitNestedLoop(Stream& s, const ExprP& pred) {
+      StateP buf = states.at(s.nlBuild);
+      Stream& b = buf->in;
+      std::string resid = "[";
+      int n = 0;
+      std::function<void(const ExprP&)> walk = [&](const ExprP& e0) {
+         const ExprP e = stripCast(e0);
+         if (e->kind == Expr::OP && e->name == "and") {
+            for (auto& a : e->args) walk(a);
+            return;
+         }
+         if (!(e->kind == Expr::OP && e->name == "cmp")) throw Unsupported("nested-loop join predicate that is not a conjunction of comparisons");
+         ExprP l = stripCast(e->args[0]), r = stripCast(e->args[1]);
+         std::string op = e->cmp;
+         if (l->build && !r->build) {
+            std::swap(l, r);
+            op = op == "LT" ? "GT" : op == "GT" ? "LT" : op == "LTE" ? "GTE" : op == "GTE" ? "LTE" : op;
+         }
+         if (l->build || !r->build) throw Unsupported("nested-loop join comparison that does not relate the two sides");
+         const std::string bc = ensureCol(b, r, "nl_build"), pc = ensureCol(s, l, "nl_probe");
+         resid += std::string(n++ ? ", " : "") + "{\"probe\": " + quote(pc) + ", \"op\": " + quote(op) + ", \"build\": " + quote(bc) + "}";
+      };
+      if (pred) walk(pred);
+      if (n > 2) throw Unsupported("nested-loop join with more than two comparison conjuncts");
+      flush(b);
+      flush(s);
+      OutStep j;
+      j.op = "join_nl";
+      j.out = fresh("j");
+      j.fields = {{"in", quote(s.rel)}, {"build", quote(b.rel)}, {"residual", resid + "]"}, {"kind", "\"inner\""}};
+      steps.push_back(j);
+      s.rel = j.out;
+      s.nlBuild.clear();
+      s.unique.clear();
+      for (auto& kv : s.cols)
+         if (kv.second->build) {
+            auto c = std::make_shared<Expr>(*kv.second);
+            c->build = false;
+            kv.second = c;
+         }
+   }
+
    std::string idOf(const StateP& st, StepCtx& c) {
       for (auto& kv : states)
          if (kv.second == st) return kv.first;
@@ -717,6 +762,26 @@ struct Translator {
                st->in.rel = tk.out;
                st->emitted = true;
             }
+            if (c.nested && st->kind == State::BUFFER) { // translateNLJ: the buffer is scanned once per tuple of the outer stream
+               s = *c.nested;
+               settle(s);
+               if (!s.nlBuild.empty()) throw Unsupported("two nested scans in one nested_map body");
+               s.nlBuild = idOf(st, c);
+               for (auto& m : mapping.arr) {
+                  auto it = st->members.find(m.s("member"));
+                  if (it == st->members.end()) throw Unsupported("scan of member '" + m.s("member") + "' that was never materialised");
+                  auto e = std::make_shared<Expr>(*stripCast(it->second));
+                  if (e->kind != Expr::COL) {
+                     const std::string colname = ensureCol(st->in, it->second, stripSuffix(it->first));
+                     it->second = mk(Expr::COL, colname);
+                     e = std::make_shared<Expr>(*it->second);
+                  }
+                  e->build = true;
+                  s.cols[m.at("column").s("displayName")] = e;
+               }
+               c.streams[ref] = s;
+               return;
+            }
             s.rel = st->in.rel;
             s.preds = st->in.preds;
             s.unique = st->in.unique;
@@ -747,6 +812,7 @@ struct Translator {
             }
          c.nested = outer;
          c.streams[ref] = last.empty() ? s : c.streams[last];
+         if (!c.streams[ref].nlBuild.empty()) emitNestedLoop(c.streams[ref], nullptr); // no predicate in the body: a cross product
          return;
       }
       if (kind == "scan_list") {
@@ -860,6 +926,10 @@ struct Translator {
             }
             if (!s.probeHiv.empty() && !s.pending) {
                resolveJoinKeys(s, e);
+               continue;
+            }
+            if (!s.nlBuild.empty()) {
+               emitNestedLoop(s, e);
                continue;
             }
             settle(s);

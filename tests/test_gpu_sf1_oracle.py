@@ -91,3 +91,24 @@ def test_subop_dump_matches_oracle(world, q):
     else:
         assert got == want
     assert got == canon(runner.run(q).to_arrow()) or q in LIMITS or q == 5  # and the hand-written plan file agrees row for row
+
+
+def test_nested_loop_dump_counts_suppliers_per_nation(world):
+    """the translateNLJ-shaped dump (tests/golden/subop_nl_band.json): supplier x nation with the key match written as a band,
+    through translator and interpreter, against a numpy count over the same generated tables"""
+    import os
+
+    import numpy as np
+
+    from lingodb_amd import api
+
+    runner, _ = world
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "subop_nl_band.json")
+    text, _report = api.translate_subop_dump(path, "nl_band")
+    got = result_rows(runner.ctx.run_plan(text, {"supplier": runner.db.supplier, "nation": runner.db.nation}).to_arrow())
+    sn = np.array(runner.db.supplier.to_arrow().column("s_nationkey").to_pylist())
+    nat = runner.db.nation.to_arrow()
+    names = dict(zip(nat.column("n_nationkey").to_pylist(), nat.column("n_name").to_pylist()))
+    cnt = np.bincount(sn, minlength=25)
+    want = sorted((names[k], int(cnt[k])) for k in range(25) if cnt[k])
+    assert [(r[0], r[1]) for r in got] == want and sum(r[1] for r in got) == len(sn)

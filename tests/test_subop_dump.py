@@ -148,6 +148,19 @@ def test_q18_having_feeds_a_semi_join():
     assert got == want  # group-by → HAVING filter → unique build → semi probe → two inner joins → five-key group-by → top 100
 
 
+def test_nested_loop_join_pattern():
+    """translateNLJ: a buffer scanned inside a nested_map body + map + filter → join_nl with the comparisons as residuals"""
+    with open(os.path.join(GOLD, "subop_nl_band.json")) as f:
+        text, report = api.translate_subop_dump(f.read(), "nl_band")
+    steps = json.loads(text)["steps"]
+    assert steps[0] == {"op": "join_nl", "in": "supplier", "build": "nation", "kind": "inner", "out": steps[0]["out"],
+                        "residual": [{"probe": "s_nationkey", "op": "GTE", "build": "n_nationkey"}, {"probe": "s_nationkey", "op": "LTE", "build": "n_nationkey"}]}
+    assert [s["op"] for s in steps] == ["join_nl", "groupby", "sort", "materialize"] and all(r["target"] == "gpu" for r in report)
+    lib = capi.host_lib()
+    arr = (capi.C.c_char_p * 2)(b"nation", b"supplier")
+    assert lib.ldb_plan_json_check(text.encode(), arr, 2) == capi.LDB_OK
+
+
 def test_steps_without_a_device_pattern_are_reported():
     d = json.loads(dump(6))
     pipe = next(n for n in d if any(s.get("subop") == "reduce" for s in n["subops"]))

@@ -682,6 +682,51 @@ def q18():
     return d.write()
 
 
+def nl_band():
+    """translateNLJ (RelAlgToSubOp.cpp:948-1033; test/lit/RelAlg/lowering.mlir:44-60): a join without an equality — the
+    right side is materialised into a buffer, a nested_map scans it for every left tuple, a map + filter applies the
+    predicate.  Not a TPC-H query: suppliers per nation with the key match written as the band
+    `s_nationkey >= n_nationkey AND s_nationkey <= n_nationkey`, so that the answer is known."""
+    d = Dump("nl_band")
+    S, N = (lambda c: col("supplier", c)), (lambda c: col("nation", c))
+    tn, tnty = get_external(d, "nation", [])
+    ts, tsty = get_external(d, "supplier", [])
+    buf = d.subop("generic_create")
+    s_buf = d.step([buf], results=[("Buffer[...]", buf["ref"], 0)])
+    sn = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("nation", ["n_nationkey", "n_name"]))
+    mt = d.subop("materialize", streams=[sn["ref"]], accesses=[arg(1)], stateType="Buffer", mapping=[{"member": "member$0", "column": N("n_nationkey")}, {"member": "member$1", "column": N("n_name")}])
+    d.step([sn, mt], inputs=[(tnty, tn, 0), ("Buffer[...]", s_buf, 0)])
+    hm = d.subop("generic_create")
+    s_hm = d.step([hm], results=[("?", hm["ref"], 0)])
+    ss = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("supplier", ["s_suppkey", "s_nationkey"]))
+    sb = d.subop("scan", accesses=[arg(1)], mapping=[{"member": "member$0", "column": N("n_nationkey")}, {"member": "member$1", "column": N("n_name")}])
+    ct = d.subop("combine_tuple", streams=[sb["ref"]])
+    pred = column("map::pred", "int1")
+    mp = d.subop("map", streams=[ct["ref"]], computed=[{"computed": pred, "expression": and_(inner(["", ">=", ""], [S("s_nationkey"), N("n_nationkey")]), inner(["", "<=", ""], [S("s_nationkey"), N("n_nationkey")]))}])
+    fl = d.subop("filter", streams=[mp["ref"]], semantic="all_true", columns=[pred])
+    nm = d.subop("nested_map", streams=[ss["ref"]], inputs=[], subops=[sb, ct, mp, fl])
+    ref = column("lookup0::ref", "?")
+    lk = d.subop("lookup_or_insert", streams=[nm["ref"]], accesses=[arg(2)], stateType="HashMap", reference=ref)
+    rd = d.subop("reduce", streams=[lk["ref"]], reference=ref, updated=[{"member": "aggrVal$0", "expression": add(member("aggrVal$0"), const(1, "int64"))}])
+    d.step([ss, nm, lk, rd], inputs=[(tsty, ts, 0), ("Buffer[...]", s_buf, 0), ("?", s_hm, 0)])
+    b2 = d.subop("generic_create")
+    s_b2 = d.step([b2], results=[("Buffer[...]", b2["ref"], 0)])
+    cnt = column("aggr0::tmp_attr0", "int64")
+    sg = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "keyval$0", "column": N("n_name")}, {"member": "aggrVal$0", "column": cnt}])
+    outs = [("n_name", N("n_name")), ("suppliers", cnt)]
+    mat = d.subop("materialize", streams=[sg["ref"]], accesses=[arg(1)], stateType="Buffer", mapping=[{"member": "%s$7" % n, "column": c} for n, c in outs])
+    d.step([sg, mat], inputs=[("?", s_hm, 0), ("Buffer[...]", s_b2, 0)])
+    sv = d.subop("create_sorted_view", accesses=[arg(0)], sortBy=[{"member": "n_name$7", "direction": "asc"}])  # EXT E4
+    s_sv = d.step([sv], inputs=[("Buffer[...]", s_b2, 0)], results=[("SortedView Buffer[...]", sv["ref"], 0)])
+    rt = d.subop("generic_create")
+    s_rt = d.step([rt], results=[("ResultTable[...]", rt["ref"], 0)])
+    final = [(n, column("sorted0::%s" % n, c["datatype"])) for n, c in outs]
+    s3 = d.subop("scan", accesses=[arg(0)], mapping=[{"member": "%s$7" % n, "column": c} for n, c in final])
+    m3 = d.subop("materialize", streams=[s3["ref"]], accesses=[arg(1)], stateType="ResultTable", mapping=[{"member": "%s$8" % n, "column": c} for n, c in final])
+    d.step([s3, m3], inputs=[("SortedView Buffer[...]", s_sv, 0), ("ResultTable[...]", s_rt, 0)])
+    return d.write()
+
+
 if __name__ == "__main__":
-    for f in (q6, q1, q3, q4, q4_probe_side, q5, q12, q18):
+    for f in (q6, q1, q3, q4, q4_probe_side, q5, q12, q18, nl_band):
         print(f())
