@@ -239,7 +239,11 @@ struct ShmTransport : Transport {
          memcpy(dst, src, bytes);
          return LDB_OK;
       }
-      LDB_HIP(hipMemcpy(dst, src, bytes, kind));
+      // on the ctx stream, never the NULL stream: the ctx stream does not synchronise with it, and a device-to-device
+      // hipMemcpy may return before it has run — what the caller enqueues next on the ctx stream (the read-back of the
+      // received metadata) then raced with the copy and saw the buffer's previous contents
+      LDB_HIP(hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
+      if (kind != hipMemcpyDeviceToDevice) LDB_HIP(hipStreamSynchronize(ctx->stream)); // host side is a mapped segment: done before it is unmapped / published
       return LDB_OK;
    }
    int32_t group_end_inner() {
