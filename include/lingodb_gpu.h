@@ -77,7 +77,8 @@ typedef enum {
    LDB_ERR_UNSUPPORTED = -2, /* legal in the reference but not implemented on the device yet */
    LDB_ERR_OOM = -3,
    LDB_ERR_HIP = -4, /* HIP runtime error; text in ldb_gpu_last_error() */
-   LDB_ERR_NO_DEVICE = -5
+   LDB_ERR_NO_DEVICE = -5,
+   LDB_ERR_RETRY = -6 /* inside a replaying trace only: a recorded count no longer holds — end the trace, run again */
 } ldb_status;
 
 /* Physical column types = the Arrow physical types LingoDB stores
@@ -166,6 +167,31 @@ int32_t ldb_gpu_jit_compile_check(char* log, int32_t cap);
  * paths (the reference has the same kind of switch: LINGODB_EXECUTION_MODE, Execution.cpp:224-228). */
 int32_t ldb_gpu_set_option(const char* name, int64_t value);
 int64_t ldb_gpu_get_option(const char* name); /* -1 when never set and no default was read yet */
+int64_t ldb_gpu_option_epoch(void); /* number of ldb_gpu_set_option calls so far (part of a prepared plan's validity) */
+
+/* ------------------------------------------------------------------ read-back traces: executing a plan without returning to the host
+ * Reference shape: one compiled pipeline runs scan → … → materialise without the query driver in between
+ * (ScanRefsTableLowering, src/compiler/Conversion/SubOpToControlFlow/SubOpToControlFlow.cpp:1123-1202), and a query is timed
+ * as ONE main() (src/execution/LLVMBackends.cpp:856-865).  At this ABI's granularity every operator whose output size
+ * decides the next allocation reads a count back, i.e. waits for the device.  A trace removes those waits for a plan that is
+ * executed again over unchanged inputs: bracket each execution with _begin / _end.  The first execution RECORDS every count
+ * the operators read back (in call order); a later one REPLAYS them — the operator calls return at once with the recorded
+ * counts while the real ones are only queued into a pinned log, so the host issues the whole plan ahead of the device — and
+ * ldb_gpu_trace_end waits once and compares log and record.  Counts are pure functions of (plan, data, options): the caller
+ * keys a trace by those (ldb_gpu_table_stamp of every input, ldb_gpu_option_epoch) and passes allow_replay = 0 when the key
+ * changed.  Should a replayed count still differ (status LDB_TRACE_MISSED, or any call returning LDB_ERR_RETRY), everything
+ * the execution produced is void: release it and execute again (the trace records afresh).  An execution that takes another
+ * path than the recorded one (a column statistic is cached by now) verifies what it replayed and records from there on.
+ * libldb_host.so's ldb_plan_prepare / ldb_plan_execute do all of this. */
+typedef struct ldb_trace ldb_trace;
+typedef enum { LDB_TRACE_OFF = 0, LDB_TRACE_RECORDED = 1, LDB_TRACE_REPLAYED = 2, LDB_TRACE_MISSED = 3 } ldb_trace_status;
+int32_t ldb_gpu_trace_create(ldb_ctx* ctx, ldb_trace** out);
+int32_t ldb_gpu_trace_destroy(ldb_ctx* ctx, ldb_trace* t);
+int32_t ldb_gpu_trace_begin(ldb_ctx* ctx, ldb_trace* t, int32_t allow_replay);
+int32_t ldb_gpu_trace_end(ldb_ctx* ctx, int32_t* status); /* synchronises the stream; *status = ldb_trace_status */
+int32_t ldb_gpu_trace_stats(const ldb_trace* t, int64_t* entries, int64_t* records, int64_t* replays, int64_t* misses);
+/* descriptor cache of the context (descriptors of a repeated plan are byte-identical: uploaded once) */
+int32_t ldb_gpu_desc_cache_stats(ldb_ctx* ctx, int64_t* hits, int64_t* misses, int64_t* bytes);
 
 /* ------------------------------------------------------------------ tables (a1) */
 /* Replaces LingoDBTable::ensureLoaded + TableChunk flattening (LingoDBTable.cpp:27-54,
@@ -198,6 +224,9 @@ int32_t ldb_gpu_table_alloc(ldb_ctx* ctx, const char* name, int32_t n_cols, cons
                             int32_t narrow_decimals, ldb_table** out);
 int32_t ldb_gpu_table_release(ldb_ctx* ctx, ldb_table* t); /* == evict */
 int64_t ldb_gpu_table_rows(const ldb_table* t);
+/* identity of the table's content: changes whenever the table is re-created, overwritten (ldb_gpu_table_write_fixed) or
+ * resized (ldb_gpu_table_set_rows); never reused inside a process */
+uint64_t ldb_gpu_table_stamp(const ldb_table* t);
 int32_t ldb_gpu_table_cols(const ldb_table* t);
 int32_t ldb_gpu_table_coltype(const ldb_table* t, int32_t col, ldb_coltype* out);
 int32_t ldb_gpu_table_col_index(const ldb_table* t, const char* name); /* -1 if absent */

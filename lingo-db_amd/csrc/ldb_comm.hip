@@ -224,7 +224,23 @@ struct ShmTransport : Transport {
       if (fd < 0) LDB_FAIL(LDB_ERR_HIP, "shm transport: shm_open(%s) failed: %s", name.c_str(), strerror(errno));
       if (create && ftruncate(fd, (off_t) bytes) != 0) {
          close(fd);
+         shm_unlink(name.c_str());
          LDB_FAIL(LDB_ERR_HIP, "shm transport: ftruncate(%zu) failed: %s", bytes, strerror(errno));
+      }
+      if (create) {
+         // reserve the pages now: ftruncate alone leaves a sparse tmpfs file, and a /dev/shm smaller than one round's
+         // volume (a container's default is 64 MB) would then kill the rank with SIGBUS in the middle of the copy while the
+         // peers wait out the barrier timeout.  A refused reservation is an ordinary error instead, posted to the peers.
+         int rc;
+         do rc = posix_fallocate(fd, 0, (off_t) bytes);
+         while (rc == EINTR);
+         if (rc != 0) {
+            close(fd);
+            shm_unlink(name.c_str());
+            if (ctl) ctl->failed.store(1, std::memory_order_release);
+            LDB_FAIL(rc == ENOSPC ? LDB_ERR_OOM : LDB_ERR_HIP, "shm transport: cannot reserve %zu bytes of shared memory for one exchange round (%s): enlarge /dev/shm or use the RCCL transport", bytes,
+                     strerror(rc));
+         }
       }
       m->p = mmap(nullptr, bytes, create ? (PROT_READ | PROT_WRITE) : PROT_READ, MAP_SHARED, fd, 0);
       close(fd);

@@ -22,8 +22,11 @@ extern "C" const char* ldb_gpu_last_error(void) { return g_err; }
 // Process-wide tuning knobs: first read comes from the environment (LDB_<NAME>), later
 // ldb_gpu_set_option calls override it — so a test can run the same process through both the
 // generic and the run-time specialised / lazily fused code paths.
+#include <atomic>
+#include <functional>
 #include <mutex>
 static std::mutex g_opt_mu;
+static std::atomic<int64_t> g_option_epoch{0}; // bumped by every ldb_gpu_set_option: a prepared plan recorded under other options is not replayed
 static std::unordered_map<std::string, int64_t> g_opts;
 int64_t ldb_option(const char* name, int64_t dflt) {
    std::lock_guard<std::mutex> lock(g_opt_mu);
@@ -38,12 +41,13 @@ int64_t ldb_option(const char* name, int64_t dflt) {
 }
 extern "C" int32_t ldb_gpu_set_option(const char* name, int64_t value) {
    if (!name) LDB_FAIL(LDB_ERR_INVALID, "set_option: NULL name");
-   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms"};
+   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass"};
    bool ok = false;
    for (const char* k : known) ok |= strcmp(k, name) == 0;
    if (!ok) LDB_FAIL(LDB_ERR_INVALID, "set_option: unknown option '%s'", name);
    std::lock_guard<std::mutex> lock(g_opt_mu);
    g_opts[name] = value;
+   g_option_epoch.fetch_add(1);
    return LDB_OK;
 }
 // the value in effect if the option was set or read before, else what LDB_<NAME> says, else -1 ("the
@@ -80,6 +84,10 @@ int32_t ldb_dev_alloc(ldb_ctx* ctx, void** out, size_t bytes) {
    if (ctx->cache_on) {
       auto it = ctx->parked.find(cls);
       if (it != ctx->parked.end() && !it->second.empty()) {
+         // the LOWEST parked address of the class (min-heap): which block an allocation gets then depends only on the set of
+         // free blocks, not on the order they were freed in — a plan that runs again finds its buffers at the same addresses,
+         // so its descriptors are byte-identical (ldb_dev_upload's cache) from the second execution on
+         std::pop_heap(it->second.begin(), it->second.end(), std::greater<void*>());
          *out = it->second.back();
          it->second.pop_back();
          ctx->cache_bytes -= cls;
@@ -100,6 +108,7 @@ int32_t ldb_dev_alloc(ldb_ctx* ctx, void** out, size_t bytes) {
 }
 void ldb_dev_free(ldb_ctx* ctx, void* p) {
    if (!p) return;
+   if (ctx->desc_blocks.count(p)) return; // a cached descriptor (ldb_dev_upload): owned by the cache
    auto it = ctx->live.find(p);
    if (it == ctx->live.end()) {
       (void) hipFreeAsync(p, ctx->stream);
@@ -108,14 +117,40 @@ void ldb_dev_free(ldb_ctx* ctx, void* p) {
    const size_t cls = it->second;
    ctx->live.erase(it);
    if (ctx->cache_bytes + cls <= ctx->cache_cap) {
-      ctx->parked[cls].push_back(p);
+      auto& heap = ctx->parked[cls];
+      heap.push_back(p);
+      std::push_heap(heap.begin(), heap.end(), std::greater<void*>());
       ctx->cache_bytes += cls;
    } else {
       (void) hipFreeAsync(p, ctx->stream);
    }
 }
-int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_out) {
-   LDB_TRY(ldb_dev_alloc(ctx, dev_out, bytes));
+// Descriptor cache.  A plan that runs again builds byte-identical descriptors (same operators over the same buffers: the
+// block cache above hands out the same addresses), so the device copy made by the previous execution can be used as it is:
+// no staging, no H2D copy, no allocation.  Entries are keyed by a 64-bit content hash and verified by memcmp; kernels take
+// descriptors as `const D*`, nothing on the device ever writes one.  ldb_dev_free recognises a cached block and leaves it
+// alone.  Bounded (desc_cache_mb, default 64 MB): when full, everything is dropped — stream-ordered frees, so launches that
+// still read an entry are unaffected.  Option desc_cache = 0 switches it off.
+static uint64_t desc_hash(const void* p, size_t bytes) {
+   const uint8_t* b = (const uint8_t*) p;
+   uint64_t h = 0x9E3779B97F4A7C15ull ^ bytes;
+   size_t i = 0;
+   for (; i + 8 <= bytes; i += 8) {
+      uint64_t w;
+      memcpy(&w, b + i, 8);
+      h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+      h ^= h >> 29;
+   }
+   for (; i < bytes; i++) h = (h ^ b[i]) * 0x100000001B3ull;
+   return h ^ (h >> 32);
+}
+static void desc_cache_drop(ldb_ctx* ctx) {
+   for (auto& kv : ctx->desc_cache) (void) hipFreeAsync(kv.second.dev, ctx->stream);
+   ctx->desc_cache.clear();
+   ctx->desc_blocks.clear();
+   ctx->desc_bytes = 0;
+}
+static int32_t upload_raw(ldb_ctx* ctx, void* dev, const void* host, size_t bytes) {
    // descriptors (a few KB) are staged through a pinned ring so that the copy is a plain async DMA
    // (a pageable source makes the runtime stage it synchronously, ~10 µs per call); `host` may be a
    // local either way.  A slot is reused only after the stream has drained (wrap → synchronize).
@@ -128,16 +163,215 @@ int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_
       void* slot = ctx->h_ring + ctx->ring_pos;
       ctx->ring_pos += need;
       memcpy(slot, host, bytes);
-      LDB_HIP(hipMemcpyAsync(*dev_out, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+      LDB_HIP(hipMemcpyAsync(dev, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
       return LDB_OK;
    }
-   LDB_HIP(hipMemcpyAsync(*dev_out, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+   LDB_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
    return LDB_OK;
 }
-int32_t ldb_read_u64(ldb_ctx* ctx, const void* d_word, uint64_t* out) {
-   LDB_HIP(hipMemcpyAsync(ctx->h_scratch, d_word, 8, hipMemcpyDeviceToHost, ctx->stream));
+int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_out, bool cacheable) {
+   const bool cache_wanted = ldb_option("desc_cache", 1) != 0;
+   if (cacheable && cache_wanted && bytes >= 64 && bytes <= (64u << 10)) {
+      const uint64_t h = desc_hash(host, bytes);
+      auto range = ctx->desc_cache.equal_range(h);
+      for (auto it = range.first; it != range.second; ++it)
+         if (it->second.copy.size() == bytes && memcmp(it->second.copy.data(), host, bytes) == 0) {
+            *dev_out = it->second.dev;
+            ctx->desc_hits++;
+            return LDB_OK;
+         }
+      const size_t cap = (size_t) ldb_option("desc_cache_mb", 64) << 20;
+      if (ctx->desc_bytes + bytes > cap) desc_cache_drop(ctx);
+      void* dev = nullptr;
+      LDB_HIP(hipMallocAsync(&dev, bytes + 16, ctx->stream));
+      int32_t st = upload_raw(ctx, dev, host, bytes);
+      if (st != LDB_OK) {
+         (void) hipFreeAsync(dev, ctx->stream);
+         return st;
+      }
+      ldb_ctx::DescEntry e;
+      e.dev = dev;
+      e.copy.assign((const uint8_t*) host, (const uint8_t*) host + bytes);
+      ctx->desc_cache.emplace(h, std::move(e));
+      ctx->desc_blocks.insert(dev);
+      ctx->desc_bytes += bytes;
+      ctx->desc_misses++;
+      *dev_out = dev;
+      return LDB_OK;
+   }
+   LDB_TRY(ldb_dev_alloc(ctx, dev_out, bytes));
+   return upload_raw(ctx, *dev_out, host, bytes);
+}
+
+// ---------------------------------------------------------------- read-backs (ldb_internal.h: ldb_readback)
+// copies `bytes` (a multiple of 4 after padding) from device memory into the pinned log; one wave
+__global__ void k_log_copy(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t bytes) {
+   for (uint32_t i = threadIdx.x; i < bytes; i += blockDim.x) dst[i] = src[i];
+}
+static int32_t readback_sync(ldb_ctx* ctx, void* host, const void* dev, size_t bytes) {
+   if (bytes <= 512 && ctx->h_scratch) { // a pinned landing area: the copy is a plain DMA / blit, no staging by the runtime
+      LDB_HIP(hipMemcpyAsync(ctx->h_scratch, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      LDB_HIP(hipStreamSynchronize(ctx->stream));
+      memcpy(host, ctx->h_scratch, bytes);
+      return LDB_OK;
+   }
+   LDB_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
    LDB_HIP(hipStreamSynchronize(ctx->stream));
-   *out = (uint64_t) ctx->h_scratch[0];
+   return LDB_OK;
+}
+// replay: everything read so far must equal the record
+static bool trace_prefix_ok(ldb_ctx* ctx, size_t upto_entries) {
+   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+   const ldb_trace* t = ctx->trace;
+   for (size_t i = 0; i < upto_entries; i++) {
+      const ldb_trace_entry& e = t->entries[i];
+      if (memcmp(ctx->h_log + e.off, t->vals.data() + e.off, e.bytes) != 0) return false;
+   }
+   return true;
+}
+int32_t ldb_readback(ldb_ctx* ctx, void* host, const void* dev, size_t bytes, uint32_t site, int flags) {
+   if (bytes == 0) return LDB_OK;
+   if (ctx->trace_mode == 0 || bytes > LDB_RB_MAX) return readback_sync(ctx, host, dev, bytes);
+   if (ctx->trace_poisoned) LDB_FAIL(LDB_ERR_RETRY, "read-back after a mis-speculated value (the plan execution is being repeated)");
+   ldb_trace* t = ctx->trace;
+   if (flags & LDB_RB_NEVER_REPLAY) { // not a function of the data alone: read for real, in both modes, and keep out of the record
+      if (ctx->trace_mode == 2 && !trace_prefix_ok(ctx, ctx->trace_pos)) {
+         ctx->trace_poisoned = true;
+         t->misses++;
+         LDB_FAIL(LDB_ERR_RETRY, "a replayed read-back differs from the recorded value");
+      }
+      return readback_sync(ctx, host, dev, bytes);
+   }
+   if (ctx->trace_mode == 2) {
+      if (ctx->trace_pos < t->entries.size() && t->entries[ctx->trace_pos].site == site && t->entries[ctx->trace_pos].bytes == bytes) {
+         const ldb_trace_entry& e = t->entries[ctx->trace_pos++];
+         hipLaunchKernelGGL(k_log_copy, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t*) dev, ctx->h_log + e.off, (uint32_t) bytes);
+         LDB_HIP(hipGetLastError());
+         memcpy(host, t->vals.data() + e.off, bytes);
+         return LDB_OK;
+      }
+      // the execution took another path than the recorded one (a statistic is cached now, an option changed …): what was
+      // replayed so far is checked, and from here on the execution records
+      if (!trace_prefix_ok(ctx, ctx->trace_pos)) {
+         ctx->trace_poisoned = true;
+         t->misses++;
+         LDB_FAIL(LDB_ERR_RETRY, "a replayed read-back differs from the recorded value");
+      }
+      t->diverged++;
+      t->entries.resize(ctx->trace_pos);
+      t->vals.resize(ctx->trace_pos ? t->entries.back().off + ((t->entries.back().bytes + 7) & ~7u) : 0);
+      ctx->trace_mode = 1;
+   }
+   LDB_TRY(readback_sync(ctx, host, dev, bytes));
+   const size_t off = t->vals.size();
+   if (off + bytes + 8 <= LDB_LOG_BYTES) {
+      t->entries.push_back({site, (uint32_t) bytes, (uint32_t) off});
+      t->vals.resize(off + ((bytes + 7) & ~(size_t) 7), 0);
+      memcpy(t->vals.data() + off, host, bytes);
+   } else {
+      t->complete = false;
+      ctx->trace_mode = 0; // more read-backs than the log holds: this plan is never replayed
+      t->entries.clear();
+      t->vals.clear();
+   }
+   return LDB_OK;
+}
+int32_t ldb_read_u64_at(ldb_ctx* ctx, const void* d_word, uint64_t* out, uint32_t site, int flags) { return ldb_readback(ctx, out, d_word, 8, site, flags); }
+
+extern "C" int32_t ldb_gpu_trace_create(ldb_ctx* ctx, ldb_trace** out) {
+   if (!ctx || !out) LDB_FAIL(LDB_ERR_INVALID, "trace_create: NULL argument");
+   *out = new ldb_trace();
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_trace_destroy(ldb_ctx* ctx, ldb_trace* t) {
+   if (ctx && ctx->trace == t) {
+      ctx->trace = nullptr;
+      ctx->trace_mode = 0;
+   }
+   delete t;
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_trace_begin(ldb_ctx* ctx, ldb_trace* t, int32_t allow_replay) {
+   if (!ctx || !t) LDB_FAIL(LDB_ERR_INVALID, "trace_begin: NULL argument");
+   if (ctx->trace_mode != 0) LDB_FAIL(LDB_ERR_INVALID, "trace_begin: a trace is already active on this context");
+   if (!ctx->h_log) LDB_HIP(hipHostMalloc((void**) &ctx->h_log, LDB_LOG_BYTES, hipHostMallocDefault));
+   const bool replay_wanted = ldb_option("plan_replay", 1) != 0;
+   ctx->trace = t;
+   ctx->trace_pos = 0;
+   ctx->trace_poisoned = false;
+   if (allow_replay && replay_wanted && t->complete && !t->entries.empty()) {
+      ctx->trace_mode = 2;
+   } else {
+      ctx->trace_mode = 1;
+      t->entries.clear();
+      t->vals.clear();
+   }
+   t->complete = false;
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_trace_end(ldb_ctx* ctx, int32_t* status) {
+   if (!ctx || !status) LDB_FAIL(LDB_ERR_INVALID, "trace_end: NULL argument");
+   ldb_trace* t = ctx->trace;
+   const int mode = ctx->trace_mode;
+   ctx->trace = nullptr;
+   ctx->trace_mode = 0;
+   if (!t || mode == 0) {
+      *status = LDB_TRACE_OFF;
+      if (t) t->complete = false;
+      return LDB_OK;
+   }
+   if (ctx->trace_poisoned) {
+      ctx->trace_poisoned = false;
+      t->complete = false;
+      t->entries.clear();
+      t->vals.clear();
+      (void) hipStreamSynchronize(ctx->stream);
+      *status = LDB_TRACE_MISSED;
+      return LDB_OK;
+   }
+   if (mode == 2) {
+      ctx->trace = t;
+      const bool ok = trace_prefix_ok(ctx, ctx->trace_pos);
+      ctx->trace = nullptr;
+      if (!ok) {
+         t->misses++;
+         t->complete = false;
+         t->entries.clear();
+         t->vals.clear();
+         *status = LDB_TRACE_MISSED;
+         return LDB_OK;
+      }
+      if (ctx->trace_pos < t->entries.size()) { // ended earlier than the record: keep what was used
+         t->entries.resize(ctx->trace_pos);
+         t->vals.resize(ctx->trace_pos ? t->entries.back().off + ((t->entries.back().bytes + 7) & ~7u) : 0);
+      }
+      t->replays++;
+      t->complete = true;
+      *status = LDB_TRACE_REPLAYED;
+      return LDB_OK;
+   }
+   t->records++;
+   t->complete = true;
+   *status = LDB_TRACE_RECORDED;
+   return LDB_OK;
+}
+extern "C" int32_t ldb_gpu_trace_stats(const ldb_trace* t, int64_t* entries, int64_t* records, int64_t* replays, int64_t* misses) {
+   if (!t) LDB_FAIL(LDB_ERR_INVALID, "trace_stats: NULL trace");
+   if (entries) *entries = (int64_t) t->entries.size();
+   if (records) *records = t->records;
+   if (replays) *replays = t->replays;
+   if (misses) *misses = t->misses;
+   return LDB_OK;
+}
+static std::atomic<uint64_t> g_serial{1};
+uint64_t ldb_next_serial() { return g_serial.fetch_add(1); }
+extern "C" uint64_t ldb_gpu_table_stamp(const ldb_table* t) { return t ? t->serial : 0; }
+extern "C" int64_t ldb_gpu_option_epoch(void) { return g_option_epoch.load(); }
+extern "C" int32_t ldb_gpu_desc_cache_stats(ldb_ctx* ctx, int64_t* hits, int64_t* misses, int64_t* bytes) {
+   if (!ctx) LDB_FAIL(LDB_ERR_INVALID, "desc_cache_stats: NULL ctx");
+   if (hits) *hits = ctx->desc_hits;
+   if (misses) *misses = ctx->desc_misses;
+   if (bytes) *bytes = (int64_t) ctx->desc_bytes;
    return LDB_OK;
 }
 
@@ -178,6 +412,7 @@ extern "C" int32_t ldb_gpu_ctx_create(int32_t device_id, void* stream, ldb_ctx**
 extern "C" int32_t ldb_gpu_ctx_destroy(ldb_ctx* ctx) {
    if (!ctx) return LDB_OK;
    (void) hipSetDevice(ctx->device);
+   desc_cache_drop(ctx);
    ldb_cache_release(ctx);
    (void) hipStreamSynchronize(ctx->stream);
    for (auto e : ctx->timers) (void) hipEventDestroy(e);
@@ -188,7 +423,10 @@ extern "C" int32_t ldb_gpu_ctx_destroy(ldb_ctx* ctx) {
    for (auto e : ctx->prof_free) (void) hipEventDestroy(e);
    if (ctx->h_scratch) (void) hipHostFree(ctx->h_scratch);
    if (ctx->h_ring) (void) hipHostFree(ctx->h_ring);
+   if (ctx->h_log) (void) hipHostFree(ctx->h_log);
    if (ctx->d_scratch) (void) hipFree(ctx->d_scratch);
+   if (ctx->scan_status) (void) hipFree(ctx->scan_status);
+   if (ctx->scan_ticket) (void) hipFree(ctx->scan_ticket);
    if (ctx->own_stream) (void) hipStreamDestroy(ctx->stream);
    delete ctx;
    return LDB_OK;
@@ -621,6 +859,7 @@ extern "C" int32_t ldb_gpu_table_set_rows(ldb_table* t, int64_t n_rows) {
    for (auto& c : t->cols)
       if (c.type.type != LDB_T_UTF8 && n_rows * c.width > c.value_bytes) LDB_FAIL(LDB_ERR_INVALID, "set_rows: %ld rows exceed capacity of column %s", (long) n_rows, c.name.c_str());
    t->n_rows = n_rows;
+   t->serial = ldb_next_serial();
    for (auto& c : t->cols) c.has_range = false, c.sorted_state = -1, c.skewed = false;
    return LDB_OK;
 }
@@ -630,7 +869,8 @@ extern "C" int32_t ldb_gpu_table_read_fixed(ldb_ctx* ctx, const ldb_table* t, in
    if (c.type.type == LDB_T_UTF8) LDB_FAIL(LDB_ERR_INVALID, "read_fixed: column %s is utf8 (use export)", c.name.c_str());
    int64_t need = t->n_rows * c.width;
    if (out_bytes < need) LDB_FAIL(LDB_ERR_INVALID, "read_fixed: buffer %ld < %ld bytes", (long) out_bytes, (long) need);
-   if (need) LDB_HIP(hipMemcpyAsync(host_out, c.values, (size_t) need, hipMemcpyDeviceToHost, ctx->stream));
+   // (a scalar-subquery result read by the plan layer is a read-back like any count: recorded / replayed inside a trace)
+   if (need) return LDB_READBACK(ctx, host_out, c.values, (size_t) need);
    LDB_HIP(hipStreamSynchronize(ctx->stream));
    return LDB_OK;
 }
@@ -640,8 +880,7 @@ extern "C" int32_t ldb_gpu_table_row_valid(ldb_ctx* ctx, const ldb_table* t, int
    *valid = 1;
    if (!c.validity) return LDB_OK;
    uint8_t byte = 0xFF;
-   LDB_HIP(hipMemcpyAsync(&byte, c.validity + (row >> 3), 1, hipMemcpyDeviceToHost, ctx->stream));
-   LDB_HIP(hipStreamSynchronize(ctx->stream));
+   LDB_TRY(LDB_READBACK(ctx, &byte, c.validity + (row >> 3), 1));
    *valid = (byte >> (row & 7)) & 1;
    return LDB_OK;
 }
@@ -653,6 +892,7 @@ extern "C" int32_t ldb_gpu_table_write_fixed(ldb_ctx* ctx, ldb_table* t, int32_t
    if (in_bytes) LDB_HIP(hipMemcpyAsync(c.values, host_in, (size_t) in_bytes, hipMemcpyHostToDevice, ctx->stream));
    LDB_HIP(hipStreamSynchronize(ctx->stream));
    c.has_range = false, c.sorted_state = -1, c.skewed = false;
+   t->serial = ldb_next_serial();
    return LDB_OK;
 }
 
@@ -1091,8 +1331,7 @@ int32_t ldb_column_range(ldb_ctx* ctx, const ldb_table* t, int32_t col, int64_t*
          dc.scale = c.type.scale;
          LDB_HIP(hipMemcpyAsync(d_out, init, 16, hipMemcpyHostToDevice, ctx->stream));
          hipLaunchKernelGGL(k_column_range, dim3(ldb_grid_for(ctx, t->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dc, (uint64_t) t->n_rows, d_out);
-         LDB_HIP(hipMemcpyAsync(got, d_out, 16, hipMemcpyDeviceToHost, ctx->stream));
-         LDB_HIP(hipStreamSynchronize(ctx->stream));
+         LDB_TRY(LDB_READBACK(ctx, got, d_out, 16));
       }
       c.vmin = got[0];
       c.vmax = got[1];
@@ -1283,6 +1522,7 @@ __global__ void k_str_copy(const uint8_t* __restrict__ src, const int64_t* __res
       uint32_t r = rowids ? rowids[i] : (uint32_t) i;
       if (r == LDB_NULL_ROW) continue;
       int64_t b = src_off[r], len = src_off[r + 1] - b, d = dst_off[i];
+      if (d + len > total) len = total > d ? total - d : 0; // (total = the host's byte count; see ldb_readback)
       for (int64_t k = 0; k < len; k++) dst[d + k] = src[b + k];
    }
 }
@@ -1363,8 +1603,7 @@ int32_t ldb_gather_columns(ldb_ctx* ctx, const ldb_rel* r, const ldb_colref* ref
    LDB_HIP(hipGetLastError());
    if (!n_slots) return LDB_OK;
    std::vector<unsigned long long> words((size_t) n_slots);
-   LDB_HIP(hipMemcpyAsync(words.data(), d_words, 8 * (size_t) n_slots, hipMemcpyDeviceToHost, ctx->stream));
-   LDB_HIP(hipStreamSynchronize(ctx->stream));
+   LDB_TRY(LDB_READBACK(ctx, words.data(), d_words, 8 * (size_t) n_slots));
    ldb_dev_free(ctx, d_words);
    for (int32_t c = 0; c < n_cols; c++) {
       Pending& p = pend[(size_t) c];
@@ -1412,7 +1651,149 @@ extern "C" int32_t ldb_gpu_materialize(ldb_ctx* ctx, ldb_rel* r, const ldb_colre
 }
 
 // ---------------------------------------------------------------- exclusive scans
-// Single-pass-per-level scan: per-block sums → recursive scan of the sums → add back.
+// Small inputs: one workgroup (k_scan_block).  Everything else: ONE launch of a chained scan with decoupled look-back
+// (k_scan_chain) — a tile of 2048 elements per workgroup, tile numbers handed out by a ticket counter (a tile only ever
+// waits for tiles whose workgroups are already running), per-tile status words {epoch, state, value} that are never
+// cleared: every call owns a fresh epoch, and a word of another epoch reads as "not there yet".  The three-level version
+// this replaces (per-block sums → recursive scan → add back) was 22 % of all launches of a 22-query pass.
+// Status word: value in the low VBITS bits, state (1 = the tile's own sum, 2 = inclusive prefix) above it, epoch on top.
+template <typename TO, int VBITS>
+__device__ __forceinline__ unsigned long long d_chain_pack(unsigned long long epoch, unsigned state, TO v) {
+   return (epoch << (VBITS + 2)) | ((unsigned long long) state << VBITS) | ((unsigned long long) v & ((1ull << VBITS) - 1));
+}
+// called by all lanes of ONE wave of the workgroup that owns `tile`: publishes the tile's sum, walks back over the
+// predecessors' status words (64 at a time) and returns the exclusive prefix of the tile (valid in every lane)
+template <typename TO, int VBITS>
+__device__ __forceinline__ TO d_chain_prefix(unsigned long long* __restrict__ status, uint64_t tile, unsigned long long epoch, TO agg, uint32_t lane) {
+   TO prefix = 0;
+   if (tile == 0) {
+      if (lane == 0) __hip_atomic_store(&status[0], d_chain_pack<TO, VBITS>(epoch, 2, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return prefix;
+   }
+   if (lane == 0) __hip_atomic_store(&status[tile], d_chain_pack<TO, VBITS>(epoch, 1, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   int64_t look = (int64_t) tile - 1;
+   for (;;) {
+      const int64_t idx = look - (int64_t) lane;
+      unsigned long long w;
+      for (;;) {
+         w = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : d_chain_pack<TO, VBITS>(epoch, 2, (TO) 0);
+         const bool ready = (w >> (VBITS + 2)) == epoch && ((w >> VBITS) & 3u) != 0;
+         if (__ballot(!ready) == 0) break;
+         __builtin_amdgcn_s_sleep(1);
+      }
+      const unsigned long long incl_mask = __ballot(((w >> VBITS) & 3u) == 2u);
+      const int first = incl_mask ? __builtin_ctzll(incl_mask) : 64;
+      TO contrib = (int) lane <= first ? (TO) (w & ((1ull << VBITS) - 1)) : (TO) 0;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) contrib += (TO) __shfl_xor((long long) contrib, off);
+      prefix += contrib;
+      if (incl_mask) break;
+      look -= 64;
+   }
+   if (lane == 0) __hip_atomic_store(&status[tile], d_chain_pack<TO, VBITS>(epoch, 2, (TO) (prefix + agg)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   return prefix;
+}
+// workgroup of 256: exclusive scan of one value per thread; returns the thread's exclusive prefix inside the workgroup and
+// the workgroup's total in *agg (s_wave: 4 words of LDS)
+template <typename TO>
+__device__ __forceinline__ TO d_block_scan256(TO sum, TO* s_wave, TO* agg) {
+   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   TO incl = sum;
+#pragma unroll
+   for (int off = 1; off < 64; off <<= 1) {
+      const TO t = (TO) __shfl_up((long long) incl, off);
+      if ((int) lane >= off) incl += t;
+   }
+   if (lane == 63) s_wave[wave] = incl;
+   __syncthreads();
+   TO wave_off = 0;
+   for (uint32_t w = 0; w < wave; w++) wave_off += s_wave[w];
+   *agg = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+   return wave_off + incl - sum;
+}
+#define CHAIN_ITEMS 8
+#define CHAIN_TILE (256 * CHAIN_ITEMS)
+template <typename T, typename TO, typename TT, int VBITS>
+__global__ __launch_bounds__(256) void k_scan_chain(const T* __restrict__ in, TO* __restrict__ out, uint64_t n, uint64_t n_tiles, TT* __restrict__ total,
+                                                    unsigned long long* __restrict__ status, unsigned long long* __restrict__ ticket, unsigned long long ticket_base,
+                                                    unsigned long long epoch) {
+   __shared__ unsigned long long s_tile;
+   __shared__ TO s_wave[4];
+   __shared__ TO s_prefix;
+   if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1ull) - ticket_base;
+   __syncthreads();
+   const uint64_t tile = s_tile;
+   const uint64_t base = tile * CHAIN_TILE + (uint64_t) threadIdx.x * CHAIN_ITEMS;
+   TO v[CHAIN_ITEMS];
+   TO sum = 0;
+#pragma unroll
+   for (int k = 0; k < CHAIN_ITEMS; k++) {
+      v[k] = base + k < n ? (TO) in[base + k] : (TO) 0;
+      sum += v[k];
+   }
+   TO agg;
+   TO excl = d_block_scan256<TO>(sum, s_wave, &agg);
+   if (threadIdx.x < 64) {
+      const TO prefix = d_chain_prefix<TO, VBITS>(status, tile, epoch, agg, threadIdx.x);
+      if (threadIdx.x == 0) s_prefix = prefix;
+   }
+   __syncthreads();
+   excl += s_prefix;
+   if (total && tile == n_tiles - 1 && threadIdx.x == 0) *total = (TT) (s_prefix + agg);
+#pragma unroll
+   for (int k = 0; k < CHAIN_ITEMS; k++) {
+      if (base + k < n) out[base + k] = excl;
+      excl += v[k];
+   }
+}
+// the chain's device state: status words for `tiles` tiles in both formats (32-bit values / 42-bit values) + the ticket
+// counter.  Returns the (masked) epoch of this call and the ticket base; grows the status arrays on demand.
+struct ChainCall {
+   unsigned long long* status;
+   unsigned long long* ticket;
+   unsigned long long ticket_base;
+   unsigned long long epoch;
+};
+static int32_t chain_begin(ldb_ctx* ctx, uint64_t n_tiles, bool wide, ChainCall* c) {
+   if (!ctx->scan_ticket) {
+      LDB_HIP(hipMalloc((void**) &ctx->scan_ticket, 64));
+      LDB_HIP(hipMemsetAsync(ctx->scan_ticket, 0, 64, ctx->stream));
+      ctx->scan_ticket_base = 0;
+   }
+   if (n_tiles > ctx->scan_status_tiles) {
+      size_t want = 4096;
+      while (want < n_tiles) want *= 2;
+      uint64_t* fresh = nullptr;
+      LDB_HIP(hipMallocAsync((void**) &fresh, 16 * want, ctx->stream)); // [0, want): 32-bit format, [want, 2 want): 42-bit format
+      LDB_HIP(hipMemsetAsync(fresh, 0, 16 * want, ctx->stream));
+      if (ctx->scan_status) (void) hipFreeAsync(ctx->scan_status, ctx->stream);
+      ctx->scan_status = fresh;
+      ctx->scan_status_tiles = want;
+   }
+   // epochs: 30 bits beside a 32-bit value, 20 bits beside a 42-bit value; epoch 0 is "never written".  When the narrower
+   // counter wraps, the words are cleared once (a stale word of the same epoch would read as ready)
+   ctx->scan_epoch++;
+   const uint32_t mask = wide ? (1u << 20) - 1 : (1u << 30) - 1;
+   if ((ctx->scan_epoch & ((1u << 20) - 1)) == 0) {
+      LDB_HIP(hipMemsetAsync(ctx->scan_status, 0, 16 * ctx->scan_status_tiles, ctx->stream));
+      ctx->scan_epoch++;
+   }
+   c->status = (unsigned long long*) ctx->scan_status + (wide ? ctx->scan_status_tiles : 0);
+   c->ticket = ctx->scan_ticket;
+   c->ticket_base = ctx->scan_ticket_base;
+   c->epoch = ctx->scan_epoch & mask;
+   ctx->scan_ticket_base += n_tiles;
+   return LDB_OK;
+}
+// a launch that did not happen took no tickets: the host mirror of the counter is re-based (the next tile numbers must
+// start at 0 again, or every later chain would wait for tiles that never run)
+static int32_t chain_failed(ldb_ctx* ctx) {
+   (void) hipMemsetAsync(ctx->scan_ticket, 0, 64, ctx->stream);
+   ctx->scan_ticket_base = 0;
+   LDB_FAIL(LDB_ERR_HIP, "chained scan: the launch failed");
+}
+
+// the three-level scan (option scan_single_pass = 0, and the single-workgroup case): per-block sums → recursive scan → add back
 template <typename T, typename TO, typename TT>
 __global__ void k_scan_block(const T* __restrict__ in, TO* __restrict__ out, TO* __restrict__ block_sums, uint64_t n, TT* __restrict__ total) {
    __shared__ TO sh[256];
@@ -1453,7 +1834,7 @@ __global__ void k_scan_add(TO* __restrict__ out, const TO* __restrict__ block_of
    for (int k = 0; k < ITEMS; k++)
       if (base + k < n) out[base + k] += add;
 }
-template <typename T, typename TO, typename TT>
+template <typename T, typename TO, typename TT, int VBITS>
 static int32_t scan_impl(ldb_ctx* ctx, const T* d_in, TO* d_out, int64_t n, TT* d_total) {
    if (n <= 0) {
       if (d_total) LDB_HIP(hipMemsetAsync(d_total, 0, sizeof(TT), ctx->stream));
@@ -1461,13 +1842,21 @@ static int32_t scan_impl(ldb_ctx* ctx, const T* d_in, TO* d_out, int64_t n, TT* 
    }
    const int64_t per_block = 256 * 8;
    int64_t nb = (n + per_block - 1) / per_block;
+   if (nb > 1 && ldb_option("scan_single_pass", 1) != 0) {
+      ChainCall c;
+      LDB_TRY(chain_begin(ctx, (uint64_t) nb, VBITS > 32, &c));
+      hipLaunchKernelGGL((k_scan_chain<T, TO, TT, VBITS>), dim3((unsigned) nb), dim3(256), 0, ctx->stream, d_in, d_out, (uint64_t) n, (uint64_t) nb, d_total, c.status, c.ticket, c.ticket_base,
+                         c.epoch);
+      if (hipGetLastError() != hipSuccess) return chain_failed(ctx);
+      return LDB_OK;
+   }
    TO* sums = nullptr;
    if (nb > 1) LDB_TRY(ldb_dev_alloc(ctx, (void**) &sums, sizeof(TO) * (size_t) (nb + 1)));
    hipLaunchKernelGGL((k_scan_block<T, TO, TT>), dim3((unsigned) nb), dim3(256), 0, ctx->stream, d_in, d_out, sums, (uint64_t) n, d_total);
    if (nb > 1) {
       TO* sums_scanned;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &sums_scanned, sizeof(TO) * (size_t) (nb + 1)));
-      LDB_TRY((scan_impl<TO, TO, TT>(ctx, sums, sums_scanned, nb, d_total)));
+      LDB_TRY((scan_impl<TO, TO, TT, VBITS>(ctx, sums, sums_scanned, nb, d_total)));
       hipLaunchKernelGGL((k_scan_add<TO>), dim3((unsigned) nb), dim3(256), 0, ctx->stream, d_out, sums_scanned, (uint64_t) n);
       ldb_dev_free(ctx, sums_scanned);
       ldb_dev_free(ctx, sums);
@@ -1477,8 +1866,119 @@ static int32_t scan_impl(ldb_ctx* ctx, const T* d_in, TO* d_out, int64_t n, TT* 
 }
 int32_t ldb_exclusive_scan_u32(ldb_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, uint64_t* d_total) {
    // the running sums are 32-bit (callers bound their totals by the uint32 row-id space); the total is stored widened
-   return scan_impl<uint32_t, uint32_t, uint64_t>(ctx, d_in, d_out, n, d_total);
+   return scan_impl<uint32_t, uint32_t, uint64_t, 32>(ctx, d_in, d_out, n, d_total);
 }
 int32_t ldb_exclusive_scan_i64(ldb_ctx* ctx, const int64_t* d_in, int64_t* d_out, int64_t n, int64_t* d_total) {
-   return scan_impl<int64_t, int64_t, int64_t>(ctx, d_in, d_out, n, d_total);
+   // non-negative inputs (string lengths) whose total stays below 2^42 bytes — 15 x the HBM of one MI355X
+   return scan_impl<int64_t, int64_t, int64_t, 42>(ctx, d_in, d_out, n, d_total);
+}
+
+// ---------------------------------------------------------------- bitmap → ascending row numbers, one launch
+// A selection bitmap (one bit per row: ballot words of a probe / filter kernel) becomes the ascending list of set positions:
+// popcount, chained scan (above) and expansion in ONE kernel — the word_pop + scan + expand sequence it replaces was five to
+// seven launches and two temporaries per join.  A tile is 2048 words (131 072 rows).  Dense tiles expand a word per wave
+// iteration (the lanes whose bit is set write one coalesced run), sparse tiles a word per lane.  With `match` the kernel also
+// writes second[j] = match[row] (the build row of a unique-key join's j-th result pair).  Entries [total, cap) are filled
+// with row 0, so that a consumer that was sized from a REPLAYED count (ldb_readback) never meets an uninitialised row id.
+__global__ __launch_bounds__(256) void k_bitmap_compact(const uint64_t* __restrict__ bitmap, uint64_t n_words, uint64_t n_tiles, uint32_t* __restrict__ out, uint64_t cap,
+                                                        const uint32_t* __restrict__ match, uint32_t* __restrict__ second, unsigned long long* __restrict__ total,
+                                                        unsigned long long* __restrict__ status, unsigned long long* __restrict__ ticket, unsigned long long ticket_base,
+                                                        unsigned long long epoch) {
+   __shared__ unsigned long long s_tile;
+   __shared__ uint32_t s_wave[4];
+   __shared__ uint32_t s_prefix;
+   __shared__ uint32_t s_off[CHAIN_TILE];
+   if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1ull) - ticket_base;
+   __syncthreads();
+   const uint64_t tile = s_tile;
+   const uint64_t word0 = tile * CHAIN_TILE;
+   // word w of the tile is handled by thread w % 256 in round w / 256 (coalesced loads); offsets go through LDS
+   uint64_t m[CHAIN_ITEMS];
+   uint32_t cnt[CHAIN_ITEMS];
+   uint32_t sum = 0;
+#pragma unroll
+   for (int k = 0; k < CHAIN_ITEMS; k++) {
+      const uint64_t w = word0 + (uint64_t) k * 256 + threadIdx.x;
+      m[k] = w < n_words ? bitmap[w] : 0;
+      cnt[k] = (uint32_t) __popcll(m[k]);
+      s_off[k * 256 + threadIdx.x] = cnt[k];
+   }
+   __syncthreads();
+   // thread t scans words [8t, 8t + 8) of the tile (consecutive words → consecutive output positions)
+   uint32_t own[CHAIN_ITEMS];
+#pragma unroll
+   for (int k = 0; k < CHAIN_ITEMS; k++) {
+      own[k] = s_off[threadIdx.x * CHAIN_ITEMS + k];
+      sum += own[k];
+   }
+   uint32_t agg;
+   uint32_t excl = d_block_scan256<uint32_t>(sum, s_wave, &agg);
+   if (threadIdx.x < 64) {
+      const uint32_t prefix = d_chain_prefix<uint32_t, 32>(status, tile, epoch, agg, threadIdx.x);
+      if (threadIdx.x == 0) s_prefix = prefix;
+   }
+   __syncthreads();
+   const uint32_t tile_base = s_prefix;
+   excl += tile_base;
+#pragma unroll
+   for (int k = 0; k < CHAIN_ITEMS; k++) {
+      s_off[threadIdx.x * CHAIN_ITEMS + k] = excl;
+      excl += own[k];
+   }
+   if (tile == n_tiles - 1 && threadIdx.x == 0) {
+      if (total) *total = (unsigned long long) tile_base + agg;
+   }
+   __syncthreads();
+   if (agg * 8u < CHAIN_TILE * 64u) { // fewer than one set bit in eight: a word per lane
+#pragma unroll
+      for (int k = 0; k < CHAIN_ITEMS; k++) {
+         uint64_t mm = m[k];
+         if (!mm) continue;
+         uint32_t at = s_off[k * 256 + threadIdx.x];
+         const uint32_t base = (uint32_t) ((word0 + (uint64_t) k * 256 + threadIdx.x) * 64);
+         while (mm) {
+            const uint32_t row = base + (uint32_t) __builtin_ctzll(mm);
+            if (at < cap) { // (cap < the real count only under a wrong replayed count: never write past the buffer)
+               out[at] = row;
+               if (match) second[at] = match[row];
+            }
+            at++;
+            mm &= mm - 1;
+         }
+      }
+   } else { // a word per wave iteration
+      const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      for (uint32_t w = wave; w < CHAIN_TILE; w += 4) {
+         if (word0 + w >= n_words) break;
+         const uint64_t mm = bitmap[word0 + w]; // wave-uniform (L1 / L2 hit: read a moment ago)
+         if ((mm >> lane) & 1) {
+            const uint32_t at = s_off[w] + d_rank_in(mm);
+            const uint32_t row = (uint32_t) ((word0 + w) * 64 + lane);
+            if (at < cap) {
+               out[at] = row;
+               if (match) second[at] = match[row];
+            }
+         }
+      }
+   }
+   if (tile == n_tiles - 1) { // the tail behind the real count (see above)
+      const uint64_t end = (uint64_t) tile_base + agg;
+      for (uint64_t i = end + threadIdx.x; i < cap; i += 256) {
+         out[i] = 0;
+         if (match) second[i] = 0;
+      }
+   }
+}
+int32_t ldb_bitmap_compact(ldb_ctx* ctx, const uint64_t* bitmap, int64_t n_words, uint32_t* out, uint64_t cap, const uint32_t* match, uint32_t* second, uint64_t* d_total) {
+   if (n_words <= 0) {
+      if (d_total) LDB_HIP(hipMemsetAsync(d_total, 0, 8, ctx->stream));
+      return LDB_OK;
+   }
+   const uint64_t n_tiles = ((uint64_t) n_words + CHAIN_TILE - 1) / CHAIN_TILE;
+   ChainCall c;
+   LDB_TRY(chain_begin(ctx, n_tiles, false, &c));
+   hipLaunchKernelGGL(k_bitmap_compact, dim3((unsigned) n_tiles), dim3(256), 0, ctx->stream, bitmap, (uint64_t) n_words, n_tiles, out, cap, match, second, (unsigned long long*) d_total, c.status,
+                      c.ticket, c.ticket_base, c.epoch);
+   if (hipGetLastError() != hipSuccess) return chain_failed(ctx);
+   return LDB_OK;
 }

@@ -650,6 +650,10 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          h->direct_keys_out = (uint64_t) direct_keys;
       } else {
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &rep_rows, 4 * (size_t) max_groups));
+         // ordered slots give up on long probe runs, which depends on the insertion order: should a REPLAYED execution
+         // (ldb_readback) meet that where the recorded one did not, its group count is too high until the trace ends and the
+         // execution is repeated — the representative rows beyond the real count must then still be valid row numbers
+         if (h->ordered_slots && ctx->trace_mode == 2) LDB_HIP(hipMemsetAsync(rep_rows, 0, 4 * (size_t) max_groups, ctx->stream));
       }
       for (int32_t a = 0; a < n_aggs; a++) {
          LDB_TRY(ldb_dev_alloc(ctx, &out_vals[(size_t) a], (size_t) oinfo[(size_t) a].width * (size_t) max_groups));
@@ -735,9 +739,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          ldb_dev_free(ctx, off);
       }
       static_assert(sizeof(ctl) <= 64 * sizeof(int64_t), "control block must fit the pinned scratch words");
-      LDB_HIP(hipMemcpyAsync(ctx->h_scratch, d_ctl, ctl_bytes, hipMemcpyDeviceToHost, ctx->stream));
-      LDB_HIP(hipStreamSynchronize(ctx->stream));
-      memcpy(ctl, ctx->h_scratch, ctl_bytes);
+      LDB_TRY(LDB_READBACK(ctx, ctl, d_ctl, ctl_bytes));
       ldb_dev_free(ctx, gk);
       ldb_dev_free(ctx, ga);
       ldb_dev_free(ctx, d);

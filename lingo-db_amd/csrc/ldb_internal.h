@@ -7,6 +7,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 // ---------------------------------------------------------------- errors
@@ -88,6 +89,43 @@ struct ldb_prof_total {
    double max_ms = 0; // the longest single launch (an operator may launch the same kernel on inputs of very different size)
 };
 #define LDB_RING_BYTES ((size_t) 1 << 20)
+
+// ---------------------------------------------------------------- read-backs and their trace (prepared plans)
+// Every device → host read of a count / flag / control block goes through ldb_readback.  Outside a trace it is an
+// asynchronous copy followed by a stream synchronisation (the host needs the value to size the next allocation).  Inside a
+// trace (ldb_gpu_trace_begin … _end, what a prepared plan brackets each execution with) the values are RECORDED in call
+// order; the next execution over the same, unchanged inputs REPLAYS them: ldb_readback returns the recorded value at once
+// and only queues a copy of the real value into a pinned log, so the host runs ahead of the device through the whole plan
+// and waits ONCE, in ldb_gpu_trace_end, where the log is compared with the record.  Counts are pure functions of the plan
+// and the data, so the comparison can only fail when something the trace key does not cover changed; then the execution is
+// discarded and repeated without replay.  The reference's counterpart is the fused pipeline that never returns to the host
+// between operators (ScanRefsTableLowering, SubOpToControlFlow.cpp:1123-1202; one main() per query, LLVMBackends.cpp:856-865).
+#define LDB_RB_MAX 4096 /* largest read that can be recorded; larger reads always synchronise */
+struct ldb_trace_entry {
+   uint32_t site; // which call site asked (hash of file + line)
+   uint32_t bytes;
+   uint32_t off; // offset of the value in ldb_trace::vals and in the pinned log (8-byte aligned)
+};
+struct ldb_trace {
+   std::vector<ldb_trace_entry> entries;
+   std::vector<uint8_t> vals;
+   bool complete = false; // the last execution that wrote it ran to ldb_gpu_trace_end
+   int64_t replays = 0, records = 0, misses = 0, diverged = 0;
+};
+#define LDB_LOG_BYTES ((size_t) 256 << 10)
+constexpr uint32_t ldb_site_hash(const char* f, int line) {
+   uint32_t h = 2166136261u;
+   for (; *f; f++) h = (h ^ (uint32_t) (unsigned char) *f) * 16777619u;
+   return (h ^ (uint32_t) line) * 16777619u;
+}
+#define LDB_SITE (ldb_site_hash(__FILE__, __LINE__))
+struct ldb_ctx;
+// read `bytes` of device memory into `host` (see above); flags: LDB_RB_NEVER_REPLAY for values that may differ between two
+// executions over the same data (flags raised by races between insertions) — those always synchronise
+#define LDB_RB_NEVER_REPLAY 1
+int32_t ldb_readback(ldb_ctx* ctx, void* host, const void* dev, size_t bytes, uint32_t site, int flags = 0);
+#define LDB_READBACK(ctx, host, dev, bytes) ldb_readback((ctx), (host), (dev), (bytes), LDB_SITE)
+
 struct ldb_ctx {
    bool prof_on = false;
    std::vector<ldb_prof_pending> prof_pending;
@@ -110,13 +148,40 @@ struct ldb_ctx {
    bool cache_on = true;
    size_t cache_bytes = 0, cache_cap = 0; // bytes parked in free lists / their limit
    std::unordered_map<void*, size_t> live; // block → its size class (bytes)
-   std::unordered_map<size_t, std::vector<void*>> parked; // size class → free blocks
+   std::unordered_map<size_t, std::vector<void*>> parked; // size class → free blocks (min-heaps by address: the lowest free block is handed out, so a
+                                                          // repeated plan sees the same addresses whatever order its blocks were freed in)
+   // descriptor cache of ldb_dev_upload: content hash → device copy (never written by a kernel: descriptors are const)
+   struct DescEntry {
+      void* dev;
+      std::vector<uint8_t> copy;
+   };
+   std::unordered_multimap<uint64_t, DescEntry> desc_cache;
+   std::unordered_set<void*> desc_blocks;
+   size_t desc_bytes = 0;
+   int64_t desc_hits = 0, desc_misses = 0;
+   // read-back trace (see ldb_readback)
+   ldb_trace* trace = nullptr;
+   int trace_mode = 0; // 0 none, 1 record, 2 replay
+   size_t trace_pos = 0;
+   bool trace_poisoned = false; // a replayed value was wrong: everything computed since is void
+   uint8_t* h_log = nullptr; // pinned, LDB_LOG_BYTES
+   // single-pass scans (ldb_exclusive_scan_*): tile status words + the ticket counter, never cleared — every scan call owns a
+   // fresh epoch / ticket range (ldb_core.hip)
+   uint64_t* scan_status = nullptr;
+   size_t scan_status_tiles = 0;
+   unsigned long long* scan_ticket = nullptr; // device
+   uint64_t scan_ticket_base = 0; // tickets handed out so far (host mirror)
+   uint32_t scan_epoch = 0;
 };
 
+uint64_t ldb_next_serial();
 struct ldb_table {
    ldb_ctx* ctx = nullptr;
    std::string name;
    int64_t n_rows = 0;
+   // identity of the table's CONTENT for prepared plans (ldb_gpu_table_stamp): a process-wide serial number taken at
+   // creation and again whenever the rows are overwritten or the row count changes
+   uint64_t serial = ldb_next_serial();
    std::vector<ldb_column> cols;
    int32_t dict_refs = 1; // a dictionary table is shared by the columns gathered from the one it was built for
    // device hash indexes over this table's key columns (ldb_gpu_table_index): built on first use, kept with the table —
@@ -163,7 +228,8 @@ struct LdbProf {
 int32_t ldb_dev_alloc(ldb_ctx* ctx, void** out, size_t bytes);
 void ldb_dev_free(ldb_ctx* ctx, void* p);
 // upload a host descriptor struct into device memory (stream-ordered)
-int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_out);
+// (read-only descriptors are cached by content, see ldb_core.hip; cacheable = false for memory a kernel will write)
+int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_out, bool cacheable = true);
 
 int32_t ldb_make_dcol(const ldb_rel* r, ldb_colref ref, DCol* out);
 int32_t ldb_make_dpred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out);
@@ -197,7 +263,11 @@ static inline int ldb_grid_for(const ldb_ctx* ctx, int64_t n, int block, int per
 // exclusive scan of n uint32 values on the device (in place allowed); total written to *d_total (uint64)
 int32_t ldb_exclusive_scan_u32(ldb_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, uint64_t* d_total);
 int32_t ldb_exclusive_scan_i64(ldb_ctx* ctx, const int64_t* d_in, int64_t* d_out, int64_t n, int64_t* d_total);
-// blocking read of one 64-bit device word
-int32_t ldb_read_u64(ldb_ctx* ctx, const void* d_word, uint64_t* out);
+// selection bitmap (n_words x 64 rows) → ascending row numbers in out[0, total), total ≤ cap; entries [total, cap) are set
+// to 0; with `match`, second[j] = match[out[j]]; *d_total (device, may be NULL) receives the count.  One launch.
+int32_t ldb_bitmap_compact(ldb_ctx* ctx, const uint64_t* bitmap, int64_t n_words, uint32_t* out, uint64_t cap, const uint32_t* match, uint32_t* second, uint64_t* d_total);
+// read of one 64-bit device word (ldb_readback)
+int32_t ldb_read_u64_at(ldb_ctx* ctx, const void* d_word, uint64_t* out, uint32_t site, int flags = 0);
+#define ldb_read_u64(ctx, d_word, out) ldb_read_u64_at((ctx), (d_word), (out), LDB_SITE)
 // new relation helpers
 ldb_rel* ldb_rel_new(ldb_ctx* ctx);

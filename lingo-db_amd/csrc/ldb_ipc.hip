@@ -232,6 +232,7 @@ void parse(const char* path, Parsed& P) {
       if (!rb) bad("IPC file: RecordBatch message without a header");
       if (rb.table(3)) bad("IPC file: compressed record batches", LDB_ERR_UNSUPPORTED);
       const int64_t length = rb.scalar<int64_t>(0, 0);
+      if (length < 0 || length > (int64_t) 1 << 40) bad("IPC file: record batch " + std::to_string(k) + " claims " + std::to_string(length) + " rows");
       uint32_t n_nodes, n_bufs;
       const size_t nodes = rb.vec(1, &n_nodes), bufs = rb.vec(2, &n_bufs);
       if (n_nodes != n_fields) bad("IPC file: record batch with " + std::to_string(n_nodes) + " field nodes for " + std::to_string(n_fields) + " columns");
@@ -247,6 +248,8 @@ void parse(const char* path, Parsed& P) {
          a.length = file.rd<int64_t>(nodes + 16 * (size_t) c);
          a.null_count = file.rd<int64_t>(nodes + 16 * (size_t) c + 8);
          if (a.length != length) bad("IPC file: column '" + cols[c].name + "' has " + std::to_string(a.length) + " rows in a batch of " + std::to_string(length));
+         if (a.null_count < -1 || a.null_count > length) bad("IPC file: column '" + cols[c].name + "' claims " + std::to_string(a.null_count) + " NULLs in " + std::to_string(length) + " rows");
+
          a.n_buffers = cols[c].n_buffers;
          b->bufs[c].resize((size_t) a.n_buffers);
          for (int j = 0; j < a.n_buffers; j++, bi++) {
@@ -256,24 +259,44 @@ void parse(const char* path, Parsed& P) {
             // how many bytes the column needs from this buffer (the register call reads exactly these)
             uint64_t need = 0;
             const std::string& f = cols[c].format;
+            if (j == 0 && a.null_count < 0) a.null_count = blen && length ? 1 : 0; // "unknown": a validity buffer, if there is one, decides (the register call counts)
             if (j == 0) need = a.null_count ? ((uint64_t) length + 7) / 8 : 0;
             else if (a.n_buffers == 3 && j == 1) need = ((uint64_t) length + 1) * (f == "U" ? 8 : 4);
             else if (a.n_buffers == 2) {
-               uint64_t w = f == "c" ? 1 : f == "s" ? 2 : (f == "i" || f == "f" || f == "tdD") ? 4 : (f == "l" || f == "g") ? 8 : f[0] == 'd' ? 16 : f[0] == 'w' ? (uint64_t) atoi(f.c_str() + 2) : 0;
+               const int64_t fw = f[0] == 'w' ? (int64_t) atoll(f.c_str() + 2) : 0;
+               if (f[0] == 'w' && (fw <= 0 || fw > 1 << 20)) bad("IPC file: fixed_size_binary column '" + cols[c].name + "' of width " + std::to_string(fw));
+               uint64_t w = f == "c" ? 1 : f == "s" ? 2 : (f == "i" || f == "f" || f == "tdD") ? 4 : (f == "l" || f == "g") ? 8 : f[0] == 'd' ? 16 : f[0] == 'w' ? (uint64_t) fw : 0;
                need = w * (uint64_t) length;
             }
-            if ((uint64_t) blen < need) bad("IPC file: buffer of column '" + cols[c].name + "' is shorter than its " + std::to_string(length) + " rows need");
+            // several Arrow writers emit a 0-byte offsets buffer for a zero-length array (RecordBatchFileReader accepts it)
+            const bool empty_offsets = a.n_buffers == 3 && j == 1 && length == 0 && blen == 0;
+            if ((uint64_t) blen < need && !empty_offsets) bad("IPC file: buffer of column '" + cols[c].name + "' is shorter than its " + std::to_string(length) + " rows need");
             b->bufs[c][(size_t) j] = blen == 0 || (j == 0 && a.null_count == 0) ? nullptr : body + bo;
-            if (a.n_buffers == 3 && j == 2 && length > 0) { // the last offset must stay inside the data buffer
+            if (empty_offsets) {
+               static const int64_t zero_offsets[2] = {0, 0};
+               b->bufs[c][1] = zero_offsets;
+            }
+            if (a.n_buffers == 3 && j == 2 && length > 0) { // every offset must stay inside the data buffer, in non-decreasing order
                const uint8_t* offs = body + file.rd<int64_t>(bufs + 16 * (size_t) (bi - 1));
-               int64_t last = 0;
-               if (f == "U") memcpy(&last, offs + 8 * (size_t) length, 8);
-               else {
-                  int32_t l32;
-                  memcpy(&l32, offs + 4 * (size_t) length, 4);
-                  last = l32;
+               const bool wide = f == "U";
+               auto at = [&](int64_t i) -> int64_t {
+                  if (wide) {
+                     int64_t v;
+                     memcpy(&v, offs + 8 * (size_t) i, 8);
+                     return v;
+                  }
+                  int32_t v;
+                  memcpy(&v, offs + 4 * (size_t) i, 4);
+                  return v;
+               };
+               int64_t prev = at(0);
+               if (prev < 0) bad("IPC file: negative string offset in column '" + cols[c].name + "'");
+               for (int64_t i = 1; i <= length; i++) {
+                  const int64_t cur = at(i);
+                  if (cur < prev) bad("IPC file: string offsets of column '" + cols[c].name + "' decrease at row " + std::to_string(i - 1));
+                  prev = cur;
                }
-               if (last < 0 || last > blen) bad("IPC file: string offsets of column '" + cols[c].name + "' exceed its data buffer");
+               if (prev > blen) bad("IPC file: string offsets of column '" + cols[c].name + "' exceed its data buffer");
                if (!b->bufs[c][2]) b->bufs[c][2] = body + bo; // an empty data buffer still needs a valid base
             }
          }
@@ -318,7 +341,7 @@ int32_t load(ldb_ctx* ctx, const char* name, const char* path, int32_t narrow, l
    Parsed P;
    parse(path, P);
    const int32_t rc = ldb_gpu_table_register(ctx, name, &P.top, P.bp.data(), (int64_t) P.bp.size(), narrow, out);
-   if (rc == LDB_OK) (void) hipStreamSynchronize(ctx->stream); // the copies read the mapping: finish them before it goes away
+   (void) hipStreamSynchronize(ctx->stream); // the copies read the mapping: finish them before it goes away (also after a failed registration: some were queued)
    return rc;
 }
 

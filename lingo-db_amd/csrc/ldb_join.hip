@@ -515,8 +515,7 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
          DJoin* dr;
          LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dr));
          hipLaunchKernelGGL(k_join_key_range, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dr, range);
-         LDB_HIP(hipMemcpyAsync(got, range, 16, hipMemcpyDeviceToHost, ctx->stream));
-         LDB_HIP(hipStreamSynchronize(ctx->stream));
+         LDB_TRY(LDB_READBACK(ctx, got, range, 16));
          ldb_dev_free(ctx, dr);
       }
       // DIRECT addressing when the key range is at most a few times the build rows (primary keys, and
@@ -557,9 +556,8 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
          LDB_HIP(hipGetLastError());
          uint64_t back[3] = {0, 0, 0}; // non-NULL keys, —, distinct keys
          uint32_t fl[2] = {0, 0};
-         LDB_HIP(hipMemcpyAsync(back, counter, 24, hipMemcpyDeviceToHost, ctx->stream));
-         LDB_HIP(hipMemcpyAsync(fl, dflags, 8, hipMemcpyDeviceToHost, ctx->stream));
-         LDB_HIP(hipStreamSynchronize(ctx->stream));
+         LDB_TRY(LDB_READBACK(ctx, back, counter, 24));
+         LDB_TRY(LDB_READBACK(ctx, fl, dflags, 8));
          ldb_dev_free(ctx, pop);
          ldb_dev_free(ctx, off);
          if (back[0] == back[2]) { // every non-NULL key set a bit of its own: unique
@@ -678,7 +676,9 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
       if (build->n_rows) LDB_TRY(launch_join(ctx, h, d, ldb_grid_for(ctx, build->n_rows, 256, 8), "k_join_build", "k_join_build_spec", k_join_build));
       ldb_dev_free(ctx, d);
       uint64_t f = 0;
-      LDB_TRY(ldb_read_u64(ctx, dflags, &f));
+      // open addressing: whether an insertion meets a long run depends on the order the insertions happened in — not a
+      // function of the data alone, so a prepared plan never replays this flag (one real wait per such build)
+      LDB_TRY(ldb_read_u64_at(ctx, dflags, &f, LDB_SITE, ht->direct ? 0 : LDB_RB_NEVER_REPLAY));
       if (ht->direct && (f & 1) && !ht->chained) { // duplicate keys in a direct table: chain them
          ht->chained = 1;
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) build->n_rows));
@@ -890,20 +890,11 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       LDB_HIP(hipGetLastError());
       uint64_t total = 0;
       LDB_TRY(ldb_read_u64(ctx, cnt, &total));
-      uint32_t *pop, *off, *sel;
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) (nbw ? nbw : 1)));
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) (nbw ? nbw : 1)));
+      uint32_t* sel;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &sel, 4 * (size_t) (total ? total : 1)));
-      if (nbw) {
-         hipLaunchKernelGGL(k_word_pop, dim3(ldb_grid_for(ctx, nbw, 256, 8)), dim3(256), 0, ctx->stream, bitmap, pop, (uint64_t) nbw);
-         LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, nbw, nullptr));
-         if (total) launch_bitmap_expand(ctx, bitmap, off, sel, nbw, total);
-      }
-      LDB_HIP(hipGetLastError());
+      if (nbw && total) LDB_TRY(ldb_bitmap_compact(ctx, bitmap, nbw, sel, total, nullptr, nullptr, nullptr));
       ldb_dev_free(ctx, flags);
       ldb_dev_free(ctx, bitmap);
-      ldb_dev_free(ctx, pop);
-      ldb_dev_free(ctx, off);
       return ldb_rel_select(ctx, ht->build, sel, (int64_t) total, out);
    }
    if (pairs && probe->sides.size() + ht->build->sides.size() > LDB_MAX_SIDES)
@@ -957,19 +948,10 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       }
       uint64_t total = 0;
       LDB_TRY(ldb_read_u64(ctx, counter, &total));
-      uint32_t *pop, *off, *sel;
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) (n_words ? n_words : 1)));
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) (n_words ? n_words : 1)));
+      uint32_t* sel;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &sel, 4 * (size_t) (total ? total : 1)));
-      if (n_words) {
-         hipLaunchKernelGGL(k_word_pop, dim3(ldb_grid_for(ctx, n_words, 256, 8)), dim3(256), 0, ctx->stream, bitmap, pop, (uint64_t) n_words);
-         LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, n_words, nullptr));
-         if (total) launch_bitmap_expand(ctx, bitmap, off, sel, n_words, total);
-      }
-      LDB_HIP(hipGetLastError());
+      if (n_words && total) LDB_TRY(ldb_bitmap_compact(ctx, bitmap, n_words, sel, total, nullptr, nullptr, nullptr));
       ldb_dev_free(ctx, bitmap);
-      ldb_dev_free(ctx, pop);
-      ldb_dev_free(ctx, off);
       return ldb_rel_select(ctx, probe, sel, (int64_t) total, out);
    }
 
@@ -999,20 +981,10 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       }
       if (kind == LDB_JOIN_INNER) {
          LDB_TRY(ldb_read_u64(ctx, counter, &produced));
-         uint32_t *pop, *off;
-         LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) (n_words ? n_words : 1)));
-         LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) (n_words ? n_words : 1)));
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &op, 4 * (size_t) (produced ? produced : 1)));
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &ob, 4 * (size_t) (produced ? produced : 1)));
-         if (n_words && produced) {
-            hipLaunchKernelGGL(k_word_pop, dim3(ldb_grid_for(ctx, n_words, 256, 8)), dim3(256), 0, ctx->stream, bitmap, pop, (uint64_t) n_words);
-            LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, n_words, nullptr));
-            launch_bitmap_expand(ctx, bitmap, off, op, n_words, produced);
-            hipLaunchKernelGGL(k_compose_null, dim3(ldb_grid_for(ctx, (int64_t) produced, 256, 8)), dim3(256), 0, ctx->stream, (const uint32_t*) match, (const uint32_t*) op, ob, produced);
-         }
-         LDB_HIP(hipGetLastError());
-         ldb_dev_free(ctx, pop);
-         ldb_dev_free(ctx, off);
+         // matched probe rows in ascending order + the build row of each, in one launch
+         if (n_words && produced) LDB_TRY(ldb_bitmap_compact(ctx, bitmap, n_words, op, produced, match, ob, nullptr));
          ldb_dev_free(ctx, bitmap);
          ldb_dev_free(ctx, match);
       } else { // LEFT_OUTER / SINGLE: exactly one output row per probe row

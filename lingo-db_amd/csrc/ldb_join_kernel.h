@@ -835,6 +835,7 @@ __device__ __forceinline__ void join_probe_pairs_body(const DJoin& m, const DJoi
    const uint32_t* chunk_off = gptr<uint32_t>(d->match);
    uint32_t* out_probe = gptr_mut<uint32_t>(d->out_probe);
    uint32_t* out_build = gptr_mut<uint32_t>(d->out_build);
+   const uint64_t out_cap = d->out_cap; // (= the count pass's total; smaller only when that total was a replayed one that no longer holds: never write past the buffers)
    for (uint64_t w0 = wave * JP_U; w0 < n_chunks; w0 += n_waves * JP_U) {
       uint64_t rows[JP_U], at[JP_U];
       bool act[JP_U];
@@ -858,14 +859,16 @@ __device__ __forceinline__ void join_probe_pairs_body(const DJoin& m, const DJoi
       }
       uint32_t again[JP_U];
       d_probe_batch<JP_U>(m, d, rows, act, again, [&](int u, uint32_t brow) {
-         out_probe[at[u] + emitted[u]] = (uint32_t) rows[u];
-         out_build[at[u] + emitted[u]] = brow;
+         if (at[u] + emitted[u] < out_cap) {
+            out_probe[at[u] + emitted[u]] = (uint32_t) rows[u];
+            out_build[at[u] + emitted[u]] = brow;
+         }
          emitted[u]++;
          return m.kind != LDB_JOIN_SINGLE;
       });
 #pragma unroll
       for (int u = 0; u < JP_U; u++) {
-         if (act[u] && emitted[u] == 0) { // unmatched (or NULL-key) probe row of an outer join
+         if (act[u] && emitted[u] == 0 && at[u] < out_cap) { // unmatched (or NULL-key) probe row of an outer join
             out_probe[at[u]] = (uint32_t) rows[u];
             out_build[at[u]] = LDB_NULL_ROW;
          }

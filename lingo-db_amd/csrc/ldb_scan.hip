@@ -86,7 +86,7 @@ bool ldb_scan_jit_check(std::string* log) {
 // Expand the bitmap into ascending row ids.  Each wave walks its words; the lane whose bit is
 // set writes its row id at block_offset + (#set bits in earlier words) + rank within the word.
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_expand(const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ block_offsets,
-                                                            uint32_t* __restrict__ out_rows, uint64_t n_rows) {
+                                                            uint32_t* __restrict__ out_rows, uint64_t n_rows, uint64_t cap) {
    __shared__ uint32_t s_pop[SCAN_WORDS_PER_BLOCK];
    const uint64_t word0 = (uint64_t) blockIdx.x * SCAN_WORDS_PER_BLOCK;
    const uint64_t n_words = (n_rows + 63) / 64;
@@ -102,15 +102,21 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_expand(const uint64_t* __re
       __syncthreads();
    }
    uint32_t excl = s_pop[threadIdx.x] - own;
+   const uint32_t block_total = s_pop[SCAN_WORDS_PER_BLOCK - 1];
    __syncthreads();
    s_pop[threadIdx.x] = excl;
    __syncthreads();
    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
    const uint32_t base = block_offsets[blockIdx.x];
+   // entries behind the real count (cap is larger only when it came from a replayed count that no longer holds) must
+   // still be row numbers: the consumer is already queued
+   if (blockIdx.x == gridDim.x - 1)
+      for (uint64_t i = (uint64_t) base + block_total + threadIdx.x; i < cap; i += SCAN_BLOCK) out_rows[i] = 0;
    for (uint32_t w = wave; w < SCAN_WORDS_PER_BLOCK; w += SCAN_BLOCK / LDB_WAVE) {
       if (word0 + w >= n_words) break;
       uint64_t m = bitmap[word0 + w]; // wave-uniform
-      if ((m >> lane) & 1) out_rows[base + s_pop[w] + d_rank_in(m)] = (uint32_t) ((word0 + w) * 64 + lane);
+      const uint64_t at = (uint64_t) base + s_pop[w] + d_rank_in(m);
+      if (((m >> lane) & 1) && at < cap) out_rows[at] = (uint32_t) ((word0 + w) * 64 + lane); // (cap = the host's count; see ldb_readback)
    }
 }
 
@@ -186,7 +192,7 @@ static int32_t scan_run_with(ldb_ctx* ctx, int64_t n, LAUNCH launch, uint32_t** 
    uint64_t total = 0;
    LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &total));
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &sel, sizeof(uint32_t) * (size_t) (total ? total : 1)));
-   if (total) hipLaunchKernelGGL(k_scan_expand, dim3((unsigned) n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, bitmap, offsets, sel, (uint64_t) n);
+   if (total) hipLaunchKernelGGL(k_scan_expand, dim3((unsigned) n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, bitmap, offsets, sel, (uint64_t) n, total);
    LDB_HIP(hipGetLastError());
    ldb_dev_free(ctx, bitmap);
    ldb_dev_free(ctx, counts);

@@ -130,16 +130,14 @@ static int32_t table_concat(ldb_ctx* ctx, const ldb_table* a, const ldb_table* b
          int64_t a_first = 0, a_bytes = 0, b_first = 0, b_bytes = 0;
          if (na) {
             int64_t e[2];
-            LDB_HIP(hipMemcpyAsync(&e[0], ca.offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
-            LDB_HIP(hipMemcpyAsync(&e[1], ca.offsets + na, 8, hipMemcpyDeviceToHost, ctx->stream));
-            LDB_HIP(hipStreamSynchronize(ctx->stream));
+            LDB_TRY(LDB_READBACK(ctx, &e[0], ca.offsets, 8));
+            LDB_TRY(LDB_READBACK(ctx, &e[1], ca.offsets + na, 8));
             a_first = e[0], a_bytes = e[1] - e[0];
          }
          if (nb) {
             int64_t e[2];
-            LDB_HIP(hipMemcpyAsync(&e[0], cb.offsets, 8, hipMemcpyDeviceToHost, ctx->stream));
-            LDB_HIP(hipMemcpyAsync(&e[1], cb.offsets + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
-            LDB_HIP(hipStreamSynchronize(ctx->stream));
+            LDB_TRY(LDB_READBACK(ctx, &e[0], cb.offsets, 8));
+            LDB_TRY(LDB_READBACK(ctx, &e[1], cb.offsets + nb, 8));
             b_first = e[0], b_bytes = e[1] - e[0];
          }
          if (a_bytes) LDB_HIP(hipMemcpyAsync(dst.values, (const char*) ca.values + a_first, (size_t) a_bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -542,8 +540,7 @@ extern "C" int32_t ldb_gpu_window(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* p
                             d_nulls + v);
       }
       std::vector<unsigned long long> nulls(vf.size(), 0);
-      LDB_HIP(hipMemcpyAsync(nulls.data(), d_nulls, 8 * vf.size(), hipMemcpyDeviceToHost, ctx->stream));
-      LDB_HIP(hipStreamSynchronize(ctx->stream));
+      LDB_TRY(LDB_READBACK(ctx, nulls.data(), d_nulls, 8 * vf.size()));
       for (size_t v = 0; v < vf.size(); v++) {
          ldb_column& oc = res.t->cols[(size_t) vf[v]];
          oc.null_count = (int64_t) nulls[v];

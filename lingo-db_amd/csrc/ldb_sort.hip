@@ -293,11 +293,12 @@ __global__ void k_sel_flags(const uint64_t* __restrict__ keys, int words, uint64
       }
    }
 }
-__global__ void k_sel_expand(const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ off, uint32_t* __restrict__ out, uint64_t n_words) {
+__global__ void k_sel_expand(const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ off, uint32_t* __restrict__ out, uint64_t n_words, uint64_t cap) {
    const uint32_t lane = threadIdx.x & 63;
    for (uint64_t w = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6; w < n_words; w += ((uint64_t) gridDim.x * blockDim.x) >> 6) {
       uint64_t mask = bitmap[w];
-      if ((mask >> lane) & 1) out[off[w] + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t) (w * 64 + lane);
+      const uint64_t at = (uint64_t) off[w] + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+      if (((mask >> lane) & 1) && at < cap) out[at] = (uint32_t) (w * 64 + lane);
    }
 }
 
@@ -315,8 +316,7 @@ static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint6
       LDB_HIP(hipMemcpyAsync(d_bits, init.data(), 16 * (size_t) words, hipMemcpyHostToDevice, ctx->stream));
       // few blocks: every wave ends in two same-address atomics (≈10 ns each when contended)
       hipLaunchKernelGGL(k_key_bits, dim3(std::min(grid, 64), words), dim3(256), 0, ctx->stream, keys, words, n, d_bits);
-      LDB_HIP(hipMemcpyAsync(bits.data(), d_bits, 16 * (size_t) words, hipMemcpyDeviceToHost, ctx->stream));
-      LDB_HIP(hipStreamSynchronize(ctx->stream));
+      LDB_TRY(LDB_READBACK(ctx, bits.data(), d_bits, 16 * (size_t) words));
       ldb_dev_free(ctx, d_bits);
       for (int w = 0; w < words; w++) varmask[(size_t) w] = bits[(size_t) w] ^ bits[(size_t) (words + w)];
    }
@@ -338,7 +338,7 @@ static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint6
       h_state.rank = k ? k - 1 : 0;
       SelState* state;
       uint32_t* hist;
-      LDB_TRY(ldb_dev_upload(ctx, &h_state, sizeof(h_state), (void**) &state));
+      LDB_TRY(ldb_dev_upload(ctx, &h_state, sizeof(h_state), (void**) &state, false)); // (k_sel_pick updates it)
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &hist, 4 * 256));
       LDB_HIP(hipMemsetAsync(hist, 0, 4 * 256, ctx->stream));
       for (int p = 0; p < n_pass; p++) {
@@ -356,7 +356,7 @@ static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint6
       LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, (int64_t) n_words, d_total));
       LDB_TRY(ldb_read_u64(ctx, d_total, &m));
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &perm, 4 * (size_t) (m ? m : 1)));
-      hipLaunchKernelGGL(k_sel_expand, dim3(grid), dim3(256), 0, ctx->stream, (const uint64_t*) bitmap, (const uint32_t*) off, perm, n_words);
+      hipLaunchKernelGGL(k_sel_expand, dim3(grid), dim3(256), 0, ctx->stream, (const uint64_t*) bitmap, (const uint32_t*) off, perm, n_words, (uint64_t) (m ? m : 1));
       LDB_HIP(hipGetLastError());
       ldb_dev_free(ctx, state);
       ldb_dev_free(ctx, hist);
@@ -405,9 +405,7 @@ static int32_t sort_perm(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, 
    unsigned long long chk[1 + SORT_MAX_SPECS] = {0};
    if (any_chk) {
       LDB_HIP(hipGetLastError());
-      LDB_HIP(hipMemcpyAsync(ctx->h_scratch, d_chk, sizeof(chk), hipMemcpyDeviceToHost, ctx->stream));
-      LDB_HIP(hipStreamSynchronize(ctx->stream));
-      memcpy(chk, ctx->h_scratch, sizeof(chk));
+      LDB_TRY(LDB_READBACK(ctx, chk, d_chk, sizeof(chk)));
       ldb_dev_free(ctx, d_chk);
       if (chk[0] & 1) LDB_FAIL(LDB_ERR_UNSUPPORTED, "sort: a key contains NULLs (nullable sort keys are not lowered to db.sort_compare)");
    }
@@ -492,8 +490,7 @@ extern "C" int32_t ldb_gpu_partition(ldb_ctx* ctx, ldb_rel* in, const ldb_colref
    // stable counting sort on the partition id (<= 8 bits → two 4-bit passes)
    LDB_TRY(radix_sort_perm(ctx, ids, 1, &perm, n, 0, 0, 0, nparts > 16 ? 8 : 4, nullptr));
    std::vector<unsigned long long> hh(256);
-   LDB_HIP(hipMemcpyAsync(hh.data(), hist, 8 * 256, hipMemcpyDeviceToHost, ctx->stream));
-   LDB_HIP(hipStreamSynchronize(ctx->stream));
+   LDB_TRY(LDB_READBACK(ctx, hh.data(), hist, 8 * 256));
    for (int p = 0; p < nparts; p++) counts[p] = (int64_t) hh[(size_t) p];
    ldb_dev_free(ctx, dk);
    ldb_dev_free(ctx, ids);

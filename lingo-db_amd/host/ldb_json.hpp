@@ -141,6 +141,7 @@ struct JParser {
       if (*p == '-' || isdigit((unsigned char) *p)) {
          const char* b = p;
          if (*p == '-') p++;
+         if (!isdigit((unsigned char) *p)) fail("digit expected after '-'");
          while (isdigit((unsigned char) *p)) p++;
          bool isInt = true;
          if (*p == '.' || *p == 'e' || *p == 'E') {
@@ -150,8 +151,12 @@ struct JParser {
          j.kind = J::NUM;
          j.isInt = isInt;
          std::string t(b, p);
-         if (isInt) j.inum = std::stoll(t);
-         j.num = std::stod(t);
+         try {
+            if (isInt) j.inum = std::stoll(t);
+            j.num = std::stod(t);
+         } catch (const std::exception&) {
+            fail("number out of range or malformed");
+         }
          return j;
       }
       fail("value expected");
@@ -166,13 +171,33 @@ struct JParser {
             switch (*p) {
                case 'n': out += '\n'; break;
                case 't': out += '\t'; break;
-               case 'u': { // \uXXXX (BMP only) → UTF-8
-                  unsigned cp = 0;
-                  for (int i = 1; i <= 4; i++) {
-                     if (!isxdigit((unsigned char) p[i])) fail("\\u needs four hex digits"); // (also stops at the NUL)
-                     cp = cp * 16 + (unsigned) (isdigit((unsigned char) p[i]) ? p[i] - '0' : (tolower(p[i]) - 'a' + 10));
-                  }
+               case 'r': out += '\r'; break;
+               case 'b': out += '\b'; break;
+               case 'f': out += '\f'; break;
+               case 'u': { // \uXXXX → UTF-8; a surrogate pair \uD8xx\uDCxx is one code point (4 bytes), a lone surrogate is an error
+                  auto hex4 = [&](const char* q) -> unsigned {
+                     unsigned v = 0;
+                     for (int i = 1; i <= 4; i++) {
+                        if (!isxdigit((unsigned char) q[i])) fail("\\u needs four hex digits"); // (also stops at the NUL)
+                        v = v * 16 + (unsigned) (isdigit((unsigned char) q[i]) ? q[i] - '0' : (tolower(q[i]) - 'a' + 10));
+                     }
+                     return v;
+                  };
+                  unsigned cp = hex4(p);
                   p += 4;
+                  if (cp >= 0xDC00 && cp <= 0xDFFF) fail("lone low surrogate in a string");
+                  if (cp >= 0xD800 && cp <= 0xDBFF) {
+                     if (p[1] != '\\' || p[2] != 'u') fail("high surrogate without its low surrogate");
+                     const unsigned lo = hex4(p + 2);
+                     if (lo < 0xDC00 || lo > 0xDFFF) fail("high surrogate without its low surrogate");
+                     p += 6;
+                     cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                     out += (char) (0xF0 | (cp >> 18));
+                     out += (char) (0x80 | ((cp >> 12) & 0x3F));
+                     out += (char) (0x80 | ((cp >> 6) & 0x3F));
+                     out += (char) (0x80 | (cp & 0x3F));
+                     break;
+                  }
                   if (cp < 0x80) out += (char) cp;
                   else if (cp < 0x800) {
                      out += (char) (0xC0 | (cp >> 6));

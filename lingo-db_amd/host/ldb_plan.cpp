@@ -883,6 +883,42 @@ thread_local std::string g_plan_json_err;
 
 } // namespace
 
+// ================================================================== prepared plans
+// A plan is static data, yet ldb_plan_run_json parses it, resolves every name and waits for the device after every
+// operator whose output size decides the next allocation.  ldb_plan_prepare parses once; ldb_plan_execute brackets the
+// interpretation with a read-back trace (lingodb_gpu.h, ldb_gpu_trace_*): the first execution over a set of input tables
+// records every count the operators read back, the following ones — same tables (ldb_gpu_table_stamp), same options
+// (ldb_gpu_option_epoch) — replay them, so that the whole plan is issued without one wait and checked once at the end.  A
+// check that fails (LDB_TRACE_MISSED / LDB_ERR_RETRY: something the key does not cover changed) discards the execution and
+// repeats it recording.  The descriptors of a repeated execution are byte-identical to the previous one's and are served
+// from the context's descriptor cache (no upload).  Reference shape: the query is compiled once and run as one main()
+// (src/execution/LLVMBackends.cpp:856-865), a pipeline never returns to the driver between its operators
+// (SubOpToControlFlow.cpp:1123-1202).
+struct ldb_plan {
+   ldb_ctx* ctx = nullptr;
+   J doc;
+   ldb_trace* trace = nullptr;
+   std::vector<uint64_t> key; // what the trace was recorded under: per input (stamp, rows), option epoch, exchange or not
+   int64_t executions = 0, replays = 0, misses = 0;
+};
+
+namespace {
+int32_t runParsed(ldb_ctx* ctx, ldb_comm* comm, const J& plan, const char* const* table_names, const ldb_table* const* tables, int32_t n_tables, ldb_table** result) {
+   try {
+      Interp in(ctx);
+      in.comm = comm;
+      in.run(plan, table_names, tables, n_tables);
+      Value& r = in.val(in.result);
+      if (r.kind != Value::TABLE || !r.owned) throw std::runtime_error("plan: result '" + in.result + "' must be a table produced by the plan");
+      *result = const_cast<ldb_table*>(r.table);
+      return LDB_OK;
+   } catch (const std::exception& e) { // (an operator that met a wrong replayed count fails with LDB_ERR_RETRY: the trace's end reports it)
+      g_plan_json_err = e.what();
+      return LDB_ERR_INVALID;
+   }
+}
+} // namespace
+
 // Run a JSON plan over the named input tables; *result = the table named by the plan's "result".
 extern "C" int32_t ldb_plan_run_json(ldb_ctx* ctx, const char* plan_json, const char* const* table_names, const ldb_table* const* tables, int32_t n_tables, ldb_table** result) {
    return ldb_plan_run_json_comm(ctx, nullptr, plan_json, table_names, tables, n_tables, result);
@@ -898,17 +934,92 @@ extern "C" int32_t ldb_plan_run_json_comm(ldb_ctx* ctx, ldb_comm* comm, const ch
    try {
       JParser parser(plan_json);
       const J plan = parser.value();
-      Interp in(ctx);
-      in.comm = comm;
-      in.run(plan, table_names, tables, n_tables);
-      Value& r = in.val(in.result);
-      if (r.kind != Value::TABLE || !r.owned) throw std::runtime_error("plan: result '" + in.result + "' must be a table produced by the plan");
-      *result = const_cast<ldb_table*>(r.table);
+      return runParsed(ctx, comm, plan, table_names, tables, n_tables, result);
+   } catch (const std::exception& e) {
+      g_plan_json_err = e.what();
+      return LDB_ERR_INVALID;
+   }
+}
+extern "C" int32_t ldb_plan_prepare(ldb_ctx* ctx, const char* plan_json, ldb_plan** out) {
+   if (!ctx || !plan_json || !out) {
+      g_plan_json_err = "plan_prepare: bad argument";
+      return LDB_ERR_INVALID;
+   }
+   try {
+      auto p = std::make_unique<ldb_plan>();
+      p->ctx = ctx;
+      JParser parser(plan_json);
+      p->doc = parser.value();
+      if (p->doc.kind != J::OBJ) throw std::runtime_error("plan: the top level must be an object");
+      (void) p->doc.at("steps");
+      if (ldb_gpu_trace_create(ctx, &p->trace) != LDB_OK) throw std::runtime_error(ldb_gpu_last_error());
+      *out = p.release();
       return LDB_OK;
    } catch (const std::exception& e) {
       g_plan_json_err = e.what();
       return LDB_ERR_INVALID;
    }
+}
+extern "C" int32_t ldb_plan_release(ldb_plan* p) {
+   if (!p) return LDB_OK;
+   if (p->trace) ldb_gpu_trace_destroy(p->ctx, p->trace);
+   delete p;
+   return LDB_OK;
+}
+extern "C" int32_t ldb_plan_execute(ldb_plan* p, ldb_comm* comm, const char* const* table_names, const ldb_table* const* tables, int32_t n_tables, ldb_table** result) {
+   if (!p || !result || n_tables < 0 || (n_tables && (!table_names || !tables))) {
+      g_plan_json_err = "plan_execute: bad argument";
+      return LDB_ERR_INVALID;
+   }
+   std::vector<uint64_t> key;
+   for (int32_t i = 0; i < n_tables; i++) {
+      key.push_back(ldb_gpu_table_stamp(tables[i]));
+      key.push_back((uint64_t) ldb_gpu_table_rows(tables[i]));
+   }
+   key.push_back((uint64_t) ldb_gpu_option_epoch());
+   key.push_back(comm ? 1 : 0);
+   // replay only over the very inputs the trace was recorded on.  With a communicator every rank would have to reach the
+   // same verdict before any of them repeats its collectives: exchanges are recorded, never replayed (yet)
+   const bool replay = !comm && key == p->key;
+   for (int attempt = 0; attempt < 2; attempt++) {
+      if (ldb_gpu_trace_begin(p->ctx, p->trace, replay && attempt == 0 ? 1 : 0) != LDB_OK) {
+         g_plan_json_err = ldb_gpu_last_error();
+         return LDB_ERR_INVALID;
+      }
+      ldb_table* out = nullptr;
+      const int32_t st = runParsed(p->ctx, comm, p->doc, table_names, tables, n_tables, &out);
+      int32_t status = LDB_TRACE_OFF;
+      if (ldb_gpu_trace_end(p->ctx, &status) != LDB_OK) {
+         if (out) ldb_gpu_table_release(p->ctx, out);
+         g_plan_json_err = ldb_gpu_last_error();
+         return LDB_ERR_HIP;
+      }
+      p->executions++;
+      if (status == LDB_TRACE_MISSED) { // a replayed count was wrong: everything computed from it is void
+         if (out) ldb_gpu_table_release(p->ctx, out);
+         p->misses++;
+         p->key.clear();
+         continue;
+      }
+      if (st != LDB_OK) {
+         p->key.clear();
+         return st;
+      }
+      if (status == LDB_TRACE_REPLAYED) p->replays++;
+      p->key = key;
+      *result = out;
+      return LDB_OK;
+   }
+   g_plan_json_err = "plan_execute: the execution could not be completed after a failed replay";
+   return LDB_ERR_INVALID;
+}
+extern "C" int32_t ldb_plan_stats(const ldb_plan* p, int64_t* executions, int64_t* replays, int64_t* misses, int64_t* readbacks) {
+   if (!p) return LDB_ERR_INVALID;
+   if (executions) *executions = p->executions;
+   if (replays) *replays = p->replays;
+   if (misses) *misses = p->misses;
+   if (readbacks) ldb_gpu_trace_stats(p->trace, readbacks, nullptr, nullptr, nullptr);
+   return LDB_OK;
 }
 extern "C" const char* ldb_plan_json_last_error(void) { return g_plan_json_err.c_str(); }
 

@@ -555,15 +555,58 @@ def translate_subop_dump(dump, name="subop_dump"):
     return buf.value.decode(), report
 
 
+class PreparedPlan:
+    """ldb_plan_prepare / ldb_plan_execute (libldb_host.so)"""
+
+    def __init__(self, ctx, text):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        st = capi.host_lib().ldb_plan_prepare(ctx.h, text.encode(), C.byref(self.h))
+        if st != capi.LDB_OK:
+            raise capi.LdbError(st, capi.host_lib().ldb_plan_json_last_error().decode(errors="replace"))
+        ctx._plans.add(self)
+
+    def execute(self, tables, comm=None):
+        names = list(tables)
+        narr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        tarr = (C.c_void_p * len(names))(*[tables[n].h for n in names])
+        t = C.c_void_p()
+        st = capi.host_lib().ldb_plan_execute(self.h, comm.h if comm is not None else None, narr, tarr, len(names), C.byref(t))
+        if st != capi.LDB_OK:
+            raise capi.LdbError(st, capi.host_lib().ldb_plan_json_last_error().decode(errors="replace"))
+        return Table(self.ctx, t)
+
+    def stats(self):
+        v = [C.c_int64() for _ in range(4)]
+        capi.host_lib().ldb_plan_stats(self.h, *[C.byref(x) for x in v])
+        return dict(zip(("executions", "replays", "misses", "readbacks"), (x.value for x in v)))
+
+    def release(self):
+        if self.h and self.ctx.h:
+            capi.host_lib().ldb_plan_release(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class Context:
     def __init__(self, device=0, stream=None):
         self.lib = capi.gpu_lib()
         h = C.c_void_p()
         check(self.lib.ldb_gpu_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
         self.h = h
+        import weakref
+
+        self._plans = weakref.WeakSet()  # prepared plans hold a trace of this context: released before it
 
     def close(self):
         if self.h:
+            for p in list(self._plans):
+                p.release()
             self.lib.ldb_gpu_ctx_destroy(self.h)
             self.h = None
 
@@ -717,6 +760,23 @@ class Context:
         if st != capi.LDB_OK:
             raise capi.LdbError(st, capi.host_lib().ldb_plan_json_last_error().decode(errors="replace"))
         return Table(self, t)
+
+    def prepare_plan(self, plan):
+        """parses a JSON plan once (ldb_plan_prepare); PreparedPlan.execute runs it — from the second execution over the same
+        tables without a host wait between operators and without descriptor uploads"""
+        import os
+
+        text = plan
+        if not plan.lstrip().startswith("{"):
+            path = plan if os.path.exists(plan) else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plans", plan)
+            with open(path) as f:
+                text = f.read()
+        return PreparedPlan(self, text)
+
+    def desc_cache_stats(self):
+        h, m, b = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.lib.ldb_gpu_desc_cache_stats(self.h, C.byref(h), C.byref(m), C.byref(b)))
+        return {"hits": h.value, "misses": m.value, "bytes": b.value}
 
     def run_subop_dump(self, dump, tables, name="subop_dump", comm=None):
         """runs a query from the reference's sub-operator dump (tools/ct/mlir-subop-to-json.cpp output, text or path):

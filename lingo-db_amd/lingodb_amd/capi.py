@@ -236,6 +236,14 @@ GPU_API = {
     "ldb_gpu_allgather": (i32, [P, P, P, C.c_char_p, PP]),
     "ldb_gpu_alltoall": (i32, [P, P, P, C.POINTER(i64), C.c_char_p, PP]),
     "ldb_gpu_shuffle": (i32, [P, P, P, C.POINTER(ColRef), i32, C.POINTER(ColRef), i32, C.c_char_p, PP]),
+    "ldb_gpu_option_epoch": (i64, []),
+    "ldb_gpu_trace_create": (i32, [P, PP]),
+    "ldb_gpu_trace_destroy": (i32, [P, P]),
+    "ldb_gpu_trace_begin": (i32, [P, P, i32]),
+    "ldb_gpu_trace_end": (i32, [P, C.POINTER(i32)]),
+    "ldb_gpu_trace_stats": (i32, [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "ldb_gpu_desc_cache_stats": (i32, [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "ldb_gpu_table_stamp": (u64, [P]),
     # include/ldb_tpchgen.h (device generator)
     "ldb_gpu_tpch_generate": (i32, [P, i32, i64, i32, i32, u64, i32, PP]),
 }
@@ -247,6 +255,10 @@ HOST_API = {
     "ldb_plan_run_json": (i32, [P, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(P), i32, PP]),
     "ldb_plan_run_json_comm": (i32, [P, P, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(P), i32, PP]),
     "ldb_plan_json_last_error": (C.c_char_p, []),
+    "ldb_plan_prepare": (i32, [P, C.c_char_p, PP]),
+    "ldb_plan_execute": (i32, [P, P, C.POINTER(C.c_char_p), C.POINTER(P), i32, PP]),
+    "ldb_plan_release": (i32, [P]),
+    "ldb_plan_stats": (i32, [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "ldb_plan_json_check": (i32, [C.c_char_p, C.POINTER(C.c_char_p), i32]),
     "ldb_subop_translate": (i32, [C.c_char_p, C.c_char_p, C.c_char_p, i64, C.POINTER(i64)]),
     "ldb_subop_last_error": (C.c_char_p, []),

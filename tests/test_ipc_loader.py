@@ -112,3 +112,30 @@ def test_unsupported_and_malformed_files_are_rejected(tmp_path):
             assert e2.status in (capi.LDB_ERR_INVALID, capi.LDB_ERR_UNSUPPORTED)
     assert lib.ldb_gpu_ipc_describe(None, None, 0) == capi.LDB_ERR_INVALID
     assert err(tmp_path / "missing.arrow").status == capi.LDB_ERR_INVALID
+
+
+def test_string_offsets_are_checked_row_by_row_and_zero_row_batches_load(tmp_path):
+    """(round-3 ADVICE) every utf8 offset is validated on the host — negative, decreasing or past the data buffer —
+    not just the last one; a zero-row batch (whatever offsets buffer its writer emitted) is accepted"""
+    t = pa.table({"s": pa.array(["aa", "bbb", "", "cccc", "dd"], pa.string()), "k": pa.array(range(5), pa.int32())})
+    write_ipc(tmp_path / "s.arrow", t)
+    raw = bytearray((tmp_path / "s.arrow").read_bytes())
+    want = (0).to_bytes(4, "little") + (2).to_bytes(4, "little") + (5).to_bytes(4, "little") + (5).to_bytes(4, "little") + (9).to_bytes(4, "little") + (11).to_bytes(4, "little")
+    at = bytes(raw).find(want)
+    assert at > 0, "offsets buffer not found in the file body"
+    assert api.describe_ipc(tmp_path / "s.arrow")["rows"] == 5
+    for row, bad in ((1, 7), (2, 1), (0, -1), (5, 1 << 20)):  # not monotonic (twice), negative, beyond the data
+        b = bytearray(raw)
+        b[at + 4 * row : at + 4 * row + 4] = int(bad).to_bytes(4, "little", signed=True)
+        (tmp_path / "bad.arrow").write_bytes(bytes(b))
+        with pytest.raises(capi.LdbError) as e:
+            api.describe_ipc(tmp_path / "bad.arrow")
+        assert e.value.status == capi.LDB_ERR_INVALID and "offset" in str(e.value), (row, bad, str(e.value))
+    # zero-row batches between ordinary ones
+    with pa.OSFile(str(tmp_path / "z.arrow"), "wb") as f:
+        with pa.ipc.new_file(f, t.schema) as w:
+            w.write_batch(t.to_batches()[0])
+            w.write_batch(t.slice(0, 0).to_batches()[0] if t.slice(0, 0).to_batches() else pa.RecordBatch.from_arrays([pa.array([], pa.string()), pa.array([], pa.int32())], schema=t.schema))
+            w.write_batch(t.to_batches()[0])
+    d = api.describe_ipc(tmp_path / "z.arrow")
+    assert d["batches"] == [5, 0, 5] and d["rows"] == 10

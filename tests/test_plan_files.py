@@ -57,10 +57,19 @@ def test_structure_check_names_what_is_wrong():
         ('{"steps": [], "result": "x\\', "unterminated escape"),  # a text ending inside an escape must not be read past its end
         ('{"steps": [], "result": "\\u12G4"}', "four hex digits"),
         ('{"steps": [], "result": "\\u12', "four hex digits"),
+        ('{"steps": [], "result": "x", "n": -}', "digit expected"),  # (was: std::stoll's own exception text)
+        ('{"steps": [], "result": "x", "n": 99999999999999999999999}', "out of range"),
+        ('{"steps": [], "result": "\\ud83d"}', "surrogate"),  # a lone high surrogate
+        ('{"steps": [], "result": "\\udc00x"}', "surrogate"),  # a lone low surrogate
     ]
     for text, needle in cases:
         st, err = _check(text, ["t"])
         assert st != 0 and needle in err, (text, err)
+    # \r \b \f decode to the control characters and a surrogate pair to ONE code point (4 bytes of UTF-8): the value named
+    # "a\r\U0001F600" below is found again under exactly that name
+    good = '{"steps": [{"op": "filter", "in": "t", "out": "a\\r\\ud83d\\ude00", "preds": []}, {"op": "materialize", "in": "a\\u000d\U0001F600", "cols": [], "out": "r"}], "result": "r"}'
+    st, err = _check(good, ["t"])
+    assert st == 0, err
 
 
 def test_database_generates_every_column_a_plan_names():

@@ -167,6 +167,8 @@ class Runner:
         self.cache = {}  # replicated dimension tables of the sharded plans: all-gathered once per database
         self.plans = {}
         self.meta = {}
+        self.prepared = {}  # q -> api.PreparedPlan (ldb_plan_prepare: parsed once, later executions replay their read-back trace)
+        self.prepared_on = os.environ.get("LDB_BENCH_PREPARED", "1") != "0"
 
     def sharded(self):
         return self.world > 1 or self.force_dist
@@ -176,7 +178,12 @@ class Runner:
             raise ValueError(f"TPC-H Q{q} has no plan")
         if self.world > 1 and self.comm is None:
             raise RuntimeError("world > 1 needs a communicator (api.Comm)")
-        res = self.ctx.run_plan(self.plan_text(q), self.plan_inputs(q), comm=self.comm)
+        if self.prepared_on:
+            if q not in self.prepared:
+                self.prepared[q] = self.ctx.prepare_plan(self.plan_text(q))
+            res = self.prepared[q].execute(self.plan_inputs(q), comm=self.comm)
+        else:
+            res = self.ctx.run_plan(self.plan_text(q), self.plan_inputs(q), comm=self.comm)
         self.last[q] = res
         return res
 
