@@ -160,6 +160,11 @@ def main():
     results = {}
     kernel_ms = {}  # (query, kernel) -> [launches, ms]
     kernel_max = {}  # (query, kernel) -> longest single launch, ms
+    # exchange per query (world > 1): ctx-stream time of the transfer groups, bytes this rank sent to other ranks, and what its
+    # busiest peer link carried (ldb_gpu_comm_stats) — zeros at N = 1
+    exch = {q: {"groups": 0, "bytes_out": 0, "max_peer_bytes_out": 0, "device_ms": 0.0, "host_ms": 0.0} for q in queries}
+    if comm is not None:
+        comm.stats(reset=True)
     ctx.prof_reset()
     barrier()
     t0 = time.perf_counter()
@@ -170,6 +175,10 @@ def main():
             ctx.timer_stop(timers[q])
             q_runs[q].append(ctx.timer_ms(timers[q]))
             q_ms[q] += q_runs[q][-1]
+            if comm is not None:
+                st = comm.stats(reset=True)
+                for k in exch[q]:
+                    exch[q][k] += st[k]
             for k, (n, ms) in ctx.prof_all().items():
                 e = kernel_ms.setdefault((q, k), [0, 0.0])
                 e[0] += n
@@ -189,6 +198,19 @@ def main():
         t = torch.tensor([per_query[q] for q in queries], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         per_query = {q: float(v) for q, v in zip(queries, t.tolist())}
+
+    # exchange, reduced over the ranks: time and the busiest link are the maximum (the step waits for the slowest rank), bytes the sum
+    ex_ms = [exch[q]["device_ms"] / args.steps for q in queries]
+    ex_host = [exch[q]["host_ms"] / args.steps for q in queries]
+    ex_peer = [exch[q]["max_peer_bytes_out"] / args.steps for q in queries]
+    ex_out = [exch[q]["bytes_out"] / args.steps for q in queries]
+    if world > 1:
+        tm = torch.tensor([ex_ms, ex_host, ex_peer], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ex_ms, ex_host, ex_peer = tm.tolist()
+        ts = torch.tensor(ex_out, device=red_dev, dtype=torch.float64)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        ex_out = ts.tolist()
 
     out = None
     if rank == 0:
@@ -215,7 +237,7 @@ def main():
             if n6:
                 t6 = ms6 / n6 * 1e-3
                 extras["scan_q6"] = {"kernel_ms": round(ms6 / n6, 4), "rows_per_s_G": round(rows_local / t6 / 1e9, 1)}
-                pmc6 = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_q6_sf%g.json" % (r, args.sf)) for r in (3, 2, 1)) if os.path.exists(p)), None)
+                pmc6 = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_q6_sf%g.json" % (r, args.sf)) for r in (4, 3, 2, 1)) if os.path.exists(p)), None)
                 if world == 1 and pmc6:
                     with open(pmc6) as f:
                         k6 = json.load(f)["kernels"]
@@ -229,7 +251,7 @@ def main():
             # command; tools/pmc_summary.py).  Counters cannot be read from inside the timed process, so the committed
             # summary of the matching configuration is quoted; null when there is none.
             tag = "_narrow" if args.narrow_decimals else ""
-            pmc_path = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_q%d_sf%g%s.json" % (r, roof_q, args.sf, tag)) for r in (3, 2, 1)) if os.path.exists(p)), None)
+            pmc_path = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_q%d_sf%g%s.json" % (r, roof_q, args.sf, tag)) for r in (4, 3, 2, 1)) if os.path.exists(p)), None)
             if world == 1 and pmc_path:
                 with open(pmc_path) as f:
                     pmc = json.load(f)
@@ -296,12 +318,38 @@ def main():
         # all kernels, helpers included: Σ kernel durations ÷ wall span per query from a rocprofv3 kernel trace of the
         # same plans on the same data (tools/query_timeline.py + tools/timeline_summary.py; profile, not this run)
         gpu_busy = None
-        tl_path = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_query_timeline_sf%g.json" % (r, args.sf)) for r in (3, 2)) if os.path.exists(p)), None)
+        tl_path = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_query_timeline_sf%g.json" % (r, args.sf)) for r in (4, 3, 2)) if os.path.exists(p)), None)
         if world == 1 and tl_path:
             with open(tl_path) as f:
                 tl = json.load(f)
             gpu_busy = {"share": tl["total"]["busy_share"], "busy_ms": tl["total"]["busy"], "span_ms": tl["total"]["span"], "source": os.path.relpath(tl_path, ROOT)}
+        # exchange summary: per query the ctx-stream time of its transfer groups, the bytes that left the ranks, and the rate of the
+        # busiest peer link (every peer pair of one MI355X node has its own xGMI link, ≈ 153 GB/s)
+        XGMI_LINK_GBS = 153.0
+        ex_q = {}
+        for i, q in enumerate(queries):
+            link = ex_peer[i] / (ex_ms[i] * 1e-3) / 1e9 if ex_ms[i] > 0 else 0.0
+            ex_q["Q%d" % q] = {"exchange_ms": round(ex_ms[i], 4), "exchange_host_ms": round(ex_host[i], 4), "exchange_bytes_out": int(ex_out[i]), "exchange_bytes_out_max_peer": int(ex_peer[i]),
+                               "peer_link_gbs": round(link, 2), "xgmi_link_frac": round(link / XGMI_LINK_GBS, 4)}
+        exchange_out = {"transport": exchange, "xgmi_link_peak_gbs": XGMI_LINK_GBS, "exchange_ms_per_step": round(sum(ex_ms), 4), "exchange_bytes_out_per_step": int(sum(ex_out)),
+                        "per_query": ex_q if world > 1 else {"all": {"exchange_ms": 0.0, "exchange_bytes_out": 0, "exchange_bytes_out_max_peer": 0, "peer_link_gbs": 0.0, "xgmi_link_frac": 0.0}}}
+        plan_stats = runner.prepared_stats()
+        if roofline is not None:
+            roofline["more"] = more  # (inside `roofline` so that the driver's record of the line keeps the other kernels' fractions)
+        # key order: the driver's record keeps the standard keys + config / roofline / cpu_baseline and the LAST 2 000 characters of
+        # the line — bulky tables first, what must survive (exchange, per-query times) last
         out = {
+            "kernel_ms_per_step": {"Q%d:%s" % (q, k): round(v[1] / args.steps, 4) for (q, k), v in sorted(kernel_ms.items())},
+            "roofline_more": more,
+            "checks": checks,
+            "hbm_ceiling": ceiling,
+            "per_query_median_ms": {"Q%d" % q: round(sorted(q_runs[q])[len(q_runs[q]) // 2], 4) for q in queries},
+            "per_query_min_ms": {"Q%d" % q: round(min(q_runs[q]), 4) for q in queries},
+        }
+        if probe:
+            out["join_probe"] = probe
+        out.update(extras)
+        out.update({
             "metric": "tpch_sf%g_geomean_ms" % args.sf,
             "value": round(geomean([per_query[q] for q in queries]), 4),
             "unit": "ms",
@@ -318,24 +366,22 @@ def main():
                 args.sf, "+".join("Q%d" % q for q in queries), world), "queries": queries, "rows_lineitem_total": int(db.n_lineitem_total),
                 "narrow_decimals": bool(args.narrow_decimals), "device": info["name"], "exchange": exchange, "load_s": round(load_s, 3),
                 "plans": "lingo-db_amd/plans/tpch/%s*.json: hand-ordered operator plans (join orders, eager aggregation), not LingoDB's optimiser output" % ("dist/" if world > 1 else ""),
+                "execution": ("prepared plans (ldb_plan_prepare / ldb_plan_execute): parsed once; executions after the warm-up replay their read-back trace (no host wait between "
+                              "operators, one check at the end) and reuse cached descriptors" if runner.prepared_on else "ldb_plan_run_json per execution (LDB_BENCH_PREPARED=0)"),
+                "built_during_warmup": "outside the timed region, kept with the base tables like the reference's catalog statistics and persisted PK hash indexes "
+                                       "(LingoDBHashIndex): column min / max and sortedness, zone maps (kept where selective), utf8 dictionaries (at registration), hash indexes of "
+                                       "unique join_build steps over bare base tables (part, supplier, nation, region, customer, orders), hiprtc kernel variants, read-back traces",
                 "row_ids": "uint32: at most 4.29 G rows per GPU fragment"},
-            "per_query_ms": {"Q%d" % q: round(v, 4) for q, v in per_query.items()},
-            "per_query_median_ms": {"Q%d" % q: round(sorted(q_runs[q])[len(q_runs[q]) // 2], 4) for q in queries},
-            "per_query_min_ms": {"Q%d" % q: round(min(q_runs[q]), 4) for q in queries},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "prepared_plans": plan_stats,
             # share of the per-query time inside the operators' HIP-event-bracketed kernels (the main kernel of every
             # operator + the group-by finalisation; helper launches — scans, compactions, gathers — are not bracketed)
             "kernel_share": round(sum(v[1] for v in kernel_ms.values()) / max(sum(q_ms.values()), 1e-9), 4),
             "gpu_busy": gpu_busy,
-            "roofline_more": more,
-            "checks": checks,
-            "kernel_ms_per_step": {"Q%d:%s" % (q, k): round(v[1] / args.steps, 4) for (q, k), v in sorted(kernel_ms.items())},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-        }
-        out["hbm_ceiling"] = ceiling
-        if probe:
-            out["join_probe"] = probe
-        out.update(extras)
+            "exchange": exchange_out,
+            "per_query_ms": {"Q%d" % q: round(v, 4) for q, v in per_query.items()},
+        })
     barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)

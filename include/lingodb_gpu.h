@@ -602,6 +602,15 @@ int32_t ldb_gpu_comm_destroy(ldb_comm* comm);
 int32_t ldb_gpu_comm_rank(const ldb_comm* comm);
 int32_t ldb_gpu_comm_world(const ldb_comm* comm);
 const char* ldb_gpu_comm_transport(const ldb_comm* comm); /* "rccl" | "shm" */
+/* bytes and time of this rank's transfer groups since the last reset (transfers to / from other ranks only) */
+typedef struct {
+   int64_t groups; /* grouped batches of sends / receives (one metadata + one data batch per exchange) */
+   int64_t bytes_out, bytes_in;
+   int64_t max_peer_bytes_out; /* the busiest peer link of this rank */
+   double host_ms; /* host wall time inside the groups */
+   double device_ms; /* ctx-stream time of the groups (HIP events around each) */
+} ldb_comm_stats;
+int32_t ldb_gpu_comm_stats(ldb_comm* comm, ldb_comm_stats* out, int32_t reset);
 /* the host-staged transport without a device (host pointers): CPU tests of the protocol with world > 1, and
  * exchange of host-side metadata between the ranks' host programs */
 int32_t ldb_gpu_comm_create_host(int32_t rank, int32_t world, const void* id128, ldb_comm** out);

@@ -91,6 +91,72 @@ Rccl& rccl() {
 //           all-to-all, displacement arithmetic, offset / bitmap rebuild on arrival — runs under test on a
 //           one-GPU box, and as the fallback when RCCL cannot be initialised; it is not a fast path.
 struct Transport {
+   // what went over the links since the last reset (ldb_gpu_comm_stats): transfers to / from OTHER ranks only — a rank's
+   // block for itself never leaves the device
+   int self = 0;
+   int64_t groups = 0, bytes_out = 0, bytes_in = 0;
+   std::vector<int64_t> out_peer;
+   double host_ms = 0, dev_ms = 0;
+   ldb_ctx* ev_ctx = nullptr; // device communicators: every group is bracketed by two events on the ctx stream
+   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
+   std::vector<hipEvent_t> ev_free;
+   std::chrono::steady_clock::time_point t_open;
+   void note(bool is_send, size_t bytes, int peer) {
+      if (peer == self) return;
+      if (is_send) {
+         bytes_out += (int64_t) bytes;
+         if ((size_t) peer >= out_peer.size()) out_peer.resize((size_t) peer + 1, 0);
+         out_peer[(size_t) peer] += (int64_t) bytes;
+      } else {
+         bytes_in += (int64_t) bytes;
+      }
+   }
+   hipEvent_t event() {
+      hipEvent_t e = nullptr;
+      if (!ev_free.empty()) {
+         e = ev_free.back();
+         ev_free.pop_back();
+      } else if (hipEventCreate(&e) != hipSuccess) {
+         e = nullptr;
+      }
+      return e;
+   }
+   void timed_open() {
+      t_open = std::chrono::steady_clock::now();
+      if (ev_ctx) {
+         hipEvent_t a = event();
+         if (a && hipEventRecord(a, ev_ctx->stream) == hipSuccess) ev_pending.push_back({a, nullptr});
+      }
+   }
+   void timed_close() {
+      groups++;
+      host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_open).count();
+      if (ev_ctx && !ev_pending.empty() && !ev_pending.back().second) {
+         hipEvent_t b = event();
+         if (b && hipEventRecord(b, ev_ctx->stream) == hipSuccess) ev_pending.back().second = b;
+         else ev_pending.pop_back();
+      }
+   }
+   void fold_events() { // (waits for the last group to finish on the device)
+      for (auto& pr : ev_pending) {
+         float ms = 0;
+         if (pr.second && hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) dev_ms += ms;
+         ev_free.push_back(pr.first);
+         if (pr.second) ev_free.push_back(pr.second);
+      }
+      ev_pending.clear();
+   }
+   void reset_stats() {
+      fold_events();
+      groups = bytes_out = bytes_in = 0;
+      out_peer.clear();
+      host_ms = dev_ms = 0;
+   }
+   void drop_events() {
+      fold_events();
+      for (auto e : ev_free) (void) hipEventDestroy(e);
+      ev_free.clear();
+   }
    virtual ~Transport() {}
    virtual const char* name() const = 0;
    virtual int32_t group_start() = 0;
@@ -106,6 +172,7 @@ struct RcclTransport : Transport {
    bool open = false;
    explicit RcclTransport(ldb_ctx* c) : ctx(c) {}
    ~RcclTransport() override {
+      drop_events();
       if (comm) (void) rccl().CommDestroy(comm);
    }
    const char* name() const override { return "rccl"; }
@@ -116,10 +183,12 @@ struct RcclTransport : Transport {
    }
    int32_t send(const void* p, size_t bytes, int peer) override {
       LDB_NCCL(rccl().Send(p, bytes, ncclUint8, peer, comm, ctx->stream));
+      note(true, bytes, peer);
       return LDB_OK;
    }
    int32_t recv(void* p, size_t bytes, int peer) override {
       LDB_NCCL(rccl().Recv(p, bytes, ncclUint8, peer, comm, ctx->stream));
+      note(false, bytes, peer);
       return LDB_OK;
    }
    int32_t group_end() override {
@@ -169,6 +238,7 @@ struct ShmTransport : Transport {
       return LDB_OK;
    }
    ~ShmTransport() override {
+      drop_events();
       if (ctl) {
          (void) barrier(); // nobody unlinks while a peer may still open
          munmap(ctl, sizeof(ShmControl));
@@ -202,10 +272,12 @@ struct ShmTransport : Transport {
    }
    int32_t send(const void* p, size_t bytes, int peer) override {
       ops.push_back({true, const_cast<void*>(p), bytes, peer});
+      note(true, bytes, peer);
       return LDB_OK;
    }
    int32_t recv(void* p, size_t bytes, int peer) override {
       ops.push_back({false, p, bytes, peer});
+      note(false, bytes, peer);
       return LDB_OK;
    }
    void group_abort() override {
@@ -360,6 +432,8 @@ extern "C" int32_t ldb_gpu_comm_create(ldb_ctx* ctx, int32_t rank, int32_t world
       auto t = std::make_unique<ShmTransport>(ctx, rank, world, tok);
       LDB_TRY(t->open_control());
       c->t = std::move(t);
+      c->t->self = rank;
+      c->t->ev_ctx = ctx;
    } else {
       if (!rccl().ok) LDB_FAIL(LDB_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded: %s", rccl().why.c_str());
       auto t = std::make_unique<RcclTransport>(ctx);
@@ -367,6 +441,8 @@ extern "C" int32_t ldb_gpu_comm_create(ldb_ctx* ctx, int32_t rank, int32_t world
       memcpy(&id, id128, sizeof(id));
       LDB_NCCL(rccl().CommInitRank(&t->comm, world, id, rank));
       c->t = std::move(t);
+      c->t->self = rank;
+      c->t->ev_ctx = ctx;
    }
    *out = c.release();
    return LDB_OK;
@@ -386,11 +462,30 @@ extern "C" int32_t ldb_gpu_comm_create_host(int32_t rank, int32_t world, const v
    auto t = std::make_unique<ShmTransport>(nullptr, rank, world, tok);
    LDB_TRY(t->open_control());
    c->t = std::move(t);
+   c->t->self = rank;
    *out = c.release();
    return LDB_OK;
 }
 extern "C" int32_t ldb_gpu_comm_destroy(ldb_comm* c) {
    delete c; // the transport's destructor closes the communicator / the shared segments
+   return LDB_OK;
+}
+// traffic and time of the transfer groups since the last reset.  device_ms = between two events on the ctx stream around every
+// group (RCCL: the grouped send / recv kernels, waits for the peers included); host_ms = host wall time inside the groups (the
+// host-staged transport does all its copying there).  max_peer_bytes_out is what the busiest of this rank's links carried:
+// on one MI355X node every peer pair has its own xGMI link (≈ 153 GB/s), so max_peer_bytes_out / device_ms is the link rate.
+extern "C" int32_t ldb_gpu_comm_stats(ldb_comm* c, ldb_comm_stats* out, int32_t reset) {
+   if (!c || !out) LDB_FAIL(LDB_ERR_INVALID, "comm_stats: NULL argument");
+   Transport* t = c->t.get();
+   t->fold_events();
+   out->groups = t->groups;
+   out->bytes_out = t->bytes_out;
+   out->bytes_in = t->bytes_in;
+   out->max_peer_bytes_out = 0;
+   for (int64_t b : t->out_peer) out->max_peer_bytes_out = std::max(out->max_peer_bytes_out, b);
+   out->host_ms = t->host_ms;
+   out->device_ms = t->dev_ms;
+   if (reset) t->reset_stats();
    return LDB_OK;
 }
 extern "C" int32_t ldb_gpu_comm_rank(const ldb_comm* c) { return c ? c->rank : 0; }
@@ -460,13 +555,16 @@ struct GroupGuard { // never leave a transfer group open on an error return
    bool open = false;
    explicit GroupGuard(Transport* tr) : t(tr) {}
    int32_t start() {
+      t->timed_open();
       LDB_TRY(t->group_start());
       open = true;
       return LDB_OK;
    }
    int32_t end() {
       open = false;
-      return t->group_end();
+      const int32_t st = t->group_end();
+      t->timed_close();
+      return st;
    }
    ~GroupGuard() {
       if (open) t->group_abort();

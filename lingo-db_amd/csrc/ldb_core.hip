@@ -4,6 +4,7 @@
 // 200-225) and result materialisation (ArrowColumnBuilder, include/lingodb/runtime/ArrowColumn.h:15-37).
 #include "ldb_internal.h"
 #include "ldb_device.h"
+#include "ldb_chain.h"
 #include <algorithm>
 #include <cstdlib>
 #include <memory>
@@ -183,7 +184,8 @@ int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_
       const size_t cap = (size_t) ldb_option("desc_cache_mb", 64) << 20;
       if (ctx->desc_bytes + bytes > cap) desc_cache_drop(ctx);
       void* dev = nullptr;
-      LDB_HIP(hipMallocAsync(&dev, bytes + 16, ctx->stream));
+      LDB_TRY(ldb_dev_alloc(ctx, &dev, bytes)); // from the block cache; the cache entry takes it out of circulation
+      ctx->live.erase(dev);
       int32_t st = upload_raw(ctx, dev, host, bytes);
       if (st != LDB_OK) {
          (void) hipFreeAsync(dev, ctx->stream);
@@ -208,6 +210,57 @@ int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_
 __global__ void k_log_copy(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t bytes) {
    for (uint32_t i = threadIdx.x; i < bytes; i += blockDim.x) dst[i] = src[i];
 }
+// the deferred copies of a replaying trace: one kernel gathers every pending (source, bytes) into the pinned log
+struct DLogList {
+   uint32_t n, pad;
+   ldb_ctx::LogCopy e[255];
+};
+__global__ void k_log_gather(const DLogList* __restrict__ l, uint8_t* __restrict__ log) {
+   for (uint32_t i = 0; i < l->n; i++) {
+      const uint8_t* src = (const uint8_t*) l->e[i].src;
+      for (uint32_t b = threadIdx.x; b < l->e[i].bytes; b += blockDim.x) log[l->e[i].off + b] = src[b];
+   }
+}
+static int32_t log_flush(ldb_ctx* ctx) {
+   size_t at = 0;
+   while (at < ctx->log_pending.size()) {
+      auto l = std::make_unique<DLogList>();
+      memset(l.get(), 0, sizeof(DLogList));
+      l->n = (uint32_t) std::min<size_t>(255, ctx->log_pending.size() - at);
+      for (uint32_t i = 0; i < l->n; i++) l->e[i] = ctx->log_pending[at + i];
+      at += l->n;
+      DLogList* d = nullptr;
+      LDB_TRY(ldb_dev_upload(ctx, l.get(), 8 + sizeof(ldb_ctx::LogCopy) * l->n, (void**) &d)); // (the same list every execution: served by the descriptor cache)
+      hipLaunchKernelGGL(k_log_gather, dim3(1), dim3(64), 0, ctx->stream, (const DLogList*) d, ctx->h_log);
+      ldb_dev_free(ctx, d);
+   }
+   ctx->log_pending.clear();
+   LDB_HIP(hipGetLastError());
+   return LDB_OK;
+}
+int32_t ldb_counters(ldb_ctx* ctx, int n_words, uint64_t** out) {
+   const size_t need = ((size_t) n_words + 7) & ~(size_t) 7;
+   if (!ctx->arena) {
+      LDB_HIP(hipMalloc((void**) &ctx->arena, 8 * LDB_ARENA_WORDS));
+      LDB_HIP(hipMemsetAsync(ctx->arena, 0, 8 * LDB_ARENA_WORDS, ctx->stream));
+      ctx->arena_pos = 0;
+   }
+   if (need > LDB_ARENA_WORDS) LDB_FAIL(LDB_ERR_INVALID, "ldb_counters: %d words", n_words);
+   if (ctx->arena_pos + need > LDB_ARENA_WORDS) { // wrap: what a replaying trace still wants from the old words is collected first
+      LDB_TRY(log_flush(ctx));
+      LDB_HIP(hipMemsetAsync(ctx->arena, 0, 8 * LDB_ARENA_WORDS, ctx->stream));
+      ctx->arena_pos = 0;
+   }
+   *out = ctx->arena + ctx->arena_pos;
+   ctx->arena_pos += need;
+   return LDB_OK;
+}
+// a plan starts at word 0 (the same words every execution → byte-identical descriptors): one clear of what the last one used
+static int32_t arena_restart(ldb_ctx* ctx) {
+   if (ctx->arena && ctx->arena_pos) LDB_HIP(hipMemsetAsync(ctx->arena, 0, 8 * ctx->arena_pos, ctx->stream));
+   ctx->arena_pos = 0;
+   return LDB_OK;
+}
 static int32_t readback_sync(ldb_ctx* ctx, void* host, const void* dev, size_t bytes) {
    if (bytes <= 512 && ctx->h_scratch) { // a pinned landing area: the copy is a plain DMA / blit, no staging by the runtime
       LDB_HIP(hipMemcpyAsync(ctx->h_scratch, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -221,6 +274,7 @@ static int32_t readback_sync(ldb_ctx* ctx, void* host, const void* dev, size_t b
 }
 // replay: everything read so far must equal the record
 static bool trace_prefix_ok(ldb_ctx* ctx, size_t upto_entries) {
+   if (log_flush(ctx) != LDB_OK) return false;
    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
    const ldb_trace* t = ctx->trace;
    for (size_t i = 0; i < upto_entries; i++) {
@@ -245,8 +299,13 @@ int32_t ldb_readback(ldb_ctx* ctx, void* host, const void* dev, size_t bytes, ui
    if (ctx->trace_mode == 2) {
       if (ctx->trace_pos < t->entries.size() && t->entries[ctx->trace_pos].site == site && t->entries[ctx->trace_pos].bytes == bytes) {
          const ldb_trace_entry& e = t->entries[ctx->trace_pos++];
-         hipLaunchKernelGGL(k_log_copy, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t*) dev, ctx->h_log + e.off, (uint32_t) bytes);
-         LDB_HIP(hipGetLastError());
+         const uint64_t* w = (const uint64_t*) dev;
+         if (ctx->arena && w >= ctx->arena && w < ctx->arena + LDB_ARENA_WORDS) { // an arena word keeps its value until the plan ends: collected with the others
+            ctx->log_pending.push_back({(uint64_t) dev, e.off, (uint32_t) bytes});
+         } else {
+            hipLaunchKernelGGL(k_log_copy, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t*) dev, ctx->h_log + e.off, (uint32_t) bytes);
+            LDB_HIP(hipGetLastError());
+         }
          memcpy(host, t->vals.data() + e.off, bytes);
          return LDB_OK;
       }
@@ -299,6 +358,8 @@ extern "C" int32_t ldb_gpu_trace_begin(ldb_ctx* ctx, ldb_trace* t, int32_t allow
    ctx->trace = t;
    ctx->trace_pos = 0;
    ctx->trace_poisoned = false;
+   ctx->log_pending.clear();
+   LDB_TRY(arena_restart(ctx));
    if (allow_replay && replay_wanted && t->complete && !t->entries.empty()) {
       ctx->trace_mode = 2;
    } else {
@@ -427,6 +488,7 @@ extern "C" int32_t ldb_gpu_ctx_destroy(ldb_ctx* ctx) {
    if (ctx->d_scratch) (void) hipFree(ctx->d_scratch);
    if (ctx->scan_status) (void) hipFree(ctx->scan_status);
    if (ctx->scan_ticket) (void) hipFree(ctx->scan_ticket);
+   if (ctx->arena) (void) hipFree(ctx->arena);
    if (ctx->own_stream) (void) hipStreamDestroy(ctx->stream);
    delete ctx;
    return LDB_OK;
@@ -941,6 +1003,23 @@ static char* dup_str(ExportPriv* p, const std::string& s) {
    return c;
 }
 
+// all buffers of a small result → the pinned ring in ONE launch (a hipMemcpyAsync per buffer was 10 – 17 copy launches for a
+// TPC-H result with string columns): workgroup b copies buffer b, 8 bytes per lane and step
+struct DExportPack {
+   int32_t n, pad;
+   const uint8_t* src[32];
+   uint8_t* dst[32];
+   uint64_t bytes[32];
+};
+__global__ __launch_bounds__(256) void k_export_pack(DExportPack d) {
+   const int b = blockIdx.x;
+   if (b >= d.n) return;
+   const uint64_t words = d.bytes[b] / 8;
+   const uint64_t* s8 = (const uint64_t*) d.src[b];
+   uint64_t* d8 = (uint64_t*) d.dst[b];
+   for (uint64_t i = threadIdx.x; i < words; i += 256) d8[i] = s8[i];
+   for (uint64_t i = words * 8 + threadIdx.x; i < d.bytes[b]; i += 256) d.dst[b][i] = d.src[b][i];
+}
 extern "C" int32_t ldb_gpu_export(ldb_ctx* ctx, const ldb_table* t, struct ArrowSchema* out_schema, struct ArrowArray* out_array) {
    if (!ctx || !t || !out_schema || !out_array) LDB_FAIL(LDB_ERR_INVALID, "export: NULL argument");
    const int64_t n = t->n_rows;
@@ -971,11 +1050,25 @@ extern "C" int32_t ldb_gpu_export(ldb_ctx* ctx, const ldb_table* t, struct Arrow
             LDB_HIP(hipStreamSynchronize(ctx->stream));
             ctx->ring_pos = 0;
          }
+         DExportPack pack;
+         memset(&pack, 0, sizeof(pack));
+         auto flush = [&]() {
+            if (pack.n) hipLaunchKernelGGL(k_export_pack, dim3((unsigned) pack.n), dim3(256), 0, ctx->stream, pack);
+            pack.n = 0;
+         };
          auto fetch = [&](const void* src, size_t bytes, const uint8_t** slot_out) -> int32_t {
             if (!bytes) return LDB_OK;
             uint8_t* slot = ctx->h_ring + ctx->ring_pos;
             ctx->ring_pos += pad(bytes);
-            LDB_HIP(hipMemcpyAsync(slot, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            if (((uintptr_t) src & 7) == 0) { // (device buffers are 256-byte aligned; a view's base need not be)
+               if (pack.n == 32) flush();
+               pack.src[pack.n] = (const uint8_t*) src;
+               pack.dst[pack.n] = slot;
+               pack.bytes[pack.n] = bytes;
+               pack.n++;
+            } else {
+               LDB_HIP(hipMemcpyAsync(slot, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            }
             *slot_out = slot;
             return LDB_OK;
          };
@@ -990,6 +1083,8 @@ extern "C" int32_t ldb_gpu_export(ldb_ctx* ctx, const ldb_table* t, struct Arrow
                LDB_TRY(fetch(col.values, (size_t) n * (size_t) col.width, &st.values));
             }
          }
+         flush();
+         LDB_HIP(hipGetLastError());
       }
    }
    LDB_HIP(hipStreamSynchronize(ctx->stream));
@@ -1381,8 +1476,9 @@ int32_t ldb_column_zones(ldb_ctx* ctx, const ldb_table* t, int32_t col, uint64_t
    if (c.zone_state < 0) {
       const int64_t nz = (t->n_rows + LDB_ZONE_ROWS - 1) >> LDB_ZONE_SHIFT;
       int64_t *zl, *zh;
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &zl, 8 * (size_t) nz));
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &zh, 8 * (size_t) nz));
+      LdbBufs tmp(ctx); // (freed on the error returns below)
+      LDB_TRY(tmp.alloc(&zl, 8 * (size_t) nz));
+      LDB_TRY(tmp.alloc(&zh, 8 * (size_t) nz));
       DCol dc;
       memset(&dc, 0, sizeof(dc));
       dc.values = (uint64_t) c.values;
@@ -1409,9 +1505,8 @@ int32_t ldb_column_zones(ldb_ctx* ctx, const ldb_table* t, int32_t col, uint64_t
       if (useful) {
          c.zone_min = zl;
          c.zone_max = zh;
-      } else {
-         ldb_dev_free(ctx, zl);
-         ldb_dev_free(ctx, zh);
+         tmp.keep(zl);
+         tmp.keep(zh);
       }
       c.zone_state = useful ? 1 : 0;
    }
@@ -1477,6 +1572,47 @@ void ldb_mark_same_col(DPred* preds, int32_t n) {
                              ? 1
                              : 0;
    }
+}
+
+// ---------------------------------------------------------------- row-id composition
+struct DComposeMulti {
+   uint64_t n;
+   const uint32_t* sel[2];
+   const uint32_t* ids[12];
+   uint32_t* out[12];
+   int32_t n_out;
+   uint8_t which[12];
+};
+__global__ void k_compose_multi(DComposeMulti d) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < d.n; i += (uint64_t) gridDim.x * blockDim.x) {
+      const uint32_t s0 = d.sel[0][i];
+      const uint32_t s1 = d.sel[1] ? d.sel[1][i] : 0u;
+#pragma unroll
+      for (int j = 0; j < 12; j++) {
+         if (j >= d.n_out) break;
+         const uint32_t s = d.which[j] ? s1 : s0;
+         d.out[j][i] = s == LDB_NULL_ROW ? LDB_NULL_ROW : (d.ids[j] ? d.ids[j][s] : s);
+      }
+   }
+}
+int32_t ldb_compose_rowids(ldb_ctx* ctx, const uint32_t* sel0, const uint32_t* sel1, const LdbComposeJob* jobs, int n_jobs, uint64_t n) {
+   if (!n || !n_jobs) return LDB_OK;
+   for (int at = 0; at < n_jobs; at += 12) {
+      DComposeMulti d;
+      memset(&d, 0, sizeof(d));
+      d.n = n;
+      d.sel[0] = sel0;
+      d.sel[1] = sel1;
+      d.n_out = std::min(12, n_jobs - at);
+      for (int j = 0; j < d.n_out; j++) {
+         d.ids[j] = jobs[at + j].ids;
+         d.out[j] = jobs[at + j].out;
+         d.which[j] = (uint8_t) jobs[at + j].which;
+      }
+      hipLaunchKernelGGL(k_compose_multi, dim3(ldb_grid_for(ctx, (int64_t) n, 256, 8)), dim3(256), 0, ctx->stream, d);
+   }
+   LDB_HIP(hipGetLastError());
+   return LDB_OK;
 }
 
 // ---------------------------------------------------------------- gather / materialize
@@ -1555,10 +1691,7 @@ int32_t ldb_gather_columns(ldb_ctx* ctx, const ldb_rel* r, const ldb_colref* ref
       if (src.type.type == LDB_T_UTF8) pend[(size_t) c].slot_bytes = n_slots++;
    }
    unsigned long long* d_words = nullptr;
-   if (n_slots) {
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_words, 8 * (size_t) n_slots));
-      LDB_HIP(hipMemsetAsync(d_words, 0, 8 * (size_t) n_slots, ctx->stream));
-   }
+   if (n_slots) LDB_TRY(ldb_counters(ctx, n_slots, (uint64_t**) &d_words)); // zeroed arena words
    for (int32_t c = 0; c < n_cols; c++) {
       Pending& p = pend[(size_t) c];
       DCol dcol;
@@ -1604,7 +1737,6 @@ int32_t ldb_gather_columns(ldb_ctx* ctx, const ldb_rel* r, const ldb_colref* ref
    if (!n_slots) return LDB_OK;
    std::vector<unsigned long long> words((size_t) n_slots);
    LDB_TRY(LDB_READBACK(ctx, words.data(), d_words, 8 * (size_t) n_slots));
-   ldb_dev_free(ctx, d_words);
    for (int32_t c = 0; c < n_cols; c++) {
       Pending& p = pend[(size_t) c];
       ldb_column* out = &outs[c];
@@ -1657,62 +1789,6 @@ extern "C" int32_t ldb_gpu_materialize(ldb_ctx* ctx, ldb_rel* r, const ldb_colre
 // cleared: every call owns a fresh epoch, and a word of another epoch reads as "not there yet".  The three-level version
 // this replaces (per-block sums → recursive scan → add back) was 22 % of all launches of a 22-query pass.
 // Status word: value in the low VBITS bits, state (1 = the tile's own sum, 2 = inclusive prefix) above it, epoch on top.
-template <typename TO, int VBITS>
-__device__ __forceinline__ unsigned long long d_chain_pack(unsigned long long epoch, unsigned state, TO v) {
-   return (epoch << (VBITS + 2)) | ((unsigned long long) state << VBITS) | ((unsigned long long) v & ((1ull << VBITS) - 1));
-}
-// called by all lanes of ONE wave of the workgroup that owns `tile`: publishes the tile's sum, walks back over the
-// predecessors' status words (64 at a time) and returns the exclusive prefix of the tile (valid in every lane)
-template <typename TO, int VBITS>
-__device__ __forceinline__ TO d_chain_prefix(unsigned long long* __restrict__ status, uint64_t tile, unsigned long long epoch, TO agg, uint32_t lane) {
-   TO prefix = 0;
-   if (tile == 0) {
-      if (lane == 0) __hip_atomic_store(&status[0], d_chain_pack<TO, VBITS>(epoch, 2, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return prefix;
-   }
-   if (lane == 0) __hip_atomic_store(&status[tile], d_chain_pack<TO, VBITS>(epoch, 1, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-   int64_t look = (int64_t) tile - 1;
-   for (;;) {
-      const int64_t idx = look - (int64_t) lane;
-      unsigned long long w;
-      for (;;) {
-         w = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : d_chain_pack<TO, VBITS>(epoch, 2, (TO) 0);
-         const bool ready = (w >> (VBITS + 2)) == epoch && ((w >> VBITS) & 3u) != 0;
-         if (__ballot(!ready) == 0) break;
-         __builtin_amdgcn_s_sleep(1);
-      }
-      const unsigned long long incl_mask = __ballot(((w >> VBITS) & 3u) == 2u);
-      const int first = incl_mask ? __builtin_ctzll(incl_mask) : 64;
-      TO contrib = (int) lane <= first ? (TO) (w & ((1ull << VBITS) - 1)) : (TO) 0;
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) contrib += (TO) __shfl_xor((long long) contrib, off);
-      prefix += contrib;
-      if (incl_mask) break;
-      look -= 64;
-   }
-   if (lane == 0) __hip_atomic_store(&status[tile], d_chain_pack<TO, VBITS>(epoch, 2, (TO) (prefix + agg)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-   return prefix;
-}
-// workgroup of 256: exclusive scan of one value per thread; returns the thread's exclusive prefix inside the workgroup and
-// the workgroup's total in *agg (s_wave: 4 words of LDS)
-template <typename TO>
-__device__ __forceinline__ TO d_block_scan256(TO sum, TO* s_wave, TO* agg) {
-   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-   TO incl = sum;
-#pragma unroll
-   for (int off = 1; off < 64; off <<= 1) {
-      const TO t = (TO) __shfl_up((long long) incl, off);
-      if ((int) lane >= off) incl += t;
-   }
-   if (lane == 63) s_wave[wave] = incl;
-   __syncthreads();
-   TO wave_off = 0;
-   for (uint32_t w = 0; w < wave; w++) wave_off += s_wave[w];
-   *agg = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-   return wave_off + incl - sum;
-}
-#define CHAIN_ITEMS 8
-#define CHAIN_TILE (256 * CHAIN_ITEMS)
 template <typename T, typename TO, typename TT, int VBITS>
 __global__ __launch_bounds__(256) void k_scan_chain(const T* __restrict__ in, TO* __restrict__ out, uint64_t n, uint64_t n_tiles, TT* __restrict__ total,
                                                     unsigned long long* __restrict__ status, unsigned long long* __restrict__ ticket, unsigned long long ticket_base,
@@ -1748,13 +1824,7 @@ __global__ __launch_bounds__(256) void k_scan_chain(const T* __restrict__ in, TO
 }
 // the chain's device state: status words for `tiles` tiles in both formats (32-bit values / 42-bit values) + the ticket
 // counter.  Returns the (masked) epoch of this call and the ticket base; grows the status arrays on demand.
-struct ChainCall {
-   unsigned long long* status;
-   unsigned long long* ticket;
-   unsigned long long ticket_base;
-   unsigned long long epoch;
-};
-static int32_t chain_begin(ldb_ctx* ctx, uint64_t n_tiles, bool wide, ChainCall* c) {
+int32_t ldb_chain_begin(ldb_ctx* ctx, uint64_t n_tiles, bool wide, ChainCall* c) {
    if (!ctx->scan_ticket) {
       LDB_HIP(hipMalloc((void**) &ctx->scan_ticket, 64));
       LDB_HIP(hipMemsetAsync(ctx->scan_ticket, 0, 64, ctx->stream));
@@ -1787,7 +1857,7 @@ static int32_t chain_begin(ldb_ctx* ctx, uint64_t n_tiles, bool wide, ChainCall*
 }
 // a launch that did not happen took no tickets: the host mirror of the counter is re-based (the next tile numbers must
 // start at 0 again, or every later chain would wait for tiles that never run)
-static int32_t chain_failed(ldb_ctx* ctx) {
+int32_t ldb_chain_failed(ldb_ctx* ctx) {
    (void) hipMemsetAsync(ctx->scan_ticket, 0, 64, ctx->stream);
    ctx->scan_ticket_base = 0;
    LDB_FAIL(LDB_ERR_HIP, "chained scan: the launch failed");
@@ -1844,10 +1914,10 @@ static int32_t scan_impl(ldb_ctx* ctx, const T* d_in, TO* d_out, int64_t n, TT* 
    int64_t nb = (n + per_block - 1) / per_block;
    if (nb > 1 && ldb_option("scan_single_pass", 1) != 0) {
       ChainCall c;
-      LDB_TRY(chain_begin(ctx, (uint64_t) nb, VBITS > 32, &c));
+      LDB_TRY(ldb_chain_begin(ctx, (uint64_t) nb, VBITS > 32, &c));
       hipLaunchKernelGGL((k_scan_chain<T, TO, TT, VBITS>), dim3((unsigned) nb), dim3(256), 0, ctx->stream, d_in, d_out, (uint64_t) n, (uint64_t) nb, d_total, c.status, c.ticket, c.ticket_base,
                          c.epoch);
-      if (hipGetLastError() != hipSuccess) return chain_failed(ctx);
+      if (hipGetLastError() != hipSuccess) return ldb_chain_failed(ctx);
       return LDB_OK;
    }
    TO* sums = nullptr;
@@ -1888,6 +1958,8 @@ __global__ __launch_bounds__(256) void k_bitmap_compact(const uint64_t* __restri
    __shared__ uint32_t s_wave[4];
    __shared__ uint32_t s_prefix;
    __shared__ uint32_t s_off[CHAIN_TILE];
+   __shared__ uint64_t s_words[CHAIN_TILE]; // the tile's words for the word-per-wave expansion (a wave re-reading them from memory one by
+                                            // one runs at memory latency: 512 dependent round trips per wave)
    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1ull) - ticket_base;
    __syncthreads();
    const uint64_t tile = s_tile;
@@ -1902,6 +1974,7 @@ __global__ __launch_bounds__(256) void k_bitmap_compact(const uint64_t* __restri
       m[k] = w < n_words ? bitmap[w] : 0;
       cnt[k] = (uint32_t) __popcll(m[k]);
       s_off[k * 256 + threadIdx.x] = cnt[k];
+      s_words[k * 256 + threadIdx.x] = m[k];
    }
    __syncthreads();
    // thread t scans words [8t, 8t + 8) of the tile (consecutive words → consecutive output positions)
@@ -1950,7 +2023,7 @@ __global__ __launch_bounds__(256) void k_bitmap_compact(const uint64_t* __restri
       const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       for (uint32_t w = wave; w < CHAIN_TILE; w += 4) {
          if (word0 + w >= n_words) break;
-         const uint64_t mm = bitmap[word0 + w]; // wave-uniform (L1 / L2 hit: read a moment ago)
+         const uint64_t mm = s_words[w]; // wave-uniform
          if ((mm >> lane) & 1) {
             const uint32_t at = s_off[w] + d_rank_in(mm);
             const uint32_t row = (uint32_t) ((word0 + w) * 64 + lane);
@@ -1976,9 +2049,9 @@ int32_t ldb_bitmap_compact(ldb_ctx* ctx, const uint64_t* bitmap, int64_t n_words
    }
    const uint64_t n_tiles = ((uint64_t) n_words + CHAIN_TILE - 1) / CHAIN_TILE;
    ChainCall c;
-   LDB_TRY(chain_begin(ctx, n_tiles, false, &c));
+   LDB_TRY(ldb_chain_begin(ctx, n_tiles, false, &c));
    hipLaunchKernelGGL(k_bitmap_compact, dim3((unsigned) n_tiles), dim3(256), 0, ctx->stream, bitmap, (uint64_t) n_words, n_tiles, out, cap, match, second, (unsigned long long*) d_total, c.status,
                       c.ticket, c.ticket_base, c.epoch);
-   if (hipGetLastError() != hipSuccess) return chain_failed(ctx);
+   if (hipGetLastError() != hipSuccess) return ldb_chain_failed(ctx);
    return LDB_OK;
 }

@@ -26,6 +26,7 @@
 //     specialised at run time on the descriptor (hiprtc, ldb_jit.hip); small inputs and any
 //     specialisation failure use the generic ahead-of-time kernel below — both are this source.
 #include "ldb_internal.h"
+#include "ldb_chain.h"
 #include "ldb_gb_kernel.h"
 #include "ldb_jit.h"
 #include <algorithm>
@@ -100,6 +101,40 @@ __global__ void k_gb_occupancy(const uint64_t* __restrict__ g_keys, uint64_t cap
       const uint64_t occ = __ballot(p < cap && g_keys[p] != 0);
       if ((threadIdx.x & 63) == 0) pop[p >> 6] = (uint32_t) __popcll(occ);
    }
+}
+// the same + the exclusive scan of the chunk counts in ONE chained launch (ldb_chain.h): a tile is 256 chunks (16 384 slots), a
+// wave takes 64 of them with independent loads; off[c] = occupied slots before chunk c, *total = number of groups
+#define GBO_TILE_CHUNKS 256
+__global__ __launch_bounds__(256) void k_gb_occupancy_scan(const uint64_t* __restrict__ occ_words, uint64_t cap, uint64_t n_chunks, uint64_t n_tiles, uint32_t* __restrict__ off,
+                                                           unsigned long long* __restrict__ total, unsigned long long* __restrict__ status, unsigned long long* __restrict__ ticket,
+                                                           unsigned long long ticket_base, unsigned long long epoch) {
+   __shared__ unsigned long long s_tile;
+   __shared__ uint32_t s_wave[4];
+   __shared__ uint32_t s_prefix;
+   __shared__ uint32_t s_cnt[GBO_TILE_CHUNKS];
+   if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1ull) - ticket_base;
+   __syncthreads();
+   const uint64_t tile = s_tile;
+   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const uint64_t chunk0 = tile * GBO_TILE_CHUNKS + (uint64_t) wave * 64;
+#pragma unroll 8
+   for (uint32_t k = 0; k < 64; k++) {
+      const uint64_t p = (chunk0 + k) * 64 + lane;
+      const uint64_t m = __ballot(p < cap && occ_words[p] != 0);
+      if (lane == 0) s_cnt[wave * 64 + k] = (uint32_t) __popcll(m);
+   }
+   __syncthreads();
+   const uint32_t own = s_cnt[threadIdx.x];
+   uint32_t agg;
+   uint32_t excl = d_block_scan256<uint32_t>(own, s_wave, &agg);
+   if (threadIdx.x < 64) {
+      const uint32_t prefix = d_chain_prefix<uint32_t, 32>(status, tile, epoch, agg, threadIdx.x);
+      if (threadIdx.x == 0) s_prefix = prefix;
+   }
+   __syncthreads();
+   const uint64_t c = tile * GBO_TILE_CHUNKS + threadIdx.x;
+   if (c < n_chunks) off[c] = s_prefix + excl;
+   if (total && tile == n_tiles - 1 && threadIdx.x == 0) *total = (unsigned long long) s_prefix + agg;
 }
 __global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restrict__ rep_rows, const uint32_t* __restrict__ chunk_off) {
    const uint64_t cap = d->g_cap;
@@ -568,9 +603,11 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
                hipLaunchKernelGGL(k_gb_sorted_heads, dim3(hgrid), dim3(256), 0, ctx->stream, dh, chunk_cnt);
             }
          }
-         LDB_TRY(ldb_exclusive_scan_u32(ctx, chunk_cnt, chunk_off, n_chunks, (uint64_t*) ctx->d_scratch));
+         uint64_t* d_groups;
+         LDB_TRY(ldb_counters(ctx, 1, &d_groups));
+         LDB_TRY(ldb_exclusive_scan_u32(ctx, chunk_cnt, chunk_off, n_chunks, d_groups));
          uint64_t groups = 0;
-         LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &groups));
+         LDB_TRY(ldb_read_u64(ctx, d_groups, &groups));
          ldb_dev_free(ctx, dh);
          ldb_dev_free(ctx, chunk_cnt);
          h->dense_sorted = 1;
@@ -611,8 +648,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    // the aggregation kernel without waiting for its flags; an overflow (rare: the estimate was far
    // too low) throws that work away and retries with a larger table.
    const size_t ctl_bytes = 8 * (size_t) (2 + GB_MAX_OUT);
-   unsigned long long* d_ctl;
-   LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_ctl, ctl_bytes));
+   unsigned long long* d_ctl = nullptr; // zeroed arena words, fresh ones per attempt (ldb_counters)
    unsigned long long ctl[2 + GB_MAX_OUT];
    DGroupBy* d = nullptr;
    uint64_t n_groups = 0;
@@ -642,6 +678,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &ga, 8 * (size_t) cap * (size_t) nw));
       h->g_keys = (uint64_t) gk;
       h->g_acc = (uint64_t) ga;
+      LDB_TRY(ldb_counters(ctx, 2 + GB_MAX_OUT, (uint64_t**) &d_ctl));
       h->g_flags = (uint64_t) d_ctl;
       // upper bound of groups = min(cap, rows) (1 for keyless)
       const uint64_t max_groups = std::max<uint64_t>(1, h->keyless ? 1 : std::min<uint64_t>(cap, (uint64_t) in->n_rows));
@@ -665,7 +702,6 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
             h->outs[a].out_valid = (uint64_t) out_valid[(size_t) a];
          }
       }
-      LDB_HIP(hipMemsetAsync(d_ctl, 0, ctl_bytes, ctx->stream));
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
       hipLaunchKernelGGL(k_gb_init, dim3(ldb_grid_for(ctx, (int64_t) cap, 256, 8)), dim3(256), 0, ctx->stream, gk, ga, d);
       // COUNT(*) per key over direct slots, many rows into a table far beyond the L2: partition, then count in LDS
@@ -722,13 +758,22 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       {
          LdbProf prof_(ctx, "k_gb_finalize");
          const int64_t n_chunks = (int64_t) ((cap + 63) / 64);
-         uint32_t *pop, *off;
-         LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) n_chunks));
+         uint32_t *pop = nullptr, *off;
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) n_chunks));
          const int fgrid = ldb_grid_for(ctx, (int64_t) cap, 256, 8);
          const uint64_t* occ = h->direct ? (const uint64_t*) h->g_acc + (uint64_t) h->direct_word * cap : (const uint64_t*) h->g_keys;
-         hipLaunchKernelGGL(k_gb_occupancy, dim3(fgrid), dim3(256), 0, ctx->stream, occ, cap, pop);
-         LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, n_chunks, (uint64_t*) (d_ctl + 1)));
+         if (ldb_option("scan_single_pass", 1) != 0) { // occupied slots per chunk + their exclusive scan + the group count: one chained launch
+            const uint64_t n_tiles = ((uint64_t) n_chunks + GBO_TILE_CHUNKS - 1) / GBO_TILE_CHUNKS;
+            ChainCall c;
+            LDB_TRY(ldb_chain_begin(ctx, n_tiles, false, &c));
+            hipLaunchKernelGGL(k_gb_occupancy_scan, dim3((unsigned) n_tiles), dim3(256), 0, ctx->stream, occ, cap, (uint64_t) n_chunks, n_tiles, off, d_ctl + 1, c.status, c.ticket, c.ticket_base,
+                               c.epoch);
+            if (hipGetLastError() != hipSuccess) return ldb_chain_failed(ctx);
+         } else {
+            LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) n_chunks));
+            hipLaunchKernelGGL(k_gb_occupancy, dim3(fgrid), dim3(256), 0, ctx->stream, occ, cap, pop);
+            LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, n_chunks, (uint64_t*) (d_ctl + 1)));
+         }
          hipLaunchKernelGGL(k_gb_finalize, dim3(fgrid), dim3(256), 0, ctx->stream, d, rep_rows, (const uint32_t*) off);
          for (int32_t a = 0; a < n_aggs; a++)
             if (out_valid[(size_t) a])
@@ -753,14 +798,12 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       }
       // global table overflowed: retry larger (the estimate was too low)
       if (cap >= cap_max) {
-         ldb_dev_free(ctx, d_ctl);
          ldb_dev_free(ctx, chunk_off);
          LDB_FAIL(LDB_ERR_HIP, "groupby: global table overflow at maximum capacity");
       }
       cap = std::min(cap * 8, cap_max);
    }
    ldb_dev_free(ctx, chunk_off);
-   ldb_dev_free(ctx, d_ctl);
    n_groups = (uint64_t) ctl[1];
    for (int32_t a = 0; a < n_aggs; a++) {
       ldb_dev_free(ctx, out_valid[(size_t) a]);

@@ -165,6 +165,17 @@ struct ldb_ctx {
    size_t trace_pos = 0;
    bool trace_poisoned = false; // a replayed value was wrong: everything computed since is void
    uint8_t* h_log = nullptr; // pinned, LDB_LOG_BYTES
+   // counter arena (ldb_counters): zeroed 64-bit device words handed out front to back — an operator's counters / flags / totals
+   // are words nobody else touches until the arena wraps, so (a) no operator clears its counters itself (one clear per plan
+   // instead of one fill launch per operator) and (b) a replaying plan collects all of them with ONE copy kernel at its end
+   // instead of one per read-back (ldb_readback defers reads of arena words)
+   uint64_t* arena = nullptr; // device, LDB_ARENA_WORDS
+   size_t arena_pos = 0;
+   struct LogCopy {
+      uint64_t src;
+      uint32_t off, bytes;
+   };
+   std::vector<LogCopy> log_pending; // deferred copies of a replaying trace: arena words → pinned log
    // single-pass scans (ldb_exclusive_scan_*): tile status words + the ticket counter, never cleared — every scan call owns a
    // fresh epoch / ticket range (ldb_core.hip)
    uint64_t* scan_status = nullptr;
@@ -231,6 +242,33 @@ void ldb_dev_free(ldb_ctx* ctx, void* p);
 // (read-only descriptors are cached by content, see ldb_core.hip; cacheable = false for memory a kernel will write)
 int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_out, bool cacheable = true);
 
+// device temporaries of one call: whatever is still listed when the scope ends is freed (error returns included)
+struct LdbBufs {
+   ldb_ctx* ctx;
+   std::vector<void*> ptrs;
+   explicit LdbBufs(ldb_ctx* c) : ctx(c) {}
+   LdbBufs(const LdbBufs&) = delete;
+   LdbBufs& operator=(const LdbBufs&) = delete;
+   ~LdbBufs() {
+      for (void* p : ptrs) ldb_dev_free(ctx, p);
+   }
+   template <typename T>
+   int32_t alloc(T** out, size_t bytes) {
+      void* p = nullptr;
+      LDB_TRY(ldb_dev_alloc(ctx, &p, bytes ? bytes : 8));
+      ptrs.push_back(p);
+      *out = (T*) p;
+      return LDB_OK;
+   }
+   void keep(void* p) { // the caller takes the block over (it outlives the call)
+      for (size_t i = 0; i < ptrs.size(); i++)
+         if (ptrs[i] == p) {
+            ptrs.erase(ptrs.begin() + (long) i);
+            return;
+         }
+   }
+};
+
 int32_t ldb_make_dcol(const ldb_rel* r, ldb_colref ref, DCol* out);
 int32_t ldb_make_dpred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out);
 void ldb_mark_same_col(DPred* preds, int32_t n);
@@ -263,6 +301,18 @@ static inline int ldb_grid_for(const ldb_ctx* ctx, int64_t n, int block, int per
 // exclusive scan of n uint32 values on the device (in place allowed); total written to *d_total (uint64)
 int32_t ldb_exclusive_scan_u32(ldb_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, uint64_t* d_total);
 int32_t ldb_exclusive_scan_i64(ldb_ctx* ctx, const int64_t* d_in, int64_t* d_out, int64_t n, int64_t* d_total);
+// out[j][i] = compose(ids[j], sel[which[j]][i]) for up to 12 row-id vectors in ONE launch (LDB_NULL_ROW passes through; ids[j] == NULL:
+// the selection itself) — the hand-over of a join / selection result: one vector per side of the result relation
+struct LdbComposeJob {
+   const uint32_t* ids;
+   uint32_t* out;
+   int which;
+};
+int32_t ldb_compose_rowids(ldb_ctx* ctx, const uint32_t* sel0, const uint32_t* sel1, const LdbComposeJob* jobs, int n_jobs, uint64_t n);
+#define LDB_ARENA_WORDS 16384
+// n_words zeroed 64-bit device words (64-byte aligned) that stay this caller's until the arena wraps: written by its kernels,
+// read back with ldb_readback; never cleared, never reused for a second purpose by the caller after the read-back
+int32_t ldb_counters(ldb_ctx* ctx, int n_words, uint64_t** out);
 // selection bitmap (n_words x 64 rows) → ascending row numbers in out[0, total), total ≤ cap; entries [total, cap) are set
 // to 0; with `match`, second[j] = match[out[j]]; *d_total (device, may be NULL) receives the count.  One launch.
 int32_t ldb_bitmap_compact(ldb_ctx* ctx, const uint64_t* bitmap, int64_t n_words, uint32_t* out, uint64_t cap, const uint32_t* match, uint32_t* second, uint64_t* d_total);

@@ -31,11 +31,17 @@ static double g_compile_ms = 0;
 
 bool ldb_jit_wanted(int64_t n_rows) { return ldb_option("jit", 1) != 0 && n_rows >= ldb_option("jit_min_rows", 4000000); }
 
-static uint64_t fnv1a(const unsigned char* p, size_t n, uint64_t h = 1469598103934665603ull) {
-   for (size_t i = 0; i < n; i++) {
-      h ^= p[i];
-      h *= 1099511628211ull;
+// 64-bit content hash, eight bytes per step (a lookup hashes a whole descriptor — up to 16 KB — on every operator call; one
+// byte per step was 20 µs of host time per group-by)
+static uint64_t hash_bytes(const unsigned char* p, size_t n, uint64_t h = 1469598103934665603ull) {
+   size_t i = 0;
+   for (; i + 8 <= n; i += 8) {
+      uint64_t w;
+      memcpy(&w, p + i, 8);
+      h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+      h ^= h >> 32;
    }
+   for (; i < n; i++) h = (h ^ p[i]) * 1099511628211ull;
    return h;
 }
 
@@ -184,7 +190,7 @@ hipFunction_t ldb_jit_kernel(int device, const char* header, const char* struct_
    key += kernels_src;
    key += '|';
    key.append((const char*) meta, meta_bytes);
-   const uint64_t h = fnv1a((const unsigned char*) key.data(), key.size());
+   const uint64_t h = hash_bytes((const unsigned char*) key.data(), key.size());
    std::lock_guard<std::mutex> lock(g_mu);
    auto& bucket = g_cache[h];
    JitModule* mod = nullptr;

@@ -20,6 +20,7 @@
 #include "ldb_internal.h"
 #include "ldb_join_kernel.h"
 #include "ldb_jit.h"
+#include "ldb_chain.h"
 #include <algorithm>
 #include <memory>
 
@@ -61,10 +62,6 @@ __global__ void k_join_key_range(const DJoin* __restrict__ d, long long* __restr
 __global__ void k_join_key_bits(const DJoin* __restrict__ d);
 __global__ void k_join_rank_bits(const DJoin* __restrict__ d);
 __global__ void k_join_rank_perm(const DJoin* __restrict__ d);
-// rank-bitmap build, pass 2: popcounts of the presence halves → (scan) → prefix halves
-__global__ void k_rank_pop(const uint64_t* __restrict__ tab, uint64_t n_words, uint32_t* __restrict__ pop) {
-   for (uint64_t w = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; w < n_words; w += (uint64_t) gridDim.x * blockDim.x) pop[w] = (uint32_t) __popc((uint32_t) tab[w]);
-}
 // coarse bit b ⇔ some build key among the 64 key values of rank words 2b, 2b + 1
 __global__ void k_rank_coarse(const uint64_t* __restrict__ tab, uint64_t n_words, uint32_t* __restrict__ coarse, uint32_t coarse_words) {
    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < coarse_words; c += gridDim.x * blockDim.x) {
@@ -77,8 +74,39 @@ __global__ void k_rank_coarse(const uint64_t* __restrict__ tab, uint64_t n_words
       coarse[c] = m;
    }
 }
-__global__ void k_rank_prefix(uint64_t* __restrict__ tab, uint64_t n_words, const uint32_t* __restrict__ off) {
-   for (uint64_t w = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; w < n_words; w += (uint64_t) gridDim.x * blockDim.x) tab[w] = (tab[w] & 0xFFFFFFFFull) | ((uint64_t) off[w] << 32);
+// rank-bitmap build, pass 2 (after k_join_rank_bits set the presence halves): popcounts → scan → prefix halves as ONE chained launch (ldb_chain.h): tab[w] = presence bits | (number of
+// build keys in the words before w) << 32; *total = number of distinct build keys
+__global__ __launch_bounds__(256) void k_rank_prefix_chain(uint64_t* __restrict__ tab, uint64_t n_words, uint64_t n_tiles, unsigned long long* __restrict__ total,
+                                                           unsigned long long* __restrict__ status, unsigned long long* __restrict__ ticket, unsigned long long ticket_base,
+                                                           unsigned long long epoch) {
+   __shared__ unsigned long long s_tile;
+   __shared__ uint32_t s_wave[4];
+   __shared__ uint32_t s_prefix;
+   if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1ull) - ticket_base;
+   __syncthreads();
+   const uint64_t tile = s_tile;
+   const uint64_t base = tile * CHAIN_TILE + (uint64_t) threadIdx.x * CHAIN_ITEMS;
+   uint32_t bits[CHAIN_ITEMS];
+   uint32_t sum = 0;
+#pragma unroll
+   for (int k = 0; k < CHAIN_ITEMS; k++) {
+      bits[k] = base + k < n_words ? (uint32_t) tab[base + k] : 0u;
+      sum += (uint32_t) __popc(bits[k]);
+   }
+   uint32_t agg;
+   uint32_t excl = d_block_scan256<uint32_t>(sum, s_wave, &agg);
+   if (threadIdx.x < 64) {
+      const uint32_t prefix = d_chain_prefix<uint32_t, 32>(status, tile, epoch, agg, threadIdx.x);
+      if (threadIdx.x == 0) s_prefix = prefix;
+   }
+   __syncthreads();
+   excl += s_prefix;
+   if (total && tile == n_tiles - 1 && threadIdx.x == 0) *total = (unsigned long long) s_prefix + agg;
+#pragma unroll
+   for (int k = 0; k < CHAIN_ITEMS; k++) {
+      if (base + k < n_words) tab[base + k] = (uint64_t) bits[k] | ((uint64_t) excl << 32);
+      excl += (uint32_t) __popc(bits[k]);
+   }
 }
 __global__ void k_join_probe_pairs(const DJoin* __restrict__ d);
 __global__ void k_join_probe_pairs_count(const DJoin* __restrict__ d);
@@ -493,8 +521,9 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
    ht->cap = std::max<uint64_t>(64, next_pow2_u64((uint64_t) build->n_rows * 2));
    h->n_rows = (uint64_t) build->n_rows;
    h->key32 = ht->key32;
-   uint32_t* dflags = (uint32_t*) (ctx->d_scratch + 24);
-   LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
+   // flags / counters: zeroed words of the context's arena (ldb_counters) — fresh ones for every pass instead of a clear
+   uint32_t* dflags;
+   LDB_TRY(ldb_counters(ctx, 1, (uint64_t**) &dflags));
    h->flags = (uint64_t) dflags;
    h->has_flags = 1;
    // KEY32: slots in key order (see DJoin::ordered_slots) — needs the build key range first
@@ -530,15 +559,12 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
           (range0 <= (unsigned __int128) std::max<int64_t>(4096, 64 * build->n_rows) || range0 <= ((unsigned __int128) 1 << 26)) && got[0] >= INT32_MIN && got[1] <= INT32_MAX && build->n_rows < (int64_t) LDB_NULL_ROW) {
          const uint64_t n_words = (uint64_t) (range0 / 32) + 1;
          uint64_t* tab = nullptr;
-         uint32_t *pop = nullptr, *off = nullptr;
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &tab, 8 * (size_t) n_words));
          ht->slots = tab; // (owned by the table object from here on: freed on every error return)
-         LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) n_words));
-         LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) n_words));
          LDB_HIP(hipMemsetAsync(tab, 0, 8 * (size_t) n_words, ctx->stream));
-         unsigned long long* counter = (unsigned long long*) (ctx->d_scratch + 16);
-         uint64_t* d_total = (uint64_t*) (ctx->d_scratch + 18);
-         LDB_HIP(hipMemsetAsync(counter, 0, 24, ctx->stream));
+         unsigned long long* counter;
+         LDB_TRY(ldb_counters(ctx, 3, (uint64_t**) &counter));
+         uint64_t* d_total = (uint64_t*) (counter + 2);
          h->direct = 2;
          h->kmin = got[0];
          h->kmax = got[1];
@@ -549,17 +575,17 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
          {
             LdbProf prof_(ctx, "k_join_build");
             hipLaunchKernelGGL(k_join_rank_bits, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dr);
-            hipLaunchKernelGGL(k_rank_pop, dim3(ldb_grid_for(ctx, (int64_t) n_words, 256, 8)), dim3(256), 0, ctx->stream, (const uint64_t*) tab, n_words, pop);
+            // popcounts → scan → prefix halves, one launch
+            const uint64_t n_tiles = (n_words + CHAIN_TILE - 1) / CHAIN_TILE;
+            ChainCall c;
+            LDB_TRY(ldb_chain_begin(ctx, n_tiles, false, &c));
+            hipLaunchKernelGGL(k_rank_prefix_chain, dim3((unsigned) n_tiles), dim3(256), 0, ctx->stream, tab, n_words, n_tiles, (unsigned long long*) d_total, c.status, c.ticket, c.ticket_base, c.epoch);
+            if (hipGetLastError() != hipSuccess) return ldb_chain_failed(ctx);
          }
-         LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, (int64_t) n_words, d_total));
-         hipLaunchKernelGGL(k_rank_prefix, dim3(ldb_grid_for(ctx, (int64_t) n_words, 256, 8)), dim3(256), 0, ctx->stream, tab, n_words, (const uint32_t*) off);
-         LDB_HIP(hipGetLastError());
          uint64_t back[3] = {0, 0, 0}; // non-NULL keys, —, distinct keys
          uint32_t fl[2] = {0, 0};
          LDB_TRY(LDB_READBACK(ctx, back, counter, 24));
          LDB_TRY(LDB_READBACK(ctx, fl, dflags, 8));
-         ldb_dev_free(ctx, pop);
-         ldb_dev_free(ctx, off);
          if (back[0] == back[2]) { // every non-NULL key set a bit of its own: unique
             ranked = true;
             ht->direct = 2;
@@ -596,7 +622,8 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
             build_unique = 0;
          }
          ldb_dev_free(ctx, dr);
-         LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
+         LDB_TRY(ldb_counters(ctx, 1, (uint64_t**) &dflags)); // (the passes below start from clean flags)
+         h->flags = (uint64_t) dflags;
       }
       if (ranked) {
          *out = ht.release();
@@ -683,7 +710,8 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
          ht->chained = 1;
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) build->n_rows));
          LDB_HIP(hipMemsetAsync(ht->slots, 0, ht->slot_bytes, ctx->stream));
-         LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
+         LDB_TRY(ldb_counters(ctx, 1, (uint64_t**) &dflags));
+         h->flags = (uint64_t) dflags;
          continue;
       }
       if ((f & 2) && !ht->chained) {
@@ -696,7 +724,8 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
             LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) build->n_rows));
          }
          LDB_HIP(hipMemsetAsync(ht->slots, 0, ht->slot_bytes, ctx->stream));
-         LDB_HIP(hipMemsetAsync(dflags, 0, 8, ctx->stream));
+         LDB_TRY(ldb_counters(ctx, 1, (uint64_t**) &dflags));
+         h->flags = (uint64_t) dflags;
          continue;
       }
       // the caller's promise of unique keys is verified: duplicates fall back to the general probe
@@ -791,8 +820,8 @@ static int32_t probe_count_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe,
    auto hp = std::make_unique<DJoin>();
    LDB_TRY(make_probe_desc(ht, probe, keys, n_keys, hp.get()));
    hp->kind = LDB_JOIN_INNER;
-   unsigned long long* counter = (unsigned long long*) (ctx->d_scratch + 16);
-   LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
+   unsigned long long* counter;
+   LDB_TRY(ldb_counters(ctx, 2, (uint64_t**) &counter));
    hp->counter = (uint64_t) counter;
    DJoin* d;
    LDB_TRY(ldb_dev_upload(ctx, hp.get(), sizeof(DJoin), (void**) &d));
@@ -880,8 +909,8 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       LDB_HIP(hipMemsetAsync(flags, 0, (size_t) (nb ? nb : 1), ctx->stream));
       hb->mark = (uint64_t) flags;
       hb->has_mark = 1;
-      unsigned long long* cnt = (unsigned long long*) (ctx->d_scratch + 16);
-      LDB_HIP(hipMemsetAsync(cnt, 0, 16, ctx->stream));
+      unsigned long long* cnt;
+      LDB_TRY(ldb_counters(ctx, 2, (uint64_t**) &cnt));
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, hb.get(), sizeof(DJoin), (void**) &d));
       if (probe->n_rows) LDB_TRY(launch_join(ctx, hb.get(), d, ldb_grid_for(ctx, probe->n_rows, 256, 8), "k_join_probe_markbuild", "k_join_probe_markbuild_spec", k_join_probe_markbuild));
@@ -903,7 +932,8 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
    DJoin* h = hp.get();
    LDB_TRY(make_probe_desc(ht, probe, keys, n_keys, h, resid, n_resid));
    h->kind = kind;
-   unsigned long long* counter = (unsigned long long*) (ctx->d_scratch + 16);
+   unsigned long long* counter; // [0] rows produced, [1] matches (+ 3 debug words): zeroed arena words
+   LDB_TRY(ldb_counters(ctx, 6, (uint64_t**) &counter));
    h->counter = (uint64_t) counter;
    const int64_t n = probe->n_rows;
    const int64_t n_words = (n + 63) / 64;
@@ -923,7 +953,6 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
          h->mark = (uint64_t) mark->cols[0].values;
          h->has_mark = 1;
       }
-      LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
       if (n) LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_exists", "k_join_probe_exists_spec", k_join_probe_exists));
@@ -968,10 +997,8 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       }
       h->match = (uint64_t) match;
       h->bitmap = (uint64_t) bitmap;
-      LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-      if (getenv("LDB_DEBUG_COUNTS")) LDB_HIP(hipMemsetAsync(counter, 0, 48, ctx->stream));
       if (n) LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_unique", "k_join_probe_unique_spec", k_join_probe_unique));
       ldb_dev_free(ctx, d);
       if (getenv("LDB_DEBUG_COUNTS")) {
@@ -1000,7 +1027,6 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &chunk_cnt, 4 * (size_t) (n_chunks ? n_chunks : 1)));
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &chunk_off, 4 * (size_t) (n_chunks ? n_chunks : 1)));
       h->match = (uint64_t) chunk_cnt;
-      LDB_HIP(hipMemsetAsync(counter, 0, 16, ctx->stream));
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
       if (n) {
@@ -1034,7 +1060,9 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
    const int cg = ldb_grid_for(ctx, (int64_t) produced, 256, 8);
    // LEFT_OUTER / SINGLE pad the build sides of unmatched probe rows with LDB_NULL_ROW
    const bool pads = kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE;
-   auto add_sides = [&](ldb_rel* src, uint32_t* sel, bool sel_may_null) -> int32_t {
+   std::vector<LdbComposeJob> jobs; // every side that needs its own vector: composed in ONE launch below
+   bool free_op = false, free_ob = false;
+   auto add_sides = [&](ldb_rel* src, uint32_t* sel, int which, bool sel_may_null, bool* free_sel) -> int32_t {
       bool sel_taken = false; // the first identity side IS the selection vector: hand it over, no copy
       for (auto& s : src->sides) {
          ldb_rel_side ns{s.table, nullptr, true, s.may_null || sel_may_null};
@@ -1043,16 +1071,19 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
             sel_taken = true;
          } else {
             LDB_TRY(ldb_dev_alloc(ctx, (void**) &ns.rowids, 4 * (size_t) (produced ? produced : 1)));
-            if (produced) hipLaunchKernelGGL(k_compose_null, dim3(cg), dim3(256), 0, ctx->stream, (const uint32_t*) s.rowids, (const uint32_t*) sel, ns.rowids, produced);
+            jobs.push_back({(const uint32_t*) s.rowids, ns.rowids, which});
          }
          r->sides.push_back(ns);
       }
-      if (!sel_taken) ldb_dev_free(ctx, sel);
+      *free_sel = !sel_taken;
       return LDB_OK;
    };
-   LDB_TRY(add_sides(probe, op, false));
-   LDB_TRY(add_sides(ht->build, ob, pads));
-   LDB_HIP(hipGetLastError());
+   (void) cg;
+   LDB_TRY(add_sides(probe, op, 0, false, &free_op));
+   LDB_TRY(add_sides(ht->build, ob, 1, pads, &free_ob));
+   LDB_TRY(ldb_compose_rowids(ctx, op, ob, jobs.data(), (int) jobs.size(), produced));
+   if (free_op) ldb_dev_free(ctx, op);
+   if (free_ob) ldb_dev_free(ctx, ob);
    *out = r;
    return LDB_OK;
 }

@@ -141,29 +141,24 @@ int32_t ldb_rel_select(ldb_ctx* ctx, ldb_rel* in, uint32_t* sel, int64_t n_sel, 
    ldb_rel* r = ldb_rel_new(ctx);
    r->n_rows = n_sel;
    bool sel_used = false;
+   std::vector<LdbComposeJob> jobs; // all sides that need a vector of their own: one launch
    for (auto& s : in->sides) {
       ldb_rel_side ns;
       ns.table = s.table;
       ns.may_null = s.may_null;
-      if (!s.rowids) {
-         if (!sel_used) {
-            ns.rowids = sel;
-            ns.owned = true;
-            sel_used = true;
-         } else { // a second identity side over the same logical rows shares ids by copy
-            LDB_TRY(ldb_dev_alloc(ctx, (void**) &ns.rowids, sizeof(uint32_t) * (size_t) (n_sel ? n_sel : 1)));
-            if (n_sel) LDB_HIP(hipMemcpyAsync(ns.rowids, sel, sizeof(uint32_t) * (size_t) n_sel, hipMemcpyDeviceToDevice, ctx->stream));
-            ns.owned = true;
-         }
-      } else {
+      if (!s.rowids && !sel_used) {
+         ns.rowids = sel;
+         ns.owned = true;
+         sel_used = true;
+      } else { // (a second identity side over the same logical rows gets a copy of the selection: ids == NULL)
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &ns.rowids, sizeof(uint32_t) * (size_t) (n_sel ? n_sel : 1)));
          ns.owned = true;
-         if (n_sel) hipLaunchKernelGGL(k_compose, dim3(ldb_grid_for(ctx, n_sel, 256, 8)), dim3(256), 0, ctx->stream, s.rowids, sel, ns.rowids, (uint64_t) n_sel);
+         jobs.push_back({(const uint32_t*) s.rowids, ns.rowids, 0});
       }
       r->sides.push_back(ns);
    }
+   LDB_TRY(ldb_compose_rowids(ctx, sel, nullptr, jobs.data(), (int) jobs.size(), (uint64_t) n_sel));
    if (!sel_used) ldb_dev_free(ctx, sel);
-   LDB_HIP(hipGetLastError());
    *out = r;
    return LDB_OK;
 }
@@ -188,9 +183,11 @@ static int32_t scan_run_with(ldb_ctx* ctx, int64_t n, LAUNCH launch, uint32_t** 
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &offsets, sizeof(uint32_t) * (size_t) n_blocks));
    LDB_TRY(launch(bitmap, counts, (unsigned) n_blocks));
    LDB_HIP(hipGetLastError());
-   LDB_TRY(ldb_exclusive_scan_u32(ctx, counts, offsets, n_blocks, (uint64_t*) ctx->d_scratch));
+   uint64_t* d_total;
+   LDB_TRY(ldb_counters(ctx, 1, &d_total));
+   LDB_TRY(ldb_exclusive_scan_u32(ctx, counts, offsets, n_blocks, d_total));
    uint64_t total = 0;
-   LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &total));
+   LDB_TRY(ldb_read_u64(ctx, d_total, &total));
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &sel, sizeof(uint32_t) * (size_t) (total ? total : 1)));
    if (total) hipLaunchKernelGGL(k_scan_expand, dim3((unsigned) n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, bitmap, offsets, sel, (uint64_t) n, total);
    LDB_HIP(hipGetLastError());
@@ -354,7 +351,8 @@ extern "C" int32_t ldb_gpu_scan_count(ldb_ctx* ctx, ldb_rel* in, const ldb_filte
    ldb_order_preds(h.preds, h.n_preds);
    DScan* d;
    LDB_TRY(ldb_dev_upload(ctx, &h, sizeof(h), (void**) &d));
-   LDB_HIP(hipMemsetAsync(ctx->d_scratch, 0, 8, ctx->stream));
+   uint64_t* d_cnt; // (a zeroed arena word: no clear of its own)
+   LDB_TRY(ldb_counters(ctx, 1, &d_cnt));
    if (in->n_rows) {
       hipFunction_t spec = nullptr;
       if (ldb_jit_wanted(in->n_rows)) {
@@ -363,7 +361,7 @@ extern "C" int32_t ldb_gpu_scan_count(ldb_ctx* ctx, ldb_rel* in, const ldb_filte
          std::string why;
          spec = ldb_jit_kernel(ctx->device, "ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, "k_scan_count_spec", &meta, sizeof(meta), &why);
       }
-      unsigned long long* total = (unsigned long long*) ctx->d_scratch;
+      unsigned long long* total = (unsigned long long*) d_cnt;
       const int grid = ldb_grid_for(ctx, in->n_rows, SCAN_BLOCK, 8);
       LdbProf prof_(ctx, "k_scan_count");
       if (spec) {
@@ -375,7 +373,7 @@ extern "C" int32_t ldb_gpu_scan_count(ldb_ctx* ctx, ldb_rel* in, const ldb_filte
    }
    LDB_HIP(hipGetLastError());
    uint64_t total = 0;
-   LDB_TRY(ldb_read_u64(ctx, ctx->d_scratch, &total));
+   LDB_TRY(ldb_read_u64(ctx, d_cnt, &total));
    ldb_dev_free(ctx, d);
    *count = (int64_t) total;
    return LDB_OK;

@@ -232,8 +232,8 @@ extern "C" int32_t ldb_gpu_set_op(ldb_ctx* ctx, ldb_rel* left, const ldb_colref*
    uint32_t *mult, *off, *sel;
    LDB_TRY(bufs.alloc(&mult, 4 * (size_t) (ng + 1)));
    LDB_TRY(bufs.alloc(&off, 4 * (size_t) (ng + 1)));
-   uint64_t* d_total = (uint64_t*) (ctx->d_scratch + 56);
-   LDB_HIP(hipMemsetAsync(d_total, 0, 8, ctx->stream));
+   uint64_t* d_total;
+   LDB_TRY(ldb_counters(ctx, 1, &d_total));
    uint64_t total = 0;
    if (ng) {
       hipLaunchKernelGGL(k_setop_multiplicity, dim3(ldb_grid_for(ctx, ng, 256, 8)), dim3(256), 0, ctx->stream, (const int64_t*) g.t->cols[(size_t) n_cols].values,
@@ -479,7 +479,8 @@ extern "C" int32_t ldb_gpu_window(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* p
    if (n_part) LDB_TRY(ldb_make_dkeys(sorted.r, part_keys, n_part, pk.get()));
    const int grid = ldb_grid_for(ctx, n, 256, 8);
    hipLaunchKernelGGL(k_win_heads, dim3(grid), dim3(256), 0, ctx->stream, *pk, (uint64_t) n, head);
-   uint64_t* d_total = (uint64_t*) (ctx->d_scratch + 56);
+   uint64_t* d_total;
+   LDB_TRY(ldb_counters(ctx, 1, &d_total));
    LDB_TRY(ldb_exclusive_scan_u32(ctx, head, pos, n, d_total));
    uint64_t n_seg = 0;
    LDB_TRY(ldb_read_u64(ctx, d_total, &n_seg));

@@ -352,7 +352,8 @@ static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint6
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &pop, 4 * (size_t) n_words));
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &off, 4 * (size_t) n_words));
       hipLaunchKernelGGL(k_sel_flags, dim3(grid), dim3(256), 0, ctx->stream, keys, words, n, sel_words, (const SelState*) state, bitmap, pop);
-      uint64_t* d_total = (uint64_t*) ctx->d_scratch;
+      uint64_t* d_total;
+      LDB_TRY(ldb_counters(ctx, 1, &d_total));
       LDB_TRY(ldb_exclusive_scan_u32(ctx, pop, off, (int64_t) n_words, d_total));
       LDB_TRY(ldb_read_u64(ctx, d_total, &m));
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &perm, 4 * (size_t) (m ? m : 1)));
@@ -393,8 +394,7 @@ static int32_t sort_perm(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, 
       const bool padded = sp.col.rowids && in->sides[(size_t) specs[s].col.side].may_null; // outer-join padding
       if (n && (sp.col.validity || padded || sp.col.type == LDB_T_UTF8)) {
          if (!any_chk) {
-            LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_chk, 8 * (size_t) (1 + SORT_MAX_SPECS)));
-            LDB_HIP(hipMemsetAsync(d_chk, 0, 8 * (size_t) (1 + SORT_MAX_SPECS), ctx->stream));
+            LDB_TRY(ldb_counters(ctx, 1 + SORT_MAX_SPECS, (uint64_t**) &d_chk)); // zeroed arena words
             any_chk = true;
          }
          // db.sort_compare is only defined for non-nullable operands (LowerToStd.cpp:1050-1052)
@@ -406,7 +406,6 @@ static int32_t sort_perm(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, 
    if (any_chk) {
       LDB_HIP(hipGetLastError());
       LDB_TRY(LDB_READBACK(ctx, chk, d_chk, sizeof(chk)));
-      ldb_dev_free(ctx, d_chk);
       if (chk[0] & 1) LDB_FAIL(LDB_ERR_UNSUPPORTED, "sort: a key contains NULLs (nullable sort keys are not lowered to db.sort_compare)");
    }
    int off = 0;

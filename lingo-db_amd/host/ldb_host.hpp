@@ -81,6 +81,8 @@ int32_t ldb_plan_prepare(ldb_ctx* ctx, const char* plan_json, ldb_plan** out);
 int32_t ldb_plan_execute(ldb_plan* plan, ldb_comm* comm, const char* const* table_names, const ldb_table* const* tables, int32_t n_tables, ldb_table** result);
 int32_t ldb_plan_release(ldb_plan* plan);
 int32_t ldb_plan_stats(const ldb_plan* plan, int64_t* executions, int64_t* replays, int64_t* misses, int64_t* readbacks);
+// over the replayed executions so far: host time spent issuing the plans / waiting in the single check at their ends
+int32_t ldb_plan_times(const ldb_plan* plan, double* issue_ms, double* wait_ms);
 // structure check without a device: parse, known steps with their required fields, values defined before use
 int32_t ldb_plan_json_check(const char* plan_json, const char* const* input_names, int32_t n_inputs);
 // ldb_subop.cpp: consumer of the reference's sub-operator dump (tools/ct/mlir-subop-to-json.cpp).  Translates the

@@ -16,6 +16,7 @@
 // compiled either into the aggregate normal form (ldb_expr) or into a postfix program (ldb_xinstr).
 #include "ldb_host.hpp"
 #include <cctype>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -900,6 +901,7 @@ struct ldb_plan {
    ldb_trace* trace = nullptr;
    std::vector<uint64_t> key; // what the trace was recorded under: per input (stamp, rows), option epoch, exchange or not
    int64_t executions = 0, replays = 0, misses = 0;
+   double issue_ms = 0, wait_ms = 0; // over the replayed executions: host time to issue the whole plan / time spent in the one wait at its end
 };
 
 namespace {
@@ -934,7 +936,17 @@ extern "C" int32_t ldb_plan_run_json_comm(ldb_ctx* ctx, ldb_comm* comm, const ch
    try {
       JParser parser(plan_json);
       const J plan = parser.value();
-      return runParsed(ctx, comm, plan, table_names, tables, n_tables, result);
+      // a one-off execution is bracketed like a prepared one (recording only): the context's counter arena restarts at the plan's
+      // first operator, so that a text that is run again builds the descriptors the descriptor cache already holds
+      ldb_trace* tr = nullptr;
+      const bool bracket = ldb_gpu_trace_create(ctx, &tr) == LDB_OK && ldb_gpu_trace_begin(ctx, tr, 0) == LDB_OK;
+      const int32_t st = runParsed(ctx, comm, plan, table_names, tables, n_tables, result);
+      if (bracket) {
+         int32_t status = 0;
+         (void) ldb_gpu_trace_end(ctx, &status);
+      }
+      if (tr) ldb_gpu_trace_destroy(ctx, tr);
+      return st;
    } catch (const std::exception& e) {
       g_plan_json_err = e.what();
       return LDB_ERR_INVALID;
@@ -987,7 +999,9 @@ extern "C" int32_t ldb_plan_execute(ldb_plan* p, ldb_comm* comm, const char* con
          return LDB_ERR_INVALID;
       }
       ldb_table* out = nullptr;
+      const auto t0 = std::chrono::steady_clock::now();
       const int32_t st = runParsed(p->ctx, comm, p->doc, table_names, tables, n_tables, &out);
+      const auto t1 = std::chrono::steady_clock::now();
       int32_t status = LDB_TRACE_OFF;
       if (ldb_gpu_trace_end(p->ctx, &status) != LDB_OK) {
          if (out) ldb_gpu_table_release(p->ctx, out);
@@ -1005,13 +1019,23 @@ extern "C" int32_t ldb_plan_execute(ldb_plan* p, ldb_comm* comm, const char* con
          p->key.clear();
          return st;
       }
-      if (status == LDB_TRACE_REPLAYED) p->replays++;
+      if (status == LDB_TRACE_REPLAYED) {
+         p->replays++;
+         p->issue_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+         p->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+      }
       p->key = key;
       *result = out;
       return LDB_OK;
    }
    g_plan_json_err = "plan_execute: the execution could not be completed after a failed replay";
    return LDB_ERR_INVALID;
+}
+extern "C" int32_t ldb_plan_times(const ldb_plan* p, double* issue_ms, double* wait_ms) {
+   if (!p) return LDB_ERR_INVALID;
+   if (issue_ms) *issue_ms = p->issue_ms;
+   if (wait_ms) *wait_ms = p->wait_ms;
+   return LDB_OK;
 }
 extern "C" int32_t ldb_plan_stats(const ldb_plan* p, int64_t* executions, int64_t* replays, int64_t* misses, int64_t* readbacks) {
    if (!p) return LDB_ERR_INVALID;

@@ -502,6 +502,12 @@ class Comm:
             self.ctx.lib.ldb_gpu_comm_destroy(self.h)
             self.h = None
 
+    def stats(self, reset=False):
+        """traffic and time of this rank's exchanges since the last reset (ldb_gpu_comm_stats)"""
+        s = capi.CommStats()
+        check(self.ctx.lib.ldb_gpu_comm_stats(self.h, C.byref(s), 1 if reset else 0))
+        return {f: getattr(s, f) for f, _ in capi.CommStats._fields_}
+
     def allgather(self, table, name="gathered"):
         t = C.c_void_p()
         check(self.ctx.lib.ldb_gpu_allgather(self.ctx.h, self.h, table.h, name.encode(), C.byref(t)))
@@ -579,7 +585,11 @@ class PreparedPlan:
     def stats(self):
         v = [C.c_int64() for _ in range(4)]
         capi.host_lib().ldb_plan_stats(self.h, *[C.byref(x) for x in v])
-        return dict(zip(("executions", "replays", "misses", "readbacks"), (x.value for x in v)))
+        out = dict(zip(("executions", "replays", "misses", "readbacks"), (x.value for x in v)))
+        a, b = C.c_double(), C.c_double()
+        capi.host_lib().ldb_plan_times(self.h, C.byref(a), C.byref(b))
+        out["issue_ms"], out["wait_ms"] = a.value, b.value
+        return out
 
     def release(self):
         if self.h and self.ctx.h:

@@ -112,6 +112,10 @@ class XInstr(C.Structure):
 X_COL, X_CONST, X_ADD, X_SUB, X_MUL, X_SDIV, X_MUL_POW10, X_SDIV_POW10, X_NEG, X_CMP, X_AND, X_OR, X_NOT, X_SELECT, X_ISNULL, X_COALESCE = range(16)
 
 
+class CommStats(C.Structure):
+    _fields_ = [("groups", C.c_int64), ("bytes_out", C.c_int64), ("bytes_in", C.c_int64), ("max_peer_bytes_out", C.c_int64), ("host_ms", C.c_double), ("device_ms", C.c_double)]
+
+
 class ArrowSchema(C.Structure):
     pass
 
@@ -230,6 +234,7 @@ GPU_API = {
     "ldb_gpu_set_op": (i32, [P, P, C.POINTER(ColRef), P, C.POINTER(ColRef), i32, i32, PP]),
     "ldb_gpu_window": (i32, [P, P, C.POINTER(ColRef), i32, C.POINTER(SortSpec), i32, i64, i64, C.POINTER(WindowFn), i32, PP, PP]),
     "ldb_gpu_comm_transport": (C.c_char_p, [P]),
+    "ldb_gpu_comm_stats": (i32, [P, C.POINTER(CommStats), i32]),
     "ldb_gpu_comm_available": (i32, []),
     "ldb_gpu_comm_create_host": (i32, [i32, i32, P, PP]),
     "ldb_gpu_comm_alltoall_bytes": (i32, [P, P, C.POINTER(C.c_int64), P, C.POINTER(C.c_int64)]),
@@ -259,6 +264,7 @@ HOST_API = {
     "ldb_plan_execute": (i32, [P, P, C.POINTER(C.c_char_p), C.POINTER(P), i32, PP]),
     "ldb_plan_release": (i32, [P]),
     "ldb_plan_stats": (i32, [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "ldb_plan_times": (i32, [P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ldb_plan_json_check": (i32, [C.c_char_p, C.POINTER(C.c_char_p), i32]),
     "ldb_subop_translate": (i32, [C.c_char_p, C.c_char_p, C.c_char_p, i64, C.POINTER(i64)]),
     "ldb_subop_last_error": (C.c_char_p, []),

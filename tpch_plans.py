@@ -187,6 +187,21 @@ class Runner:
         self.last[q] = res
         return res
 
+    def prepared_stats(self):
+        """executions / replays / mis-speculations of the prepared plans + the context's descriptor-cache counters"""
+        tot = {"executions": 0, "replays": 0, "misses": 0, "readbacks_per_pass": 0, "host_issue_ms_per_replay": {}, "host_wait_ms_per_replay": {}}
+        for q, p in sorted(self.prepared.items()):
+            st = p.stats()
+            tot["executions"] += st["executions"]
+            tot["replays"] += st["replays"]
+            tot["misses"] += st["misses"]
+            tot["readbacks_per_pass"] += st["readbacks"]
+            if st["replays"]:  # how long the host needs to issue the plan vs how long it then waits for the device
+                tot["host_issue_ms_per_replay"]["Q%d" % q] = round(st["issue_ms"] / st["replays"], 3)
+                tot["host_wait_ms_per_replay"]["Q%d" % q] = round(st["wait_ms"] / st["replays"], 3)
+        tot["descriptor_cache"] = self.ctx.desc_cache_stats()
+        return tot
+
     def plan_inputs(self, q):
         inputs = {name: getattr(self.db, attr) for name, attr in JSON_PLANS[q].items()}
         if self.sharded():
@@ -363,10 +378,13 @@ def cpu_baseline(queries, sample_sf, runs="1+3", budget_s=100.0, ctx=None, narro
         if time.perf_counter() - t_start > budget_s and q not in (1, 6, 3):
             continue
         ts = []
-        for r in range(warm + measured):
+        # the three queries of BASELINE configs[1..2] follow the reference's own protocol (tools/scripts/benchmark.py:32-33: 3 warm-up + 10
+        # measured) whatever `runs` says; the others use `runs` inside the time budget
+        w_q, m_q = (max(warm, 3), max(measured, 10)) if q in (1, 6, 3) else (warm, measured)
+        for r in range(w_q + m_q):
             t0 = time.perf_counter()
             rows = legs.run(q)
-            if r >= warm:
+            if r >= w_q:
                 ts.append((time.perf_counter() - t0) * 1000.0)
         leg_rows[q] = rows
         med[q], mn[q] = statistics.median(ts), min(ts)
@@ -374,7 +392,7 @@ def cpu_baseline(queries, sample_sf, runs="1+3", budget_s=100.0, ctx=None, narro
     gm = math.exp(sum(math.log(max(med[q], 1e-9)) for q in done) / max(len(done), 1))
     out = {"value": round(gm, 3), "unit": "ms", "cores": legs.threads, "kind": "port",
            "sample": "SF%g (%d orders; same generator and seed as the GPU leg): oracle restatement of the reference CPU path (reference binary not buildable offline), "
-                     "%d threads, morsel 20000, %d warm-up + %d measured passes per query; geomean of the per-query medians over %s%s" % (
+                     "%d threads, morsel 20000, %d warm-up + %d measured passes per query (Q1 / Q6 / Q3: 3 + 10, the reference's benchmark.py protocol); geomean of the per-query medians over %s%s" % (
                          sample_sf, n_orders, legs.threads, warm, measured, "+".join("Q%d" % q for q in done),
                          "" if len(done) == len(queries) else " (time budget %g s: %s not measured)" % (budget_s, "+".join("Q%d" % q for q in queries if q not in med))),
            "per_query_median_ms": {"Q%d" % q: round(med[q], 3) for q in done}, "per_query_min_ms": {"Q%d" % q: round(mn[q], 3) for q in done}, "sample_sf": sample_sf,
