@@ -88,6 +88,83 @@ def make_comm(ctx, rank, world, dist, torch, backend):
     raise SystemExit("bench.py: no exchange transport works on every rank")
 
 
+def dry_run(args):
+    """What `--gpus N --sf S --queries …` needs per rank, computed on the host (the generator is a pure function of (table, row)):
+    rows of every table fragment (ldb_tpch_host_rows), bytes of the resident columns (fixed widths; utf8 from a 20 000-order sample
+    of the host generator), the largest row-id space, and — for plans with a shuffle — the bytes a rank sends if its rows spread evenly.
+    Budgets: 288 GB of HBM per MI355X (80 % usable by tables + intermediates), uint32 row ids (4 294 967 294 rows per fragment)."""
+    import ctypes as C
+
+    import tpch_plans
+    from lingodb_amd import capi
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tpch_data
+
+    lib = capi.host_lib()
+    world = args.gpus
+    queries = [int(q) for q in args.queries.split(",") if q] or list(range(1, 23))
+    n_orders = int(round(args.sf * ORDERS_PER_SF))
+    tables = tpch_plans.Database.tables_for(queries)
+    HBM, USABLE, ROWID_MAX = 288e9, 0.8, 4294967294
+    sample_orders = 20000
+
+    def col_bytes_per_row(table_id, col):
+        typ = tpch_data.SCHEMAS[table_id][col][1]
+        import pyarrow as pa
+
+        if pa.types.is_string(typ):
+            n = lib.ldb_tpch_host_rows(table_id, sample_orders, 0, 1)
+            offs = (C.c_int64 * (n + 1))()
+            nbytes = C.c_int64()
+            lib.ldb_tpch_host_column(table_id, col, sample_orders, 0, 1, None, offs, C.byref(nbytes))
+            return 8.0 + nbytes.value / max(n, 1)  # int64 offsets on the device + the bytes
+        if pa.types.is_decimal(typ):
+            return 8.0 if args.narrow_decimals else 16.0
+        return 4.0
+
+    per_row = {(tid, c): col_bytes_per_row(tid, c) for _, tid, cols in tables for c in cols}
+    ranks = []
+    for r in range(world):
+        rows, resident = {}, 0.0
+        for attr, tid, cols in tables:
+            n = int(lib.ldb_tpch_host_rows(tid, n_orders, r, world))
+            rows[attr] = n
+            resident += n * sum(per_row[(tid, c)] for c in cols)
+        ranks.append({"rank": r, "rows": rows, "resident_bytes": int(resident), "max_fragment_rows": max(rows.values())})
+    # exchange volume of the sharded plans' shuffle steps over base tables (the large ones): the listed columns of every row, (N-1)/N of them leave the rank
+    shuffles = []
+    for q in queries:
+        path = os.path.join(ROOT, "lingo-db_amd", "plans", "tpch", "dist", "q%d.json" % q)
+        if world == 1 or not os.path.exists(path):
+            continue
+        with open(path) as f:
+            plan = json.load(f)
+        # which base table a value's ROWS come from: a step keeps the row lineage of its "in" (a join probe emits probe rows)
+        origin = {name: attr for name, attr in tpch_plans.JSON_PLANS[q].items()}
+        width_of = {n: per_row.get((tid, i), 4.0) for _, tid, cols in tables for i, (n, _) in enumerate(tpch_data.SCHEMAS[tid]) if i in cols}
+        for st in plan["steps"]:
+            src = st.get("in") or st.get("table")
+            if st.get("out") and src in origin and st["op"] not in ("groupby", "allgather"):
+                origin[st["out"]] = origin[src]
+            if st["op"] == "shuffle" and st["in"] in origin and any(a == origin[st["in"]] for a, _, _ in tables):
+                attr = origin[st["in"]]
+                names = [c if isinstance(c, str) else c["col"] for c in st["cols"]]
+                bpr = sum(width_of.get(n, 8.0) for n in names)  # (a computed column: 8 bytes)
+                out = max(rk["rows"][attr] for rk in ranks) * bpr * (world - 1) / world
+                shuffles.append({"query": q, "input": st["in"], "rows_descend_from": attr, "bytes_per_row": round(bpr, 1), "bytes_out_per_rank_upper_bound": int(out),
+                                 "note": "every row of the fragment (the filters and semi joins in front of the shuffle only lower it; Q9's '%green%' keeps 5.4 %)",
+                                 "ms_at_xgmi_link_rate_upper_bound": round(out / max(world - 1, 1) / 153e9 * 1e3, 2)})
+    worst = max(ranks, key=lambda rk: rk["resident_bytes"])
+    biggest_shuffle = max([s["bytes_out_per_rank_upper_bound"] for s in shuffles] or [0])
+    # intermediates: a shuffled input arrives once more on the receiving side; hash tables / row-id vectors stay below the largest fragment's touched columns
+    need = worst["resident_bytes"] + 2 * biggest_shuffle + 0.25 * worst["resident_bytes"]
+    checks = {"row_ids_fit_uint32": all(rk["max_fragment_rows"] <= ROWID_MAX for rk in ranks), "hbm_fits": need <= HBM * USABLE}
+    return {"dry_run": True, "n_gpus": world, "sf": args.sf, "queries": queries, "n_orders_total": n_orders, "narrow_decimals": bool(args.narrow_decimals),
+            "per_rank": ranks, "shuffles_of_base_tables": shuffles, "hbm_bytes_per_gpu": int(HBM), "hbm_needed_worst_rank": int(need),
+            "hbm_model": "resident columns + 2 x the largest shuffled input + 25 % for hash tables and row-id vectors, against 80 % of 288 GB", "checks": checks}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,7 +176,11 @@ def main():
     ap.add_argument("--cpu-sample-sf", type=float, default=10.0, help="scale of the CPU-baseline sample (0 = skip); the GPU runs the same sample beside it")
     ap.add_argument("--cpu-runs", default="1+3", help="CPU baseline protocol warm-up+measured passes (the reference's tools/scripts/benchmark.py uses 3+10)")
     ap.add_argument("--cpu-budget-s", type=float, default=100.0, help="stop starting new CPU legs after this many seconds (the line names the queries measured)")
+    ap.add_argument("--dry-run", action="store_true", help="no device, no torch: per-rank rows / resident bytes / exchange volume of the configuration against the HBM and row-id budgets")
     args = ap.parse_args()
+    if args.dry_run:
+        print(json.dumps(dry_run(args)), flush=True)
+        return
 
     import torch
     import torch.distributed as dist

@@ -382,7 +382,9 @@ typedef enum {
    LDB_X_NOT = 12,
    LDB_X_SELECT = 13, /* c a b → (c is true) ? a : b */
    LDB_X_ISNULL = 14,
-   LDB_X_COALESCE = 15 /* a b → a unless NULL, then b */
+   LDB_X_COALESCE = 15, /* a b → a unless NULL, then b */
+   LDB_X_ROW = 16 /* push the LOGICAL row number of the relation (0 … n-1): the identity of a tuple of the outer stream when a
+                     nested_map's inner pipeline is reduced per outer tuple (subop.nested_map, SubOpToControlFlow.cpp:1204-1250) */
 } ldb_xop;
 typedef struct {
    int32_t op; /* ldb_xop */

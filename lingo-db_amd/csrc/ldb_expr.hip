@@ -80,7 +80,8 @@ extern "C" int32_t ldb_gpu_map_expr(ldb_ctx* ctx, ldb_rel* in, const ldb_xinstr*
             if (x.col.type == LDB_T_UTF8 || x.col.type == LDB_T_FLOAT32 || x.col.type == LDB_T_FLOAT64) LDB_FAIL(LDB_ERR_UNSUPPORTED, "map_expr: instruction %d: integer / decimal / date / bool columns only", k);
             break;
          }
-         case LDB_X_CONST: break;
+         case LDB_X_CONST:
+         case LDB_X_ROW: break;
          case LDB_X_ADD:
          case LDB_X_SUB:
          case LDB_X_MUL:

@@ -44,6 +44,11 @@ __device__ __forceinline__ void map_expr_body(const DXProg& m, const DXProg* __r
                nul[sp] = false;
                sp++;
                break;
+            case LDB_X_ROW:
+               st[sp] = (i128) i;
+               nul[sp] = false;
+               sp++;
+               break;
             case LDB_X_ADD:
             case LDB_X_SUB:
             case LDB_X_MUL:

@@ -15,10 +15,12 @@
 // expressions are trees typed by the reference's decimal rules (sql_analyzer.cpp:3058-3159) and
 // compiled either into the aggregate normal form (ldb_expr) or into a postfix program (ldb_xinstr).
 #include "ldb_host.hpp"
+#include <algorithm>
 #include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <sstream>
 
@@ -161,10 +163,18 @@ struct Interp {
          int64_t t;
          memcpy(&t, buf.data(), 8);
          x = t;
-      } else {
+      } else if (w == 4) {
          int32_t t;
          memcpy(&t, buf.data(), 4);
          x = t;
+      } else if (w == 2) {
+         int16_t t;
+         memcpy(&t, buf.data(), 2);
+         x = t;
+      } else if (w == 1) { // int8 / bool
+         x = (int8_t) buf[0];
+      } else {
+         throw std::runtime_error("plan: scalar source column of width " + std::to_string(w));
       }
       return x;
    }
@@ -417,6 +427,19 @@ struct Interp {
          b.ins.insert(b.ins.end(), rb.ins.begin(), rb.ins.end());
          b.push(LDB_X_SDIV);
          return decScalar(t);
+      }
+      if (op == "idiv") { // integer division of two integers (arith.divsi: truncating) — the result stays an integer
+         arity(2);
+         const Scalar l = compileX(sides, args.arr[0], b);
+         const Scalar r = compileX(sides, args.arr[1], b);
+         if (l.kind != Scalar::INT || r.kind != Scalar::INT) throw std::runtime_error("plan: idiv takes two integers (decimals divide with 'div')");
+         b.push(LDB_X_SDIV);
+         return Scalar{};
+      }
+      if (op == "row_number") { // the logical row number of the input relation, 0 … n-1 (a tuple's identity inside nested_map)
+         arity(0);
+         b.push(LDB_X_ROW);
+         return Scalar{};
       }
       if (op == "cmp") { // ["GT", a, b]
          arity(3);
@@ -874,8 +897,181 @@ struct Interp {
             i++;
          }
          putTable(st.s("out"), out);
+      } else if (op == "nested_map") {
+         nestedMap(st);
+      } else if (op == "loop") {
+         loop(st);
       } else {
          throw std::runtime_error("unknown step");
+      }
+   }
+
+   // ------------------------------------------------------------ nested_map / loop
+   static J jStr(const std::string& s) {
+      J j;
+      j.kind = J::STR;
+      j.str = s;
+      return j;
+   }
+   static J jObj(std::vector<std::pair<std::string, J>> fields) {
+      J j;
+      j.kind = J::OBJ;
+      j.obj = std::move(fields);
+      return j;
+   }
+   static J jArr(std::vector<J> items) {
+      J j;
+      j.kind = J::ARR;
+      j.arr = std::move(items);
+      return j;
+   }
+   int tmpCounter = 0;
+   // subop.nested_map (NestedMapLowering, SubOpToControlFlow.cpp:3996-4048): for every tuple of the outer stream the nested steps
+   // run with the tuple's columns as parameters — in kmeans.mlir / pagerank.mlir: scan a state, map over (outer tuple, scanned
+   // tuple), reduce into a per-tuple simple_state, scan that state.  On the device the correlation is removed: the outer tuples get
+   // their row number as identity, the nested scan becomes a nested-loop join (outer x scanned state, optional residual conjuncts),
+   // the nested maps run over the pairs, and the per-tuple state is a group-by on the identity.  Without "reduce" the pairs
+   // themselves are the result (the nested stream returned as it is).
+   //   {"op": "nested_map", "in": outer, "scan": inner, "residual": [...], "map": [{"as", "expr"} …],
+   //    "reduce": {"aggs": [...], "keep": [outer columns]}, "out": name}
+   void nestedMap(const J& st) {
+      const std::string base = "__nm" + std::to_string(tmpCounter++) + "_";
+      const std::string& out = st.s("out");
+      const J* red = st.get("reduce");
+      std::string cur = st.s("in");
+      if (red) {
+         step(jObj({{"op", jStr("map")}, {"in", jStr(cur)}, {"as", jStr("__tuple")}, {"expr", jObj({{"row_number", jArr({})}})}, {"out", jStr(base + "id")}}));
+         cur = base + "id";
+      }
+      {
+         std::vector<std::pair<std::string, J>> f = {{"op", jStr("join_nl")}, {"in", jStr(cur)}, {"build", jStr(st.s("scan"))}, {"kind", jStr("inner")}, {"out", jStr(base + "pairs")}};
+         if (const J* rs = st.get("residual")) f.push_back({"residual", *rs});
+         step(jObj(std::move(f)));
+         cur = base + "pairs";
+      }
+      int k = 0;
+      if (const J* maps = st.get("map"))
+         for (auto& m : maps->arr) {
+            const std::string nm = base + "m" + std::to_string(k++);
+            step(jObj({{"op", jStr("map")}, {"in", jStr(cur)}, {"as", jStr(m.s("as"))}, {"expr", m.at("expr")}, {"out", jStr(nm)}}));
+            cur = nm;
+         }
+      if (!red) { // the nested stream itself: the last value under the step's name
+         auto it = env.find(cur);
+         Value v = std::move(it->second);
+         env.erase(it);
+         put(out, std::move(v));
+         return;
+      }
+      std::vector<J> aggs = red->at("aggs").arr;
+      if (const J* keep = red->get("keep"))
+         for (auto& c : keep->arr) aggs.push_back(jObj({{"fn", jStr("any")}, {"expr", jStr(c.str)}, {"as", jStr(c.str)}}));
+      step(jObj({{"op", jStr("groupby")}, {"in", jStr(cur)}, {"keys", jArr({jStr("__tuple")})}, {"aggs", jArr(std::move(aggs))}, {"est_groups", jObj({{"rows_of", jStr(st.s("in"))}})}, {"out", jStr(out)}}));
+   }
+
+   // subop.loop (LoopLowering, SubOpToControlFlow.cpp:4058-4120: an scf.while over (condition, loop-carried states)): the body's
+   // steps run once per iteration with the loop variables bound to the current states; loop_continue names the condition (a member
+   // of a simple_state, here: column `col` of the one-row table `from`) and the states of the next iteration.  As in the
+   // reference the loop's results are the states handed to the LAST loop_continue (the one whose condition was false).
+   //   {"op": "loop", "vars": [{"name", "init"}], "body": [steps], "continue": {"from", "col"}, "next": [{"var", "from"}],
+   //    "results": [{"name", "var"}], "max_iterations": 1000}
+   // Loop-carried values are tables (materialised states: buffers, simple states, hash-map contents).
+   void loop(const J& st) {
+      struct Var {
+         std::string name, next, result;
+         const ldb_table* cur = nullptr;
+         bool owned = false;
+      };
+      std::vector<Var> vars;
+      for (auto& jv : st.at("vars").arr) {
+         Var v;
+         v.name = jv.s("name");
+         Value& init = val(jv.s("init"));
+         if (init.kind != Value::TABLE) throw std::runtime_error("loop: the initial value of '" + v.name + "' must be a table (materialize first)");
+         v.cur = init.table;
+         vars.push_back(v);
+      }
+      for (auto& jn : st.at("next").arr) {
+         bool found = false;
+         for (auto& v : vars)
+            if (v.name == jn.s("var")) v.next = jn.s("from"), found = true;
+         if (!found) throw std::runtime_error("loop: next names the unknown variable '" + jn.s("var") + "'");
+      }
+      for (auto& v : vars)
+         if (v.next.empty()) throw std::runtime_error("loop: no next value for '" + v.name + "'");
+      for (auto& jr : st.at("results").arr)
+         for (auto& v : vars)
+            if (v.name == jr.s("var")) v.result = jr.s("name");
+      const J& body = st.at("body");
+      const J& cont = st.at("continue");
+      const int64_t maxIter = st.iOr("max_iterations", 1000);
+      auto releaseVar = [&](Var& v) {
+         if (v.owned && v.cur) ldb_gpu_table_release(ctx, const_cast<ldb_table*>(v.cur));
+         v.cur = nullptr;
+         v.owned = false;
+      };
+      try {
+         for (int64_t iter = 0;; iter++) {
+            if (iter >= maxIter) throw std::runtime_error("loop: no fixpoint after " + std::to_string(maxIter) + " iterations");
+            std::vector<std::string> before;
+            for (auto& kv : env) before.push_back(kv.first);
+            const size_t hiddenBefore = hidden.size();
+            for (auto& v : vars) {
+               Value b;
+               b.kind = Value::TABLE;
+               b.table = v.cur;
+               b.owned = false; // the loop owns it
+               put(v.name, std::move(b));
+            }
+            for (auto& s : body.arr) step(s);
+            // the condition and the next states, read before the iteration's values go away
+            bool again = false;
+            if (rowsOf(cont.s("from")) >= 1 && !scalarIsNull(cont.s("from"), cont.s("col"))) again = readScalar(cont.s("from"), cont.s("col")) != 0;
+            std::vector<const ldb_table*> nexts;
+            for (auto& v : vars) {
+               Value& nv = val(v.next);
+               if (nv.kind != Value::TABLE || !nv.owned) throw std::runtime_error("loop: the next value '" + v.next + "' must be a table produced inside the body");
+               nexts.push_back(nv.table);
+               nv.owned = false; // taken over by the loop
+            }
+            // everything else the body defined dies with the iteration: hash tables, then relations, then tables
+            std::vector<std::string> mine;
+            for (auto& kv : env)
+               if (!std::binary_search(before.begin(), before.end(), kv.first)) mine.push_back(kv.first);
+            for (auto& n : mine) {
+               Value& v = env[n];
+               if (v.kind == Value::HT && v.owned && v.ht) ldb_gpu_hashtable_release(ctx, v.ht);
+            }
+            for (auto& n : mine) {
+               Value& v = env[n];
+               if (v.lazyRel) ldb_gpu_rel_release(ctx, v.lazyRel);
+               if (v.kind == Value::REL && v.owned && v.rel) ldb_gpu_rel_release(ctx, v.rel);
+            }
+            for (auto& n : mine) {
+               Value& v = env[n];
+               if (v.kind == Value::TABLE && v.owned && v.table) ldb_gpu_table_release(ctx, const_cast<ldb_table*>(v.table));
+               env.erase(n);
+            }
+            for (size_t h = hiddenBefore; h < hidden.size(); h++) ldb_gpu_table_release(ctx, hidden[h]);
+            hidden.resize(hiddenBefore);
+            for (size_t i = 0; i < vars.size(); i++) {
+               releaseVar(vars[i]);
+               vars[i].cur = nexts[i];
+               vars[i].owned = true;
+            }
+            if (!again) break;
+         }
+      } catch (...) {
+         for (auto& v : vars) releaseVar(v);
+         throw;
+      }
+      for (auto& v : vars) {
+         if (v.result.empty()) {
+            releaseVar(v);
+         } else {
+            putTable(v.result, const_cast<ldb_table*>(v.cur));
+            v.cur = nullptr;
+         }
       }
    }
 };
@@ -1075,11 +1271,38 @@ extern "C" int32_t ldb_plan_json_check(const char* plan_json, const char* const*
       static const std::vector<Shape> shapes = {{"scan", {"table"}, {}},           {"filter", {"in"}, {"preds"}},        {"filter_dnf", {"in"}, {"clauses"}},
                                                 {"join_build", {"in"}, {"keys"}},  {"join_probe", {"ht", "in"}, {"keys"}}, {"groupby", {"in"}, {"aggs"}},
                                                 {"map", {"in"}, {"as"}},           {"sort", {"in"}, {"by"}},             {"topk", {"in"}, {"by", "k"}},
-                                                {"materialize", {"in"}, {"cols"}}, {"join_nl", {"in", "build"}, {}}, {"allgather", {"in"}, {}},           {"shuffle", {"in"}, {"keys", "cols"}}};
+                                                {"materialize", {"in"}, {"cols"}}, {"join_nl", {"in", "build"}, {}}, {"allgather", {"in"}, {}},           {"shuffle", {"in"}, {"keys", "cols"}},
+                                                {"nested_map", {"in", "scan"}, {}}};
       const J& steps = plan.at("steps");
       if (steps.kind != J::ARR) throw std::runtime_error("plan: 'steps' must be an array");
-      for (auto& st : steps.arr) {
+      std::function<void(const J&, std::map<std::string, bool>&)> checkSteps = [&](const J& list, std::map<std::string, bool>& known) {
+      for (auto& st : list.arr) {
          const std::string& op = st.s("op");
+         if (op == "loop") { // variables bound from existing tables, a body with its own scope, results defined afterwards
+            std::map<std::string, bool> inner = known;
+            std::vector<std::string> vars;
+            for (auto& v : st.at("vars").arr) {
+               if (!known.count(v.s("init"))) throw std::runtime_error("plan: loop variable '" + v.s("name") + "' starts from '" + v.s("init") + "' before it exists");
+               if (inner.count(v.s("name"))) throw std::runtime_error("plan: value '" + v.s("name") + "' defined twice");
+               inner[v.s("name")] = true;
+               vars.push_back(v.s("name"));
+            }
+            if (st.at("body").kind != J::ARR) throw std::runtime_error("plan: loop 'body' must be an array of steps");
+            checkSteps(st.at("body"), inner);
+            if (!inner.count(st.at("continue").s("from"))) throw std::runtime_error("plan: loop condition reads '" + st.at("continue").s("from") + "' before it exists");
+            (void) st.at("continue").s("col");
+            for (auto& n : st.at("next").arr) {
+               if (std::find(vars.begin(), vars.end(), n.s("var")) == vars.end()) throw std::runtime_error("plan: loop 'next' names the unknown variable '" + n.s("var") + "'");
+               auto it = inner.find(n.s("from"));
+               if (it == inner.end() || known.count(n.s("from"))) throw std::runtime_error("plan: loop 'next' value '" + n.s("from") + "' is not produced by the body");
+            }
+            for (auto& r : st.at("results").arr) {
+               if (std::find(vars.begin(), vars.end(), r.s("var")) == vars.end()) throw std::runtime_error("plan: loop result names the unknown variable '" + r.s("var") + "'");
+               if (known.count(r.s("name"))) throw std::runtime_error("plan: value '" + r.s("name") + "' defined twice");
+               known[r.s("name")] = true;
+            }
+            continue;
+         }
          const Shape* sh = nullptr;
          for (auto& c : shapes)
             if (op == c.op) sh = &c;
@@ -1093,6 +1316,8 @@ extern "C" int32_t ldb_plan_json_check(const char* plan_json, const char* const*
          known[out] = true;
          if (const J* mo = st.get("mark_out")) known[mo->str] = true;
       }
+      };
+      checkSteps(steps, known);
       const std::string result = plan.sOr("result", "result");
       auto it = known.find(result);
       if (it == known.end() || !it->second) throw std::runtime_error("plan: result '" + result + "' is not produced by a step");

@@ -109,7 +109,7 @@ class XInstr(C.Structure):
     _fields_ = [("op", C.c_int32), ("arg", C.c_int32), ("col", ColRef), ("lo", C.c_int64), ("hi", C.c_int64)]
 
 
-X_COL, X_CONST, X_ADD, X_SUB, X_MUL, X_SDIV, X_MUL_POW10, X_SDIV_POW10, X_NEG, X_CMP, X_AND, X_OR, X_NOT, X_SELECT, X_ISNULL, X_COALESCE = range(16)
+X_COL, X_CONST, X_ADD, X_SUB, X_MUL, X_SDIV, X_MUL_POW10, X_SDIV_POW10, X_NEG, X_CMP, X_AND, X_OR, X_NOT, X_SELECT, X_ISNULL, X_COALESCE, X_ROW = range(17)
 
 
 class CommStats(C.Structure):

@@ -114,6 +114,64 @@ def main():
     if rank == 0:
         print(f"[dist-check] hash shuffle: {'OK' if same else 'MISMATCH'} {allc.column(0).to_pylist()}", flush=True)
     ok = ok and same
+    # ---- skew: most rows carry ONE key, so one rank receives almost everything (receive buffers sized from the peers' counts)
+    if os.environ.get("LDB_CHECK_SKEW", "1") != "0":
+        import numpy as np
+
+        n = 40_000
+        rng = np.random.default_rng(100 + rank)
+        k = np.where(rng.random(n) < 0.85, 7, rng.integers(0, 5000, n)).astype(np.int32)
+        v = rng.integers(0, 1000, n).astype(np.int64)
+        tk = ctx.register("skew_%d" % rank, pa.table({"k": pa.array(k, pa.int32()), "v": pa.array(v, pa.int64()), "s": pa.array(["k%d" % x for x in k], pa.string())}))
+        shk = comm.shuffle(tk.rel(), [(0, 0)], [(0, 0), (0, 1), (0, 2)], "skewed")
+        part = ctx.run_plan('{"steps": [{"op": "groupby", "in": "t", "keys": ["k"], "aggs": [{"fn": "count_star", "as": "n"}, {"fn": "sum", "expr": "v", "as": "sv"}], "est_groups": 6000, "out": "result"}], "result": "result"}',
+                            {"t": shk})
+        allp = comm.allgather(part, "skew_groups").to_arrow()
+        got_groups = sorted(zip(allp.column(0).to_pylist(), allp.column(1).to_pylist(), allp.column(2).to_pylist()))
+        want = {}
+        for r in range(world):
+            rr = np.random.default_rng(100 + r)
+            kk = np.where(rr.random(n) < 0.85, 7, rr.integers(0, 5000, n)).astype(np.int32)
+            vv = rr.integers(0, 1000, n).astype(np.int64)
+            for key, val in zip(kk.tolist(), vv.tolist()):
+                c = want.setdefault(key, [0, 0])
+                c[0] += 1
+                c[1] += val
+        same = got_groups == sorted((key, c[0], c[1]) for key, c in want.items())  # every key on exactly one rank, nothing lost, nothing twice
+        if rank == 0:
+            print(f"[dist-check] skewed shuffle (85 % of the rows on one key): {'OK' if same else 'MISMATCH'} ({shk.rows} rows arrived on rank 0)", flush=True)
+        ok = ok and same
+    # ---- stress: many exchanges back to back with strings, NULLs and mixed widths of changing sizes (pins the staging-copy race
+    # of round 3: a transfer still in flight when the read-back of the received metadata ran)
+    iters = int(os.environ.get("LDB_CHECK_STRESS", "0"))
+    bad = 0
+    for it in range(iters):
+        import numpy as np
+
+        def piece(r):
+            g = np.random.default_rng(1000 * it + r)
+            m = int(g.integers(0, 40)) if (it + r) % 5 else 0
+            ks = g.integers(0, 50, m).astype(np.int32)
+            return pa.table({"k": pa.array(ks, pa.int32()), "s": pa.array([None if x % 7 == 0 else "s%d-%s" % (x, "y" * int(x % 13)) for x in ks.tolist()], pa.string()),
+                             "d": pa.array([decimal.Decimal(int(x)) / 100 for x in ks.tolist()], pa.decimal128(12, 2)), "w": pa.array([None if x % 3 == 0 else int(x) << 33 for x in ks.tolist()], pa.int64())})
+
+        t_it = ctx.register("st_%d_%d" % (it, rank), piece(rank), bool(it % 2))
+        ag = rows_of(comm.allgather(t_it, "st_all").to_arrow())
+        exp = [row for r in range(world) for row in rows_of(piece(r))]
+        if ag != exp:
+            bad += 1
+        sh2 = comm.shuffle(t_it.rel(), [(0, 0)], [(0, 0), (0, 1), (0, 3)], "st_sh").to_arrow()
+        cnt2 = ctx.register("stc_%d_%d" % (it, rank), pa.table({"n": pa.array([sh2.num_rows], pa.int64())}))
+        tot = sum(comm.allgather(cnt2, "stc_all").to_arrow().column(0).to_pylist())
+        if tot != len(exp):
+            bad += 1
+    if iters and rank == 0:
+        print(f"[dist-check] stress loop x{iters}: {'OK' if bad == 0 else 'MISMATCH (%d)' % bad}", flush=True)
+    ok = ok and bad == 0
+    st = comm.stats()
+    if rank == 0:
+        print(f"[dist-check] exchange statistics: {st}", flush=True)
+    ok = ok and st["groups"] > 0 and st["bytes_out"] > 0 and st["max_peer_bytes_out"] <= st["bytes_out"]
     comm.close()
     ctx.close()
     sys.exit(0 if ok else 1)

@@ -33,14 +33,30 @@ def run_ranks(world, extra_env=None, timeout=900):
 def test_sharded_plans_match_single_gpu(world):
     codes, outs = run_ranks(world)
     assert all(c == 0 for c in codes), "\n".join(o[-3000:] for o in outs)
-    assert outs[0].count(": OK") == 22 + 2, outs[0]
+    assert outs[0].count(": OK") == 22 + 3, outs[0]
+
+
+def test_world8_all_sharded_plans_skew_and_stress():
+    """8 ranks on the one GPU (BASELINE's largest world): all 22 sharded plans against the single-GPU plans, a shuffle whose rows
+    almost all go to one rank, and 60 back-to-back exchanges of strings / NULLs / mixed widths of changing sizes"""
+    codes, outs = run_ranks(8, {"LDB_CHECK_ORDERS": "90006", "LDB_CHECK_STRESS": "60"}, timeout=1500)
+    assert all(c == 0 for c in codes), "\n".join(o[-3000:] for o in outs)
+    assert outs[0].count(": OK") == 22 + 4, outs[0]
+    assert "exchange statistics" in outs[0]
+
+
+def test_exchange_stress_loop_world3():
+    """200 iterations at world 3 (the race fixed in 78e5108 showed once in 276 tests)"""
+    codes, outs = run_ranks(3, {"LDB_CHECK_QUERIES": "6", "LDB_CHECK_STRESS": "200", "LDB_CHECK_SKEW": "0"})
+    assert all(c == 0 for c in codes), "\n".join(o[-3000:] for o in outs)
+    assert "stress loop x200: OK" in outs[0], outs[0]
 
 
 def test_sharded_plans_with_narrow_decimals():
     """--narrow-decimals: 8-byte decimal columns next to the 16-byte aggregates group-by produces"""
     codes, outs = run_ranks(2, {"LDB_CHECK_NARROW": "1", "LDB_CHECK_QUERIES": "1,3,10,15,18,11"})
     assert all(c == 0 for c in codes), "\n".join(o[-3000:] for o in outs)
-    assert outs[0].count(": OK") == 6 + 2, outs[0]
+    assert outs[0].count(": OK") == 6 + 3, outs[0]
 
 
 def test_sharded_plans_on_one_rank_equal_the_single_gpu_plans():

@@ -228,3 +228,94 @@ def test_nested_loop_join_equals_brute_force(ctx):
     rows = ctx.run_plan(plan, {"p": probe, "b": build}).to_arrow().to_pylist()
     cnt = match.sum(axis=0)
     assert rows == [{"b": int(j), "n": int(cnt[j])} for j in range(m) if cnt[j]]
+
+
+# ------------------------------------------------------------------ subop.loop / nested_map (f4's fourth item)
+def _plan(name):
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lingo-db_amd", "plans", "subop", name)) as f:
+        return f.read()
+
+
+def test_loop_counter_of_the_reference_lit_test(ctx):
+    """test/lit/SubOp/loop.mlir: a counter state carried through subop.loop, continued while ctr < 5 → CHECK: 6"""
+    t = ctx.register("ctr0", pa.table({"ctr": pa.array([0], pa.int32())}))
+    got = ctx.run_plan(_plan("loop_counter.json"), {"ctr0": t}).to_arrow().to_pylist()
+    assert got == [{"ctr": 6}]
+    # a loop that never reaches its fixpoint is an error, not a hang
+    import json
+
+    p = json.loads(_plan("loop_counter.json"))
+    p["steps"][0]["body"][2]["expr"] = {"cmp": ["GTE", "ctr", 0]}
+    p["steps"][0]["max_iterations"] = 7
+    with pytest.raises(capi.LdbError) as e:
+        ctx.run_plan(json.dumps(p), {"ctr0": t})
+    assert "no fixpoint after 7 iterations" in str(e.value)
+
+
+KMEANS_POINTS = [(1, 1), (1, 2), (2, 1), (2, 4), (2, 5), (3, 2), (3, 5), (6, 3), (6, 5), (8, 4)]  # kmeans.mlir's ten points
+
+
+def _kmeans_model(points, cents):
+    """the plan's arithmetic in Python integers: nearest centroid by squared distance (ties → lowest id), truncating means"""
+    iters = 0
+    while True:
+        iters += 1
+        acc = {}
+        for px, py in points:
+            best = min(((cx - px) ** 2 + (cy - py) ** 2) * 1024 + cid for cid, (cx, cy) in cents.items())
+            a = acc.setdefault(best % 1024, [0, 0, 0])
+            a[0] += px
+            a[1] += py
+            a[2] += 1
+        nxt = {cid: (sx // n, sy // n) for cid, (sx, sy, n) in acc.items()}
+        moved = any(nxt[c] != cents[c] for c in nxt if c in cents)
+        cents = nxt
+        if not moved:
+            return cents, iters
+
+
+@pytest.mark.parametrize("prepared", [False, True])
+def test_kmeans_to_a_fixpoint_after_the_reference_lit_test(ctx, prepared):
+    """test/lit/SubOp/kmeans.mlir in fixed point (x 1000): nested_map (per point: scan the centroids, distance, arg-min state),
+    hash aggregation per centroid, next centroids = means, loop while a centroid moved.  The fixpoint is the lit test's CHECK
+    (1.75, 1.5) / (2.3333333, 4.6666665) / (6.6666665, 4) truncated to three digits — and equals a Python model of the same integer
+    arithmetic, also on 3 000 random points with 12 centroids"""
+    pts = [(x * 1000, y * 1000) for x, y in KMEANS_POINTS]
+    cases = [(pts, {i: pts[i] for i in range(3)}, [{"id": 0, "x": 1750, "y": 1500}, {"id": 1, "x": 2333, "y": 4666}, {"id": 2, "x": 6666, "y": 4000}])]
+    rng = np.random.default_rng(8)
+    big = [(int(x), int(y)) for x, y in zip(rng.integers(0, 100_000, 3000), rng.integers(0, 100_000, 3000))]
+    cases.append((big, {i: big[i * 37] for i in range(12)}, None))
+    for points, cents, literal in cases:
+        model, iters = _kmeans_model(points, dict(cents))
+        want = [{"id": c, "x": model[c][0], "y": model[c][1]} for c in sorted(model)]
+        if literal is not None:
+            assert want == literal
+        assert iters >= 3  # (a real iteration, not a one-shot)
+        tp = ctx.register("points", pa.table({"px": pa.array([p[0] for p in points], pa.int64()), "py": pa.array([p[1] for p in points], pa.int64())}))
+        tc = ctx.register("initial", pa.table({"cx": pa.array([cents[c][0] for c in sorted(cents)], pa.int64()), "cy": pa.array([cents[c][1] for c in sorted(cents)], pa.int64()),
+                                               "cid": pa.array(sorted(cents), pa.int64())}))
+        if prepared:
+            plan = ctx.prepare_plan(_plan("kmeans.json"))
+            for _ in range(3):
+                got = plan.execute({"points": tp, "initial": tc}).to_arrow().to_pylist()
+                assert got == want
+            assert plan.stats()["misses"] == 0 and plan.stats()["replays"] >= 1
+            plan.release()
+        else:
+            assert ctx.run_plan(_plan("kmeans.json"), {"points": tp, "initial": tc}).to_arrow().to_pylist() == want
+
+
+def test_nested_map_without_a_reduce_returns_the_nested_stream(ctx):
+    """the general form: the nested pipeline's tuples themselves (outer x scanned state, filtered by the residual, mapped)"""
+    import json
+
+    a = ctx.register("nm_a", pa.table({"x": pa.array([1, 5, 9, 12], pa.int64())}))
+    b = ctx.register("nm_b", pa.table({"lo": pa.array([0, 4, 10], pa.int64()), "hi": pa.array([6, 9, 20], pa.int64())}))
+    plan = {"steps": [{"op": "nested_map", "in": "a", "scan": "b", "residual": [{"probe": "x", "build": "lo", "op": "GTE"}, {"probe": "x", "build": "hi", "op": "LTE"}],
+                       "map": [{"as": "w", "expr": {"sub": ["hi", "x"]}}], "out": "s"},
+                      {"op": "materialize", "in": "s", "cols": ["x", "lo", "w"], "out": "result"}], "result": "result"}
+    got = sorted(tuple(r.values()) for r in ctx.run_plan(json.dumps(plan), {"a": a, "b": b}).to_arrow().to_pylist())
+    want = sorted((x, lo, hi - x) for x in (1, 5, 9, 12) for lo, hi in ((0, 6), (4, 9), (10, 20)) if lo <= x <= hi)
+    assert got == want

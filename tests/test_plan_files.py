@@ -150,3 +150,64 @@ def test_exchange_steps_are_checked():
     assert st != 0 and "keys" in err
     st, err = _check('{"steps": [{"op": "allgather", "in": "nope", "out": "r"}], "result": "r"}', ["t"])
     assert st != 0 and "before it exists" in err
+
+
+def test_bench_dry_run_checks_budgets_without_a_device():
+    """`bench.py --dry-run`: per-rank rows, resident bytes and shuffle volume of BASELINE configs[4] (SF300 Q9 on 8 GPUs) against
+    the HBM and uint32 row-id budgets — and a configuration that cannot fit says so"""
+    import json
+    import subprocess
+    import sys
+
+    def run(*args):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", *args], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    d = run("--gpus", "8", "--sf", "300", "--queries", "9")
+    assert d["checks"] == {"row_ids_fit_uint32": True, "hbm_fits": True}
+    assert len(d["per_rank"]) == 8
+    total_li = sum(r["rows"]["lineitem"] for r in d["per_rank"])
+    n = 450_000_000
+    assert total_li == (n // 7) * 28 + [0, 4, 5, 12, 15, 21, 23, 28][n % 7]
+    assert sum(r["rows"]["orders"] for r in d["per_rank"]) == n
+    sh = {s["input"]: s for s in d["shuffles_of_base_tables"]}
+    assert set(sh) == {"lpy", "ps1"} and sh["lpy"]["rows_descend_from"] == "lineitem"
+    # SURVEY §8(e): ≈ 11.8 GB egress per GPU over 7 links ≈ 11 ms when every lineitem row travels
+    assert 10e9 < sh["lpy"]["bytes_out_per_rank_upper_bound"] < 14e9 and 9 < sh["lpy"]["ms_at_xgmi_link_rate_upper_bound"] < 13
+    one = run("--gpus", "1", "--sf", "1000", "--queries", "9")
+    assert one["checks"]["row_ids_fit_uint32"] is False and one["checks"]["hbm_fits"] is False  # 6 G lineitem rows on one GPU
+
+
+def test_loop_and_nested_map_plans_pass_the_structure_check():
+    """plans/subop/: the reference's loop.mlir counter and a k-means after kmeans.mlir, written with the `loop` / `nested_map` steps"""
+    import json
+
+    for name, inputs in (("loop_counter.json", ["ctr0"]), ("kmeans.json", ["points", "initial"])):
+        with open(os.path.join(ROOT, "lingo-db_amd", "plans", "subop", name)) as f:
+            text = f.read()
+        st, err = _check(text, inputs)
+        assert st == 0, (name, err)
+    with open(os.path.join(ROOT, "lingo-db_amd", "plans", "subop", "loop_counter.json")) as f:
+        good = json.load(f)
+
+    def broken(edit):
+        p = json.loads(json.dumps(good))
+        edit(p["steps"][0])
+        return json.dumps(p)
+
+    cases = [(lambda l: l["vars"][0].update(init="nope"), "before it exists"),
+             (lambda l: l["next"][0].update(var="other"), "unknown variable"),
+             (lambda l: l["next"][0].update(**{"from": "ctr0"}), "not produced by the body"),
+             (lambda l: l["continue"].update(**{"from": "later"}), "before it exists"),
+             (lambda l: l["body"].append({"op": "materialize", "in": "s2", "cols": ["x"], "out": "cond"}), "defined twice"),
+             (lambda l: l["results"][0].update(name="ctr0"), "defined twice"),
+             (lambda l: l.pop("body"), "body")]
+    for edit, needle in cases:
+        st, err = _check(broken(edit), ["ctr0"])
+        assert st != 0 and needle in err, (needle, err)
+    # a value defined inside the body is not visible after the loop; the loop's result is
+    after = json.loads(json.dumps(good))
+    after["steps"][1]["in"] = "newCounter"
+    st, err = _check(json.dumps(after), ["ctr0"])
+    assert st != 0 and "before it exists" in err

@@ -44,8 +44,12 @@ class Database:
     """Slice rank/world of the SF database, generated straight into HBM (only the columns the
     selected queries touch — the reference likewise scans only referenced columns)."""
 
-    def __init__(self, ctx, n_orders, rank, world, queries, narrow):
-        self.ctx, self.n_orders, self.rank, self.world = ctx, n_orders, rank, world
+    @staticmethod
+    def tables_for(queries):
+        """[(Database attribute, generator table id, sorted column ids)] of everything the given queries touch — also what
+        `bench.py --dry-run` sizes a rank's HBM from, without a device"""
+        gen = []
+        have = set()
         lcols = set()
         if 1 in queries:
             lcols |= {L_QUANTITY, L_EXTENDEDPRICE, L_DISCOUNT, L_TAX, L_RETURNFLAG, L_LINESTATUS, L_SHIPDATE}
@@ -80,8 +84,7 @@ class Database:
         if 21 in queries:
             lcols |= {L_ORDERKEY, 2, L_COMMITDATE, L_RECEIPTDATE}
         lcols |= {L_EXTENDEDPRICE, L_SHIPDATE}  # hbm_ceiling() calibration scans
-        self.lineitem = ctx.tpch_generate(LINEITEM, n_orders, rank, world, sorted(lcols), narrow)
-        self.orders = self.customer = None
+        gen.append(("lineitem", LINEITEM, sorted(lcols))); have.add("lineitem")
         ocols, ccols = set(), set()
         if 3 in queries:
             ocols |= {O_ORDERKEY, O_CUSTKEY, O_ORDERDATE, O_SHIPPRIORITY}
@@ -104,7 +107,6 @@ class Database:
         if 22 in queries:
             ocols |= {O_CUSTKEY}
             ccols |= {C_CUSTKEY, 2, 5}  # + c_acctbal, c_phone
-        self.part = self.supplier = self.partsupp = self.nation = self.region = None
         if 9 in queries:
             ocols |= {O_ORDERKEY, O_ORDERDATE}
         pcols = set()
@@ -114,7 +116,7 @@ class Database:
             if q in queries:
                 pcols |= cs
         if pcols:
-            self.part = ctx.tpch_generate(PART, n_orders, rank, world, sorted(pcols), narrow)
+            gen.append(("part", PART, sorted(pcols))); have.add("part")
         pscols = set()
         if 9 in queries or 11 in queries:  # ps_partkey, ps_suppkey, [ps_availqty,] ps_supplycost
             pscols |= {0, 1, 2, 3} if 11 in queries else {0, 1, 3}
@@ -122,35 +124,43 @@ class Database:
             if q in queries:
                 pscols |= cs
         if pscols:
-            self.partsupp = ctx.tpch_generate(PARTSUPP, n_orders, rank, world, sorted(pscols), narrow)
+            gen.append(("partsupp", PARTSUPP, sorted(pscols))); have.add("partsupp")
         if 5 in queries or 8 in queries:
             ocols |= {O_ORDERKEY, O_CUSTKEY, O_ORDERDATE}
             ccols |= {C_CUSTKEY, 1}  # + c_nationkey
-            self.region = ctx.tpch_generate(7, n_orders, rank, world, [0, 1], narrow)  # r_regionkey, r_name
+            gen.append(("region", 7, [0, 1])); have.add("region")  # r_regionkey, r_name
         if 7 in queries:
             ocols |= {O_ORDERKEY, O_CUSTKEY}
             ccols |= {C_CUSTKEY, 1}  # + c_nationkey
         if 10 in queries and not any(q in queries for q in (5, 7, 8, 9, 11)):
-            self.nation = ctx.tpch_generate(NATION, n_orders, rank, world, [0, 1, 2], narrow)
+            gen.append(("nation", NATION, [0, 1, 2])); have.add("nation")
         if 15 in queries and not any(q in queries for q in (5, 7, 8, 9, 11)):
-            self.supplier = ctx.tpch_generate(SUPPLIER, n_orders, rank, world, [0, 1], narrow)
+            gen.append(("supplier", SUPPLIER, [0, 1])); have.add("supplier")
         if any(q in queries for q in (5, 7, 8, 9, 11)):
-            self.supplier = ctx.tpch_generate(SUPPLIER, n_orders, rank, world, [0, 1], narrow)  # s_suppkey, s_nationkey
-            self.nation = ctx.tpch_generate(NATION, n_orders, rank, world, [0, 1, 2], narrow)  # n_nationkey, n_regionkey, n_name
+            gen.append(("supplier", SUPPLIER, [0, 1])); have.add("supplier")  # s_suppkey, s_nationkey
+            gen.append(("nation", NATION, [0, 1, 2])); have.add("nation")  # n_nationkey, n_regionkey, n_name
         scols = set()
         for q, cs in ((2, {0, 1, 2, 3, 4, 5, 6}), (16, {0, 6}), (20, {0, 1, 3, 4}), (21, {0, 1, 3})):
             if q in queries:
                 scols |= cs
         if scols:  # the wider supplier table of the queries that show supplier strings (s_name, s_address, …)
-            self.supplier_full = ctx.tpch_generate(SUPPLIER, n_orders, rank, world, sorted(scols | {0, 1}), narrow)
-            if self.nation is None:
-                self.nation = ctx.tpch_generate(NATION, n_orders, rank, world, [0, 1, 2], narrow)
-        if 2 in queries and self.region is None:
-            self.region = ctx.tpch_generate(7, n_orders, rank, world, [0, 1], narrow)
+            gen.append(("supplier_full", SUPPLIER, sorted(scols | {0, 1}))); have.add("supplier_full")
+            if "nation" not in have:
+                gen.append(("nation", NATION, [0, 1, 2])); have.add("nation")
+        if 2 in queries and "region" not in have:
+            gen.append(("region", 7, [0, 1])); have.add("region")
         if ocols:
-            self.orders = ctx.tpch_generate(ORDERS, n_orders, rank, world, sorted(ocols), narrow)
+            gen.append(("orders", ORDERS, sorted(ocols))); have.add("orders")
         if ccols:
-            self.customer = ctx.tpch_generate(CUSTOMER, n_orders, rank, world, sorted(ccols), narrow)
+            gen.append(("customer", CUSTOMER, sorted(ccols))); have.add("customer")
+
+        return gen
+
+    def __init__(self, ctx, n_orders, rank, world, queries, narrow):
+        self.ctx, self.n_orders, self.rank, self.world = ctx, n_orders, rank, world
+        self.lineitem = self.orders = self.customer = self.part = self.supplier = self.partsupp = self.nation = self.region = None
+        for attr, table_id, cols in self.tables_for(queries):
+            setattr(self, attr, ctx.tpch_generate(table_id, n_orders, rank, world, cols, narrow))
         self.n_lineitem_total = (n_orders // 7) * 28 + [0, 4, 5, 12, 15, 21, 23, 28][n_orders % 7]
 
 
