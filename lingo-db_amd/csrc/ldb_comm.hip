@@ -606,6 +606,8 @@ static int32_t exchange(ldb_ctx* ctx, ldb_comm* c, const ldb_table* t, const std
                         ldb_table** out) {
    const int world = c->world;
    const int nc = (int) t->cols.size();
+   for (auto& col : t->cols) // the exchange ships string bytes: dictionary-coded (lazy) columns are written out first
+      if (ldb_column_is_lazy(col)) LDB_TRY(ldb_column_strings(ctx, col, t->n_rows));
    Transport* tr = c->t.get();
    DevBufs bufs(ctx);
    std::vector<int> ucols; // utf8 columns

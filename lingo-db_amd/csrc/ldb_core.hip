@@ -42,7 +42,7 @@ int64_t ldb_option(const char* name, int64_t dflt) {
 }
 extern "C" int32_t ldb_gpu_set_option(const char* name, int64_t value) {
    if (!name) LDB_FAIL(LDB_ERR_INVALID, "set_option: NULL name");
-   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass"};
+   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass", "lazy_strings", "lazy_strings_min_rows", "gb_partition_wc", "join_radix_wc"};
    bool ok = false;
    for (const char* k : known) ok |= strcmp(k, name) == 0;
    if (!ok) LDB_FAIL(LDB_ERR_INVALID, "set_option: unknown option '%s'", name);
@@ -909,6 +909,7 @@ extern "C" int32_t ldb_gpu_table_col_width(const ldb_table* t, int32_t col) {
 extern "C" int32_t ldb_gpu_table_col_ptrs(const ldb_table* t, int32_t col, void** values, void** offsets, void** validity, int64_t* value_bytes) {
    if (!t || col < 0 || (size_t) col >= t->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "col_ptrs: bad column %d", col);
    const ldb_column& c = t->cols[(size_t) col];
+   if (ldb_column_is_lazy(c)) LDB_TRY(ldb_column_strings(t->ctx, c, t->n_rows));
    c.has_range = false, c.sorted_state = -1, c.skewed = false; // the caller may write through the raw pointers
    if (values) *values = c.values;
    if (offsets) *offsets = c.offsets;
@@ -1024,6 +1025,8 @@ extern "C" int32_t ldb_gpu_export(ldb_ctx* ctx, const ldb_table* t, struct Arrow
    if (!ctx || !t || !out_schema || !out_array) LDB_FAIL(LDB_ERR_INVALID, "export: NULL argument");
    const int64_t n = t->n_rows;
    const int64_t nc = (int64_t) t->cols.size();
+   for (auto& col : t->cols)
+      if (ldb_column_is_lazy(col)) LDB_TRY(ldb_column_strings(ctx, col, n)); // (dictionary-coded strings are written out only here)
    // Small results (the usual case: a query's final rows) come over in ONE batch: every device
    // buffer is copied asynchronously into the pinned ring, one synchronize, then plain memcpys —
    // instead of a blocking pageable hipMemcpy (~20 µs) per buffer.
@@ -1253,6 +1256,7 @@ int32_t ldb_make_dcol(const ldb_rel* r, ldb_colref ref, DCol* out) {
    const ldb_rel_side& s = r->sides[(size_t) ref.side];
    if (ref.col < 0 || (size_t) ref.col >= s.table->cols.size()) LDB_FAIL(LDB_ERR_INVALID, "column ref: col %d out of range on side %d", ref.col, ref.side);
    const ldb_column& c = s.table->cols[(size_t) ref.col];
+   if (ldb_column_is_lazy(c)) LDB_TRY(ldb_column_strings(r->ctx, c, s.table->n_rows)); // a byte-wise consumer: the strings are needed now
    out->values = (uint64_t) c.values;
    out->offsets = (uint64_t) c.offsets;
    out->validity = (uint64_t) c.validity;
@@ -1597,6 +1601,7 @@ __global__ void k_compose_multi(DComposeMulti d) {
 }
 int32_t ldb_compose_rowids(ldb_ctx* ctx, const uint32_t* sel0, const uint32_t* sel1, const LdbComposeJob* jobs, int n_jobs, uint64_t n) {
    if (!n || !n_jobs) return LDB_OK;
+   LdbProf prof_(ctx, "k_compose_rowids");
    for (int at = 0; at < n_jobs; at += 12) {
       DComposeMulti d;
       memset(&d, 0, sizeof(d));
@@ -1683,20 +1688,25 @@ int32_t ldb_gather_columns(ldb_ctx* ctx, const ldb_rel* r, const ldb_colref* ref
    };
    std::vector<Pending> pend((size_t) n_cols);
    int n_slots = 0;
+   const bool lazy_on = ldb_option("lazy_strings", 1) != 0;
+   const uint64_t lazy_min = (uint64_t) ldb_option("lazy_strings_min_rows", 4096);
+   std::vector<ldb_column*> lazy_small; // lazy outputs too short to be worth keeping lazy: written out before returning
    for (int32_t c = 0; c < n_cols; c++) {
       const ldb_rel_side& side = r->sides[(size_t) refs[c].side];
       const ldb_column& src = side.table->cols[(size_t) refs[c].col];
       pend[(size_t) c].col = c;
       if (src.validity || (side.rowids && side.may_null)) pend[(size_t) c].slot_nulls = n_slots++;
-      if (src.type.type == LDB_T_UTF8) pend[(size_t) c].slot_bytes = n_slots++;
+      const bool will_be_lazy = src.type.type == LDB_T_UTF8 && src.dict_codes && src.dict && (ldb_column_is_lazy(src) || (n >= 64 && n >= lazy_min && lazy_on));
+      if (src.type.type == LDB_T_UTF8 && !will_be_lazy) pend[(size_t) c].slot_bytes = n_slots++;
    }
    unsigned long long* d_words = nullptr;
    if (n_slots) LDB_TRY(ldb_counters(ctx, n_slots, (uint64_t**) &d_words)); // zeroed arena words
+   LdbProf prof_(ctx, "k_gather"); // (all gather launches of the call; the string copies after the read-back are not inside)
    for (int32_t c = 0; c < n_cols; c++) {
       Pending& p = pend[(size_t) c];
-      DCol dcol;
-      LDB_TRY(ldb_make_dcol(r, refs[c], &dcol));
-      p.rowids = (const uint32_t*) dcol.rowids;
+      // (only the side's row ids are needed here; ldb_make_dcol would write a lazy source column's strings out — the very
+      // thing a code-only gather avoids — and change its laziness between the slot assignment above and the branch below)
+      p.rowids = r->sides[(size_t) refs[c].side].rowids;
       const ldb_column& src = r->sides[(size_t) refs[c].side].table->cols[(size_t) refs[c].col];
       ldb_column* out = &outs[c];
       out->name = src.name;
@@ -1707,16 +1717,22 @@ int32_t ldb_gather_columns(ldb_ctx* ctx, const ldb_rel* r, const ldb_colref* ref
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &out->validity, (size_t) ((n + 7) / 8 + 8)));
          if (n) hipLaunchKernelGGL(k_gather_validity, dim3(grid), dim3(256), 0, ctx->stream, src.validity, p.rowids, (uint64_t*) out->validity, n, d_words + p.slot_nulls);
       }
-      if (src.type.type == LDB_T_UTF8 && src.dict_codes && src.dict && n >= 64) {
+      const bool src_lazy = ldb_column_is_lazy(src);
+      if (src.type.type == LDB_T_UTF8 && src.dict_codes && src.dict && (n >= 64 || src_lazy)) {
          // the gathered column inherits the source's dictionary: codes gathered alongside, the dictionary table shared
-         LDB_TRY(ldb_dev_alloc(ctx, (void**) &out->dict_codes, 4 * (size_t) n));
-         hipLaunchKernelGGL(k_gather_fixed<uint32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*) src.dict_codes, p.rowids, out->dict_codes, n);
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &out->dict_codes, 4 * (size_t) (n ? n : 1)));
+         if (n) hipLaunchKernelGGL(k_gather_fixed<uint32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*) src.dict_codes, p.rowids, out->dict_codes, n);
          out->dict = src.dict;
          out->dict->dict_refs++;
          out->dict_size = src.dict_size;
          out->dict_pred_cache = new std::unordered_map<std::string, std::string>();
       }
-      if (src.type.type == LDB_T_UTF8) {
+      if (src.type.type == LDB_T_UTF8 && out->dict_codes && (src_lazy || (n >= lazy_min && lazy_on))) {
+         // LAZY: codes + dictionary only; whoever needs the bytes writes them out of the dictionary (ldb_column_strings)
+         out->value_bytes = -1;
+         p.slot_bytes = -1;
+         lazy_small.push_back(src_lazy && n < 64 ? out : nullptr);
+      } else if (src.type.type == LDB_T_UTF8) {
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &p.lens, sizeof(int64_t) * (size_t) (n + 1)));
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &out->offsets, sizeof(int64_t) * (size_t) (n + 1)));
          hipLaunchKernelGGL(k_str_lens, dim3(grid), dim3(256), 0, ctx->stream, src.offsets, p.rowids, p.lens, n);
@@ -1734,7 +1750,12 @@ int32_t ldb_gather_columns(ldb_ctx* ctx, const ldb_rel* r, const ldb_colref* ref
       }
    }
    LDB_HIP(hipGetLastError());
-   if (!n_slots) return LDB_OK;
+   auto finish_lazy = [&]() -> int32_t {
+      for (ldb_column* lc : lazy_small)
+         if (lc) LDB_TRY(ldb_column_strings(ctx, *lc, (int64_t) n));
+      return LDB_OK;
+   };
+   if (!n_slots) return finish_lazy();
    std::vector<unsigned long long> words((size_t) n_slots);
    LDB_TRY(LDB_READBACK(ctx, words.data(), d_words, 8 * (size_t) n_slots));
    for (int32_t c = 0; c < n_cols; c++) {
@@ -1758,9 +1779,40 @@ int32_t ldb_gather_columns(ldb_ctx* ctx, const ldb_rel* r, const ldb_colref* ref
       }
    }
    LDB_HIP(hipGetLastError());
-   return LDB_OK;
+   return finish_lazy();
 }
 int32_t ldb_gather_column(ldb_ctx* ctx, const ldb_rel* r, ldb_colref ref, ldb_column* out) { return ldb_gather_columns(ctx, r, &ref, 1, out); }
+
+// writes a lazy utf8 column's strings out of its dictionary: string i = dictionary[code i] (a NULL code gives the empty string;
+// the column's validity bitmap is separate).  The column object is logically const (the same value, another representation).
+int32_t ldb_column_strings(ldb_ctx* ctx, const ldb_column& cc, int64_t n_rows) {
+   if (!ldb_column_is_lazy(cc)) return LDB_OK;
+   ldb_column& c = const_cast<ldb_column&>(cc);
+   const ldb_column& dict = c.dict->cols[0];
+   const uint64_t n = (uint64_t) n_rows;
+   const int grid = ldb_grid_for(ctx, n_rows, 256, 8);
+   int64_t *lens = nullptr, *offsets = nullptr;
+   LdbBufs tmp(ctx);
+   LDB_TRY(tmp.alloc(&lens, 8 * (size_t) (n + 1)));
+   LDB_TRY(tmp.alloc(&offsets, 8 * (size_t) (n + 1)));
+   uint64_t* d_total;
+   LDB_TRY(ldb_counters(ctx, 1, &d_total));
+   if (n) hipLaunchKernelGGL(k_str_lens, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*) dict.offsets, (const uint32_t*) c.dict_codes, lens, n);
+   LDB_TRY(ldb_exclusive_scan_i64(ctx, lens, offsets, n_rows, (int64_t*) d_total));
+   uint64_t total = 0;
+   LDB_TRY(ldb_read_u64(ctx, d_total, &total));
+   void* values = nullptr;
+   LDB_TRY(tmp.alloc((uint8_t**) &values, (size_t) total));
+   hipLaunchKernelGGL(k_str_copy, dim3(grid > 0 ? grid : 1), dim3(256), 0, ctx->stream, (const uint8_t*) dict.values, (const int64_t*) dict.offsets, (const uint32_t*) c.dict_codes, offsets, (uint8_t*) values, n,
+                      (int64_t) total);
+   LDB_HIP(hipGetLastError());
+   tmp.keep(offsets);
+   tmp.keep(values);
+   c.offsets = offsets;
+   c.values = values;
+   c.value_bytes = (int64_t) total;
+   return LDB_OK;
+}
 
 extern "C" int32_t ldb_gpu_materialize(ldb_ctx* ctx, ldb_rel* r, const ldb_colref* cols, int32_t n_cols, ldb_table** out) {
    if (!ctx || !r || !out || n_cols < 0) LDB_FAIL(LDB_ERR_INVALID, "materialize: bad argument");
@@ -1946,10 +1998,14 @@ int32_t ldb_exclusive_scan_i64(ldb_ctx* ctx, const int64_t* d_in, int64_t* d_out
 // ---------------------------------------------------------------- bitmap → ascending row numbers, one launch
 // A selection bitmap (one bit per row: ballot words of a probe / filter kernel) becomes the ascending list of set positions:
 // popcount, chained scan (above) and expansion in ONE kernel — the word_pop + scan + expand sequence it replaces was five to
-// seven launches and two temporaries per join.  A tile is 2048 words (131 072 rows).  Dense tiles expand a word per wave
+// seven launches and two temporaries per join.  A tile is 512 words (32 768 rows).  Dense tiles expand a word per wave
 // iteration (the lanes whose bit is set write one coalesced run), sparse tiles a word per lane.  With `match` the kernel also
 // writes second[j] = match[row] (the build row of a unique-key join's j-th result pair).  Entries [total, cap) are filled
 // with row 0, so that a consumer that was sized from a REPLAYED count (ldb_readback) never meets an uninitialised row id.
+// (a tile of 512 words = 32 768 rows, two words per thread: the word-per-wave expansion of a dense tile is then 128 dependent
+// steps per wave instead of 512 — a compaction over few tiles runs at that latency)
+#define BC_ITEMS 2
+#define BC_TILE (256 * BC_ITEMS)
 __global__ __launch_bounds__(256) void k_bitmap_compact(const uint64_t* __restrict__ bitmap, uint64_t n_words, uint64_t n_tiles, uint32_t* __restrict__ out, uint64_t cap,
                                                         const uint32_t* __restrict__ match, uint32_t* __restrict__ second, unsigned long long* __restrict__ total,
                                                         unsigned long long* __restrict__ status, unsigned long long* __restrict__ ticket, unsigned long long ticket_base,
@@ -1957,19 +2013,19 @@ __global__ __launch_bounds__(256) void k_bitmap_compact(const uint64_t* __restri
    __shared__ unsigned long long s_tile;
    __shared__ uint32_t s_wave[4];
    __shared__ uint32_t s_prefix;
-   __shared__ uint32_t s_off[CHAIN_TILE];
-   __shared__ uint64_t s_words[CHAIN_TILE]; // the tile's words for the word-per-wave expansion (a wave re-reading them from memory one by
+   __shared__ uint32_t s_off[BC_TILE];
+   __shared__ uint64_t s_words[BC_TILE]; // the tile's words for the word-per-wave expansion (a wave re-reading them from memory one by
                                             // one runs at memory latency: 512 dependent round trips per wave)
    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1ull) - ticket_base;
    __syncthreads();
    const uint64_t tile = s_tile;
-   const uint64_t word0 = tile * CHAIN_TILE;
+   const uint64_t word0 = tile * BC_TILE;
    // word w of the tile is handled by thread w % 256 in round w / 256 (coalesced loads); offsets go through LDS
-   uint64_t m[CHAIN_ITEMS];
-   uint32_t cnt[CHAIN_ITEMS];
+   uint64_t m[BC_ITEMS];
+   uint32_t cnt[BC_ITEMS];
    uint32_t sum = 0;
 #pragma unroll
-   for (int k = 0; k < CHAIN_ITEMS; k++) {
+   for (int k = 0; k < BC_ITEMS; k++) {
       const uint64_t w = word0 + (uint64_t) k * 256 + threadIdx.x;
       m[k] = w < n_words ? bitmap[w] : 0;
       cnt[k] = (uint32_t) __popcll(m[k]);
@@ -1978,10 +2034,10 @@ __global__ __launch_bounds__(256) void k_bitmap_compact(const uint64_t* __restri
    }
    __syncthreads();
    // thread t scans words [8t, 8t + 8) of the tile (consecutive words → consecutive output positions)
-   uint32_t own[CHAIN_ITEMS];
+   uint32_t own[BC_ITEMS];
 #pragma unroll
-   for (int k = 0; k < CHAIN_ITEMS; k++) {
-      own[k] = s_off[threadIdx.x * CHAIN_ITEMS + k];
+   for (int k = 0; k < BC_ITEMS; k++) {
+      own[k] = s_off[threadIdx.x * BC_ITEMS + k];
       sum += own[k];
    }
    uint32_t agg;
@@ -1994,17 +2050,17 @@ __global__ __launch_bounds__(256) void k_bitmap_compact(const uint64_t* __restri
    const uint32_t tile_base = s_prefix;
    excl += tile_base;
 #pragma unroll
-   for (int k = 0; k < CHAIN_ITEMS; k++) {
-      s_off[threadIdx.x * CHAIN_ITEMS + k] = excl;
+   for (int k = 0; k < BC_ITEMS; k++) {
+      s_off[threadIdx.x * BC_ITEMS + k] = excl;
       excl += own[k];
    }
    if (tile == n_tiles - 1 && threadIdx.x == 0) {
       if (total) *total = (unsigned long long) tile_base + agg;
    }
    __syncthreads();
-   if (agg * 8u < CHAIN_TILE * 64u) { // fewer than one set bit in eight: a word per lane
+   if (agg * 8u < BC_TILE * 64u) { // fewer than one set bit in eight: a word per lane
 #pragma unroll
-      for (int k = 0; k < CHAIN_ITEMS; k++) {
+      for (int k = 0; k < BC_ITEMS; k++) {
          uint64_t mm = m[k];
          if (!mm) continue;
          uint32_t at = s_off[k * 256 + threadIdx.x];
@@ -2021,7 +2077,7 @@ __global__ __launch_bounds__(256) void k_bitmap_compact(const uint64_t* __restri
       }
    } else { // a word per wave iteration
       const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-      for (uint32_t w = wave; w < CHAIN_TILE; w += 4) {
+      for (uint32_t w = wave; w < BC_TILE; w += 4) {
          if (word0 + w >= n_words) break;
          const uint64_t mm = s_words[w]; // wave-uniform
          if ((mm >> lane) & 1) {
@@ -2047,9 +2103,10 @@ int32_t ldb_bitmap_compact(ldb_ctx* ctx, const uint64_t* bitmap, int64_t n_words
       if (d_total) LDB_HIP(hipMemsetAsync(d_total, 0, 8, ctx->stream));
       return LDB_OK;
    }
-   const uint64_t n_tiles = ((uint64_t) n_words + CHAIN_TILE - 1) / CHAIN_TILE;
+   const uint64_t n_tiles = ((uint64_t) n_words + BC_TILE - 1) / BC_TILE;
    ChainCall c;
    LDB_TRY(ldb_chain_begin(ctx, n_tiles, false, &c));
+   LdbProf prof_(ctx, "k_bitmap_compact");
    hipLaunchKernelGGL(k_bitmap_compact, dim3((unsigned) n_tiles), dim3(256), 0, ctx->stream, bitmap, (uint64_t) n_words, n_tiles, out, cap, match, second, (unsigned long long*) d_total, c.status,
                       c.ticket, c.ticket_base, c.epoch);
    if (hipGetLastError() != hipSuccess) return ldb_chain_failed(ctx);

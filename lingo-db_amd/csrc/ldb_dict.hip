@@ -72,6 +72,7 @@ std::unique_ptr<ldb_table> view_of(const ldb_table* t, int32_t col, int64_t rows
    v->ctx = t->ctx;
    v->name = t->name + "#dictview";
    v->n_rows = rows;
+   (void) ldb_column_strings(t->ctx, t->cols[(size_t) col], t->n_rows); // (a view shares the bytes: a lazy column writes them out first)
    v->cols.push_back(t->cols[(size_t) col]);
    ldb_column& c = v->cols[0];
    c.owned = false;
@@ -180,11 +181,17 @@ static void code_dcol(const ldb_rel_side& s, const ldb_column& c, DCol* out) {
    out->width = 4;
 }
 int32_t ldb_make_dcol_dict(const ldb_rel* r, ldb_colref ref, DCol* out) {
-   LDB_TRY(ldb_make_dcol(r, ref, out));
-   const ldb_rel_side& s = r->sides[(size_t) ref.side];
-   const ldb_column& c = s.table->cols[(size_t) ref.col];
-   if (c.type.type == LDB_T_UTF8 && c.dict_codes) code_dcol(s, c, out);
-   return LDB_OK;
+   if (ref.side >= 0 && (size_t) ref.side < r->sides.size()) { // the codes first: a lazy column (no bytes yet) must not be written out for a consumer that reads codes
+      const ldb_rel_side& s = r->sides[(size_t) ref.side];
+      if (ref.col >= 0 && (size_t) ref.col < s.table->cols.size()) {
+         const ldb_column& c = s.table->cols[(size_t) ref.col];
+         if (c.type.type == LDB_T_UTF8 && c.dict_codes) {
+            code_dcol(s, c, out);
+            return LDB_OK;
+         }
+      }
+   }
+   return ldb_make_dcol(r, ref, out);
 }
 int32_t ldb_make_dkeys_dict(const ldb_rel* r, const ldb_colref* keys, int32_t n_keys, DKeys* out) {
    if (n_keys < 0 || n_keys > LDB_MAX_KEYS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "%d key columns (max %d)", n_keys, LDB_MAX_KEYS);

@@ -79,6 +79,11 @@ __global__ __launch_bounds__(GBP_SBLOCK) void k_gbp_scatter(const DGroupBy* __re
       slots_out[atomicAdd(&cur[slot >> GBP_SHIFT], 1u)] = slot;
    }
 }
+// the rows' direct slots as a dense 32-bit array: the input of the write-combining partition (ldb_wc.hip)
+__global__ void k_gbp_slots(const DGroupBy* __restrict__ d, uint32_t* __restrict__ slots) {
+   const uint64_t n = d->n_rows;
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) slots[i] = (uint32_t) d_direct_slot(*d, d, i);
+}
 __global__ __launch_bounds__(GBP_BLOCK) void k_gbp_count(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ offs, uint32_t grid0, uint32_t nparts, uint64_t n_total,
                                                          uint64_t* __restrict__ counters) {
    __shared__ uint32_t c[1u << GBP_SHIFT];
@@ -711,8 +716,29 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          const uint32_t nparts = (uint32_t) (cap >> GBP_SHIFT);
          const uint32_t g0 = (uint32_t) std::max<int64_t>(1, std::min<int64_t>((int64_t) ctx->cus, (in->n_rows + 16383) / 16384));
          const uint64_t rows_per_wg = ((uint64_t) in->n_rows + g0 - 1) / g0;
-         uint32_t *hist, *offs, *slots;
+         uint32_t *hist = nullptr, *offs = nullptr, *slots = nullptr;
          const size_t hn = (size_t) nparts * g0;
+         if (ldb_option("gb_partition_wc", 1) != 0 && nparts > 64) {
+            // write-combining two-pass partition (ldb_wc.hip): the slots are written once as a dense array, tile-sorted by
+            // partition in LDS and stored in full-line runs — the one-pass scatter below keeps nparts open 4-byte streams per
+            // workgroup (Q13: 1 024), most of whose lines leave the L2 half written (2.4 ms for 148 M rows)
+            uint32_t *raw, *part = nullptr, chunks = 1;
+            LdbBufs tmpb(ctx);
+            LDB_TRY(tmpb.alloc(&raw, 4 * (size_t) in->n_rows));
+            LDB_TRY(tmpb.alloc(&slots, 4 * (size_t) in->n_rows));
+            {
+               LdbProf prof_(ctx, "k_gbp_slots");
+               hipLaunchKernelGGL(k_gbp_slots, dim3(ldb_grid_for(ctx, in->n_rows, 256, 8)), dim3(256), 0, ctx->stream, (const DGroupBy*) d, raw);
+            }
+            LDB_TRY(ldb_wc_partition(ctx, raw, nullptr, (uint64_t) in->n_rows, 0u, (uint32_t) (cap - 1), GBP_SHIFT, nparts, slots, nullptr, &part, &chunks, "k_gbp_hist", "k_gbp_scatter"));
+            {
+               LdbProf prof_(ctx, "k_gbp_count");
+               hipLaunchKernelGGL(k_gbp_count, dim3(nparts), dim3(GBP_BLOCK), 0, ctx->stream, (const uint32_t*) slots, (const uint32_t*) part, chunks, nparts, (uint64_t) in->n_rows,
+                                  ga + (uint64_t) h->direct_word * cap);
+            }
+            ldb_dev_free(ctx, part);
+            slots = nullptr; // (owned by tmpb)
+         } else {
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &hist, 4 * hn));
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &offs, 4 * hn));
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &slots, 4 * (size_t) in->n_rows));
@@ -729,6 +755,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
             LdbProf prof_(ctx, "k_gbp_count");
             hipLaunchKernelGGL(k_gbp_count, dim3(nparts), dim3(GBP_BLOCK), 0, ctx->stream, (const uint32_t*) slots, (const uint32_t*) offs, g0, nparts, (uint64_t) in->n_rows,
                                ga + (uint64_t) h->direct_word * cap);
+         }
          }
          ldb_dev_free(ctx, hist);
          ldb_dev_free(ctx, offs);

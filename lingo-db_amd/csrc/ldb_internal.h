@@ -269,6 +269,13 @@ struct LdbBufs {
    }
 };
 
+// A utf8 column gathered from a dictionary-encoded one is LAZY: it holds the gathered codes and shares the dictionary, but has
+// no offsets / bytes (values == offsets == NULL, value_bytes = -1) until a consumer needs them — group-by, join, sort and
+// predicate evaluation read the codes; ldb_make_dcol (byte-wise consumers), export, the exchange, raw pointer access and
+// concatenation call ldb_column_strings first, which writes the strings out of the dictionary (one pass over the codes).
+// Q16: the 11 M distinct (brand, type, size, supplier) rows never had their two string columns written (2.5 ms of 10).
+int32_t ldb_column_strings(ldb_ctx* ctx, const ldb_column& c, int64_t n_rows);
+static inline bool ldb_column_is_lazy(const ldb_column& c) { return c.type.type == LDB_T_UTF8 && !c.offsets && c.dict_codes && c.dict; }
 int32_t ldb_make_dcol(const ldb_rel* r, ldb_colref ref, DCol* out);
 int32_t ldb_make_dpred(const ldb_rel* r, const ldb_filter_desc* p, DPred* out);
 void ldb_mark_same_col(DPred* preds, int32_t n);
@@ -309,6 +316,12 @@ struct LdbComposeJob {
    int which;
 };
 int32_t ldb_compose_rowids(ldb_ctx* ctx, const uint32_t* sel0, const uint32_t* sel1, const LdbComposeJob* jobs, int n_jobs, uint64_t n);
+// write-combining radix partition (ldb_wc.hip): n keys (+ payload: pay_in, or the item number when pay_in == NULL and pay_out
+// != NULL) into nparts partitions q(key) = (key - bias) >> shift (0 for keys outside [bias, bias + range]), partitions back to
+// back in q order in keys_out / pay_out; two tile-sorting passes above 64 partitions.  *part_offs_out (device, owned by the
+// caller afterwards, may be NULL): begin of partition q at [q * *chunks_out].  prof_* = string literals.
+int32_t ldb_wc_partition(ldb_ctx* ctx, const uint32_t* keys_in, const uint32_t* pay_in, uint64_t n, uint32_t bias, uint32_t range, uint32_t shift, uint32_t nparts, uint32_t* keys_out,
+                         uint32_t* pay_out, uint32_t** part_offs_out, uint32_t* chunks_out, const char* prof_hist, const char* prof_scatter);
 #define LDB_ARENA_WORDS 16384
 // n_words zeroed 64-bit device words (64-byte aligned) that stay this caller's until the arena wraps: written by its kernels,
 // read back with ldb_readback; never cleared, never reused for a second purpose by the caller after the read-back

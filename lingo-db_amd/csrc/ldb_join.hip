@@ -446,15 +446,26 @@ static int32_t radix_prepare(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, co
    d.pshift = lg - lp;
    d.grid = (uint32_t) std::min<int64_t>(ctx->cus * 8, (n + 4095) / 4096);
    d.rows_per_wg = ((uint64_t) n + d.grid - 1) / d.grid;
-   uint32_t *hist, *offs, *perm;
+   uint32_t *hist = nullptr, *offs = nullptr, *perm;
    const size_t hn = (size_t) nparts * d.grid;
-   LDB_TRY(ldb_dev_alloc(ctx, (void**) &hist, 4 * hn));
-   LDB_TRY(ldb_dev_alloc(ctx, (void**) &offs, 4 * hn));
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &perm, 4 * (size_t) n));
    ldb_coltype kt = {LDB_T_INT32, 0, 0, 0};
    kt.type = kc.type;
    const char* nm = "radix_key";
    LDB_TRY(ldb_gpu_table_alloc(ctx, "radix_keys", 1, &kt, &nm, n, nullptr, 0, &rp.keys));
+   if (ldb_option("join_radix_wc", 1) != 0 && ht->direct && !kc.rowids && nparts > 16 && ht->kmax - ht->kmin <= (int64_t) 0xFFFFFFFFll) {
+      // write-combining partition (ldb_wc.hip): tile-sort in LDS, full-line runs, two passes above 64 partitions — the
+      // scatter below keeps `nparts` open 4-byte streams per workgroup and loses to the direct probe beyond ~16 partitions
+      const uint32_t shift = d.pshift + (ht->direct == 2 ? 5u : 0u);
+      const int32_t st = ldb_wc_partition(ctx, (const uint32_t*) kc.values, nullptr, (uint64_t) n, (uint32_t) (int32_t) ht->kmin, (uint32_t) (ht->kmax - ht->kmin), shift, nparts,
+                                          (uint32_t*) rp.keys->cols[0].values, perm, nullptr, nullptr, "k_radix_hist", "k_radix_scatter");
+      if (st != LDB_OK) {
+         ldb_dev_free(ctx, perm);
+         return st;
+      }
+   } else {
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &hist, 4 * hn));
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &offs, 4 * hn));
    {
       LdbProf prof_(ctx, "k_radix_hist");
       hipLaunchKernelGGL(k_radix_hist, dim3(d.grid), dim3(RX_BLOCK), 0, ctx->stream, d, hist);
@@ -465,6 +476,7 @@ static int32_t radix_prepare(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, co
       hipLaunchKernelGGL(k_radix_scatter, dim3(d.grid), dim3(RX_BLOCK), 0, ctx->stream, d, (const uint32_t*) offs, (uint32_t*) rp.keys->cols[0].values, perm);
    }
    LDB_HIP(hipGetLastError());
+   }
    ldb_dev_free(ctx, hist);
    ldb_dev_free(ctx, offs);
    ldb_rel* r = ldb_rel_new(ctx);

@@ -103,6 +103,9 @@ static int32_t table_concat(ldb_ctx* ctx, const ldb_table* a, const ldb_table* b
    if ((int) b->cols.size() != nc) LDB_FAIL(LDB_ERR_INVALID, "set_op: the inputs have %d and %zu columns", nc, b->cols.size());
    const int64_t na = a->n_rows, nb = b->n_rows, n = na + nb;
    if (n >= (int64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "set_op: %ld rows exceed uint32 row ids", (long) n);
+   for (const ldb_table* t : {a, b}) // the concatenation copies string bytes: dictionary-coded (lazy) columns are written out first
+      for (auto& c : t->cols)
+         if (ldb_column_is_lazy(c)) LDB_TRY(ldb_column_strings(ctx, c, t->n_rows));
    std::vector<ldb_coltype> types;
    std::vector<const char*> names;
    std::vector<int64_t> data_bytes;

@@ -29,6 +29,7 @@ SRCS=(
   src/runtime/Heap.cpp
   src/runtime/SimpleState.cpp
   src/runtime/Hashtable.cpp
+  src/runtime/HashMultiMap.cpp
   src/runtime/SegmentTreeView.cpp
   src/runtime/StringRuntime.cpp
   src/runtime/ListRuntime.cpp
@@ -44,7 +45,8 @@ for s in "${SRCS[@]}"; do
 done
 for s in sched_shim.cpp ref_glue.cpp; do
   o="$OUT/obj/$s.o"
-  $CXX $FLAGS -c "$HERE/$s" -o "$o"
+  # (-fno-access-control: the glue reads HashMultiMap's private entry / value structs as the generated code does by offset)
+  $CXX $FLAGS -fno-access-control -c "$HERE/$s" -o "$o"
   OBJS+=("$o")
 done
 ARROW_SO="$(ls "$PA_LIB"/libarrow.so.* | head -1)"

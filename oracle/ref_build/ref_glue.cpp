@@ -22,6 +22,7 @@
 #include "lingodb/runtime/helpers.h"
 #include "lingodb/runtime/Heap.h"
 #include "lingodb/runtime/Hashtable.h"
+#include "lingodb/runtime/HashMultiMap.h"
 #include "lingodb/runtime/SimpleState.h"
 #include "lingodb/runtime/SegmentTreeView.h"
 #include "lingodb/runtime/DateRuntime.h"
@@ -524,5 +525,82 @@ int32_t ref_segment_tree(const int64_t* vals, const uint8_t* valid, int64_t n, i
       out_valid[q] = (uint8_t) (res.ok ? 1 : 0);
    }
    return 0;
+}
+// ---------------------------------------------------------------- HashMultiMap: outer joins that keep the build side
+// translateHJWithMarker (RelAlgToSubOp.cpp:1248-1287): the LEFT input is inserted into a MultiMap [keys] → [values + flag]
+// (subop.insert: one ENTRY per distinct key — found with the eq function — and one VALUE per row), every tuple of the right
+// input looks its key up, walks the values of the matching entry, emits the pairs and scatters flag = true; afterwards the map
+// is scanned and the rows whose flag is still false are emitted NULL-extended.  The container is the reference's own
+// (src/runtime/HashMultiMap.cpp, compiled in place); the generated per-tuple code — hash the key as db.hash does, compare the
+// stored hash and the key, walk next / valueList — is restated here around it.  NULL keys: with nullsEqual = false the eq
+// function is never true for them, so every NULL-key build row becomes an entry of its own that no probe reaches.
+// (The entry / value structs are private to the class: this file is compiled with -fno-access-control.)
+int64_t ref_hmm_outer_join(const int64_t* bkeys, const uint8_t* bvalid, int64_t nb, const int64_t* pkeys, const uint8_t* pvalid, int64_t np, int64_t initial_capacity, int64_t* out_probe,
+                           int64_t* out_build, int64_t cap, int64_t* unmatched_build, int64_t* n_unmatched_build, uint8_t* probe_matched) {
+   CtxScope scope(1);
+   struct KeyPart {
+      int64_t key;
+      uint8_t valid;
+   };
+   struct ValPart {
+      int64_t row;
+      uint8_t flag;
+   };
+   using HMM = runtime::HashMultiMap;
+   HMM* hmm = HMM::create(sizeof(HMM::Entry) + sizeof(KeyPart), sizeof(HMM::Value) + sizeof(ValPart), (size_t) (initial_capacity > 0 ? initial_capacity : 4));
+   auto hashOf = [](int64_t k) { // db.hash of one integer (Hash.cpp:25-28, LowerToLLVM.cpp:493-503)
+      const uint64_t m = 11400714819323198549ull * (uint64_t) k;
+      return (size_t) (m ^ __builtin_bswap64(m));
+   };
+   auto find = [&](size_t h, int64_t key) -> HMM::Entry* {
+      for (HMM::Entry* e = runtime::filterTagged(hmm->ht.at(h & hmm->hashMask), h); e; e = e->next) {
+         auto* kp = reinterpret_cast<KeyPart*>(e->keyContent);
+         if (e->hashValue == h && kp->valid && kp->key == key) return e;
+      }
+      return nullptr;
+   };
+   for (int64_t i = 0; i < nb; i++) {
+      const bool ok = !bvalid || bvalid[i];
+      const size_t h = ok ? hashOf(bkeys[i]) : 0; // (a NULL key part is skipped by db.hash: the running hash stays 0)
+      HMM::Entry* e = ok ? find(h, bkeys[i]) : nullptr;
+      if (!e) {
+         e = hmm->insertEntry(h);
+         auto* kp = reinterpret_cast<KeyPart*>(e->keyContent);
+         kp->key = ok ? bkeys[i] : 0;
+         kp->valid = ok ? 1 : 0;
+      }
+      HMM::Value* v = hmm->insertValue(e);
+      auto* vp = reinterpret_cast<ValPart*>(v->valueContent);
+      vp->row = i;
+      vp->flag = 0;
+   }
+   int64_t n_pairs = 0;
+   for (int64_t j = 0; j < np; j++) {
+      probe_matched[j] = 0;
+      if (pvalid && !pvalid[j]) continue;
+      HMM::Entry* e = find(hashOf(pkeys[j]), pkeys[j]);
+      if (!e) continue;
+      for (HMM::Value* v = e->valueList; v; v = v->nextValue) {
+         auto* vp = reinterpret_cast<ValPart*>(v->valueContent);
+         vp->flag = 1;
+         probe_matched[j] = 1;
+         if (n_pairs < cap) {
+            out_probe[n_pairs] = j;
+            out_build[n_pairs] = vp->row;
+         }
+         n_pairs++;
+      }
+   }
+   // the scan of the map: entries in the order of the entry buffer, the values of an entry in list order
+   int64_t nu = 0;
+   hmm->entries.iterate([&](uint8_t* raw) {
+      auto* e = reinterpret_cast<HMM::Entry*>(raw);
+      for (HMM::Value* v = e->valueList; v; v = v->nextValue) {
+         auto* vp = reinterpret_cast<ValPart*>(v->valueContent);
+         if (!vp->flag) unmatched_build[nu++] = vp->row;
+      }
+   });
+   *n_unmatched_build = nu;
+   return n_pairs;
 }
 } // extern "C"

@@ -180,3 +180,23 @@ def test_window_frames_match_the_reference_segment_tree(oracle):
             want = [int(v) if (k or fn == 4) else None for v, k in zip(z["f%d_fn%d_val" % (fi, fn)].tolist(), z["f%d_fn%d_ok" % (fi, fn)].tolist())]
             got = oracle_bind.window(oracle, vals, valid, [0] * n, [n] * n, fn, frm, to)
             assert got == want, (fi, fn)
+
+
+def test_outer_join_fixture_of_the_reference_hash_multi_map_is_what_sql_says():
+    """tests/golden/ref_hmm.npz (the reference's real HashMultiMap driven as translateHJWithMarker drives it,
+    RelAlgToSubOp.cpp:1248-1287) against an independent evaluation: the pairs are the equi-join on non-NULL keys, the
+    flag-less build rows are those no probe key reaches (every NULL-key row among them), the partner-less probe rows the rest"""
+    import collections
+
+    z = np.load(os.path.join(golden_io.GOLDEN, "ref_hmm.npz"))
+    for c in range(int(z["n_cases"][0])):
+        bk, bv, pk, pv = (z["c%d_%s" % (c, n)] for n in ("bk", "bv", "pk", "pv"))
+        by_key = collections.defaultdict(list)
+        for i, (k, ok) in enumerate(zip(bk.tolist(), bv.tolist())):
+            if ok:
+                by_key[k].append(i)
+        want_pairs = sorted((j, i) for j, (k, ok) in enumerate(zip(pk.tolist(), pv.tolist())) if ok for i in by_key.get(k, ()))
+        assert sorted(zip(z["c%d_pairs_p" % c].tolist(), z["c%d_pairs_b" % c].tolist())) == want_pairs, c
+        probed = {k for k, ok in zip(pk.tolist(), pv.tolist()) if ok}
+        assert sorted(z["c%d_unmatched_b" % c].tolist()) == [i for i, (k, ok) in enumerate(zip(bk.tolist(), bv.tolist())) if not ok or k not in probed], c
+        assert z["c%d_probe_matched" % c].tolist() == [1 if ok and k in by_key else 0 for k, ok in zip(pk.tolist(), pv.tolist())], c

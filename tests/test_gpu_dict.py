@@ -142,3 +142,49 @@ def test_gathered_columns_inherit_the_dictionary(tables):
     s = srt.column(0).to_pylist()
     assert all(s[i].encode() <= s[i + 1].encode() for i in range(len(s) - 1)) and len(s) == m.rows
     assert m.rel().scan_filter([api.pred((0, 0), capi.F_LIKE, "%AIR%")]).rows == sum(1 for x in m.to_arrow().column(0).to_pylist() if "AIR" in x)
+
+
+# ------------------------------------------------------------------ lazy strings (round 4): gathered dictionary columns keep codes only
+@pytest.mark.parametrize("lazy", [1, 0])
+def test_lazy_dictionary_strings_are_written_out_only_where_bytes_are_needed(ctx, tables, lazy):
+    """a column gathered from a dictionary-encoded one carries codes + the shared dictionary and no bytes (>= 4 096 rows) until
+    export, a byte-wise join / LIKE, a concatenation or a second gather below the threshold needs them: every consumer must
+    see exactly the strings — with lazy_strings = 0 (bytes written at every gather) as the control"""
+    t, enc, plain = tables
+    lib = capi.gpu_lib()
+    lib.ldb_gpu_set_option(b"lazy_strings", lazy)
+    try:
+        s, v, k = t.column(0).to_pylist(), t.column(1).to_pylist(), t.column(2).to_pylist()
+        keep = [i for i in range(len(s)) if v[i] < 700]
+        m = enc.rel().scan_filter([api.pred((0, 1), capi.F_LT, 700)]).materialize([(0, 0), (0, 2), (0, 1)])  # lazy when on: 35 k rows
+        assert m.dict_size(0) == len(WORDS)
+        # (1) export writes the strings (NULLs stay NULL)
+        assert m.to_arrow().column(0).to_pylist() == [s[i] for i in keep]
+        # (2) a second gather of few rows from the (possibly still lazy) column
+        few = m.rel().scan_filter([api.pred((0, 2), capi.F_LT, 1)]).materialize([(0, 0), (0, 2)])
+        assert few.to_arrow().column(0).to_pylist() == [s[i] for i in keep if v[i] < 1]
+        # (3) group-by on the string key (codes) of a fresh lazy column, keys come out as strings
+        m2 = enc.rel().scan_filter([api.pred((0, 1), capi.F_LT, 700)]).materialize([(0, 0), (0, 1)])
+        g = m2.rel().groupby([(0, 0)], [api.agg(capi.AGG_COUNT_STAR), api.agg(capi.AGG_SUM, api.col_expr((0, 1)))], est_groups=32).to_arrow()
+        want = collections.Counter(), collections.Counter()
+        for i in keep:
+            want[0][s[i]] += 1
+            want[1][s[i]] += v[i]
+        got = {a: (b, c) for a, b, c in zip(g.column(0).to_pylist(), g.column(1).to_pylist(), g.column(2).to_pylist())}
+        assert got == {key: (want[0][key], want[1][key]) for key in want[0]}
+        # (4) byte-wise consumers of a fresh lazy column: LIKE through the dictionary, an equi-join on the strings
+        m3 = enc.rel().scan_filter([api.pred((0, 1), capi.F_LT, 700)]).materialize([(0, 0), (0, 1)])
+        hit = m3.rel().scan_filter([api.pred((0, 0), capi.F_LIKE, "%AIR%")]).rowids(0)
+        assert hit.tolist() == [j for j, i in enumerate(keep) if s[i] is not None and "AIR" in s[i]]
+        words = ctx.register("lazy_words", pa.table({"w": pa.array(["MAIL", "Zürich", "nope", "中文"], pa.string()), "id": pa.array([0, 1, 2, 3], pa.int32())}))
+        j = words.rel().join_build([(0, 0)], unique=True).probe(m3.rel(), [(0, 0)], capi.JOIN_INNER)
+        pr, br = j.rowids(0), j.rowids(1)
+        wl = ["MAIL", "Zürich", "nope", "中文"]
+        assert sorted(zip(pr.tolist(), br.tolist())) == sorted((jj, wl.index(s[i])) for jj, i in enumerate(keep) if s[i] in wl)
+        # (5) concatenation (set operation) of two lazy columns
+        a1 = enc.rel().scan_filter([api.pred((0, 1), capi.F_LT, 100)]).materialize([(0, 0)])
+        a2 = enc.rel().scan_filter([api.pred((0, 1), capi.F_GTE, 900)]).materialize([(0, 0)])
+        u = a1.rel().set_op(a2.rel(), capi.SET_UNION_ALL).to_arrow().column(0).to_pylist()
+        assert sorted(x or "\0" for x in u) == sorted((s[i] or "\0") for i in range(len(s)) if v[i] < 100 or v[i] >= 900)
+    finally:
+        lib.ldb_gpu_set_option(b"lazy_strings", 1)

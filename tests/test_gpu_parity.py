@@ -671,7 +671,8 @@ def test_groupby_partitioned_lds_count(ctx):
             t = pa.table({"k": pa.array(keys, ktype), "w": pa.array(w, pa.int32())})
             g = ctx.register("part_keys", t)
             aggs = [api.agg(capi.AGG_COUNT_STAR)]
-            for pre in (False, True):
+            for pre, wc in ((False, 1), (True, 1), (False, 0)):  # wc: the write-combining two-pass partition (ldb_wc.hip) / the one-pass LDS-cursor scatter
+                lib.ldb_gpu_set_option(b"gb_partition_wc", wc)
                 grel = g.rel()
                 sel = np.ones(n, bool)
                 if pre:
@@ -695,5 +696,6 @@ def test_groupby_partitioned_lds_count(ctx):
                     lib.ldb_gpu_set_option(b"gb_partition", 1)
                 assert sorted(rows_of(atomic.to_arrow())) == rows
     finally:
+        lib.ldb_gpu_set_option(b"gb_partition_wc", 1)
         lib.ldb_gpu_set_option(b"gb_partition_min_rows", 8 << 20)
         ctx.prof_enable(False)

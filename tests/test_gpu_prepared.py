@@ -199,3 +199,48 @@ def test_plan_replay_can_be_switched_off(ctx):
     finally:
         capi.gpu_lib().ldb_gpu_set_option(b"plan_replay", 1)
     t.release()
+
+
+# ------------------------------------------------------------------ write-combining radix partition (ldb_wc.hip)
+@pytest.mark.parametrize("part_bytes", [1 << 10, 1 << 14, 1 << 22])
+def test_radix_probe_over_the_write_combining_partition(ctx, part_bytes):
+    """join_radix = 1 with a DENSE probe column into a rank / direct table: the probe keys are partitioned by table position
+    with the tile-sorting scatter — one pass up to 64 partitions, two passes above (4 096 at 1 KB of table per partition) —
+    and probed partition by partition: counts, pairs and the semi-join rows equal the direct probe's and numpy's, with keys
+    outside the build range, duplicates and unmatched keys"""
+    lib = capi.gpu_lib()
+    rng = np.random.default_rng(21)
+    nb, npr = 400_000, 3_000_000
+    bk = rng.permutation(1_600_000)[:nb].astype(np.int32) + 1000
+    pk = rng.integers(0, 1_700_000, npr).astype(np.int32)
+    pk[:1000] = -5  # below the range
+    b, p = ctx.register("wc_b", pa.table({"k": pa.array(bk, pa.int32())})), ctx.register("wc_p", pa.table({"k": pa.array(pk, pa.int32())}))
+    pos = {int(k): i for i, k in enumerate(bk.tolist())}
+    hit = np.isin(pk, bk)
+    want_pairs = sorted((j, pos[int(pk[j])]) for j in np.nonzero(hit)[0].tolist())
+    try:
+        for rank in (1, 0):  # the rank-bitmap table, then the direct word table
+            lib.ldb_gpu_set_option(b"join_rank", rank)
+            ht = b.rel().join_build([(0, 0)], unique=True)
+            lib.ldb_gpu_set_option(b"join_radix_part_bytes", part_bytes)
+            lib.ldb_gpu_set_option(b"join_radix", 1)
+            ctx.prof_enable(True)
+            ctx.prof_reset()
+            assert ht.probe_count(p.rel(), [(0, 0)]) == int(hit.sum())
+            assert ctx.prof_all().get("k_radix_scatter", (0, 0.0))[0] >= 1, "the radix path did not run"
+            r = ht.probe(p.rel(), [(0, 0)])
+            assert sorted(zip(r.rowids(0).tolist(), r.rowids(1).tolist())) == want_pairs
+            for wc in (0,):  # the one-pass cursor scatter as the control
+                lib.ldb_gpu_set_option(b"join_radix_wc", wc)
+                assert ht.probe_count(p.rel(), [(0, 0)]) == int(hit.sum())
+                lib.ldb_gpu_set_option(b"join_radix_wc", 1)
+            lib.ldb_gpu_set_option(b"join_radix", 0)
+            assert ht.probe_count(p.rel(), [(0, 0)]) == int(hit.sum())
+            ht.release()
+    finally:
+        lib.ldb_gpu_set_option(b"join_radix", 0)
+        lib.ldb_gpu_set_option(b"join_radix_wc", 1)
+        lib.ldb_gpu_set_option(b"join_radix_part_bytes", 1 << 20)
+        lib.ldb_gpu_set_option(b"join_rank", 1)
+        ctx.prof_enable(False)
+    b.release(), p.release()

@@ -206,3 +206,31 @@ def test_substr_matches_reference_string_runtime(ctx):
         assert got == [r[1] for r in rows] + [None], (fr, ln)
         done += len(rows)
     assert done >= 100
+
+
+@pytest.mark.parametrize("unique_hint", [False, True])
+def test_right_and_full_outer_joins_vs_reference_hash_multi_map(ctx, unique_hint):
+    """LDB_JOIN_RIGHT_OUTER / FULL_OUTER against the answers of the reference's real HashMultiMap (tests/golden/ref_hmm.npz,
+    tests/golden/make_ref_hmm.py): pairs, build rows no probe reached (probe side NULL), probe rows without a partner
+    (build side NULL) as multisets of (probe row number, build row number)"""
+    import collections
+    import os
+
+    z = np.load(os.path.join(golden_io.GOLDEN, "ref_hmm.npz"))
+    for c in range(int(z["n_cases"][0])):
+        bk, bv, pk, pv = (z["c%d_%s" % (c, n)] for n in ("bk", "bv", "pk", "pv"))
+        if len(bk) == 0 or len(pk) == 0:
+            continue
+        b = ctx.register("hmm_b", pa.table({"k": pa.array(bk, pa.int64(), mask=bv == 0), "i": pa.array(np.arange(len(bk), dtype=np.int64))}))
+        p = ctx.register("hmm_p", pa.table({"k": pa.array(pk, pa.int64(), mask=pv == 0), "j": pa.array(np.arange(len(pk), dtype=np.int64))}))
+        ht = b.rel().join_build([(0, 0)], unique=unique_hint)  # (a wrong promise of unique keys must be detected by the build)
+        pairs = list(zip(z["c%d_pairs_p" % c].tolist(), z["c%d_pairs_b" % c].tolist()))
+        unb = [(None, i) for i in z["c%d_unmatched_b" % c].tolist()]
+        unp = [(j, None) for j, m in enumerate(z["c%d_probe_matched" % c].tolist()) if not m]
+        for kind, want in ((capi.JOIN_RIGHT_OUTER, pairs + unb), (capi.JOIN_FULL_OUTER, pairs + unb + unp), (capi.JOIN_LEFT_OUTER, pairs + unp), (capi.JOIN_INNER, pairs)):
+            out = ht.probe(p.rel(), [(0, 0)], kind).materialize([(0, 1), (1, 1)]).to_arrow()
+            got = collections.Counter(zip(out.column(0).to_pylist(), out.column(1).to_pylist()))
+            assert got == collections.Counter(want), (c, kind)
+        # the build rows with / without a partner alone: the semi / anti forms that keep the build side
+        assert sorted(ht.probe(p.rel(), [(0, 0)], capi.JOIN_ANTI_BUILD).rowids(0).tolist()) == sorted(z["c%d_unmatched_b" % c].tolist())
+        ht.release(), b.release(), p.release()

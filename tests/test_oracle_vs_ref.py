@@ -230,3 +230,23 @@ def test_segment_tree_restatement_equals_the_real_segment_tree_view(oracle):
             if fn == 4:
                 want = [int(v) for v in ov.tolist()]  # COUNT is never NULL
             assert got == want, (n, fn)
+
+
+def test_hash_multi_map_fixture_is_what_the_compiled_reference_answers_now():
+    """tests/golden/ref_hmm.npz replayed through src/runtime/HashMultiMap.cpp compiled in place (glue ref_hmm_outer_join): the
+    committed fixture is current, and the container's answer does not depend on its initial capacity (resize)"""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_ref_hmm
+
+    lib = C.CDLL(REF_LIB)
+    lib.ref_hmm_outer_join.restype = C.c_int64
+    lib.ref_hmm_outer_join.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_hmm.npz"))
+    for c in range(int(z["n_cases"][0])):
+        args = [np.ascontiguousarray(z["c%d_%s" % (c, n)]) for n in ("bk", "bv", "pk", "pv")]
+        for cap0 in (4, 64, 4096):
+            op, ob, ub, pm = make_ref_hmm.run(lib, *args, cap0)
+            assert sorted(zip(op.tolist(), ob.tolist())) == sorted(zip(z["c%d_pairs_p" % c].tolist(), z["c%d_pairs_b" % c].tolist())), (c, cap0)
+            assert sorted(ub.tolist()) == sorted(z["c%d_unmatched_b" % c].tolist()) and pm.tolist() == z["c%d_probe_matched" % c].tolist(), (c, cap0)

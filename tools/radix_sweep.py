@@ -48,10 +48,19 @@ for rank in (0, 1):
         if tb // pb > 4096 * 1:  # RX_MAX_PARTS partitions at most
             continue
         L.ldb_gpu_set_option(b"join_radix_part_bytes", pb)
-        ks, total, m = timed()
-        assert m == m0, (m, m0)
-        out["runs"].append({"table": "rank" if rank else "ordered", "table_bytes": tb, "radix": True, "part_bytes": pb, "kernels_ms": ks, "total_ms": total, "matches": m,
-                            "bytes": {"hist": rows * 4, "scatter": rows * 4 + rows * 8, "probe": rows * 4 + tb}})
+        for wc in ((1, 0) if rank else (0,)):  # round 4: the write-combining tile-sort partition (ldb_wc.hip; direct / rank tables) beside the one-pass cursor scatter
+            L.ldb_gpu_set_option(b"join_radix_wc", wc)
+            ks, total, m = timed()
+            assert m == m0, (m, m0)
+            parts = 16
+            while parts < 4096 and tb // parts > pb:
+                parts *= 2
+            passes = 2 if (wc and parts > 64) else 1
+            # bytes: histogram reads the keys; scatter pass 1 reads keys, writes (key, row); pass 2 reads the keys again for its histogram, then reads and writes (key, row)
+            by = {"hist": rows * 4 * passes, "scatter": rows * (4 + 8) + (rows * 16 if passes == 2 else 0), "probe": rows * 8 + tb}
+            out["runs"].append({"table": "rank" if rank else "ordered", "table_bytes": tb, "radix": True, "write_combining": bool(wc), "partitions": parts, "passes": passes, "part_bytes": pb,
+                                "kernels_ms": ks, "total_ms": total, "matches": m, "bytes": by})
+        L.ldb_gpu_set_option(b"join_radix_wc", 1)
     L.ldb_gpu_set_option(b"join_radix", 0)
     del ht
 print(json.dumps(out, indent=1))
