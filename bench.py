@@ -358,6 +358,13 @@ def main():
                     more.append({"kernel": "k_join_probe_count: " + name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                  "compulsory_bytes_per_launch": rows * 4 + tb, "table_bytes": tb, "survey_model_gbs": round(rows * 12 / (sub["probe_ms"] * 1e-3) / 1e9, 1),
                                  "grows_per_s": sub["probe_grows_per_s"], "avg_kernel_ms": sub["probe_ms"]})
+                    if sub.get("radix_partitioned"):
+                        # the partitioned path MOVES more than the compulsory bytes on purpose: two histogram passes over the keys, two scatter
+                        # passes (keys in, (key, row) out; (key, row) in and out), the keys once more for the LDS-staged probe, the table once
+                        moved = rows * 4 * 2 + rows * (4 + 8) + rows * 16 + rows * 4 + tb
+                        more[-1].update({"kernel": "k_radix_hist + k_radix_scatter + k_join_probe_count (LDS-staged): " + name, "kernels_ms": sub.get("kernels_ms"),
+                                         "partitioned_bytes_per_launch": moved, "partitioned_gbs": round(moved / (sub["probe_ms"] * 1e-3) / 1e9, 1),
+                                         "partitioned_frac": round(moved / (sub["probe_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
         if (18, "k_groupby") in kernel_max:
             # Q18 launches k_groupby twice (the 600 M → 150 M aggregation and a tiny final group-by): the LARGEST launch is
             # priced, and the §8(d) byte model (rows x (key + agg input) + groups x entry x 2) covers the sorted-key pre-pass

@@ -383,20 +383,109 @@ __global__ void k_radix_locality(DRadix d, uint64_t stride, unsigned int* __rest
 struct RadixProbe { // the clustered stand-in for a probe relation
    ldb_rel* rel = nullptr; // sides: [keys table (identity)] + the probe's sides through the permutation
    ldb_table* keys = nullptr;
+   // rank-table probes whose partitions are LDS-sized: where partition q begins (part_offs[q * chunks]) and what it covers
+   uint32_t* part_offs = nullptr;
+   uint32_t chunks = 0, nparts = 0, shift = 0;
 };
 static void radix_release(ldb_ctx* ctx, RadixProbe& rp) {
    if (rp.rel) ldb_gpu_rel_release(ctx, rp.rel);
    if (rp.keys) ldb_gpu_table_release(ctx, rp.keys);
+   ldb_dev_free(ctx, rp.part_offs);
    rp.rel = nullptr;
    rp.keys = nullptr;
+   rp.part_offs = nullptr;
+}
+
+// ---------------------------------------------------------------- LDS-staged probe of a radix-partitioned probe side
+// North star: "radix-partitioned hash-join build/probe … LDS-staged hash buckets".  After the write-combining partition
+// (ldb_wc.hip) the probe keys of partition q all fall into ONE slice of the rank table (2^shift key values = 2^(shift-5)
+// 8-byte words, at most 64 KB).  One workgroup of 1 024 threads per partition copies the slice into LDS once and probes its
+// keys there: a probe is an LDS read (32 banks) instead of one L2 line request per lane — the L1 / TA pipe handles 64
+// distinct lines per wave instruction at ~1 line per cycle, which is what bounds the cache-resident probe (3.4 ms for
+// 600 M keys).  A 64-row chunk belongs to the workgroup whose partition holds the chunk's first row; the few rows of a chunk
+// that belong to the next partition read their word from memory.  Outputs are those of the ordinary unique probe (dense
+// match[] + ballot bitmap + counter) so everything downstream is unchanged.
+struct DPartProbe {
+   uint64_t n, tab_words;
+   const int32_t* keys;
+   const uint64_t* tab;
+   const uint32_t* perm; // rank → build row (NULL: the rank is the row)
+   const uint32_t* part_offs;
+   uint32_t chunks, nparts, words_per_part, range;
+   int64_t kmin;
+   uint32_t* match;
+   uint64_t* bitmap;
+   unsigned long long* counter;
+   int32_t mode, has_bitmap; // mode 0: count matches (counter[1]); 1: unique pairs (match, bitmap, counter[0])
+};
+__global__ __launch_bounds__(1024) void k_join_probe_lds(DPartProbe d) {
+   extern __shared__ uint64_t s_tab[];
+   const uint32_t p = blockIdx.x;
+   const uint64_t b = d.part_offs[(uint64_t) p * d.chunks], e = p + 1 < d.nparts ? (uint64_t) d.part_offs[(uint64_t) (p + 1) * d.chunks] : d.n;
+   const uint64_t cb = (b + 63) / 64, ce = (e + 63) / 64; // the 64-row chunks whose first row lies in [b, e)
+   if (cb >= ce) return;
+   const uint64_t w0 = (uint64_t) p * d.words_per_part;
+   for (uint32_t k = threadIdx.x; k < d.words_per_part; k += blockDim.x) s_tab[k] = w0 + k < d.tab_words ? d.tab[w0 + k] : 0ull;
+   __syncthreads();
+   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+   unsigned long long local = 0;
+   for (uint64_t c = cb + wave; c < ce; c += n_waves) {
+      const uint64_t i = c * 64 + lane;
+      uint32_t hw = 0; // rank + 1, or 0: no such key
+      if (i < d.n) {
+         const uint32_t r = (uint32_t) d.keys[i] - (uint32_t) d.kmin;
+         if (r <= d.range) {
+            const uint64_t wi = (uint64_t) (r >> 5);
+            const uint64_t w = (wi >= w0 && wi < w0 + d.words_per_part) ? s_tab[wi - w0] : d.tab[wi];
+            hw = d_rank_word(w, r);
+         }
+      }
+      const uint64_t mm = __ballot(hw != 0);
+      if (d.mode == 1) {
+         const uint32_t brow = hw ? (d.perm ? d.perm[hw - 1u] : hw - 1u) : LDB_NULL_ROW;
+         if (i < d.n && (hw || !d.has_bitmap)) d.match[i] = brow;
+         if (lane == 0 && d.has_bitmap) d.bitmap[c] = mm;
+      }
+      local += (unsigned long long) __popcll(mm);
+   }
+   if (lane == 0 && local) atomicAdd(d.counter + (d.mode == 0 ? 1 : 0), local);
+}
+// the LDS-staged probe is possible: a rank table, partitions known, a slice fits 64 KB, plain key equality
+static bool part_probe_ok(const ldb_hashtable* ht, const RadixProbe* rp, int32_t n_resid) {
+   return rp && rp->part_offs && ht->direct == 2 && n_resid == 0 && rp->shift >= 5 && (8ull << (rp->shift - 5)) <= (64u << 10) && ldb_option("join_radix_lds", 1) != 0;
+}
+static int32_t launch_part_probe(ldb_ctx* ctx, ldb_hashtable* ht, const RadixProbe* rp, int64_t n, int mode, uint32_t* match, uint64_t* bitmap, unsigned long long* counter) {
+   DPartProbe d;
+   memset(&d, 0, sizeof(d));
+   d.n = (uint64_t) n;
+   d.tab_words = (uint64_t) ((ht->kmax - ht->kmin) / 32 + 1);
+   d.keys = (const int32_t*) rp->keys->cols[0].values;
+   d.tab = ht->slots;
+   d.perm = ht->rank_sorted ? nullptr : ht->next;
+   d.part_offs = rp->part_offs;
+   d.chunks = rp->chunks;
+   d.nparts = rp->nparts;
+   d.words_per_part = 1u << (rp->shift - 5);
+   d.range = (uint32_t) (ht->kmax - ht->kmin);
+   d.kmin = ht->kmin;
+   d.match = match;
+   d.bitmap = bitmap;
+   d.counter = counter;
+   d.mode = mode;
+   d.has_bitmap = bitmap ? 1 : 0;
+   LdbProf prof_(ctx, mode == 0 ? "k_join_probe_count" : "k_join_probe_unique");
+   hipLaunchKernelGGL(k_join_probe_lds, dim3(rp->nparts), dim3(1024), (size_t) d.words_per_part * 8, ctx->stream, d);
+   LDB_HIP(hipGetLastError());
+   return LDB_OK;
 }
 // decides whether to cluster and, if so, builds the clustered relation; rp.rel stays NULL otherwise
 static int32_t radix_prepare(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind, RadixProbe& rp) {
-   // 0 off (default), 1 whenever possible, -1 auto (locality sample + size thresholds).  Off by default: on
-   // MI355X the direct probe of unclustered keys already runs at the HBM random-access rate (46 Grows/s
-   // into a 4.3 GB table), the partition pass costs more than the L2-resident probe (56 Grows/s) wins back
-   // — see DESIGN.md §Join for the measured crossover
-   const int64_t mode = ldb_option("join_radix", 0);
+   // 0 off, 1 whenever possible, -1 auto (default since round 4): a dense, unfiltered probe column of >= 16 M rows into a
+   // direct / rank table of >= 64 MB whose keys a locality sample finds unclustered is partitioned with the write-combining
+   // scatter (ldb_wc.hip) into LDS-sized table slices and probed from LDS: 600 M random FK probes 10.9 → 7.6 ms (DESIGN.md §2
+   // Join).  Clustered probe sides (every large TPC-H probe) keep the direct probe; row-id or lazily filtered probe sides too
+   // (the one-pass cursor scatter they would need loses to the direct probe).
+   const int64_t mode = ldb_option("join_radix", -1);
    if (mode == 0 || n_keys != 1 || !ht->key32 || !(ht->ordered_slots || ht->direct) || ht->chained || probe->n_rows < 2) return LDB_OK;
    if (kind == LDB_JOIN_MARK || kind == LDB_JOIN_SEMI || kind == LDB_JOIN_ANTI) return LDB_OK; // results promised in probe order
    if (probe->sides.size() + 1 + ht->build->sides.size() > LDB_MAX_SIDES) return LDB_OK;
@@ -407,6 +496,7 @@ static int32_t radix_prepare(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, co
    const uint64_t units = ht->direct == 2 ? (ht->cap + 31) / 32 : ht->cap;
    const uint64_t unit_bytes = ht->direct == 1 ? 4 : 8;
    if (mode < 0 && (units * unit_bytes < (uint64_t) ldb_option("join_radix_min_table_bytes", 64ll << 20) || probe->n_rows < ldb_option("join_radix_min_rows", 16ll << 20))) return LDB_OK;
+   if (mode < 0 && (!probe->pending.empty() || kc.rowids || !ht->direct || ldb_option("join_radix_wc", 1) == 0)) return LDB_OK; // auto: only where the write-combining path applies
    LDB_TRY(ldb_rel_force(ctx, probe));
    LDB_TRY(ldb_make_dcol(probe, keys[0], &kc));
    const int64_t n = probe->n_rows;
@@ -435,7 +525,7 @@ static int32_t radix_prepare(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, co
    }
    // partitions of ~1 MB of slots each
    uint32_t nparts = 16;
-   const uint64_t part_bytes = (uint64_t) ldb_option("join_radix_part_bytes", 1 << 20);
+   const uint64_t part_bytes = (uint64_t) ldb_option("join_radix_part_bytes", ht->direct == 2 ? (64 << 10) : (1 << 20)); // rank table: slices that fit LDS
    while (nparts < RX_MAX_PARTS && (units * unit_bytes) / nparts > part_bytes) nparts <<= 1;
    uint32_t lg = 0;
    while ((1ull << lg) < units) lg++;
@@ -458,11 +548,13 @@ static int32_t radix_prepare(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, co
       // scatter below keeps `nparts` open 4-byte streams per workgroup and loses to the direct probe beyond ~16 partitions
       const uint32_t shift = d.pshift + (ht->direct == 2 ? 5u : 0u);
       const int32_t st = ldb_wc_partition(ctx, (const uint32_t*) kc.values, nullptr, (uint64_t) n, (uint32_t) (int32_t) ht->kmin, (uint32_t) (ht->kmax - ht->kmin), shift, nparts,
-                                          (uint32_t*) rp.keys->cols[0].values, perm, nullptr, nullptr, "k_radix_hist", "k_radix_scatter");
+                                          (uint32_t*) rp.keys->cols[0].values, perm, &rp.part_offs, &rp.chunks, "k_radix_hist", "k_radix_scatter");
       if (st != LDB_OK) {
          ldb_dev_free(ctx, perm);
          return st;
       }
+      rp.nparts = nparts;
+      rp.shift = shift;
    } else {
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &hist, 4 * hn));
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &offs, 4 * hn));
@@ -813,18 +905,18 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    return LDB_OK;
 }
 
-static int32_t probe_count_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int64_t* matches, bool radix_ok);
+static int32_t probe_count_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int64_t* matches, bool radix_ok, const RadixProbe* part = nullptr);
 extern "C" int32_t ldb_gpu_join_probe_count(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int64_t* matches) {
    return probe_count_impl(ctx, ht, probe, keys, n_keys, matches, true);
 }
-static int32_t probe_count_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int64_t* matches, bool radix_ok) {
+static int32_t probe_count_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int64_t* matches, bool radix_ok, const RadixProbe* part) {
    if (!ctx || !ht || !probe || !matches) LDB_FAIL(LDB_ERR_INVALID, "join_probe_count: NULL argument");
    if (radix_ok) {
       RadixProbe rp;
       LDB_TRY(radix_prepare(ctx, ht, probe, keys, n_keys, LDB_JOIN_INNER, rp));
       if (rp.rel) { // an unclustered probe side: partitioned by slot range first
          const ldb_colref k0 = {0, 0};
-         const int32_t st = probe_count_impl(ctx, ht, rp.rel, &k0, 1, matches, false);
+         const int32_t st = probe_count_impl(ctx, ht, rp.rel, &k0, 1, matches, false, &rp);
          radix_release(ctx, rp);
          return st;
       }
@@ -837,7 +929,8 @@ static int32_t probe_count_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe,
    hp->counter = (uint64_t) counter;
    DJoin* d;
    LDB_TRY(ldb_dev_upload(ctx, hp.get(), sizeof(DJoin), (void**) &d));
-   if (probe->n_rows) LDB_TRY(launch_join(ctx, hp.get(), d, ldb_grid_for(ctx, probe->n_rows, 256, 8), "k_join_probe_count", "k_join_probe_count_spec", k_join_probe_count));
+   if (probe->n_rows && part_probe_ok(ht, part, 0)) LDB_TRY(launch_part_probe(ctx, ht, part, probe->n_rows, 0, nullptr, nullptr, counter)); // partitions staged in LDS
+   else if (probe->n_rows) LDB_TRY(launch_join(ctx, hp.get(), d, ldb_grid_for(ctx, probe->n_rows, 256, 8), "k_join_probe_count", "k_join_probe_count_spec", k_join_probe_count));
    uint64_t m = 0;
    LDB_TRY(ldb_read_u64(ctx, counter + 1, &m));
    ldb_dev_free(ctx, d);
@@ -851,13 +944,13 @@ extern "C" int32_t ldb_gpu_join_probe(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* 
 }
 
 static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind, const ldb_join_residual* resid, int32_t n_resid,
-                          ldb_rel** out, ldb_table** mark_out, bool radix_ok);
+                          ldb_rel** out, ldb_table** mark_out, bool radix_ok, const RadixProbe* part = nullptr);
 extern "C" int32_t ldb_gpu_join_probe_residual(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind,
                                                const ldb_join_residual* resid, int32_t n_resid, ldb_rel** out, ldb_table** mark_out) {
    return probe_impl(ctx, ht, probe, keys, n_keys, kind, resid, n_resid, out, mark_out, true);
 }
 static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind, const ldb_join_residual* resid, int32_t n_resid,
-                          ldb_rel** out, ldb_table** mark_out, bool radix_ok) {
+                          ldb_rel** out, ldb_table** mark_out, bool radix_ok, const RadixProbe* part) {
    if (!ctx || !ht || !probe || !out) LDB_FAIL(LDB_ERR_INVALID, "join_probe: NULL argument");
    if (kind < LDB_JOIN_INNER || kind > LDB_JOIN_FULL_OUTER) LDB_FAIL(LDB_ERR_INVALID, "join_probe: bad kind %d", kind);
    if (kind == LDB_JOIN_RIGHT_OUTER || kind == LDB_JOIN_FULL_OUTER) {
@@ -899,7 +992,7 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
          const ldb_colref k0 = {0, 0};
          std::vector<ldb_join_residual> rs(resid, resid + (n_resid > 0 ? n_resid : 0));
          for (auto& x : rs) x.probe_col.side += 1; // the key table sits in front of the probe's sides
-         const int32_t st = probe_impl(ctx, ht, rp.rel, &k0, 1, kind, rs.data(), n_resid, out, mark_out, false);
+         const int32_t st = probe_impl(ctx, ht, rp.rel, &k0, 1, kind, rs.data(), n_resid, out, mark_out, false, &rp);
          if (st == LDB_OK && kind != LDB_JOIN_SEMI_BUILD && kind != LDB_JOIN_ANTI_BUILD) radix_strip(ctx, *out);
          radix_release(ctx, rp);
          return st;
@@ -1011,7 +1104,8 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       h->bitmap = (uint64_t) bitmap;
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
-      if (n) LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_unique", "k_join_probe_unique_spec", k_join_probe_unique));
+      if (n && part_probe_ok(ht, part, n_resid) && probe->pending.empty()) LDB_TRY(launch_part_probe(ctx, ht, part, n, 1, match, bitmap, counter)); // partitions staged in LDS
+      else if (n) LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_unique", "k_join_probe_unique_spec", k_join_probe_unique));
       ldb_dev_free(ctx, d);
       if (getenv("LDB_DEBUG_COUNTS")) {
          uint64_t c[3];

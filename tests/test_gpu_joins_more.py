@@ -154,7 +154,7 @@ def test_radix_clustered_probe_gives_the_direct_probe_results(ctx, oracle, data)
         lib.ldb_gpu_set_option(b"join_radix", 1)
         radix = run()
     finally:
-        lib.ldb_gpu_set_option(b"join_radix", 0)
+        lib.ldb_gpu_set_option(b"join_radix", -1)  # the default: auto
         lib.ldb_gpu_set_option(b"join_radix_part_bytes", 1 << 20)
     assert radix == direct
     want, wb, _ = oracle.join(ho, [(0, 0)], hl, [(0, 0)], capi.JOIN_INNER, threads=2)

@@ -230,6 +230,16 @@ def test_radix_probe_over_the_write_combining_partition(ctx, part_bytes):
             assert ctx.prof_all().get("k_radix_scatter", (0, 0.0))[0] >= 1, "the radix path did not run"
             r = ht.probe(p.rel(), [(0, 0)])
             assert sorted(zip(r.rowids(0).tolist(), r.rowids(1).tolist())) == want_pairs
+            lo = ht.probe(p.rel(), [(0, 0)], capi.JOIN_LEFT_OUTER)  # every probe row once; the build side padded where there is no partner
+            lp, lb = lo.rowids(0), lo.rowids(1)
+            assert len(lp) == npr and sorted(lp.tolist()) == list(range(npr))
+            assert sorted((int(a), int(b_)) for a, b_ in zip(lp.tolist(), lb.tolist()) if b_ != 0xFFFFFFFF) == want_pairs
+            for lds in (0,):  # the partitions probed from the cache instead of LDS
+                lib.ldb_gpu_set_option(b"join_radix_lds", lds)
+                assert ht.probe_count(p.rel(), [(0, 0)]) == int(hit.sum())
+                r2 = ht.probe(p.rel(), [(0, 0)])
+                assert sorted(zip(r2.rowids(0).tolist(), r2.rowids(1).tolist())) == want_pairs
+                lib.ldb_gpu_set_option(b"join_radix_lds", 1)
             for wc in (0,):  # the one-pass cursor scatter as the control
                 lib.ldb_gpu_set_option(b"join_radix_wc", wc)
                 assert ht.probe_count(p.rel(), [(0, 0)]) == int(hit.sum())
@@ -238,8 +248,9 @@ def test_radix_probe_over_the_write_combining_partition(ctx, part_bytes):
             assert ht.probe_count(p.rel(), [(0, 0)]) == int(hit.sum())
             ht.release()
     finally:
-        lib.ldb_gpu_set_option(b"join_radix", 0)
+        lib.ldb_gpu_set_option(b"join_radix", -1)  # the default: auto
         lib.ldb_gpu_set_option(b"join_radix_wc", 1)
+        lib.ldb_gpu_set_option(b"join_radix_lds", 1)
         lib.ldb_gpu_set_option(b"join_radix_part_bytes", 1 << 20)
         lib.ldb_gpu_set_option(b"join_rank", 1)
         ctx.prof_enable(False)

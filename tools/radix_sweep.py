@@ -3,7 +3,7 @@ l_orderkey-like keys → 150 M orders at SF100), for both table layouts (ordered
 over partition sizes from LDS-sized to L2/MALL-sized.  Prints one JSON document: per configuration the
 per-kernel milliseconds (k_radix_hist, k_radix_scatter, the probe kernel, helpers), their sum, the algorithmic
 bytes of each pass and the matches (must equal the direct probe's).
-usage: python tools/radix_sweep.py [SF=100]"""
+usage: python tools/radix_sweep.py [SF=100] [tables=0,1]"""
 import json
 import os
 import sys
@@ -34,7 +34,8 @@ def timed(reps=3):
     return ks, round(sum(ks.values()), 3), m
 
 
-for rank in (0, 1):
+tables = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,1").split(",")]  # 0 = ordered 8-byte slots, 1 = rank table
+for rank in tables:
     L.ldb_gpu_set_option(b"join_rank", rank)
     L.ldb_gpu_set_option(b"join_direct", rank)
     ht = od.rel().join_build([(0, 0)], unique=True)
@@ -48,8 +49,9 @@ for rank in (0, 1):
         if tb // pb > 4096 * 1:  # RX_MAX_PARTS partitions at most
             continue
         L.ldb_gpu_set_option(b"join_radix_part_bytes", pb)
-        for wc in ((1, 0) if rank else (0,)):  # round 4: the write-combining tile-sort partition (ldb_wc.hip; direct / rank tables) beside the one-pass cursor scatter
+        for wc, lds in (((1, 1), (1, 0), (0, 0)) if rank else ((0, 0),)):  # round 4: write-combining partition (ldb_wc.hip) [+ LDS-staged probe] beside the one-pass cursor scatter
             L.ldb_gpu_set_option(b"join_radix_wc", wc)
+            L.ldb_gpu_set_option(b"join_radix_lds", lds)
             ks, total, m = timed()
             assert m == m0, (m, m0)
             parts = 16
@@ -58,9 +60,10 @@ for rank in (0, 1):
             passes = 2 if (wc and parts > 64) else 1
             # bytes: histogram reads the keys; scatter pass 1 reads keys, writes (key, row); pass 2 reads the keys again for its histogram, then reads and writes (key, row)
             by = {"hist": rows * 4 * passes, "scatter": rows * (4 + 8) + (rows * 16 if passes == 2 else 0), "probe": rows * 8 + tb}
-            out["runs"].append({"table": "rank" if rank else "ordered", "table_bytes": tb, "radix": True, "write_combining": bool(wc), "partitions": parts, "passes": passes, "part_bytes": pb,
+            out["runs"].append({"table": "rank" if rank else "ordered", "table_bytes": tb, "radix": True, "write_combining": bool(wc), "lds_staged_probe": bool(lds and pb <= 65536), "partitions": parts, "passes": passes, "part_bytes": pb,
                                 "kernels_ms": ks, "total_ms": total, "matches": m, "bytes": by})
         L.ldb_gpu_set_option(b"join_radix_wc", 1)
+        L.ldb_gpu_set_option(b"join_radix_lds", 1)
     L.ldb_gpu_set_option(b"join_radix", 0)
     del ht
 print(json.dumps(out, indent=1))

@@ -276,11 +276,16 @@ class Runner:
         ctx.prof_reset()
         for _ in range(reps):
             m2 = ht.probe_count(pk.rel(), [(0, 0)])
-        n_p, ms_p = ctx.prof_all().get("k_join_probe_count", (0, 0.0))
+        pr = ctx.prof_all()
+        n_p, ms_p = pr.get("k_join_probe_count", (0, 0.0))
         if n_p:
-            avg = ms_p / n_p
+            # since round 4 the library partitions such a probe side itself (join_radix = -1: write-combining two-pass partition into
+            # LDS-sized table slices + LDS-staged probe): the time of a probe is histogram + scatter + probe kernels together
+            parts = {k: round(pr[k][1] / reps, 4) for k in ("k_radix_hist", "k_radix_scatter", "k_join_probe_count") if k in pr}
+            avg = sum(parts.values())
             out["unclustered"] = {"probe_rows": pk.rows, "matches": m2, "probe_ms": round(avg, 4), "probe_grows_per_s": round(pk.rows / (avg * 1e-3) / 1e9, 3),
-                                  "survey_model_gbs": round(pk.rows * 12 / (avg * 1e-3) / 1e9, 1)}
+                                  "survey_model_gbs": round(pk.rows * 12 / (avg * 1e-3) / 1e9, 1), "kernels_ms": parts,
+                                  "radix_partitioned": "k_radix_scatter" in parts}
         pk.release()
         ht.release()
         # selective variant: build side filtered to ≈10 % of orders (o_orderdate < 1992-09-01)
