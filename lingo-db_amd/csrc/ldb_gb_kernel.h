@@ -37,7 +37,9 @@ enum { ACC_SUM64 = 0,
        ACC_MAX64 = 4,
        ACC_SUMF64 = 5,
        ACC_MINF64 = 6,
-       ACC_MAXF64 = 7 };
+       ACC_MAXF64 = 7,
+       ACC_MIN128 = 8, // three words: low, high (signed), lock
+       ACC_MAX128 = 9 };
 
 struct DFactorG {
    int32_t has_col;
@@ -245,6 +247,45 @@ __device__ __forceinline__ void d_sink_add128(const Sink& s, int word, u128 v) {
    if (hi) atomicAdd(s.w(word + 1), hi);
 }
 
+// 128-bit MIN / MAX: gfx950 has no 128-bit atomic, and the two halves cannot be lowered independently
+// (the low word only means something next to its high word), so the pair is updated under a
+// per-slot lock word.  The winning lane takes the lock, compares, stores and releases inside the
+// same branch — lanes of one wave that lose retry in the next iteration, so there is no
+// intra-wave wait on a lane that cannot progress.  A value whose high word is already worse than
+// the slot's (which only ever improves) is rejected without the lock.
+// (the reference's reduce function is a signed `arith.minsi` / `maxsi` on i128 values under the
+// entry's lock-free single-writer fragment, SubOpToControlFlow.cpp:1861-1938 merges fragments)
+__device__ __forceinline__ void d_sink_minmax128(const Sink& s, int word, i128 v, bool is_min) {
+   const unsigned long long lo = (unsigned long long) (u128) v;
+   const long long hi = (long long) (v >> 64);
+   if (s.plain) { // only contributor of an identity-initialised slot
+      *s.w(word) = lo;
+      *s.w(word + 1) = (unsigned long long) hi;
+      return;
+   }
+   const long long seen = (long long) __hip_atomic_load(s.w(word + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+   if (is_min ? hi > seen : hi < seen) return;
+   unsigned long long* lock = s.w(word + 2);
+   bool done = false;
+   do {
+      if (atomicCAS(lock, 0ull, 1ull) == 0ull) {
+         __threadfence();
+         const unsigned long long clo = __hip_atomic_load(s.w(word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         const long long chi = (long long) __hip_atomic_load(s.w(word + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         const i128 cur = (i128) (((u128) (unsigned long long) chi << 64) | clo);
+         if (is_min ? v < cur : v > cur) {
+            __hip_atomic_store(s.w(word), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(s.w(word + 1), (unsigned long long) hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         }
+         __threadfence();
+         atomicExch(lock, 0ull);
+         done = true;
+      }
+   } while (!done);
+}
+#define GB_I128_MAX ((i128) ((((u128) 0x7FFFFFFFFFFFFFFFull) << 64) | (u128) 0xFFFFFFFFFFFFFFFFull))
+#define GB_I128_MIN ((i128) (((u128) 0x8000000000000000ull) << 64))
+
 // fold one input row into the accumulators of its group
 __device__ __forceinline__ void d_accumulate(const DGroupBy& m, const DGroupBy* __restrict__ d, const RowVals& rv, uint32_t rvalid, uint64_t i,
                                              const Sink& s) {
@@ -279,6 +320,8 @@ __device__ __forceinline__ void d_accumulate(const DGroupBy& m, const DGroupBy* 
          case ACC_SUM64: atomicAdd(s.w(acc.word), (unsigned long long) v); break; // i64 wrap = SUM in the argument type
          case ACC_SUM128: d_sink_add128(s, acc.word, (u128) v); break;
          case ACC_MIN64: atomicMin((long long*) s.w(acc.word), (long long) v); break;
+         case ACC_MIN128: d_sink_minmax128(s, acc.word, v, true); break;
+         case ACC_MAX128: d_sink_minmax128(s, acc.word, v, false); break;
          default: atomicMax((long long*) s.w(acc.word), (long long) v); break;
       }
    }
@@ -385,6 +428,16 @@ __device__ __forceinline__ void d_accumulate_runs(const DGroupBy& m, const DGrou
             if (apply && r != GB_I64_MAX) atomicMin((long long*) s.w(acc.word), r);
             break;
          }
+         case ACC_MIN128: {
+            u128 r = d_seg_reduce<u128>(ok ? (u128) v : (u128) GB_I128_MAX, lane, run_end, [](u128 x, u128 y) { return (i128) y < (i128) x ? y : x; });
+            if (apply && (i128) r != GB_I128_MAX) d_sink_minmax128(s, acc.word, (i128) r, true);
+            break;
+         }
+         case ACC_MAX128: {
+            u128 r = d_seg_reduce<u128>(ok ? (u128) v : (u128) GB_I128_MIN, lane, run_end, [](u128 x, u128 y) { return (i128) y > (i128) x ? y : x; });
+            if (apply && (i128) r != GB_I128_MIN) d_sink_minmax128(s, acc.word, (i128) r, false);
+            break;
+         }
          default: {
             long long r = d_seg_reduce<long long>(ok ? (long long) v : GB_I64_MIN, lane, run_end, [](long long x, long long y) { return y > x ? y : x; });
             if (apply && r != GB_I64_MIN) atomicMax((long long*) s.w(acc.word), r);
@@ -414,6 +467,12 @@ __device__ __forceinline__ void d_combine(const DGroupBy& m, const Sink& src, co
          }
          case ACC_MIN64: atomicMin((long long*) dst.w(acc.word), (long long) x); break;
          case ACC_MAX64: atomicMax((long long*) dst.w(acc.word), (long long) x); break;
+         case ACC_MIN128:
+         case ACC_MAX128: {
+            const i128 v = (i128) (((u128) *src.w(acc.word + 1) << 64) | x);
+            if (v != (acc.kind == ACC_MIN128 ? GB_I128_MAX : GB_I128_MIN)) d_sink_minmax128(dst, acc.word, v, acc.kind == ACC_MIN128);
+            break;
+         }
          case ACC_SUMF64:
             if (__longlong_as_double((long long) x) != 0.0) atomicAdd((double*) dst.w(acc.word), __longlong_as_double((long long) x));
             break;

@@ -220,7 +220,7 @@ __global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restri
             default: {
                const DAcc& a = d->accs[out.acc];
                uint64_t lo = acc[(uint64_t) a.word * cap];
-               if (a.kind == ACC_SUM128) v = (i128) (((u128) acc[(uint64_t) (a.word + 1) * cap] << 64) | lo);
+               if (a.kind == ACC_SUM128 || a.kind == ACC_MIN128 || a.kind == ACC_MAX128) v = (i128) (((u128) acc[(uint64_t) (a.word + 1) * cap] << 64) | lo);
                else v = (i128) (int64_t) lo;
                if (out.fn == LDB_AGG_AVG && ok) {
                   // (sum * 10^k) sdiv count in i128 (DecimalOpScaledLowering, LowerToStd.cpp:631-651)
@@ -373,7 +373,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       if (h->n_accs >= GB_MAX_ACCS || h->n_words + words > GB_MAX_WORDS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: too many distinct accumulators");
       a.word = h->n_words;
       h->word_init[h->n_words] = init;
-      if (words == 2) h->word_init[h->n_words + 1] = 0;
+      for (int k = 1; k < words; k++) h->word_init[h->n_words + k] = 0;
       h->n_words += words;
       h->accs[h->n_accs] = a;
       *idx = h->n_accs++;
@@ -487,8 +487,14 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          }
          case LDB_AGG_MIN:
          case LDB_AGG_MAX: {
-            if (sp.wide && !sp.arg.is_float) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: MIN/MAX over 128-bit decimals");
-            if (sp.arg.is_float) {
+            if (sp.wide && !sp.arg.is_float) { // low word, signed high word, lock word (d_sink_minmax128)
+               acc.kind = sp.fn == LDB_AGG_MIN ? ACC_MIN128 : ACC_MAX128;
+               LDB_TRY(add_acc(acc, 3, 0, &o.acc));
+               const int w0 = h->accs[o.acc].word;
+               h->word_init[w0] = sp.fn == LDB_AGG_MIN ? ~0ull : 0ull;
+               h->word_init[w0 + 1] = sp.fn == LDB_AGG_MIN ? (uint64_t) INT64_MAX : (uint64_t) INT64_MIN;
+               h->word_init[w0 + 2] = 0;
+            } else if (sp.arg.is_float) {
                double init = sp.fn == LDB_AGG_MIN ? __builtin_inf() : -__builtin_inf();
                uint64_t bits;
                memcpy(&bits, &init, 8);

@@ -46,11 +46,12 @@ struct Unsupported : std::runtime_error {
 struct Expr;
 using ExprP = std::shared_ptr<Expr>;
 struct Expr {
-   enum Kind { COL, CONST_INT, CONST_STR, CONST_BOOL, MEMBER, REF, HASH, MARKER, FLAG, UNKNOWN, OP } kind = UNKNOWN; // MARKER: "a partner exists" of a probe row; FLAG: of a build row
-   std::string name; // COL: column name in the plan language; MEMBER: member; OP: add sub mul div cast cmp and or not isnull select between in
+   enum Kind { COL, CONST_INT, CONST_STR, CONST_BOOL, MEMBER, REF, HASH, MARKER, FLAG, NULLV, UNKNOWN, OP } kind = UNKNOWN; // MARKER: "a partner exists" of a probe row; FLAG: of a build row; NULLV: db.null
+   std::string name; // COL: column name in the plan language; MEMBER: member; OP: add sub mul div cast cmp and or not isnull select between in call (cmp = the runtime function)
    std::string cmp; // OP cmp: EQ NEQ LT LTE GT GTE; constants: the dump's data_type
    int64_t i = 0;
    bool build = false; // COL gathered from the build side of the hash join being matched
+   bool base = false; // COL of a scanned base table (its type is the table's: column-vs-column restrictions compare like with like)
    std::vector<ExprP> args;
 };
 ExprP mk(Expr::Kind k, const std::string& name = "") {
@@ -116,6 +117,7 @@ struct Stream {
    bool bareTable = false; // `rel` is an input table nothing has been applied to yet (its restrictions are in `preds`)
    std::vector<std::string> preds; // restrictions not yet applied (JSON objects of the plan language)
    std::map<std::string, ExprP> cols; // column displayName ("lineitem::l_quantity") → what it is
+   std::set<std::string> names; // every column name the relation physically has (the plan language resolves columns by name)
    std::vector<std::set<std::string>> unique; // column sets known to identify a row
    std::string probeHiv, aggState; // the hash-indexed view being probed / the state being reduced into
    // the equalities of the hash join being matched are known, the join kind is not yet: inner unless the marker idiom of a
@@ -124,6 +126,11 @@ struct Stream {
    std::vector<std::string> probeKeys, buildKeys;
    std::string flagState; // scan of a build buffer whose flag member a semi / anti join with reversed sides has set
    std::string nlBuild; // nested-loop join (translateNLJ): the buffer being scanned once per tuple of this stream
+   bool inJoinBody = false; // between the gather of a hash join and the end of its nested_map: filters are conjuncts of the join predicate
+   std::vector<std::string> residual; // non-equality conjuncts relating the two sides ({"probe", "op", "build"})
+   std::vector<ExprP> postJoin; // conjuncts of the join predicate that do not relate one probe with one build column: applied to the joined rows (inner joins only)
+   bool antiBranch = false; // outer / single join: the branch of the probe rows WITHOUT a partner (filter none_true on the marker)
+   std::string constState; // constant single join: the one-row state this stream looked up
 };
 struct AggSpec {
    std::string member, fn;
@@ -140,7 +147,7 @@ struct OutStep {
    std::vector<OutAgg> aggs; // groupby
 };
 struct State {
-   enum Kind { UNKNOWN, TABLE, AGG, BUFFER, HIV, SORTED, HEAP, RESULT, MARKER } kind = UNKNOWN;
+   enum Kind { UNKNOWN, TABLE, AGG, BUFFER, HIV, SORTED, HEAP, RESULT, MARKER, CONST1 } kind = UNKNOWN; // CONST1: the scattered one-row state of a constant single join
    std::string table; // TABLE
    std::map<std::string, std::string> memberToIdent;
    std::vector<std::string> filters, pkey;
@@ -218,6 +225,7 @@ struct Translator {
             throw Unsupported("floating-point constant");
          }
          if (leaf == "member") return mk(Expr::MEMBER, e.s("member"));
+         if (leaf == "null") return mk(Expr::NULLV);
          return mk(Expr::UNKNOWN); // "unknown" / "null": only legal inside the recognised aggregate bodies
       }
       if (type != "expression_inner") throw Unsupported("expression node of type '" + type + "'");
@@ -284,7 +292,13 @@ struct Translator {
          r->args = a;
          return r;
       }
-      throw Unsupported("expression '" + first + "…' (runtime call or operator without a device form)");
+      if (first.size() > 1 && first.back() == '(' && isalpha((unsigned char) first[0])) { // db.runtime_call: "Fn(" a ", " b ")" (mlir-subop-to-json.cpp:318-326)
+         ExprP r = mk(Expr::OP, "call");
+         r->cmp = first.substr(0, first.size() - 1);
+         r->args = a;
+         return r;
+      }
+      throw Unsupported("expression '" + first + "…' (operator without a device form)");
    }
 
    // ---------------------------------------------------------------- emission helpers
@@ -312,6 +326,22 @@ struct Translator {
       if (e->kind == Expr::COL) use(e->name);
       for (auto& a : e->args) useAll(a);
    }
+   // runtime calls nested inside an expression become columns first (the expression language is arithmetic / boolean only)
+   ExprP materializeCalls(Stream& s, const ExprP& e, const std::string& hint) {
+      if (e->kind != Expr::OP) return e;
+      if (e->name == "call" && (e->cmp == "ExtractYearFromDate" || e->cmp == "Substring")) return mk(Expr::COL, ensureCol(s, e, hint + "_f" + std::to_string(++nval)));
+      bool changed = false;
+      std::vector<ExprP> args;
+      for (auto& a : e->args) {
+         ExprP n = materializeCalls(s, a, hint);
+         changed = changed || n != a;
+         args.push_back(n);
+      }
+      if (!changed) return e;
+      auto r = std::make_shared<Expr>(*e);
+      r->args = args;
+      return r;
+   }
    // a plain column holding `e` on the stream: a computed expression becomes a `map` step
    std::string ensureCol(Stream& s, const ExprP& e0, const std::string& hint) {
       const ExprP e = stripCast(e0);
@@ -319,15 +349,32 @@ struct Translator {
          use(e->name);
          return e->name;
       }
-      flush(s);
-      useAll(e);
       OutStep m;
       m.op = "map";
-      m.out = fresh("v");
       const std::string as = sanitize(hint);
-      m.fields = {{"in", quote(s.rel)}, {"expr", exprJson(flattenMul(e))}, {"as", quote(as)}};
+      if (e->kind == Expr::OP && e->name == "call") { // the runtime functions with a device kernel: extract(year …) and substring
+         const ExprP a0 = e->args.empty() ? nullptr : stripCast(e->args[0]);
+         if (e->cmp == "ExtractYearFromDate" && e->args.size() == 1) {
+            const std::string src = ensureCol(s, a0, hint + "_arg");
+            flush(s);
+            m.fields = {{"in", quote(s.rel)}, {"fn", "\"extract_year\""}, {"col", quote(src)}, {"as", quote(as)}};
+         } else if (e->cmp == "Substring" && e->args.size() == 3 && stripCast(e->args[1])->kind == Expr::CONST_INT && stripCast(e->args[2])->kind == Expr::CONST_INT) {
+            const std::string src = ensureCol(s, a0, hint + "_arg"); // StringRuntime::substr(str, from, len)
+            flush(s);
+            m.fields = {{"in", quote(s.rel)}, {"fn", "\"substr\""}, {"col", quote(src)}, {"from", std::to_string(stripCast(e->args[1])->i)}, {"for", std::to_string(stripCast(e->args[2])->i)}, {"as", quote(as)}};
+         } else {
+            throw Unsupported("runtime function '" + e->cmp + "' has no device form");
+         }
+      } else {
+         const ExprP x = materializeCalls(s, e, hint);
+         flush(s);
+         useAll(x);
+         m.fields = {{"in", quote(s.rel)}, {"expr", exprJson(flattenMul(x))}, {"as", quote(as)}};
+      }
+      m.out = fresh("v");
       steps.push_back(m);
       s.rel = m.out;
+      s.names.insert(as);
       ExprP c = mk(Expr::COL, as);
       for (auto& kv : s.cols)
          if (kv.second == e0) kv.second = c;
@@ -356,6 +403,36 @@ struct Translator {
          if (l->kind != Expr::COL || !isConst(r)) return false;
          use(l->name);
          out.push_back("{\"col\": " + quote(l->name) + ", \"op\": " + quote(op) + ", \"value\": " + lit(r) + "}");
+         return true;
+      }
+      if (c->name == "in") { // db.oneof: column in [constants]
+         const ExprP l = stripCast(c->args[0]);
+         if (l->kind != Expr::COL || c->args.size() < 2) return false;
+         std::string vals;
+         for (size_t k = 1; k < c->args.size(); k++) {
+            const ExprP v = stripCast(c->args[k]);
+            if (!isConst(v)) return false;
+            vals += (vals.empty() ? "" : ", ") + lit(v);
+         }
+         use(l->name);
+         out.push_back("{\"col\": " + quote(l->name) + ", \"op\": \"IN\", \"values\": [" + vals + "]}");
+         return true;
+      }
+      if (c->name == "call" || (c->name == "not" && stripCast(c->args[0])->kind == Expr::OP && stripCast(c->args[0])->name == "call")) { // [not] ConstLike(column, pattern)
+         const bool neg = c->name == "not";
+         const ExprP f = neg ? stripCast(c->args[0]) : c;
+         if ((f->cmp != "ConstLike" && f->cmp != "Like") || f->args.size() != 2) return false;
+         const ExprP l = stripCast(f->args[0]), pat = stripCast(f->args[1]);
+         if (l->kind != Expr::COL || pat->kind != Expr::CONST_STR) return false;
+         use(l->name);
+         out.push_back("{\"col\": " + quote(l->name) + ", \"op\": " + (neg ? "\"NOT LIKE\"" : "\"LIKE\"") + ", \"value\": " + quote(pat->name) + "}");
+         return true;
+      }
+      if (c->name == "not" && stripCast(c->args[0])->kind == Expr::OP && stripCast(c->args[0])->name == "isnull") { // not (x is null)
+         const ExprP l = stripCast(stripCast(c->args[0])->args[0]);
+         if (l->kind != Expr::COL) return false;
+         use(l->name);
+         out.push_back("{\"col\": " + quote(l->name) + ", \"op\": \"NOTNULL\"}");
          return true;
       }
       if (c->name == "or") {
@@ -442,6 +519,8 @@ struct Translator {
       steps.push_back(g);
       Stream out;
       out.rel = g.out;
+      out.names.insert(keys.begin(), keys.end());
+      for (auto& a : g.aggs) out.names.insert(a.as);
       if (!keys.empty()) out.unique.push_back(std::set<std::string>(keys.begin(), keys.end()));
       size_t kk = 0;
       for (auto& m : mapping.arr) {
@@ -458,6 +537,7 @@ struct Translator {
       std::map<std::string, StateP> local; // "<ref>#<resnr>" of states created inside the step
       std::map<std::string, Stream> streams; // by producing sub-operator
       Stream* nested = nullptr; // the stream a nested_map hands to its body
+      bool outerBody = false; // the nested_map body being walked ends in a union: an outer / single join (RelAlgToSubOp.cpp:1486-1587)
    };
    StateP resolve(const J& acc, StepCtx& c) {
       const std::string& t = acc.s("type");
@@ -499,11 +579,21 @@ struct Translator {
       return p + "}";
    }
 
-   // the `=` conjuncts that follow the gather name the keys of the hash join
-   void resolveJoinKeys(Stream& s, const ExprP& pred) {
+   // which side of the hash join being matched an expression reads: 0 nothing, 1 probe, 2 build, 3 both
+   static int sideOf(const ExprP& e) {
+      int r = e->kind == Expr::COL ? (e->build ? 2 : 1) : 0;
+      for (auto& a : e->args) r |= sideOf(a);
+      return r;
+   }
+   static std::string mirrored(const std::string& op) { return op == "LT" ? "GT" : op == "GT" ? "LT" : op == "LTE" ? "GTE" : op == "GTE" ? "LTE" : op; }
+   // one filter inside the nested_map body of a hash join = conjunct(s) of the join predicate (translateSelection emits one
+   // map + filter per conjunct, RelAlgToSubOp.cpp:173-258): probe = build equalities are the keys, other comparisons
+   // between the sides the residual of the probe, anything else is applied to the joined rows
+   void addJoinConjunct(Stream& s, const ExprP& pred) {
       StateP hiv = states.at(s.probeHiv);
       std::vector<ExprP> conj;
-      std::function<void(const ExprP&)> split = [&](const ExprP& e) {
+      std::function<void(const ExprP&)> split = [&](const ExprP& e0) {
+         const ExprP e = stripCast(e0);
          if (e->kind == Expr::OP && e->name == "and")
             for (auto& a : e->args) split(a);
          else
@@ -512,14 +602,74 @@ struct Translator {
       split(pred);
       Stream& b = hiv->source->in;
       for (auto& e : conj) {
-         if (!(e->kind == Expr::OP && e->name == "cmp" && e->cmp == "EQ")) throw Unsupported("hash join with a residual (non-equality) predicate");
-         ExprP l = stripCast(e->args[0]), r = stripCast(e->args[1]);
-         if (l->build && !r->build) std::swap(l, r);
-         if (l->build || !r->build) throw Unsupported("join equality does not compare a probe column with a gathered build column");
-         s.buildKeys.push_back(ensureCol(b, r, "build_key"));
-         s.probeKeys.push_back(ensureCol(s, l, "probe_key"));
+         if (e->kind == Expr::OP && e->name == "cmp") {
+            ExprP l = stripCast(e->args[0]), r = stripCast(e->args[1]);
+            std::string op = e->cmp;
+            if (sideOf(l) == 2 && sideOf(r) == 1) {
+               std::swap(l, r);
+               op = mirrored(op);
+            }
+            if (sideOf(l) == 1 && sideOf(r) == 2) {
+               const std::string bc = ensureCol(b, r, "build_key"), pc = ensureCol(s, l, "probe_key");
+               if (op == "EQ") {
+                  s.buildKeys.push_back(bc);
+                  s.probeKeys.push_back(pc);
+               } else {
+                  s.residual.push_back("{\"probe\": " + quote(pc) + ", \"op\": " + quote(op) + ", \"build\": " + quote(bc) + "}");
+               }
+               continue;
+            }
+         }
+         s.postJoin.push_back(e);
       }
       s.pending = true;
+   }
+   // the plan language resolves columns by name: when the rows of `buf` are about to be joined to a stream that already has
+   // columns of the same names (self joins, the same table inside a subquery, a group key named like its input column), the
+   // buffer's columns are re-materialised under fresh names first
+   void separateNames(const Stream& s, const StateP& buf, bool built) {
+      Stream& b = buf->in;
+      bool clash = false;
+      for (auto& n : b.names) clash = clash || s.names.count(n);
+      if (!clash) return;
+      if (built) throw Unsupported("column names of the two join sides collide and the hash table is already built");
+      std::vector<std::pair<std::string, std::string>> cols; // member → current column
+      for (auto& kv : buf->members) {
+         const Expr::Kind k = stripCast(kv.second)->kind;
+         if (k == Expr::HASH || k == Expr::REF || k == Expr::CONST_BOOL || k == Expr::FLAG || k == Expr::MARKER || k == Expr::NULLV) continue;
+         cols.push_back({kv.first, ensureCol(b, kv.second, stripSuffix(kv.first))});
+      }
+      flush(b);
+      std::map<std::string, std::string> renamed;
+      std::string list = "[";
+      for (auto& mc : cols) {
+         if (renamed.count(mc.second)) continue;
+         const std::string to = s.names.count(mc.second) ? mc.second + "_" + std::to_string(++nval) : mc.second;
+         renamed[mc.second] = to;
+         list += std::string(list.size() > 1 ? ", " : "") + (to == mc.second ? quote(to) : "{\"col\": " + quote(mc.second) + ", \"as\": " + quote(to) + "}");
+      }
+      OutStep m;
+      m.op = "materialize";
+      m.out = fresh("v");
+      m.fields = {{"in", quote(b.rel)}, {"cols", list + "]"}};
+      steps.push_back(m);
+      b.rel = m.out;
+      b.bareTable = false;
+      b.names.clear();
+      for (auto& r : renamed) b.names.insert(r.second);
+      for (auto& mc : cols) buf->members[mc.first] = mk(Expr::COL, renamed[mc.second]);
+      std::vector<std::set<std::string>> uniq;
+      for (auto& u : b.unique) {
+         std::set<std::string> r;
+         bool all = true;
+         for (auto& k : u) {
+            auto it = renamed.find(k);
+            all = all && it != renamed.end();
+            if (it != renamed.end()) r.insert(it->second);
+         }
+         if (all) uniq.push_back(r);
+      }
+      b.unique = uniq;
    }
    static std::string nameList(const std::vector<std::string>& v) {
       std::string o = "[";
@@ -530,6 +680,7 @@ struct Translator {
    std::string emitJoin(Stream& s, const std::string& kind) {
       StateP hiv = states.at(s.probeHiv);
       Stream& b = hiv->source->in;
+      if (s.probeKeys.empty()) throw Unsupported("hash join without an equality between the sides");
       if (hiv->ht.empty()) {
          flush(b);
          bool uniq = false;
@@ -555,6 +706,12 @@ struct Translator {
       jp.op = "join_probe";
       jp.out = fresh("j");
       jp.fields = {{"ht", quote(hiv->ht)}, {"in", quote(s.rel)}, {"keys", nameList(s.probeKeys)}, {"kind", quote(kind)}};
+      if (!s.residual.empty()) {
+         std::string r = "[";
+         for (size_t k = 0; k < s.residual.size(); k++) r += (k ? ", " : "") + s.residual[k];
+         jp.fields.push_back({"residual", r + "]"});
+      }
+      if (kind != "inner" && !s.postJoin.empty()) throw Unsupported("a " + kind + " join whose predicate has a conjunct on one side only");
       steps.push_back(jp);
       return jp.out;
    }
@@ -563,11 +720,21 @@ struct Translator {
       if (!s.pending) return;
       StateP hiv = states.at(s.probeHiv);
       s.rel = emitJoin(s, "inner");
+      s.names.insert(hiv->source->in.names.begin(), hiv->source->in.names.end());
+      clearJoin(s);
+      if (!hiv->htUnique) s.unique.clear(); // probe rows may repeat
+      const std::vector<ExprP> post = s.postJoin;
+      s.postJoin.clear();
+      for (auto& e : post) applyFilter(s, e);
+   }
+   // the join has been emitted: its build columns are columns of the stream now
+   void clearJoin(Stream& s) {
       s.pending = false;
+      s.inJoinBody = false;
       s.probeHiv.clear();
       s.probeKeys.clear();
       s.buildKeys.clear();
-      if (!hiv->htUnique) s.unique.clear(); // probe rows may repeat
+      s.residual.clear();
       for (auto& kv : s.cols)
          if (kv.second->build) {
             auto c = std::make_shared<Expr>(*kv.second);
@@ -575,13 +742,57 @@ struct Translator {
             kv.second = c;
          }
    }
+   // a restriction on the rows of a stream: conjunctions of column-vs-constant comparisons / IN / LIKE / NOT NULL, two
+   // columns of base tables, a disjunction of such conjunctions (→ filter_dnf), or any arithmetic / boolean expression
+   // (→ a computed boolean column + `= true`)
+   void applyFilter(Stream& s, const ExprP& e0) {
+      const ExprP e = materializeCalls(s, stripCast(e0), "pred");
+      std::vector<std::string> ps;
+      if (condPreds(e, ps)) {
+         s.preds.insert(s.preds.end(), ps.begin(), ps.end());
+         return;
+      }
+      if (e->kind == Expr::OP && e->name == "cmp") {
+         const ExprP l = stripCast(e->args[0]), r = stripCast(e->args[1]);
+         if (l->kind == Expr::COL && r->kind == Expr::COL && l->base && r->base) {
+            use(l->name), use(r->name);
+            s.preds.push_back("{\"col\": " + quote(l->name) + ", \"op\": " + quote(e->cmp) + ", \"rhs_col\": " + quote(r->name) + "}");
+            return;
+         }
+      }
+      if (e->kind == Expr::OP && e->name == "or") { // disjunctive normal form
+         std::string clauses = "[";
+         bool ok = true;
+         for (size_t k = 0; k < e->args.size() && ok; k++) {
+            std::vector<std::string> cl;
+            ok = condPreds(e->args[k], cl);
+            clauses += std::string(k ? ", " : "") + "[";
+            for (size_t j = 0; j < cl.size(); j++) clauses += (j ? ", " : "") + cl[j];
+            clauses += "]";
+         }
+         if (ok) {
+            flush(s);
+            OutStep f;
+            f.op = "filter_dnf";
+            f.out = fresh("v");
+            f.fields = {{"in", quote(s.rel)}, {"clauses", clauses + "]"}};
+            steps.push_back(f);
+            s.rel = f.out;
+            return;
+         }
+      }
+      const std::string col = ensureCol(s, e, "pred" + std::to_string(++nval));
+      s.preds.push_back("{\"col\": " + quote(col) + ", \"op\": \"EQ\", \"value\": 1}");
+   }
    // semi / anti join keeping the PROBE rows: the build columns are gone afterwards
    void finishProbeSide(Stream& s, bool anti) {
       s.rel = emitJoin(s, anti ? "anti" : "semi");
       s.pending = false;
+      s.inJoinBody = false;
       s.probeHiv.clear();
       s.probeKeys.clear();
       s.buildKeys.clear();
+      s.residual.clear();
       for (auto it = s.cols.begin(); it != s.cols.end();)
          it = it->second->build || it->second->kind == Expr::MARKER ? s.cols.erase(it) : std::next(it);
    }
@@ -620,6 +831,7 @@ struct Translator {
       j.fields = {{"in", quote(s.rel)}, {"build", quote(b.rel)}, {"residual", resid + "]"}, {"kind", "\"inner\""}};
       steps.push_back(j);
       s.rel = j.out;
+      s.names.insert(b.names.begin(), b.names.end());
       s.nlBuild.clear();
       s.unique.clear();
       for (auto& kv : s.cols)
@@ -727,10 +939,13 @@ struct Translator {
             s.bareTable = true;
             s.preds = st->filters;
             if (!st->pkey.empty()) s.unique.push_back(std::set<std::string>(st->pkey.begin(), st->pkey.end()));
+            for (auto& kv : st->memberToIdent) s.names.insert(kv.second);
             for (auto& m : mapping.arr) {
                auto it = st->memberToIdent.find(m.s("member"));
                if (it == st->memberToIdent.end()) throw Unsupported("scan of member '" + m.s("member") + "' that get_external does not map");
-               s.cols[m.at("column").s("displayName")] = mk(Expr::COL, it->second);
+               ExprP c = mk(Expr::COL, it->second);
+               c->base = true;
+               s.cols[m.at("column").s("displayName")] = c;
             }
          } else if (st->kind == State::AGG) {
             emitGroupBy(st, mapping);
@@ -767,6 +982,7 @@ struct Translator {
                settle(s);
                if (!s.nlBuild.empty()) throw Unsupported("two nested scans in one nested_map body");
                s.nlBuild = idOf(st, c);
+               separateNames(s, st, false);
                for (auto& m : mapping.arr) {
                   auto it = st->members.find(m.s("member"));
                   if (it == st->members.end()) throw Unsupported("scan of member '" + m.s("member") + "' that was never materialised");
@@ -803,15 +1019,21 @@ struct Translator {
       if (kind == "nested_map") { // the body runs once per tuple of the input stream: inline it
          Stream s = input(op, c);
          Stream* outer = c.nested;
+         const bool outerWas = c.outerBody;
          c.nested = &s;
+         c.outerBody = false;
          std::string last;
-         if (const J* body = op.get("subops"))
+         if (const J* body = op.get("subops")) {
+            for (auto& b : body->arr) c.outerBody = c.outerBody || (b.get("subop") && b.s("subop") == "union");
             for (auto& b : body->arr) {
                handle(b, c);
                if (b.get("subop") && c.streams.count(b.s("ref"))) last = b.s("ref");
             }
+         }
          c.nested = outer;
+         c.outerBody = outerWas;
          c.streams[ref] = last.empty() ? s : c.streams[last];
+         c.streams[ref].inJoinBody = false;
          if (!c.streams[ref].nlBuild.empty()) emitNestedLoop(c.streams[ref], nullptr); // no predicate in the body: a cross product
          return;
       }
@@ -824,8 +1046,34 @@ struct Translator {
       }
       if (kind == "gather") {
          Stream s = input(op, c);
+         if (!s.constState.empty()) { // constant single join (SingleJoinLowering, constantJoin): every tuple meets the one scattered row
+            StateP st = states.at(s.constState);
+            Stream& b = st->in;
+            separateNames(s, st, false);
+            for (auto& m : op.at("mapping").arr) {
+               auto it = st->members.find(m.s("member"));
+               if (it == st->members.end()) throw Unsupported("gather of member '" + m.s("member") + "' that was never scattered");
+               const std::string col = ensureCol(b, it->second, stripSuffix(it->first));
+               it->second = mk(Expr::COL, col);
+               s.cols[m.at("column").s("displayName")] = it->second;
+            }
+            flush(b);
+            flush(s);
+            OutStep j;
+            j.op = "join_nl";
+            j.out = fresh("j");
+            j.fields = {{"in", quote(s.rel)}, {"build", quote(b.rel)}, {"residual", "[]"}, {"kind", "\"inner\""}};
+            steps.push_back(j);
+            s.rel = j.out;
+            s.names.insert(b.names.begin(), b.names.end());
+            s.constState.clear();
+            c.streams[ref] = s;
+            return;
+         }
          if (s.probeHiv.empty()) throw Unsupported("gather outside a hash join");
+         s.inJoinBody = true;
          StateP hiv = states.at(s.probeHiv);
+         separateNames(s, hiv->source, !hiv->ht.empty());
          for (auto& m : op.at("mapping").arr) {
             auto it = hiv->source->members.find(m.s("member"));
             if (it == hiv->source->members.end()) throw Unsupported("gather of member '" + m.s("member") + "' that the build side did not materialise");
@@ -857,7 +1105,7 @@ struct Translator {
       }
       if (kind == "map") {
          Stream s = input(op, c);
-         if (s.pending) { // `map … = true` is the first sub-operator of the marker idioms; anything else consumes the pairs
+         if (s.pending && !s.inJoinBody) { // `map … = true` is the first sub-operator of the marker idioms; anything else consumes the pairs
             bool marker = true;
             for (auto& cm : op.at("computed").arr) marker = marker && convert(cm.at("expression"), s)->kind == Expr::CONST_BOOL;
             if (!marker) settle(s);
@@ -898,8 +1146,10 @@ struct Translator {
                auto it = s.cols.find(col.s("displayName"));
                if (it == s.cols.end()) throw Unsupported("filter on an undefined column");
                const Expr::Kind k = stripCast(it->second)->kind;
-               if (k == Expr::MARKER && s.pending) finishProbeSide(s, true);
-               else if (k == Expr::FLAG) {
+               if (k == Expr::MARKER && s.pending) {
+                  if (c.outerBody) s.antiBranch = true; // outer / single join: the partner-less rows are null-extended and united with the matches
+                  else finishProbeSide(s, true);
+               } else if (k == Expr::FLAG) {
                   StateP buf = states.at(s.flagState);
                   if (buf->antiRel.empty()) buf->antiRel = emitJoin(*buf->flagProbe, "anti_build");
                   s.rel = buf->antiRel;
@@ -913,19 +1163,25 @@ struct Translator {
             auto it = s.cols.find(col.s("displayName"));
             if (it == s.cols.end()) throw Unsupported("filter on an undefined column");
             const ExprP e = it->second;
-            if (stripCast(e)->kind == Expr::MARKER) { // anyTuple's marker: the probe row has (all_true) / lacks (all_false) a partner
+            const ExprP p = stripCast(e);
+            if (p->kind == Expr::MARKER) { // anyTuple's marker: the probe row has (all_true) / lacks (all_false) a partner
                if (!s.pending) throw Unsupported("marker filter without a pending hash join");
                finishProbeSide(s, false);
                continue;
             }
-            if (stripCast(e)->kind == Expr::FLAG) { // flag member of a build buffer: build rows with a partner
+            if (p->kind == Expr::OP && p->name == "not" && stripCast(p->args[0])->kind == Expr::MARKER) { // `not mark` of a mark join
+               if (!s.pending) throw Unsupported("marker filter without a pending hash join");
+               finishProbeSide(s, true);
+               continue;
+            }
+            if (p->kind == Expr::FLAG) { // flag member of a build buffer: build rows with a partner
                StateP buf = states.at(s.flagState);
                s.rel = buf->semiRel;
                s.flagState.clear();
                continue;
             }
-            if (!s.probeHiv.empty() && !s.pending) {
-               resolveJoinKeys(s, e);
+            if (s.inJoinBody && !s.probeHiv.empty()) {
+               addJoinConjunct(s, e);
                continue;
             }
             if (!s.nlBuild.empty()) {
@@ -933,32 +1189,36 @@ struct Translator {
                continue;
             }
             settle(s);
-            const ExprP p = stripCast(e);
-            if (p->kind == Expr::OP && p->name == "cmp") {
-               ExprP l = stripCast(p->args[0]), r = stripCast(p->args[1]);
-               std::string cmp = p->cmp;
-               if (l->kind != Expr::COL && r->kind == Expr::COL) {
-                  std::swap(l, r);
-                  static const std::pair<const char*, const char*> rev[] = {{"LT", "GT"}, {"GT", "LT"}, {"LTE", "GTE"}, {"GTE", "LTE"}, {"EQ", "EQ"}, {"NEQ", "NEQ"}};
-                  for (auto& rv : rev)
-                     if (cmp == rv.first) {
-                        cmp = rv.second;
-                        break;
-                     }
-               }
-               if (l->kind == Expr::COL && (r->kind == Expr::CONST_INT || r->kind == Expr::CONST_STR)) {
-                  use(l->name);
-                  s.preds.push_back("{\"col\": " + quote(l->name) + ", \"op\": " + quote(cmp) + ", \"value\": " + (r->kind == Expr::CONST_INT ? std::to_string(r->i) : quote(r->name)) + "}");
-                  continue;
-               }
-               if (l->kind == Expr::COL && r->kind == Expr::COL) {
-                  use(l->name), use(r->name);
-                  s.preds.push_back("{\"col\": " + quote(l->name) + ", \"op\": " + quote(cmp) + ", \"rhs_col\": " + quote(r->name) + "}");
-                  continue;
-               }
-            }
-            throw Unsupported("filter on a computed predicate that is not column-vs-constant or column-vs-column");
+            applyFilter(s, e);
          }
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "union") {
+         std::vector<Stream*> ins;
+         for (auto& e : op.at("outerEdges").arr)
+            if (e.s("type") == "stream") {
+               auto it = c.streams.find(e.at("input").s("ref"));
+               if (it == c.streams.end()) throw Unsupported("stream input '" + e.at("input").s("ref") + "' is not produced in this step");
+               ins.push_back(&it->second);
+            }
+         if (ins.size() != 2) throw Unsupported("union of " + std::to_string(ins.size()) + " streams");
+         Stream* m = ins[0]->antiBranch ? ins[1] : ins[0];
+         Stream* n = ins[0]->antiBranch ? ins[0] : ins[1];
+         // matches (columns mapped to their nullable copies) ∪ partner-less probe rows (the same columns mapped to NULL) of ONE
+         // pending hash join = a left outer join (OuterJoinLowering / SingleJoinLowering without reverseSides)
+         if (!(m->pending && !m->antiBranch && n->pending && n->antiBranch && m->probeHiv == n->probeHiv && !m->probeHiv.empty()))
+            throw Unsupported("union of two streams that are not the two halves of an outer join (set operation)");
+         Stream s = *m;
+         for (auto& kv : n->cols)
+            if (kv.second->kind == Expr::NULLV && !s.cols.count(kv.first)) throw Unsupported("outer join: column '" + kv.first + "' is NULL on one side and undefined on the other");
+         s.rel = emitJoin(s, "left_outer");
+         {
+            const Stream& bs = states.at(s.probeHiv)->source->in;
+            s.names.insert(bs.names.begin(), bs.names.end());
+         }
+         clearJoin(s);
+         for (auto it = s.cols.begin(); it != s.cols.end();) it = it->second->kind == Expr::MARKER ? s.cols.erase(it) : std::next(it);
          c.streams[ref] = s;
          return;
       }
@@ -978,6 +1238,9 @@ struct Translator {
             if (!s.probeHiv.empty()) throw Unsupported("nested hash-indexed-view lookups");
             states[id] = st;
             s.probeHiv = id;
+         } else if (stateType == "SimpleState" && kind == "lookup" && st->kind == State::CONST1) {
+            states[id] = st;
+            s.constState = id;
          } else if ((stateType == "SimpleState" && kind == "lookup") || (stateType == "HashMap" && kind == "lookup_or_insert")) {
             if (st->kind != State::UNKNOWN) throw Unsupported("aggregation into a state that is already in use");
             states[id] = st;
@@ -1011,14 +1274,43 @@ struct Translator {
                   a.fn = "sum";
                   a.arg = e->args[1];
                }
-            } else if (e->kind == Expr::OP && e->name == "select" && e->args[0]->kind == Expr::OP && e->args[0]->name == "cmp" && isMember(e->args[0]->args[0]) && isMember(e->args[2])) {
-               a.fn = e->args[0]->cmp == "GT" ? "min" : e->args[0]->cmp == "LT" ? "max" : "";
+            } else if (e->kind == Expr::OP && e->name == "add" && e->args[0]->kind == Expr::OP && e->args[0]->name == "select" && e->args[0]->args[0]->kind == Expr::OP &&
+                       e->args[0]->args[0]->name == "isnull" && isMember(e->args[0]->args[0]->args[0]) && e->args[1]->kind == Expr::OP && e->args[1]->name == "select" &&
+                       e->args[1]->args[0]->kind == Expr::OP && e->args[1]->args[0]->name == "isnull") {
+               // nullable state, nullable argument: (isnull(state) ? 0 : val(state)) + (isnull(arg) ? 0 : val(arg)) — NULLs do not count
+               a.fn = "sum";
+               a.arg = e->args[1]->args[0]->args[0];
+            } else if (e->kind == Expr::OP && e->name == "select" && e->args[0]->kind == Expr::OP && e->args[0]->name == "isnull" && !isMember(e->args[0]->args[0]) && isMember(e->args[1]) &&
+                       e->args[2]->kind == Expr::OP && e->args[2]->name == "add" && isMember(e->args[2]->args[0])) { // CountAggrFunc over a nullable argument: isnull(arg) ? state : state + 1
+               a.fn = "count";
+               a.arg = e->args[0]->args[0];
+            } else if (e->kind == Expr::OP && e->name == "select" && isMember(e->args[2]) && e->args[0]->kind == Expr::OP && (e->args[0]->name == "cmp" || e->args[0]->name == "or")) {
+               // Min / Max: state > arg ? arg : state; with a nullable state the condition is (state > arg) or isnull(state) (arith.ori, emitter extension E7)
+               ExprP cmp = e->args[0];
+               if (cmp->name == "or") {
+                  ExprP found;
+                  for (auto& x : cmp->args)
+                     if (x->kind == Expr::OP && x->name == "cmp") found = x;
+                  if (!found) throw Unsupported("aggregate body with an unrecognised condition");
+                  cmp = found;
+               }
+               if (!isMember(cmp->args[0])) throw Unsupported("aggregate body with an unrecognised comparison");
+               a.fn = cmp->cmp == "GT" ? "min" : cmp->cmp == "LT" ? "max" : "";
                a.arg = e->args[1];
                if (a.fn.empty()) throw Unsupported("aggregate body with an unrecognised comparison");
+            } else if (e->kind == Expr::COL || (e->kind == Expr::OP && e->name == "cast" && stripCast(e)->kind == Expr::COL)) { // AnyAggrFunc: the state becomes the argument
+               a.fn = "any";
+               a.arg = e;
             } else {
                throw Unsupported("aggregate body of member '" + a.member + "' is not sum / count / min / max");
             }
             if (a.arg && (a.arg->kind == Expr::UNKNOWN || a.arg->kind == Expr::MEMBER)) throw Unsupported("aggregate argument without a device form");
+            st->aggs.push_back(a);
+         }
+         if (st->aggs.empty()) { // ProjectionDistinctLowering: a map of keys only
+            AggSpec a;
+            a.member = "distinct$count";
+            a.fn = "count_star";
             st->aggs.push_back(a);
          }
          st->kind = State::AGG;
@@ -1071,6 +1363,20 @@ struct Translator {
       }
       if (kind == "scatter") { // only as part of the two marker idioms of semi / anti joins
          Stream s = input(op, c);
+         if (!s.pending && !s.aggState.empty() && s.probeHiv.empty()) { // constant single join: the one row of this stream becomes the state
+            StateP st = states.at(s.aggState);
+            if (st->kind != State::UNKNOWN) throw Unsupported("scatter into a state that is already in use");
+            st->kind = State::CONST1;
+            for (auto& m : op.at("mapping").arr) {
+               auto it = s.cols.find(m.at("column").s("displayName"));
+               if (it == s.cols.end()) throw Unsupported("scatter of an undefined column");
+               st->members[m.s("member")] = it->second;
+            }
+            s.aggState.clear();
+            st->in = s;
+            c.streams[ref] = s;
+            return;
+         }
          if (!s.pending) throw Unsupported("scatter outside the marker idiom of a semi / anti join");
          for (auto& m : op.at("mapping").arr) {
             auto it = s.cols.find(m.at("column").s("displayName"));

@@ -374,6 +374,38 @@ def test_groupby_null_keys_and_values(ctx, oracle):
         assert_groupby_equal(got, h, keys, rep, vals, valid)
 
 
+def test_groupby_min_max_over_128_bit_decimals(ctx, oracle):
+    """MIN / MAX with a 128-bit argument (decimal p >= 19 keeps its type, sql_analyzer.cpp:2631): the (low, high) pair is
+    updated under a per-slot lock word — few groups (LDS table), many groups in key order (run combining), many groups
+    in random order (global atomics), no key, NULL arguments, a filter, and values that differ only in one of the halves"""
+    rng = np.random.default_rng(41)
+    n = 150000
+    his = rng.integers(-3, 4, n)  # few distinct high words: many ties decided by the low word
+    los = rng.integers(0, 1 << 62, n) * 4 + rng.integers(0, 4, n)
+    vals = [int(h) * (1 << 64) + int(l) for h, l in zip(his, los)]
+    wide = pa.array([None if i % 9 == 0 else decimal.Decimal(v) for i, v in enumerate(vals)], pa.decimal128(38, 0))
+    few = rng.integers(0, 13, n)
+    many_sorted = np.sort(rng.integers(0, 60000, n))
+    many_random = rng.integers(0, 60000, n)
+    t = pa.table({"few": pa.array(few, pa.int32()), "srt": pa.array(many_sorted, pa.int64()), "rnd": pa.array(many_random, pa.int64()), "v": wide,
+                  "w": pa.array(rng.integers(0, 100, n), pa.int32())})
+    g, h = ctx.register("minmax128", t), HostTable(t)
+    D = capi.T_DECIMAL128
+    aggs = [api.agg(capi.AGG_MIN, api.col_expr((0, 3)), wide=True, out_type=D, p=38, s=0), api.agg(capi.AGG_MAX, api.col_expr((0, 3)), wide=True, out_type=D, p=38, s=0),
+            api.agg(capi.AGG_COUNT, api.col_expr((0, 3))), api.agg(capi.AGG_MIN, api.col_expr((0, 3)), wide=True, out_type=D, p=38, s=0, preds=[api.pred((0, 4), capi.F_LT, 3)])]
+    filt = [api.pred((0, 4), capi.F_GTE, 20)]
+    for keys, est in (([(0, 0)], 13), ([(0, 1)], 60000), ([(0, 2)], 60000), ([], 1), ([(0, 0), (0, 2)], 0)):
+        for plist in ([], filt):
+            rep, want, valid = oracle.groupby(h.rel(), keys, aggs, plist)
+            got = g.rel().groupby(keys, aggs, plist, est_groups=est)
+            assert_groupby_equal(got, h.rel(), keys, rep, want, valid)
+    # a group whose values are all NULL has NULL MIN / MAX
+    t2 = pa.table({"k": pa.array([1, 1, 2], pa.int32()), "v": pa.array([None, None, decimal.Decimal(-(1 << 100))], pa.decimal128(38, 0))})
+    got = rows_of(ctx.register("minmax128_nulls", t2).rel().groupby([(0, 0)], [api.agg(capi.AGG_MIN, api.col_expr((0, 1)), wide=True, out_type=D, p=38, s=0),
+                                                                                api.agg(capi.AGG_MAX, api.col_expr((0, 1)), wide=True, out_type=D, p=38, s=0)]).to_arrow())
+    assert sorted(got, key=repr) == sorted([(1, None, None), (2, -(1 << 100), -(1 << 100))], key=repr)
+
+
 def test_groupby_float_sum_within_tolerance(ctx, oracle):
     """floating-point SUM/AVG: atomics reorder additions → relative tolerance 1e-9 (BASELINE.md parity rule)"""
     rng = np.random.default_rng(4)

@@ -8,6 +8,7 @@ export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/final_r04
 mkdir -p $OUT
+timeout 300 python -m pytest tests/test_gpu_parity.py -q -k groupby > $OUT/tests_groupby.log 2>&1; tail -3 $OUT/tests_groupby.log
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 head -c 200 $OUT/bench_default.json; echo; tail -2 $OUT/bench_default.err
 B="python $R/bench.py --steps 3 --warmup 3 --cpu-sample-sf 0"
