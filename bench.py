@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--cpu-sample-sf", type=float, default=10.0, help="scale of the CPU-baseline sample (0 = skip); the GPU runs the same sample beside it")
     ap.add_argument("--cpu-runs", default="1+3", help="CPU baseline protocol warm-up+measured passes (the reference's tools/scripts/benchmark.py uses 3+10)")
     ap.add_argument("--cpu-budget-s", type=float, default=100.0, help="stop starting new CPU legs after this many seconds (the line names the queries measured)")
+    ap.add_argument("--plans", default="files", choices=["files", "subop"], help="files: lingo-db_amd/plans/tpch/*.json (the default, the benched configuration); subop: the reference-schema sub-operator dumps "
+                    "tests/golden/subop_tpch_qN.json translated by ldb_subop_translate at load time (one GPU) — the plans a LingoDB with the GPU step handler would hand over")
     ap.add_argument("--dry-run", action="store_true", help="no device, no torch: per-rank rows / resident bytes / exchange volume of the configuration against the HBM and row-id budgets")
     args = ap.parse_args()
     if args.dry_run:
@@ -220,7 +222,7 @@ def main():
     comm, exchange = None, "none"
     if world > 1:
         comm, exchange = make_comm(ctx, rank, world, dist, torch, backend)
-    runner = tpch_plans.Runner(ctx, db, world, dist if world > 1 else None, torch, comm=comm)
+    runner = tpch_plans.Runner(ctx, db, world, dist if world > 1 else None, torch, comm=comm, plans=args.plans)
 
     def barrier():
         ctx.sync()
@@ -453,7 +455,9 @@ def main():
             "config": {"workload": "TPC-H SF%g %s on %d x MI355X, Arrow columns resident in HBM (synthetic dbgen-shaped data, seed 20260925)" % (
                 args.sf, "+".join("Q%d" % q for q in queries), world), "queries": queries, "rows_lineitem_total": int(db.n_lineitem_total),
                 "narrow_decimals": bool(args.narrow_decimals), "device": info["name"], "exchange": exchange, "load_s": round(load_s, 3),
-                "plans": "lingo-db_amd/plans/tpch/%s*.json: hand-ordered operator plans (join orders, eager aggregation), not LingoDB's optimiser output" % ("dist/" if world > 1 else ""),
+                "plans": ("tests/golden/subop_tpch_q*.json: sub-operator dumps in the reference's mlir-subop-to-json schema, translated by ldb_subop_translate (straightforward join trees, no eager aggregation)"
+                          if args.plans == "subop" else
+                          "lingo-db_amd/plans/tpch/%s*.json: hand-ordered operator plans (join orders, eager aggregation), not LingoDB's optimiser output" % ("dist/" if world > 1 else "")),
                 "execution": ("prepared plans (ldb_plan_prepare / ldb_plan_execute): parsed once; executions after the warm-up replay their read-back trace (no host wait between "
                               "operators, one check at the end) and reuse cached descriptors" if runner.prepared_on else "ldb_plan_run_json per execution (LDB_BENCH_PREPARED=0)"),
                 "built_during_warmup": "outside the timed region, kept with the base tables like the reference's catalog statistics and persisted PK hash indexes "

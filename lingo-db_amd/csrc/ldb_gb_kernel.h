@@ -249,12 +249,13 @@ __device__ __forceinline__ void d_sink_add128(const Sink& s, int word, u128 v) {
 
 // 128-bit MIN / MAX: gfx950 has no 128-bit atomic, and the two halves cannot be lowered independently
 // (the low word only means something next to its high word), so the pair is updated under a
-// per-slot lock word.  The winning lane takes the lock, compares, stores and releases inside the
-// same branch — lanes of one wave that lose retry in the next iteration, so there is no
-// intra-wave wait on a lane that cannot progress.  A value whose high word is already worse than
-// the slot's (which only ever improves) is rejected without the lock.
-// (the reference's reduce function is a signed `arith.minsi` / `maxsi` on i128 values under the
-// entry's lock-free single-writer fragment, SubOpToControlFlow.cpp:1861-1938 merges fragments)
+// per-slot lock word.  A lane that spins on a lock while another lane OF THE SAME WAVE holds it would
+// never let the holder run (the wave executes one side of a branch at a time), so the lanes of a
+// wave that need a lock take turns: one leader at a time spins, updates and releases while the others
+// wait at the reconvergence point holding nothing.  A value whose high word is already worse than the
+// slot's (which only ever improves) is rejected without the lock.
+// (the reference's reduce function is a signed compare-and-select on i128 values inside the
+// single-writer fragment of a thread; MergePreAggrHashMap combines fragments, SubOpToControlFlow.cpp:1861-1938)
 __device__ __forceinline__ void d_sink_minmax128(const Sink& s, int word, i128 v, bool is_min) {
    const unsigned long long lo = (unsigned long long) (u128) v;
    const long long hi = (long long) (v >> 64);
@@ -266,22 +267,21 @@ __device__ __forceinline__ void d_sink_minmax128(const Sink& s, int word, i128 v
    const long long seen = (long long) __hip_atomic_load(s.w(word + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
    if (is_min ? hi > seen : hi < seen) return;
    unsigned long long* lock = s.w(word + 2);
-   bool done = false;
-   do {
-      if (atomicCAS(lock, 0ull, 1ull) == 0ull) {
-         __threadfence();
-         const unsigned long long clo = __hip_atomic_load(s.w(word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-         const long long chi = (long long) __hip_atomic_load(s.w(word + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-         const i128 cur = (i128) (((u128) (unsigned long long) chi << 64) | clo);
-         if (is_min ? v < cur : v > cur) {
-            __hip_atomic_store(s.w(word), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(s.w(word + 1), (unsigned long long) hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-         }
-         __threadfence();
-         atomicExch(lock, 0ull);
-         done = true;
+   const unsigned int lane = __lane_id();
+   for (unsigned long long turn = __ballot(1); turn; turn &= turn - 1) {
+      if (lane != (unsigned int) (__ffsll((long long) turn) - 1)) continue;
+      while (atomicCAS(lock, 0ull, 1ull) != 0ull) __builtin_amdgcn_s_sleep(1);
+      __threadfence();
+      const unsigned long long clo = __hip_atomic_load(s.w(word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long chi = (long long) __hip_atomic_load(s.w(word + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const i128 cur = (i128) (((u128) (unsigned long long) chi << 64) | clo);
+      if (is_min ? v < cur : v > cur) {
+         __hip_atomic_store(s.w(word), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         __hip_atomic_store(s.w(word + 1), (unsigned long long) hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-   } while (!done);
+      __threadfence();
+      atomicExch(lock, 0ull);
+   }
 }
 #define GB_I128_MAX ((i128) ((((u128) 0x7FFFFFFFFFFFFFFFull) << 64) | (u128) 0xFFFFFFFFFFFFFFFFull))
 #define GB_I128_MIN ((i128) (((u128) 0x8000000000000000ull) << 64))

@@ -27,6 +27,7 @@
 // columns (RelAlgToSubOp.cpp:2158-2166, test/lit/RelAlg/lowering.mlir:37), so keys are read off that scan.
 #include "ldb_host.hpp"
 #include "ldb_json.hpp"
+#include <algorithm>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -52,6 +53,7 @@ struct Expr {
    int64_t i = 0;
    bool build = false; // COL gathered from the build side of the hash join being matched
    bool base = false; // COL of a scanned base table (its type is the table's: column-vs-column restrictions compare like with like)
+   std::string dtype; // COL: the dump's datatype of the column it was first defined as ("decimal(12,2)", "int32", …; may be empty)
    std::vector<ExprP> args;
 };
 ExprP mk(Expr::Kind k, const std::string& name = "") {
@@ -124,6 +126,7 @@ struct Stream {
    // semi / anti join follows (RelAlgToSubOp.cpp:1296-1375)
    bool pending = false;
    std::vector<std::string> probeKeys, buildKeys;
+   std::vector<bool> keyDecimal; // per key pair: a decimal column is involved (kept as a residual equality when an integer key exists)
    std::string flagState; // scan of a build buffer whose flag member a semi / anti join with reversed sides has set
    std::string nlBuild; // nested-loop join (translateNLJ): the buffer being scanned once per tuple of this stream
    bool inJoinBody = false; // between the gather of a hash join and the end of its nested_map: filters are conjuncts of the join predicate
@@ -498,7 +501,7 @@ struct Translator {
          for (auto& m : mapping.arr)
             if (m.s("member") == a.member) as = sanitize(m.at("column").s("displayName"));
          o.as = as.empty() ? sanitize(st->in.rel + "." + a.member) : as;
-         o.used = false;
+         o.used = a.member == "distinct$count"; // (a distinct projection reads no aggregate: its group-by keeps the row count)
          st->aggOut[a.member] = o.as;
          g.aggs.push_back(o);
       }
@@ -609,11 +612,13 @@ struct Translator {
                std::swap(l, r);
                op = mirrored(op);
             }
+            if (getenv("LDB_SUBOP_DEBUG")) fprintf(stderr, "conjunct %s: l=%s side %d, r=%s side %d\n", op.c_str(), l->name.c_str(), sideOf(l), r->name.c_str(), sideOf(r));
             if (sideOf(l) == 1 && sideOf(r) == 2) {
                const std::string bc = ensureCol(b, r, "build_key"), pc = ensureCol(s, l, "probe_key");
                if (op == "EQ") {
                   s.buildKeys.push_back(bc);
                   s.probeKeys.push_back(pc);
+                  s.keyDecimal.push_back(l->dtype.find("decimal") != std::string::npos || r->dtype.find("decimal") != std::string::npos);
                } else {
                   s.residual.push_back("{\"probe\": " + quote(pc) + ", \"op\": " + quote(op) + ", \"build\": " + quote(bc) + "}");
                }
@@ -681,6 +686,21 @@ struct Translator {
       StateP hiv = states.at(s.probeHiv);
       Stream& b = hiv->source->in;
       if (s.probeKeys.empty()) throw Unsupported("hash join without an equality between the sides");
+      if (s.keyDecimal.size() == s.probeKeys.size() && std::count(s.keyDecimal.begin(), s.keyDecimal.end(), false) > 0 && std::count(s.keyDecimal.begin(), s.keyDecimal.end(), true) > 0) {
+         // integer keys hash; an equality of decimals (a correlated MIN / MAX joined back, Q2) stays a residual comparison of the pair
+         std::vector<std::string> pk, bk;
+         for (size_t k = 0; k < s.probeKeys.size(); k++) {
+            if (!s.keyDecimal[k]) {
+               pk.push_back(s.probeKeys[k]);
+               bk.push_back(s.buildKeys[k]);
+            } else {
+               s.residual.push_back("{\"probe\": " + quote(s.probeKeys[k]) + ", \"op\": \"EQ\", \"build\": " + quote(s.buildKeys[k]) + "}");
+            }
+         }
+         s.probeKeys = pk;
+         s.buildKeys = bk;
+         s.keyDecimal.assign(pk.size(), false);
+      }
       if (hiv->ht.empty()) {
          flush(b);
          bool uniq = false;
@@ -734,6 +754,7 @@ struct Translator {
       s.probeHiv.clear();
       s.probeKeys.clear();
       s.buildKeys.clear();
+      s.keyDecimal.clear();
       s.residual.clear();
       for (auto& kv : s.cols)
          if (kv.second->build) {
@@ -792,6 +813,7 @@ struct Translator {
       s.probeHiv.clear();
       s.probeKeys.clear();
       s.buildKeys.clear();
+      s.keyDecimal.clear();
       s.residual.clear();
       for (auto it = s.cols.begin(); it != s.cols.end();)
          it = it->second->build || it->second->kind == Expr::MARKER ? s.cols.erase(it) : std::next(it);
@@ -945,6 +967,7 @@ struct Translator {
                if (it == st->memberToIdent.end()) throw Unsupported("scan of member '" + m.s("member") + "' that get_external does not map");
                ExprP c = mk(Expr::COL, it->second);
                c->base = true;
+               c->dtype = m.at("column").sOr("datatype", "");
                s.cols[m.at("column").s("displayName")] = c;
             }
          } else if (st->kind == State::AGG) {
@@ -953,7 +976,9 @@ struct Translator {
             for (auto& m : mapping.arr) {
                auto it = st->aggOut.find(m.s("member"));
                if (it == st->aggOut.end()) throw Unsupported("scan of member '" + m.s("member") + "' the aggregation does not produce");
-               s.cols[m.at("column").s("displayName")] = mk(Expr::COL, it->second);
+               ExprP c = mk(Expr::COL, it->second);
+               c->dtype = m.at("column").sOr("datatype", "");
+               s.cols[m.at("column").s("displayName")] = c;
             }
          } else if (st->kind == State::MARKER) { // the per-row marker of anyTuple: the pending join continues on the probe stream
             s = st->in;
@@ -1001,6 +1026,8 @@ struct Translator {
             s.rel = st->in.rel;
             s.preds = st->in.preds;
             s.unique = st->in.unique;
+            s.names = st->in.names;
+            s.bareTable = st->in.bareTable;
             for (auto& m : mapping.arr) {
                auto it = st->members.find(m.s("member"));
                if (it == st->members.end()) throw Unsupported("scan of member '" + m.s("member") + "' that was never materialised");
@@ -1153,6 +1180,8 @@ struct Translator {
                   StateP buf = states.at(s.flagState);
                   if (buf->antiRel.empty()) buf->antiRel = emitJoin(*buf->flagProbe, "anti_build");
                   s.rel = buf->antiRel;
+                  s.preds.clear();
+                  s.bareTable = false;
                   s.flagState.clear();
                } else throw Unsupported("filter with all_false semantic on a computed predicate");
             }
@@ -1176,7 +1205,10 @@ struct Translator {
             }
             if (p->kind == Expr::FLAG) { // flag member of a build buffer: build rows with a partner
                StateP buf = states.at(s.flagState);
+               if (buf->semiRel.empty()) buf->semiRel = emitJoin(*buf->flagProbe, "semi_build");
                s.rel = buf->semiRel;
+               s.preds.clear(); // (the build side's restrictions were applied when its hash table was built)
+               s.bareTable = false;
                s.flagState.clear();
                continue;
             }
@@ -1394,8 +1426,7 @@ struct Translator {
             if (!buf->members.count(member)) throw Unsupported("scatter into member '" + member + "' that the build side did not materialise");
             if (!buf->flagMember.empty()) throw Unsupported("two joins set flags in one build buffer");
             buf->flagMember = member;
-            buf->semiRel = emitJoin(s, "semi_build");
-            buf->flagProbe = std::make_shared<Stream>(s);
+            buf->flagProbe = std::make_shared<Stream>(s); // the join is emitted when the flag is read: all_true → semi_build, all_false → anti_build
             s.pending = false;
          }
          c.streams[ref] = s;

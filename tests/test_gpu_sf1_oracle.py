@@ -66,10 +66,23 @@ def test_plan_matches_oracle(world, q):
         assert got == want
 
 
-@pytest.mark.parametrize("q", [6, 1, 3, 4, "4_probe_side", 5, 12, 18])
+def assert_matches_legs(q, got, want):
+    if q in LIMITS:
+        k, key = LIMITS[q]
+        assert len(got) == min(k, len(want))
+        assert [key(r) for r in got] == [key(r) for r in want[: len(got)]]
+        assert set(got) <= set(want)  # (the Q10 leg lists only the 64 best customers)
+    elif q in (5, 11):  # ORDER BY one aggregate: equal values may swap
+        assert [r[1] for r in got] == [r[1] for r in want] and sorted(got) == sorted(want)
+    else:
+        assert got == want
+
+
+@pytest.mark.parametrize("q", [1, 2, 3, 4, "4_probe_side", 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_subop_dump_matches_oracle(world, q):
-    """f1 end to end: the reference-schema dump of the query (tests/golden/subop_tpch_qN.json, the format of
-    tools/ct/mlir-subop-to-json.cpp) → ldb_subop_translate → the plan interpreter → the same oracle leg"""
+    """f1 end to end, all 22 queries: the reference-schema dump of the query (tests/golden/subop_tpch_qN.json, the format of
+    tools/ct/mlir-subop-to-json.cpp; Q1 / Q3 – Q6 / Q12 / Q18 authored sub-operator by sub-operator, the others lowered from
+    relational algebra by tools/subop_lower.py) → ldb_subop_translate → the plan interpreter → the same oracle leg"""
     import os
 
     from lingodb_amd import api
@@ -81,16 +94,10 @@ def test_subop_dump_matches_oracle(world, q):
     assert all(r["target"] == "gpu" for r in report)
     got = canon(runner.ctx.run_plan(text, runner.plan_inputs(q)).to_arrow())
     want = legs.run(q)
-    if q in LIMITS:
-        k, key = LIMITS[q]
-        assert len(got) == min(k, len(want))
-        assert [key(r) for r in got] == [key(r) for r in want[: len(got)]]
-        assert set(got) <= set(want)
-    elif q == 5:  # ORDER BY one aggregate: equal values may swap
-        assert [r[1] for r in got] == [r[1] for r in want] and sorted(got) == sorted(want)
-    else:
-        assert got == want
-    assert got == canon(runner.run(q).to_arrow()) or q in LIMITS or q == 5  # and the hand-written plan file agrees row for row
+    assert want, "empty oracle result: the check would be vacuous"
+    assert_matches_legs(q, got, want)
+    if q not in LIMITS and q not in (5, 11):
+        assert got == canon(runner.run(q).to_arrow())  # and the hand-written plan file agrees row for row
 
 
 def test_nested_loop_dump_counts_suppliers_per_nation(world):

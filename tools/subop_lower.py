@@ -54,17 +54,8 @@ def one_of(x, vals): return inner(["", " in ["] + [", "] * (len(vals) - 1) + ["]
 def call(fn, *args): return inner([fn + "("] + [", "] * (len(args) - 1) + [")"], list(args))  # db.runtime_call
 def null(): return {"type": "expression_leaf", "leaf_type": "null"}
 def sconst(s): return const(s, "string")
-def dconst(s, p=12, sc=2): return const(s, "decimal(%d,%d)" % (p, sc))  # printed by the tool as the scaled integer; see dec()
-
-
-def dec(text, p, s):
-    """a decimal literal as the tool prints it: the attribute's integer value with the type decimal(p,s)"""
-    neg = text.startswith("-")
-    t = text.lstrip("-")
-    whole, _, frac = t.partition(".")
-    frac = (frac + "0" * s)[:s]
-    v = int(whole or "0") * 10 ** s + int(frac or "0")
-    return const(-v if neg else v, "decimal(%d,%d)" % (p, s))
+def date(s): return const(s, "date")
+def dec(text, p, s): return const(text, "decimal(%d,%d)" % (p, s))  # db.constant("0.2") : !db.decimal<p,s> (a StringAttr; integers come as IntegerAttr: const(1, "decimal(12,2)"))
 
 
 def refs(e, out=None):
@@ -78,11 +69,15 @@ def refs(e, out=None):
     return out
 
 
+TYPE_OF = {}  # display name → type of every column defined so far
+
+
 class C:
     """a tuples column: scope::name + type"""
     def __init__(self, name, dtype):
         self.name, self.dtype = name, dtype
         self.j = column(name, dtype)
+        TYPE_OF[name] = dtype  # buffers re-define a column with the type it was created with
 
     @property
     def base(self): return self.name.split("::")[-1]
@@ -245,8 +240,8 @@ class Join(Node):
             if name not in seen:
                 seen.add(name)
                 payload.append(name)
-        types = self._types(cx)
-        members = {name: "%s$%s" % (name.split("::")[-1], n) for name in payload}
+        types = TYPE_OF
+        members = {name: "%s$%s" % (name.replace("::", "_"), n) for name in payload}
         mapping = [{"member": "hash$%s" % n, "column": h.j}] + [{"member": members[name], "column": column(name, types.get(name, "?"))} for name in payload]
         flag_member = "flag$%s" % n
         if flagged:
@@ -280,9 +275,8 @@ class Join(Node):
             mk = cx.col("marker", "marker", "int1")
             m = self._any_tuple(pp, body, filtered, mk)
             f = pp.raw("filter", [m], semantic="all_false", columns=[mk.j])
-            used = [(nw, old) for nw, old in self.mapping if nw.name in need or True]
-            nulls = pp.raw("map", [f["ref"]], computed=[{"computed": nw.j, "expression": null()} for nw, _ in used])  # mapColsToNull
-            nullable = pp.raw("map", [filtered], computed=[{"computed": nw.j, "expression": old.j} for nw, old in used])  # mapColsToNullable (db.as_nullable prints its operand)
+            nulls = pp.raw("map", [f["ref"]], computed=[{"computed": nw.j, "expression": null()} for nw, _ in self.mapping])  # mapColsToNull
+            nullable = pp.raw("map", [filtered], computed=[{"computed": nw.j, "expression": old.j} for nw, old in self.mapping])  # mapColsToNullable (db.as_nullable prints its operand)
             u = pp.raw("union", [nullable["ref"], nulls["ref"]])
             body += [f, nulls, nullable, u]
             out = u["ref"]
@@ -320,9 +314,6 @@ class Join(Node):
         pp.last = u["ref"]
         return pp
 
-    def _types(self, cx):
-        return TYPE_OF
-
     @staticmethod
     def _any_tuple(pp, body, stream, mk):
         cx = pp.cx
@@ -335,15 +326,6 @@ class Join(Node):
         sm = pp.raw("scan", accesses=[node(ms["ref"])], mapping=[{"member": "marker$0", "column": mk.j}])
         body += [ms, mb, ml, sca, sm]
         return sm["ref"]
-
-
-TYPE_OF = {}  # display name → type of every column a query defines (filled by the C constructors of a query through `T`)
-
-
-def T(c):
-    """remember a column's type so that buffers re-define it with the same type"""
-    TYPE_OF[c.name] = c.dtype
-    return c
 
 
 class ConstJoin(Node):
@@ -440,7 +422,7 @@ class Distinct(Node):
 
 
 def _materialize_all(cx, p, names, state_step, state_ty, state_type, tag):
-    members = {name: "%s$%s" % (name.split("::")[-1], tag) for name in names}
+    members = {name: "%s$%s" % (name.replace("::", "_"), tag) for name in names}
     p.op("materialize", accesses=[p.state_arg(state_step, state_ty)], stateType=state_type, mapping=[{"member": members[n], "column": column(n, TYPE_OF.get(n, "?"))} for n in names])
     return members
 
@@ -474,7 +456,7 @@ class TopK(Node):
     def lower(self, cx, required):
         names = sorted(set(required) | {c.name for c, _ in self.by})
         tag = cx.scope("t")
-        members = {n: "%s$%s" % (n.split("::")[-1], tag) for n in names}
+        members = {n: "%s$%s" % (n.replace("::", "_"), tag) for n in names}
         s_hp, ty = cx.state("create_heap", maxRows=self.k, sortBy=[{"member": members[c.name], "direction": dr} for c, dr in self.by])  # EXT E4
         p = self.child.lower(cx, set(names))
         _materialize_all(cx, p, names, s_hp, ty, "Heap", tag)
@@ -510,10 +492,10 @@ class Rename(Node):
     def __init__(self, child, renamed):
         self.child, self.renamed = child, list(renamed)  # [(new C, old C)]
 
-    def avail(self): return self.child.avail() | {n.name for n, _ in self.renamed}
+    def avail(self): return (self.child.avail() - {o.name for _, o in self.renamed}) | {n.name for n, _ in self.renamed}
 
     def lower(self, cx, required):
-        need = (set(required) - {n.name for n, _ in self.renamed}) | {o.name for _, o in self.renamed}
+        need = (set(required) - {n.name for n, _ in self.renamed}) | {o.name for n, o in self.renamed if n.name in required}
         p = self.child.lower(cx, need & self.child.avail())
         p.op("renaming", renamed=[{"new": n.j, "old": o.j} for n, o in self.renamed])
         return p

@@ -169,8 +169,9 @@ class Runner:
     (world > 1) or dist=True — the sharded plan plans/tpch/dist/qN.json, whose allgather / shuffle steps go
     through the library's exchange (ldb_plan_run_json_comm)."""
 
-    def __init__(self, ctx, db, world, dist, torch, comm=None, force_dist=False):
+    def __init__(self, ctx, db, world, dist, torch, comm=None, force_dist=False, plans="files"):
         self.ctx, self.db, self.world, self.dist, self.torch = ctx, db, world, dist, torch
+        self.plan_source = plans  # "files": the plan files; "subop": the reference-schema dumps (tests/golden/subop_tpch_qN.json) through ldb_subop_translate
         self.comm = comm  # api.Comm or None
         self.force_dist = force_dist
         self.last = {}
@@ -235,10 +236,19 @@ class Runner:
 
     def plan_text(self, q):
         if q not in self.plans:
+            import json
+
+            if self.plan_source == "subop":  # f1: what a LingoDB with the GPU step handler would hand over — its own sub-operator dump
+                if self.sharded():
+                    raise RuntimeError("translated sub-operator dumps are single-GPU plans")
+                from lingodb_amd import api
+
+                self.plans[q] = api.translate_subop_dump(os.path.join(ROOT, "tests", "golden", "subop_tpch_q%d.json" % q), "tpch_q%d" % q)[0]
+                self.meta[q] = json.loads(self.plans[q])
+                return self.plans[q]
             sub = ("dist", "q%d.json" % q) if self.sharded() else ("q%d.json" % q,)
             with open(os.path.join(ROOT, "lingo-db_amd", "plans", "tpch", *sub)) as f:
                 self.plans[q] = f.read()
-            import json
 
             self.meta[q] = json.loads(self.plans[q])
         return self.plans[q]
