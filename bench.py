@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--cpu-sample-sf", type=float, default=10.0, help="scale of the CPU-baseline sample (0 = skip); the GPU runs the same sample beside it")
     ap.add_argument("--cpu-runs", default="1+3", help="CPU baseline protocol warm-up+measured passes (the reference's tools/scripts/benchmark.py uses 3+10)")
     ap.add_argument("--cpu-budget-s", type=float, default=100.0, help="stop starting new CPU legs after this many seconds (the line names the queries measured)")
+    ap.add_argument("--oracle-spot-check", type=int, default=1, help="1: Q6 by the oracle at the bench's own scale, generated and summed slice by slice on the host (checks.oracle_q6_at_bench_scale)")
     ap.add_argument("--plans", default="files", choices=["files", "subop"], help="files: lingo-db_amd/plans/tpch/*.json (the default, the benched configuration); subop: the reference-schema sub-operator dumps "
                     "tests/golden/subop_tpch_qN.json translated by ldb_subop_translate at load time (one GPU) — the plans a LingoDB with the GPU step handler would hand over")
     ap.add_argument("--dry-run", action="store_true", help="no device, no torch: per-rank rows / resident bytes / exchange volume of the configuration against the HBM and row-id budgets")
@@ -392,6 +393,15 @@ def main():
             checks["q1_count_conservation"] = bool(sum(results[1].column(9).to_pylist()) == n_pass)  # Σ count(*) over groups == rows passing the filter (scan kernel)
         if world == 1 and 6 in results and 1 in results:
             checks["q6_rows"] = results[6].num_rows == 1
+        if world == 1 and 6 in results and args.oracle_spot_check:
+            # the oracle at the bench's OWN scale for one query: Q6 over the host-generated columns, slice by slice (≈ 10 s of host time at SF100)
+            try:
+                want, secs = tpch_plans.oracle_q6_at_scale(n_orders)
+                got = results[6].column(0)[0].as_py()
+                got = None if got is None else int(got.scaleb(results[6].schema.field(0).type.scale))
+                checks["oracle_q6_at_bench_scale"] = {"equal": bool(got == want), "sf": args.sf, "seconds": round(secs, 1), "value_unscaled": str(want)}
+            except Exception as e:  # the spot check must not cost the bench line
+                checks["oracle_q6_at_bench_scale"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # no roofline fraction may exceed what HBM can give a streaming read: the larger of this box's own scan ceiling (+ 10 %: the
         # calibration scan is itself a kernel of this library, not the hardware limit) and the guide's ≈ 6.3 TB/s achievable figure
         if ceiling and "scan_count_gbs" in ceiling:

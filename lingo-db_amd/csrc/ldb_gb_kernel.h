@@ -501,6 +501,13 @@ __device__ __forceinline__ uint64_t d_global_slot(const DGroupBy& m, const DGrou
          atomicOr(gptr_mut<uint32_t>(d->g_flags), 2u);
          return ~0ull;
       }
+      // a long run means the table is (nearly) full — the estimate was too low, or there was none: without this exit every remaining
+      // row walks the whole table before it reports the overflow (6 M rows x 4 M slots).  The first lane to see it raises the flag, the
+      // others notice within 32 steps and stop probing; the host retries with 8 x the capacity.
+      if (step >= 32 && (step & 31) == 0 && (step >= 4096 || (__hip_atomic_load(gptr_mut<uint32_t>(d->g_flags), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u))) {
+         atomicOr(gptr_mut<uint32_t>(d->g_flags), 1u);
+         return ~0ull;
+      }
       unsigned long long w = __hip_atomic_load(&gk[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (w == 0) {
          unsigned long long old = atomicCAS(&gk[pos], 0ull, (unsigned long long) mine);

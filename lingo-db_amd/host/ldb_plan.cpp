@@ -716,6 +716,14 @@ struct Interp {
             if (kind == LDB_JOIN_INNER || kind == LDB_JOIN_LEFT_OUTER || kind == LDB_JOIN_SINGLE || kind == LDB_JOIN_RIGHT_OUTER || kind == LDB_JOIN_FULL_OUTER)
                outSides.insert(outSides.end(), ht.sides.begin(), ht.sides.end());
          }
+         if (mark && st.get("mark_as")) { // the mark column as a column of the result relation (MarkJoinLowering: the stream carries the mark attribute)
+            ldb_gpu_table_rename_col(mark, 0, st.s("mark_as").c_str());
+            ldb_rel* z;
+            check(ldb_gpu_rel_zip(ctx, r, mark, &z), "join_probe (mark column)");
+            outSides.push_back(mark);
+            ldb_gpu_rel_release(ctx, r);
+            r = z;
+         }
          putRel(st.s("out"), r, std::move(outSides));
          if (mark) {
             if (const J* mo = st.get("mark_out")) putTable(mo->str, mark);
@@ -868,6 +876,67 @@ struct Interp {
             i++;
          }
          putTable(st.s("out"), t);
+      } else if (op == "set_op") { // UnionAll / UnionDistinct / CountingSetOperation lowerings: two relations, column lists of pairwise equal types
+         std::vector<const ldb_table*>*ls, *rs;
+         ldb_rel* left = relOf(st.s("left"), &ls);
+         ldb_rel* right = relOf(st.s("right"), &rs);
+         auto lc = cols(*ls, st.at("left_cols"), "set_op (left)");
+         auto rc = cols(*rs, st.at("right_cols"), "set_op (right)");
+         if (lc.size() != rc.size() || lc.empty()) throw std::runtime_error("set_op: the two column lists must have the same, non-zero length");
+         static const std::map<std::string, int32_t> kinds = {{"union_all", LDB_SET_UNION_ALL}, {"union", LDB_SET_UNION},   {"intersect", LDB_SET_INTERSECT},
+                                                             {"intersect_all", LDB_SET_INTERSECT_ALL}, {"except", LDB_SET_EXCEPT}, {"except_all", LDB_SET_EXCEPT_ALL}};
+         auto kit = kinds.find(st.s("kind"));
+         if (kit == kinds.end()) throw std::runtime_error("set_op: unknown kind '" + st.s("kind") + "'");
+         ldb_table* t;
+         check(ldb_gpu_set_op(ctx, left, lc.data(), right, rc.data(), (int32_t) lc.size(), kit->second, &t), "set_op");
+         if (const J* as = st.get("as"))
+            for (size_t k = 0; k < as->arr.size() && k < lc.size(); k++) ldb_gpu_table_rename_col(t, (int32_t) k, as->arr[k].str.c_str());
+         putTable(st.s("out"), t);
+      } else if (op == "window") { // WindowLowering: partition + order, one frame for all functions; the function results are attached as new columns
+         std::vector<const ldb_table*>* sides;
+         ldb_rel* in = relOf(st.s("in"), &sides);
+         std::vector<ldb_colref> part;
+         if (const J* pk = st.get("partition_by")) part = cols(*sides, *pk, "window partition key");
+         std::vector<ldb_sort_spec> order;
+         if (const J* ob = st.get("order_by"))
+            for (auto& b : ob->arr) order.push_back({resolve(*sides, b.kind == J::STR ? b.str : b.s("col"), "window order"), b.kind == J::OBJ && b.bOr("desc", false) ? 1 : 0, 0});
+         auto frameEnd = [&](const char* key, int64_t dflt) -> int64_t {
+            const J* f = st.get(key);
+            if (!f) return dflt;
+            if (f->kind == J::STR) {
+               if (f->str == "unbounded_preceding") return LDB_FRAME_UNBOUNDED_PRECEDING;
+               if (f->str == "unbounded_following") return LDB_FRAME_UNBOUNDED_FOLLOWING;
+               if (f->str == "current_row") return 0;
+               throw std::runtime_error("window: frame end '" + f->str + "'");
+            }
+            return f->inum;
+         };
+         const int64_t from = frameEnd("frame_from", LDB_FRAME_UNBOUNDED_PRECEDING), to = frameEnd("frame_to", 0);
+         static const std::map<std::string, int32_t> fns = {{"rank", LDB_WIN_RANK}, {"sum", LDB_WIN_SUM}, {"min", LDB_WIN_MIN}, {"max", LDB_WIN_MAX}, {"count", LDB_WIN_COUNT}, {"count_star", LDB_WIN_COUNT_STAR}};
+         std::vector<ldb_window_fn> wf;
+         std::vector<std::string> names;
+         for (auto& f : st.at("fns").arr) {
+            auto fit = fns.find(f.s("fn"));
+            if (fit == fns.end()) throw std::runtime_error("window: unknown function '" + f.s("fn") + "'");
+            ldb_window_fn w;
+            memset(&w, 0, sizeof(w));
+            w.fn = fit->second;
+            if (const J* c = f.get("col")) w.col = resolve(*sides, c->str, "window argument");
+            wf.push_back(w);
+            names.push_back(f.s("as"));
+         }
+         if (wf.empty()) throw std::runtime_error("window: no functions");
+         ldb_rel* r;
+         ldb_table* t;
+         check(ldb_gpu_window(ctx, in, part.data(), (int32_t) part.size(), order.data(), (int32_t) order.size(), from, to, wf.data(), (int32_t) wf.size(), &r, &t), "window");
+         for (size_t k = 0; k < names.size(); k++) ldb_gpu_table_rename_col(t, (int32_t) k, names[k].c_str());
+         hidden.push_back(t);
+         ldb_rel* z;
+         check(ldb_gpu_rel_zip(ctx, r, t, &z), "window zip");
+         ldb_gpu_rel_release(ctx, r);
+         auto outSides = *sides;
+         outSides.push_back(t);
+         putRel(st.s("out"), z, std::move(outSides));
       } else if (op == "allgather") { // every rank's rows of a (small) table, concatenated in rank order on every rank
          Value& t = val(st.s("in"));
          if (t.kind != Value::TABLE) throw std::runtime_error("allgather: 'in' must be a table (materialize first)");
@@ -1272,7 +1341,7 @@ extern "C" int32_t ldb_plan_json_check(const char* plan_json, const char* const*
                                                 {"join_build", {"in"}, {"keys"}},  {"join_probe", {"ht", "in"}, {"keys"}}, {"groupby", {"in"}, {"aggs"}},
                                                 {"map", {"in"}, {"as"}},           {"sort", {"in"}, {"by"}},             {"topk", {"in"}, {"by", "k"}},
                                                 {"materialize", {"in"}, {"cols"}}, {"join_nl", {"in", "build"}, {}}, {"allgather", {"in"}, {}},           {"shuffle", {"in"}, {"keys", "cols"}},
-                                                {"nested_map", {"in", "scan"}, {}}};
+                                                {"nested_map", {"in", "scan"}, {}}, {"set_op", {"left", "right"}, {"left_cols", "right_cols", "kind"}}, {"window", {"in"}, {"fns"}}};
       const J& steps = plan.at("steps");
       if (steps.kind != J::ARR) throw std::runtime_error("plan: 'steps' must be an array");
       std::function<void(const J&, std::map<std::string, bool>&)> checkSteps = [&](const J& list, std::map<std::string, bool>& known) {

@@ -47,7 +47,7 @@ struct Unsupported : std::runtime_error {
 struct Expr;
 using ExprP = std::shared_ptr<Expr>;
 struct Expr {
-   enum Kind { COL, CONST_INT, CONST_STR, CONST_BOOL, MEMBER, REF, HASH, MARKER, FLAG, NULLV, UNKNOWN, OP } kind = UNKNOWN; // MARKER: "a partner exists" of a probe row; FLAG: of a build row; NULLV: db.null
+   enum Kind { COL, CONST_INT, CONST_STR, CONST_BOOL, MEMBER, REF, HASH, MARKER, FLAG, NULLV, SETCNT, UNKNOWN, OP } kind = UNKNOWN; // SETCNT: one of the two counters of INTERSECT / EXCEPT (i = 1 | 2) // MARKER: "a partner exists" of a probe row; FLAG: of a build row; NULLV: db.null
    std::string name; // COL: column name in the plan language; MEMBER: member; OP: add sub mul div cast cmp and or not isnull select between in call (cmp = the runtime function)
    std::string cmp; // OP cmp: EQ NEQ LT LTE GT GTE; constants: the dump's data_type
    int64_t i = 0;
@@ -134,6 +134,9 @@ struct Stream {
    std::vector<ExprP> postJoin; // conjuncts of the join predicate that do not relate one probe with one build column: applied to the joined rows (inner joins only)
    bool antiBranch = false; // outer / single join: the branch of the probe rows WITHOUT a partner (filter none_true on the marker)
    std::string constState; // constant single join: the one-row state this stream looked up
+   std::vector<std::string> lastMapped; // the columns the most recent map defined (UNION ALL maps both inputs to the result columns)
+   std::string gjState; // group join: this stream probes the map the other input created (GroupJoinLowering, RelAlgToSubOp.cpp:2682-2950)
+   std::string setState; // scan of the counting map of INTERSECT / EXCEPT: the set operation is emitted when its predicate / repeat count is consumed
 };
 struct AggSpec {
    std::string member, fn;
@@ -171,6 +174,16 @@ struct State {
    std::string flagMember, semiRel, antiRel;
    std::shared_ptr<Stream> flagProbe;
    std::shared_ptr<State> flagHiv;
+   // AGG reduced by TWO pipelines with nothing but row counters: the map of a UNION (distinct) / INTERSECT / EXCEPT
+   // AGG whose map a second stream looks up and aggregates into: a group join
+   std::shared_ptr<Stream> gjRight;
+   std::vector<AggSpec> gjAggs;
+   std::vector<ExprP> gjFilters;
+   std::vector<std::pair<std::string, ExprP>> gjPairs, gjStored; // (left key column, the right column renamed to it); (gjval member, placeholder of the stored left column)
+   bool gjInner = false;
+   std::shared_ptr<Stream> setRight;
+   std::string setLeftCounter, setRightCounter;
+   std::vector<std::string> setLeftCols, setRightCols;
 };
 using StateP = std::shared_ptr<State>;
 
@@ -180,6 +193,7 @@ struct Translator {
    std::map<std::string, std::pair<int, int>> aggCol; // output column name → (groupby step, agg index)
    std::set<std::string> inputs;
    std::string result;
+   std::string markName; // the column a mark join about to be emitted adds
    std::string report; // JSON array body
    int nval = 0;
 
@@ -458,6 +472,7 @@ struct Translator {
    }
 
    // ---------------------------------------------------------------- states
+   static bool isKeyMember(const std::string& m) { return m.rfind("keyval", 0) == 0 || m.rfind("gjkeyval", 0) == 0; } // performAggregation / GroupJoinLowering member names
    StateP emitGroupBy(const StateP& st, const J& mapping) {
       if (st->groupbyStep >= 0) return st;
       Stream& in = st->in;
@@ -467,7 +482,7 @@ struct Translator {
       std::vector<std::string> keys;
       for (auto& m : mapping.arr) {
          const std::string& member = m.s("member");
-         if (member.rfind("keyval", 0) != 0) continue;
+         if (!isKeyMember(member)) continue;
          // the scan re-defines the grouped column itself: its binding on the reduced stream is the key
          auto it = in.cols.find(m.at("column").s("displayName"));
          if (it == in.cols.end()) throw Unsupported("group key '" + m.at("column").s("displayName") + "' is not a column of the aggregated stream");
@@ -528,10 +543,45 @@ struct Translator {
       size_t kk = 0;
       for (auto& m : mapping.arr) {
          const std::string& member = m.s("member");
-         if (member.rfind("keyval", 0) == 0) st->aggOut[member] = keys[kk++];
+         if (isKeyMember(member)) st->aggOut[member] = keys[kk++];
       }
       st->in = out; // from here on the state IS the aggregated table
       return st;
+   }
+
+   // the set operation whose counting map `s` scans: distinct kinds keep one row per key, the ALL kinds min(c1, c2) / max(c1 - c2, 0) rows
+   void emitSetOp(Stream& s, const std::string& kind) {
+      StateP st = states.at(s.setState);
+      flush(st->in);
+      flush(*st->setRight);
+      OutStep u;
+      u.op = "set_op";
+      u.out = fresh("u");
+      u.fields = {{"kind", quote(kind)}, {"left", quote(st->in.rel)}, {"left_cols", nameList(st->setLeftCols)}, {"right", quote(st->setRight->rel)}, {"right_cols", nameList(st->setRightCols)}};
+      steps.push_back(u);
+      s.rel = u.out;
+      s.setState.clear();
+      for (auto it = s.cols.begin(); it != s.cols.end();)
+         it = it->second->kind == Expr::SETCNT || (it->second->kind == Expr::OP && it->second->name == "setop") ? s.cols.erase(it) : std::next(it);
+   }
+   // what a map over the two counters computes (CountingSetOperationLowering, :868-915; arith.cmpi / andi / subi / select: emitter extension E7)
+   static std::string classifySet(const ExprP& e0) {
+      const ExprP e = stripCast(e0);
+      auto cnt = [](const ExprP& x, int which) { return stripCast(x)->kind == Expr::SETCNT && stripCast(x)->i == which; };
+      auto zero = [](const ExprP& x) { return stripCast(x)->kind == Expr::CONST_INT && stripCast(x)->i == 0; };
+      auto diff = [&](const ExprP& x) { return stripCast(x)->kind == Expr::OP && stripCast(x)->name == "sub" && cnt(stripCast(x)->args[0], 1) && cnt(stripCast(x)->args[1], 2); };
+      if (e->kind != Expr::OP) return "";
+      if (e->name == "and" && e->args.size() == 2) {
+         const ExprP l = stripCast(e->args[0]), r = stripCast(e->args[1]);
+         if (l->kind == Expr::OP && l->name == "cmp" && l->cmp == "GT" && cnt(l->args[0], 1) && zero(l->args[1]) && r->kind == Expr::OP && r->name == "cmp" && cnt(r->args[0], 2) && zero(r->args[1]))
+            return r->cmp == "GT" ? "intersect" : r->cmp == "EQ" ? "except" : "";
+      }
+      if (e->name == "select" && e->args.size() == 3) {
+         const ExprP c = stripCast(e->args[0]);
+         if (c->kind == Expr::OP && c->name == "cmp" && c->cmp == "LT" && diff(c->args[0]) && zero(c->args[1]) && zero(e->args[1]) && diff(e->args[2])) return "except_all";
+         if (c->kind == Expr::OP && c->name == "cmp" && c->cmp == "GT" && cnt(c->args[0], 1) && cnt(c->args[1], 2) && cnt(e->args[1], 2) && cnt(e->args[2], 1)) return "intersect_all";
+      }
+      return "";
    }
 
    // ---------------------------------------------------------------- one execution step
@@ -541,6 +591,7 @@ struct Translator {
       std::map<std::string, Stream> streams; // by producing sub-operator
       Stream* nested = nullptr; // the stream a nested_map hands to its body
       bool outerBody = false; // the nested_map body being walked ends in a union: an outer / single join (RelAlgToSubOp.cpp:1486-1587)
+      bool outerStep = false; // the step itself has a union: an outer join with reverseSides unites the matches with the unmatched build rows
    };
    StateP resolve(const J& acc, StepCtx& c) {
       const std::string& t = acc.s("type");
@@ -731,6 +782,7 @@ struct Translator {
          for (size_t k = 0; k < s.residual.size(); k++) r += (k ? ", " : "") + s.residual[k];
          jp.fields.push_back({"residual", r + "]"});
       }
+      if (kind == "mark") jp.fields.push_back({"mark_as", quote(markName)});
       if (kind != "inner" && !s.postJoin.empty()) throw Unsupported("a " + kind + " join whose predicate has a conjunct on one side only");
       steps.push_back(jp);
       return jp.out;
@@ -739,6 +791,26 @@ struct Translator {
    void settle(Stream& s) {
       if (!s.pending) return;
       StateP hiv = states.at(s.probeHiv);
+      bool marked = false;
+      for (auto& kv : s.cols) marked = marked || kv.second->kind == Expr::MARKER;
+      if (marked) { // MarkJoinLowering (RelAlgToSubOp.cpp:1376-1408): the marker is read as a value (mark or …), not filtered on: every probe row + a boolean column
+         markName = "mark" + std::to_string(++nval);
+         s.rel = emitJoin(s, "mark");
+         ExprP m = mk(Expr::COL, markName);
+         s.names.insert(markName);
+         s.pending = false;
+         s.inJoinBody = false;
+         s.probeHiv.clear();
+         s.probeKeys.clear();
+         s.buildKeys.clear();
+         s.keyDecimal.clear();
+         s.residual.clear();
+         for (auto it = s.cols.begin(); it != s.cols.end();) {
+            if (it->second->kind == Expr::MARKER) it->second = m;
+            it = it->second->build ? s.cols.erase(it) : std::next(it);
+         }
+         return;
+      }
       s.rel = emitJoin(s, "inner");
       s.names.insert(hiv->source->in.names.begin(), hiv->source->in.names.end());
       clearJoin(s);
@@ -970,6 +1042,153 @@ struct Translator {
                c->dtype = m.at("column").sOr("datatype", "");
                s.cols[m.at("column").s("displayName")] = c;
             }
+         } else if (st->kind == State::AGG && st->gjRight) {
+            // GroupJoinLowering: the left input created one entry per key (its stored columns are ANY aggregates), the right input looked its
+            // group up and aggregated into it.  Emitted as: distinct left keys (+ stored columns) → unique hash table → the right input
+            // probes it (inner) → the join predicate → group by the key with the aggregates.  The inner behaviour (marker member) keeps
+            // exactly the groups this produces; the outer behaviour would need the unmatched left rows with default aggregates.
+            if (!st->gjInner) throw Unsupported("group join with outer behaviour (groups without a partner keep default aggregates)");
+            // the left side: one row per key; the stored columns are functionally dependent on it and travel as further keys
+            // (ANY over a string has no device form, a key has)
+            std::map<std::string, std::string> storedName; // gjval member → display name
+            for (auto& m : mapping.arr)
+               if (m.s("member").rfind("gjval$", 0) == 0) storedName[m.s("member")] = m.at("column").s("displayName");
+            {
+               std::string lm = "[";
+               for (auto& m : mapping.arr)
+                  if (isKeyMember(m.s("member"))) lm += std::string(lm.size() > 1 ? ", " : "") + "{\"member\": " + quote(m.s("member")) + ", \"column\": {\"displayName\": " + quote(m.at("column").s("displayName")) + "}}";
+               std::vector<AggSpec> keep;
+               for (auto& a : st->aggs) {
+                  if (a.fn == "any" && storedName.count(a.member) && a.arg) {
+                     st->in.cols[storedName[a.member]] = a.arg;
+                     lm += ", {\"member\": " + quote("keyval$" + a.member) + ", \"column\": {\"displayName\": " + quote(storedName[a.member]) + "}}";
+                  } else {
+                     keep.push_back(a);
+                  }
+               }
+               st->aggs = keep;
+               if (st->aggs.empty()) {
+                  AggSpec a;
+                  a.member = "distinct$count";
+                  a.fn = "count_star";
+                  st->aggs.push_back(a);
+               }
+               lm += "]";
+               JParser lp(lm.c_str());
+               const J lmj = lp.value();
+               emitGroupBy(st, lmj);
+            }
+            auto tmp = std::make_shared<State>();
+            tmp->kind = State::BUFFER;
+            tmp->in = st->in;
+            std::vector<std::string> keyMembers, keyNames;
+            for (auto& m : mapping.arr)
+               if (isKeyMember(m.s("member"))) {
+                  keyMembers.push_back(m.s("member"));
+                  keyNames.push_back(m.at("column").s("displayName"));
+                  tmp->members[m.s("member")] = mk(Expr::COL, st->aggOut.at(m.s("member")));
+               }
+            for (auto& sp : st->gjStored) {
+               auto it = st->aggOut.find("keyval$" + sp.first);
+               if (it == st->aggOut.end()) throw Unsupported("group join gathers member '" + sp.first + "' the left input did not store");
+               tmp->members[sp.first] = mk(Expr::COL, it->second);
+            }
+            Stream r = *st->gjRight;
+            separateNames(r, tmp, false);
+            for (auto& sp : st->gjStored) { // the placeholders handed out by the gather become the (possibly renamed) stored columns
+               sp.second->name = tmp->members.at(sp.first)->name;
+               sp.second->build = false;
+            }
+            std::vector<std::string> bk, pk;
+            for (size_t k = 0; k < keyMembers.size(); k++) {
+               ExprP right;
+               for (auto& pr : st->gjPairs)
+                  if (pr.first == keyNames[k]) right = pr.second;
+               if (!right) throw Unsupported("group join: no renaming names the right key of '" + keyNames[k] + "'");
+               bk.push_back(tmp->members.at(keyMembers[k])->name);
+               pk.push_back(ensureCol(r, right, "gj_key"));
+            }
+            flush(tmp->in);
+            OutStep jb;
+            jb.op = "join_build";
+            jb.out = fresh("h");
+            jb.fields = {{"in", quote(tmp->in.rel)}, {"keys", nameList(bk)}, {"unique", "true"}};
+            steps.push_back(jb);
+            flush(r);
+            OutStep jp;
+            jp.op = "join_probe";
+            jp.out = fresh("j");
+            jp.fields = {{"ht", quote(jb.out)}, {"in", quote(r.rel)}, {"keys", nameList(pk)}, {"kind", "\"inner\""}};
+            steps.push_back(jp);
+            r.rel = jp.out;
+            r.names.insert(tmp->in.names.begin(), tmp->in.names.end());
+            for (auto& e : st->gjFilters) applyFilter(r, e);
+            // the final aggregation: keyed by the (right) key columns, carrying the stored columns as ANY
+            auto fin = std::make_shared<State>();
+            fin->kind = State::AGG;
+            fin->in = r;
+            fin->aggs = st->gjAggs;
+            std::string mj = "[";
+            for (size_t k = 0; k < keyMembers.size(); k++) {
+               fin->in.cols[keyNames[k]] = mk(Expr::COL, pk[k]);
+               mj += std::string(k ? ", " : "") + "{\"member\": " + quote(keyMembers[k]) + ", \"column\": {\"displayName\": " + quote(keyNames[k]) + "}}";
+            }
+            for (auto& sp : st->gjStored) { // carried as keys (see above)
+               auto sn = storedName.find(sp.first);
+               if (sn == storedName.end()) continue; // gathered for the predicate only
+               fin->in.cols[sn->second] = sp.second;
+               mj += ", {\"member\": " + quote("keyval$" + sp.first) + ", \"column\": {\"displayName\": " + quote(sn->second) + "}}";
+            }
+            for (auto& m : mapping.arr)
+               if (!isKeyMember(m.s("member")) && !storedName.count(m.s("member"))) mj += ", {\"member\": " + quote(m.s("member")) + ", \"column\": {\"displayName\": " + quote(m.at("column").s("displayName")) + "}}";
+            mj += "]";
+            JParser jp2(mj.c_str());
+            const J fm = jp2.value();
+            emitGroupBy(fin, fm);
+            s = fin->in;
+            for (auto& m : mapping.arr) {
+               auto it = fin->aggOut.find(storedName.count(m.s("member")) ? "keyval$" + m.s("member") : m.s("member"));
+               if (it == fin->aggOut.end()) { // the marker member: every group here has a partner
+                  ExprP t = mk(Expr::CONST_BOOL);
+                  t->i = 1;
+                  s.cols[m.at("column").s("displayName")] = t;
+                  continue;
+               }
+               ExprP c2 = mk(Expr::COL, it->second);
+               c2->dtype = m.at("column").sOr("datatype", "");
+               s.cols[m.at("column").s("displayName")] = c2;
+            }
+         } else if (st->kind == State::AGG && st->setRight) { // the map both inputs of a set operation counted into
+            Stream &a = st->in, &b = *st->setRight;
+            st->setLeftCols.clear();
+            st->setRightCols.clear();
+            std::vector<std::string> names;
+            for (auto& m : mapping.arr) {
+               if (m.s("member").rfind("keyval", 0) != 0) continue;
+               const std::string& name = m.at("column").s("displayName");
+               auto ia = a.cols.find(name), ib = b.cols.find(name);
+               if (ia == a.cols.end() || ib == b.cols.end()) throw Unsupported("set operation: column '" + name + "' is not defined on both inputs");
+               st->setLeftCols.push_back(ensureCol(a, ia->second, name));
+               st->setRightCols.push_back(ensureCol(b, ib->second, name));
+               names.push_back(name);
+            }
+            if (names.empty()) throw Unsupported("set operation without columns");
+            for (size_t k = 0; k < names.size(); k++) {
+               s.cols[names[k]] = mk(Expr::COL, st->setLeftCols[k]);
+               s.names.insert(st->setLeftCols[k]);
+            }
+            s.setState = idOf(st, c);
+            if (st->setLeftCounter.empty()) {
+               emitSetOp(s, "union"); // UnionDistinctLowering: the keys of the map are the result
+            } else {
+               for (auto& m : mapping.arr) {
+                  const int which = m.s("member") == st->setLeftCounter ? 1 : m.s("member") == st->setRightCounter ? 2 : 0;
+                  if (!which) continue;
+                  ExprP cnt = mk(Expr::SETCNT);
+                  cnt->i = which;
+                  s.cols[m.at("column").s("displayName")] = cnt;
+               }
+            }
          } else if (st->kind == State::AGG) {
             emitGroupBy(st, mapping);
             s = st->in;
@@ -1045,6 +1264,15 @@ struct Translator {
       }
       if (kind == "nested_map") { // the body runs once per tuple of the input stream: inline it
          Stream s = input(op, c);
+         if (!s.setState.empty()) { // INTERSECT ALL / EXCEPT ALL: the body generates `repeat` copies of the key (generate + scf.for, :893-911)
+            std::string kind;
+            for (auto& kv : s.cols)
+               if (kv.second->kind == Expr::OP && kv.second->name == "setop") kind = kv.second->cmp;
+            if (kind != "intersect_all" && kind != "except_all") throw Unsupported("nested_map over the counters of a set operation without a repeat count");
+            emitSetOp(s, kind);
+            c.streams[ref] = s;
+            return;
+         }
          Stream* outer = c.nested;
          const bool outerWas = c.outerBody;
          c.nested = &s;
@@ -1068,6 +1296,23 @@ struct Translator {
          Stream s = input(op, c);
          if (s.probeHiv.empty()) throw Unsupported("scan_list outside a hash-indexed-view lookup");
          s.cols[op.at("elem").s("displayName")] = mk(Expr::REF);
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "unwrap_optional_ref") { // group join: tuples without a group are dropped — the inner join emitted for the group join does that
+         Stream s = input(op, c);
+         if (s.gjState.empty()) throw Unsupported("unwrap_optional_ref outside a group join");
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "gather" && !input(op, c).gjState.empty()) { // the left input's stored columns: resolved when the group join is emitted
+         Stream s = input(op, c);
+         StateP st = states.at(s.gjState);
+         for (auto& m : op.at("mapping").arr) {
+            ExprP ph = mk(Expr::COL, "?" + m.s("member"));
+            st->gjStored.push_back({m.s("member"), ph});
+            s.cols[m.at("column").s("displayName")] = ph;
+         }
          c.streams[ref] = s;
          return;
       }
@@ -1126,6 +1371,7 @@ struct Translator {
             auto it = s.cols.find(r.at("old").s("displayName"));
             if (it == s.cols.end()) throw Unsupported("renaming of an undefined column");
             s.cols[r.at("new").s("displayName")] = it->second;
+            if (!s.gjState.empty()) states.at(s.gjState)->gjPairs.push_back({r.at("new").s("displayName"), it->second}); // left key := the right key it equals
          }
          c.streams[ref] = s;
          return;
@@ -1137,9 +1383,19 @@ struct Translator {
             for (auto& cm : op.at("computed").arr) marker = marker && convert(cm.at("expression"), s)->kind == Expr::CONST_BOOL;
             if (!marker) settle(s);
          }
+         s.lastMapped.clear();
          for (auto& cm : op.at("computed").arr) {
             const std::string& name = cm.at("computed").s("displayName");
             ExprP e = convert(cm.at("expression"), s);
+            s.lastMapped.push_back(name);
+            if (!s.setState.empty()) { // the predicate / repeat count over the counters of INTERSECT / EXCEPT
+               const std::string kind = classifySet(e);
+               if (kind.empty()) throw Unsupported("expression over the counters of a set operation that is neither INTERSECT nor EXCEPT");
+               ExprP r = mk(Expr::OP, "setop");
+               r->cmp = kind;
+               s.cols[name] = r;
+               continue;
+            }
             // sum(x) / count(x) over one aggregation = avg(x) (the frontend's expansion of avg)
             ExprP d = stripCast(e);
             if (d->kind == Expr::OP && d->name == "div") {
@@ -1176,6 +1432,8 @@ struct Translator {
                if (k == Expr::MARKER && s.pending) {
                   if (c.outerBody) s.antiBranch = true; // outer / single join: the partner-less rows are null-extended and united with the matches
                   else finishProbeSide(s, true);
+               } else if (k == Expr::FLAG && c.outerStep) {
+                  s.antiBranch = true; // the unmatched BUILD rows of an outer join with reverseSides: null-extended and united with the matches below
                } else if (k == Expr::FLAG) {
                   StateP buf = states.at(s.flagState);
                   if (buf->antiRel.empty()) buf->antiRel = emitJoin(*buf->flagProbe, "anti_build");
@@ -1212,6 +1470,16 @@ struct Translator {
                s.flagState.clear();
                continue;
             }
+            if (p->kind == Expr::CONST_BOOL && p->i) continue; // (the `matched` marker of an inner group join: true for every group the join produced)
+            if (!s.gjState.empty()) { // the group join's predicate: applied to the joined rows before they are aggregated
+               states.at(s.gjState)->gjFilters.push_back(e);
+               continue;
+            }
+            if (p->kind == Expr::OP && p->name == "setop") { // INTERSECT / EXCEPT (distinct): keep the keys whose counters satisfy the predicate
+               if (s.setState.empty() || p->cmp.size() > 9) throw Unsupported("filter on the counters of a set operation without its map");
+               emitSetOp(s, p->cmp);
+               continue;
+            }
             if (s.inJoinBody && !s.probeHiv.empty()) {
                addJoinConjunct(s, e);
                continue;
@@ -1239,8 +1507,45 @@ struct Translator {
          Stream* n = ins[0]->antiBranch ? ins[0] : ins[1];
          // matches (columns mapped to their nullable copies) ∪ partner-less probe rows (the same columns mapped to NULL) of ONE
          // pending hash join = a left outer join (OuterJoinLowering / SingleJoinLowering without reverseSides)
+         if (m->pending && !m->antiBranch && !m->probeHiv.empty() && n->antiBranch && !n->flagState.empty() && states.count(n->flagState) &&
+             states.at(m->probeHiv)->source == states.at(n->flagState)) {
+            // OuterJoinLowering with reverseSides (:1511-1525): the probing side's matches (the preserved BUILD side carries a flag they set) ∪ the
+            // build rows whose flag stayed false, the probe side's columns NULL = the inner pairs followed by the unmatched build rows
+            Stream s = *m;
+            s.rel = emitJoin(s, "right_outer");
+            const Stream& bs = states.at(s.probeHiv)->source->in;
+            s.names.insert(bs.names.begin(), bs.names.end());
+            clearJoin(s);
+            s.unique.clear();
+            c.streams[ref] = s;
+            return;
+         }
+         if (!m->pending && !n->pending && !m->antiBranch && !n->antiBranch && !m->lastMapped.empty() && m->lastMapped == n->lastMapped) {
+            // UnionAllLowering (:622-634): both inputs mapped to the result columns (as nullable), then united
+            Stream a = *m, b = *n;
+            std::vector<std::string> lc, rc;
+            for (auto& name : a.lastMapped) {
+               lc.push_back(ensureCol(a, a.cols.at(name), name));
+               rc.push_back(ensureCol(b, b.cols.at(name), name));
+            }
+            flush(a);
+            flush(b);
+            OutStep u;
+            u.op = "set_op";
+            u.out = fresh("u");
+            u.fields = {{"kind", "\"union_all\""}, {"left", quote(a.rel)}, {"left_cols", nameList(lc)}, {"right", quote(b.rel)}, {"right_cols", nameList(rc)}};
+            steps.push_back(u);
+            Stream s;
+            s.rel = u.out;
+            for (size_t k = 0; k < lc.size(); k++) {
+               s.cols[a.lastMapped[k]] = mk(Expr::COL, lc[k]);
+               s.names.insert(lc[k]);
+            }
+            c.streams[ref] = s;
+            return;
+         }
          if (!(m->pending && !m->antiBranch && n->pending && n->antiBranch && m->probeHiv == n->probeHiv && !m->probeHiv.empty()))
-            throw Unsupported("union of two streams that are not the two halves of an outer join (set operation)");
+            throw Unsupported("union of two streams that are neither the halves of an outer join nor two mapped inputs of a UNION ALL");
          Stream s = *m;
          for (auto& kv : n->cols)
             if (kv.second->kind == Expr::NULLV && !s.cols.count(kv.first)) throw Unsupported("outer join: column '" + kv.first + "' is NULL on one side and undefined on the other");
@@ -1270,11 +1575,15 @@ struct Translator {
             if (!s.probeHiv.empty()) throw Unsupported("nested hash-indexed-view lookups");
             states[id] = st;
             s.probeHiv = id;
+         } else if (stateType == "HashMap" && kind == "lookup") { // the second input of a group join looks its group up (an optional reference)
+            if (st->kind != State::AGG || st->gjRight) throw Unsupported("lookup into a hash map that no other pipeline has filled");
+            states[id] = st;
+            s.gjState = id;
          } else if (stateType == "SimpleState" && kind == "lookup" && st->kind == State::CONST1) {
             states[id] = st;
             s.constState = id;
          } else if ((stateType == "SimpleState" && kind == "lookup") || (stateType == "HashMap" && kind == "lookup_or_insert")) {
-            if (st->kind != State::UNKNOWN) throw Unsupported("aggregation into a state that is already in use");
+            if (st->kind != State::UNKNOWN && !(st->kind == State::AGG && kind == "lookup_or_insert" && !st->setRight)) throw Unsupported("aggregation into a state that is already in use");
             states[id] = st;
             s.aggState = id;
          } else {
@@ -1287,14 +1596,16 @@ struct Translator {
       if (kind == "reduce") {
          Stream s = input(op, c);
          settle(s);
-         if (s.aggState.empty()) throw Unsupported("reduce without a preceding lookup into an aggregation state");
-         StateP st = states.at(s.aggState);
-         if (st->kind != State::UNKNOWN) throw Unsupported("two pipelines reduce into one state");
+         if (s.aggState.empty() && s.gjState.empty()) throw Unsupported("reduce without a preceding lookup into an aggregation state");
+         const bool gj = s.aggState.empty();
+         StateP st = states.at(gj ? s.gjState : s.aggState);
+         std::vector<AggSpec> mine;
          for (auto& u : op.at("updated").arr) {
             AggSpec a;
             a.member = u.s("member");
             ExprP e = convert(u.at("expression"), s);
             auto isMember = [&](const ExprP& x) { return x->kind == Expr::MEMBER && x->name == a.member; };
+            if (isMember(e)) continue; // a member returned unchanged (the other input's counter of a set operation)
             // SumAggrFunc / CountAggrFunc / CountStarAggrFunc / Min / Max bodies (RelAlgToSubOp.cpp:1805-2020)
             if (e->kind == Expr::OP && e->name == "select" && e->args[0]->kind == Expr::OP && e->args[0]->name == "isnull" && isMember(e->args[0]->args[0]) &&
                 e->args[2]->kind == Expr::OP && e->args[2]->name == "add") { // nullable state: isnull(state) ? arg : state + arg
@@ -1337,8 +1648,28 @@ struct Translator {
                throw Unsupported("aggregate body of member '" + a.member + "' is not sum / count / min / max");
             }
             if (a.arg && (a.arg->kind == Expr::UNKNOWN || a.arg->kind == Expr::MEMBER)) throw Unsupported("aggregate argument without a device form");
-            st->aggs.push_back(a);
+            mine.push_back(a);
          }
+         if (gj) { // the aggregates of a group join, over the tuples of this input that found their group
+            st->gjAggs = mine;
+            st->gjRight = std::make_shared<Stream>(s);
+            st->gjRight->gjState.clear();
+            c.streams[ref] = s;
+            return;
+         }
+         if (st->kind == State::AGG) { // the second input of UnionDistinctLowering / CountingSetOperationLowering (:636-915) counts into the same map
+            bool counters = !st->setRight && mine.size() <= 1 && st->aggs.size() == 1 && st->aggs[0].fn == "count_star" && (mine.empty() || mine[0].fn == "count_star");
+            if (!counters || (mine.empty() != (st->aggs[0].member == "distinct$count"))) throw Unsupported("two pipelines reduce into one state");
+            st->setRight = std::make_shared<Stream>(s);
+            st->setRight->aggState.clear();
+            st->setLeftCounter = mine.empty() ? "" : st->aggs[0].member;
+            st->setRightCounter = mine.empty() ? "" : mine[0].member;
+            s.aggState.clear();
+            c.streams[ref] = s;
+            return;
+         }
+         if (st->kind != State::UNKNOWN) throw Unsupported("two pipelines reduce into one state");
+         st->aggs = mine;
          if (st->aggs.empty()) { // ProjectionDistinctLowering: a map of keys only
             AggSpec a;
             a.member = "distinct$count";
@@ -1395,6 +1726,11 @@ struct Translator {
       }
       if (kind == "scatter") { // only as part of the two marker idioms of semi / anti joins
          Stream s = input(op, c);
+         if (!s.gjState.empty()) { // inner group join: the matched groups get their marker set
+            states.at(s.gjState)->gjInner = true;
+            c.streams[ref] = s;
+            return;
+         }
          if (!s.pending && !s.aggState.empty() && s.probeHiv.empty()) { // constant single join: the one row of this stream becomes the state
             StateP st = states.at(s.aggState);
             if (st->kind != State::UNKNOWN) throw Unsupported("scatter into a state that is already in use");
@@ -1462,6 +1798,7 @@ struct Translator {
                   auto it = states.find(id);
                   c.args[argnr] = it == states.end() ? nullptr : it->second;
                }
+               for (auto& op : node.at("subops").arr) c.outerStep = c.outerStep || (op.get("subop") && op.s("subop") == "union");
                for (auto& op : node.at("subops").arr) handle(op, c);
                if (const J* ie = node.get("innerEdges"))
                   for (auto& e : ie->arr) {

@@ -406,6 +406,23 @@ def test_groupby_min_max_over_128_bit_decimals(ctx, oracle):
     assert sorted(got, key=repr) == sorted([(1, None, None), (2, -(1 << 80), -(1 << 80))], key=repr)
 
 
+def test_groupby_without_an_estimate_and_more_groups_than_the_first_table(ctx):
+    """est_groups = 0 sizes the global table at most 4 M slots; with 5.5 M groups it fills up.  A full table used to make every remaining
+    row walk all of it before the overflow was reported (quadratic: the translated Q18 dump did not finish at SF10); now a long probe run
+    raises the flag, the other lanes stop probing and the host retries with 8 x the capacity.  Sums and counts against numpy."""
+    n, groups = 6_000_000, 5_500_000
+    rng = np.random.default_rng(77)
+    keys = (rng.permutation(n) % groups).astype(np.int64)
+    vals = rng.integers(-1000, 1000, n).astype(np.int64)
+    g = ctx.register("no_estimate", pa.table({"k": pa.array(keys), "v": pa.array(vals)}))
+    got = g.rel().groupby([(0, 0)], [api.agg(capi.AGG_SUM, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT_STAR)], est_groups=0).to_arrow()
+    k = got.column(0).to_numpy()
+    order = np.argsort(k)
+    assert got.num_rows == groups and np.array_equal(k[order], np.arange(groups))
+    assert np.array_equal(got.column(1).to_numpy()[order], np.bincount(keys, weights=vals.astype(np.float64), minlength=groups).astype(np.int64))
+    assert np.array_equal(got.column(2).to_numpy()[order], np.bincount(keys, minlength=groups))
+
+
 def test_groupby_float_sum_within_tolerance(ctx, oracle):
     """floating-point SUM/AVG: atomics reorder additions → relative tolerance 1e-9 (BASELINE.md parity rule)"""
     rng = np.random.default_rng(4)

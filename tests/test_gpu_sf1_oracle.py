@@ -119,3 +119,53 @@ def test_nested_loop_dump_counts_suppliers_per_nation(world):
     cnt = np.bincount(sn, minlength=25)
     want = sorted((names[k], int(cnt[k])) for k in range(25) if cnt[k])
     assert [(r[0], r[1]) for r in got] == want and sum(r[1] for r in got) == len(sn)
+
+
+def test_pattern_dumps_match_numpy(world):
+    """the lowering patterns TPC-H does not exercise (tests/golden/subop_pat_*.json, tools/write_subop_dumps_patterns.py): mark join read
+    as a value, outer join with reverseSides, UNION [ALL] / INTERSECT [ALL] / EXCEPT [ALL] — dump → translator → interpreter against
+    plain Python over the same generated tables"""
+    import collections
+    import decimal
+    import os
+
+    from lingodb_amd import api
+
+    runner, _ = world
+    db = runner.db
+    col = lambda t, c: t.to_arrow().column(c).to_pylist()
+    sup = db.supplier_full  # (the queries that show supplier strings / balances read the wider supplier table)
+    s_key, s_nat, s_bal = col(sup, "s_suppkey"), col(sup, "s_nationkey"), col(sup, "s_acctbal")
+    n_key, n_reg = col(db.nation, "n_nationkey"), col(db.nation, "n_regionkey")
+    c_nat, c_bal = col(db.customer, "c_nationkey"), col(db.customer, "c_acctbal")
+    rich, richest = decimal.Decimal("9000.00"), decimal.Decimal("9990.00")
+
+    def run(name, inputs):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "subop_pat_%s.json" % name)
+        text, report = api.translate_subop_dump(path, "pat_" + name)
+        assert all(r["target"] == "gpu" for r in report)
+        return result_rows(runner.ctx.run_plan(text, inputs).to_arrow())
+
+    region1 = {k for k, r in zip(n_key, n_reg) if r == 1}
+    want = sorted(k for k, n, b in zip(s_key, s_nat, s_bal) if n in region1 or b > rich)
+    assert 0 < len(want) < len(s_key) and any(n not in region1 for k, n, b in zip(s_key, s_nat, s_bal) if b > rich)
+    assert run("mark", {"supplier": sup, "nation": db.nation}) == [(k,) for k in want]
+
+    per_nation = collections.Counter(n for n, b in zip(s_nat, s_bal) if b > rich)
+    assert run("right_outer", {"supplier": sup, "nation": db.nation}) == [(k, per_nation.get(k, 0)) for k in sorted(n_key)]
+
+    n_name = dict(zip(n_key, col(db.nation, "n_name")))
+    total = collections.Counter()
+    for n, b in zip(s_nat, s_bal):
+        if b > rich:
+            total[n] += int(b.scaleb(2))
+    assert run("groupjoin", {"supplier": sup, "nation": db.nation}) == [(k, n_name[k], per_nation[k], total[k]) for k in sorted(per_nation)]
+
+    left = [n for n, b in zip(c_nat, c_bal) if b > rich]
+    right = [n for n, b in zip(s_nat, s_bal) if b > richest]
+    assert right and set(left) - set(right) and set(left) & set(right)
+    cl, cr = collections.Counter(left), collections.Counter(right)
+    expected = {"union_all": sorted(left + right), "union": sorted(set(left) | set(right)), "intersect": sorted(set(left) & set(right)), "except": sorted(set(left) - set(right)),
+                "intersect_all": sorted((cl & cr).elements()), "except_all": sorted((cl - cr).elements())}
+    for kind, rows in expected.items():
+        assert run(kind, {"customer": db.customer, "supplier": sup}) == [(k,) for k in rows], kind

@@ -274,6 +274,60 @@ def test_translated_plans_that_equal_the_hand_written_ones():
     assert [g for g in got if g[0] != "materialize"][:4] == [w for w in want if w[0] != "materialize"][:4]  # filter, build, semi probe, avg per part
 
 
+PATTERNS = ["mark", "right_outer", "groupjoin", "union_all", "union", "intersect", "except", "intersect_all", "except_all"]  # tools/write_subop_dumps_patterns.py
+
+
+def pattern_steps(name):
+    with open(os.path.join(GOLD, "subop_pat_%s.json" % name)) as f:
+        text, report = api.translate_subop_dump(f.read(), "pat_" + name)
+    plan = json.loads(text)
+    ins = plan["inputs"]
+    arr = (capi.C.c_char_p * len(ins))(*[n.encode() for n in ins])
+    assert capi.host_lib().ldb_plan_json_check(text.encode(), arr, len(ins)) == capi.LDB_OK, capi.host_lib().ldb_plan_json_last_error()
+    assert all(r["target"] == "gpu" for r in report)
+    return plan["steps"]
+
+
+def test_mark_join_read_as_a_value():
+    """MarkJoinLowering (RelAlgToSubOp.cpp:1376-1408): anyTuple defines the mark column; `mark or balance > 9000` reads it as a value, so the
+    probe keeps every row and the mark becomes a boolean column of the result (join_probe kind mark + mark_as)"""
+    st = pattern_steps("mark")
+    jp = [s for s in st if s["op"] == "join_probe"][0]
+    assert jp["kind"] == "mark" and jp["keys"] == ["s_nationkey"] and jp["mark_as"].startswith("mark")
+    mp = st[st.index(jp) + 1]
+    assert mp["op"] == "map" and mp["expr"] == {"or": [jp["mark_as"], {"cmp": ["GT", "s_acctbal", "9000.00"]}]}
+
+
+def test_outer_join_with_reversed_sides():
+    """OuterJoinLowering with reverseSides (:1511-1525): the preserved side is the flagged build buffer; matches (mapped as-nullable) ∪ the scan
+    of the buffer filtered on `flag = false` with NULLs for the probe side = join_probe kind right_outer"""
+    st = pattern_steps("right_outer")
+    assert [s["op"] for s in st] == ["join_build", "filter", "join_probe", "groupby", "sort", "materialize"]
+    assert st[0]["in"] == "nation" and st[2]["kind"] == "right_outer" and st[2]["keys"] == ["s_nationkey"] and st[3]["aggs"][0]["fn"] == "count" and st[3]["aggs"][0]["expr"] == "s_suppkey"
+
+
+def test_group_join():
+    """GroupJoinLowering (:2682-2950), inner behaviour: one map entry per left key with the stored columns, the right input looks its group
+    up, applies the predicate and aggregates into it → distinct left keys (+ stored columns as further keys) → unique build → inner probe
+    by the right input → predicate → group by"""
+    st = pattern_steps("groupjoin")
+    assert [s["op"] for s in st] == ["groupby", "join_build", "join_probe", "filter", "groupby", "sort", "materialize"]
+    assert st[0]["in"] == "nation" and st[0]["keys"] == ["n_nationkey", "n_name"] and st[1]["unique"] is True and st[1]["keys"] == ["n_nationkey"]
+    assert st[2]["kind"] == "inner" and st[2]["in"] == "supplier" and st[2]["keys"] == ["s_nationkey"]
+    assert st[3]["preds"] == [{"col": "s_acctbal", "op": "GT", "value": "9000.00"}]
+    assert st[4]["keys"] == ["s_nationkey", "n_name"] and [a["fn"] for a in st[4]["aggs"]] == ["count_star", "sum"]
+
+
+@pytest.mark.parametrize("kind", PATTERNS[3:])
+def test_set_operations(kind):
+    """UnionAllLowering (map both inputs + union), UnionDistinctLowering (both inputs lookup_or_insert into one key-only map),
+    CountingSetOperationLowering (two counters; a predicate or a repeat count over them, :622-915) → one set_op step"""
+    st = pattern_steps(kind)
+    so = [s for s in st if s["op"] == "set_op"]
+    assert len(so) == 1 and so[0]["kind"] == kind and so[0]["left_cols"] == ["c_nationkey"] and so[0]["right_cols"] == ["s_nationkey"]
+    assert [s["op"] for s in st] == ["filter", "filter", "set_op", "sort", "materialize"]
+
+
 def test_dumps_are_what_the_generator_writes(tmp_path):
     import subprocess
     import sys
@@ -283,6 +337,10 @@ def test_dumps_are_what_the_generator_writes(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "write_subop_dumps.py")], stdout=subprocess.DEVNULL)
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "write_subop_dumps_relalg.py")], stdout=subprocess.DEVNULL, cwd=os.path.join(ROOT, "tools"))
     assert {q: dump(q) for q in qs} == before
+    pat = lambda: {n: open(os.path.join(GOLD, "subop_pat_%s.json" % n)).read() for n in PATTERNS}
+    before = pat()
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "write_subop_dumps_patterns.py")], stdout=subprocess.DEVNULL, cwd=os.path.join(ROOT, "tools"))
+    assert pat() == before
 
 
 def test_mutated_dumps_never_crash_the_consumer():

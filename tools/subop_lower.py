@@ -125,6 +125,24 @@ class Pipe:
     def close(self):
         return self.cx.d.step(self.ops, inputs=self.inputs)
 
+    def absorb(self, other):
+        """the sub-operators of another pipeline of the same execution step (two scans meeting in a union): its state arguments are renumbered"""
+        remap = {}
+        for i, (ty, s, r) in enumerate(other.inputs):
+            remap[i] = self.state_arg(s, ty, r)["argnr"]
+
+        def walk(x):
+            if isinstance(x, dict):
+                if x.get("type") == "parentArg":
+                    x["argnr"] = remap[x["argnr"]]
+                for v in x.values():
+                    walk(v)
+            elif isinstance(x, list):
+                for v in x:
+                    walk(v)
+        walk(other.ops)
+        self.ops += other.ops
+
 
 class Node:
     def avail(self): raise NotImplementedError
@@ -499,6 +517,105 @@ class Rename(Node):
         p = self.child.lower(cx, need & self.child.avail())
         p.op("renaming", renamed=[{"new": n.j, "old": o.j} for n, o in self.renamed])
         return p
+
+
+class SetOp(Node):
+    """UnionAllLowering (:622-634), UnionDistinctLowering (:636-727), CountingSetOperationLowering (:728-915); kind: union_all | union |
+    intersect | except | intersect_all | except_all; mapping = [(result column, left column, right column)]"""
+    def __init__(self, kind, left, right, mapping):
+        self.kind, self.left, self.right, self.mapping = kind, left, right, list(mapping)
+
+    def avail(self): return {n.name for n, _, _ in self.mapping}
+
+    def lower(self, cx, required):
+        lp = self.left.lower(cx, {l.name for _, l, _ in self.mapping})
+        lp.op("map", computed=[{"computed": n.j, "expression": l.j} for n, l, _ in self.mapping])  # mapColsToNullable(…, 0)
+        rp = self.right.lower(cx, {r.name for _, _, r in self.mapping})
+        rp.op("map", computed=[{"computed": n.j, "expression": r.j} for n, _, r in self.mapping])  # mapColsToNullable(…, 1)
+        if self.kind == "union_all":
+            lp.absorb(rp)
+            u = lp.raw("union", [lp.last, rp.last])
+            lp.ops.append(u)
+            lp.last = u["ref"]
+            return lp
+        counting = self.kind != "union"
+        s_st, _ = cx.state("generic_create")
+        for i, p in enumerate((lp, rp)):
+            ref = cx.col("lookup", "ref", "?")
+            p.op("lookup_or_insert", accesses=[p.state_arg(s_st)], stateType="HashMap", reference=ref.j)
+            upd = []
+            if counting:  # the input's own counter + 1, the other one returned unchanged
+                upd = [{"member": "counter$%d" % k, "expression": add(member("counter$%d" % k), const(1, "int64")) if k == i else member("counter$%d" % k)} for k in (0, 1)]
+            p.op("reduce", reference=ref.j, updated=upd)
+            p.close()
+        sp = Pipe(cx)
+        c1, c2 = cx.col("set", "counter", "int64"), cx.col("set", "counter", "int64")
+        sp.op("scan", source=True, accesses=[sp.state_arg(s_st)],
+              mapping=[{"member": "keyval$%d" % i, "column": n.j} for i, (n, _, _) in enumerate(self.mapping)] + ([{"member": "counter$0", "column": c1.j}, {"member": "counter$1", "column": c2.j}] if counting else []))
+        if not counting:
+            return sp
+        zero = const(0, "int64")
+        if self.kind in ("intersect", "except"):  # EXT E7: arith.cmpi / arith.andi
+            pred = cx.col("set", "predicate", "int1")
+            sp.op("map", computed=[{"computed": pred.j, "expression": and_(gt(c1.j, zero), gt(c2.j, zero) if self.kind == "intersect" else eq(c2.j, zero))}])
+            sp.op("filter", semantic="all_true", columns=[pred.j])
+            return sp
+        rep = cx.col("set", "repeat", "index")  # EXT E7: arith.subi / arith.select
+        sp.op("map", computed=[{"computed": rep.j, "expression": select(lt(sub(c1.j, c2.j), zero), zero, sub(c1.j, c2.j)) if self.kind == "except_all" else select(gt(c1.j, c2.j), c2.j, c1.j)}])
+        gen = sp.raw("generate", generated=[])
+        nm = sp.raw("nested_map", [sp.last], inputs=[rep.j], subops=[gen])
+        sp.ops.append(nm)
+        sp.last = nm["ref"]
+        return sp
+
+
+class GroupJoin(Node):
+    """GroupJoinLowering (:2682-2950), inner behaviour: the left input creates one map entry per key (its `stored` columns are members), the
+    right input looks its group up (an optional reference), gathers the stored columns, takes the left key's name for its own key
+    column (renaming), applies the predicate, marks the group and reduces the aggregates into it; the map is scanned, filtered on the
+    marker and the right key's name is restored.  keys = [(left column, right column)], aggs = [(fn, right column | None, result column)]"""
+    def __init__(self, left, right, keys, aggs, stored=(), predicate=()):
+        self.left, self.right, self.keys, self.aggs, self.stored, self.predicate = left, right, list(keys), list(aggs), list(stored), list(predicate)
+
+    def avail(self): return {r.name for _, r in self.keys} | {l.name for l, _ in self.keys} | {c.name for c in self.stored} | {o.name for _, _, o in self.aggs}
+
+    def lower(self, cx, required):
+        s_st, _ = cx.state("generic_create")
+        lp = self.left.lower(cx, {l.name for l, _ in self.keys} | {c.name for c in self.stored})
+        ref = cx.col("lookup", "ref", "?")
+        lp.op("lookup_or_insert", accesses=[lp.state_arg(s_st)], stateType="HashMap", reference=ref.j)
+        members = ["gjvalmarker$0"] + ["gjval$%d" % k for k in range(len(self.stored))] + ["aggrval$%d" % i for i in range(len(self.aggs))]
+        stored_m = {"gjval$%d" % k: c for k, c in enumerate(self.stored)}
+        lp.op("reduce", reference=ref.j, updated=[{"member": m, "expression": stored_m[m].j if m in stored_m else member(m)} for m in members])  # stores the columns, keeps the rest
+        lp.close()
+        need = {r.name for _, r in self.keys} | {a.name for _, a, _ in self.aggs if a is not None}
+        for e in self.predicate:
+            need |= refs(e)
+        rp = self.right.lower(cx, need & self.right.avail())
+        opt, ref2 = cx.col("lookup", "ref", "?"), cx.col("lookup", "ref", "?")
+        rp.op("lookup", accesses=[rp.state_arg(s_st)], stateType="HashMap", reference=opt.j)
+        rp.op("unwrap_optional_ref", reference=ref2.j, optionalRef=opt.j)
+        if self.stored:
+            rp.op("gather", reference=ref2.j, mapping=[{"member": m, "column": c.j} for m, c in stored_m.items()])
+        rp.op("renaming", renamed=[{"new": l.j, "old": r.j} for l, r in self.keys if l.name not in {c.name for c in self.stored}])
+        selection(rp, self.predicate)
+        bv = cx.col("map", "boolval", "int1")
+        rp.op("map", computed=[{"computed": bv.j, "expression": const(True, "int1")}])
+        rp.op("scatter", reference=ref2.j, mapping=[{"member": "gjvalmarker$0", "column": bv.j}])
+        upd = []
+        for i, (fn, a, _) in enumerate(self.aggs):
+            m = "aggrval$%d" % i
+            upd.append({"member": m, "expression": agg_body(fn, m, a.j if a is not None else None, fn in ("sum", "min", "max"))})
+        rp.op("reduce", reference=ref2.j, updated=[{"member": "gjvalmarker$0", "expression": member("gjvalmarker$0")}] + [{"member": m, "expression": member(m)} for m in stored_m] + upd)
+        rp.close()
+        sp = Pipe(cx)
+        marker = cx.col("groupjoin", "marker", "int1")
+        sp.op("scan", source=True, accesses=[sp.state_arg(s_st)],
+              mapping=[{"member": "gjvalmarker$0", "column": marker.j}] + [{"member": m, "column": c.j} for m, c in stored_m.items()] +
+                      [{"member": "aggrval$%d" % i, "column": o.j} for i, (_, _, o) in enumerate(self.aggs)] + [{"member": "gjkeyval$%d" % i, "column": l.j} for i, (l, _) in enumerate(self.keys)])
+        sp.op("filter", semantic="all_true", columns=[marker.j])
+        sp.op("renaming", renamed=[{"new": r.j, "old": l.j} for l, r in self.keys])
+        return sp
 
 
 def result(cx, child, outs):

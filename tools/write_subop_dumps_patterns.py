@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Small dumps for the lowering patterns TPC-H does not exercise (tools/subop_lower.py, the schema of the reference's
+`tools/ct/mlir-subop-to-json.cpp`), each with a numpy-checkable answer over the generated tables:
+  pat_mark         MarkJoinLowering (:1376-1408): suppliers whose nation is in region 1 OR whose balance exceeds 9000 — the mark is a value
+  pat_right_outer  OuterJoinLowering with reverseSides (:1511-1525): every nation with the number of its rich suppliers (0 when none)
+  pat_groupjoin    GroupJoinLowering (:2682-2950), inner: per nation with a rich supplier its name, their number and total balance
+  pat_<set op>     UnionAll / UnionDistinct / CountingSetOperation lowerings (:622-915) over the nation keys of rich customers (balance > 9000) / the richest suppliers (> 9990)
+Writes tests/golden/subop_pat_*.json."""
+from subop_lower import Aggregate, C, Cx, GroupJoin, Join, Select, SetOp, Sort, Table, dec, eq, gt, or_, result, const
+
+RICH = dec("9000.00", 12, 2)
+
+
+def mark():
+    cx = Cx("pat_mark")
+    s, n = Table("supplier"), Table("nation", filters=[("n_regionkey", "EQ", 1)])
+    m = C("markjoin0::mark", "int1")
+    j = Join("mark", s, n, [(s["s_nationkey"], n["n_nationkey"])], mark=m)
+    sel = Select(j, or_(m.j, gt(s["s_acctbal"].j, RICH)))
+    return result(cx, Sort(sel, [(s["s_suppkey"], "asc")]), [("s_suppkey", s["s_suppkey"])])
+
+
+def right_outer():
+    cx = Cx("pat_right_outer")
+    n, s = Table("nation"), Table("supplier", filters=[("s_acctbal", "GT", "9000.00")])
+    oj = C("oj0::s_suppkey", "nullable(int32)")
+    j = Join("outer", s, n, [(s["s_nationkey"], n["n_nationkey"])], reverse=True, mapping=[(oj, s["s_suppkey"])])
+    cnt = C("aggr0::rich", "int64")
+    g = Aggregate(j, [n["n_nationkey"]], [("count", oj, cnt)], nullable_args=[oj])
+    return result(cx, Sort(g, [(n["n_nationkey"], "asc")]), [("n_nationkey", n["n_nationkey"]), ("rich", cnt)])
+
+
+def set_op(kind):
+    cx = Cx("pat_" + kind)
+    c, s = Table("customer", filters=[("c_acctbal", "GT", "9000.00")]), Table("supplier", filters=[("s_acctbal", "GT", "9990.00")])
+    k = C("setop0::nationkey", "nullable(int32)")
+    u = SetOp(kind, c, s, [(k, c["c_nationkey"], s["s_nationkey"])])
+    return result(cx, Sort(u, [(k, "asc")]), [("nationkey", k)])
+
+
+def groupjoin():
+    cx = Cx("pat_groupjoin")
+    n, s = Table("nation"), Table("supplier")
+    cnt, tot = C("aggr0::suppliers", "int64"), C("aggr0::balance", "nullable(decimal(38,2))")
+    gj = GroupJoin(n, s, [(n["n_nationkey"], s["s_nationkey"])], [("count_star", None, cnt), ("sum", s["s_acctbal"], tot)], stored=[n["n_name"]], predicate=[gt(s["s_acctbal"].j, RICH)])
+    return result(cx, Sort(gj, [(s["s_nationkey"], "asc")]), [("s_nationkey", s["s_nationkey"]), ("n_name", n["n_name"]), ("suppliers", cnt), ("balance", tot)])
+
+
+SET_KINDS = ("union_all", "union", "intersect", "except", "intersect_all", "except_all")
+
+if __name__ == "__main__":
+    print(mark())
+    print(right_outer())
+    print(groupjoin())
+    for kind in SET_KINDS:
+        print(set_op(kind))
