@@ -663,7 +663,6 @@ struct Translator {
                std::swap(l, r);
                op = mirrored(op);
             }
-            if (getenv("LDB_SUBOP_DEBUG")) fprintf(stderr, "conjunct %s: l=%s side %d, r=%s side %d\n", op.c_str(), l->name.c_str(), sideOf(l), r->name.c_str(), sideOf(r));
             if (sideOf(l) == 1 && sideOf(r) == 2) {
                const std::string bc = ensureCol(b, r, "build_key"), pc = ensureCol(s, l, "probe_key");
                if (op == "EQ") {

@@ -211,3 +211,18 @@ def test_loop_and_nested_map_plans_pass_the_structure_check():
     after["steps"][1]["in"] = "newCounter"
     st, err = _check(json.dumps(after), ["ctr0"])
     assert st != 0 and "before it exists" in err
+
+
+def test_oracle_q6_in_slices_equals_the_whole_table():
+    """bench.py's spot check at its own scale (checks.oracle_q6_at_bench_scale) runs the oracle's Q6 leg over host-generated SLICES of lineitem and adds
+    the partial sums: the same number as the leg over the whole table (small scale here; the generator is counter-based, a slice is a row range)"""
+    import sys
+
+    sys.path[:0] = [os.path.join(ROOT, "oracle"), ROOT]
+    import tpch_legs
+    import tpch_plans
+
+    n_orders = 60_000
+    whole = tpch_legs.Legs(n_orders, queries=[6]).q6()
+    got, secs = tpch_plans.oracle_q6_at_scale(n_orders, n_parts=7, threads=3)
+    assert whole == [(got,)] and got is not None and got > 0 and secs >= 0
