@@ -135,6 +135,15 @@ struct Stream {
    bool antiBranch = false; // outer / single join: the branch of the probe rows WITHOUT a partner (filter none_true on the marker)
    std::string constState; // constant single join: the one-row state this stream looked up
    std::vector<std::string> lastMapped; // the columns the most recent map defined (UNION ALL maps both inputs to the result columns)
+   // a window being evaluated on this stream: the continuous view it scans, the functions collected so far and their common frame
+   std::string winView, winLookup;
+   struct WinFn {
+      std::string fn, col, as;
+   };
+   std::vector<WinFn> winFns;
+   bool winFrame = false;
+   int64_t winFrom = 0, winTo = 0;
+   std::string partState; // scan of the map of per-partition buffers: the buffer column stands for this state inside the nested_map
    std::string gjState; // group join: this stream probes the map the other input created (GroupJoinLowering, RelAlgToSubOp.cpp:2682-2950)
    std::string setState; // scan of the counting map of INTERSECT / EXCEPT: the set operation is emitted when its predicate / repeat count is consumed
 };
@@ -153,7 +162,7 @@ struct OutStep {
    std::vector<OutAgg> aggs; // groupby
 };
 struct State {
-   enum Kind { UNKNOWN, TABLE, AGG, BUFFER, HIV, SORTED, HEAP, RESULT, MARKER, CONST1 } kind = UNKNOWN; // CONST1: the scattered one-row state of a constant single join
+   enum Kind { UNKNOWN, TABLE, AGG, BUFFER, HIV, SORTED, HEAP, RESULT, MARKER, CONST1, CONTVIEW, SEGTREE } kind = UNKNOWN; // CONST1: the scattered one-row state of a constant single join; CONTVIEW / SEGTREE: the views of a window
    std::string table; // TABLE
    std::map<std::string, std::string> memberToIdent;
    std::vector<std::string> filters, pkey;
@@ -175,6 +184,15 @@ struct State {
    std::shared_ptr<Stream> flagProbe;
    std::shared_ptr<State> flagHiv;
    // AGG reduced by TWO pipelines with nothing but row counters: the map of a UNION (distinct) / INTERSECT / EXCEPT
+   // windows (WindowLowering, RelAlgToSubOp.cpp:2193-2553): SORTED remembers its order, a BUFFER filled inside the reduce of a map keyed by the
+   // PARTITION BY columns remembers them, a SEGTREE its aggregates (emitter extension E8)
+   std::vector<std::pair<std::string, bool>> sortCols; // column, descending
+   std::vector<std::string> partCols;
+   bool partPending = false; // BUFFER filled per partition: the keys are named by the scan of the map
+   struct WinAgg {
+      std::string member, fn, source;
+   };
+   std::vector<WinAgg> winAggs;
    // AGG whose map a second stream looks up and aggregates into: a group join
    std::shared_ptr<Stream> gjRight;
    std::vector<AggSpec> gjAggs;
@@ -608,6 +626,7 @@ struct Translator {
          if (jt != states.end()) return jt->second;
          throw Unsupported("state '" + id + "' is produced by a sub-operator this consumer does not know");
       }
+      if (t == "nested_map_arg" && c.nested && !c.nested->partState.empty()) return states.at(c.nested->partState); // the per-partition buffer of a window
       throw Unsupported("state access of type '" + t + "'");
    }
    Stream& input(const J& op, StepCtx& c) {
@@ -786,8 +805,65 @@ struct Translator {
       steps.push_back(jp);
       return jp.out;
    }
+   // ---------------------------------------------------------------- windows
+   static ExprP wref(const char* what, int64_t k = 0) {
+      ExprP r = mk(Expr::REF, what);
+      r->i = k;
+      return r;
+   }
+   static int64_t frameEnd(const ExprP& r) { // a reference into the continuous view as a frame end: offset from the current row, or unbounded
+      if (r->kind != Expr::REF) throw Unsupported("window frame end that is not a view reference");
+      if (r->name == "w:begin") return INT64_MIN;
+      if (r->name == "w:end") return INT64_MAX;
+      if (r->name == "w:cur") return 0;
+      if (r->name == "w:off") return r->i;
+      throw Unsupported("window frame end that is not a view reference");
+   }
+   void setFrame(Stream& s, int64_t from, int64_t to, bool haveTo) {
+      if (s.winFrame && (s.winFrom != from || (haveTo && s.winTo != to))) throw Unsupported("window functions with different frames in one window");
+      if (!s.winFrame) s.winTo = 0;
+      s.winFrame = true;
+      s.winFrom = from;
+      if (haveTo) s.winTo = to;
+   }
+   // the functions collected on this stream become ONE window step: partition + order of the view, one frame, one result column each
+   void flushWindow(Stream& s) {
+      if (s.winFns.empty()) return;
+      StateP view = states.at(s.winView);
+      flush(s);
+      auto end = [](int64_t v) { return v == INT64_MIN ? std::string("\"unbounded_preceding\"") : v == INT64_MAX ? std::string("\"unbounded_following\"") : std::to_string(v); };
+      OutStep w;
+      w.op = "window";
+      w.out = fresh("w");
+      w.fields = {{"in", quote(s.rel)}};
+      if (!view->partCols.empty()) w.fields.push_back({"partition_by", nameList(view->partCols)});
+      if (!view->sortCols.empty()) {
+         std::string by = "[";
+         for (size_t k = 0; k < view->sortCols.size(); k++) by += (k ? ", " : "") + (view->sortCols[k].second ? "{\"col\": " + quote(view->sortCols[k].first) + ", \"desc\": true}" : quote(view->sortCols[k].first));
+         w.fields.push_back({"order_by", by + "]"});
+      }
+      w.fields.push_back({"frame_from", end(s.winFrom)});
+      w.fields.push_back({"frame_to", end(s.winTo)});
+      std::string fns = "[";
+      for (size_t k = 0; k < s.winFns.size(); k++) {
+         const auto& f = s.winFns[k];
+         fns += std::string(k ? ", " : "") + "{\"fn\": " + quote(f.fn) + (f.col.empty() ? "" : ", \"col\": " + quote(f.col)) + ", \"as\": " + quote(f.as) + "}";
+         s.names.insert(f.as);
+      }
+      w.fields.push_back({"fns", fns + "]"});
+      steps.push_back(w);
+      s.rel = w.out;
+      s.bareTable = false;
+      s.unique.clear();
+      s.winFns.clear();
+      s.winView.clear();
+      s.winLookup.clear();
+      s.winFrame = false;
+   }
+
    // the pending join turns out to be an ordinary (inner) one: some other sub-operator consumes the matched pairs
    void settle(Stream& s) {
+      flushWindow(s);
       if (!s.pending) return;
       StateP hiv = states.at(s.probeHiv);
       bool marked = false;
@@ -1006,14 +1082,20 @@ struct Translator {
          s->source = src;
          s->in = src->in;
          s->members = src->members;
-         flush(s->in);
+         if (!src->partPending) flush(s->in);
          std::string by = "[";
          for (size_t k = 0; k < sb->arr.size(); k++) {
             auto it = s->members.find(sb->arr[k].s("member"));
             if (it == s->members.end()) throw Unsupported("sort key '" + sb->arr[k].s("member") + "' is not a member of the buffer");
             const std::string col = ensureCol(s->in, it->second, stripSuffix(it->first));
             it->second = mk(Expr::COL, col);
+            s->sortCols.push_back({col, sb->arr[k].sOr("direction", "asc") == "desc"});
             by += (k ? ", " : "") + (sb->arr[k].sOr("direction", "asc") == "desc" ? "{\"col\": " + quote(col) + ", \"desc\": true}" : quote(col));
+         }
+         s->partCols = src->partCols;
+         if (src->partPending) { // one partition's buffer of a window: the window step orders the rows inside their partitions itself
+            if (s->in.rel != src->in.rel) throw Unsupported("window ordered by a computed column inside a partition");
+            return;
          }
          OutStep so;
          so.op = "sort";
@@ -1021,6 +1103,64 @@ struct Translator {
          so.fields = {{"in", quote(s->in.rel)}, {"by", by + "]"}};
          steps.push_back(so);
          s->in.rel = so.out;
+         return;
+      }
+      if (kind == "create_continuous_view") { // the rows of a (sorted) buffer addressable by position: the input of a window evaluation
+         StateP src = resolve(op.at("accesses").arr.at(0), c);
+         if (src->kind != State::SORTED && src->kind != State::BUFFER) throw Unsupported("continuous view over a state that is neither a buffer nor a sorted view");
+         StateP v = newState(State::CONTVIEW);
+         v->source = src;
+         v->in = src->in;
+         v->members = src->members;
+         v->sortCols = src->sortCols;
+         v->partCols = src->partCols;
+         return;
+      }
+      if (kind == "create_segment_tree_view") {
+         StateP src = resolve(op.at("accesses").arr.at(0), c);
+         if (src->kind != State::CONTVIEW) throw Unsupported("segment tree over a state that is not a continuous view");
+         const J* ag = op.get("aggregates"); // emitter extension E8: the tool prints neither the functions nor their source members
+         if (!ag || ag->arr.empty()) throw Unsupported("create_segment_tree_view without its aggregates (emitter extension E8)");
+         StateP t = newState(State::SEGTREE);
+         t->source = src;
+         for (auto& a : ag->arr) t->winAggs.push_back({a.s("member"), a.s("fn"), a.sOr("source", "")});
+         return;
+      }
+      if (kind == "scan_ref") { // every entry of the continuous view, by reference
+         StateP st = resolve(op.at("accesses").arr.at(0), c);
+         if (st->kind != State::CONTVIEW) throw Unsupported("scan_ref over a state that is not a continuous view");
+         Stream s = c.nested && !st->partCols.empty() ? *c.nested : st->in;
+         s.winView = idOf(st, c);
+         s.cols[op.at("reference").s("displayName")] = wref("w:cur");
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "get_begin_reference" || kind == "get_end_reference") {
+         Stream s = input(op, c);
+         if (s.winView.empty()) throw Unsupported(kind + " outside a window evaluation");
+         s.cols[op.at("reference").s("displayName")] = wref(kind == "get_begin_reference" ? "w:begin" : "w:end");
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "offset_reference_by") { // ROWS k PRECEDING / FOLLOWING: the current reference moved by a constant, clamped into the partition
+         Stream s = input(op, c);
+         auto r = s.cols.find(op.at("reference").s("displayName"));
+         auto o = s.cols.find(op.at("offset").s("displayName"));
+         if (s.winView.empty() || r == s.cols.end() || r->second->kind != Expr::REF || r->second->name != "w:cur" || o == s.cols.end() || stripCast(o->second)->kind != Expr::CONST_INT)
+            throw Unsupported("offset_reference_by that does not move the current row of a window by a constant");
+         s.cols[op.at("newRef").s("displayName")] = wref("w:off", stripCast(o->second)->i);
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "entries_between") { // RankWindowFunc (:2043-2058): entries between the frame begin and the current row
+         Stream s = input(op, c);
+         auto l = s.cols.find(op.at("leftRef").s("displayName"));
+         auto r = s.cols.find(op.at("rightRef").s("displayName"));
+         if (s.winView.empty() || l == s.cols.end() || r == s.cols.end() || r->second->kind != Expr::REF || r->second->name != "w:cur") throw Unsupported("entries_between that does not end at the current row of a window");
+         ExprP b = mk(Expr::OP, "wbetween");
+         b->i = frameEnd(l->second);
+         s.cols[op.at("between").s("displayName")] = b;
+         c.streams[ref] = s;
          return;
       }
       if (kind == "scan") {
@@ -1201,6 +1341,23 @@ struct Translator {
          } else if (st->kind == State::MARKER) { // the per-row marker of anyTuple: the pending join continues on the probe stream
             s = st->in;
             for (auto& m : mapping.arr) s.cols[m.at("column").s("displayName")] = mk(Expr::MARKER);
+         } else if (st->kind == State::BUFFER && st->partPending) { // the map keyed by the PARTITION BY columns whose value is the partition's buffer
+            s = st->in;
+            st->partCols.clear();
+            for (auto& m : mapping.arr) {
+               const std::string& name = m.at("column").s("displayName");
+               if (isKeyMember(m.s("member"))) {
+                  auto it = st->in.cols.find(name);
+                  if (it == st->in.cols.end()) throw Unsupported("partition key '" + name + "' is not a column of the windowed stream");
+                  st->partCols.push_back(ensureCol(st->in, it->second, name));
+               } else {
+                  s.cols[name] = wref("w:partbuf");
+               }
+            }
+            s = st->in; // (ensureCol may have added columns)
+            for (auto& m : mapping.arr)
+               if (!isKeyMember(m.s("member"))) s.cols[m.at("column").s("displayName")] = wref("w:partbuf");
+            s.partState = idOf(st, c);
          } else if (st->kind == State::BUFFER || st->kind == State::SORTED || st->kind == State::HEAP || st->kind == State::RESULT) {
             if (st->kind == State::HEAP && !st->emitted) { // the heap keeps the best maxRows rows: a top-k over what was materialised
                flush(st->in);
@@ -1288,6 +1445,7 @@ struct Translator {
          c.outerBody = outerWas;
          c.streams[ref] = last.empty() ? s : c.streams[last];
          c.streams[ref].inJoinBody = false;
+         flushWindow(c.streams[ref]); // a window evaluated per partition inside the body
          if (!c.streams[ref].nlBuild.empty()) emitNestedLoop(c.streams[ref], nullptr); // no predicate in the body: a cross product
          return;
       }
@@ -1301,6 +1459,43 @@ struct Translator {
       if (kind == "unwrap_optional_ref") { // group join: tuples without a group are dropped — the inner join emitted for the group join does that
          Stream s = input(op, c);
          if (s.gjState.empty()) throw Unsupported("unwrap_optional_ref outside a group join");
+         c.streams[ref] = s;
+         return;
+      }
+      if (kind == "gather" && !input(op, c).winView.empty()) {
+         Stream s = input(op, c);
+         auto r = s.cols.find(op.at("reference").s("displayName"));
+         if (r == s.cols.end() || r->second->kind != Expr::REF) throw Unsupported("gather through an undefined reference");
+         StateP view = states.at(s.winView);
+         if (r->second->name == "w:cur") { // the columns of the current row
+            for (auto& m : op.at("mapping").arr) {
+               auto it = view->members.find(m.s("member"));
+               if (it == view->members.end()) throw Unsupported("gather of member '" + m.s("member") + "' that was never materialised");
+               s.cols[m.at("column").s("displayName")] = it->second;
+            }
+         } else if (r->second->name == "w:lookup") { // the aggregates of the frame, from the segment tree
+            StateP seg = states.at(s.winLookup);
+            for (auto& m : op.at("mapping").arr) {
+               const State::WinAgg* a = nullptr;
+               for (auto& x : seg->winAggs)
+                  if (x.member == m.s("member")) a = &x;
+               if (!a) throw Unsupported("gather of member '" + m.s("member") + "' the segment tree does not aggregate");
+               static const std::set<std::string> known = {"sum", "min", "max", "count", "count_star"};
+               if (!known.count(a->fn)) throw Unsupported("window aggregate '" + a->fn + "'");
+               Stream::WinFn f;
+               f.fn = a->fn;
+               if (a->fn != "count_star") {
+                  auto it = view->members.find(a->source);
+                  if (it == view->members.end()) throw Unsupported("window aggregate over member '" + a->source + "' that was never materialised");
+                  f.col = ensureCol(s, it->second, stripSuffix(a->source));
+               }
+               f.as = sanitize(m.at("column").s("displayName"));
+               s.winFns.push_back(f);
+               s.cols[m.at("column").s("displayName")] = mk(Expr::COL, f.as);
+            }
+         } else {
+            throw Unsupported("gather through a frame reference");
+         }
          c.streams[ref] = s;
          return;
       }
@@ -1382,11 +1577,30 @@ struct Translator {
             for (auto& cm : op.at("computed").arr) marker = marker && convert(cm.at("expression"), s)->kind == Expr::CONST_BOOL;
             if (!marker) settle(s);
          }
+         if (!s.winFns.empty() || !s.winView.empty()) { // a map that is not part of the window evaluation consumes its results
+            bool part = true;
+            for (auto& cm : op.at("computed").arr) {
+               const ExprP e = stripCast(convert(cm.at("expression"), s));
+               part = part && (e->kind == Expr::CONST_INT || (e->kind == Expr::OP && e->name == "add" && stripCast(e->args[0])->kind == Expr::OP && stripCast(e->args[0])->name == "wbetween"));
+            }
+            if (!part) flushWindow(s);
+         }
          s.lastMapped.clear();
          for (auto& cm : op.at("computed").arr) {
             const std::string& name = cm.at("computed").s("displayName");
             ExprP e = convert(cm.at("expression"), s);
             s.lastMapped.push_back(name);
+            if (!s.winView.empty() && stripCast(e)->kind == Expr::OP && stripCast(e)->name == "add" && stripCast(stripCast(e)->args[0])->kind == Expr::OP &&
+                stripCast(stripCast(e)->args[0])->name == "wbetween" && stripCast(stripCast(e)->args[1])->kind == Expr::CONST_INT && stripCast(stripCast(e)->args[1])->i == 1) {
+               // rank = entries between the frame begin and the current row + 1 (arith.addi: emitter extension E7)
+               setFrame(s, stripCast(stripCast(e)->args[0])->i, 0, false);
+               Stream::WinFn f;
+               f.fn = "rank";
+               f.as = sanitize(name);
+               s.winFns.push_back(f);
+               s.cols[name] = mk(Expr::COL, f.as);
+               continue;
+            }
             if (!s.setState.empty()) { // the predicate / repeat count over the counters of INTERSECT / EXCEPT
                const std::string kind = classifySet(e);
                if (kind.empty()) throw Unsupported("expression over the counters of a set operation that is neither INTERSECT nor EXCEPT");
@@ -1568,6 +1782,18 @@ struct Translator {
          if (id.empty())
             for (auto& kv : states)
                if (kv.second == st) id = kv.first;
+         if (stateType == "SegmentTreeView" && kind == "lookup") { // the aggregates of the frame [keys[0], keys[1]] (the keys: emitter extension E8)
+            const J* keys = op.get("keys");
+            if (st->kind != State::SEGTREE || s.winView.empty() || !keys || keys->arr.size() != 2) throw Unsupported("segment-tree lookup without its frame references (emitter extension E8)");
+            auto b = s.cols.find(keys->arr[0].s("displayName")), e = s.cols.find(keys->arr[1].s("displayName"));
+            if (b == s.cols.end() || e == s.cols.end()) throw Unsupported("segment-tree lookup through undefined references");
+            setFrame(s, frameEnd(b->second), frameEnd(e->second), true);
+            states[id] = st;
+            s.winLookup = id;
+            s.cols[op.at("reference").s("displayName")] = wref("w:lookup");
+            c.streams[ref] = s;
+            return;
+         }
          if (!(stateType == "SimpleState" && kind == "lookup")) settle(s);
          if (stateType == "HashIndexedView" && kind == "lookup") {
             if (st->kind != State::HIV) throw Unsupported("lookup into a hash-indexed view that was not created from a buffer");
@@ -1595,6 +1821,22 @@ struct Translator {
       if (kind == "reduce") {
          Stream s = input(op, c);
          settle(s);
+         if (const J* mat = op.get("materialized")) { // WindowLowering with PARTITION BY: the reduce appends the tuple to its partition's buffer (emitter extension E9)
+            if (s.aggState.empty()) throw Unsupported("reduce without a preceding lookup into an aggregation state");
+            StateP st = states.at(s.aggState);
+            if (st->kind != State::UNKNOWN) throw Unsupported("two pipelines reduce into one state");
+            st->kind = State::BUFFER;
+            st->partPending = true;
+            for (auto& m : mat->arr) {
+               auto it = s.cols.find(m.at("column").s("displayName"));
+               if (it == s.cols.end()) throw Unsupported("materialize of an undefined column '" + m.at("column").s("displayName") + "'");
+               st->members[m.s("member")] = it->second;
+            }
+            s.aggState.clear();
+            st->in = s;
+            c.streams[ref] = s;
+            return;
+         }
          if (s.aggState.empty() && s.gjState.empty()) throw Unsupported("reduce without a preceding lookup into an aggregation state");
          const bool gj = s.aggState.empty();
          StateP st = states.at(gj ? s.gjState : s.aggState);

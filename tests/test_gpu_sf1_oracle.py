@@ -161,6 +161,18 @@ def test_pattern_dumps_match_numpy(world):
             total[n] += int(b.scaleb(2))
     assert run("groupjoin", {"supplier": sup, "nation": db.nation}) == [(k, n_name[k], per_nation[k], total[k]) for k in sorted(per_nation)]
 
+    # windows: rank / SUM / COUNT(*) over the suppliers in key order — a 3-row frame over all of them, and per nation from the partition start
+    order = sorted(range(len(s_key)), key=lambda i: s_key[i])
+    bal = [int(s_bal[i].scaleb(2)) for i in order]
+    want = [(s_key[i], min(p, 2) + 1, sum(bal[max(0, p - 2): p + 1]), min(p, 2) + 1) for p, i in enumerate(order)]
+    assert run("window", {"supplier": sup}) == want
+    seen, running, want = collections.Counter(), collections.Counter(), []
+    for p, i in enumerate(order):
+        seen[s_nat[i]] += 1
+        running[s_nat[i]] += bal[p]
+        want.append((s_key[i], seen[s_nat[i]], running[s_nat[i]], seen[s_nat[i]]))
+    assert run("window_part", {"supplier": sup}) == want
+
     left = [n for n, b in zip(c_nat, c_bal) if b > rich]
     right = [n for n, b in zip(s_nat, s_bal) if b > richest]
     assert right and set(left) - set(right) and set(left) & set(right)

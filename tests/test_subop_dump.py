@@ -274,7 +274,7 @@ def test_translated_plans_that_equal_the_hand_written_ones():
     assert [g for g in got if g[0] != "materialize"][:4] == [w for w in want if w[0] != "materialize"][:4]  # filter, build, semi probe, avg per part
 
 
-PATTERNS = ["mark", "right_outer", "groupjoin", "union_all", "union", "intersect", "except", "intersect_all", "except_all"]  # tools/write_subop_dumps_patterns.py
+PATTERNS = ["mark", "right_outer", "groupjoin", "window", "window_part", "union_all", "union", "intersect", "except", "intersect_all", "except_all"]  # tools/write_subop_dumps_patterns.py
 
 
 def pattern_steps(name):
@@ -318,7 +318,22 @@ def test_group_join():
     assert st[4]["keys"] == ["s_nationkey", "n_name"] and [a["fn"] for a in st[4]["aggs"]] == ["count_star", "sum"]
 
 
-@pytest.mark.parametrize("kind", PATTERNS[3:])
+def test_window_evaluation_over_continuous_views():
+    """WindowLowering (:2193-2553): sorted view → continuous view [→ segment tree]; scan_ref + gather, begin / end references, offset_reference_by
+    for a bounded frame end, entries_between + 1 = rank, a segment-tree lookup over the frame's references + gather = the aggregates → ONE window step;
+    with PARTITION BY the buffers are the values of a map and the evaluation runs inside a nested_map over the buffer column"""
+    st = pattern_steps("window")
+    w = [s for s in st if s["op"] == "window"][0]
+    assert "partition_by" not in w and w["order_by"] == ["s_suppkey"] and (w["frame_from"], w["frame_to"]) == (-2, 0)
+    assert [(f["fn"], f.get("col")) for f in w["fns"]] == [("rank", None), ("sum", "s_acctbal"), ("count_star", None)]
+    st = pattern_steps("window_part")
+    assert [s["op"] for s in st] == ["window", "sort", "materialize"]
+    w = st[0]
+    assert w["in"] == "supplier" and w["partition_by"] == ["s_nationkey"] and w["order_by"] == ["s_suppkey"] and (w["frame_from"], w["frame_to"]) == ("unbounded_preceding", 0)
+    assert st[2]["cols"] == ["s_suppkey"] + [f["as"] for f in w["fns"]]
+
+
+@pytest.mark.parametrize("kind", PATTERNS[5:])
 def test_set_operations(kind):
     """UnionAllLowering (map both inputs + union), UnionDistinctLowering (both inputs lookup_or_insert into one key-only map),
     CountingSetOperationLowering (two counters; a predicate or a repeat count over them, :622-915) → one set_op step"""

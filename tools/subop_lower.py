@@ -29,8 +29,9 @@ the form write_subop_dumps.py already uses):
   MaterializeLowering      :1762-1784 materialize(ResultTable)
 
 Emitter extensions (fields the tool does not print today): E1 " - " for db.sub, E4 sortBy / maxRows,
-E5 primaryKey, E6 combine_tuple — as in write_subop_dumps.py — and E7: arith.ori / arith.andi (the nullable MIN / MAX / SUM
-bodies, RelAlgToSubOp.cpp:1865-1870) printed like db.or / db.and instead of an "unknown" leaf."""
+E5 primaryKey, E6 combine_tuple — as in write_subop_dumps.py — and E7: arith.ori / andi / cmpi / subi / addi (the nullable MIN / MAX / SUM
+bodies, RelAlgToSubOp.cpp:1865-1870; the counters of INTERSECT / EXCEPT; the rank) printed like db.or / db.and / db.cmp / db.sub / db.add instead of an
+"unknown" leaf; E8: `aggregates` on create_segment_tree_view and `keys` on lookup; E9: `materialized` on the reduce that fills a window partition's buffer."""
 import collections
 
 import write_subop_dumps as W
@@ -616,6 +617,119 @@ class GroupJoin(Node):
         sp.op("filter", semantic="all_true", columns=[marker.j])
         sp.op("renaming", renamed=[{"new": r.j, "old": l.j} for l, r in self.keys])
         return sp
+
+
+I64_MIN, I64_MAX = -(1 << 63), (1 << 63) - 1
+
+
+class Window(Node):
+    """WindowLowering (:2193-2553).  Without PARTITION BY: materialize(Buffer) → create_sorted_view → create_continuous_view [→ create_segment_tree_view]
+    → scan_ref → gather → get_begin_reference → get_end_reference → [map const + offset_reference_by per bounded frame end] → rank: entries_between +
+    map(+ 1); aggregates: lookup(SegmentTreeView, keys = the frame's references) + gather.  With PARTITION BY the buffer is the value of a map keyed by
+    the partition columns (lookup_or_insert + a reduce that materializes into it), the map is scanned and the chain above runs inside a nested_map over
+    the buffer column.  frame = (from, to) as row offsets, I64_MIN / I64_MAX = unbounded; fns = [(fn, argument column | None, result column)].
+    Emitter extensions: E4 (sortBy), E7 (arith.addi of the rank), E8 (`aggregates` of create_segment_tree_view, `keys` of its lookup), E9 (`materialized` of the
+    reduce that fills a partition's buffer: the region is printed as an unknown expression today)."""
+    def __init__(self, child, partition_by, order_by, frame, fns):
+        self.child, self.partition_by, self.order_by, self.frame, self.fns = child, list(partition_by), list(order_by), frame, list(fns)
+
+    def avail(self): return self.child.avail() | {o.name for _, _, o in self.fns}
+
+    def lower(self, cx, required):
+        outs = {o.name for _, _, o in self.fns}
+        need = (set(required) - outs) | {c.name for c in self.partition_by} | {c.name for c, _ in self.order_by} | {a.name for _, a, _ in self.fns if a is not None}
+        p = self.child.lower(cx, need & self.child.avail())
+        pkeys = {c.name for c in self.partition_by}
+        names = sorted(need - pkeys)
+        tag = cx.scope("w")
+        members = {n: "%s$%s" % (n.replace("::", "_"), tag) for n in names}
+        colmap = [{"member": members[n], "column": column(n, TYPE_OF.get(n, "?"))} for n in names]
+        if not self.partition_by:
+            s_buf, ty = cx.state("generic_create", "Buffer[...]")
+            p.op("materialize", accesses=[p.state_arg(s_buf, ty)], stateType="Buffer", mapping=colmap)
+            p.close()
+            ep = Pipe(cx)
+            return self._evaluate(cx, ep, ep.ops, ep.state_arg(s_buf, ty), members, colmap, None)
+        s_map, _ = cx.state("generic_create")
+        ref = cx.col("lookup", "ref", "?")
+        p.op("lookup_or_insert", accesses=[p.state_arg(s_map)], stateType="HashMap", reference=ref.j)
+        p.op("reduce", reference=ref.j, updated=[{"member": "buffer$0", "expression": unknown()}], materialized=colmap)  # EXT E9
+        p.close()
+        sp = Pipe(cx)
+        buf = cx.col("window", "buffer", "?")
+        sp.op("scan", source=True, accesses=[sp.state_arg(s_map)], mapping=[{"member": "keyval$%d" % i, "column": k.j} for i, k in enumerate(self.partition_by)] + [{"member": "buffer$0", "column": buf.j}])
+        body = []
+        outer = sp.last
+        access = {"type": "nested_map_arg", "column": buf.j, "id": "pending"}
+        self._evaluate(cx, sp, body, access, members, colmap, body)
+        nm = sp.raw("nested_map", [outer], inputs=[buf.j], subops=body)
+        access["id"] = nm["ref"] + "_0"
+        sp.ops.append(nm)
+        sp.last = nm["ref"]
+        return sp
+
+    def _evaluate(self, cx, p, ops, buffer_access, members, colmap, body):
+        """the evaluation over one (partition's) buffer; `ops` collects the sub-operators (the step's own list, or a nested_map body)"""
+        def state(kind, accesses, **fields):  # a view: inside a body an ordinary sub-operator, otherwise its own execution step
+            if body is not None:
+                o = p.raw(kind, accesses=accesses, **fields)
+                ops.append(o)
+                return node(o["ref"])
+            o = cx.d.subop(kind, accesses=[arg(0)], **fields)
+            step = cx.d.step([o], inputs=[("?", accesses[0]["_step"], 0)], results=[("?", o["ref"], 0)])
+            return {"_step": step}
+
+        def acc(a):  # how the evaluating pipeline names a view
+            return a if body is not None else p.state_arg(a["_step"])
+
+        if body is None:
+            buffer_access = {"_step": p.inputs[buffer_access["argnr"]][1]}
+        view = buffer_access
+        if self.order_by:
+            view = state("create_sorted_view", [view], sortBy=[{"member": members[c.name], "direction": dr} for c, dr in self.order_by])  # EXT E4
+        cv = state("create_continuous_view", [view])
+        frm, to = self.frame
+        aggs = [(fn, a, o) for fn, a, o in self.fns if fn != "rank"]
+        stv = None
+        if aggs:
+            stv = state("create_segment_tree_view", [cv], aggregates=[{"member": "aggrVal$%d" % i, "fn": fn, "source": members[a.name] if a is not None else ""} for i, (fn, a, _) in enumerate(aggs)])  # EXT E8
+        chain = []
+
+        def op(kind, source=False, **fields):
+            o = p.raw(kind, [] if source or not chain else [chain[-1]["ref"]], **fields)
+            chain.append(o)
+            ops.append(o)
+            return o
+        cur, begin, end = cx.col("scan", "ref", "?"), cx.col("view", "begin", "?"), cx.col("view", "end", "?")
+        op("scan_ref", source=True, accesses=[acc(cv)], stateType="ContinuousView", reference=cur.j)
+        op("gather", reference=cur.j, mapping=colmap)
+        op("get_begin_reference", accesses=[acc(cv)], reference=begin.j)
+        op("get_end_reference", accesses=[acc(cv)], reference=end.j)
+
+        def frame_ref(k, name):
+            if k == I64_MIN:
+                return begin
+            if k == I64_MAX:
+                return end
+            if k == 0:
+                return cur
+            iv, nr = cx.col("map", "ival", "index"), cx.col("frame", name, "?")
+            op("map", computed=[{"computed": iv.j, "expression": const(k, "index")}])
+            op("offset_reference_by", reference=cur.j, offset=iv.j, newRef=nr.j)
+            return nr
+        fb, fe = frame_ref(frm, "from"), frame_ref(to, "to")
+        for fn, a, o in self.fns:
+            if fn == "rank":
+                between = cx.col("window", "entries_between", "index")
+                op("entries_between", leftRef=fb.j, rightRef=cur.j, between=between.j)
+                op("map", computed=[{"computed": o.j, "expression": add(between.j, const(1, "index"))}])  # EXT E7
+        if aggs:
+            lref = cx.col("lookup", "ref", "?")
+            op("lookup", accesses=[acc(stv)], stateType="SegmentTreeView", reference=lref.j, keys=[fb.j, fe.j])  # EXT E8
+            op("gather", reference=lref.j, mapping=[{"member": "aggrVal$%d" % i, "column": o.j} for i, (_, _, o) in enumerate(aggs)])
+        if body is None:
+            p.last = chain[-1]["ref"]
+        return p
 
 
 def result(cx, child, outs):

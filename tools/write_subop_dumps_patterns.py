@@ -4,9 +4,10 @@
   pat_mark         MarkJoinLowering (:1376-1408): suppliers whose nation is in region 1 OR whose balance exceeds 9000 — the mark is a value
   pat_right_outer  OuterJoinLowering with reverseSides (:1511-1525): every nation with the number of its rich suppliers (0 when none)
   pat_groupjoin    GroupJoinLowering (:2682-2950), inner: per nation with a rich supplier its name, their number and total balance
+  pat_window[_part] WindowLowering (:2193-2553): rank + SUM + COUNT(*) over the suppliers by key, over a 3-row frame / per nation from the partition start
   pat_<set op>     UnionAll / UnionDistinct / CountingSetOperation lowerings (:622-915) over the nation keys of rich customers (balance > 9000) / the richest suppliers (> 9990)
 Writes tests/golden/subop_pat_*.json."""
-from subop_lower import Aggregate, C, Cx, GroupJoin, Join, Select, SetOp, Sort, Table, dec, eq, gt, or_, result, const
+from subop_lower import I64_MIN, Aggregate, C, Cx, GroupJoin, Join, Select, SetOp, Sort, Table, Window, dec, eq, gt, or_, result, const
 
 RICH = dec("9000.00", 12, 2)
 
@@ -46,11 +47,24 @@ def groupjoin():
     return result(cx, Sort(gj, [(s["s_nationkey"], "asc")]), [("s_nationkey", s["s_nationkey"]), ("n_name", n["n_name"]), ("suppliers", cnt), ("balance", tot)])
 
 
+def window(partitioned):
+    """rank and running / moving aggregates over the suppliers ordered by their key: per nation with an unbounded-preceding frame, or over all of them
+    with ROWS BETWEEN 2 PRECEDING AND CURRENT ROW"""
+    cx = Cx("pat_window_part" if partitioned else "pat_window")
+    s = Table("supplier")
+    rank, total, cnt = C("win0::rank", "int64"), C("win0::balance", "nullable(decimal(38,2))"), C("win0::rows", "int64")
+    w = Window(s, [s["s_nationkey"]] if partitioned else [], [(s["s_suppkey"], "asc")], (I64_MIN, 0) if partitioned else (-2, 0),
+               [("rank", None, rank), ("sum", s["s_acctbal"], total), ("count_star", None, cnt)])
+    return result(cx, Sort(w, [(s["s_suppkey"], "asc")]), [("s_suppkey", s["s_suppkey"]), ("rank", rank), ("balance", total), ("rows", cnt)])
+
+
 SET_KINDS = ("union_all", "union", "intersect", "except", "intersect_all", "except_all")
 
 if __name__ == "__main__":
     print(mark())
     print(right_outer())
     print(groupjoin())
+    print(window(False))
+    print(window(True))
     for kind in SET_KINDS:
         print(set_op(kind))
