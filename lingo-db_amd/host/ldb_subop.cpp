@@ -75,7 +75,7 @@ std::string exprJson(const ExprP& e0) { // the plan language of ldb_plan.cpp (co
       case Expr::OP: {
          if (e->name == "cmp") return "{\"cmp\": [" + quote(e->cmp) + ", " + exprJson(e->args[0]) + ", " + exprJson(e->args[1]) + "]}";
          if (e->name == "select") return "{\"case\": [" + exprJson(e->args[0]) + ", " + exprJson(e->args[1]) + ", " + exprJson(e->args[2]) + "]}";
-         if (e->name == "add" || e->name == "sub" || e->name == "mul" || e->name == "div" || e->name == "and" || e->name == "or" || e->name == "not" || e->name == "isnull") {
+         if (e->name == "add" || e->name == "sub" || e->name == "mul" || e->name == "div" || e->name == "and" || e->name == "or" || e->name == "not" || e->name == "isnull" || e->name == "coalesce") {
             std::string o = "{" + quote(e->name) + ": [";
             if ((e->name == "and" || e->name == "or" || e->name == "mul") && e->args.size() > 2) { // n-ary in the dump, flattened for mul, nested for and/or
                if (e->name == "mul") {
@@ -132,11 +132,12 @@ struct Stream {
    bool inJoinBody = false; // between the gather of a hash join and the end of its nested_map: filters are conjuncts of the join predicate
    std::vector<std::string> residual; // non-equality conjuncts relating the two sides ({"probe", "op", "build"})
    std::vector<ExprP> postJoin; // conjuncts of the join predicate that do not relate one probe with one build column: applied to the joined rows (inner joins only)
+   bool fullOuter = false; // the matches and the partner-less probe rows of a FULL outer join: united with the unmatched build rows after the probe pipeline
    bool antiBranch = false; // outer / single join: the branch of the probe rows WITHOUT a partner (filter none_true on the marker)
    std::string constState; // constant single join: the one-row state this stream looked up
    std::vector<std::string> lastMapped; // the columns the most recent map defined (UNION ALL maps both inputs to the result columns)
    // a window being evaluated on this stream: the continuous view it scans, the functions collected so far and their common frame
-   std::string winView, winLookup;
+   std::string winView, winLookup, winStatic; // winStatic: a plain scan of the view feeding the whole-partition aggregation of a frame unbounded on both sides
    struct WinFn {
       std::string fn, col, as;
    };
@@ -1186,7 +1187,7 @@ struct Translator {
             // group up and aggregated into it.  Emitted as: distinct left keys (+ stored columns) → unique hash table → the right input
             // probes it (inner) → the join predicate → group by the key with the aggregates.  The inner behaviour (marker member) keeps
             // exactly the groups this produces; the outer behaviour would need the unmatched left rows with default aggregates.
-            if (!st->gjInner) throw Unsupported("group join with outer behaviour (groups without a partner keep default aggregates)");
+            const bool outerGj = !st->gjInner; // outer behaviour: every left key comes out, groups without a partner with their default aggregates (count 0, the others NULL)
             // the left side: one row per key; the stored columns are functionally dependent on it and travel as further keys
             // (ANY over a string has no device form, a key has)
             std::map<std::string, std::string> storedName; // gjval member → display name
@@ -1274,7 +1275,7 @@ struct Translator {
             }
             for (auto& sp : st->gjStored) { // carried as keys (see above)
                auto sn = storedName.find(sp.first);
-               if (sn == storedName.end()) continue; // gathered for the predicate only
+               if (sn == storedName.end() || outerGj) continue; // gathered for the predicate only / taken from the left side below
                fin->in.cols[sn->second] = sp.second;
                mj += ", {\"member\": " + quote("keyval$" + sp.first) + ", \"column\": {\"displayName\": " + quote(sn->second) + "}}";
             }
@@ -1284,6 +1285,49 @@ struct Translator {
             JParser jp2(mj.c_str());
             const J fm = jp2.value();
             emitGroupBy(fin, fm);
+            if (outerGj) { // the left keys (+ stored columns) left-outer-joined with their groups; a count without a group is 0
+               std::vector<std::string> gk;
+               for (auto& km : keyMembers) gk.push_back(fin->aggOut.at(km));
+               Stream left = tmp->in;
+               flush(fin->in);
+               OutStep jb2;
+               jb2.op = "join_build";
+               jb2.out = fresh("h");
+               jb2.fields = {{"in", quote(fin->in.rel)}, {"keys", nameList(gk)}, {"unique", "true"}};
+               steps.push_back(jb2);
+               OutStep jp3;
+               jp3.op = "join_probe";
+               jp3.out = fresh("j");
+               jp3.fields = {{"ht", quote(jb2.out)}, {"in", quote(left.rel)}, {"keys", nameList(bk)}, {"kind", "\"left_outer\""}};
+               steps.push_back(jp3);
+               s = left;
+               s.rel = jp3.out;
+               s.names.insert(fin->in.names.begin(), fin->in.names.end());
+               for (auto& m : mapping.arr) {
+                  const std::string& name = m.at("column").s("displayName");
+                  if (isKeyMember(m.s("member"))) {
+                     s.cols[name] = tmp->members.at(m.s("member"));
+                  } else if (storedName.count(m.s("member"))) {
+                     auto it = st->aggOut.find("keyval$" + m.s("member"));
+                     if (it == st->aggOut.end()) throw Unsupported("group join scans a stored member the left input did not store");
+                     s.cols[name] = mk(Expr::COL, it->second);
+                  } else {
+                     auto it = fin->aggOut.find(m.s("member"));
+                     if (it == fin->aggOut.end()) throw Unsupported("group join scans member '" + m.s("member") + "' nothing aggregates");
+                     ExprP v = mk(Expr::COL, it->second);
+                     bool counts = false;
+                     for (auto& a : st->gjAggs) counts = counts || (a.member == m.s("member") && (a.fn == "count" || a.fn == "count_star"));
+                     if (counts) { // CountAggrFunc / CountStarAggrFunc start at 0 (createDefaultValue, :1812, :1826)
+                        ExprP zero = mk(Expr::CONST_INT), co = mk(Expr::OP, "coalesce");
+                        co->args = {v, zero};
+                        v = co;
+                     }
+                     s.cols[name] = v;
+                  }
+               }
+               c.streams[ref] = s;
+               return;
+            }
             s = fin->in;
             for (auto& m : mapping.arr) {
                auto it = fin->aggOut.find(storedName.count(m.s("member")) ? "keyval$" + m.s("member") : m.s("member"));
@@ -1341,6 +1385,14 @@ struct Translator {
          } else if (st->kind == State::MARKER) { // the per-row marker of anyTuple: the pending join continues on the probe stream
             s = st->in;
             for (auto& m : mapping.arr) s.cols[m.at("column").s("displayName")] = mk(Expr::MARKER);
+         } else if (st->kind == State::CONTVIEW) { // every row of the (partition's) view once: the static aggregation of an UNBOUNDED … UNBOUNDED frame (:2497-2499)
+            s = c.nested && !st->partCols.empty() ? *c.nested : st->in;
+            for (auto& m : mapping.arr) {
+               auto it = st->members.find(m.s("member"));
+               if (it == st->members.end()) throw Unsupported("scan of member '" + m.s("member") + "' that was never materialised");
+               s.cols[m.at("column").s("displayName")] = it->second;
+            }
+            s.winStatic = idOf(st, c);
          } else if (st->kind == State::BUFFER && st->partPending) { // the map keyed by the PARTITION BY columns whose value is the partition's buffer
             s = st->in;
             st->partCols.clear();
@@ -1489,6 +1541,22 @@ struct Translator {
                   if (it == view->members.end()) throw Unsupported("window aggregate over member '" + a->source + "' that was never materialised");
                   f.col = ensureCol(s, it->second, stripSuffix(a->source));
                }
+               f.as = sanitize(m.at("column").s("displayName"));
+               s.winFns.push_back(f);
+               s.cols[m.at("column").s("displayName")] = mk(Expr::COL, f.as);
+            }
+         } else if (r->second->name == "w:static") {
+            StateP agg = states.at(s.winLookup);
+            setFrame(s, INT64_MIN, INT64_MAX, true);
+            for (auto& m : op.at("mapping").arr) {
+               const AggSpec* a = nullptr;
+               for (auto& x : agg->aggs)
+                  if (x.member == m.s("member")) a = &x;
+               static const std::set<std::string> known = {"sum", "min", "max", "count", "count_star"};
+               if (!a || !known.count(a->fn)) throw Unsupported("window aggregate of member '" + m.s("member") + "'");
+               Stream::WinFn f;
+               f.fn = a->fn;
+               if (a->arg) f.col = ensureCol(s, a->arg, stripSuffix(a->member));
                f.as = sanitize(m.at("column").s("displayName"));
                s.winFns.push_back(f);
                s.cols[m.at("column").s("displayName")] = mk(Expr::COL, f.as);
@@ -1725,7 +1793,8 @@ struct Translator {
             // OuterJoinLowering with reverseSides (:1511-1525): the probing side's matches (the preserved BUILD side carries a flag they set) ∪ the
             // build rows whose flag stayed false, the probe side's columns NULL = the inner pairs followed by the unmatched build rows
             Stream s = *m;
-            s.rel = emitJoin(s, "right_outer");
+            s.rel = emitJoin(s, s.fullOuter ? "full_outer" : "right_outer"); // (FullOuterJoinLowering, :1446-1484: the body united the matches with the partner-less probe rows)
+            s.fullOuter = false;
             const Stream& bs = states.at(s.probeHiv)->source->in;
             s.names.insert(bs.names.begin(), bs.names.end());
             clearJoin(s);
@@ -1762,6 +1831,11 @@ struct Translator {
          Stream s = *m;
          for (auto& kv : n->cols)
             if (kv.second->kind == Expr::NULLV && !s.cols.count(kv.first)) throw Unsupported("outer join: column '" + kv.first + "' is NULL on one side and undefined on the other");
+         if (!states.at(s.probeHiv)->source->flagMember.empty()) { // the build entries carry a flag the matches set: a FULL outer join, emitted with its third part
+            s.fullOuter = true;
+            c.streams[ref] = s;
+            return;
+         }
          s.rel = emitJoin(s, "left_outer");
          {
             const Stream& bs = states.at(s.probeHiv)->source->in;
@@ -1782,6 +1856,14 @@ struct Translator {
          if (id.empty())
             for (auto& kv : states)
                if (kv.second == st) id = kv.first;
+         if (stateType == "SimpleState" && kind == "lookup" && st->kind == State::AGG && !s.winView.empty() && st->in.winStatic == s.winView) {
+            // the whole partition's aggregates, computed once by a scan of the view (frame UNBOUNDED PRECEDING … UNBOUNDED FOLLOWING)
+            states[id] = st;
+            s.winLookup = id;
+            s.cols[op.at("reference").s("displayName")] = wref("w:static");
+            c.streams[ref] = s;
+            return;
+         }
          if (stateType == "SegmentTreeView" && kind == "lookup") { // the aggregates of the frame [keys[0], keys[1]] (the keys: emitter extension E8)
             const J* keys = op.get("keys");
             if (st->kind != State::SEGTREE || s.winView.empty() || !keys || keys->arr.size() != 2) throw Unsupported("segment-tree lookup without its frame references (emitter extension E8)");

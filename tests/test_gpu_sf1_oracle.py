@@ -173,6 +173,31 @@ def test_pattern_dumps_match_numpy(world):
         want.append((s_key[i], seen[s_nat[i]], running[s_nat[i]], seen[s_nat[i]]))
     assert run("window_part", {"supplier": sup}) == want
 
+    # … and with a frame unbounded on both sides (the reference aggregates the partition once into a simple state)
+    all_total, nat_total, nat_rows = sum(bal), collections.Counter(), collections.Counter(s_nat)
+    for p, i in enumerate(order):
+        nat_total[s_nat[i]] += bal[p]
+    assert run("window_total", {"supplier": sup}) == [(s_key[i], all_total, len(order)) for i in order]
+    assert run("window_total_part", {"supplier": sup}) == [(s_key[i], nat_total[s_nat[i]], nat_rows[s_nat[i]]) for i in order]
+
+    # full outer join: matches + suppliers of other nations + nations of the region without such a supplier, counted over the nullable columns
+    richest_s = [(k, n) for k, n, b in zip(s_key, s_nat, s_bal) if b > richest]
+    region2 = {k for k, r in zip(n_key, n_reg) if r == 2}
+    matches = [(k, n) for k, n in richest_s if n in region2]
+    lonely_s = [(k, n) for k, n in richest_s if n not in region2]
+    lonely_n = [n for n in region2 if n not in {x for _, x in richest_s}]
+    assert matches and lonely_s and lonely_n
+    assert run("full_outer", {"supplier": sup, "nation": db.nation}) == [(len(matches) + len(lonely_s) + len(lonely_n), len(matches) + len(lonely_s), len(matches) + len(lonely_n),
+                                                                       sum(k for k, _ in matches + lonely_s), sum(n for _, n in matches) + sum(lonely_n))]
+
+    # group join with outer behaviour: every nation; 0 suppliers / NULL balance where no supplier is above 9990
+    per9990, tot9990 = collections.Counter(), collections.Counter()
+    for n, b in zip(s_nat, s_bal):
+        if b > richest:
+            per9990[n] += 1
+            tot9990[n] += int(b.scaleb(2))
+    assert run("groupjoin_outer", {"supplier": sup, "nation": db.nation}) == [(k, n_name[k], per9990.get(k, 0), tot9990[k] if k in tot9990 else None) for k in sorted(n_key)]
+
     left = [n for n, b in zip(c_nat, c_bal) if b > rich]
     right = [n for n, b in zip(s_nat, s_bal) if b > richest]
     assert right and set(left) - set(right) and set(left) & set(right)

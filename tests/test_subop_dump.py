@@ -274,7 +274,7 @@ def test_translated_plans_that_equal_the_hand_written_ones():
     assert [g for g in got if g[0] != "materialize"][:4] == [w for w in want if w[0] != "materialize"][:4]  # filter, build, semi probe, avg per part
 
 
-PATTERNS = ["mark", "right_outer", "groupjoin", "window", "window_part", "union_all", "union", "intersect", "except", "intersect_all", "except_all"]  # tools/write_subop_dumps_patterns.py
+PATTERNS = ["mark", "right_outer", "full_outer", "groupjoin", "groupjoin_outer", "window", "window_part", "window_total", "window_total_part", "union_all", "union", "intersect", "except", "intersect_all", "except_all"]  # tools/write_subop_dumps_patterns.py
 
 
 def pattern_steps(name):
@@ -333,7 +333,25 @@ def test_window_evaluation_over_continuous_views():
     assert st[2]["cols"] == ["s_suppkey"] + [f["as"] for f in w["fns"]]
 
 
-@pytest.mark.parametrize("kind", PATTERNS[5:])
+def test_full_outer_join_group_join_outer_behaviour_and_static_window_aggregates():
+    """FullOuterJoinLowering (:1446-1484): the body unites the matches with the partner-less probe rows, the step unites that with the unflagged
+    build rows → join_probe kind full_outer.  GroupJoinLowering with outer behaviour (no marker member): the groups left-outer-joined back to
+    the distinct left keys, counts coalesced to 0.  A window frame unbounded on both sides: a scan of the view aggregated into a simple state
+    that every row looks up → the same window step with frame unbounded_preceding … unbounded_following"""
+    st = pattern_steps("full_outer")
+    jp = [s for s in st if s["op"] == "join_probe"]
+    assert len(jp) == 1 and jp[0]["kind"] == "full_outer" and jp[0]["keys"] == ["s_nationkey"]
+    assert [a["fn"] for s in st if s["op"] == "groupby" for a in s["aggs"]] == ["count_star", "count", "count", "sum", "sum"]
+    st = pattern_steps("groupjoin_outer")
+    assert [s.get("kind") for s in st if s["op"] == "join_probe"] == ["inner", "left_outer"]
+    assert [s for s in st if s["op"] == "map"][0]["expr"] == {"coalesce": [[a["as"] for s2 in st if s2["op"] == "groupby" for a in s2["aggs"] if a["fn"] == "count_star"][-1], 0]}
+    for name, part in (("window_total", None), ("window_total_part", ["s_nationkey"])):
+        w = [s for s in pattern_steps(name) if s["op"] == "window"][0]
+        assert w.get("partition_by") == part and "order_by" not in w and (w["frame_from"], w["frame_to"]) == ("unbounded_preceding", "unbounded_following")
+        assert [(f["fn"], f.get("col")) for f in w["fns"]] == [("sum", "s_acctbal"), ("count_star", None)]
+
+
+@pytest.mark.parametrize("kind", PATTERNS[9:])
 def test_set_operations(kind):
     """UnionAllLowering (map both inputs + union), UnionDistinctLowering (both inputs lookup_or_insert into one key-only map),
     CountingSetOperationLowering (two counters; a predicate or a repeat count over them, :622-915) → one set_op step"""

@@ -228,6 +228,8 @@ class Join(Node):
             return self.build.avail() if self.reverse else self.probe.avail()
         if self.kind == "mark":
             return self.probe.avail() | {self.mark.name}
+        if self.kind == "full":  # every column of both sides comes out as its nullable copy
+            return {n.name for n, _ in self.mapping}
         if self.reverse:  # outer with reverseSides: the build side is preserved, the probe side's columns come out nullable
             return self.build.avail() | {n.name for n, _ in self.mapping}
         return self.probe.avail() | {n.name for n, _ in self.mapping}
@@ -242,7 +244,7 @@ class Join(Node):
             need |= {pk.name, bk.name}
         for e in self.residual:
             need |= refs(e)
-        flagged = self.reverse and self.kind in ("semi", "anti", "outer", "single")
+        flagged = (self.reverse and self.kind in ("semi", "anti", "outer", "single")) or self.kind == "full"
         # ---- build side: translateHJ / translateHJWithMarker
         bp = self.build.lower(cx, need & ba)
         s_buf, _ = cx.state("generic_create", "Buffer[...]")
@@ -309,6 +311,20 @@ class Join(Node):
                 nullable = pp.raw("map", [filtered], computed=[{"computed": nw.j, "expression": old.j} for nw, old in self.mapping])
                 body.append(nullable)
                 out = nullable["ref"]
+            if self.kind == "full":  # FullOuterJoinLowering (:1446-1484): the matches ∪ the probe rows without a partner, build side NULL
+                probe_side = [(nw, old) for nw, old in self.mapping if old.name in pa]
+                build_side = [(nw, old) for nw, old in self.mapping if old.name not in pa]
+                nullable = pp.raw("map", [filtered], computed=[{"computed": nw.j, "expression": old.j} for nw, old in self.mapping])
+                mk2 = cx.col("marker", "marker", "int1")
+                body.append(nullable)
+                m = self._any_tuple(pp, body, filtered, mk2)
+                f = pp.raw("filter", [m], semantic="all_false", columns=[mk2.j])
+                ct2 = pp.raw("combine_tuple", [f["ref"]])
+                keep = pp.raw("map", [ct2["ref"]], computed=[{"computed": nw.j, "expression": old.j} for nw, old in probe_side])
+                nulls = pp.raw("map", [keep["ref"]], computed=[{"computed": nw.j, "expression": null()} for nw, _ in build_side])
+                u = pp.raw("union", [nullable["ref"], nulls["ref"]])
+                body += [f, ct2, keep, nulls, u]
+                out = u["ref"]
         nm = pp.raw("nested_map", [lk["ref"]], inputs=[], subops=body)
         sl["accesses"][0]["id"] = nm["ref"] + "_0"
         pp.ops.append(nm)
@@ -327,6 +343,13 @@ class Join(Node):
         sb = pp.raw("scan", accesses=[pp.state_arg(s_buf, "Buffer[...]")],
                     mapping=[{"member": members[name], "column": column(name, types.get(name, "?"))} for name in payload] + [{"member": flag_member, "column": flag.j}])
         fb = pp.raw("filter", [sb["ref"]], semantic="all_false", columns=[flag.j])
+        if self.kind == "full":  # the unmatched build rows: their own columns as nullable copies, the probe side NULL
+            keep = pp.raw("map", [fb["ref"]], computed=[{"computed": nw.j, "expression": old.j} for nw, old in self.mapping if old.name not in pa])
+            nulls = pp.raw("map", [keep["ref"]], computed=[{"computed": nw.j, "expression": null()} for nw, old in self.mapping if old.name in pa])
+            u = pp.raw("union", [pp.last, nulls["ref"]])
+            pp.ops += [sb, fb, keep, nulls, u]
+            pp.last = u["ref"]
+            return pp
         nulls = pp.raw("map", [fb["ref"]], computed=[{"computed": nw.j, "expression": null()} for nw, _ in self.mapping])
         u = pp.raw("union", [pp.last, nulls["ref"]])
         pp.ops += [sb, fb, nulls, u]
@@ -575,8 +598,9 @@ class GroupJoin(Node):
     right input looks its group up (an optional reference), gathers the stored columns, takes the left key's name for its own key
     column (renaming), applies the predicate, marks the group and reduces the aggregates into it; the map is scanned, filtered on the
     marker and the right key's name is restored.  keys = [(left column, right column)], aggs = [(fn, right column | None, result column)]"""
-    def __init__(self, left, right, keys, aggs, stored=(), predicate=()):
+    def __init__(self, left, right, keys, aggs, stored=(), predicate=(), behavior="inner"):
         self.left, self.right, self.keys, self.aggs, self.stored, self.predicate = left, right, list(keys), list(aggs), list(stored), list(predicate)
+        self.inner = behavior == "inner"  # outer behaviour: no marker member — every left key comes out, with default aggregates when no tuple joined it
 
     def avail(self): return {r.name for _, r in self.keys} | {l.name for l, _ in self.keys} | {c.name for c in self.stored} | {o.name for _, _, o in self.aggs}
 
@@ -585,7 +609,7 @@ class GroupJoin(Node):
         lp = self.left.lower(cx, {l.name for l, _ in self.keys} | {c.name for c in self.stored})
         ref = cx.col("lookup", "ref", "?")
         lp.op("lookup_or_insert", accesses=[lp.state_arg(s_st)], stateType="HashMap", reference=ref.j)
-        members = ["gjvalmarker$0"] + ["gjval$%d" % k for k in range(len(self.stored))] + ["aggrval$%d" % i for i in range(len(self.aggs))]
+        members = (["gjvalmarker$0"] if self.inner else []) + ["gjval$%d" % k for k in range(len(self.stored))] + ["aggrval$%d" % i for i in range(len(self.aggs))]
         stored_m = {"gjval$%d" % k: c for k, c in enumerate(self.stored)}
         lp.op("reduce", reference=ref.j, updated=[{"member": m, "expression": stored_m[m].j if m in stored_m else member(m)} for m in members])  # stores the columns, keeps the rest
         lp.close()
@@ -600,21 +624,23 @@ class GroupJoin(Node):
             rp.op("gather", reference=ref2.j, mapping=[{"member": m, "column": c.j} for m, c in stored_m.items()])
         rp.op("renaming", renamed=[{"new": l.j, "old": r.j} for l, r in self.keys if l.name not in {c.name for c in self.stored}])
         selection(rp, self.predicate)
-        bv = cx.col("map", "boolval", "int1")
-        rp.op("map", computed=[{"computed": bv.j, "expression": const(True, "int1")}])
-        rp.op("scatter", reference=ref2.j, mapping=[{"member": "gjvalmarker$0", "column": bv.j}])
+        if self.inner:
+            bv = cx.col("map", "boolval", "int1")
+            rp.op("map", computed=[{"computed": bv.j, "expression": const(True, "int1")}])
+            rp.op("scatter", reference=ref2.j, mapping=[{"member": "gjvalmarker$0", "column": bv.j}])
         upd = []
         for i, (fn, a, _) in enumerate(self.aggs):
             m = "aggrval$%d" % i
             upd.append({"member": m, "expression": agg_body(fn, m, a.j if a is not None else None, fn in ("sum", "min", "max"))})
-        rp.op("reduce", reference=ref2.j, updated=[{"member": "gjvalmarker$0", "expression": member("gjvalmarker$0")}] + [{"member": m, "expression": member(m)} for m in stored_m] + upd)
+        rp.op("reduce", reference=ref2.j, updated=([{"member": "gjvalmarker$0", "expression": member("gjvalmarker$0")}] if self.inner else []) + [{"member": m, "expression": member(m)} for m in stored_m] + upd)
         rp.close()
         sp = Pipe(cx)
         marker = cx.col("groupjoin", "marker", "int1")
         sp.op("scan", source=True, accesses=[sp.state_arg(s_st)],
-              mapping=[{"member": "gjvalmarker$0", "column": marker.j}] + [{"member": m, "column": c.j} for m, c in stored_m.items()] +
+              mapping=([{"member": "gjvalmarker$0", "column": marker.j}] if self.inner else []) + [{"member": m, "column": c.j} for m, c in stored_m.items()] +
                       [{"member": "aggrval$%d" % i, "column": o.j} for i, (_, _, o) in enumerate(self.aggs)] + [{"member": "gjkeyval$%d" % i, "column": l.j} for i, (l, _) in enumerate(self.keys)])
-        sp.op("filter", semantic="all_true", columns=[marker.j])
+        if self.inner:
+            sp.op("filter", semantic="all_true", columns=[marker.j])
         sp.op("renaming", renamed=[{"new": r.j, "old": l.j} for l, r in self.keys])
         return sp
 
@@ -690,8 +716,26 @@ class Window(Node):
         cv = state("create_continuous_view", [view])
         frm, to = self.frame
         aggs = [(fn, a, o) for fn, a, o in self.fns if fn != "rank"]
-        stv = None
-        if aggs:
+        stv = static = None
+        if aggs and frm == I64_MIN and to == I64_MAX:  # the whole partition: aggregated once by a scan of the view into a simple state (:2497-2499), looked up by every row
+            upd = [{"member": "aggrVal$%d" % i, "expression": agg_body(fn, "aggrVal$%d" % i, a.j if a is not None else None, fn in ("sum", "min", "max"))} for i, (fn, a, _) in enumerate(aggs)]
+            aref = cx.col("lookup", "ref", "?")
+            if body is not None:
+                cs = p.raw("create_simple_state")
+                sc = p.raw("scan", accesses=[acc(cv)], mapping=colmap)
+                lk = p.raw("lookup", [sc["ref"]], accesses=[node(cs["ref"])], stateType="SimpleState", reference=aref.j)
+                rd = p.raw("reduce", [lk["ref"]], reference=aref.j, updated=upd)
+                ops.extend([cs, sc, lk, rd])
+                static = node(cs["ref"])
+            else:
+                s_cs, _ = cx.state("create_simple_state")
+                ap = Pipe(cx)
+                ap.op("scan", source=True, accesses=[ap.state_arg(cv["_step"])], mapping=colmap)
+                ap.op("lookup", accesses=[ap.state_arg(s_cs)], stateType="SimpleState", reference=aref.j)
+                ap.op("reduce", reference=aref.j, updated=upd)
+                ap.close()
+                static = {"_step": s_cs}
+        elif aggs:
             stv = state("create_segment_tree_view", [cv], aggregates=[{"member": "aggrVal$%d" % i, "fn": fn, "source": members[a.name] if a is not None else ""} for i, (fn, a, _) in enumerate(aggs)])  # EXT E8
         chain = []
 
@@ -723,7 +767,11 @@ class Window(Node):
                 between = cx.col("window", "entries_between", "index")
                 op("entries_between", leftRef=fb.j, rightRef=cur.j, between=between.j)
                 op("map", computed=[{"computed": o.j, "expression": add(between.j, const(1, "index"))}])  # EXT E7
-        if aggs:
+        if static is not None:
+            lref = cx.col("lookup", "ref", "?")
+            op("lookup", accesses=[acc(static)], stateType="SimpleState", reference=lref.j)
+            op("gather", reference=lref.j, mapping=[{"member": "aggrVal$%d" % i, "column": o.j} for i, (_, _, o) in enumerate(aggs)])
+        elif aggs:
             lref = cx.col("lookup", "ref", "?")
             op("lookup", accesses=[acc(stv)], stateType="SegmentTreeView", reference=lref.j, keys=[fb.j, fe.j])  # EXT E8
             op("gather", reference=lref.j, mapping=[{"member": "aggrVal$%d" % i, "column": o.j} for i, (_, _, o) in enumerate(aggs)])
