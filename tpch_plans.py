@@ -454,17 +454,12 @@ def cpu_baseline(queries, sample_sf, runs="1+3", budget_s=100.0, ctx=None, narro
     return out
 
 
-def oracle_q6_at_scale(n_orders, n_parts=256, threads=None):
-    """TPC-H Q6 by the ORACLE over the bench's own scale (verdict item 9: a spot check where the conservation laws are not enough): the four
-    lineitem columns are generated on the host in `n_parts` slices of the same counter-based generator the device uses
-    (tests/tpch_data.host_table with part / n_parts), each slice runs the oracle's Q6 leg (oracle/tpch_legs.py: the C restatement of the reference's scan
-    + restrictions + key-less SUM), the partial sums add up in Python integers.  Slices run on a thread pool (the generator and the oracle are C
-    calls that release the GIL).  Returns (unscaled sum or None, seconds)."""
-    import concurrent.futures
+def _oracle_q6_slice(job):
+    """one slice of oracle_q6_at_scale (no device, no torch)"""
+    n_orders, part, n_parts = job
     import sys
-    import time
 
-    for sub in ("oracle", "tests"):
+    for sub in ("oracle", "tests", "lingo-db_amd"):
         path = os.path.join(ROOT, sub)
         if path not in sys.path:
             sys.path.insert(0, path)
@@ -472,16 +467,24 @@ def oracle_q6_at_scale(n_orders, n_parts=256, threads=None):
     import tpch_data as T
     import tpch_legs
 
+    leg = tpch_legs.Legs(n_orders, threads=1, queries=[6])
+    leg._tables[T.LINEITEM] = oracle_bind.HostTable(T.host_table(T.LINEITEM, n_orders, part=part, n_parts=n_parts, cols=tpch_legs.Legs.NEED[T.LINEITEM][6]))
+    (v,), = leg.q6()
+    return v
+
+
+def oracle_q6_at_scale(n_orders, n_parts=256, threads=None):
+    """TPC-H Q6 by the ORACLE over the bench's own scale (verdict item 9: a spot check where the conservation laws are not enough): the four
+    lineitem columns are generated on the host in `n_parts` slices of the same counter-based generator the device uses
+    (tests/tpch_data.host_table with part / n_parts), each slice runs the oracle's Q6 leg (oracle/tpch_legs.py: the C restatement of the reference's scan
+    + restrictions + key-less SUM), the partial sums add up in Python integers.  Slices run on a thread pool (the generator and the oracle are C calls
+    that release the GIL: 19 M rows/s on 8 cores here, SF100 = 600 M rows).  Returns (unscaled sum or None, seconds)."""
+    import concurrent.futures
+    import time
+
     t0 = time.time()
-    threads = threads or min(64, os.cpu_count() or 8)
-
-    def one(part):
-        leg = tpch_legs.Legs(n_orders, threads=1, queries=[6])
-        leg._tables[T.LINEITEM] = oracle_bind.HostTable(T.host_table(T.LINEITEM, n_orders, part=part, n_parts=n_parts, cols=tpch_legs.Legs.NEED[T.LINEITEM][6]))
-        (v,), = leg.q6()
-        return v
-
-    with concurrent.futures.ThreadPoolExecutor(threads) as pool:
-        parts = list(pool.map(one, range(n_parts)))
+    workers = threads or min(64, os.cpu_count() or 8)
+    with concurrent.futures.ThreadPoolExecutor(workers) as pool:
+        parts = list(pool.map(_oracle_q6_slice, [(n_orders, part, n_parts) for part in range(n_parts)]))
     vals = [v for v in parts if v is not None]
     return (sum(vals) if vals else None), time.time() - t0
