@@ -361,6 +361,50 @@ def test_set_operations(kind):
     assert [s["op"] for s in st] == ["filter", "filter", "set_op", "sort", "materialize"]
 
 
+def test_pattern_variants_without_a_device_form_are_reported():
+    """what the matcher does not accept is named per execution step, never mistranslated: a segment tree without its aggregates (emitter
+    extension E8 missing), a window whose rank and aggregates use different frames, a union of two streams that are not the halves of a join"""
+    def walk(ops):
+        for o in ops:
+            yield o
+            yield from walk(o.get("subops", []))
+
+    def load(name):
+        with open(os.path.join(GOLD, "subop_pat_%s.json" % name)) as f:
+            return json.load(f)
+
+    d = load("window")
+    for step in d:
+        for o in walk(step.get("subops", [])):
+            if o.get("subop") == "create_segment_tree_view":
+                del o["aggregates"]
+    with pytest.raises(capi.LdbError) as e:
+        api.translate_subop_dump(json.dumps(d))
+    assert e.value.status == capi.LDB_ERR_UNSUPPORTED and "E8" in str(e.value)
+
+    d = load("window")  # the rank counts from the partition start, the aggregates keep ROWS 2 PRECEDING
+    begin = None
+    for step in d:
+        for o in walk(step.get("subops", [])):
+            if o.get("subop") == "get_begin_reference":
+                begin = o["reference"]
+            if o.get("subop") == "entries_between":
+                o["leftRef"] = begin
+    with pytest.raises(capi.LdbError) as e:
+        api.translate_subop_dump(json.dumps(d))
+    assert e.value.status == capi.LDB_ERR_UNSUPPORTED and "different frames" in str(e.value)
+
+    d = load("union_all")  # drop one of the two maps: the inputs no longer define the same result columns
+    for step in d:
+        ops = step.get("subops", [])
+        maps = [o for o in ops if o.get("subop") == "map"]
+        if len(maps) == 2 and any(o.get("subop") == "union" for o in ops):
+            maps[1]["computed"][0]["computed"]["displayName"] = "other::column"
+    with pytest.raises(capi.LdbError) as e:
+        api.translate_subop_dump(json.dumps(d))
+    assert e.value.status == capi.LDB_ERR_UNSUPPORTED and "union" in str(e.value)
+
+
 def test_dumps_are_what_the_generator_writes(tmp_path):
     import subprocess
     import sys
