@@ -11,7 +11,7 @@
 //   get_external + scan                         → a base table relation; meta.filters → restrictions
 //   map                                         → column bindings (expressions are inlined into their consumers)
 //   filter all_true                             → restrictions / the equality of a hash join
-//   lookup(SimpleState) | lookup_or_insert(HashMap) + reduce [+ create_thread_local / get_local / merge]
+//   lookup(SimpleState) | lookup_or_insert(HashMap) + reduce [+ create_thread_local / merge]
 //                                               → groupby (sum / count / count(*) / min / max; sum ÷ count → avg)
 //   materialize(Buffer) + create_hash_indexed_view + lookup(HashIndexedView) + nested_map{scan_list, gather,
 //     combine_tuple, map, filter}                → join_build + join_probe (inner)
@@ -20,9 +20,11 @@
 //
 // Everything else is reported per execution step as "cpu" with the reason (the reference would run such a step on
 // its CPU backend; there is none here, so the translation as a whole fails with LDB_ERR_UNSUPPORTED and the report
-// says which step).  The dump loses a few facts a backend needs; the consumer relies on five small emitter
-// additions, listed in INTEGRATION.md §1b and in tools/write_subop_dumps.py (E1 " - " for db.sub, E3 get_local,
-// E4 sortBy/maxRows on create_sorted_view/create_heap, E5 primaryKey, E6 combine_tuple).  Group-by keys need no
+// says which step).  The dump loses a few facts a backend needs; the consumer relies on small emitter additions, listed in
+// INTEGRATION.md §1b and in tools/write_subop_dumps.py / tools/subop_lower.py (E1 " - " for db.sub, E4 sortBy / maxRows on
+// create_sorted_view / create_heap, E5 primaryKey, E6 combine_tuple, E7 the arith.* ops of the nullable aggregate bodies / set-operation
+// counters / rank, E8 the aggregates of create_segment_tree_view and the keys of lookup, E9 the materialize inside the reduce that
+// fills a window partition's buffer).  Group-by keys need no
 // extension: performAggregation names key members "keyval$n" and the later scan of the map re-defines the SAME
 // columns (RelAlgToSubOp.cpp:2158-2166, test/lit/RelAlg/lowering.mlir:37), so keys are read off that scan.
 #include "ldb_host.hpp"
@@ -1063,7 +1065,7 @@ struct Translator {
          if (s->maxRows < 0 || s->sortBy.empty()) throw Unsupported("create_heap without maxRows / sortBy (emitter extension E4)");
          return;
       }
-      if (kind == "get_local" || kind == "merge") { // thread-local plumbing of the parallelize pass: one state on a GPU
+      if (kind == "merge") { // the thread-local instances merged into one state: there is one state on a GPU (a thread-local step input is the state itself)
          c.local[ref + "#0"] = resolve(op.at("accesses").arr.at(0), c);
          return;
       }

@@ -15,7 +15,8 @@ fields; the sub-operator sequences follow the reference's lowerings:
 Fields the tool does NOT emit today and a GPU backend needs (INTEGRATION.md §1b lists the one-line emitter
 changes); they are marked EXT below:
   E1  db.sub is printed with the separator " + " (mlir-subop-to-json.cpp:334) — dumps here use " - "
-  E3  subop.get_local (the thread-local accessor the parallelize pass inserts) has no case → {"subop": "get_local"}
+  (E3 is withdrawn: earlier rounds modelled the thread-local access as a `get_local` sub-operator; the reference has none — a step input is
+      marked thread-local on the execution step itself, SubOpToControlFlow.cpp:4367-4378 — and a GPU consumer does not need the mark)
   E4  create_sorted_view / create_heap carry no sort criteria → "sortBy": [{"member", "direction"}], "maxRows"
   E5  get_external meta has no key information → optional "primaryKey": [identifiers]
   E6  subop.combine_tuple has no case → {"subop": "combine_tuple"}
@@ -159,14 +160,15 @@ def q6():
     scan = d.subop("scan", accesses=[arg(0)], mapping=scan_mapping("lineitem", ["l_extendedprice", "l_discount"]))
     prod = column("map0::tmp_attr0", "decimal(24,4)")
     mp = d.subop("map", streams=[scan["ref"]], computed=[{"computed": prod, "expression": mul(col("lineitem", "l_extendedprice"), col("lineitem", "l_discount"))}])
-    loc = d.subop("get_local", accesses=[arg(1)])  # EXT E3
     ref = column("lookup0::ref", "?")
-    lk = d.subop("lookup", streams=[mp["ref"]], accesses=[node(loc["ref"])], stateType="SimpleState", reference=ref)
+    # the step's second input is the thread-local state: handleExecutionStepCPU hands the block argument the calling thread's instance
+    # (step.getIsThreadLocal(), SubOpToControlFlow.cpp:4367-4378) — there is no sub-operator for that, the lookup accesses the argument
+    lk = d.subop("lookup", streams=[mp["ref"]], accesses=[arg(1)], stateType="SimpleState", reference=ref)
     # SumAggrFunc::aggregate with a nullable state and a non-nullable argument (RelAlgToSubOp.cpp:1996-2002):
     # select(isnull(state), arg, nullable_get_val(state) + arg); the tool has no case for nullable_get_val
     rd = d.subop("reduce", streams=[lk["ref"]], reference=ref,
                  updated=[{"member": "aggrVal$0", "expression": select(isnull(member("aggrVal$0")), prod, add(unknown(), prod))}])
-    d.step([scan, mp, loc, lk, rd], inputs=[(tty, t, 0), ("?", s_tl, 0)])
+    d.step([scan, mp, lk, rd], inputs=[(tty, t, 0), ("?", s_tl, 0)])
     mg = d.subop("merge", accesses=[arg(0)], stateType="SimpleState")
     s_mg = d.step([mg], inputs=[("?", s_tl, 0)], results=[("?", mg["ref"], 0)])
     rt = d.subop("generic_create")
@@ -192,9 +194,8 @@ def q1():
     mp = d.subop("map", streams=[scan["ref"]], computed=[
         {"computed": disc, "expression": mul(L("l_extendedprice"), sub(one, L("l_discount")))},
         {"computed": charge, "expression": mul(mul(L("l_extendedprice"), sub(one, L("l_discount"))), add(one, L("l_tax")))}])
-    loc = d.subop("get_local", accesses=[arg(1)])
     ref = column("lookup0::ref", "?")
-    lk = d.subop("lookup_or_insert", streams=[mp["ref"]], accesses=[node(loc["ref"])], stateType="HashMap", reference=ref)
+    lk = d.subop("lookup_or_insert", streams=[mp["ref"]], accesses=[arg(1)], stateType="HashMap", reference=ref)
     # the frontend splits avg(x) into sum(x) / count(x) (sql_analyzer); CountAggrFunc over a non-nullable
     # argument and CountStarAggrFunc are both state + 1 (RelAlgToSubOp.cpp:1815-1837)
     srcs = [L("l_quantity"), L("l_extendedprice"), disc, charge, L("l_quantity"), None, L("l_extendedprice"), None, L("l_discount"), None, None]
@@ -203,7 +204,7 @@ def q1():
         m = "aggrVal$%d" % i
         upd.append({"member": m, "expression": add(member(m), s if s is not None else const(1, "int64"))})
     rd = d.subop("reduce", streams=[lk["ref"]], reference=ref, updated=upd)
-    d.step([scan, mp, loc, lk, rd], inputs=[(tty, t, 0), ("?", s_tl, 0)])
+    d.step([scan, mp, lk, rd], inputs=[(tty, t, 0), ("?", s_tl, 0)])
     mg = d.subop("merge", accesses=[arg(0)], stateType="HashMap")
     s_mg = d.step([mg], inputs=[("?", s_tl, 0)], results=[("?", mg["ref"], 0)])
     buf = d.subop("generic_create")
