@@ -9,14 +9,25 @@
 // the C-ABI's operator-level steps (the step list ldb_plan.cpp interprets):
 //
 //   get_external + scan                         → a base table relation; meta.filters → restrictions
-//   map                                         → column bindings (expressions are inlined into their consumers)
-//   filter all_true                             → restrictions / the equality of a hash join
+//   map                                         → column bindings (expressions are inlined into their consumers; runtime calls
+//                                                 ExtractYearFromDate / Substring → map fn, ConstLike → LIKE restrictions)
+//   filter all_true                             → restrictions (conjunctions, IN, LIKE, DNF → filter_dnf, anything else → a computed
+//                                                 boolean column + `= true`) / the conjuncts of a hash join (keys, residuals, post-join filters)
 //   lookup(SimpleState) | lookup_or_insert(HashMap) + reduce [+ create_thread_local / merge]
-//                                               → groupby (sum / count / count(*) / min / max; sum ÷ count → avg)
+//                                               → groupby (sum / count / count(*) / min / max / any, the nullable bodies; sum ÷ count → avg;
+//                                                 an empty reduce → distinct)
 //   materialize(Buffer) + create_hash_indexed_view + lookup(HashIndexedView) + nested_map{scan_list, gather,
-//     combine_tuple, map, filter}                → join_build + join_probe (inner)
+//     combine_tuple, map, filter …}             → join_build + join_probe: inner; anyTuple + marker filter → semi / anti, read as a value →
+//                                                 mark; flag member + scatter → semi_build / anti_build; + null / as-nullable maps + union →
+//                                                 left_outer, right_outer (reverseSides), full_outer
+//   create_simple_state + scatter / lookup + gather → the cross product with a one-row side (constant single join)
+//   lookup(HashMap) + unwrap_optional_ref + … + reduce into another input's map → group join
+//   two inputs counting into one map / two maps + union → set_op (UNION [ALL], INTERSECT [ALL], EXCEPT [ALL])
+//   sorted / continuous / segment-tree views + scan_ref, frame references, entries_between, lookup(SegmentTreeView) → window
+//   a buffer scanned inside a nested_map body   → join_nl
 //   materialize(Buffer) + create_sorted_view    → sort          materialize(Heap) + scan → topk
 //   materialize(ResultTable)                    → materialize (the query result)
+// (INTEGRATION.md §1b has the table with the lowering each row comes from.)
 //
 // Everything else is reported per execution step as "cpu" with the reason (the reference would run such a step on
 // its CPU backend; there is none here, so the translation as a whole fails with LDB_ERR_UNSUPPORTED and the report
