@@ -226,3 +226,20 @@ def test_oracle_q6_in_slices_equals_the_whole_table():
     whole = tpch_legs.Legs(n_orders, queries=[6]).q6()
     got, secs = tpch_plans.oracle_q6_at_scale(n_orders, n_parts=7, threads=3)
     assert whole == [(got,)] and got is not None and got > 0 and secs >= 0
+
+
+def test_set_op_and_window_steps_are_checked():
+    """the steps the dump consumer emits for set operations and windows (round 4): both inputs of a set_op must exist and it needs its kind and the
+    two column lists; a window needs its functions"""
+    ok = ('{"steps": [{"op": "set_op", "kind": "except_all", "left": "t", "left_cols": ["a"], "right": "u", "right_cols": ["b"], "out": "s"},'
+          ' {"op": "window", "in": "s", "partition_by": ["a"], "order_by": [{"col": "a", "desc": true}], "frame_from": "unbounded_preceding", "frame_to": 0,'
+          ' "fns": [{"fn": "rank", "as": "r"}, {"fn": "sum", "col": "a", "as": "x"}], "out": "w"},'
+          ' {"op": "join_build", "in": "u", "keys": ["b"], "out": "h"}, {"op": "join_probe", "ht": "h", "in": "w", "keys": ["a"], "kind": "mark", "mark_as": "m", "out": "j"}], "result": "j"}')
+    assert _check(ok, ["t", "u"])[0] == 0
+    for text, needle in (
+            ('{"steps": [{"op": "set_op", "kind": "union", "left": "t", "left_cols": ["a"], "right": "nope", "right_cols": ["b"], "out": "s"}], "result": "s"}', "before it exists"),
+            ('{"steps": [{"op": "set_op", "left": "t", "left_cols": ["a"], "right": "u", "right_cols": ["b"], "out": "s"}], "result": "s"}', "kind"),
+            ('{"steps": [{"op": "set_op", "kind": "union", "left": "t", "right": "u", "right_cols": ["b"], "out": "s"}], "result": "s"}', "left_cols"),
+            ('{"steps": [{"op": "window", "in": "t", "order_by": ["a"], "out": "w"}], "result": "w"}', "fns")):
+        st, err = _check(text, ["t", "u"])
+        assert st != 0 and needle in err, (text, err)
