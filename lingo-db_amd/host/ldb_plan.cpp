@@ -58,6 +58,9 @@ struct Interp {
    std::vector<std::unique_ptr<Restrictions>> keepRestr; // constant storage the descriptors point into
    std::vector<std::unique_ptr<std::string>> keepStr;
    std::string result;
+   // a prepared plan remembers how many groups each group-by WITHOUT an estimate produced (by its `out` name): the next execution sizes the
+   // table from that instead of paying an overflowing attempt again (plans translated from the reference's dumps carry no cardinalities)
+   std::map<std::string, int64_t>* groupsSeen = nullptr;
    explicit Interp(ldb_ctx* c) : ctx(c) {}
    ~Interp() {
       // hash tables first (they reference relations), then relations, then tables
@@ -822,8 +825,14 @@ struct Interp {
             }
          }
          if (st.sOr("est_groups_from", "") == "rows") est = std::max<int64_t>(1, ldb_gpu_rel_rows(ctx, in));
+         const bool learn = est == 0 && groupsSeen && !keys.empty();
+         if (learn) {
+            auto seen = groupsSeen->find(st.s("out"));
+            if (seen != groupsSeen->end()) est = std::max<int64_t>(1, seen->second);
+         }
          ldb_table* out;
          check(ldb_gpu_groupby(ctx, in, ps.data(), (int32_t) ps.size(), keys.data(), (int32_t) keys.size(), aggs.data(), (int32_t) aggs.size(), est, &out), "groupby");
+         if (learn) (*groupsSeen)[st.s("out")] = ldb_gpu_table_rows(out);
          for (size_t a = 0; a < names.size(); a++)
             if (!names[a].empty()) ldb_gpu_table_rename_col(out, (int32_t) (keys.size() + a), names[a].c_str());
          if (const J* kn = st.get("key_names"))
@@ -1165,15 +1174,18 @@ struct ldb_plan {
    J doc;
    ldb_trace* trace = nullptr;
    std::vector<uint64_t> key; // what the trace was recorded under: per input (stamp, rows), option epoch, exchange or not
+   std::map<std::string, int64_t> groupsSeen; // Interp::groupsSeen
    int64_t executions = 0, replays = 0, misses = 0;
    double issue_ms = 0, wait_ms = 0; // over the replayed executions: host time to issue the whole plan / time spent in the one wait at its end
 };
 
 namespace {
-int32_t runParsed(ldb_ctx* ctx, ldb_comm* comm, const J& plan, const char* const* table_names, const ldb_table* const* tables, int32_t n_tables, ldb_table** result) {
+int32_t runParsed(ldb_ctx* ctx, ldb_comm* comm, const J& plan, const char* const* table_names, const ldb_table* const* tables, int32_t n_tables, ldb_table** result,
+                  std::map<std::string, int64_t>* groupsSeen = nullptr) {
    try {
       Interp in(ctx);
       in.comm = comm;
+      in.groupsSeen = groupsSeen;
       in.run(plan, table_names, tables, n_tables);
       Value& r = in.val(in.result);
       if (r.kind != Value::TABLE || !r.owned) throw std::runtime_error("plan: result '" + in.result + "' must be a table produced by the plan");
@@ -1265,7 +1277,7 @@ extern "C" int32_t ldb_plan_execute(ldb_plan* p, ldb_comm* comm, const char* con
       }
       ldb_table* out = nullptr;
       const auto t0 = std::chrono::steady_clock::now();
-      const int32_t st = runParsed(p->ctx, comm, p->doc, table_names, tables, n_tables, &out);
+      const int32_t st = runParsed(p->ctx, comm, p->doc, table_names, tables, n_tables, &out, &p->groupsSeen);
       const auto t1 = std::chrono::steady_clock::now();
       int32_t status = LDB_TRACE_OFF;
       if (ldb_gpu_trace_end(p->ctx, &status) != LDB_OK) {
