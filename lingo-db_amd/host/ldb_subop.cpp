@@ -1770,7 +1770,7 @@ struct Translator {
                continue;
             }
             if (p->kind == Expr::OP && p->name == "setop") { // INTERSECT / EXCEPT (distinct): keep the keys whose counters satisfy the predicate
-               if (s.setState.empty() || p->cmp.size() > 9) throw Unsupported("filter on the counters of a set operation without its map");
+               if (s.setState.empty() || (p->cmp != "intersect" && p->cmp != "except")) throw Unsupported("filter on the counters of a set operation that is not INTERSECT / EXCEPT (distinct)");
                emitSetOp(s, p->cmp);
                continue;
             }
