@@ -484,3 +484,42 @@ class Interp:
 def rows(rel):
     cols = [v for s in rel.sides for (_, v) in s.values()]
     return list(zip(*cols)) if cols else []
+
+
+def run_sharded(plan, rank_tables):
+    """the SAME step list on every rank over its shard, in lockstep (ldb_plan_run_json_comm): `allgather` hands every rank all ranks' rows in rank
+    order, `shuffle` sends each row to the rank its key hashes to (any function of the key will do for correctness: equal keys meet on one rank).
+    rank_tables: one {input name: Rel} per rank → one result Rel per rank"""
+    world = len(rank_tables)
+    ranks = [Interp(t) for t in rank_tables]
+
+    def concat(rels):
+        sides = []
+        for k in range(len(rels[0].sides)):
+            sides.append({n: (t, [x for r in rels for x in r.sides[k][n][1]]) for n, (t, _) in rels[0].sides[k].items()})
+        return Rel(sides, sum(r.n for r in rels))
+    for st in plan["steps"]:
+        if st["op"] == "allgather":
+            mine = []
+            for it in ranks:  # a table travels whole: every column of its single side
+                r = it.rel(st["in"])
+                mine.append(Rel([{n: c for s in r.sides for n, c in s.items()}], r.n))
+            everybody = concat(mine)
+            for it in ranks:
+                it.env[st["out"]] = everybody
+        elif st["op"] == "shuffle":
+            parts = [[] for _ in range(world)]
+            for it in ranks:
+                r = it.rel(st["in"])
+                cols = {c: r.col(c) for c in st["cols"]}
+                keys = [r.col(k)[1] for k in st["keys"]]
+                dest = [hash(tuple(k[i] for k in keys)) % world for i in range(r.n)]
+                for d in range(world):
+                    idx = [i for i in range(r.n) if dest[i] == d]
+                    parts[d].append(Rel([{c: (t, [v[i] for i in idx]) for c, (t, v) in cols.items()}], len(idx)))
+            for d, it in enumerate(ranks):
+                it.env[st["out"]] = concat(parts[d])
+        else:
+            for it in ranks:
+                getattr(it, "op_" + st["op"])(st)
+    return [it.env[plan.get("result", "result")] for it in ranks]

@@ -126,3 +126,26 @@ def test_pattern_dumps_say_what_plain_python_computes(world):
                 "intersect_all": sorted((cl & cr).elements()), "except_all": sorted((cl - cr).elements())}
     for kind, rows_ in expected.items():
         assert pat(kind) == [(k,) for k in rows_], kind
+
+
+@pytest.mark.parametrize("world_size", [2, 3, 8])
+def test_sharded_plans_on_every_rank_say_what_the_oracle_computes(world, world_size):
+    """§8(e) without devices: the sharded step lists (plans/tpch/dist/qN.json) run in lockstep on `world_size` simulated ranks over the shards the
+    generator gives each rank (orders / lineitem co-located by order ranges, the other tables by row ranges, nation / region replicated), their
+    allgather / shuffle steps executed between the ranks — EVERY rank ends with the oracle's answer for the whole database"""
+    _, legs = world
+    shards = [{name: plan_ref.table_from_arrow(T.host_table(tid, N_ORDERS, part=r, n_parts=world_size)) for name, tid in TABLES.items()} for r in range(world_size)]
+    for q in range(1, 23):
+        with open(os.path.join(ROOT, "lingo-db_amd", "plans", "tpch", "dist", "q%d.json" % q)) as f:
+            plan = json.load(f)
+        inputs = []
+        for r in range(world_size):
+            t = dict(shards[r])
+            for name, spec in plan.get("replicated_inputs", {}).items():  # a static dimension table the host program all-gathers once per database
+                cols = spec.get("cols") or list(shards[0][spec["table"]].sides[0])
+                t[name] = plan_ref.Rel([{c: (shards[0][spec["table"]].sides[0][c][0], [x for sh in shards for x in sh[spec["table"]].sides[0][c][1]]) for c in cols}],
+                                       sum(sh[spec["table"]].n for sh in shards))
+            inputs.append({n: t[n] for n in plan["inputs"]})
+        want = legs.run(q)
+        for r, res in enumerate(plan_ref.run_sharded(plan, inputs)):
+            same(q, plan_ref.rows(res), want)
