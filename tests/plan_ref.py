@@ -201,6 +201,11 @@ class Interp:
         if op == "neg":
             t, v = self.expr(rel, args[0])
             return t, [None if a is None else -a for a in v]
+        if op == "idiv":  # arith.divsi over two integers
+            (_, lv), (_, rv) = self.expr(rel, args[0]), self.expr(rel, args[1])
+            return INT, [None if a is None or b is None or b == 0 else tdiv(a, b) for a, b in zip(lv, rv)]
+        if op == "row_number":
+            return INT, list(range(rel.n))
         raise ValueError("expression operator '%s'" % op)
 
     @staticmethod
@@ -416,6 +421,39 @@ class Interp:
             side[alias.split(":", 1)[-1] if isinstance(c, str) else alias] = r.col(name)
         self.env[st["out"]] = Rel([side], r.n)
 
+
+    def op_nested_map(self, st):
+        """NestedMapLowering de-correlated as ldb_plan.cpp does it: (outer tuple x scanned state) pairs passing the residual, the nested maps over the
+        pairs, and — with `reduce` — one group per OUTER tuple (its row number) carrying the kept outer columns"""
+        outer, inner = self.rel(st["in"]), self.rel(st["scan"])
+        resid = [(outer.col(r["probe"])[1], CMP[r["op"]], inner.col(r["build"])[1]) for r in st.get("residual", [])]
+        pairs = [(i, j) for i in range(outer.n) for j in range(inner.n) if all(f(pv[i], bv[j]) for pv, f, bv in resid)]
+        left, right = outer.take([i for i, _ in pairs]), inner.take([j for _, j in pairs])
+        cur = Rel(left.sides + right.sides + [{"__tuple": (INT, [i for i, _ in pairs])}], len(pairs))
+        for m in st.get("map", []):
+            cur = Rel(cur.sides + [{m["as"]: self.expr(cur, m["expr"])}], cur.n)
+        red = st.get("reduce")
+        if red is None:
+            self.env[st["out"]] = cur
+            return
+        self.env["__nm"] = cur
+        self.op_groupby({"in": "__nm", "keys": ["__tuple"], "aggs": list(red["aggs"]) + [{"fn": "any", "expr": c, "as": c} for c in red.get("keep", [])], "out": st["out"]})
+
+    def op_loop(self, st):
+        """LoopLowering: the body once per iteration over the loop-carried tables; the results are the states handed to the LAST loop_continue"""
+        state = {v["name"]: self.env[v["init"]] for v in st["vars"]}
+        for _ in range(st.get("max_iterations", 1000)):
+            body = Interp({**self.env, **state})
+            for b in st["body"]:
+                getattr(body, "op_" + b["op"])(b)
+            state = {**state, **{n["var"]: body.env[n["from"]] for n in st["next"]}}
+            cond = body.rel(st["continue"]["from"]).col(st["continue"]["col"])[1]
+            if not (cond and cond[0]):
+                break
+        else:
+            raise RuntimeError("no fixpoint after %d iterations" % st.get("max_iterations", 1000))
+        for r in st["results"]:
+            self.env[r["name"]] = state[r["var"]]
 
     def op_set_op(self, st):
         """UNION [ALL] / INTERSECT [ALL] / EXCEPT [ALL] over two column lists (NULLs compare equal); the result carries the left names"""

@@ -149,3 +149,21 @@ def test_sharded_plans_on_every_rank_say_what_the_oracle_computes(world, world_s
         want = legs.run(q)
         for r, res in enumerate(plan_ref.run_sharded(plan, inputs)):
             same(q, plan_ref.rows(res), want)
+
+
+def test_loop_and_nested_map_plans_of_the_reference_lit_tests():
+    """plans/subop/loop_counter.json (test/lit/SubOp/loop.mlir, CHECK: 6) and kmeans.json (test/lit/SubOp/kmeans.mlir in fixed point x 1000: the lit
+    test's CHECK values truncated to three digits) — what tests/test_gpu_f4.py pins on the device, read here without one"""
+    import pyarrow as pa
+
+    def plan(name):
+        with open(os.path.join(ROOT, "lingo-db_amd", "plans", "subop", name)) as f:
+            return json.load(f)
+
+    ctr = plan_ref.table_from_arrow(pa.table({"ctr": pa.array([0], pa.int32())}))
+    assert plan_ref.rows(plan_ref.Interp({"ctr0": ctr}).run(plan("loop_counter.json"))) == [(6,)]
+    pts = [(x * 1000, y * 1000) for x, y in [(1, 1), (1, 2), (2, 1), (2, 4), (2, 5), (3, 2), (3, 5), (6, 3), (6, 5), (8, 4)]]  # kmeans.mlir's ten points
+    points = plan_ref.table_from_arrow(pa.table({"px": pa.array([p[0] for p in pts], pa.int64()), "py": pa.array([p[1] for p in pts], pa.int64())}))
+    initial = plan_ref.table_from_arrow(pa.table({"cx": pa.array([pts[i][0] for i in range(3)], pa.int64()), "cy": pa.array([pts[i][1] for i in range(3)], pa.int64()),
+                                                  "cid": pa.array([0, 1, 2], pa.int64())}))
+    assert plan_ref.rows(plan_ref.Interp({"points": points, "initial": initial}).run(plan("kmeans.json"))) == [(0, 1750, 1500), (1, 2333, 4666), (2, 6666, 4000)]
