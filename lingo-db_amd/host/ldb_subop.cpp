@@ -145,6 +145,7 @@ struct Stream {
    bool inJoinBody = false; // between the gather of a hash join and the end of its nested_map: filters are conjuncts of the join predicate
    std::vector<std::string> residual; // non-equality conjuncts relating the two sides ({"probe", "op", "build"})
    std::vector<ExprP> postJoin; // conjuncts of the join predicate that do not relate one probe with one build column: applied to the joined rows (inner joins only)
+   bool flagAntiPending = false; // a flagged buffer scanned for its UNflagged rows in a step that also has a union: the unmatched half of a reversed outer join (when a map of NULLs follows) or an ordinary anti join of the build side (anything else)
    bool fullOuter = false; // the matches and the partner-less probe rows of a FULL outer join: united with the unmatched build rows after the probe pipeline
    bool antiBranch = false; // outer / single join: the branch of the probe rows WITHOUT a partner (filter none_true on the marker)
    std::string constState; // constant single join: the one-row state this stream looked up
@@ -875,8 +876,20 @@ struct Translator {
       s.winFrame = false;
    }
 
+   // the unflagged rows of a build buffer are consumed as rows: an anti join keeping the build side
+   void realiseFlag(Stream& s) {
+      if (!s.flagAntiPending) return;
+      s.flagAntiPending = false;
+      StateP buf = states.at(s.flagState);
+      if (buf->antiRel.empty()) buf->antiRel = emitJoin(*buf->flagProbe, "anti_build");
+      s.rel = buf->antiRel;
+      s.preds.clear();
+      s.bareTable = false;
+      s.flagState.clear();
+   }
    // the pending join turns out to be an ordinary (inner) one: some other sub-operator consumes the matched pairs
    void settle(Stream& s) {
+      realiseFlag(s);
       flushWindow(s);
       if (!s.pending) return;
       StateP hiv = states.at(s.probeHiv);
@@ -1658,6 +1671,20 @@ struct Translator {
             for (auto& cm : op.at("computed").arr) marker = marker && convert(cm.at("expression"), s)->kind == Expr::CONST_BOOL;
             if (!marker) settle(s);
          }
+         if (s.flagAntiPending) {
+            bool nulls = true, copies = true;
+            for (auto& cm : op.at("computed").arr) {
+               const Expr::Kind k = stripCast(convert(cm.at("expression"), s))->kind;
+               nulls = nulls && k == Expr::NULLV;
+               copies = copies && k == Expr::COL;
+            }
+            if (nulls) { // the unmatched BUILD rows of an outer join with reverseSides: null-extended and united with the matches below
+               s.flagAntiPending = false;
+               s.antiBranch = true;
+            } else if (!copies) { // (as-nullable copies of the build columns precede the NULLs of a full outer join: still undecided)
+               realiseFlag(s);
+            }
+         }
          if (!s.winFns.empty() || !s.winView.empty()) { // a map that is not part of the window evaluation consumes its results
             bool part = true;
             for (auto& cm : op.at("computed").arr) {
@@ -1727,7 +1754,7 @@ struct Translator {
                   if (c.outerBody) s.antiBranch = true; // outer / single join: the partner-less rows are null-extended and united with the matches
                   else finishProbeSide(s, true);
                } else if (k == Expr::FLAG && c.outerStep) {
-                  s.antiBranch = true; // the unmatched BUILD rows of an outer join with reverseSides: null-extended and united with the matches below
+                  s.flagAntiPending = true; // decided by what consumes the rows (realiseFlag)
                } else if (k == Expr::FLAG) {
                   StateP buf = states.at(s.flagState);
                   if (buf->antiRel.empty()) buf->antiRel = emitJoin(*buf->flagProbe, "anti_build");

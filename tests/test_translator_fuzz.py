@@ -1,0 +1,174 @@
+"""Seeded random relational-algebra trees over a tiny generated database: lowered to a sub-operator dump (tools/subop_lower.py), translated
+(`ldb_subop_translate`), the step list read by tests/plan_ref.py — against the DIRECT evaluation of the tree (tests/relalg_eval.py), which passes through
+none of those.  Joins of every kind along the schema's key edges (inner, semi, anti, mark, outer, full; with and without reverseSides; with residual
+conjuncts), pushed-down and residual restrictions, group-bys with nullable arguments, distinct — the shapes the TPC-H dumps do not enumerate.  A
+disagreement is a bug in one of the four; so far they were in the translator."""
+import json
+import os
+import random
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "tools"), ROOT]
+
+import plan_ref  # noqa: E402
+import relalg_eval  # noqa: E402
+import subop_lower as L  # noqa: E402
+import tpch_data as T  # noqa: E402
+from lingodb_amd import api  # noqa: E402
+
+N_ORDERS = 1500
+IDS = {"lineitem": T.LINEITEM, "orders": T.ORDERS, "customer": T.CUSTOMER, "part": T.PART, "supplier": T.SUPPLIER, "partsupp": T.PARTSUPP, "nation": T.NATION, "region": T.REGION}
+EDGES = [("lineitem", "l_orderkey", "orders", "o_orderkey"), ("orders", "o_custkey", "customer", "c_custkey"), ("lineitem", "l_suppkey", "supplier", "s_suppkey"),
+         ("supplier", "s_nationkey", "nation", "n_nationkey"), ("customer", "c_nationkey", "nation", "n_nationkey"), ("lineitem", "l_partkey", "part", "p_partkey"),
+         ("partsupp", "ps_partkey", "part", "p_partkey"), ("partsupp", "ps_suppkey", "supplier", "s_suppkey"), ("nation", "n_regionkey", "region", "r_regionkey")]
+FILTERS = {"lineitem": [("l_shipdate", "GTE", "1995-01-01"), ("l_quantity", "LT", "24"), ("l_discount", "GTE", "0.05"), ("l_linenumber", "LTE", 3), ("l_shipmode", "IN", ["AIR", "MAIL", "SHIP"])],
+           "orders": [("o_orderdate", "LT", "1995-03-15"), ("o_totalprice", "GT", "150000.00"), ("o_orderpriority", "EQ", "1-URGENT")],
+           "customer": [("c_acctbal", "GT", "3000.00"), ("c_mktsegment", "EQ", "BUILDING")], "part": [("p_size", "LTE", 25), ("p_brand", "NEQ", "Brand#45")],
+           "supplier": [("s_acctbal", "GT", "1000.00")], "partsupp": [("ps_availqty", "GT", 4000), ("ps_supplycost", "LT", "500.00")],
+           "nation": [("n_regionkey", "NEQ", 2)], "region": [("r_name", "NEQ", "ASIA")]}
+KIND = {"int32": "int", "date": "date", "str": "str", "decimal(12,2)": "dec"}
+
+
+@pytest.fixture(scope="module")
+def db():
+    arrow = {name: T.host_table(tid, N_ORDERS) for name, tid in IDS.items()}
+    return arrow, {name: plan_ref.table_from_arrow(t) for name, t in arrow.items()}
+
+
+def usable(table):
+    return [c for c in L.W.TABLES[table] if L.W.TYPES[c] in KIND]
+
+
+class Gen:
+    def __init__(self, seed):
+        self.rng = random.Random(seed)
+        self.n = 0
+        self.cols = {}  # display name → (C, kind, nullable)
+
+    def leaf(self, table):
+        self.n += 1
+        fs = [f for f in FILTERS[table] if self.rng.random() < 0.4]
+        t = L.Table(table, "%s%d" % (table[0], self.n), fs)
+        for c in usable(table):
+            self.cols[t[c].name] = (t[c], KIND[L.W.TYPES[c]], False)
+        node = t
+        if table == "lineitem" and self.rng.random() < 0.3:
+            node = L.Select(t, L.lt(t["l_commitdate"].j, t["l_receiptdate"].j))
+        return t, node
+
+    def av(self, node):
+        return sorted(n for n in node.avail() if n in self.cols)
+
+    def join(self, probe, build, pk, bk):
+        """(node, avail names) of a random join kind of the two inputs on probe.pk = build.bk"""
+        rng = self.rng
+        kind = rng.choice(["inner", "inner", "semi", "anti", "semi_rev", "anti_rev", "outer", "outer_rev", "mark", "full"])
+        pints = [n for n in self.av(probe) if self.cols[n][1] == "int" and n != pk.name]
+        bints = [n for n in self.av(build) if self.cols[n][1] == "int" and n != bk.name]
+        resid = []
+        if pints and bints and rng.random() < 0.35:
+            f = rng.choice([L.neq, L.lt, L.gte])
+            resid = [f(self.cols[rng.choice(pints)][0].j, self.cols[rng.choice(bints)][0].j)]
+
+        def nullable(names, tag):
+            out = []
+            for name in names:
+                c, k, _ = self.cols[name]
+                self.n += 1
+                nc = L.C("%s%d::%s" % (tag, self.n, c.base), "nullable(%s)" % c.dtype.replace("nullable(", "").rstrip(")") if c.dtype.startswith("nullable(") else "nullable(%s)" % c.dtype)
+                self.cols[nc.name] = (nc, k, True)
+                out.append((nc, c))
+            return out
+        if kind == "inner":
+            return L.Join("inner", probe, build, [(pk, bk)], residual=resid)
+        if kind in ("semi", "anti"):
+            return L.Join(kind, probe, build, [(pk, bk)], residual=resid)
+        if kind in ("semi_rev", "anti_rev"):
+            return L.Join(kind[:-4], probe, build, [(pk, bk)], residual=resid, reverse=True)
+        if kind == "mark":
+            self.n += 1
+            m = L.C("markjoin%d::mark" % self.n, "int1")
+            j = L.Join("mark", probe, build, [(pk, bk)], residual=resid, mark=m)
+            other = [n for n in self.av(probe) if self.cols[n][1] == "int"]
+            c = self.cols[rng.choice(other)][0]
+            pred = L.or_(m.j, L.lt(c.j, L.const(3, "int32"))) if rng.random() < 0.6 else L.not_(m.j)
+            return L.Select(j, pred)
+        if kind in ("outer", "outer_rev"):
+            side = probe if kind == "outer_rev" else build  # the NON-preserved side's columns come out nullable
+            names = rng.sample(self.av(side), min(2, len(self.av(side))))
+            return L.Join("outer", probe, build, [(pk, bk)], residual=resid, reverse=kind == "outer_rev", mapping=nullable(names, "oj"))
+        names = [pk.name, bk.name] + rng.sample([n for n in self.av(probe) if n != pk.name], 1) + rng.sample([n for n in self.av(build) if n != bk.name], 1)
+        return L.Join("full", probe, build, [(pk, bk)], mapping=nullable(list(dict.fromkeys(names)), "foj"))
+
+    def tree(self):
+        rng = self.rng
+        ft, fk, pt, pk = rng.choice(EDGES)
+        (a_t, a), (b_t, b) = self.leaf(ft), self.leaf(pt)
+        if rng.random() < 0.3:
+            node = self.join(b, a, b_t[pk], a_t[fk])
+        else:
+            node = self.join(a, b, a_t[fk], b_t[pk])
+        avail = self.av(node)
+        # a second join on top where the result still has a foreign key
+        if rng.random() < 0.5:
+            nxt = [(f, t2, p2) for (t1, f, t2, p2) in EDGES for n in avail if n.endswith("::" + f) and not self.cols[n][2]]
+            if nxt:
+                f, t2, p2 = rng.choice(nxt)
+                src = next(n for n in avail if n.endswith("::" + f) and not self.cols[n][2])
+                c_t, c = self.leaf(t2)
+                node = self.join(node, c, self.cols[src][0], c_t[p2])
+                avail = self.av(node)
+        outs = []
+        if rng.random() < 0.65:
+            keyable = [n for n in avail if self.cols[n][1] in ("int", "str", "date")]
+            keys = [self.cols[n][0] for n in rng.sample(keyable, rng.choice([0, 1, 1, 2]))] if keyable else []
+            aggs, nullable_args = [], []
+            self.n += 1
+            cnt = L.C("aggr%d::rows" % self.n, "int64")
+            aggs.append(("count_star", None, cnt))
+            self.cols[cnt.name] = (cnt, "int", False)
+            for name in rng.sample(avail, min(len(avail), rng.choice([1, 2, 3]))):
+                c, k, nul = self.cols[name]
+                fn = rng.choice(["sum", "min", "max", "count"] if k in ("int", "dec") else ["min", "max", "count"] if k == "date" else ["count"])
+                self.n += 1
+                o = L.C("aggr%d::%s_%s" % (self.n, fn, c.base), "int64" if fn == "count" else c.dtype)
+                self.cols[o.name] = (o, "int" if fn == "count" else k, True)
+                aggs.append((fn, c, o))
+                if nul:
+                    nullable_args.append(c)
+            node = L.Aggregate(node, keys, aggs, nullable_args=nullable_args)
+            outs = keys + [o for _, _, o in aggs]
+        elif rng.random() < 0.3:
+            keyable = [n for n in avail if self.cols[n][1] in ("int", "str", "date")]
+            outs = [self.cols[n][0] for n in rng.sample(keyable, min(len(keyable), 2))]
+            node = L.Distinct(node, outs)
+        else:
+            outs = [self.cols[n][0] for n in rng.sample(avail, min(len(avail), 4))]
+        return node, outs
+
+
+def scale_of(c):
+    d = c.dtype.replace("nullable(", "")
+    return int(d.split(",")[1].rstrip(")")) if d.startswith("decimal") else None
+
+
+def norm(rows):
+    return sorted(rows, key=lambda r: tuple((x is None, x) for x in r))
+
+
+@pytest.mark.parametrize("seed", list(range(120)))
+def test_random_trees_agree_with_their_direct_evaluation(db, seed):
+    arrow, tables = db
+    g = Gen(seed)
+    node, outs = g.tree()
+    want = [tuple(None if r[c.name] is None else (int(r[c.name] * 10 ** scale_of(c)) if scale_of(c) is not None else (int(r[c.name]) if isinstance(r[c.name], bool) else r[c.name])) for c in outs)
+            for r in relalg_eval.evaluate(node, arrow)]
+    cx = L.Cx("fuzz%d" % seed)
+    dump = L.result(cx, node, [("c%d" % i, c) for i, c in enumerate(outs)], write=False)
+    text, report = api.translate_subop_dump(dump, "fuzz%d" % seed)
+    plan = json.loads(text)
+    got = plan_ref.rows(plan_ref.Interp({n: tables[n] for n in plan["inputs"]}).run(plan))
+    assert norm(got) == norm(want), text

@@ -237,9 +237,8 @@ class Join(Node):
     def lower(self, cx, required):
         pa, ba = self.probe.avail(), self.build.avail()
         need = set(required)
-        for n, old in self.mapping:
-            if n.name in need:
-                need.add(old.name)
+        for n, old in self.mapping:  # the mapping's sources are used columns of the join, whether or not the copies are read above
+            need.add(old.name)
         for pk, bk in self.keys:
             need |= {pk.name, bk.name}
         for e in self.residual:
@@ -780,10 +779,14 @@ class Window(Node):
         return p
 
 
-def result(cx, child, outs):
-    """MaterializeLowering: outs = [(result column name, C)]"""
+def result(cx, child, outs, write=True):
+    """MaterializeLowering: outs = [(result column name, C)]; writes tests/golden/subop_<name>.json (or returns the document's text)"""
     p = child.lower(cx, {c.name for _, c in outs})
     s_rt, ty = cx.state("generic_create", "ResultTable[...]")
     p.op("materialize", accesses=[p.state_arg(s_rt, ty)], stateType="ResultTable", mapping=[{"member": "%s$r" % n, "column": c.j} for n, c in outs])
     p.close()
+    if not write:
+        import json
+
+        return json.dumps(cx.d.plan)
     return cx.d.write()
