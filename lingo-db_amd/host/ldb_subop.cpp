@@ -156,7 +156,7 @@ struct Stream {
       std::string fn, col, as;
    };
    std::vector<WinFn> winFns;
-   bool winFrame = false;
+   bool winFrame = false, winHasTo = false;
    int64_t winFrom = 0, winTo = 0;
    std::string partState; // scan of the map of per-partition buffers: the buffer column stands for this state inside the nested_map
    std::string gjState; // group join: this stream probes the map the other input created (GroupJoinLowering, RelAlgToSubOp.cpp:2682-2950)
@@ -835,11 +835,14 @@ struct Translator {
       throw Unsupported("window frame end that is not a view reference");
    }
    void setFrame(Stream& s, int64_t from, int64_t to, bool haveTo) {
-      if (s.winFrame && (s.winFrom != from || (haveTo && s.winTo != to))) throw Unsupported("window functions with different frames in one window");
-      if (!s.winFrame) s.winTo = 0;
+      if (s.winFrame && (s.winFrom != from || (haveTo && s.winHasTo && s.winTo != to))) throw Unsupported("window functions with different frames in one window");
+      if (!s.winFrame) s.winTo = 0; // (a rank alone reads only the frame's begin)
       s.winFrame = true;
       s.winFrom = from;
-      if (haveTo) s.winTo = to;
+      if (haveTo) {
+         s.winTo = to;
+         s.winHasTo = true;
+      }
    }
    // the functions collected on this stream become ONE window step: partition + order of the view, one frame, one result column each
    void flushWindow(Stream& s) {
@@ -874,6 +877,7 @@ struct Translator {
       s.winView.clear();
       s.winLookup.clear();
       s.winFrame = false;
+      s.winHasTo = false;
    }
 
    // the unflagged rows of a build buffer are consumed as rows: an anti join keeping the build side

@@ -190,4 +190,56 @@ def evaluate(node, tables):
         rows = {"union_all": l + r, "union": list(dict.fromkeys(l + r)), "intersect": [k for k in dict.fromkeys(l) if k in cr], "except": [k for k in dict.fromkeys(l) if k not in cr],
                 "intersect_all": list((cl & cr).elements()), "except_all": list((cl - cr).elements())}[node.kind]
         return [{n.name: k[i] for i, (n, _, _) in enumerate(node.mapping)} for k in rows]
+    if isinstance(node, L.ConstJoin):
+        one = evaluate(node.single, tables)
+        assert len(one) == 1, "a constant join's single side has one row"
+        return [{**r, **{n.name: one[0][o.name] for n, o in node.mapping}} for r in evaluate(node.left, tables)]
+    if isinstance(node, L.GroupJoin):
+        left, right = evaluate(node.left, tables), evaluate(node.right, tables)
+        groups = {}
+        for l in left:  # one entry per key: the map keeps the first tuple's stored columns … the inputs here have unique keys
+            groups.setdefault(tuple(l[lk.name] for lk, _ in node.keys), (l, []))
+        for r in right:
+            k = tuple(r[rk.name] for _, rk in node.keys)
+            if None in k or k not in groups:
+                continue
+            row = {**groups[k][0], **r, **{lk.name: r[rk.name] for lk, rk in node.keys}}
+            if all(truth(ev(e, row)) for e in node.predicate):
+                groups[k][1].append(r)
+        out = []
+        for k, (l, rs) in groups.items():
+            if node.inner and not rs:
+                continue
+            row = {rk.name: k[i] for i, (_, rk) in enumerate(node.keys)}
+            row.update({lk.name: k[i] for i, (lk, _) in enumerate(node.keys)})
+            row.update({c.name: l[c.name] for c in node.stored})
+            for fn, a, o in node.aggs:
+                vals = [r[a.name] for r in rs if r[a.name] is not None] if a is not None else None
+                row[o.name] = len(rs) if fn == "count_star" else len(vals) if fn == "count" else (sum(vals) if vals else None) if fn == "sum" else (min(vals) if vals else None) if fn == "min" else (max(vals) if vals else None)
+            out.append(row)
+        return out
+    if isinstance(node, L.Window):
+        rows = evaluate(node.child, tables)
+        order = sorted(range(len(rows)), key=lambda i: tuple(rows[i][c.name] for c in node.partition_by) + tuple(rows[i][c.name] for c, _ in node.order_by))
+        assert all(d == "asc" for _, d in node.order_by)
+        out = []
+        pos = 0
+        while pos < len(order):
+            end = pos
+            key = tuple(rows[order[pos]][c.name] for c in node.partition_by)
+            while end + 1 < len(order) and tuple(rows[order[end + 1]][c.name] for c in node.partition_by) == key:
+                end += 1
+            part = [rows[i] for i in order[pos:end + 1]]
+            frm, to = node.frame
+            for p, r in enumerate(part):
+                a = 0 if frm == L.I64_MIN else max(0, min(len(part) - 1, p + frm))
+                b = len(part) - 1 if to == L.I64_MAX else max(0, min(len(part) - 1, p + to))
+                row = dict(r)
+                for fn, c, o in node.fns:
+                    vals = [x[c.name] for x in part[a:b + 1] if x[c.name] is not None] if c is not None else None
+                    row[o.name] = (p - a + 1 if fn == "rank" else b - a + 1 if fn == "count_star" else len(vals) if fn == "count" else (sum(vals) if vals else None) if fn == "sum" else
+                                   (min(vals) if vals else None) if fn == "min" else (max(vals) if vals else None))
+                out.append(row)
+            pos = end + 1
+        return out
     raise TypeError(type(node).__name__)

@@ -1,8 +1,11 @@
 """Seeded random relational-algebra trees over a tiny generated database: lowered to a sub-operator dump (tools/subop_lower.py), translated
 (`ldb_subop_translate`), the step list read by tests/plan_ref.py — against the DIRECT evaluation of the tree (tests/relalg_eval.py), which passes through
 none of those.  Joins of every kind along the schema's key edges (inner, semi, anti, mark, outer, full; with and without reverseSides; with residual
-conjuncts), pushed-down and residual restrictions, group-bys with nullable arguments, distinct — the shapes the TPC-H dumps do not enumerate.  A
-disagreement is a bug in one of the four; so far they were in the translator."""
+conjuncts), one or two levels deep, pushed-down and residual restrictions, group-bys with nullable arguments, distinct, set operations, scalar subqueries
+(constant single joins), group joins (inner / outer behaviour), windows (rank + a frame aggregate, with and without PARTITION BY, five frame shapes) — the
+shapes the TPC-H dumps do not enumerate.  A disagreement is a bug in one of the four parts; the ones found so far: the lowering must materialise the sources of an outer
+join's mapping; the unflagged rows of a build buffer are an anti join unless a map of NULLs follows (translator); a rank alone fixes only the frame's begin
+(translator).  1 500 seeds agree; 200 run here."""
 import json
 import os
 import random
@@ -103,8 +106,76 @@ class Gen:
         names = [pk.name, bk.name] + rng.sample([n for n in self.av(probe) if n != pk.name], 1) + rng.sample([n for n in self.av(build) if n != bk.name], 1)
         return L.Join("full", probe, build, [(pk, bk)], mapping=nullable(list(dict.fromkeys(names)), "foj"))
 
+    def special(self):
+        """the shapes beyond joins: a set operation over two key columns, a scalar subquery (constant single join) compared with a column, a group join along a
+        key edge (inner / outer behaviour), a window over a table ordered by its key"""
+        rng = self.rng
+        what = rng.choice(["setop", "const", "groupjoin", "window"])
+        ft, fk, pt, pk = rng.choice(EDGES)
+        if what == "setop":
+            (a_t, a), (b_t, b) = self.leaf(ft), self.leaf(pt)
+            self.n += 1
+            k = L.C("setop%d::key" % self.n, "nullable(int32)")
+            self.cols[k.name] = (k, "int", True)
+            return L.SetOp(rng.choice(["union_all", "union", "intersect", "except", "intersect_all", "except_all"]), a, b, [(k, a_t[fk], b_t[pk])]), [k]
+        if what == "const":
+            (a_t, a), (b_t, b) = self.leaf(ft), self.leaf(pt)
+            self.n += 1
+            fn = rng.choice(["min", "max", "sum"])
+            m, mn = L.C("aggr%d::m" % self.n, "nullable(int32)"), L.C("sj%d::m" % self.n, "nullable(int32)")
+            self.cols[mn.name] = (mn, "int", True)
+            sub = L.Aggregate(b, [], [(fn, b_t[pk], m)])
+            node = L.Select(L.ConstJoin(a, sub, [(mn, m)]), rng.choice([L.lt, L.gte, L.neq])(a_t[fk].j, mn.j))
+            return node, [self.cols[n][0] for n in rng.sample(self.av(a), min(3, len(self.av(a))))] + [mn]
+        if what == "groupjoin":
+            (l_t, left), (r_t, right) = self.leaf(pt), self.leaf(ft)  # the side with the unique key creates the groups
+            if isinstance(left, L.Select):
+                left = l_t
+            self.n += 1
+            cnt, agg = L.C("aggr%d::n" % self.n, "int64"), None
+            self.cols[cnt.name] = (cnt, "int", False)
+            aggs = [("count_star", None, cnt)]
+            nums = [n for n in self.av(right) if self.cols[n][1] in ("int", "dec") and n != r_t[fk].name]
+            if nums:
+                c = self.cols[rng.choice(nums)][0]
+                fn = rng.choice(["sum", "min", "max"])
+                agg = L.C("aggr%d::%s" % (self.n, fn), "nullable(%s)" % c.dtype)
+                self.cols[agg.name] = (agg, self.cols[c.name][1], True)
+                aggs.append((fn, c, agg))
+            stored = [self.cols[n][0] for n in rng.sample([n for n in self.av(left) if n != l_t[pk].name], 1)]
+            pred = []
+            ints = [n for n in self.av(right) if self.cols[n][1] == "int" and n != r_t[fk].name]
+            if ints and rng.random() < 0.5:
+                pred = [L.gt(self.cols[rng.choice(ints)][0].j, L.const(1, "int32"))]
+            node = L.GroupJoin(left, right, [(l_t[pk], r_t[fk])], aggs, stored=stored, predicate=pred, behavior=rng.choice(["inner", "outer"]))
+            return node, [r_t[fk]] + stored + [o for _, _, o in aggs]
+        t_t, t = self.leaf(pt)
+        if isinstance(t, L.Select):
+            t = t_t
+        self.n += 1
+        part = [self.cols[n][0] for n in rng.sample([n for n in self.av(t) if self.cols[n][1] in ("int", "str") and n != t_t[pk].name], rng.choice([0, 1]))]
+        frame = rng.choice([(L.I64_MIN, 0), (-2, 0), (-1, 1), (0, L.I64_MAX), (L.I64_MIN, L.I64_MAX)])
+        fns = []
+        if frame != (L.I64_MIN, L.I64_MAX):
+            rk = L.C("win%d::rank" % self.n, "int64")
+            self.cols[rk.name] = (rk, "int", False)
+            fns.append(("rank", None, rk))
+        nums = [n for n in self.av(t) if self.cols[n][1] in ("int", "dec") and n not in {p.name for p in part}]  # (a partition key is not a member of the partition's buffer)
+        c = self.cols[rng.choice(nums)][0]
+        fn = rng.choice(["sum", "min", "max", "count"])
+        o = L.C("win%d::%s" % (self.n, fn), "int64" if fn == "count" else "nullable(%s)" % c.dtype)
+        self.cols[o.name] = (o, "int" if fn == "count" else self.cols[c.name][1], True)
+        fns.append((fn, c, o))
+        cs = L.C("win%d::rows" % self.n, "int64")
+        self.cols[cs.name] = (cs, "int", False)
+        fns.append(("count_star", None, cs))
+        node = L.Window(t, part, [(t_t[pk], "asc")] if frame != (L.I64_MIN, L.I64_MAX) or rng.random() < 0.5 else [], frame, fns)
+        return node, [t_t[pk]] + [o for _, _, o in fns]
+
     def tree(self):
         rng = self.rng
+        if rng.random() < 0.3:
+            return self.special()
         ft, fk, pt, pk = rng.choice(EDGES)
         (a_t, a), (b_t, b) = self.leaf(ft), self.leaf(pt)
         if rng.random() < 0.3:
@@ -159,7 +230,7 @@ def norm(rows):
     return sorted(rows, key=lambda r: tuple((x is None, x) for x in r))
 
 
-@pytest.mark.parametrize("seed", list(range(120)))
+@pytest.mark.parametrize("seed", list(range(200)))
 def test_random_trees_agree_with_their_direct_evaluation(db, seed):
     arrow, tables = db
     g = Gen(seed)
