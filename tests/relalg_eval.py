@@ -76,6 +76,15 @@ def ev(e, row):
         a = val(0)
         lo, hi = _constant(ev(subs[1], row), a), _constant(ev(subs[2], row), a)
         return None if a is None else lo <= a <= hi
+    if len(ss) == 3 and ss[0] == "" and ss[2] == "" and ss[1] in (" + ", " - ", " * "):
+        a, b = val(0), val(1)
+        return None if a is None or b is None else (a + b if ss[1] == " + " else a - b if ss[1] == " - " else a * b)
+    if ss[0] in ("ConstLike(", "Like(") and len(subs) == 2:
+        import re
+
+        a, pat = val(0), ev(subs[1], row)["value"]
+        rx = "".join(".*" if c == "%" else "." if c == "_" else re.escape(c) for c in pat)
+        return None if a is None else re.fullmatch(rx, a, re.S) is not None
     raise ValueError("expression %r" % ss)
 
 

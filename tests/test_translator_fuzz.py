@@ -106,6 +106,45 @@ class Gen:
         names = [pk.name, bk.name] + rng.sample([n for n in self.av(probe) if n != pk.name], 1) + rng.sample([n for n in self.av(build) if n != bk.name], 1)
         return L.Join("full", probe, build, [(pk, bk)], mapping=nullable(list(dict.fromkeys(names)), "foj"))
 
+    PATTERNS = {"str": ["%a%", "S%", "%e", "%an%ar%", "1-%"]}
+
+    def predicate(self, node):
+        """a random restriction over the columns a node offers: the forms the consumer turns into restrictions, an IN list, a DNF, or a computed predicate"""
+        rng = self.rng
+        av = [n for n in self.av(node) if not self.cols[n][2]]
+        ints = [n for n in av if self.cols[n][1] == "int"]
+        strs = [n for n in av if self.cols[n][1] == "str"]
+        col = lambda n: self.cols[n][0].j
+        small = lambda: L.const(rng.choice([1, 2, 3, 5, 10, 25, 100, 1000]), "int32")
+        cmp = lambda: rng.choice([L.lt, L.lte, L.gt, L.gte, L.eq, L.neq])
+        forms = []
+        if ints:
+            forms += ["cmp", "between", "in", "or", "arith"]
+        if len(ints) >= 2:
+            forms += ["colcol"]
+        if strs:
+            forms += ["like", "notlike"]
+        if not forms:
+            return None
+        f = rng.choice(forms)
+        if f == "cmp":
+            return cmp()(col(rng.choice(ints)), small())
+        if f == "between":
+            return L.between(col(rng.choice(ints)), L.const(2, "int32"), L.const(rng.choice([5, 50, 500]), "int32"))
+        if f == "in":
+            return L.one_of(col(rng.choice(ints)), [L.const(v, "int32") for v in rng.sample([0, 1, 2, 3, 4, 7, 10, 15, 24], 3)])
+        if f == "or":
+            a, b = rng.choice(ints), rng.choice(ints)
+            return L.or_(L.and_(cmp()(col(a), small()), cmp()(col(b), small())), cmp()(col(b), small()))
+        if f == "arith":
+            a, b = rng.choice(ints), rng.choice(ints)
+            return cmp()(rng.choice([L.add, L.sub, L.mul])(col(a), col(b)), small())
+        if f == "colcol":
+            a, b = rng.sample(ints, 2)
+            return cmp()(col(a), col(b))
+        p = L.call("ConstLike", col(rng.choice(strs)), L.sconst(rng.choice(self.PATTERNS["str"])))
+        return p if f == "like" else L.not_(p)
+
     def special(self):
         """the shapes beyond joins: a set operation over two key columns, a scalar subquery (constant single join) compared with a column, a group join along a
         key edge (inner / outer behaviour), a window over a table ordered by its key"""
@@ -192,6 +231,10 @@ class Gen:
                 c_t, c = self.leaf(t2)
                 node = self.join(node, c, self.cols[src][0], c_t[p2])
                 avail = self.av(node)
+        if rng.random() < 0.5:
+            pred = self.predicate(node)
+            if pred is not None:
+                node = L.Select(node, pred) if rng.random() < 0.7 else L.Select(node, pred, *[q for q in [self.predicate(node)] if q is not None])
         outs = []
         if rng.random() < 0.65:
             keyable = [n for n in avail if self.cols[n][1] in ("int", "str", "date")]
