@@ -215,6 +215,20 @@ class Gen:
         rng = self.rng
         if rng.random() < 0.3:
             return self.special()
+        if rng.random() < 0.12:  # the composite key of partsupp: two equalities = two conjuncts of the join predicate
+            (a_t, a), (b_t, b) = self.leaf("lineitem"), self.leaf("partsupp")
+            kind = rng.choice(["inner", "semi", "anti", "outer"])
+            keys = [(a_t["l_partkey"], b_t["ps_partkey"]), (a_t["l_suppkey"], b_t["ps_suppkey"])]
+            if kind == "outer":
+                self.n += 1
+                nc = L.C("oj%d::ps_availqty" % self.n, "nullable(int32)")
+                self.cols[nc.name] = (nc, "int", True)
+                node = L.Join("outer", a, b, keys, mapping=[(nc, b_t["ps_availqty"])])
+            else:
+                node = L.Join(kind, a, b, keys)
+            avail = self.av(node)
+            outs = [self.cols[n][0] for n in rng.sample(avail, min(len(avail), 4))]
+            return node, outs
         ft, fk, pt, pk = rng.choice(EDGES)
         (a_t, a), (b_t, b) = self.leaf(ft), self.leaf(pt)
         if rng.random() < 0.3:
