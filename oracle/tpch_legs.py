@@ -227,17 +227,26 @@ class Legs:
     def revenue(self, f, ext="l_extendedprice", disc="l_discount"):
         return ("sum", f.expr([ext, ("1-", disc)]), True)  # decimal(12,2) x decimal(21,2) → decimal(33,4), 128-bit accumulator
 
-    def q1(self):
+    def q1_partials(self):
+        """{(returnflag, linestatus): [Σ qty, Σ price, Σ disc_price, Σ charge, Σ discount, count]} — sums and counts add up over any
+        partition of lineitem (bench.py's sliced oracle at the bench's own scale adds the slices' partials before the averages)"""
         li = self.frame(T.LINEITEM)
         aggs = [("sum", li.expr(["l_quantity"]), False), ("sum", li.expr(["l_extendedprice"]), False), self.revenue(li),
                 ("sum", li.expr(["l_extendedprice", ("1-", "l_discount"), ("1+", "l_tax")]), True), ("sum", li.expr(["l_discount"]), False), ("count_star", None, False)]
-        g, (sq, sb, sd, sc, sdisc, cnt), _ = li.groupby(["l_returnflag", "l_linestatus"], aggs, [("l_shipdate", "LTE", days("1998-09-02"))])
+        g, cols, _ = li.groupby(["l_returnflag", "l_linestatus"], aggs, [("l_shipdate", "LTE", days("1998-09-02"))])
+        rf, ls = g.np("l_returnflag"), g.np("l_linestatus")
+        return {(int(rf[i]), int(ls[i])): [int(c[i]) for c in cols] for i in range(g.n)}
+
+    @staticmethod
+    def q1_finish(partials):
         rows = []
-        for i in range(g.n):
-            c = int(cnt[i])
+        for (rf, ls), (sq, sb, sd, sc, sdisc, c) in partials.items():
             avg = lambda s: (int(s) * 10**19) // c  # AVG = (SUM * 10^19) sdiv COUNT → decimal(31,21)
-            rows.append((int(g.np("l_returnflag")[i]), int(g.np("l_linestatus")[i]), int(sq[i]), int(sb[i]), int(sd[i]), int(sc[i]), avg(sq[i]), avg(sb[i]), avg(sdisc[i]), c))
+            rows.append((rf, ls, sq, sb, sd, sc, avg(sq), avg(sb), avg(sdisc), c))
         return sorted(rows)
+
+    def q1(self):
+        return self.q1_finish(self.q1_partials())
 
     def q6(self):
         li = self.frame(T.LINEITEM)

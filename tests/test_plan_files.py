@@ -228,6 +228,27 @@ def test_oracle_q6_in_slices_equals_the_whole_table():
     assert whole == [(got,)] and got is not None and got > 0 and secs >= 0
 
 
+def test_oracle_q1_and_q3_in_slices_equal_the_whole_tables():
+    """bench.py's checks.oracle_q1_at_bench_scale / oracle_q3_at_bench_scale (BASELINE configs[1] / [2] at the bench's own scale): Q1's partial sums
+    and counts add up over lineitem slices; Q3 runs per order-range slice (all customers, the slice's orders and lineitems — orders and lineitem are
+    cut at the same order boundaries) and the slices' ten best rows merge into the query's ten best"""
+    import sys
+
+    sys.path[:0] = [os.path.join(ROOT, "oracle"), ROOT]
+    import tpch_legs
+    import tpch_plans
+
+    n_orders = 90_000
+    whole1 = tpch_legs.Legs(n_orders, queries=[1]).q1()
+    got1, _ = tpch_plans.oracle_q1_at_scale(n_orders, n_parts=7, threads=3)
+    assert got1 == whole1 and len(got1) == 4
+    whole3 = tpch_legs.Legs(n_orders, queries=[3]).q3()
+    got3, _ = tpch_plans.oracle_q3_at_scale(n_orders, n_parts=7, threads=3)
+    assert len(whole3) > 50 and got3[:10] == whole3[:10]
+    assert tpch_plans.matches_legs(3, whole3[:10], got3) and not tpch_plans.matches_legs(3, whole3[1:11], got3)
+    assert tpch_plans.matches_legs(1, whole1, got1) and not tpch_plans.matches_legs(1, whole1[:3], got1) and not tpch_plans.matches_legs(6, [], [])
+
+
 def test_set_op_and_window_steps_are_checked():
     """the steps the dump consumer emits for set operations and windows (round 4): both inputs of a set_op must exist and it needs its kind and the
     two column lists; a window needs its functions"""

@@ -370,6 +370,24 @@ def _canon(table):
     return rows
 
 
+# LIMIT queries whose ORDER BY keys do not decide every tie: (limit, key of a result row); compared on the key sequence + membership
+_LIMITS = {3: (10, lambda r: (-r[1], r[2])), 10: (20, lambda r: -r[2]), 18: (100, lambda r: (-r[4], r[3]))}
+
+
+def matches_legs(q, got, want):
+    """GPU result rows of TPC-H Q`q` (in the legs' conventions, _canon) against the oracle leg's rows: bit-exact row for row; LIMIT queries on
+    their ORDER BY keys + membership (ties beyond the keys are unspecified in the reference too); Q5 / Q11 (ORDER BY one aggregate) up to
+    swaps of equal values.  An empty oracle result never counts as a match (the check would be vacuous)."""
+    if not want:
+        return False
+    if q in _LIMITS:
+        k, key = _LIMITS[q]
+        return bool(len(got) == min(k, len(want)) and [key(r) for r in got] == [key(r) for r in want[: len(got)]] and set(got) <= set(want))
+    if q in (5, 11):
+        return bool([r[1] for r in got] == [r[1] for r in want] and sorted(got) == sorted(want))
+    return bool(got == want)
+
+
 def cpu_baseline(queries, sample_sf, runs="1+3", budget_s=100.0, ctx=None, narrow=False, checks=None):
     """The oracle legs (oracle/tpch_legs.py: the C restatement of the reference's CPU path — morsels of
     20 000 rows, HashIndexedView / PreAggregationHashtable restated — plus numpy for the few rows after
@@ -439,18 +457,13 @@ def cpu_baseline(queries, sample_sf, runs="1+3", budget_s=100.0, ctx=None, narro
             g_med[q] = statistics.median(ts)
         out["gpu_same_sample"] = {"value": round(math.exp(sum(math.log(max(g_med[q], 1e-9)) for q in done) / max(len(done), 1)), 3), "unit": "ms",
                                   "per_query_median_ms": {"Q%d" % q: round(g_med[q], 3) for q in done}, "protocol": "1 warm-up + 3 measured, host wall clock around plan + result hand-over"}
-        if checks is not None:  # BASELINE configs[1] / [2] at the sample scale: bit-exact against the oracle legs, in this run
+        if checks is not None:  # every measured query at the sample scale, bit-exact against the oracle legs, in this run (BASELINE configs[1] / [2] are Q1 / Q3)
             ver = {}
-            for q in (1, 6, 3):
-                if q not in got or q not in leg_rows:
-                    continue
-                g, w = _canon(got[q]), leg_rows[q]
-                if q == 3:  # LIMIT 10: ORDER BY keys in order + membership (ties beyond the keys are unspecified)
-                    key = lambda r: (-r[1], r[2])  # noqa: E731
-                    ver["Q3"] = bool(len(g) == min(10, len(w)) and [key(r) for r in g] == [key(r) for r in w[: len(g)]] and set(g) <= set(w))
-                else:
-                    ver["Q%d" % q] = bool(g == w and len(w) > 0)
+            for q in done:
+                if q in got and q in leg_rows:
+                    ver["Q%d" % q] = matches_legs(q, _canon(got[q]), leg_rows[q])
             checks["oracle_bit_exact_at_sample_sf%g" % sample_sf] = ver
+            checks["oracle_bit_exact_at_sample_all"] = bool(ver) and all(ver.values())
     return out
 
 
@@ -488,3 +501,96 @@ def oracle_q6_at_scale(n_orders, n_parts=256, threads=None):
         parts = list(pool.map(_oracle_q6_slice, [(n_orders, part, n_parts) for part in range(n_parts)]))
     vals = [v for v in parts if v is not None]
     return (sum(vals) if vals else None), time.time() - t0
+
+
+def _slice_paths():
+    import sys
+
+    for sub in ("oracle", "tests", "lingo-db_amd"):
+        path = os.path.join(ROOT, sub)
+        if path not in sys.path:
+            sys.path.insert(0, path)
+
+
+def _oracle_q1_slice(job):
+    """one slice of oracle_q1_at_scale: the oracle's Q1 partial sums and counts per (returnflag, linestatus)"""
+    n_orders, part, n_parts = job
+    _slice_paths()
+    import oracle_bind
+    import tpch_data as T
+    import tpch_legs
+
+    leg = tpch_legs.Legs(n_orders, threads=1, queries=[1])
+    leg._tables[T.LINEITEM] = oracle_bind.HostTable(T.host_table(T.LINEITEM, n_orders, part=part, n_parts=n_parts, cols=tpch_legs.Legs.NEED[T.LINEITEM][1]))
+    return leg.q1_partials()
+
+
+def oracle_q1_at_scale(n_orders, n_parts=256, threads=None):
+    """TPC-H Q1 (BASELINE configs[1]) by the ORACLE over the bench's own scale: lineitem generated on the host slice by slice (the counter-based
+    generator the device uses), each slice through the oracle's Q1 leg up to its SUMs and COUNT (oracle/tpch_legs.py q1_partials: the C restatement of
+    scan + restriction + PreAggregationHashtable), the partials added in Python integers, the averages taken at the end (q1_finish).
+    Returns (rows in the legs' conventions, seconds)."""
+    import concurrent.futures
+    import time
+
+    _slice_paths()
+    import tpch_legs
+
+    t0 = time.time()
+    workers = threads or min(64, os.cpu_count() or 8)
+    total = {}
+    with concurrent.futures.ThreadPoolExecutor(workers) as pool:
+        for partial in pool.map(_oracle_q1_slice, [(n_orders, part, n_parts) for part in range(n_parts)]):
+            for key, vals in partial.items():
+                acc = total.setdefault(key, [0] * len(vals))
+                for i, v in enumerate(vals):
+                    acc[i] += v
+    return tpch_legs.Legs.q1_finish(total), time.time() - t0
+
+
+def _oracle_q3_slice(job):
+    """one order-range slice of oracle_q3_at_scale: the oracle's Q3 over (all customers, the slice's orders, the slice's lineitems) — orders and
+    lineitem are cut at the same order boundaries, so every group (l_orderkey) lies inside one slice; the slice's best rows by (revenue desc,
+    orderdate), with everything that ties with the tenth"""
+    n_orders, part, n_parts, customer, keep = job
+    _slice_paths()
+    import oracle_bind
+    import tpch_data as T
+    import tpch_legs
+
+    leg = tpch_legs.Legs(n_orders, threads=1, queries=[3])
+    leg._tables[T.CUSTOMER] = customer
+    for tid in (T.ORDERS, T.LINEITEM):
+        leg._tables[tid] = oracle_bind.HostTable(T.host_table(tid, n_orders, part=part, n_parts=n_parts, cols=tpch_legs.Legs.NEED[tid][3]))
+    rows = leg.q3()  # sorted by (-revenue, orderdate)
+    if len(rows) > keep:
+        last = (rows[keep - 1][1], rows[keep - 1][2])
+        cut = keep
+        while cut < len(rows) and (rows[cut][1], rows[cut][2]) == last:
+            cut += 1
+        rows = rows[:cut]
+    return rows
+
+
+def oracle_q3_at_scale(n_orders, n_parts=256, threads=None, keep=10):
+    """TPC-H Q3 (BASELINE configs[2]) by the ORACLE over the bench's own scale: customer generated whole (15 M rows at SF100, two columns), orders and
+    lineitem slice by slice at the same order boundaries; every slice runs the oracle's Q3 leg (C restatement of the scans, both hash joins and the
+    aggregation) and keeps its ten best rows (+ ties); the merged list sorted by the query's ORDER BY is what the caller compares the GPU's ten rows
+    with (matches_legs: key sequence + membership).  Returns (rows, seconds)."""
+    import concurrent.futures
+    import time
+
+    _slice_paths()
+    import oracle_bind
+    import tpch_data as T
+    import tpch_legs
+
+    t0 = time.time()
+    customer = oracle_bind.HostTable(T.host_table(T.CUSTOMER, n_orders, cols=tpch_legs.Legs.NEED[T.CUSTOMER][3]))
+    workers = threads or min(64, os.cpu_count() or 8)
+    rows = []
+    with concurrent.futures.ThreadPoolExecutor(workers) as pool:
+        for part_rows in pool.map(_oracle_q3_slice, [(n_orders, part, n_parts, customer, keep) for part in range(n_parts)]):
+            rows.extend(part_rows)
+    rows.sort(key=lambda r: (-r[1], r[2]))
+    return rows, time.time() - t0
