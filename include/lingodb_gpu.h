@@ -187,7 +187,15 @@ typedef struct ldb_trace ldb_trace;
 typedef enum { LDB_TRACE_OFF = 0, LDB_TRACE_RECORDED = 1, LDB_TRACE_REPLAYED = 2, LDB_TRACE_MISSED = 3 } ldb_trace_status;
 int32_t ldb_gpu_trace_create(ldb_ctx* ctx, ldb_trace** out);
 int32_t ldb_gpu_trace_destroy(ldb_ctx* ctx, ldb_trace* t);
+/* allow_replay: bit 0 = replay if the trace holds a complete record; LDB_TRACE_COLLECTIVE = the plan exchanges rows with other ranks
+ * (ldb_gpu_allgather / _shuffle): all ranks must pass the same bit 0 (agree with ldb_gpu_comm_agree on the minimum of
+ * ldb_gpu_trace_replayable first), the exchanges' metadata reads are replayed like any count — the transfers of a replayed plan are queued
+ * with the recorded sizes on every rank, no rank waits for another's counts — and a rank whose replayed count turns out wrong runs on over
+ * the recorded sizes (its peers are queued against them) and reports LDB_TRACE_MISSED at the end; the ranks then agree on the minimum of
+ * their verdicts and all of them repeat the execution recording. */
+#define LDB_TRACE_COLLECTIVE 2
 int32_t ldb_gpu_trace_begin(ldb_ctx* ctx, ldb_trace* t, int32_t allow_replay);
+int32_t ldb_gpu_trace_replayable(const ldb_trace* t); /* 1 = _begin with bit 0 would replay */
 int32_t ldb_gpu_trace_end(ldb_ctx* ctx, int32_t* status); /* synchronises the stream; *status = ldb_trace_status */
 int32_t ldb_gpu_trace_stats(const ldb_trace* t, int64_t* entries, int64_t* records, int64_t* replays, int64_t* misses);
 /* descriptor cache of the context (descriptors of a repeated plan are byte-identical: uploaded once) */
@@ -243,7 +251,11 @@ int32_t ldb_gpu_table_col_width(const ldb_table* t, int32_t col);
  * call encodes a column of a smaller table.  *n_distinct / the return of _dict_size: dictionary entries, -1 = not encoded. */
 int32_t ldb_gpu_table_dict_encode(ldb_ctx* ctx, ldb_table* t, int32_t col, int32_t* n_distinct);
 int32_t ldb_gpu_table_dict_size(const ldb_table* t, int32_t col);
-/* raw device pointers (for RCCL exchange / zero-copy wrap); offsets/validity may be NULL */
+/* raw device pointers (for RCCL exchange / zero-copy wrap); offsets/validity may be NULL.  The table's content stamp (ldb_gpu_table_stamp)
+ * does NOT change when somebody writes through these pointers: a writer calls ldb_gpu_table_set_rows (same row count is fine) or
+ * ldb_gpu_table_write_fixed afterwards so that prepared plans record afresh.  A plan that replays over silently changed bytes is still
+ * caught — its recorded counts are compared with the real ones at the end and the execution is repeated (LDB_TRACE_MISSED) — but that
+ * costs one wasted execution. */
 int32_t ldb_gpu_table_col_ptrs(const ldb_table* t, int32_t col, void** values, void** offsets, void** validity,
                                int64_t* value_bytes);
 /* shrink the logical row count (receive buffers allocated at capacity) */
@@ -619,6 +631,9 @@ int32_t ldb_gpu_comm_create_host(int32_t rank, int32_t world, const void* id128,
 /* raw all-to-all of bytes (one grouped batch): send_bytes[p] bytes of `send` (peer runs back to back) go to peer p,
  * recv_bytes[p] bytes from peer p arrive in `recv` (peer runs back to back).  Device pointers for a device
  * communicator, host pointers for ldb_gpu_comm_create_host */
+/* *all_min = the minimum of `mine` over all ranks (one 8-byte transfer to and from every peer + one wait): how the ranks of a sharded
+ * prepared plan agree to replay together and, afterwards, whether every rank's replay was confirmed.  ctx may be NULL for a host communicator. */
+int32_t ldb_gpu_comm_agree(ldb_ctx* ctx, ldb_comm* comm, int32_t mine, int32_t* all_min);
 int32_t ldb_gpu_comm_alltoall_bytes(ldb_comm* comm, const void* send, const int64_t* send_bytes, void* recv, const int64_t* recv_bytes);
 /* every rank's rows of `t` concatenated in rank order on every rank (replicated small build sides,
  * partial aggregates; fixed-width and utf8 columns, validity bitmaps travel along) */

@@ -124,8 +124,17 @@ struct Transport {
    void timed_open() {
       t_open = std::chrono::steady_clock::now();
       if (ev_ctx) {
+         // a process that never asks for statistics must not pile up events: pairs the device has finished are folded as we go
+         while (ev_pending.size() > 32 && ev_pending.front().second && hipEventQuery(ev_pending.front().second) == hipSuccess) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev_pending.front().first, ev_pending.front().second) == hipSuccess) dev_ms += ms;
+            ev_free.push_back(ev_pending.front().first);
+            ev_free.push_back(ev_pending.front().second);
+            ev_pending.erase(ev_pending.begin());
+         }
          hipEvent_t a = event();
          if (a && hipEventRecord(a, ev_ctx->stream) == hipSuccess) ev_pending.push_back({a, nullptr});
+         else if (a) ev_free.push_back(a);
       }
    }
    void timed_close() {
@@ -133,8 +142,13 @@ struct Transport {
       host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_open).count();
       if (ev_ctx && !ev_pending.empty() && !ev_pending.back().second) {
          hipEvent_t b = event();
-         if (b && hipEventRecord(b, ev_ctx->stream) == hipSuccess) ev_pending.back().second = b;
-         else ev_pending.pop_back();
+         if (b && hipEventRecord(b, ev_ctx->stream) == hipSuccess) {
+            ev_pending.back().second = b;
+         } else {
+            if (b) ev_free.push_back(b);
+            ev_free.push_back(ev_pending.back().first);
+            ev_pending.pop_back();
+         }
       }
    }
    void fold_events() { // (waits for the last group to finish on the device)
@@ -516,6 +530,17 @@ __global__ void k_count_zero_bytes(const uint8_t* __restrict__ bytes, uint64_t n
    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
+#define PICK_MAX 32
+struct PickList {
+   int32_t n, pad;
+   int64_t idx[PICK_MAX];
+};
+// out[i] = src[idx[i]] (0 for idx < 0): the string offsets at the run boundaries of an exchange, gathered for one read-back
+__global__ void k_pick_i64(const int64_t* __restrict__ src, PickList pl, int64_t* __restrict__ out) {
+   const int i = (int) threadIdx.x;
+   if (i < pl.n) out[i] = pl.idx[i] >= 0 ? src[pl.idx[i]] : 0;
+}
+
 // ---------------------------------------------------------------- the exchange
 // Every rank sends the rows [send_off[p], send_off[p] + send_cnt[p]) of `t` to peer p and receives
 // recv_cnt[p] rows from it; the result holds the received rows in peer order.  allgather = every peer
@@ -617,17 +642,33 @@ static int32_t exchange(ldb_ctx* ctx, ldb_comm* c, const ldb_table* t, const std
    // ---- metadata per destination peer: [rows, bytes of every utf8 column, per column: validity flag, width, type]
    const int mw = 1 + nu + 3 * nc; // words per (sender, receiver) pair
    std::vector<int64_t> meta((size_t) world * mw, 0);
+   // byte ranges of the utf8 columns per peer: the offsets at the run boundaries, picked on the device and read back ONCE for all columns
+   // (a read-back like any count: recorded / replayed inside a trace)
    std::vector<std::vector<int64_t>> h_offs((size_t) nu);
-   for (int u = 0; u < nu; u++) { // byte ranges of the utf8 columns per peer: the offsets at the run boundaries, ONE read-back per column
-      const ldb_column& col = t->cols[(size_t) ucols[(size_t) u]];
-      h_offs[(size_t) u].assign((size_t) world * 2, 0);
-      for (int p = 0; p < world; p++) {
-         if (send_cnt[(size_t) p] <= 0) continue;
-         LDB_HIP(hipMemcpyAsync(&h_offs[(size_t) u][(size_t) p * 2], col.offsets + send_off[(size_t) p], 8, hipMemcpyDeviceToHost, ctx->stream));
-         LDB_HIP(hipMemcpyAsync(&h_offs[(size_t) u][(size_t) p * 2 + 1], col.offsets + send_off[(size_t) p] + send_cnt[(size_t) p], 8, hipMemcpyDeviceToHost, ctx->stream));
+   for (int u = 0; u < nu; u++) h_offs[(size_t) u].assign((size_t) world * 2, 0);
+   if (nu) {
+      int64_t* d_pick;
+      const size_t n_pick = (size_t) nu * 2 * (size_t) world;
+      LDB_TRY(bufs.alloc(&d_pick, 8 * n_pick));
+      for (int u = 0; u < nu; u++) {
+         const ldb_column& col = t->cols[(size_t) ucols[(size_t) u]];
+         for (int p0 = 0; p0 < world; p0 += PICK_MAX / 2) {
+            PickList pl;
+            pl.n = 0;
+            for (int p = p0; p < world && pl.n + 2 <= PICK_MAX; p++) {
+               const bool any = send_cnt[(size_t) p] > 0;
+               pl.idx[pl.n++] = any ? send_off[(size_t) p] : -1;
+               pl.idx[pl.n++] = any ? send_off[(size_t) p] + send_cnt[(size_t) p] : -1;
+            }
+            hipLaunchKernelGGL(k_pick_i64, dim3(1), dim3(64), 0, ctx->stream, (const int64_t*) col.offsets, pl, d_pick + ((size_t) u * world + (size_t) p0) * 2);
+         }
       }
+      LDB_HIP(hipGetLastError());
+      std::vector<int64_t> picked(n_pick, 0);
+      LDB_TRY(LDB_READBACK(ctx, picked.data(), d_pick, 8 * n_pick));
+      for (int u = 0; u < nu; u++)
+         for (int k = 0; k < 2 * world; k++) h_offs[(size_t) u][(size_t) k] = picked[(size_t) u * 2 * world + (size_t) k];
    }
-   if (nu) LDB_HIP(hipStreamSynchronize(ctx->stream));
    for (int p = 0; p < world; p++) {
       int64_t* m = &meta[(size_t) p * mw];
       m[0] = send_cnt[(size_t) p];
@@ -642,8 +683,8 @@ static int32_t exchange(ldb_ctx* ctx, ldb_comm* c, const ldb_table* t, const std
    int64_t *d_send, *d_recv;
    LDB_TRY(bufs.alloc(&d_send, 8 * meta.size()));
    LDB_TRY(bufs.alloc(&d_recv, 8 * meta.size()));
-   LDB_HIP(hipMemcpyAsync(d_send, meta.data(), 8 * meta.size(), hipMemcpyHostToDevice, ctx->stream));
-   LDB_HIP(hipStreamSynchronize(ctx->stream)); // (meta is a host vector)
+   LDB_TRY(ldb_h2d_small(ctx, d_send, meta.data(), 8 * meta.size())); // (through the pinned ring: `meta` may die before the copy runs)
+   if (8 * meta.size() > LDB_RING_BYTES / 8) LDB_HIP(hipStreamSynchronize(ctx->stream)); // (too large for the ring: copied from the vector itself)
    GroupGuard grp(tr);
    LDB_TRY(grp.start());
    for (int p = 0; p < world; p++) {
@@ -651,9 +692,10 @@ static int32_t exchange(ldb_ctx* ctx, ldb_comm* c, const ldb_table* t, const std
       LDB_TRY(tr->recv(d_recv + (size_t) p * mw, 8 * (size_t) mw, p));
    }
    LDB_TRY(grp.end());
+   // what the peers send: a read-back like any count — a replaying plan takes the recorded metadata and queues the data transfers at once
+   // (every rank replays the same execution: sender and receiver use the same recorded sizes), the real words are checked at the trace's end
    std::vector<int64_t> rmeta((size_t) world * mw);
-   LDB_HIP(hipMemcpyAsync(rmeta.data(), d_recv, 8 * rmeta.size(), hipMemcpyDeviceToHost, ctx->stream));
-   LDB_HIP(hipStreamSynchronize(ctx->stream));
+   LDB_TRY(LDB_READBACK(ctx, rmeta.data(), d_recv, 8 * rmeta.size()));
    // ---- every rank must have passed the same schema (count is implied by mw: a mismatch garbles the words below)
    for (int p = 0; p < world; p++)
       for (int k = 0; k < nc; k++) {
@@ -749,8 +791,7 @@ static int32_t exchange(ldb_ctx* ctx, ldb_comm* c, const ldb_table* t, const std
          }
       }
       std::vector<unsigned long long> nulls(vcols.size(), 0);
-      LDB_HIP(hipMemcpyAsync(nulls.data(), d_nulls, 8 * vcols.size(), hipMemcpyDeviceToHost, ctx->stream));
-      LDB_HIP(hipStreamSynchronize(ctx->stream));
+      LDB_TRY(LDB_READBACK(ctx, nulls.data(), d_nulls, 8 * vcols.size()));
       for (size_t v = 0; v < vcols.size(); v++) {
          ldb_column& dst = res.t->cols[(size_t) vcols[v]];
          dst.null_count = (int64_t) nulls[v];
@@ -787,6 +828,56 @@ extern "C" int32_t ldb_gpu_shuffle(ldb_ctx* ctx, ldb_comm* c, ldb_rel* in, const
    std::vector<int64_t> counts((size_t) c->world, 0);
    LDB_TRY(ldb_gpu_partition(ctx, in, keys, n_keys, c->world, cols, n_cols, &packed.t, counts.data()));
    return ldb_gpu_alltoall(ctx, c, packed.t, counts.data(), name, out);
+}
+
+extern "C" int32_t ldb_gpu_comm_agree(ldb_ctx* ctx, ldb_comm* c, int32_t mine, int32_t* all_min) {
+   if (!c || !all_min) LDB_FAIL(LDB_ERR_INVALID, "comm_agree: NULL argument");
+   const int world = c->world;
+   if (world == 1) {
+      *all_min = mine;
+      return LDB_OK;
+   }
+   if (world > 63) LDB_FAIL(LDB_ERR_UNSUPPORTED, "comm_agree: more than 63 ranks");
+   std::vector<int64_t> h((size_t) world + 1, 0);
+   h[0] = mine;
+   int64_t *send = h.data(), *recv = h.data() + 1;
+   void* dev = nullptr;
+   if (ctx) { // a device communicator moves device memory: [mine | one word per peer]
+      LDB_TRY(ldb_dev_alloc(ctx, &dev, 8 * ((size_t) world + 1)));
+      send = (int64_t*) dev;
+      recv = send + 1;
+      const int32_t st = ldb_h2d_small(ctx, send, h.data(), 8);
+      if (st != LDB_OK) {
+         ldb_dev_free(ctx, dev);
+         return st;
+      }
+   }
+   int32_t st = LDB_OK;
+   {
+      GroupGuard grp(c->t.get());
+      st = grp.start();
+      for (int p = 0; p < world && st == LDB_OK; p++) {
+         st = c->t->send(send, 8, p);
+         if (st == LDB_OK) st = c->t->recv(recv + p, 8, p);
+      }
+      if (st == LDB_OK) st = grp.end();
+   }
+   if (st == LDB_OK && ctx) {
+      hipError_t e = hipMemcpyAsync(ctx->h_scratch, recv, 8 * (size_t) std::min(world, 63), hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) {
+         ldb_set_error("comm_agree: %s", hipGetErrorString(e));
+         st = LDB_ERR_HIP;
+      } else {
+         memcpy(h.data() + 1, ctx->h_scratch, 8 * (size_t) std::min(world, 63));
+      }
+   }
+   if (ctx) ldb_dev_free(ctx, dev);
+   if (st != LDB_OK) return st;
+   int64_t m = mine;
+   for (int p = 0; p < world; p++) m = std::min(m, h[(size_t) p + 1]);
+   *all_min = (int32_t) m;
+   return LDB_OK;
 }
 
 // raw all-to-all of bytes: send_bytes[p] bytes from `send` (peer runs back to back) to peer p, recv_bytes[p]

@@ -65,6 +65,13 @@ extern "C" int64_t ldb_gpu_get_option(const char* name) {
 }
 /* (ldb_gpu_set_option(name, v) with the use site's default restores the default behaviour) */
 
+double ldb_host_trace_threshold() {
+   static const double thr = [] {
+      const char* e = getenv("LDB_HOST_TRACE");
+      return e && *e ? atof(e) : -1.0;
+   }();
+   return thr;
+}
 // ---------------------------------------------------------------- memory
 // size classes of the block cache: 8 per doubling (≤ 12.5 % internal waste), 256 B minimum
 static size_t ldb_size_class(size_t bytes) {
@@ -96,7 +103,11 @@ int32_t ldb_dev_alloc(ldb_ctx* ctx, void** out, size_t bytes) {
          return LDB_OK;
       }
    }
-   hipError_t e = hipMallocAsync(out, cls, ctx->stream);
+   hipError_t e;
+   {
+      LdbSlow slow_("hipMallocAsync", cls);
+      e = hipMallocAsync(out, cls, ctx->stream);
+   }
    if (e != hipSuccess && ctx->cache_bytes) { // the parked blocks are the only memory we can give back
       (void) hipGetLastError();
       ldb_cache_release(ctx);
@@ -109,9 +120,14 @@ int32_t ldb_dev_alloc(ldb_ctx* ctx, void** out, size_t bytes) {
 }
 void ldb_dev_free(ldb_ctx* ctx, void* p) {
    if (!p) return;
-   if (ctx->desc_blocks.count(p)) return; // a cached descriptor (ldb_dev_upload): owned by the cache
+   auto dref = ctx->desc_blocks.find(p);
+   if (dref != ctx->desc_blocks.end()) { // a cached descriptor (ldb_dev_upload): owned by the cache, this holder is done with it
+      if (dref->second > 0) dref->second--;
+      return;
+   }
    auto it = ctx->live.find(p);
    if (it == ctx->live.end()) {
+      LdbSlow slow_("hipFreeAsync (untracked block)");
       (void) hipFreeAsync(p, ctx->stream);
       return;
    }
@@ -123,6 +139,7 @@ void ldb_dev_free(ldb_ctx* ctx, void* p) {
       std::push_heap(heap.begin(), heap.end(), std::greater<void*>());
       ctx->cache_bytes += cls;
    } else {
+      LdbSlow slow_("hipFreeAsync (cache full)", cls);
       (void) hipFreeAsync(p, ctx->stream);
    }
 }
@@ -130,8 +147,8 @@ void ldb_dev_free(ldb_ctx* ctx, void* p) {
 // block cache above hands out the same addresses), so the device copy made by the previous execution can be used as it is:
 // no staging, no H2D copy, no allocation.  Entries are keyed by a 64-bit content hash and verified by memcmp; kernels take
 // descriptors as `const D*`, nothing on the device ever writes one.  ldb_dev_free recognises a cached block and leaves it
-// alone.  Bounded (desc_cache_mb, default 64 MB): when full, everything is dropped — stream-ordered frees, so launches that
-// still read an entry are unaffected.  Option desc_cache = 0 switches it off.
+// alone (it only gives its reference back).  Bounded (desc_cache_mb, default 64 MB): when full, every entry that no operator
+// holds any more is dropped (stream-ordered frees, so launches already queued are unaffected).  Option desc_cache = 0 switches it off.
 static uint64_t desc_hash(const void* p, size_t bytes) {
    const uint8_t* b = (const uint8_t*) p;
    uint64_t h = 0x9E3779B97F4A7C15ull ^ bytes;
@@ -145,19 +162,34 @@ static uint64_t desc_hash(const void* p, size_t bytes) {
    for (; i < bytes; i++) h = (h ^ b[i]) * 0x100000001B3ull;
    return h ^ (h >> 32);
 }
-static void desc_cache_drop(ldb_ctx* ctx) {
-   for (auto& kv : ctx->desc_cache) (void) hipFreeAsync(kv.second.dev, ctx->stream);
-   ctx->desc_cache.clear();
-   ctx->desc_blocks.clear();
-   ctx->desc_bytes = 0;
+// eviction: only entries no operator holds (reference count 0 — every ldb_dev_upload is paired with an ldb_dev_free of the pointer it
+// returned); an entry that is still referenced keeps its device copy and its place in the cache, so a pointer handed out earlier never
+// dangles and is never freed twice.  `force` (context teardown) drops everything.
+static void desc_cache_drop(ldb_ctx* ctx, bool force = false) {
+   for (auto it = ctx->desc_cache.begin(); it != ctx->desc_cache.end();) {
+      auto ref = ctx->desc_blocks.find(it->second.dev);
+      if (!force && ref != ctx->desc_blocks.end() && ref->second > 0) {
+         ++it;
+         continue;
+      }
+      (void) hipFreeAsync(it->second.dev, ctx->stream);
+      ctx->desc_bytes -= std::min(ctx->desc_bytes, it->second.copy.size());
+      if (ref != ctx->desc_blocks.end()) ctx->desc_blocks.erase(ref);
+      it = ctx->desc_cache.erase(it);
+   }
+   if (force) {
+      ctx->desc_blocks.clear();
+      ctx->desc_bytes = 0;
+   }
 }
-static int32_t upload_raw(ldb_ctx* ctx, void* dev, const void* host, size_t bytes) {
+int32_t ldb_h2d_small(ldb_ctx* ctx, void* dev, const void* host, size_t bytes) {
    // descriptors (a few KB) are staged through a pinned ring so that the copy is a plain async DMA
    // (a pageable source makes the runtime stage it synchronously, ~10 µs per call); `host` may be a
    // local either way.  A slot is reused only after the stream has drained (wrap → synchronize).
    const size_t need = (bytes + 63) & ~(size_t) 63;
    if (ctx->h_ring && need <= LDB_RING_BYTES / 8) {
       if (ctx->ring_pos + need > LDB_RING_BYTES) {
+         LdbSlow slow_("staging ring wrap: hipStreamSynchronize");
          LDB_HIP(hipStreamSynchronize(ctx->stream));
          ctx->ring_pos = 0;
       }
@@ -178,6 +210,7 @@ int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_
       for (auto it = range.first; it != range.second; ++it)
          if (it->second.copy.size() == bytes && memcmp(it->second.copy.data(), host, bytes) == 0) {
             *dev_out = it->second.dev;
+            ctx->desc_blocks[it->second.dev]++;
             ctx->desc_hits++;
             return LDB_OK;
          }
@@ -186,7 +219,7 @@ int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_
       void* dev = nullptr;
       LDB_TRY(ldb_dev_alloc(ctx, &dev, bytes)); // from the block cache; the cache entry takes it out of circulation
       ctx->live.erase(dev);
-      int32_t st = upload_raw(ctx, dev, host, bytes);
+      int32_t st = ldb_h2d_small(ctx, dev, host, bytes);
       if (st != LDB_OK) {
          (void) hipFreeAsync(dev, ctx->stream);
          return st;
@@ -195,14 +228,14 @@ int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_
       e.dev = dev;
       e.copy.assign((const uint8_t*) host, (const uint8_t*) host + bytes);
       ctx->desc_cache.emplace(h, std::move(e));
-      ctx->desc_blocks.insert(dev);
+      ctx->desc_blocks[dev] = 1;
       ctx->desc_bytes += bytes;
       ctx->desc_misses++;
       *dev_out = dev;
       return LDB_OK;
    }
    LDB_TRY(ldb_dev_alloc(ctx, dev_out, bytes));
-   return upload_raw(ctx, *dev_out, host, bytes);
+   return ldb_h2d_small(ctx, *dev_out, host, bytes);
 }
 
 // ---------------------------------------------------------------- read-backs (ldb_internal.h: ldb_readback)
@@ -248,20 +281,25 @@ int32_t ldb_counters(ldb_ctx* ctx, int n_words, uint64_t** out) {
    if (need > LDB_ARENA_WORDS) LDB_FAIL(LDB_ERR_INVALID, "ldb_counters: %d words", n_words);
    if (ctx->arena_pos + need > LDB_ARENA_WORDS) { // wrap: what a replaying trace still wants from the old words is collected first
       LDB_TRY(log_flush(ctx));
-      LDB_HIP(hipMemsetAsync(ctx->arena, 0, 8 * LDB_ARENA_WORDS, ctx->stream));
+      // words handed out earlier may not have been read back yet (a caller that allocates, launches and meets a nested allocation
+      // before its read-back): nothing is cleared wholesale — from here until the next restart every allocation clears its own range
+      ctx->arena_wrapped = true;
       ctx->arena_pos = 0;
    }
    *out = ctx->arena + ctx->arena_pos;
+   if (ctx->arena_wrapped) LDB_HIP(hipMemsetAsync(*out, 0, 8 * need, ctx->stream));
    ctx->arena_pos += need;
    return LDB_OK;
 }
 // a plan starts at word 0 (the same words every execution → byte-identical descriptors): one clear of what the last one used
 static int32_t arena_restart(ldb_ctx* ctx) {
-   if (ctx->arena && ctx->arena_pos) LDB_HIP(hipMemsetAsync(ctx->arena, 0, 8 * ctx->arena_pos, ctx->stream));
+   if (ctx->arena && (ctx->arena_pos || ctx->arena_wrapped)) LDB_HIP(hipMemsetAsync(ctx->arena, 0, 8 * (ctx->arena_wrapped ? (size_t) LDB_ARENA_WORDS : ctx->arena_pos), ctx->stream));
    ctx->arena_pos = 0;
+   ctx->arena_wrapped = false;
    return LDB_OK;
 }
 static int32_t readback_sync(ldb_ctx* ctx, void* host, const void* dev, size_t bytes) {
+   LdbSlow slow_("read-back with a stream wait", bytes);
    if (bytes <= 512 && ctx->h_scratch) { // a pinned landing area: the copy is a plain DMA / blit, no staging by the runtime
       LDB_HIP(hipMemcpyAsync(ctx->h_scratch, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
       LDB_HIP(hipStreamSynchronize(ctx->stream));
@@ -274,6 +312,7 @@ static int32_t readback_sync(ldb_ctx* ctx, void* host, const void* dev, size_t b
 }
 // replay: everything read so far must equal the record
 static bool trace_prefix_ok(ldb_ctx* ctx, size_t upto_entries) {
+   LdbSlow slow_("trace check: wait for the replayed plan", upto_entries);
    if (log_flush(ctx) != LDB_OK) return false;
    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
    const ldb_trace* t = ctx->trace;
@@ -286,13 +325,16 @@ static bool trace_prefix_ok(ldb_ctx* ctx, size_t upto_entries) {
 int32_t ldb_readback(ldb_ctx* ctx, void* host, const void* dev, size_t bytes, uint32_t site, int flags) {
    if (bytes == 0) return LDB_OK;
    if (ctx->trace_mode == 0 || bytes > LDB_RB_MAX) return readback_sync(ctx, host, dev, bytes);
-   if (ctx->trace_poisoned) LDB_FAIL(LDB_ERR_RETRY, "read-back after a mis-speculated value (the plan execution is being repeated)");
+   // a mis-speculated execution is void.  Alone, the rank stops at once (LDB_ERR_RETRY); inside a COLLECTIVE trace (a plan that exchanges rows
+   // with other ranks) it runs on over the recorded counts — its peers are queued against exactly those transfer sizes and would wait for ever
+   // for a rank that left — and the verdict at the trace's end makes every rank repeat the execution
+   if (ctx->trace_poisoned && !ctx->trace_collective) LDB_FAIL(LDB_ERR_RETRY, "read-back after a mis-speculated value (the plan execution is being repeated)");
    ldb_trace* t = ctx->trace;
    if (flags & LDB_RB_NEVER_REPLAY) { // not a function of the data alone: read for real, in both modes, and keep out of the record
-      if (ctx->trace_mode == 2 && !trace_prefix_ok(ctx, ctx->trace_pos)) {
+      if (ctx->trace_mode == 2 && !ctx->trace_poisoned && !trace_prefix_ok(ctx, ctx->trace_pos)) {
          ctx->trace_poisoned = true;
          t->misses++;
-         LDB_FAIL(LDB_ERR_RETRY, "a replayed read-back differs from the recorded value");
+         if (!ctx->trace_collective) LDB_FAIL(LDB_ERR_RETRY, "a replayed read-back differs from the recorded value");
       }
       return readback_sync(ctx, host, dev, bytes);
    }
@@ -311,9 +353,9 @@ int32_t ldb_readback(ldb_ctx* ctx, void* host, const void* dev, size_t bytes, ui
       }
       // the execution took another path than the recorded one (a statistic is cached now, an option changed …): what was
       // replayed so far is checked, and from here on the execution records
-      if (!trace_prefix_ok(ctx, ctx->trace_pos)) {
+      if (ctx->trace_poisoned || !trace_prefix_ok(ctx, ctx->trace_pos)) {
+         if (!ctx->trace_poisoned) t->misses++;
          ctx->trace_poisoned = true;
-         t->misses++;
          LDB_FAIL(LDB_ERR_RETRY, "a replayed read-back differs from the recorded value");
       }
       t->diverged++;
@@ -358,9 +400,10 @@ extern "C" int32_t ldb_gpu_trace_begin(ldb_ctx* ctx, ldb_trace* t, int32_t allow
    ctx->trace = t;
    ctx->trace_pos = 0;
    ctx->trace_poisoned = false;
+   ctx->trace_collective = (allow_replay & LDB_TRACE_COLLECTIVE) != 0;
    ctx->log_pending.clear();
    LDB_TRY(arena_restart(ctx));
-   if (allow_replay && replay_wanted && t->complete && !t->entries.empty()) {
+   if ((allow_replay & 1) && replay_wanted && t->complete && !t->entries.empty()) {
       ctx->trace_mode = 2;
    } else {
       ctx->trace_mode = 1;
@@ -376,6 +419,7 @@ extern "C" int32_t ldb_gpu_trace_end(ldb_ctx* ctx, int32_t* status) {
    const int mode = ctx->trace_mode;
    ctx->trace = nullptr;
    ctx->trace_mode = 0;
+   ctx->trace_collective = false;
    if (!t || mode == 0) {
       *status = LDB_TRACE_OFF;
       if (t) t->complete = false;
@@ -416,6 +460,8 @@ extern "C" int32_t ldb_gpu_trace_end(ldb_ctx* ctx, int32_t* status) {
    *status = LDB_TRACE_RECORDED;
    return LDB_OK;
 }
+// would ldb_gpu_trace_begin(ctx, t, 1) replay?  (what the ranks of a sharded plan agree on BEFORE any of them begins: they replay together or not at all)
+extern "C" int32_t ldb_gpu_trace_replayable(const ldb_trace* t) { return t && t->complete && !t->entries.empty() && ldb_option("plan_replay", 1) != 0 ? 1 : 0; }
 extern "C" int32_t ldb_gpu_trace_stats(const ldb_trace* t, int64_t* entries, int64_t* records, int64_t* replays, int64_t* misses) {
    if (!t) LDB_FAIL(LDB_ERR_INVALID, "trace_stats: NULL trace");
    if (entries) *entries = (int64_t) t->entries.size();
@@ -473,7 +519,7 @@ extern "C" int32_t ldb_gpu_ctx_create(int32_t device_id, void* stream, ldb_ctx**
 extern "C" int32_t ldb_gpu_ctx_destroy(ldb_ctx* ctx) {
    if (!ctx) return LDB_OK;
    (void) hipSetDevice(ctx->device);
-   desc_cache_drop(ctx);
+   desc_cache_drop(ctx, true);
    ldb_cache_release(ctx);
    (void) hipStreamSynchronize(ctx->stream);
    for (auto e : ctx->timers) (void) hipEventDestroy(e);
@@ -1428,7 +1474,7 @@ int32_t ldb_column_range(ldb_ctx* ctx, const ldb_table* t, int32_t col, int64_t*
          dc.width = c.width;
          dc.precision = c.type.precision;
          dc.scale = c.type.scale;
-         LDB_HIP(hipMemcpyAsync(d_out, init, 16, hipMemcpyHostToDevice, ctx->stream));
+         LDB_TRY(ldb_h2d_small(ctx, d_out, init, 16)); // (pinned staging: a pageable source makes the copy wait for the stream)
          hipLaunchKernelGGL(k_column_range, dim3(ldb_grid_for(ctx, t->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dc, (uint64_t) t->n_rows, d_out);
          LDB_TRY(LDB_READBACK(ctx, got, d_out, 16));
       }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -156,7 +157,7 @@ struct ldb_ctx {
       std::vector<uint8_t> copy;
    };
    std::unordered_multimap<uint64_t, DescEntry> desc_cache;
-   std::unordered_set<void*> desc_blocks;
+   std::unordered_map<void*, int> desc_blocks; // device copy → operators holding it (ldb_dev_upload … ldb_dev_free)
    size_t desc_bytes = 0;
    int64_t desc_hits = 0, desc_misses = 0;
    // read-back trace (see ldb_readback)
@@ -164,6 +165,7 @@ struct ldb_ctx {
    int trace_mode = 0; // 0 none, 1 record, 2 replay
    size_t trace_pos = 0;
    bool trace_poisoned = false; // a replayed value was wrong: everything computed since is void
+   bool trace_collective = false; // the traced plan exchanges rows with other ranks: a mis-speculating rank runs on (see ldb_readback)
    uint8_t* h_log = nullptr; // pinned, LDB_LOG_BYTES
    // counter arena (ldb_counters): zeroed 64-bit device words handed out front to back — an operator's counters / flags / totals
    // are words nobody else touches until the arena wraps, so (a) no operator clears its counters itself (one clear per plan
@@ -171,6 +173,7 @@ struct ldb_ctx {
    // instead of one per read-back (ldb_readback defers reads of arena words)
    uint64_t* arena = nullptr; // device, LDB_ARENA_WORDS
    size_t arena_pos = 0;
+   bool arena_wrapped = false; // the arena wrapped inside the current plan: allocations clear their own range until the next restart
    struct LogCopy {
       uint64_t src;
       uint32_t off, bytes;
@@ -235,12 +238,32 @@ struct LdbProf {
    ~LdbProf();
 };
 
+// diagnostics (env LDB_HOST_TRACE=<ms>): host calls that took longer than <ms> milliseconds are reported on stderr with their site — how a
+// blocking call inside a replayed plan is found without a profiler (LDB_HOST_TRACE=0.2 python bench.py …)
+double ldb_host_trace_threshold();
+struct LdbSlow {
+   const char* what;
+   size_t arg;
+   double thr;
+   std::chrono::steady_clock::time_point t0;
+   LdbSlow(const char* w, size_t a = 0) : what(w), arg(a), thr(ldb_host_trace_threshold()) {
+      if (thr >= 0) t0 = std::chrono::steady_clock::now();
+   }
+   ~LdbSlow() {
+      if (thr < 0) return;
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (ms >= thr) fprintf(stderr, "[ldb host] %s(%zu): %.3f ms\n", what, arg, ms);
+   }
+};
 // device allocation helpers (stream-ordered pool)
 int32_t ldb_dev_alloc(ldb_ctx* ctx, void** out, size_t bytes);
 void ldb_dev_free(ldb_ctx* ctx, void* p);
 // upload a host descriptor struct into device memory (stream-ordered)
 // (read-only descriptors are cached by content, see ldb_core.hip; cacheable = false for memory a kernel will write)
 int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_out, bool cacheable = true);
+// a few bytes host → device through the pinned staging ring: a plain asynchronous DMA (hipMemcpyAsync from pageable memory is staged by the
+// runtime and WAITS for the stream — inside a replayed plan that is the whole queue)
+int32_t ldb_h2d_small(ldb_ctx* ctx, void* dev, const void* host, size_t bytes);
 
 // device temporaries of one call: whatever is still listed when the scope ends is freed (error returns included)
 struct LdbBufs {

@@ -644,7 +644,7 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
       } else {
          long long* range = (long long*) (ctx->d_scratch + 32);
          const long long init[2] = {INT64_MAX, INT64_MIN};
-         LDB_HIP(hipMemcpyAsync(range, init, 16, hipMemcpyHostToDevice, ctx->stream));
+         LDB_TRY(ldb_h2d_small(ctx, range, init, 16));
          DJoin* dr;
          LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dr));
          hipLaunchKernelGGL(k_join_key_range, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dr, range);
@@ -1145,6 +1145,10 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &op, 4 * (size_t) (produced ? produced : 1)));
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &ob, 4 * (size_t) (produced ? produced : 1)));
       if (produced) {
+         if (ctx->trace_mode == 2) { // a replayed `produced` may exceed what the kernel really emits: no uninitialised row id behind the real tail
+            LDB_HIP(hipMemsetAsync(op, 0, 4 * (size_t) produced, ctx->stream));
+            LDB_HIP(hipMemsetAsync(ob, 0, 4 * (size_t) produced, ctx->stream));
+         }
          h->match = (uint64_t) chunk_off;
          h->out_probe = (uint64_t) op;
          h->out_build = (uint64_t) ob;

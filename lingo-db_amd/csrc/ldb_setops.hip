@@ -405,6 +405,9 @@ __global__ void k_win_pack_validity(const uint8_t* __restrict__ bytes, uint64_t 
    if ((threadIdx.x & 63) == 0 && c) atomicAdd(nulls, c);
 }
 
+__global__ void k_window_iota(uint32_t* out, uint64_t n) {
+   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = (uint32_t) i;
+}
 extern "C" int32_t ldb_gpu_window(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* part_keys, int32_t n_part, const ldb_sort_spec* order, int32_t n_order, int64_t frame_from,
                                   int64_t frame_to, const ldb_window_fn* fns, int32_t n_fns, ldb_rel** out_rel, ldb_table** out_cols) {
    if (!ctx || !in || !out_rel || !out_cols || n_part < 0 || n_order < 0 || n_fns < 1 || n_fns > LDB_WIN_MAX_FNS || !fns || n_part > LDB_MAX_KEYS)
@@ -421,10 +424,8 @@ extern "C" int32_t ldb_gpu_window(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* p
    } else { // no PARTITION BY, no ORDER BY: one partition in input order
       uint32_t* iota;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &iota, 4 * (size_t) (in->n_rows ? in->n_rows : 1)));
-      std::vector<uint32_t> h((size_t) in->n_rows);
-      for (size_t i = 0; i < h.size(); i++) h[i] = (uint32_t) i;
-      if (!h.empty()) LDB_HIP(hipMemcpyAsync(iota, h.data(), 4 * h.size(), hipMemcpyHostToDevice, ctx->stream));
-      LDB_HIP(hipStreamSynchronize(ctx->stream));
+      if (in->n_rows) hipLaunchKernelGGL(k_window_iota, dim3(ldb_grid_for(ctx, in->n_rows, 256, 8)), dim3(256), 0, ctx->stream, iota, (uint64_t) in->n_rows);
+      LDB_HIP(hipGetLastError());
       LDB_TRY(ldb_rel_select(ctx, in, iota, in->n_rows, &sorted.r));
    }
    const int64_t n = sorted.r->n_rows;

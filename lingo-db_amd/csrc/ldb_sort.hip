@@ -313,7 +313,7 @@ static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint6
       std::vector<unsigned long long> init((size_t) (2 * words), 0ull), bits((size_t) (2 * words));
       for (int w = 0; w < words; w++) init[(size_t) (words + w)] = ~0ull;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &d_bits, 16 * (size_t) words));
-      LDB_HIP(hipMemcpyAsync(d_bits, init.data(), 16 * (size_t) words, hipMemcpyHostToDevice, ctx->stream));
+      LDB_TRY(ldb_h2d_small(ctx, d_bits, init.data(), 16 * (size_t) words)); // (pinned staging, never a pageable source inside a plan)
       // few blocks: every wave ends in two same-address atomics (≈10 ns each when contended)
       hipLaunchKernelGGL(k_key_bits, dim3(std::min(grid, 64), words), dim3(256), 0, ctx->stream, keys, words, n, d_bits);
       LDB_TRY(LDB_READBACK(ctx, bits.data(), d_bits, 16 * (size_t) words));

@@ -630,9 +630,14 @@ struct Interp {
       }
       const J& steps = plan.at("steps");
       result = plan.sOr("result", "result");
+      static const bool stepTrace = getenv("LDB_PLAN_STEP_TRACE") != nullptr; // diagnostics: host time of every step on stderr
       for (auto& st : steps.arr) {
          try {
+            const auto t0 = std::chrono::steady_clock::now();
             step(st);
+            if (stepTrace)
+               fprintf(stderr, "[ldb plan] %s: %s -> %s: %.3f ms host\n", plan.sOr("name", "plan").c_str(), st.sOr("op", "?").c_str(), st.sOr("out", "").c_str(),
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
          } catch (const std::exception& e) {
             throw std::runtime_error(plan.sOr("name", "plan") + ": step '" + st.sOr("op", "?") + "' → '" + st.sOr("out", "") + "': " + e.what());
          }
@@ -1175,7 +1180,7 @@ struct ldb_plan {
    ldb_trace* trace = nullptr;
    std::vector<uint64_t> key; // what the trace was recorded under: per input (stamp, rows), option epoch, exchange or not
    std::map<std::string, int64_t> groupsSeen; // Interp::groupsSeen
-   int64_t executions = 0, replays = 0, misses = 0;
+   int64_t executions = 0, replays = 0, misses = 0, peerMisses = 0; // peerMisses: executions repeated because ANOTHER rank's replay failed
    double issue_ms = 0, wait_ms = 0; // over the replayed executions: host time to issue the whole plan / time spent in the one wait at its end
 };
 
@@ -1267,17 +1272,28 @@ extern "C" int32_t ldb_plan_execute(ldb_plan* p, ldb_comm* comm, const char* con
    }
    key.push_back((uint64_t) ldb_gpu_option_epoch());
    key.push_back(comm ? 1 : 0);
-   // replay only over the very inputs the trace was recorded on.  With a communicator every rank would have to reach the
-   // same verdict before any of them repeats its collectives: exchanges are recorded, never replayed (yet)
-   const bool replay = !comm && key == p->key;
+   // replay only over the very inputs the trace was recorded on.  With a communicator the ranks replay TOGETHER or not at all (a replaying rank
+   // queues its transfers with the recorded sizes, so its peers must do the same): they agree on the minimum of "I could replay" before the
+   // execution and on the minimum of their verdicts after it; a miss on any rank makes every rank repeat the execution recording.  Two small
+   // collectives per execution instead of a wait at every operator (ldb_gpu_comm_agree); the plan itself is issued without a host wait.
+   bool replay = key == p->key;
+   if (comm) {
+      int32_t all = 0;
+      if (ldb_gpu_comm_agree(p->ctx, comm, replay && ldb_gpu_trace_replayable(p->trace) ? 1 : 0, &all) != LDB_OK) {
+         g_plan_json_err = ldb_gpu_last_error();
+         return LDB_ERR_HIP;
+      }
+      replay = all == 1;
+   }
+   const int32_t collective = comm ? LDB_TRACE_COLLECTIVE : 0;
    for (int attempt = 0; attempt < 2; attempt++) {
-      if (ldb_gpu_trace_begin(p->ctx, p->trace, replay && attempt == 0 ? 1 : 0) != LDB_OK) {
+      if (ldb_gpu_trace_begin(p->ctx, p->trace, (replay && attempt == 0 ? 1 : 0) | collective) != LDB_OK) {
          g_plan_json_err = ldb_gpu_last_error();
          return LDB_ERR_INVALID;
       }
       ldb_table* out = nullptr;
       const auto t0 = std::chrono::steady_clock::now();
-      const int32_t st = runParsed(p->ctx, comm, p->doc, table_names, tables, n_tables, &out, &p->groupsSeen);
+      int32_t st = runParsed(p->ctx, comm, p->doc, table_names, tables, n_tables, &out, &p->groupsSeen);
       const auto t1 = std::chrono::steady_clock::now();
       int32_t status = LDB_TRACE_OFF;
       if (ldb_gpu_trace_end(p->ctx, &status) != LDB_OK) {
@@ -1286,6 +1302,18 @@ extern "C" int32_t ldb_plan_execute(ldb_plan* p, ldb_comm* comm, const char* con
          return LDB_ERR_HIP;
       }
       p->executions++;
+      if (comm && replay && attempt == 0) { // did every rank's replay hold?  (only asked where a replay was attempted: all ranks take this branch together)
+         int32_t all_ok = 0;
+         if (ldb_gpu_comm_agree(p->ctx, comm, status == LDB_TRACE_MISSED ? 0 : 1, &all_ok) != LDB_OK) {
+            if (out) ldb_gpu_table_release(p->ctx, out);
+            g_plan_json_err = ldb_gpu_last_error();
+            return LDB_ERR_HIP;
+         }
+         if (!all_ok && status != LDB_TRACE_MISSED) { // a peer mis-speculated: what it sent here is void too
+            status = LDB_TRACE_MISSED;
+            p->peerMisses++;
+         }
+      }
       if (status == LDB_TRACE_MISSED) { // a replayed count was wrong: everything computed from it is void
          if (out) ldb_gpu_table_release(p->ctx, out);
          p->misses++;

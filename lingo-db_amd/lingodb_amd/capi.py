@@ -246,6 +246,8 @@ GPU_API = {
     "ldb_gpu_trace_destroy": (i32, [P, P]),
     "ldb_gpu_trace_begin": (i32, [P, P, i32]),
     "ldb_gpu_trace_end": (i32, [P, C.POINTER(i32)]),
+    "ldb_gpu_trace_replayable": (i32, [P]),
+    "ldb_gpu_comm_agree": (i32, [P, P, i32, C.POINTER(i32)]),
     "ldb_gpu_trace_stats": (i32, [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "ldb_gpu_desc_cache_stats": (i32, [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "ldb_gpu_table_stamp": (u64, [P]),

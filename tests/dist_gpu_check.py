@@ -65,6 +65,21 @@ def main():
     got = {}
     for q in queries:
         got[q] = runner.run(q).to_arrow()
+    # the sharded plans again: prepared plans REPLAY their read-back trace under the communicator (all ranks together: ldb_gpu_comm_agree before
+    # and after every execution) — same rows as the recording run, and every rank did replay
+    n_again = int(os.environ.get("LDB_CHECK_REPLAY", "2"))
+    replay_ok = True
+    for _ in range(n_again):
+        for q in queries:
+            again = runner.run(q).to_arrow()
+            replay_ok = replay_ok and same_result(q, rows_of(again), rows_of(got[q]))
+    if n_again:
+        stats = runner.prepared_stats()
+        replay_ok = replay_ok and stats["replays"] >= len(queries) * (n_again - 1) and stats["misses"] == 0
+        if rank == 0:
+            print(f"[dist-check] replayed executions under the communicator: {'OK' if replay_ok else 'MISMATCH'} "
+                  f"(executions {stats['executions']}, replays {stats['replays']}, misses {stats['misses']})", flush=True)
+        ok = ok and replay_ok
     if rank == 0:
         full = tpch_plans.Database(ctx, n_orders, 0, 1, queries, bool(int(os.environ.get("LDB_CHECK_NARROW", "0"))))
         single = tpch_plans.Runner(ctx, full, 1, None, None)
@@ -76,6 +91,65 @@ def main():
             if not same:
                 print("   sharded:", va[:3], "\n   single: ", vb[:3], flush=True)
             ok = ok and same
+    # ---- a forced divergence on ONE rank: its table is overwritten through raw device pointers (the one change a trace key cannot see), so its
+    # replayed counts are wrong; it runs on over the recorded transfer sizes, reports the miss, and EVERY rank repeats the execution recording
+    if n_again:
+        import json
+
+        import numpy as np
+        import pyarrow as pa
+
+        def piece(r, changed):
+            g = np.random.default_rng(500 + r)
+            x = g.integers(0, 1000, 60_000).astype(np.int32)
+            if changed:
+                x = np.where(g.random(len(x)) < 0.5, x, 0).astype(np.int32)  # more rows pass the filter than were recorded
+            return x
+
+        def expect(changed_rank):
+            n = s_ = 0
+            for r in range(world):
+                x = piece(r, r == changed_rank)
+                sel = np.nonzero(x < 500)[0]
+                n += len(sel)
+                s_ += int((sel + r * 1_000_000).sum())
+            return n, s_
+
+        x0 = piece(rank, False)
+        tt = ctx.register("div_%d" % rank, pa.table({"x": pa.array(x0, pa.int32()), "i": pa.array(np.arange(len(x0), dtype=np.int64) + rank * 1_000_000)}))
+        plan = ctx.prepare_plan(json.dumps({"name": "dist_replay", "inputs": ["t"], "steps": [
+            {"op": "scan", "table": "t", "out": "s"}, {"op": "filter", "in": "s", "preds": [{"col": "x", "op": "LT", "value": 500}], "out": "f"},
+            {"op": "shuffle", "in": "f", "keys": ["i"], "cols": ["i", "x"], "out": "sh"},
+            {"op": "groupby", "in": "sh", "aggs": [{"fn": "count_star", "as": "n"}, {"fn": "sum", "expr": "i", "as": "s"}], "out": "part"},
+            {"op": "allgather", "in": "part", "out": "result"}], "result": "result"}))
+
+        def total():
+            res = plan.execute({"t": tt}, comm=comm).to_arrow()
+            return sum(res.column(0).to_pylist()), sum(v for v in res.column(1).to_pylist() if v is not None)
+
+        # (every rank makes every collective call whatever it has seen so far: no short-circuit in front of total())
+        first = [total() for _ in range(3)]
+        div_ok = all(v == expect(-1) for v in first) and plan.stats()["replays"] >= 1 and plan.stats()["misses"] == 0
+        victim = world - 1
+        if rank == victim:
+            y = piece(rank, True)
+            other = ctx.register("div_other_%d" % rank, pa.table({"x": pa.array(y, pa.int32())}))
+            dst, _, _, nbytes = tt.col_ptrs(0)
+            src, _, _, _ = other.col_ptrs(0)
+            api.check(ctx.lib.ldb_gpu_memcpy_d2d(ctx.h, dst, src, nbytes))
+            ctx.sync()
+        after = total()
+        st_div = plan.stats()
+        again = total()
+        # the victim's own miss — on the other ranks the repeat a peer's miss forces — and exactly one of them; the repeated execution and the
+        # next (replaying the new record) return the new answer
+        div_ok = div_ok and after == expect(victim) and again == expect(victim) and st_div["misses"] == 1 and plan.stats()["misses"] == 1
+        flags = ctx.register("divok_%d" % rank, pa.table({"ok": pa.array([1 if div_ok else 0], pa.int32())}))
+        all_ok = comm.allgather(flags, "divok_all").to_arrow().column(0).to_pylist()
+        if rank == 0:
+            print(f"[dist-check] forced divergence on rank {victim} repeats the execution on every rank: {'OK' if all(all_ok) else 'MISMATCH'} {all_ok} {st_div}", flush=True)
+        ok = ok and all(all_ok)
+        plan.release()
     # the exchange itself on ragged inputs: strings, NULLs, a narrow (8-byte) decimal key next to a 16-byte aggregate, empty ranks
     import decimal
 

@@ -106,6 +106,25 @@ def test_ragged_alltoall_rounds(world):
     assert _run(world, "_do_rounds") == [[True] * 4] * world
 
 
+# ---------------------------------------------------------------- the verdict of a sharded prepared plan: minimum over the ranks
+def _do_agree(comm, rank, world):
+    """ldb_gpu_comm_agree (host communicator, ctx = NULL): what ldb_plan_execute asks before a collective replay ("can everybody replay?")
+    and after it ("did everybody's replay hold?") — the minimum of the ranks' flags, the same answer on every rank, round after round"""
+    from lingodb_amd import capi
+
+    out = []
+    for rnd, mine in enumerate([1, 1 if rank != world - 1 else 0, 1, 0 if rank == 0 else 1, 1]):
+        got = C.c_int32(-7)
+        capi.check(comm.lib.ldb_gpu_comm_agree(None, comm.h, mine, C.byref(got)))
+        out.append(got.value)
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_agree_is_the_minimum_over_the_ranks(world):
+    assert _run(world, "_do_agree") == [[1, 0, 1, 0, 1]] * world
+
+
 # ---------------------------------------------------------------- replicate (all-gather = everybody sends everything to everybody)
 def _rank_rows(rank, n):
     rng = np.random.default_rng(100 + rank)

@@ -33,7 +33,8 @@ def run_ranks(world, extra_env=None, timeout=900):
 def test_sharded_plans_match_single_gpu(world):
     codes, outs = run_ranks(world)
     assert all(c == 0 for c in codes), "\n".join(o[-3000:] for o in outs)
-    assert outs[0].count(": OK") == 22 + 3, outs[0]
+    assert outs[0].count(": OK") == 22 + 5, outs[0]
+    assert "replayed executions under the communicator: OK" in outs[0] and "repeats the execution on every rank: OK" in outs[0]
 
 
 def test_world8_all_sharded_plans_skew_and_stress():
@@ -41,7 +42,7 @@ def test_world8_all_sharded_plans_skew_and_stress():
     almost all go to one rank, and 60 back-to-back exchanges of strings / NULLs / mixed widths of changing sizes"""
     codes, outs = run_ranks(8, {"LDB_CHECK_ORDERS": "90006", "LDB_CHECK_STRESS": "60"}, timeout=1500)
     assert all(c == 0 for c in codes), "\n".join(o[-3000:] for o in outs)
-    assert outs[0].count(": OK") == 22 + 4, outs[0]
+    assert outs[0].count(": OK") == 22 + 6, outs[0]
     assert "exchange statistics" in outs[0]
 
 
@@ -56,7 +57,7 @@ def test_sharded_plans_with_narrow_decimals():
     """--narrow-decimals: 8-byte decimal columns next to the 16-byte aggregates group-by produces"""
     codes, outs = run_ranks(2, {"LDB_CHECK_NARROW": "1", "LDB_CHECK_QUERIES": "1,3,10,15,18,11"})
     assert all(c == 0 for c in codes), "\n".join(o[-3000:] for o in outs)
-    assert outs[0].count(": OK") == 6 + 3, outs[0]
+    assert outs[0].count(": OK") == 6 + 5, outs[0]
 
 
 def test_sharded_plans_on_one_rank_equal_the_single_gpu_plans():
