@@ -536,6 +536,13 @@ typedef struct {
 } ldb_join_residual;
 int32_t ldb_gpu_join_probe_residual(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind,
                                     const ldb_join_residual* resid, int32_t n_resid, ldb_rel** out, ldb_table** mark_out);
+/* Build-side semi AND anti join over the same hash table in one pass over the probe side (TPC-H Q21's EXISTS … AND NOT EXISTS … pair; the
+ * reference runs two marker joins, translateHJWithMarker, RelAlgToSubOp.cpp:1248-1287, residuals as in SpecializeSubOpPass.cpp:152-205):
+ * *out = the build rows with a partner among the probe rows (key equality + residual conjuncts) and WITHOUT a partner among the probe
+ * rows that also satisfy the conjunction `anti_preds` (columns of the probe relation; at most 2).  Same rows as kind SEMI_BUILD, a table
+ * over its result, and kind ANTI_BUILD probed by the filtered probe side. */
+int32_t ldb_gpu_join_probe_semi_anti_build(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, const ldb_join_residual* resid,
+                                           int32_t n_resid, const ldb_filter_desc* anti_preds, int32_t n_anti_preds, ldb_rel** out);
 /* Nested-loop join (translateNLJ, RelAlgToSubOp.cpp:948-1033): no key equality — the join predicate is the conjunction of
  * `resid` (0..2 column-vs-column comparisons between a probe and a build column; none = cross product).  Every build row is
  * visited for every probe row, so this is for SMALL build sides (band joins against dimension tables, scalar-subquery

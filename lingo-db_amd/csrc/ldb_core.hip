@@ -42,7 +42,7 @@ int64_t ldb_option(const char* name, int64_t dflt) {
 }
 extern "C" int32_t ldb_gpu_set_option(const char* name, int64_t value) {
    if (!name) LDB_FAIL(LDB_ERR_INVALID, "set_option: NULL name");
-   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass", "lazy_strings", "lazy_strings_min_rows", "gb_partition_wc", "join_radix_wc", "join_radix_lds"};
+   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass", "lazy_strings", "lazy_strings_min_rows", "gb_partition_wc", "join_radix_wc", "join_radix_lds", "gb_dense_out"};
    bool ok = false;
    for (const char* k : known) ok |= strcmp(k, name) == 0;
    if (!ok) LDB_FAIL(LDB_ERR_INVALID, "set_option: unknown option '%s'", name);
@@ -310,6 +310,17 @@ static int32_t readback_sync(ldb_ctx* ctx, void* host, const void* dev, size_t b
    LDB_HIP(hipStreamSynchronize(ctx->stream));
    return LDB_OK;
 }
+static std::mutex g_site_mu;
+static std::unordered_map<uint32_t, std::string> g_sites;
+uint32_t ldb_site_note(uint32_t hash, const char* file, int line) {
+   std::lock_guard<std::mutex> lock(g_site_mu);
+   auto it = g_sites.find(hash);
+   if (it == g_sites.end()) {
+      const char* base = strrchr(file, '/');
+      g_sites.emplace(hash, std::string(base ? base + 1 : file) + ":" + std::to_string(line));
+   }
+   return hash;
+}
 // replay: everything read so far must equal the record
 static bool trace_prefix_ok(ldb_ctx* ctx, size_t upto_entries) {
    LdbSlow slow_("trace check: wait for the replayed plan", upto_entries);
@@ -318,7 +329,18 @@ static bool trace_prefix_ok(ldb_ctx* ctx, size_t upto_entries) {
    const ldb_trace* t = ctx->trace;
    for (size_t i = 0; i < upto_entries; i++) {
       const ldb_trace_entry& e = t->entries[i];
-      if (memcmp(ctx->h_log + e.off, t->vals.data() + e.off, e.bytes) != 0) return false;
+      if (memcmp(ctx->h_log + e.off, t->vals.data() + e.off, e.bytes) != 0) {
+         if (ldb_host_trace_threshold() >= 0) { // which read-back was it, and what did it say
+            std::lock_guard<std::mutex> lock(g_site_mu);
+            auto it = g_sites.find(e.site);
+            unsigned long long rec[2] = {0, 0}, got[2] = {0, 0};
+            memcpy(rec, t->vals.data() + e.off, std::min<size_t>(16, e.bytes));
+            memcpy(got, ctx->h_log + e.off, std::min<size_t>(16, e.bytes));
+            fprintf(stderr, "[ldb host] replayed read-back %zu of %zu differs (%s, %u bytes): recorded %llx %llx, now %llx %llx\n", i, t->entries.size(),
+                    it != g_sites.end() ? it->second.c_str() : "?", e.bytes, rec[0], rec[1], got[0], got[1]);
+         }
+         return false;
+      }
    }
    return true;
 }
@@ -1785,6 +1807,14 @@ int32_t ldb_gather_columns(ldb_ctx* ctx, const ldb_rel* r, const ldb_colref* ref
          LDB_TRY(ldb_exclusive_scan_i64(ctx, p.lens, out->offsets, (int64_t) n, (int64_t*) (d_words + p.slot_bytes)));
       } else {
          out->value_bytes = (int64_t) n * src.width;
+         // the gathered values are a subset of the source's: its cached [min, max] stays a valid (superset) statistic of the new column —
+         // an intermediate's key range is then known without a pass over it in every execution (Q18: 150 M group keys, k_column_range
+         // 0.35 ms inside the timed run; Q14, Q7).  Not where padding rows (outer joins) or NULL slots carry other bytes.
+         if (src.has_range && p.slot_nulls < 0) {
+            out->has_range = true;
+            out->vmin = src.vmin;
+            out->vmax = src.vmax;
+         }
          LDB_TRY(ldb_dev_alloc(ctx, &out->values, (size_t) out->value_bytes));
          switch (src.width) {
             case 1: hipLaunchKernelGGL(k_gather_fixed<uint8_t>, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*) src.values, p.rowids, (uint8_t*) out->values, n); break;

@@ -113,6 +113,16 @@ struct DGroupBy {
    // `direct_word`; the output key column is written from the slot number by k_gb_finalize.
    int32_t direct;
    uint64_t chunk_off; // uint32_t*: dense_sorted: number of groups that start before each 64-row chunk
+   // dense_sorted with in-kernel finalisation (dense_out): a group that begins and ends inside one wave never touches a table — its head
+   // lane reduces the run and writes the group's FINAL output values and its representative row; only groups that cross a 64-row chunk
+   // boundary are accumulated with atomics, in a table with ONE slot per chunk (slot = the chunk that holds the group's first row; g_acc,
+   // g_cap = number of chunks), and finished by k_gb_finalize_cross from the per-chunk flags.  Q18 (600 M rows → 150 M groups): no slot
+   // word, no 16-byte accumulator per group written and read back twice, no occupancy scan (DESIGN §2 Group-by).
+   int32_t dense_out;
+   int32_t pad_dense;
+   uint64_t rep_rows_out; // uint32_t*: dense_out: representative row of every group (written by the group's first row)
+   uint64_t cross_flags; // uint8_t*, one per chunk, pre-zeroed: 1 = the group that begins in this chunk continues into the next one
+   uint64_t dense_groups; // dense_sorted: number of output slots (a group number beyond it — possible only under a mis-speculated replay — is dropped)
    uint64_t direct_keys_out; // device address of the output key column (run-time)
    int32_t direct_word; // accumulator word of the row counter
    int32_t direct_key_width; // 4, 8 or 16 bytes per output key
@@ -394,12 +404,18 @@ __device__ __forceinline__ void d_accumulate_runs(const DGroupBy& m, const DGrou
             }
             case ACC_MINF64: {
                double r = d_seg_reduce<double>(ok ? fv : __builtin_inf(), lane, run_end, [](double x, double y) { return y < x ? y : x; });
-               if (apply && r != __builtin_inf()) d_atomic_minmax_f64(s.w(acc.word), r, true);
+               if (apply && r != __builtin_inf()) {
+                  if (s.plain) *(double*) s.w(acc.word) = r;
+                  else d_atomic_minmax_f64(s.w(acc.word), r, true);
+               }
                break;
             }
             default: {
                double r = d_seg_reduce<double>(ok ? fv : -__builtin_inf(), lane, run_end, [](double x, double y) { return y > x ? y : x; });
-               if (apply && r != -__builtin_inf()) d_atomic_minmax_f64(s.w(acc.word), r, false);
+               if (apply && r != -__builtin_inf()) {
+                  if (s.plain) *(double*) s.w(acc.word) = r;
+                  else d_atomic_minmax_f64(s.w(acc.word), r, false);
+               }
                break;
             }
          }
@@ -425,7 +441,10 @@ __device__ __forceinline__ void d_accumulate_runs(const DGroupBy& m, const DGrou
          }
          case ACC_MIN64: {
             long long r = d_seg_reduce<long long>(ok ? (long long) v : GB_I64_MAX, lane, run_end, [](long long x, long long y) { return y < x ? y : x; });
-            if (apply && r != GB_I64_MAX) atomicMin((long long*) s.w(acc.word), r);
+            if (apply && r != GB_I64_MAX) {
+               if (s.plain) *(long long*) s.w(acc.word) = r;
+               else atomicMin((long long*) s.w(acc.word), r);
+            }
             break;
          }
          case ACC_MIN128: {
@@ -440,7 +459,10 @@ __device__ __forceinline__ void d_accumulate_runs(const DGroupBy& m, const DGrou
          }
          default: {
             long long r = d_seg_reduce<long long>(ok ? (long long) v : GB_I64_MIN, lane, run_end, [](long long x, long long y) { return y > x ? y : x; });
-            if (apply && r != GB_I64_MIN) atomicMax((long long*) s.w(acc.word), r);
+            if (apply && r != GB_I64_MIN) {
+               if (s.plain) *(long long*) s.w(acc.word) = r;
+               else atomicMax((long long*) s.w(acc.word), r);
+            }
             break;
          }
       }
@@ -479,6 +501,92 @@ __device__ __forceinline__ void d_combine(const DGroupBy& m, const Sink& src, co
          case ACC_MINF64: d_atomic_minmax_f64(dst.w(acc.word), __longlong_as_double((long long) x), true); break;
          default: d_atomic_minmax_f64(dst.w(acc.word), __longlong_as_double((long long) x), false); break;
       }
+   }
+}
+
+// ---------------------------------------------------------------- a group's output row
+// The output aggregates of ONE group from its accumulator words (word w at acc[w * stride]): the last step of the reference's
+// aggregation (the scan over the merged hash table that feeds the result columns, SubOpToControlFlow.cpp:1861-1938 + the AVG / validity
+// arithmetic of LowerToStd.cpp:631-651).  Called by k_gb_finalize for table slots, and by the dense_sorted kernel itself for groups
+// that live inside one wave (acc = the head lane's private words, stride 1).  `g` = output position, `rep` = representative input row.
+__device__ __forceinline__ void d_finalize_group(const DGroupBy& m, const DGroupBy* __restrict__ d, const unsigned long long* acc, uint64_t stride, uint64_t g, uint32_t rep) {
+   const int no = m.n_outs;
+   LDB_UNROLL
+   for (int o = 0; o < no; o++) {
+      const DOut& out = m.outs[o];
+      const uint64_t out_values = d->outs[o].out_values, out_valid = d->outs[o].out_valid;
+      bool ok = true;
+      unsigned long long cnt = 0;
+      if (out.cnt_acc >= 0) {
+         cnt = acc[(uint64_t) m.accs[out.cnt_acc].word * stride];
+         ok = cnt != 0;
+      }
+      if (out.cnt_rows_acc >= 0) { // conditional SUM: rows failing the predicates contribute a non-NULL 0
+         unsigned long long rows = acc[(uint64_t) m.accs[out.cnt_rows_acc].word * stride];
+         unsigned long long passing = out.cnt_pass_acc >= 0 ? acc[(uint64_t) m.accs[out.cnt_pass_acc].word * stride] : 0;
+         unsigned long long nonnull = out.cnt_pass_acc >= 0 ? cnt : 0; // not nullable: no passing row is NULL
+         ok = rows - passing + nonnull != 0;
+      }
+      if (out.is_float) {
+         double v = 0;
+         if (out.fn == LDB_AGG_COUNT || out.fn == LDB_AGG_COUNT_STAR) {
+            // counts are integers; handled below
+         } else if (out.fn == LDB_AGG_ANY) {
+            RowVals rv;
+            uint32_t rvalid = 0;
+            if (d->n_rows) d_load_vals(m, d, rep, rv, rvalid);
+            ok = d->n_rows != 0 && d_eval_flt(m, out.e, rv, rvalid, &v);
+         } else {
+            v = __longlong_as_double((long long) acc[(uint64_t) m.accs[out.acc].word * stride]);
+            if (out.fn == LDB_AGG_AVG && ok) v = v / (double) cnt;
+         }
+         if (out.fn != LDB_AGG_COUNT && out.fn != LDB_AGG_COUNT_STAR) {
+            ((double*) out_values)[g] = ok ? v : 0.0;
+            if (out_valid) ((uint8_t*) out_valid)[g] = ok ? 1 : 0;
+            continue;
+         }
+      }
+      i128 v = 0;
+      switch (out.fn) {
+         case LDB_AGG_COUNT:
+         case LDB_AGG_COUNT_STAR:
+            v = (i128) acc[(uint64_t) m.accs[out.acc].word * stride];
+            ok = true;
+            break;
+         case LDB_AGG_ANY: {
+            if (d->n_rows == 0) { // key-less aggregation over no rows: the pre-seeded group has no representative row
+               ok = false;
+               break;
+            }
+            RowVals rv;
+            uint32_t rvalid;
+            d_load_vals(m, d, rep, rv, rvalid);
+            ok = d_eval_int(m, d, out.e, rv, rvalid, rep, &v);
+            break;
+         }
+         default: {
+            const DAcc& a = m.accs[out.acc];
+            uint64_t lo = acc[(uint64_t) a.word * stride];
+            if (a.kind == ACC_SUM128 || a.kind == ACC_MIN128 || a.kind == ACC_MAX128) v = (i128) (((u128) acc[(uint64_t) (a.word + 1) * stride] << 64) | lo);
+            else v = (i128) (int64_t) lo;
+            if (out.fn == LDB_AGG_AVG && ok) {
+               // (sum * 10^k) sdiv count in i128 (DecimalOpScaledLowering, LowerToStd.cpp:631-651)
+               v = d_sdiv128((i128) ((u128) v * (u128) d_pow10(out.avg_pow10)), (i128) cnt);
+            }
+            break;
+         }
+      }
+      if (!ok) v = 0;
+      switch (out.out_width) {
+         case 4: ((int32_t*) out_values)[g] = (int32_t) v; break;
+         case 8: ((int64_t*) out_values)[g] = (int64_t) v; break;
+         default: {
+            if (!out.wide && out.fn != LDB_AGG_AVG) v = (i128) (int64_t) v;
+            ((uint64_t*) out_values)[2 * g] = (uint64_t) v;
+            ((uint64_t*) out_values)[2 * g + 1] = (uint64_t) (v >> 64);
+         }
+      }
+      if (out_valid) ((uint8_t*) out_valid)[g] = ok ? 1 : 0;
    }
 }
 
@@ -622,7 +730,7 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
          // loop below only shuffles, stores and issues atomics: without this each batch row paid
          // three dependent round trips of its own and the kernel ran at latency, not bandwidth
          bool eqprev[ROWS], eqnext[ROWS];
-         uint32_t gbase[ROWS];
+         uint32_t gbase[ROWS], gprev[ROWS];
          if (m.dense_sorted) {
             // one dense NOT NULL integer key (what the sorted statistic guarantees): branch-free
             // clamped loads of the previous / own / next key for the whole batch, compares after
@@ -635,6 +743,7 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
                kprev[u] = d_load_i64(kc, (uint32_t) (ii > 0 ? ii - 1 : 0));
                knext[u] = d_load_i64(kc, (uint32_t) (ii + 1 < n ? ii + 1 : ii));
                gbase[u] = gptr<uint32_t>(d->chunk_off)[ii >> 6];
+               if (m.dense_out) gprev[u] = gptr<uint32_t>(d->chunk_off)[(ii >> 6) ? (ii >> 6) - 1 : 0];
             }
 #pragma unroll
             for (int u = 0; u < ROWS; u++) {
@@ -676,7 +785,50 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
                   const uint64_t upto = lane >= 63 ? ~0ull : ((2ull << lane) - 1ull);
                   g = (uint64_t) gbase[u] + (uint64_t) __popcll(thmask & upto) - 1ull;
                   plain = true_head && !(run_end == 63 && cont); // the whole group lives inside this run
-                  if (true_head) gptr_mut<unsigned long long>(d->g_keys)[g] = (h & 0xFFFFFFFF00000000ull) | (unsigned long long) ((uint32_t) i + 1u);
+                  if (g >= d->dense_groups) g = ~0ull; // (only under a mis-speculated replay: the output arrays were sized from the recorded count)
+                  if (m.dense_out) {
+                     if (true_head && g != ~0ull) gptr_mut<uint32_t>(d->rep_rows_out)[g] = (uint32_t) i;
+                  } else if (true_head && g != ~0ull) {
+                     gptr_mut<unsigned long long>(d->g_keys)[g] = (h & 0xFFFFFFFF00000000ull) | (unsigned long long) ((uint32_t) i + 1u);
+                  }
+               }
+               if (m.dense_out) {
+                  // a group inside one run: reduced into the head lane's private words and written out as the group's final row.  A group
+                  // that crosses a chunk boundary: atomics into the slot of the chunk that holds its first row — this chunk for a run that
+                  // begins here, an earlier one for the run that arrives at lane 0 (normally the previous chunk; a group longer than a
+                  // chunk finds its first chunk by bisection of the group numbers) — finished by k_gb_finalize_cross
+                  const uint64_t chunk = (i - lane) >> 6;
+                  unsigned long long loc[GB_MAX_WORDS];
+                  LDB_UNROLL
+                  for (int w = 0; w < nw; w++) loc[w] = m.word_init[w];
+                  uint64_t slot = chunk;
+                  if (head && !plain && !true_head && g != ~0ull) { // the run continuing from the previous chunk (lane 0)
+                     slot = chunk - 1;
+                     if (gprev[u] == gbase[u]) { // no group begins in the previous chunk either: the largest chunk c with chunk_off[c] <= g
+                        const uint32_t* co = gptr<uint32_t>(d->chunk_off);
+                        uint64_t lo_c = 0, hi_c = chunk - 1;
+                        while (lo_c < hi_c) {
+                           const uint64_t mid = (lo_c + hi_c + 1) >> 1;
+                           if ((uint64_t) co[mid] <= g) lo_c = mid;
+                           else hi_c = mid - 1;
+                        }
+                        slot = lo_c;
+                     }
+                  }
+                  if (head && !plain && true_head && g != ~0ull) gptr_mut<uint8_t>(d->cross_flags)[chunk] = 1;
+                  // every head lane reduces its run into its OWN words (plain stores into identity-initialised words: registers in the
+                  // specialised kernel); then the words become the group's output row, or are merged into the crossing group's slot
+                  const Sink ls{loc, 1, true};
+                  d_accumulate_runs(m, d, rvv[u], rvalidv[u], i, pass, head, lane, run_end, ls);
+                  if (head && g != ~0ull) {
+                     if (plain) {
+                        d_finalize_group(m, d, loc, 1, g, (uint32_t) i);
+                     } else {
+                        const Sink dst{g_acc + slot, g_cap};
+                        d_combine(m, ls, dst);
+                     }
+                  }
+                  continue;
                }
             } else if (head) {
                g = m.direct ? d_direct_slot(m, d, i) : d_global_slot(m, d, h, i);

@@ -43,7 +43,7 @@ __global__ void k_gb_init(uint64_t* keys, uint64_t* acc, const DGroupBy* __restr
    const uint64_t cap = d->g_cap;
    const int nw = d->n_words;
    for (uint64_t p = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; p < cap; p += (uint64_t) gridDim.x * blockDim.x) {
-      keys[p] = (d->keyless && p == 0) ? 1ull : 0ull;
+      if (keys) keys[p] = (d->keyless && p == 0) ? 1ull : 0ull; // (dense_out: no slot words at all)
       for (int w = 0; w < nw; w++) acc[(uint64_t) w * cap + p] = d->word_init[w];
    }
 }
@@ -165,83 +165,24 @@ __global__ void k_gb_finalize(const DGroupBy* __restrict__ d, uint32_t* __restri
       } else {
          rep_rows[g] = rep;
       }
-      const uint64_t* acc = (const uint64_t*) d->g_acc + p;
-      for (int o = 0; o < d->n_outs; o++) {
-         const DOut& out = d->outs[o];
-         bool ok = true;
-         unsigned long long cnt = 0;
-         if (out.cnt_acc >= 0) {
-            cnt = acc[(uint64_t) d->accs[out.cnt_acc].word * cap];
-            ok = cnt != 0;
-         }
-         if (out.cnt_rows_acc >= 0) { // conditional SUM: rows failing the predicates contribute a non-NULL 0
-            unsigned long long rows = acc[(uint64_t) d->accs[out.cnt_rows_acc].word * cap];
-            unsigned long long passing = out.cnt_pass_acc >= 0 ? acc[(uint64_t) d->accs[out.cnt_pass_acc].word * cap] : 0;
-            unsigned long long nonnull = out.cnt_pass_acc >= 0 ? cnt : 0; // not nullable: no passing row is NULL
-            ok = rows - passing + nonnull != 0;
-         }
-         if (out.is_float) {
-            double v = 0;
-            if (out.fn == LDB_AGG_COUNT || out.fn == LDB_AGG_COUNT_STAR) {
-               // counts are integers; handled below
-            } else if (out.fn == LDB_AGG_ANY) {
-               RowVals rv;
-               uint32_t rvalid = 0;
-               if (d->n_rows) d_load_vals(*d, d, rep, rv, rvalid);
-               ok = d->n_rows != 0 && d_eval_flt(*d, out.e, rv, rvalid, &v);
-            } else {
-               v = __longlong_as_double((long long) acc[(uint64_t) d->accs[out.acc].word * cap]);
-               if (out.fn == LDB_AGG_AVG && ok) v = v / (double) cnt;
-            }
-            if (out.fn != LDB_AGG_COUNT && out.fn != LDB_AGG_COUNT_STAR) {
-               ((double*) out.out_values)[g] = ok ? v : 0.0;
-               if (out.out_valid) ((uint8_t*) out.out_valid)[g] = ok ? 1 : 0;
-               continue;
-            }
-         }
-         i128 v = 0;
-         switch (out.fn) {
-            case LDB_AGG_COUNT:
-            case LDB_AGG_COUNT_STAR:
-               v = (i128) acc[(uint64_t) d->accs[out.acc].word * cap];
-               ok = true;
-               break;
-            case LDB_AGG_ANY: {
-               if (d->n_rows == 0) { // key-less aggregation over no rows: the pre-seeded group has no representative row
-                  ok = false;
-                  break;
-               }
-               RowVals rv;
-               uint32_t rvalid;
-               d_load_vals(*d, d, rep, rv, rvalid);
-               ok = d_eval_int(*d, d, out.e, rv, rvalid, rep, &v);
-               break;
-            }
-            default: {
-               const DAcc& a = d->accs[out.acc];
-               uint64_t lo = acc[(uint64_t) a.word * cap];
-               if (a.kind == ACC_SUM128 || a.kind == ACC_MIN128 || a.kind == ACC_MAX128) v = (i128) (((u128) acc[(uint64_t) (a.word + 1) * cap] << 64) | lo);
-               else v = (i128) (int64_t) lo;
-               if (out.fn == LDB_AGG_AVG && ok) {
-                  // (sum * 10^k) sdiv count in i128 (DecimalOpScaledLowering, LowerToStd.cpp:631-651)
-                  v = d_sdiv128((i128) ((u128) v * (u128) d_pow10(out.avg_pow10)), (i128) cnt);
-               }
-               break;
-            }
-         }
-         if (!ok) v = 0;
-         switch (out.out_width) {
-            case 4: ((int32_t*) out.out_values)[g] = (int32_t) v; break;
-            case 8: ((int64_t*) out.out_values)[g] = (int64_t) v; break;
-            default: {
-               if (!out.wide && out.fn != LDB_AGG_AVG) v = (i128) (int64_t) v;
-               ((uint64_t*) out.out_values)[2 * g] = (uint64_t) v;
-               ((uint64_t*) out.out_values)[2 * g + 1] = (uint64_t) (v >> 64);
-            }
-         }
-         if (out.out_valid) ((uint8_t*) out.out_valid)[g] = ok ? 1 : 0;
-      }
+      d_finalize_group(*d, d, (const unsigned long long*) d->g_acc + p, cap, g, rep);
    }
+}
+// dense_out: the groups that cross a chunk boundary.  One lane per chunk: a flagged chunk holds the first row of a group that continues
+// into the next chunk; its accumulators are the chunk's slot (word w at g_acc[w * n_chunks + chunk]), its number is the last group that
+// begins in the chunk, its representative row was written by its first row.
+__global__ void k_gb_finalize_cross(const DGroupBy* __restrict__ d, uint64_t n_chunks, const unsigned long long* __restrict__ d_groups) {
+   const uint8_t* flags = (const uint8_t*) d->cross_flags;
+   const uint32_t* chunk_off = (const uint32_t*) d->chunk_off;
+   for (uint64_t c = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; c + 1 < n_chunks; c += (uint64_t) gridDim.x * blockDim.x) {
+      if (!flags[c]) continue;
+      const uint64_t g = (uint64_t) chunk_off[c + 1] - 1ull;
+      if (g >= d->dense_groups) continue; // (mis-speculated replay)
+      d_finalize_group(*d, d, (const unsigned long long*) d->g_acc + c, n_chunks, g, ((const uint32_t*) d->rep_rows_out)[g]);
+   }
+   // the output arrays were sized from a count that may have been REPLAYED: should the real one be smaller (the execution is void and will be
+   // repeated, but its consumers are queued already), the representative rows behind it must still be row numbers.  Normally an empty range.
+   for (uint64_t g = (uint64_t) *d_groups + blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; g < d->dense_groups; g += (uint64_t) gridDim.x * blockDim.x) ((uint32_t*) d->rep_rows_out)[g] = 0;
 }
 
 // per-group validity bytes → Arrow bitmap; *nulls += number of zero bytes (one atomic per wave of a
@@ -589,6 +530,8 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    }
    // sorted key column, no filter (DGroupBy::dense_sorted): number the groups by key changes
    uint32_t* chunk_off = nullptr;
+   uint64_t sorted_groups = 0, sorted_chunks = 0; // dense_sorted: number of groups / of 64-row chunks
+   uint64_t* d_sorted_groups = nullptr; // the same count on the device (an arena word)
    const bool gb_sorted = ldb_option("gb_sorted", 1) != 0;
    if (gb_sorted && !h->use_lds && n_keys == 1 && h->n_preds == 0 && in->n_rows > 0) {
       const ldb_rel_side& ks = in->sides[(size_t) keys[0].side];
@@ -625,6 +568,13 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          h->ordered_slots = 0;
          h->chunk_off = (uint64_t) chunk_off;
          cap = std::max<uint64_t>(1, groups); // the dense group array: exactly one slot per group
+         sorted_groups = groups;
+         sorted_chunks = (uint64_t) n_chunks;
+         d_sorted_groups = d_groups;
+         // groups inside one wave leave the kernel as final rows; the table shrinks to one slot per CHUNK for the groups that cross a
+         // chunk boundary (DGroupBy::dense_out)
+         h->dense_out = ldb_option("gb_dense_out", 1) != 0 ? 1 : 0;
+         if (h->dense_out) cap = std::max<uint64_t>(1, sorted_chunks);
       }
    }
    // direct-address slots (DGroupBy::direct): one NOT NULL integer key whose value range is at most twice
@@ -684,20 +634,28 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    for (;;) {
       h->g_cap = cap;
       h->kmult = h->ordered_slots ? (uint64_t) ((((unsigned __int128) cap) << 32) / key_range) : 0;
-      uint64_t *gk, *ga;
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &gk, 8 * (size_t) cap));
+      uint64_t *gk = nullptr, *ga;
+      uint8_t* cross = nullptr;
+      if (!h->dense_out) LDB_TRY(ldb_dev_alloc(ctx, (void**) &gk, 8 * (size_t) cap));
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &ga, 8 * (size_t) cap * (size_t) nw));
       h->g_keys = (uint64_t) gk;
       h->g_acc = (uint64_t) ga;
       LDB_TRY(ldb_counters(ctx, 2 + GB_MAX_OUT, (uint64_t**) &d_ctl));
       h->g_flags = (uint64_t) d_ctl;
-      // upper bound of groups = min(cap, rows) (1 for keyless)
-      const uint64_t max_groups = std::max<uint64_t>(1, h->keyless ? 1 : std::min<uint64_t>(cap, (uint64_t) in->n_rows));
+      // upper bound of groups = min(cap, rows) (1 for keyless); the sorted path knows the exact number
+      const uint64_t max_groups = std::max<uint64_t>(1, h->keyless ? 1 : h->dense_sorted ? sorted_groups : std::min<uint64_t>(cap, (uint64_t) in->n_rows));
+      h->dense_groups = h->dense_sorted ? max_groups : 0;
+      if (h->dense_out) {
+         LDB_TRY(ldb_dev_alloc(ctx, (void**) &cross, (size_t) sorted_chunks + 8));
+         LDB_HIP(hipMemsetAsync(cross, 0, (size_t) sorted_chunks + 8, ctx->stream));
+         h->cross_flags = (uint64_t) cross;
+      }
       if (h->direct) {
          LDB_TRY(ldb_dev_alloc(ctx, &direct_keys, (size_t) h->direct_key_width * (size_t) max_groups));
          h->direct_keys_out = (uint64_t) direct_keys;
       } else {
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &rep_rows, 4 * (size_t) max_groups));
+         h->rep_rows_out = (uint64_t) rep_rows;
          // ordered slots give up on long probe runs, which depends on the insertion order: should a REPLAYED execution
          // (ldb_readback) meet that where the recorded one did not, its group count is too high until the trace ends and the
          // execution is repeated — the representative rows beyond the real count must then still be valid row numbers
@@ -788,7 +746,16 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       }
       LDB_HIP(hipGetLastError());
       // ---- finalize (speculative: valid only if the flags come back clean)
-      {
+      if (h->dense_out) { // every group inside one wave is final already: only the chunk-crossing groups are left, the count is known
+         LdbProf prof_(ctx, "k_gb_finalize");
+         hipLaunchKernelGGL(k_gb_finalize_cross, dim3(ldb_grid_for(ctx, (int64_t) sorted_chunks, 256, 8)), dim3(256), 0, ctx->stream, (const DGroupBy*) d, sorted_chunks,
+                            (const unsigned long long*) d_sorted_groups);
+         for (int32_t a = 0; a < n_aggs; a++)
+            if (out_valid[(size_t) a])
+               hipLaunchKernelGGL(k_pack_valid_bytes, dim3(ldb_grid_for(ctx, (int64_t) max_groups, 256 * 8, 4)), dim3(256), 0, ctx->stream, out_valid[(size_t) a], bitmaps[(size_t) a],
+                                  (const unsigned long long*) d_sorted_groups, d_ctl + 2 + a);
+         LDB_HIP(hipGetLastError());
+      } else {
          LdbProf prof_(ctx, "k_gb_finalize");
          const int64_t n_chunks = (int64_t) ((cap + 63) / 64);
          uint32_t *pop = nullptr, *off;
@@ -818,8 +785,10 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       }
       static_assert(sizeof(ctl) <= 64 * sizeof(int64_t), "control block must fit the pinned scratch words");
       LDB_TRY(LDB_READBACK(ctx, ctl, d_ctl, ctl_bytes));
+      if (h->dense_out) ctl[1] = sorted_groups; // (no occupancy scan ran: the heads pass counted the groups)
       ldb_dev_free(ctx, gk);
       ldb_dev_free(ctx, ga);
+      ldb_dev_free(ctx, cross);
       ldb_dev_free(ctx, d);
       const uint64_t flags = (uint64_t) ctl[0];
       if ((flags & 3) == 0) break;

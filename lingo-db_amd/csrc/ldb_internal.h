@@ -119,7 +119,9 @@ constexpr uint32_t ldb_site_hash(const char* f, int line) {
    for (; *f; f++) h = (h ^ (uint32_t) (unsigned char) *f) * 16777619u;
    return (h ^ (uint32_t) line) * 16777619u;
 }
-#define LDB_SITE (ldb_site_hash(__FILE__, __LINE__))
+// (the call site's file:line is remembered under its hash, so that a mismatching replayed value can be named: LDB_HOST_TRACE)
+uint32_t ldb_site_note(uint32_t hash, const char* file, int line);
+#define LDB_SITE (ldb_site_note(ldb_site_hash(__FILE__, __LINE__), __FILE__, __LINE__))
 struct ldb_ctx;
 // read `bytes` of device memory into `host` (see above); flags: LDB_RB_NEVER_REPLAY for values that may differ between two
 // executions over the same data (flags raised by races between insertions) — those always synchronise

@@ -269,6 +269,7 @@ static void gb_meta(const DGroupBy* h, DGroupBy* m) {
    m->kmin = 0;
    m->kmult = 0;
    m->chunk_off = 0;
+   m->rep_rows_out = m->cross_flags = m->dense_groups = 0;
    ldb_jit_strip_keys(m->keys);
    for (int p = 0; p < LDB_MAX_PREDS; p++) ldb_jit_strip_pred(m->preds[p]);
    for (int p = 0; p < GB_MAX_CPREDS; p++) ldb_jit_strip_pred(m->cpreds[p]);
@@ -326,6 +327,38 @@ extern "C" int32_t ldb_gpu_jit_compile_check(char* log, int32_t cap) {
    std::vector<char> code;
    std::string err;
    bool ok = compile(build_source("ldb_gb_kernel.h", "DGroupBy", GB_SPEC_SRC, (const unsigned char*) meta.get(), sizeof(DGroupBy)), &code, &err);
+   if (ok) { // the sorted-key high-cardinality shape (TPC-H Q18: one int32 key, SUM of a decimal, no LDS table, rows final inside the wave)
+      auto q = std::make_unique<DGroupBy>();
+      memset(q.get(), 0, sizeof(DGroupBy));
+      q->keys.n_keys = 1;
+      q->keys.cols[0].type = LDB_T_INT32;
+      q->keys.cols[0].width = 4;
+      q->n_cols = 1;
+      q->cols[0].type = LDB_T_DECIMAL128;
+      q->cols[0].width = 16;
+      q->cols[0].precision = 12;
+      q->cols[0].scale = 2;
+      q->n_accs = 2;
+      q->accs[0].kind = ACC_SUM128;
+      q->accs[0].e.n_terms = 1;
+      q->accs[0].e.t[0].n_factors = 1;
+      q->accs[0].e.t[0].f[0] = {1, 0, 0, 1};
+      q->accs[1].kind = ACC_COUNT;
+      q->accs[1].word = 2;
+      q->n_words = 3;
+      q->n_outs = 1;
+      q->outs[0].fn = LDB_AGG_SUM;
+      q->outs[0].acc = 0;
+      q->outs[0].cnt_acc = 1;
+      q->outs[0].cnt_rows_acc = q->outs[0].cnt_pass_acc = -1;
+      q->outs[0].wide = 1;
+      q->outs[0].out_width = 16;
+      q->dense_sorted = q->dense_out = 1;
+      q->batch_rows = 4;
+      gb_meta(q.get(), meta.get());
+      code.clear();
+      ok = compile(build_source("ldb_gb_kernel.h", "DGroupBy", GB_SPEC_SRC, (const unsigned char*) meta.get(), sizeof(DGroupBy)), &code, &err);
+   }
    if (ok) ok = ldb_scan_jit_check(&err);
    if (ok) ok = ldb_join_jit_check(&err);
    if (ok) ok = ldb_expr_jit_check(&err);

@@ -117,6 +117,9 @@ __global__ void k_join_probe_markbuild(const DJoin* __restrict__ d);
 __global__ void k_join_flags_bitmap(const uint8_t* __restrict__ flags, uint64_t n, int anti, uint64_t* __restrict__ bitmap, unsigned long long* __restrict__ counter) {
    join_flags_bitmap_body(flags, n, anti, bitmap, counter);
 }
+__global__ void k_join_flags_bitmap2(const uint8_t* __restrict__ flags, const uint8_t* __restrict__ not_flags, uint64_t n, uint64_t* __restrict__ bitmap, unsigned long long* __restrict__ counter) {
+   join_flags_bitmap_body(flags, n, 0, bitmap, counter, not_flags);
+}
 
 // run-time specialised variants (hiprtc; ldb_jit.hip)
 static const char* JOIN_SPEC_SRC =
@@ -136,7 +139,7 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
       auto meta = std::make_unique<DJoin>();
       memcpy(meta.get(), h, sizeof(DJoin));
       meta->n_rows = meta->cap = meta->slots = meta->out_probe = meta->out_build = meta->out_cap = 0;
-      meta->counter = meta->bitmap = meta->mark = meta->match = meta->flags = 0;
+      meta->counter = meta->bitmap = meta->mark = meta->mark2 = meta->match = meta->flags = 0;
       meta->kmin = meta->kmax = 0;
       meta->kmult = 0;
       meta->kmult32 = meta->ksh = 0;
@@ -147,6 +150,7 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
       ldb_jit_strip_keys(meta->bkeys);
       ldb_jit_strip_keys(meta->pkeys);
       for (int p = 0; p < LDB_MAX_PREDS; p++) ldb_jit_strip_pred(meta->ppreds[p]);
+      for (int p = 0; p < LDB_MAX_M2PREDS; p++) ldb_jit_strip_pred(meta->m2preds[p]);
       for (int k = 0; k < LDB_MAX_RESID; k++) {
          ldb_jit_strip_col(meta->resid[k].pcol);
          ldb_jit_strip_col(meta->resid[k].bcol);
@@ -807,9 +811,12 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
       if (build->n_rows) LDB_TRY(launch_join(ctx, h, d, ldb_grid_for(ctx, build->n_rows, 256, 8), "k_join_build", "k_join_build_spec", k_join_build));
       ldb_dev_free(ctx, d);
       uint64_t f = 0;
-      // open addressing: whether an insertion meets a long run depends on the order the insertions happened in — not a
-      // function of the data alone, so a prepared plan never replays this flag (one real wait per such build)
-      LDB_TRY(ldb_read_u64_at(ctx, dflags, &f, LDB_SITE, ht->direct ? 0 : LDB_RB_NEVER_REPLAY));
+      // open addressing: which insertion meets a long run depends on the order the insertions happen in, but whether ANY does is in practice
+      // a property of the keys (a run of 512 needs hundreds of equal or colliding keys: then some insertion walks it in every order).  The
+      // flag is replayed like any count — round 4 read it for real in every execution, one stream wait in the middle of every plan with an
+      // open-addressing build (Q18: 11.5 of 13.8 ms of host time blocked in this call) — and a run that does come out differently is caught
+      // by the comparison at the trace's end like any other mis-speculation
+      LDB_TRY(ldb_read_u64_at(ctx, dflags, &f, LDB_SITE, 0));
       if (ht->direct && (f & 1) && !ht->chained) { // duplicate keys in a direct table: chain them
          ht->chained = 1;
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) build->n_rows));
@@ -949,6 +956,55 @@ extern "C" int32_t ldb_gpu_join_probe_residual(ldb_ctx* ctx, ldb_hashtable* ht, 
                                                const ldb_join_residual* resid, int32_t n_resid, ldb_rel** out, ldb_table** mark_out) {
    return probe_impl(ctx, ht, probe, keys, n_keys, kind, resid, n_resid, out, mark_out, true);
 }
+// Build-side semi join AND build-side anti join against the same table in one pass over the probe side: *out = the build rows that have a
+// partner among the probe rows (key equality + residual conjuncts) but NO partner among the probe rows that also satisfy `anti_preds`.
+// Equal to SEMI_BUILD, a table over its result, and ANTI_BUILD probed by `probe` filtered on anti_preds — TPC-H Q21's EXISTS / NOT EXISTS
+// pair, which the reference runs as two marker joins (translateHJWithMarker, RelAlgToSubOp.cpp:1248-1287) — with one walk of each chain.
+extern "C" int32_t ldb_gpu_join_probe_semi_anti_build(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, const ldb_join_residual* resid,
+                                                      int32_t n_resid, const ldb_filter_desc* anti_preds, int32_t n_anti_preds, ldb_rel** out) {
+   if (!ctx || !ht || !probe || !out || n_keys < 1 || !anti_preds || n_anti_preds < 1) LDB_FAIL(LDB_ERR_INVALID, "join_probe_semi_anti_build: bad argument");
+   if (n_anti_preds > LDB_MAX_M2PREDS) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe_semi_anti_build: more than %d conjuncts on the anti side", LDB_MAX_M2PREDS);
+   LDB_TRY(ldb_rel_force(ctx, probe)); // (the second marker's conjuncts are evaluated per matching pair; a lazy probe filter is applied first)
+   auto hb = std::make_unique<DJoin>();
+   LDB_TRY(make_probe_desc(ht, probe, keys, n_keys, hb.get(), resid, n_resid));
+   hb->kind = LDB_JOIN_SEMI_BUILD;
+   for (int32_t p = 0; p < n_anti_preds; p++) LDB_TRY(ldb_make_dpred(probe, &anti_preds[p], &hb->m2preds[p]));
+   hb->n_m2preds = n_anti_preds;
+   const int64_t nb = ht->build->n_rows, nbw = (nb + 63) / 64;
+   LdbBufs tmp(ctx);
+   uint8_t *flags, *flags2;
+   uint64_t* bitmap;
+   LDB_TRY(tmp.alloc(&flags, 2 * (size_t) (nb ? nb : 1)));
+   flags2 = flags + (nb ? nb : 1);
+   LDB_TRY(tmp.alloc(&bitmap, 8 * (size_t) (nbw ? nbw : 1)));
+   LDB_HIP(hipMemsetAsync(flags, 0, 2 * (size_t) (nb ? nb : 1), ctx->stream));
+   hb->mark = (uint64_t) flags;
+   hb->mark2 = (uint64_t) flags2;
+   hb->has_mark = 1;
+   unsigned long long* cnt;
+   LDB_TRY(ldb_counters(ctx, 2, (uint64_t**) &cnt));
+   DJoin* d;
+   LDB_TRY(ldb_dev_upload(ctx, hb.get(), sizeof(DJoin), (void**) &d));
+   int32_t st = LDB_OK;
+   if (probe->n_rows) st = launch_join(ctx, hb.get(), d, ldb_grid_for(ctx, probe->n_rows, 256, 8), "k_join_probe_markbuild", "k_join_probe_markbuild_spec", k_join_probe_markbuild);
+   ldb_dev_free(ctx, d);
+   LDB_TRY(st);
+   if (nb) hipLaunchKernelGGL(k_join_flags_bitmap2, dim3(ldb_grid_for(ctx, nb, 256, 8)), dim3(256), 0, ctx->stream, (const uint8_t*) flags, (const uint8_t*) flags2, (uint64_t) nb, bitmap, cnt);
+   LDB_HIP(hipGetLastError());
+   uint64_t total = 0;
+   LDB_TRY(ldb_read_u64(ctx, cnt, &total));
+   uint32_t* sel;
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &sel, 4 * (size_t) (total ? total : 1)));
+   if (nbw && total) {
+      st = ldb_bitmap_compact(ctx, bitmap, nbw, sel, total, nullptr, nullptr, nullptr);
+      if (st != LDB_OK) {
+         ldb_dev_free(ctx, sel);
+         return st;
+      }
+   }
+   return ldb_rel_select(ctx, ht->build, sel, (int64_t) total, out);
+}
+
 static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const ldb_colref* keys, int32_t n_keys, int32_t kind, const ldb_join_residual* resid, int32_t n_resid,
                           ldb_rel** out, ldb_table** mark_out, bool radix_ok, const RadixProbe* part) {
    if (!ctx || !ht || !probe || !out) LDB_FAIL(LDB_ERR_INVALID, "join_probe: NULL argument");

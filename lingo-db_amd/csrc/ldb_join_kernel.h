@@ -8,6 +8,7 @@
 #include "ldb_keys.h"
 
 #define LDB_MAX_RESID 2
+#define LDB_MAX_M2PREDS 2
 struct DJoinResid {
    DCol pcol; // read at the probe relation's logical row
    DCol bcol; // read at the build relation's logical row
@@ -25,6 +26,7 @@ struct DJoin {
    uint64_t counter; // unsigned long long*: [0] = rows produced (may exceed out_cap), [1] = matches
    uint64_t bitmap; // uint64_t*: SEMI / ANTI / unique-build INNER
    uint64_t mark; // uint8_t*: MARK
+   uint64_t mark2; // uint8_t*: n_m2preds > 0 (build-side semi + anti in one pass): second flag per build row
    uint64_t match; // uint32_t*: unique-build path: build row (or LDB_NULL_ROW) per probe row; pairs path: per-chunk counts / offsets
    uint64_t flags; // uint32_t*: build: [0] |= 1 when two build rows carry the same key (or tag), |= 2 on a long probe run
    int64_t kmin, kmax; // KEY32 + ordered slots: range of the build keys
@@ -94,6 +96,13 @@ struct DJoin {
    int32_t pad_m;
    DJoinResid resid[LDB_MAX_RESID];
    DPred ppreds[LDB_MAX_PREDS];
+   // Build-side semi AND anti join against the same table in ONE pass (TPC-H Q21: EXISTS (l2 …) AND NOT EXISTS (l3 … AND l3.l_receiptdate >
+   // l3.l_commitdate) probe the same l_orderkey table with the same residual): a matching pair sets the build row's first flag, and its
+   // second flag too when the PROBE row also satisfies these conjuncts — evaluated only for rows that found a partner, so their columns
+   // are read for a few per cent of the probe side.  The reference runs two marker joins (translateHJWithMarker, RelAlgToSubOp.cpp:1248-1287).
+   int32_t n_m2preds;
+   int32_t pad_m2;
+   DPred m2preds[LDB_MAX_M2PREDS];
 };
 
 extern __shared__ uint32_t ldb_join_lds[]; // dynamic LDS of the probe kernels: the coarse key bitmap (has_coarse), else empty
@@ -1160,8 +1169,15 @@ __device__ __forceinline__ void join_probe_markbuild_body(const DJoin& m, const 
       pipe.step(m, d, t * JE_U * 64, n, par);
       d_probe_batch<JE_U>(
          m, d, rows, act, mt,
-         [&](int, uint32_t b) {
+         [&](int u, uint32_t b) {
             flags[b] = 1;
+            if (m.n_m2preds > 0) { // the second marker: this probe row also satisfies the extra conjuncts
+               bool also = true;
+               LDB_UNROLL
+               for (int p = 0; p < m.n_m2preds; p++)
+                  if (also) also = d_eval_pred(PV(m.m2preds[p], d->m2preds[p]), rows[u]);
+               if (also) gptr_mut<uint8_t>(d->mark2)[b] = 1;
+            }
             return true;
          },
          pipe.keys(m), pipe.words(m));
@@ -1170,7 +1186,7 @@ __device__ __forceinline__ void join_probe_markbuild_body(const DJoin& m, const 
 }
 // flags (one byte per build row) → ballot bitmap of the rows to keep (+ their count)
 __device__ __forceinline__ void join_flags_bitmap_body(const uint8_t* __restrict__ flags, uint64_t n, int anti, uint64_t* __restrict__ bitmap,
-                                                       unsigned long long* __restrict__ counter) {
+                                                       unsigned long long* __restrict__ counter, const uint8_t* __restrict__ not_flags = nullptr) {
    const uint64_t n_words = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;
    const uint64_t wave = d_wave_id();
@@ -1179,6 +1195,7 @@ __device__ __forceinline__ void join_flags_bitmap_body(const uint8_t* __restrict
    for (uint64_t w = wave; w < n_words; w += n_waves) {
       const uint64_t i = w * 64 + lane;
       bool keep = i < n && ((flags[i] != 0) != (anti != 0));
+      if (not_flags && keep) keep = not_flags[i] == 0; // semi + anti in one pass: the first marker set, the second not
       uint64_t mm = __ballot(keep);
       if (lane == 0) {
          bitmap[w] = mm;

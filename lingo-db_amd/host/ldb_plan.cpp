@@ -707,6 +707,18 @@ struct Interp {
          static const std::map<std::string, int32_t> kinds = {{"inner", LDB_JOIN_INNER}, {"semi", LDB_JOIN_SEMI}, {"anti", LDB_JOIN_ANTI}, {"left_outer", LDB_JOIN_LEFT_OUTER},
                                                              {"mark", LDB_JOIN_MARK},   {"single", LDB_JOIN_SINGLE}, {"semi_build", LDB_JOIN_SEMI_BUILD}, {"anti_build", LDB_JOIN_ANTI_BUILD},
                                                              {"right_outer", LDB_JOIN_RIGHT_OUTER}, {"full_outer", LDB_JOIN_FULL_OUTER}};
+         if (st.sOr("kind", "inner") == "semi_anti_build") {
+            // EXISTS (probe rows) AND NOT EXISTS (probe rows that also pass `anti_preds`) for every build row, one pass over the probe side
+            // (Q21; the reference lowers the two subqueries to two marker joins, translateHJWithMarker)
+            std::vector<ldb_join_residual> resid;
+            if (const J* rs = st.get("residual"))
+               for (auto& r : rs->arr) resid.push_back({resolve(*sides, r.s("probe"), "residual probe"), resolve(ht.sides, r.s("build"), "residual build"), opOf(r.s("op")), 0});
+            auto ap = preds(*sides, &st.at("anti_preds"));
+            ldb_rel* r;
+            check(ldb_gpu_join_probe_semi_anti_build(ctx, ht.ht, in, keys.data(), (int32_t) keys.size(), resid.data(), (int32_t) resid.size(), ap.data(), (int32_t) ap.size(), &r), "join_probe (semi + anti, build side)");
+            putRel(st.s("out"), r, ht.sides);
+            return;
+         }
          auto kit = kinds.find(st.sOr("kind", "inner"));
          if (kit == kinds.end()) throw std::runtime_error("join_probe: unknown kind");
          const int32_t kind = kit->second;

@@ -458,6 +458,19 @@ class HashTable:
             return out, Table(self.ctx, m)
         return out
 
+    def probe_semi_anti_build(self, probe_rel, keys, anti_preds, residual=()):
+        """build rows with a partner among the probe rows and none among the probe rows that also pass `anti_preds`
+        (ldb_gpu_join_probe_semi_anti_build: SEMI_BUILD + ANTI_BUILD over the same table in one pass)"""
+        arr, n = _refs(keys)
+        ra = (capi.JoinResidual * max(len(residual), 1))()
+        for i, (pc, op, bc) in enumerate(residual):
+            ra[i].probe_col, ra[i].op, ra[i].build_col = colref(*pc), op, colref(*bc)
+        parr, np_, keep = preds_array(anti_preds)
+        r = C.c_void_p()
+        check(self.ctx.lib.ldb_gpu_join_probe_semi_anti_build(self.ctx.h, self.h, probe_rel.h, arr, n, ra, len(residual), parr, np_, C.byref(r)))
+        del keep
+        return Rel(self.ctx, r, probe_rel.deps + self.build.deps + [self.build])
+
     def probe_count(self, probe_rel, keys):
         arr, n = _refs(keys)
         c = C.c_int64()

@@ -221,6 +221,7 @@ GPU_API = {
     "ldb_gpu_hashtable_bytes": (i64, [P]),
     "ldb_gpu_join_probe": (i32, [P, P, P, C.POINTER(ColRef), i32, i32, PP, PP]),
     "ldb_gpu_join_probe_residual": (i32, [P, P, P, C.POINTER(ColRef), i32, i32, C.POINTER(JoinResidual), i32, PP, PP]),
+    "ldb_gpu_join_probe_semi_anti_build": (i32, [P, P, P, C.POINTER(ColRef), i32, C.POINTER(JoinResidual), i32, C.POINTER(FilterDesc), i32, PP]),
     "ldb_gpu_join_nl": (i32, [P, P, P, i32, C.POINTER(JoinResidual), i32, PP, PP]),
     "ldb_gpu_join_probe_count": (i32, [P, P, P, C.POINTER(ColRef), i32, C.POINTER(i64)]),
     "ldb_gpu_sort": (i32, [P, P, C.POINTER(SortSpec), i32, PP]),

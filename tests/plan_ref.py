@@ -298,6 +298,10 @@ class Interp:
             out = p.take([i for i in range(p.n) if matched[i]])
         elif kind == "anti":
             out = p.take([i for i in range(p.n) if not matched[i]])
+        elif kind == "semi_anti_build":  # a partner among the probe rows, none among those that also pass anti_preds
+            am = self.conj_mask(p, st["anti_preds"])
+            hit_anti = {j for i, j in pairs if am[i]}
+            out = b.take([j for j in sorted(hit_b) if j not in hit_anti])
         elif kind == "semi_build":
             out = b.take(sorted(hit_b))
         elif kind == "anti_build":

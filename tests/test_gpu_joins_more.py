@@ -45,6 +45,45 @@ def test_build_side_semi_with_duplicate_build_keys(ctx, oracle):
             assert np.array_equal(gb.join_build(keys).probe(gp, keys, kind).rowids(0), want)
 
 
+@pytest.mark.parametrize("layout", ["int32 keys (direct / chained)", "int64 keys (hashed)", "row-id probe side"])
+def test_build_side_semi_and_anti_in_one_pass_q21_shape(ctx, layout):
+    """ldb_gpu_join_probe_semi_anti_build (TPC-H Q21: EXISTS l2 AND NOT EXISTS late l3, both with l_suppkey <> l1.l_suppkey): the build rows with a
+    partner among the probe rows and none among the probe rows that also pass the extra conjunct — against plain numpy, and equal to the two-step
+    form (SEMI_BUILD, a table over its result, ANTI_BUILD probed by the filtered probe side); duplicate build keys, NULL-free integer keys"""
+    rng = np.random.default_rng(2121)
+    nb, npr = 40_000, 400_000
+    kt = pa.int64() if layout.startswith("int64") else pa.int32()
+    bk, bs = rng.integers(0, 30_000, nb), rng.integers(0, 6, nb)
+    pk, ps = rng.integers(0, 33_000, npr), rng.integers(0, 6, npr)
+    pa_, pb_ = rng.integers(0, 100, npr), rng.integers(0, 100, npr)  # "late" = a > b
+    b = ctx.register("q21_build", pa.table({"k": pa.array(bk, kt), "s": pa.array(bs, pa.int32())}))
+    p = ctx.register("q21_probe", pa.table({"k": pa.array(pk, kt), "s": pa.array(ps, pa.int32()), "a": pa.array(pa_, pa.int32()), "b": pa.array(pb_, pa.int32())}))
+    prel = p.rel()
+    keep = np.arange(npr)
+    if layout.startswith("row-id"):
+        prel = prel.scan_filter([api.pred((0, 3), capi.F_LT, 90)])  # materialised row ids on the probe side
+        keep = np.nonzero(pb_ < 90)[0]
+    # numpy: per key the set of supplier values among all / among late probe rows
+    late = pa_ > pb_
+    all_by_key, late_by_key = {}, {}
+    for i in keep:
+        all_by_key.setdefault(int(pk[i]), set()).add(int(ps[i]))
+        if late[i]:
+            late_by_key.setdefault(int(pk[i]), set()).add(int(ps[i]))
+    want = [j for j in range(nb) if (all_by_key.get(int(bk[j]), set()) - {int(bs[j])}) and not (late_by_key.get(int(bk[j]), set()) - {int(bs[j])})]
+    assert 0 < len(want) < nb
+    resid = [((0, 1), capi.F_NEQ, (0, 1))]
+    anti = [api.pred((0, 2), capi.F_GT, rhs_col=(0, 3))]
+    ht = b.rel().join_build([(0, 0)])
+    got = ht.probe_semi_anti_build(prel, [(0, 0)], anti, residual=resid)
+    assert got.sides == 1 and np.array_equal(got.rowids(0), np.array(want, dtype=np.uint32))
+    # the two-step form
+    l2 = ht.probe(prel, [(0, 0)], capi.JOIN_SEMI_BUILD, residual=resid)
+    late_rel = p.rel().scan_filter(([api.pred((0, 3), capi.F_LT, 90)] if layout.startswith("row-id") else []) + anti)
+    l3 = l2.join_build([(0, 0)]).probe(late_rel, [(0, 0)], capi.JOIN_ANTI_BUILD, residual=resid)
+    assert np.array_equal(l3.rowids(0), got.rowids(0))
+
+
 def test_ordered_slots_fall_back_to_hashing_on_clustered_keys(ctx, oracle):
     """KEY32 tables spread their slots over [min key, max key]; one outlier key squeezes all others
     into a handful of slots → the build sees long probe runs and must rebuild hashed.  Results are

@@ -481,6 +481,62 @@ def test_groupby_run_combining_high_cardinality(ctx, oracle):
             assert s == pytest.approx(vals[gi][0], rel=1e-9, abs=1e-9) and mn == vals[gi][1] and mx == vals[gi][2]
 
 
+def test_groupby_sorted_keys_final_rows_from_the_wave(ctx, oracle):
+    """sorted NOT NULL key column (DGroupBy::dense_sorted): groups inside one 64-row chunk leave the kernel as final rows, groups that cross a
+    chunk boundary go through one table slot per chunk (dense_out).  Run lengths 1 … 9 mixed with groups of 60 – 400 rows (several whole
+    chunks: the slot of the group's first chunk is found by bisection), a group that begins exactly on a chunk boundary, one that ends on one, a
+    single group over everything; SUM / COUNT / MIN / MAX / AVG / 128-bit SUM / conditional aggregates / float aggregates / 128-bit MIN, NULL
+    values.  Against the oracle, and identical to the table path (gb_dense_out = 0) and the hashed path (gb_sorted = 0)."""
+    rng = np.random.default_rng(2718)
+    lib = capi.gpu_lib()
+    f = api.factor
+    D = capi.T_DECIMAL128
+    shapes = []
+    runs = np.where(rng.random(6000) < 0.03, rng.integers(60, 400, 6000), rng.integers(1, 10, 6000))
+    shapes.append(runs)
+    shapes.append(np.array([64, 64, 1, 63, 128, 5, 59, 192, 1, 1, 62, 700, 3]))  # boundaries hit exactly
+    shapes.append(np.array([5000]))  # one group
+    shapes.append(np.ones(777, dtype=np.int64))  # every row its own group
+    for runs in shapes:
+        k = np.repeat(np.arange(len(runs)) * 7 - 1000, runs).astype(np.int64)
+        n = len(k)
+        v = [None if x % 11 == 0 else int(x) for x in rng.integers(-10**9, 10**9, n)]
+        w = rng.integers(0, 100, n)
+        x = rng.uniform(-5, 5, n)
+        big = [None if i % 13 == 0 else decimal.Decimal(int(a) * (1 << 70) + int(b)) for i, (a, b) in enumerate(zip(rng.integers(-4, 5, n), rng.integers(0, 1 << 60, n)))]
+        t = pa.table({"k": pa.array(k), "v": pa.array(v, pa.int64()), "w": pa.array(w, pa.int32()), "x": pa.array(x, pa.float64()), "b": pa.array(big, pa.decimal128(38, 0)),
+                      "d": pa.array([decimal.Decimal(int(q)) / 100 for q in rng.integers(0, 10**6, n)], pa.decimal128(12, 2))})
+        g, h = ctx.register("sorted_runs", t), HostTable(t)
+        sq = api.expr([{"factors": [f(0, 1, (0, 1)), f(0, 1, (0, 1)), f(3, 1, (0, 2))]}])
+        cond = [api.pred((0, 2), capi.F_GTE, 50)]
+        aggs = [api.agg(capi.AGG_SUM, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT, api.col_expr((0, 1))), api.agg(capi.AGG_MIN, api.col_expr((0, 1))),
+                api.agg(capi.AGG_MAX, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT_STAR), api.agg(capi.AGG_SUM, sq, wide=True, out_type=D, p=38, s=0),
+                api.agg(capi.AGG_SUM, api.col_expr((0, 1)), preds=cond), api.agg(capi.AGG_COUNT_STAR, preds=cond),
+                api.agg(capi.AGG_AVG, api.col_expr((0, 5)), out_type=D, p=31, s=21, avg_pow10=19), api.agg(capi.AGG_SUM, api.col_expr((0, 5)), out_type=D, p=12, s=2),
+                api.agg(capi.AGG_MIN, api.col_expr((0, 4)), wide=True, out_type=D, p=38, s=0), api.agg(capi.AGG_MAX, api.col_expr((0, 4)), wide=True, out_type=D, p=38, s=0)]
+        faggs = [api.agg(capi.AGG_SUM, api.col_expr((0, 3), True), out_type=capi.T_FLOAT64), api.agg(capi.AGG_MIN, api.col_expr((0, 3), True), out_type=capi.T_FLOAT64),
+                 api.agg(capi.AGG_MAX, api.col_expr((0, 3), True), out_type=capi.T_FLOAT64)]
+        rep, vals, valid = oracle.groupby(h.rel(), [(0, 0)], aggs)
+        got = g.rel().groupby([(0, 0)], aggs, est_groups=len(runs))
+        assert got.rows == len(runs)
+        assert_groupby_equal(got, h.rel(), [(0, 0)], rep, vals, valid)
+        dense_rows = rows_of(got.to_arrow())
+        assert [r[0] for r in dense_rows] == sorted(r[0] for r in dense_rows)  # groups come out in key order
+        frow = rows_of(g.rel().groupby([(0, 0)], faggs, est_groups=len(runs)).to_arrow())
+        try:
+            for opt in (b"gb_dense_out", b"gb_sorted"):
+                lib.ldb_gpu_set_option(opt, 0)
+                other = rows_of(g.rel().groupby([(0, 0)], aggs, est_groups=len(runs)).to_arrow())
+                assert sorted(other, key=repr) == sorted(dense_rows, key=repr), opt
+                fo = {r[0]: r[1:] for r in rows_of(g.rel().groupby([(0, 0)], faggs, est_groups=len(runs)).to_arrow())}
+                for r in frow:
+                    assert r[1] == pytest.approx(fo[r[0]][0], rel=1e-9, abs=1e-9) and r[2:] == fo[r[0]][1:]
+        finally:
+            lib.ldb_gpu_set_option(b"gb_dense_out", 1)
+            lib.ldb_gpu_set_option(b"gb_sorted", 1)
+        g.release()
+
+
 def test_groupby_direct_address_slots(ctx, oracle):
     """one NOT NULL integer key whose value range is at most twice the expected groups: the table is indexed by
     key - min (DGroupBy::direct) — no slot word, no probing, the key column written from the slot number.  Random

@@ -200,12 +200,14 @@ class Runner:
 
     def prepared_stats(self):
         """executions / replays / mis-speculations of the prepared plans + the context's descriptor-cache counters"""
-        tot = {"executions": 0, "replays": 0, "misses": 0, "readbacks_per_pass": 0, "host_issue_ms_per_replay": {}, "host_wait_ms_per_replay": {}}
+        tot = {"executions": 0, "replays": 0, "misses": 0, "misses_by_query": {}, "readbacks_per_pass": 0, "host_issue_ms_per_replay": {}, "host_wait_ms_per_replay": {}}
         for q, p in sorted(self.prepared.items()):
             st = p.stats()
             tot["executions"] += st["executions"]
             tot["replays"] += st["replays"]
             tot["misses"] += st["misses"]
+            if st["misses"]:
+                tot["misses_by_query"]["Q%d" % q] = st["misses"]
             tot["readbacks_per_pass"] += st["readbacks"]
             if st["replays"]:  # how long the host needs to issue the plan vs how long it then waits for the device
                 tot["host_issue_ms_per_replay"]["Q%d" % q] = round(st["issue_ms"] / st["replays"], 3)
@@ -374,12 +376,12 @@ def _canon(table):
 _LIMITS = {3: (10, lambda r: (-r[1], r[2])), 10: (20, lambda r: -r[2]), 18: (100, lambda r: (-r[4], r[3]))}
 
 
-def matches_legs(q, got, want):
+def matches_legs(q, got, want, allow_empty=False):
     """GPU result rows of TPC-H Q`q` (in the legs' conventions, _canon) against the oracle leg's rows: bit-exact row for row; LIMIT queries on
     their ORDER BY keys + membership (ties beyond the keys are unspecified in the reference too); Q5 / Q11 (ORDER BY one aggregate) up to
-    swaps of equal values.  An empty oracle result never counts as a match (the check would be vacuous)."""
+    swaps of equal values.  An empty oracle result counts as a match only where the caller says the query may be empty (the check would be vacuous)."""
     if not want:
-        return False
+        return allow_empty and not got
     if q in _LIMITS:
         k, key = _LIMITS[q]
         return bool(len(got) == min(k, len(want)) and [key(r) for r in got] == [key(r) for r in want[: len(got)]] and set(got) <= set(want))
@@ -461,7 +463,11 @@ def cpu_baseline(queries, sample_sf, runs="1+3", budget_s=100.0, ctx=None, narro
             ver = {}
             for q in done:
                 if q in got and q in leg_rows:
-                    ver["Q%d" % q] = matches_legs(q, _canon(got[q]), leg_rows[q])
+                    # Q11's HAVING fraction is the constant 0.0001 of the reference's resources/sql/tpch/11.sql (the TPC-H text scales it by 1 / SF): from
+                    # about SF 3 on no part reaches it and the query returns no row — on both sides
+                    ver["Q%d" % q] = matches_legs(q, _canon(got[q]), leg_rows[q], allow_empty=(q == 11))
+                    if not leg_rows[q]:
+                        checks.setdefault("empty_results_at_sample", []).append("Q%d" % q)
             checks["oracle_bit_exact_at_sample_sf%g" % sample_sf] = ver
             checks["oracle_bit_exact_at_sample_all"] = bool(ver) and all(ver.values())
     return out
