@@ -624,16 +624,50 @@ __device__ __forceinline__ void d_eval_conj_batch(const DPred* mp, const DPred* 
          // bytes, made the 20 M-name LIKE scan of Q9 take 4.9 ms
          const bool simple = mp[p].n_in > 0; // position-parallel matcher (d_like_simple_wave)
          if (!simple && lane < (uint32_t) mp[p].str_len) stage[LDS_STR_PAT + lane] = (uint8_t) mp[p].str[lane];
+         // Software pipeline over the batch slots.  A slot is a dependent chain offsets → string bytes → LDS → match, and a wave that walks it
+         // slot by slot pays two global round trips per 64 rows with nothing else in flight (Q13: 150 M comments at 2.2 TB/s, 0.27 of peak).
+         // So: the offsets of ALL slots are loaded first (independent), and the string bytes of slot u + 1 travel into registers while slot
+         // u is being matched out of LDS (up to LDS_STR_STAGE bytes per wave = 12 eight-byte words per lane).
+         typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+         constexpr int NPRE = LDS_STR_STAGE / 512;
+         int64_t ob[U], oe[U];
 #pragma unroll
          for (int u = 0; u < U; u++) {
-            if (__ballot(pass[u]) == 0) continue; // wave-uniform
             const uint64_t row = rows[u] < n_rows ? rows[u] : n_rows; // offsets has n_rows + 1 entries
-            const int64_t o = offs[row], o1 = offs[row < n_rows ? row + 1 : n_rows];
+            ob[u] = offs[row];
+            oe[u] = offs[row < n_rows ? row + 1 : n_rows];
+         }
+         uint64_t pre[NPRE];
+#pragma unroll
+         for (int t = 0; t < NPRE; t++) pre[t] = 0;
+         auto fetch = [&](int u) __attribute__((always_inline)) {
+            if (__ballot(pass[u]) == 0) return; // wave-uniform
+            const int64_t begin = __shfl((long long) ob[u], 0), end = __shfl((long long) oe[u], 63);
+            const uint64_t span = (uint64_t) (end - begin);
+            if (span > LDS_STR_STAGE) return;
+#pragma unroll
+            for (int t = 0; t < NPRE; t++) {
+               const uint64_t k = (uint64_t) lane * 8 + (uint64_t) t * 512;
+               if (k < span) pre[t] = *(const LDB_GLOBAL u64_unaligned*) (vals + begin + k);
+            }
+         };
+         fetch(0);
+#pragma unroll
+         for (int u = 0; u < U; u++) {
+            if (__ballot(pass[u]) == 0) { // wave-uniform
+               if (u + 1 < U) fetch(u + 1);
+               continue;
+            }
+            const int64_t o = ob[u], o1 = oe[u];
             const int64_t begin = __shfl((long long) o, 0), end = __shfl((long long) o1, 63);
             const uint64_t span = (uint64_t) (end - begin);
             if (span <= LDS_STR_STAGE) {
-               typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-               for (uint64_t k = (uint64_t) lane * 8; k < span; k += 512) *(uint64_t*) (stage + k) = *(const LDB_GLOBAL u64_unaligned*) (vals + begin + k);
+#pragma unroll
+               for (int t = 0; t < NPRE; t++) {
+                  const uint64_t k = (uint64_t) lane * 8 + (uint64_t) t * 512;
+                  if (k < span) *(uint64_t*) (stage + k) = pre[t];
+               }
+               if (u + 1 < U) fetch(u + 1); // the next slot's bytes are on their way while this one is matched
                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                __builtin_amdgcn_wave_barrier();
                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -647,8 +681,9 @@ __device__ __forceinline__ void d_eval_conj_batch(const DPred* mp, const DPred* 
                   pass[u] = d_like_on(s, (uint32_t) (o1 - o), pat, (uint32_t) mp[p].str_len) == (mp[p].op == LDB_F_LIKE);
                }
                __builtin_amdgcn_wave_barrier(); // the next batch slot overwrites the stage
-            } else if (pass[u]) {
-               pass[u] = d_eval_pred(pv, rows[u]);
+            } else {
+               if (u + 1 < U) fetch(u + 1);
+               if (pass[u]) pass[u] = d_eval_pred(pv, rows[u]);
             }
          }
       } else if (d_pred_is_colcol_dense(mp[p])) {

@@ -97,6 +97,39 @@ __global__ __launch_bounds__(GBP_BLOCK) void k_gbp_count(const uint32_t* __restr
    for (uint32_t j = threadIdx.x; j < (1u << GBP_SHIFT); j += GBP_BLOCK) out[j] = c[j];
 }
 
+// the general case of the partitioned path: ANY aggregates over direct slots (Q15: SUM of a 128-bit product per supplier over 23 M random
+// keys — 13 G global atomics / s = 4.6 ms).  The (slot, row) pairs are partitioned by slot range like the counts above; ONE workgroup then owns
+// 2^shift consecutive slots, keeps their accumulator words in LDS (word w of local slot j at lds[w << shift | j]), folds its rows in with LDS
+// atomics — the row's columns are gathered by row number — and writes the finished words to the table with plain coalesced stores.  The
+// reference's merge works the same way: one task per partition of the pre-aggregation fragments (PreAggregationHashtable.cpp:76-158).
+extern __shared__ __attribute__((aligned(16))) unsigned long long gbp_lds[];
+__global__ __launch_bounds__(GBP_BLOCK) void k_gbp_agg(const DGroupBy* __restrict__ d, const uint32_t* __restrict__ slots, const uint32_t* __restrict__ rows, const uint32_t* __restrict__ offs,
+                                                       uint32_t grid0, uint32_t nparts, uint64_t n_total, uint32_t shift) {
+   const uint32_t P = 1u << shift;
+   const int nw = d->n_words;
+   for (int w = 0; w < nw; w++) {
+      const unsigned long long init = d->word_init[w];
+      for (uint32_t j = threadIdx.x; j < P; j += GBP_BLOCK) gbp_lds[((uint32_t) w << shift) + j] = init;
+   }
+   __syncthreads();
+   const uint32_t p = blockIdx.x;
+   const uint64_t b = offs[(uint64_t) p * grid0], e = p + 1 < nparts ? (uint64_t) offs[(uint64_t) (p + 1) * grid0] : n_total;
+   for (uint64_t i = b + threadIdx.x; i < e; i += GBP_BLOCK) {
+      const uint32_t slot = slots[i] & (P - 1);
+      const uint64_t row = rows[i];
+      RowVals rv;
+      uint32_t rvalid;
+      d_load_vals(*d, d, row, rv, rvalid);
+      const Sink s{gbp_lds + slot, P};
+      d_accumulate(*d, d, rv, rvalid, row, s);
+   }
+   __syncthreads();
+   unsigned long long* acc = (unsigned long long*) d->g_acc;
+   const uint64_t cap = d->g_cap;
+   for (int w = 0; w < nw; w++)
+      for (uint32_t j = threadIdx.x; j < P; j += GBP_BLOCK) acc[(uint64_t) w * cap + ((uint64_t) p << shift) + j] = gbp_lds[((uint32_t) w << shift) + j];
+}
+
 // compact occupied slots → dense outputs
 // occupied slots per 64-slot chunk (→ exclusive scan → output position of every group).  A cursor
 // atomic per wave instead is one contended address: ~10 ns each in the L2 — 84 ms for the 8.4 M
@@ -289,6 +322,19 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
             LDB_TRY(ldb_rel_force(ctx, in));
             break;
          }
+   // one integer key over a range too large for the caches, many rows, a lazy filter in front: the filter is evaluated FIRST — the partitioned
+   // aggregation below (k_gbp_agg) wants the surviving rows as a dense list, and a selective filter (Q15: 23 M of 600 M rows) then decides
+   // whether it is worth it at all.  The fused alternative pays one global atomic per accumulator and surviving row.
+   if (n_keys == 1 && n_preds == 0 && !in->pending.empty() && in->n_rows >= ldb_option("gb_partition_min_rows", 8ll << 20) && ldb_option("gb_partition", 1) != 0 &&
+       ldb_option("gb_partition_values", 1) != 0 && ldb_option("gb_direct", 1) != 0 && est_groups >= (1 << 19)) {
+      const ldb_rel_side& ks = in->sides[(size_t) keys[0].side];
+      const ldb_column& kc = ks.table->cols[(size_t) keys[0].col];
+      int64_t lo = 0, hi = -1;
+      if (!kc.validity && !ks.rowids && (kc.width == 4 || kc.width == 8) && ldb_column_range(ctx, ks.table, keys[0].col, &lo, &hi) == LDB_OK && hi >= lo) {
+         const unsigned __int128 range = (unsigned __int128) ((__int128) hi - lo) + 1;
+         if (range >= ((unsigned __int128) 1 << 19) && range <= (unsigned __int128) est_groups * 2 && range <= ((unsigned __int128) 1 << 30)) LDB_TRY(ldb_rel_force(ctx, in));
+      }
+   }
    if (n_aggs < 0 || n_aggs > GB_MAX_OUT) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: %d aggregates (max %d)", n_aggs, GB_MAX_OUT);
    if (in->n_rows >= (int64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "groupby: too many rows");
    auto hp = std::make_unique<DGroupBy>();
@@ -676,6 +722,13 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       // COUNT(*) per key over direct slots, many rows into a table far beyond the L2: partition, then count in LDS
       const bool partitioned = h->direct && h->n_words == 1 && h->n_accs == 1 && h->n_preds == 0 && h->n_cpreds == 0 && cap >= (1ull << 20) && (cap >> GBP_SHIFT) <= GBP_MAX_PARTS &&
          in->n_rows >= ldb_option("gb_partition_min_rows", 8ll << 20) && (uint64_t) in->n_rows < (1ull << 32) && ldb_option("gb_partition", 1) != 0;
+      // the same for arbitrary aggregates (k_gbp_agg): as many slots per partition as their accumulator words fit into 60 KB of LDS
+      uint32_t pv_shift = 0;
+      while (pv_shift < 16 && ((size_t) 8 * (size_t) nw << (pv_shift + 1)) <= 60 * 1024) pv_shift++;
+      bool wide_minmax = false;
+      for (int a = 0; a < h->n_accs; a++) wide_minmax = wide_minmax || h->accs[a].kind == ACC_MIN128 || h->accs[a].kind == ACC_MAX128;
+      const bool part_values = !partitioned && h->direct && h->n_preds == 0 && !wide_minmax && cap >= (1ull << 20) && pv_shift >= 8 && (cap >> pv_shift) <= GBP_MAX_PARTS &&
+         in->n_rows >= ldb_option("gb_partition_min_rows", 8ll << 20) && (uint64_t) in->n_rows < (1ull << 32) && ldb_option("gb_partition", 1) != 0 && ldb_option("gb_partition_values", 1) != 0;
       if (partitioned) {
          const uint32_t nparts = (uint32_t) (cap >> GBP_SHIFT);
          const uint32_t g0 = (uint32_t) std::max<int64_t>(1, std::min<int64_t>((int64_t) ctx->cus, (in->n_rows + 16383) / 16384));
@@ -724,6 +777,25 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          ldb_dev_free(ctx, hist);
          ldb_dev_free(ctx, offs);
          ldb_dev_free(ctx, slots);
+      } else if (part_values) {
+         // any aggregates over direct slots too many for the caches, many rows: partition (slot, row) pairs, aggregate every slot range in LDS
+         const uint32_t nparts = (uint32_t) (cap >> pv_shift);
+         uint32_t *raw, *slots, *prow, *part = nullptr, chunks = 1;
+         LdbBufs tmpb(ctx);
+         LDB_TRY(tmpb.alloc(&raw, 4 * (size_t) in->n_rows));
+         LDB_TRY(tmpb.alloc(&slots, 4 * (size_t) in->n_rows));
+         LDB_TRY(tmpb.alloc(&prow, 4 * (size_t) in->n_rows));
+         {
+            LdbProf prof_(ctx, "k_gbp_slots");
+            hipLaunchKernelGGL(k_gbp_slots, dim3(ldb_grid_for(ctx, in->n_rows, 256, 8)), dim3(256), 0, ctx->stream, (const DGroupBy*) d, raw);
+         }
+         LDB_TRY(ldb_wc_partition(ctx, raw, nullptr, (uint64_t) in->n_rows, 0u, (uint32_t) (cap - 1), pv_shift, nparts, slots, prow, &part, &chunks, "k_gbp_hist", "k_gbp_scatter"));
+         {
+            LdbProf prof_(ctx, "k_gbp_agg");
+            hipLaunchKernelGGL(k_gbp_agg, dim3(nparts), dim3(GBP_BLOCK), (size_t) 8 * (size_t) nw << pv_shift, ctx->stream, (const DGroupBy*) d, (const uint32_t*) slots, (const uint32_t*) prow,
+                               (const uint32_t*) part, chunks, nparts, (uint64_t) in->n_rows, pv_shift);
+         }
+         ldb_dev_free(ctx, part);
       } else if (in->n_rows) {
          int per_cu = lds_bytes > 40 * 1024 ? 2 : 4;
          if (const int64_t forced = ldb_option("gb_wgs_per_cu", 0)) per_cu = (int) std::max<int64_t>(1, std::min<int64_t>(forced, 16)); // experiments (Q1's line re-fetches)

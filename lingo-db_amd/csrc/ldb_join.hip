@@ -45,6 +45,7 @@ struct ldb_hashtable {
    uint32_t* coarse = nullptr; // one bit per 64 key values (DJoin::has_coarse), or NULL
    uint32_t coarse_words = 0; // direct == 2: a key's rank IS its build row (ascending keys without NULLs); else next[] = rank → row
    size_t slot_bytes = 0; // bytes of the slot array (cap x 8, or cap x 4 when direct)
+   int32_t pair32 = 0; // two 4-byte keys: slots are pairs of words (DJoin::pair32), cap x 16 bytes
    // the table owns its device buffers: an early error return from the build frees them with the object
    ~ldb_hashtable() {
       if (!ctx) return;
@@ -787,7 +788,16 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
       ht->chained = 1;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) (build->n_rows ? build->n_rows : 1)));
    }
-   ht->slot_bytes = (ht->direct ? 4 : 8) * (size_t) ht->cap;
+   // two 4-byte integer keys, open addressing: the key values live in the slot (DJoin::pair32)
+   if (!ht->direct && !ht->chained && n_keys == 2 && ldb_option("join_pair32", 1) != 0) {
+      bool narrow = true;
+      for (int k = 0; k < 2; k++) {
+         const DCol& c = h->bkeys.cols[k];
+         narrow = narrow && c.width == 4 && (c.type == LDB_T_INT32 || c.type == LDB_T_DATE32 || c.type == LDB_T_CHAR4);
+      }
+      ht->pair32 = narrow ? 1 : 0;
+   }
+   ht->slot_bytes = (ht->direct ? 4 : ht->pair32 ? 16 : 8) * (size_t) ht->cap;
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->slots, ht->slot_bytes));
    LDB_HIP(hipMemsetAsync(ht->slots, 0, ht->slot_bytes, ctx->stream));
    h->cap = ht->cap;
@@ -805,6 +815,8 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
       h->has_key_bits = ht->key_bits ? 1 : 0;
       h->chained = ht->chained;
       h->next = (uint64_t) ht->next;
+      if (ht->chained) ht->pair32 = 0; // (a chained rebuild uses the first cap words of the same allocation)
+      h->pair32 = ht->pair32;
       DJoin* d;
       LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
       if (build->n_rows && h->has_key_bits && (h->ordered_slots || h->direct)) hipLaunchKernelGGL(k_join_key_bits, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d);
@@ -888,6 +900,15 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    h->has_key_bits = ht->key_bits ? 1 : 0;
    h->chained = ht->chained;
    h->next = (uint64_t) ht->next;
+   h->pair32 = 0;
+   if (ht->pair32 && !ht->chained) { // verify from the slot when the probe's key columns are 4-byte integers too, else through the rows
+      bool narrow = true;
+      for (int k = 0; k < 2; k++) {
+         const DCol& c = h->pkeys.cols[k];
+         narrow = narrow && c.width == 4 && (c.type == LDB_T_INT32 || c.type == LDB_T_DATE32 || c.type == LDB_T_CHAR4);
+      }
+      h->pair32 = narrow ? 1 : 2;
+   }
    h->build_unique = (ht->unique && !ht->chained) ? 1 : 0;
    // a lazy probe relation brings its filter along: evaluated inside the probe kernel
    h->n_ppreds = (int32_t) probe->pending.size();

@@ -93,7 +93,11 @@ struct DJoin {
    // and tested first — a clear bit proves the miss without leaving the CU.  Only for probe launches without a fused
    // filter (the tile kernels are written for 256-thread workgroups).
    int32_t has_coarse;
-   int32_t pad_m;
+   // TWO 4-byte integer keys (ps_partkey, ps_suppkey; l_suppkey, c_nationkey …) in a hashed table: a slot is a PAIR of words, the usual
+   // {hash tag : build row + 1} and behind it the two key values themselves, so a probe verifies its candidate from the 16 bytes it has just
+   // loaded instead of gathering two key columns at the build row (Q9: 32 M probes, two random lines less each).  1 = verify from the pair,
+   // 2 = the pair layout is there but the probe's key columns are not both 4 bytes wide: verify through the rows as before.
+   int32_t pair32;
    DJoinResid resid[LDB_MAX_RESID];
    DPred ppreds[LDB_MAX_PREDS];
    // Build-side semi AND anti join against the same table in ONE pass (TPC-H Q21: EXISTS (l2 …) AND NOT EXISTS (l3 … AND l3.l_receiptdate >
@@ -139,6 +143,13 @@ __device__ __forceinline__ uint64_t d_join_slot(const DJoin& m, const DJoin* __r
    x *= 0xFF51AFD7ED558CCDull;
    x ^= x >> 33;
    return x & mask;
+}
+
+// the two 4-byte key values of logical row i as one word (pair32; the caller has checked that neither is NULL)
+__device__ __forceinline__ unsigned long long d_key_pair32(const KV& keys, uint64_t i) {
+   const CV a = keys.col(0), b = keys.col(1);
+   const uint32_t ka = (uint32_t) d_load_i64(a, d_phys_row(a, i)), kb = (uint32_t) d_load_i64(b, d_phys_row(b, i));
+   return (unsigned long long) ka | ((unsigned long long) kb << 32);
 }
 
 __device__ __forceinline__ void join_build_body(const DJoin& m, const DJoin* __restrict__ d) {
@@ -205,9 +216,13 @@ __device__ __forceinline__ void join_build_body(const DJoin& m, const DJoin* __r
          }
          continue;
       }
+      const int ss = m.pair32 ? 1 : 0; // pair32: slot p = words 2p (tag : row) and 2p + 1 (the two key values)
       for (;;) {
-         unsigned long long old = atomicCAS(&slots[pos], 0ull, (unsigned long long) word);
-         if (old == 0) break;
+         unsigned long long old = atomicCAS(&slots[pos << ss], 0ull, (unsigned long long) word);
+         if (old == 0) {
+            if (m.pair32) slots[(pos << 1) + 1] = d_key_pair32(bkeys, i); // (read by the probe kernels only: a later launch)
+            break;
+         }
          // same key (KEY32) / same hash tag AND equal key columns (TAG mode: a 32-bit tag collision of
          // different keys is not a duplicate): the build side is not unique
          if (m.has_flags && (old >> 32) == (word >> 32) && (m.key32 || d_keys_equal(bkeys, (uint64_t) ((uint32_t) old - 1u), bkeys, i, false))) {
@@ -560,6 +575,42 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
          hw[u] = bits_only ? 1u : tab[pos[u]];
       }
       d_direct_resolve<U>(m, d, rows, live, hw, bits_only, matches, emit);
+      return;
+   }
+   if (m.pair32 && !m.chained) { // two 4-byte keys: the slot carries them, no gather at the build row
+      typedef unsigned long long __attribute__((ext_vector_type(2))) slot_pair;
+      const slot_pair* pairs = (const slot_pair*) slots;
+      slot_pair sp[U];
+      unsigned long long mine[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         sp[u] = slot_pair{0ull, 0ull};
+         mine[u] = 0;
+         if (!live[u]) continue;
+         sp[u] = pairs[pos[u]];
+         if (m.pair32 == 1) mine[u] = d_key_pair32(pkeys, rows[u]);
+      }
+      const KV bkeys2(m.bkeys, d->bkeys);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         if (!live[u]) continue;
+         uint64_t p = pos[u];
+         slot_pair w = sp[u];
+         for (;;) {
+            if (w.x == 0) break;
+            const bool same = m.pair32 == 1 ? w.y == mine[u] : ((w.x >> 32) == tag[u] && d_keys_equal(bkeys2, (uint64_t) ((uint32_t) w.x - 1u), pkeys, rows[u], false));
+            if (same) {
+               bool stop = false;
+               if (m.n_resid == 0 || d_resid_ok(m, d, rows[u], (uint32_t) w.x - 1u)) {
+                  matches[u]++;
+                  stop = !emit(u, (uint32_t) w.x - 1u);
+               }
+               if (stop || m.build_unique) break;
+            }
+            p = (p + 1) & mask;
+            w = pairs[p];
+         }
+      }
       return;
    }
    // the first two slots of every live row

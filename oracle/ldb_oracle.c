@@ -438,6 +438,7 @@ static void run_units(int threads, int64_t n_units, unit_fn fn, void* arg) {
       return;
    }
    if (threads > 256) threads = 256;
+   if ((int64_t) threads > n_units) threads = (int) n_units; /* never more workers than units (the merge has 64 partitions) */
    pthread_t th[256];
    pool_arg pas[256];
    for (int t = 0; t < threads; t++) {

@@ -516,19 +516,20 @@ def test_groupby_sorted_keys_final_rows_from_the_wave(ctx, oracle):
                 api.agg(capi.AGG_MIN, api.col_expr((0, 4)), wide=True, out_type=D, p=38, s=0), api.agg(capi.AGG_MAX, api.col_expr((0, 4)), wide=True, out_type=D, p=38, s=0)]
         faggs = [api.agg(capi.AGG_SUM, api.col_expr((0, 3), True), out_type=capi.T_FLOAT64), api.agg(capi.AGG_MIN, api.col_expr((0, 3), True), out_type=capi.T_FLOAT64),
                  api.agg(capi.AGG_MAX, api.col_expr((0, 3), True), out_type=capi.T_FLOAT64)]
+        est = 50_000  # (an estimate far above what an LDS table holds: the global-table paths, of which the sorted one is the first choice)
         rep, vals, valid = oracle.groupby(h.rel(), [(0, 0)], aggs)
-        got = g.rel().groupby([(0, 0)], aggs, est_groups=len(runs))
+        got = g.rel().groupby([(0, 0)], aggs, est_groups=est)
         assert got.rows == len(runs)
         assert_groupby_equal(got, h.rel(), [(0, 0)], rep, vals, valid)
         dense_rows = rows_of(got.to_arrow())
         assert [r[0] for r in dense_rows] == sorted(r[0] for r in dense_rows)  # groups come out in key order
-        frow = rows_of(g.rel().groupby([(0, 0)], faggs, est_groups=len(runs)).to_arrow())
+        frow = rows_of(g.rel().groupby([(0, 0)], faggs, est_groups=est).to_arrow())
         try:
             for opt in (b"gb_dense_out", b"gb_sorted"):
                 lib.ldb_gpu_set_option(opt, 0)
-                other = rows_of(g.rel().groupby([(0, 0)], aggs, est_groups=len(runs)).to_arrow())
+                other = rows_of(g.rel().groupby([(0, 0)], aggs, est_groups=est).to_arrow())
                 assert sorted(other, key=repr) == sorted(dense_rows, key=repr), opt
-                fo = {r[0]: r[1:] for r in rows_of(g.rel().groupby([(0, 0)], faggs, est_groups=len(runs)).to_arrow())}
+                fo = {r[0]: r[1:] for r in rows_of(g.rel().groupby([(0, 0)], faggs, est_groups=est).to_arrow())}
                 for r in frow:
                     assert r[1] == pytest.approx(fo[r[0]][0], rel=1e-9, abs=1e-9) and r[2:] == fo[r[0]][1:]
         finally:
@@ -620,6 +621,72 @@ def test_join_duplicates_composite_and_string_keys(ctx, oracle):
     mk_rel, mark = gb.join_build([(0, 0)]).probe(gp, [(0, 0)], capi.JOIN_MARK)
     _, _, omark = oracle.join(hb, [(0, 0)], hp, [(0, 0)], capi.JOIN_MARK)
     assert np.array_equal(mark.read_fixed(0), omark)
+
+
+def test_join_two_int32_keys_verified_from_the_slot(ctx, oracle):
+    """two 4-byte integer keys in a hashed table (DJoin::pair32: the key values sit in the slot behind the tag word — Q9's (ps_partkey, ps_suppkey),
+    Q5's (l_suppkey, c_nationkey)): unique and duplicated build keys, NULL key parts on both sides, every kind, a residual conjunct, a probe side whose
+    key columns are 8 bytes wide (verified through the rows instead), row-id inputs; against the oracle and equal to the word-per-slot layout"""
+    rng = np.random.default_rng(99)
+    nb, npr = 60_000, 250_000
+    lib = capi.gpu_lib()
+
+    def col(vals, typ, null_every):
+        return pa.array([None if null_every and i % null_every == 0 else int(v) for i, v in enumerate(vals)], typ)
+
+    for unique in (True, False):
+        if unique:
+            combos = rng.permutation(400 * 300)[:nb]
+            ba, bb = combos // 300 - 50, combos % 300
+        else:
+            ba, bb = rng.integers(-50, 350, nb), rng.integers(0, 40, nb)
+        pa_, pb_ = rng.integers(-60, 360, npr), rng.integers(0, 300 if unique else 45, npr)
+        b = pa.table({"a": col(ba, pa.int32(), 0 if unique else 97), "b": col(bb, pa.date32() if unique else pa.int32(), 0), "x": pa.array(rng.integers(0, 10, nb), pa.int32())})
+        p4 = pa.table({"a": col(pa_, pa.int32(), 89), "b": col(pb_, pa.date32() if unique else pa.int32(), 0), "x": pa.array(rng.integers(0, 10, npr), pa.int32())})
+        gb, hb = ctx.register("p32_build", b), HostTable(b)
+        gp, hp = ctx.register("p32_probe", p4), HostTable(p4)
+        keys = [(0, 0), (0, 1)]
+        sel = [api.pred((0, 2), capi.F_LT, 7)]
+        for kind in (capi.JOIN_INNER, capi.JOIN_SEMI, capi.JOIN_ANTI, capi.JOIN_LEFT_OUTER, capi.JOIN_SEMI_BUILD):
+            for rowids in (False, True):
+                hbr, hpr, gbr, gpr = hb.rel(), hp.rel(), gb.rel(), gp.rel()
+                if rowids:
+                    hbr, hpr = hbr.select(oracle.scan_filter(hbr, sel)), hpr.select(oracle.scan_filter(hpr, sel))
+                    gbr, gpr = gbr.scan_filter(sel), gpr.scan_filter(sel)
+                op, ob, _ = oracle.join(hbr, keys, hpr, keys, kind)
+                got = {}
+                for layout in (1, 0):
+                    lib.ldb_gpu_set_option(b"join_pair32", layout)
+                    try:
+                        out = gbr.join_build(keys, unique=unique).probe(gpr, keys, kind)
+                    finally:
+                        lib.ldb_gpu_set_option(b"join_pair32", 1)
+                    if kind in (capi.JOIN_SEMI, capi.JOIN_ANTI):
+                        got[layout] = out.rowids(0).tolist()
+                        want = hpr.phys(0)[op].tolist()
+                    elif kind == capi.JOIN_SEMI_BUILD:
+                        got[layout] = out.rowids(0).tolist()
+                        want = hbr.phys(0)[op].tolist()
+                    else:
+                        got[layout] = pairs(out)
+                        want = sorted(zip(hpr.phys(0)[op].tolist(), [capi.LDB_NULL_ROW if x == capi.LDB_NULL_ROW else int(hbr.phys(0)[x]) for x in ob.tolist()]))
+                    assert got[layout] == want, (unique, kind, rowids, layout)
+        # a residual conjunct on top of the pair, and a probe side with 8-byte key columns (pair layout, verification through the rows)
+        resid = [((0, 2), capi.F_NEQ, (0, 2))]
+        a = gb.rel().join_build(keys, unique=unique).probe(gp.rel(), keys, capi.JOIN_INNER, residual=resid)
+        lib.ldb_gpu_set_option(b"join_pair32", 0)
+        try:
+            c = gb.rel().join_build(keys, unique=unique).probe(gp.rel(), keys, capi.JOIN_INNER, residual=resid)
+        finally:
+            lib.ldb_gpu_set_option(b"join_pair32", 1)
+        assert pairs(a) == pairs(c) and 0 < a.rows
+        if not unique:
+            p8 = pa.table({"a": col(pa_, pa.int64(), 89), "b": col(pb_, pa.int64(), 0)})
+            g8, h8 = ctx.register("p32_probe8", p8), HostTable(p8)
+            op, ob, _ = oracle.join(hb.rel(), keys, h8.rel(), keys, capi.JOIN_INNER)
+            assert pairs(gb.rel().join_build(keys).probe(g8.rel(), keys, capi.JOIN_INNER)) == sorted(zip(op.tolist(), ob.tolist()))
+            g8.release()
+        gb.release(), gp.release()
 
 
 def test_join_null_keys_and_empty_sides(ctx, oracle):
@@ -803,4 +870,64 @@ def test_groupby_partitioned_lds_count(ctx):
     finally:
         lib.ldb_gpu_set_option(b"gb_partition_wc", 1)
         lib.ldb_gpu_set_option(b"gb_partition_min_rows", 8 << 20)
+        ctx.prof_enable(False)
+
+
+def test_groupby_partitioned_lds_values(ctx, oracle):
+    """any aggregates per key over direct slots, table far beyond the L2 (Q15's revenue per supplier): (slot, row) pairs are radix-partitioned and
+    every slot range is aggregated by one workgroup in LDS (k_gbp_agg), the table written without atomics.  128-bit SUM of a product, SUM / MIN / MAX /
+    COUNT / AVG with NULL values, a conditional aggregate; a LAZY filter in front (evaluated first), a row-id input, int32 / int64 keys.  Same rows as the
+    oracle and as the atomic direct path."""
+    rng = np.random.default_rng(1515)
+    lib = capi.gpu_lib()
+    n = 2_000_000
+    f = api.factor
+    D = capi.T_DECIMAL128
+    lib.ldb_gpu_set_option(b"gb_partition_min_rows", 0)
+    lazy_before = lib.ldb_gpu_get_option(b"lazy_min_rows")
+    try:
+        for ktype, lo, span in ((pa.int32(), -9, 1_200_000), (pa.int64(), 5_000_000_000, 1_050_000)):
+            keys = lo + rng.integers(0, span, n)
+            keys[:3] = lo + span - 1
+            v = [None if x % 9 == 0 else int(x) for x in rng.integers(-10**9, 10**9, n)]
+            w = rng.integers(0, 100, n)
+            t = pa.table({"k": pa.array(keys, ktype), "v": pa.array(v, pa.int64()), "w": pa.array(w, pa.int32()),
+                          "d": pa.array([decimal.Decimal(int(q)) / 100 for q in rng.integers(0, 10**7, n)], pa.decimal128(12, 2))})
+            g, h = ctx.register("part_vals", t), HostTable(t)
+            prod = api.expr([{"factors": [f(0, 1, (0, 3)), f(100, -1, (0, 2))]}])  # d x (100 - w): the Q15 shape, a 128-bit sum
+            cond = [api.pred((0, 2), capi.F_GTE, 50)]
+            aggs = [api.agg(capi.AGG_SUM, prod, wide=True, out_type=D, p=38, s=2), api.agg(capi.AGG_SUM, api.col_expr((0, 1))), api.agg(capi.AGG_MIN, api.col_expr((0, 1))),
+                    api.agg(capi.AGG_MAX, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT_STAR),
+                    api.agg(capi.AGG_AVG, api.col_expr((0, 3)), out_type=D, p=31, s=21, avg_pow10=19), api.agg(capi.AGG_SUM, api.col_expr((0, 1)), preds=cond)]
+            filt = [api.pred((0, 2), capi.F_LT, 35)]
+            for mode in ("dense", "lazy filter", "row ids"):
+                grel, hrel = g.rel(), h.rel()
+                if mode != "dense":
+                    hrel = hrel.select(oracle.scan_filter(h.rel(), filt))
+                if mode == "lazy filter":
+                    lib.ldb_gpu_set_option(b"lazy_min_rows", 1 << 16)
+                    grel = grel.scan_filter(filt)
+                elif mode == "row ids":
+                    lib.ldb_gpu_set_option(b"lazy_min_rows", 1 << 30)
+                    grel = grel.scan_filter(filt)
+                    grel.rows
+                rep, vals, valid = oracle.groupby(hrel, [(0, 0)], aggs)
+                ctx.prof_reset()
+                ctx.prof_enable(True)
+                got = grel.groupby([(0, 0)], aggs, est_groups=span)
+                prof = ctx.prof_all()
+                assert prof.get("k_gbp_agg", (0, 0.0))[0] >= 1 and "k_groupby_direct" not in prof, (mode, sorted(prof))
+                assert_groupby_equal(got, hrel, [(0, 0)], rep, vals, valid)
+                lib.ldb_gpu_set_option(b"gb_partition_values", 0)
+                try:
+                    ctx.prof_reset()
+                    atomic = g.rel().scan_filter(filt).groupby([(0, 0)], aggs, est_groups=span) if mode != "dense" else g.rel().groupby([(0, 0)], aggs, est_groups=span)
+                    assert ctx.prof_all().get("k_groupby_direct", (0, 0.0))[0] >= 1
+                finally:
+                    lib.ldb_gpu_set_option(b"gb_partition_values", 1)
+                assert sorted(rows_of(atomic.to_arrow()), key=repr) == sorted(rows_of(got.to_arrow()), key=repr)
+            g.release()
+    finally:
+        lib.ldb_gpu_set_option(b"gb_partition_min_rows", 8 << 20)
+        lib.ldb_gpu_set_option(b"lazy_min_rows", lazy_before if lazy_before >= 0 else 1 << 20)
         ctx.prof_enable(False)

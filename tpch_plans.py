@@ -416,6 +416,20 @@ def cpu_baseline(queries, sample_sf, runs="1+3", budget_s=100.0, ctx=None, narro
         if any(q in tpch_legs.Legs.NEED[tid] for q in queries):
             legs.table(tid)
     gen_s = time.perf_counter() - t_gen
+    # how many threads the legs are worth on this host: the C oracle starts `threads` workers per phase over morsels of 20 000 rows; beyond the
+    # physical cores of one socket more threads only add start-up and memory-system contention (round 4: 256 threads ran Q1 at SF10 in 300 – 500 ms).
+    # One probe query (Q1 when selected: the longest scan + aggregation leg), one run per candidate after a warm-up, the fastest count is used for
+    # every leg and reported as `cores`
+    calib = {}
+    probe_q = 1 if 1 in queries else queries[0]
+    all_threads = legs.threads
+    legs.run(probe_q)
+    for cand in sorted({all_threads, max(1, all_threads // 2), max(1, all_threads // 4), max(1, all_threads // 8)}, reverse=True):
+        legs.threads = cand
+        t0 = time.perf_counter()
+        legs.run(probe_q)
+        calib[cand] = (time.perf_counter() - t0) * 1000.0
+    legs.threads = min(calib, key=calib.get)
     med, mn, leg_rows = {}, {}, {}
     t_start = time.perf_counter()
     order = [q for q in (1, 6, 3) if q in queries] + [q for q in queries if q not in (1, 6, 3)]  # the three configs[1..2] queries first: they carry the oracle check
@@ -441,7 +455,8 @@ def cpu_baseline(queries, sample_sf, runs="1+3", budget_s=100.0, ctx=None, narro
                          sample_sf, n_orders, legs.threads, warm, measured, "+".join("Q%d" % q for q in done),
                          "" if len(done) == len(queries) else " (time budget %g s: %s not measured)" % (budget_s, "+".join("Q%d" % q for q in queries if q not in med))),
            "per_query_median_ms": {"Q%d" % q: round(med[q], 3) for q in done}, "per_query_min_ms": {"Q%d" % q: round(mn[q], 3) for q in done}, "sample_sf": sample_sf,
-           "host_generation_s": round(gen_s, 2)}
+           "host_generation_s": round(gen_s, 2), "hardware_threads": all_threads,
+           "thread_calibration_ms": {"Q%d with %d threads" % (probe_q, k): round(v, 1) for k, v in sorted(calib.items())}}
     if ctx is not None:
         # the GPU on the SAME sample: same plans, generator, seed and SF — the number to read beside `value`
         sdb = Database(ctx, n_orders, 0, 1, list(queries), narrow)
