@@ -186,6 +186,13 @@ def main():
         print(json.dumps(dry_run(args)), flush=True)
         return
 
+    # the configuration must fit before anything is generated: per-rank resident bytes + exchange buffers against 288 GB of HBM, fragment rows
+    # against the 32-bit row ids (the same arithmetic as --dry-run; a few milliseconds on the host)
+    budget = dry_run(args)
+    if not all(budget["checks"].values()):
+        raise SystemExit("bench.py: --gpus %d --sf %g does not fit: %s (python bench.py --dry-run --gpus %d --sf %g --queries %s shows the per-rank figures)" % (
+            args.gpus, args.sf, {k: v for k, v in budget["checks"].items() if not v}, args.gpus, args.sf, args.queries or "1-22"))
+
     import torch
     import torch.distributed as dist
 

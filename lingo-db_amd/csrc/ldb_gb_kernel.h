@@ -905,10 +905,19 @@ __device__ __forceinline__ void gb_sorted_heads_body(const DGroupBy& m, const DG
    const uint32_t lane = threadIdx.x & 63;
    const KV keys(m.keys, d->keys);
    const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
-   for (uint64_t c = wave; c < n_chunks; c += n_waves) {
-      const uint64_t i = c * 64 + lane;
-      const bool th = i < n && (i == 0 || !d_keys_equal(keys, i - 1, keys, i, true));
-      const uint64_t mask = __ballot(th);
-      if (lane == 0) chunk_cnt[c] = (uint32_t) __popcll(mask);
+   // four chunks per wave and iteration: their key loads are independent and issue back to back (one chunk per iteration left a single
+   // pair of loads in flight per wave: 2.4 GB of keys at 2.9 TB/s)
+   for (uint64_t c0 = wave * 4; c0 < n_chunks; c0 += n_waves * 4) {
+      bool th[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         const uint64_t i = (c0 + u) * 64 + lane;
+         th[u] = i < n && (i == 0 || !d_keys_equal(keys, i - 1, keys, i, true));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         const uint64_t mask = __ballot(th[u]);
+         if (lane == 0 && c0 + u < n_chunks) chunk_cnt[c0 + u] = (uint32_t) __popcll(mask);
+      }
    }
 }
