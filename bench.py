@@ -361,7 +361,7 @@ def main():
             if n6:
                 t6 = ms6 / n6 * 1e-3
                 extras["scan_q6"] = {"kernel_ms": round(ms6 / n6, 4), "rows_per_s_G": round(rows_local / t6 / 1e9, 1)}
-                pmc6 = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_q6_sf%g.json" % (r, args.sf)) for r in (4, 3, 2, 1)) if os.path.exists(p)), None)
+                pmc6 = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_q6_sf%g.json" % (r, args.sf)) for r in (5, 4, 3, 2, 1)) if os.path.exists(p)), None)
                 if world == 1 and pmc6:
                     with open(pmc6) as f:
                         k6 = json.load(f)["kernels"]
@@ -375,7 +375,7 @@ def main():
             # command; tools/pmc_summary.py).  Counters cannot be read from inside the timed process, so the committed
             # summary of the matching configuration is quoted; null when there is none.
             tag = "_narrow" if args.narrow_decimals else ""
-            pmc_path = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_q%d_sf%g%s.json" % (r, roof_q, args.sf, tag)) for r in (4, 3, 2, 1)) if os.path.exists(p)), None)
+            pmc_path = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_q%d_sf%g%s.json" % (r, roof_q, args.sf, tag)) for r in (5, 4, 3, 2, 1)) if os.path.exists(p)), None)
             if world == 1 and pmc_path:
                 with open(pmc_path) as f:
                     pmc = json.load(f)
@@ -470,7 +470,7 @@ def main():
         # all kernels, helpers included: Σ kernel durations ÷ wall span per query from a rocprofv3 kernel trace of the
         # same plans on the same data (tools/query_timeline.py + tools/timeline_summary.py; profile, not this run)
         gpu_busy = None
-        tl_path = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_query_timeline_sf%g.json" % (r, args.sf)) for r in (4, 3, 2)) if os.path.exists(p)), None)
+        tl_path = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_query_timeline_sf%g.json" % (r, args.sf)) for r in (5, 4, 3, 2)) if os.path.exists(p)), None)
         if world == 1 and tl_path:
             with open(tl_path) as f:
                 tl = json.load(f)

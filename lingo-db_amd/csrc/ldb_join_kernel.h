@@ -577,42 +577,13 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
       d_direct_resolve<U>(m, d, rows, live, hw, bits_only, matches, emit);
       return;
    }
-   if (m.pair32 && !m.chained) { // two 4-byte keys: the slot carries them, no gather at the build row
-      typedef unsigned long long __attribute__((ext_vector_type(2))) slot_pair;
-      const slot_pair* pairs = (const slot_pair*) slots;
-      slot_pair sp[U];
-      unsigned long long mine[U];
+   // pair32 (two 4-byte keys): slot p = words 2p (tag : build row + 1) and 2p + 1 (the two key values) — a candidate is verified against
+   // the second word of the 16 bytes its first word came with, instead of two key columns gathered at the build row
+   const int ss = (m.pair32 && !m.chained) ? 1 : 0;
+   const bool pair_cmp = m.pair32 == 1 && !m.chained;
+   unsigned long long mine[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-         sp[u] = slot_pair{0ull, 0ull};
-         mine[u] = 0;
-         if (!live[u]) continue;
-         sp[u] = pairs[pos[u]];
-         if (m.pair32 == 1) mine[u] = d_key_pair32(pkeys, rows[u]);
-      }
-      const KV bkeys2(m.bkeys, d->bkeys);
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-         if (!live[u]) continue;
-         uint64_t p = pos[u];
-         slot_pair w = sp[u];
-         for (;;) {
-            if (w.x == 0) break;
-            const bool same = m.pair32 == 1 ? w.y == mine[u] : ((w.x >> 32) == tag[u] && d_keys_equal(bkeys2, (uint64_t) ((uint32_t) w.x - 1u), pkeys, rows[u], false));
-            if (same) {
-               bool stop = false;
-               if (m.n_resid == 0 || d_resid_ok(m, d, rows[u], (uint32_t) w.x - 1u)) {
-                  matches[u]++;
-                  stop = !emit(u, (uint32_t) w.x - 1u);
-               }
-               if (stop || m.build_unique) break;
-            }
-            p = (p + 1) & mask;
-            w = pairs[p];
-         }
-      }
-      return;
-   }
+   for (int u = 0; u < U; u++) mine[u] = 0;
    // the first two slots of every live row
    uint64_t w0[U], w1[U];
 #pragma unroll
@@ -621,13 +592,14 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
       w0[u] = w1[u] = 0;
       if (!live[u]) continue; // (predicated by EXEC: the live lanes' loads still issue back to back)
 #endif
-      w0[u] = slots[pos[u]];
+      w0[u] = slots[pos[u] << ss];
 #ifndef JOIN_NO_PREFETCH2
       // the second slot only for tables with duplicate keys (their rows sit in consecutive slots): for a
       // unique table it is needed after a collision only, and fetching it always costs an unclustered
       // probe 40 % (600 M random probes: 18.3 → 13.0 ms) for 5 % on a clustered one
-      if (!m.build_unique) w1[u] = slots[(pos[u] + 1) & mask];
+      if (!m.build_unique) w1[u] = slots[((pos[u] + 1) & mask) << ss];
 #endif
+      if (pair_cmp) mine[u] = d_key_pair32(pkeys, rows[u]);
    }
    const KV bkeys(m.bkeys, d->bkeys);
 #pragma unroll
@@ -637,7 +609,7 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
       uint32_t step = 0;
       for (;;) {
          if (w == 0) break;
-         if ((w >> 32) == tag[u] && (m.key32 || d_keys_equal(bkeys, (uint64_t) ((uint32_t) w - 1u), pkeys, rows[u], false))) {
+         if ((w >> 32) == tag[u] && (m.key32 || (pair_cmp ? slots[(p << 1) + 1] == mine[u] : d_keys_equal(bkeys, (uint64_t) ((uint32_t) w - 1u), pkeys, rows[u], false)))) {
             if (m.chained) { // the key's only slot: its rows are the chain
                const uint32_t* next = gptr<uint32_t>(d->next);
                for (uint32_t r = (uint32_t) w; r != 0; r = next[r - 1u]) {
@@ -662,9 +634,9 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
          p = (p + 1) & mask;
          step++;
 #ifndef JOIN_NO_PREFETCH2
-         w = (step == 1 && !m.build_unique) ? w1[u] : slots[p];
+         w = (step == 1 && !m.build_unique) ? w1[u] : slots[p << ss];
 #else
-         w = slots[p];
+         w = slots[p << ss];
 #endif
       }
    }

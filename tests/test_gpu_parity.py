@@ -628,7 +628,7 @@ def test_join_two_int32_keys_verified_from_the_slot(ctx, oracle):
     Q5's (l_suppkey, c_nationkey)): unique and duplicated build keys, NULL key parts on both sides, every kind, a residual conjunct, a probe side whose
     key columns are 8 bytes wide (verified through the rows instead), row-id inputs; against the oracle and equal to the word-per-slot layout"""
     rng = np.random.default_rng(99)
-    nb, npr = 60_000, 250_000
+    nb, npr = 24_000, 90_000
     lib = capi.gpu_lib()
 
     def col(vals, typ, null_every):
@@ -647,8 +647,8 @@ def test_join_two_int32_keys_verified_from_the_slot(ctx, oracle):
         gp, hp = ctx.register("p32_probe", p4), HostTable(p4)
         keys = [(0, 0), (0, 1)]
         sel = [api.pred((0, 2), capi.F_LT, 7)]
-        for kind in (capi.JOIN_INNER, capi.JOIN_SEMI, capi.JOIN_ANTI, capi.JOIN_LEFT_OUTER, capi.JOIN_SEMI_BUILD):
-            for rowids in (False, True):
+        for kind, rowid_modes in ((capi.JOIN_INNER, (False, True)), (capi.JOIN_SEMI, (False,)), (capi.JOIN_ANTI, (True,)), (capi.JOIN_LEFT_OUTER, (False,)), (capi.JOIN_SEMI_BUILD, (True,))):
+            for rowids in rowid_modes:
                 hbr, hpr, gbr, gpr = hb.rel(), hp.rel(), gb.rel(), gp.rel()
                 if rowids:
                     hbr, hpr = hbr.select(oracle.scan_filter(hbr, sel)), hpr.select(oracle.scan_filter(hpr, sel))
@@ -880,7 +880,7 @@ def test_groupby_partitioned_lds_values(ctx, oracle):
     oracle and as the atomic direct path."""
     rng = np.random.default_rng(1515)
     lib = capi.gpu_lib()
-    n = 2_000_000
+    n = 500_000
     f = api.factor
     D = capi.T_DECIMAL128
     lib.ldb_gpu_set_option(b"gb_partition_min_rows", 0)
