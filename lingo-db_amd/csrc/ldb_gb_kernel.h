@@ -740,17 +740,13 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
             for (int u = 0; u < ROWS; u++) {
                const uint64_t ii = rowsv[u] < n ? rowsv[u] : n - 1;
                kcur[u] = d_load_i64(kc, (uint32_t) ii);
-               // the wave's rows are 64 consecutive ones: the previous key is the lane below's, only lane 0 loads row i - 1 and only lane 63
-               // (the one that decides whether the chunk's last run continues) loads row i + 1 — one key load per row instead of three
-               kprev[u] = lane == 0 ? d_load_i64(kc, (uint32_t) (ii > 0 ? ii - 1 : 0)) : 0;
-               knext[u] = lane == 63 ? d_load_i64(kc, (uint32_t) (ii + 1 < n ? ii + 1 : ii)) : 0;
+               // (the neighbours' keys are LOADED, not shuffled: taking the lane below's key by __shfl_up and loading only the chunk's outer
+               // neighbours in lanes 0 / 63 made this kernel 28 % slower at SF100, 3.93 → 5.04 ms — the extra loads hit lines already in flight,
+               // the 64-bit cross-lane moves and the two divergent single-lane loads sit on the critical path of every batch)
+               kprev[u] = d_load_i64(kc, (uint32_t) (ii > 0 ? ii - 1 : 0));
+               knext[u] = d_load_i64(kc, (uint32_t) (ii + 1 < n ? ii + 1 : ii));
                gbase[u] = gptr<uint32_t>(d->chunk_off)[ii >> 6];
                if (m.dense_out) gprev[u] = gptr<uint32_t>(d->chunk_off)[(ii >> 6) ? (ii >> 6) - 1 : 0];
-            }
-#pragma unroll
-            for (int u = 0; u < ROWS; u++) {
-               const long long below = __shfl_up(kcur[u], 1); // (rows past the end carry the last key: their lanes do not pass)
-               if (lane != 0) kprev[u] = below;
             }
 #pragma unroll
             for (int u = 0; u < ROWS; u++) {
@@ -916,29 +912,10 @@ __device__ __forceinline__ void gb_sorted_heads_body(const DGroupBy& m, const DG
    // pair of loads in flight per wave: 2.4 GB of keys at 2.9 TB/s)
    for (uint64_t c0 = wave * 4; c0 < n_chunks; c0 += n_waves * 4) {
       bool th[4];
-      if (m.keys.n_keys == 1 && !m.keys.cols[0].rowids && !m.keys.cols[0].validity && m.keys.cols[0].type != LDB_T_UTF8 && !d_is_wide(keys.col(0)) && !d_is_flt(keys.col(0))) {
-         // one dense NOT NULL integer key (what the sorted statistic was taken over): one load per lane, the neighbour's key by shuffle
-         const CV kc = keys.col(0);
-         long long kc4[4], kp4[4];
 #pragma unroll
-         for (int u = 0; u < 4; u++) {
-            const uint64_t i = (c0 + u) * 64 + lane, ii = i < n ? i : n - 1;
-            kc4[u] = d_load_i64(kc, (uint32_t) ii);
-            kp4[u] = lane == 0 ? d_load_i64(kc, (uint32_t) (ii > 0 ? ii - 1 : 0)) : 0;
-         }
-#pragma unroll
-         for (int u = 0; u < 4; u++) {
-            const uint64_t i = (c0 + u) * 64 + lane;
-            const long long below = __shfl_up(kc4[u], 1);
-            if (lane != 0) kp4[u] = below;
-            th[u] = i < n && (i == 0 || kp4[u] != kc4[u]);
-         }
-      } else {
-#pragma unroll
-         for (int u = 0; u < 4; u++) {
-            const uint64_t i = (c0 + u) * 64 + lane;
-            th[u] = i < n && (i == 0 || !d_keys_equal(keys, i - 1, keys, i, true));
-         }
+      for (int u = 0; u < 4; u++) {
+         const uint64_t i = (c0 + u) * 64 + lane;
+         th[u] = i < n && (i == 0 || !d_keys_equal(keys, i - 1, keys, i, true));
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {

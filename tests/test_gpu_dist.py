@@ -40,7 +40,7 @@ def test_sharded_plans_match_single_gpu(world):
 def test_world8_all_sharded_plans_skew_and_stress():
     """8 ranks on the one GPU (BASELINE's largest world): all 22 sharded plans against the single-GPU plans, a shuffle whose rows
     almost all go to one rank, and 60 back-to-back exchanges of strings / NULLs / mixed widths of changing sizes"""
-    codes, outs = run_ranks(8, {"LDB_CHECK_ORDERS": "90006", "LDB_CHECK_STRESS": "60"}, timeout=1500)
+    codes, outs = run_ranks(8, {"LDB_CHECK_ORDERS": "90006", "LDB_CHECK_STRESS": "60", "LDB_CHECK_REPLAY": "1"}, timeout=1500)
     assert all(c == 0 for c in codes), "\n".join(o[-3000:] for o in outs)
     assert outs[0].count(": OK") == 22 + 6, outs[0]
     assert "exchange statistics" in outs[0]
