@@ -8,6 +8,7 @@ export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/final_r05
 mkdir -p $OUT
+timeout 300 python -m pytest tests/test_gpu_z_golden.py -m gpu -q -k "like" > $OUT/tests_like.log 2>&1; tail -2 $OUT/tests_like.log
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -c 1500 $OUT/bench_default.json; echo; tail -2 $OUT/bench_default.err
 B="python $R/bench.py --steps 3 --warmup 3 --cpu-sample-sf 0 --oracle-spot-check 0 --record-runs 0"
