@@ -159,6 +159,12 @@ int32_t ldb_gpu_jit_compile_check(char* log, int32_t cap);
  *   join_ordered, join_chained, join_radix, join_radix_min_rows, join_radix_min_table_bytes, join_radix_part_bytes, probe_batch
  *   join_direct, join_rank, join_coarse (0/1) — the direct / rank-bitmap / LDS coarse-bitmap table layouts (default on)
  *   gb_ordered, gb_sorted, gb_direct, gb_partition (0/1), gb_partition_min_rows (8 M), gb_wgs_per_cu (0 = automatic)
+ *   gb_dense_out (0/1)   — sorted keys: groups inside one wave leave the kernel as final rows (round 5, default on)
+ *   gb_partition_values (0/1) — any aggregates over partitioned LDS slots, not only COUNT(*) (round 5, default on)
+ *   join_pair32 (0/1)    — two 4-byte keys: the key values live in the slot (round 5, default on)
+ *   plan_replay (0/1), desc_cache (0/1), desc_cache_mb — prepared plans: replay of the read-back trace, descriptor cache
+ *   (environment only: LDB_HOST_TRACE=<ms> reports host calls of the library that took longer, with their site, and names a replayed
+ *   read-back that differs from its record; libldb_host.so: LDB_PLAN_STEP_TRACE=1 prints the host time of every plan step)
  *   dict_encode (0/1), dict_min_rows — utf8 dictionary encoding at registration
  *   zone_maps (0/1), zone_min_rows (1 M) — zone maps of selective integer-like columns
  *   comm_transport (0 = RCCL, 1 = shared memory), comm_timeout_ms — the exchange

@@ -424,7 +424,7 @@ def cpu_baseline(queries, sample_sf, runs="1+3", budget_s=100.0, ctx=None, narro
     probe_q = 1 if 1 in queries else queries[0]
     all_threads = legs.threads
     legs.run(probe_q)
-    for cand in sorted({all_threads, max(1, all_threads // 2), max(1, all_threads // 4), max(1, all_threads // 8)}, reverse=True):
+    for cand in sorted({all_threads, max(1, all_threads // 2), max(1, all_threads // 4), max(1, all_threads // 8), max(1, all_threads // 16), max(1, all_threads // 32)}, reverse=True):
         legs.threads = cand
         t0 = time.perf_counter()
         legs.run(probe_q)
