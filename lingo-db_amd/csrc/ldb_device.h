@@ -498,42 +498,23 @@ __device__ __forceinline__ bool d_like_simple_wave(const DPred& m, uint8_t* stag
    const LDB_LDS uint8_t* text = (const LDB_LDS uint8_t*) stage;
    LDB_LDS uint8_t* bits = (LDB_LDS uint8_t*) stage + LDS_STR_BITS;
    const uint32_t nb = (span + 7) >> 3;
-   // Round 5: the counters say this phase is VALU-bound (profiles/r05_pmc_q13_q9_set*.json: 78 % VALU-active, no LDS bank conflict), so the compare
-   // works on 32-bit windows: W[k] = the four text bytes at byte offset k of the lane's 24-byte view, ONE v_alignbyte_b32 each and shared by every
-   // offset and segment (the 64-bit version paid two 64-bit funnel shifts per offset and 64-bit and / compare per segment: about three times the work).
-   // A segment of L <= 16 bytes is up to four masked 32-bit compares against W[o], W[o + 4], W[o + 8], W[o + 12].
-   uint32_t P[LDB_LIKE_MAX_SEG][4], M[LDB_LIKE_MAX_SEG][4];
-   LDB_UNROLL
-   for (int j = 0; j < LDB_LIKE_MAX_SEG; j++) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) P[j][q] = M[j][q] = 0;
-      if (j < nseg) {
-         const int off = m.in_off[2 * j], len = m.in_off[2 * j + 1];
-#pragma unroll
-         for (int k = 0; k < 16; k++)
-            if (k < len) {
-               P[j][k >> 2] |= (uint32_t) (uint8_t) m.str[off + k] << (8 * (k & 3));
-               M[j][k >> 2] |= 0xFFu << (8 * (k & 3));
-            }
-      }
-   }
    for (uint32_t b = lane; b < nb; b += 64) {
       const uint64_t w0 = *(const LDB_LDS uint64_t*) (text + 8 * b), w1 = *(const LDB_LDS uint64_t*) (text + 8 * b + 8), w2 = *(const LDB_LDS uint64_t*) (text + 8 * b + 16);
-      const uint32_t d[6] = {(uint32_t) w0, (uint32_t) (w0 >> 32), (uint32_t) w1, (uint32_t) (w1 >> 32), (uint32_t) w2, (uint32_t) (w2 >> 32)};
-      uint32_t W[20];
-#pragma unroll
-      for (int k = 0; k < 20; k++) W[k] = (k & 3) == 0 ? d[k >> 2] : __builtin_amdgcn_alignbyte(d[(k >> 2) + 1], d[k >> 2], (uint32_t) (k & 3));
       LDB_UNROLL
       for (int j = 0; j < LDB_LIKE_MAX_SEG; j++) {
          if (j >= nseg) break;
+         uint64_t pat[2], msk[2];
          const int len = m.in_off[2 * j + 1];
+         d_like_seg_words(m.str, m.in_off[2 * j], len, pat, msk);
          uint32_t found = 0;
 #pragma unroll
          for (int o = 0; o < 8; o++) {
-            bool eq = (W[o] & M[j][0]) == P[j][0];
-            if (len > 4) eq = eq && (W[o + 4] & M[j][1]) == P[j][1];
-            if (len > 8) eq = eq && (W[o + 8] & M[j][2]) == P[j][2];
-            if (len > 12) eq = eq && (W[o + 12] & M[j][3]) == P[j][3];
+            const uint64_t x0 = o ? (w0 >> (8 * o)) | (w1 << (64 - 8 * o)) : w0;
+            bool eq = (x0 & msk[0]) == pat[0];
+            if (len > 8) {
+               const uint64_t x1 = o ? (w1 >> (8 * o)) | (w2 << (64 - 8 * o)) : w1;
+               eq = eq && (x1 & msk[1]) == pat[1];
+            }
             found |= (eq ? 1u : 0u) << o;
          }
          bits[j * LDS_LIKE_STRIDE + b] = (uint8_t) found;
