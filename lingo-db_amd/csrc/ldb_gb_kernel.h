@@ -119,7 +119,9 @@ struct DGroupBy {
    // g_cap = number of chunks), and finished by k_gb_finalize_cross from the per-chunk flags.  Q18 (600 M rows → 150 M groups): no slot
    // word, no 16-byte accumulator per group written and read back twice, no occupancy scan (DESIGN §2 Group-by).
    int32_t dense_out;
-   int32_t pad_dense;
+   // dense_out: 1 / 2 = the group's first row also writes its KEY into the output key column (direct_keys_out, direct_key_width) — no gather of
+   // representative rows afterwards; 2 = and no representative rows at all (no ANY aggregate needs them)
+   int32_t dense_keys;
    uint64_t rep_rows_out; // uint32_t*: dense_out: representative row of every group (written by the group's first row)
    uint64_t cross_flags; // uint8_t*, one per chunk, pre-zeroed: 1 = the group that begins in this chunk continues into the next one
    uint64_t dense_groups; // dense_sorted: number of output slots (a group number beyond it — possible only under a mis-speculated replay — is dropped)
@@ -731,11 +733,12 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
          // three dependent round trips of its own and the kernel ran at latency, not bandwidth
          bool eqprev[ROWS], eqnext[ROWS];
          uint32_t gbase[ROWS], gprev[ROWS];
+         long long kcur[ROWS]; // dense_sorted: the row's key (also the value of the output key column, dense_keys)
          if (m.dense_sorted) {
             // one dense NOT NULL integer key (what the sorted statistic guarantees): branch-free
             // clamped loads of the previous / own / next key for the whole batch, compares after
             const CV kc = keys.col(0);
-            long long kcur[ROWS], kprev[ROWS], knext[ROWS];
+            long long kprev[ROWS], knext[ROWS];
 #pragma unroll
             for (int u = 0; u < ROWS; u++) {
                const uint64_t ii = rowsv[u] < n ? rowsv[u] : n - 1;
@@ -761,6 +764,7 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
                eqprev[u] = passv[u] && i > 0 && (m.keyless || d_keys_equal(keys, i - 1, keys, i, true));
                eqnext[u] = false;
                gbase[u] = 0;
+               kcur[u] = 0;
             }
          }
 #pragma unroll
@@ -790,7 +794,19 @@ __device__ __forceinline__ void gb_body(const DGroupBy& m, const DGroupBy* __res
                   plain = true_head && !(run_end == 63 && cont); // the whole group lives inside this run
                   if (g >= d->dense_groups) g = ~0ull; // (only under a mis-speculated replay: the output arrays were sized from the recorded count)
                   if (m.dense_out) {
-                     if (true_head && g != ~0ull) gptr_mut<uint32_t>(d->rep_rows_out)[g] = (uint32_t) i;
+                     if (true_head && g != ~0ull) {
+                        if (m.dense_keys != 2) gptr_mut<uint32_t>(d->rep_rows_out)[g] = (uint32_t) i;
+                        if (m.dense_keys) { // the key column of the result, written where the key is in a register anyway
+                           const long long key = kcur[u];
+                           switch (m.direct_key_width) {
+                              case 4: gptr_mut<int32_t>(d->direct_keys_out)[g] = (int32_t) key; break;
+                              case 8: gptr_mut<int64_t>(d->direct_keys_out)[g] = (int64_t) key; break;
+                              default:
+                                 gptr_mut<int64_t>(d->direct_keys_out)[2 * g] = (int64_t) key;
+                                 gptr_mut<int64_t>(d->direct_keys_out)[2 * g + 1] = key < 0 ? -1 : 0;
+                           }
+                        }
+                     }
                   } else if (true_head && g != ~0ull) {
                      gptr_mut<unsigned long long>(d->g_keys)[g] = (h & 0xFFFFFFFF00000000ull) | (unsigned long long) ((uint32_t) i + 1u);
                   }

@@ -211,11 +211,23 @@ __global__ void k_gb_finalize_cross(const DGroupBy* __restrict__ d, uint64_t n_c
       if (!flags[c]) continue;
       const uint64_t g = (uint64_t) chunk_off[c + 1] - 1ull;
       if (g >= d->dense_groups) continue; // (mis-speculated replay)
-      d_finalize_group(*d, d, (const unsigned long long*) d->g_acc + c, n_chunks, g, ((const uint32_t*) d->rep_rows_out)[g]);
+      d_finalize_group(*d, d, (const unsigned long long*) d->g_acc + c, n_chunks, g, d->dense_keys == 2 ? 0u : ((const uint32_t*) d->rep_rows_out)[g]);
    }
    // the output arrays were sized from a count that may have been REPLAYED: should the real one be smaller (the execution is void and will be
-   // repeated, but its consumers are queued already), the representative rows behind it must still be row numbers.  Normally an empty range.
-   for (uint64_t g = (uint64_t) *d_groups + blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; g < d->dense_groups; g += (uint64_t) gridDim.x * blockDim.x) ((uint32_t*) d->rep_rows_out)[g] = 0;
+   // repeated, but its consumers are queued already), the representative rows behind it must still be row numbers and the keys behind it keys
+   // of the column's range (a table built over them indexes by key - min): row 0 / the first group's key.  Normally an empty range.
+   for (uint64_t g = (uint64_t) *d_groups + blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; g < d->dense_groups; g += (uint64_t) gridDim.x * blockDim.x) {
+      if (d->dense_keys != 2) ((uint32_t*) d->rep_rows_out)[g] = 0;
+      if (d->dense_keys) {
+         switch (d->direct_key_width) {
+            case 4: ((int32_t*) d->direct_keys_out)[g] = ((const int32_t*) d->direct_keys_out)[0]; break;
+            case 8: ((int64_t*) d->direct_keys_out)[g] = ((const int64_t*) d->direct_keys_out)[0]; break;
+            default:
+               ((int64_t*) d->direct_keys_out)[2 * g] = ((const int64_t*) d->direct_keys_out)[0];
+               ((int64_t*) d->direct_keys_out)[2 * g + 1] = ((const int64_t*) d->direct_keys_out)[1];
+         }
+      }
+   }
 }
 
 // per-group validity bytes → Arrow bitmap; *nulls += number of zero bytes (one atomic per wave of a
@@ -575,6 +587,8 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       }
    }
    // sorted key column, no filter (DGroupBy::dense_sorted): number the groups by key changes
+   void* direct_keys = nullptr; // the output key column where the kernel writes it itself (direct slots; sorted keys with dense_keys)
+   const ldb_column* direct_src = nullptr;
    uint32_t* chunk_off = nullptr;
    uint64_t sorted_groups = 0, sorted_chunks = 0; // dense_sorted: number of groups / of 64-row chunks
    uint64_t* d_sorted_groups = nullptr; // the same count on the device (an arena word)
@@ -621,12 +635,21 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          // chunk boundary (DGroupBy::dense_out)
          h->dense_out = ldb_option("gb_dense_out", 1) != 0 ? 1 : 0;
          if (h->dense_out) cap = std::max<uint64_t>(1, sorted_chunks);
+         // … and the key column itself: the first row of a group has its key in a register (no representative rows + gather afterwards: Q18's
+         // 150 M keys, k_gather 0.72 ms); representative rows are still written when an ANY aggregate reads them
+         const ldb_column& skc = ks.table->cols[(size_t) keys[0].col];
+         if (h->dense_out && ldb_option("gb_dense_keys", 1) != 0 && !skc.validity && (skc.width == 4 || skc.width == 8 || skc.width == 16) && skc.type.type != LDB_T_UTF8 &&
+             h->keys.cols[0].width == skc.width) {
+            bool any_fn = false;
+            for (int32_t a = 0; a < n_aggs; a++) any_fn = any_fn || aggs[a].fn == LDB_AGG_ANY;
+            h->dense_keys = any_fn ? 1 : 2;
+            h->direct_key_width = skc.width;
+            direct_src = &skc;
+         }
       }
    }
    // direct-address slots (DGroupBy::direct): one NOT NULL integer key whose value range is at most twice
    // the expected number of groups — the table is indexed by key - kmin
-   void* direct_keys = nullptr;
-   const ldb_column* direct_src = nullptr;
    if (ldb_option("gb_direct", 1) != 0 && h->ordered_slots && !h->dense_sorted && n_keys == 1) {
       const ldb_rel_side& ks = in->sides[(size_t) keys[0].side];
       const ldb_column& kc = ks.table->cols[(size_t) keys[0].col];
@@ -696,10 +719,11 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          LDB_HIP(hipMemsetAsync(cross, 0, (size_t) sorted_chunks + 8, ctx->stream));
          h->cross_flags = (uint64_t) cross;
       }
-      if (h->direct) {
+      if (h->direct || h->dense_keys) {
          LDB_TRY(ldb_dev_alloc(ctx, &direct_keys, (size_t) h->direct_key_width * (size_t) max_groups));
          h->direct_keys_out = (uint64_t) direct_keys;
-      } else {
+      }
+      if (!h->direct && h->dense_keys != 2) {
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &rep_rows, 4 * (size_t) max_groups));
          h->rep_rows_out = (uint64_t) rep_rows;
          // ordered slots give up on long probe runs, which depends on the insertion order: should a REPLAYED execution
@@ -887,7 +911,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    // ---- result table: key columns = gather of representative rows, then aggregates
    res->n_rows = (int64_t) n_groups;
    res->cols.resize((size_t) (n_keys + n_aggs));
-   if (h->direct) { // the key column was written by k_gb_finalize
+   if (h->direct || h->dense_keys) { // the key column was written by k_gb_finalize / by the sorted aggregation itself
       ldb_column& kc = res->cols[0];
       kc.name = direct_src->name;
       kc.type = direct_src->type;
@@ -895,6 +919,13 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       kc.values = direct_keys;
       kc.value_bytes = (int64_t) n_groups * kc.width;
       kc.owned = true;
+      if (direct_src->has_range) { // the groups' keys are values of the source column: its cached range stays a valid superset
+         kc.has_range = true;
+         kc.vmin = direct_src->vmin;
+         kc.vmax = direct_src->vmax;
+      }
+      ldb_dev_free(ctx, rep_rows); // (sorted keys with an ANY aggregate: the representative rows were only read by the finalisation)
+      rep_rows = nullptr;
    } else {
       ldb_rel* reps = nullptr;
       LDB_TRY(ldb_rel_select(ctx, in, rep_rows, (int64_t) n_groups, &reps));

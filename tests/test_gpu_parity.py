@@ -525,7 +525,7 @@ def test_groupby_sorted_keys_final_rows_from_the_wave(ctx, oracle):
         assert [r[0] for r in dense_rows] == sorted(r[0] for r in dense_rows)  # groups come out in key order
         frow = rows_of(g.rel().groupby([(0, 0)], faggs, est_groups=est).to_arrow())
         try:
-            for opt in (b"gb_dense_out", b"gb_sorted"):
+            for opt in (b"gb_dense_keys", b"gb_dense_out", b"gb_sorted"):
                 lib.ldb_gpu_set_option(opt, 0)
                 other = rows_of(g.rel().groupby([(0, 0)], aggs, est_groups=est).to_arrow())
                 assert sorted(other, key=repr) == sorted(dense_rows, key=repr), opt
@@ -533,8 +533,15 @@ def test_groupby_sorted_keys_final_rows_from_the_wave(ctx, oracle):
                 for r in frow:
                     assert r[1] == pytest.approx(fo[r[0]][0], rel=1e-9, abs=1e-9) and r[2:] == fo[r[0]][1:]
         finally:
+            lib.ldb_gpu_set_option(b"gb_dense_keys", 1)
             lib.ldb_gpu_set_option(b"gb_dense_out", 1)
             lib.ldb_gpu_set_option(b"gb_sorted", 1)
+        # an ANY aggregate keeps the representative rows beside the directly written key column (a value that is constant inside a group: 3 x key)
+        t3 = pa.table({"k": pa.array(k), "kk": pa.array(k * 3), "v": pa.array(v, pa.int64())})
+        g3 = ctx.register("sorted_runs_any", t3)
+        rows3 = rows_of(g3.rel().groupby([(0, 0)], [api.agg(capi.AGG_ANY, api.col_expr((0, 1))), api.agg(capi.AGG_COUNT_STAR)], est_groups=est).to_arrow())
+        assert [(r[0], r[1], r[2]) for r in rows3] == [(int(key), int(key) * 3, int(c)) for key, c in zip(np.arange(len(runs)) * 7 - 1000, runs)]
+        g3.release()
         g.release()
 
 
