@@ -177,6 +177,9 @@ def test_bench_dry_run_checks_budgets_without_a_device():
     assert 10e9 < sh["lpy"]["bytes_out_per_rank_upper_bound"] < 14e9 and 9 < sh["lpy"]["ms_at_xgmi_link_rate_upper_bound"] < 13
     one = run("--gpus", "1", "--sf", "1000", "--queries", "9")
     assert one["checks"]["row_ids_fit_uint32"] is False and one["checks"]["hbm_fits"] is False  # 6 G lineitem rows on one GPU
+    # the same arithmetic guards a real run: a configuration that cannot fit is refused before torch is imported or anything is generated
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--sf", "300"], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "does not fit" in out.stderr and "hbm_fits" in out.stderr, out.stderr[-500:]
 
 
 def test_loop_and_nested_map_plans_pass_the_structure_check():
