@@ -390,6 +390,17 @@ def matches_legs(q, got, want, allow_empty=False):
     return bool(got == want)
 
 
+def _cgroup_cpus():
+    """CPUs the container may use (cgroup v2 cpu.max = quota / period), or None when unlimited / unknown: os.cpu_count() reports the machine's
+    hardware threads, which a quota can be far below — the legs then stop scaling at the quota (round 5: 32 of 256 on the GPU box)"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else round(int(quota) / int(period), 2)
+    except Exception:
+        return None
+
+
 def cpu_baseline(queries, sample_sf, runs="1+3", budget_s=100.0, ctx=None, narrow=False, checks=None):
     """The oracle legs (oracle/tpch_legs.py: the C restatement of the reference's CPU path — morsels of
     20 000 rows, HashIndexedView / PreAggregationHashtable restated — plus numpy for the few rows after
@@ -455,7 +466,7 @@ def cpu_baseline(queries, sample_sf, runs="1+3", budget_s=100.0, ctx=None, narro
                          sample_sf, n_orders, legs.threads, warm, measured, "+".join("Q%d" % q for q in done),
                          "" if len(done) == len(queries) else " (time budget %g s: %s not measured)" % (budget_s, "+".join("Q%d" % q for q in queries if q not in med))),
            "per_query_median_ms": {"Q%d" % q: round(med[q], 3) for q in done}, "per_query_min_ms": {"Q%d" % q: round(mn[q], 3) for q in done}, "sample_sf": sample_sf,
-           "host_generation_s": round(gen_s, 2), "hardware_threads": all_threads,
+           "host_generation_s": round(gen_s, 2), "hardware_threads": all_threads, "cgroup_cpu_limit": _cgroup_cpus(),
            "thread_calibration_ms": {"Q%d with %d threads" % (probe_q, k): round(v, 1) for k, v in sorted(calib.items())}}
     if ctx is not None:
         # the GPU on the SAME sample: same plans, generator, seed and SF — the number to read beside `value`
