@@ -822,7 +822,8 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          ldb_dev_free(ctx, part);
       } else if (in->n_rows) {
          int per_cu = lds_bytes > 40 * 1024 ? 2 : 4;
-         if (h->dense_sorted) per_cu = 6; // (no LDS, a pure stream: 6 resident workgroups per CU measured best — 2: 5.52, 3: 4.22, 4: 3.90, 6: 3.70, 8: 3.83 ms for Q18's 600 M rows)
+         // (the sorted, LDS-free path was swept over 2 / 3 / 4 / 6 / 8 resident workgroups per CU: 5.52 / 4.22 / 3.90 / 3.70 / 3.83 ms on one box, but 6 gave 4.05 ms on the
+         // next one where 4 gives ≈ 3.95: inside the box-to-box spread, so the default stays)
          if (const int64_t forced = ldb_option("gb_wgs_per_cu", 0)) per_cu = (int) std::max<int64_t>(1, std::min<int64_t>(forced, 16)); // experiments (Q1's line re-fetches)
          int grid = ldb_grid_for(ctx, in->n_rows, GB_BLOCK, per_cu);
          hipFunction_t spec = nullptr;
