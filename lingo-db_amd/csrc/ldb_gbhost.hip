@@ -705,8 +705,9 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       h->kmult = h->ordered_slots ? (uint64_t) ((((unsigned __int128) cap) << 32) / key_range) : 0;
       uint64_t *gk = nullptr, *ga;
       uint8_t* cross = nullptr;
-      if (!h->dense_out) LDB_TRY(ldb_dev_alloc(ctx, (void**) &gk, 8 * (size_t) cap));
-      LDB_TRY(ldb_dev_alloc(ctx, (void**) &ga, 8 * (size_t) cap * (size_t) nw));
+      LdbBufs attempt(ctx); // the table of this attempt: released when the attempt ends, on every path (an error return included)
+      if (!h->dense_out) LDB_TRY(attempt.alloc(&gk, 8 * (size_t) cap));
+      LDB_TRY(attempt.alloc(&ga, 8 * (size_t) cap * (size_t) nw));
       h->g_keys = (uint64_t) gk;
       h->g_acc = (uint64_t) ga;
       LDB_TRY(ldb_counters(ctx, 2 + GB_MAX_OUT, (uint64_t**) &d_ctl));
@@ -715,7 +716,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       const uint64_t max_groups = std::max<uint64_t>(1, h->keyless ? 1 : h->dense_sorted ? sorted_groups : std::min<uint64_t>(cap, (uint64_t) in->n_rows));
       h->dense_groups = h->dense_sorted ? max_groups : 0;
       if (h->dense_out) {
-         LDB_TRY(ldb_dev_alloc(ctx, (void**) &cross, (size_t) sorted_chunks + 8));
+         LDB_TRY(attempt.alloc(&cross, (size_t) sorted_chunks + 8));
          LDB_HIP(hipMemsetAsync(cross, 0, (size_t) sorted_chunks + 8, ctx->stream));
          h->cross_flags = (uint64_t) cross;
       }
@@ -884,9 +885,6 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       static_assert(sizeof(ctl) <= 64 * sizeof(int64_t), "control block must fit the pinned scratch words");
       LDB_TRY(LDB_READBACK(ctx, ctl, d_ctl, ctl_bytes));
       if (h->dense_out) ctl[1] = sorted_groups; // (no occupancy scan ran: the heads pass counted the groups)
-      ldb_dev_free(ctx, gk);
-      ldb_dev_free(ctx, ga);
-      ldb_dev_free(ctx, cross);
       ldb_dev_free(ctx, d);
       const uint64_t flags = (uint64_t) ctl[0];
       if ((flags & 3) == 0) break;
