@@ -176,7 +176,7 @@ def main():
     ap.add_argument("--cpu-sample-sf", type=float, default=10.0, help="scale of the CPU-baseline sample (0 = skip); the GPU runs the same sample beside it")
     ap.add_argument("--cpu-runs", default="1+3", help="CPU baseline protocol warm-up+measured passes (the reference's tools/scripts/benchmark.py uses 3+10)")
     ap.add_argument("--cpu-budget-s", type=float, default=100.0, help="stop starting new CPU legs after this many seconds (the line names the queries measured)")
-    ap.add_argument("--oracle-spot-check", type=int, default=1, help="1: Q1 / Q3 / Q6 by the oracle at the bench's own scale, generated slice by slice on the host and merged (checks.oracle_q*_at_bench_scale)")
+    ap.add_argument("--oracle-spot-check", type=int, default=1, help="1: Q1 / Q3 / Q6 / Q9 / Q18 by the oracle at the bench's own scale, generated slice by slice on the host and merged (checks.oracle_q*_at_bench_scale; at N > 1 only Q9, 2: all of them)")
     ap.add_argument("--record-runs", type=int, default=3, help="executions per query with replay off after the timed region (per_query_record_ms); 0 = skip")
     ap.add_argument("--plans", default="files", choices=["files", "subop"], help="files: lingo-db_amd/plans/tpch/*.json (the default, the benched configuration); subop: the reference-schema sub-operator dumps "
                     "tests/golden/subop_tpch_qN.json translated by ldb_subop_translate at load time (one GPU) — the plans a LingoDB with the GPU step handler would hand over")
@@ -442,14 +442,19 @@ def main():
                 checks["oracle_q6_at_bench_scale"] = {"equal": bool(got == want), "sf": args.sf, "seconds": round(secs, 1), "value_unscaled": str(want)}
             except Exception as e:  # the spot check must not cost the bench line
                 checks["oracle_q6_at_bench_scale"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1 and args.oracle_spot_check:
-            # BASELINE configs[1] / [2] at the bench's own scale: Q1 (partials of every slice added, averages at the end) and Q3 (order-range slices: all
-            # customers x the slice's orders and lineitems, ten best rows per slice, merged) by the oracle, against the rows the timed executions returned
-            for q, fn in ((1, tpch_plans.oracle_q1_at_scale), (3, tpch_plans.oracle_q3_at_scale)):
-                if q not in results:
+        if args.oracle_spot_check:
+            # BASELINE configs[1] / [2] / [4]'s queries at the bench's own scale: Q1 (partials of every slice added, averages at the end), Q3 (order-range
+            # slices: all customers x the slice's orders and lineitems, ten best rows per slice, merged), Q9 (order-range slices against the green parts and
+            # their partsupp rows, partial sums per nation and year added) and Q18 (a group never crosses an order-range slice; the big orders meet the
+            # customers at the end) by the oracle, against the rows the timed executions returned.  At N > 1 every rank holds the whole result of these
+            # plans (the partials are all-gathered), so rank 0's rows are compared the same way
+            slices = max(8, min(512, n_orders // 250_000))
+            for q, fn, kw in ((1, tpch_plans.oracle_q1_at_scale, {"n_parts": slices}), (3, tpch_plans.oracle_q3_at_scale, {"n_parts": slices}),
+                              (9, tpch_plans.oracle_q9_at_scale, {}), (18, tpch_plans.oracle_q18_at_scale, {"n_parts": slices})):
+                if q not in results or (world > 1 and q != 9 and args.oracle_spot_check < 2):
                     continue
                 try:
-                    want, secs = fn(n_orders, n_parts=max(8, min(512, n_orders // 250_000)))
+                    want, secs = fn(n_orders, **kw)
                     ok = tpch_plans.matches_legs(q, tpch_plans._canon(results[q]), want)
                     checks["oracle_q%d_at_bench_scale" % q] = {"equal": bool(ok), "sf": args.sf, "seconds": round(secs, 1), "rows_compared": results[q].num_rows}
                 except Exception as e:

@@ -322,22 +322,29 @@ class Legs:
             out.append((int(y), num * 10**6 // den))  # decimal(38,6): (num * 10^6) sdiv den
         return out
 
-    def q9(self):
-        import pyarrow.compute as pc
-
+    def q9_partials(self):
+        """{(s_nationkey, year): Σ amount} — the sums add up over any partition of lineitem that keeps an order's lines with its order row (bench.py's
+        sliced oracle at the bench's own scale; tpch_plans.oracle_q9_at_scale hands in part / partsupp already reduced to the '%green%' parts — the
+        semi-join reduction leaves every join below unchanged)"""
         pt = self.frame(T.PART).where(("p_name", "LIKE", "%green%"))
         lp = self.frame(T.LINEITEM).join(pt, [("l_partkey", "p_partkey")], "semi")
         lps = lp.join(self.frame(T.PARTSUPP), [("l_partkey", "ps_partkey"), ("l_suppkey", "ps_suppkey")])
         ls = lps.join(self.frame(T.SUPPLIER), [("l_suppkey", "s_suppkey")])
         lo = ls.join(self.frame(T.ORDERS), [("l_orderkey", "o_orderkey")])
-        na = self.frame(T.NATION)
-        nname = dict(zip(na.np("n_nationkey").tolist(), na.strs("n_name").tolist()))
         amount = lo.np("l_extendedprice") * (100 - lo.np("l_discount")) - lo.np("ps_supplycost") * lo.np("l_quantity")
         key = lo.np("s_nationkey") * 10000 + year_of(lo.np("o_orderdate"))
         uk, inv = np.unique(key, return_inverse=True)
         sums = np.zeros(len(uk), dtype=np.int64)
         np.add.at(sums, inv, amount)
-        return sorted(((nname[int(k) // 10000], int(k) % 10000, int(s)) for k, s in zip(uk, sums)), key=lambda r: (r[0], -r[1]))
+        return {(int(k) // 10000, int(k) % 10000): int(s) for k, s in zip(uk, sums)}
+
+    def q9_finish(self, partials):
+        na = self.frame(T.NATION)
+        nname = dict(zip(na.np("n_nationkey").tolist(), na.strs("n_name").tolist()))
+        return sorted(((nname[nk], yr, int(s)) for (nk, yr), s in partials.items()), key=lambda r: (r[0], -r[1]))
+
+    def q9(self):
+        return self.q9_finish(self.q9_partials())
 
     def q10(self):
         od = self.frame(T.ORDERS).where(("o_orderdate", "GTE", days("1993-10-01")), ("o_orderdate", "LT", days("1994-01-01")))
@@ -415,16 +422,29 @@ class Legs:
         s = int(l1.np("l_extendedprice")[np.array(keep, dtype=bool)].sum()) if any(keep) else None
         return [(None if s is None else (s * 10**5) // 70,)]  # sum / 7.0 → decimal(17,6)
 
-    def q18(self):
+    def q18_big(self):
+        """[(o_custkey, o_orderkey, o_orderdate, o_totalprice, Σ l_quantity)] of the orders with Σ l_quantity > 300 — an order's lines never leave its
+        order-range slice, so the lists of any such partition of (orders, lineitem) concatenate (tpch_plans.oracle_q18_at_scale)"""
         li = self.frame(T.LINEITEM)
         g, (sq,), _ = li.groupby(["l_orderkey"], [("sum", li.expr(["l_quantity"]), False)])
         big = g.take(np.nonzero(sq > 300 * 100)[0])
         bigq = dict(zip(big.np("l_orderkey").tolist(), sq[sq > 300 * 100].tolist()))
         od = self.frame(T.ORDERS).join(big, [("o_orderkey", "l_orderkey")], "semi")
-        oc = od.join(self.frame(T.CUSTOMER), [("o_custkey", "c_custkey")])
-        rows = [(nm, int(ck), int(ok), int(d), int(tp), int(bigq[int(ok)])) for nm, ck, ok, d, tp in
-                zip(oc.strs("c_name"), oc.np("c_custkey"), oc.np("o_orderkey"), oc.np("o_orderdate"), oc.np("o_totalprice"))]
+        return [(int(ck), int(ok), int(d), int(tp), int(bigq[int(ok)])) for ck, ok, d, tp in
+                zip(od.np("o_custkey"), od.np("o_orderkey"), od.np("o_orderdate"), od.np("o_totalprice"))]
+
+    def q18_finish(self, big_rows):
+        """the customer join of the big orders (hash table on customer, probed by the few surviving orders) + ORDER BY"""
+        if not big_rows:
+            return []
+        oc_t = oracle_bind.HostTable(pa.table({"b_custkey": pa.array([r[0] for r in big_rows], type=pa.int32())}))
+        oc = Frame(self, [(oc_t, None)]).join(self.frame(T.CUSTOMER), [("b_custkey", "c_custkey")])
+        src = oc.rel.phys(0)  # the row of big_rows each joined row comes from
+        rows = [(nm, int(ck)) + tuple(big_rows[int(i)][1:]) for nm, ck, i in zip(oc.strs("c_name"), oc.np("c_custkey"), src)]
         return sorted(rows, key=lambda r: (-r[4], r[3]))  # the caller applies LIMIT 100
+
+    def q18(self):
+        return self.q18_finish(self.q18_big())
 
     def q19(self):
         li = self.frame(T.LINEITEM).where(("l_shipmode", "IN", ["AIR", "AIR REG"]), ("l_shipinstruct", "EQ", "DELIVER IN PERSON"))

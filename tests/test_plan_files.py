@@ -252,6 +252,27 @@ def test_oracle_q1_and_q3_in_slices_equal_the_whole_tables():
     assert tpch_plans.matches_legs(1, whole1, got1) and not tpch_plans.matches_legs(1, whole1[:3], got1) and not tpch_plans.matches_legs(6, [], [])
 
 
+def test_oracle_q9_and_q18_in_slices_equal_the_whole_tables():
+    """bench.py's checks.oracle_q9_at_bench_scale / oracle_q18_at_bench_scale (round 6: BASELINE configs[4]'s query and the query with the round-5
+    kernel paths): Q9's partial sums per (nation, year) add up over order-range slices joined against the green parts and the partsupp rows of those
+    parts; Q18's big orders never cross a slice and meet the customers at the end"""
+    import sys
+
+    sys.path[:0] = [os.path.join(ROOT, "oracle"), ROOT]
+    import tpch_legs
+    import tpch_plans
+
+    n_orders = 120_000
+    whole9 = tpch_legs.Legs(n_orders, queries=[9]).q9()
+    got9, _ = tpch_plans.oracle_q9_at_scale(n_orders, n_parts=7, threads=3, dim_parts=3)
+    assert got9 == whole9 and len(got9) == 175
+    assert tpch_plans.matches_legs(9, whole9, got9) and not tpch_plans.matches_legs(9, whole9[:-1], got9)
+    whole18 = tpch_legs.Legs(n_orders, queries=[18]).q18()
+    got18, _ = tpch_plans.oracle_q18_at_scale(n_orders, n_parts=7, threads=3)
+    assert got18 == whole18 and len(got18) >= 3
+    assert tpch_plans.matches_legs(18, whole18[:100], got18) and not tpch_plans.matches_legs(18, whole18[1:], got18)
+
+
 def test_set_op_and_window_steps_are_checked():
     """the steps the dump consumer emits for set operations and windows (round 4): both inputs of a set_op must exist and it needs its kind and the
     two column lists; a window needs its functions"""

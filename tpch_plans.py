@@ -626,3 +626,132 @@ def oracle_q3_at_scale(n_orders, n_parts=256, threads=None, keep=10):
             rows.extend(part_rows)
     rows.sort(key=lambda r: (-r[1], r[2]))
     return rows, time.time() - t0
+
+
+def _host_memory_room():
+    """bytes this process may still allocate: MemAvailable, capped by the cgroup's limit minus its usage; None when unknown"""
+    room = None
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    room = int(line.split()[1]) * 1024
+        with open("/sys/fs/cgroup/memory.max") as f:
+            lim = f.read().strip()
+        if lim != "max":
+            with open("/sys/fs/cgroup/memory.current") as f:
+                cur = int(f.read().strip())
+            room = min(room, int(lim) - cur) if room is not None else int(lim) - cur
+    except Exception:
+        pass
+    return room
+
+
+def _oracle_q9_slice(job):
+    """one order-range slice of oracle_q9_at_scale: the oracle's Q9 joins over (the green parts, their partsupp rows, all suppliers, the slice's
+    orders and lineitems) up to the partial sums per (nation, year)"""
+    n_orders, part, n_parts, shared = job
+    _slice_paths()
+    import oracle_bind
+    import tpch_data as T
+    import tpch_legs
+
+    leg = tpch_legs.Legs(n_orders, threads=1, queries=[9])
+    leg._tables.update(shared)
+    for tid in (T.ORDERS, T.LINEITEM):
+        leg._tables[tid] = oracle_bind.HostTable(T.host_table(tid, n_orders, part=part, n_parts=n_parts, cols=tpch_legs.Legs.NEED[tid][9]))
+    return leg.q9_partials()
+
+
+def oracle_q9_at_scale(n_orders, n_parts=None, threads=None, dim_parts=None):
+    """TPC-H Q9 (the query BASELINE configs[4] names) by the ORACLE over the bench's own scale.  The dimension side once: part generated in `dim_parts`
+    slices, each through the oracle's LIKE '%green%' restriction, the survivors kept (5.4 %); partsupp slice by slice through the oracle's semi join
+    against those parts (the semi-join reduction: the rows the (l_partkey, l_suppkey) probe can reach); supplier and nation whole.  Then orders and
+    lineitem slice by slice at the same order boundaries, every slice through the oracle's four hash joins (tpch_legs.q9_partials), the partial sums per
+    (nation, year) added in Python integers.  Every slice builds its own hash table on the green partsupp rows (4.3 M at SF100), so the slices are
+    few and large: two per worker, at most ≈ 30 M lineitems each (≈ 2 GB of host columns per worker).  Returns (rows in the legs' conventions, seconds)."""
+    import concurrent.futures
+    import time
+
+    import pyarrow as pa
+
+    _slice_paths()
+    import oracle_bind
+    import tpch_data as T
+    import tpch_legs
+
+    t0 = time.time()
+    workers = threads or min(32, os.cpu_count() or 8)
+    n_parts = n_parts or max(2 * workers, -(-n_orders * 4 // 30_000_000))
+    # a worker holds one slice's columns (≈ 64 B per lineitem + 12 B per order) and about as much again in row ids and gathered values: never more
+    # workers than a third of the memory this process may still take
+    room = _host_memory_room()
+    if room is not None:
+        per_worker = 3 * (n_orders * 4 // n_parts) * 80
+        workers = max(1, min(workers, int(room / 3 // max(per_worker, 1))))
+    dim_parts = dim_parts or max(1, min(64, n_orders // 4_000_000))
+    need = tpch_legs.Legs.NEED
+
+    def green_part(p):
+        leg = tpch_legs.Legs(n_orders, threads=1, queries=[9])
+        t = oracle_bind.HostTable(T.host_table(T.PART, n_orders, part=p, n_parts=dim_parts, cols=need[T.PART][9]))
+        fr = tpch_legs.Frame(leg, [(t, None)]).where(("p_name", "LIKE", "%green%"))
+        return t.arrow.take(pa.array(fr.rel.phys(0)))
+
+    with concurrent.futures.ThreadPoolExecutor(workers) as pool:
+        green = oracle_bind.HostTable(pa.concat_tables(list(pool.map(green_part, range(dim_parts)))).combine_chunks())
+
+        def green_partsupp(p):
+            leg = tpch_legs.Legs(n_orders, threads=1, queries=[9])
+            t = oracle_bind.HostTable(T.host_table(T.PARTSUPP, n_orders, part=p, n_parts=dim_parts, cols=need[T.PARTSUPP][9]))
+            fr = tpch_legs.Frame(leg, [(t, None)]).join(tpch_legs.Frame(leg, [(green, None)]), [("ps_partkey", "p_partkey")], "semi")
+            return t.arrow.take(pa.array(fr.rel.phys(0)))
+
+        shared = {T.PART: green, T.PARTSUPP: oracle_bind.HostTable(pa.concat_tables(list(pool.map(green_partsupp, range(dim_parts)))).combine_chunks()),
+                  T.SUPPLIER: oracle_bind.HostTable(T.host_table(T.SUPPLIER, n_orders, cols=need[T.SUPPLIER][9])),
+                  T.NATION: oracle_bind.HostTable(T.host_table(T.NATION, n_orders, cols=need[T.NATION][9]))}
+        total = {}
+        for partial in pool.map(_oracle_q9_slice, [(n_orders, part, n_parts, shared) for part in range(n_parts)]):
+            for key, v in partial.items():
+                total[key] = total.get(key, 0) + v
+    fin = tpch_legs.Legs(n_orders, threads=1, queries=[9])
+    fin._tables.update(shared)
+    return fin.q9_finish(total), time.time() - t0
+
+
+def _oracle_q18_slice(job):
+    """one order-range slice of oracle_q18_at_scale: the oracle's group-by of the slice's lineitems by order and the semi join of its orders"""
+    n_orders, part, n_parts = job
+    _slice_paths()
+    import oracle_bind
+    import tpch_data as T
+    import tpch_legs
+
+    leg = tpch_legs.Legs(n_orders, threads=1, queries=[18])
+    for tid in (T.ORDERS, T.LINEITEM):
+        leg._tables[tid] = oracle_bind.HostTable(T.host_table(tid, n_orders, part=part, n_parts=n_parts, cols=tpch_legs.Legs.NEED[tid][18]))
+    return leg.q18_big()
+
+
+def oracle_q18_at_scale(n_orders, n_parts=256, threads=None):
+    """TPC-H Q18 by the ORACLE over the bench's own scale: orders and lineitem slice by slice at the same order boundaries (a group — one order's
+    lines — never crosses a slice), every slice through the oracle's PreAggregationHashtable restatement and the semi join (tpch_legs.q18_big); the few
+    orders above 300 units are joined with the whole customer table at the end (q18_finish) and sorted by the query's ORDER BY.  The caller compares
+    the GPU's hundred rows with matches_legs (key sequence + membership).  Returns (rows, seconds)."""
+    import concurrent.futures
+    import time
+
+    _slice_paths()
+    import oracle_bind
+    import tpch_data as T
+    import tpch_legs
+
+    t0 = time.time()
+    workers = threads or min(64, os.cpu_count() or 8)
+    big = []
+    with concurrent.futures.ThreadPoolExecutor(workers) as pool:
+        for rows in pool.map(_oracle_q18_slice, [(n_orders, part, n_parts) for part in range(n_parts)]):
+            big.extend(rows)
+    fin = tpch_legs.Legs(n_orders, queries=[18])
+    fin._tables[T.CUSTOMER] = oracle_bind.HostTable(T.host_table(T.CUSTOMER, n_orders, cols=tpch_legs.Legs.NEED[T.CUSTOMER][18]))
+    return fin.q18_finish(big), time.time() - t0
