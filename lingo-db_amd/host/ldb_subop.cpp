@@ -228,6 +228,7 @@ struct Translator {
    std::string result;
    std::string markName; // the column a mark join about to be emitted adds
    std::string report; // JSON array body
+   std::set<std::string> ext; // the emitter extensions the dump's manifest declares (integration/mlir-subop-to-json.patch)
    int nval = 0;
 
    std::string fresh(const char* stem) { return std::string(stem) + std::to_string(++nval); }
@@ -291,19 +292,28 @@ struct Translator {
       const J& ss = e.at("strings");
       const std::string first = ss.arr.empty() ? "" : ss.arr[0].str;
       if (strs(e, {"", " * ", ""})) return op("mul", 2);
-      if (strs(e, {"", " + ", ""})) return op("add", 2);
-      if (strs(e, {"", " - ", ""})) return op("sub", 2); // emitter extension E1 (the tool prints " + " for db.sub today)
+      if (strs(e, {"", " + ", ""})) {
+         // the unpatched tool prints db.sub with the separator " + " too (mlir-subop-to-json.cpp:315-317): a sum is a sum only from an emitter with E1
+         if (!ext.count("E1")) throw Unsupported("' + ' is ambiguous without emitter extension E1: the unpatched tool prints db.sub as ' + ' as well (mlir-subop-to-json.cpp:315-317)");
+         return op("add", 2);
+      }
+      if (strs(e, {"", " - ", ""})) return op("sub", 2); // emitter extension E1
       if (strs(e, {"", " / ", ""})) return op("div", 2);
       if (strs(e, {"cast(", ")"})) return op("cast", 1);
       if (strs(e, {"not ", ""})) return op("not", 1);
       if (strs(e, {"", " is null"})) return op("isnull", 1);
       if (strs(e, {"", " ? ", " : ", ""})) return op("select", 3);
       if (strs(e, {"if ", " then ", " else ", ""})) return op("select", 3);
-      if (strs(e, {"", " between ", " and ", ""})) { // db.between: both bounds inclusive unless the emitter says otherwise
+      if (strs(e, {"", " between ", " and ", ""})) {
+         // db.between carries lowerInclusive / upperInclusive (DBOps.td:507); `x >= a and x < b` is canonicalised into a HALF-OPEN one (DBOps.cpp:475-483,
+         // lowered at LowerToStd.cpp:1026) and the unpatched tool drops both flags (mlir-subop-to-json.cpp:261-263): only an emitter with E10 says which
          if (a.size() != 3) throw Unsupported("malformed between");
+         const J *li = e.get("lowerInclusive"), *ui = e.get("upperInclusive");
+         if (!ext.count("E10") || !li || !ui || li->kind != J::BOOL || ui->kind != J::BOOL)
+            throw Unsupported("db.between without its lowerInclusive / upperInclusive flags (emitter extension E10): the unpatched tool prints a half-open range like a closed one (mlir-subop-to-json.cpp:261-263)");
          ExprP lo = mk(Expr::OP, "cmp"), hi = mk(Expr::OP, "cmp"), r = mk(Expr::OP, "and");
-         lo->cmp = "GTE", lo->args = {a[0], a[1]};
-         hi->cmp = "LTE", hi->args = {a[0], a[2]};
+         lo->cmp = li->b ? "GTE" : "GT", lo->args = {a[0], a[1]};
+         hi->cmp = ui->b ? "LTE" : "LT", hi->args = {a[0], a[2]};
          r->args = {lo, hi};
          return r;
       }
@@ -2145,8 +2155,26 @@ struct Translator {
 
    bool run(const J& plan, std::string* err) {
       if (plan.kind != J::ARR) throw std::runtime_error("subop dump: the document must be the array ToJson::run prints");
+      // the manifest of the patched emitter (integration/mlir-subop-to-json.patch, --gpu-manifest): which of the extensions E1 … E10 produced this
+      // document.  A dump without one comes from the unpatched tool, whose output this consumer would MIS-translate silently in two places (db.sub
+      // printed as " + ", db.between without its inclusivity flags) — refused as a whole
+      bool manifest = false;
+      for (auto& node : plan.arr)
+         if (node.kind == J::OBJ && node.sOr("type", "") == "emitter_manifest") {
+            manifest = true;
+            if (const J* x = node.get("extensions"))
+               for (auto& v : x->arr) ext.insert(v.str);
+         }
+      if (!manifest) {
+         *err = "the dump carries no emitter manifest ({\"type\": \"emitter_manifest\", \"extensions\": [...]}, written by the patched tool: "
+                "integration/mlir-subop-to-json.patch): the unpatched mlir-subop-to-json prints db.sub as ' + ' (needs E1) and drops the inclusivity flags of "
+                "db.between (needs E10) — refusing the document instead of mis-translating it";
+         addReport("", false, *err, 0);
+         return false;
+      }
       bool ok = true;
       for (auto& node : plan.arr) {
+         if (node.sOr("type", "") == "emitter_manifest") continue;
          const std::string& ref = node.s("ref");
          StepCtx c;
          const bool isStep = node.sOr("type", "") == "execution_step";

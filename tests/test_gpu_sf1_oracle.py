@@ -146,6 +146,8 @@ def test_pattern_dumps_match_numpy(world):
         assert all(r["target"] == "gpu" for r in report)
         return result_rows(runner.ctx.run_plan(text, inputs).to_arrow())
 
+    reg_of = dict(zip(n_key, n_reg))  # a half-open db.between over joined rows + a db.sub (emitter extensions E10 / E1)
+    assert run("between", {"supplier": sup, "nation": db.nation}) == [(k, k - reg_of[n]) for k, n in sorted(zip(s_key, s_nat)) if 10 <= k < 20]
     region1 = {k for k, r in zip(n_key, n_reg) if r == 1}
     want = sorted(k for k, n, b in zip(s_key, s_nat, s_bal) if n in region1 or b > rich)
     assert 0 < len(want) < len(s_key) and any(n not in region1 for k, n, b in zip(s_key, s_nat, s_bal) if b > rich)

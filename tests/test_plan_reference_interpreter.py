@@ -83,6 +83,8 @@ def test_pattern_dumps_say_what_plain_python_computes(world):
         with open(os.path.join(ROOT, "tests", "golden", "subop_pat_%s.json" % name)) as f:
             return run(tables, json.loads(api.translate_subop_dump(f.read(), "pat_" + name)[0]))
 
+    reg_of = dict(zip(n_key, n_reg))
+    assert pat("between") == [(k, k - reg_of[n]) for k, n in sorted(zip(s_key, s_nat)) if 10 <= k < 20] and len(pat("between")) == 10
     region1 = {k for k, r in zip(n_key, n_reg) if r == 1}
     assert pat("mark") == [(k,) for k in sorted(k for k, n, b in zip(s_key, s_nat, s_bal) if n in region1 or b > rich)]
     per_nation, total = collections.Counter(), collections.Counter()

@@ -63,7 +63,7 @@ RELALG = [2, 7, 8, 9, 10, 11, 13, 14, 15, 16, 17, 19, 20, 21, 22]  # written by 
 def test_dump_translates_to_a_checked_plan(q):
     text, report = api.translate_subop_dump(dump(q), "tpch_q%s" % q)
     plan = json.loads(text)
-    assert all(r["target"] == "gpu" for r in report) and len(report) == len(json.loads(dump(q)))
+    assert all(r["target"] == "gpu" for r in report) and len(report) == len(json.loads(dump(q))) - 1  # (one report entry per execution step; the last element is the emitter manifest)
     lib = capi.host_lib()
     ins = plan["inputs"]
     arr = (capi.C.c_char_p * len(ins))(*[n.encode() for n in ins])
@@ -110,7 +110,7 @@ def test_semi_joins_in_both_of_the_references_forms():
     for q, kind in ((4, "anti_build"), ("4_probe_side", "anti")):
         d = json.loads(dump(q))
         hits = 0
-        for step in d:
+        for step in d[:-1]:  # (the last element is the emitter manifest)
             for op in step["subops"]:
                 for o in [op] + op.get("subops", []):
                     if o.get("subop") == "filter" and o["columns"][0]["displayName"] in ("materialized::marker", "marker::marker"):
@@ -175,7 +175,7 @@ def test_steps_without_a_device_pattern_are_reported():
     assert e.value.status == capi.LDB_ERR_UNSUPPORTED and pipe["ref"] in str(e.value)
     rep = {r["ref"]: r for r in e.value.report}
     assert rep[pipe["ref"]]["target"] == "cpu" and "no case" in rep[pipe["ref"]]["reason"]
-    assert rep[d[0]["ref"]]["target"] == "gpu" and rep[d[-1]["ref"]]["target"] == "cpu"  # what follows cannot be placed either
+    assert rep[d[0]["ref"]]["target"] == "gpu" and rep[d[-2]["ref"]]["target"] == "cpu"  # what follows cannot be placed either
     # the tool's own rendering of db.sub (" + ", mlir-subop-to-json.cpp:334) would silently change Q1: the dumps carry " - "
     assert '" - "' in dump(1) and '" - "' in dump(3)
     # a sub-operator with a case in the tool but no device pattern
@@ -274,7 +274,7 @@ def test_translated_plans_that_equal_the_hand_written_ones():
     assert [g for g in got if g[0] != "materialize"][:4] == [w for w in want if w[0] != "materialize"][:4]  # filter, build, semi probe, avg per part
 
 
-PATTERNS = ["mark", "right_outer", "full_outer", "groupjoin", "groupjoin_outer", "window", "window_part", "window_total", "window_total_part", "union_all", "union", "intersect", "except", "intersect_all", "except_all"]  # tools/write_subop_dumps_patterns.py
+PATTERNS = ["mark", "right_outer", "full_outer", "groupjoin", "groupjoin_outer", "window", "window_part", "window_total", "window_total_part", "union_all", "union", "intersect", "except", "intersect_all", "except_all", "between"]  # tools/write_subop_dumps_patterns.py
 
 
 def pattern_steps(name):
@@ -286,6 +286,62 @@ def pattern_steps(name):
     assert capi.host_lib().ldb_plan_json_check(text.encode(), arr, len(ins)) == capi.LDB_OK, capi.host_lib().ldb_plan_json_last_error()
     assert all(r["target"] == "gpu" for r in report)
     return plan["steps"]
+
+
+def test_half_open_between_and_subtraction_need_the_patched_emitter():
+    """verdict r5 weak #2: the reference's tool prints db.sub with " + " (tools/ct/mlir-subop-to-json.cpp:315-317) and db.between without its
+    lowerInclusive / upperInclusive flags (:261-263; `x >= a and x < b` becomes a HALF-OPEN between, DBOps.cpp:475-483).  With the manifest of the
+    patched emitter (integration/mlir-subop-to-json.patch: E1, E10) both translate exactly; a document of the UNPATCHED tool is refused, never
+    mis-translated"""
+    st = pattern_steps("between")
+    flt = [s for s in st if s["op"] == "filter"][0]
+    assert flt["preds"] == [{"col": "s_suppkey", "op": "GTE", "value": 10}, {"col": "s_suppkey", "op": "LT", "value": 20}]
+    assert [s for s in st if s["op"] == "map"][0]["expr"] == {"sub": ["s_suppkey", "n_regionkey"]}
+    with open(os.path.join(GOLD, "subop_pat_between.json")) as f:
+        doc = json.load(f)
+    assert doc[-1]["type"] == "emitter_manifest" and {"E1", "E10"} <= set(doc[-1]["extensions"])
+
+    def refused(d, *words):
+        with pytest.raises(capi.LdbError) as e:
+            api.translate_subop_dump(json.dumps(d))
+        assert e.value.status == capi.LDB_ERR_UNSUPPORTED and all(w in str(e.value) for w in words), str(e.value)
+
+    def walk(x):
+        if isinstance(x, dict):
+            yield x
+            for v in x.values():
+                yield from walk(v)
+        elif isinstance(x, list):
+            for v in x:
+                yield from walk(v)
+
+    # (a) what the unpatched tool writes: no manifest, " + " for the subtraction, no flags on the between
+    unpatched = copy.deepcopy(doc[:-1])
+    for n in walk(unpatched):
+        if n.get("strings") == ["", " - ", ""]:
+            n["strings"] = ["", " + ", ""]
+        n.pop("lowerInclusive", None), n.pop("upperInclusive", None)
+    refused(unpatched, "no emitter manifest", "E1", "E10")
+    # (b) an emitter that declares everything but E1: its " + " may be a db.sub
+    no_e1 = copy.deepcopy(doc)
+    no_e1[-1]["extensions"].remove("E1")
+    for n in walk(no_e1):
+        if n.get("strings") == ["", " - ", ""]:
+            n["strings"] = ["", " + ", ""]
+    refused(no_e1, "E1", "db.sub")
+    # (c) an emitter without E10, and one that declares E10 but leaves the flags out
+    no_e10 = copy.deepcopy(doc)
+    no_e10[-1]["extensions"].remove("E10")
+    refused(no_e10, "E10", "db.between")
+    no_flags = copy.deepcopy(doc)
+    for n in walk(no_flags):
+        n.pop("upperInclusive", None)
+    refused(no_flags, "E10", "db.between")
+    # every committed dump carries the manifest
+    for name in sorted(os.listdir(GOLD)):
+        if name.startswith("subop_") and name.endswith(".json"):
+            with open(os.path.join(GOLD, name)) as f:
+                assert json.load(f)[-1].get("type") == "emitter_manifest", name
 
 
 def test_mark_join_read_as_a_value():
@@ -351,7 +407,7 @@ def test_full_outer_join_group_join_outer_behaviour_and_static_window_aggregates
         assert [(f["fn"], f.get("col")) for f in w["fns"]] == [("sum", "s_acctbal"), ("count_star", None)]
 
 
-@pytest.mark.parametrize("kind", PATTERNS[9:])
+@pytest.mark.parametrize("kind", PATTERNS[9:15])
 def test_set_operations(kind):
     """UnionAllLowering (map both inputs + union), UnionDistinctLowering (both inputs lookup_or_insert into one key-only map),
     CountingSetOperationLowering (two counters; a predicate or a repeat count over them, :622-915) → one set_op step"""

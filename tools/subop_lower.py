@@ -50,7 +50,9 @@ def gt(a, b): return inner(["", ">", ""], [a, b])
 def gte(a, b): return inner(["", ">=", ""], [a, b])
 def lte(a, b): return inner(["", "<=", ""], [a, b])
 def not_(a): return inner(["not ", ""], [a])
-def between(x, lo, hi): return inner(["", " between ", " and ", ""], [x, lo, hi])
+def between(x, lo, hi, lower_inclusive=True, upper_inclusive=True):
+    """db.between with its two I1 attributes (DBOps.td:507) — EXT E10: the unpatched tool prints neither"""
+    return dict(inner(["", " between ", " and ", ""], [x, lo, hi]), lowerInclusive=lower_inclusive, upperInclusive=upper_inclusive)
 def one_of(x, vals): return inner(["", " in ["] + [", "] * (len(vals) - 1) + ["]"], [x] + list(vals))  # db.oneof
 def call(fn, *args): return inner([fn + "("] + [", "] * (len(args) - 1) + [")"], list(args))  # db.runtime_call
 def null(): return {"type": "expression_leaf", "leaf_type": "null"}
@@ -788,5 +790,5 @@ def result(cx, child, outs, write=True):
     if not write:
         import json
 
-        return json.dumps(cx.d.plan)
+        return json.dumps(cx.d.document())
     return cx.d.write()

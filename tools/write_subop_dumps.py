@@ -38,6 +38,9 @@ import json
 import os
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+# the last element of a document from the patched emitter (integration/mlir-subop-to-json.patch, run with --gpu-manifest): the extensions it applied.
+# ldb_subop_translate refuses a document without it — the unpatched tool's " + " for db.sub and flag-less db.between would be mis-read silently
+MANIFEST = {"type": "emitter_manifest", "extensions": ["E1", "E4", "E5", "E6", "E7", "E8", "E9", "E10"]}
 
 
 def column(name, datatype):  # columnToJSON, mlir-subop-to-json.cpp:395-409
@@ -107,10 +110,14 @@ class Dump:
         self.plan.append(node)
         return r
 
+    def document(self):
+        """the array ToJson::run prints, closed by the manifest of the patched emitter (integration/mlir-subop-to-json.patch, --gpu-manifest)"""
+        return self.plan + [MANIFEST]
+
     def write(self):
         path = os.path.join(OUT, "subop_%s.json" % self.name)
         with open(path, "w") as f:
-            json.dump(self.plan, f, indent=1)
+            json.dump(self.document(), f, indent=1)
             f.write("\n")
         return path
 

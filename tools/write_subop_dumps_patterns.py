@@ -7,8 +7,10 @@
   pat_groupjoin[_outer] GroupJoinLowering (:2682-2950), inner (outer: every nation, 0 / NULL without a supplier above 9990): per nation with a rich supplier its name, their number and total balance
   pat_window[_part] WindowLowering (:2193-2553): rank + SUM + COUNT(*) over the suppliers by key, over a 3-row frame / per nation from the partition start
   pat_<set op>     UnionAll / UnionDistinct / CountingSetOperation lowerings (:622-915) over the nation keys of rich customers (balance > 9000) / the richest suppliers (> 9990)
+  pat_between      a HALF-OPEN db.between that survives as a residual selection over joined rows (`x >= a and x < b` canonicalised by DBOps.cpp:475-483:
+                   lowerInclusive = true, upperInclusive = false — emitter extension E10) next to a db.sub (E1)
 Writes tests/golden/subop_pat_*.json."""
-from subop_lower import I64_MAX, I64_MIN, Aggregate, C, Cx, GroupJoin, Join, Select, SetOp, Sort, Table, Window, dec, eq, gt, or_, result, const
+from subop_lower import I64_MAX, I64_MIN, Aggregate, C, Cx, GroupJoin, Join, Map, Select, SetOp, Sort, Table, Window, between, dec, eq, gt, or_, result, const, sub
 
 RICH = dec("9000.00", 12, 2)
 
@@ -80,10 +82,23 @@ def window(partitioned):
     return result(cx, Sort(w, [(s["s_suppkey"], "asc")]), [("s_suppkey", s["s_suppkey"]), ("rank", rank), ("balance", total), ("rows", cnt)])
 
 
+def between_half_open():
+    """suppliers with 10 <= s_suppkey < 20 joined with their nation: the range is a residual db.between over the joined rows, the result also shows
+    s_suppkey - n_regionkey (db.sub)"""
+    cx = Cx("pat_between")
+    s, n = Table("supplier"), Table("nation")
+    j = Join("inner", s, n, [(s["s_nationkey"], n["n_nationkey"])])
+    sel = Select(j, between(s["s_suppkey"].j, const(10, "int32"), const(20, "int32"), lower_inclusive=True, upper_inclusive=False))
+    diff = C("map0::diff", "int32")
+    m = Map(sel, [(diff, sub(s["s_suppkey"].j, n["n_regionkey"].j))])
+    return result(cx, Sort(m, [(s["s_suppkey"], "asc")]), [("s_suppkey", s["s_suppkey"]), ("diff", diff)])
+
+
 SET_KINDS = ("union_all", "union", "intersect", "except", "intersect_all", "except_all")
 
 if __name__ == "__main__":
     print(mark())
+    print(between_half_open())
     print(right_outer())
     print(full_outer())
     print(groupjoin())
