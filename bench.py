@@ -246,14 +246,38 @@ def main():
     # the FIRST execution of a plan pays what the reference reports as compile time (include/lingodb/execution/Timing.h:47-50 lists the lowering /
     # codegen phases beside executionTime): hiprtc specialisation of its kernels, column statistics, hash indexes of the base tables, overflow
     # retries of unestimated tables and the read-back record.  Timed separately (host wall clock, result hand-over included), never part of `value`
+    # Round 6: specialisations compile on worker threads while the first execution runs the generic ahead-of-time kernels (the reference's baseline /
+    # optimising backend pair, Execution.h:103-104), code objects are kept on disk (~/.cache/ldb_jit).  After the first pass the bench waits for the
+    # compilations (untimed, reported as jit.wait_after_first_pass_s) and runs at least one more untimed pass, which loads the specialised modules:
+    # the timed region never contains a compilation, a module load or a generic kernel that has a specialised twin
+    from lingodb_amd import capi as _capi_jit
+    import ctypes as _C
+
+    def _jit_ms():
+        n, h, ms = _C.c_int64(), _C.c_int64(), _C.c_double()
+        _capi_jit.gpu_lib().ldb_gpu_jit_stats(_C.byref(n), _C.byref(h), _C.byref(ms))
+        return ms.value
+
+    def jit_info():
+        vals = (_C.c_int64 * 8)()
+        _capi_jit.gpu_lib().ldb_gpu_jit_info(vals, 8)
+        return dict(zip(("compiled", "memory_hits", "disk_hits", "disk_writes", "outstanding", "failed", "answered_still_compiling", "worker_threads"), [int(v) for v in vals]))
+
     first_ms = {}
-    for w in range(max(args.warmup, 1)):
+    jit_wait_s = 0.0
+    for w in range(max(args.warmup, 2)):
         for q in queries:
             t_q = time.perf_counter()
             runner.run(q).to_arrow()
             if w == 0:
                 ctx.sync()
                 first_ms[q] = (time.perf_counter() - t_q) * 1000.0
+        if w == 0:
+            t_w = time.perf_counter()
+            pend = _C.c_int64()
+            _capi_jit.gpu_lib().ldb_gpu_jit_wait(600_000, _C.byref(pend))
+            jit_wait_s = time.perf_counter() - t_w
+            jit_first = jit_info()
     timers = {q: ctx.timer() for q in queries}
     q_ms = {q: 0.0 for q in queries}
     q_runs = {q: [] for q in queries}
@@ -339,8 +363,8 @@ def main():
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel: the fused scan+filter+aggregate kernel of Q1
-        roof_q = 1 if 1 in queries else queries[0]
-        n_l, ms_l = kernel_ms.get((roof_q, "k_groupby"), [0, 0.0])
+        roof_q = 1
+        n_l, ms_l = kernel_ms.get((roof_q, "k_groupby"), [0, 0.0]) if 1 in queries else (0, 0.0)  # (the 76 B/row model is Q1's: no Q1, no dominant-kernel entry)
         rows_local = db.lineitem.rows
         bpr = Q1_BYTES_PER_ROW_NARROW if args.narrow_decimals else Q1_BYTES_PER_ROW
         roofline = None
@@ -522,6 +546,8 @@ def main():
             "config": {"workload": "TPC-H SF%g %s on %d x MI355X, Arrow columns resident in HBM (synthetic dbgen-shaped data, seed 20260925)" % (
                 args.sf, "+".join("Q%d" % q for q in queries), world), "queries": queries, "rows_lineitem_total": int(db.n_lineitem_total),
                 "narrow_decimals": bool(args.narrow_decimals), "device": info["name"], "exchange": exchange, "load_s": round(load_s, 3),
+                **({"functional_only": "all %d ranks share ONE GPU and exchange over the host-staged transport (LDB_DIST_BACKEND=gloo): a functional run of the sharded plans, "
+                                       "not a scaling measurement" % world} if world > 1 and backend == "gloo" else {}),
                 "plans": ("tests/golden/subop_tpch_q*.json: sub-operator dumps in the reference's mlir-subop-to-json schema, translated by ldb_subop_translate (straightforward join trees, no eager aggregation)"
                           if args.plans == "subop" else
                           "lingo-db_amd/plans/tpch/%s*.json: hand-ordered operator plans (join orders, eager aggregation), not LingoDB's optimiser output" % ("dist/" if world > 1 else "")),
@@ -544,6 +570,8 @@ def main():
             "checks": checks,
             # timing modes beside `per_query_ms` (replayed executions, what `value` is the geomean of): the first execution of each plan (host wall clock:
             # hiprtc + statistics + indexes + the recording run — the reference's compile-time columns, Timing.h:47-50) and the steady state with replay off
+            "jit": dict(jit_info(), compile_ms_total=round(_jit_ms(), 1), wait_after_first_pass_s=round(jit_wait_s, 2), after_first_pass=jit_first,
+                        mode="asynchronous: the first execution runs the generic kernels while hiprtc compiles on worker threads; code objects cached on disk"),
             "first_execution_ms": {"Q%d" % q: round(first_ms[q], 1) for q in queries if q in first_ms},
             "per_query_record_ms": {"Q%d" % q: round(record_ms[q], 4) for q in queries if q in record_ms},
             "record_geomean_ms": round(geomean([record_ms[q] for q in queries]), 4) if len(record_ms) == len(queries) else None,

@@ -152,6 +152,20 @@ int32_t ldb_gpu_prof_marker(ldb_ctx* ctx, int32_t id);
  * and a device-less compile check of the specialiser (hiprtc log into `log`). */
 int32_t ldb_gpu_jit_stats(int64_t* compiled, int64_t* cache_hits, double* compile_ms);
 int32_t ldb_gpu_jit_compile_check(char* log, int32_t cap);
+/* Specialisations compile on worker threads (option jit_async, default 1; jit_threads): the operator that asked launches its generic
+ * ahead-of-time kernel meanwhile — the reference's answer to compile latency is a baseline backend that emits code in milliseconds with an
+ * optimising one behind it (include/lingodb/execution/Execution.h:103-104, src/execution/baseline/).  Code objects are kept on disk under a
+ * content hash ($LDB_JIT_CACHE_DIR, default ~/.cache/ldb_jit/<arch>/<hash>.co; option jit_disk_cache = 0 disables), so a second process start
+ * compiles nothing.  ldb_gpu_jit_wait blocks until nothing is queued or compiling (timeout_ms < 0: no limit; *pending = still outstanding) — what a
+ * benchmark calls between its first execution and its timed region.  ldb_gpu_jit_info: vals[0..8) = compiled here, in-memory hits, disk hits,
+ * disk writes, outstanding, failed, calls answered "still compiling", worker threads. */
+int32_t ldb_gpu_jit_wait(int64_t timeout_ms, int64_t* pending);
+int32_t ldb_gpu_jit_info(int64_t* vals, int32_t n);
+/* stop the compile workers: queued specialisations are dropped, running ones finish.  Call before the process exits (the library also registers an
+ * exit handler, but hiprtc's own statics may be torn down first when a compilation is still in flight at exit) */
+int32_t ldb_gpu_jit_shutdown(void);
+/* device-less self-test of the above (CPU test suite): asynchronous request → wait → code object on disk → second request answered from the disk */
+int32_t ldb_gpu_jit_cache_selftest(char* log, int32_t cap);
 
 /* Process-wide tuning options (each also readable from the environment as LDB_<NAME> on first use):
  *   jit (0/1), jit_min_rows      — run-time kernel specialisation and its row threshold (default 4 M)

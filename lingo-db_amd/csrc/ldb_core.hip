@@ -42,7 +42,7 @@ int64_t ldb_option(const char* name, int64_t dflt) {
 }
 extern "C" int32_t ldb_gpu_set_option(const char* name, int64_t value) {
    if (!name) LDB_FAIL(LDB_ERR_INVALID, "set_option: NULL name");
-   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass", "lazy_strings", "lazy_strings_min_rows", "gb_partition_wc", "join_radix_wc", "join_radix_lds", "gb_dense_out", "gb_partition_values", "join_pair32", "gb_dense_keys"};
+   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass", "lazy_strings", "lazy_strings_min_rows", "gb_partition_wc", "join_radix_wc", "join_radix_lds", "gb_dense_out", "gb_partition_values", "join_pair32", "gb_dense_keys", "jit_async", "jit_threads", "jit_disk_cache"};
    bool ok = false;
    for (const char* k : known) ok |= strcmp(k, name) == 0;
    if (!ok) LDB_FAIL(LDB_ERR_INVALID, "set_option: unknown option '%s'", name);
@@ -321,6 +321,16 @@ uint32_t ldb_site_note(uint32_t hash, const char* file, int line) {
    }
    return hash;
 }
+uint32_t ldb_site_derived(uint32_t base, uint32_t salt) {
+   const uint32_t hash = base ^ (salt * 2654435761u);
+   if (ldb_host_trace_threshold() < 0) return hash; // (names are only ever printed under LDB_HOST_TRACE)
+   std::lock_guard<std::mutex> lock(g_site_mu);
+   if (!g_sites.count(hash)) {
+      auto it = g_sites.find(base);
+      g_sites.emplace(hash, (it != g_sites.end() ? it->second : std::string("?")) + " n=" + std::to_string(salt));
+   }
+   return hash;
+}
 // replay: everything read so far must equal the record
 static bool trace_prefix_ok(ldb_ctx* ctx, size_t upto_entries) {
    LdbSlow slow_("trace check: wait for the replayed plan", upto_entries);
@@ -378,7 +388,12 @@ int32_t ldb_readback(ldb_ctx* ctx, void* host, const void* dev, size_t bytes, ui
       if (ctx->trace_poisoned || !trace_prefix_ok(ctx, ctx->trace_pos)) {
          if (!ctx->trace_poisoned) t->misses++;
          ctx->trace_poisoned = true;
-         LDB_FAIL(LDB_ERR_RETRY, "a replayed read-back differs from the recorded value");
+         if (!ctx->trace_collective) LDB_FAIL(LDB_ERR_RETRY, "a replayed read-back differs from the recorded value");
+         // collective: a rank on void data easily leaves the recorded sequence (an empty input skips a read, a table overflows …).  Its peers are
+         // still inside their exchanges, queued against this rank's transfers: abandoning the plan here would stall them until the communicator's
+         // time-out (shm) or for good (RCCL).  It reads the real value — consistent with what is on the device now — leaves the record alone and
+         // goes on to the end, where the agreed verdict makes every rank repeat the execution
+         return readback_sync(ctx, host, dev, bytes);
       }
       t->diverged++;
       t->entries.resize(ctx->trace_pos);

@@ -232,9 +232,11 @@ __global__ void k_gb_finalize_cross(const DGroupBy* __restrict__ d, uint64_t n_c
 
 // per-group validity bytes → Arrow bitmap; *nulls += number of zero bytes (one atomic per wave of a
 // bounded grid)
-// (the row count is read on the device: the launch is queued before the host knows the number of groups)
-__global__ void k_pack_valid_bytes(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bitmap, const unsigned long long* __restrict__ d_n, unsigned long long* __restrict__ nulls) {
-   const uint64_t n = (uint64_t) *d_n;
+// (the row count is read on the device: the launch is queued before the host knows the number of groups; `cap` = the rows `bytes` and `bitmap` were
+// allocated for — under a replay that is the RECORDED group count, and a mis-speculated execution may really have more groups: it is repeated
+// after the end-of-trace comparison, but until then nothing may be read or written past the allocations)
+__global__ void k_pack_valid_bytes(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bitmap, const unsigned long long* __restrict__ d_n, uint64_t cap, unsigned long long* __restrict__ nulls) {
+   const uint64_t n = min((uint64_t) *d_n, cap);
    uint64_t nb = (n + 7) / 8;
    unsigned int zeros = 0;
    for (uint64_t b = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; b < nb; b += (uint64_t) gridDim.x * blockDim.x) {
@@ -852,7 +854,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          for (int32_t a = 0; a < n_aggs; a++)
             if (out_valid[(size_t) a])
                hipLaunchKernelGGL(k_pack_valid_bytes, dim3(ldb_grid_for(ctx, (int64_t) max_groups, 256 * 8, 4)), dim3(256), 0, ctx->stream, out_valid[(size_t) a], bitmaps[(size_t) a],
-                                  (const unsigned long long*) d_sorted_groups, d_ctl + 2 + a);
+                                  (const unsigned long long*) d_sorted_groups, (uint64_t) max_groups, d_ctl + 2 + a);
          LDB_HIP(hipGetLastError());
       } else {
          LdbProf prof_(ctx, "k_gb_finalize");
@@ -877,7 +879,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          for (int32_t a = 0; a < n_aggs; a++)
             if (out_valid[(size_t) a])
                hipLaunchKernelGGL(k_pack_valid_bytes, dim3(ldb_grid_for(ctx, (int64_t) max_groups, 256 * 8, 4)), dim3(256), 0, ctx->stream, out_valid[(size_t) a], bitmaps[(size_t) a],
-                                  (const unsigned long long*) (d_ctl + 1), d_ctl + 2 + a);
+                                  (const unsigned long long*) (d_ctl + 1), (uint64_t) max_groups, d_ctl + 2 + a);
          LDB_HIP(hipGetLastError());
          ldb_dev_free(ctx, pop);
          ldb_dev_free(ctx, off);

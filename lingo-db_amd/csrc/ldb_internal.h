@@ -121,7 +121,11 @@ constexpr uint32_t ldb_site_hash(const char* f, int line) {
 }
 // (the call site's file:line is remembered under its hash, so that a mismatching replayed value can be named: LDB_HOST_TRACE)
 uint32_t ldb_site_note(uint32_t hash, const char* file, int line);
-#define LDB_SITE (ldb_site_note(ldb_site_hash(__FILE__, __LINE__), __FILE__, __LINE__))
+// registered ONCE per call site (a function-local static inside an immediately-invoked lambda): the hot host path of a replayed plan evaluates
+// LDB_SITE at every read-back and must not take a process-wide mutex there
+#define LDB_SITE ([]() -> uint32_t { static const uint32_t site_ = ldb_site_note(ldb_site_hash(__FILE__, __LINE__), __FILE__, __LINE__); return site_; }())
+// a site derived from another (the scan's per-size sites): registered under the base site's name + the salt, for the mismatch diagnostic
+uint32_t ldb_site_derived(uint32_t base, uint32_t salt);
 struct ldb_ctx;
 // read `bytes` of device memory into `host` (see above); flags: LDB_RB_NEVER_REPLAY for values that may differ between two
 // executions over the same data (flags raised by races between insertions) — those always synchronise

@@ -35,3 +35,5 @@ hipFunction_t ldb_jit_groupby_kernel(int device, const DGroupBy* h, const char* 
 
 // statistics for tests / bench: kernels compiled, cache hits, total compile milliseconds
 extern "C" int32_t ldb_gpu_jit_stats(int64_t* compiled, int64_t* cache_hits, double* compile_ms);
+extern "C" int32_t ldb_gpu_jit_wait(int64_t timeout_ms, int64_t* pending);
+extern "C" int32_t ldb_gpu_jit_info(int64_t* vals, int32_t n);

@@ -1,10 +1,17 @@
 // ldb_jit.hip — run-time kernel specialisation with hiprtc (see ldb_jit.h).
 #include "ldb_jit.h"
 #include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <cerrno>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
+#include <deque>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 
 // the kernel headers, embedded at build time (Makefile → ldb_jit_sources.inc)
@@ -17,16 +24,32 @@ static const EmbeddedHeader g_headers[] = {
 };
 static const int g_n_headers = (int) (sizeof(g_headers) / sizeof(g_headers[0]));
 
+// One entry per (device, key).  A specialisation is COMPILED on a worker thread (hiprtc takes 0.3 – 3 s per kernel; the reference answers the same
+// problem with a baseline backend that emits code in milliseconds and an optimising one behind it, include/lingodb/execution/Execution.h:103-104): the
+// operator that asked launches its generic ahead-of-time kernel meanwhile and picks the specialised one up on a later call.  Code objects are kept
+// on disk under a content hash, so a second process start compiles nothing.
 struct JitModule {
-   std::string key; // header | struct | kernel source | metadata bytes
+   std::string key; // device | arch | header | struct | kernel source | metadata bytes
+   enum State { PENDING, CODE_READY, LOADED, FAILED };
+   State state = PENDING;
+   int device = 0;
    hipModule_t module = nullptr;
    std::unordered_map<std::string, hipFunction_t> fns;
    std::vector<char> code;
-   std::string error; // non-empty: compilation failed once, do not retry
+   std::string error; // FAILED: compilation failed once, do not retry
+   bool from_disk = false;
+};
+struct JitJob {
+   JitModule* mod;
+   std::string src, arch, disk_path, dump_name;
 };
 static std::mutex g_mu;
+static std::condition_variable g_cv; // an entry left PENDING / the queue changed
 static std::unordered_map<uint64_t, std::vector<std::unique_ptr<JitModule>>> g_cache;
-static int64_t g_compiled = 0, g_hits = 0;
+static std::deque<JitJob> g_queue;
+static int g_workers = 0, g_running = 0;
+static bool g_stop = false;
+static int64_t g_compiled = 0, g_hits = 0, g_disk_hits = 0, g_disk_writes = 0, g_failed = 0, g_async_misses = 0;
 static double g_compile_ms = 0;
 
 bool ldb_jit_wanted(int64_t n_rows) { return ldb_option("jit", 1) != 0 && n_rows >= ldb_option("jit_min_rows", 4000000); }
@@ -130,9 +153,9 @@ static bool compile(const std::string& src, std::vector<char>* code, std::string
    hiprtcGetCode(prog, code->data());
    hiprtcDestroyProgram(&prog);
    if (const char* dir = getenv("LDB_JIT_DUMP_ALL")) { // every code object, numbered (offline ISA / register-usage inspection)
-      static int seq = 0;
+      static std::atomic<int> seq{0}; // (compilations run on several worker threads)
       char path[512];
-      snprintf(path, sizeof(path), "%s/ldb_spec_%03d.co", dir, seq++);
+      snprintf(path, sizeof(path), "%s/ldb_spec_%03d.co", dir, seq.fetch_add(1));
       if (FILE* f = fopen(path, "wb")) {
          fwrite(code->data(), 1, code->size(), f);
          fclose(f);
@@ -172,26 +195,192 @@ static std::string device_arch(int device) {
    return a;
 }
 
-hipFunction_t ldb_jit_kernel(int device, const char* header, const char* struct_name, const char* kernels_src, const char* kernel_name, const void* meta, size_t meta_bytes,
-                             std::string* why) {
-   // a module is loaded into ONE device: the cache is keyed by device too, and the load happens
-   // with that device current (a process may hold contexts on several GPUs)
-   const std::string arch = device_arch(device);
-   std::string key;
-   key.reserve(meta_bytes + 256);
-   key += std::to_string(device);
-   key += '|';
-   key += arch;
-   key += '|';
-   key += header;
-   key += '|';
-   key += struct_name;
-   key += '|';
-   key += kernels_src;
-   key += '|';
-   key.append((const char*) meta, meta_bytes);
-   const uint64_t h = hash_bytes((const unsigned char*) key.data(), key.size());
+// ---------------------------------------------------------------- on-disk cache of code objects
+// <dir>/<arch>/<hash of (arch, header name, struct, kernel source, metadata, the embedded headers' TEXT, extra defines)>.co ; `dir` = $LDB_JIT_CACHE_DIR,
+// else $HOME/.cache/ldb_jit, else /tmp/ldb_jit_<uid>; option jit_disk_cache = 0 (LDB_JIT_DISK_CACHE=0) turns it off.  Files are written to a
+// temporary name and renamed, so a reader never sees half a file; a file that does not load is removed and compiled again.
+static uint64_t headers_hash() {
+   static const uint64_t h = [] {
+      uint64_t x = 0x9E3779B97F4A7C15ull;
+      for (int i = 0; i < g_n_headers; i++) {
+         x = hash_bytes((const unsigned char*) g_headers[i].name, strlen(g_headers[i].name), x);
+         x = hash_bytes((const unsigned char*) g_headers[i].text, strlen(g_headers[i].text), x);
+      }
+      if (const char* defs = getenv("LDB_JIT_DEFINES")) x = hash_bytes((const unsigned char*) defs, strlen(defs), x);
+      return x;
+   }();
+   return h;
+}
+static std::string cache_dir() {
+   if (ldb_option("jit_disk_cache", 1) == 0) return "";
+   if (const char* d = getenv("LDB_JIT_CACHE_DIR")) return *d ? std::string(d) : std::string();
+   if (const char* home = getenv("HOME"))
+      if (*home) return std::string(home) + "/.cache/ldb_jit";
+   return "/tmp/ldb_jit_" + std::to_string((unsigned) getuid());
+}
+static bool make_dirs(const std::string& path) {
+   for (size_t i = 1; i <= path.size(); i++)
+      if (i == path.size() || path[i] == '/') {
+         const std::string sub = path.substr(0, i);
+         if (mkdir(sub.c_str(), 0755) != 0 && errno != EEXIST) return false;
+      }
+   return true;
+}
+static std::string disk_path_for(const std::string& arch, const std::string& key_nodev) {
+   const std::string dir = cache_dir();
+   if (dir.empty()) return "";
+   std::string a = arch;
+   for (char& c : a)
+      if (!(isalnum((unsigned char) c) || c == '+' || c == '-')) c = '_';
+   const uint64_t h1 = hash_bytes((const unsigned char*) key_nodev.data(), key_nodev.size(), headers_hash());
+   const uint64_t h2 = hash_bytes((const unsigned char*) key_nodev.data(), key_nodev.size(), headers_hash() ^ 0xD6E8FEB86659FD93ull);
+   char name[64];
+   snprintf(name, sizeof(name), "%016llx%016llx.co", (unsigned long long) h1, (unsigned long long) h2);
+   return dir + "/" + a + "/" + name;
+}
+static bool disk_read(const std::string& path, std::vector<char>* code) {
+   if (path.empty()) return false;
+   FILE* f = fopen(path.c_str(), "rb");
+   if (!f) return false;
+   bool ok = false;
+   if (fseek(f, 0, SEEK_END) == 0) {
+      const long n = ftell(f);
+      if (n > 64 && n < (64l << 20) && fseek(f, 0, SEEK_SET) == 0) {
+         code->resize((size_t) n);
+         ok = fread(code->data(), 1, (size_t) n, f) == (size_t) n && memcmp(code->data(), "\x7f" "ELF", 4) == 0;
+      }
+   }
+   fclose(f);
+   if (!ok) code->clear();
+   return ok;
+}
+static bool disk_write(const std::string& path, const std::vector<char>& code) {
+   if (path.empty()) return false;
+   const size_t slash = path.rfind('/');
+   if (slash == std::string::npos || !make_dirs(path.substr(0, slash))) return false;
+   char suffix[64];
+   snprintf(suffix, sizeof(suffix), ".tmp.%d.%llx", (int) getpid(), (unsigned long long) std::hash<std::thread::id>()(std::this_thread::get_id()));
+   const std::string tmp = path + suffix;
+   FILE* f = fopen(tmp.c_str(), "wb");
+   if (!f) return false;
+   const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+   if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) {
+      unlink(tmp.c_str());
+      return false;
+   }
+   return true;
+}
+
+// ---------------------------------------------------------------- compile workers
+static void stop_workers();
+static void run_job(JitJob& job) {
+   auto t0 = std::chrono::steady_clock::now();
+   std::vector<char> code;
+   std::string err;
+   const bool ok = compile(job.src, &code, &err, job.arch.c_str());
+   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+   bool wrote = false;
+   if (ok) {
+      wrote = disk_write(job.disk_path, code);
+      if (const char* dir = getenv("LDB_JIT_DUMP_DIR")) { // code objects for llvm-objdump inspection
+         const std::string path = std::string(dir) + "/" + job.dump_name + ".co";
+         if (FILE* f = fopen(path.c_str(), "wb")) {
+            fwrite(code.data(), 1, code.size(), f);
+            fclose(f);
+         }
+      }
+   }
+   atexit(stop_workers); // (see stop_workers: ahead of the statics this compilation created)
    std::lock_guard<std::mutex> lock(g_mu);
+   g_compile_ms += ms;
+   if (ok) {
+      job.mod->code = std::move(code);
+      job.mod->state = JitModule::CODE_READY;
+      g_disk_writes += wrote ? 1 : 0;
+   } else {
+      job.mod->error = err;
+      job.mod->state = JitModule::FAILED;
+      g_failed++;
+   }
+}
+static void worker_main() {
+   std::unique_lock<std::mutex> lock(g_mu);
+   for (;;) {
+      g_cv.wait(lock, [] { return g_stop || !g_queue.empty(); });
+      if (g_stop) break;
+      JitJob job = std::move(g_queue.front());
+      g_queue.pop_front();
+      g_running++;
+      lock.unlock();
+      run_job(job);
+      lock.lock();
+      g_running--;
+      g_cv.notify_all();
+   }
+   g_workers--;
+   g_cv.notify_all();
+}
+// at process exit: queued jobs are dropped, running compilations finish (hiprtc must not be torn down under a worker).  Exit handlers run in
+// reverse order of registration and hiprtc / LLVM create statics lazily DURING compilations, so the handler is registered again after every finished
+// compilation (it is idempotent): it then runs before the destructors of everything the finished compilations created.  Hosts that can should call
+// ldb_gpu_jit_shutdown() themselves before they exit (the Python binding does, from `atexit`).
+static void stop_workers() {
+   std::unique_lock<std::mutex> lock(g_mu);
+   g_stop = true;
+   g_queue.clear();
+   g_cv.notify_all();
+   g_cv.wait_for(lock, std::chrono::seconds(60), [] { return g_workers == 0; });
+}
+extern "C" int32_t ldb_gpu_jit_shutdown(void) {
+   stop_workers();
+   return LDB_OK;
+}
+static void ensure_workers_locked() {
+   if (g_workers > 0 || g_stop) return;
+   atexit(stop_workers);
+   int64_t n = ldb_option("jit_threads", 0);
+   if (n <= 0) n = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t) std::thread::hardware_concurrency() / 2));
+   for (int64_t i = 0; i < n; i++) {
+      g_workers++;
+      std::thread(worker_main).detach();
+   }
+}
+
+// load a CODE_READY entry into its device (the calling thread; g_mu held)
+static void load_locked(JitModule* mod) {
+   int prev = -1;
+   (void) hipGetDevice(&prev);
+   (void) hipSetDevice(mod->device);
+   const hipError_t le = hipModuleLoadData(&mod->module, mod->code.data());
+   if (prev >= 0 && prev != mod->device) (void) hipSetDevice(prev);
+   if (le != hipSuccess) {
+      mod->error = "hipModuleLoadData failed for the specialised kernel";
+      mod->module = nullptr;
+      mod->state = JitModule::FAILED;
+      g_failed++;
+   } else {
+      mod->state = JitModule::LOADED;
+      if (!mod->from_disk) g_compiled++;
+   }
+}
+
+// the entry for (device, header, struct, kernels, meta): LOADED into `device` (load = true) or at least CODE_READY (load = false: the device-less
+// self-test), or nullptr with *why — also while the compilation is still running and the caller does not want to wait (async)
+static JitModule* jit_acquire(std::unique_lock<std::mutex>& lock, int device, const std::string& arch, const char* header, const char* struct_name, const char* kernels_src,
+                              const char* kernel_name, const void* meta, size_t meta_bytes, bool async, bool load, std::string* why) {
+   std::string key_nodev;
+   key_nodev.reserve(meta_bytes + 256);
+   key_nodev += arch;
+   key_nodev += '|';
+   key_nodev += header;
+   key_nodev += '|';
+   key_nodev += struct_name;
+   key_nodev += '|';
+   key_nodev += kernels_src;
+   key_nodev += '|';
+   key_nodev.append((const char*) meta, meta_bytes);
+   const std::string key = std::to_string(device) + "|" + key_nodev;
+   const uint64_t h = hash_bytes((const unsigned char*) key.data(), key.size());
    auto& bucket = g_cache[h];
    JitModule* mod = nullptr;
    for (auto& e : bucket)
@@ -199,48 +388,79 @@ hipFunction_t ldb_jit_kernel(int device, const char* header, const char* struct_
    if (!mod) {
       auto e = std::make_unique<JitModule>();
       e->key = key;
-      auto t0 = std::chrono::steady_clock::now();
-      const std::string src = build_source(header, struct_name, kernels_src, (const unsigned char*) meta, meta_bytes);
-      if (const char* dir = getenv("LDB_JIT_DUMP_DIR")) { // the specialised translation unit, for offline ISA inspection
-         char path[512];
-         snprintf(path, sizeof(path), "%s/%s_%016llx.hip", dir, kernel_name, (unsigned long long) h);
-         if (FILE* f = fopen(path, "wb")) {
-            fwrite(src.data(), 1, src.size(), f);
-            fclose(f);
+      e->device = device;
+      bucket.push_back(std::move(e));
+      mod = bucket.back().get();
+      const std::string path = disk_path_for(arch, key_nodev);
+      if (disk_read(path, &mod->code)) { // compiled by an earlier process (or for another device of this one)
+         mod->from_disk = true;
+         mod->state = JitModule::CODE_READY;
+         if (load) load_locked(mod);
+         if (mod->state != JitModule::FAILED) {
+            g_disk_hits++;
+         } else { // a damaged file: forget it and compile
+            unlink(path.c_str());
+            mod->from_disk = false;
+            mod->error.clear();
+            mod->code.clear();
+            mod->state = JitModule::PENDING;
+            g_failed--;
          }
       }
-      bool ok = compile(src, &e->code, &e->error, arch.c_str());
-      g_compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      if (ok) {
-         if (const char* dir = getenv("LDB_JIT_DUMP_DIR")) { // code objects for llvm-objdump inspection
-            char path[512];
-            snprintf(path, sizeof(path), "%s/%s_%016llx.co", dir, kernel_name, (unsigned long long) h);
-            if (FILE* f = fopen(path, "wb")) {
-               fwrite(e->code.data(), 1, e->code.size(), f);
+      if (mod->state == JitModule::PENDING) {
+         JitJob job;
+         job.mod = mod;
+         job.arch = arch;
+         job.disk_path = path;
+         job.src = build_source(header, struct_name, kernels_src, (const unsigned char*) meta, meta_bytes);
+         char dump[160];
+         snprintf(dump, sizeof(dump), "%s_%016llx", kernel_name, (unsigned long long) h);
+         job.dump_name = dump;
+         if (const char* dir = getenv("LDB_JIT_DUMP_DIR")) { // the specialised translation unit, for offline ISA inspection
+            const std::string p = std::string(dir) + "/" + dump + ".hip";
+            if (FILE* f = fopen(p.c_str(), "wb")) {
+               fwrite(job.src.data(), 1, job.src.size(), f);
                fclose(f);
             }
          }
-         int prev = -1;
-         (void) hipGetDevice(&prev);
-         (void) hipSetDevice(device);
-         const hipError_t le = hipModuleLoadData(&e->module, e->code.data());
-         if (prev >= 0 && prev != device) (void) hipSetDevice(prev);
-         if (le != hipSuccess) {
-            e->error = "hipModuleLoadData failed for the specialised kernel";
-            e->module = nullptr;
-         } else {
-            g_compiled++;
+         ensure_workers_locked();
+         if (g_workers > 0) {
+            g_queue.push_back(std::move(job));
+            g_cv.notify_all();
+         } else { // (no worker could be started: compile here)
+            lock.unlock();
+            run_job(job);
+            lock.lock();
          }
       }
-      bucket.push_back(std::move(e));
-      mod = bucket.back().get();
-   } else if (mod->module) {
+   } else if (mod->state == JitModule::LOADED) {
       g_hits++;
    }
-   if (!mod->module) {
+   if (mod->state == JitModule::PENDING) {
+      if (async) { // the caller launches its generic kernel now and finds the specialised one on a later call
+         g_async_misses++;
+         if (why) *why = "the specialised kernel is being compiled in the background";
+         return nullptr;
+      }
+      g_cv.wait(lock, [&] { return mod->state != JitModule::PENDING; });
+   }
+   if (mod->state == JitModule::CODE_READY && load) load_locked(mod);
+   if (mod->state == JitModule::FAILED) {
       if (why) *why = mod->error;
       return nullptr;
    }
+   return mod;
+}
+
+hipFunction_t ldb_jit_kernel(int device, const char* header, const char* struct_name, const char* kernels_src, const char* kernel_name, const void* meta, size_t meta_bytes,
+                             std::string* why) {
+   // a module is loaded into ONE device: the cache is keyed by device too, and the load happens
+   // with that device current (a process may hold contexts on several GPUs)
+   const std::string arch = device_arch(device);
+   const bool async = ldb_option("jit_async", 1) != 0;
+   std::unique_lock<std::mutex> lock(g_mu);
+   JitModule* mod = jit_acquire(lock, device, arch, header, struct_name, kernels_src, kernel_name, meta, meta_bytes, async, true, why);
+   if (!mod) return nullptr;
    auto it = mod->fns.find(kernel_name);
    if (it != mod->fns.end()) return it->second;
    hipFunction_t fn = nullptr;
@@ -250,6 +470,27 @@ hipFunction_t ldb_jit_kernel(int device, const char* header, const char* struct_
    }
    mod->fns[kernel_name] = fn;
    return fn;
+}
+
+// block until no specialisation is queued or compiling (or `timeout_ms` passed; < 0 = no limit).  *pending = what is still outstanding
+extern "C" int32_t ldb_gpu_jit_wait(int64_t timeout_ms, int64_t* pending) {
+   std::unique_lock<std::mutex> lock(g_mu);
+   auto idle = [] { return g_queue.empty() && g_running == 0; };
+   if (timeout_ms < 0)
+      g_cv.wait(lock, idle);
+   else
+      g_cv.wait_for(lock, std::chrono::milliseconds(timeout_ms), idle);
+   if (pending) *pending = (int64_t) g_queue.size() + g_running;
+   return LDB_OK;
+}
+// vals[0..n): kernels compiled in this process, in-memory hits, code objects taken from the disk cache, written to it, compilations outstanding,
+// failed, calls answered "still compiling" (the caller ran its generic kernel), worker threads
+extern "C" int32_t ldb_gpu_jit_info(int64_t* vals, int32_t n) {
+   if (!vals || n < 0) LDB_FAIL(LDB_ERR_INVALID, "jit_info: NULL argument");
+   std::lock_guard<std::mutex> lock(g_mu);
+   const int64_t all[8] = {g_compiled, g_hits, g_disk_hits, g_disk_writes, (int64_t) g_queue.size() + g_running, g_failed, g_async_misses, (int64_t) g_workers};
+   for (int32_t i = 0; i < n; i++) vals[i] = i < 8 ? all[i] : 0;
+   return LDB_OK;
 }
 
 // ---------------------------------------------------------------- group-by
@@ -374,9 +615,69 @@ extern "C" int32_t ldb_gpu_jit_compile_check(char* log, int32_t cap) {
    return ok ? LDB_OK : LDB_ERR_HIP;
 }
 
+// Device-less self-test of the specialiser's plumbing (CPU test suite): a TPC-H-Q6-shaped scan-free group-by descriptor is requested
+// asynchronously (the first answer must be "still compiling"), awaited, found on disk under `cache_dir`, forgotten, and requested again — the second
+// answer must come from the disk cache without a compilation.  Nothing is loaded into a device.
+extern "C" int32_t ldb_gpu_jit_cache_selftest(char* log, int32_t cap) {
+   auto say = [&](const std::string& m) {
+      if (log && cap > 0) snprintf(log, (size_t) cap, "%s", m.c_str());
+      return LDB_ERR_HIP;
+   };
+   if (cache_dir().empty()) return say("the disk cache is disabled");
+   auto h = std::make_unique<DGroupBy>();
+   memset(h.get(), 0, sizeof(DGroupBy));
+   h->n_cols = 1;
+   h->cols[0].type = LDB_T_DECIMAL128;
+   h->cols[0].width = 16;
+   h->cols[0].precision = 12;
+   h->cols[0].scale = 2;
+   h->n_accs = 1;
+   h->accs[0].kind = ACC_SUM64;
+   h->accs[0].e.n_terms = 1;
+   h->accs[0].e.t[0].n_factors = 1;
+   h->accs[0].e.t[0].f[0] = {1, 0, 0, 1};
+   h->n_words = 1;
+   h->use_lds = 1;
+   auto meta = std::make_unique<DGroupBy>();
+   gb_meta(h.get(), meta.get());
+   meta->n_preds = 0;
+   const std::string arch = "gfx950";
+   const int device = -1; // an entry of its own: never loaded
+   int64_t before[8], after[8];
+   ldb_gpu_jit_info(before, 8);
+   {
+      std::unique_lock<std::mutex> lock(g_mu);
+      std::string why;
+      JitModule* m = jit_acquire(lock, device, arch, "ldb_gb_kernel.h", "DGroupBy", GB_SPEC_SRC, "k_groupby_spec", meta.get(), sizeof(DGroupBy), true, false, &why);
+      if (m && !m->from_disk) return say("the first asynchronous request returned a module at once");
+      if (m) return say("cache directory not empty for this key: use a fresh LDB_JIT_CACHE_DIR");
+   }
+   int64_t pending = -1;
+   ldb_gpu_jit_wait(120000, &pending);
+   if (pending != 0) return say("compilation still outstanding after 120 s");
+   {
+      std::unique_lock<std::mutex> lock(g_mu);
+      std::string why;
+      JitModule* m = jit_acquire(lock, device, arch, "ldb_gb_kernel.h", "DGroupBy", GB_SPEC_SRC, "k_groupby_spec", meta.get(), sizeof(DGroupBy), true, false, &why);
+      if (!m || m->state != JitModule::CODE_READY || m->code.empty()) return say("no code object after the wait: " + why);
+      // forget the entry: the next request must be answered from the disk
+      for (auto& kv : g_cache)
+         for (size_t i = 0; i < kv.second.size(); i++)
+            if (kv.second[i].get() == m) {
+               kv.second.erase(kv.second.begin() + (long) i);
+               break;
+            }
+      JitModule* again = jit_acquire(lock, device, arch, "ldb_gb_kernel.h", "DGroupBy", GB_SPEC_SRC, "k_groupby_spec", meta.get(), sizeof(DGroupBy), true, false, &why);
+      if (!again || !again->from_disk || again->code.empty()) return say("the second request was not answered from the disk cache: " + why);
+   }
+   ldb_gpu_jit_info(after, 8);
+   if (after[2] != before[2] + 1 || after[3] != before[3] + 1 || after[6] != before[6] + 1) return say("statistics do not show one disk write, one disk hit and one asynchronous miss");
+   return LDB_OK;
+}
+
 extern "C" int32_t ldb_gpu_jit_stats(int64_t* compiled, int64_t* cache_hits, double* compile_ms) {
    std::lock_guard<std::mutex> lock(g_mu);
-   if (compiled) *compiled = g_compiled;
+   if (compiled) *compiled = g_compiled + g_disk_hits; // (modules made available to this process: compiled here or taken from the disk cache)
    if (cache_hits) *cache_hits = g_hits;
    if (compile_ms) *compile_ms = g_compile_ms;
    return LDB_OK;

@@ -191,7 +191,7 @@ static int32_t scan_run_with(ldb_ctx* ctx, int64_t n, LAUNCH launch, uint32_t** 
    // predicate whose code set is cached by then — must not hand ITS count to the next scan of the plan; a different identity makes the replay
    // see that the execution took another path, check what it replayed and record from there, instead of replaying a wrong count and losing
    // the whole execution at the final comparison: 7 of the 22 queries paid that once during warm-up)
-   LDB_TRY(ldb_read_u64_at(ctx, d_total, &total, LDB_SITE ^ ((uint32_t) n * 2654435761u), 0));
+   LDB_TRY(ldb_read_u64_at(ctx, d_total, &total, ldb_site_derived(LDB_SITE, (uint32_t) n), 0));
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &sel, sizeof(uint32_t) * (size_t) (total ? total : 1)));
    if (total) hipLaunchKernelGGL(k_scan_expand, dim3((unsigned) n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, bitmap, offsets, sel, (uint64_t) n, total);
    LDB_HIP(hipGetLastError());

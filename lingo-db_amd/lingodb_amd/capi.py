@@ -174,6 +174,10 @@ GPU_API = {
     "ldb_gpu_prof_names": (i32, [P, C.c_char_p, i32]),
     "ldb_gpu_jit_stats": (i32, [C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),
     "ldb_gpu_jit_compile_check": (i32, [C.c_char_p, i32]),
+    "ldb_gpu_jit_wait": (i32, [i64, C.POINTER(i64)]),
+    "ldb_gpu_jit_info": (i32, [C.POINTER(i64), i32]),
+    "ldb_gpu_jit_shutdown": (i32, []),
+    "ldb_gpu_jit_cache_selftest": (i32, [C.c_char_p, i32]),
     "ldb_gpu_set_option": (i32, [C.c_char_p, i64]),
     "ldb_gpu_get_option": (i64, [C.c_char_p]),
     "ldb_gpu_table_register": (i32, [P, C.c_char_p, C.POINTER(ArrowSchema), C.POINTER(C.POINTER(ArrowArray)), i64, i32, PP]),
@@ -301,6 +305,9 @@ def gpu_lib():
         if not os.path.exists(GPU_LIB_PATH):
             raise LibraryMissing(f"{GPU_LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'` " "(there is no CPU fallback)")
         _gpu = _bind(C.CDLL(GPU_LIB_PATH, mode=C.RTLD_GLOBAL), GPU_API)
+        import atexit
+
+        atexit.register(_gpu.ldb_gpu_jit_shutdown)  # compile workers stop before the interpreter (and hiprtc's statics) go away
     return _gpu
 
 

@@ -16,6 +16,10 @@ SPEC_MODULES = {"test_gpu_parity", "test_gpu_joins_more", "test_gpu_tpch_more", 
                 "test_gpu_new_ops"}
 
 
+# GPU suite: specialisations compile synchronously, so that the 'spec' passes below launch the specialised kernels on their FIRST call (the library
+# default — jit_async = 1 — answers "still compiling" and launches the generic kernel; tests/test_gpu_jit_async.py covers that mode)
+os.environ.setdefault("LDB_JIT_ASYNC", "0")
+
 try:  # torch first: it ships its own HIP runtime / RCCL copies, which must be the ones the process binds (see api.Comm)
     import torch  # noqa: F401
 except ImportError:

@@ -146,6 +146,30 @@ def main():
         # the victim's own miss — on the other ranks the repeat a peer's miss forces — and exactly one of them; the repeated execution and the
         # next (replaying the new record) return the new answer
         div_ok = div_ok and after == expect(victim) and again == expect(victim) and st_div["misses"] == 1 and plan.stats()["misses"] == 1
+        # a divergence that also leaves the recorded SEQUENCE of read-backs: no row of the victim passes the filter any more, so its
+        # operators take their empty-input paths; it must still meet every exchange of the plan (a rank that stopped at the first unexpected
+        # read-back would leave its peers waiting inside the shuffle), and every rank repeats
+        if rank == victim:
+            none = ctx.register("div_none_%d" % rank, pa.table({"x": pa.array(np.full(len(x0), 999, dtype=np.int32), pa.int32())}))
+            dst, _, _, nbytes = tt.col_ptrs(0)
+            src, _, _, _ = none.col_ptrs(0)
+            api.check(ctx.lib.ldb_gpu_memcpy_d2d(ctx.h, dst, src, nbytes))
+            ctx.sync()
+
+        def expect_empty_victim():
+            n = s_ = 0
+            for r in range(world):
+                if r == victim:
+                    continue
+                sel = np.nonzero(piece(r, False) < 500)[0]
+                n += len(sel)
+                s_ += int((sel + r * 1_000_000).sum())
+            return n, s_
+
+        empty1 = total()
+        st_empty = plan.stats()
+        empty2 = total()
+        div_ok = div_ok and empty1 == expect_empty_victim() and empty2 == expect_empty_victim() and st_empty["misses"] == 2 and plan.stats()["misses"] == 2
         flags = ctx.register("divok_%d" % rank, pa.table({"ok": pa.array([1 if div_ok else 0], pa.int32())}))
         all_ok = comm.allgather(flags, "divok_all").to_arrow().column(0).to_pylist()
         if rank == 0:

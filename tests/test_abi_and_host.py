@@ -173,3 +173,31 @@ def test_like_planner_classifies_patterns():
         assert plan(general)[0] == 0, general
     n = C.c_int32()
     assert lib.ldb_gpu_like_plan(b"x" * 49, 49, C.byref(n), None, None) != 0  # longer than the descriptor's inline constant
+
+
+def test_jit_compiles_in_the_background_and_caches_code_objects_on_disk(tmp_path):
+    """round 6 (verdict r5 #4): a specialisation is compiled on a worker thread — the first request is answered "still compiling" (the operator
+    launches its generic kernel), ldb_gpu_jit_wait drains the queue — and the code object is kept on disk under a content hash, so the same
+    request in a fresh cache state is answered from the file without hiprtc.  Device-less (hiprtc cross-compiles for gfx950); run in a child
+    process so that LDB_JIT_CACHE_DIR is this test's own directory"""
+    import subprocess
+    import sys
+
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from lingodb_amd import capi; lib = capi.gpu_lib(); buf = C.create_string_buffer(4000);"
+            "st = lib.ldb_gpu_jit_cache_selftest(buf, 4000); v = (C.c_int64 * 8)(); lib.ldb_gpu_jit_info(v, 8); print(st, list(v), buf.value.decode())") % os.path.join(ROOT, "lingo-db_amd")
+    env = dict(os.environ, LDB_JIT_CACHE_DIR=str(tmp_path / "jit"), LDB_JIT_ASYNC="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("0 "), r.stdout + r.stderr
+    files = [os.path.join(d, f) for d, _, fs in os.walk(str(tmp_path / "jit")) for f in fs]
+    assert len(files) == 1 and files[0].endswith(".co") and "gfx950" in files[0] and os.path.getsize(files[0]) > 1000
+    with open(files[0], "rb") as f:
+        assert f.read(4) == b"\x7fELF"
+    # a second process: the same request is a disk hit at once (the self-test then reports a non-empty cache for its key)
+    r2 = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0 and "cache directory not empty" in r2.stdout, r2.stdout + r2.stderr
+    info = eval(r2.stdout.split(" ", 1)[1].split("]")[0] + "]")
+    assert info[2] == 1 and info[0] == 0 and info[3] == 0, info  # one disk hit, nothing compiled, nothing written
+    # with the disk cache off nothing is written
+    env3 = dict(env, LDB_JIT_CACHE_DIR=str(tmp_path / "off"), LDB_JIT_DISK_CACHE="0")
+    r3 = subprocess.run([sys.executable, "-c", code], env=env3, capture_output=True, text=True, timeout=600)
+    assert r3.returncode == 0 and "disk cache is disabled" in r3.stdout and not os.path.exists(str(tmp_path / "off")), r3.stdout + r3.stderr
