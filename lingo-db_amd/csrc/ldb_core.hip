@@ -42,7 +42,7 @@ int64_t ldb_option(const char* name, int64_t dflt) {
 }
 extern "C" int32_t ldb_gpu_set_option(const char* name, int64_t value) {
    if (!name) LDB_FAIL(LDB_ERR_INVALID, "set_option: NULL name");
-   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass", "lazy_strings", "lazy_strings_min_rows", "gb_partition_wc", "join_radix_wc", "join_radix_lds", "gb_dense_out", "gb_partition_values", "join_pair32", "gb_dense_keys", "jit_async", "jit_threads", "jit_disk_cache"};
+   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass", "lazy_strings", "lazy_strings_min_rows", "gb_partition_wc", "join_radix_wc", "join_radix_lds", "gb_dense_out", "gb_partition_values", "join_pair32", "gb_dense_keys", "jit_async", "jit_threads", "jit_disk_cache", "join_all_match"};
    bool ok = false;
    for (const char* k : known) ok |= strcmp(k, name) == 0;
    if (!ok) LDB_FAIL(LDB_ERR_INVALID, "set_option: unknown option '%s'", name);
@@ -125,6 +125,13 @@ void ldb_dev_free(ldb_ctx* ctx, void* p) {
       if (dref->second > 0) dref->second--;
       return;
    }
+   if (!ctx->shared.empty()) {
+      auto sh = ctx->shared.find(p);
+      if (sh != ctx->shared.end()) { // another relation still reads this vector
+         if (--sh->second == 0) ctx->shared.erase(sh);
+         return;
+      }
+   }
    auto it = ctx->live.find(p);
    if (it == ctx->live.end()) {
       LdbSlow slow_("hipFreeAsync (untracked block)");
@@ -142,6 +149,9 @@ void ldb_dev_free(ldb_ctx* ctx, void* p) {
       LdbSlow slow_("hipFreeAsync (cache full)", cls);
       (void) hipFreeAsync(p, ctx->stream);
    }
+}
+void ldb_dev_share(ldb_ctx* ctx, void* p) {
+   if (p) ctx->shared[p]++;
 }
 // Descriptor cache.  A plan that runs again builds byte-identical descriptors (same operators over the same buffers: the
 // block cache above hands out the same addresses), so the device copy made by the previous execution can be used as it is:
@@ -1455,6 +1465,22 @@ void ldb_like_plan(DPred* d) {
    }
    if (nseg == 0) return; // "", "%", "%%": the general matcher decides at once
    for (int j = 0; j < 2 * nseg; j++) d->in_off[j] = off[j];
+   // in_hi[j] = offset of segment j's RAREST byte (the position-parallel matcher tests that byte first, d_like_simple_wave): letters by their
+   // frequency rank in English text, everything that is not a lower-case letter or a blank counts as rarer than any letter
+   static const char* by_frequency = "etaoinsrhldcumfpgwybvkxjqz";
+   for (int j = 0; j < nseg; j++) {
+      int best = 0, best_score = -2;
+      for (int k = 0; k < off[2 * j + 1]; k++) {
+         const char c = d->str[off[2 * j] + k];
+         const char* at = c ? strchr(by_frequency, c) : nullptr;
+         const int score = c == ' ' ? -1 : at ? (int) (at - by_frequency) : 30;
+         if (score > best_score) {
+            best_score = score;
+            best = k;
+         }
+      }
+      d->in_hi[j] = best;
+   }
    d->n_in = nseg;
    d->lo = (d->str[0] != '%' ? 1u : 0u) | (d->str[n - 1] != '%' ? 2u : 0u);
 }

@@ -507,8 +507,20 @@ __device__ __forceinline__ bool d_like_simple_wave(const DPred& m, uint8_t* stag
          const int len = m.in_off[2 * j + 1];
          d_like_seg_words(m.str, m.in_off[2 * j], len, pat, msk);
          uint32_t found = 0;
-#pragma unroll
-         for (int o = 0; o < 8; o++) {
+         // Fewer compares per byte (round 6): the eight start positions of this block are first tested on ONE byte of the segment — its rarest
+         // (host: ldb_like_plan puts the offset into in_hi[j]; 'q' of "requests", 'p' of "special") — with one SWAR byte compare over the
+         // 8-byte window those bytes lie in; only the surviving positions (a fraction of a position per block on English text) get the full
+         // masked 16-byte compare.  Before, all eight shifted windows were compared in full for every segment: ~13 instructions per byte.
+         const int r = (int) m.in_hi[j];
+         const int rs = r & 7;
+         const uint64_t rlo = (r >> 3) ? w1 : w0, rhi = (r >> 3) ? w2 : w1;
+         const uint64_t rw = rs ? (rlo >> (8 * rs)) | (rhi << (64 - 8 * rs)) : rlo; // byte k = text byte 8b + k + r
+         const uint64_t x = rw ^ (0x0101010101010101ull * (uint64_t) (uint8_t) m.str[m.in_off[2 * j] + r]);
+         const uint64_t t = ((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x; // byte of t has its top bit clear ⇔ byte of x is zero
+         uint64_t cand = ~t & 0x8080808080808080ull;
+         while (cand) {
+            const uint32_t o = (uint32_t) __builtin_ctzll(cand) >> 3;
+            cand &= cand - 1;
             const uint64_t x0 = o ? (w0 >> (8 * o)) | (w1 << (64 - 8 * o)) : w0;
             bool eq = (x0 & msk[0]) == pat[0];
             if (len > 8) {

@@ -164,6 +164,7 @@ struct ldb_ctx {
    };
    std::unordered_multimap<uint64_t, DescEntry> desc_cache;
    std::unordered_map<void*, int> desc_blocks; // device copy → operators holding it (ldb_dev_upload … ldb_dev_free)
+   std::unordered_map<void*, int> shared; // block → EXTRA holders beyond the first (ldb_dev_share): ldb_dev_free gives one back, the last one frees
    size_t desc_bytes = 0;
    int64_t desc_hits = 0, desc_misses = 0;
    // read-back trace (see ldb_readback)
@@ -264,6 +265,9 @@ struct LdbSlow {
 // device allocation helpers (stream-ordered pool)
 int32_t ldb_dev_alloc(ldb_ctx* ctx, void** out, size_t bytes);
 void ldb_dev_free(ldb_ctx* ctx, void* p);
+// one more holder of a read-only block (the row-id vector of a relation side carried over unchanged into the next relation): every holder calls
+// ldb_dev_free, the last call frees
+void ldb_dev_share(ldb_ctx* ctx, void* p);
 // upload a host descriptor struct into device memory (stream-ordered)
 // (read-only descriptors are cached by content, see ldb_core.hip; cacheable = false for memory a kernel will write)
 int32_t ldb_dev_upload(ldb_ctx* ctx, const void* host, size_t bytes, void** dev_out, bool cacheable = true);

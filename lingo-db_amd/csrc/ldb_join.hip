@@ -274,6 +274,19 @@ __global__ void k_iota_u32j(uint32_t* out, uint64_t n) {
    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = (uint32_t) i;
 }
 // out[j] = ids[sel[j]] with LDB_NULL_ROW passthrough
+// all-match shortcut of a replayed unique probe: match[] of a row whose bitmap bit is clear was never written
+__global__ void k_unmatched_to_zero(const uint64_t* __restrict__ bitmap, uint32_t* __restrict__ match, uint64_t n) {
+   const uint64_t n_words = (n + 63) / 64;
+   for (uint64_t w = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; w < n_words; w += (uint64_t) gridDim.x * blockDim.x) {
+      uint64_t missing = ~bitmap[w];
+      if (w == n_words - 1 && (n & 63)) missing &= (1ull << (n & 63)) - 1ull;
+      while (missing) {
+         const int b = __ffsll((unsigned long long) missing) - 1;
+         match[w * 64 + (uint64_t) b] = 0u;
+         missing &= missing - 1;
+      }
+   }
+}
 __global__ void k_compose_null(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ sel, uint32_t* __restrict__ out, uint64_t n) {
    for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
       uint32_t s = sel[i];
@@ -1191,6 +1204,39 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       }
       if (kind == LDB_JOIN_INNER) {
          LDB_TRY(ldb_read_u64(ctx, counter, &produced));
+         if (produced == (uint64_t) n && n > 0 && ldb_option("join_all_match", 1) != 0) {
+            // EVERY probe row found its partner (a foreign key probing its primary key: most joins of a TPC-H plan): the result has the probe
+            // relation's rows in the probe relation's order, so its sides carry over as they are — shared, not copied — and match[] IS the
+            // build side's selection.  No bitmap compaction, no composition of the probe sides (round 6; the reference never materialises
+            // between the operators of a pipeline either, SubOpToControlFlow.cpp:1123-1202)
+            if (ctx->trace_mode == 2 && n_words) // a replayed count: should a row be partner-less after all, its match[] word must not be garbage
+               hipLaunchKernelGGL(k_unmatched_to_zero, dim3(ldb_grid_for(ctx, (int64_t) n_words, 256, 8)), dim3(256), 0, ctx->stream, (const uint64_t*) bitmap, match, (uint64_t) n);
+            ldb_dev_free(ctx, bitmap);
+            ldb_rel* r = ldb_rel_new(ctx);
+            r->n_rows = n;
+            for (auto& s : probe->sides) {
+               ldb_rel_side ns{s.table, s.rowids, s.rowids != nullptr, s.may_null};
+               if (s.rowids) ldb_dev_share(ctx, s.rowids);
+               r->sides.push_back(ns);
+            }
+            std::vector<LdbComposeJob> bjobs;
+            bool match_taken = false;
+            for (auto& s : ht->build->sides) {
+               ldb_rel_side ns{s.table, nullptr, true, s.may_null};
+               if (!s.rowids && !match_taken) {
+                  ns.rowids = match;
+                  match_taken = true;
+               } else {
+                  LDB_TRY(ldb_dev_alloc(ctx, (void**) &ns.rowids, 4 * (size_t) n));
+                  bjobs.push_back({(const uint32_t*) s.rowids, ns.rowids, 1});
+               }
+               r->sides.push_back(ns);
+            }
+            LDB_TRY(ldb_compose_rowids(ctx, match, match, bjobs.data(), (int) bjobs.size(), (uint64_t) n));
+            if (!match_taken) ldb_dev_free(ctx, match);
+            *out = r;
+            return LDB_OK;
+         }
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &op, 4 * (size_t) (produced ? produced : 1)));
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &ob, 4 * (size_t) (produced ? produced : 1)));
          // matched probe rows in ascending order + the build row of each, in one launch

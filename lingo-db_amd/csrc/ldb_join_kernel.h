@@ -394,6 +394,12 @@ __device__ __forceinline__ bool d_resid_ok(const DJoin& m, const DJoin* __restri
    return ok;
 }
 
+// existence kinds over a direct table with key bits: the bit IS the answer (round 6: Q9's 600 M l_partkey probes of the green parts' bits ran one
+// dependent chain deep — key, then bit — with the waves waiting 89 % of their cycles; the bit words now travel through the same two-deep pipeline as
+// the rank words, DProbePipe)
+__device__ __forceinline__ bool d_exists_by_bits(const DJoin& m) {
+   return m.direct == 1 && m.has_key_bits && m.n_resid == 0 && (m.kind == LDB_JOIN_SEMI || m.kind == LDB_JOIN_ANTI || m.kind == LDB_JOIN_MARK);
+}
 // direct-addressed table: resolve the batch from its table words (0 = no such key)
 template <int U, typename EMIT>
 __device__ __forceinline__ void d_direct_resolve(const DJoin& m, const DJoin* __restrict__ d, const uint64_t (&rows)[U], const bool (&live)[U], const uint32_t (&hw)[U], bool bits_only,
@@ -450,7 +456,7 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
       uint32_t hw[U];
 #pragma unroll
       for (int u = 0; u < U; u++) hw[u] = prew[u];
-      d_direct_resolve<U>(m, d, rows, live, hw, false, matches, emit);
+      d_direct_resolve<U>(m, d, rows, live, hw, d_exists_by_bits(m), matches, emit);
       return;
    }
    if (m.key32) {
@@ -690,7 +696,8 @@ __device__ __forceinline__ void d_prefetch_keys32(const DJoin* __restrict__ d, u
 #pragma unroll
    for (int u = 0; u < U; u++) {
       const uint32_t o = (uint32_t) u * 64u + lane;
-      k[u] = (uint32_t) kt[o < left32 ? o : 0u];
+      // (a probe key is read once: a non-temporal load keeps the stream from evicting the table words / key bits the L2 is there for)
+      k[u] = (uint32_t) __builtin_nontemporal_load(&kt[o < left32 ? o : 0u]);
    }
 }
 // The per-wave software pipeline of the probe loops.  A probe is the dependent chain key → table word →
@@ -716,7 +723,8 @@ struct DProbePipe {
    // (pf / pw are recomputed from the — compile-time — metadata at every use: as members they would keep the
    // struct in memory and the specialised kernel could not fold them)
    static __device__ __forceinline__ bool pf(const DJoin& m) { return d_keys_prefetchable(m); }
-   static __device__ __forceinline__ bool pw(const DJoin& m) { return d_keys_prefetchable(m) && ((m.direct == 1 && !m.has_key_bits) || (m.direct == 2 && m.rank_sorted)); }
+   static __device__ __forceinline__ bool bits(const DJoin& m) { return d_exists_by_bits(m); }
+   static __device__ __forceinline__ bool pw(const DJoin& m) { return d_keys_prefetchable(m) && ((m.direct == 1 && !m.has_key_bits) || (m.direct == 2 && m.rank_sorted) || bits(m)); }
    uint64_t stride; // rows between a wave's consecutive tiles
    uint32_t ck[U], cw[U]; // pf: keys of the tile being resolved;  pw: its table words
    uint32_t k[U]; // keys in flight (pf: of the coming tile; pw: of the tile after the coming one once its step ran)
@@ -737,6 +745,7 @@ struct DProbePipe {
       for (int u = 0; u < U; u++) {
          const uint32_t r = off[set][u] == 0xFFFFFFFFu ? 0u : off[set][u];
          if (m.direct == 2) w[set][u] = gptr<uint64_t>(d->slots)[r >> 5];
+         else if (bits(m)) w[set][u] = (uint64_t) gptr<uint32_t>(d->key_bits)[r >> 5];
          else w[set][u] = (uint64_t) gptr<uint32_t>(d->slots)[r];
       }
    }
@@ -771,6 +780,7 @@ struct DProbePipe {
 #pragma unroll
          for (int u = 0; u < U; u++) { // → build row + 1 of every row of the tile (0 = no partner)
             if (off[P][u] == 0xFFFFFFFFu) cw[u] = 0u;
+            else if (bits(m)) cw[u] = ((uint32_t) w[P][u] >> (off[P][u] & 31u)) & 1u; // 1 = "some build row" (existence kinds never ask which)
             else cw[u] = m.direct == 2 ? d_rank_word(w[P][u], off[P][u]) : (uint32_t) w[P][u];
          }
       } else if (pf(m)) {

@@ -303,6 +303,38 @@ struct Interp {
       keepRestr.push_back(Restrictions::create({fd}, tab, c.side));
       return keepRestr.back()->data()[0];
    }
+   static constexpr int kMaxInConstants = 8, kMaxConjuncts = 8; // what one scan_filter call takes (LDB_MAX_IN / LDB_MAX_PREDS of the kernels' descriptors)
+   // rows of `cur` whose column d.col is one of d's constants: cur ⋉ (table of the constants).  The table, its relation and the hash table live as hidden
+   // values until the plan run ends
+   ldb_rel* semiJoinConstants(ldb_rel* cur, const ldb_filter_desc& d, const std::vector<const ldb_table*>& sides, const std::string& stem) {
+      ldb_coltype ct;
+      check(ldb_gpu_table_coltype(sides[(size_t) d.col.side], d.col.col, &ct), "IN list (column type)");
+      const size_t w = ct.type == LDB_T_INT32 || ct.type == LDB_T_DATE32 || ct.type == LDB_T_CHAR4 ? 4 : ct.type == LDB_T_INT64 ? 8 : 0;
+      if (!w) throw std::runtime_error("filter: an IN list of more than " + std::to_string(kMaxInConstants) + " constants over a column that is not a 4- or 8-byte integer / date / char(1)");
+      std::vector<uint8_t> buf(w * (size_t) d.n_in);
+      for (int32_t k = 0; k < d.n_in; k++) memcpy(buf.data() + w * (size_t) k, &d.in_values[2 * k], w); // (little-endian low word of the 128-bit constant)
+      ct.nullable = 0;
+      const char* colName = "in_value";
+      const std::string tag = "$in_list:" + stem + ":" + std::to_string(env.size());
+      ldb_table* t = nullptr;
+      check(ldb_gpu_table_alloc(ctx, "in_list", 1, &ct, &colName, d.n_in, nullptr, 0, &t), "IN list (table)");
+      putTable(tag, t);
+      check(ldb_gpu_table_write_fixed(ctx, t, 0, buf.data(), (int64_t) buf.size()), "IN list (constants)");
+      ldb_rel* br = nullptr;
+      check(ldb_gpu_rel_from_table(ctx, t, &br), "IN list (relation)");
+      putRel(tag + ":rel", br, {t});
+      const ldb_colref key{0, 0};
+      Value hv;
+      hv.kind = Value::HT;
+      hv.owned = true;
+      hv.sides = {t};
+      check(ldb_gpu_join_build(ctx, br, &key, 1, 0, &hv.ht), "IN list (hash table)");
+      ldb_hashtable* ht = hv.ht;
+      put(tag + ":ht", std::move(hv));
+      ldb_rel* out = nullptr;
+      check(ldb_gpu_join_probe(ctx, ht, cur, &d.col, 1, LDB_JOIN_SEMI, &out, nullptr), "IN list (semi join)");
+      return out;
+   }
    std::vector<ldb_filter_desc> preds(const std::vector<const ldb_table*>& sides, const J* list) {
       std::vector<ldb_filter_desc> out;
       if (!list) return out;
@@ -662,9 +694,24 @@ struct Interp {
          std::vector<const ldb_table*>* sides;
          ldb_rel* in = relOf(st.s("in"), &sides);
          auto ps = preds(*sides, &st.at("preds"));
-         ldb_rel* r;
-         check(ldb_gpu_scan_filter(ctx, in, ps.data(), (int32_t) ps.size(), &r), "filter");
-         putRel(st.s("out"), r, *sides);
+         // Limits of ONE scan_filter call that the reference's Restrictions do not have (round 6): a conjunction of more than eight conjuncts is applied
+         // eight at a time (a conjunction may be evaluated in any order); an integer IN list of more than eight constants — Restrictions.cpp:481-515 keeps
+         // a hash set of any size — becomes what it is relationally: a semi join against the table of its constants
+         std::vector<ldb_filter_desc> plain, longIn;
+         for (auto& d : ps) (d.op == LDB_F_IN && d.n_in > kMaxInConstants && d.in_values ? longIn : plain).push_back(d);
+         ldb_rel* cur = in;
+         auto advance = [&](ldb_rel* next) {
+            if (cur != in) check(ldb_gpu_rel_release(ctx, cur), "filter (intermediate)");
+            cur = next;
+         };
+         for (size_t at = 0; at < plain.size() || (at == 0 && longIn.empty()); at += kMaxConjuncts) {
+            const size_t n = std::min<size_t>(kMaxConjuncts, plain.size() - at);
+            ldb_rel* r;
+            check(ldb_gpu_scan_filter(ctx, cur, plain.data() + at, (int32_t) n, &r), "filter");
+            advance(r);
+         }
+         for (auto& d : longIn) advance(semiJoinConstants(cur, d, *sides, st.s("out")));
+         putRel(st.s("out"), cur, *sides);
       } else if (op == "filter_dnf") {
          std::vector<const ldb_table*>* sides;
          ldb_rel* in = relOf(st.s("in"), &sides);
