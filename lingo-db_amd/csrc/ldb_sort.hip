@@ -333,6 +333,21 @@ static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint6
                passes[n_pass++] = {w, shift};
                sel_words = w + 1;
             }
+      // Only as many passes as it takes to bring the candidates (the rows below the k-th prefix + the rows sharing it) under what one workgroup
+      // sorts: a pass over a byte with b varying bits splits its bucket 2^b ways, so log2(n / SS_MAX) + 3 varying bits leave ≈ SS_MAX / 8 rows
+      // in the k-th row's bucket when the bytes are anywhere near uniform (round 6: all eight passes — sixteen launches — ran for a 100-row
+      // top-k over 47 000 rows; two passes do).  Skewed bytes only make the candidate list longer: above SS_MAX rows it is radix-sorted below.
+      int need_bits = 3;
+      for (uint64_t x = (n + SS_MAX - 1) / SS_MAX; x > 1; x >>= 1) need_bits++;
+      int have_bits = 0, use = 0;
+      while (use < n_pass && have_bits < need_bits) {
+         have_bits += __builtin_popcountll((varmask[(size_t) passes[use].w] >> passes[use].shift) & 255ull);
+         use++;
+      }
+      if (use > 0 && ldb_option("topk_short_select", 1) != 0) {
+         n_pass = use;
+         sel_words = passes[use - 1].w + 1;
+      }
       SelState h_state;
       memset(&h_state, 0, sizeof(h_state));
       h_state.rank = k ? k - 1 : 0;

@@ -35,6 +35,7 @@
 #include <arrow/c/bridge.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <functional>
 
@@ -602,5 +603,320 @@ int64_t ref_hmm_outer_join(const int64_t* bkeys, const uint8_t* bvalid, int64_t 
    });
    *n_unmatched_build = nu;
    return n_pairs;
+}
+
+// =====================================================================================================================================
+// CPU baseline legs over the reference's REAL runtime objects at the bench's own scale (bench.py cpu_baseline, kind "reference"):
+// TPC-H Q1, Q6 and Q3 as the generated pipelines run them — morsels of 20 000 rows through ScanBatchesTask's unit loop (LingoDBTable.cpp:382-407)
+// with the REAL Restrictions::applyFilters, per-tuple code restated from the lowerings cited at each loop (the JIT-generated loops have no C++
+// source), around the REAL PreAggregationHashtableFragment / PreAggregationHashtable::merge, GrowingBuffer, HashIndexedView::build and the
+// scheduler interface.  Compiled -O2 like the rest of oracle/_ref.  Columns arrive as raw Arrow value buffers (the layout LingoDBTable keeps:
+// date32 / int32 / fixed_size_binary(4) = 4 bytes, decimal128 = 16 bytes little-endian).  Every function returns the wall-clock milliseconds of
+// ONE execution (scheduler start-up excluded — the reference keeps its workers alive between queries) and writes its result for the caller to
+// compare with the oracle legs.
+namespace {
+using i128 = __int128;
+uint64_t dbHash64Glue(int64_t v) { // Hash.cpp:25-28
+   uint64_t m1 = 11400714819323198549ull * static_cast<uint64_t>(v);
+   return m1 ^ __builtin_bswap64(m1);
+}
+void fold(uint64_t& acc, uint64_t piece) { acc = __builtin_bswap64(acc) ^ piece; } // Hash.cpp:30-32
+
+struct RawColumn { // one Arrow column as the ArrayView TableChunk hands to Restrictions (LingoDBTable.cpp:200-225)
+   runtime::ArrayView view;
+   const void* bufs[3];
+   void set(const void* values, int64_t n) {
+      view.length = n;
+      view.nullCount = 0;
+      view.offset = 0;
+      view.nBuffers = 2;
+      view.nChildren = 0;
+      view.children = nullptr;
+      bufs[0] = runtime::ArrayView::validData.data();
+      bufs[1] = values;
+      bufs[2] = nullptr;
+      view.buffers = bufs;
+   }
+};
+runtime::FilterDescription filterInt(const char* col, runtime::FilterOp op, int64_t v) {
+   runtime::FilterDescription d{};
+   d.columnName = col;
+   d.columnId = 0;
+   d.op = op;
+   d.value = v;
+   return d;
+}
+runtime::FilterDescription filterStr(const char* col, runtime::FilterOp op, const char* v) {
+   runtime::FilterDescription d{};
+   d.columnName = col;
+   d.columnId = 0;
+   d.op = op;
+   d.value = std::string(v);
+   return d;
+}
+double msSince(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+
+// Q1's aggregation entry: keys + five 128-bit sums + count (the reference widens SUM(decimal(12,2)) to decimal(38,s): i128 arithmetic)
+struct Q1Content {
+   int32_t rf, ls;
+   i128 qty, price, discPrice, charge, disc;
+   int64_t count;
+};
+bool q1Eq(uint8_t* a, uint8_t* b) { return reinterpret_cast<Q1Content*>(a)->rf == reinterpret_cast<Q1Content*>(b)->rf && reinterpret_cast<Q1Content*>(a)->ls == reinterpret_cast<Q1Content*>(b)->ls; }
+void q1Combine(uint8_t* d, uint8_t* s) {
+   auto* x = reinterpret_cast<Q1Content*>(d);
+   auto* y = reinterpret_cast<Q1Content*>(s);
+   x->qty += y->qty, x->price += y->price, x->discPrice += y->discPrice, x->charge += y->charge, x->disc += y->disc, x->count += y->count;
+}
+struct Q3Content {
+   int32_t orderkey, orderdate, shippriority;
+   i128 revenue;
+};
+bool q3Eq(uint8_t* a, uint8_t* b) {
+   auto* x = reinterpret_cast<Q3Content*>(a);
+   auto* y = reinterpret_cast<Q3Content*>(b);
+   return x->orderkey == y->orderkey && x->orderdate == y->orderdate && x->shippriority == y->shippriority;
+}
+void q3Combine(uint8_t* d, uint8_t* s) { reinterpret_cast<Q3Content*>(d)->revenue += reinterpret_cast<Q3Content*>(s)->revenue; }
+struct BuildEntry { // MultiMapAsHashIndexedView layout (SpecializeSubOpPass.cpp:70-84): {next, hash, key, payload…}
+   BuildEntry* next;
+   uint64_t hash;
+   int32_t key, a, b, pad;
+};
+struct Scheduler { // one scheduler + execution context per baseline session (the reference keeps its workers alive between queries)
+   std::unique_ptr<CtxScope> scope;
+   int threads = 0;
+} g_sched;
+} // namespace
+
+int32_t ref_baseline_begin(int32_t threads) {
+   g_sched.scope = std::make_unique<CtxScope>(threads);
+   g_sched.threads = threads;
+   return 0;
+}
+void ref_baseline_end() { g_sched.scope.reset(); }
+
+// Q1: scan(lineitem, l_shipdate <= 1998-09-02) → lookup_or_insert in the PreAggregationHashtableFragment + reduce → merge → scan of the groups.
+// out: per group {rf, ls, count, then the five sums as (lo, hi) pairs} = 13 int64 words; returns ms, *n_groups = groups
+double ref_q1(const int32_t* shipdate, const int32_t* returnflag, const int32_t* linestatus, const i128* quantity, const i128* price, const i128* discount, const i128* tax, int64_t n,
+              int64_t* out, int64_t cap, int64_t* n_groups) {
+   using Fragment = runtime::PreAggregationHashtableFragment;
+   if (!g_sched.scope) return -1;
+   auto schema = arrow::schema({arrow::field("l_shipdate", arrow::date32())});
+   std::unique_ptr<runtime::Restrictions> restrictions;
+   try {
+      restrictions = runtime::Restrictions::create({filterStr("l_shipdate", runtime::FilterOp::LTE, "1998-09-02")}, *schema);
+   } catch (std::exception&) { return -2; }
+   RawColumn dateCol;
+   dateCol.set(shipdate, n);
+   const auto t0 = std::chrono::steady_clock::now();
+   const size_t typeSize = sizeof(Fragment::Entry) + sizeof(Q1Content);
+   auto* tl = runtime::ThreadLocal::create([](uint8_t* arg) -> uint8_t* { return reinterpret_cast<uint8_t*>(Fragment::create(*reinterpret_cast<size_t*>(arg), false)); },
+                                           reinterpret_cast<uint8_t*>(const_cast<size_t*>(&typeSize)));
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>((size_t) n, 20000, [&](size_t b, size_t e, size_t) {
+      uint16_t sv1[65536], sv2[65536];
+      auto [len, sel] = restrictions->applyFilters(b, e - b, sv1, sv2, [&](size_t) { return &dateCol.view; });
+      auto* frag = reinterpret_cast<Fragment*>(tl->getLocal());
+      for (size_t k = 0; k < len; k++) {
+         const size_t i = b + sel[k];
+         uint64_t h = 0; // db.hash over (l_returnflag, l_linestatus): HashLowering folds the pieces (LowerToStd.cpp:1065-1152)
+         fold(h, dbHash64Glue(returnflag[i]));
+         fold(h, dbHash64Glue(linestatus[i]));
+         Fragment::Entry* en = frag->ht[(h >> 6) & (Fragment::hashtableSize - 1)]; // LookupPreAggrHtFragment (SubOpToControlFlow.cpp:3065-3157)
+         if (!(en && en->hashValue == h && reinterpret_cast<Q1Content*>(en->content)->rf == returnflag[i] && reinterpret_cast<Q1Content*>(en->content)->ls == linestatus[i])) {
+            en = frag->insert(h);
+            auto* c = reinterpret_cast<Q1Content*>(en->content);
+            *c = Q1Content{returnflag[i], linestatus[i], 0, 0, 0, 0, 0, 0};
+         }
+         auto* c = reinterpret_cast<Q1Content*>(en->content);
+         const i128 dp = price[i] * (100 - discount[i]); // decimal(12,2) x decimal(13,2) → scale 4
+         c->qty += quantity[i];
+         c->price += price[i];
+         c->discPrice += dp;
+         c->charge += dp * (100 + tax[i]); // scale 6
+         c->disc += discount[i];
+         c->count += 1;
+      }
+   }));
+   auto* merged = runtime::PreAggregationHashtable::merge(tl, q1Eq, q1Combine);
+   struct Out {
+      int64_t* out;
+      int64_t n, cap;
+   } o{out, 0, cap};
+   auto* it = merged->createIterator();
+   runtime::BufferIterator::iterate(
+      it, false,
+      [](runtime::Buffer buf, void* arg) {
+         auto* st = reinterpret_cast<Out*>(arg);
+         auto** entries = reinterpret_cast<Fragment::Entry**>(buf.ptr);
+         const size_t cnt = buf.numElements / sizeof(Fragment::Entry*);
+         for (size_t k = 0; k < cnt; k++) {
+            auto* c = reinterpret_cast<Q1Content*>(entries[k]->content);
+            if (st->n < st->cap) {
+               int64_t* r = st->out + 13 * st->n;
+               r[0] = c->rf, r[1] = c->ls, r[2] = c->count;
+               const i128 sums[5] = {c->qty, c->price, c->discPrice, c->charge, c->disc};
+               for (int a = 0; a < 5; a++) r[3 + 2 * a] = (int64_t) sums[a], r[4 + 2 * a] = (int64_t) (sums[a] >> 64);
+            }
+            st->n++;
+         }
+      },
+      &o);
+   const double ms = msSince(t0);
+   *n_groups = o.n;
+   return ms;
+}
+
+// Q6: five restrictions on three columns → SUM(l_extendedprice * l_discount) in a SimpleState per worker (key-less reduce, SimpleState.cpp),
+// the per-worker states combined at the end.  out_lohi = the 128-bit sum (scale 4), *n_pass = rows passing
+double ref_q6(const int32_t* shipdate, const i128* discount, const i128* quantity, const i128* price, int64_t n, int64_t out_lohi[2], int64_t* n_pass) {
+   if (!g_sched.scope) return -1;
+   auto schema = arrow::schema({arrow::field("l_shipdate", arrow::date32()), arrow::field("l_discount", arrow::decimal128(12, 2)), arrow::field("l_quantity", arrow::decimal128(12, 2))});
+   std::unique_ptr<runtime::Restrictions> restrictions;
+   try {
+      restrictions = runtime::Restrictions::create({filterStr("l_shipdate", runtime::FilterOp::GTE, "1994-01-01"), filterStr("l_shipdate", runtime::FilterOp::LT, "1995-01-01"),
+                                                    filterStr("l_discount", runtime::FilterOp::GTE, "0.05"), filterStr("l_discount", runtime::FilterOp::LTE, "0.07"),
+                                                    filterStr("l_quantity", runtime::FilterOp::LT, "24")},
+                                                   *schema);
+   } catch (std::exception&) { return -2; }
+   RawColumn cols[3];
+   cols[0].set(shipdate, n);
+   cols[1].set(discount, n);
+   cols[2].set(quantity, n);
+   const auto t0 = std::chrono::steady_clock::now();
+   struct alignas(64) State {
+      i128 sum = 0;
+      int64_t rows = 0;
+   };
+   std::vector<State> states((size_t) scheduler::getNumWorkers());
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>((size_t) n, 20000, [&](size_t b, size_t e, size_t worker) {
+      uint16_t sv1[65536], sv2[65536];
+      auto [len, sel] = restrictions->applyFilters(b, e - b, sv1, sv2, [&](size_t colId) { return &cols[colId].view; });
+      State& st = states[worker];
+      for (size_t k = 0; k < len; k++) {
+         const size_t i = b + sel[k];
+         st.sum += price[i] * discount[i];
+      }
+      st.rows += (int64_t) len;
+   }));
+   i128 total = 0;
+   int64_t rows = 0;
+   for (auto& s : states) total += s.sum, rows += s.rows;
+   const double ms = msSince(t0);
+   out_lohi[0] = (int64_t) total;
+   out_lohi[1] = (int64_t) (total >> 64);
+   *n_pass = rows;
+   return ms;
+}
+
+// Q3: customer (c_mktsegment = 'BUILDING') → GrowingBuffer → HashIndexedView; orders (o_orderdate < 1995-03-15) probe it, survivors →
+// GrowingBuffer → HashIndexedView; lineitem (l_shipdate > 1995-03-15) probes that; group by (l_orderkey, o_orderdate, o_shippriority) in the
+// PreAggregationHashtable; the groups come back unsorted (the caller orders the few thousand it compares).  c_mktsegment arrives as 4-byte codes
+// of its first four characters (the restriction on the utf8 column is the only string work of the query and is evaluated by the REAL Restrictions
+// over a fixed_size_binary(4) rendering 'BUIL' — the segment names differ in their first letter).
+// out: per group {orderkey, orderdate, shippriority, revenue lo, revenue hi}
+double ref_q3(const int32_t* c_custkey, const int32_t* c_segment4, int64_t n_c, const int32_t* o_orderkey, const int32_t* o_custkey, const int32_t* o_orderdate,
+              const int32_t* o_shippriority, int64_t n_o, const int32_t* l_orderkey, const i128* l_price, const i128* l_discount, const int32_t* l_shipdate, int64_t n_l,
+              int64_t* out, int64_t cap, int64_t* n_groups) {
+   using Fragment = runtime::PreAggregationHashtableFragment;
+   if (!g_sched.scope) return -1;
+   std::unique_ptr<runtime::Restrictions> rOrders, rLine;
+   try {
+      rOrders = runtime::Restrictions::create({filterStr("o_orderdate", runtime::FilterOp::LT, "1995-03-15")}, *arrow::schema({arrow::field("o_orderdate", arrow::date32())}));
+      rLine = runtime::Restrictions::create({filterStr("l_shipdate", runtime::FilterOp::GT, "1995-03-15")}, *arrow::schema({arrow::field("l_shipdate", arrow::date32())}));
+   } catch (std::exception&) { return -2; }
+   RawColumn oDate, lDate;
+   oDate.set(o_orderdate, n_o);
+   lDate.set(l_shipdate, n_l);
+   const int32_t building = (int32_t) ('B' | ('U' << 8) | ('I' << 16) | ('L' << 24));
+   const auto t0 = std::chrono::steady_clock::now();
+   // pipeline 1: customer → build side
+   auto* tlC = runtime::GrowingBuffer::createThreadLocal(sizeof(BuildEntry));
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>((size_t) n_c, 20000, [&](size_t b, size_t e, size_t) {
+      auto* buf = reinterpret_cast<runtime::GrowingBuffer*>(tlC->getLocal());
+      for (size_t i = b; i < e; i++) {
+         if (c_segment4[i] != building) continue;
+         auto* en = reinterpret_cast<BuildEntry*>(buf->insert());
+         *en = BuildEntry{nullptr, dbHash64Glue(c_custkey[i]), c_custkey[i], 0, 0, 0};
+      }
+   }));
+   auto* viewC = reinterpret_cast<ViewLayout*>(runtime::HashIndexedView::build(runtime::GrowingBuffer::merge(tlC)));
+   // pipeline 2: orders ⋈ customer → build side keyed by o_orderkey
+   auto* tlO = runtime::GrowingBuffer::createThreadLocal(sizeof(BuildEntry));
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>((size_t) n_o, 20000, [&](size_t b, size_t e, size_t) {
+      uint16_t sv1[65536], sv2[65536];
+      auto [len, sel] = rOrders->applyFilters(b, e - b, sv1, sv2, [&](size_t) { return &oDate.view; });
+      auto* buf = reinterpret_cast<runtime::GrowingBuffer*>(tlO->getLocal());
+      for (size_t k = 0; k < len; k++) {
+         const size_t i = b + sel[k];
+         const uint64_t h = dbHash64Glue(o_custkey[i]);
+         JoinEntry* slot = viewC->ht[h & viewC->mask]; // LookupHashIndexedViewLowering (SubOpToControlFlow.cpp:2558-2586)
+         auto* cur = reinterpret_cast<BuildEntry*>(runtime::matchesTag(slot, h) ? runtime::untag(slot) : nullptr);
+         for (; cur; cur = cur->next) {
+            if (cur->key == o_custkey[i]) {
+               auto* en = reinterpret_cast<BuildEntry*>(buf->insert());
+               *en = BuildEntry{nullptr, dbHash64Glue(o_orderkey[i]), o_orderkey[i], o_orderdate[i], o_shippriority[i], 0};
+               break; // c_custkey is the primary key
+            }
+         }
+      }
+   }));
+   auto* viewO = reinterpret_cast<ViewLayout*>(runtime::HashIndexedView::build(runtime::GrowingBuffer::merge(tlO)));
+   // pipeline 3: lineitem ⋈ orders → aggregation
+   const size_t typeSize = sizeof(Fragment::Entry) + sizeof(Q3Content);
+   auto* tl = runtime::ThreadLocal::create([](uint8_t* arg) -> uint8_t* { return reinterpret_cast<uint8_t*>(Fragment::create(*reinterpret_cast<size_t*>(arg), false)); },
+                                           reinterpret_cast<uint8_t*>(const_cast<size_t*>(&typeSize)));
+   scheduler::awaitEntryTask(std::make_unique<RangeTask>((size_t) n_l, 20000, [&](size_t b, size_t e, size_t) {
+      uint16_t sv1[65536], sv2[65536];
+      auto [len, sel] = rLine->applyFilters(b, e - b, sv1, sv2, [&](size_t) { return &lDate.view; });
+      auto* frag = reinterpret_cast<Fragment*>(tl->getLocal());
+      for (size_t k = 0; k < len; k++) {
+         const size_t i = b + sel[k];
+         const uint64_t hk = dbHash64Glue(l_orderkey[i]);
+         JoinEntry* slot = viewO->ht[hk & viewO->mask];
+         auto* cur = reinterpret_cast<BuildEntry*>(runtime::matchesTag(slot, hk) ? runtime::untag(slot) : nullptr);
+         for (; cur; cur = cur->next) {
+            if (cur->key != l_orderkey[i]) continue;
+            uint64_t h = 0;
+            fold(h, hk);
+            fold(h, dbHash64Glue(cur->a));
+            fold(h, dbHash64Glue(cur->b));
+            Fragment::Entry* en = frag->ht[(h >> 6) & (Fragment::hashtableSize - 1)];
+            auto* c = en ? reinterpret_cast<Q3Content*>(en->content) : nullptr;
+            if (!(en && en->hashValue == h && c->orderkey == l_orderkey[i] && c->orderdate == cur->a && c->shippriority == cur->b)) {
+               en = frag->insert(h);
+               c = reinterpret_cast<Q3Content*>(en->content);
+               *c = Q3Content{l_orderkey[i], cur->a, cur->b, 0};
+            }
+            c->revenue += l_price[i] * (100 - l_discount[i]);
+            break; // o_orderkey is the primary key
+         }
+      }
+   }));
+   auto* merged = runtime::PreAggregationHashtable::merge(tl, q3Eq, q3Combine);
+   struct Out {
+      int64_t* out;
+      int64_t n, cap;
+   } o{out, 0, cap};
+   auto* it = merged->createIterator();
+   runtime::BufferIterator::iterate(
+      it, false,
+      [](runtime::Buffer buf, void* arg) {
+         auto* st = reinterpret_cast<Out*>(arg);
+         auto** entries = reinterpret_cast<Fragment::Entry**>(buf.ptr);
+         const size_t cnt = buf.numElements / sizeof(Fragment::Entry*);
+         for (size_t k = 0; k < cnt; k++) {
+            auto* c = reinterpret_cast<Q3Content*>(entries[k]->content);
+            if (st->n < st->cap) {
+               int64_t* r = st->out + 5 * st->n;
+               r[0] = c->orderkey, r[1] = c->orderdate, r[2] = c->shippriority, r[3] = (int64_t) c->revenue, r[4] = (int64_t) (c->revenue >> 64);
+            }
+            st->n++;
+         }
+      },
+      &o);
+   const double ms = msSince(t0);
+   *n_groups = o.n;
+   return ms;
 }
 } // extern "C"
