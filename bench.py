@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--narrow-decimals", type=int, default=0)
     ap.add_argument("--cpu-sample-sf", type=float, default=10.0, help="scale of the CPU-baseline sample (0 = skip); the GPU runs the same sample beside it")
     ap.add_argument("--cpu-runs", default="1+3", help="CPU baseline protocol warm-up+measured passes (the reference's tools/scripts/benchmark.py uses 3+10)")
+    ap.add_argument("--cpu-reference-legs", type=int, default=1, help="1: cpu_baseline = TPC-H Q1 / Q6 / Q3 at the bench's own scale over the reference's real runtime objects (oracle/_ref, compiled loops, "
+                    "3 + 10 runs, the container's CPU quota as thread count); the interpreter legs move to cpu_baseline.interpreter_legs")
     ap.add_argument("--cpu-budget-s", type=float, default=100.0, help="stop starting new CPU legs after this many seconds (the line names the queries measured)")
     ap.add_argument("--oracle-spot-check", type=int, default=1, help="1: Q1 / Q3 / Q6 / Q9 / Q18 by the oracle at the bench's own scale, generated slice by slice on the host and merged (checks.oracle_q*_at_bench_scale; at N > 1 only Q9, 2: all of them)")
     ap.add_argument("--record-runs", type=int, default=3, help="executions per query with replay off after the timed region (per_query_record_ms); 0 = skip")
@@ -385,7 +387,7 @@ def main():
             if n6:
                 t6 = ms6 / n6 * 1e-3
                 extras["scan_q6"] = {"kernel_ms": round(ms6 / n6, 4), "rows_per_s_G": round(rows_local / t6 / 1e9, 1)}
-                pmc6 = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_q6_sf%g.json" % (r, args.sf)) for r in (5, 4, 3, 2, 1)) if os.path.exists(p)), None)
+                pmc6 = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_q6_sf%g.json" % (r, args.sf)) for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(p)), None)
                 if world == 1 and pmc6:
                     with open(pmc6) as f:
                         k6 = json.load(f)["kernels"]
@@ -399,7 +401,7 @@ def main():
             # command; tools/pmc_summary.py).  Counters cannot be read from inside the timed process, so the committed
             # summary of the matching configuration is quoted; null when there is none.
             tag = "_narrow" if args.narrow_decimals else ""
-            pmc_path = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_q%d_sf%g%s.json" % (r, roof_q, args.sf, tag)) for r in (5, 4, 3, 2, 1)) if os.path.exists(p)), None)
+            pmc_path = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_q%d_sf%g%s.json" % (r, roof_q, args.sf, tag)) for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(p)), None)
             if world == 1 and pmc_path:
                 with open(pmc_path) as f:
                     pmc = json.load(f)
@@ -496,10 +498,21 @@ def main():
             # release the SF`--sf` database first: the sample database of the same-SF GPU leg needs room only when SF is huge, but the
             # host legs keep whole tables as numpy arrays
             cpu = tpch_plans.cpu_baseline(queries, args.cpu_sample_sf, args.cpu_runs, args.cpu_budget_s, ctx=ctx, narrow=bool(args.narrow_decimals), checks=checks)
+        if world == 1 and args.cpu_reference_legs and not args.narrow_decimals:
+            # the baseline proper (round 6): Q1 / Q6 / Q3 at THIS scale over the reference's real runtime objects, compiled; the interpreter legs above (all 22
+            # queries at the sample scale, kind "port") stay beside it as `interpreter_legs`
+            try:
+                ref_legs = tpch_plans.cpu_reference_legs(ctx, db, n_orders, results, checks)
+            except Exception as e:
+                ref_legs = None
+                checks["reference_objects_error"] = "%s: %s" % (type(e).__name__, e)
+            if ref_legs is not None:
+                ref_legs["interpreter_legs"] = cpu
+                cpu = ref_legs
         # all kernels, helpers included: Σ kernel durations ÷ wall span per query from a rocprofv3 kernel trace of the
         # same plans on the same data (tools/query_timeline.py + tools/timeline_summary.py; profile, not this run)
         gpu_busy = None
-        tl_path = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_query_timeline_sf%g.json" % (r, args.sf)) for r in (5, 4, 3, 2)) if os.path.exists(p)), None)
+        tl_path = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_query_timeline_sf%g.json" % (r, args.sf)) for r in (6, 5, 4, 3, 2)) if os.path.exists(p)), None)
         if world == 1 and tl_path:
             with open(tl_path) as f:
                 tl = json.load(f)

@@ -1465,22 +1465,6 @@ void ldb_like_plan(DPred* d) {
    }
    if (nseg == 0) return; // "", "%", "%%": the general matcher decides at once
    for (int j = 0; j < 2 * nseg; j++) d->in_off[j] = off[j];
-   // in_hi[j] = offset of segment j's RAREST byte (the position-parallel matcher tests that byte first, d_like_simple_wave): letters by their
-   // frequency rank in English text, everything that is not a lower-case letter or a blank counts as rarer than any letter
-   static const char* by_frequency = "etaoinsrhldcumfpgwybvkxjqz";
-   for (int j = 0; j < nseg; j++) {
-      int best = 0, best_score = -2;
-      for (int k = 0; k < off[2 * j + 1]; k++) {
-         const char c = d->str[off[2 * j] + k];
-         const char* at = c ? strchr(by_frequency, c) : nullptr;
-         const int score = c == ' ' ? -1 : at ? (int) (at - by_frequency) : 30;
-         if (score > best_score) {
-            best_score = score;
-            best = k;
-         }
-      }
-      d->in_hi[j] = best;
-   }
    d->n_in = nseg;
    d->lo = (d->str[0] != '%' ? 1u : 0u) | (d->str[n - 1] != '%' ? 2u : 0u);
 }

@@ -228,6 +228,8 @@ struct SelState {
    unsigned long long pval[SEL_WORDS];
    unsigned long long pmask[SEL_WORDS];
    unsigned long long rank;
+   unsigned long long rank0; // k - 1: the rank asked for
+   unsigned long long cand; // after a pass: rows whose selected bytes are <= the k-th row's = what the passes so far leave to sort
 };
 __device__ __forceinline__ bool d_sel_match(const uint64_t* __restrict__ rec, const SelState& st, int upto) {
    bool m = true;
@@ -262,6 +264,7 @@ __global__ void k_sel_pick(SelState* __restrict__ state, uint32_t* __restrict__ 
       state->pval[w] |= (unsigned long long) dsel << shift;
       state->pmask[w] |= 255ull << shift;
       state->rank = rank - cum;
+      state->cand = (state->rank0 - (rank - cum)) + hist[dsel]; // rows below the chosen prefix + rows sharing it
    }
    __syncthreads();
    for (int k = threadIdx.x; k < 256; k += blockDim.x) hist[k] = 0;
@@ -333,32 +336,31 @@ static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint6
                passes[n_pass++] = {w, shift};
                sel_words = w + 1;
             }
-      // Only as many passes as it takes to bring the candidates (the rows below the k-th prefix + the rows sharing it) under what one workgroup
-      // sorts: a pass over a byte with b varying bits splits its bucket 2^b ways, so log2(n / SS_MAX) + 3 varying bits leave ≈ SS_MAX / 8 rows
-      // in the k-th row's bucket when the bytes are anywhere near uniform (round 6: all eight passes — sixteen launches — ran for a 100-row
-      // top-k over 47 000 rows; two passes do).  Skewed bytes only make the candidate list longer: above SS_MAX rows it is radix-sorted below.
-      int need_bits = 3;
-      for (uint64_t x = (n + SS_MAX - 1) / SS_MAX; x > 1; x >>= 1) need_bits++;
-      int have_bits = 0, use = 0;
-      while (use < n_pass && have_bits < need_bits) {
-         have_bits += __builtin_popcountll((varmask[(size_t) passes[use].w] >> passes[use].shift) & 255ull);
-         use++;
-      }
-      if (use > 0 && ldb_option("topk_short_select", 1) != 0) {
-         n_pass = use;
-         sel_words = passes[use - 1].w + 1;
-      }
       SelState h_state;
       memset(&h_state, 0, sizeof(h_state));
-      h_state.rank = k ? k - 1 : 0;
+      h_state.rank = h_state.rank0 = k ? k - 1 : 0;
+      h_state.cand = n;
       SelState* state;
       uint32_t* hist;
       LDB_TRY(ldb_dev_upload(ctx, &h_state, sizeof(h_state), (void**) &state, false)); // (k_sel_pick updates it)
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &hist, 4 * 256));
       LDB_HIP(hipMemsetAsync(hist, 0, 4 * 256, ctx->stream));
+      // Passes stop as soon as what they leave — the rows below the k-th prefix + the rows sharing it — fits the one-workgroup sort (round 6: all
+      // eight passes, sixteen launches, ran whatever the data; two or three bytes decide most of TPC-H's top-k inputs).  The count is an ordinary
+      // read-back: a recording execution waits for it after every pass, a replayed plan launches exactly the recorded number of passes.  (The
+      // varying-BIT count of a byte does not predict this: the bytes of a sign-flipped decimal column with both signs all vary, and all say the same.)
+      const bool early = ldb_option("topk_short_select", 1) != 0;
       for (int p = 0; p < n_pass; p++) {
          hipLaunchKernelGGL(k_sel_hist, dim3(grid), dim3(256), 0, ctx->stream, keys, words, n, passes[p].w, passes[p].shift, (const SelState*) state, hist);
          hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(256), 0, ctx->stream, state, hist, passes[p].w, passes[p].shift);
+         if (early && p + 1 < n_pass) {
+            uint64_t cand = 0;
+            LDB_TRY(ldb_read_u64(ctx, (const uint64_t*) &state->cand, &cand));
+            if (cand <= SS_MAX) {
+               sel_words = passes[p].w + 1;
+               break;
+            }
+         }
       }
       const uint64_t n_words = (n + 63) / 64;
       uint64_t* bitmap;

@@ -401,6 +401,86 @@ def _cgroup_cpus():
         return None
 
 
+def cpu_reference_legs(ctx, db, n_orders, results, checks, runs="3+10", budget_s=150.0):
+    """TPC-H Q1 / Q6 / Q3 at the BENCH'S OWN scale as compiled morsel loops around the reference's real runtime objects (oracle/ref_baseline.py,
+    oracle/ref_build/ref_glue.cpp over oracle/_ref: Restrictions::applyFilters, PreAggregationHashtableFragment + merge, GrowingBuffer, HashIndexedView::build,
+    the scheduler interface) — SURVEY §8(d)'s CPU baseline, kind "reference".  The columns are the device tables' own bytes, copied back to the host
+    once (outside every timing); `cores` = the container's CPU quota; the reference's benchmark.py protocol (3 warm-up + 10 measured, median and
+    min).  The legs' results are compared with the rows the GPU returned in the timed region (checks.reference_objects_q*_at_bench_scale).  None when
+    oracle/_ref is not there."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import math
+    import statistics
+
+    import numpy as np
+
+    import ref_baseline
+    import tpch_data as T
+    import tpch_legs
+
+    if not ref_baseline.available() or db.lineitem is None:
+        return None
+    t_all = time.perf_counter()
+    quota = _cgroup_cpus()
+    threads = max(1, int(quota) if quota else (os.cpu_count() or 1))
+    warm, measured = (int(x) for x in runs.split("+"))
+
+    def host(table, names):
+        out = {}
+        for nme in names:
+            i = table.col(nme)
+            raw = table.read_fixed(i)
+            out[nme] = raw.view(np.dtype("V16")) if table.col_width(i) == 16 else raw.view(np.int32)
+        return out
+
+    t0 = time.perf_counter()
+    want_li = ["l_shipdate", "l_quantity", "l_extendedprice", "l_discount"] + (["l_tax", "l_returnflag", "l_linestatus"] if 1 in results else []) + (["l_orderkey"] if 3 in results else [])
+    li = host(db.lineitem, want_li)
+    od = cu = None
+    if 3 in results and db.orders is not None and db.customer is not None:
+        od = host(db.orders, ["o_orderkey", "o_custkey", "o_orderdate", "o_shippriority"])
+        cu = host(db.customer, ["c_custkey"])
+        cu["c_segment4"] = ref_baseline.segment4(T.host_column(T.CUSTOMER, 3, n_orders))  # (the device keeps c_mktsegment as utf8: its first four bytes from the same generator on the host)
+    copy_s = time.perf_counter() - t0
+    med, mn, note = {}, {}, {}
+    with ref_baseline.Session(threads) as s:
+        legs = [(q, fn) for q, fn in ((1, lambda: s.q1(li)), (6, lambda: s.q6(li)), (3, lambda: s.q3(cu, od, li) if od is not None else None)) if q in results and (q != 3 or od is not None)]
+        for q, fn in legs:
+            ts, res = [], None
+            for r in range(warm + measured):
+                if time.perf_counter() - t_all > budget_s and len(ts) >= 3:
+                    note["Q%d" % q] = "%d measured runs (time budget)" % len(ts)
+                    break
+                ms, res = fn()
+                if r >= warm:
+                    ts.append(ms)
+            med[q], mn[q] = statistics.median(ts), min(ts)
+            try:
+                if q == 1:
+                    ok = matches_legs(1, _canon(results[1]), tpch_legs.Legs.q1_finish(res))
+                elif q == 6:
+                    got = results[6].column(0)[0].as_py()
+                    ok = (None if got is None else int(got.scaleb(results[6].schema.field(0).type.scale))) == res
+                else:
+                    ok = matches_legs(3, _canon(results[3]), res)
+                checks["reference_objects_q%d_at_bench_scale" % q] = bool(ok)
+            except Exception as e:
+                checks["reference_objects_q%d_at_bench_scale" % q] = "%s: %s" % (type(e).__name__, e)
+    done = sorted(med)
+    if not done:
+        return None
+    gm = math.exp(sum(math.log(max(med[q], 1e-9)) for q in done) / len(done))
+    return {"value": round(gm, 3), "unit": "ms", "cores": threads, "kind": "reference",
+            "sample": "TPC-H SF%g %s at the bench's own scale over the device tables' bytes copied back to the host: compiled (-O2) morsel loops (20 000 rows) around the reference's real "
+                      "runtime objects — Restrictions::applyFilters, PreAggregationHashtableFragment + PreAggregationHashtable::merge, GrowingBuffer, HashIndexedView::build, the scheduler "
+                      "interface — built from /root/reference into oracle/_ref; the JIT-generated per-tuple loops restated after the lowerings (oracle/ref_build/ref_glue.cpp); %d threads (the "
+                      "container's CPU quota); %d warm-up + %d measured runs, geomean of the medians" % (n_orders / 1_500_000, "+".join("Q%d" % q for q in done), threads, warm, measured),
+            "per_query_median_ms": {"Q%d" % q: round(med[q], 3) for q in done}, "per_query_min_ms": {"Q%d" % q: round(mn[q], 3) for q in done}, "sample_sf": n_orders / 1_500_000,
+            "device_to_host_copy_s": round(copy_s, 2), "hardware_threads": os.cpu_count(), "cgroup_cpu_limit": quota, **({"shortened": note} if note else {}),
+            "seconds": round(time.perf_counter() - t_all, 1)}
+
+
 def _jit_wait(timeout_ms=600_000):
     import ctypes as C
 
