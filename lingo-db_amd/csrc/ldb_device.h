@@ -471,6 +471,10 @@ __device__ __forceinline__ bool d_pred_is_colcol_dense(const DPred& pm) {
 #define LDS_STR_PAT (LDS_STR_BITS + LDB_LIKE_MAX_SEG * LDS_LIKE_STRIDE)
 #define LDS_STR_BYTES (LDS_STR_PAT + 64)
 
+#ifndef LDB_LIKE_MQSAD
+#define LDB_LIKE_MQSAD 1
+#endif
+typedef unsigned int ldb_u32x4 __attribute__((ext_vector_type(4)));
 // the first 16 bytes of pattern segment [off, off + len) as two little-endian words and their masks
 __device__ __forceinline__ void d_like_seg_words(const char* str, int off, int len, uint64_t (&pat)[2], uint64_t (&msk)[2]) {
    pat[0] = pat[1] = msk[0] = msk[1] = 0;
@@ -492,128 +496,88 @@ __device__ __forceinline__ void d_like_seg_words(const char* str, int off, int l
 // bitmaps (greedy leftmost placement decides %A%B% patterns; an anchored first / last segment has
 // one admissible position).  Bits computed from bytes beyond `span` are garbage but lie beyond every
 // row's last admissible position.
-// match bits of pattern segment j over the stage: bit (8b + o) of its bitmap ⇔ the segment matches at byte 8b + o (all lanes; followed by the fence + barrier below)
-__device__ __forceinline__ void d_like_segment_bits(const DPred& m, int j, const LDB_LDS uint8_t* text, LDB_LDS uint8_t* bits, uint32_t nb) {
-   const uint32_t lane = threadIdx.x & 63;
-   uint64_t pat[2], msk[2];
-   const int len = m.in_off[2 * j + 1];
-   d_like_seg_words(m.str, m.in_off[2 * j], len, pat, msk);
-   for (uint32_t b = lane; b < nb; b += 64) {
-      const uint64_t w0 = *(const LDB_LDS uint64_t*) (text + 8 * b), w1 = *(const LDB_LDS uint64_t*) (text + 8 * b + 8), w2 = *(const LDB_LDS uint64_t*) (text + 8 * b + 16);
-      uint32_t found = 0;
-#pragma unroll
-      for (int o = 0; o < 8; o++) {
-         const uint64_t x0 = o ? (w0 >> (8 * o)) | (w1 << (64 - 8 * o)) : w0;
-         bool eq = (x0 & msk[0]) == pat[0];
-         if (len > 8) {
-            const uint64_t x1 = o ? (w1 >> (8 * o)) | (w2 << (64 - 8 * o)) : w1;
-            eq = eq && (x1 & msk[1]) == pat[1];
-         }
-         found |= (eq ? 1u : 0u) << o;
-      }
-      bits[j * LDS_LIKE_STRIDE + b] = (uint8_t) found;
-   }
-   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-   __builtin_amdgcn_wave_barrier();
-   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// leftmost set bit of segment j's bitmap in [lo, hi], or 0xFFFFFFFF
-__device__ __forceinline__ uint32_t d_like_first_bit(const LDB_LDS uint8_t* bits, int j, uint32_t lo, uint32_t hi) {
-   const LDB_LDS uint64_t* M = (const LDB_LDS uint64_t*) (bits + j * LDS_LIKE_STRIDE);
-   uint32_t w = lo >> 6, at = 0xFFFFFFFFu;
-   uint64_t word = M[w] & (~0ull << (lo & 63));
-   for (;;) {
-      if (word) {
-         at = (w << 6) + (uint32_t) __builtin_ctzll(word);
-         break;
-      }
-      w++;
-      if ((w << 6) > hi) break;
-      word = M[w];
-   }
-   return at > hi ? 0xFFFFFFFFu : at;
-}
-// how many rows of a wave's batch may still be alive after a segment for the later segments to be placed row by row (below) instead of position by
-// position: with more, the bitmap of the next segment is computed for the whole stage as for the first
-#ifndef LDB_LIKE_COOP_ROWS
-#define LDB_LIKE_COOP_ROWS 8
-#endif
 __device__ __forceinline__ bool d_like_simple_wave(const DPred& m, uint8_t* stage, uint32_t span, uint32_t row_off, uint32_t row_len, bool active) {
    const uint32_t lane = threadIdx.x & 63;
    const int nseg = m.n_in;
    const LDB_LDS uint8_t* text = (const LDB_LDS uint8_t*) stage;
    LDB_LDS uint8_t* bits = (LDB_LDS uint8_t*) stage + LDS_STR_BITS;
    const uint32_t nb = (span + 7) >> 3;
-   // Round 6: only the FIRST segment is matched at every position of the stage.  A later segment matters only for the rows that placed all the
-   // segments before it — a few per cent of TPC-H's comment columns ('%special%requests%', '%Customer%Complaints%') — so those rows are taken one
-   // at a time and the 64 lanes split the row's admissible positions: one masked 16-byte compare per lane and 64 positions, a ballot, done.
-   // Before, every segment was matched at every byte (~13 instructions per byte and segment: the kernel was VALU-bound at 0.32 of the HBM peak).
-   d_like_segment_bits(m, 0, text, bits, nb);
-   bool ok = active;
-   uint32_t pos = row_off;
-   const uint32_t row_end = row_off + row_len;
-   if (ok) {
-      const uint32_t len = (uint32_t) m.in_off[1];
-      if (pos + len > row_end) {
-         ok = false;
-      } else {
-         const uint32_t lo = (nseg == 1 && (m.lo & 2)) ? row_end - len : pos; // anchored end: the last segment closes the row
-         const uint32_t hi = (m.lo & 1) ? pos : row_end - len; // anchored start: the first segment opens it
-         const uint32_t at = lo > hi ? 0xFFFFFFFFu : d_like_first_bit(bits, 0, lo, hi);
-         ok = at != 0xFFFFFFFFu;
-         pos = at + len;
+   for (uint32_t b = lane; b < nb; b += 64) {
+      const uint64_t w0 = *(const LDB_LDS uint64_t*) (text + 8 * b), w1 = *(const LDB_LDS uint64_t*) (text + 8 * b + 8), w2 = *(const LDB_LDS uint64_t*) (text + 8 * b + 16);
+      LDB_UNROLL
+      for (int j = 0; j < LDB_LIKE_MAX_SEG; j++) {
+         if (j >= nseg) break;
+         uint64_t pat[2], msk[2];
+         const int len = m.in_off[2 * j + 1];
+         d_like_seg_words(m.str, m.in_off[2 * j], len, pat, msk);
+         uint32_t found = 0;
+#if LDB_LIKE_MQSAD
+         // Round 6: v_mqsad_u32_u8 — four masked sums of absolute byte differences of a 4-byte reference against the four byte offsets of an
+         // 8-byte window, accumulated — does the work of four shifted masked compares in one instruction: the segment is cut into 4-byte pieces
+         // (zero-padded: a zero reference byte is masked out, and no pattern byte is zero), the window of piece p at offsets 4g … 4g + 3 is simply
+         // the register pair (t[p + g], t[p + g + 1]) of the block's 24 text bytes, no shifting; sum == 0 ⇔ the segment matches at that offset.
+         // Before: eight funnel-shifted 64-bit masked compares per segment and block (~13 instructions per text byte; the kernel was VALU-bound).
+         const uint32_t t[6] = {(uint32_t) w0, (uint32_t) (w0 >> 32), (uint32_t) w1, (uint32_t) (w1 >> 32), (uint32_t) w2, (uint32_t) (w2 >> 32)};
+         const uint32_t piece[4] = {(uint32_t) pat[0], (uint32_t) (pat[0] >> 32), (uint32_t) pat[1], (uint32_t) (pat[1] >> 32)};
+         const int n_piece = (len + 3) >> 2;
+#pragma unroll
+         for (int g = 0; g < 2; g++) {
+            ldb_u32x4 acc = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int pc = 0; pc < 4; pc++)
+               if (pc < n_piece) acc = __builtin_amdgcn_mqsad_u32_u8((uint64_t) t[pc + g] | ((uint64_t) t[pc + g + 1] << 32), piece[pc], acc);
+            found |= (acc[0] == 0u ? 1u : 0u) << (4 * g) | (acc[1] == 0u ? 2u : 0u) << (4 * g) | (acc[2] == 0u ? 4u : 0u) << (4 * g) | (acc[3] == 0u ? 8u : 0u) << (4 * g);
+         }
+#else
+#pragma unroll
+         for (int o = 0; o < 8; o++) {
+            const uint64_t x0 = o ? (w0 >> (8 * o)) | (w1 << (64 - 8 * o)) : w0;
+            bool eq = (x0 & msk[0]) == pat[0];
+            if (len > 8) {
+               const uint64_t x1 = o ? (w1 >> (8 * o)) | (w2 << (64 - 8 * o)) : w1;
+               eq = eq && (x1 & msk[1]) == pat[1];
+            }
+            found |= (eq ? 1u : 0u) << o;
+         }
+#endif
+         bits[j * LDS_LIKE_STRIDE + b] = (uint8_t) found;
       }
    }
-   LDB_UNROLL
-   for (int j = 1; j < LDB_LIKE_MAX_SEG; j++) {
-      if (j >= nseg) break;
-      const uint32_t len = (uint32_t) m.in_off[2 * j + 1];
-      if (ok && pos + len > row_end) ok = false;
-      const uint32_t lo = (j == nseg - 1 && (m.lo & 2)) ? row_end - len : pos;
-      const uint32_t hi = row_end - len;
-      if (ok && lo > hi) ok = false;
-      uint64_t alive = __ballot(ok);
-      if (!alive) break; // (wave-uniform)
-      if (__popcll(alive) > LDB_LIKE_COOP_ROWS) { // many rows still alive: this segment at every position after all
-         d_like_segment_bits(m, j, text, bits, nb);
-         if (ok) {
-            const uint32_t at = d_like_first_bit(bits, j, lo, hi);
-            ok = at != 0xFFFFFFFFu;
-            pos = at + len;
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+   __builtin_amdgcn_wave_barrier();
+   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   bool ok = active;
+   if (active) {
+      uint32_t pos = row_off;
+      const uint32_t row_end = row_off + row_len;
+      LDB_UNROLL
+      for (int j = 0; j < LDB_LIKE_MAX_SEG; j++) {
+         if (j >= nseg || !ok) break;
+         const uint32_t len = (uint32_t) m.in_off[2 * j + 1];
+         if (pos + len > row_end) {
+            ok = false;
+            break;
          }
-         continue;
-      }
-      uint64_t pat[2], msk[2];
-      d_like_seg_words(m.str, m.in_off[2 * j], (int) len, pat, msk);
-      while (alive) {
-         const int r = __builtin_ctzll(alive); // wave-uniform: the row being placed
-         alive &= alive - 1;
-         const uint32_t lo_r = (uint32_t) __shfl((int) lo, r), hi_r = (uint32_t) __shfl((int) hi, r);
-         uint32_t at = 0xFFFFFFFFu;
-         for (uint32_t base = lo_r; base <= hi_r; base += 64) {
-            const uint32_t p = base + lane;
-            bool eq = false;
-            if (p <= hi_r) {
-               const uint32_t a8 = p & ~7u, sh = (p & 7u) * 8u;
-               const uint64_t w0 = *(const LDB_LDS uint64_t*) (text + a8), w1 = *(const LDB_LDS uint64_t*) (text + a8 + 8);
-               const uint64_t x0 = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
-               eq = (x0 & msk[0]) == pat[0];
-               if (len > 8) {
-                  const uint64_t w2 = *(const LDB_LDS uint64_t*) (text + a8 + 16);
-                  const uint64_t x1 = sh ? (w1 >> sh) | (w2 << (64 - sh)) : w1;
-                  eq = eq && (x1 & msk[1]) == pat[1];
-               }
-            }
-            const uint64_t hit = __ballot(eq);
-            if (hit) {
-               at = base + (uint32_t) __builtin_ctzll(hit);
+         const uint32_t lo = (j == nseg - 1 && (m.lo & 2)) ? row_end - len : pos; // anchored end: the last segment closes the row
+         const uint32_t hi = (j == 0 && (m.lo & 1)) ? pos : row_end - len; // anchored start: the first segment opens it
+         if (lo > hi) {
+            ok = false;
+            break;
+         }
+         const LDB_LDS uint64_t* M = (const LDB_LDS uint64_t*) (bits + j * LDS_LIKE_STRIDE);
+         uint32_t w = lo >> 6, at = 0xFFFFFFFFu;
+         uint64_t word = M[w] & (~0ull << (lo & 63));
+         for (;;) {
+            if (word) {
+               at = (w << 6) + (uint32_t) __builtin_ctzll(word);
                break;
             }
+            w++;
+            if ((w << 6) > hi) break;
+            word = M[w];
          }
-         if ((int) lane == r) {
-            ok = at != 0xFFFFFFFFu;
-            pos = at + len;
-         }
+         if (at > hi) ok = false; // (no bit: at = 0xFFFFFFFF)
+         pos = at + len;
       }
    }
    __builtin_amdgcn_wave_barrier(); // the next batch slot overwrites the stage

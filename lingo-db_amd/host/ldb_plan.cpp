@@ -303,7 +303,7 @@ struct Interp {
       keepRestr.push_back(Restrictions::create({fd}, tab, c.side));
       return keepRestr.back()->data()[0];
    }
-   static constexpr int kMaxInConstants = 8, kMaxConjuncts = 8; // what one scan_filter call takes (LDB_MAX_IN / LDB_MAX_PREDS of the kernels' descriptors)
+   static constexpr int kMaxInConstants = 8, kMaxConjuncts = 8, kMaxResidual = 2; // what one scan_filter call takes (LDB_MAX_IN / LDB_MAX_PREDS of the kernels' descriptors)
    // rows of `cur` whose column d.col is one of d's constants: cur ⋉ (table of the constants).  The table, its relation and the hash table live as hidden
    // values until the plan run ends
    ldb_rel* semiJoinConstants(ldb_rel* cur, const ldb_filter_desc& d, const std::vector<const ldb_table*>& sides, const std::string& stem) {
@@ -774,7 +774,33 @@ struct Interp {
             for (auto& r : rs->arr) resid.push_back({resolve(*sides, r.s("probe"), "residual probe"), resolve(ht.sides, r.s("build"), "residual build"), opOf(r.s("op")), 0});
          ldb_rel* r;
          ldb_table* mark = nullptr;
+         // an INNER join takes any number of residual conjuncts (round 6): the probe kernel checks the first two on the candidate pair, the rest are
+         // column-vs-column comparisons over the joined rows — for an inner join the same rows (the reference evaluates the whole non-equality part of
+         // the predicate as the filter behind the lookup, SpecializeSubOpPass.cpp:152-205).  The other kinds decide per PROBE row and keep the limit
+         std::vector<ldb_join_residual> later;
+         if (kind == LDB_JOIN_INNER && resid.size() > (size_t) kMaxResidual) {
+            later.assign(resid.begin() + kMaxResidual, resid.end());
+            resid.resize((size_t) kMaxResidual);
+         }
          check(ldb_gpu_join_probe_residual(ctx, ht.ht, in, keys.data(), (int32_t) keys.size(), kind, resid.data(), (int32_t) resid.size(), &r, &mark), "join_probe");
+         if (!later.empty()) {
+            std::vector<ldb_filter_desc> fs;
+            for (auto& x : later) {
+               ldb_filter_desc d;
+               memset(&d, 0, sizeof(d));
+               d.col = x.probe_col;
+               d.op = x.op;
+               d.rhs_kind = LDB_RHS_COLUMN;
+               d.rhs_col = {(int32_t) (x.build_col.side + (int32_t) sides->size()), x.build_col.col}; // (the result's sides: probe sides, then build sides)
+               fs.push_back(d);
+            }
+            for (size_t at = 0; at < fs.size(); at += kMaxConjuncts) {
+               ldb_rel* f;
+               check(ldb_gpu_scan_filter(ctx, r, fs.data() + at, (int32_t) std::min<size_t>(kMaxConjuncts, fs.size() - at), &f), "join_probe (further residual conjuncts)");
+               check(ldb_gpu_rel_release(ctx, r), "join_probe (intermediate)");
+               r = f;
+            }
+         }
          std::vector<const ldb_table*> outSides;
          if (kind == LDB_JOIN_SEMI_BUILD || kind == LDB_JOIN_ANTI_BUILD) {
             outSides = ht.sides;

@@ -129,3 +129,29 @@ def test_long_in_lists_and_long_conjunctions(ctx):
     # only the long lists alone, and an empty result
     only = {"steps": [{"op": "filter", "in": "t", "out": "f", "preds": [{"col": "c0", "op": "IN", "values": list(range(200, 212))}]}, {"op": "materialize", "in": "f", "cols": ["i"], "out": "result"}], "result": "result"}
     assert ctx.run_plan(json.dumps(only), {"t": dev}).rows == 0
+
+
+def test_inner_join_with_more_than_two_residual_conjuncts(ctx):
+    """round 6: the probe kernel checks two residual conjuncts on the candidate pair; an inner join's further conjuncts are applied to the joined rows"""
+    import numpy as np
+
+    rng = np.random.default_rng(61)
+    nb, n = 5_000, 200_000
+    build = pa.table({"bk": pa.array(np.arange(nb, dtype=np.int32)), "b1": pa.array(rng.integers(0, 100, nb).astype(np.int32)), "b2": pa.array(rng.integers(0, 100, nb).astype(np.int32)),
+                      "b3": pa.array(rng.integers(0, 100, nb).astype(np.int32)), "b4": pa.array(rng.integers(0, 100, nb).astype(np.int32))})
+    probe = pa.table({"pk": pa.array(rng.integers(0, nb + 500, n).astype(np.int32)), "p1": pa.array(rng.integers(0, 100, n).astype(np.int32)), "p2": pa.array(rng.integers(0, 100, n).astype(np.int32)),
+                      "p3": pa.array(rng.integers(0, 100, n).astype(np.int32)), "p4": pa.array(rng.integers(0, 100, n).astype(np.int32)), "i": pa.array(np.arange(n, dtype=np.int64))})
+    plan = {"steps": [{"op": "join_build", "in": "b", "keys": ["bk"], "unique": True, "index": False, "out": "h"},
+                      {"op": "join_probe", "ht": "h", "in": "p", "keys": ["pk"], "kind": "inner",
+                       "residual": [{"probe": "p1", "op": "LT", "build": "b1"}, {"probe": "p2", "op": "GTE", "build": "b2"}, {"probe": "p3", "op": "NEQ", "build": "b3"}, {"probe": "p4", "op": "LTE", "build": "b4"}],
+                       "out": "j"},
+                      {"op": "materialize", "in": "j", "cols": ["i", "bk"], "out": "result"}], "result": "result"}
+    got = ctx.run_plan(json.dumps(plan), {"b": ctx.register("res_b", build), "p": ctx.register("res_p", probe)}).to_arrow()
+    pk = probe.column("pk").to_numpy()
+    ok = pk < nb
+    bi = np.where(ok, pk, 0)
+    col = lambda t, c: t.column(c).to_numpy()
+    keep = ok & (col(probe, "p1") < col(build, "b1")[bi]) & (col(probe, "p2") >= col(build, "b2")[bi]) & (col(probe, "p3") != col(build, "b3")[bi]) & (col(probe, "p4") <= col(build, "b4")[bi])
+    want = np.nonzero(keep)[0]
+    assert 0 < len(want) < n // 4
+    assert got.column(0).to_pylist() == want.tolist() and got.column(1).to_pylist() == pk[want].tolist()
