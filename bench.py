@@ -172,7 +172,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sf", type=float, default=100.0)
     ap.add_argument("--queries", default="", help="TPC-H queries of one step (default: all 22)")
-    ap.add_argument("--narrow-decimals", type=int, default=0)
+    ap.add_argument("--narrow-decimals", type=int, default=0, help="0: the reference's physical widths (headline); 1: decimals of precision < 19 as 8 bytes; 2: every such decimal and char(1) at the narrowest "
+                    "width its column's value range allows (a labelled side line: config.resident_format)")
     ap.add_argument("--cpu-sample-sf", type=float, default=10.0, help="scale of the CPU-baseline sample (0 = skip); the GPU runs the same sample beside it")
     ap.add_argument("--cpu-runs", default="1+3", help="CPU baseline protocol warm-up+measured passes (the reference's tools/scripts/benchmark.py uses 3+10)")
     ap.add_argument("--cpu-reference-legs", type=int, default=1, help="1: cpu_baseline = TPC-H Q1 / Q6 / Q3 at the bench's own scale over the reference's real runtime objects (oracle/_ref, compiled loops, "
@@ -227,7 +228,7 @@ def main():
     ctx = ldb.Context(local_rank)
     info = ctx.device_info()
     t_load = time.perf_counter()
-    db = tpch_plans.Database(ctx, n_orders, rank, world, queries, bool(args.narrow_decimals))
+    db = tpch_plans.Database(ctx, n_orders, rank, world, queries, int(args.narrow_decimals))
     ctx.sync()
     load_s = time.perf_counter() - t_load  # one-time: the tables generated straight into HBM (a real deployment registers Arrow batches here)
     comm, exchange = None, "none"
@@ -369,6 +370,9 @@ def main():
         n_l, ms_l = kernel_ms.get((roof_q, "k_groupby"), [0, 0.0]) if 1 in queries else (0, 0.0)  # (the 76 B/row model is Q1's: no Q1, no dominant-kernel entry)
         rows_local = db.lineitem.rows
         bpr = Q1_BYTES_PER_ROW_NARROW if args.narrow_decimals else Q1_BYTES_PER_ROW
+        if args.narrow_decimals >= 2 and 1 in queries:
+            # the compressed resident format (narrowest width per column): the kernel's algorithmic bytes are the widths the columns really have
+            bpr = sum(db.lineitem.col_width(db.lineitem.col(c)) for c in ("l_shipdate", "l_returnflag", "l_linestatus", "l_quantity", "l_extendedprice", "l_discount", "l_tax"))
         roofline = None
         if n_l:
             avg_ms = ms_l / n_l
@@ -497,7 +501,7 @@ def main():
         if world == 1 and args.cpu_sample_sf > 0:
             # release the SF`--sf` database first: the sample database of the same-SF GPU leg needs room only when SF is huge, but the
             # host legs keep whole tables as numpy arrays
-            cpu = tpch_plans.cpu_baseline(queries, args.cpu_sample_sf, args.cpu_runs, args.cpu_budget_s, ctx=ctx, narrow=bool(args.narrow_decimals), checks=checks)
+            cpu = tpch_plans.cpu_baseline(queries, args.cpu_sample_sf, args.cpu_runs, args.cpu_budget_s, ctx=ctx, narrow=int(args.narrow_decimals), checks=checks)
         if world == 1 and args.cpu_reference_legs and not args.narrow_decimals:
             # the baseline proper (round 6): Q1 / Q6 / Q3 at THIS scale over the reference's real runtime objects, compiled; the interpreter legs above (all 22
             # queries at the sample scale, kind "port") stay beside it as `interpreter_legs`
@@ -558,7 +562,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "TPC-H SF%g %s on %d x MI355X, Arrow columns resident in HBM (synthetic dbgen-shaped data, seed 20260925)" % (
                 args.sf, "+".join("Q%d" % q for q in queries), world), "queries": queries, "rows_lineitem_total": int(db.n_lineitem_total),
-                "narrow_decimals": bool(args.narrow_decimals), "device": info["name"], "exchange": exchange, "load_s": round(load_s, 3),
+                "narrow_decimals": (int(args.narrow_decimals) if args.narrow_decimals >= 2 else bool(args.narrow_decimals)), "device": info["name"],
+                **({"resident_format": "narrow level 2 — NOT the headline configuration: decimals of precision < 19 at the narrowest of 1 / 2 / 4 / 8 bytes their column's value range allows, "
+                                       "char(1) at one byte; widened in registers, arithmetic in i64 / i128 as LowerToStd.cpp:128-132,1479-1486: bit-identical results (checks.*); "
+                                       "roofline.frac is on the COMPRESSED bytes (roofline.bytes_per_row)"} if args.narrow_decimals >= 2 else {}), "exchange": exchange, "load_s": round(load_s, 3),
                 **({"functional_only": "all %d ranks share ONE GPU and exchange over the host-staged transport (LDB_DIST_BACKEND=gloo): a functional run of the sharded plans, "
                                        "not a scaling measurement" % world} if world > 1 and backend == "gloo" else {}),
                 "plans": ("tests/golden/subop_tpch_q*.json: sub-operator dumps in the reference's mlir-subop-to-json schema, translated by ldb_subop_translate (straightforward join trees, no eager aggregation)"

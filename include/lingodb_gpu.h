@@ -225,8 +225,12 @@ int32_t ldb_gpu_desc_cache_stats(ldb_ctx* ctx, int64_t* hits, int64_t* misses, i
 /* Replaces LingoDBTable::ensureLoaded + TableChunk flattening (LingoDBTable.cpp:27-54,
  * 200-225).  `schema` is a struct schema (format "+s"); each batch a struct array whose
  * children's buffers are exactly ArrayView.buffers[0..2].  Batches are concatenated per
- * column into one device buffer.  narrow_decimals != 0 stores decimal128(p<19) as int64
- * on the device (the width the generated code truncates to anyway, LowerToStd.cpp:128-132). */
+ * column into one device buffer.  narrow_decimals = 1 stores decimal128(p<19) as int64
+ * on the device (the width the generated code truncates to anyway, LowerToStd.cpp:128-132);
+ * narrow_decimals = 2 (round 6, a compressed resident format) stores every such decimal at the narrowest of
+ * 1 / 2 / 4 / 8 bytes the column's value range allows and a char(1) column of ASCII letters at one byte:
+ * kernels widen in registers and compute in i64 / i128 as before — results are bit-identical — and
+ * ldb_gpu_export widens back to the Arrow widths. */
 int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct ArrowSchema* schema,
                                struct ArrowArray** batches, int64_t n_batches, int32_t narrow_decimals,
                                ldb_table** out);

@@ -739,6 +739,17 @@ int32_t ldb_width_of(const ldb_coltype& t, int narrow) {
    }
 }
 
+// narrow == 2 (round 6, "compressed resident format"): a column whose values fit is stored at the narrowest of 1 / 2 / 4 / 8 bytes — decimals of
+// precision < 19 (the generated code truncates those to 64 bits anyway, LowerToStd.cpp:128-132) and char(1) (one byte when every value is ASCII).
+// Kernels widen in registers (d_load_i64 dispatches on the column's width) and compute in i64 / i128 exactly as before: results are bit-identical.
+int32_t ldb_narrowest_width(int64_t lo, int64_t hi) {
+   if (lo >= -128 && hi <= 127) return 1;
+   if (lo >= -32768 && hi <= 32767) return 2;
+   if (lo >= INT32_MIN && hi <= INT32_MAX) return 4;
+   return 8;
+}
+bool ldb_type_narrows(const ldb_coltype& t) { return (t.type == LDB_T_DECIMAL128 && t.precision < 19) || t.type == LDB_T_CHAR4; }
+
 static int parse_format(const char* f, ldb_coltype* t, bool* large) {
    *large = false;
    t->precision = t->scale = 0;
@@ -873,6 +884,29 @@ extern "C" int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct
          LDB_HIP(hipStreamSynchronize(ctx->stream));
       } else {
          int src_w = ldb_width_of(col.type, 0);
+         if (narrow >= 2 && ldb_type_narrows(col.type)) { // the narrowest width the column's value range allows (NULL slots count too: they only ever widen it)
+            int64_t lo = INT64_MAX, hi = INT64_MIN;
+            for (int64_t b = 0; b < n_batches; b++) {
+               struct ArrowArray* a = batches[b]->children[c];
+               const int64_t alen = batches[b]->length, aoff = batches[b]->offset + a->offset;
+               const uint8_t* src = (const uint8_t*) a->buffers[1] + aoff * src_w;
+               for (int64_t i = 0; i < alen; i++) {
+                  int64_t v = 0;
+                  if (src_w == 16) {
+                     memcpy(&v, src + i * 16, 8);
+                  } else {
+                     int32_t w32;
+                     memcpy(&w32, src + i * 4, 4);
+                     v = w32;
+                  }
+                  lo = std::min(lo, v);
+                  hi = std::max(hi, v);
+               }
+            }
+            if (lo > hi) lo = hi = 0;
+            col.width = ldb_narrowest_width(lo, hi);
+            if (col.type.type == LDB_T_CHAR4 && (col.width > 1 || lo < 0)) col.width = 4; // (a byte >= 0x80 or a second character: the four raw bytes stay)
+         }
          col.value_bytes = rows * col.width;
          LDB_TRY(ldb_dev_alloc(ctx, &col.values, (size_t) col.value_bytes));
          int64_t pos = 0;
@@ -884,10 +918,12 @@ extern "C" int32_t ldb_gpu_table_register(ldb_ctx* ctx, const char* name, struct
             const uint8_t* src = (const uint8_t*) a->buffers[1] + aoff * src_w;
             if (src_w == col.width) {
                LDB_HIP(hipMemcpyAsync((uint8_t*) col.values + pos * col.width, src, (size_t) (alen * src_w), hipMemcpyHostToDevice, ctx->stream));
-            } else { // narrowed decimal: keep the low 64 bits (the value fits, p < 19)
-               tmp.resize((size_t) alen);
-               for (int64_t i = 0; i < alen; i++) memcpy(&tmp[(size_t) i], src + i * 16, 8);
-               LDB_HIP(hipMemcpyAsync((uint8_t*) col.values + pos * 8, tmp.data(), (size_t) (alen * 8), hipMemcpyHostToDevice, ctx->stream));
+            } else { // narrowed column: keep the low `width` bytes (little-endian two's complement: the value fits)
+               const size_t w = (size_t) col.width;
+               tmp.resize((size_t) ((alen * (int64_t) w + 7) / 8));
+               uint8_t* dstb = (uint8_t*) tmp.data();
+               for (int64_t i = 0; i < alen; i++) memcpy(dstb + (size_t) i * w, src + i * src_w, w);
+               LDB_HIP(hipMemcpyAsync((uint8_t*) col.values + pos * (int64_t) w, tmp.data(), (size_t) alen * w, hipMemcpyHostToDevice, ctx->stream));
                LDB_HIP(hipStreamSynchronize(ctx->stream));
             }
             pos += alen;
@@ -1285,13 +1321,21 @@ extern "C" int32_t ldb_gpu_export(ldb_ctx* ctx, const ldb_table* t, struct Arrow
          cap->bufs.push_back(hv);
          if (out_w == col.width) {
             LDB_TRY(d2h(hv, col.values, bytes, staged[(size_t) c].values));
-         } else { // narrowed decimal → sign-extend back to 128 bit (reference LowerToStd.cpp:211-298)
-            std::vector<int64_t> tmp((size_t) n);
-            LDB_TRY(d2h(tmp.data(), col.values, (size_t) n * 8, staged[(size_t) c].values));
+         } else { // narrowed column → sign-extend back to its Arrow width (decimal128: reference LowerToStd.cpp:211-298; char(1): its byte + three zero bytes)
+            const size_t w = (size_t) col.width;
+            std::vector<uint8_t> tmp((size_t) n * w + 8);
+            LDB_TRY(d2h(tmp.data(), col.values, (size_t) n * w, staged[(size_t) c].values));
             for (int64_t i = 0; i < n; i++) {
-               int64_t lo = tmp[(size_t) i], hi = lo >> 63;
-               memcpy(hv + i * 16, &lo, 8);
-               memcpy(hv + i * 16 + 8, &hi, 8);
+               int64_t lo = 0;
+               switch (w) {
+                  case 1: lo = (int8_t) tmp[(size_t) i]; break;
+                  case 2: { int16_t v; memcpy(&v, tmp.data() + (size_t) i * 2, 2); lo = v; break; }
+                  case 4: { int32_t v; memcpy(&v, tmp.data() + (size_t) i * 4, 4); lo = v; break; }
+                  default: memcpy(&lo, tmp.data() + (size_t) i * 8, 8); break;
+               }
+               const int64_t hi = lo >> 63;
+               memcpy(hv + i * out_w, &lo, (size_t) std::min(out_w, 8));
+               if (out_w == 16) memcpy(hv + i * 16 + 8, &hi, 8);
             }
          }
          cap->buffers[1] = hv;

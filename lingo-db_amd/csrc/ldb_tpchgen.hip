@@ -12,14 +12,20 @@ struct GenCols {
 };
 
 __device__ __forceinline__ void put_dec(const GenCols& g, int c, uint64_t i, int64_t v) {
-   if (g.width[c] == 8) {
-      ((int64_t*) g.values[c])[i] = v;
-   } else {
-      ((int64_t*) g.values[c])[2 * i] = v;
-      ((int64_t*) g.values[c])[2 * i + 1] = v >> 63;
+   switch (g.width[c]) {
+      case 1: ((int8_t*) g.values[c])[i] = (int8_t) v; break; // (narrow level 2: the generator knows each column's value range, gen_width below)
+      case 2: ((int16_t*) g.values[c])[i] = (int16_t) v; break;
+      case 4: ((int32_t*) g.values[c])[i] = (int32_t) v; break;
+      case 8: ((int64_t*) g.values[c])[i] = v; break;
+      default:
+         ((int64_t*) g.values[c])[2 * i] = v;
+         ((int64_t*) g.values[c])[2 * i + 1] = v >> 63;
    }
 }
-__device__ __forceinline__ void put_i32(const GenCols& g, int c, uint64_t i, int32_t v) { ((int32_t*) g.values[c])[i] = v; }
+__device__ __forceinline__ void put_i32(const GenCols& g, int c, uint64_t i, int32_t v) {
+   if (g.width[c] == 1) ((int8_t*) g.values[c])[i] = (int8_t) v; // a char(1) column at one byte (narrow level 2)
+   else ((int32_t*) g.values[c])[i] = v;
+}
 #define HAS(c) ((g.mask >> (c)) & 1)
 
 __global__ void k_gen_lineitem(GenCols g, int64_t n_orders, int64_t row0, uint64_t n) {
@@ -246,6 +252,27 @@ static void table_slice(int32_t table, int64_t n_orders, int32_t part, int32_t n
    }
 }
 
+// narrow level 2: bytes per value of a generated column, from the value ranges the generator's definition guarantees (include/ldb_tpchgen.h) — what
+// ldb_gpu_table_register finds by scanning an imported column's values
+static int32_t gen_width(int32_t table, int32_t c, const ldb_coltype& t, int32_t narrow) {
+   const int32_t w = ldb_width_of(t, narrow);
+   if (narrow < 2) return w;
+   if (t.type == LDB_T_CHAR4) return 1; // l_returnflag, l_linestatus, o_orderstatus: one ASCII letter
+   if (t.type != LDB_T_DECIMAL128) return w;
+   switch (table) {
+      case LDB_TPCH_LINEITEM:
+         if (c == L_DISCOUNT || c == L_TAX) return 1; // 0.00 … 0.10 / 0.08
+         if (c == L_QUANTITY) return 2; // 1.00 … 50.00
+         return 4; // l_extendedprice <= 104 949.50
+      case LDB_TPCH_ORDERS: return 4; // o_totalprice: at most seven lines
+      case LDB_TPCH_CUSTOMER:
+      case LDB_TPCH_SUPPLIER: return 4; // -999.99 … 9 999.99
+      case LDB_TPCH_PART: return 4; // p_retailprice <= 2 100.00
+      case LDB_TPCH_PARTSUPP: return 4; // ps_supplycost <= 1 000.00
+      default: return w;
+   }
+}
+
 extern "C" int32_t ldb_gpu_tpch_generate(ldb_ctx* ctx, int32_t table_id, int64_t n_orders, int32_t part, int32_t n_parts, uint64_t col_mask,
                                          int32_t narrow, ldb_table** out) {
    if (!ctx || !out || n_orders < 1 || n_parts < 1 || part < 0 || part >= n_parts) LDB_FAIL(LDB_ERR_INVALID, "tpch_generate: bad argument");
@@ -270,7 +297,7 @@ extern "C" int32_t ldb_gpu_tpch_generate(ldb_ctx* ctx, int32_t table_id, int64_t
       ldb_column col;
       col.name = defs[c].name;
       col.type = defs[c].type;
-      col.width = ldb_width_of(col.type, narrow);
+      col.width = gen_width(table_id, c, col.type, narrow);
       if (col.type.type == LDB_T_UTF8 && table_id == LDB_TPCH_CUSTOMER && c == C_NAME) {
          col.value_bytes = n * LDB_TPCH_CNAME_LEN;
          LDB_TRY(ldb_dev_alloc(ctx, &col.values, (size_t) col.value_bytes));

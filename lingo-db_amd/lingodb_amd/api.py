@@ -699,7 +699,7 @@ class Context:
         ptrs = (C.POINTER(capi.ArrowArray) * len(arrays))(*[C.pointer(a) for a in arrays])
         h = C.c_void_p()
         try:
-            check(self.lib.ldb_gpu_table_register(self.h, name.encode(), C.byref(schema), ptrs, len(arrays), 1 if narrow_decimals else 0, C.byref(h)))
+            check(self.lib.ldb_gpu_table_register(self.h, name.encode(), C.byref(schema), ptrs, len(arrays), int(narrow_decimals), C.byref(h)))
         finally:
             # the library copied everything to the device: release the exported structs
             rel_t = C.CFUNCTYPE(None, C.c_void_p)
@@ -716,7 +716,7 @@ class Context:
             for c in cols:
                 mask |= 1 << c
         h = C.c_void_p()
-        check(self.lib.ldb_gpu_tpch_generate(self.h, table_id, n_orders, part, n_parts, mask, 1 if narrow_decimals else 0, C.byref(h)))
+        check(self.lib.ldb_gpu_tpch_generate(self.h, table_id, n_orders, part, n_parts, mask, int(narrow_decimals), C.byref(h)))
         return Table(self, h)
 
     # ---- plans: data (lingo-db_amd/plans/tpch/qN.json) interpreted by libldb_host.so; these wrappers only name the inputs
@@ -811,5 +811,5 @@ class Context:
         file per table and reads all its record batches (LingoDBTable.cpp:27-54, loadTable).  The library maps
         and parses the file itself (ldb_gpu_table_load_ipc, csrc/ldb_ipc.hip); pyarrow is not involved."""
         t = C.c_void_p()
-        check(self.lib.ldb_gpu_table_load_ipc(self.h, name.encode(), str(path).encode(), 1 if narrow_decimals else 0, C.byref(t)))
+        check(self.lib.ldb_gpu_table_load_ipc(self.h, name.encode(), str(path).encode(), int(narrow_decimals), C.byref(t)))
         return Table(self, t)
