@@ -471,8 +471,11 @@ __device__ __forceinline__ bool d_pred_is_colcol_dense(const DPred& pm) {
 #define LDS_STR_PAT (LDS_STR_BITS + LDB_LIKE_MAX_SEG * LDS_LIKE_STRIDE)
 #define LDS_STR_BYTES (LDS_STR_PAT + 64)
 
+// (round 6, measured on Q13's scan — 3.33 ms with the funnel-shift compares below: v_mqsad_u32_u8 pieces 3.57 ms, a rarest-byte SWAR prefilter 4.07 ms,
+// first segment by position + later segments row-cooperative 3.89 ms.  The instruction count of the MQSAD form is a third, its issue rate is not;
+// kept as a compile-time alternative: LDB_JIT_DEFINES=-DLDB_LIKE_MQSAD=1)
 #ifndef LDB_LIKE_MQSAD
-#define LDB_LIKE_MQSAD 1
+#define LDB_LIKE_MQSAD 0
 #endif
 typedef unsigned int ldb_u32x4 __attribute__((ext_vector_type(4)));
 // the first 16 bytes of pattern segment [off, off + len) as two little-endian words and their masks
