@@ -47,7 +47,11 @@ struct DFactorG {
    int64_t a, b;
 };
 struct DTermG {
-   int32_t n_factors, negate, div_pow10, pad;
+   // fits64 (host: GbBuilder::conv_expr): every factor and the whole product provably fit 63 bits — from the widths the columns are STORED at (a column
+   // narrowed to w bytes holds |v| < 2^(8w-1)) and their decimal precisions — so the product is formed with 64-bit multiplies and only the
+   // accumulation is 128 bits wide.  Same value as the wrapping 128-bit product whenever the proof holds (round 6: the compressed resident format
+   // makes Q1 ALU-bound, and its time is the two 128 x 128-bit products of sum_disc_price / sum_charge)
+   int32_t n_factors, negate, div_pow10, fits64;
    DFactorG f[LDB_MAX_FACTORS];
 };
 struct DExprG {
@@ -174,6 +178,24 @@ __device__ __forceinline__ bool d_eval_int(const DGroupBy& m, const DGroupBy* __
       const DTermG& tm = e.t[t];
       u128 prod = 1;
       const int nf = tm.n_factors;
+      if (tm.fits64) { // (no wide column among the factors: the host checked)
+         long long p64 = 1;
+         LDB_UNROLL
+         for (int f = 0; f < nf; f++) {
+            const DFactorG& fa = tm.f[f];
+            long long v = fa.a;
+            if (fa.has_col) {
+               const int ci = fa.col_idx;
+               if (!((rvalid >> ci) & 1)) return false;
+               v += fa.b * rv[ci];
+            }
+            p64 = f == 0 ? v : p64 * v;
+         }
+         i128 wide = (i128) p64;
+         if (tm.div_pow10 > 0) wide = d_sdiv128(wide, d_pow10(tm.div_pow10));
+         total = tm.negate ? total - (u128) wide : total + (u128) wide;
+         continue;
+      }
       LDB_UNROLL
       for (int f = 0; f < nf; f++) {
          const DFactorG& fa = tm.f[f];

@@ -29,6 +29,7 @@
 #include "ldb_chain.h"
 #include "ldb_gb_kernel.h"
 #include "ldb_jit.h"
+#include <cmath>
 #include <algorithm>
 #include <memory>
 
@@ -296,6 +297,9 @@ struct GbBuilder {
          out->t[t].n_factors = tm.n_factors;
          out->t[t].negate = tm.negate;
          out->t[t].div_pow10 = tm.div_pow10;
+         // fits64: a bound on |Π (a + b * col)| from the bytes each column is stored in and its decimal precision (no statistics needed)
+         long double bound = 1.0L;
+         bool provable = !e->is_float && tm.n_factors > 0 && ldb_option("gb_fits64", 1) != 0;
          for (int f = 0; f < tm.n_factors; f++) {
             out->t[t].f[f].has_col = tm.f[f].has_col;
             out->t[t].f[f].a = tm.f[f].a;
@@ -310,8 +314,20 @@ struct GbBuilder {
                *nullable = *nullable || c.validity != nullptr || (sd.rowids && sd.may_null);
                bool colf = c.type.type == LDB_T_FLOAT64 || c.type.type == LDB_T_FLOAT32;
                if (colf && !e->is_float) LDB_FAIL(LDB_ERR_INVALID, "expression: float column in an integer expression (set is_float)");
+               long double cb = c.width >= 8 ? 9.3e18L : (long double) (1ull << (8 * c.width - 1)); // |v| <= 2^(8w-1)
+               if (c.type.type == LDB_T_DECIMAL128) {
+                  long double pb = 1.0L;
+                  for (int k = 0; k < c.type.precision; k++) pb *= 10.0L;
+                  cb = std::min(cb, pb);
+                  if (c.type.precision >= 19) provable = false; // (a wide column is read as 128 bits)
+               }
+               if (colf) provable = false;
+               bound *= std::max(1.0L, fabsl((long double) tm.f[f].a) + fabsl((long double) tm.f[f].b) * cb);
+            } else {
+               bound *= std::max(1.0L, fabsl((long double) tm.f[f].a));
             }
          }
+         out->t[t].fits64 = provable && bound < 4.0e18L ? 1 : 0; // < 2^62; every factor's bound is >= 1, so every partial product is bounded by it too
       }
       return LDB_OK;
    }
