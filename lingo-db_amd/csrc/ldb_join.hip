@@ -42,7 +42,8 @@ struct ldb_hashtable {
    uint32_t* next = nullptr;
    int32_t direct = 0; // 1: slots = uint32_t[kmax - kmin + 1] indexed by key - kmin; 2: rank-bitmap words (DJoin::direct)
    int32_t rank_sorted = 0;
-   uint32_t* coarse = nullptr; // one bit per 64 key values (DJoin::has_coarse), or NULL
+   uint32_t* coarse = nullptr; // one bit per 2^coarse_shift key values (DJoin::has_coarse), or NULL
+   uint32_t coarse_shift = 6;
    uint32_t coarse_words = 0; // direct == 2: a key's rank IS its build row (ascending keys without NULLs); else next[] = rank → row
    size_t slot_bytes = 0; // bytes of the slot array (cap x 8, or cap x 4 when direct)
    int32_t pair32 = 0; // two 4-byte keys: slots are pairs of words (DJoin::pair32), cap x 16 bytes
@@ -63,13 +64,22 @@ __global__ void k_join_key_range(const DJoin* __restrict__ d, long long* __restr
 __global__ void k_join_key_bits(const DJoin* __restrict__ d);
 __global__ void k_join_rank_bits(const DJoin* __restrict__ d);
 __global__ void k_join_rank_perm(const DJoin* __restrict__ d);
-// coarse bit b ⇔ some build key among the 64 key values of rank words 2b, 2b + 1
-__global__ void k_rank_coarse(const uint64_t* __restrict__ tab, uint64_t n_words, uint32_t* __restrict__ coarse, uint32_t coarse_words) {
+// coarse bit b ⇔ some build key among the 2^shift key values b << shift … (shift = 6: rank words 2b, 2b + 1; 5: word b; 4: one half of word b / 2)
+__global__ void k_rank_coarse(const uint64_t* __restrict__ tab, uint64_t n_words, uint32_t* __restrict__ coarse, uint32_t coarse_words, uint32_t shift) {
    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < coarse_words; c += gridDim.x * blockDim.x) {
       uint32_t m = 0;
       for (uint32_t b = 0; b < 32; b++) {
-         const uint64_t w = ((uint64_t) c * 32 + b) * 2;
-         const uint32_t any = (w < n_words ? (uint32_t) tab[w] : 0u) | (w + 1 < n_words ? (uint32_t) tab[w + 1] : 0u);
+         const uint64_t bit = (uint64_t) c * 32 + b; // covers key values [bit << shift, (bit + 1) << shift); a rank word's low half = 32 presence bits
+         uint32_t any;
+         if (shift == 6) {
+            const uint64_t w = bit * 2;
+            any = (w < n_words ? (uint32_t) tab[w] : 0u) | (w + 1 < n_words ? (uint32_t) tab[w + 1] : 0u);
+         } else if (shift == 5) {
+            any = bit < n_words ? (uint32_t) tab[bit] : 0u;
+         } else {
+            const uint64_t w = bit >> 1;
+            any = w < n_words ? ((uint32_t) tab[w] >> ((bit & 1) * 16)) & 0xFFFFu : 0u;
+         }
          if (any) m |= 1u << b;
       }
       coarse[c] = m;
@@ -171,9 +181,15 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
    }
    // a launch with a coarse key bitmap: 512-thread workgroups, each staging the bitmap (<= 40 KB) in dynamic LDS — four of
    // them share a CU's 160 KB, i.e. the same 32 waves per CU as the 256-thread launches
-   const unsigned block = h->has_coarse ? 512u : 256u;
    const unsigned lds = h->has_coarse ? 4u * h->coarse_words : 0u;
-   if (h->has_coarse) grid = (int) std::max<int64_t>(1, std::min<int64_t>(((int64_t) h->n_rows + 511) / 512, (int64_t) ctx->cus * 4));
+   const bool big_lds = lds > 40u * 1024u; // the fine filter (<= 156 KB): one 1024-thread workgroup per CU
+   const unsigned block = h->has_coarse ? (big_lds ? 1024u : 512u) : 256u;
+   if (h->has_coarse) grid = (int) std::max<int64_t>(1, std::min<int64_t>(((int64_t) h->n_rows + block - 1) / block, (int64_t) ctx->cus * (big_lds ? 1 : 4)));
+   if (big_lds) { // more than 64 KB of dynamic LDS per workgroup has to be asked for
+      if (spec) (void) hipFuncSetAttribute((const void*) spec, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+      else (void) hipFuncSetAttribute((const void*) generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+      (void) hipGetLastError();
+   }
    LdbProf prof_(ctx, prof_name);
    if (spec) {
       void* params[] = {(void*) &d};
@@ -232,7 +248,7 @@ bool ldb_join_jit_check(std::string* log) {
    if (!ldb_jit_compile_only("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, m.get(), sizeof(DJoin), log)) return false;
    // … and with the LDS-resident coarse key bitmap in front of it (512-thread workgroups)
    m->rank_sorted = 1;
-   m->has_coarse = 1;
+   m->has_coarse = 6;
    return ldb_jit_compile_only("ldb_join_kernel.h", "DJoin", JOIN_SPEC_SRC, m.get(), sizeof(DJoin), log);
 }
 
@@ -718,11 +734,26 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
             ht->rank_sorted = (fl[0] & 4u) ? 0 : 1;
             // the LDS-resident coarse filter for selective builds over a small key range (DJoin::has_coarse): at most 40 KB
             // (four 512-thread workgroups per CU) and worth it when most 64-key blocks are empty
-            const uint64_t cwords = (uint64_t) (range0 / 64 / 32) + 1;
-            if (ldb_option("join_coarse", 1) != 0 && cwords * 4 <= 40 * 1024 && (unsigned __int128) back[2] * 64 * 2 <= range0) {
+            // Round 6: a build too dense for that (Q9's green parts: 5.4 % of the key range, 97 % of the 64-key blocks hold a key) gets one bit per
+            // 16 key values when that fits 156 KB — ONE 1024-thread workgroup per CU — and still turns a worthwhile share of the probes away
+            // (1 - 0.946^16 = 59 % pass).  Option join_coarse_fine (default 1).
+            uint32_t shift = 6;
+            uint64_t cwords = (uint64_t) (range0 / 64 / 32) + 1;
+            bool want = ldb_option("join_coarse", 1) != 0 && cwords * 4 <= 40 * 1024 && (unsigned __int128) back[2] * 64 * 2 <= range0;
+            if (!want && ldb_option("join_coarse", 1) != 0 && ldb_option("join_coarse_fine", 1) != 0) {
+               const uint64_t fine_words = (uint64_t) (range0 / 16 / 32) + 1;
+               // dense enough that 64-key blocks are useless, sparse enough that a 16-key block is empty at least a third of the time: 16 * density <= 1.1
+               if (fine_words * 4 <= 156 * 1024 && fine_words * 4 > 40 * 1024 && (unsigned __int128) back[2] * 16 * 10 <= range0 * 11) {
+                  shift = 4;
+                  cwords = fine_words;
+                  want = true;
+               }
+            }
+            if (want) {
                LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->coarse, 4 * (size_t) cwords));
                ht->coarse_words = (uint32_t) cwords;
-               hipLaunchKernelGGL(k_rank_coarse, dim3((unsigned) ((cwords + 255) / 256)), dim3(256), 0, ctx->stream, (const uint64_t*) tab, n_words, ht->coarse, (uint32_t) cwords);
+               ht->coarse_shift = shift;
+               hipLaunchKernelGGL(k_rank_coarse, dim3((unsigned) ((cwords + 255) / 256)), dim3(256), 0, ctx->stream, (const uint64_t*) tab, n_words, ht->coarse, (uint32_t) cwords, shift);
                LDB_HIP(hipGetLastError());
             }
             if (!ht->rank_sorted) {
@@ -928,7 +959,7 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    if (ht->coarse && probe->pending.empty() && probe->n_rows >= (1 << 22)) { // (the staging costs every workgroup 56 KB of loads: large probes only)
       h->coarse = (uint64_t) ht->coarse;
       h->coarse_words = ht->coarse_words;
-      h->has_coarse = 1;
+      h->has_coarse = (int32_t) ht->coarse_shift; // (6, or 4 for the fine filter: the kernels read the granularity from here)
    }
    for (size_t p = 0; p < probe->pending.size(); p++) h->ppreds[p] = probe->pending[p];
    ldb_order_preds(h->ppreds, h->n_ppreds);

@@ -116,7 +116,12 @@ __device__ __forceinline__ void d_stage_coarse(const DJoin& m, const DJoin* __re
    for (uint32_t i = threadIdx.x; i < d->coarse_words; i += blockDim.x) ldb_join_lds[i] = src[i];
    __syncthreads();
 }
-__device__ __forceinline__ bool d_coarse_hit(uint32_t r) { return (ldb_join_lds[r >> 11] >> ((r >> 6) & 31u)) & 1u; }
+// (has_coarse holds the filter's granularity: 6 = one bit per 64 key values, the <= 40 KB form; 5 / 4 = one per 32 / 16 — round 6: up to 156 KB, one
+// 1024-thread workgroup per CU, for builds too dense for 64-key blocks to be empty — Q9's green parts, 5.4 % of the key range)
+__device__ __forceinline__ bool d_coarse_hit(const DJoin& m, uint32_t r) {
+   const uint32_t s = (uint32_t) m.has_coarse;
+   return (ldb_join_lds[r >> (s + 5u)] >> ((r >> s) & 31u)) & 1u;
+}
 __device__ __forceinline__ bool d_probe_pass(const DJoin& m, const DJoin* __restrict__ d, uint64_t i) {
    bool pass = true;
    const int np = m.n_ppreds;
@@ -508,7 +513,7 @@ __device__ __forceinline__ void d_probe_batch(const DJoin& m, const DJoin* __res
          for (int u = 0; u < U; u++) {
             r[u] = k32[u] - kmin32;
             live[u] = live[u] && r[u] <= span; // outside the build key range
-            if (m.has_coarse) live[u] = live[u] && d_coarse_hit(live[u] ? r[u] : 0u); // no build key in its 64-key block (LDS)
+            if (m.has_coarse) live[u] = live[u] && d_coarse_hit(m, live[u] ? r[u] : 0u); // no build key in its block of key values (LDS)
          }
          if (m.has_key_bits) {
             const uint32_t* bits = gptr<uint32_t>(d->key_bits);
@@ -731,13 +736,14 @@ struct DProbePipe {
    uint64_t w[2][U]; // pw: table words in flight, alternating sets (direct == 1 uses the low half)
    uint32_t off[2][U]; // pw: the keys' table offsets (key - kmin), ~0 = outside the table's range
    // the table offsets of the keys in k[]; the words are loaded by words_at
-   __device__ __forceinline__ void offsets_of(const DJoin* __restrict__ d, int set, bool has_coarse) {
+   __device__ __forceinline__ void offsets_of(const DJoin& m, const DJoin* __restrict__ d, int set) {
+      const bool has_coarse = m.has_coarse != 0;
       const uint32_t kmin32 = (uint32_t) d->kmin, span = (uint32_t) (d->kmax - d->kmin);
 #pragma unroll
       for (int u = 0; u < U; u++) {
          const uint32_t r = k[u] - kmin32;
          off[set][u] = r <= span ? r : 0xFFFFFFFFu;
-         if (has_coarse && r <= span && !d_coarse_hit(r)) off[set][u] = 0xFFFFFFFFu; // a proven miss never asks the L2 for its word
+         if (has_coarse && r <= span && !d_coarse_hit(m, r)) off[set][u] = 0xFFFFFFFFu; // a proven miss never asks the L2 for its word
       }
    }
    __device__ __forceinline__ void words_at(const DJoin& m, const DJoin* __restrict__ d, int set) {
@@ -759,7 +765,7 @@ struct DProbePipe {
       }
       if (pf(m)) d_prefetch_keys32<U>(d, row0, n, k);
       if (pw(m)) {
-         offsets_of(d, 0, m.has_coarse != 0);
+         offsets_of(m, d, 0);
          d_prefetch_keys32<U>(d, row0 + stride, n, k);
          words_at(m, d, 0);
       }
@@ -771,7 +777,7 @@ struct DProbePipe {
       if (pw(m)) {
 #pragma unroll
          for (int u = 0; u < U; u++) LDB_PIN(k[u]); // keys(s+1) are here (words(s) may still be in flight)
-         offsets_of(d, 1 - P, m.has_coarse != 0);
+         offsets_of(m, d, 1 - P);
          d_prefetch_keys32<U>(d, row0 + 2 * stride, n, k); // keys(s+2), into the registers just consumed
          asm volatile("" : : : "memory"); // (keeps the key loads ahead of the word loads in issue order; no wait)
          words_at(m, d, 1 - P); // words(s+1)

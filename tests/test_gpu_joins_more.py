@@ -239,3 +239,33 @@ def test_selective_unique_build_large_probe_every_layout(ctx, table):
         for k in opts:
             lib.ldb_gpu_set_option(k.encode(), 1)
         lib.ldb_gpu_set_option(b"debug_check", 0)
+
+
+@pytest.mark.parametrize("fine", [1, 0])
+def test_dense_unique_build_gets_the_fine_lds_filter(ctx, fine):
+    """round 6: a 5 % build side over an 8 M key range — too dense for 64-key blocks to be empty — probed by 6 M unfiltered rows: the rank table with
+    one filter bit per SIXTEEN key values in LDS (62 KB here, up to 156 KB: one 1024-thread workgroup per CU, more than 64 KB of dynamic LDS per
+    workgroup), every probe kind against numpy; the same with the fine filter switched off (join_coarse_fine = 0)"""
+    lib = capi.gpu_lib()
+    rng = np.random.default_rng(29)
+    keyspace = 8_000_000
+    bkeys = np.sort(rng.choice(keyspace, keyspace // 20, replace=False)).astype(np.int32) + 77
+    pkeys = rng.integers(0, keyspace + 5000, 6_000_000).astype(np.int32)
+    b = ctx.register("fine_b_%d" % fine, pa.table({"k": pa.array(bkeys)}))
+    p = ctx.register("fine_p_%d" % fine, pa.table({"k": pa.array(pkeys)}))
+    lib.ldb_gpu_set_option(b"join_coarse_fine", fine)
+    lib.ldb_gpu_set_option(b"debug_check", 1)
+    try:
+        ht = b.rel().join_build([(0, 0)], unique=True)
+        idx = np.searchsorted(bkeys, pkeys)
+        hit = (idx < len(bkeys)) & (bkeys[np.minimum(idx, len(bkeys) - 1)] == pkeys)
+        rows = np.nonzero(hit)[0]
+        assert 200_000 < len(rows) < 400_000
+        assert ht.probe_count(p.rel(), [(0, 0)]) == len(rows)
+        assert np.array_equal(ht.probe(p.rel(), [(0, 0)], capi.JOIN_SEMI).rowids(0), rows)
+        assert np.array_equal(ht.probe(p.rel(), [(0, 0)], capi.JOIN_ANTI).rowids(0), np.nonzero(~hit)[0])
+        inner = ht.probe(p.rel(), [(0, 0)])
+        assert np.array_equal(inner.rowids(0), rows) and np.array_equal(inner.rowids(1), idx[rows].astype(np.uint32))
+    finally:
+        lib.ldb_gpu_set_option(b"join_coarse_fine", 1)
+        lib.ldb_gpu_set_option(b"debug_check", 0)
