@@ -20,6 +20,7 @@
 #include "ldb_internal.h"
 #include "ldb_join_kernel.h"
 #include "ldb_jit.h"
+#include <cmath>
 #include "ldb_chain.h"
 #include <algorithm>
 #include <memory>
@@ -734,16 +735,21 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
             ht->rank_sorted = (fl[0] & 4u) ? 0 : 1;
             // the LDS-resident coarse filter for selective builds over a small key range (DJoin::has_coarse): at most 40 KB
             // (four 512-thread workgroups per CU) and worth it when most 64-key blocks are empty
-            // Round 6: a build too dense for that (Q9's green parts: 5.4 % of the key range, 97 % of the 64-key blocks hold a key) gets one bit per
-            // 16 key values when that fits 156 KB — ONE 1024-thread workgroup per CU — and still turns a worthwhile share of the probes away
-            // (1 - 0.946^16 = 59 % pass).  Option join_coarse_fine (default 1).
+            // Round 6: one bit per SIXTEEN key values where that pays.  p(g) = 1 - (1 - density)^g is the share of probes a g-key filter lets
+            // through to the L2.  Q9's green parts (5.4 % of the key range): p(64) = 0.97 — useless — p(16) = 0.59; Q8's part filter (0.67 %):
+            // 0.35 against 0.10.  The fine filter of a 20 M key range is 156 KB: ONE 1024-thread workgroup per CU instead of four of 512 — taken
+            // when the coarse one would pass more than a quarter of the probes; where the fine filter itself fits 40 KB it simply replaces the
+            // coarse one.  Option join_coarse_fine (default 1).
             uint32_t shift = 6;
             uint64_t cwords = (uint64_t) (range0 / 64 / 32) + 1;
-            bool want = ldb_option("join_coarse", 1) != 0 && cwords * 4 <= 40 * 1024 && (unsigned __int128) back[2] * 64 * 2 <= range0;
-            if (!want && ldb_option("join_coarse", 1) != 0 && ldb_option("join_coarse_fine", 1) != 0) {
+            const double density = range0 > 0 ? (double) back[2] / (double) range0 : 1.0;
+            const double pass64 = 1.0 - pow(1.0 - density, 64.0), pass16 = 1.0 - pow(1.0 - density, 16.0);
+            const bool coarse_on = ldb_option("join_coarse", 1) != 0;
+            bool want = coarse_on && cwords * 4 <= 40 * 1024 && (unsigned __int128) back[2] * 64 * 2 <= range0;
+            if (coarse_on && ldb_option("join_coarse_fine", 1) != 0 && pass16 <= 0.7) {
                const uint64_t fine_words = (uint64_t) (range0 / 16 / 32) + 1;
-               // dense enough that 64-key blocks are useless, sparse enough that a 16-key block is empty at least a third of the time: 16 * density <= 1.1
-               if (fine_words * 4 <= 156 * 1024 && fine_words * 4 > 40 * 1024 && (unsigned __int128) back[2] * 16 * 10 <= range0 * 11) {
+               const bool small = fine_words * 4 <= 40 * 1024;
+               if (small || (fine_words * 4 <= 156 * 1024 && (!want || pass64 > 0.25))) {
                   shift = 4;
                   cwords = fine_words;
                   want = true;
