@@ -1009,66 +1009,64 @@ __device__ __forceinline__ void d_tile_probe(const DJoin& m, const DJoin* __rest
    __syncthreads();
 #endif
    const uint32_t qn = st.qn;
-   // JT_PB queue entries per lane at a time while that many are left, two per lane for what remains: a tile whose filter kept a quarter of its
-   // rows (512 of 2048) is ONE iteration, and at four entries per lane half of every lane's batch slots ran empty — predicated-off loads and
-   // resolves that still issue (round 6, measured through LDB_JIT_DEFINES: Q10's probe 1.92 → 1.38 ms at two per lane, Q3's 1.88 → 1.94; the
-   // choice per chunk keeps both)
-   auto chunk = [&](uint32_t j0, auto pb) __attribute__((always_inline)) {
-      constexpr int PB = decltype(pb)::v;
-      uint64_t rows[PB];
-      uint32_t rel[PB], mt[PB];
-      bool act[PB];
+   for (uint32_t j0 = 0; j0 < qn; j0 += JT_PB * JT_BLOCK) {
+      uint64_t rows[JT_PB];
+      uint32_t rel[JT_PB], mt[JT_PB];
+      bool act[JT_PB];
 #pragma unroll
-      for (int u = 0; u < PB; u++) {
+      for (int u = 0; u < JT_PB; u++) {
          const uint32_t j = j0 + (uint32_t) u * JT_BLOCK + threadIdx.x;
          act[u] = j < qn;
          rel[u] = act[u] ? st.q[j] : 0u;
          rows[u] = base + rel[u];
       }
-      d_probe_batch<PB>(m, d, rows, act, mt, [&](int u, uint32_t b) { return on_match(rel[u], b); });
+      d_probe_batch<JT_PB>(m, d, rows, act, mt, [&](int u, uint32_t b) { return on_match(rel[u], b); });
 #pragma unroll
-      for (int u = 0; u < PB; u++)
+      for (int u = 0; u < JT_PB; u++)
          if (act[u]) after(rel[u], mt[u]);
-   };
-   for (uint32_t j0 = 0; j0 < qn;) {
-      if (JT_PB > 2 && qn - j0 <= 2 * JT_BLOCK) {
-         chunk(j0, DPar<2>{});
-         j0 += 2 * JT_BLOCK;
-      } else {
-         chunk(j0, DPar<JT_PB>{});
-         j0 += JT_PB * JT_BLOCK;
-      }
    }
 }
 // the same for the kinds that only need each queued row's FIRST match: AFTER(tile-relative row, build row | LDB_NULL_ROW)
 template <typename AFTER>
 __device__ __forceinline__ void d_tile_probe_first(const DJoin& m, const DJoin* __restrict__ d, uint64_t base, JoinTile& st, AFTER after) {
    const uint32_t qn = st.qn;
-   auto chunk = [&](uint32_t j0, auto pb) __attribute__((always_inline)) { // (see d_tile_probe: JT_PB entries per lane, two for the tail)
-      constexpr int PB = decltype(pb)::v;
-      uint64_t rows[PB];
-      uint32_t rel[PB], brow[PB];
-      bool act[PB];
+   for (uint32_t j0 = 0; j0 < qn; j0 += JT_PB * JT_BLOCK) {
+      uint64_t rows[JT_PB];
+      uint32_t rel[JT_PB], brow[JT_PB];
+      bool act[JT_PB];
 #pragma unroll
-      for (int u = 0; u < PB; u++) {
+      for (int u = 0; u < JT_PB; u++) {
          const uint32_t j = j0 + (uint32_t) u * JT_BLOCK + threadIdx.x;
          act[u] = j < qn;
          rel[u] = act[u] ? st.q[j] : 0u;
          rows[u] = base + rel[u];
       }
-      d_probe_first<PB>(m, d, rows, act, brow);
+      d_probe_first<JT_PB>(m, d, rows, act, brow);
+#ifdef JOIN_DEBUG_COUNTS
+      {
+         unsigned long long* dc = gptr_mut<unsigned long long>(d->counter);
+         unsigned long long q = 0, hit = 0, inr = 0;
 #pragma unroll
-      for (int u = 0; u < PB; u++)
-         if (act[u]) after(rel[u], brow[u]);
-   };
-   for (uint32_t j0 = 0; j0 < qn;) {
-      if (JT_PB > 2 && qn - j0 <= 2 * JT_BLOCK) {
-         chunk(j0, DPar<2>{});
-         j0 += 2 * JT_BLOCK;
-      } else {
-         chunk(j0, DPar<JT_PB>{});
-         j0 += JT_PB * JT_BLOCK;
+         for (int u = 0; u < JT_PB; u++) {
+            q += act[u] ? 1 : 0;
+            hit += (act[u] && brow[u] != LDB_NULL_ROW) ? 1 : 0;
+            if (act[u]) {
+               const CV c = KV(m.pkeys, d->pkeys).col(0);
+               const int64_t kv = d_load_i64(c, (uint32_t) rows[u]);
+               if (kv >= d->kmin && kv <= d->kmax) {
+                  const uint64_t r = (uint64_t) (kv - d->kmin);
+                  inr += (gptr<uint32_t>(d->key_bits)[r >> 5] >> (r & 31)) & 1u;
+               }
+            }
+         }
+         atomicAdd(dc + 2, q);
+         atomicAdd(dc + 3, inr);
+         atomicAdd(dc + 4, hit);
       }
+#endif
+#pragma unroll
+      for (int u = 0; u < JT_PB; u++)
+         if (act[u]) after(rel[u], brow[u]);
    }
 }
 // write the tile's LDS bitmap out and count its bits; ends with a barrier
