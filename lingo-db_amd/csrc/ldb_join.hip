@@ -184,8 +184,9 @@ static int32_t launch_join(ldb_ctx* ctx, const DJoin* h, const DJoin* d, int gri
    // them share a CU's 160 KB, i.e. the same 32 waves per CU as the 256-thread launches
    const unsigned lds = h->has_coarse ? 4u * h->coarse_words : 0u;
    const bool big_lds = lds > 40u * 1024u; // the fine filter (<= 156 KB): one 1024-thread workgroup per CU
-   const unsigned block = h->has_coarse ? (big_lds ? 1024u : 512u) : 256u;
-   if (h->has_coarse) grid = (int) std::max<int64_t>(1, std::min<int64_t>(((int64_t) h->n_rows + block - 1) / block, (int64_t) ctx->cus * (big_lds ? 1 : 4)));
+   const bool tiles = h->n_ppreds > 0; // the tile kernels are written for 256-thread workgroups: their launch shape stays, the filter only adds dynamic LDS
+   const unsigned block = (h->has_coarse && !tiles) ? (big_lds ? 1024u : 512u) : 256u;
+   if (h->has_coarse && !tiles) grid = (int) std::max<int64_t>(1, std::min<int64_t>(((int64_t) h->n_rows + block - 1) / block, (int64_t) ctx->cus * (big_lds ? 1 : 4)));
    if (big_lds) { // more than 64 KB of dynamic LDS per workgroup has to be asked for
       if (spec) (void) hipFuncSetAttribute((const void*) spec, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
       else (void) hipFuncSetAttribute((const void*) generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
@@ -962,7 +963,10 @@ static int32_t make_probe_desc(ldb_hashtable* ht, ldb_rel* probe, const ldb_colr
    h->build_unique = (ht->unique && !ht->chained) ? 1 : 0;
    // a lazy probe relation brings its filter along: evaluated inside the probe kernel
    h->n_ppreds = (int32_t) probe->pending.size();
-   if (ht->coarse && probe->pending.empty() && probe->n_rows >= (1 << 22)) { // (the staging costs every workgroup 56 KB of loads: large probes only)
+   // (the staging costs every workgroup the filter's bytes in loads: large probes only.  A probe with a fused filter runs the tile kernels — 256-thread
+   // workgroups with their queue in static LDS, ~8 per CU —: only a filter of <= 16 KB rides along there (round 6: Q21's 380 M filtered probes of
+   // the 1 M supplier keys, 4 % of them present: half the L2 requests end in LDS))
+   if (ht->coarse && probe->n_rows >= (1 << 22) && (probe->pending.empty() || (4u * ht->coarse_words <= 16u * 1024u && ldb_option("join_coarse_filtered", 1) != 0))) {
       h->coarse = (uint64_t) ht->coarse;
       h->coarse_words = ht->coarse_words;
       h->has_coarse = (int32_t) ht->coarse_shift; // (6, or 4 for the fine filter: the kernels read the granularity from here)

@@ -1249,11 +1249,11 @@ __device__ __forceinline__ void join_flags_bitmap_body(const uint8_t* __restrict
 // by the ordered bitmap expansion — no atomics on an output cursor, deterministic ascending
 // order.  JE_U consecutive words (256 rows) per wave iteration, probed as one batch.
 __device__ __forceinline__ void join_probe_unique_body(const DJoin& m, const DJoin* __restrict__ d) {
+   d_stage_coarse(m, d); // (round 6: also in front of the tile kernels — a small filter, <= 16 KB, beside the tile's queue; the host decides)
    if (m.n_ppreds > 0 && m.has_bitmap) { // INNER with a fused filter
       join_probe_unique_filtered_body(m, d);
       return;
    }
-   d_stage_coarse(m, d);
    const uint64_t n = d->n_rows;
    const uint64_t n_words = (n + 63) / 64;
    const uint32_t lane = threadIdx.x & 63;
