@@ -218,8 +218,14 @@ int32_t ldb_gpu_trace_begin(ldb_ctx* ctx, ldb_trace* t, int32_t allow_replay);
 int32_t ldb_gpu_trace_replayable(const ldb_trace* t); /* 1 = _begin with bit 0 would replay */
 int32_t ldb_gpu_trace_end(ldb_ctx* ctx, int32_t* status); /* synchronises the stream; *status = ldb_trace_status */
 int32_t ldb_gpu_trace_stats(const ldb_trace* t, int64_t* entries, int64_t* records, int64_t* replays, int64_t* misses);
+/* process-wide: replays that failed on a value which depends on the order a kernel's atomics ran in (the open-addressing build's
+ * "long probe run" flag, ldb_join.hip) rather than on the data — 0 unless a build's key distribution sits on the run-length threshold */
+int64_t ldb_gpu_order_dependent_misses(void);
 /* descriptor cache of the context (descriptors of a repeated plan are byte-identical: uploaded once) */
 int32_t ldb_gpu_desc_cache_stats(ldb_ctx* ctx, int64_t* hits, int64_t* misses, int64_t* bytes);
+/* references operators hold on cached descriptors right now (0 between operator calls: every holder gives its reference back on every
+ * path, so an unused entry can always be evicted) and the number of references ever given back that nobody held (0: a caller's bug) */
+int32_t ldb_gpu_desc_cache_held(ldb_ctx* ctx, int64_t* held, int64_t* underflows);
 
 /* ------------------------------------------------------------------ tables (a1) */
 /* Replaces LingoDBTable::ensureLoaded + TableChunk flattening (LingoDBTable.cpp:27-54,

@@ -42,7 +42,7 @@ int64_t ldb_option(const char* name, int64_t dflt) {
 }
 extern "C" int32_t ldb_gpu_set_option(const char* name, int64_t value) {
    if (!name) LDB_FAIL(LDB_ERR_INVALID, "set_option: NULL name");
-   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass", "lazy_strings", "lazy_strings_min_rows", "gb_partition_wc", "join_radix_wc", "join_radix_lds", "gb_dense_out", "gb_partition_values", "join_pair32", "gb_dense_keys", "jit_async", "jit_threads", "jit_disk_cache", "join_all_match", "topk_short_select", "gb_fits64", "join_coarse_fine", "join_coarse_filtered"};
+   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass", "lazy_strings", "lazy_strings_min_rows", "gb_partition_wc", "join_radix_wc", "join_radix_lds", "gb_dense_out", "gb_partition_values", "join_pair32", "gb_dense_keys", "jit_async", "jit_threads", "jit_disk_cache", "join_all_match", "topk_short_select", "gb_fits64", "join_coarse_fine", "join_coarse_filtered", "compact_wide_tiles"};
    bool ok = false;
    for (const char* k : known) ok |= strcmp(k, name) == 0;
    if (!ok) LDB_FAIL(LDB_ERR_INVALID, "set_option: unknown option '%s'", name);
@@ -123,6 +123,10 @@ void ldb_dev_free(ldb_ctx* ctx, void* p) {
    auto dref = ctx->desc_blocks.find(p);
    if (dref != ctx->desc_blocks.end()) { // a cached descriptor (ldb_dev_upload): owned by the cache, this holder is done with it
       if (dref->second > 0) dref->second--;
+      else {
+         ctx->desc_underflows++; // nobody held it: the count stays at 0 (never negative), and another holder's reference is not touched
+         if (ldb_host_trace_threshold() >= 0) fprintf(stderr, "[ldb] descriptor %p given back twice\n", p);
+      }
       return;
    }
    if (!ctx->shared.empty()) {
@@ -272,10 +276,9 @@ static int32_t log_flush(ldb_ctx* ctx) {
       l->n = (uint32_t) std::min<size_t>(255, ctx->log_pending.size() - at);
       for (uint32_t i = 0; i < l->n; i++) l->e[i] = ctx->log_pending[at + i];
       at += l->n;
-      DLogList* d = nullptr;
-      LDB_TRY(ldb_dev_upload(ctx, l.get(), 8 + sizeof(ldb_ctx::LogCopy) * l->n, (void**) &d)); // (the same list every execution: served by the descriptor cache)
-      hipLaunchKernelGGL(k_log_gather, dim3(1), dim3(64), 0, ctx->stream, (const DLogList*) d, ctx->h_log);
-      ldb_dev_free(ctx, d);
+      LdbDesc<DLogList> d(ctx);
+      LDB_TRY(d.upload(l.get(), 8 + sizeof(ldb_ctx::LogCopy) * l->n)); // (the same list every execution: served by the descriptor cache)
+      hipLaunchKernelGGL(k_log_gather, dim3(1), dim3(64), 0, ctx->stream, (const DLogList*) d.p, ctx->h_log);
    }
    ctx->log_pending.clear();
    LDB_HIP(hipGetLastError());
@@ -341,6 +344,8 @@ uint32_t ldb_site_derived(uint32_t base, uint32_t salt) {
    }
    return hash;
 }
+static std::atomic<int64_t> g_order_misses{0};
+extern "C" int64_t ldb_gpu_order_dependent_misses(void) { return g_order_misses.load(); }
 // replay: everything read so far must equal the record
 static bool trace_prefix_ok(ldb_ctx* ctx, size_t upto_entries) {
    LdbSlow slow_("trace check: wait for the replayed plan", upto_entries);
@@ -350,6 +355,7 @@ static bool trace_prefix_ok(ldb_ctx* ctx, size_t upto_entries) {
    for (size_t i = 0; i < upto_entries; i++) {
       const ldb_trace_entry& e = t->entries[i];
       if (memcmp(ctx->h_log + e.off, t->vals.data() + e.off, e.bytes) != 0) {
+         if (e.flags & LDB_RB_ORDER_DEPENDENT) g_order_misses.fetch_add(1);
          if (ldb_host_trace_threshold() >= 0) { // which read-back was it, and what did it say
             std::lock_guard<std::mutex> lock(g_site_mu);
             auto it = g_sites.find(e.site);
@@ -413,7 +419,7 @@ int32_t ldb_readback(ldb_ctx* ctx, void* host, const void* dev, size_t bytes, ui
    LDB_TRY(readback_sync(ctx, host, dev, bytes));
    const size_t off = t->vals.size();
    if (off + bytes + 8 <= LDB_LOG_BYTES) {
-      t->entries.push_back({site, (uint32_t) bytes, (uint32_t) off});
+      t->entries.push_back({site, (uint32_t) bytes, (uint32_t) off, (uint32_t) (flags & LDB_RB_ORDER_DEPENDENT)});
       t->vals.resize(off + ((bytes + 7) & ~(size_t) 7), 0);
       memcpy(t->vals.data() + off, host, bytes);
    } else {
@@ -521,6 +527,14 @@ static std::atomic<uint64_t> g_serial{1};
 uint64_t ldb_next_serial() { return g_serial.fetch_add(1); }
 extern "C" uint64_t ldb_gpu_table_stamp(const ldb_table* t) { return t ? t->serial : 0; }
 extern "C" int64_t ldb_gpu_option_epoch(void) { return g_option_epoch.load(); }
+extern "C" int32_t ldb_gpu_desc_cache_held(ldb_ctx* ctx, int64_t* held, int64_t* underflows) {
+   if (!ctx) LDB_FAIL(LDB_ERR_INVALID, "desc_cache_held: NULL ctx");
+   int64_t n = 0;
+   for (auto& b : ctx->desc_blocks) n += b.second;
+   if (held) *held = n;
+   if (underflows) *underflows = ctx->desc_underflows;
+   return LDB_OK;
+}
 extern "C" int32_t ldb_gpu_desc_cache_stats(ldb_ctx* ctx, int64_t* hits, int64_t* misses, int64_t* bytes) {
    if (!ctx) LDB_FAIL(LDB_ERR_INVALID, "desc_cache_stats: NULL ctx");
    if (hits) *hits = ctx->desc_hits;
@@ -2149,8 +2163,10 @@ int32_t ldb_exclusive_scan_i64(ldb_ctx* ctx, const int64_t* d_in, int64_t* d_out
 // with row 0, so that a consumer that was sized from a REPLAYED count (ldb_readback) never meets an uninitialised row id.
 // (a tile of 512 words = 32 768 rows, two words per thread: the word-per-wave expansion of a dense tile is then 128 dependent
 // steps per wave instead of 512 — a compaction over few tiles runs at that latency)
-#define BC_ITEMS 2
-#define BC_TILE (256 * BC_ITEMS)
+// (round 6: two words per thread only where the bitmap is short.  A tile costs a fixed latency — ticket, loads, block scan, look-back — whatever
+// it holds: the 18 311 tiles of a 600 M-row bitmap took 16 – 27 ns each, 0.3 – 0.5 ms where its 75 MB + the row ids written are 0.05 ms of
+// traffic.  Bitmaps of >= 2 048 larger tiles take four or eight words per thread.)
+template <int BC_ITEMS>
 __global__ __launch_bounds__(256) void k_bitmap_compact(const uint64_t* __restrict__ bitmap, uint64_t n_words, uint64_t n_tiles, uint32_t* __restrict__ out, uint64_t cap,
                                                         const uint32_t* __restrict__ match, uint32_t* __restrict__ second, unsigned long long* __restrict__ total,
                                                         unsigned long long* __restrict__ status, unsigned long long* __restrict__ ticket, unsigned long long ticket_base,
@@ -2158,6 +2174,7 @@ __global__ __launch_bounds__(256) void k_bitmap_compact(const uint64_t* __restri
    __shared__ unsigned long long s_tile;
    __shared__ uint32_t s_wave[4];
    __shared__ uint32_t s_prefix;
+   constexpr uint32_t BC_TILE = 256 * BC_ITEMS;
    __shared__ uint32_t s_off[BC_TILE];
    __shared__ uint64_t s_words[BC_TILE]; // the tile's words for the word-per-wave expansion (a wave re-reading them from memory one by
                                             // one runs at memory latency: 512 dependent round trips per wave)
@@ -2248,12 +2265,19 @@ int32_t ldb_bitmap_compact(ldb_ctx* ctx, const uint64_t* bitmap, int64_t n_words
       if (d_total) LDB_HIP(hipMemsetAsync(d_total, 0, 8, ctx->stream));
       return LDB_OK;
    }
-   const uint64_t n_tiles = ((uint64_t) n_words + BC_TILE - 1) / BC_TILE;
+   const int64_t wide = ldb_option("compact_wide_tiles", 1);
+   const int items = wide && n_words >= 2048ll * 256 * 8 ? 8 : wide && n_words >= 2048ll * 256 * 4 ? 4 : 2;
+   const uint64_t n_tiles = ((uint64_t) n_words + 256u * items - 1) / (256u * items);
    ChainCall c;
    LDB_TRY(ldb_chain_begin(ctx, n_tiles, false, &c));
    LdbProf prof_(ctx, "k_bitmap_compact");
-   hipLaunchKernelGGL(k_bitmap_compact, dim3((unsigned) n_tiles), dim3(256), 0, ctx->stream, bitmap, (uint64_t) n_words, n_tiles, out, cap, match, second, (unsigned long long*) d_total, c.status,
-                      c.ticket, c.ticket_base, c.epoch);
+#define LDB_BC_LAUNCH(I) \
+   hipLaunchKernelGGL(k_bitmap_compact<I>, dim3((unsigned) n_tiles), dim3(256), 0, ctx->stream, bitmap, (uint64_t) n_words, n_tiles, out, cap, match, second, (unsigned long long*) d_total, c.status, \
+                      c.ticket, c.ticket_base, c.epoch)
+   if (items == 8) LDB_BC_LAUNCH(8);
+   else if (items == 4) LDB_BC_LAUNCH(4);
+   else LDB_BC_LAUNCH(2);
+#undef LDB_BC_LAUNCH
    if (hipGetLastError() != hipSuccess) return ldb_chain_failed(ctx);
    return LDB_OK;
 }

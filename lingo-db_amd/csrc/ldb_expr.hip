@@ -119,8 +119,9 @@ extern "C" int32_t ldb_gpu_map_expr(ldb_ctx* ctx, ldb_rel* in, const ldb_xinstr*
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &bm, (size_t) ((n + 7) / 8 + 1)));
    const int grid = ldb_grid_for(ctx, n, 256, 8);
    if (n) {
-      DXProg* d;
-      LDB_TRY(ldb_dev_upload(ctx, hp.get(), sizeof(DXProg), (void**) &d));
+      LdbDesc<DXProg> d_desc(ctx);
+      LDB_TRY(d_desc.upload(hp.get(), sizeof(DXProg)));
+      DXProg* d = d_desc.p;
       {
          hipFunction_t spec = nullptr;
          if (ldb_jit_wanted(n)) {
@@ -141,7 +142,7 @@ extern "C" int32_t ldb_gpu_map_expr(ldb_ctx* ctx, ldb_rel* in, const ldb_xinstr*
          }
       }
       hipLaunchKernelGGL(k_pack_bytes_to_bits_x, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*) vb, bm, (uint64_t) n);
-      ldb_dev_free(ctx, d);
+      d_desc.release();
    }
    res->cols[0].validity = bm;
    res->cols[0].null_count = -1; // unknown (Arrow convention)

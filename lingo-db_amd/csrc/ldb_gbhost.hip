@@ -620,8 +620,9 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          uint32_t* chunk_cnt;
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &chunk_cnt, 4 * (size_t) n_chunks));
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &chunk_off, 4 * (size_t) n_chunks));
-         DGroupBy* dh;
-         LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dh));
+         LdbDesc<DGroupBy> dh_desc(ctx);
+         LDB_TRY(dh_desc.upload(h, sizeof(*h)));
+         DGroupBy* dh = dh_desc.p;
          {
             const int hgrid = ldb_grid_for(ctx, in->n_rows, 256, 8);
             hipFunction_t spec = nullptr;
@@ -640,7 +641,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
          LDB_TRY(ldb_exclusive_scan_u32(ctx, chunk_cnt, chunk_off, n_chunks, d_groups));
          uint64_t groups = 0;
          LDB_TRY(ldb_read_u64(ctx, d_groups, &groups));
-         ldb_dev_free(ctx, dh);
+         dh_desc.release();
          ldb_dev_free(ctx, chunk_cnt);
          h->dense_sorted = 1;
          h->ordered_slots = 0;
@@ -698,6 +699,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
    const size_t ctl_bytes = 8 * (size_t) (2 + GB_MAX_OUT);
    unsigned long long* d_ctl = nullptr; // zeroed arena words, fresh ones per attempt (ldb_counters)
    unsigned long long ctl[2 + GB_MAX_OUT];
+   LdbDesc<DGroupBy> d_desc(ctx); // (one per attempt: given back after the attempt's control words are read, and on every error return)
    DGroupBy* d = nullptr;
    uint64_t n_groups = 0;
    uint32_t* rep_rows = nullptr;
@@ -760,7 +762,8 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
             h->outs[a].out_valid = (uint64_t) out_valid[(size_t) a];
          }
       }
-      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+      LDB_TRY(d_desc.upload(h, sizeof(*h)));
+      d = d_desc.p;
       hipLaunchKernelGGL(k_gb_init, dim3(ldb_grid_for(ctx, (int64_t) cap, 256, 8)), dim3(256), 0, ctx->stream, gk, ga, d);
       // COUNT(*) per key over direct slots, many rows into a table far beyond the L2: partition, then count in LDS
       const bool partitioned = h->direct && h->n_words == 1 && h->n_accs == 1 && h->n_preds == 0 && h->n_cpreds == 0 && cap >= (1ull << 20) && (cap >> GBP_SHIFT) <= GBP_MAX_PARTS &&
@@ -903,7 +906,7 @@ extern "C" int32_t ldb_gpu_groupby(ldb_ctx* ctx, ldb_rel* in, const ldb_filter_d
       static_assert(sizeof(ctl) <= 64 * sizeof(int64_t), "control block must fit the pinned scratch words");
       LDB_TRY(LDB_READBACK(ctx, ctl, d_ctl, ctl_bytes));
       if (h->dense_out) ctl[1] = sorted_groups; // (no occupancy scan ran: the heads pass counted the groups)
-      ldb_dev_free(ctx, d);
+      d_desc.release();
       const uint64_t flags = (uint64_t) ctl[0];
       if ((flags & 3) == 0) break;
       drop_outputs();

@@ -27,11 +27,12 @@ extern "C" int32_t ldb_gpu_hash_keys(ldb_ctx* ctx, ldb_rel* in, const ldb_colref
    const char* nm = "hash";
    ldb_table* res;
    LDB_TRY(ldb_gpu_table_alloc(ctx, "hash", 1, &t, &nm, in->n_rows, nullptr, 0, &res));
-   DKeys* d;
-   LDB_TRY(ldb_dev_upload(ctx, &h, sizeof(h), (void**) &d));
+   LdbDesc<DKeys> d_desc(ctx);
+   LDB_TRY(d_desc.upload(&h, sizeof(h)));
+   DKeys* d = d_desc.p;
    if (in->n_rows) hipLaunchKernelGGL(k_hash_keys, dim3(ldb_grid_for(ctx, in->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d, (uint64_t*) res->cols[0].values, (uint64_t) in->n_rows);
    LDB_HIP(hipGetLastError());
-   ldb_dev_free(ctx, d);
+   d_desc.release();
    *out = res;
    return LDB_OK;
 }

@@ -106,6 +106,7 @@ struct ldb_trace_entry {
    uint32_t site; // which call site asked (hash of file + line)
    uint32_t bytes;
    uint32_t off; // offset of the value in ldb_trace::vals and in the pinned log (8-byte aligned)
+   uint32_t flags; // LDB_RB_ORDER_DEPENDENT: a mis-speculation here is counted apart (ldb_gpu_order_dependent_misses)
 };
 struct ldb_trace {
    std::vector<ldb_trace_entry> entries;
@@ -130,6 +131,10 @@ struct ldb_ctx;
 // read `bytes` of device memory into `host` (see above); flags: LDB_RB_NEVER_REPLAY for values that may differ between two
 // executions over the same data (flags raised by races between insertions) — those always synchronise
 #define LDB_RB_NEVER_REPLAY 1
+// replayed, but the value may depend on the order in which a kernel's atomics happened (the open-addressing build's "long probe run" bit): a
+// differing replay is caught at the trace's end like any other and the execution repeated — such repeats are counted apart, so that spurious
+// re-runs (a key distribution sitting on the run-length threshold) are visible instead of looking like data-dependent mis-speculation
+#define LDB_RB_ORDER_DEPENDENT 2
 int32_t ldb_readback(ldb_ctx* ctx, void* host, const void* dev, size_t bytes, uint32_t site, int flags = 0);
 #define LDB_READBACK(ctx, host, dev, bytes) ldb_readback((ctx), (host), (dev), (bytes), LDB_SITE)
 
@@ -166,7 +171,7 @@ struct ldb_ctx {
    std::unordered_map<void*, int> desc_blocks; // device copy → operators holding it (ldb_dev_upload … ldb_dev_free)
    std::unordered_map<void*, int> shared; // block → EXTRA holders beyond the first (ldb_dev_share): ldb_dev_free gives one back, the last one frees
    size_t desc_bytes = 0;
-   int64_t desc_hits = 0, desc_misses = 0;
+   int64_t desc_hits = 0, desc_misses = 0, desc_underflows = 0; // (underflow: a reference given back that nobody held — a caller's bug, counted and reported)
    // read-back trace (see ldb_readback)
    ldb_trace* trace = nullptr;
    int trace_mode = 0; // 0 none, 1 record, 2 replay
@@ -299,6 +304,27 @@ struct LdbBufs {
             ptrs.erase(ptrs.begin() + (long) i);
             return;
          }
+   }
+};
+
+// a descriptor uploaded for one call (ldb_dev_upload): its reference on the descriptor cache — or its block, when it was not cacheable — is
+// given back when the scope ends, error returns included, so an entry no operator uses any more can always be evicted (desc_cache_mb stays
+// a bound) and no holder can give back a reference twice
+template <typename T>
+struct LdbDesc {
+   ldb_ctx* ctx;
+   T* p = nullptr;
+   explicit LdbDesc(ldb_ctx* c) : ctx(c) {}
+   LdbDesc(const LdbDesc&) = delete;
+   LdbDesc& operator=(const LdbDesc&) = delete;
+   ~LdbDesc() { release(); }
+   int32_t upload(const void* host, size_t bytes, bool cacheable = true) {
+      release();
+      return ldb_dev_upload(ctx, host, bytes, (void**) &p, cacheable);
+   }
+   void release() {
+      if (p) ldb_dev_free(ctx, p);
+      p = nullptr;
    }
 };
 

@@ -681,11 +681,12 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
          long long* range = (long long*) (ctx->d_scratch + 32);
          const long long init[2] = {INT64_MAX, INT64_MIN};
          LDB_TRY(ldb_h2d_small(ctx, range, init, 16));
-         DJoin* dr;
-         LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dr));
+         LdbDesc<DJoin> dr_desc(ctx);
+         LDB_TRY(dr_desc.upload(h, sizeof(*h)));
+         DJoin* dr = dr_desc.p;
          hipLaunchKernelGGL(k_join_key_range, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dr, range);
          LDB_TRY(LDB_READBACK(ctx, got, range, 16));
-         ldb_dev_free(ctx, dr);
+         dr_desc.release();
       }
       // DIRECT addressing when the key range is at most a few times the build rows (primary keys, and
       // filtered subsets of one): the table is then no larger than the open-addressing array it replaces
@@ -710,8 +711,9 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
          h->kmax = got[1];
          h->slots = (uint64_t) tab;
          h->counter = (uint64_t) counter;
-         DJoin* dr;
-         LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dr));
+         LdbDesc<DJoin> dr_desc(ctx);
+         LDB_TRY(dr_desc.upload(h, sizeof(*h)));
+         DJoin* dr = dr_desc.p;
          {
             LdbProf prof_(ctx, "k_join_build");
             hipLaunchKernelGGL(k_join_rank_bits, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dr);
@@ -766,11 +768,12 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
             if (!ht->rank_sorted) {
                LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) (build->n_rows ? build->n_rows : 1)));
                h->next = (uint64_t) ht->next;
-               DJoin* dp;
-               LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &dp));
+               LdbDesc<DJoin> dp_desc(ctx);
+               LDB_TRY(dp_desc.upload(h, sizeof(*h)));
+               DJoin* dp = dp_desc.p;
                hipLaunchKernelGGL(k_join_rank_perm, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, dp);
                LDB_HIP(hipGetLastError());
-               ldb_dev_free(ctx, dp);
+               dp_desc.release();
             }
          } else { // duplicate keys: the promise does not hold — the general layouts below
             ldb_dev_free(ctx, tab);
@@ -781,7 +784,7 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
             ht->unique = 0;
             build_unique = 0;
          }
-         ldb_dev_free(ctx, dr);
+         dr_desc.release();
          LDB_TRY(ldb_counters(ctx, 1, (uint64_t**) &dflags)); // (the passes below start from clean flags)
          h->flags = (uint64_t) dflags;
       }
@@ -868,18 +871,21 @@ extern "C" int32_t ldb_gpu_join_build(ldb_ctx* ctx, ldb_rel* build, const ldb_co
       h->next = (uint64_t) ht->next;
       if (ht->chained) ht->pair32 = 0; // (a chained rebuild uses the first cap words of the same allocation)
       h->pair32 = ht->pair32;
-      DJoin* d;
-      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+      LdbDesc<DJoin> d_desc(ctx);
+      LDB_TRY(d_desc.upload(h, sizeof(*h)));
+      DJoin* d = d_desc.p;
       if (build->n_rows && h->has_key_bits && (h->ordered_slots || h->direct)) hipLaunchKernelGGL(k_join_key_bits, dim3(ldb_grid_for(ctx, build->n_rows, 256, 8)), dim3(256), 0, ctx->stream, d);
       if (build->n_rows) LDB_TRY(launch_join(ctx, h, d, ldb_grid_for(ctx, build->n_rows, 256, 8), "k_join_build", "k_join_build_spec", k_join_build));
-      ldb_dev_free(ctx, d);
+      d_desc.release();
       uint64_t f = 0;
       // open addressing: which insertion meets a long run depends on the order the insertions happen in, but whether ANY does is in practice
       // a property of the keys (a run of 512 needs hundreds of equal or colliding keys: then some insertion walks it in every order).  The
       // flag is replayed like any count — round 4 read it for real in every execution, one stream wait in the middle of every plan with an
       // open-addressing build (Q18: 11.5 of 13.8 ms of host time blocked in this call) — and a run that does come out differently is caught
-      // by the comparison at the trace's end like any other mis-speculation
-      LDB_TRY(ldb_read_u64_at(ctx, dflags, &f, LDB_SITE, 0));
+      // by the comparison at the trace's end like any other mis-speculation: the execution is void (an insertion that gave up dropped its row)
+      // and is repeated.  Such repeats are counted apart (LDB_RB_ORDER_DEPENDENT → ldb_gpu_order_dependent_misses, bench.py's prepared_plans
+      // block): a key distribution that sits on the run-length threshold shows there instead of hiding among data-dependent misses
+      LDB_TRY(ldb_read_u64_at(ctx, dflags, &f, LDB_SITE, LDB_RB_ORDER_DEPENDENT));
       if (ht->direct && (f & 1) && !ht->chained) { // duplicate keys in a direct table: chain them
          ht->chained = 1;
          LDB_TRY(ldb_dev_alloc(ctx, (void**) &ht->next, 4 * (size_t) build->n_rows));
@@ -1009,13 +1015,14 @@ static int32_t probe_count_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe,
    unsigned long long* counter;
    LDB_TRY(ldb_counters(ctx, 2, (uint64_t**) &counter));
    hp->counter = (uint64_t) counter;
-   DJoin* d;
-   LDB_TRY(ldb_dev_upload(ctx, hp.get(), sizeof(DJoin), (void**) &d));
+   LdbDesc<DJoin> d_desc(ctx);
+   LDB_TRY(d_desc.upload(hp.get(), sizeof(DJoin)));
+   DJoin* d = d_desc.p;
    if (probe->n_rows && part_probe_ok(ht, part, 0)) LDB_TRY(launch_part_probe(ctx, ht, part, probe->n_rows, 0, nullptr, nullptr, counter)); // partitions staged in LDS
    else if (probe->n_rows) LDB_TRY(launch_join(ctx, hp.get(), d, ldb_grid_for(ctx, probe->n_rows, 256, 8), "k_join_probe_count", "k_join_probe_count_spec", k_join_probe_count));
    uint64_t m = 0;
    LDB_TRY(ldb_read_u64(ctx, counter + 1, &m));
-   ldb_dev_free(ctx, d);
+   d_desc.release();
    *matches = (int64_t) m;
    return LDB_OK;
 }
@@ -1058,11 +1065,12 @@ extern "C" int32_t ldb_gpu_join_probe_semi_anti_build(ldb_ctx* ctx, ldb_hashtabl
    hb->has_mark = 1;
    unsigned long long* cnt;
    LDB_TRY(ldb_counters(ctx, 2, (uint64_t**) &cnt));
-   DJoin* d;
-   LDB_TRY(ldb_dev_upload(ctx, hb.get(), sizeof(DJoin), (void**) &d));
+   LdbDesc<DJoin> d_desc(ctx);
+   LDB_TRY(d_desc.upload(hb.get(), sizeof(DJoin)));
+   DJoin* d = d_desc.p;
    int32_t st = LDB_OK;
    if (probe->n_rows) st = launch_join(ctx, hb.get(), d, ldb_grid_for(ctx, probe->n_rows, 256, 8), "k_join_probe_markbuild", "k_join_probe_markbuild_spec", k_join_probe_markbuild);
-   ldb_dev_free(ctx, d);
+   d_desc.release();
    LDB_TRY(st);
    if (nb) hipLaunchKernelGGL(k_join_flags_bitmap2, dim3(ldb_grid_for(ctx, nb, 256, 8)), dim3(256), 0, ctx->stream, (const uint8_t*) flags, (const uint8_t*) flags2, (uint64_t) nb, bitmap, cnt);
    LDB_HIP(hipGetLastError());
@@ -1147,10 +1155,11 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       hb->has_mark = 1;
       unsigned long long* cnt;
       LDB_TRY(ldb_counters(ctx, 2, (uint64_t**) &cnt));
-      DJoin* d;
-      LDB_TRY(ldb_dev_upload(ctx, hb.get(), sizeof(DJoin), (void**) &d));
+      LdbDesc<DJoin> d_desc(ctx);
+      LDB_TRY(d_desc.upload(hb.get(), sizeof(DJoin)));
+      DJoin* d = d_desc.p;
       if (probe->n_rows) LDB_TRY(launch_join(ctx, hb.get(), d, ldb_grid_for(ctx, probe->n_rows, 256, 8), "k_join_probe_markbuild", "k_join_probe_markbuild_spec", k_join_probe_markbuild));
-      ldb_dev_free(ctx, d);
+      d_desc.release();
       if (nb) hipLaunchKernelGGL(k_join_flags_bitmap, dim3(ldb_grid_for(ctx, nb, 256, 8)), dim3(256), 0, ctx->stream, (const uint8_t*) flags, (uint64_t) nb, kind == LDB_JOIN_ANTI_BUILD ? 1 : 0, bitmap, cnt);
       LDB_HIP(hipGetLastError());
       uint64_t total = 0;
@@ -1189,10 +1198,11 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
          h->mark = (uint64_t) mark->cols[0].values;
          h->has_mark = 1;
       }
-      DJoin* d;
-      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+      LdbDesc<DJoin> d_desc(ctx);
+      LDB_TRY(d_desc.upload(h, sizeof(*h)));
+      DJoin* d = d_desc.p;
       if (n) LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_exists", "k_join_probe_exists_spec", k_join_probe_exists));
-      ldb_dev_free(ctx, d);
+      d_desc.release();
       if (kind == LDB_JOIN_MARK) {
          ldb_dev_free(ctx, bitmap);
          *mark_out = mark;
@@ -1233,11 +1243,12 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       }
       h->match = (uint64_t) match;
       h->bitmap = (uint64_t) bitmap;
-      DJoin* d;
-      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+      LdbDesc<DJoin> d_desc(ctx);
+      LDB_TRY(d_desc.upload(h, sizeof(*h)));
+      DJoin* d = d_desc.p;
       if (n && part_probe_ok(ht, part, n_resid) && probe->pending.empty()) LDB_TRY(launch_part_probe(ctx, ht, part, n, 1, match, bitmap, counter)); // partitions staged in LDS
       else if (n) LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_unique", "k_join_probe_unique_spec", k_join_probe_unique));
-      ldb_dev_free(ctx, d);
+      d_desc.release();
       if (getenv("LDB_DEBUG_COUNTS")) {
          uint64_t c[3];
          for (int k = 0; k < 3; k++) LDB_TRY(ldb_read_u64(ctx, counter + 2 + k, &c[k]));
@@ -1297,14 +1308,15 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &chunk_cnt, 4 * (size_t) (n_chunks ? n_chunks : 1)));
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &chunk_off, 4 * (size_t) (n_chunks ? n_chunks : 1)));
       h->match = (uint64_t) chunk_cnt;
-      DJoin* d;
-      LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+      LdbDesc<DJoin> d_desc(ctx);
+      LDB_TRY(d_desc.upload(h, sizeof(*h)));
+      DJoin* d = d_desc.p;
       if (n) {
          LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_pairs_count", "k_join_probe_pairs_count_spec", k_join_probe_pairs_count));
          LDB_TRY(ldb_exclusive_scan_u32(ctx, chunk_cnt, chunk_off, n_chunks, nullptr));
          LDB_TRY(ldb_read_u64(ctx, counter, &produced));
       }
-      ldb_dev_free(ctx, d);
+      d_desc.release();
       if (produced >= (uint64_t) LDB_NULL_ROW) LDB_FAIL(LDB_ERR_UNSUPPORTED, "join_probe: %llu result rows exceed uint32 row ids", (unsigned long long) produced);
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &op, 4 * (size_t) (produced ? produced : 1)));
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &ob, 4 * (size_t) (produced ? produced : 1)));
@@ -1317,9 +1329,10 @@ static int32_t probe_impl(ldb_ctx* ctx, ldb_hashtable* ht, ldb_rel* probe, const
          h->out_probe = (uint64_t) op;
          h->out_build = (uint64_t) ob;
          h->out_cap = produced;
-         LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+         LDB_TRY(d_desc.upload(h, sizeof(*h)));
+         d = d_desc.p;
          LDB_TRY(launch_join(ctx, h, d, grid, "k_join_probe_pairs", "k_join_probe_pairs_spec", k_join_probe_pairs));
-         ldb_dev_free(ctx, d);
+         d_desc.release();
       }
       ldb_dev_free(ctx, chunk_cnt);
       ldb_dev_free(ctx, chunk_off);

@@ -206,8 +206,9 @@ static int32_t scan_run_with(ldb_ctx* ctx, int64_t n, LAUNCH launch, uint32_t** 
 // run the conjunction over the dense base rows of `in` → ascending row numbers (device, owned by caller)
 static int32_t scan_run(ldb_ctx* ctx, ldb_rel* in, const DScan& h, uint32_t** sel_out, uint64_t* total_out) {
    const int64_t n = in->n_rows;
-   DScan* d = nullptr;
-   if (n) LDB_TRY(ldb_dev_upload(ctx, &h, sizeof(h), (void**) &d));
+   LdbDesc<DScan> d_desc(ctx);
+   if (n) LDB_TRY(d_desc.upload(&h, sizeof(h)));
+   DScan* d = d_desc.p;
    const int32_t st = scan_run_with(
       ctx, n,
       [&](uint64_t* bitmap, uint32_t* counts, unsigned n_blocks) -> int32_t {
@@ -228,7 +229,7 @@ static int32_t scan_run(ldb_ctx* ctx, ldb_rel* in, const DScan& h, uint32_t** se
          return LDB_OK;
       },
       sel_out, total_out);
-   ldb_dev_free(ctx, d);
+   d_desc.release();
    return st;
 }
 
@@ -253,8 +254,9 @@ extern "C" int32_t ldb_gpu_scan_filter_dnf(ldb_ctx* ctx, ldb_rel* in, const ldb_
       for (int32_t p = 0; p < clause_sizes[c]; p++, total_preds++) LDB_TRY(ldb_make_dpred(in, &preds[total_preds], &hp->preds[total_preds]));
       hp->clause_end[c] = total_preds;
    }
-   DScanDnf* d = nullptr;
-   if (in->n_rows) LDB_TRY(ldb_dev_upload(ctx, hp.get(), sizeof(DScanDnf), (void**) &d));
+   LdbDesc<DScanDnf> d_desc(ctx);
+   if (in->n_rows) LDB_TRY(d_desc.upload(hp.get(), sizeof(DScanDnf)));
+   DScanDnf* d = d_desc.p;
    uint32_t* sel;
    uint64_t total;
    const int32_t st = scan_run_with(
@@ -279,7 +281,7 @@ extern "C" int32_t ldb_gpu_scan_filter_dnf(ldb_ctx* ctx, ldb_rel* in, const ldb_
          return LDB_OK;
       },
       &sel, &total);
-   ldb_dev_free(ctx, d);
+   d_desc.release();
    LDB_TRY(st);
    return ldb_rel_select(ctx, in, sel, (int64_t) total, out);
 }
@@ -353,8 +355,9 @@ extern "C" int32_t ldb_gpu_scan_count(ldb_ctx* ctx, ldb_rel* in, const ldb_filte
    LDB_TRY(build_scan_desc(in, preds, n_preds, &h));
    for (auto& dp : in->pending) h.preds[h.n_preds++] = dp; // a lazy input's own conjuncts, fused
    ldb_order_preds(h.preds, h.n_preds);
-   DScan* d;
-   LDB_TRY(ldb_dev_upload(ctx, &h, sizeof(h), (void**) &d));
+   LdbDesc<DScan> d_desc(ctx);
+   LDB_TRY(d_desc.upload(&h, sizeof(h)));
+   DScan* d = d_desc.p;
    uint64_t* d_cnt; // (a zeroed arena word: no clear of its own)
    LDB_TRY(ldb_counters(ctx, 1, &d_cnt));
    if (in->n_rows) {
@@ -378,7 +381,7 @@ extern "C" int32_t ldb_gpu_scan_count(ldb_ctx* ctx, ldb_rel* in, const ldb_filte
    LDB_HIP(hipGetLastError());
    uint64_t total = 0;
    LDB_TRY(ldb_read_u64(ctx, d_cnt, &total));
-   ldb_dev_free(ctx, d);
+   d_desc.release();
    *count = (int64_t) total;
    return LDB_OK;
 }

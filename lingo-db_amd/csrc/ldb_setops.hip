@@ -512,9 +512,9 @@ extern "C" int32_t ldb_gpu_window(ldb_ctx* ctx, ldb_rel* in, const ldb_colref* p
          d->tree_ok[f] = (uint64_t) to;
       }
    }
-   DWindow* dd;
-   LDB_TRY(ldb_dev_upload(ctx, d.get(), sizeof(DWindow), (void**) &dd));
-   bufs.ptrs.push_back(dd);
+   LdbDesc<DWindow> dd_desc(ctx);
+   LDB_TRY(dd_desc.upload(d.get(), sizeof(DWindow)));
+   DWindow* dd = dd_desc.p;
    {
       LdbProf prof_(ctx, "k_segtree_build");
       hipLaunchKernelGGL(k_segtree_leaves, dim3(grid), dim3(256), 0, ctx->stream, (const DWindow*) dd);

@@ -340,9 +340,10 @@ static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint6
       memset(&h_state, 0, sizeof(h_state));
       h_state.rank = h_state.rank0 = k ? k - 1 : 0;
       h_state.cand = n;
-      SelState* state;
+      LdbDesc<SelState> state_desc(ctx);
       uint32_t* hist;
-      LDB_TRY(ldb_dev_upload(ctx, &h_state, sizeof(h_state), (void**) &state, false)); // (k_sel_pick updates it)
+      LDB_TRY(state_desc.upload(&h_state, sizeof(h_state), false)); // (k_sel_pick updates it)
+      SelState* state = state_desc.p;
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &hist, 4 * 256));
       LDB_HIP(hipMemsetAsync(hist, 0, 4 * 256, ctx->stream));
       // Passes stop as soon as what they leave — the rows below the k-th prefix + the rows sharing it — fits the one-workgroup sort (round 6: all
@@ -376,7 +377,7 @@ static int32_t sort_records(ldb_ctx* ctx, const uint64_t* keys, int words, uint6
       LDB_TRY(ldb_dev_alloc(ctx, (void**) &perm, 4 * (size_t) (m ? m : 1)));
       hipLaunchKernelGGL(k_sel_expand, dim3(grid), dim3(256), 0, ctx->stream, (const uint64_t*) bitmap, (const uint32_t*) off, perm, n_words, (uint64_t) (m ? m : 1));
       LDB_HIP(hipGetLastError());
-      ldb_dev_free(ctx, state);
+      state_desc.release();
       ldb_dev_free(ctx, hist);
       ldb_dev_free(ctx, bitmap);
       ldb_dev_free(ctx, pop);
@@ -444,12 +445,13 @@ static int32_t sort_perm(ldb_ctx* ctx, ldb_rel* in, const ldb_sort_spec* specs, 
    h->words = (off + 7) / 8;
    uint64_t* keys;
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &keys, 8 * (size_t) h->words * (size_t) (n ? n : 1)));
-   DSort* d;
-   LDB_TRY(ldb_dev_upload(ctx, h, sizeof(*h), (void**) &d));
+   LdbDesc<DSort> d_desc(ctx);
+   LDB_TRY(d_desc.upload(h, sizeof(*h)));
+   DSort* d = d_desc.p;
    if (n) hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, d, keys);
    LDB_HIP(hipGetLastError());
    LDB_TRY(sort_records(ctx, keys, h->words, n, k, perm_out));
-   ldb_dev_free(ctx, d);
+   d_desc.release();
    ldb_dev_free(ctx, keys);
    return LDB_OK;
 }
@@ -487,8 +489,9 @@ extern "C" int32_t ldb_gpu_partition(ldb_ctx* ctx, ldb_rel* in, const ldb_colref
    const uint64_t n = (uint64_t) in->n_rows;
    DKeys hk;
    LDB_TRY(ldb_make_dkeys(in, keys, n_keys, &hk));
-   DKeys* dk;
-   LDB_TRY(ldb_dev_upload(ctx, &hk, sizeof(hk), (void**) &dk));
+   LdbDesc<DKeys> dk_desc(ctx);
+   LDB_TRY(dk_desc.upload(&hk, sizeof(hk)));
+   DKeys* dk = dk_desc.p;
    uint64_t* ids;
    uint32_t* perm;
    unsigned long long* hist;
@@ -508,7 +511,7 @@ extern "C" int32_t ldb_gpu_partition(ldb_ctx* ctx, ldb_rel* in, const ldb_colref
    std::vector<unsigned long long> hh(256);
    LDB_TRY(LDB_READBACK(ctx, hh.data(), hist, 8 * 256));
    for (int p = 0; p < nparts; p++) counts[p] = (int64_t) hh[(size_t) p];
-   ldb_dev_free(ctx, dk);
+   dk_desc.release();
    ldb_dev_free(ctx, ids);
    ldb_dev_free(ctx, hist);
    ldb_rel* permuted;

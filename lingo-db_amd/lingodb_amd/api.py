@@ -799,7 +799,9 @@ class Context:
     def desc_cache_stats(self):
         h, m, b = C.c_int64(), C.c_int64(), C.c_int64()
         check(self.lib.ldb_gpu_desc_cache_stats(self.h, C.byref(h), C.byref(m), C.byref(b)))
-        return {"hits": h.value, "misses": m.value, "bytes": b.value}
+        held, under = C.c_int64(), C.c_int64()
+        check(self.lib.ldb_gpu_desc_cache_held(self.h, C.byref(held), C.byref(under)))
+        return {"hits": h.value, "misses": m.value, "bytes": b.value, "held": held.value, "underflows": under.value}
 
     def run_subop_dump(self, dump, tables, name="subop_dump", comm=None):
         """runs a query from the reference's sub-operator dump (tools/ct/mlir-subop-to-json.cpp output, text or path):

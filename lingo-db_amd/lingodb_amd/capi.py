@@ -255,6 +255,8 @@ GPU_API = {
     "ldb_gpu_comm_agree": (i32, [P, P, i32, C.POINTER(i32)]),
     "ldb_gpu_trace_stats": (i32, [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "ldb_gpu_desc_cache_stats": (i32, [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "ldb_gpu_desc_cache_held": (i32, [P, C.POINTER(i64), C.POINTER(i64)]),
+    "ldb_gpu_order_dependent_misses": (i64, []),
     "ldb_gpu_table_stamp": (u64, [P]),
     # include/ldb_tpchgen.h (device generator)
     "ldb_gpu_tpch_generate": (i32, [P, i32, i64, i32, i32, u64, i32, PP]),

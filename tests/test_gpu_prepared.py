@@ -117,6 +117,27 @@ def test_replay_is_used_and_descriptors_are_cached(ctx, world):
     plan.release()
 
 
+def test_no_operator_keeps_a_descriptor_reference(ctx, world):
+    """every operator gives its reference on a cached descriptor back when its call ends (LdbDesc, error returns included): between plans nothing
+    is held, so every entry can be evicted (`desc_cache_mb` is a bound) — and no reference was ever given back twice.  The open-addressing
+    builds' run-length flag (ldb_join.hip) never mis-speculated in this process either: that kind of replay miss is counted apart"""
+    db, runner = world
+    for q in (3, 9, 13, 18, 21):
+        plan = ctx.prepare_plan(runner.plan_text(q))
+        for _ in range(3):
+            plan.execute(runner.plan_inputs(q)).release()
+        plan.release()
+    st = ctx.desc_cache_stats()
+    assert st["held"] == 0 and st["underflows"] == 0, st
+    t = ctx.register("t_err", pa.table({"x": pa.array([1, 2, 3], pa.int32())}))
+    with pytest.raises(Exception):  # an operator that fails: still nothing held afterwards
+        ctx.run_plan(json.dumps({"name": "bad", "inputs": ["t"], "steps": [{"op": "scan", "table": "t", "out": "s"},
+                                 {"op": "filter", "in": "s", "preds": [{"col": "nope", "op": "LT", "value": 1}], "out": "result"}], "result": "result"}), {"t": t})
+    st = ctx.desc_cache_stats()
+    assert st["held"] == 0 and st["underflows"] == 0, st
+    assert ctx.lib.ldb_gpu_order_dependent_misses() == 0
+
+
 PLAN_COUNT = json.dumps({"name": "count_below", "inputs": ["t"], "steps": [
     {"op": "scan", "table": "t", "out": "s"}, {"op": "filter", "in": "s", "preds": [{"col": "x", "op": "LT", "value": 500}], "out": "f"},
     {"op": "materialize", "in": "f", "cols": ["i"], "out": "m"},

@@ -213,6 +213,7 @@ class Runner:
                 tot["host_issue_ms_per_replay"]["Q%d" % q] = round(st["issue_ms"] / st["replays"], 3)
                 tot["host_wait_ms_per_replay"]["Q%d" % q] = round(st["wait_ms"] / st["replays"], 3)
         tot["descriptor_cache"] = self.ctx.desc_cache_stats()
+        tot["order_dependent_misses"] = int(self.ctx.lib.ldb_gpu_order_dependent_misses())  # of `misses`: on the open-addressing build's run-length flag
         return tot
 
     def plan_inputs(self, q):
@@ -256,7 +257,14 @@ class Runner:
         return self.plans[q]
 
     def probe_microbench(self, reps=3):
-        """FK probe of l_orderkey into a table built on o_orderkey (100 % match), SURVEY §8(d)."""
+        """FK probe of l_orderkey into a table built on o_orderkey (100 % match), SURVEY §8(d).  With asynchronous specialisation (round 6) the
+        first launches of a new kernel shape run the generic kernels: one untimed pass first, then wait for the compiler — the bench lines of
+        round 6 up to run 25 timed the generic kernel here (8.7 ms where the specialised one takes 0.6)."""
+        self._probe_microbench_once(1)
+        _jit_wait()
+        return self._probe_microbench_once(reps)
+
+    def _probe_microbench_once(self, reps):
         from lingodb_amd import api, capi
 
         ctx, db = self.ctx, self.db
@@ -338,7 +346,11 @@ class Runner:
         from lingodb_amd import api, capi
 
         col = db.lineitem.col("l_extendedprice")
+        col4 = db.lineitem.col("l_shipdate")
         lrel = db.lineitem.rel()
+        for c in (col, col4):  # (asynchronous specialisation: the first launch of a shape runs the generic kernel — one untimed call each, then wait)
+            lrel.scan_count([api.pred((0, c), capi.F_GTE, 0)])
+        _jit_wait()
         ctx.prof_reset()
         for _ in range(reps):
             lrel.scan_count([api.pred((0, col), capi.F_GTE, 0)])
@@ -349,7 +361,6 @@ class Runner:
             out["scan_count_ms"] = round(ms_s / n_s, 4)
         # the same over a 4-byte column (second PMC calibration point: dword loads)
         ctx.prof_reset()
-        col4 = db.lineitem.col("l_shipdate")
         for _ in range(reps):
             lrel.scan_count([api.pred((0, col4), capi.F_GTE, 0)])
         n_s, ms_s = ctx.prof_all().get("k_scan_count", (0, 0.0))
