@@ -42,7 +42,7 @@ int64_t ldb_option(const char* name, int64_t dflt) {
 }
 extern "C" int32_t ldb_gpu_set_option(const char* name, int64_t value) {
    if (!name) LDB_FAIL(LDB_ERR_INVALID, "set_option: NULL name");
-   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass", "lazy_strings", "lazy_strings_min_rows", "gb_partition_wc", "join_radix_wc", "join_radix_lds", "gb_dense_out", "gb_partition_values", "join_pair32", "gb_dense_keys", "jit_async", "jit_threads", "jit_disk_cache", "join_all_match", "topk_short_select", "gb_fits64", "join_coarse_fine", "join_coarse_filtered", "compact_wide_tiles"};
+   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass", "lazy_strings", "lazy_strings_min_rows", "gb_partition_wc", "join_radix_wc", "join_radix_lds", "gb_dense_out", "gb_partition_values", "join_pair32", "gb_dense_keys", "jit_async", "jit_threads", "jit_disk_cache", "join_all_match", "topk_short_select", "gb_fits64", "join_coarse_fine", "join_coarse_filtered", "compact_wide_tiles", "compact_max_words"};
    bool ok = false;
    for (const char* k : known) ok |= strcmp(k, name) == 0;
    if (!ok) LDB_FAIL(LDB_ERR_INVALID, "set_option: unknown option '%s'", name);
@@ -2265,8 +2265,10 @@ int32_t ldb_bitmap_compact(ldb_ctx* ctx, const uint64_t* bitmap, int64_t n_words
       if (d_total) LDB_HIP(hipMemsetAsync(d_total, 0, 8, ctx->stream));
       return LDB_OK;
    }
-   const int64_t wide = ldb_option("compact_wide_tiles", 1);
-   const int items = wide && n_words >= 2048ll * 256 * 8 ? 8 : wide && n_words >= 2048ll * 256 * 4 ? 4 : 2;
+   const int64_t wide = ldb_option("compact_wide_tiles", 1); // 0 = two words per thread always, 1 = the default floor of 2 048 tiles, n > 1 = that floor
+   const int64_t floor_tiles = wide > 1 ? wide : 2048;
+   const int64_t most = ldb_option("compact_max_words", 8);
+   const int items = !wide ? 2 : n_words >= floor_tiles * 256 * 16 && most >= 16 ? 16 : n_words >= floor_tiles * 256 * 8 ? 8 : n_words >= floor_tiles * 256 * 4 ? 4 : 2;
    const uint64_t n_tiles = ((uint64_t) n_words + 256u * items - 1) / (256u * items);
    ChainCall c;
    LDB_TRY(ldb_chain_begin(ctx, n_tiles, false, &c));
@@ -2274,7 +2276,8 @@ int32_t ldb_bitmap_compact(ldb_ctx* ctx, const uint64_t* bitmap, int64_t n_words
 #define LDB_BC_LAUNCH(I) \
    hipLaunchKernelGGL(k_bitmap_compact<I>, dim3((unsigned) n_tiles), dim3(256), 0, ctx->stream, bitmap, (uint64_t) n_words, n_tiles, out, cap, match, second, (unsigned long long*) d_total, c.status, \
                       c.ticket, c.ticket_base, c.epoch)
-   if (items == 8) LDB_BC_LAUNCH(8);
+   if (items == 16) LDB_BC_LAUNCH(16);
+   else if (items == 8) LDB_BC_LAUNCH(8);
    else if (items == 4) LDB_BC_LAUNCH(4);
    else LDB_BC_LAUNCH(2);
 #undef LDB_BC_LAUNCH
