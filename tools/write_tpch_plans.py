@@ -157,12 +157,12 @@ PLANS[5] = dict(ref="resources/sql/tpch/5.sql", inputs=["customer", "orders", "l
                     mat("gs", ["n_name", "revenue"])])
 
 PLANS[7] = dict(ref="resources/sql/tpch/7.sql", inputs=["customer", "orders", "lineitem", "supplier", "nation"],
-                doc="(n1 = A and n2 = B) or (n1 = B and n2 = A) = both nations in {A, B} (pushed into the two dimension tables) and n1 <> n2 (a residual column-vs-column conjunct); orders probe the reduced lineitem side",
+                doc="(n1 = A and n2 = B) or (n1 = B and n2 = A) = both nations in {A, B} (pushed into the two dimension tables) and n1 <> n2 (a residual column-vs-column conjunct); the orders of the two nations' customers (8 %) are the UNIQUE build side the reduced lineitem side probes (round 6: 150 M orders probing a non-unique table of the lineitem side cost 3.6 ms of pair counting, pairs and build, and the lineitem side was materialised for it)",
                 steps=members("customer", "c_custkey", "c_nationkey", "custs", [f("n_name", "IN", values=["FRANCE", "GERMANY"])]) +
                 members("supplier", "s_suppkey", "s_nationkey", "supps", [f("n_name", "IN", values=["FRANCE", "GERMANY"])]) + [
                     scan_filter("lineitem", "l1", [f("l_shipdate", "GTE", "1995-01-01"), f("l_shipdate", "LTE", "1996-12-31")]), build("supps", ["s_suppkey"], "hs"),
-                    probe("hs", "l1", ["l_suppkey"], "ls"), mat("ls", ["l_orderkey", "l_shipdate", "l_extendedprice", "l_discount", "s_nationkey"], "m"),
-                    build("m", ["l_orderkey"], "hm", unique=False), probe("hm", "orders", ["o_orderkey"], "om"), build("custs", ["c_custkey"], "hc"), probe("hc", "om", ["o_custkey"], "omc"),
+                    probe("hs", "l1", ["l_suppkey"], "ls"), build("custs", ["c_custkey"], "hc"), probe("hc", "orders", ["o_custkey"], "oc"),
+                    build("oc", ["o_orderkey"], "ho"), probe("ho", "ls", ["l_orderkey"], "omc"),
                     scan_filter("omc", "diff", [f("s_nationkey", "NEQ", rhs_col="c_nationkey")]),
                     {"op": "map", "in": "diff", "fn": "extract_year", "col": "l_shipdate", "as": "l_year", "out": "dy"},
                     groupby("dy", ["s_nationkey", "c_nationkey", "l_year"], [agg("sum", REV, "volume")], "partial", est=16), build("nation", ["n_nationkey"], "hn"),
@@ -171,12 +171,11 @@ PLANS[7] = dict(ref="resources/sql/tpch/7.sql", inputs=["customer", "orders", "l
                     sort("g", ["supp_nation", "cust_nation", "l_year"], "gs"), mat("gs", ["supp_nation", "cust_nation", "l_year", "revenue"])])
 
 PLANS[8] = dict(ref="resources/sql/tpch/8.sql", inputs=["part", "supplier", "lineitem", "orders", "customer", "nation", "region"],
-                doc="the part-type filter keeps 1/150 of part and reduces lineitem first; two years of orders probe the reduced lineitem side; customers of the region are a semi join; the CASE is a conditional SUM on the supplier's nation name",
+                doc="the part-type filter keeps 1/150 of part and reduces lineitem first; two years of orders, semi-joined with the customers of the region, are the UNIQUE build side the reduced lineitem side probes (round 6, as in Q7); the CASE is a conditional SUM on the supplier's nation name",
                 steps=[scan_filter("part", "p1", [f("p_type", "EQ", "ECONOMY ANODIZED STEEL")]), mat("p1", ["p_partkey"], "parts")] + members("customer", "c_custkey", "c_nationkey", "custs", None, "AMERICA") + [
                     build("parts", ["p_partkey"], "hp"), probe("hp", "lineitem", ["l_partkey"], "lp", "semi"), build("supplier", ["s_suppkey"], "hs"), probe("hs", "lp", ["l_suppkey"], "ls"),
-                    mat("ls", ["l_orderkey", "l_extendedprice", "l_discount", "s_nationkey"], "m"),
-                    scan_filter("orders", "o1", [f("o_orderdate", "GTE", "1995-01-01"), f("o_orderdate", "LTE", "1996-12-31")]), build("m", ["l_orderkey"], "hm", unique=False),
-                    probe("hm", "o1", ["o_orderkey"], "om"), build("custs", ["c_custkey"], "hc"), probe("hc", "om", ["o_custkey"], "omc", "semi"), build("nation", ["n_nationkey"], "hn"),
+                    scan_filter("orders", "o1", [f("o_orderdate", "GTE", "1995-01-01"), f("o_orderdate", "LTE", "1996-12-31")]), build("custs", ["c_custkey"], "hc"),
+                    probe("hc", "o1", ["o_custkey"], "oc", "semi"), build("oc", ["o_orderkey"], "ho"), probe("ho", "ls", ["l_orderkey"], "omc"), build("nation", ["n_nationkey"], "hn"),
                     probe("hn", "omc", ["s_nationkey"], "omn"), {"op": "map", "in": "omn", "fn": "extract_year", "col": "o_orderdate", "as": "o_year", "out": "oy"},
                     groupby("oy", ["o_year"], [agg("sum", REV, "brazil", when=[f("n_name", "EQ", "BRAZIL")]), agg("sum", REV, "total")], "g", est=8),
                     {"op": "map", "in": "g", "expr": {"div": ["brazil", "total"]}, "as": "mkt_share", "out": "gz"}, sort("gz", ["o_year"], "gs"), mat("gs", ["o_year", "mkt_share"])])
@@ -221,8 +220,13 @@ def dump_step(st):
     return json.dumps(st, ensure_ascii=False)
 
 
+HAND_MAINTAINED = {9}  # q9.json was re-ordered by hand in round 4 (the lines probe the orders primary-key index): this script leaves it alone
+
+
 def main():
     for q, p in sorted(PLANS.items()):
+        if q in HAND_MAINTAINED:
+            continue
         head = {"name": "tpch_q%d" % q, "ref": p["ref"], "doc": p["doc"], "inputs": p["inputs"]}
         lines = ["{" + json.dumps(head, ensure_ascii=False)[1:-1] + ",", ' "steps": [']
         lines += ["  " + dump_step(s) + ("," if i + 1 < len(p["steps"]) else "") for i, s in enumerate(p["steps"])]
@@ -230,7 +234,7 @@ def main():
         with open(os.path.join(OUT, "q%d.json" % q), "w") as f:
             f.write("\n".join(lines) + "\n")
         json.load(open(os.path.join(OUT, "q%d.json" % q)))
-    print("wrote", sorted(PLANS))
+    print("wrote", sorted(set(PLANS) - HAND_MAINTAINED))
 
 
 if __name__ == "__main__":
