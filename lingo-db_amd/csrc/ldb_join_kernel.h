@@ -119,7 +119,7 @@ __device__ __forceinline__ void d_stage_coarse(const DJoin& m, const DJoin* __re
 // (has_coarse holds the filter's granularity: 6 = one bit per 64 key values, the <= 40 KB form; 5 / 4 = one per 32 / 16 — round 6: up to 156 KB, one
 // 1024-thread workgroup per CU, for builds too dense for 64-key blocks to be empty — Q9's green parts, 5.4 % of the key range)
 __device__ __forceinline__ bool d_coarse_hit(const DJoin& m, uint32_t r) {
-   const uint32_t s = (uint32_t) m.has_coarse;
+   const uint32_t s = (uint32_t) m.has_coarse & 31u; // (has_coarse = 32 | log2 of the key values per bit: non-zero also for the exact filter)
    return (ldb_join_lds[r >> (s + 5u)] >> ((r >> s) & 31u)) & 1u;
 }
 __device__ __forceinline__ bool d_probe_pass(const DJoin& m, const DJoin* __restrict__ d, uint64_t i) {

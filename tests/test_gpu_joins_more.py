@@ -269,3 +269,40 @@ def test_dense_unique_build_gets_the_fine_lds_filter(ctx, fine):
     finally:
         lib.ldb_gpu_set_option(b"join_coarse_fine", 1)
         lib.ldb_gpu_set_option(b"debug_check", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("keyspace,share", [(1_000_000, 25), (400_000, 12), (100_000, 4)])
+def test_small_key_range_gets_the_finest_lds_filter_that_fits(ctx, keyspace, share):
+    """round 6: where the key range is small enough (a supplier-sized table), the LDS key filter takes the finest granularity that fits 16 KB — 8, 4 … 1
+    key values per bit (1 = the presence bits themselves) — and rides along with the filtered (tile) probes too: unfiltered and filtered probes of every
+    kind against numpy, with the row-id checks on; the same with the option off (16 keys per bit)"""
+    lib = capi.gpu_lib()
+    rng = np.random.default_rng(31 + share)
+    bkeys = np.sort(rng.choice(keyspace, keyspace // share, replace=False)).astype(np.int32) + 5
+    pkeys = rng.integers(0, keyspace + 300, 5_000_000).astype(np.int32)
+    flag = rng.integers(0, 4, len(pkeys)).astype(np.int32)
+    b = ctx.register("finest_b_%d" % keyspace, pa.table({"k": pa.array(bkeys)}))
+    p = ctx.register("finest_p_%d" % keyspace, pa.table({"k": pa.array(pkeys), "f": pa.array(flag)}))
+    idx = np.searchsorted(bkeys, pkeys)
+    hit = (idx < len(bkeys)) & (bkeys[np.minimum(idx, len(bkeys) - 1)] == pkeys)
+    lib.ldb_gpu_set_option(b"debug_check", 1)
+    try:
+        for finest in (1, 0):
+            lib.ldb_gpu_set_option(b"join_coarse_finest", finest)
+            ht = b.rel().join_build([(0, 0)], unique=True)
+            rows = np.nonzero(hit)[0]
+            assert ht.probe_count(p.rel(), [(0, 0)]) == len(rows)
+            assert np.array_equal(ht.probe(p.rel(), [(0, 0)], capi.JOIN_SEMI).rowids(0), rows)
+            assert np.array_equal(ht.probe(p.rel(), [(0, 0)], capi.JOIN_ANTI).rowids(0), np.nonzero(~hit)[0])
+            inner = ht.probe(p.rel(), [(0, 0)])
+            assert np.array_equal(inner.rowids(0), rows) and np.array_equal(inner.rowids(1), idx[rows].astype(np.uint32))
+            lazy = p.rel().scan_filter([api.pred((0, 1), capi.F_EQ, 2)])  # >= 1 M rows: stays lazy, the probe runs the tile kernels
+            frows = np.nonzero(hit & (flag == 2))[0]
+            finner = ht.probe(lazy, [(0, 0)])
+            assert np.array_equal(finner.rowids(0), frows) and np.array_equal(finner.rowids(1), idx[frows].astype(np.uint32))
+            assert np.array_equal(ht.probe(lazy, [(0, 0)], capi.JOIN_SEMI).rowids(0), frows)
+            ht.release()
+    finally:
+        lib.ldb_gpu_set_option(b"join_coarse_finest", 1)
+        lib.ldb_gpu_set_option(b"debug_check", 0)
