@@ -86,7 +86,7 @@ bool ldb_scan_jit_check(std::string* log) {
 // Expand the bitmap into ascending row ids.  Each wave walks its words; the lane whose bit is
 // set writes its row id at block_offset + (#set bits in earlier words) + rank within the word.
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_expand(const uint64_t* __restrict__ bitmap, const uint32_t* __restrict__ block_offsets,
-                                                            uint32_t* __restrict__ out_rows, uint64_t n_rows, uint64_t cap) {
+                                                            uint32_t* __restrict__ out_rows, uint64_t n_rows, uint64_t cap, uint32_t parts) {
    __shared__ uint32_t s_pop[SCAN_WORDS_PER_BLOCK];
    const uint64_t word0 = (uint64_t) blockIdx.x * SCAN_WORDS_PER_BLOCK;
    const uint64_t n_words = (n_rows + 63) / 64;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_expand(const uint64_t* __re
    s_pop[threadIdx.x] = excl;
    __syncthreads();
    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-   const uint32_t base = block_offsets[blockIdx.x];
+   const uint32_t base = block_offsets[blockIdx.x * parts]; // (the scan kernels count per part of a zone: the first part's offset is the zone's)
    // entries behind the real count (cap is larger only when it came from a replayed count that no longer holds) must
    // still be row numbers: the consumer is already queued
    if (blockIdx.x == gridDim.x - 1)
@@ -176,16 +176,20 @@ static int32_t scan_run_with(ldb_ctx* ctx, int64_t n, LAUNCH launch, uint32_t** 
       *total_out = 0;
       return LDB_OK;
    }
+   // a short input is cut finer than one workgroup per 16 384 rows: 2 … 16 workgroups share a zone (the kernels read the split from gridDim.y)
+   unsigned parts = 1;
+   if (ldb_option("scan_split", 1) != 0)
+      while (parts < 16 && n_blocks * parts < 2048) parts *= 2;
    uint64_t* bitmap;
    uint32_t *counts, *offsets;
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &bitmap, sizeof(uint64_t) * (size_t) n_words));
-   LDB_TRY(ldb_dev_alloc(ctx, (void**) &counts, sizeof(uint32_t) * (size_t) n_blocks));
-   LDB_TRY(ldb_dev_alloc(ctx, (void**) &offsets, sizeof(uint32_t) * (size_t) n_blocks));
-   LDB_TRY(launch(bitmap, counts, (unsigned) n_blocks));
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &counts, sizeof(uint32_t) * (size_t) n_blocks * parts));
+   LDB_TRY(ldb_dev_alloc(ctx, (void**) &offsets, sizeof(uint32_t) * (size_t) n_blocks * parts));
+   LDB_TRY(launch(bitmap, counts, (unsigned) n_blocks, parts));
    LDB_HIP(hipGetLastError());
    uint64_t* d_total;
    LDB_TRY(ldb_counters(ctx, 1, &d_total));
-   LDB_TRY(ldb_exclusive_scan_u32(ctx, counts, offsets, n_blocks, d_total));
+   LDB_TRY(ldb_exclusive_scan_u32(ctx, counts, offsets, n_blocks * parts, d_total));
    uint64_t total = 0;
    // (the read-back's identity includes the scanned row count: a scan that ran in the recorded execution and is skipped now — a dictionary
    // predicate whose code set is cached by then — must not hand ITS count to the next scan of the plan; a different identity makes the replay
@@ -193,7 +197,7 @@ static int32_t scan_run_with(ldb_ctx* ctx, int64_t n, LAUNCH launch, uint32_t** 
    // the whole execution at the final comparison: 7 of the 22 queries paid that once during warm-up)
    LDB_TRY(ldb_read_u64_at(ctx, d_total, &total, ldb_site_derived(LDB_SITE, (uint32_t) n), 0));
    LDB_TRY(ldb_dev_alloc(ctx, (void**) &sel, sizeof(uint32_t) * (size_t) (total ? total : 1)));
-   if (total) hipLaunchKernelGGL(k_scan_expand, dim3((unsigned) n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, bitmap, offsets, sel, (uint64_t) n, total);
+   if (total) hipLaunchKernelGGL(k_scan_expand, dim3((unsigned) n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, bitmap, offsets, sel, (uint64_t) n, total, (uint32_t) parts);
    LDB_HIP(hipGetLastError());
    ldb_dev_free(ctx, bitmap);
    ldb_dev_free(ctx, counts);
@@ -211,9 +215,13 @@ static int32_t scan_run(ldb_ctx* ctx, ldb_rel* in, const DScan& h, uint32_t** se
    DScan* d = d_desc.p;
    const int32_t st = scan_run_with(
       ctx, n,
-      [&](uint64_t* bitmap, uint32_t* counts, unsigned n_blocks) -> int32_t {
+      [&](uint64_t* bitmap, uint32_t* counts, unsigned n_blocks, unsigned parts) -> int32_t {
          hipFunction_t spec = nullptr;
-         if (ldb_jit_wanted(n)) {
+         // a LIKE is specialised from far fewer rows on (round 6): with its pattern as compile-time constants the matcher is ~50 x the generic one per
+         // row — Q16's '%Customer%Complaints%' over 1 M supplier comments took 1.13 ms generic, the 150 M comments of Q13 take 3.3 ms specialised
+         bool has_like = false;
+         for (int p = 0; p < h.n_preds; p++) has_like = has_like || h.preds[p].op == LDB_F_LIKE || h.preds[p].op == LDB_F_NOT_LIKE;
+         if (ldb_jit_wanted(n) || (has_like && ldb_option("jit", 1) != 0 && n >= ldb_option("jit_min_rows_like", 65536))) {
             DScan meta;
             scan_meta(&h, &meta);
             std::string why;
@@ -222,9 +230,9 @@ static int32_t scan_run(ldb_ctx* ctx, ldb_rel* in, const DScan& h, uint32_t** se
          LdbProf prof_(ctx, "k_scan_bitmap");
          if (spec) {
             void* params[] = {(void*) &d, (void*) &bitmap, (void*) &counts};
-            LDB_HIP(hipModuleLaunchKernel(spec, n_blocks, 1, 1, SCAN_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
+            LDB_HIP(hipModuleLaunchKernel(spec, n_blocks, parts, 1, SCAN_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
          } else {
-            hipLaunchKernelGGL(k_scan_bitmap, dim3(n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, d, bitmap, counts);
+            hipLaunchKernelGGL(k_scan_bitmap, dim3(n_blocks, parts), dim3(SCAN_BLOCK), 0, ctx->stream, d, bitmap, counts);
          }
          return LDB_OK;
       },
@@ -261,7 +269,7 @@ extern "C" int32_t ldb_gpu_scan_filter_dnf(ldb_ctx* ctx, ldb_rel* in, const ldb_
    uint64_t total;
    const int32_t st = scan_run_with(
       ctx, in->n_rows,
-      [&](uint64_t* bitmap, uint32_t* counts, unsigned n_blocks) -> int32_t {
+      [&](uint64_t* bitmap, uint32_t* counts, unsigned n_blocks, unsigned parts) -> int32_t {
          hipFunction_t spec = nullptr;
          if (ldb_jit_wanted(in->n_rows)) { // the clause structure and every conjunct's type / operator / constant as compile-time constants
             auto meta = std::make_unique<DScanDnf>();
@@ -274,9 +282,9 @@ extern "C" int32_t ldb_gpu_scan_filter_dnf(ldb_ctx* ctx, ldb_rel* in, const ldb_
          LdbProf prof_(ctx, "k_scan_bitmap_dnf");
          if (spec) {
             void* params[] = {(void*) &d, (void*) &bitmap, (void*) &counts};
-            LDB_HIP(hipModuleLaunchKernel(spec, n_blocks, 1, 1, SCAN_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
+            LDB_HIP(hipModuleLaunchKernel(spec, n_blocks, parts, 1, SCAN_BLOCK, 1, 1, 0, ctx->stream, params, nullptr));
          } else {
-            hipLaunchKernelGGL(k_scan_bitmap_dnf, dim3(n_blocks), dim3(SCAN_BLOCK), 0, ctx->stream, (const DScanDnf*) d, bitmap, counts);
+            hipLaunchKernelGGL(k_scan_bitmap_dnf, dim3(n_blocks, parts), dim3(SCAN_BLOCK), 0, ctx->stream, (const DScanDnf*) d, bitmap, counts);
          }
          return LDB_OK;
       },

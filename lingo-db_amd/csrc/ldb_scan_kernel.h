@@ -42,7 +42,11 @@ __device__ __forceinline__ void scan_bitmap_body(const DScan& m, const DScan* __
                                                  uint32_t* __restrict__ block_counts, uint32_t* s_cnt) {
    const uint64_t n = d->n_rows;
    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-   const uint64_t word0 = (uint64_t) blockIdx.x * SCAN_WORDS_PER_BLOCK;
+   // (round 6: a short input is cut finer — gridDim.y = 2 … 16 workgroups share a zone's 256 words, so that 1 M rows are 976 workgroups instead of
+   // 61 whose waves each walk 64 words one after the other: Q16's LIKE over the supplier comments took 1.1 ms that way)
+   const uint32_t wpb = SCAN_WORDS_PER_BLOCK / gridDim.y;
+   const uint64_t word0 = (uint64_t) blockIdx.x * SCAN_WORDS_PER_BLOCK + (uint64_t) blockIdx.y * wpb;
+   const uint32_t block_slot = blockIdx.x * gridDim.y + blockIdx.y;
    // zone maps: this block's 16 384 rows are exactly one zone; if a conjunct's zone cannot match, the block is all zeros
    static_assert(SCAN_WORDS_PER_BLOCK * 64 == LDB_ZONE_ROWS, "one scan block per zone");
    {
@@ -52,15 +56,15 @@ __device__ __forceinline__ void scan_bitmap_body(const DScan& m, const DScan* __
          if (p < m.n_preds && m.preds[p].zmin && d_pred_is_simple(m.preds[p]))
             excluded = excluded || !d_zone_may_pass(m.preds[p].op, gptr<int64_t>(d->preds[p].zmin)[blockIdx.x], gptr<int64_t>(d->preds[p].zmax)[blockIdx.x], (int64_t) m.preds[p].lo);
       if (excluded) { // (block-uniform)
-         for (uint32_t w = threadIdx.x; w < SCAN_WORDS_PER_BLOCK; w += SCAN_BLOCK)
+         for (uint32_t w = threadIdx.x; w < wpb; w += SCAN_BLOCK)
             if ((word0 + w) * 64 < n) bitmap[word0 + w] = 0;
-         if (threadIdx.x == 0) block_counts[blockIdx.x] = 0;
+         if (threadIdx.x == 0) block_counts[block_slot] = 0;
          return;
       }
    }
    uint32_t cnt = 0;
    constexpr uint32_t WPW = SCAN_BLOCK / LDB_WAVE; // waves per block
-   for (uint32_t w = wave; w < SCAN_WORDS_PER_BLOCK; w += 4 * WPW) {
+   for (uint32_t w = wave; w < wpb; w += 4 * WPW) { // (wpb is a multiple of 4 * WPW = 16)
       bool pass[4];
       uint64_t rows[4];
 #pragma unroll
@@ -81,7 +85,7 @@ __device__ __forceinline__ void scan_bitmap_body(const DScan& m, const DScan* __
    if (threadIdx.x == 0) {
       uint32_t t = 0;
       for (int k = 0; k < SCAN_BLOCK / LDB_WAVE; k++) t += s_cnt[k];
-      block_counts[blockIdx.x] = t;
+      block_counts[block_slot] = t;
    }
 }
 
@@ -140,9 +144,10 @@ __device__ __forceinline__ void scan_bitmap_dnf_body(const DScanDnf& m, const DS
                                                      uint32_t* s_cnt) {
    const uint64_t n = d->n_rows;
    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-   const uint64_t word0 = (uint64_t) blockIdx.x * SCAN_WORDS_PER_BLOCK;
+   const uint32_t wpb = SCAN_WORDS_PER_BLOCK / gridDim.y; // (see scan_bitmap_body)
+   const uint64_t word0 = (uint64_t) blockIdx.x * SCAN_WORDS_PER_BLOCK + (uint64_t) blockIdx.y * wpb;
    uint32_t cnt = 0;
-   for (uint32_t w = wave; w < SCAN_WORDS_PER_BLOCK; w += SCAN_BLOCK / LDB_WAVE) {
+   for (uint32_t w = wave; w < wpb; w += SCAN_BLOCK / LDB_WAVE) {
       const uint64_t i = (word0 + w) * 64 + lane;
       const bool pass = i < n && d_eval_dnf(m, d, i);
       const uint64_t mask = __ballot(pass);
@@ -154,6 +159,6 @@ __device__ __forceinline__ void scan_bitmap_dnf_body(const DScanDnf& m, const DS
    if (threadIdx.x == 0) {
       uint32_t t = 0;
       for (int k = 0; k < SCAN_BLOCK / LDB_WAVE; k++) t += s_cnt[k];
-      block_counts[blockIdx.x] = t;
+      block_counts[blockIdx.x * gridDim.y + blockIdx.y] = t;
    }
 }
