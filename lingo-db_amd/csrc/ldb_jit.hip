@@ -52,7 +52,10 @@ static bool g_stop = false;
 static int64_t g_compiled = 0, g_hits = 0, g_disk_hits = 0, g_disk_writes = 0, g_failed = 0, g_async_misses = 0;
 static double g_compile_ms = 0;
 
-bool ldb_jit_wanted(int64_t n_rows) { return ldb_option("jit", 1) != 0 && n_rows >= ldb_option("jit_min_rows", 4000000); }
+// (round 6: from 256 K rows on — 4 M until then.  With compilation off the critical path and the code objects on disk the threshold only decides
+// how many shapes the compiler sees: 94 instead of 80 over the 22 TPC-H plans, + 35 s of background compilation on a cold start, for Q11 1.41 → 1.14,
+// Q17 1.92 → 1.70, Q20 3.62 → 3.29, Q3 4.49 → 4.22 ms — geomean 3.70 → 3.57 ms; `tools/r06_run36.sh`.  The test suite pins 4 M: tests/conftest.py.)
+bool ldb_jit_wanted(int64_t n_rows) { return ldb_option("jit", 1) != 0 && n_rows >= ldb_option("jit_min_rows", 262144); }
 
 // 64-bit content hash, eight bytes per step (a lookup hashes a whole descriptor — up to 16 KB — on every operator call; one
 // byte per step was 20 µs of host time per group-by)

@@ -19,6 +19,7 @@ SPEC_MODULES = {"test_gpu_parity", "test_gpu_joins_more", "test_gpu_tpch_more", 
 # GPU suite: specialisations compile synchronously, so that the 'spec' passes below launch the specialised kernels on their FIRST call (the library
 # default — jit_async = 1 — answers "still compiling" and launches the generic kernel; tests/test_gpu_jit_async.py covers that mode)
 os.environ.setdefault("LDB_JIT_ASYNC", "0")
+os.environ.setdefault("LDB_JIT_MIN_ROWS", "4000000")  # the library default is 256 K rows since round 6: at test sizes that would compile hundreds of shapes one after the other
 
 try:  # torch first: it ships its own HIP runtime / RCCL copies, which must be the ones the process binds (see api.Comm)
     import torch  # noqa: F401
