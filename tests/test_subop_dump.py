@@ -141,7 +141,10 @@ def test_q12_conditional_aggregates_equal_the_hand_plan():
     assert [s["op"] for s in got] == [s["op"] for s in want]
     strip = lambda a: {k: v for k, v in a.items() if k != "as"}
     assert [strip(a) for a in got[3]["aggs"]] == [strip(a) for a in want[3]["aggs"]]
-    assert got[0]["preds"] == want[0]["preds"] and got[1]["keys"] == want[1]["keys"] and got[1]["unique"] is False
+    assert got[0]["preds"] == want[0]["preds"]
+    # the join's direction differs since round 6: the reference's optimiser builds on the few late lineitems (non-unique) and lets the orders probe; the
+    # hand plan lets those lineitems probe the orders primary-key index
+    assert got[1]["keys"] == ["l_orderkey"] and got[1]["unique"] is False and want[1]["keys"] == ["o_orderkey"] and want[1]["unique"] is True
     assert got[3]["keys"] == ["l_shipmode"] and got[4]["by"] == ["l_shipmode"]
 
 
