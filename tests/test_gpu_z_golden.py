@@ -80,7 +80,7 @@ def test_device_like_vs_reference_string_runtime(ctx):
     multi-byte characters, % and _ runs, escapes and the reference's quirks"""
     cases = golden_io.like_cases()[:700]
     if capi.gpu_lib().ldb_gpu_get_option(b"jit_min_rows") == 0:
-        cases = cases[:260]  # specialised mode compiles one scan kernel per pattern (hiprtc, ≈ 0.5 s each): a third of the patterns there
+        cases = cases[:130]  # specialised mode compiles one scan kernel per pattern (hiprtc, ≈ 1 s each — 238 s for 260 at the end of round 6): a fifth of the patterns there
     subjects = pa.table({"s": pa.array([s for s, _, _ in cases], pa.string())})
     rel = ctx.register("golden_like", subjects).rel()
     by_pattern = {}
