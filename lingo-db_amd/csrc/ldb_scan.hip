@@ -224,6 +224,7 @@ static int32_t scan_run(ldb_ctx* ctx, ldb_rel* in, const DScan& h, uint32_t** se
          if (ldb_jit_wanted(n) || (has_like && ldb_option("jit", 1) != 0 && n >= ldb_option("jit_min_rows_like", 65536))) {
             DScan meta;
             scan_meta(&h, &meta);
+            meta.n_rows = parts > 1 ? 1 : 0; // (which of the two loop forms this specialisation is compiled for: ldb_scan_kernel.h)
             std::string why;
             spec = ldb_jit_kernel(ctx->device, "ldb_scan_kernel.h", "DScan", SCAN_SPEC_SRC, "k_scan_bitmap_spec", &meta, sizeof(meta), &why);
          }
@@ -274,7 +275,7 @@ extern "C" int32_t ldb_gpu_scan_filter_dnf(ldb_ctx* ctx, ldb_rel* in, const ldb_
          if (ldb_jit_wanted(in->n_rows)) { // the clause structure and every conjunct's type / operator / constant as compile-time constants
             auto meta = std::make_unique<DScanDnf>();
             memcpy(meta.get(), hp.get(), sizeof(DScanDnf));
-            meta->n_rows = 0;
+            meta->n_rows = parts > 1 ? 1 : 0; // (the loop form, as in scan_run)
             for (int p = 0; p < DNF_MAX_PREDS; p++) ldb_jit_strip_pred(meta->preds[p]);
             std::string why;
             spec = ldb_jit_kernel(ctx->device, "ldb_scan_kernel.h", "DScanDnf", DNF_SPEC_SRC, "k_scan_bitmap_dnf_spec", meta.get(), sizeof(DScanDnf), &why);

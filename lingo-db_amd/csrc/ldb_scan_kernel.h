@@ -82,8 +82,15 @@ __device__ __forceinline__ void scan_bitmap_body(const DScan& m, const DScan* __
          }
       }
    };
-   // the whole-zone form keeps its compile-time trip count (with a run-time bound the long scans lost a fifth: Q13's LIKE 3.3 → 4.1 ms)
-   if (gridDim.y == 1) words(SCAN_WORDS_PER_BLOCK);
+   // the whole-zone form keeps its compile-time trip count (with a run-time bound the long scans lost a fifth: Q13's LIKE 3.3 → 4.1 ms).  A
+   // specialised kernel is compiled for ONE of the two forms — the host says which in the metadata's n_rows (0 = whole zones, 1 = split; the row
+   // count itself is read from the run-time descriptor) — so that the conjunction is not generated twice
+#ifdef LDB_JIT_SPECIALIZED
+   const bool whole = m.n_rows == 0;
+#else
+   const bool whole = gridDim.y == 1;
+#endif
+   if (whole) words(SCAN_WORDS_PER_BLOCK);
    else words(wpb);
    if (lane == 0) s_cnt[wave] = cnt;
    __syncthreads();
@@ -161,7 +168,12 @@ __device__ __forceinline__ void scan_bitmap_dnf_body(const DScanDnf& m, const DS
          cnt += (uint32_t) __popcll(mask);
       }
    };
-   if (gridDim.y == 1) words(SCAN_WORDS_PER_BLOCK); // (compile-time trip count, as in scan_bitmap_body)
+#ifdef LDB_JIT_SPECIALIZED
+   const bool whole = m.n_rows == 0; // (as in scan_bitmap_body)
+#else
+   const bool whole = gridDim.y == 1;
+#endif
+   if (whole) words(SCAN_WORDS_PER_BLOCK);
    else words(wpb);
    if (lane == 0) s_cnt[wave] = cnt;
    __syncthreads();
