@@ -262,9 +262,9 @@ def main():
         return ms.value
 
     def jit_info():
-        vals = (_C.c_int64 * 8)()
-        _capi_jit.gpu_lib().ldb_gpu_jit_info(vals, 8)
-        return dict(zip(("compiled", "memory_hits", "disk_hits", "disk_writes", "outstanding", "failed", "answered_still_compiling", "worker_threads"), [int(v) for v in vals]))
+        vals = (_C.c_int64 * 9)()
+        _capi_jit.gpu_lib().ldb_gpu_jit_info(vals, 9)
+        return dict(zip(("compiled", "memory_hits", "disk_hits", "disk_writes", "outstanding", "failed", "answered_still_compiling", "worker_threads", "taken_from_peer_processes"), [int(v) for v in vals]))
 
     first_ms = {}
     jit_wait_s = 0.0

@@ -157,8 +157,9 @@ int32_t ldb_gpu_jit_compile_check(char* log, int32_t cap);
  * optimising one behind it (include/lingodb/execution/Execution.h:103-104, src/execution/baseline/).  Code objects are kept on disk under a
  * content hash ($LDB_JIT_CACHE_DIR, default ~/.cache/ldb_jit/<arch>/<hash>.co; option jit_disk_cache = 0 disables), so a second process start
  * compiles nothing.  ldb_gpu_jit_wait blocks until nothing is queued or compiling (timeout_ms < 0: no limit; *pending = still outstanding) — what a
- * benchmark calls between its first execution and its timed region.  ldb_gpu_jit_info: vals[0..8) = compiled here, in-memory hits, disk hits,
- * disk writes, outstanding, failed, calls answered "still compiling", worker threads. */
+ * benchmark calls between its first execution and its timed region.  ldb_gpu_jit_info: vals[0..9) = compiled here, in-memory hits, disk hits,
+ * disk writes, outstanding, failed, calls answered "still compiling", worker threads, code objects taken over from another process that was
+ * compiling the same shape (the ranks of a multi-GPU run share the work through claims in the disk cache; option jit_share_compiles). */
 int32_t ldb_gpu_jit_wait(int64_t timeout_ms, int64_t* pending);
 int32_t ldb_gpu_jit_info(int64_t* vals, int32_t n);
 /* stop the compile workers: queued specialisations are dropped, running ones finish.  Call before the process exits (the library also registers an

@@ -42,7 +42,7 @@ int64_t ldb_option(const char* name, int64_t dflt) {
 }
 extern "C" int32_t ldb_gpu_set_option(const char* name, int64_t value) {
    if (!name) LDB_FAIL(LDB_ERR_INVALID, "set_option: NULL name");
-   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass", "lazy_strings", "lazy_strings_min_rows", "gb_partition_wc", "join_radix_wc", "join_radix_lds", "gb_dense_out", "gb_partition_values", "join_pair32", "gb_dense_keys", "jit_async", "jit_threads", "jit_disk_cache", "join_all_match", "topk_short_select", "gb_fits64", "join_coarse_fine", "join_coarse_filtered", "compact_wide_tiles", "compact_max_words", "join_fuse_max_conjuncts", "join_coarse_finest", "jit_min_rows_like", "scan_split"};
+   static const char* known[] = {"jit", "jit_min_rows", "lazy_filter", "lazy_min_rows", "join_ordered", "join_chained", "gb_ordered", "gb_sorted", "zone_maps", "zone_min_rows", "gb_direct", "gb_wgs_per_cu", "gb_partition", "gb_partition_min_rows", "join_radix", "join_radix_min_rows", "join_radix_min_table_bytes", "join_radix_part_bytes", "probe_batch", "debug_check", "join_direct", "join_rank", "join_coarse", "dict_encode", "dict_min_rows", "comm_transport", "comm_timeout_ms", "desc_cache", "desc_cache_mb", "plan_replay", "scan_single_pass", "lazy_strings", "lazy_strings_min_rows", "gb_partition_wc", "join_radix_wc", "join_radix_lds", "gb_dense_out", "gb_partition_values", "join_pair32", "gb_dense_keys", "jit_async", "jit_threads", "jit_disk_cache", "join_all_match", "topk_short_select", "gb_fits64", "join_coarse_fine", "join_coarse_filtered", "compact_wide_tiles", "compact_max_words", "join_fuse_max_conjuncts", "join_coarse_finest", "jit_min_rows_like", "scan_split", "jit_share_compiles"};
    bool ok = false;
    for (const char* k : known) ok |= strcmp(k, name) == 0;
    if (!ok) LDB_FAIL(LDB_ERR_INVALID, "set_option: unknown option '%s'", name);

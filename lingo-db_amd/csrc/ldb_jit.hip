@@ -1,6 +1,7 @@
 // ldb_jit.hip — run-time kernel specialisation with hiprtc (see ldb_jit.h).
 #include "ldb_jit.h"
 #include <hip/hiprtc.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <atomic>
@@ -8,6 +9,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
+#include <ctime>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -276,14 +278,55 @@ static bool disk_write(const std::string& path, const std::vector<char>& code) {
 
 // ---------------------------------------------------------------- compile workers
 static void stop_workers();
+// Several processes on one host share the disk cache and meet the same shapes at the same time (the ranks of a multi-GPU run: eight ranks compiling
+// the same hundred kernels each is eight times the compiler work on the same cores).  A worker CLAIMS a shape before compiling it — `<hash>.co.lock`,
+// created exclusively —; a worker that finds the claim of another process waits for that process's code object instead (polling; a claim older than
+// five minutes, or one that disappears without a code object, is ignored and the shape compiled here after all).
+static std::atomic<int64_t> g_shared_from_peers{0};
+static bool claim_or_wait(const std::string& path, std::vector<char>* code, bool* claimed) {
+   *claimed = false;
+   if (path.empty() || ldb_option("jit_share_compiles", 1) == 0) return false;
+   const size_t slash = path.rfind('/');
+   if (slash == std::string::npos || !make_dirs(path.substr(0, slash))) return false;
+   const std::string lock = path + ".lock";
+   for (int attempt = 0; attempt < 2; attempt++) {
+      const int fd = open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0644);
+      if (fd >= 0) {
+         close(fd);
+         *claimed = true;
+         return false;
+      }
+      if (errno != EEXIST) return false;
+      struct stat st;
+      if (stat(lock.c_str(), &st) == 0 && time(nullptr) - st.st_mtime > 300) { // a claim left behind by a process that died
+         unlink(lock.c_str());
+         continue;
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      while (std::chrono::steady_clock::now() - t0 < std::chrono::seconds(300)) {
+         if (disk_read(path, code)) return true;
+         if (stat(lock.c_str(), &st) != 0) return disk_read(path, code); // the claim is gone: its owner finished (or failed)
+         {
+            std::lock_guard<std::mutex> lk(g_mu);
+            if (g_stop) return false;
+         }
+         std::this_thread::sleep_for(std::chrono::milliseconds(25));
+      }
+      return false;
+   }
+   return false;
+}
 static void run_job(JitJob& job) {
    auto t0 = std::chrono::steady_clock::now();
    std::vector<char> code;
    std::string err;
-   const bool ok = compile(job.src, &code, &err, job.arch.c_str());
-   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+   bool claimed = false;
+   const bool from_peer = claim_or_wait(job.disk_path, &code, &claimed);
+   const bool ok = from_peer || compile(job.src, &code, &err, job.arch.c_str());
+   const double ms = from_peer ? 0.0 : std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
    bool wrote = false;
-   if (ok) {
+   if (from_peer) g_shared_from_peers.fetch_add(1);
+   if (ok && !from_peer) {
       wrote = disk_write(job.disk_path, code);
       if (const char* dir = getenv("LDB_JIT_DUMP_DIR")) { // code objects for llvm-objdump inspection
          const std::string path = std::string(dir) + "/" + job.dump_name + ".co";
@@ -293,12 +336,14 @@ static void run_job(JitJob& job) {
          }
       }
    }
+   if (claimed) unlink((job.disk_path + ".lock").c_str());
    atexit(stop_workers); // (see stop_workers: ahead of the statics this compilation created)
    std::lock_guard<std::mutex> lock(g_mu);
    g_compile_ms += ms;
    if (ok) {
       job.mod->code = std::move(code);
       job.mod->state = JitModule::CODE_READY;
+      if (from_peer) job.mod->from_disk = true; // (not compiled here: ldb_gpu_jit_info counts it under "taken from a peer process")
       g_disk_writes += wrote ? 1 : 0;
    } else {
       job.mod->error = err;
@@ -491,8 +536,8 @@ extern "C" int32_t ldb_gpu_jit_wait(int64_t timeout_ms, int64_t* pending) {
 extern "C" int32_t ldb_gpu_jit_info(int64_t* vals, int32_t n) {
    if (!vals || n < 0) LDB_FAIL(LDB_ERR_INVALID, "jit_info: NULL argument");
    std::lock_guard<std::mutex> lock(g_mu);
-   const int64_t all[8] = {g_compiled, g_hits, g_disk_hits, g_disk_writes, (int64_t) g_queue.size() + g_running, g_failed, g_async_misses, (int64_t) g_workers};
-   for (int32_t i = 0; i < n; i++) vals[i] = i < 8 ? all[i] : 0;
+   const int64_t all[9] = {g_compiled, g_hits, g_disk_hits, g_disk_writes, (int64_t) g_queue.size() + g_running, g_failed, g_async_misses, (int64_t) g_workers, g_shared_from_peers.load()};
+   for (int32_t i = 0; i < n; i++) vals[i] = i < 9 ? all[i] : 0;
    return LDB_OK;
 }
 

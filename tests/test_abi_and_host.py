@@ -201,3 +201,49 @@ def test_jit_compiles_in_the_background_and_caches_code_objects_on_disk(tmp_path
     env3 = dict(env, LDB_JIT_CACHE_DIR=str(tmp_path / "off"), LDB_JIT_DISK_CACHE="0")
     r3 = subprocess.run([sys.executable, "-c", code], env=env3, capture_output=True, text=True, timeout=600)
     assert r3.returncode == 0 and "disk cache is disabled" in r3.stdout and not os.path.exists(str(tmp_path / "off")), r3.stdout + r3.stderr
+
+
+def test_processes_sharing_a_jit_cache_compile_a_shape_once(tmp_path):
+    """round 6: the ranks of a multi-GPU run meet the same kernel shapes at the same time and share one disk cache — a worker claims a shape
+    (`<hash>.co.lock`) before compiling it, a worker of another process that finds the claim waits for the code object instead of compiling it again;
+    a claim left behind by a dead process (older than five minutes) is ignored.  Without a device: hiprtc only."""
+    import shutil
+    import subprocess
+    import sys
+    import time
+
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from lingodb_amd import capi; lib = capi.gpu_lib(); buf = C.create_string_buffer(4000);"
+            "st = lib.ldb_gpu_jit_cache_selftest(buf, 4000); v = (C.c_int64 * 9)(); lib.ldb_gpu_jit_info(v, 9); print(st, list(v), buf.value.decode())") % os.path.join(ROOT, "lingo-db_amd")
+
+    def env_for(d):
+        return dict(os.environ, LDB_JIT_CACHE_DIR=str(d), LDB_JIT_ASYNC="1")
+
+    # a process of its own compiles the shape: the code object a "peer" will deliver below
+    r = subprocess.run([sys.executable, "-c", code], env=env_for(tmp_path / "a"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("0 "), r.stdout + r.stderr
+    made = [os.path.join(d, f) for d, _, fs in os.walk(str(tmp_path / "a")) for f in fs]
+    assert len(made) == 1 and made[0].endswith(".co")
+    rel = os.path.relpath(made[0], str(tmp_path / "a"))
+    # a peer holds the claim: this process must wait for the peer's code object and compile nothing
+    target = os.path.join(str(tmp_path / "b"), rel)
+    os.makedirs(os.path.dirname(target))
+    open(target + ".lock", "w").close()
+    p = subprocess.Popen([sys.executable, "-c", code], env=env_for(tmp_path / "b"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(4.0)
+    assert p.poll() is None, "the process did not wait for the peer's claim: " + p.stdout.read()
+    shutil.copy(made[0], target + ".part")
+    os.rename(target + ".part", target)
+    os.unlink(target + ".lock")
+    out, err = p.communicate(timeout=300)
+    info = eval(out.split(" ", 1)[1].split("]")[0] + "]")
+    assert info[8] == 1 and info[3] == 0 and info[5] == 0, (info, out, err)  # one code object taken from the peer, nothing written, nothing failed
+    # a stale claim (its owner died): ignored, the shape is compiled here
+    target_c = os.path.join(str(tmp_path / "c"), rel)
+    os.makedirs(os.path.dirname(target_c))
+    open(target_c + ".lock", "w").close()
+    old = time.time() - 1000
+    os.utime(target_c + ".lock", (old, old))
+    r = subprocess.run([sys.executable, "-c", code], env=env_for(tmp_path / "c"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("0 "), r.stdout + r.stderr
+    left = sorted(f for _, _, fs in os.walk(str(tmp_path / "c")) for f in fs)
+    assert len(left) == 1 and left[0].endswith(".co"), left
