@@ -288,3 +288,30 @@ def test_set_op_and_window_steps_are_checked():
             ('{"steps": [{"op": "window", "in": "t", "order_by": ["a"], "out": "w"}], "result": "w"}', "fns")):
         st, err = _check(text, ["t", "u"])
         assert st != 0 and needle in err, (text, err)
+
+
+def test_no_base_table_probes_a_non_unique_table_of_its_own_primary_key():
+    """round 6: four hand plans kept a NON-unique hash table of a reduced lineitem side that every order probed with its primary key — pair
+    counting, pairs and an expansion where the side with the unique key could have been the table (Q7 8.7 → 5.4 ms, Q8 4.9 → 3.4, Q12 5.1 → 3.4, Q21
+    8.4 → 7.4).  No plan, single-GPU or sharded, does that any more: a relation that still carries a base table's primary key (the table itself, or a
+    filter / semi join of it) never probes a non-unique table with that key.  (The two that remain probe with the CUSTOMER key into a handful of rows:
+    Q10's 20 winners and Q18's few large orders.)"""
+    primary = {"orders": "o_orderkey", "customer": "c_custkey", "part": "p_partkey", "supplier": "s_suppkey", "nation": "n_nationkey", "region": "r_regionkey"}
+    allowed = {(10, "c_custkey"), (18, "c_custkey")}
+    for sub in ("", "dist"):
+        for q in range(1, 23):
+            with open(os.path.join(ROOT, "lingo-db_amd", "plans", "tpch", sub, "q%d.json" % q)) as f:
+                plan = json.load(f)
+            base = {t: t for t in primary}  # relation name → the base table whose rows (a subset of them) it holds
+            builds = {}
+            for s in plan["steps"]:
+                if s["op"] in ("filter", "filter_dnf") and s["in"] in base:
+                    base[s["out"]] = base[s["in"]]
+                elif s["op"] == "join_build":
+                    builds[s["out"]] = s
+                elif s["op"] == "join_probe":
+                    if s["kind"] in ("semi", "anti") and s["in"] in base:
+                        base[s["out"]] = base[s["in"]]
+                    b = builds[s["ht"]]
+                    if not b.get("unique", False) and s["in"] in base and s["keys"] == [primary[base[s["in"]]]]:
+                        assert (q, s["keys"][0]) in allowed, (sub or "single", q, s)
